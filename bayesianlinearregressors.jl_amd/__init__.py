@@ -1,0 +1,39 @@
+"""MI355X-native posterior / logpdf / marginals / rand path of BayesianLinearRegressors.jl.
+
+Import as ``import blr_amd`` (the directory name follows the reference repository and is not a valid
+Python identifier; ``blr_amd.py`` at the repository root loads it under that name).
+
+Exports mirror reference src/BayesianLinearRegressors.jl:11-12.
+"""
+from . import _abi
+from ._abi import BLRError, PosDefException
+from .regressor import (
+    BasisFunctionRegressor,
+    BayesianLinearRegressor,
+    BLRFunctionSample,
+    ColVecs,
+    Diagonal,
+    FiniteGP,
+    Normal,
+    PDMat,
+    RowVecs,
+    Symmetric,
+    cov,
+    logpdf,
+    logpdf_columns,
+    marginals,
+    mean,
+    mean_and_cov,
+    mean_and_var,
+    posterior,
+    rand,
+    rand_b,
+    std,
+    var,
+)
+
+__all__ = [
+    "logpdf", "rand", "mean", "std", "cov", "var", "BayesianLinearRegressor", "marginals", "posterior",
+    "BasisFunctionRegressor", "ColVecs", "RowVecs", "Diagonal", "Symmetric", "PDMat", "Normal", "FiniteGP",
+    "BLRFunctionSample", "mean_and_var", "mean_and_cov", "rand_b", "logpdf_columns", "BLRError", "PosDefException",
+]

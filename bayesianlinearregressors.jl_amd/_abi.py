@@ -1,0 +1,220 @@
+"""ctypes binding of the C ABI in include/blr_mi355x.h (libblr_mi355x.so, hand-written HIP for gfx950).
+
+There is NO CPU fallback: if the shared library has not been built, or no MI355X is visible when a
+handle is requested, this module raises.  Build with ``python -c "import __graft_entry__ as g; g.build()"``
+(or ``make -C bayesianlinearregressors.jl_amd/csrc``).
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+import threading
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "csrc", "libblr_mi355x.so")
+
+LAYOUT_COLVECS, LAYOUT_ROWVECS = 0, 1
+NOISE_ISOTROPIC, NOISE_DIAGONAL = 0, 1
+PRIOR_DENSE, PRIOR_UPPER_FACTOR, PRIOR_DIAGONAL = 0, 1, 2
+MEM_HOST, MEM_DEVICE = 0, 1
+
+_i64, _int, _vp = C.c_int64, C.c_int, C.c_void_p
+_H = C.c_void_p
+
+
+class BLRError(RuntimeError):
+    """HIP/runtime failure or invalid argument reported by the library (negative return code)."""
+
+    def __init__(self, code, msg):
+        super().__init__(f"libblr_mi355x: code {code}: {msg}")
+        self.code = code
+
+
+class PosDefException(np.linalg.LinAlgError):
+    """Mirrors LinearAlgebra.PosDefException(info): Cholesky broke at leading minor ``info``."""
+
+    def __init__(self, info):
+        super().__init__(f"matrix is not positive definite; Cholesky factorization failed (info = {info})")
+        self.info = info
+
+
+_SIGS = {
+    "blr_abi_version": ([], _int),
+    "blr_device_count": ([], _int),
+    "blr_create": ([_int, C.POINTER(_H)], _int),
+    "blr_destroy": ([_H], _int),
+    "blr_last_error": ([_H], C.c_char_p),
+    "blr_set_stream": ([_H, _vp], _int),
+    "blr_set_async": ([_H, _int], _int),
+    "blr_synchronize": ([_H], _int),
+    "blr_device_alloc": ([_H, C.c_size_t, C.POINTER(_vp)], _int),
+    "blr_device_free": ([_H, _vp], _int),
+    "blr_memcpy_h2d": ([_H, _vp, _vp, C.c_size_t], _int),
+    "blr_memcpy_d2h": ([_H, _vp, _vp, C.c_size_t], _int),
+    "blr_timer_start": ([_H], _int),
+    "blr_timer_stop": ([_H, C.POINTER(C.c_float)], _int),
+    "blr_logpdf_sum": ([_H, _int, _i64, _vp, _vp], _int),
+}
+for _suf in ("f64", "f32"):
+    _SIGS[f"blr_posterior_batched_{_suf}"] = (
+        [_H, _int, _int, _i64, _i64, _i64, _vp, _i64, _i64, _vp, _i64, _int, _vp, _i64, _int, _vp, _i64, _vp, _i64, _i64,
+         _vp, _i64, _vp, _i64, _i64, _vp, _i64, _i64, _vp, _vp], _int)
+    _SIGS[f"blr_posterior_{_suf}"] = (
+        [_H, _int, _i64, _i64, _vp, _i64, _vp, _int, _vp, _int, _vp, _vp, _i64, _vp, _vp, _i64, _vp, _i64, _vp], _int)
+    _SIGS[f"blr_marginals_batched_{_suf}"] = (
+        [_H, _int, _int, _i64, _i64, _i64, _vp, _i64, _i64, _int, _vp, _i64, _int, _vp, _i64, _vp, _i64, _i64,
+         _vp, _i64, _vp, _i64, _vp], _int)
+    _SIGS[f"blr_rand_{_suf}"] = (
+        [_H, _int, _int, _i64, _i64, _i64, _vp, _i64, _int, _vp, _int, _vp, _vp, _i64, _vp, _i64, _vp, _i64, _vp, _i64], _int)
+    _SIGS[f"blr_sample_weights_{_suf}"] = (
+        [_H, _int, _i64, _i64, _int, _vp, _vp, _i64, _vp, _i64, _vp, _i64], _int)
+
+EXPORTED_SYMBOLS = tuple(_SIGS)
+
+_lib = None
+_lib_lock = threading.Lock()
+
+
+def load_library():
+    """dlopen the HIP library (works without a GPU: only handle creation needs one)."""
+    global _lib
+    with _lib_lock:
+        if _lib is None:
+            if not os.path.exists(LIB_PATH):
+                raise ImportError(
+                    f"{LIB_PATH} is missing: the HIP extension has not been built. "
+                    "Run `python -c 'import __graft_entry__ as g; g.build()'`. There is no CPU fallback."
+                )
+            lib = C.CDLL(LIB_PATH)
+            for name, (argtypes, restype) in _SIGS.items():
+                fn = getattr(lib, name)  # AttributeError if the library does not export a declared symbol
+                fn.argtypes = argtypes
+                fn.restype = restype
+            _lib = lib
+    return _lib
+
+
+def _ptr(a):
+    """void* of a numpy array, an int device pointer, or None."""
+    if a is None:
+        return None
+    if isinstance(a, np.ndarray):
+        return a.ctypes.data_as(_vp)
+    return _vp(int(a))
+
+
+def suffix(dtype):
+    dtype = np.dtype(dtype)
+    if dtype == np.float64:
+        return "f64"
+    if dtype == np.float32:
+        return "f32"
+    raise TypeError(f"unsupported element type {dtype}; the library is built for Float64 and Float32")
+
+
+class Handle:
+    """One library handle = one device + one stream + scratch.  Not thread-safe (one per thread)."""
+
+    def __init__(self, device=0):
+        self.lib = load_library()
+        h = _H()
+        rc = self.lib.blr_create(int(device), C.byref(h))
+        if rc != 0:
+            raise BLRError(rc, "blr_create failed: no usable MI355X/HIP device (the product path has no CPU fallback)")
+        self._h = h
+        self.device = device
+
+    def close(self):
+        if getattr(self, "_h", None):
+            self.lib.blr_destroy(self._h)
+            self._h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    # -- error translation ---------------------------------------------------------------------
+    def check(self, rc):
+        if rc < 0:
+            msg = self.lib.blr_last_error(self._h)
+            raise BLRError(rc, msg.decode() if msg else "")
+        return rc
+
+    def set_stream(self, stream_ptr):
+        self.check(self.lib.blr_set_stream(self._h, _vp(int(stream_ptr)) if stream_ptr else None))
+
+    def set_async(self, flag):
+        self.check(self.lib.blr_set_async(self._h, int(bool(flag))))
+
+    def synchronize(self):
+        self.check(self.lib.blr_synchronize(self._h))
+
+    def timer_start(self):
+        self.check(self.lib.blr_timer_start(self._h))
+
+    def timer_stop(self):
+        ms = C.c_float()
+        self.check(self.lib.blr_timer_stop(self._h, C.byref(ms)))
+        return float(ms.value)
+
+    # -- raw entry points (see include/blr_mi355x.h for argument meaning) ---------------------------
+    def posterior_batched(self, dtype, memspace, layout, B, D, N, X, ldx, strideX, y, stridey, noise_kind, s, strides,
+                          prior_kind, mw, stridemw, Lw, ldl, strideLw, mw_post, stride_mwpost, T_post, ldt, strideT,
+                          Lw_post, ldlp, strideLp, logpdf, info):
+        fn = getattr(self.lib, f"blr_posterior_batched_{suffix(dtype)}")
+        return self.check(fn(self._h, memspace, layout, B, D, N, _ptr(X), ldx, strideX, _ptr(y), stridey, noise_kind,
+                             _ptr(s), strides, prior_kind, _ptr(mw), stridemw, _ptr(Lw), ldl, strideLw,
+                             _ptr(mw_post), stride_mwpost, _ptr(T_post), ldt, strideT, _ptr(Lw_post), ldlp, strideLp,
+                             _ptr(logpdf), _ptr(info)))
+
+    def posterior(self, dtype, layout, D, N, X, ldx, y, noise_kind, s, prior_kind, mw, Lw, ldl, mw_post, T_post, ldt,
+                  Lw_post, ldlp, logpdf):
+        fn = getattr(self.lib, f"blr_posterior_{suffix(dtype)}")
+        rc = self.check(fn(self._h, layout, D, N, _ptr(X), ldx, _ptr(y), noise_kind, _ptr(s), prior_kind, _ptr(mw),
+                           _ptr(Lw), ldl, _ptr(mw_post), _ptr(T_post), ldt, _ptr(Lw_post), ldlp, _ptr(logpdf)))
+        if rc > 0:
+            raise PosDefException(rc)
+        return rc
+
+    def marginals_batched(self, dtype, memspace, layout, B, D, N, X, ldx, strideX, noise_kind, s, strides, prior_kind,
+                          mw, stridemw, Lw, ldl, strideLw, mean, stridemean, var, stridevar, info):
+        fn = getattr(self.lib, f"blr_marginals_batched_{suffix(dtype)}")
+        return self.check(fn(self._h, memspace, layout, B, D, N, _ptr(X), ldx, strideX, noise_kind, _ptr(s), strides,
+                             prior_kind, _ptr(mw), stridemw, _ptr(Lw), ldl, strideLw, _ptr(mean), stridemean,
+                             _ptr(var), stridevar, _ptr(info)))
+
+    def rand(self, dtype, memspace, layout, D, N, S, X, ldx, noise_kind, s, prior_kind, mw, Lw, ldl, Z1, ldz1, Z2, ldz2,
+             Y, ldy):
+        fn = getattr(self.lib, f"blr_rand_{suffix(dtype)}")
+        rc = self.check(fn(self._h, memspace, layout, D, N, S, _ptr(X), ldx, noise_kind, _ptr(s), prior_kind, _ptr(mw),
+                           _ptr(Lw), ldl, _ptr(Z1), ldz1, _ptr(Z2), ldz2, _ptr(Y), ldy))
+        if rc > 0:
+            raise PosDefException(rc)
+        return rc
+
+    def sample_weights(self, dtype, memspace, D, S, prior_kind, mw, Lw, ldl, Z, ldz, W, ldw):
+        fn = getattr(self.lib, f"blr_sample_weights_{suffix(dtype)}")
+        rc = self.check(fn(self._h, memspace, D, S, prior_kind, _ptr(mw), _ptr(Lw), ldl, _ptr(Z), ldz, _ptr(W), ldw))
+        if rc > 0:
+            raise PosDefException(rc)
+        return rc
+
+    def logpdf_sum(self, memspace, B, logpdf, total):
+        return self.check(self.lib.blr_logpdf_sum(self._h, memspace, B, _ptr(logpdf), _ptr(total)))
+
+
+_default = {}
+_default_lock = threading.Lock()
+
+
+def default_handle(device=0):
+    """Process-wide handle per device (created on first use; raises without a GPU)."""
+    with _default_lock:
+        key = (os.getpid(), device)
+        if key not in _default:
+            _default[key] = Handle(device)
+        return _default[key]

@@ -1,0 +1,665 @@
+// Host side of the C ABI declared in include/blr_mi355x.h: argument validation, host<->device
+// staging for BLR_MEM_HOST calls, kernel dispatch.  No exception crosses the boundary.
+#include "../../include/blr_mi355x.h"
+
+#include <hip/hip_runtime.h>
+
+#include <algorithm>
+#include <cstdio>
+#include <cstring>
+#include <new>
+#include <string>
+#include <vector>
+
+#include "blr_aux_kernels.hpp"
+#include "blr_fused_small.hpp"
+
+using namespace blr;
+
+struct blr_handle {
+  int device = 0;
+  hipStream_t own_stream = nullptr;
+  hipStream_t stream = nullptr;
+  bool async = false;
+  std::string err = "";
+  hipEvent_t ev0 = nullptr, ev1 = nullptr;
+  std::vector<void*> staged;  // device buffers of the current HOST-memspace call
+  char* ws = nullptr;          // grow-only scratch (factors, info)
+  size_t ws_bytes = 0;
+};
+
+namespace {
+
+constexpr int kMaxSmallD = 128;
+
+int hip_fail(blr_handle* h, hipError_t e, const char* what) {
+  if (h) {
+    h->err = std::string(what) + ": " + hipGetErrorString(e);
+  }
+  return -(1000 + (int)e);
+}
+#define HIP_TRY(h, expr)                                   \
+  do {                                                     \
+    hipError_t e__ = (expr);                               \
+    if (e__ != hipSuccess) return hip_fail(h, e__, #expr); \
+  } while (0)
+
+int bad_arg(blr_handle* h, int pos, const char* why) {
+  if (h) h->err = std::string("argument ") + std::to_string(pos) + ": " + why;
+  return -pos;
+}
+
+struct Staging {  // RAII for the device copies of one HOST-memspace call
+  blr_handle* h;
+  explicit Staging(blr_handle* hh) : h(hh) {}
+  ~Staging() {
+    for (void* p : h->staged) (void)hipFree(p);
+    h->staged.clear();
+  }
+};
+
+template <typename T>
+int stage_in(blr_handle* h, const T* host, size_t count, const T** dev) {
+  *dev = nullptr;
+  if (!host || count == 0) return 0;
+  void* p = nullptr;
+  HIP_TRY(h, hipMalloc(&p, count * sizeof(T)));
+  h->staged.push_back(p);
+  HIP_TRY(h, hipMemcpyAsync(p, host, count * sizeof(T), hipMemcpyHostToDevice, h->stream));
+  *dev = static_cast<const T*>(p);
+  return 0;
+}
+template <typename T>
+int stage_out_alloc(blr_handle* h, const T* host_initial, size_t count, T** dev) {
+  // outputs with gaps (ld > rows, stride > extent) keep the caller's bytes in the gaps: copy the
+  // current host contents in first.
+  *dev = nullptr;
+  if (!host_initial || count == 0) return 0;
+  void* p = nullptr;
+  HIP_TRY(h, hipMalloc(&p, count * sizeof(T)));
+  h->staged.push_back(p);
+  HIP_TRY(h, hipMemcpyAsync(p, host_initial, count * sizeof(T), hipMemcpyHostToDevice, h->stream));
+  *dev = static_cast<T*>(p);
+  return 0;
+}
+
+int ensure_ws(blr_handle* h, size_t bytes) {
+  if (bytes <= h->ws_bytes) return 0;
+  if (h->ws) {
+    HIP_TRY(h, hipStreamSynchronize(h->stream));
+    HIP_TRY(h, hipFree(h->ws));
+    h->ws = nullptr;
+    h->ws_bytes = 0;
+  }
+  size_t want = std::max(bytes, (size_t)1 << 20);
+  HIP_TRY(h, hipMalloc((void**)&h->ws, want));
+  h->ws_bytes = want;
+  return 0;
+}
+
+size_t extent(int64_t B, int64_t stride, size_t one) {  // elements spanned by B items at `stride`
+  if (B <= 0) return 0;
+  return (size_t)((B - 1) * stride) + one;
+}
+size_t mat_extent(int64_t rows, int64_t cols, int64_t ld) {
+  if (rows <= 0 || cols <= 0) return 0;
+  return (size_t)((cols - 1) * ld + rows);
+}
+
+template <typename T>
+bool aligned16(const T* p, int64_t ld, int64_t stride) {
+  return ((uintptr_t)p % 16 == 0) && ((ld * (int64_t)sizeof(T)) % 16 == 0) && ((stride * (int64_t)sizeof(T)) % 16 == 0);
+}
+
+// ---- fused small-D dispatch -----------------------------------------------------------------------
+template <typename T, int NB, int MODE>
+int launch_fused_small(blr_handle* h, const PosteriorArgs<T>& a) {
+  using C = SmallCfg<T, NB>;
+  static bool attr_set = false;
+  auto kern = fused_small_kernel<T, NB, MODE>;
+  if (!attr_set) {
+    HIP_TRY(h, hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                   C::LDS_BYTES));
+    attr_set = true;
+  }
+  int grid = (int)std::min<int64_t>(a.B, 1 << 20);
+  hipLaunchKernelGGL(kern, dim3(grid), dim3(kThreads), C::LDS_BYTES, h->stream, a);
+  HIP_TRY(h, hipGetLastError());
+  return 0;
+}
+
+template <typename T, int NB>
+int launch_fused_small_mode(blr_handle* h, const PosteriorArgs<T>& a) {
+  if (a.layout == BLR_LAYOUT_ROWVECS) return launch_fused_small<T, NB, 1>(h, a);
+  if (a.vec_ok) return launch_fused_small<T, NB, 3>(h, a);
+  return launch_fused_small<T, NB, 0>(h, a);
+}
+
+template <typename T>
+int dispatch_fused_small(blr_handle* h, const PosteriorArgs<T>& a) {
+  int NB = (a.D + 15) / 16;
+  switch (NB) {
+    case 1: return launch_fused_small_mode<T, 1>(h, a);
+    case 2: return launch_fused_small_mode<T, 2>(h, a);
+    case 3: return launch_fused_small_mode<T, 3>(h, a);
+    case 4: return launch_fused_small_mode<T, 4>(h, a);
+    case 5: return launch_fused_small_mode<T, 5>(h, a);
+    case 6: return launch_fused_small_mode<T, 6>(h, a);
+    case 7: return launch_fused_small_mode<T, 7>(h, a);
+    case 8: return launch_fused_small_mode<T, 8>(h, a);
+    default: return bad_arg(h, 5, "D > 128 is not supported by this build");
+  }
+}
+
+template <typename T>
+int posterior_batched(blr_handle* h, int memspace, int layout, int64_t B, int64_t D, int64_t N, const T* X,
+                      int64_t ldx, int64_t strideX, const T* y, int64_t stridey, int noise_kind, const T* s,
+                      int64_t strides, int prior_kind, const T* mw, int64_t stridemw, const T* Lw, int64_t ldl,
+                      int64_t strideLw, T* mw_post, int64_t stride_mwpost, T* T_post, int64_t ldt, int64_t strideT,
+                      T* Lw_post, int64_t ldlp, int64_t strideLp, double* logpdf, int32_t* info) {
+  if (!h) return -1;
+  h->err.clear();
+  if (memspace != BLR_MEM_HOST && memspace != BLR_MEM_DEVICE) return bad_arg(h, 2, "memspace");
+  if (layout != BLR_LAYOUT_COLVECS && layout != BLR_LAYOUT_ROWVECS) return bad_arg(h, 3, "unknown layout (reference :26-31)");
+  if (B < 0) return bad_arg(h, 4, "B < 0");
+  if (D < 1) return bad_arg(h, 5, "D < 1");
+  if (D > kMaxSmallD) return bad_arg(h, 5, "D > 128 is not supported by this build");
+  if (N < 0 || N > (1 << 30)) return bad_arg(h, 6, "N out of range");
+  if (B == 0) return 0;
+  if (N > 0 && !X) return bad_arg(h, 7, "X is NULL");
+  if (layout == BLR_LAYOUT_COLVECS ? ldx < D : ldx < std::max<int64_t>(N, 1)) return bad_arg(h, 8, "ldx too small");
+  if (strideX < 0) return bad_arg(h, 9, "strideX < 0");
+  if (N > 0 && !y) return bad_arg(h, 10, "y is NULL (reference :74 length check)");
+  if (stridey < 0) return bad_arg(h, 11, "stridey < 0");
+  if (noise_kind != BLR_NOISE_ISOTROPIC && noise_kind != BLR_NOISE_DIAGONAL)
+    return bad_arg(h, 12, "noise_kind (dense Sigma_y is outside the GPU scope)");
+  if (!s) return bad_arg(h, 13, "s is NULL");
+  if (strides < 0) return bad_arg(h, 14, "strides < 0");
+  if (prior_kind != BLR_PRIOR_DENSE && prior_kind != BLR_PRIOR_UPPER_FACTOR && prior_kind != BLR_PRIOR_DIAGONAL)
+    return bad_arg(h, 15, "prior_kind");
+  if (!mw) return bad_arg(h, 16, "mw is NULL");
+  if (stridemw < 0) return bad_arg(h, 17, "stridemw < 0");
+  if (!Lw) return bad_arg(h, 18, "Lw is NULL");
+  if (prior_kind != BLR_PRIOR_DIAGONAL && ldl < D) return bad_arg(h, 19, "ldl < D");
+  if (strideLw < 0) return bad_arg(h, 20, "strideLw < 0");
+  if (mw_post && B > 1 && stride_mwpost < D) return bad_arg(h, 22, "stride_mwpost < D");
+  if (T_post && ldt < D) return bad_arg(h, 24, "ldt < D");
+  if (T_post && B > 1 && strideT < (int64_t)mat_extent(D, D, ldt)) return bad_arg(h, 25, "strideT too small");
+  if (Lw_post && ldlp < D) return bad_arg(h, 27, "ldlp < D");
+  if (Lw_post && B > 1 && strideLp < (int64_t)mat_extent(D, D, ldlp)) return bad_arg(h, 28, "strideLp too small");
+  if (!info) return bad_arg(h, 30, "info is NULL");
+
+  HIP_TRY(h, hipSetDevice(h->device));
+  PosteriorArgs<T> a{};
+  a.ldx = ldx; a.strideX = strideX; a.stridey = stridey; a.strides = strides; a.stridemw = stridemw;
+  a.ldl = ldl; a.strideLw = strideLw; a.stride_mwpost = stride_mwpost; a.ldt = ldt; a.strideT = strideT;
+  a.ldlp = ldlp; a.strideLp = strideLp;
+  a.layout = layout; a.noise_kind = noise_kind; a.prior_kind = prior_kind;
+  a.D = (int)D; a.N = (int)N; a.B = (int)B;
+
+  if (memspace == BLR_MEM_DEVICE) {
+    a.X = X; a.y = y; a.s = s; a.mw = mw; a.Lw = Lw;
+    a.mw_post = mw_post; a.T_post = T_post; a.Lw_post = Lw_post; a.logpdf = logpdf; a.info = info;
+    a.vec_ok = (layout == BLR_LAYOUT_COLVECS && D % Mfma<T>::VEC == 0 && aligned16(X, ldx, strideX)) ? 1 : 0;
+    int rc = dispatch_fused_small<T>(h, a);
+    if (rc) return rc;
+    if (!h->async) HIP_TRY(h, hipStreamSynchronize(h->stream));
+    return 0;
+  }
+
+  // host pointers: stage through device copies
+  Staging guard(h);
+  const size_t x_one = layout == BLR_LAYOUT_COLVECS ? mat_extent(D, N, ldx) : mat_extent(N, D, ldx);
+  const size_t lw_one = prior_kind == BLR_PRIOR_DIAGONAL ? (size_t)D : mat_extent(D, D, ldl);
+  const size_t s_one = noise_kind == BLR_NOISE_DIAGONAL ? (size_t)N : 1;
+  int rc;
+  if ((rc = stage_in(h, X, extent(B, strideX, x_one), &a.X))) return rc;
+  if ((rc = stage_in(h, y, extent(B, stridey, (size_t)N), &a.y))) return rc;
+  if ((rc = stage_in(h, s, extent(B, strides, s_one), &a.s))) return rc;
+  if ((rc = stage_in(h, mw, extent(B, stridemw, (size_t)D), &a.mw))) return rc;
+  if ((rc = stage_in(h, Lw, extent(B, strideLw, lw_one), &a.Lw))) return rc;
+  const size_t n_mw = extent(B, stride_mwpost, (size_t)D);
+  const size_t n_T = extent(B, strideT, mat_extent(D, D, ldt));
+  const size_t n_Lp = extent(B, strideLp, mat_extent(D, D, ldlp));
+  if ((rc = stage_out_alloc(h, mw_post, n_mw, &a.mw_post))) return rc;
+  if ((rc = stage_out_alloc(h, T_post, n_T, &a.T_post))) return rc;
+  if ((rc = stage_out_alloc(h, Lw_post, n_Lp, &a.Lw_post))) return rc;
+  if ((rc = stage_out_alloc(h, logpdf, (size_t)B, &a.logpdf))) return rc;
+  if ((rc = stage_out_alloc(h, info, (size_t)B, &a.info))) return rc;
+  if (N == 0) {  // no data: the kernel never dereferences X / y, but keep the pointers valid
+    if (!a.X) a.X = a.mw;
+    if (!a.y) a.y = a.mw;
+  }
+  a.vec_ok = (layout == BLR_LAYOUT_COLVECS && D % Mfma<T>::VEC == 0 && aligned16(a.X, ldx, strideX)) ? 1 : 0;
+  if ((rc = dispatch_fused_small<T>(h, a))) return rc;
+  if (mw_post) HIP_TRY(h, hipMemcpyAsync(mw_post, a.mw_post, n_mw * sizeof(T), hipMemcpyDeviceToHost, h->stream));
+  if (T_post) HIP_TRY(h, hipMemcpyAsync(T_post, a.T_post, n_T * sizeof(T), hipMemcpyDeviceToHost, h->stream));
+  if (Lw_post) HIP_TRY(h, hipMemcpyAsync(Lw_post, a.Lw_post, n_Lp * sizeof(T), hipMemcpyDeviceToHost, h->stream));
+  if (logpdf) HIP_TRY(h, hipMemcpyAsync(logpdf, a.logpdf, (size_t)B * sizeof(double), hipMemcpyDeviceToHost, h->stream));
+  HIP_TRY(h, hipMemcpyAsync(info, a.info, (size_t)B * sizeof(int32_t), hipMemcpyDeviceToHost, h->stream));
+  HIP_TRY(h, hipStreamSynchronize(h->stream));
+  return 0;
+}
+
+template <typename T>
+int posterior_single(blr_handle* h, int layout, int64_t D, int64_t N, const T* X, int64_t ldx, const T* y,
+                     int noise_kind, const T* s, int prior_kind, const T* mw, const T* Lw, int64_t ldl, T* mw_post,
+                     T* T_post, int64_t ldt, T* Lw_post, int64_t ldlp, double* logpdf) {
+  int32_t info = 0;
+  int rc = posterior_batched<T>(h, BLR_MEM_HOST, layout, 1, D, N, X, ldx, 0, y, 0, noise_kind, s, 0, prior_kind, mw, 0,
+                                Lw, ldl, 0, mw_post, D, T_post, ldt, ldt * D, Lw_post, ldlp, ldlp * D, logpdf, &info);
+  if (rc) {
+    // re-number argument positions of the batched form onto the single form
+    static const int map[31] = {0, 1, 0, 2, 0, 3, 4, 5, 6, 0, 7, 0, 8, 9, 0, 10, 11, 0, 12, 13, 0,
+                                14, 0, 15, 16, 0, 17, 18, 0, 19, 0};
+    if (rc < 0 && rc > -31 && map[-rc]) return -map[-rc];
+    return rc;
+  }
+  return info;
+}
+
+// ---- factor of the prior precision for marginals / draws ----------------------------------------------
+// Returns a device pointer to U (upper factor, ld = D, stride D*D) or to d (diagonal) per regressor.
+template <typename T>
+int prior_factor(blr_handle* h, int64_t B, int64_t D, int prior_kind, const T* Lw_dev, int64_t ldl, int64_t strideLw,
+                 const T** U, int64_t* ldu, int64_t* strideU, int* kind_out, int32_t** info_dev) {
+  *info_dev = nullptr;
+  if (prior_kind != BLR_PRIOR_DENSE) {
+    *U = Lw_dev; *ldu = ldl; *strideU = strideLw; *kind_out = prior_kind;
+    return 0;
+  }
+  size_t need = (size_t)B * D * D * sizeof(T) + (size_t)B * sizeof(int32_t) + 64;
+  int rc = ensure_ws(h, need);
+  if (rc) return rc;
+  T* Uw = reinterpret_cast<T*>(h->ws);
+  int32_t* inf = reinterpret_cast<int32_t*>(h->ws + (((size_t)B * D * D * sizeof(T) + 15) & ~(size_t)15));
+  size_t lds = ((size_t)D * (D + 1) / 2 + D) * sizeof(T) + 16;
+  auto kern = chol_small_kernel<T>;
+  HIP_TRY(h, hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+  hipLaunchKernelGGL(kern, dim3((unsigned)std::min<int64_t>(B, 1 << 20)), dim3(kThreads), lds, h->stream, Lw_dev, ldl,
+                     strideLw, Uw, D, D * D, inf, (int)D, (int)B);
+  HIP_TRY(h, hipGetLastError());
+  *U = Uw; *ldu = D; *strideU = D * D; *kind_out = BLR_PRIOR_UPPER_FACTOR; *info_dev = inf;
+  return 0;
+}
+
+template <typename T>
+int marginals_batched(blr_handle* h, int memspace, int layout, int64_t B, int64_t D, int64_t N, const T* X, int64_t ldx,
+                      int64_t strideX, int noise_kind, const T* s, int64_t strides, int prior_kind, const T* mw,
+                      int64_t stridemw, const T* Lw, int64_t ldl, int64_t strideLw, T* mean, int64_t stridemean, T* var,
+                      int64_t stridevar, int32_t* info) {
+  if (!h) return -1;
+  h->err.clear();
+  if (memspace != BLR_MEM_HOST && memspace != BLR_MEM_DEVICE) return bad_arg(h, 2, "memspace");
+  if (layout != BLR_LAYOUT_COLVECS && layout != BLR_LAYOUT_ROWVECS) return bad_arg(h, 3, "unknown layout (reference :26-31)");
+  if (B < 0) return bad_arg(h, 4, "B < 0");
+  if (D < 1 || D > kMaxSmallD) return bad_arg(h, 5, "D out of range for this build (1..128)");
+  if (N < 0 || N > (1 << 30)) return bad_arg(h, 6, "N out of range");
+  if (B == 0 || N == 0) return 0;
+  if (!X) return bad_arg(h, 7, "X is NULL");
+  if (layout == BLR_LAYOUT_COLVECS ? ldx < D : ldx < N) return bad_arg(h, 8, "ldx too small");
+  if (noise_kind != BLR_NOISE_ISOTROPIC && noise_kind != BLR_NOISE_DIAGONAL) return bad_arg(h, 10, "noise_kind");
+  if (var && !s) return bad_arg(h, 11, "s is NULL");
+  if (prior_kind != BLR_PRIOR_DENSE && prior_kind != BLR_PRIOR_UPPER_FACTOR && prior_kind != BLR_PRIOR_DIAGONAL)
+    return bad_arg(h, 13, "prior_kind");
+  if (!mw) return bad_arg(h, 14, "mw is NULL");
+  if (var && !Lw) return bad_arg(h, 16, "Lw is NULL");
+  if (prior_kind != BLR_PRIOR_DIAGONAL && ldl < D) return bad_arg(h, 17, "ldl < D");
+  if (mean && B > 1 && stridemean < N) return bad_arg(h, 20, "stridemean < N");
+  if (var && B > 1 && stridevar < N) return bad_arg(h, 22, "stridevar < N");
+  if (!info) return bad_arg(h, 23, "info is NULL");
+  HIP_TRY(h, hipSetDevice(h->device));
+
+  Staging guard(h);
+  MarginalArgs<T> a{};
+  a.ldx = ldx; a.strideX = strideX; a.strides = strides; a.stridemw = stridemw;
+  a.stridemean = stridemean; a.stridevar = stridevar;
+  a.layout = layout; a.noise_kind = noise_kind; a.D = (int)D; a.N = (int)N; a.B = (int)B;
+  const T* Lw_dev = Lw;
+  int32_t* info_out_dev = info;
+  int rc;
+  if (memspace == BLR_MEM_HOST) {
+    const size_t x_one = layout == BLR_LAYOUT_COLVECS ? mat_extent(D, N, ldx) : mat_extent(N, D, ldx);
+    const size_t lw_one = prior_kind == BLR_PRIOR_DIAGONAL ? (size_t)D : mat_extent(D, D, ldl);
+    if ((rc = stage_in(h, X, extent(B, strideX, x_one), &a.X))) return rc;
+    if ((rc = stage_in(h, s, s ? extent(B, strides, noise_kind == BLR_NOISE_DIAGONAL ? (size_t)N : 1) : 0, &a.s))) return rc;
+    if ((rc = stage_in(h, mw, extent(B, stridemw, (size_t)D), &a.mw))) return rc;
+    if ((rc = stage_in(h, Lw, Lw ? extent(B, strideLw, lw_one) : 0, &Lw_dev))) return rc;
+    if ((rc = stage_out_alloc(h, mean, extent(B, stridemean, (size_t)N), &a.mean))) return rc;
+    if ((rc = stage_out_alloc(h, var, extent(B, stridevar, (size_t)N), &a.var))) return rc;
+    if ((rc = stage_out_alloc(h, info, (size_t)B, &info_out_dev))) return rc;
+  } else {
+    a.X = X; a.s = s; a.mw = mw; a.mean = mean; a.var = var;
+  }
+  int32_t* chol_info = nullptr;
+  int kind = prior_kind;
+  if (var) {
+    if ((rc = prior_factor<T>(h, B, D, prior_kind, Lw_dev, ldl, strideLw, &a.U, &a.ldu, &a.strideU, &kind, &chol_info)))
+      return rc;
+  } else {
+    a.U = Lw_dev; a.ldu = ldl; a.strideU = strideLw;
+  }
+  a.prior_kind = kind;
+  a.info = chol_info;
+  if (chol_info) HIP_TRY(h, hipMemcpyAsync(info_out_dev, chol_info, (size_t)B * sizeof(int32_t), hipMemcpyDeviceToDevice, h->stream));
+  else HIP_TRY(h, hipMemsetAsync(info_out_dev, 0, (size_t)B * sizeof(int32_t), h->stream));
+  size_t lds = ((size_t)D * 64 + D) * sizeof(T) + 16;
+  auto kern = marginals_kernel<T>;
+  HIP_TRY(h, hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+  dim3 grid((unsigned)((N + 63) / 64), (unsigned)B);
+  hipLaunchKernelGGL(kern, grid, dim3(64), lds, h->stream, a);
+  HIP_TRY(h, hipGetLastError());
+  if (memspace == BLR_MEM_HOST) {
+    if (mean) HIP_TRY(h, hipMemcpyAsync(mean, a.mean, extent(B, stridemean, (size_t)N) * sizeof(T), hipMemcpyDeviceToHost, h->stream));
+    if (var) HIP_TRY(h, hipMemcpyAsync(var, a.var, extent(B, stridevar, (size_t)N) * sizeof(T), hipMemcpyDeviceToHost, h->stream));
+    HIP_TRY(h, hipMemcpyAsync(info, info_out_dev, (size_t)B * sizeof(int32_t), hipMemcpyDeviceToHost, h->stream));
+    HIP_TRY(h, hipStreamSynchronize(h->stream));
+  } else if (!h->async) {
+    HIP_TRY(h, hipStreamSynchronize(h->stream));
+  }
+  return 0;
+}
+
+template <typename T>
+int sample_weights_impl(blr_handle* h, int memspace, int64_t D, int64_t S, int prior_kind, const T* mw, const T* Lw,
+                        int64_t ldl, const T* Z, int64_t ldz, T* W, int64_t ldw, bool sync_and_copy, T** W_dev_out,
+                        Staging* outer) {
+  (void)outer;
+  const T *mw_d = mw, *Lw_d = Lw, *Z_d = Z;
+  T* W_d = W;
+  int rc;
+  if (memspace == BLR_MEM_HOST) {
+    const size_t lw_one = prior_kind == BLR_PRIOR_DIAGONAL ? (size_t)D : mat_extent(D, D, ldl);
+    if ((rc = stage_in(h, mw, (size_t)D, &mw_d))) return rc;
+    if ((rc = stage_in(h, Lw, lw_one, &Lw_d))) return rc;
+    if ((rc = stage_in(h, Z, mat_extent(D, S, ldz), &Z_d))) return rc;
+    if (W) {
+      if ((rc = stage_out_alloc(h, W, mat_extent(D, S, ldw), &W_d))) return rc;
+    }
+  }
+  if (!W_d) {  // internal temporary (rand): dense D x S
+    void* p = nullptr;
+    HIP_TRY(h, hipMalloc(&p, (size_t)D * S * sizeof(T)));
+    h->staged.push_back(p);
+    W_d = static_cast<T*>(p);
+    ldw = D;
+  }
+  const T* U;
+  int64_t ldu, strideU;
+  int kind;
+  int32_t* chol_info;
+  if ((rc = prior_factor<T>(h, 1, D, prior_kind, Lw_d, ldl, 0, &U, &ldu, &strideU, &kind, &chol_info))) return rc;
+  int32_t hinfo = 0;
+  if (chol_info) {
+    HIP_TRY(h, hipMemcpyAsync(&hinfo, chol_info, sizeof(int32_t), hipMemcpyDeviceToHost, h->stream));
+    HIP_TRY(h, hipStreamSynchronize(h->stream));
+    if (hinfo != 0) return hinfo;
+  }
+  size_t lds = (size_t)D * 64 * sizeof(T) + 16;
+  auto kern = sample_weights_kernel<T>;
+  HIP_TRY(h, hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+  hipLaunchKernelGGL(kern, dim3((unsigned)((S + 63) / 64)), dim3(64), lds, h->stream, mw_d, U, ldu, kind, Z_d, ldz, W_d, ldw,
+                     (int)D, S);
+  HIP_TRY(h, hipGetLastError());
+  if (W_dev_out) *W_dev_out = W_d;
+  if (sync_and_copy) {
+    if (memspace == BLR_MEM_HOST) {
+      HIP_TRY(h, hipMemcpyAsync(W, W_d, mat_extent(D, S, ldw) * sizeof(T), hipMemcpyDeviceToHost, h->stream));
+      HIP_TRY(h, hipStreamSynchronize(h->stream));
+    } else if (!h->async) {
+      HIP_TRY(h, hipStreamSynchronize(h->stream));
+    }
+  }
+  return 0;
+}
+
+template <typename T>
+int sample_weights(blr_handle* h, int memspace, int64_t D, int64_t S, int prior_kind, const T* mw, const T* Lw,
+                   int64_t ldl, const T* Z, int64_t ldz, T* W, int64_t ldw) {
+  if (!h) return -1;
+  h->err.clear();
+  if (memspace != BLR_MEM_HOST && memspace != BLR_MEM_DEVICE) return bad_arg(h, 2, "memspace");
+  if (D < 1 || D > kMaxSmallD) return bad_arg(h, 3, "D out of range for this build (1..128)");
+  if (S < 0) return bad_arg(h, 4, "S < 0");
+  if (S == 0) return 0;
+  if (prior_kind != BLR_PRIOR_DENSE && prior_kind != BLR_PRIOR_UPPER_FACTOR && prior_kind != BLR_PRIOR_DIAGONAL)
+    return bad_arg(h, 5, "prior_kind");
+  if (!mw) return bad_arg(h, 6, "mw is NULL");
+  if (!Lw) return bad_arg(h, 7, "Lw is NULL");
+  if (prior_kind != BLR_PRIOR_DIAGONAL && ldl < D) return bad_arg(h, 8, "ldl < D");
+  if (!Z) return bad_arg(h, 9, "Z is NULL");
+  if (ldz < D) return bad_arg(h, 10, "ldz < D");
+  if (!W) return bad_arg(h, 11, "W is NULL");
+  if (ldw < D) return bad_arg(h, 12, "ldw < D");
+  HIP_TRY(h, hipSetDevice(h->device));
+  Staging guard(h);
+  return sample_weights_impl<T>(h, memspace, D, S, prior_kind, mw, Lw, ldl, Z, ldz, W, ldw, true, nullptr, &guard);
+}
+
+template <typename T>
+int rand_impl(blr_handle* h, int memspace, int layout, int64_t D, int64_t N, int64_t S, const T* X, int64_t ldx,
+              int noise_kind, const T* s, int prior_kind, const T* mw, const T* Lw, int64_t ldl, const T* Z1,
+              int64_t ldz1, const T* Z2, int64_t ldz2, T* Y, int64_t ldy) {
+  if (!h) return -1;
+  h->err.clear();
+  if (memspace != BLR_MEM_HOST && memspace != BLR_MEM_DEVICE) return bad_arg(h, 2, "memspace");
+  if (layout != BLR_LAYOUT_COLVECS && layout != BLR_LAYOUT_ROWVECS) return bad_arg(h, 3, "unknown layout (reference :26-31)");
+  if (D < 1 || D > kMaxSmallD) return bad_arg(h, 4, "D out of range for this build (1..128)");
+  if (N < 0 || N > (1 << 30)) return bad_arg(h, 5, "N out of range");
+  if (S < 0) return bad_arg(h, 6, "S < 0");
+  if (N == 0 || S == 0) return 0;
+  if (!X) return bad_arg(h, 7, "X is NULL");
+  if (layout == BLR_LAYOUT_COLVECS ? ldx < D : ldx < N) return bad_arg(h, 8, "ldx too small");
+  if (noise_kind != BLR_NOISE_ISOTROPIC && noise_kind != BLR_NOISE_DIAGONAL) return bad_arg(h, 9, "noise_kind");
+  if (!s) return bad_arg(h, 10, "s is NULL");
+  if (prior_kind != BLR_PRIOR_DENSE && prior_kind != BLR_PRIOR_UPPER_FACTOR && prior_kind != BLR_PRIOR_DIAGONAL)
+    return bad_arg(h, 11, "prior_kind");
+  if (!mw) return bad_arg(h, 12, "mw is NULL");
+  if (!Lw) return bad_arg(h, 13, "Lw is NULL");
+  if (prior_kind != BLR_PRIOR_DIAGONAL && ldl < D) return bad_arg(h, 14, "ldl < D");
+  if (!Z1) return bad_arg(h, 15, "Z1 is NULL");
+  if (ldz1 < D) return bad_arg(h, 16, "ldz1 < D");
+  if (!Z2) return bad_arg(h, 17, "Z2 is NULL");
+  if (ldz2 < N) return bad_arg(h, 18, "ldz2 < N");
+  if (!Y) return bad_arg(h, 19, "Y is NULL");
+  if (ldy < N) return bad_arg(h, 20, "ldy < N");
+  HIP_TRY(h, hipSetDevice(h->device));
+  Staging guard(h);
+  T* W_dev = nullptr;
+  // weights first (Z1 is the FIRST randn draw of reference :51), host staging handled inside
+  int rc = sample_weights_impl<T>(h, memspace, D, S, prior_kind, mw, Lw, ldl, Z1, ldz1, (T*)nullptr, D, false, &W_dev, &guard);
+  if (rc) return rc;
+  const T *X_d = X, *s_d = s, *Z2_d = Z2;
+  T* Y_d = Y;
+  if (memspace == BLR_MEM_HOST) {
+    const size_t x_one = layout == BLR_LAYOUT_COLVECS ? mat_extent(D, N, ldx) : mat_extent(N, D, ldx);
+    if ((rc = stage_in(h, X, x_one, &X_d))) return rc;
+    if ((rc = stage_in(h, s, noise_kind == BLR_NOISE_DIAGONAL ? (size_t)N : 1, &s_d))) return rc;
+    if ((rc = stage_in(h, Z2, mat_extent(N, S, ldz2), &Z2_d))) return rc;
+    if ((rc = stage_out_alloc(h, Y, mat_extent(N, S, ldy), &Y_d))) return rc;
+  }
+  dim3 grid((unsigned)((N + 63) / 64), (unsigned)((S + 63) / 64));
+  hipLaunchKernelGGL(rand_project_kernel<T>, grid, dim3(kThreads), 0, h->stream, X_d, ldx, layout, (const T*)W_dev,
+                     (int64_t)D, s_d, noise_kind, Z2_d, ldz2, Y_d, ldy, (int)D, (int)N, S);
+  HIP_TRY(h, hipGetLastError());
+  if (memspace == BLR_MEM_HOST) {
+    HIP_TRY(h, hipMemcpyAsync(Y, Y_d, mat_extent(N, S, ldy) * sizeof(T), hipMemcpyDeviceToHost, h->stream));
+  }
+  HIP_TRY(h, hipStreamSynchronize(h->stream));  // W_dev is a temporary: always drain before freeing it
+  return 0;
+}
+
+}  // namespace
+
+// =======================================================================================================
+extern "C" {
+
+int blr_abi_version(void) { return BLR_ABI_VERSION; }
+
+int blr_device_count(void) {
+  int n = 0;
+  if (hipGetDeviceCount(&n) != hipSuccess) return 0;
+  return n;
+}
+
+int blr_create(int device, blr_handle** out) {
+  if (!out) return -2;
+  *out = nullptr;
+  int n = 0;
+  hipError_t e = hipGetDeviceCount(&n);
+  if (e != hipSuccess || n == 0) return -(1000 + (int)(e == hipSuccess ? hipErrorNoDevice : e));
+  if (device < 0 || device >= n) return -1;
+  blr_handle* h = new (std::nothrow) blr_handle();
+  if (!h) return -(1000 + (int)hipErrorOutOfMemory);
+  h->device = device;
+  if ((e = hipSetDevice(device)) != hipSuccess || (e = hipStreamCreateWithFlags(&h->own_stream, hipStreamNonBlocking)) != hipSuccess ||
+      (e = hipEventCreate(&h->ev0)) != hipSuccess || (e = hipEventCreate(&h->ev1)) != hipSuccess) {
+    delete h;
+    return -(1000 + (int)e);
+  }
+  h->stream = h->own_stream;
+  *out = h;
+  return 0;
+}
+
+int blr_destroy(blr_handle* h) {
+  if (!h) return 0;
+  (void)hipSetDevice(h->device);
+  (void)hipStreamSynchronize(h->stream);
+  if (h->ws) (void)hipFree(h->ws);
+  if (h->ev0) (void)hipEventDestroy(h->ev0);
+  if (h->ev1) (void)hipEventDestroy(h->ev1);
+  if (h->own_stream) (void)hipStreamDestroy(h->own_stream);
+  delete h;
+  return 0;
+}
+
+const char* blr_last_error(blr_handle* h) { return h ? h->err.c_str() : "null handle"; }
+
+int blr_set_stream(blr_handle* h, void* hip_stream) {
+  if (!h) return -1;
+  h->stream = hip_stream ? static_cast<hipStream_t>(hip_stream) : h->own_stream;
+  return 0;
+}
+int blr_set_async(blr_handle* h, int async) {
+  if (!h) return -1;
+  h->async = async != 0;
+  return 0;
+}
+int blr_synchronize(blr_handle* h) {
+  if (!h) return -1;
+  HIP_TRY(h, hipStreamSynchronize(h->stream));
+  return 0;
+}
+
+int blr_device_alloc(blr_handle* h, size_t bytes, void** dptr) {
+  if (!h) return -1;
+  if (!dptr) return -3;
+  HIP_TRY(h, hipSetDevice(h->device));
+  HIP_TRY(h, hipMalloc(dptr, bytes ? bytes : 1));
+  return 0;
+}
+int blr_device_free(blr_handle* h, void* dptr) {
+  if (!h) return -1;
+  HIP_TRY(h, hipSetDevice(h->device));
+  HIP_TRY(h, hipStreamSynchronize(h->stream));
+  HIP_TRY(h, hipFree(dptr));
+  return 0;
+}
+int blr_memcpy_h2d(blr_handle* h, void* dst, const void* src, size_t bytes) {
+  if (!h) return -1;
+  HIP_TRY(h, hipMemcpyAsync(dst, src, bytes, hipMemcpyHostToDevice, h->stream));
+  HIP_TRY(h, hipStreamSynchronize(h->stream));
+  return 0;
+}
+int blr_memcpy_d2h(blr_handle* h, void* dst, const void* src, size_t bytes) {
+  if (!h) return -1;
+  HIP_TRY(h, hipMemcpyAsync(dst, src, bytes, hipMemcpyDeviceToHost, h->stream));
+  HIP_TRY(h, hipStreamSynchronize(h->stream));
+  return 0;
+}
+
+int blr_timer_start(blr_handle* h) {
+  if (!h) return -1;
+  HIP_TRY(h, hipEventRecord(h->ev0, h->stream));
+  return 0;
+}
+int blr_timer_stop(blr_handle* h, float* elapsed_ms) {
+  if (!h) return -1;
+  if (!elapsed_ms) return -2;
+  HIP_TRY(h, hipEventRecord(h->ev1, h->stream));
+  HIP_TRY(h, hipEventSynchronize(h->ev1));
+  HIP_TRY(h, hipEventElapsedTime(elapsed_ms, h->ev0, h->ev1));
+  return 0;
+}
+
+#define BLR_DEFINE(SUF, T)                                                                                          \
+  int blr_posterior_batched_##SUF(blr_handle* h, int memspace, int layout, int64_t B, int64_t D, int64_t N,        \
+                                  const T* X, int64_t ldx, int64_t strideX, const T* y, int64_t stridey,            \
+                                  int noise_kind, const T* s, int64_t strides, int prior_kind, const T* mw,         \
+                                  int64_t stridemw, const T* Lw, int64_t ldl, int64_t strideLw, T* mw_post,         \
+                                  int64_t stride_mwpost, T* T_post, int64_t ldt, int64_t strideT, T* Lw_post,      \
+                                  int64_t ldlp, int64_t strideLp, double* logpdf, int32_t* info) {                  \
+    return posterior_batched<T>(h, memspace, layout, B, D, N, X, ldx, strideX, y, stridey, noise_kind, s, strides,  \
+                                prior_kind, mw, stridemw, Lw, ldl, strideLw, mw_post, stride_mwpost, T_post, ldt,    \
+                                strideT, Lw_post, ldlp, strideLp, logpdf, info);                                    \
+  }                                                                                                                 \
+  int blr_posterior_##SUF(blr_handle* h, int layout, int64_t D, int64_t N, const T* X, int64_t ldx, const T* y,     \
+                          int noise_kind, const T* s, int prior_kind, const T* mw, const T* Lw, int64_t ldl,        \
+                          T* mw_post, T* T_post, int64_t ldt, T* Lw_post, int64_t ldlp, double* logpdf) {           \
+    return posterior_single<T>(h, layout, D, N, X, ldx, y, noise_kind, s, prior_kind, mw, Lw, ldl, mw_post, T_post, \
+                               ldt, Lw_post, ldlp, logpdf);                                                         \
+  }                                                                                                                 \
+  int blr_marginals_batched_##SUF(blr_handle* h, int memspace, int layout, int64_t B, int64_t D, int64_t N,        \
+                                  const T* X, int64_t ldx, int64_t strideX, int noise_kind, const T* s,             \
+                                  int64_t strides, int prior_kind, const T* mw, int64_t stridemw, const T* Lw,      \
+                                  int64_t ldl, int64_t strideLw, T* mean, int64_t stridemean, T* var,               \
+                                  int64_t stridevar, int32_t* info) {                                               \
+    return marginals_batched<T>(h, memspace, layout, B, D, N, X, ldx, strideX, noise_kind, s, strides, prior_kind,  \
+                                mw, stridemw, Lw, ldl, strideLw, mean, stridemean, var, stridevar, info);           \
+  }                                                                                                                 \
+  int blr_rand_##SUF(blr_handle* h, int memspace, int layout, int64_t D, int64_t N, int64_t S, const T* X,          \
+                     int64_t ldx, int noise_kind, const T* s, int prior_kind, const T* mw, const T* Lw,             \
+                     int64_t ldl, const T* Z1, int64_t ldz1, const T* Z2, int64_t ldz2, T* Y, int64_t ldy) {        \
+    return rand_impl<T>(h, memspace, layout, D, N, S, X, ldx, noise_kind, s, prior_kind, mw, Lw, ldl, Z1, ldz1, Z2, \
+                        ldz2, Y, ldy);                                                                              \
+  }                                                                                                                 \
+  int blr_sample_weights_##SUF(blr_handle* h, int memspace, int64_t D, int64_t S, int prior_kind, const T* mw,      \
+                               const T* Lw, int64_t ldl, const T* Z, int64_t ldz, T* W, int64_t ldw) {              \
+    return sample_weights<T>(h, memspace, D, S, prior_kind, mw, Lw, ldl, Z, ldz, W, ldw);                           \
+  }
+
+BLR_DEFINE(f64, double)
+BLR_DEFINE(f32, float)
+
+int blr_logpdf_sum(blr_handle* h, int memspace, int64_t B, const double* logpdf, double* total) {
+  if (!h) return -1;
+  h->err.clear();
+  if (memspace != BLR_MEM_HOST && memspace != BLR_MEM_DEVICE) return bad_arg(h, 2, "memspace");
+  if (B < 0) return bad_arg(h, 3, "B < 0");
+  if (B > 0 && !logpdf) return bad_arg(h, 4, "logpdf is NULL");
+  if (!total) return bad_arg(h, 5, "total is NULL");
+  HIP_TRY(h, hipSetDevice(h->device));
+  Staging guard(h);
+  const double* lp = logpdf;
+  double* tot = total;
+  int rc;
+  if (memspace == BLR_MEM_HOST) {
+    if ((rc = stage_in(h, logpdf, (size_t)B, &lp))) return rc;
+    void* p = nullptr;
+    HIP_TRY(h, hipMalloc(&p, sizeof(double)));
+    h->staged.push_back(p);
+    tot = static_cast<double*>(p);
+  }
+  hipLaunchKernelGGL(logpdf_sum_kernel, dim3(1), dim3(kThreads), 0, h->stream, lp, B, tot);
+  HIP_TRY(h, hipGetLastError());
+  if (memspace == BLR_MEM_HOST) {
+    HIP_TRY(h, hipMemcpyAsync(total, tot, sizeof(double), hipMemcpyDeviceToHost, h->stream));
+    HIP_TRY(h, hipStreamSynchronize(h->stream));
+  } else if (!h->async) {
+    HIP_TRY(h, hipStreamSynchronize(h->stream));
+  }
+  return 0;
+}
+
+}  // extern "C"

@@ -1,0 +1,209 @@
+// Auxiliary kernels of the path: standalone small Cholesky, marginal stream, weight draws,
+// projection of draws, fixed-order log-evidence sum.
+#pragma once
+#include "blr_common.hpp"
+#include "blr_fused_small.hpp"
+
+namespace blr {
+
+// ---- U = chol(Lw).U for a dense D x D precision (D <= 128), one workgroup per regressor ----------
+// reference :41 / :51 / sampling_functions.jl:29 call _cholesky(Lw) before every var / rand / draw.
+template <typename T>
+__global__ __launch_bounds__(kThreads) void chol_small_kernel(const T* __restrict__ Lw, int64_t ldl, int64_t strideLw,
+                                                              T* __restrict__ U, int64_t ldu, int64_t strideU,
+                                                              int32_t* __restrict__ info, int D, int B) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  T* const P = reinterpret_cast<T*>(smem);
+  T* const dinv = P + D * (D + 1) / 2;
+  const int tid = threadIdx.x;
+  for (int reg = blockIdx.x; reg < B; reg += gridDim.x) {
+    const T* A = Lw + (int64_t)reg * strideLw;
+    T* out = U + (int64_t)reg * strideU;
+    __syncthreads();
+    for (int idx = tid; idx < D * D; idx += kThreads) {
+      int i = idx / D, k = idx % D;
+      if (k <= i) P[pidx(i, k)] = A[(int64_t)i * ldl + k];
+    }
+    int r = chol_packed(P, dinv, D, tid);
+    if (tid == 0) info[reg] = r;
+    if (r == 0) {
+      for (int idx = tid; idx < D * D; idx += kThreads) {
+        int c = idx / D, rr = idx % D;
+        out[(int64_t)c * ldu + rr] = (rr <= c) ? P[pidx(c, rr)] : T(0);
+      }
+    }
+  }
+}
+
+// ---- marginal stream --------------------------------------------------------------------------------
+// mean_n = x_n'mw (:33), var_n = |U^-T x_n|^2 + s_n (:40-43) for a tile of 64 columns per wave-sized
+// workgroup.  The tile is staged as alpha[d][t] in LDS (coalesced for either layout) and the forward
+// substitution alpha = U^-T x runs in place, one column per lane.  prior_kind is UPPER_FACTOR (U D x D,
+// upper) or DIAGONAL (d[D]).
+template <typename T>
+struct MarginalArgs {
+  const T* X; int64_t ldx, strideX;
+  const T* s; int64_t strides;
+  const T* mw; int64_t stridemw;
+  const T* U; int64_t ldu, strideU;
+  T* mean; int64_t stridemean;
+  T* var; int64_t stridevar;
+  const int32_t* info;  // per-regressor status of a preceding factorisation (may be NULL)
+  int layout, noise_kind, prior_kind;
+  int D, N, B;
+};
+
+template <typename T>
+__global__ __launch_bounds__(64) void marginals_kernel(MarginalArgs<T> a) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  const int D = a.D, N = a.N;
+  T* const alpha = reinterpret_cast<T*>(smem);  // [D][64]
+  T* const mwv = alpha + (size_t)D * 64;        // [D]
+  const int lane = threadIdx.x;
+  const int reg = blockIdx.y;
+  if (a.info && a.info[reg] != 0) return;
+  const T* X = a.X + (int64_t)reg * a.strideX;
+  const T* U = a.U + (int64_t)reg * a.strideU;
+  const T* s = a.s + (int64_t)reg * a.strides;
+  const T* mw = a.mw + (int64_t)reg * a.stridemw;
+  const int n0 = blockIdx.x * 64;
+  const int nt = min(64, N - n0);
+  for (int d = lane; d < D; d += 64) mwv[d] = mw[d];
+  if (a.layout == LAYOUT_COLVECS) {
+    for (int idx = lane; idx < D * 64; idx += 64) {
+      int d = idx % D, t = idx / D;
+      alpha[d * 64 + t] = (t < nt) ? X[(int64_t)(n0 + t) * a.ldx + d] : T(0);
+    }
+  } else {
+    for (int d = 0; d < D; ++d) alpha[d * 64 + lane] = (lane < nt) ? X[(int64_t)d * a.ldx + n0 + lane] : T(0);
+  }
+  __syncthreads();
+  T m = T(0);
+  for (int d = 0; d < D; ++d) m += alpha[d * 64 + lane] * mwv[d];
+  T v = T(0);
+  if (a.var) {
+    if (a.prior_kind == PRIOR_DIAGONAL) {
+      for (int d = 0; d < D; ++d) {
+        T x = alpha[d * 64 + lane];
+        v += x * x / U[d];
+      }
+    } else {
+      for (int i = 0; i < D; ++i) {
+        T accv = alpha[i * 64 + lane];
+        const T* ucol = U + (int64_t)i * a.ldu;  // column i of U: U[k,i], k <= i (wave-uniform address)
+        for (int k = 0; k < i; ++k) accv -= ucol[k] * alpha[k * 64 + lane];
+        accv /= ucol[i];
+        alpha[i * 64 + lane] = accv;
+        v += accv * accv;
+      }
+    }
+    v += (a.noise_kind == NOISE_DIAGONAL) ? ((lane < nt) ? s[n0 + lane] : T(0)) : s[0];
+  }
+  if (lane < nt) {
+    if (a.mean) a.mean[(int64_t)reg * a.stridemean + n0 + lane] = m;
+    if (a.var) a.var[(int64_t)reg * a.stridevar + n0 + lane] = v;
+  }
+}
+
+// ---- weight draws: W = mw .+ U \ Z  (:51, sampling_functions.jl:29,35,44) -----------------------------
+// One sample per lane; back substitution in place in LDS (w[d][t]).
+template <typename T>
+__global__ __launch_bounds__(64) void sample_weights_kernel(const T* __restrict__ mw, const T* __restrict__ U, int64_t ldu,
+                                                            int prior_kind, const T* __restrict__ Z, int64_t ldz,
+                                                            T* __restrict__ W, int64_t ldw, int D, int64_t S) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  T* const w = reinterpret_cast<T*>(smem);  // [D][64]
+  const int lane = threadIdx.x;
+  const int64_t s0 = (int64_t)blockIdx.x * 64;
+  const int nt = (int)min((int64_t)64, S - s0);
+  for (int idx = lane; idx < D * 64; idx += 64) {
+    int d = idx % D, t = idx / D;
+    w[d * 64 + t] = (t < nt) ? Z[(s0 + t) * ldz + d] : T(0);
+  }
+  __syncthreads();
+  if (prior_kind == PRIOR_DIAGONAL) {
+    for (int d = 0; d < D; ++d) w[d * 64 + lane] = w[d * 64 + lane] / sqrt(U[d]);
+  } else {
+    for (int i = D - 1; i >= 0; --i) {
+      T accv = w[i * 64 + lane];
+      for (int k = i + 1; k < D; ++k) accv -= U[(int64_t)k * ldu + i] * w[k * 64 + lane];
+      w[i * 64 + lane] = accv / U[(int64_t)i * ldu + i];
+    }
+  }
+  __syncthreads();
+  for (int idx = lane; idx < D * 64; idx += 64) {
+    int d = idx % D, t = idx / D;
+    if (t < nt) W[(s0 + t) * ldw + d] = mw[d] + w[d * 64 + t];
+  }
+}
+
+// ---- Y = X'W .+ sqrt.(s) .* Z2   (:52) ---------------------------------------------------------------
+// 64 x 64 output tile per workgroup, 256 threads, X and W tiles staged in LDS in chunks of 32 rows of d.
+template <typename T>
+__global__ __launch_bounds__(kThreads) void rand_project_kernel(const T* __restrict__ X, int64_t ldx, int layout,
+                                                                const T* __restrict__ W, int64_t ldw,
+                                                                const T* __restrict__ s, int noise_kind,
+                                                                const T* __restrict__ Z2, int64_t ldz2,
+                                                                T* __restrict__ Y, int64_t ldy, int D, int N, int64_t S) {
+  __shared__ T xs[32][65];
+  __shared__ T ws[32][65];
+  const int tid = threadIdx.x;
+  const int n0 = blockIdx.x * 64;
+  const int64_t s0 = (int64_t)blockIdx.y * 64;
+  const int tn = tid & 63, ts = tid >> 6;  // thread computes n = n0+tn, samples s0 + ts + 4*j, j < 16
+  T accv[16];
+#pragma unroll
+  for (int j = 0; j < 16; ++j) accv[j] = T(0);
+  for (int d0 = 0; d0 < D; d0 += 32) {
+    __syncthreads();
+    for (int idx = tid; idx < 32 * 64; idx += kThreads) {
+      int dd, t;
+      if (layout == LAYOUT_COLVECS) { dd = idx % 32; t = idx / 32; }
+      else                          { t = idx % 64; dd = idx / 64; }
+      int d = d0 + dd, n = n0 + t;
+      T xv = T(0);
+      if (d < D && n < N) xv = (layout == LAYOUT_COLVECS) ? X[(int64_t)n * ldx + d] : X[(int64_t)d * ldx + n];
+      xs[dd][t] = xv;
+      int dd2 = idx % 32, t2 = idx / 32;
+      int d2 = d0 + dd2;
+      int64_t sidx = s0 + t2;
+      ws[dd2][t2] = (d2 < D && sidx < S) ? W[sidx * ldw + d2] : T(0);
+    }
+    __syncthreads();
+#pragma unroll 4
+    for (int dd = 0; dd < 32; ++dd) {
+      T xv = xs[dd][tn];
+#pragma unroll
+      for (int j = 0; j < 16; ++j) accv[j] += xv * ws[dd][ts + 4 * j];
+    }
+  }
+  const int n = n0 + tn;
+  if (n < N) {
+    const T sd = sqrt((noise_kind == NOISE_DIAGONAL) ? s[n] : s[0]);
+#pragma unroll
+    for (int j = 0; j < 16; ++j) {
+      int64_t sidx = s0 + ts + 4 * j;
+      if (sidx < S) Y[sidx * ldy + n] = accv[j] + sd * Z2[sidx * ldz2 + n];
+    }
+  }
+}
+
+// ---- fixed-order sum of logpdf[B] --------------------------------------------------------
+// One workgroup.  Thread t sums elements t, t+256, ... in order, then a fixed tree over threads: the
+// result depends only on B and the values, never on launch geometry.
+__global__ __launch_bounds__(kThreads) void logpdf_sum_kernel(const double* __restrict__ lp, int64_t B,
+                                                              double* __restrict__ total) {
+  __shared__ double part[kThreads];
+  const int tid = threadIdx.x;
+  double v = 0.0;
+  for (int64_t i = tid; i < B; i += kThreads) v += lp[i];
+  part[tid] = v;
+  __syncthreads();
+  for (int m = kThreads / 2; m >= 1; m >>= 1) {
+    if (tid < m) part[tid] += part[tid + m];
+    __syncthreads();
+  }
+  if (tid == 0) *total = part[0];
+}
+
+}  // namespace blr

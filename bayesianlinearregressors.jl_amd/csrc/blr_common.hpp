@@ -1,0 +1,120 @@
+// Shared device-side helpers for the gfx950 kernels (wave64, MFMA 16x16x4 in f64 / f32).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+namespace blr {
+
+constexpr int kWave = 64;
+constexpr int kThreads = 256;  // 4 waves: one per SIMD of a CU
+constexpr int kWaves = kThreads / kWave;
+
+enum : int { LAYOUT_COLVECS = 0, LAYOUT_ROWVECS = 1 };
+enum : int { NOISE_ISOTROPIC = 0, NOISE_DIAGONAL = 1 };
+enum : int { PRIOR_DENSE = 0, PRIOR_UPPER_FACTOR = 1, PRIOR_DIAGONAL = 2 };
+
+// ---- MFMA traits ---------------------------------------------------------------------------
+// v_mfma_f64_16x16x4_f64 / v_mfma_f32_16x16x4_f32: lane l supplies A[i = l&15][k = l>>4] and
+// B[k = l>>4][j = l&15].  For the Gram G = X S X' both operands are the SAME fragment shape
+// frag(I)[l] = X[16I + (l&15), n0 + (l>>4)], so one LDS image feeds both sides.
+// C/D maps differ: f64 row = (l>>4) + 4v, f32 row = 4(l>>4) + v; col = l&15 in both.
+template <typename T>
+struct Mfma;
+
+template <>
+struct Mfma<double> {
+  typedef double acc4 __attribute__((ext_vector_type(4)));
+  static constexpr int VEC = 2;  // elements per 16-byte vector
+  static __device__ __forceinline__ acc4 mma(double a, double b, acc4 c) {
+    return __builtin_amdgcn_mfma_f64_16x16x4f64(a, b, c, 0, 0, 0);
+  }
+  static __device__ __forceinline__ int crow(int lane, int v) { return (lane >> 4) + 4 * v; }
+};
+
+template <>
+struct Mfma<float> {
+  typedef float acc4 __attribute__((ext_vector_type(4)));
+  static constexpr int VEC = 4;
+  static __device__ __forceinline__ acc4 mma(float a, float b, acc4 c) {
+    return __builtin_amdgcn_mfma_f32_16x16x4f32(a, b, c, 0, 0, 0);
+  }
+  static __device__ __forceinline__ int crow(int lane, int v) { return 4 * (lane >> 4) + v; }
+};
+
+// lower-triangular tile enumeration t = I(I+1)/2 + J, J <= I
+__host__ __device__ constexpr int tile_I(int t) {
+  int i = 0;
+  while ((i + 1) * (i + 2) / 2 <= t) ++i;
+  return i;
+}
+__host__ __device__ constexpr int tile_J(int t) { return t - tile_I(t) * (tile_I(t) + 1) / 2; }
+
+// ---- cross-lane helpers --------------------------------------------------------------------
+template <int CTRL>
+__device__ __forceinline__ float dpp_mov(float x) {
+  int v = __builtin_amdgcn_update_dpp(0, __float_as_int(x), CTRL, 0xF, 0xF, false);
+  return __int_as_float(v);
+}
+template <int CTRL>
+__device__ __forceinline__ double dpp_mov(double x) {
+  int lo = __double2loint(x), hi = __double2hiint(x);
+  lo = __builtin_amdgcn_update_dpp(0, lo, CTRL, 0xF, 0xF, false);
+  hi = __builtin_amdgcn_update_dpp(0, hi, CTRL, 0xF, 0xF, false);
+  return __hiloint2double(hi, lo);
+}
+
+// All-reduce (sum) over each 16-lane DPP row.  Butterfly with commutative adds: every lane of a row
+// ends with the bitwise-identical value.  quad_perm[1,0,3,2], quad_perm[2,3,0,1], row_half_mirror,
+// row_mirror.
+template <typename T>
+__device__ __forceinline__ T row16_allreduce(T x) {
+  x += dpp_mov<0xB1>(x);
+  x += dpp_mov<0x4E>(x);
+  x += dpp_mov<0x141>(x);
+  x += dpp_mov<0x140>(x);
+  return x;
+}
+
+__device__ __forceinline__ double wave_allreduce(double x) {
+#pragma unroll
+  for (int m = 32; m >= 1; m >>= 1) x += __shfl_xor(x, m, 64);
+  return x;
+}
+
+__device__ __forceinline__ double readlane_f64(double x, int srclane /*wave-uniform*/) {
+  int lo = __builtin_amdgcn_readlane(__double2loint(x), srclane);
+  int hi = __builtin_amdgcn_readlane(__double2hiint(x), srclane);
+  return __hiloint2double(hi, lo);
+}
+__device__ __forceinline__ float readlane_f32(float x, int srclane) {
+  return __int_as_float(__builtin_amdgcn_readlane(__float_as_int(x), srclane));
+}
+__device__ __forceinline__ double readlane(double x, int l) { return readlane_f64(x, l); }
+__device__ __forceinline__ float readlane(float x, int l) { return readlane_f32(x, l); }
+
+// Fixed-order block reduction: wave butterflies, then the 4 wave partials summed 0..3 by everyone.
+// `scratch` needs kWaves doubles; contains two barriers.
+__device__ __forceinline__ double block_allreduce(double v, double* scratch, int tid) {
+  v = wave_allreduce(v);
+  __syncthreads();
+  if ((tid & 63) == 0) scratch[tid >> 6] = v;
+  __syncthreads();
+  return ((scratch[0] + scratch[1]) + scratch[2]) + scratch[3];
+}
+__device__ __forceinline__ int block_min_int(int v, int* scratch, int tid) {
+#pragma unroll
+  for (int m = 32; m >= 1; m >>= 1) {
+    int o = __shfl_xor(v, m, 64);
+    v = o < v ? o : v;
+  }
+  __syncthreads();
+  if ((tid & 63) == 0) scratch[tid >> 6] = v;
+  __syncthreads();
+  int a = scratch[0] < scratch[1] ? scratch[0] : scratch[1];
+  int b = scratch[2] < scratch[3] ? scratch[2] : scratch[3];
+  return a < b ? a : b;
+}
+
+__host__ __device__ __forceinline__ int pidx(int i, int k) { return i * (i + 1) / 2 + k; }  // packed lower, k <= i
+
+}  // namespace blr

@@ -1,0 +1,472 @@
+// Fused per-regressor inference kernel for D <= 128 (one 256-thread workgroup per regressor).
+//
+// Replaces reference src/bayesian_linear_regression.jl:72-89 (__compute_inference_quantities),
+// :55-58 (logpdf), :60-69 (posterior) with the direct Gram form of SURVEY.md 0.1:
+//   phase 0  (dense prior only) Cholesky of Lw in LDS -> logdet Lw, SPD check          (:78)
+//   phase 1  one streaming pass over X: MFMA SYRK  G += x_n w_n x_n'  (lower 16x16 tiles only),
+//            per column mu_n = x_n'mw, delta_n, b += x_n delta_n w_n, q += delta_n^2 w_n,
+//            l += log s_n                                                  (:79-84, :86, :57)
+//   phase 2  A = Lw + G into packed LDS; in-place Cholesky A = L L' (T = L')              (:86, :67)
+//   phase 3  u = L^-1 b, m = L^-T u, mw' = mw + m, evidence                              (:57, :64, :68)
+// X is read from HBM exactly once; nothing intermediate touches HBM.
+//
+// LDS image of a stage (4*KS columns): [k-step j][row block I][lane l] holds
+//   X[16I + (l&15), n0 + 4j + (l>>4)]  -- i.e. already in MFMA operand order, so every fragment
+// read is one conflict-free ds_read of 64 consecutive elements.
+#pragma once
+#include <utility>
+
+#include "blr_common.hpp"
+
+#ifndef BLR_JUNROLL
+#define BLR_JUNROLL 2
+#endif
+
+namespace blr {
+
+template <typename T>
+struct PosteriorArgs {
+  const T* X; int64_t ldx, strideX;
+  const T* y; int64_t stridey;
+  const T* s; int64_t strides;
+  const T* mw; int64_t stridemw;
+  const T* Lw; int64_t ldl, strideLw;
+  T* mw_post; int64_t stride_mwpost;
+  T* T_post; int64_t ldt, strideT;
+  T* Lw_post; int64_t ldlp, strideLp;
+  double* logpdf;
+  int32_t* info;
+  int layout, noise_kind, prior_kind;
+  int D, N, B;
+  int vec_ok;  // ColVecs, 16-byte aligned columns: vector loads allowed
+};
+
+template <typename T, int NB>
+struct SmallCfg {
+  static constexpr int DP = 16 * NB;
+  // k-steps (of 4 columns) per stage; chosen so PER is a multiple of the 16-byte vector width
+  static constexpr int KS = (NB < 3 || ((NB & 1) && sizeof(T) == 4)) ? 16 : 8;
+  static constexpr int NSC = 4 * KS;                    // columns per stage
+  static constexpr int SLOT = KS * NB * 64;             // elements per LDS slot
+  static constexpr int PER = SLOT / kThreads;           // elements per thread per stage
+  static constexpr int NT = NB * (NB + 1) / 2;          // lower-triangular 16x16 tiles
+  static constexpr int TPW = (NT + kWaves - 1) / kWaves;  // tiles per wave
+  static constexpr int PACKED = DP * (DP + 1) / 2;
+  static constexpr int RED_BYTES = 16 * DP * 8;          // b partials: 4 waves x 4 lane-rows x DP doubles
+  static constexpr int REGION0_A = 2 * SLOT * (int)sizeof(T);
+  static constexpr int REGION0_B = PACKED * (int)sizeof(T);
+  static constexpr int REGION0_C = RED_BYTES;
+  static constexpr int REGION0 =
+      ((REGION0_A > REGION0_B ? (REGION0_A > REGION0_C ? REGION0_A : REGION0_C)
+                              : (REGION0_B > REGION0_C ? REGION0_B : REGION0_C)) + 15) & ~15;
+  // after region 0: ybuf[2][NSC], wbuf[2][NSC], bvec[DP], dinv[DP] (T); scratch doubles/ints
+  static constexpr int OFF_Y = REGION0;
+  static constexpr int OFF_W = OFF_Y + 2 * NSC * (int)sizeof(T);
+  static constexpr int OFF_B = OFF_W + 2 * NSC * (int)sizeof(T);
+  static constexpr int OFF_DINV = OFF_B + DP * (int)sizeof(T);
+  static constexpr int OFF_MW = OFF_DINV + DP * (int)sizeof(T);
+  static constexpr int OFF_SCR = (OFF_MW + DP * (int)sizeof(T) + 15) & ~15;
+  static constexpr int LDS_BYTES = OFF_SCR + 64;
+};
+
+// ---- stage loader ------------------------------------------------------------------------------
+// MODE 0: ColVecs data, generic (any D, ldx, alignment)   MODE 1: RowVecs data
+// MODE 2: prior factor U as pseudo-observations: element (d, j) = U[j + d*ld] for j <= d, else 0
+// MODE 3: ColVecs data, 16-byte vectors (D % VEC == 0, 16-byte aligned columns)
+template <typename T, int NB>
+struct StageRegs {
+  T x[SmallCfg<T, NB>::PER];
+  T yv, wv;
+};
+
+__device__ __forceinline__ int frag_off(int NB, int d, int nl) {
+  return ((((nl >> 2) * NB + (d >> 4)) * 4 + (nl & 3)) << 4) + (d & 15);
+}
+
+template <typename T, int NB, int MODE>
+__device__ __forceinline__ void stage_load(StageRegs<T, NB>& r, const T* __restrict__ base, int64_t ld, int D, int ncols,
+                                           int n0, int tid) {
+  using C = SmallCfg<T, NB>;
+  constexpr int VEC = Mfma<T>::VEC;
+  // Opaque copy of tid: keeps the per-element index arithmetic inside the stage loop.  Hoisted out
+  // (LICM) it costs > 100 VGPRs of loop-invariant addresses and masks and forces spills.
+  asm volatile("" : "+v"(tid));
+  if constexpr (MODE == 3) {
+    typedef T vecT __attribute__((ext_vector_type(VEC)));
+    constexpr int VPC = C::DP / VEC;  // vectors per (padded) column
+    static_assert(C::PER % VEC == 0, "PER must be a multiple of the vector width");
+#pragma unroll
+    for (int e = 0; e < C::PER / VEC; ++e) {
+      int vidx = tid + kThreads * e;
+      int dv = vidx % VPC, nl = vidx / VPC;
+      int n = n0 + nl;
+      bool ok = dv * VEC < D && n < ncols;
+      int64_t addr = ok ? (int64_t)n * ld + dv * VEC : 0;
+      vecT v = *reinterpret_cast<const vecT*>(base + addr);
+#pragma unroll
+      for (int c = 0; c < VEC; ++c) r.x[e * VEC + c] = ok ? v[c] : T(0);
+    }
+  } else {
+#pragma unroll
+    for (int e = 0; e < C::PER; ++e) {
+      int idx = tid + kThreads * e;
+      int d, nl;
+      if constexpr (MODE == 0) { d = idx % C::DP; nl = idx / C::DP; }
+      else                     { nl = idx % C::NSC; d = idx / C::NSC; }
+      int n = n0 + nl;
+      bool ok = d < D && n < ncols && (MODE != 2 || n <= d);
+      int64_t addr = (MODE == 0) ? (int64_t)n * ld + d : (int64_t)d * ld + n;
+      T v = base[ok ? addr : 0];  // unconditional load of a valid address, then select: no branches
+      r.x[e] = ok ? v : T(0);
+    }
+  }
+}
+
+template <typename T, int NB, int MODE>
+__device__ __forceinline__ void stage_store(const StageRegs<T, NB>& r, T* __restrict__ slot, T* ybuf, T* wbuf, int tid) {
+  using C = SmallCfg<T, NB>;
+  constexpr int VEC = Mfma<T>::VEC;
+  asm volatile("" : "+v"(tid));
+  if constexpr (MODE == 3) {
+    typedef T vecT __attribute__((ext_vector_type(VEC)));
+    constexpr int VPC = C::DP / VEC;
+#pragma unroll
+    for (int e = 0; e < C::PER / VEC; ++e) {
+      int vidx = tid + kThreads * e;
+      int dv = vidx % VPC, nl = vidx / VPC;
+      vecT v;
+#pragma unroll
+      for (int c = 0; c < VEC; ++c) v[c] = r.x[e * VEC + c];
+      *reinterpret_cast<vecT*>(slot + frag_off(NB, dv * VEC, nl)) = v;
+    }
+  } else {
+#pragma unroll
+    for (int e = 0; e < C::PER; ++e) {
+      int idx = tid + kThreads * e;
+      int d, nl;
+      if constexpr (MODE == 0) { d = idx % C::DP; nl = idx / C::DP; }
+      else                     { nl = idx % C::NSC; d = idx / C::NSC; }
+      slot[frag_off(NB, d, nl)] = r.x[e];
+    }
+  }
+  if (tid < C::NSC) { ybuf[tid] = r.yv; wbuf[tid] = r.wv; }
+}
+
+// ---- one stage of MFMA + vector work for wave W -------------------------------------------------
+template <typename T, int NB>
+using AccArr = typename Mfma<T>::acc4[SmallCfg<T, NB>::TPW];
+
+template <typename T, int NB, int t, int slot_i>
+__device__ __forceinline__ void mma_one(AccArr<T, NB>& acc, const T (&fa)[NB],
+                                        const T (&f)[NB]) {
+  if constexpr (t < SmallCfg<T, NB>::NT) {
+    constexpr int I = tile_I(t), J = tile_J(t);
+    acc[slot_i] = Mfma<T>::mma(fa[I], f[J], acc[slot_i]);
+  }
+}
+
+template <typename T, int NB, int W, int... Is>
+__device__ __forceinline__ void mma_all(AccArr<T, NB>& acc, const T (&fa)[NB],
+                                        const T (&f)[NB], std::integer_sequence<int, Is...>) {
+  (mma_one<T, NB, W + kWaves * Is, Is>(acc, fa, f), ...);
+}
+
+template <typename T, int NB, int W>
+__device__ __forceinline__ void compute_stage(const T* __restrict__ slot, const T* __restrict__ ybuf,
+                                              const T* __restrict__ wbuf,
+                                              AccArr<T, NB>& acc, double (&bacc)[NB],
+                                              double& qacc, const T* __restrict__ mwl, int lane, bool is_data) {
+  using C = SmallCfg<T, NB>;
+#pragma unroll BLR_JUNROLL
+  for (int j = 0; j < C::KS; ++j) {
+    T f[NB], fa[NB];
+#pragma unroll
+    for (int I = 0; I < NB; ++I) f[I] = slot[(j * NB + I) * 64 + lane];
+    const T w = wbuf[4 * j + (lane >> 4)];
+#pragma unroll
+    for (int I = 0; I < NB; ++I) fa[I] = f[I] * w;
+    mma_all<T, NB, W>(acc, fa, f, std::make_integer_sequence<int, C::TPW>{});
+    if ((j & 3) == W && is_data) {
+      // column vector work for the 4 columns of this k-step: lane (r, q) holds rows 16I + r of column q
+      T mu = T(0);
+#pragma unroll
+      for (int I = 0; I < NB; ++I) mu += f[I] * mwl[16 * I + (lane & 15)];
+      mu = row16_allreduce(mu);
+      const T delta = ybuf[4 * j + (lane >> 4)] - mu;  // :82  y - mean(fx)
+      const T rn = delta * w;
+      if ((lane & 15) == 0) qacc += (double)delta * (double)rn;
+#pragma unroll
+      for (int I = 0; I < NB; ++I) bacc[I] += (double)f[I] * (double)rn;
+    }
+  }
+}
+
+// ---- in-LDS Cholesky on the packed lower triangle (row i at i(i+1)/2) ----------------------------
+// Right-looking with deferred column scaling: one barrier per column.  On exit P holds L (A = L L'),
+// dinv[j] = 1 / L[j][j].  Returns 0 or the LAPACK-style index (1-based) of the failing leading minor.
+template <typename T>
+__device__ __forceinline__ int chol_packed(T* __restrict__ P, T* __restrict__ dinv, int D, int tid) {
+  const int ti = tid >> 4, tk = tid & 15;
+  int info = 0;
+  __syncthreads();
+  for (int j = 0; j < D; ++j) {
+    const T ajj = P[pidx(j, j)];
+    if (!(ajj > T(0))) { info = j + 1; break; }  // wave- and block-uniform: everyone reads the same word
+    const T inv = T(1) / ajj;
+    for (int i = j + 1 + ti; i < D; i += 16) {
+      const T ci = P[pidx(i, j)] * inv;
+      T* row = P + pidx(i, 0);
+      for (int k = j + 1 + tk; k <= i; k += 16) row[k] -= ci * P[pidx(k, j)];
+    }
+    __syncthreads();
+  }
+  if (info) return info;
+  if (tid < D) dinv[tid] = T(1) / sqrt(P[pidx(tid, tid)]);
+  __syncthreads();
+  for (int i = ti; i < D; i += 16) {
+    T* row = P + pidx(i, 0);
+    for (int k = tk; k < i; k += 16) row[k] *= dinv[k];
+  }
+  if (tid < D) P[pidx(tid, tid)] = sqrt(P[pidx(tid, tid)]);
+  __syncthreads();
+  return 0;
+}
+
+// ---- the kernel -----------------------------------------------------------------------------------
+template <typename T, int NB, int MODE /* data loader: 0 ColVecs generic, 1 RowVecs, 3 ColVecs vector */>
+__global__ __launch_bounds__(kThreads, 2) void fused_small_kernel(PosteriorArgs<T> a) {
+  using C = SmallCfg<T, NB>;
+  using acc4 = typename Mfma<T>::acc4;
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  T* const slot0 = reinterpret_cast<T*>(smem);
+  T* const P = reinterpret_cast<T*>(smem);
+  double* const red = reinterpret_cast<double*>(smem);
+  T* const ybuf = reinterpret_cast<T*>(smem + C::OFF_Y);
+  T* const wbuf = reinterpret_cast<T*>(smem + C::OFF_W);
+  T* const bvec = reinterpret_cast<T*>(smem + C::OFF_B);
+  T* const dinv = reinterpret_cast<T*>(smem + C::OFF_DINV);
+  T* const mwl = reinterpret_cast<T*>(smem + C::OFF_MW);
+  double* const scr = reinterpret_cast<double*>(smem + C::OFF_SCR);
+  int* const iscr = reinterpret_cast<int*>(smem + C::OFF_SCR + 32);
+
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);  // scalar: the per-wave switch below is a real branch
+  const int D = a.D, N = a.N;
+  const double kNaN = __longlong_as_double(0x7ff8000000000000LL);
+
+  for (int reg = blockIdx.x; reg < a.B; reg += gridDim.x) {
+    const T* X = a.X + (int64_t)reg * a.strideX;
+    const T* y = a.y + (int64_t)reg * a.stridey;
+    const T* s = a.s + (int64_t)reg * a.strides;
+    const T* mw = a.mw + (int64_t)reg * a.stridemw;
+    const T* Lw = a.Lw + (int64_t)reg * a.strideLw;
+    int info = 0;
+    double logdet_Lw = 0.0;
+
+    // ---- phase 0: prior -----------------------------------------------------------------------
+    if (a.prior_kind == PRIOR_DENSE) {
+      __syncthreads();
+      for (int idx = tid; idx < D * D; idx += kThreads) {  // upper triangle (k <= i) of column i
+        int i = idx / D, k = idx % D;
+        if (k <= i) P[pidx(i, k)] = Lw[(int64_t)i * a.ldl + k];
+      }
+      info = chol_packed(P, dinv, D, tid);  // :78
+      double v = (info == 0 && tid < D) ? log((double)P[pidx(tid, tid)]) : 0.0;
+      logdet_Lw = 2.0 * block_allreduce(v, scr, tid);
+    } else {
+      // diagonal entries of d (DIAGONAL) or of the factor U (UPPER_FACTOR) must be positive
+      double v = 0.0;
+      int bad = 0x7fffffff;
+      if (tid < D) {
+        T dv = (a.prior_kind == PRIOR_DIAGONAL) ? Lw[tid] : Lw[(int64_t)tid * a.ldl + tid];
+        if (dv > T(0)) v = log((double)dv);
+        else bad = tid + 1;
+      }
+      bad = block_min_int(bad, iscr, tid);
+      if (bad != 0x7fffffff) info = bad;
+      v = block_allreduce(v, scr, tid);
+      logdet_Lw = (a.prior_kind == PRIOR_DIAGONAL) ? v : 2.0 * v;
+    }
+    if (info != 0) {  // block-uniform
+      if (tid == 0) {
+        a.info[reg] = info;
+        if (a.logpdf) a.logpdf[reg] = kNaN;
+      }
+      continue;
+    }
+
+    // ---- phase 1: streaming Gram ----------------------------------------------------------------
+    acc4 acc[C::TPW];
+#pragma unroll
+    for (int i = 0; i < C::TPW; ++i)
+#pragma unroll
+      for (int v = 0; v < 4; ++v) acc[i][v] = T(0);
+    double bacc[NB];
+#pragma unroll
+    for (int I = 0; I < NB; ++I) bacc[I] = 0.0;
+    if (tid < C::DP) mwl[tid] = tid < D ? mw[tid] : T(0);  // visible after the first stage barrier
+    double qacc = 0.0, lacc = 0.0;
+
+    const bool prior_cols = (a.prior_kind == PRIOR_UPPER_FACTOR);
+    const int nprior_stages = prior_cols ? (D + C::NSC - 1) / C::NSC : 0;
+    const int ndata_stages = (N + C::NSC - 1) / C::NSC;
+    const int nstages = nprior_stages + ndata_stages;
+    const bool diag_noise = (a.noise_kind == NOISE_DIAGONAL);
+    const T s_iso = diag_noise ? T(1) : s[0];
+
+    StageRegs<T, NB> regs;
+    auto issue = [&](int td) {  // prefetch data stage td into registers
+      const int n0 = td * C::NSC;
+      stage_load<T, NB, MODE>(regs, X, a.ldx, D, N, n0, tid);
+      regs.yv = T(0);
+      regs.wv = T(0);
+      if (tid < C::NSC && n0 + tid < N) {
+        regs.yv = y[n0 + tid];
+        T sv = diag_noise ? s[n0 + tid] : s_iso;
+        regs.wv = T(1) / sv;                       // :79/:81  Sigma_y^-1 on the diagonal
+        if (diag_noise) lacc += log((double)sv);   // :84  logdet(Sigma_y)
+      }
+    };
+
+    __syncthreads();  // region 0 is free (previous regressor / phase 0 done)
+    if (ndata_stages > 0) issue(0);
+    for (int t = 0; t < nstages; ++t) {
+      const int sl = t & 1;
+      T* slot = slot0 + sl * C::SLOT;
+      const bool is_data = t >= nprior_stages;
+      if (!is_data) {
+        // prior pseudo-observations: a handful of stages, loaded synchronously (registers die here)
+        StageRegs<T, NB> pr;
+        const int n0 = t * C::NSC;
+        stage_load<T, NB, 2>(pr, Lw, a.ldl, D, D, n0, tid);
+        pr.yv = T(0);
+        pr.wv = (tid < C::NSC && n0 + tid < D) ? T(1) : T(0);
+        stage_store<T, NB, 2>(pr, slot, ybuf + sl * C::NSC, wbuf + sl * C::NSC, tid);
+      } else {
+        stage_store<T, NB, MODE>(regs, slot, ybuf + sl * C::NSC, wbuf + sl * C::NSC, tid);
+      }
+      __syncthreads();
+      const int tdn = t + 1 - nprior_stages;  // next data stage
+      if (tdn > 0 && tdn < ndata_stages) issue(tdn);  // in flight while this stage computes
+      const T* yb = ybuf + sl * C::NSC;
+      const T* wb = wbuf + sl * C::NSC;
+      switch (wave) {
+        case 0: compute_stage<T, NB, 0>(slot, yb, wb, acc, bacc, qacc, mwl, lane, is_data); break;
+        case 1: compute_stage<T, NB, 1>(slot, yb, wb, acc, bacc, qacc, mwl, lane, is_data); break;
+        case 2: compute_stage<T, NB, 2>(slot, yb, wb, acc, bacc, qacc, mwl, lane, is_data); break;
+        default: compute_stage<T, NB, 3>(slot, yb, wb, acc, bacc, qacc, mwl, lane, is_data); break;
+      }
+    }
+
+    // ---- phase 2: b, A -> LDS ---------------------------------------------------------------------
+    __syncthreads();
+    {
+      const int q = lane >> 4, r = lane & 15;
+#pragma unroll
+      for (int I = 0; I < NB; ++I) red[(wave * 4 + q) * C::DP + 16 * I + r] = bacc[I];
+    }
+    __syncthreads();
+    if (tid < C::DP) {
+      double sum = 0.0;
+#pragma unroll
+      for (int p = 0; p < 16; ++p) sum += red[p * C::DP + tid];  // fixed order
+      bvec[tid] = (T)sum;                                         // b = X S (y - X'mw)   (:57 Bt'dy, unwhitened)
+    }
+    const double quad = block_allreduce(qacc, scr, tid);          // (y-m)' S (y-m)
+    double logdet_Sy = block_allreduce(lacc, scr, tid);
+    if (!diag_noise) logdet_Sy = (double)N * log((double)s_iso);
+    // (block_allreduce's barriers also fence the reads of `red` above)
+
+    // accumulators -> packed lower triangle, adding the prior precision
+#pragma unroll
+    for (int i = 0; i < C::TPW; ++i) {
+      const int t = wave + kWaves * i;
+      if (t < C::NT) {
+        // tile coordinates: t is wave-dependent, recompute (cheap, once per regressor)
+        int I = 0;
+        while ((I + 1) * (I + 2) / 2 <= t) ++I;
+        const int J = t - I * (I + 1) / 2;
+        const int col = 16 * J + (lane & 15);
+#pragma unroll
+        for (int v = 0; v < 4; ++v) {
+          const int row = 16 * I + Mfma<T>::crow(lane, v);
+          if (col <= row && row < D) {
+            T val = acc[i][v];
+            if (a.prior_kind == PRIOR_DENSE) val += Lw[(int64_t)row * a.ldl + col];  // upper entry (col,row)
+            else if (a.prior_kind == PRIOR_DIAGONAL && row == col) val += Lw[row];
+            P[pidx(row, col)] = val;
+          }
+        }
+      }
+    }
+    __syncthreads();
+    if (a.Lw_post) {  // posterior precision Lw' = A, full symmetric (:92)
+      T* out = a.Lw_post + (int64_t)reg * a.strideLp;
+      for (int idx = tid; idx < D * D; idx += kThreads) {
+        int c = idx / D, r = idx % D;
+        out[(int64_t)c * a.ldlp + r] = (r >= c) ? P[pidx(r, c)] : P[pidx(c, r)];
+      }
+    }
+
+    info = chol_packed(P, dinv, D, tid);  // :86 (and :67: T = L' is chol(Lw + G).U directly)
+    if (info != 0) {
+      if (tid == 0) {
+        a.info[reg] = info;
+        if (a.logpdf) a.logpdf[reg] = kNaN;
+      }
+      continue;
+    }
+
+    if (a.T_post) {
+      T* out = a.T_post + (int64_t)reg * a.strideT;
+      for (int idx = tid; idx < D * D; idx += kThreads) {
+        int c = idx / D, r = idx % D;
+        out[(int64_t)c * a.ldt + r] = (r <= c) ? P[pidx(c, r)] : T(0);
+      }
+    }
+
+    // ---- phase 3: triangular solves + evidence (wave 0) ----------------------------------------------
+    if (wave == 0) {
+      const int i0 = lane, i1 = lane + 64;
+      T b0 = i0 < D ? bvec[i0] : T(0);
+      T b1 = i1 < D ? bvec[i1] : T(0);
+      // forward: u = L^-1 b                                     (:57  Lam.U' \ (Bt'dy))
+      for (int k = 0; k < D; ++k) {
+        T src = (k < 64) ? b0 : b1;
+        T uk = readlane(src, k & 63) * dinv[k];
+        if (lane == (k & 63)) { if (k < 64) b0 = uk; else b1 = uk; }
+        if (i0 > k && i0 < D) b0 -= P[pidx(i0, k)] * uk;
+        if (i1 > k && i1 < D) b1 -= P[pidx(i1, k)] * uk;
+      }
+      double uu = (double)b0 * (double)b0 + (double)b1 * (double)b1;
+      uu = wave_allreduce(uu);
+      // backward: m = L^-T u                                    (:64, :68)
+      for (int k = D - 1; k >= 0; --k) {
+        T src = (k < 64) ? b0 : b1;
+        T mk = readlane(src, k & 63) * dinv[k];
+        if (lane == (k & 63)) { if (k < 64) b0 = mk; else b1 = mk; }
+        const T* row = P + pidx(k, 0);
+        if (i0 < k) b0 -= row[i0] * mk;
+        if (i1 < k) b1 -= row[i1] * mk;
+      }
+      if (a.mw_post) {
+        T* out = a.mw_post + (int64_t)reg * a.stride_mwpost;
+        if (i0 < D) out[i0] = mw[i0] + b0;  // :68  mw + Uw \ m_eps
+        if (i1 < D) out[i1] = mw[i1] + b1;
+      }
+      double ld = 0.0;
+      if (i0 < D) ld += log((double)P[pidx(i0, i0)]);
+      if (i1 < D) ld += log((double)P[pidx(i1, i1)]);
+      ld = 2.0 * wave_allreduce(ld);  // logdet A
+      if (lane == 0) {
+        a.info[reg] = 0;
+        if (a.logpdf) {
+          const double LOG2PI = 1.8378770664093454835606594728112;
+          a.logpdf[reg] = -0.5 * ((double)N * LOG2PI + logdet_Sy + quad + ld - logdet_Lw - uu);  // :84 + :57
+        }
+      }
+    }
+  }
+}
+
+}  // namespace blr

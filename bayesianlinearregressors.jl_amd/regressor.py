@@ -1,0 +1,473 @@
+"""Host-side mirror of BayesianLinearRegressors.jl's AbstractGPs surface, backed by the MI355X library.
+
+Julia is not available in the build image, so this is the reference's operator interface restated
+in Python over the same C ABI a Julia ``ccall`` shim binds: same names, same
+argument meaning, same error behaviour.  Every number is computed by the HIP kernels; there is no
+CPU fallback.
+
+    f   = BayesianLinearRegressor(mw, Lw)            # reference src/bayesian_linear_regression.jl:11-14
+    fx  = f(ColVecs(X), Sigma)                       # FiniteGP (AbstractGPs)
+    logpdf(fx, y); posterior(fx, y)                  # :55-58, :60-69
+    mean(fx); var(fx); mean_and_var(fx); marginals(fx)   # :33, :40-43, :47
+    rand(rng, fx, S)                                 # :49-53
+    rand(rng, f) / rand(rng, f, dims)                # src/sampling_functions.jl:27-38
+    BasisFunctionRegressor(f, phi)                   # src/basis_function_regression.jl:34-65
+"""
+from __future__ import annotations
+
+import math
+
+import numpy as np
+
+from . import _abi
+
+__all__ = [
+    "ColVecs", "RowVecs", "Diagonal", "Symmetric", "PDMat", "Normal",
+    "BayesianLinearRegressor", "BasisFunctionRegressor", "BLRFunctionSample", "FiniteGP",
+    "mean", "var", "cov", "std", "mean_and_var", "mean_and_cov", "marginals", "rand", "rand_b", "logpdf", "posterior",
+]
+
+
+# ---------------------------------------------------------------------------------------------------
+# containers (KernelFunctions.ColVecs / RowVecs, LinearAlgebra.Diagonal / Symmetric, PDMats.PDMat)
+# ---------------------------------------------------------------------------------------------------
+class ColVecs:
+    """D x N matrix whose columns are the inputs."""
+
+    def __init__(self, X):
+        X = np.asarray(X)
+        if X.ndim != 2:
+            raise ValueError("ColVecs expects a matrix")
+        self.X = X
+
+    def __len__(self):
+        return self.X.shape[1]
+
+    def __getitem__(self, idx):
+        return ColVecs(self.X[:, idx])
+
+
+class RowVecs:
+    """N x D matrix whose rows are the inputs."""
+
+    def __init__(self, X):
+        X = np.asarray(X)
+        if X.ndim != 2:
+            raise ValueError("RowVecs expects a matrix")
+        self.X = X
+
+    def __len__(self):
+        return self.X.shape[0]
+
+    def __getitem__(self, idx):
+        return RowVecs(self.X[idx, :])
+
+
+class Diagonal:
+    def __init__(self, diag):
+        self.diag = np.asarray(diag)
+        if self.diag.ndim != 1:
+            raise ValueError("Diagonal expects a vector")
+
+    @property
+    def shape(self):
+        n = self.diag.shape[0]
+        return (n, n)
+
+    def toarray(self):
+        return np.diag(self.diag)
+
+
+class Symmetric:
+    def __init__(self, data):
+        self.data = np.asarray(data)
+
+    @property
+    def shape(self):
+        return self.data.shape
+
+    def toarray(self):
+        u = np.triu(self.data)
+        return u + np.triu(self.data, 1).T
+
+
+class PDMat:
+    """Positive-definite matrix carried by its upper Cholesky factor (PDMats.PDMat(Cholesky(U)))."""
+
+    def __init__(self, U):
+        self.U = np.asarray(U)
+
+    @property
+    def shape(self):
+        return self.U.shape
+
+    def toarray(self):
+        u = np.triu(self.U)
+        return u.T @ u
+
+
+class Normal:
+    """Distributions.Normal(mu, sigma) -- what `marginals` returns per input."""
+
+    __slots__ = ("mu", "sigma")
+
+    def __init__(self, mu, sigma):
+        self.mu, self.sigma = float(mu), float(sigma)
+
+    def __repr__(self):
+        return f"Normal(mu={self.mu}, sigma={self.sigma})"
+
+
+def std(n):
+    return n.sigma if isinstance(n, Normal) else np.array([k.sigma for k in n])
+
+
+# ---------------------------------------------------------------------------------------------------
+# x_as_colvecs: reference :20-31.  Index/shape work only -- resolved to (pointer, layout flag, ld)
+# ---------------------------------------------------------------------------------------------------
+def _x_layout(x, dtype):
+    """-> (array kept alive, layout flag, ldx, D, N) with zero copies for C- or F-contiguous input."""
+    if isinstance(x, ColVecs):
+        M, colvecs = x.X, True
+    elif isinstance(x, RowVecs):
+        M, colvecs = x.X, False
+    elif isinstance(x, np.ndarray) and x.ndim == 2:
+        M, colvecs = x, True  # AbstractGPs turns a raw D x N matrix into ColVecs
+    else:
+        raise TypeError(
+            f"{type(x).__name__} is not a subtype of AbstractVector that is known. "
+            "Please provide either a ColVecs or RowVecs."
+        )
+    M = np.asarray(M, dtype=dtype)
+    if not (M.flags.c_contiguous or M.flags.f_contiguous):
+        M = np.ascontiguousarray(M)
+    if colvecs:
+        D, N = M.shape
+        # (D, N) Fortran order  == D x N column-major == COLVECS;  C order == N x D column-major == ROWVECS
+        if M.flags.f_contiguous:
+            return M, _abi.LAYOUT_COLVECS, max(D, 1), D, N
+        return M, _abi.LAYOUT_ROWVECS, max(N, 1), D, N
+    N, D = M.shape
+    if M.flags.f_contiguous:
+        return M, _abi.LAYOUT_ROWVECS, max(N, 1), D, N
+    return M, _abi.LAYOUT_COLVECS, max(D, 1), D, N
+
+
+def _noise(Sy, N, dtype):
+    """-> (array, noise_kind).  Scalar = f(x, sigma^2); vector / Diagonal = Diagonal(v)."""
+    if isinstance(Sy, Diagonal):
+        Sy = Sy.diag
+    Sy = np.asarray(Sy, dtype=dtype)
+    if Sy.ndim == 0:
+        return Sy.reshape(1).copy(), _abi.NOISE_ISOTROPIC
+    if Sy.ndim == 1:
+        if Sy.shape[0] != N:
+            raise ValueError("length of the noise diagonal != number of inputs")
+        return np.ascontiguousarray(Sy), _abi.NOISE_DIAGONAL
+    raise NotImplementedError(
+        "a dense N x N noise covariance is outside the MI355X hot path (SURVEY.md 2 #19): "
+        "only isotropic and Diagonal noise are offloaded"
+    )
+
+
+def _prior(Lw, D, dtype):
+    """-> (array, prior_kind, ldl)."""
+    if isinstance(Lw, Diagonal):
+        d = np.ascontiguousarray(Lw.diag, dtype=dtype)
+        if d.shape[0] != D:
+            raise ValueError("size of the prior precision != length(mw)")
+        return d, _abi.PRIOR_DIAGONAL, 1
+    if isinstance(Lw, PDMat):
+        U = np.asfortranarray(Lw.U, dtype=dtype)
+        kind = _abi.PRIOR_UPPER_FACTOR
+    else:
+        A = Lw.data if isinstance(Lw, Symmetric) else Lw
+        U = np.asfortranarray(A, dtype=dtype)  # upper triangle is read (LAPACK 'U')
+        kind = _abi.PRIOR_DENSE
+    if U.shape != (D, D):
+        raise ValueError("size of the prior precision != length(mw)")
+    return U, kind, max(D, 1)
+
+
+def _dtype_of(*arrays):
+    dts = [np.asarray(a).dtype for a in arrays if a is not None]
+    if dts and all(dt == np.float32 for dt in dts):
+        return np.float32
+    return np.float64
+
+
+# ---------------------------------------------------------------------------------------------------
+# the regressors
+# ---------------------------------------------------------------------------------------------------
+class BayesianLinearRegressor:
+    """w ~ Normal(mw, inv(Lw));  f(x) = dot(x, w).   reference :11-14"""
+
+    def __init__(self, mw, Lw):
+        self.mw = np.asarray(mw)
+        if self.mw.ndim != 1:
+            raise ValueError("mw must be a vector")
+        self.Lw = Lw
+
+    # field name used by the reference
+    @property
+    def Λw(self):  # noqa: PLC2401
+        return self.Lw
+
+    def __call__(self, x, Sy=1e-18):
+        return FiniteGP(self, x, Sy)
+
+
+class BasisFunctionRegressor:
+    """bfr(X) = blr(phi(X)).   reference src/basis_function_regression.jl:34-37"""
+
+    def __init__(self, blr, phi):
+        if not isinstance(blr, BayesianLinearRegressor):
+            raise TypeError("BasisFunctionRegressor wraps a BayesianLinearRegressor")
+        self.blr = blr
+        self.phi = phi
+
+    @property
+    def ϕ(self):  # noqa: PLC2401
+        return self.phi
+
+    def __call__(self, x, Sy=1e-18):
+        return FiniteGP(self, x, Sy)
+
+
+class FiniteGP:
+    """AbstractGPs.FiniteGP: a regressor evaluated at inputs x with observation-noise covariance Sy."""
+
+    def __init__(self, f, x, Sy):
+        self.f, self.x, self.Sy = f, x, Sy
+
+    @property
+    def Σy(self):  # noqa: PLC2401
+        return self.Sy
+
+
+def _to_finite_blr(fx):
+    """reference src/basis_function_regression.jl:41"""
+    if isinstance(fx.f, BasisFunctionRegressor):
+        return FiniteGP(fx.f.blr, fx.f.phi(fx.x), fx.Sy)
+    if isinstance(fx.f, BayesianLinearRegressor):
+        return fx
+    raise TypeError("expected a FiniteGP over a BayesianLinearRegressor or BasisFunctionRegressor")
+
+
+def _handle():
+    return _abi.default_handle()
+
+
+def _wrap_like(prior_Lw, T, A):
+    """__build_Lambda, reference :92-93: PDMat prior -> PDMat posterior carrying T; else Symmetric(T'T)."""
+    if isinstance(prior_Lw, PDMat):
+        return PDMat(T)
+    return Symmetric(A)
+
+
+# ---------------------------------------------------------------------------------------------------
+# AbstractGPs API
+# ---------------------------------------------------------------------------------------------------
+def _fused(fx, y, want_posterior):
+    fx = _to_finite_blr(fx)
+    blr = fx.f
+    dtype = _dtype_of(blr.mw, y)
+    X, layout, ldx, D, N = _x_layout(fx.x, dtype)
+    y = np.ascontiguousarray(y, dtype=dtype)
+    if y.ndim != 1:
+        raise ValueError("y must be a vector")
+    if y.shape[0] != N:
+        raise ValueError("length(y) != size(fx.x.X, 2)")  # reference :74
+    mw = np.ascontiguousarray(blr.mw, dtype=dtype)
+    if mw.shape[0] != D:
+        raise ValueError("length(mw) != dimension of the inputs")
+    s, noise_kind = _noise(fx.Sy, N, dtype)
+    Lw, prior_kind, ldl = _prior(blr.Lw, D, dtype)
+    lp = np.zeros(1, dtype=np.float64)
+    if want_posterior:
+        mw_post = np.empty(D, dtype=dtype)
+        T = np.empty((D, D), dtype=dtype, order="F")
+        A = np.empty((D, D), dtype=dtype, order="F") if not isinstance(blr.Lw, PDMat) else None
+    else:
+        mw_post = T = A = None
+    _handle().posterior(dtype, layout, D, N, X, ldx, y, noise_kind, s, prior_kind, mw, Lw, ldl, mw_post, T, max(D, 1),
+                        A, max(D, 1), lp)
+    return float(lp[0]), mw_post, T, A
+
+
+def logpdf(fx, y):
+    """reference :55-58.  A matrix Y (N x S) gives the column-wise log densities (AbstractGPs fallback)."""
+    y = np.asarray(y)
+    if y.ndim == 2:
+        return logpdf_columns(fx, y)
+    return _fused(fx, y, want_posterior=False)[0]
+
+
+def logpdf_columns(fx, Y):
+    """Shared-X multi-output evidence: one batched launch, X shared through strideX = 0."""
+    fx = _to_finite_blr(fx)
+    blr = fx.f
+    dtype = _dtype_of(blr.mw, Y)
+    X, layout, ldx, D, N = _x_layout(fx.x, dtype)
+    Yf = np.asfortranarray(Y, dtype=dtype)
+    if Yf.shape[0] != N:
+        raise ValueError("length(y) != size(fx.x.X, 2)")
+    S = Yf.shape[1]
+    mw = np.ascontiguousarray(blr.mw, dtype=dtype)
+    s, noise_kind = _noise(fx.Sy, N, dtype)
+    Lw, prior_kind, ldl = _prior(blr.Lw, D, dtype)
+    lp = np.zeros(S, dtype=np.float64)
+    info = np.zeros(S, dtype=np.int32)
+    _handle().posterior_batched(dtype, _abi.MEM_HOST, layout, S, D, N, X, ldx, 0, Yf, N, noise_kind, s, 0, prior_kind,
+                                mw, 0, Lw, ldl, 0, None, D, None, max(D, 1), D * D, None, max(D, 1), D * D, lp, info)
+    bad = np.flatnonzero(info)
+    if bad.size:
+        raise _abi.PosDefException(int(info[bad[0]]))
+    return lp
+
+
+def posterior(fx, y):
+    """reference :60-69 (and basis_function_regression.jl:62-65): same wrapper type as the prior."""
+    _, mw_post, T, A = _fused(fx, y, want_posterior=True)
+    base = fx.f.blr if isinstance(fx.f, BasisFunctionRegressor) else fx.f
+    post = BayesianLinearRegressor(mw_post, _wrap_like(base.Lw, T, A))
+    if isinstance(fx.f, BasisFunctionRegressor):
+        return BasisFunctionRegressor(post, fx.f.phi)
+    return post
+
+
+def _marginals(fx, want_mean, want_var):
+    fx = _to_finite_blr(fx)
+    blr = fx.f
+    dtype = _dtype_of(blr.mw)
+    X, layout, ldx, D, N = _x_layout(fx.x, dtype)
+    mw = np.ascontiguousarray(blr.mw, dtype=dtype)
+    if mw.shape[0] != D:
+        raise ValueError("length(mw) != dimension of the inputs")
+    s, noise_kind = _noise(fx.Sy, N, dtype)
+    Lw, prior_kind, ldl = _prior(blr.Lw, D, dtype)
+    m = np.empty(N, dtype=dtype) if want_mean else None
+    v = np.empty(N, dtype=dtype) if want_var else None
+    info = np.zeros(1, dtype=np.int32)
+    _handle().marginals_batched(dtype, _abi.MEM_HOST, layout, 1, D, N, X, ldx, 0, noise_kind, s, 0, prior_kind, mw, 0,
+                                Lw, ldl, 0, m, N, v, N, info)
+    if info[0] > 0:
+        raise _abi.PosDefException(int(info[0]))
+    return m, v
+
+
+def mean(fx):
+    """reference :33"""
+    return _marginals(fx, True, False)[0]
+
+
+def var(fx):
+    """reference :40-43"""
+    return _marginals(fx, False, True)[1]
+
+
+def mean_and_var(fx):
+    """reference :47"""
+    return _marginals(fx, True, True)
+
+
+def marginals(fx):
+    """AbstractGPs.marginals: Normal.(mean, sqrt.(var))"""
+    m, v = mean_and_var(fx)
+    return [Normal(mi, math.sqrt(vi)) for mi, vi in zip(m, v)]
+
+
+def cov(fx):
+    """reference :35-38.  The N x N predictive covariance is excluded from the GPU scope
+    (SURVEY.md 8 a10); use var(fx) / marginals(fx) for the streamed diagonal."""
+    raise NotImplementedError("cov(fx) (N x N) is outside the MI355X hot path; use var(fx)")
+
+
+def mean_and_cov(fx):
+    raise NotImplementedError("mean_and_cov(fx) (N x N) is outside the MI355X hot path; use mean_and_var(fx)")
+
+
+def _randn(rng, rows, cols, dtype):
+    """randn(rng, rows, cols) filled in column-major order like Julia (memory order == draw order)."""
+    return np.asarray(rng.standard_normal((cols, rows)), dtype=dtype).T  # F-contiguous (rows, cols)
+
+
+class BLRFunctionSample:
+    """A function sampled from a regressor by fixing w ~ p(w).  reference src/sampling_functions.jl:12-19"""
+
+    def __init__(self, w, phi):
+        self.w = w
+        self.phi = phi
+
+    def __call__(self, X):
+        x = self.phi(X) if self.phi is not None else X
+        f = BayesianLinearRegressor(self.w, Diagonal(np.ones_like(self.w)))
+        return _marginals(FiniteGP(f, x, 0.0), True, False)[0]  # phi(X)' w through the mean-only stream
+
+
+def _blr_and_mapping(b):
+    """reference src/sampling_functions.jl:51-52"""
+    if isinstance(b, BasisFunctionRegressor):
+        return b.blr, b.phi
+    if isinstance(b, BayesianLinearRegressor):
+        return b, None
+    raise TypeError("expected a BayesianLinearRegressor or BasisFunctionRegressor")
+
+
+def _sample_weights(rng, blr, S):
+    dtype = _dtype_of(blr.mw)
+    D = blr.mw.shape[0]
+    mw = np.ascontiguousarray(blr.mw, dtype=dtype)
+    Lw, prior_kind, ldl = _prior(blr.Lw, D, dtype)
+    Z = _randn(rng, D, S, dtype)
+    W = np.empty((D, S), dtype=dtype, order="F")
+    _handle().sample_weights(dtype, _abi.MEM_HOST, D, S, prior_kind, mw, Lw, ldl, Z, D, W, D)
+    return W
+
+
+def rand(rng, f, *dims):
+    """rand(rng, fx[, S]) -- reference :49-53;  rand(rng, f[, dims...]) -- sampling_functions.jl:27-38."""
+    if isinstance(f, FiniteGP):
+        if len(dims) == 0:
+            return rand(rng, f, 1)[:, 0]
+        if len(dims) != 1:
+            raise TypeError("rand(rng, fx, samples::Int)")
+        return _rand_finite(rng, f, int(dims[0]))
+    blr, phi = _blr_and_mapping(f)
+    if len(dims) == 0:
+        return BLRFunctionSample(_sample_weights(rng, blr, 1)[:, 0].copy(), phi)
+    if len(dims) == 1 and isinstance(dims[0], (tuple, list)):
+        dims = tuple(dims[0])
+    S = int(np.prod(dims))
+    W = _sample_weights(rng, blr, S)
+    out = np.empty(S, dtype=object)
+    for i in range(S):
+        out[i] = BLRFunctionSample(W[:, i].copy(), phi)
+    return out.reshape(dims, order="F")
+
+
+def rand_b(rng, A, f):
+    """rand!(rng, A, f): fill an existing array of samples.  sampling_functions.jl:40-49"""
+    blr, phi = _blr_and_mapping(f)
+    W = _sample_weights(rng, blr, A.size)
+    flat = A.reshape(-1, order="F")
+    for i in range(A.size):
+        flat[i] = BLRFunctionSample(W[:, i].copy(), phi)
+    A[...] = flat.reshape(A.shape, order="F")
+    return A
+
+
+def _rand_finite(rng, fx, S):
+    fx = _to_finite_blr(fx)
+    blr = fx.f
+    dtype = _dtype_of(blr.mw)
+    X, layout, ldx, D, N = _x_layout(fx.x, dtype)
+    mw = np.ascontiguousarray(blr.mw, dtype=dtype)
+    s, noise_kind = _noise(fx.Sy, N, dtype)
+    Lw, prior_kind, ldl = _prior(blr.Lw, D, dtype)
+    Z1 = _randn(rng, D, S, dtype)  # FIRST draw  (reference :51)
+    Z2 = _randn(rng, N, S, dtype)  # SECOND draw (reference :52)
+    Y = np.empty((N, S), dtype=dtype, order="F")
+    _handle().rand(dtype, _abi.MEM_HOST, layout, D, N, S, X, ldx, noise_kind, s, prior_kind, mw, Lw, ldl, Z1, D, Z2, N,
+                   Y, N)
+    return Y

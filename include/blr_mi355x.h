@@ -1,0 +1,176 @@
+/*
+ * blr_mi355x.h -- C ABI of the MI355X (gfx950) implementation of the posterior / logpdf / marginals /
+ * rand hot path of BayesianLinearRegressors.jl.
+ *
+ * The reference has no FFI boundary: its "operator API" is Julia dispatch on
+ * FiniteGP{<:BayesianLinearRegressor} (reference src/bayesian_linear_regression.jl:33-69).  The entry
+ * points below are what a `ccall` from those methods binds; each one cites the reference lines it
+ * replaces.  INTEGRATION.md shows the Julia side.
+ *
+ * Conventions
+ *   - everything is column-major (Julia native); sizes/strides are int64_t (Julia Int), in ELEMENTS;
+ *   - `_f64` / `_f32` suffix = element type of X, y, s, mw, Lw and of the array outputs;
+ *     the log marginal likelihood is ALWAYS double (reference :84 promotes through log(2pi)::Float64);
+ *   - the caller owns every buffer; no pointer is retained after a call returns;
+ *   - calls are synchronous w.r.t. the handle's stream unless the handle was put in async mode
+ *     (blr_set_async): then DEVICE-memspace calls only enqueue and the caller synchronises;
+ *   - no C++ exception crosses this boundary.
+ *
+ * Return codes (LAPACK `info` semantics)
+ *      0  success
+ *     >0  (single-problem calls) Cholesky broke at leading minor k: the matrix is not positive
+ *         definite -> the Julia shim throws PosDefException(k), as `cholesky` at reference :78/:86 would
+ *     <0  argument -k is invalid (shape/stride/enum/NULL) -> DimensionMismatch / ErrorException
+ *         (the reference's own checks are :74 and :26-31)
+ *  <= -1000  HIP runtime failure: -(1000 + hipError_t); text via blr_last_error()
+ *   Batched calls fill info[B] per regressor (0 / k>0) and return 0 when the launch itself succeeded:
+ *   one non-SPD regressor does not poison the batch.
+ */
+#ifndef BLR_MI355X_H
+#define BLR_MI355X_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define BLR_ABI_VERSION 1
+
+/* layout of X -- mirrors x_as_colvecs, reference :20-31 (index/shape work, bit-exact) */
+#define BLR_LAYOUT_COLVECS 0 /* X is D x N column-major: element (d,n) at X[d + n*ldx], ldx >= D   (:22) */
+#define BLR_LAYOUT_ROWVECS 1 /* X is N x D column-major: element (d,n) at X[n + d*ldx], ldx >= N   (:24) */
+
+/* observation-noise covariance Sigma_y (FiniteGP field, reference :79) */
+#define BLR_NOISE_ISOTROPIC 0 /* s points to ONE variance  (AbstractGPs f(x, sigma^2))  */
+#define BLR_NOISE_DIAGONAL 1  /* s[N] variances            (Diagonal(v))                */
+/* a dense N x N Sigma_y is outside the GPU scope: callers keep their CPU path */
+
+/* prior precision Lambda_w (struct field, reference :11-14; _cholesky at :78) */
+#define BLR_PRIOR_DENSE 0        /* Lw: D x D symmetric, UPPER triangle read (as LAPACK potrf 'U'), ldl >= D */
+#define BLR_PRIOR_UPPER_FACTOR 1 /* Lw: upper factor U with Lambda_w = U'U (PDMat / previous T, :93); strictly-lower part ignored */
+#define BLR_PRIOR_DIAGONAL 2     /* Lw: d[D], Lambda_w = Diagonal(d); ldl ignored */
+
+/* where the pointers of a call live */
+#define BLR_MEM_HOST 0   /* host pointers: the library stages through its own device workspace */
+#define BLR_MEM_DEVICE 1 /* device pointers (hipMalloc / torch / CUDA.jl-style allocator)       */
+
+typedef struct blr_handle blr_handle;
+
+/* ---- lifetime ------------------------------------------------------------------------------- */
+int blr_abi_version(void);
+int blr_device_count(void);                       /* number of visible HIP devices (0 if none)          */
+int blr_create(int device, blr_handle** out);     /* one handle per Julia task / thread                  */
+int blr_destroy(blr_handle* h);
+const char* blr_last_error(blr_handle* h);        /* valid until the next call on h; never NULL         */
+int blr_set_stream(blr_handle* h, void* hip_stream); /* NULL = the handle's own stream                 */
+int blr_set_async(blr_handle* h, int async);      /* 1: DEVICE-memspace calls return after enqueue       */
+int blr_synchronize(blr_handle* h);
+
+/* ---- device memory helpers (so a host language needs no HIP binding of its own) -------------- */
+int blr_device_alloc(blr_handle* h, size_t bytes, void** dptr);
+int blr_device_free(blr_handle* h, void* dptr);
+int blr_memcpy_h2d(blr_handle* h, void* dst_device, const void* src_host, size_t bytes);
+int blr_memcpy_d2h(blr_handle* h, void* dst_host, const void* src_device, size_t bytes);
+
+/* ---- timing helpers: HIP events on the handle's stream (bench.py roofline leg) ---------------- */
+int blr_timer_start(blr_handle* h);
+int blr_timer_stop(blr_handle* h, float* elapsed_ms); /* records, synchronises, returns the interval */
+
+/* ---- fused inference: replaces __compute_inference_quantities + logpdf + posterior ------------
+ * reference src/bayesian_linear_regression.jl:72-89 (shared quantities), :55-58 (logpdf),
+ * :60-69 (posterior), :92-93 (__build_Lambda).  One pass produces everything both need:
+ *   A = Lw + X S X'   T = chol(A).U   mw' = mw + A^-1 X S (y - X'mw)
+ *   logpdf = -1/2 [N log 2pi + logdet Sy + d'Sd + logdet A - logdet Lw - |T^-T b|^2]
+ * Outputs (each may be NULL to skip it):
+ *   mw_post[D]; T_post D x D upper factor (strictly-lower part written as zero), ldt >= D;
+ *   Lw_post D x D full symmetric A, ldlp >= D; logpdf (double).
+ * Batched form: regressor i reads X + i*strideX, y + i*stridey, s + i*strides, mw + i*stridemw,
+ * Lw + i*strideLw and writes the outputs at their strides; a stride of 0 shares an input.
+ */
+int blr_posterior_batched_f64(blr_handle* h, int memspace, int layout, int64_t B, int64_t D, int64_t N,
+                              const double* X, int64_t ldx, int64_t strideX,
+                              const double* y, int64_t stridey,
+                              int noise_kind, const double* s, int64_t strides,
+                              int prior_kind, const double* mw, int64_t stridemw,
+                              const double* Lw, int64_t ldl, int64_t strideLw,
+                              double* mw_post, int64_t stride_mwpost,
+                              double* T_post, int64_t ldt, int64_t strideT,
+                              double* Lw_post, int64_t ldlp, int64_t strideLp,
+                              double* logpdf, int32_t* info);
+int blr_posterior_batched_f32(blr_handle* h, int memspace, int layout, int64_t B, int64_t D, int64_t N,
+                              const float* X, int64_t ldx, int64_t strideX,
+                              const float* y, int64_t stridey,
+                              int noise_kind, const float* s, int64_t strides,
+                              int prior_kind, const float* mw, int64_t stridemw,
+                              const float* Lw, int64_t ldl, int64_t strideLw,
+                              float* mw_post, int64_t stride_mwpost,
+                              float* T_post, int64_t ldt, int64_t strideT,
+                              float* Lw_post, int64_t ldlp, int64_t strideLp,
+                              double* logpdf, int32_t* info);
+
+/* single regressor, host pointers; returns info (see "Return codes") */
+int blr_posterior_f64(blr_handle* h, int layout, int64_t D, int64_t N, const double* X, int64_t ldx,
+                      const double* y, int noise_kind, const double* s,
+                      int prior_kind, const double* mw, const double* Lw, int64_t ldl,
+                      double* mw_post, double* T_post, int64_t ldt, double* Lw_post, int64_t ldlp,
+                      double* logpdf);
+int blr_posterior_f32(blr_handle* h, int layout, int64_t D, int64_t N, const float* X, int64_t ldx,
+                      const float* y, int noise_kind, const float* s,
+                      int prior_kind, const float* mw, const float* Lw, int64_t ldl,
+                      float* mw_post, float* T_post, int64_t ldt, float* Lw_post, int64_t ldlp,
+                      double* logpdf);
+
+/* ---- marginal stream: replaces mean (:33), var (:40-43), mean_and_var (:47) --------------------
+ *   mean_n = x_n' mw          var_n = |Uw^-T x_n|^2 + Sy_nn
+ * mean or var may be NULL (mean-only = evaluating a function sample, sampling_functions.jl:17-19).
+ */
+int blr_marginals_batched_f64(blr_handle* h, int memspace, int layout, int64_t B, int64_t D, int64_t N,
+                              const double* X, int64_t ldx, int64_t strideX,
+                              int noise_kind, const double* s, int64_t strides,
+                              int prior_kind, const double* mw, int64_t stridemw,
+                              const double* Lw, int64_t ldl, int64_t strideLw,
+                              double* mean, int64_t stridemean, double* var, int64_t stridevar,
+                              int32_t* info);
+int blr_marginals_batched_f32(blr_handle* h, int memspace, int layout, int64_t B, int64_t D, int64_t N,
+                              const float* X, int64_t ldx, int64_t strideX,
+                              int noise_kind, const float* s, int64_t strides,
+                              int prior_kind, const float* mw, int64_t stridemw,
+                              const float* Lw, int64_t ldl, int64_t strideLw,
+                              float* mean, int64_t stridemean, float* var, int64_t stridevar,
+                              int32_t* info);
+
+/* ---- draws: replaces rand (:49-53) and the weight draws of sampling_functions.jl:29,35,44 ------
+ * The host keeps drawing the normals so its RNG stream is the reference's:
+ *   Z1 = randn(rng, D, S) FIRST, then Z2 = randn(rng, N, S).
+ *   W = mw .+ Uw \ Z1 ;  Y = X'W .+ sqrt.(s) .* Z2          (Y is N x S, ldy >= N)
+ */
+int blr_rand_f64(blr_handle* h, int memspace, int layout, int64_t D, int64_t N, int64_t S,
+                 const double* X, int64_t ldx, int noise_kind, const double* s,
+                 int prior_kind, const double* mw, const double* Lw, int64_t ldl,
+                 const double* Z1, int64_t ldz1, const double* Z2, int64_t ldz2,
+                 double* Y, int64_t ldy);
+int blr_rand_f32(blr_handle* h, int memspace, int layout, int64_t D, int64_t N, int64_t S,
+                 const float* X, int64_t ldx, int noise_kind, const float* s,
+                 int prior_kind, const float* mw, const float* Lw, int64_t ldl,
+                 const float* Z1, int64_t ldz1, const float* Z2, int64_t ldz2,
+                 float* Y, int64_t ldy);
+/*   W = mw .+ Uw \ Z   (D x S) */
+int blr_sample_weights_f64(blr_handle* h, int memspace, int64_t D, int64_t S,
+                           int prior_kind, const double* mw, const double* Lw, int64_t ldl,
+                           const double* Z, int64_t ldz, double* W, int64_t ldw);
+int blr_sample_weights_f32(blr_handle* h, int memspace, int64_t D, int64_t S,
+                           int prior_kind, const float* mw, const float* Lw, int64_t ldl,
+                           const float* Z, int64_t ldz, float* W, int64_t ldw);
+
+/* ---- sharded log-evidence: fixed-order sum of logpdf[B] on the device ----------
+ * Deterministic (no float atomics): the same bits for the same B regardless of launch geometry.
+ * The cross-rank step is one RCCL all-gather of these per-rank partials done by the host framework
+ * (torch.distributed / MPI.jl); the data path has no other collective. */
+int blr_logpdf_sum(blr_handle* h, int memspace, int64_t B, const double* logpdf, double* total);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* BLR_MI355X_H */

@@ -1,0 +1,126 @@
+"""CPU-side checks: the C-ABI library loads and exports every symbol include/blr_mi355x.h declares,
+the product path fails loudly without a GPU (no fallback), and the host-side index/shape logic
+(the x_as_colvecs mirror, reference src/bayesian_linear_regression.jl:20-31) is exact."""
+import os
+import re
+
+import numpy as np
+import pytest
+
+import blr_amd
+from blr_amd import _abi
+from blr_amd import regressor as R
+
+
+def _declared_functions(repo_root):
+    text = open(os.path.join(repo_root, "include", "blr_mi355x.h")).read()
+    text = re.sub(r"/\*.*?\*/", "", text, flags=re.S)
+    return sorted(set(re.findall(r"\b(blr_[a-z0-9_]+)\s*\(", text)))
+
+
+def test_library_exports_every_declared_symbol(repo_root):
+    lib = _abi.load_library()
+    names = _declared_functions(repo_root)
+    assert len(names) >= 25
+    for n in names:
+        assert hasattr(lib, n), f"{n} declared in include/blr_mi355x.h but not exported"
+    assert set(names) == set(_abi.EXPORTED_SYMBOLS), "ctypes binding and header disagree"
+    assert lib.blr_abi_version() == 1
+    assert lib.blr_last_error(None) == b"null handle"
+
+
+def test_no_cpu_fallback_without_gpu():
+    lib = _abi.load_library()
+    if lib.blr_device_count() > 0:
+        pytest.skip("a GPU is visible")
+    with pytest.raises(_abi.BLRError):
+        _abi.Handle(0)
+    f = blr_amd.BayesianLinearRegressor(np.zeros(2), blr_amd.Diagonal(np.ones(2)))
+    with pytest.raises(_abi.BLRError):
+        blr_amd.logpdf(f(np.zeros((2, 3)), 0.1), np.zeros(3))
+    import subprocess
+    import sys
+
+    # the product package never imports the oracle
+    code = "import sys, blr_amd; assert not any(m.startswith('oracle') for m in sys.modules), 'oracle imported'"
+    subprocess.run([sys.executable, "-c", code], check=True, cwd=os.path.dirname(os.path.dirname(__file__)))
+
+
+def test_missing_library_fails_loudly(monkeypatch, tmp_path):
+    monkeypatch.setattr(_abi, "_lib", None)
+    monkeypatch.setattr(_abi, "LIB_PATH", str(tmp_path / "libblr_mi355x.so"))
+    with pytest.raises(ImportError, match="no CPU fallback"):
+        _abi.load_library()
+
+
+def test_x_layout_is_zero_copy_and_bit_exact():
+    D, N = 3, 5
+    X = np.arange(D * N, dtype=np.float64).reshape(D, N)
+
+    def element(arr, layout, ld, d, n):
+        flat = arr.ravel(order="K")  # memory order
+        return flat[d + n * ld] if layout == _abi.LAYOUT_COLVECS else flat[n + d * ld]
+
+    cases = [
+        (np.asfortranarray(X), _abi.LAYOUT_COLVECS, D),  # raw D x N matrix -> ColVecs (AbstractGPs)
+        (np.ascontiguousarray(X), _abi.LAYOUT_ROWVECS, N),
+        (R.ColVecs(np.asfortranarray(X)), _abi.LAYOUT_COLVECS, D),
+        (R.ColVecs(np.ascontiguousarray(X)), _abi.LAYOUT_ROWVECS, N),
+        (R.RowVecs(np.ascontiguousarray(X.T)), _abi.LAYOUT_COLVECS, D),  # reference :24, lazy adjoint
+        (R.RowVecs(np.asfortranarray(X.T)), _abi.LAYOUT_ROWVECS, N),
+    ]
+    for x, want_layout, want_ld in cases:
+        arr, layout, ld, d_, n_ = R._x_layout(x, np.float64)
+        assert (layout, ld, d_, n_) == (want_layout, want_ld, D, N)
+        src = x.X if hasattr(x, "X") else x
+        assert np.shares_memory(arr, src), "layout normalisation must not copy"
+        for d in range(D):
+            for n in range(N):
+                assert element(arr, layout, ld, d, n) == X[d, n]
+    with pytest.raises(TypeError, match="ColVecs or RowVecs"):  # reference :26-31
+        R._x_layout([np.zeros(3), np.zeros(3)], np.float64)
+    # non-contiguous views are compacted once
+    arr, layout, ld, d_, n_ = R._x_layout(R.ColVecs(np.zeros((6, 10))[::2, ::2]), np.float64)
+    assert (d_, n_) == (3, 5) and (arr.flags.c_contiguous or arr.flags.f_contiguous)
+
+
+def test_noise_and_prior_classification():
+    s, kind = R._noise(0.1, 7, np.float64)
+    assert kind == _abi.NOISE_ISOTROPIC and s.shape == (1,) and s[0] == 0.1
+    s, kind = R._noise(R.Diagonal(np.ones(7)), 7, np.float32)
+    assert kind == _abi.NOISE_DIAGONAL and s.dtype == np.float32
+    with pytest.raises(ValueError):
+        R._noise(np.ones(6), 7, np.float64)
+    with pytest.raises(NotImplementedError):
+        R._noise(np.eye(7), 7, np.float64)
+    A = np.array([[2.0, 1.0], [1.0, 3.0]])
+    for Lw, want in ((A, _abi.PRIOR_DENSE), (R.Symmetric(A), _abi.PRIOR_DENSE), (R.PDMat(np.linalg.cholesky(A).T),
+                                                                                 _abi.PRIOR_UPPER_FACTOR)):
+        arr, kind, ldl = R._prior(Lw, 2, np.float64)
+        assert kind == want and ldl == 2 and arr.flags.f_contiguous
+    arr, kind, ldl = R._prior(R.Diagonal(np.ones(2)), 2, np.float64)
+    assert kind == _abi.PRIOR_DIAGONAL
+    with pytest.raises(ValueError):
+        R._prior(np.eye(3), 2, np.float64)
+    np.testing.assert_allclose(R.PDMat(np.linalg.cholesky(A).T).toarray(), A)
+    np.testing.assert_allclose(R.Symmetric(np.triu(A)).toarray(), A)
+
+
+def test_wrapper_type_closure_and_exports():
+    # reference :92-93 and src/BayesianLinearRegressors.jl:11-12
+    T = np.triu(np.ones((2, 2)))
+    A = T.T @ T
+    assert isinstance(R._wrap_like(R.PDMat(T), T, None), R.PDMat)
+    assert isinstance(R._wrap_like(np.eye(2), T, A), R.Symmetric)
+    assert isinstance(R._wrap_like(R.Diagonal(np.ones(2)), T, A), R.Symmetric)
+    for name in ("logpdf", "rand", "mean", "std", "cov", "BayesianLinearRegressor", "marginals", "posterior",
+                 "BasisFunctionRegressor"):
+        assert hasattr(blr_amd, name)
+    f = blr_amd.BayesianLinearRegressor(np.zeros(2), np.eye(2))
+    fx = f(np.zeros((2, 3)))
+    assert fx.Sy == 1e-18 and fx.f is f  # AbstractGPs default noise
+    bf = blr_amd.BasisFunctionRegressor(f, lambda x: x)
+    assert R._to_finite_blr(bf(np.zeros((2, 3)), 0.5)).f is f
+    Z = R._randn(np.random.default_rng(0), 3, 4, np.float64)
+    assert Z.shape == (3, 4) and Z.flags.f_contiguous
+    np.testing.assert_array_equal(Z.ravel(order="F"), np.random.default_rng(0).standard_normal(12))

@@ -1,0 +1,498 @@
+"""Parity of the HIP path (through the C ABI) against the CPU oracle.  All tests need an MI355X."""
+import numpy as np
+import pytest
+
+from oracle import blr_oracle as O
+
+pytestmark = pytest.mark.gpu
+
+# fp64: the GPU forms A = Lw + X S X' directly; the oracle's literal sequence whitens first.  Both are
+# backward stable; on the well-conditioned toy problems they agree to ~1e-12.  Tolerances are stated per test.
+RTOL64 = 1e-10
+RTOL32 = 2e-4
+
+
+@pytest.fixture(scope="module")
+def B():
+    import blr_amd
+
+    blr_amd._abi.default_handle()  # raises if the extension or the GPU is missing: no silent fallback
+    return blr_amd
+
+
+def _rng(i=0):
+    return np.random.Generator(np.random.PCG64(987654 + i))
+
+
+def _prior_variants(B, Lw):
+    U = O.chol_upper(Lw)
+    return {"dense": Lw, "symmetric": B.Symmetric(Lw), "pdmat": B.PDMat(U)}
+
+
+def _x_variants(B, X):
+    return {
+        "matrix_F": np.asfortranarray(X),
+        "matrix_C": np.ascontiguousarray(X),
+        "colvecs": B.ColVecs(np.asfortranarray(X)),
+        "rowvecs_C": B.RowVecs(np.ascontiguousarray(X.T)),
+        "rowvecs_F": B.RowVecs(np.asfortranarray(X.T)),
+    }
+
+
+def test_readme_example_c1(B):
+    # BASELINE config 1: D=2, N=10, Diagonal prior, heteroscedastic Diagonal noise (reference README.md:44-51)
+    rng = _rng(1)
+    N = 10
+    X = np.vstack([np.linspace(-5.0, 5.0, N), np.ones(N)])
+    s = np.exp(rng.standard_normal(N))
+    f = B.BayesianLinearRegressor(np.zeros(2), B.Diagonal(np.ones(2)))
+    fX = f(B.ColVecs(X), B.Diagonal(s))
+    y = B.rand(rng, fX)
+    assert y.shape == (N,)
+    lp = B.logpdf(fX, y)
+    assert lp == pytest.approx(O.logpdf_literal(np.zeros(2), np.ones(2), X, s, y), rel=1e-12)
+    fp = B.posterior(fX, y)
+    mw_o, T_o, L_o = O.posterior_literal(np.zeros(2), np.ones(2), X, s, y)
+    np.testing.assert_allclose(fp.mw, mw_o, rtol=1e-12)
+    np.testing.assert_allclose(fp.Lw.toarray(), L_o, rtol=1e-12)
+    assert isinstance(fp.Lw, B.Symmetric)
+    # posterior predictive marginals at new inputs (README.md:80-86)
+    Xp = np.vstack([np.linspace(-6.0, 6.0, 1000), np.ones(1000)])
+    eps = np.finfo(float).eps
+    ms = B.marginals(fp(B.ColVecs(Xp), eps))
+    m_o, v_o = O.mean(mw_o, Xp), O.var(mw_o, L_o, Xp, eps)
+    np.testing.assert_allclose([n.mu for n in ms], m_o, rtol=1e-11, atol=1e-13)
+    np.testing.assert_allclose(B.std(ms), np.sqrt(v_o), rtol=1e-11)
+
+
+def test_doctest_golden_vector_on_gpu(B):
+    # reference src/basis_function_regression.jl:11-28
+    x = B.RowVecs(np.linspace(-1.0, 1.0, 5)[:, None])
+    blr = B.BayesianLinearRegressor(np.zeros(2), B.Diagonal(np.ones(2)))
+    phi = lambda x: B.RowVecs(np.column_stack([np.ones(len(x)), np.prod(x.X, axis=1)]))
+    bfr = B.BasisFunctionRegressor(blr, phi)
+    np.testing.assert_allclose(B.var(bfr(x)), [2.0, 1.25, 1.0, 1.25, 2.0], rtol=0, atol=1e-15)
+    np.testing.assert_array_equal(B.var(bfr(x)), B.var(blr(phi(x))))  # README.md:120
+
+
+@pytest.mark.parametrize("N,D", [(11, 3), (13, 7), (11, 2), (10, 2), (40, 16), (5, 9), (100, 17), (33, 100), (257, 128)])
+@pytest.mark.parametrize("prior", ["dense", "symmetric", "pdmat", "diagonal"])
+def test_posterior_logpdf_vs_oracle_f64(B, N, D, prior):
+    rng = _rng(N * 1000 + D)
+    X, mw, Lw, s = O.generate_toy_problem(rng, N, D, dense_noise_cov=False)
+    if prior == "diagonal":
+        dvec = np.exp(rng.standard_normal(D))
+        Lw, Lw_arg = np.diag(dvec), B.Diagonal(dvec)
+    else:
+        Lw_arg = _prior_variants(B, Lw)[prior]
+    y = rng.standard_normal(N)
+    mw_o, T_o, L_o = O.posterior_literal(mw, Lw, X, s, y)
+    lp_o = O.logpdf_literal(mw, Lw, X, s, y)
+    f = B.BayesianLinearRegressor(mw, Lw_arg)
+    for name, x in _x_variants(B, X).items():
+        for Sy in (s, B.Diagonal(s)):
+            fx = f(x, Sy)
+            assert B.logpdf(fx, y) == pytest.approx(lp_o, rel=RTOL64), name
+        fp = B.posterior(f(x, s), y)
+        np.testing.assert_allclose(fp.mw, mw_o, rtol=1e-9, atol=1e-11, err_msg=name)
+        if prior == "pdmat":
+            assert isinstance(fp.Lw, B.PDMat)  # reference :93 / test :109
+            np.testing.assert_allclose(fp.Lw.U, T_o, rtol=1e-9, atol=1e-11)
+            assert np.all(np.tril(fp.Lw.U, -1) == 0)
+        else:
+            assert isinstance(fp.Lw, B.Symmetric)  # reference :92 / test :110
+            np.testing.assert_allclose(fp.Lw.toarray(), L_o, rtol=1e-9, atol=1e-11)
+    # isotropic noise
+    lp_iso = B.logpdf(f(X, 0.37), y)
+    assert lp_iso == pytest.approx(O.logpdf_literal(mw, Lw, X, 0.37, y), rel=RTOL64)
+
+
+@pytest.mark.parametrize("N,D", [(13, 7), (64, 32), (300, 128)])
+def test_posterior_logpdf_vs_oracle_f32(B, N, D):
+    rng = _rng(77 + D)
+    X, mw, Lw, s = O.generate_toy_problem(rng, N, D, dense_noise_cov=False, dtype=np.float32)
+    y = rng.standard_normal(N).astype(np.float32)
+    # the oracle runs in fp64 on the fp32-rounded inputs: tolerance is fp32 accumulation error
+    mw_o, T_o, L_o, lp_o = O.posterior_logpdf_direct(mw.astype(float), Lw.astype(float), X.astype(float),
+                                                     s.astype(float), y.astype(float))
+    f = B.BayesianLinearRegressor(mw, Lw)
+    for x in (np.asfortranarray(X), B.RowVecs(np.ascontiguousarray(X.T)), np.ascontiguousarray(X)):
+        fx = f(x, s)
+        lp = B.logpdf(fx, y)
+        assert isinstance(lp, float)
+        assert lp == pytest.approx(lp_o, rel=RTOL32)
+        fp = B.posterior(fx, y)
+        assert fp.mw.dtype == np.float32
+        np.testing.assert_allclose(fp.mw, mw_o, rtol=5e-3, atol=5e-4)
+        np.testing.assert_allclose(fp.Lw.toarray(), L_o, rtol=1e-4, atol=1e-4)
+
+
+def test_c2_shape_fp64(B):
+    # BASELINE config 2: D=128, N=4096 ColVecs, isotropic noise, fp64 -- Gram + Cholesky vs CPU
+    rng = _rng(2)
+    D, N = 128, 4096
+    X = np.asfortranarray(rng.standard_normal((D, N)))
+    w = rng.standard_normal(D)
+    y = X.T @ w + np.sqrt(0.1) * rng.standard_normal(N)
+    mw = rng.standard_normal(D)
+    f = B.BayesianLinearRegressor(mw, B.Diagonal(np.ones(D)))
+    fx = f(B.ColVecs(X), 0.1)
+    lp = B.logpdf(fx, y)
+    fp = B.posterior(fx, y)
+    mw_o, T_o, L_o, lp_o = O.posterior_logpdf_direct(mw, np.ones(D), X, 0.1, y)
+    assert lp == pytest.approx(lp_o, rel=1e-11)
+    np.testing.assert_allclose(fp.mw, mw_o, rtol=1e-9, atol=1e-12)
+    np.testing.assert_allclose(fp.Lw.toarray(), L_o, rtol=1e-11)
+    assert lp == pytest.approx(O.logpdf_literal(mw, np.ones(D), X, 0.1, y), rel=1e-10)
+    # determinism: fixed accumulation order, no float atomics -> bitwise reproducible
+    assert B.logpdf(fx, y) == lp
+    np.testing.assert_array_equal(B.posterior(fx, y).mw, fp.mw)
+
+
+def test_logpdf_naive_identity(B):
+    # reference test/bayesian_linear_regression.jl:22-38, on the GPU path
+    rng = _rng(3)
+    N, D = 13, 7
+    X, mw, Lw, s = O.generate_toy_problem(rng, N, D, dense_noise_cov=False)
+    y = B.rand(rng, B.BayesianLinearRegressor(mw, Lw)(X, s))
+    lp = B.logpdf(B.BayesianLinearRegressor(mw, Lw)(X, s), y)
+    assert lp == pytest.approx(O.logpdf_naive(mw, Lw, X, s, y), rel=1.5e-8)
+    assert lp == pytest.approx(O.logpdf_naive_mp(mw, Lw, X, s, y), rel=1e-11)
+
+
+def test_posterior_low_noise(B):
+    # reference test/bayesian_linear_regression.jl:40-48 (cov -> var: the N x N cov is out of GPU scope)
+    rng = _rng(4)
+    N, D = 13, 7
+    X, mw, Lw, _ = O.generate_toy_problem(rng, N, D)
+    eps = np.finfo(float).eps
+    f = B.BayesianLinearRegressor(mw, Lw)
+    y = B.rand(rng, f(X, eps))
+    fp = B.posterior(f(X, eps), y)
+    np.testing.assert_allclose(B.mean(fp(X, eps)), y, rtol=1.5e-8)
+    assert np.all(B.var(fp(X, eps)) < 1000 * eps)
+    assert np.all(O.cov(fp.mw, fp.Lw.toarray(), X, eps) < 1000 * eps)
+
+
+def test_posterior_repeated_conditioning(B):
+    # reference test/bayesian_linear_regression.jl:49-70 with diagonal noise
+    rng = _rng(5)
+    N, D = 13, 7
+    X, mw, Lw, s = O.generate_toy_problem(rng, N, D, dense_noise_cov=False)
+    Xp = rng.standard_normal((D, N))
+    for Lw_arg in (Lw, B.PDMat(O.chol_upper(Lw))):
+        f = B.BayesianLinearRegressor(mw, Lw_arg)
+        y = B.rand(rng, f(X, s))
+        N1 = N - 3
+        f1 = B.posterior(f(X[:, :N1], s[:N1]), y[:N1])
+        f2 = B.posterior(f1(X[:, N1:], s[N1:]), y[N1:])
+        fo = B.posterior(f(X, s), y)
+        np.testing.assert_allclose(B.mean(fo(Xp, s)), B.mean(f2(Xp, s)), rtol=1.5e-8)
+        np.testing.assert_allclose(B.var(fo(Xp, s)), B.var(f2(Xp, s)), rtol=1.5e-8)
+        # evidence chain rule
+        lp = B.logpdf(f(X[:, :N1], s[:N1]), y[:N1]) + B.logpdf(f1(X[:, N1:], s[N1:]), y[N1:])
+        assert lp == pytest.approx(B.logpdf(f(X, s), y), rel=1e-11)
+
+
+def test_pdmat_symmetric_closure(B):
+    # reference test/bayesian_linear_regression.jl:90-112
+    rng = _rng(6)
+    N, D = 13, 7
+    X, Xp = rng.standard_normal((D, N)), rng.standard_normal((D, N))
+    U = np.triu(rng.standard_normal((D, D)))
+    mw, s = rng.standard_normal(D), np.exp(rng.standard_normal(N))
+    Lw = U.T @ U + np.eye(D)
+    f_pd = B.BayesianLinearRegressor(mw, B.PDMat(O.chol_upper(Lw)))
+    f_sym = B.BayesianLinearRegressor(mw, B.Symmetric(Lw))
+    y = B.rand(rng, f_pd(X, s))
+    p_pd, p_sym = B.posterior(f_pd(X, s), y), B.posterior(f_sym(X, s), y)
+    assert isinstance(p_pd.Lw, B.PDMat) and isinstance(p_sym.Lw, B.Symmetric)
+    np.testing.assert_allclose(B.mean(p_pd(Xp, s)), B.mean(p_sym(Xp, s)), rtol=1.5e-8)
+    np.testing.assert_allclose(B.var(p_pd(Xp, s)), B.var(p_sym(Xp, s)), rtol=1.5e-8)
+
+
+@pytest.mark.parametrize("D,N", [(3, 11), (7, 200), (64, 1000), (128, 130)])
+@pytest.mark.parametrize("dtype", [np.float64, np.float32])
+def test_marginals_vs_oracle(B, D, N, dtype):
+    rng = _rng(8 + D)
+    X, mw, Lw, s = O.generate_toy_problem(rng, N, D, dense_noise_cov=False, dtype=dtype)
+    rt = 1e-10 if dtype == np.float64 else 2e-4
+    m_o = O.mean(mw.astype(float), X.astype(float))
+    v_o = O.var(mw.astype(float), Lw.astype(float), X.astype(float), s.astype(float))
+    for name, Lw_arg in {**_prior_variants(B, Lw)}.items():
+        f = B.BayesianLinearRegressor(mw, Lw_arg)
+        for xname, x in _x_variants(B, X).items():
+            m, v = B.mean_and_var(f(x, s))
+            assert m.dtype == dtype and v.dtype == dtype
+            np.testing.assert_allclose(m, m_o, rtol=rt, atol=rt, err_msg=f"{name}/{xname}")
+            np.testing.assert_allclose(v, v_o, rtol=rt, err_msg=f"{name}/{xname}")
+    dvec = np.exp(rng.standard_normal(D)).astype(dtype)
+    f = B.BayesianLinearRegressor(mw, B.Diagonal(dvec))
+    v = B.var(f(X, dtype(0.5)))
+    np.testing.assert_allclose(v, O.var(mw.astype(float), np.diag(dvec).astype(float), X.astype(float), 0.5), rtol=rt)
+
+
+@pytest.mark.parametrize("D,N,S", [(3, 11, 7), (7, 13, 100), (64, 200, 65), (128, 70, 129)])
+def test_rand_given_normals_vs_oracle(B, D, N, S):
+    # reference :49-53 with Z1 (D x S) drawn FIRST and Z2 (N x S) second, supplied through the ABI
+    from blr_amd import _abi
+
+    rng = _rng(9 + D)
+    X, mw, Lw, s = O.generate_toy_problem(rng, N, D, dense_noise_cov=False)
+    Z1 = np.asfortranarray(rng.standard_normal((D, S)))
+    Z2 = np.asfortranarray(rng.standard_normal((N, S)))
+    Y_o = O.rand(mw, Lw, X, s, Z1, Z2)
+    h = _abi.default_handle()
+    for layout, Xa, ldx in ((_abi.LAYOUT_COLVECS, np.asfortranarray(X), D), (_abi.LAYOUT_ROWVECS, np.ascontiguousarray(X), N)):
+        Y = np.empty((N, S), order="F")
+        h.rand(np.float64, _abi.MEM_HOST, layout, D, N, S, Xa, ldx, _abi.NOISE_DIAGONAL, s, _abi.PRIOR_DENSE, mw,
+               np.asfortranarray(Lw), D, Z1, D, Z2, N, Y, N)
+        np.testing.assert_allclose(Y, Y_o, rtol=1e-10, atol=1e-11)
+    W = np.empty((D, S), order="F")
+    h.sample_weights(np.float64, _abi.MEM_HOST, D, S, _abi.PRIOR_UPPER_FACTOR, mw, np.asfortranarray(O.chol_upper(Lw)), D,
+                     Z1, D, W, D)
+    np.testing.assert_allclose(W, O.sample_weights(mw, Lw, Z1), rtol=1e-10, atol=1e-11)
+
+
+def test_rand_moments_and_rng_order(B):
+    # reference test/bayesian_linear_regression.jl:11-21 (2e5 samples); also checks the draw order Z1 then Z2
+    rng = _rng(10)
+    N, D, S = 11, 3, 200_000
+    X, mw, Lw, s = O.generate_toy_problem(rng, N, D, dense_noise_cov=False)
+    f = B.BayesianLinearRegressor(mw, Lw)
+    r1 = np.random.Generator(np.random.PCG64(42))
+    Y = B.rand(r1, f(X, s), S)
+    assert Y.shape == (N, S)
+    r2 = np.random.Generator(np.random.PCG64(42))
+    Z1 = r2.standard_normal((S, D)).T
+    Z2 = r2.standard_normal((S, N)).T
+    np.testing.assert_allclose(Y, O.rand(mw, Lw, X, s, Z1, Z2), rtol=1e-9, atol=1e-10)
+    m_emp = Y.mean(axis=1)
+    Yc = Y - m_emp[:, None]
+    np.testing.assert_allclose(B.mean(f(X, s)), m_emp, atol=2e-2, rtol=2e-2)
+    np.testing.assert_allclose(O.cov(mw, Lw, X, s), Yc @ Yc.T / S, atol=3e-2, rtol=3e-2)
+
+
+def test_function_samples(B):
+    # reference test/sampling_functions.jl:3-24
+    rng = _rng(11)
+    N, D = 11, 5
+    X, mw, Lw, s = O.generate_toy_problem(rng, N, D, dense_noise_cov=False)
+    f = B.BayesianLinearRegressor(mw, Lw)
+    g = B.rand(rng, f)
+    assert isinstance(g, B.BLRFunctionSample)
+    assert np.array_equal(g(X), g(X))
+    np.testing.assert_allclose(g(X), g(B.ColVecs(X)), rtol=1e-15)
+    np.testing.assert_allclose(g(X), g(B.RowVecs(np.ascontiguousarray(X.T))), rtol=1e-13)
+    np.testing.assert_allclose(g(X), X.T @ g.w, rtol=1e-13)
+    gs = B.rand(rng, f, 20, 30)
+    assert gs.shape == (20, 30) and isinstance(gs[3, 4], B.BLRFunctionSample)
+    S = 40_000
+    gs = B.rand(rng, f, S)
+    W = np.stack([h.w for h in gs], axis=1)
+    np.testing.assert_allclose(W.mean(axis=1), mw, atol=2e-2)
+    np.testing.assert_allclose(np.cov(W), np.linalg.inv(Lw), atol=2e-2)
+    A = np.empty((4, 5), dtype=object)
+    A = B.rand_b(rng, A, f)
+    assert all(isinstance(a, B.BLRFunctionSample) for a in A.ravel())
+    # basis-function version evaluates phi(X)'w
+    phi = lambda x: O.phi_test(x) if not isinstance(x, (B.ColVecs, B.RowVecs)) else type(x)(O.phi_test(
+        O.ColVecs(x.X) if isinstance(x, B.ColVecs) else O.RowVecs(x.X)).X)
+    X2, mw2, Lw2, _ = O.generate_toy_problem(rng, N, 2, dense_noise_cov=False)
+    fb = B.BasisFunctionRegressor(B.BayesianLinearRegressor(mw2, Lw2), phi)
+    gb = B.rand(rng, fb)
+    np.testing.assert_allclose(gb(X2), O.phi_test(X2).T @ gb.w, rtol=1e-13)
+
+
+@pytest.mark.parametrize("container", ["matrix", "colvecs", "rowvecs"])
+def test_bfr_consistency_with_blr(B, container):
+    # reference test/basis_function_regression.jl:13-28
+    rng = _rng(12)
+    N, D = 11, 2
+    X, mw, Lw, s = O.generate_toy_problem(rng, N, D, dense_noise_cov=False)
+    x = {"matrix": X, "colvecs": B.ColVecs(X), "rowvecs": B.RowVecs(np.ascontiguousarray(X.T))}[container]
+
+    def phi(x):
+        if isinstance(x, B.RowVecs):
+            return B.RowVecs(np.column_stack([np.ones(len(x)), np.prod(x.X, axis=1)]))
+        if isinstance(x, B.ColVecs):
+            return B.ColVecs(np.vstack([np.ones(len(x)), np.prod(x.X, axis=0)]))
+        return phi(B.ColVecs(x)).X
+
+    f = B.BayesianLinearRegressor(mw, Lw)
+    f_bf = B.BasisFunctionRegressor(f, phi)
+    y = B.rand(rng, f_bf(x, s))
+    assert B.logpdf(f(phi(x), s), y) == pytest.approx(B.logpdf(f_bf(x, s), y), rel=1e-14)
+    p_bf, p = B.posterior(f_bf(x, s), y), B.posterior(f(phi(x), s), y)
+    assert isinstance(p_bf, B.BasisFunctionRegressor)
+    np.testing.assert_allclose(B.mean(p_bf(x)), B.mean(p(phi(x))), rtol=1e-14)
+
+
+def test_logpdf_matrix_columns(B):
+    # AbstractGPs secondary API exercised by TestUtils (reference test :7-9): logpdf(fx, Y::Matrix)
+    rng = _rng(13)
+    N, D, S = 13, 7, 5
+    X, mw, Lw, s = O.generate_toy_problem(rng, N, D, dense_noise_cov=False)
+    f = B.BayesianLinearRegressor(mw, Lw)
+    Y = B.rand(rng, f(X, s), S)
+    lps = B.logpdf(f(X, s), Y)
+    assert lps.shape == (S,)
+    for j in range(S):
+        assert lps[j] == pytest.approx(B.logpdf(f(X, s), Y[:, j]), rel=1e-14)
+
+
+def test_error_paths(B):
+    rng = _rng(14)
+    N, D = 11, 5
+    X, mw, Lw, s = O.generate_toy_problem(rng, N, D, dense_noise_cov=False)
+    f = B.BayesianLinearRegressor(mw, Lw)
+    # reference test :116-122: a vector of vectors is neither ColVecs nor RowVecs
+    with pytest.raises(TypeError):
+        B.rand(rng, f([row for row in X.T], s))
+    with pytest.raises(ValueError):  # reference :74
+        B.logpdf(f(X, s), np.zeros(N - 1))
+    # PosDefException from the prior (:78) and from the posterior precision (:86)
+    with pytest.raises(B.PosDefException) as ei:
+        B.logpdf(B.BayesianLinearRegressor(mw, -Lw)(X, s), np.zeros(N))
+    assert ei.value.info == 1
+    bad = Lw.copy()
+    bad[3, 3] = -50.0
+    with pytest.raises(np.linalg.LinAlgError) as ei:
+        B.posterior(B.BayesianLinearRegressor(mw, bad)(X, s), np.zeros(N))
+    assert ei.value.info == 4
+    with pytest.raises(B.PosDefException):
+        B.var(B.BayesianLinearRegressor(mw, -Lw)(X, s))
+    with pytest.raises(NotImplementedError):  # dense Sigma_y is rejected, not silently computed elsewhere
+        B.logpdf(f(X, np.eye(N)), np.zeros(N))
+    with pytest.raises(NotImplementedError):
+        B.cov(f(X, s))
+
+
+def test_abi_argument_errors(B):
+    from blr_amd import _abi
+
+    h = _abi.default_handle()
+    D, N = 4, 8
+    X = np.zeros((D, N), order="F")
+    v = np.zeros(N)
+    lp = np.zeros(1)
+    with pytest.raises(_abi.BLRError) as ei:  # ldx < D -> argument 6 of the single-problem form
+        h.posterior(np.float64, _abi.LAYOUT_COLVECS, D, N, X, D - 1, v, _abi.NOISE_DIAGONAL, v, _abi.PRIOR_DIAGONAL,
+                    np.zeros(D), np.ones(D), 1, None, None, D, None, D, lp)
+    assert ei.value.code == -6
+    with pytest.raises(_abi.BLRError) as ei:  # unknown layout (reference :26-31)
+        h.posterior(np.float64, 7, D, N, X, D, v, _abi.NOISE_DIAGONAL, v, _abi.PRIOR_DIAGONAL, np.zeros(D), np.ones(D), 1,
+                    None, None, D, None, D, lp)
+    assert ei.value.code == -2
+    with pytest.raises(_abi.BLRError) as ei:  # D beyond this build
+        h.posterior(np.float64, _abi.LAYOUT_COLVECS, 100000, N, X, 100000, v, _abi.NOISE_DIAGONAL, v, _abi.PRIOR_DIAGONAL,
+                    np.zeros(D), np.ones(D), 1, None, None, D, None, D, lp)
+    assert ei.value.code == -3
+
+
+@pytest.mark.parametrize("dtype", [np.float64, np.float32])
+def test_batched_device_path_c4_shape(B, dtype):
+    # BASELINE config 4 shape (D=64, N=1024), a 96-regressor slice, device-resident, one launch
+    import torch
+
+    from blr_amd import _abi
+
+    rng = _rng(15)
+    Bn, D, N = 96, 64, 1024
+    X = rng.standard_normal((Bn, N, D)).astype(dtype)  # each [N, D] C-order == D x N column-major
+    w = rng.standard_normal((Bn, D))
+    s = np.exp(0.3 * rng.standard_normal((Bn, N))).astype(dtype)
+    y = (np.einsum("bnd,bd->bn", X, w) + np.sqrt(s) * rng.standard_normal((Bn, N))).astype(dtype)
+    mw = rng.standard_normal((Bn, D)).astype(dtype)
+    dprior = np.exp(0.2 * rng.standard_normal((Bn, D))).astype(dtype)
+    bad = 17
+    dprior[bad, 5] = -1.0  # one non-SPD regressor must not poison the batch
+    tdt = torch.float64 if dtype == np.float64 else torch.float32
+    dev = torch.device("cuda:0")
+    tX, ty, ts, tmw, td = (torch.from_numpy(a).to(dev) for a in (X, y, s, mw, dprior))
+    t_mwp = torch.empty((Bn, D), dtype=tdt, device=dev)
+    t_T = torch.empty((Bn, D, D), dtype=tdt, device=dev)
+    t_A = torch.empty((Bn, D, D), dtype=tdt, device=dev)
+    t_lp = torch.empty(Bn, dtype=torch.float64, device=dev)
+    t_info = torch.full((Bn,), -7, dtype=torch.int32, device=dev)
+    h = _abi.default_handle()
+    h.posterior_batched(dtype, _abi.MEM_DEVICE, _abi.LAYOUT_COLVECS, Bn, D, N, tX.data_ptr(), D, N * D, ty.data_ptr(), N,
+                        _abi.NOISE_DIAGONAL, ts.data_ptr(), N, _abi.PRIOR_DIAGONAL, tmw.data_ptr(), D, td.data_ptr(), 1, D,
+                        t_mwp.data_ptr(), D, t_T.data_ptr(), D, D * D, t_A.data_ptr(), D, D * D, t_lp.data_ptr(),
+                        t_info.data_ptr())
+    info = t_info.cpu().numpy()
+    assert info[bad] == 6 and np.all(np.delete(info, bad) == 0)
+    lp = t_lp.cpu().numpy()
+    assert np.isnan(lp[bad])
+    mwp, Tm, Am = t_mwp.cpu().numpy(), t_T.cpu().numpy(), t_A.cpu().numpy()
+    rt_lp, rt = (1e-11, 1e-9) if dtype == np.float64 else (2e-4, 5e-3)
+    for b in list(range(0, Bn, 7)) + [Bn - 1]:
+        if b == bad:
+            continue
+        Xb = X[b].T.astype(float)
+        mw_o, T_o, A_o, lp_o = O.posterior_logpdf_direct(mw[b].astype(float), dprior[b].astype(float), Xb,
+                                                         s[b].astype(float), y[b].astype(float))
+        assert lp[b] == pytest.approx(lp_o, rel=rt_lp)
+        np.testing.assert_allclose(mwp[b], mw_o, rtol=rt, atol=rt * 1e-2)
+        np.testing.assert_allclose(Tm[b].T, T_o, rtol=rt, atol=rt)  # [D, D] C-order holds the column-major T
+        np.testing.assert_allclose(Am[b].T, A_o, rtol=rt, atol=rt)
+    # fixed-order log-evidence sum on the device
+    good = np.delete(np.arange(Bn), bad)
+    t_good = t_lp[torch.from_numpy(good).to(dev)].contiguous()
+    t_tot = torch.zeros(1, dtype=torch.float64, device=dev)
+    h.logpdf_sum(_abi.MEM_DEVICE, len(good), t_good.data_ptr(), t_tot.data_ptr())
+    tot = float(t_tot.cpu()[0])
+    assert tot == pytest.approx(float(np.sum(lp[good])), rel=1e-13)
+    h.logpdf_sum(_abi.MEM_DEVICE, len(good), t_good.data_ptr(), t_tot.data_ptr())
+    assert float(t_tot.cpu()[0]) == tot  # bitwise reproducible
+
+
+def test_full_size_properties_c2_batch(B):
+    # BASELINE full size (D=128, N=4096, fp64), 32 regressors: size-independent properties --
+    # (1) evidence chain rule over a split of the columns, carrying the factor T forward (reference :93);
+    # (2) T'T == A;  (3) A mw' == Lw mw + X S y  (normal equations).
+    import torch
+
+    from blr_amd import _abi
+
+    rng = _rng(16)
+    Bn, D, N, N1 = 32, 128, 4096, 3000
+    dev = torch.device("cuda:0")
+    g = torch.Generator(device="cpu").manual_seed(1234)
+    X = torch.randn((Bn, N, D), generator=g, dtype=torch.float64)
+    w = torch.randn((Bn, D), generator=g, dtype=torch.float64)
+    y = torch.einsum("bnd,bd->bn", X, w) + 0.3 * torch.randn((Bn, N), generator=g, dtype=torch.float64)
+    mw = torch.randn((Bn, D), generator=g, dtype=torch.float64)
+    s2 = torch.tensor([0.09], dtype=torch.float64)
+    ones = torch.ones((Bn, D), dtype=torch.float64)
+    tX, ty, tmw, ts, td = (a.to(dev) for a in (X, y, mw, s2, ones))
+    h = _abi.default_handle()
+
+    def run(n0, n1, prior_kind, t_prior_mw, t_prior, ldl, strideL):
+        t_mwp = torch.empty((Bn, D), dtype=torch.float64, device=dev)
+        t_T = torch.empty((Bn, D, D), dtype=torch.float64, device=dev)
+        t_A = torch.empty((Bn, D, D), dtype=torch.float64, device=dev)
+        t_lp = torch.empty(Bn, dtype=torch.float64, device=dev)
+        t_info = torch.empty(Bn, dtype=torch.int32, device=dev)
+        h.posterior_batched(np.float64, _abi.MEM_DEVICE, _abi.LAYOUT_COLVECS, Bn, D, n1 - n0,
+                            tX.data_ptr() + n0 * D * 8, D, N * D, ty.data_ptr() + n0 * 8, N, _abi.NOISE_ISOTROPIC,
+                            ts.data_ptr(), 0, prior_kind, t_prior_mw.data_ptr(), D, t_prior.data_ptr(), ldl, strideL,
+                            t_mwp.data_ptr(), D, t_T.data_ptr(), D, D * D, t_A.data_ptr(), D, D * D, t_lp.data_ptr(),
+                            t_info.data_ptr())
+        assert int(t_info.abs().sum()) == 0
+        return t_mwp, t_T, t_A, t_lp
+
+    m_all, T_all, A_all, lp_all = run(0, N, _abi.PRIOR_DIAGONAL, tmw, td, 1, D)
+    m1, T1, A1, lp1 = run(0, N1, _abi.PRIOR_DIAGONAL, tmw, td, 1, D)
+    m2, T2, A2, lp2 = run(N1, N, _abi.PRIOR_UPPER_FACTOR, m1, T1, D, D * D)
+    torch.testing.assert_close(lp1 + lp2, lp_all, rtol=1e-11, atol=0)
+    torch.testing.assert_close(m2, m_all, rtol=1e-9, atol=1e-11)
+    torch.testing.assert_close(A2, A_all, rtol=1e-11, atol=1e-9)
+    Tm = T_all.transpose(1, 2)  # [b] C-order holds column-major T -> transpose gives T as a matrix
+    torch.testing.assert_close(Tm.transpose(1, 2) @ Tm, A_all.transpose(1, 2), rtol=1e-11, atol=1e-9)
+    Xm = tX.transpose(1, 2)  # D x N
+    rhs = tmw + torch.einsum("bdn,bn->bd", Xm, ty) / 0.09
+    lhs = torch.einsum("bij,bj->bi", A_all, m_all)  # A symmetric
+    torch.testing.assert_close(lhs, rhs, rtol=1e-9, atol=1e-7)
+    A_ref = torch.eye(D, dtype=torch.float64, device=dev)[None] + torch.einsum("bdn,ben->bde", Xm, Xm) / 0.09
+    torch.testing.assert_close(A_all, A_ref, rtol=1e-11, atol=1e-9)
