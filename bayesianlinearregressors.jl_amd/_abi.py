@@ -47,6 +47,7 @@ _SIGS = {
     "blr_destroy": ([_H], _int),
     "blr_last_error": ([_H], C.c_char_p),
     "blr_set_stream": ([_H, _vp], _int),
+    "blr_reset_stream": ([_H], _int),
     "blr_set_async": ([_H, _int], _int),
     "blr_synchronize": ([_H], _int),
     "blr_device_alloc": ([_H, C.c_size_t, C.POINTER(_vp)], _int),
@@ -145,7 +146,11 @@ class Handle:
         return rc
 
     def set_stream(self, stream_ptr):
+        """Run on the caller's hipStream_t (0 / None = the HIP null stream, torch's default stream)."""
         self.check(self.lib.blr_set_stream(self._h, _vp(int(stream_ptr)) if stream_ptr else None))
+
+    def reset_stream(self):
+        self.check(self.lib.blr_reset_stream(self._h))
 
     def set_async(self, flag):
         self.check(self.lib.blr_set_async(self._h, int(bool(flag))))

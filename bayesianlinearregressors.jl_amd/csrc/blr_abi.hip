@@ -538,7 +538,12 @@ const char* blr_last_error(blr_handle* h) { return h ? h->err.c_str() : "null ha
 
 int blr_set_stream(blr_handle* h, void* hip_stream) {
   if (!h) return -1;
-  h->stream = hip_stream ? static_cast<hipStream_t>(hip_stream) : h->own_stream;
+  h->stream = static_cast<hipStream_t>(hip_stream);
+  return 0;
+}
+int blr_reset_stream(blr_handle* h) {
+  if (!h) return -1;
+  h->stream = h->own_stream;
   return 0;
 }
 int blr_set_async(blr_handle* h, int async) {

@@ -203,7 +203,7 @@ __device__ __forceinline__ void compute_stage(const T* __restrict__ slot, const 
 
 // ---- in-LDS Cholesky on the packed lower triangle (row i at i(i+1)/2) ----------------------------
 // Right-looking with deferred column scaling: one barrier per column.  On exit P holds L (A = L L'),
-// dinv[j] = 1 / L[j][j].  Returns 0 or the LAPACK-style index (1-based) of the failing leading minor.
+// dinv[j] = L[j][j].  Returns 0 or the LAPACK-style index (1-based) of the failing leading minor.
 template <typename T>
 __device__ __forceinline__ int chol_packed(T* __restrict__ P, T* __restrict__ dinv, int D, int tid) {
   const int ti = tid >> 4, tk = tid & 15;
@@ -212,22 +212,21 @@ __device__ __forceinline__ int chol_packed(T* __restrict__ P, T* __restrict__ di
   for (int j = 0; j < D; ++j) {
     const T ajj = P[pidx(j, j)];
     if (!(ajj > T(0))) { info = j + 1; break; }  // wave- and block-uniform: everyone reads the same word
-    const T inv = T(1) / ajj;
     for (int i = j + 1 + ti; i < D; i += 16) {
-      const T ci = P[pidx(i, j)] * inv;
+      const T ci = P[pidx(i, j)] / ajj;
       T* row = P + pidx(i, 0);
       for (int k = j + 1 + tk; k <= i; k += 16) row[k] -= ci * P[pidx(k, j)];
     }
     __syncthreads();
   }
   if (info) return info;
-  if (tid < D) dinv[tid] = T(1) / sqrt(P[pidx(tid, tid)]);
+  if (tid < D) dinv[tid] = sqrt(P[pidx(tid, tid)]);  // dinv holds the DIAGONAL of L (true divisions below)
   __syncthreads();
   for (int i = ti; i < D; i += 16) {
     T* row = P + pidx(i, 0);
-    for (int k = tk; k < i; k += 16) row[k] *= dinv[k];
+    for (int k = tk; k < i; k += 16) row[k] /= dinv[k];
   }
-  if (tid < D) P[pidx(tid, tid)] = sqrt(P[pidx(tid, tid)]);
+  if (tid < D) P[pidx(tid, tid)] = dinv[tid];
   __syncthreads();
   return 0;
 }
@@ -433,7 +432,7 @@ __global__ __launch_bounds__(kThreads, 2) void fused_small_kernel(PosteriorArgs<
       // forward: u = L^-1 b                                     (:57  Lam.U' \ (Bt'dy))
       for (int k = 0; k < D; ++k) {
         T src = (k < 64) ? b0 : b1;
-        T uk = readlane(src, k & 63) * dinv[k];
+        T uk = readlane(src, k & 63) / dinv[k];
         if (lane == (k & 63)) { if (k < 64) b0 = uk; else b1 = uk; }
         if (i0 > k && i0 < D) b0 -= P[pidx(i0, k)] * uk;
         if (i1 > k && i1 < D) b1 -= P[pidx(i1, k)] * uk;
@@ -443,7 +442,7 @@ __global__ __launch_bounds__(kThreads, 2) void fused_small_kernel(PosteriorArgs<
       // backward: m = L^-T u                                    (:64, :68)
       for (int k = D - 1; k >= 0; --k) {
         T src = (k < 64) ? b0 : b1;
-        T mk = readlane(src, k & 63) * dinv[k];
+        T mk = readlane(src, k & 63) / dinv[k];
         if (lane == (k & 63)) { if (k < 64) b0 = mk; else b1 = mk; }
         const T* row = P + pidx(k, 0);
         if (i0 < k) b0 -= row[i0] * mk;

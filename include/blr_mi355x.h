@@ -64,7 +64,8 @@ int blr_device_count(void);                       /* number of visible HIP devic
 int blr_create(int device, blr_handle** out);     /* one handle per Julia task / thread                  */
 int blr_destroy(blr_handle* h);
 const char* blr_last_error(blr_handle* h);        /* valid until the next call on h; never NULL         */
-int blr_set_stream(blr_handle* h, void* hip_stream); /* NULL = the handle's own stream                 */
+int blr_set_stream(blr_handle* h, void* hip_stream); /* run on the caller's hipStream_t; NULL = the HIP null stream */
+int blr_reset_stream(blr_handle* h);              /* back to the handle's own (non-blocking) stream      */
 int blr_set_async(blr_handle* h, int async);      /* 1: DEVICE-memspace calls return after enqueue       */
 int blr_synchronize(blr_handle* h);
 

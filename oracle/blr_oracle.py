@@ -166,18 +166,41 @@ def sample_weights(mw, Lw, Z):
 # --------------------------------------------------------------------------------------------
 # the hot loop, literally: bayesian_linear_regression.jl:72-89
 # --------------------------------------------------------------------------------------------
+class _NoiseChol:
+    """_cholesky(fx.Sy) (:79).  Julia dispatches on the matrix type: a Diagonal (or Diagonal{Fill}) noise
+    covariance factorises in O(N) and `Sy.U' \\ M` is a row scaling; a dense Sy goes through potrf/trtrs."""
+
+    def __init__(self, Sy, N, dt):
+        Sy = np.asarray(Sy, dtype=dt)
+        if Sy.ndim == 2:
+            self.U, self.d = chol_upper(Sy), None
+        else:
+            d = np.full(N, Sy, dtype=dt) if Sy.ndim == 0 else Sy
+            if np.any(d <= 0):
+                raise np.linalg.LinAlgError("noise covariance is not positive definite")
+            self.U, self.d = None, np.sqrt(d)
+
+    def solve_Ut(self, M):  # Sy.U' \ M
+        if self.U is not None:
+            return _solve_tri(self.U, M, trans=True)
+        return M / (self.d[:, None] if M.ndim == 2 else self.d)
+
+    def logdet(self):
+        diag = np.diag(self.U) if self.U is not None else self.d
+        return 2.0 * float(np.sum(np.log(diag.astype(np.float64))))
+
+
 def compute_inference_quantities(mw, Lw, X, Sy, y):
     D, N = X.shape
     if y.shape[0] != N:  # :74
         raise ValueError("length(y) != size(fx.x.X, 2)")
     dt = X.dtype
     Uw = chol_upper(dense_precision(Lw, D, dt))  # :78
-    Us = chol_upper(dense_noise(Sy, N, dt))  # :79
-    Bt = _solve_tri(Us, _solve_tri(Uw, X, trans=True).T, trans=True)  # :81  N x D
-    dy = _solve_tri(Us, y - mean(mw, X), trans=True)  # :82
-    logdet_Sy = 2.0 * np.sum(np.log(np.diag(Us)))
+    Sc = _NoiseChol(Sy, N, dt)  # :79
+    Bt = Sc.solve_Ut(np.ascontiguousarray(_solve_tri(Uw, X, trans=True).T))  # :81  N x D (the ' materialises)
+    dy = Sc.solve_Ut(y - mean(mw, X))  # :82
     # :84 -- log(2pi) is a Float64 in Julia, so the scalar is promoted to double for f32 inputs
-    logpdf_dy = -(N * LOG2PI + float(logdet_Sy) + float(np.sum(dy * dy))) / 2
+    logpdf_dy = -(N * LOG2PI + Sc.logdet() + float(np.sum(dy * dy))) / 2
     Lam = chol_upper(Bt.T @ Bt + np.eye(D, dtype=dt))  # :86  (this is .U of the Cholesky object)
     return Uw, Bt, dy, logpdf_dy, Lam
 
