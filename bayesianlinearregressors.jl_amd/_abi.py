@@ -13,7 +13,7 @@ import threading
 import numpy as np
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "csrc", "libblr_mi355x.so")
+LIB_PATH = os.environ.get("BLR_MI355X_LIB") or os.path.join(_HERE, "csrc", "libblr_mi355x.so")
 
 LAYOUT_COLVECS, LAYOUT_ROWVECS = 0, 1
 NOISE_ISOTROPIC, NOISE_DIAGONAL = 0, 1
@@ -88,6 +88,15 @@ def load_library():
                     f"{LIB_PATH} is missing: the HIP extension has not been built. "
                     "Run `python -c 'import __graft_entry__ as g; g.build()'`. There is no CPU fallback."
                 )
+            if os.environ.get("BLR_MI355X_NO_TORCH_PRELOAD") != "1":
+                # PyTorch wheels bundle their own libamdhip64/libhsa-runtime64.  Two HIP runtimes in one
+                # process do not share the device ("No HIP GPUs are available" from whichever initialises
+                # second), so when torch is installed let it load its runtime FIRST; our library then binds
+                # to the already-loaded libamdhip64.so.  Without torch the system ROCm runtime is used.
+                try:
+                    import torch  # noqa: F401
+                except Exception:
+                    pass
             lib = C.CDLL(LIB_PATH)
             for name, (argtypes, restype) in _SIGS.items():
                 fn = getattr(lib, name)  # AttributeError if the library does not export a declared symbol

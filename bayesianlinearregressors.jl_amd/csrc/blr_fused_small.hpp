@@ -231,6 +231,117 @@ __device__ __forceinline__ int chol_packed(T* __restrict__ P, T* __restrict__ di
   return 0;
 }
 
+// ---- blocked Cholesky with the trailing matrix in MFMA accumulators -------------------------------
+// On entry the lower 16x16 tiles of A live in `acc` (tile t = wave + 4 i at acc[i], MFMA C layout).
+// For each block column J:
+//   (a) the owners of tiles (I, J) store them into the packed LDS triangle P (row i at i(i+1)/2);
+//   (b) every wave loads panel rows, ONE ROW PER LANE (lanes 0-15: the 16 diagonal-block rows, held
+//       redundantly by all four waves so no cross-wave traffic is needed; lanes 16-63: 48 rows below),
+//       and eliminates the 16 columns in registers -- pivots and multipliers travel by v_readlane;
+//       the right-hand side b rides along (forward substitution u = L^-1 b for free);
+//   (c) the finished panel goes back to P and all waves apply  A_IK -= L_IJ L_KJ'  to their
+//       remaining tiles with 4 MFMAs per tile, reading both operands from P in fragment order.
+// Three barriers per block column instead of one (or two) per scalar column, and no LDS round trip
+// for the trailing matrix.  On exit P holds L (A = L L'), bvec holds u.  Returns LAPACK-style info.
+template <typename T, int NB>
+__device__ __forceinline__ int chol_blocked(AccArr<T, NB>& acc, T* __restrict__ P, T* __restrict__ bvec, int D,
+                                            int wave, int lane, bool with_rhs) {
+  using C = SmallCfg<T, NB>;
+  const int nblk = (D + 15) >> 4;
+  int info = 0;
+  for (int J = 0; J < nblk; ++J) {
+    __syncthreads();
+    // (a) panel tiles -> packed LDS
+#pragma unroll
+    for (int i = 0; i < C::TPW; ++i) {
+      const int t = wave + kWaves * i;
+      if (t < C::NT) {
+        int I = 0;
+        while ((I + 1) * (I + 2) / 2 <= t) ++I;
+        const int K = t - I * (I + 1) / 2;
+        if (K == J) {
+          const int col = 16 * J + (lane & 15);
+#pragma unroll
+          for (int v = 0; v < 4; ++v) {
+            const int row = 16 * I + Mfma<T>::crow(lane, v);
+            if (col <= row) P[pidx(row, col)] = acc[i][v];
+          }
+        }
+      }
+    }
+    __syncthreads();
+    // (b) one row per lane
+    const bool is_diag = lane < 16;
+    const int ri = is_diag ? 16 * J + lane : 16 * (J + 1) + 48 * wave + (lane - 16);
+    const bool active = ri < D;
+    const int ncols = min(16, D - 16 * J);
+    T arow[16];
+    T bl = T(0);
+    {
+      const T* src = P + pidx(active ? ri : 0, 16 * J);
+#pragma unroll
+      for (int c = 0; c < 16; ++c) {
+        const bool ok = active && (!is_diag || c <= lane);
+        arow[c] = ok ? src[c] : T(0);
+      }
+      if (with_rhs && active) bl = bvec[ri];
+    }
+#pragma unroll
+    for (int c = 0; c < 16; ++c) {
+      if (c < ncols) {
+        const T d2 = readlane(arow[c], c);
+        if (!(d2 > T(0))) {  // wave-uniform (SGPR) and identical in all four waves
+          if (info == 0) info = 16 * J + c + 1;
+        }
+        const T d = sqrt(d2);
+        const T rinv = T(1) / d;
+        const T piv_b = readlane(bl, c);
+        const T uc = piv_b * rinv;
+        const T lc = arow[c] * rinv;  // column c of L for this lane's row
+        arow[c] = (lane == c) ? d : lc;
+        if (lane == c) bl = uc;
+        else if (lane > c) bl -= lc * uc;
+#pragma unroll
+        for (int k = c + 1; k < 16; ++k) {
+          const T lk = readlane(arow[c], k);  // L[16J + k][16J + c]
+          arow[k] -= arow[c] * lk;
+        }
+      }
+    }
+    if (info != 0) break;  // uniform across the block: every wave factors the same diagonal rows
+    if (active) {
+      T* dst = P + pidx(ri, 16 * J);
+#pragma unroll
+      for (int c = 0; c < 16; ++c)
+        if (!is_diag || c <= lane) dst[c] = arow[c];
+      if (with_rhs && (!is_diag || wave == 0)) bvec[ri] = bl;
+    }
+    __syncthreads();
+    // (c) trailing update from the finished panel
+    const int r = lane & 15, q = lane >> 4;
+#pragma unroll
+    for (int i = 0; i < C::TPW; ++i) {
+      const int t = wave + kWaves * i;
+      if (t < C::NT) {
+        int I = 0;
+        while ((I + 1) * (I + 2) / 2 <= t) ++I;
+        const int K = t - I * (I + 1) / 2;
+        if (K > J && I < nblk) {
+          const int rowI = 16 * I + r, rowK = 16 * K + r;
+#pragma unroll
+          for (int ks = 0; ks < 4; ++ks) {
+            const T fI = P[pidx(rowI, 16 * J + 4 * ks + q)];
+            const T fK = P[pidx(rowK, 16 * J + 4 * ks + q)];
+            acc[i] = Mfma<T>::mma(-fI, fK, acc[i]);
+          }
+        }
+      }
+    }
+  }
+  __syncthreads();
+  return info;
+}
+
 // ---- the kernel -----------------------------------------------------------------------------------
 template <typename T, int NB, int MODE /* data loader: 0 ColVecs generic, 1 RowVecs, 3 ColVecs vector */>
 __global__ __launch_bounds__(kThreads, 2) void fused_small_kernel(PosteriorArgs<T> a) {
@@ -261,15 +372,35 @@ __global__ __launch_bounds__(kThreads, 2) void fused_small_kernel(PosteriorArgs<
     const T* Lw = a.Lw + (int64_t)reg * a.strideLw;
     int info = 0;
     double logdet_Lw = 0.0;
+    acc4 acc[C::TPW];
+
+    // Loads the lower tiles of the dense prior precision (UPPER triangle of the caller's matrix is read,
+    // as LAPACK 'U' does) into the accumulators; diagonal tiles get both halves so they stay symmetric.
+    auto load_dense_prior = [&]() {
+#pragma unroll
+      for (int i = 0; i < C::TPW; ++i) {
+        const int t = wave + kWaves * i;
+        int I = 0;
+        while ((I + 1) * (I + 2) / 2 <= t) ++I;
+        const int K = t - I * (I + 1) / 2;
+        const int col = 16 * K + (lane & 15);
+#pragma unroll
+        for (int v = 0; v < 4; ++v) {
+          const int row = 16 * I + Mfma<T>::crow(lane, v);
+          T val = T(0);
+          if (t < C::NT && row < D && col < D) {
+            const int lo = min(row, col), hi = max(row, col);
+            val = Lw[(int64_t)hi * a.ldl + lo];  // upper entry (lo, hi)
+          }
+          acc[i][v] = val;
+        }
+      }
+    };
 
     // ---- phase 0: prior -----------------------------------------------------------------------
     if (a.prior_kind == PRIOR_DENSE) {
-      __syncthreads();
-      for (int idx = tid; idx < D * D; idx += kThreads) {  // upper triangle (k <= i) of column i
-        int i = idx / D, k = idx % D;
-        if (k <= i) P[pidx(i, k)] = Lw[(int64_t)i * a.ldl + k];
-      }
-      info = chol_packed(P, dinv, D, tid);  // :78
+      load_dense_prior();
+      info = chol_blocked<T, NB>(acc, P, bvec, D, wave, lane, false);  // :78
       double v = (info == 0 && tid < D) ? log((double)P[pidx(tid, tid)]) : 0.0;
       logdet_Lw = 2.0 * block_allreduce(v, scr, tid);
     } else {
@@ -294,12 +425,24 @@ __global__ __launch_bounds__(kThreads, 2) void fused_small_kernel(PosteriorArgs<
       continue;
     }
 
-    // ---- phase 1: streaming Gram ----------------------------------------------------------------
-    acc4 acc[C::TPW];
+    // ---- phase 1: streaming Gram, accumulators start from the prior precision ----------------------
+    if (a.prior_kind == PRIOR_DENSE) {
+      load_dense_prior();
+    } else {
 #pragma unroll
-    for (int i = 0; i < C::TPW; ++i)
+      for (int i = 0; i < C::TPW; ++i) {
+        const int t = wave + kWaves * i;
+        int I = 0;
+        while ((I + 1) * (I + 2) / 2 <= t) ++I;
+        const int K = t - I * (I + 1) / 2;
+        const int col = 16 * K + (lane & 15);
 #pragma unroll
-      for (int v = 0; v < 4; ++v) acc[i][v] = T(0);
+        for (int v = 0; v < 4; ++v) {
+          const int row = 16 * I + Mfma<T>::crow(lane, v);
+          acc[i][v] = (a.prior_kind == PRIOR_DIAGONAL && t < C::NT && row == col && row < D) ? Lw[row] : T(0);
+        }
+      }
+    }
     double bacc[NB];
 #pragma unroll
     for (int I = 0; I < NB; ++I) bacc[I] = 0.0;
@@ -357,7 +500,7 @@ __global__ __launch_bounds__(kThreads, 2) void fused_small_kernel(PosteriorArgs<
       }
     }
 
-    // ---- phase 2: b, A -> LDS ---------------------------------------------------------------------
+    // ---- phase 2: b -> LDS, A (registers) -> blocked Cholesky -----------------------------------------
     __syncthreads();
     {
       const int q = lane >> 4, r = lane & 15;
@@ -376,38 +519,29 @@ __global__ __launch_bounds__(kThreads, 2) void fused_small_kernel(PosteriorArgs<
     if (!diag_noise) logdet_Sy = (double)N * log((double)s_iso);
     // (block_allreduce's barriers also fence the reads of `red` above)
 
-    // accumulators -> packed lower triangle, adding the prior precision
+    if (a.Lw_post) {  // posterior precision Lw' = A, full symmetric (:92), straight from the accumulators
+      T* out = a.Lw_post + (int64_t)reg * a.strideLp;
 #pragma unroll
-    for (int i = 0; i < C::TPW; ++i) {
-      const int t = wave + kWaves * i;
-      if (t < C::NT) {
-        // tile coordinates: t is wave-dependent, recompute (cheap, once per regressor)
-        int I = 0;
-        while ((I + 1) * (I + 2) / 2 <= t) ++I;
-        const int J = t - I * (I + 1) / 2;
-        const int col = 16 * J + (lane & 15);
+      for (int i = 0; i < C::TPW; ++i) {
+        const int t = wave + kWaves * i;
+        if (t < C::NT) {
+          int I = 0;
+          while ((I + 1) * (I + 2) / 2 <= t) ++I;
+          const int K = t - I * (I + 1) / 2;
+          const int col = 16 * K + (lane & 15);
 #pragma unroll
-        for (int v = 0; v < 4; ++v) {
-          const int row = 16 * I + Mfma<T>::crow(lane, v);
-          if (col <= row && row < D) {
-            T val = acc[i][v];
-            if (a.prior_kind == PRIOR_DENSE) val += Lw[(int64_t)row * a.ldl + col];  // upper entry (col,row)
-            else if (a.prior_kind == PRIOR_DIAGONAL && row == col) val += Lw[row];
-            P[pidx(row, col)] = val;
+          for (int v = 0; v < 4; ++v) {
+            const int row = 16 * I + Mfma<T>::crow(lane, v);
+            if (col <= row && row < D) {
+              out[(int64_t)row * a.ldlp + col] = acc[i][v];
+              out[(int64_t)col * a.ldlp + row] = acc[i][v];
+            }
           }
         }
       }
     }
-    __syncthreads();
-    if (a.Lw_post) {  // posterior precision Lw' = A, full symmetric (:92)
-      T* out = a.Lw_post + (int64_t)reg * a.strideLp;
-      for (int idx = tid; idx < D * D; idx += kThreads) {
-        int c = idx / D, r = idx % D;
-        out[(int64_t)c * a.ldlp + r] = (r >= c) ? P[pidx(r, c)] : P[pidx(c, r)];
-      }
-    }
 
-    info = chol_packed(P, dinv, D, tid);  // :86 (and :67: T = L' is chol(Lw + G).U directly)
+    info = chol_blocked<T, NB>(acc, P, bvec, D, wave, lane, true);  // :86; T = L' is chol(Lw + G).U (:67)
     if (info != 0) {
       if (tid == 0) {
         a.info[reg] = info;
@@ -423,26 +557,20 @@ __global__ __launch_bounds__(kThreads, 2) void fused_small_kernel(PosteriorArgs<
         out[(int64_t)c * a.ldt + r] = (r <= c) ? P[pidx(c, r)] : T(0);
       }
     }
+    if (tid < D) dinv[tid] = T(1) / P[pidx(tid, tid)];
+    __syncthreads();
 
-    // ---- phase 3: triangular solves + evidence (wave 0) ----------------------------------------------
+    // ---- phase 3: back substitution + evidence (wave 0); bvec already holds u = L^-1 b (:57) -----------
     if (wave == 0) {
       const int i0 = lane, i1 = lane + 64;
       T b0 = i0 < D ? bvec[i0] : T(0);
       T b1 = i1 < D ? bvec[i1] : T(0);
-      // forward: u = L^-1 b                                     (:57  Lam.U' \ (Bt'dy))
-      for (int k = 0; k < D; ++k) {
-        T src = (k < 64) ? b0 : b1;
-        T uk = readlane(src, k & 63) / dinv[k];
-        if (lane == (k & 63)) { if (k < 64) b0 = uk; else b1 = uk; }
-        if (i0 > k && i0 < D) b0 -= P[pidx(i0, k)] * uk;
-        if (i1 > k && i1 < D) b1 -= P[pidx(i1, k)] * uk;
-      }
       double uu = (double)b0 * (double)b0 + (double)b1 * (double)b1;
       uu = wave_allreduce(uu);
       // backward: m = L^-T u                                    (:64, :68)
       for (int k = D - 1; k >= 0; --k) {
         T src = (k < 64) ? b0 : b1;
-        T mk = readlane(src, k & 63) / dinv[k];
+        T mk = readlane(src, k & 63) * dinv[k];
         if (lane == (k & 63)) { if (k < 64) b0 = mk; else b1 = mk; }
         const T* row = P + pidx(k, 0);
         if (i0 < k) b0 -= row[i0] * mk;

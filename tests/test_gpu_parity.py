@@ -169,7 +169,13 @@ def test_posterior_low_noise(B):
     f = B.BayesianLinearRegressor(mw, Lw)
     y = B.rand(rng, f(X, eps))
     fp = B.posterior(f(X, eps), y)
-    np.testing.assert_allclose(B.mean(fp(X, eps)), y, rtol=1.5e-8)
+    # The reference asserts mean ~ y at rtol sqrt(eps) on ITS seed; how closely the posterior mean
+    # interpolates depends on the instance (the reference's own op sequence gives 1.9e-8 on this one),
+    # so: interpolation at 1e-7, and agreement with the reference op sequence at 1e-9.
+    np.testing.assert_allclose(B.mean(fp(X, eps)), y, rtol=1e-7)
+    mw_o, _, L_o = O.posterior_literal(mw, Lw, X, eps, y)
+    np.testing.assert_allclose(B.mean(fp(X, eps)), O.mean(mw_o, X), rtol=1e-9)
+    np.testing.assert_allclose(fp.mw, mw_o, rtol=1e-7)
     assert np.all(B.var(fp(X, eps)) < 1000 * eps)
     assert np.all(O.cov(fp.mw, fp.Lw.toarray(), X, eps) < 1000 * eps)
 
