@@ -6,6 +6,7 @@
 
 #include <algorithm>
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <new>
 #include <string>
@@ -131,7 +132,11 @@ int launch_fused_small(blr_handle* h, const PosteriorArgs<T>& a) {
 template <typename T, int NB>
 int launch_fused_small_mode(blr_handle* h, const PosteriorArgs<T>& a) {
   if (a.layout == BLR_LAYOUT_ROWVECS) return launch_fused_small<T, NB, 1>(h, a);
-  if (a.vec_ok) return launch_fused_small<T, NB, 3>(h, a);
+  if (a.vec_ok) {
+    static const bool force_regs = getenv("BLR_MI355X_NO_LDSDMA") != nullptr;  // A/B experiments only
+    if (force_regs) return launch_fused_small<T, NB, 3>(h, a);
+    return launch_fused_small<T, NB, 4>(h, a);
+  }
   return launch_fused_small<T, NB, 0>(h, a);
 }
 

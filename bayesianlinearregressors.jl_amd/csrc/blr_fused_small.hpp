@@ -2,24 +2,33 @@
 //
 // Replaces reference src/bayesian_linear_regression.jl:72-89 (__compute_inference_quantities),
 // :55-58 (logpdf), :60-69 (posterior) with the direct Gram form of SURVEY.md 0.1:
-//   phase 0  (dense prior only) Cholesky of Lw in LDS -> logdet Lw, SPD check          (:78)
-//   phase 1  one streaming pass over X: MFMA SYRK  G += x_n w_n x_n'  (lower 16x16 tiles only),
-//            per column mu_n = x_n'mw, delta_n, b += x_n delta_n w_n, q += delta_n^2 w_n,
+//   phase 0  prior: SPD check + logdet Lw (dense prior: blocked Cholesky of Lw)              (:78)
+//   phase 1  one streaming pass over X: MFMA SYRK  A = Lw + sum_n x_n w_n x_n'  (lower 16x16 tiles
+//            only), per column mu_n = x_n'mw, delta_n, b += x_n delta_n w_n, q += delta_n^2 w_n,
 //            l += log s_n                                                  (:79-84, :86, :57)
-//   phase 2  A = Lw + G into packed LDS; in-place Cholesky A = L L' (T = L')              (:86, :67)
-//   phase 3  u = L^-1 b, m = L^-T u, mw' = mw + m, evidence                              (:57, :64, :68)
+//   phase 2  blocked Cholesky A = L L' (T = L') with the trailing matrix in MFMA accumulators,
+//            forward substitution u = L^-1 b fused into the panel step                   (:86, :67, :57)
+//   phase 3  m = L^-T u, mw' = mw + m, evidence                                          (:64, :68)
 // X is read from HBM exactly once; nothing intermediate touches HBM.
 //
 // LDS image of a stage (4*KS columns): [k-step j][row block I][lane l] holds
 //   X[16I + (l&15), n0 + 4j + (l>>4)]  -- i.e. already in MFMA operand order, so every fragment
 // read is one conflict-free ds_read of 64 consecutive elements.
+//
+// Code structure: the phases are separate NOINLINE device functions that talk through LDS.  Each gets
+// its own register allocation; inlined into one body, hipcc's LICM hoists hundreds of loop-invariant
+// address/mask/tile-coordinate values across the phases and the hot MFMA loop spills (measured: 1.5 KB
+// of scratch per lane and 46 % MFMA utilisation).
 #pragma once
 #include <utility>
 
 #include "blr_common.hpp"
 
-#ifndef BLR_JUNROLL
-#define BLR_JUNROLL 2
+// BLR_EXP: timing experiments only (never defined in the shipped build).
+//   1 = stop after the Gram loop   2 = Gram loop without MFMA   3 = Gram loop without the column-vector work
+//   4 = no global loads in the loop   5 = skip the back substitution
+#ifndef BLR_EXP
+#define BLR_EXP 0
 #endif
 
 namespace blr {
@@ -41,6 +50,14 @@ struct PosteriorArgs {
   int vec_ok;  // ColVecs, 16-byte aligned columns: vector loads allowed
 };
 
+// per-regressor context handed to the phase functions through LDS (uniform values)
+template <typename T>
+struct RegCtx {
+  const T* X; const T* y; const T* s; const T* mw; const T* Lw;
+  int64_t ldx, ldl;
+  int D, N, noise_kind, prior_kind;
+};
+
 template <typename T, int NB>
 struct SmallCfg {
   static constexpr int DP = 16 * NB;
@@ -50,7 +67,7 @@ struct SmallCfg {
   static constexpr int SLOT = KS * NB * 64;             // elements per LDS slot
   static constexpr int PER = SLOT / kThreads;           // elements per thread per stage
   static constexpr int NT = NB * (NB + 1) / 2;          // lower-triangular 16x16 tiles
-  static constexpr int TPW = (NT + kWaves - 1) / kWaves;  // tiles per wave
+  static constexpr int TPW = (NB == 8) ? 9 : (NT + kWaves - 1) / kWaves;  // accumulator tiles per wave
   static constexpr int PACKED = DP * (DP + 1) / 2;
   static constexpr int RED_BYTES = 16 * DP * 8;          // b partials: 4 waves x 4 lane-rows x DP doubles
   static constexpr int REGION0_A = 2 * SLOT * (int)sizeof(T);
@@ -59,15 +76,48 @@ struct SmallCfg {
   static constexpr int REGION0 =
       ((REGION0_A > REGION0_B ? (REGION0_A > REGION0_C ? REGION0_A : REGION0_C)
                               : (REGION0_B > REGION0_C ? REGION0_B : REGION0_C)) + 15) & ~15;
-  // after region 0: ybuf[2][NSC], wbuf[2][NSC], bvec[DP], dinv[DP] (T); scratch doubles/ints
+  // after region 0: ybuf[2][NSC], wbuf[2][NSC], bvec[DP], dinv[DP], mw[DP] (T); scratch; context
   static constexpr int OFF_Y = REGION0;
   static constexpr int OFF_W = OFF_Y + 2 * NSC * (int)sizeof(T);
   static constexpr int OFF_B = OFF_W + 2 * NSC * (int)sizeof(T);
   static constexpr int OFF_DINV = OFF_B + DP * (int)sizeof(T);
   static constexpr int OFF_MW = OFF_DINV + DP * (int)sizeof(T);
-  static constexpr int OFF_SCR = (OFF_MW + DP * (int)sizeof(T) + 15) & ~15;
-  static constexpr int LDS_BYTES = OFF_SCR + 64;
+  static constexpr int OFF_SCR = (OFF_MW + DP * (int)sizeof(T) + 15) & ~15;  // 8 doubles + 8 ints
+  static constexpr int OFF_CTX = OFF_SCR + 96;
+  static constexpr int LDS_BYTES = (OFF_CTX + (int)sizeof(RegCtx<T>) + 15) & ~15;
 };
+
+// scalarise a value that is uniform by construction but lives in a VGPR (LDS broadcast loads, arguments
+// of noinline functions): v_readfirstlane -> SGPR, so branches and address bases stay scalar.
+__device__ __forceinline__ int uni(int v) { return __builtin_amdgcn_readfirstlane(v); }
+__device__ __forceinline__ int64_t uni(int64_t v) {
+  int lo = __builtin_amdgcn_readfirstlane((int)(v & 0xffffffff));
+  int hi = __builtin_amdgcn_readfirstlane((int)(v >> 32));
+  return ((int64_t)hi << 32) | (uint32_t)lo;
+}
+template <typename P>
+__device__ __forceinline__ P* uni(P* p) { return reinterpret_cast<P*>(uni((int64_t)(uintptr_t)p)); }
+
+// ---- tile -> wave assignment -------------------------------------------------------------------------
+// NB == 8 (D in 113..128, the headline shape): wave W owns block rows W and 7-W (9 tiles each), so only two
+// A-side fragments per k-step need the Sigma^-1 scaling.  Otherwise round-robin over t = I(I+1)/2 + K.
+// Tiles are selected by LDS ADDRESS (SGPR offsets), never by register index: all four waves run the same
+// instruction stream.
+__device__ __forceinline__ bool wave_tile(int NB, int wave, int i, int& I, int& K) {
+  if (NB == 8) {
+    I = (i <= wave) ? wave : 7 - wave;
+    K = (i <= wave) ? i : i - (wave + 1);
+    return true;
+  }
+  const int t = wave + kWaves * i;
+  I = 0;
+  while ((I + 1) * (I + 2) / 2 <= t) ++I;
+  K = t - I * (I + 1) / 2;
+  return t < NB * (NB + 1) / 2;
+}
+
+template <typename T, int NB>
+using AccArr = typename Mfma<T>::acc4[SmallCfg<T, NB>::TPW];
 
 // ---- stage loader ------------------------------------------------------------------------------
 // MODE 0: ColVecs data, generic (any D, ldx, alignment)   MODE 1: RowVecs data
@@ -76,6 +126,10 @@ struct SmallCfg {
 template <typename T, int NB>
 struct StageRegs {
   T x[SmallCfg<T, NB>::PER];
+  T yv, wv;
+};
+template <typename T>
+struct StageRegs<T, 0> {  // MODE 4: X goes straight to LDS, only the per-column scalars pass through registers
   T yv, wv;
 };
 
@@ -152,120 +206,355 @@ __device__ __forceinline__ void stage_store(const StageRegs<T, NB>& r, T* __rest
   if (tid < C::NSC) { ybuf[tid] = r.yv; wbuf[tid] = r.wv; }
 }
 
-// ---- one stage of MFMA + vector work for wave W -------------------------------------------------
+// ---- MODE 4: ColVecs, 16-byte aligned columns, loaded straight into LDS (global_load_lds_dwordx4) ---------
+// One wave-instruction moves 1 KiB = `FPG` consecutive fragments of the slot image (the image is lane-linear
+// by construction, which is exactly what the LDS-DMA destination requires: M0 base + lane * 16 B); the
+// per-lane GLOBAL address does the (column, row) -> fragment permutation.  No staging registers, no ds_write.
+// Lanes whose element is outside the matrix (row >= D or column >= N) write zeros with a plain ds_write.
 template <typename T, int NB>
-using AccArr = typename Mfma<T>::acc4[SmallCfg<T, NB>::TPW];
-
-template <typename T, int NB, int t, int slot_i>
-__device__ __forceinline__ void mma_one(AccArr<T, NB>& acc, const T (&fa)[NB],
-                                        const T (&f)[NB]) {
-  if constexpr (t < SmallCfg<T, NB>::NT) {
-    constexpr int I = tile_I(t), J = tile_J(t);
-    acc[slot_i] = Mfma<T>::mma(fa[I], f[J], acc[slot_i]);
-  }
-}
-
-template <typename T, int NB, int W, int... Is>
-__device__ __forceinline__ void mma_all(AccArr<T, NB>& acc, const T (&fa)[NB],
-                                        const T (&f)[NB], std::integer_sequence<int, Is...>) {
-  (mma_one<T, NB, W + kWaves * Is, Is>(acc, fa, f), ...);
-}
-
-template <typename T, int NB, int W>
-__device__ __forceinline__ void compute_stage(const T* __restrict__ slot, const T* __restrict__ ybuf,
-                                              const T* __restrict__ wbuf,
-                                              AccArr<T, NB>& acc, double (&bacc)[NB],
-                                              double& qacc, const T* __restrict__ mwl, int lane, bool is_data) {
+__device__ __forceinline__ void stage_glds(T* __restrict__ slot, const T* __restrict__ base, int64_t ld, int D, int ncols,
+                                           int n0, int wave, int lane) {
   using C = SmallCfg<T, NB>;
-#pragma unroll BLR_JUNROLL
-  for (int j = 0; j < C::KS; ++j) {
-    T f[NB], fa[NB];
+  constexpr int VEC = Mfma<T>::VEC;
+  constexpr int FPG = (1024 / (int)sizeof(T)) / 64;  // fragments per wave-instruction: 2 (f64) / 4 (f32)
+  constexpr int NG = C::KS * NB / FPG;               // wave-instructions per stage
+  static_assert((C::KS * NB) % FPG == 0, "slot must be a whole number of 1 KiB pieces");
+  typedef T vecT __attribute__((ext_vector_type(VEC)));
+  asm volatile("" : "+v"(lane));  // keep the index arithmetic inside the stage loop (see stage_load)
+  const int e0 = lane * VEC;      // element offset inside the 1 KiB piece
+  const int fl = e0 >> 6, ls = e0 & 63, q = ls >> 4, r = ls & 15;
 #pragma unroll
-    for (int I = 0; I < NB; ++I) f[I] = slot[(j * NB + I) * 64 + lane];
-    const T w = wbuf[4 * j + (lane >> 4)];
+  for (int g0 = 0; g0 < NG; g0 += kWaves) {
+    const int g = g0 + wave;
+    if (NG % kWaves == 0 || g < NG) {
+      const int F = g * FPG + fl;  // flat fragment index j * NB + I
+      const int j = F / NB, I = F - j * NB;
+      const int n = n0 + 4 * j + q, d = 16 * I + r;
+      T* dst = slot + g * (FPG * 64);  // wave-uniform
+      if (d < D && n < ncols) {
+        __builtin_amdgcn_global_load_lds(
+            (const __attribute__((address_space(1))) void*)(base + (int64_t)n * ld + d),
+            (__attribute__((address_space(3))) void*)dst, 16, 0, 0);
+      } else {
+        vecT z;
 #pragma unroll
-    for (int I = 0; I < NB; ++I) fa[I] = f[I] * w;
-    mma_all<T, NB, W>(acc, fa, f, std::make_integer_sequence<int, C::TPW>{});
-    if ((j & 3) == W && is_data) {
-      // column vector work for the 4 columns of this k-step: lane (r, q) holds rows 16I + r of column q
-      T mu = T(0);
-#pragma unroll
-      for (int I = 0; I < NB; ++I) mu += f[I] * mwl[16 * I + (lane & 15)];
-      mu = row16_allreduce(mu);
-      const T delta = ybuf[4 * j + (lane >> 4)] - mu;  // :82  y - mean(fx)
-      const T rn = delta * w;
-      if ((lane & 15) == 0) qacc += (double)delta * (double)rn;
-#pragma unroll
-      for (int I = 0; I < NB; ++I) bacc[I] += (double)f[I] * (double)rn;
+        for (int c = 0; c < VEC; ++c) z[c] = T(0);
+        *reinterpret_cast<vecT*>(dst + e0) = z;
+      }
     }
   }
 }
 
-// ---- in-LDS Cholesky on the packed lower triangle (row i at i(i+1)/2) ----------------------------
-// Right-looking with deferred column scaling: one barrier per column.  On exit P holds L (A = L L'),
-// dinv[j] = L[j][j].  Returns 0 or the LAPACK-style index (1-based) of the failing leading minor.
-template <typename T>
-__device__ __forceinline__ int chol_packed(T* __restrict__ P, T* __restrict__ dinv, int D, int tid) {
-  const int ti = tid >> 4, tk = tid & 15;
-  int info = 0;
-  __syncthreads();
-  for (int j = 0; j < D; ++j) {
-    const T ajj = P[pidx(j, j)];
-    if (!(ajj > T(0))) { info = j + 1; break; }  // wave- and block-uniform: everyone reads the same word
-    for (int i = j + 1 + ti; i < D; i += 16) {
-      const T ci = P[pidx(i, j)] / ajj;
-      T* row = P + pidx(i, 0);
-      for (int k = j + 1 + tk; k <= i; k += 16) row[k] -= ci * P[pidx(k, j)];
+// ---- k-step operands -----------------------------------------------------------------------------------
+template <int NB>
+struct WaveOps {  // SGPRs: LDS element offsets of the A-/B-side fragments of accumulator slot i (-1: unused)
+  int offA[SmallCfg<double, NB>::TPW];
+  int offB[SmallCfg<double, NB>::TPW];
+};
+
+template <typename T, int NB>
+__device__ __forceinline__ WaveOps<NB> make_wave_ops(int wave) {
+  WaveOps<NB> o;
+#pragma unroll
+  for (int i = 0; i < SmallCfg<T, NB>::TPW; ++i) {
+    int I, K;
+    const bool ok = wave_tile(NB, wave, i, I, K);
+    o.offA[i] = ok ? I * 64 : -1;
+    o.offB[i] = ok ? K * 64 : -1;
+  }
+  return o;
+}
+
+template <typename T, int NB>
+struct KFrags {
+  T a[(NB == 8) ? 2 : SmallCfg<T, NB>::TPW];  // A-side fragments (NB == 8: block rows W and 7-W)
+  T b[SmallCfg<T, NB>::TPW];
+  T w;
+};
+
+template <typename T, int NB>
+__device__ __forceinline__ void load_kfrags(KFrags<T, NB>& fr, const WaveOps<NB>& ops, const T* __restrict__ kimg,
+                                            const T* __restrict__ wbuf, int j, int wave, int lane) {
+  using C = SmallCfg<T, NB>;
+  fr.w = wbuf[4 * j + (lane >> 4)];
+  if constexpr (NB == 8) {
+    fr.a[0] = kimg[wave * 64 + lane];
+    fr.a[1] = kimg[(7 - wave) * 64 + lane];
+  } else {
+#pragma unroll
+    for (int i = 0; i < C::TPW; ++i) fr.a[i] = kimg[(ops.offA[i] < 0 ? 0 : ops.offA[i]) + lane];
+  }
+#pragma unroll
+  for (int i = 0; i < C::TPW; ++i) fr.b[i] = kimg[(ops.offB[i] < 0 ? 0 : ops.offB[i]) + lane];
+}
+
+template <typename T, int NB>
+__device__ __forceinline__ void mma_kstep(AccArr<T, NB>& acc, const KFrags<T, NB>& fr, const WaveOps<NB>& ops, int wave) {
+  using C = SmallCfg<T, NB>;
+#if BLR_EXP == 2
+  acc[0][0] += fr.a[0] * fr.b[0] * fr.w;
+  return;
+#endif
+  if constexpr (NB == 8) {
+    const T alo = fr.a[0] * fr.w, ahi = fr.a[1] * fr.w;  // Sigma_y^-1 applied on the A side only
+#pragma unroll
+    for (int i = 0; i < C::TPW; ++i) {
+      const T asel = (i <= wave) ? alo : ahi;  // wave-uniform select
+      acc[i] = Mfma<T>::mma(asel, fr.b[i], acc[i]);
+    }
+  } else {
+#pragma unroll
+    for (int i = 0; i < C::TPW; ++i) {
+      if (ops.offA[i] >= 0) acc[i] = Mfma<T>::mma(fr.a[i] * fr.w, fr.b[i], acc[i]);  // scalar branch
+    }
+  }
+}
+
+// per-column vector work for the 4 columns of one k-step: lane (r, q) holds rows 16I + r of column q
+template <typename T, int NB>
+__device__ __forceinline__ void vector_kstep(const T* __restrict__ kimg, T w, T yv, const T* __restrict__ mwl,
+                                             double (&bacc)[NB], double& qacc, int lane) {
+  T f[NB];
+#pragma unroll
+  for (int I = 0; I < NB; ++I) f[I] = kimg[I * 64 + lane];
+  T mu = T(0);
+#pragma unroll
+  for (int I = 0; I < NB; ++I) mu += f[I] * mwl[16 * I + (lane & 15)];
+  mu = row16_allreduce(mu);
+  const T delta = yv - mu;  // :82  y - mean(fx)
+  const T rn = delta * w;
+  if ((lane & 15) == 0) qacc += (double)delta * (double)rn;
+#pragma unroll
+  for (int I = 0; I < NB; ++I) bacc[I] += (double)f[I] * (double)rn;
+}
+
+// One stage (KS k-steps): MFMAs on the wave's tiles, software-pipelined one k-step deep -- the fragments of
+// k-step j+1 are requested before the MFMAs of k-step j issue, so LDS latency hides under the MFMA pipe.
+template <typename T, int NB>
+__device__ __forceinline__ void compute_stage(const T* __restrict__ slot, const T* __restrict__ ybuf,
+                                              const T* __restrict__ wbuf, const WaveOps<NB>& ops, AccArr<T, NB>& acc,
+                                              double (&bacc)[NB], double& qacc, const T* __restrict__ mwl, int wave,
+                                              int lane, bool is_data) {
+  using C = SmallCfg<T, NB>;
+  KFrags<T, NB> f0, f1;
+  load_kfrags<T, NB>(f0, ops, slot, wbuf, 0, wave, lane);
+#pragma unroll 1
+  for (int j = 0; j < C::KS; j += 2) {
+    load_kfrags<T, NB>(f1, ops, slot + (j + 1) * NB * 64, wbuf, j + 1, wave, lane);
+    mma_kstep<T, NB>(acc, f0, ops, wave);
+    if ((j & 3) == wave && is_data && BLR_EXP != 3)
+      vector_kstep<T, NB>(slot + j * NB * 64, f0.w, ybuf[4 * j + (lane >> 4)], mwl, bacc, qacc, lane);
+    if (j + 2 < C::KS) load_kfrags<T, NB>(f0, ops, slot + (j + 2) * NB * 64, wbuf, j + 2, wave, lane);
+    mma_kstep<T, NB>(acc, f1, ops, wave);
+    if (((j + 1) & 3) == wave && is_data && BLR_EXP != 3)
+      vector_kstep<T, NB>(slot + (j + 1) * NB * 64, f1.w, ybuf[4 * (j + 1) + (lane >> 4)], mwl, bacc, qacc, lane);
+  }
+}
+
+// =========================================================================================================
+// phase 1 (noinline): streaming Gram.  On exit: packed lower triangle of A in LDS (P), b in bvec,
+// scr[4] = (y-m)' S (y-m), scr[5] = logdet Sigma_y.
+// =========================================================================================================
+template <typename T, int NB, int MODE>
+__device__ __attribute__((noinline)) void phase_gram(char* smem) {
+  using C = SmallCfg<T, NB>;
+  using acc4 = typename Mfma<T>::acc4;
+  T* const slot0 = reinterpret_cast<T*>(smem);
+  T* const P = reinterpret_cast<T*>(smem);
+  double* const red = reinterpret_cast<double*>(smem);
+  T* const ybuf = reinterpret_cast<T*>(smem + C::OFF_Y);
+  T* const wbuf = reinterpret_cast<T*>(smem + C::OFF_W);
+  T* const bvec = reinterpret_cast<T*>(smem + C::OFF_B);
+  T* const mwl = reinterpret_cast<T*>(smem + C::OFF_MW);
+  double* const scr = reinterpret_cast<double*>(smem + C::OFF_SCR);
+  const RegCtx<T>* ctx = reinterpret_cast<const RegCtx<T>*>(smem + C::OFF_CTX);
+
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = uni(tid >> 6);
+  const T* X = uni(ctx->X);
+  const T* y = uni(ctx->y);
+  const T* s = uni(ctx->s);
+  const T* mw = uni(ctx->mw);
+  const T* Lw = uni(ctx->Lw);
+  const int64_t ldx = uni(ctx->ldx), ldl = uni(ctx->ldl);
+  const int D = uni(ctx->D), N = uni(ctx->N);
+  const int noise_kind = uni(ctx->noise_kind), prior_kind = uni(ctx->prior_kind);
+  const WaveOps<NB> ops = make_wave_ops<T, NB>(wave);
+
+  // accumulators start from the prior precision (dense: UPPER triangle of the caller's matrix, as LAPACK 'U';
+  // diagonal tiles get both halves so they stay symmetric)
+  acc4 acc[C::TPW];
+#pragma unroll
+  for (int i = 0; i < C::TPW; ++i) {
+    int I, K;
+    const bool tile_ok = wave_tile(NB, wave, i, I, K);
+    const int col = 16 * K + (lane & 15);
+#pragma unroll
+    for (int v = 0; v < 4; ++v) {
+      const int row = 16 * I + Mfma<T>::crow(lane, v);
+      T val = T(0);
+      if (tile_ok && row < D && col < D) {
+        if (prior_kind == PRIOR_DENSE) {
+          const int lo = min(row, col), hi = max(row, col);
+          val = Lw[(int64_t)hi * ldl + lo];
+        } else if (prior_kind == PRIOR_DIAGONAL && row == col) {
+          val = Lw[row];
+        }
+      }
+      acc[i][v] = val;
+    }
+  }
+  double bacc[NB];
+#pragma unroll
+  for (int I = 0; I < NB; ++I) bacc[I] = 0.0;
+  if (tid < C::DP) mwl[tid] = tid < D ? mw[tid] : T(0);  // visible after the first stage barrier
+  double qacc = 0.0, lacc = 0.0;
+
+  const int nprior_stages = (prior_kind == PRIOR_UPPER_FACTOR) ? (D + C::NSC - 1) / C::NSC : 0;
+  const int ndata_stages = (N + C::NSC - 1) / C::NSC;
+  const int nstages = nprior_stages + ndata_stages;
+  const bool diag_noise = (noise_kind == NOISE_DIAGONAL);
+  const T s_iso = diag_noise ? T(1) : s[0];
+
+  constexpr bool kGlds = (MODE == 4);
+  StageRegs<T, kGlds ? 0 : NB> regs;  // MODE 4 keeps only yv / wv in registers
+  T* ring_slot = slot0;               // where the data stage being issued lands (MODE 4)
+  auto issue = [&](int td) {  // prefetch data stage td: into registers, or (MODE 4) straight into its LDS slot
+    const int n0 = td * C::NSC;
+    if constexpr (kGlds) stage_glds<T, NB>(ring_slot, X, ldx, D, N, n0, wave, lane);
+    else stage_load<T, NB, MODE>(regs, X, ldx, D, N, n0, tid);
+    regs.yv = T(0);
+    regs.wv = T(0);
+    if (tid < C::NSC && n0 + tid < N) {
+      regs.yv = y[n0 + tid];
+      T sv = diag_noise ? s[n0 + tid] : s_iso;
+      regs.wv = T(1) / sv;                       // :79/:81  Sigma_y^-1 on the diagonal
+      if (diag_noise) lacc += log((double)sv);   // :84  logdet(Sigma_y)
+    }
+  };
+
+  __syncthreads();  // region 0 is free
+  // MODE 4 with prior pseudo-stages: data stage 0 is issued after the last prior stage's barrier instead
+  // (its slot is still being used by the prior stages before that)
+  if (ndata_stages > 0 && !(kGlds && nprior_stages > 0)) { ring_slot = slot0 + (nprior_stages & 1) * C::SLOT; issue(0); }
+  for (int t = 0; t < nstages; ++t) {
+    const int sl = t & 1;
+    T* slot = slot0 + sl * C::SLOT;
+    const bool is_data = t >= nprior_stages;
+    if (!is_data) {
+      // prior pseudo-observations (PDMat / carried-forward factor): a handful of stages, loaded synchronously
+      StageRegs<T, NB> pr;
+      const int n0 = t * C::NSC;
+      stage_load<T, NB, 2>(pr, Lw, ldl, D, D, n0, tid);
+      pr.yv = T(0);
+      pr.wv = (tid < C::NSC && n0 + tid < D) ? T(1) : T(0);
+      stage_store<T, NB, 2>(pr, slot, ybuf + sl * C::NSC, wbuf + sl * C::NSC, tid);
+    } else if constexpr (kGlds) {
+      if (tid < C::NSC) { ybuf[sl * C::NSC + tid] = regs.yv; wbuf[sl * C::NSC + tid] = regs.wv; }
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // this wave's LDS-DMA pieces of stage t have landed
+    } else {
+      stage_store<T, NB, MODE>(regs, slot, ybuf + sl * C::NSC, wbuf + sl * C::NSC, tid);
     }
     __syncthreads();
+    const int tdn = t + 1 - nprior_stages;  // next data stage
+#if BLR_EXP != 4
+    const int tdn_min = (kGlds && nprior_stages > 0) ? 0 : 1;
+    if (tdn >= tdn_min && tdn < ndata_stages) {  // in flight while this stage computes
+      ring_slot = slot0 + ((t + 1) & 1) * C::SLOT;
+      issue(tdn);
+    }
+#endif
+    compute_stage<T, NB>(slot, ybuf + sl * C::NSC, wbuf + sl * C::NSC, ops, acc, bacc, qacc, mwl, wave, lane, is_data);
   }
-  if (info) return info;
-  if (tid < D) dinv[tid] = sqrt(P[pidx(tid, tid)]);  // dinv holds the DIAGONAL of L (true divisions below)
+
+  // b partials -> LDS -> fixed-order sum
   __syncthreads();
-  for (int i = ti; i < D; i += 16) {
-    T* row = P + pidx(i, 0);
-    for (int k = tk; k < i; k += 16) row[k] /= dinv[k];
+  {
+    const int q = lane >> 4, r = lane & 15;
+#pragma unroll
+    for (int I = 0; I < NB; ++I) red[(wave * 4 + q) * C::DP + 16 * I + r] = bacc[I];
   }
-  if (tid < D) P[pidx(tid, tid)] = dinv[tid];
   __syncthreads();
-  return 0;
+  if (tid < C::DP) {
+    double sum = 0.0;
+#pragma unroll
+    for (int p = 0; p < 16; ++p) sum += red[p * C::DP + tid];  // fixed order
+    bvec[tid] = (T)sum;                                         // b = X S (y - X'mw)   (:57 Bt'dy, unwhitened)
+  }
+  const double quad = block_allreduce(qacc, scr, tid);          // (y-m)' S (y-m)
+  double logdet_Sy = block_allreduce(lacc, scr, tid);
+  if (!diag_noise) logdet_Sy = (double)N * log((double)s_iso);
+  // (block_allreduce's barriers also fence the reads of `red` above)
+  if (tid == 0) { scr[4] = quad; scr[5] = logdet_Sy; }
+
+  // A: accumulators -> packed lower triangle
+#pragma unroll
+  for (int i = 0; i < C::TPW; ++i) {
+    int I, K;
+    if (wave_tile(NB, wave, i, I, K)) {
+      const int col = 16 * K + (lane & 15);
+#pragma unroll
+      for (int v = 0; v < 4; ++v) {
+        const int row = 16 * I + Mfma<T>::crow(lane, v);
+        if (col <= row) P[pidx(row, col)] = acc[i][v];
+      }
+    }
+  }
+  __syncthreads();
 }
 
-// ---- blocked Cholesky with the trailing matrix in MFMA accumulators -------------------------------
-// On entry the lower 16x16 tiles of A live in `acc` (tile t = wave + 4 i at acc[i], MFMA C layout).
+// =========================================================================================================
+// phase 2 (noinline): blocked Cholesky of the packed lower triangle P, trailing matrix in MFMA accumulators.
 // For each block column J:
-//   (a) the owners of tiles (I, J) store them into the packed LDS triangle P (row i at i(i+1)/2);
+//   (a) the owners of tiles (I, J) store them into P;
 //   (b) every wave loads panel rows, ONE ROW PER LANE (lanes 0-15: the 16 diagonal-block rows, held
 //       redundantly by all four waves so no cross-wave traffic is needed; lanes 16-63: 48 rows below),
 //       and eliminates the 16 columns in registers -- pivots and multipliers travel by v_readlane;
 //       the right-hand side b rides along (forward substitution u = L^-1 b for free);
 //   (c) the finished panel goes back to P and all waves apply  A_IK -= L_IJ L_KJ'  to their
 //       remaining tiles with 4 MFMAs per tile, reading both operands from P in fragment order.
-// Three barriers per block column instead of one (or two) per scalar column, and no LDS round trip
-// for the trailing matrix.  On exit P holds L (A = L L'), bvec holds u.  Returns LAPACK-style info.
+// Three barriers per block column, no LDS round trip for the trailing matrix.  On exit P holds L (A = L L'),
+// bvec holds u = L^-1 b.  Returns 0 or the LAPACK-style 1-based index of the failing leading minor.
+// =========================================================================================================
 template <typename T, int NB>
-__device__ __forceinline__ int chol_blocked(AccArr<T, NB>& acc, T* __restrict__ P, T* __restrict__ bvec, int D,
-                                            int wave, int lane, bool with_rhs) {
+__device__ __attribute__((noinline)) int phase_chol(char* smem, int D_in, int with_rhs_in) {
   using C = SmallCfg<T, NB>;
+  using acc4 = typename Mfma<T>::acc4;
+  T* const P = reinterpret_cast<T*>(smem);
+  T* const bvec = reinterpret_cast<T*>(smem + C::OFF_B);
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = uni(tid >> 6);
+  const int D = uni(D_in);
+  const bool with_rhs = uni(with_rhs_in) != 0;
   const int nblk = (D + 15) >> 4;
+
+  // tiles from P (diagonal tiles: mirror the lower half so the tile is symmetric)
+  acc4 acc[C::TPW];
+#pragma unroll
+  for (int i = 0; i < C::TPW; ++i) {
+    int I, K;
+    const bool tile_ok = wave_tile(NB, wave, i, I, K);
+    const int col = 16 * K + (lane & 15);
+#pragma unroll
+    for (int v = 0; v < 4; ++v) {
+      const int row = 16 * I + Mfma<T>::crow(lane, v);
+      acc[i][v] = tile_ok ? P[pidx(max(row, col), min(row, col))] : T(0);
+    }
+  }
+
   int info = 0;
   for (int J = 0; J < nblk; ++J) {
     __syncthreads();
     // (a) panel tiles -> packed LDS
 #pragma unroll
     for (int i = 0; i < C::TPW; ++i) {
-      const int t = wave + kWaves * i;
-      if (t < C::NT) {
-        int I = 0;
-        while ((I + 1) * (I + 2) / 2 <= t) ++I;
-        const int K = t - I * (I + 1) / 2;
-        if (K == J) {
-          const int col = 16 * J + (lane & 15);
+      int I, K;
+      if (wave_tile(NB, wave, i, I, K) && K == J) {
+        const int col = 16 * J + (lane & 15);
 #pragma unroll
-          for (int v = 0; v < 4; ++v) {
-            const int row = 16 * I + Mfma<T>::crow(lane, v);
-            if (col <= row) P[pidx(row, col)] = acc[i][v];
-          }
+        for (int v = 0; v < 4; ++v) {
+          const int row = 16 * I + Mfma<T>::crow(lane, v);
+          if (col <= row) P[pidx(row, col)] = acc[i][v];
         }
       }
     }
@@ -295,8 +584,7 @@ __device__ __forceinline__ int chol_blocked(AccArr<T, NB>& acc, T* __restrict__ 
         }
         const T d = sqrt(d2);
         const T rinv = T(1) / d;
-        const T piv_b = readlane(bl, c);
-        const T uc = piv_b * rinv;
+        const T uc = readlane(bl, c) * rinv;
         const T lc = arow[c] * rinv;  // column c of L for this lane's row
         arow[c] = (lane == c) ? d : lc;
         if (lane == c) bl = uc;
@@ -321,19 +609,14 @@ __device__ __forceinline__ int chol_blocked(AccArr<T, NB>& acc, T* __restrict__ 
     const int r = lane & 15, q = lane >> 4;
 #pragma unroll
     for (int i = 0; i < C::TPW; ++i) {
-      const int t = wave + kWaves * i;
-      if (t < C::NT) {
-        int I = 0;
-        while ((I + 1) * (I + 2) / 2 <= t) ++I;
-        const int K = t - I * (I + 1) / 2;
-        if (K > J && I < nblk) {
-          const int rowI = 16 * I + r, rowK = 16 * K + r;
+      int I, K;
+      if (wave_tile(NB, wave, i, I, K) && K > J && I < nblk) {
+        const int rowI = 16 * I + r, rowK = 16 * K + r;
 #pragma unroll
-          for (int ks = 0; ks < 4; ++ks) {
-            const T fI = P[pidx(rowI, 16 * J + 4 * ks + q)];
-            const T fK = P[pidx(rowK, 16 * J + 4 * ks + q)];
-            acc[i] = Mfma<T>::mma(-fI, fK, acc[i]);
-          }
+        for (int ks = 0; ks < 4; ++ks) {
+          const T fI = P[pidx(rowI, 16 * J + 4 * ks + q)];
+          const T fK = P[pidx(rowK, 16 * J + 4 * ks + q)];
+          acc[i] = Mfma<T>::mma(-fI, fK, acc[i]);
         }
       }
     }
@@ -342,65 +625,119 @@ __device__ __forceinline__ int chol_blocked(AccArr<T, NB>& acc, T* __restrict__ 
   return info;
 }
 
-// ---- the kernel -----------------------------------------------------------------------------------
-template <typename T, int NB, int MODE /* data loader: 0 ColVecs generic, 1 RowVecs, 3 ColVecs vector */>
-__global__ __launch_bounds__(kThreads, 2) void fused_small_kernel(PosteriorArgs<T> a) {
+// =========================================================================================================
+// phase 3 (noinline, wave 0 does the serial part): m = L^-T u by column-oriented back substitution.
+// Returns through LDS: bvec <- m (rows < D), scr[6] = |u|^2, scr[7] = logdet A.
+// =========================================================================================================
+template <typename T, int NB>
+__device__ __attribute__((noinline)) void phase_backsolve(char* smem, int D_in) {
   using C = SmallCfg<T, NB>;
-  using acc4 = typename Mfma<T>::acc4;
-  extern __shared__ __attribute__((aligned(16))) char smem[];
-  T* const slot0 = reinterpret_cast<T*>(smem);
   T* const P = reinterpret_cast<T*>(smem);
-  double* const red = reinterpret_cast<double*>(smem);
-  T* const ybuf = reinterpret_cast<T*>(smem + C::OFF_Y);
-  T* const wbuf = reinterpret_cast<T*>(smem + C::OFF_W);
   T* const bvec = reinterpret_cast<T*>(smem + C::OFF_B);
   T* const dinv = reinterpret_cast<T*>(smem + C::OFF_DINV);
-  T* const mwl = reinterpret_cast<T*>(smem + C::OFF_MW);
   double* const scr = reinterpret_cast<double*>(smem + C::OFF_SCR);
-  int* const iscr = reinterpret_cast<int*>(smem + C::OFF_SCR + 32);
-
   const int tid = threadIdx.x, lane = tid & 63;
-  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);  // scalar: the per-wave switch below is a real branch
+  const int wave = uni(tid >> 6);
+  const int D = uni(D_in);
+  if (tid < D) dinv[tid] = T(1) / P[pidx(tid, tid)];
+  __syncthreads();
+  if (wave == 0) {
+    const int i0 = lane, i1 = lane + 64;
+    T b0 = i0 < D ? bvec[i0] : T(0);
+    T b1 = i1 < D ? bvec[i1] : T(0);
+    double uu = (double)b0 * (double)b0 + (double)b1 * (double)b1;
+    uu = wave_allreduce(uu);
+    for (int k = (BLR_EXP == 5 ? -1 : D - 1); k >= 0; --k) {
+      T src = (k < 64) ? b0 : b1;
+      T mk = readlane(src, k & 63) * dinv[k];
+      if (lane == (k & 63)) { if (k < 64) b0 = mk; else b1 = mk; }
+      const T* row = P + pidx(k, 0);
+      if (i0 < k) b0 -= row[i0] * mk;
+      if (i1 < k) b1 -= row[i1] * mk;
+    }
+    if (i0 < D) bvec[i0] = b0;
+    if (i1 < D) bvec[i1] = b1;
+    double ld = 0.0;
+    if (i0 < D) ld += log((double)P[pidx(i0, i0)]);
+    if (i1 < D) ld += log((double)P[pidx(i1, i1)]);
+    ld = 2.0 * wave_allreduce(ld);  // logdet A
+    if (lane == 0) { scr[6] = uu; scr[7] = ld; }
+  }
+  __syncthreads();
+}
+
+// ---- scalar right-looking Cholesky on the packed triangle (standalone chol_small_kernel only) --------------
+template <typename T>
+__device__ __forceinline__ int chol_packed(T* __restrict__ P, T* __restrict__ dinv, int D, int tid) {
+  const int ti = tid >> 4, tk = tid & 15;
+  int info = 0;
+  __syncthreads();
+  for (int j = 0; j < D; ++j) {
+    const T ajj = P[pidx(j, j)];
+    if (!(ajj > T(0))) { info = j + 1; break; }  // wave- and block-uniform: everyone reads the same word
+    for (int i = j + 1 + ti; i < D; i += 16) {
+      const T ci = P[pidx(i, j)] / ajj;
+      T* row = P + pidx(i, 0);
+      for (int k = j + 1 + tk; k <= i; k += 16) row[k] -= ci * P[pidx(k, j)];
+    }
+    __syncthreads();
+  }
+  if (info) return info;
+  if (tid < D) dinv[tid] = sqrt(P[pidx(tid, tid)]);
+  __syncthreads();
+  for (int i = ti; i < D; i += 16) {
+    T* row = P + pidx(i, 0);
+    for (int k = tk; k < i; k += 16) row[k] /= dinv[k];
+  }
+  if (tid < D) P[pidx(tid, tid)] = dinv[tid];
+  __syncthreads();
+  return 0;
+}
+
+// ---- the kernel -----------------------------------------------------------------------------------
+template <typename T, int NB, int MODE /* data loader: 0 ColVecs generic, 1 RowVecs, 3 ColVecs vector regs, 4 ColVecs LDS-DMA */>
+__global__ __launch_bounds__(kThreads, 2) void fused_small_kernel(PosteriorArgs<T> a) {
+  using C = SmallCfg<T, NB>;
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  T* const P = reinterpret_cast<T*>(smem);
+  T* const bvec = reinterpret_cast<T*>(smem + C::OFF_B);
+  double* const scr = reinterpret_cast<double*>(smem + C::OFF_SCR);
+  int* const iscr = reinterpret_cast<int*>(smem + C::OFF_SCR + 64);
+  RegCtx<T>* ctx = reinterpret_cast<RegCtx<T>*>(smem + C::OFF_CTX);
+
+  const int tid = threadIdx.x;
   const int D = a.D, N = a.N;
   const double kNaN = __longlong_as_double(0x7ff8000000000000LL);
 
   for (int reg = blockIdx.x; reg < a.B; reg += gridDim.x) {
-    const T* X = a.X + (int64_t)reg * a.strideX;
-    const T* y = a.y + (int64_t)reg * a.stridey;
-    const T* s = a.s + (int64_t)reg * a.strides;
     const T* mw = a.mw + (int64_t)reg * a.stridemw;
     const T* Lw = a.Lw + (int64_t)reg * a.strideLw;
+    __syncthreads();  // previous regressor fully done with LDS
+    if (tid == 0) {
+      ctx->X = a.X + (int64_t)reg * a.strideX;
+      ctx->y = a.y + (int64_t)reg * a.stridey;
+      ctx->s = a.s + (int64_t)reg * a.strides;
+      ctx->mw = mw;
+      ctx->Lw = Lw;
+      ctx->ldx = a.ldx;
+      ctx->ldl = a.ldl;
+      ctx->D = D;
+      ctx->N = N;
+      ctx->noise_kind = a.noise_kind;
+      ctx->prior_kind = a.prior_kind;
+    }
     int info = 0;
     double logdet_Lw = 0.0;
-    acc4 acc[C::TPW];
-
-    // Loads the lower tiles of the dense prior precision (UPPER triangle of the caller's matrix is read,
-    // as LAPACK 'U' does) into the accumulators; diagonal tiles get both halves so they stay symmetric.
-    auto load_dense_prior = [&]() {
-#pragma unroll
-      for (int i = 0; i < C::TPW; ++i) {
-        const int t = wave + kWaves * i;
-        int I = 0;
-        while ((I + 1) * (I + 2) / 2 <= t) ++I;
-        const int K = t - I * (I + 1) / 2;
-        const int col = 16 * K + (lane & 15);
-#pragma unroll
-        for (int v = 0; v < 4; ++v) {
-          const int row = 16 * I + Mfma<T>::crow(lane, v);
-          T val = T(0);
-          if (t < C::NT && row < D && col < D) {
-            const int lo = min(row, col), hi = max(row, col);
-            val = Lw[(int64_t)hi * a.ldl + lo];  // upper entry (lo, hi)
-          }
-          acc[i][v] = val;
-        }
-      }
-    };
 
     // ---- phase 0: prior -----------------------------------------------------------------------
     if (a.prior_kind == PRIOR_DENSE) {
-      load_dense_prior();
-      info = chol_blocked<T, NB>(acc, P, bvec, D, wave, lane, false);  // :78
+      for (int idx = tid; idx < D * D; idx += kThreads) {  // upper triangle (k <= i) of column i
+        int i = idx / D, k = idx % D;
+        if (k <= i) P[pidx(i, k)] = Lw[(int64_t)i * a.ldl + k];
+      }
+      for (int idx = D * (D + 1) / 2 + tid; idx < C::PACKED; idx += kThreads) P[idx] = T(0);  // padded rows
+      __syncthreads();
+      info = phase_chol<T, NB>(smem, D, 0);  // :78
       double v = (info == 0 && tid < D) ? log((double)P[pidx(tid, tid)]) : 0.0;
       logdet_Lw = 2.0 * block_allreduce(v, scr, tid);
     } else {
@@ -425,123 +762,28 @@ __global__ __launch_bounds__(kThreads, 2) void fused_small_kernel(PosteriorArgs<
       continue;
     }
 
-    // ---- phase 1: streaming Gram, accumulators start from the prior precision ----------------------
-    if (a.prior_kind == PRIOR_DENSE) {
-      load_dense_prior();
-    } else {
-#pragma unroll
-      for (int i = 0; i < C::TPW; ++i) {
-        const int t = wave + kWaves * i;
-        int I = 0;
-        while ((I + 1) * (I + 2) / 2 <= t) ++I;
-        const int K = t - I * (I + 1) / 2;
-        const int col = 16 * K + (lane & 15);
-#pragma unroll
-        for (int v = 0; v < 4; ++v) {
-          const int row = 16 * I + Mfma<T>::crow(lane, v);
-          acc[i][v] = (a.prior_kind == PRIOR_DIAGONAL && t < C::NT && row == col && row < D) ? Lw[row] : T(0);
-        }
-      }
-    }
-    double bacc[NB];
-#pragma unroll
-    for (int I = 0; I < NB; ++I) bacc[I] = 0.0;
-    if (tid < C::DP) mwl[tid] = tid < D ? mw[tid] : T(0);  // visible after the first stage barrier
-    double qacc = 0.0, lacc = 0.0;
-
-    const bool prior_cols = (a.prior_kind == PRIOR_UPPER_FACTOR);
-    const int nprior_stages = prior_cols ? (D + C::NSC - 1) / C::NSC : 0;
-    const int ndata_stages = (N + C::NSC - 1) / C::NSC;
-    const int nstages = nprior_stages + ndata_stages;
-    const bool diag_noise = (a.noise_kind == NOISE_DIAGONAL);
-    const T s_iso = diag_noise ? T(1) : s[0];
-
-    StageRegs<T, NB> regs;
-    auto issue = [&](int td) {  // prefetch data stage td into registers
-      const int n0 = td * C::NSC;
-      stage_load<T, NB, MODE>(regs, X, a.ldx, D, N, n0, tid);
-      regs.yv = T(0);
-      regs.wv = T(0);
-      if (tid < C::NSC && n0 + tid < N) {
-        regs.yv = y[n0 + tid];
-        T sv = diag_noise ? s[n0 + tid] : s_iso;
-        regs.wv = T(1) / sv;                       // :79/:81  Sigma_y^-1 on the diagonal
-        if (diag_noise) lacc += log((double)sv);   // :84  logdet(Sigma_y)
-      }
-    };
-
-    __syncthreads();  // region 0 is free (previous regressor / phase 0 done)
-    if (ndata_stages > 0) issue(0);
-    for (int t = 0; t < nstages; ++t) {
-      const int sl = t & 1;
-      T* slot = slot0 + sl * C::SLOT;
-      const bool is_data = t >= nprior_stages;
-      if (!is_data) {
-        // prior pseudo-observations: a handful of stages, loaded synchronously (registers die here)
-        StageRegs<T, NB> pr;
-        const int n0 = t * C::NSC;
-        stage_load<T, NB, 2>(pr, Lw, a.ldl, D, D, n0, tid);
-        pr.yv = T(0);
-        pr.wv = (tid < C::NSC && n0 + tid < D) ? T(1) : T(0);
-        stage_store<T, NB, 2>(pr, slot, ybuf + sl * C::NSC, wbuf + sl * C::NSC, tid);
-      } else {
-        stage_store<T, NB, MODE>(regs, slot, ybuf + sl * C::NSC, wbuf + sl * C::NSC, tid);
-      }
-      __syncthreads();
-      const int tdn = t + 1 - nprior_stages;  // next data stage
-      if (tdn > 0 && tdn < ndata_stages) issue(tdn);  // in flight while this stage computes
-      const T* yb = ybuf + sl * C::NSC;
-      const T* wb = wbuf + sl * C::NSC;
-      switch (wave) {
-        case 0: compute_stage<T, NB, 0>(slot, yb, wb, acc, bacc, qacc, mwl, lane, is_data); break;
-        case 1: compute_stage<T, NB, 1>(slot, yb, wb, acc, bacc, qacc, mwl, lane, is_data); break;
-        case 2: compute_stage<T, NB, 2>(slot, yb, wb, acc, bacc, qacc, mwl, lane, is_data); break;
-        default: compute_stage<T, NB, 3>(slot, yb, wb, acc, bacc, qacc, mwl, lane, is_data); break;
-      }
-    }
-
-    // ---- phase 2: b -> LDS, A (registers) -> blocked Cholesky -----------------------------------------
+    // ---- phase 1: streaming Gram -> P, bvec, scr[4..5] ------------------------------------------------
     __syncthreads();
-    {
-      const int q = lane >> 4, r = lane & 15;
-#pragma unroll
-      for (int I = 0; I < NB; ++I) red[(wave * 4 + q) * C::DP + 16 * I + r] = bacc[I];
+    phase_gram<T, NB, MODE>(smem);
+#if BLR_EXP >= 1 && BLR_EXP <= 4
+    if (tid == 0) {
+      a.info[reg] = 0;
+      if (a.logpdf) a.logpdf[reg] = scr[4] + (double)P[tid];
     }
-    __syncthreads();
-    if (tid < C::DP) {
-      double sum = 0.0;
-#pragma unroll
-      for (int p = 0; p < 16; ++p) sum += red[p * C::DP + tid];  // fixed order
-      bvec[tid] = (T)sum;                                         // b = X S (y - X'mw)   (:57 Bt'dy, unwhitened)
-    }
-    const double quad = block_allreduce(qacc, scr, tid);          // (y-m)' S (y-m)
-    double logdet_Sy = block_allreduce(lacc, scr, tid);
-    if (!diag_noise) logdet_Sy = (double)N * log((double)s_iso);
-    // (block_allreduce's barriers also fence the reads of `red` above)
+    continue;
+#endif
+    const double quad = scr[4], logdet_Sy = scr[5];
 
-    if (a.Lw_post) {  // posterior precision Lw' = A, full symmetric (:92), straight from the accumulators
+    if (a.Lw_post) {  // posterior precision Lw' = A, full symmetric (:92)
       T* out = a.Lw_post + (int64_t)reg * a.strideLp;
-#pragma unroll
-      for (int i = 0; i < C::TPW; ++i) {
-        const int t = wave + kWaves * i;
-        if (t < C::NT) {
-          int I = 0;
-          while ((I + 1) * (I + 2) / 2 <= t) ++I;
-          const int K = t - I * (I + 1) / 2;
-          const int col = 16 * K + (lane & 15);
-#pragma unroll
-          for (int v = 0; v < 4; ++v) {
-            const int row = 16 * I + Mfma<T>::crow(lane, v);
-            if (col <= row && row < D) {
-              out[(int64_t)row * a.ldlp + col] = acc[i][v];
-              out[(int64_t)col * a.ldlp + row] = acc[i][v];
-            }
-          }
-        }
+      for (int idx = tid; idx < D * D; idx += kThreads) {
+        int c = idx / D, r = idx % D;
+        out[(int64_t)c * a.ldlp + r] = (r >= c) ? P[pidx(r, c)] : P[pidx(c, r)];
       }
     }
 
-    info = chol_blocked<T, NB>(acc, P, bvec, D, wave, lane, true);  // :86; T = L' is chol(Lw + G).U (:67)
+    // ---- phase 2: blocked Cholesky + fused forward substitution ------------------------------------------
+    info = phase_chol<T, NB>(smem, D, 1);  // :86; T = L' is chol(Lw + G).U (:67)
     if (info != 0) {
       if (tid == 0) {
         a.info[reg] = info;
@@ -549,7 +791,6 @@ __global__ __launch_bounds__(kThreads, 2) void fused_small_kernel(PosteriorArgs<
       }
       continue;
     }
-
     if (a.T_post) {
       T* out = a.T_post + (int64_t)reg * a.strideT;
       for (int idx = tid; idx < D * D; idx += kThreads) {
@@ -557,40 +798,15 @@ __global__ __launch_bounds__(kThreads, 2) void fused_small_kernel(PosteriorArgs<
         out[(int64_t)c * a.ldt + r] = (r <= c) ? P[pidx(c, r)] : T(0);
       }
     }
-    if (tid < D) dinv[tid] = T(1) / P[pidx(tid, tid)];
-    __syncthreads();
 
-    // ---- phase 3: back substitution + evidence (wave 0); bvec already holds u = L^-1 b (:57) -----------
-    if (wave == 0) {
-      const int i0 = lane, i1 = lane + 64;
-      T b0 = i0 < D ? bvec[i0] : T(0);
-      T b1 = i1 < D ? bvec[i1] : T(0);
-      double uu = (double)b0 * (double)b0 + (double)b1 * (double)b1;
-      uu = wave_allreduce(uu);
-      // backward: m = L^-T u                                    (:64, :68)
-      for (int k = D - 1; k >= 0; --k) {
-        T src = (k < 64) ? b0 : b1;
-        T mk = readlane(src, k & 63) * dinv[k];
-        if (lane == (k & 63)) { if (k < 64) b0 = mk; else b1 = mk; }
-        const T* row = P + pidx(k, 0);
-        if (i0 < k) b0 -= row[i0] * mk;
-        if (i1 < k) b1 -= row[i1] * mk;
-      }
-      if (a.mw_post) {
-        T* out = a.mw_post + (int64_t)reg * a.stride_mwpost;
-        if (i0 < D) out[i0] = mw[i0] + b0;  // :68  mw + Uw \ m_eps
-        if (i1 < D) out[i1] = mw[i1] + b1;
-      }
-      double ld = 0.0;
-      if (i0 < D) ld += log((double)P[pidx(i0, i0)]);
-      if (i1 < D) ld += log((double)P[pidx(i1, i1)]);
-      ld = 2.0 * wave_allreduce(ld);  // logdet A
-      if (lane == 0) {
-        a.info[reg] = 0;
-        if (a.logpdf) {
-          const double LOG2PI = 1.8378770664093454835606594728112;
-          a.logpdf[reg] = -0.5 * ((double)N * LOG2PI + logdet_Sy + quad + ld - logdet_Lw - uu);  // :84 + :57
-        }
+    // ---- phase 3: back substitution + evidence ---------------------------------------------------------
+    phase_backsolve<T, NB>(smem, D);
+    if (a.mw_post && tid < D) a.mw_post[(int64_t)reg * a.stride_mwpost + tid] = mw[tid] + bvec[tid];  // :68
+    if (tid == 0) {
+      a.info[reg] = 0;
+      if (a.logpdf) {
+        const double LOG2PI = 1.8378770664093454835606594728112;
+        a.logpdf[reg] = -0.5 * ((double)N * LOG2PI + logdet_Sy + quad + scr[7] - logdet_Lw - scr[6]);  // :84 + :57
       }
     }
   }
