@@ -30,6 +30,16 @@
 #ifndef BLR_EXP
 #define BLR_EXP 0
 #endif
+// Phase functions: noinline (own register allocation, but the AMDGPU call ABI saves ~108 callee-saved
+// VGPRs per call to scratch) or always-inline with an opaque thread id at phase entry.
+#ifndef BLR_PHASE_INLINE
+#define BLR_PHASE_INLINE 0
+#endif
+#if BLR_PHASE_INLINE
+#define BLR_PHASE __device__ __forceinline__
+#else
+#define BLR_PHASE __device__ __attribute__((noinline))
+#endif
 
 namespace blr {
 
@@ -356,7 +366,7 @@ __device__ __forceinline__ void compute_stage(const T* __restrict__ slot, const 
 // scr[4] = (y-m)' S (y-m), scr[5] = logdet Sigma_y.
 // =========================================================================================================
 template <typename T, int NB, int MODE>
-__device__ __attribute__((noinline)) void phase_gram(char* smem) {
+BLR_PHASE void phase_gram(char* smem) {
   using C = SmallCfg<T, NB>;
   using acc4 = typename Mfma<T>::acc4;
   T* const slot0 = reinterpret_cast<T*>(smem);
@@ -369,7 +379,9 @@ __device__ __attribute__((noinline)) void phase_gram(char* smem) {
   double* const scr = reinterpret_cast<double*>(smem + C::OFF_SCR);
   const RegCtx<T>* ctx = reinterpret_cast<const RegCtx<T>*>(smem + C::OFF_CTX);
 
-  const int tid = threadIdx.x, lane = tid & 63;
+  int tid = threadIdx.x;
+  asm volatile("" : "+v"(tid));  // nothing derived from tid may be hoisted above this phase
+  const int lane = tid & 63;
   const int wave = uni(tid >> 6);
   const T* X = uni(ctx->X);
   const T* y = uni(ctx->y);
@@ -517,12 +529,14 @@ __device__ __attribute__((noinline)) void phase_gram(char* smem) {
 // bvec holds u = L^-1 b.  Returns 0 or the LAPACK-style 1-based index of the failing leading minor.
 // =========================================================================================================
 template <typename T, int NB>
-__device__ __attribute__((noinline)) int phase_chol(char* smem, int D_in, int with_rhs_in) {
+BLR_PHASE int phase_chol(char* smem, int D_in, int with_rhs_in) {
   using C = SmallCfg<T, NB>;
   using acc4 = typename Mfma<T>::acc4;
   T* const P = reinterpret_cast<T*>(smem);
   T* const bvec = reinterpret_cast<T*>(smem + C::OFF_B);
-  const int tid = threadIdx.x, lane = tid & 63;
+  int tid = threadIdx.x;
+  asm volatile("" : "+v"(tid));
+  const int lane = tid & 63;
   const int wave = uni(tid >> 6);
   const int D = uni(D_in);
   const bool with_rhs = uni(with_rhs_in) != 0;
@@ -630,13 +644,15 @@ __device__ __attribute__((noinline)) int phase_chol(char* smem, int D_in, int wi
 // Returns through LDS: bvec <- m (rows < D), scr[6] = |u|^2, scr[7] = logdet A.
 // =========================================================================================================
 template <typename T, int NB>
-__device__ __attribute__((noinline)) void phase_backsolve(char* smem, int D_in) {
+BLR_PHASE void phase_backsolve(char* smem, int D_in) {
   using C = SmallCfg<T, NB>;
   T* const P = reinterpret_cast<T*>(smem);
   T* const bvec = reinterpret_cast<T*>(smem + C::OFF_B);
   T* const dinv = reinterpret_cast<T*>(smem + C::OFF_DINV);
   double* const scr = reinterpret_cast<double*>(smem + C::OFF_SCR);
-  const int tid = threadIdx.x, lane = tid & 63;
+  int tid = threadIdx.x;
+  asm volatile("" : "+v"(tid));
+  const int lane = tid & 63;
   const int wave = uni(tid >> 6);
   const int D = uni(D_in);
   if (tid < D) dinv[tid] = T(1) / P[pidx(tid, tid)];

@@ -29,6 +29,10 @@ import numpy as np  # noqa: E402
 # spec-sheet peaks: HBM3E 8.0 TB/s; fp64 matrix 78.6 TF; fp32 matrix 157.3 TF
 PEAK_HBM_GBS = 8000.0
 PEAK_TF = {"f64": 78.6, "f32": 157.3}
+# what tools/mfma_peak.hip sustains on this pool: v_mfma_f64_16x16x4 tops out at 47.7 TF
+MEASURED_MFMA_TF = {"f64": 47.7, "f32": 155.0}
+# HBM bytes per regressor from the PMC passes of profiles/r01_bench_c2_f64_pmc.json (FETCH_SIZE x2 + WRITE_SIZE)
+PMC_TRAFFIC_BYTES_PER_UPDATE = {("f64", 128, 4096, "isotropic"): 4832916304.0 / 1024}
 
 
 def algorithmic_bytes(D, N, w, diag_noise):
@@ -142,7 +146,7 @@ def main():
     lp = torch.empty((B,), dtype=torch.float64, device=dev)
     info = torch.empty((B,), dtype=torch.int32, device=dev)
     lp_sum = torch.zeros((1,), dtype=torch.float64, device=dev)
-    gathered = torch.zeros((world,), dtype=torch.float64, device=dev)
+    lp_all = torch.empty((B * world,), dtype=torch.float64, device=dev)
     torch.cuda.synchronize(dev)
 
     noise_kind = _abi.NOISE_DIAGONAL if diag else _abi.NOISE_ISOTROPIC
@@ -159,11 +163,13 @@ def main():
         fused_launch()
         if ev is not None:
             ev[1].record(stream)
-        h.logpdf_sum(_abi.MEM_DEVICE, B, lp.data_ptr(), lp_sum.data_ptr())
-        if dist is not None:  # the path's only exchange: per-rank partial log evidences (8 B per rank)
-            dist.all_gather_into_tensor(gathered, lp_sum)
+        if dist is not None:
+            # the path's only exchange: all-gather of the per-regressor log evidences (8 B each), then the SAME
+            # fixed-order device sum on every rank -> identical bits for every rank count
+            dist.all_gather_into_tensor(lp_all, lp)
+            h.logpdf_sum(_abi.MEM_DEVICE, B * world, lp_all.data_ptr(), lp_sum.data_ptr())
         else:
-            gathered.copy_(lp_sum)
+            h.logpdf_sum(_abi.MEM_DEVICE, B, lp.data_ptr(), lp_sum.data_ptr())
 
     for _ in range(args.warmup):
         step()
@@ -189,7 +195,7 @@ def main():
 
     # sanity: the timed work produced valid results
     assert int(info.abs().sum().item()) == 0, "a regressor failed to factorise"
-    total_evidence = float(gathered.sum().item())  # fixed order: rank 0..R-1
+    total_evidence = float(lp_sum.item())
     assert np.isfinite(total_evidence)
 
     if rank == 0:
@@ -205,8 +211,14 @@ def main():
                     "frac": tf / PEAK_TF[args.dtype]}
         else:
             roof = {"bound": "hbm", "achieved": gbs, "peak": PEAK_HBM_GBS, "unit": "GB/s", "frac": gbs / PEAK_HBM_GBS}
+        per_update = PMC_TRAFFIC_BYTES_PER_UPDATE.get((args.dtype, D, N, args.noise))
         roof.update({
-            "traffic": None,
+            "traffic": per_update * B if per_update else None,
+            "traffic_source": "rocprofv3 --pmc FETCH_SIZE (x2, gfx950) + WRITE_SIZE, profiles/r01_bench_c2_f64_pmc.json"
+                              if per_update else None,
+            "algorithmic_bytes": by, "algorithmic_flops": fl,
+            "mfma_peak_measured_TFLOPps": MEASURED_MFMA_TF[args.dtype],
+            "mfma_frac_of_measured_peak": tf / MEASURED_MFMA_TF[args.dtype],
             "kernel": "fused_small_kernel",
             "kernel_ms_avg": kern_ms,
             "units_per_launch": B,
@@ -230,7 +242,7 @@ def main():
                 "workload": f"c2: independent regressors D={D}, N={N}, ColVecs, {args.noise} noise, {args.dtype}, "
                             f"Lw=I, fused posterior+logpdf",
                 "D": D, "N": N, "batch_per_gpu": B, "global_batch": B * world,
-                "sharding": f"regressors x{world}, no data-path collective; one all-gather of {world} doubles",
+                "sharding": f"regressors x{world}, no data-path collective; one all-gather of {B * world} doubles",
             },
             "roofline": roof,
             "total_log_evidence": total_evidence,

@@ -1,0 +1,84 @@
+"""N > 1 path on CPU: world_size-2 gloo.  Checks the partition (bit-exact index work) and that the gathered
+log-evidence vector -- hence the fixed-order sum every rank then runs on it -- is identical on every rank and
+equal to the single-rank result."""
+import os
+import socket
+
+import numpy as np
+import pytest
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+import blr_amd  # noqa: F401
+from blr_amd import sharding
+
+
+def fixed_order_sum(v):
+    """Host emulation of blr::logpdf_sum_kernel (csrc/blr_aux_kernels.hpp): thread t sums elements
+    t, t+256, ... in order, then a halving tree over the 256 partials."""
+    part = np.zeros(256)
+    for t in range(256):
+        s = 0.0
+        for x in v[t::256]:
+            s += float(x)
+        part[t] = s
+    m = 128
+    while m >= 1:
+        part[:m] = part[:m] + part[m:2 * m]
+        m //= 2
+    return float(part[0])
+
+
+def test_shard_range_partitions_exactly():
+    for total in (0, 1, 7, 8, 1000, 8192, 8195):
+        for world in (1, 2, 3, 4, 8):
+            blocks = [sharding.shard_range(total, r, world) for r in range(world)]
+            assert blocks[0][0] == 0 and blocks[-1][1] == total
+            for (a, b), (c, d) in zip(blocks, blocks[1:]):
+                assert b == c and a <= b
+            sizes = sharding.shard_sizes(total, world)
+            assert sum(sizes) == total and max(sizes) - min(sizes) <= 1
+    with pytest.raises(ValueError):
+        sharding.shard_range(10, 2, 2)
+
+
+TOTALS = (8192, 1001)
+
+
+def _lp_all(total):
+    rng = np.random.default_rng(4242 + total)
+    return -1e3 * rng.random(total) - 500.0  # what the fused kernel would have produced for every regressor
+
+
+def _worker(rank, world, port, q):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    for total in TOTALS:
+        lp_all = _lp_all(total)
+        lo, hi = sharding.shard_range(total, rank, world)
+        local = torch.from_numpy(lp_all[lo:hi].copy())
+        gathered = sharding.gather_logpdf(local, total)
+        q.put((rank, total, gathered.numpy().tobytes(), fixed_order_sum(gathered.numpy())))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_gather_is_rank_count_independent():
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    procs = [ctx.Process(target=_worker, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    res = [q.get(timeout=240) for _ in range(2 * len(TOTALS))]
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    for rank, total, raw, tot in res:
+        lp_all = _lp_all(total)
+        assert raw == lp_all.tobytes(), f"rank {rank}: gathered vector differs"
+        assert tot == fixed_order_sum(lp_all)  # bitwise: same order of additions for every rank count
