@@ -14,6 +14,7 @@
 
 #include "blr_aux_kernels.hpp"
 #include "blr_fused_small.hpp"
+#include "blr_large.hpp"
 
 using namespace blr;
 
@@ -32,6 +33,7 @@ struct blr_handle {
 namespace {
 
 constexpr int kMaxSmallD = 128;
+constexpr int kMaxLargeD = 8192;
 
 int hip_fail(blr_handle* h, hipError_t e, const char* what) {
   if (h) {
@@ -156,6 +158,187 @@ int dispatch_fused_small(blr_handle* h, const PosteriorArgs<T>& a) {
   }
 }
 
+// ---- large-D path (D > 128): multi-kernel pipeline of blr_large.hpp ---------------------------------------------
+template <typename T>
+int set_lds(blr_handle* h, const void* kern, size_t bytes) {
+  HIP_TRY(h, hipFuncSetAttribute(kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes));
+  return 0;
+}
+
+// In-place blocked (128) right-looking Cholesky of the lower triangle of M (nrows_total x DP, ld); rows beyond DP
+// (the right-hand-side block of the augmented matrix) are carried through the TRSM and the trailing updates.
+template <typename T>
+int chol_large(blr_handle* h, T* M, int64_t ld, int DP, int nrows_total, int32_t* info_dev) {
+  using SC = SmallCfg<T, 8>;
+  using TC = TrsmCfg<T>;
+  using LC = LargeCfg<T>;
+  const int NC = DP / kPB;
+  const int NRB = (nrows_total + kPB - 1) / kPB;  // row blocks including the rhs block
+  int rc;
+  if ((rc = set_lds<T>(h, reinterpret_cast<const void*>(chol_diag_kernel<T>), SC::LDS_BYTES))) return rc;
+  if ((rc = set_lds<T>(h, reinterpret_cast<const void*>(trsm_block_kernel<T>), TC::LDS_BYTES))) return rc;
+  if ((rc = set_lds<T>(h, reinterpret_cast<const void*>(gram_tile_kernel<T>), LC::LDS_BYTES))) return rc;
+  for (int p = 0; p < NC; ++p) {
+    hipLaunchKernelGGL(chol_diag_kernel<T>, dim3(1), dim3(kThreads), SC::LDS_BYTES, h->stream, M, ld, p, info_dev, 0);
+    const int row_begin = (p + 1) * kPB;
+    if (row_begin < nrows_total) {
+      const int nblk = (nrows_total - row_begin + TC::RB - 1) / TC::RB;
+      hipLaunchKernelGGL(trsm_block_kernel<T>, dim3(nblk), dim3(kThreads), TC::LDS_BYTES, h->stream, M, ld, p, row_begin,
+                         nrows_total, (const int32_t*)info_dev);
+    }
+    const int m = NC - 1 - p;  // remaining column blocks
+    if (m > 0) {
+      GramTileArgs<T> g{};
+      g.X = M + (int64_t)p * kPB * ld; g.ldx = ld; g.layout = LAYOUT_COLVECS; g.use_dma = 1;
+      g.s = nullptr; g.noise_kind = NOISE_ISOTROPIC; g.r = nullptr;
+      g.D = nrows_total; g.n_begin = 0; g.n_end = kPB; g.nsplit = 1;
+      g.tile_i0 = p + 1; g.tile_j0 = p + 1; g.tri = 1; g.ntiles = m * (m + 1) / 2; g.nblocks = NRB;
+      g.C = M; g.ldc = ld; g.mode_out = 1;
+      hipLaunchKernelGGL(gram_tile_kernel<T>, dim3(g.ntiles), dim3(kThreads), LC::LDS_BYTES, h->stream, g);
+      if (NRB > NC) {  // the rhs row block: tiles (NC, p+1 .. NC-1)
+        g.tile_i0 = NC; g.tile_j0 = p + 1; g.tri = 2; g.ntiles = m;
+        hipLaunchKernelGGL(gram_tile_kernel<T>, dim3(g.ntiles), dim3(kThreads), LC::LDS_BYTES, h->stream, g);
+      }
+    }
+  }
+  HIP_TRY(h, hipGetLastError());
+  return 0;
+}
+
+template <typename T>
+int posterior_large_one(blr_handle* h, const PosteriorArgs<T>& a, int64_t reg) {
+  using LC = LargeCfg<T>;
+  using SC = SmallCfg<T, 8>;
+  const int D = a.D, N = a.N;
+  const int DP = (D + kPB - 1) / kPB * kPB, NC = DP / kPB;
+  const int64_t lda = DP + kPB;
+  const int ntiles = NC * (NC + 1) / 2;
+  const int nstage_cols = LC::NSC;
+  int nsplit = std::max(1, std::min((768 + ntiles - 1) / ntiles, (N + nstage_cols - 1) / nstage_cols));
+  const bool prior_factor = a.prior_kind == PRIOR_UPPER_FACTOR;
+  const int nsplit_total = nsplit + (prior_factor ? 1 : 0);
+  const int gridc = 1024;
+
+  // workspace carve
+  size_t off = 0;
+  auto carve = [&](size_t bytes) { size_t o = off; off = (off + bytes + 255) & ~(size_t)255; return o; };
+  const size_t o_abar = carve((size_t)lda * DP * sizeof(T));
+  const size_t o_w = carve(a.prior_kind == PRIOR_DENSE ? (size_t)DP * DP * sizeof(T) : 0);
+  const size_t o_gp = carve((size_t)nsplit_total * ntiles * kPB * kPB * sizeof(T));
+  const size_t o_bp = carve((size_t)nsplit_total * NC * kPB * sizeof(double));
+  const size_t o_r = carve((size_t)std::max(N, 1) * sizeof(T));
+  const size_t o_q = carve((size_t)gridc * sizeof(double));
+  const size_t o_l = carve((size_t)gridc * sizeof(double));
+  const size_t o_m = carve((size_t)DP * sizeof(T));
+  const size_t o_sc = carve(64);
+  int rc = ensure_ws(h, off);
+  if (rc) return rc;
+  char* ws = h->ws;
+  T* Abar = reinterpret_cast<T*>(ws + o_abar);
+  T* W = reinterpret_cast<T*>(ws + o_w);
+  T* Gpart = reinterpret_cast<T*>(ws + o_gp);
+  double* bpart = reinterpret_cast<double*>(ws + o_bp);
+  T* rvec = reinterpret_cast<T*>(ws + o_r);
+  double* qpart = reinterpret_cast<double*>(ws + o_q);
+  double* lpart = reinterpret_cast<double*>(ws + o_l);
+  T* mwork = reinterpret_cast<T*>(ws + o_m);
+  double* logdetLw = reinterpret_cast<double*>(ws + o_sc);
+  int32_t* info_prior = reinterpret_cast<int32_t*>(ws + o_sc + 8);
+  int32_t* info_chol = reinterpret_cast<int32_t*>(ws + o_sc + 12);
+
+  const T* X = a.X + reg * a.strideX;
+  const T* y = a.y + reg * a.stridey;
+  const T* s = a.s + reg * a.strides;
+  const T* mw = a.mw + reg * a.stridemw;
+  const T* Lw = a.Lw + reg * a.strideLw;
+
+  HIP_TRY(h, hipMemsetAsync(ws + o_sc, 0, 64, h->stream));
+  HIP_TRY(h, hipMemsetAsync(bpart, 0, (size_t)nsplit_total * NC * kPB * sizeof(double), h->stream));
+  HIP_TRY(h, hipMemsetAsync(mwork, 0, (size_t)DP * sizeof(T), h->stream));
+
+  // ---- prior: SPD check + logdet (reference :78)
+  if (a.prior_kind == PRIOR_DENSE) {
+    hipLaunchKernelGGL(prior_copy_kernel<T>, dim3(1024), dim3(kThreads), 0, h->stream, Lw, a.ldl, D, DP, W, (int64_t)DP);
+    if ((rc = chol_large<T>(h, W, DP, DP, DP, info_prior))) return rc;
+    hipLaunchKernelGGL(logdet_kernel<T>, dim3(1), dim3(kThreads), 0, h->stream, (const T*)W, (int64_t)DP, D, logdetLw);
+  } else {
+    hipLaunchKernelGGL(prior_diag_kernel<T>, dim3(1), dim3(kThreads), 0, h->stream, Lw, a.ldl, a.prior_kind, D, logdetLw,
+                       info_prior);
+  }
+
+  // ---- column statistics (reference :82-84)
+  {
+    ColstatsArgs<T> c{};
+    c.X = X; c.ldx = a.ldx; c.y = y; c.s = s; c.mw = mw; c.r = rvec; c.qpart = qpart; c.lpart = lpart;
+    c.layout = a.layout; c.noise_kind = a.noise_kind; c.D = D; c.N = N;
+    size_t lds = (((size_t)D * sizeof(T) + 15) & ~(size_t)15) + 64;
+    hipLaunchKernelGGL(colstats_kernel<T>, dim3(gridc), dim3(kThreads), lds, h->stream, c);
+  }
+
+  // ---- Gram (reference :86) : split-K partial tiles, then the prior factor as pseudo-observations
+  if ((rc = set_lds<T>(h, reinterpret_cast<const void*>(gram_tile_kernel<T>), LC::LDS_BYTES))) return rc;
+  {
+    GramTileArgs<T> g{};
+    g.X = X; g.ldx = a.ldx; g.layout = a.layout;
+    g.use_dma = (a.layout == LAYOUT_COLVECS && ((uintptr_t)X % 16 == 0) && ((a.ldx * (int64_t)sizeof(T)) % 16 == 0)) ? 1 : 0;
+    g.s = s; g.noise_kind = a.noise_kind; g.r = rvec;
+    g.D = D; g.n_begin = 0; g.n_end = N; g.nsplit = nsplit;
+    g.tile_i0 = 0; g.tile_j0 = 0; g.tri = 1; g.ntiles = ntiles; g.nblocks = NC;
+    g.Gpart = Gpart; g.bpart = bpart; g.mode_out = 0;
+    hipLaunchKernelGGL(gram_tile_kernel<T>, dim3(ntiles * nsplit), dim3(kThreads), LC::LDS_BYTES, h->stream, g);
+    if (prior_factor) {
+      GramTileArgs<T> u = g;
+      u.X = Lw; u.ldx = a.ldl; u.layout = 2; u.use_dma = 0; u.s = nullptr; u.r = nullptr;
+      u.n_begin = 0; u.n_end = D; u.nsplit = 1;
+      u.Gpart = Gpart + (int64_t)nsplit * ntiles * kPB * kPB;
+      u.bpart = bpart + (int64_t)nsplit * NC * kPB;
+      hipLaunchKernelGGL(gram_tile_kernel<T>, dim3(ntiles), dim3(kThreads), LC::LDS_BYTES, h->stream, u);
+    }
+  }
+  {
+    ReduceArgs<T> r{};
+    r.Gpart = Gpart; r.bpart = bpart; r.nsplit_total = nsplit_total; r.ntiles = ntiles; r.nblocks = NC;
+    r.Lw = Lw; r.ldl = a.ldl; r.prior_kind = a.prior_kind; r.D = D; r.DP = DP; r.Abar = Abar; r.lda = lda;
+    r.Lw_post = a.Lw_post ? a.Lw_post + reg * a.strideLp : nullptr; r.ldlp = a.ldlp;
+    hipLaunchKernelGGL(gram_reduce_kernel<T>, dim3(ntiles + NC), dim3(kThreads), 0, h->stream, r);
+  }
+
+  // ---- blocked Cholesky of Abar (rows DP.. = rhs) -> L, u  (reference :86, :57)
+  // a failed prior factorisation short-circuits everything: seed info_chol with it
+  HIP_TRY(h, hipMemcpyAsync(info_chol, info_prior, sizeof(int32_t), hipMemcpyDeviceToDevice, h->stream));
+  if ((rc = chol_large<T>(h, Abar, lda, DP, DP + kPB, info_chol))) return rc;
+
+  // ---- back substitution, posterior mean, evidence (reference :64, :68, :57)
+  {
+    BacksolveArgs<T> b{};
+    b.Abar = Abar; b.lda = lda; b.D = D; b.DP = DP; b.mw = mw;
+    b.mw_post = a.mw_post ? a.mw_post + reg * a.stride_mwpost : nullptr;
+    b.qpart = qpart; b.lpart = lpart; b.nparts = gridc; b.logdet_Lw = 0.0; b.logdet_Lw_dev = logdetLw;
+    b.noise_kind = a.noise_kind; b.s = s; b.N = N;
+    b.logpdf = a.logpdf ? a.logpdf + reg : nullptr; b.info = a.info + reg; b.chol_info = info_chol; b.mwork = mwork;
+    size_t lds = SC::LDS_BYTES + 2048;
+    if ((rc = set_lds<T>(h, reinterpret_cast<const void*>(backsolve_kernel<T>), lds))) return rc;
+    hipLaunchKernelGGL(backsolve_kernel<T>, dim3(1), dim3(kThreads), lds, h->stream, b);
+  }
+  if (a.T_post) {
+    dim3 grid((D + 31) / 32, (D + 31) / 32);
+    hipLaunchKernelGGL(transpose_out_kernel<T>, grid, dim3(kThreads), 0, h->stream, (const T*)Abar, lda, D,
+                       a.T_post + reg * a.strideT, a.ldt);
+  }
+  HIP_TRY(h, hipGetLastError());
+  return 0;
+}
+
+template <typename T>
+int dispatch_posterior(blr_handle* h, const PosteriorArgs<T>& a) {
+  if (a.D <= kMaxSmallD) return dispatch_fused_small<T>(h, a);
+  for (int64_t reg = 0; reg < a.B; ++reg) {
+    int rc = posterior_large_one<T>(h, a, reg);
+    if (rc) return rc;
+  }
+  return 0;
+}
+
 template <typename T>
 int posterior_batched(blr_handle* h, int memspace, int layout, int64_t B, int64_t D, int64_t N, const T* X,
                       int64_t ldx, int64_t strideX, const T* y, int64_t stridey, int noise_kind, const T* s,
@@ -168,7 +351,7 @@ int posterior_batched(blr_handle* h, int memspace, int layout, int64_t B, int64_
   if (layout != BLR_LAYOUT_COLVECS && layout != BLR_LAYOUT_ROWVECS) return bad_arg(h, 3, "unknown layout (reference :26-31)");
   if (B < 0) return bad_arg(h, 4, "B < 0");
   if (D < 1) return bad_arg(h, 5, "D < 1");
-  if (D > kMaxSmallD) return bad_arg(h, 5, "D > 128 is not supported by this build");
+  if (D > kMaxLargeD) return bad_arg(h, 5, "D > 8192 is not supported by this build");
   if (N < 0 || N > (1 << 30)) return bad_arg(h, 6, "N out of range");
   if (B == 0) return 0;
   if (N > 0 && !X) return bad_arg(h, 7, "X is NULL");
@@ -206,7 +389,7 @@ int posterior_batched(blr_handle* h, int memspace, int layout, int64_t B, int64_
     a.X = X; a.y = y; a.s = s; a.mw = mw; a.Lw = Lw;
     a.mw_post = mw_post; a.T_post = T_post; a.Lw_post = Lw_post; a.logpdf = logpdf; a.info = info;
     a.vec_ok = (layout == BLR_LAYOUT_COLVECS && D % Mfma<T>::VEC == 0 && aligned16(X, ldx, strideX)) ? 1 : 0;
-    int rc = dispatch_fused_small<T>(h, a);
+    int rc = dispatch_posterior<T>(h, a);
     if (rc) return rc;
     if (!h->async) HIP_TRY(h, hipStreamSynchronize(h->stream));
     return 0;
@@ -236,7 +419,7 @@ int posterior_batched(blr_handle* h, int memspace, int layout, int64_t B, int64_
     if (!a.y) a.y = a.mw;
   }
   a.vec_ok = (layout == BLR_LAYOUT_COLVECS && D % Mfma<T>::VEC == 0 && aligned16(a.X, ldx, strideX)) ? 1 : 0;
-  if ((rc = dispatch_fused_small<T>(h, a))) return rc;
+  if ((rc = dispatch_posterior<T>(h, a))) return rc;
   if (mw_post) HIP_TRY(h, hipMemcpyAsync(mw_post, a.mw_post, n_mw * sizeof(T), hipMemcpyDeviceToHost, h->stream));
   if (T_post) HIP_TRY(h, hipMemcpyAsync(T_post, a.T_post, n_T * sizeof(T), hipMemcpyDeviceToHost, h->stream));
   if (Lw_post) HIP_TRY(h, hipMemcpyAsync(Lw_post, a.Lw_post, n_Lp * sizeof(T), hipMemcpyDeviceToHost, h->stream));

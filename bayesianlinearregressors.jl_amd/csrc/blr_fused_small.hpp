@@ -221,14 +221,13 @@ __device__ __forceinline__ void stage_store(const StageRegs<T, NB>& r, T* __rest
 // by construction, which is exactly what the LDS-DMA destination requires: M0 base + lane * 16 B); the
 // per-lane GLOBAL address does the (column, row) -> fragment permutation.  No staging registers, no ds_write.
 // Lanes whose element is outside the matrix (row >= D or column >= N) write zeros with a plain ds_write.
-template <typename T, int NB>
+template <typename T, int NB, int KS = SmallCfg<T, NB>::KS>
 __device__ __forceinline__ void stage_glds(T* __restrict__ slot, const T* __restrict__ base, int64_t ld, int D, int ncols,
                                            int n0, int wave, int lane) {
-  using C = SmallCfg<T, NB>;
   constexpr int VEC = Mfma<T>::VEC;
   constexpr int FPG = (1024 / (int)sizeof(T)) / 64;  // fragments per wave-instruction: 2 (f64) / 4 (f32)
-  constexpr int NG = C::KS * NB / FPG;               // wave-instructions per stage
-  static_assert((C::KS * NB) % FPG == 0, "slot must be a whole number of 1 KiB pieces");
+  constexpr int NG = KS * NB / FPG;                  // wave-instructions per stage
+  static_assert((KS * NB) % FPG == 0, "slot must be a whole number of 1 KiB pieces");
   typedef T vecT __attribute__((ext_vector_type(VEC)));
   asm volatile("" : "+v"(lane));  // keep the index arithmetic inside the stage loop (see stage_load)
   const int e0 = lane * VEC;      // element offset inside the 1 KiB piece

@@ -1,0 +1,574 @@
+// Large-D path (D > 128): the same direct Gram form as blr_fused_small.hpp, split over workgroups.
+//
+//   colstats_kernel      mu_n = x_n'mw, r_n = (y_n - mu_n)/s_n, partial q = sum delta r, l = sum log s   (:82-84)
+//   gram_tile_kernel     128x128 macro tile of  sum_n x_n w_n x_n'  over one N-slice (split-K), MFMA 16x16x4,
+//                        X staged in fragment order by LDS-DMA; diagonal tiles also give  b_I = X_I r      (:86, :57)
+//   gram_reduce_kernel   fixed-order sum of the split partials + prior precision -> augmented matrix Abar
+//   chol_diag_kernel     in-LDS blocked Cholesky of one 128x128 diagonal block (phase_chol of the small path)
+//   trsm_block_kernel    X <- X L_pp^-T for one row block below the diagonal block: left-looking 16-column
+//                        chunks, MFMA for the inter-chunk update, one row per lane inside the chunk
+//   (trailing update)    gram_tile_kernel again, X := the finished panel of L, subtracting in place
+//   backsolve_kernel     m = L^-T u, logdet A, |u|^2, posterior mean, evidence
+//   transpose_out_kernel T = L' (upper, column-major) for the caller
+//
+// Abar is (DP + 128) x DP, column-major, ld = DP + 128, DP = 128 ceil(D/128): rows [0, DP) hold the lower
+// triangle of A (padding: unit diagonal), row DP holds b' -- the right-hand side is carried as one more ROW
+// of the matrix, so the panel TRSM and the trailing updates perform the forward substitution u = L^-1 b
+// without any extra kernel (same trick as the fused small-D kernel).
+#pragma once
+#include "blr_fused_small.hpp"
+
+namespace blr {
+
+constexpr int kPB = 128;  // panel / macro-tile edge
+
+template <typename T>
+struct LargeCfg {
+  static constexpr int KS = (sizeof(T) == 4) ? 8 : 4;   // k-steps per stage (32 / 16 columns)
+  static constexpr int NSC = 4 * KS;
+  static constexpr int SIDE = KS * 8 * 64;              // elements of one operand side per slot
+  static constexpr int SLOT = 2 * SIDE;                 // A side + B side
+  static constexpr int OFF_W = 2 * SLOT * (int)sizeof(T);          // wbuf[2][NSC], rbuf[2][NSC]
+  static constexpr int OFF_R = OFF_W + 2 * NSC * (int)sizeof(T);
+  static constexpr int OFF_RED = (OFF_R + 2 * NSC * (int)sizeof(T) + 15) & ~15;  // 16 x 128 doubles
+  static constexpr int LDS_BYTES = OFF_RED + 16 * 128 * 8;
+};
+
+// ---- column statistics -------------------------------------------------------------------------------------
+template <typename T>
+struct ColstatsArgs {
+  const T* X; int64_t ldx;
+  const T* y; const T* s; const T* mw;
+  T* r;               // [N]  delta_n / s_n
+  double* qpart;      // [gridDim.x]
+  double* lpart;      // [gridDim.x]
+  int layout, noise_kind, D, N;
+};
+
+template <typename T>
+__global__ __launch_bounds__(kThreads) void colstats_kernel(ColstatsArgs<T> a) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  T* const mwl = reinterpret_cast<T*>(smem);
+  double* const scr = reinterpret_cast<double*>(smem + (((size_t)a.D * sizeof(T) + 15) & ~(size_t)15));
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int D = a.D, N = a.N;
+  for (int d = tid; d < D; d += kThreads) mwl[d] = a.mw[d];
+  __syncthreads();
+  const bool diag = a.noise_kind == NOISE_DIAGONAL;
+  const T s_iso = diag ? T(1) : a.s[0];
+  double q = 0.0, l = 0.0;
+  if (a.layout == LAYOUT_COLVECS) {
+    // one column per wave: lanes stride over d (coalesced), fixed-order butterfly
+    for (int n = blockIdx.x * kWaves + wave; n < N; n += gridDim.x * kWaves) {
+      const T* col = a.X + (int64_t)n * a.ldx;
+      double mu = 0.0;
+      for (int d = lane; d < D; d += 64) mu += (double)col[d] * (double)mwl[d];
+      mu = wave_allreduce(mu);
+      const T sv = diag ? a.s[n] : s_iso;
+      const T delta = a.y[n] - (T)mu;
+      const T rn = delta / sv;
+      if (lane == 0) {
+        a.r[n] = rn;
+        q += (double)delta * (double)rn;
+        if (diag) l += log((double)sv);
+      }
+    }
+  } else {
+    // RowVecs: one column per thread, coalesced along n
+    for (int n = blockIdx.x * kThreads + tid; n < N; n += gridDim.x * kThreads) {
+      double mu = 0.0;
+      for (int d = 0; d < D; ++d) mu += (double)a.X[(int64_t)d * a.ldx + n] * (double)mwl[d];
+      const T sv = diag ? a.s[n] : s_iso;
+      const T delta = a.y[n] - (T)mu;
+      const T rn = delta / sv;
+      a.r[n] = rn;
+      q += (double)delta * (double)rn;
+      if (diag) l += log((double)sv);
+    }
+  }
+  q = block_allreduce(q, scr, tid);
+  l = block_allreduce(l, scr, tid);
+  if (tid == 0) { a.qpart[blockIdx.x] = q; a.lpart[blockIdx.x] = l; }
+}
+
+// ---- 128 x 128 macro tile of a (weighted) Gram matrix ---------------------------------------------------------
+// mode_out 0: write the tile (and, for diagonal tiles with r != NULL, b_I) to the split-partial workspace
+// mode_out 1: subtract the tile in place from C (trailing update of the blocked Cholesky; single split)
+template <typename T>
+struct GramTileArgs {
+  const T* X; int64_t ldx;   // operand matrix; element (d, n) at X[d + n*ldx] (ColVecs) or X[n + d*ldx] (RowVecs)
+  int layout;                // LAYOUT_COLVECS / LAYOUT_ROWVECS / 2 = upper factor as pseudo-columns (mask n <= d)
+  int use_dma;               // ColVecs, 16-byte aligned: LDS-DMA staging
+  const T* s; int noise_kind;  // weights w_n = 1/s_n; s == NULL: w = 1
+  const T* r;                // delta_n / s_n for the b partials (NULL: skip)
+  int D;                     // rows of the operand
+  int n_begin, n_end;        // column range of the whole contraction
+  int nsplit;                // split-K factor over [n_begin, n_end)
+  int tile_i0, tile_j0;      // first row-block / col-block index of the tile grid
+  int ntile_rows;            // tiles are enumerated over rows I >= J (lower) when tri != 0
+  int tri;                   // 1: lower-triangular enumeration t -> (I >= J); 0: column of tiles (I = i0 + t, J = j0);
+                             // 2: row of tiles (I = i0, J = j0 + t)
+  T* Gpart;                  // mode 0: [nsplit][ntiles][128*128] row-major (row = A-side row)
+  double* bpart;             // mode 0: [nsplit][nblocks][128]
+  int ntiles, nblocks;
+  T* C; int64_t ldc;         // mode 1: C[row + col*ldc] -= tile
+  int mode_out;
+};
+
+template <typename T>
+__global__ __launch_bounds__(kThreads, 2) void gram_tile_kernel(GramTileArgs<T> a) {
+  using L = LargeCfg<T>;
+  using acc4 = typename Mfma<T>::acc4;
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  T* const slot0 = reinterpret_cast<T*>(smem);
+  T* const wbuf = reinterpret_cast<T*>(smem + L::OFF_W);
+  T* const rbuf = reinterpret_cast<T*>(smem + L::OFF_R);
+  double* const red = reinterpret_cast<double*>(smem + L::OFF_RED);
+  int tid = threadIdx.x;
+  const int lane = tid & 63;
+  const int wave = uni(tid >> 6);
+  const int wr = wave >> 1, wc = wave & 1;
+
+  const int t = blockIdx.x % a.ntiles, sidx = blockIdx.x / a.ntiles;
+  int I, J;
+  if (a.tri == 1) {
+    int ii = 0;
+    while ((ii + 1) * (ii + 2) / 2 <= t) ++ii;
+    I = a.tile_i0 + ii;
+    J = a.tile_j0 + (t - ii * (ii + 1) / 2);
+  } else if (a.tri == 0) {
+    I = a.tile_i0 + t;
+    J = a.tile_j0;
+  } else {  // a row of tiles: fixed row block, column blocks j0 + t
+    I = a.tile_i0;
+    J = a.tile_j0 + t;
+  }
+  const bool diag_tile = (I == J);
+  const int rowA = I * kPB, rowB = J * kPB;
+  const int span = a.n_end - a.n_begin;
+  const int per = ((span + a.nsplit - 1) / a.nsplit + L::NSC - 1) / L::NSC * L::NSC;  // whole stages per split
+  const int c0 = a.n_begin + sidx * per;
+  const int c1 = min(a.n_end, c0 + per);
+  const int nstages = c1 > c0 ? (c1 - c0 + L::NSC - 1) / L::NSC : 0;
+  const bool diag_noise = a.noise_kind == NOISE_DIAGONAL;
+  const T s_iso = (a.s && !diag_noise) ? a.s[0] : T(1);
+  const bool want_b = diag_tile && a.r != nullptr && a.mode_out == 0;
+
+  acc4 acc[4][4];
+#pragma unroll
+  for (int i = 0; i < 4; ++i)
+#pragma unroll
+    for (int j = 0; j < 4; ++j)
+#pragma unroll
+      for (int v = 0; v < 4; ++v) acc[i][j][v] = T(0);
+  double bacc[8];
+#pragma unroll
+  for (int i = 0; i < 8; ++i) bacc[i] = 0.0;
+
+  // stage loader: one operand side (128 rows starting at row0) into dst
+  auto load_side = [&](T* dst, int row0, int n0) {
+    const int rows = min(kPB, a.D - row0);  // may be <= 0 for padding blocks: everything zero-filled
+    if (a.use_dma) {
+      stage_glds<T, 8, L::KS>(dst, a.X + row0, a.ldx, rows, c1, n0, wave, lane);
+    } else {
+      int tt = tid;
+      asm volatile("" : "+v"(tt));
+      for (int idx = tt; idx < L::SIDE; idx += kThreads) {
+        int d, nl;
+        if (a.layout == LAYOUT_COLVECS) { d = idx % kPB; nl = idx / kPB; }
+        else                            { nl = idx % L::NSC; d = idx / L::NSC; }
+        const int n = n0 + nl;
+        const int dg = row0 + d;
+        bool ok = d < rows && n < c1 && (a.layout != 2 || n <= dg);
+        int64_t addr = (a.layout == LAYOUT_COLVECS) ? (int64_t)n * a.ldx + dg : (int64_t)dg * a.ldx + n;
+        T v = a.X[ok ? addr : 0];
+        dst[frag_off(8, d, nl)] = ok ? v : T(0);
+      }
+    }
+  };
+  auto issue = [&](int st) {
+    const int n0 = c0 + st * L::NSC;
+    T* slot = slot0 + (st & 1) * L::SLOT;
+    load_side(slot, rowA, n0);
+    if (!diag_tile) load_side(slot + L::SIDE, rowB, n0);
+    if (tid < L::NSC) {
+      const int n = n0 + tid;
+      T wv = T(0), rv = T(0);
+      if (n < c1) {
+        wv = a.s ? T(1) / (diag_noise ? a.s[n] : s_iso) : T(1);
+        if (want_b) rv = a.r[n];
+      }
+      wbuf[(st & 1) * L::NSC + tid] = wv;
+      rbuf[(st & 1) * L::NSC + tid] = rv;
+    }
+  };
+
+  if (nstages > 0) issue(0);
+  for (int st = 0; st < nstages; ++st) {
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+    if (st + 1 < nstages) issue(st + 1);
+    const T* sA = slot0 + (st & 1) * L::SLOT;
+    const T* sB = diag_tile ? sA : sA + L::SIDE;
+    const T* wb = wbuf + (st & 1) * L::NSC;
+    const T* rb = rbuf + (st & 1) * L::NSC;
+#pragma unroll 2
+    for (int j = 0; j < L::KS; ++j) {
+      const T w = wb[4 * j + (lane >> 4)];
+      T fa[4], fb[4];
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+        fa[i] = sA[(j * 8 + 4 * wr + i) * 64 + lane] * w;
+        fb[i] = sB[(j * 8 + 4 * wc + i) * 64 + lane];
+      }
+#pragma unroll
+      for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int k = 0; k < 4; ++k) acc[i][k] = Mfma<T>::mma(fa[i], fb[k], acc[i][k]);
+      if (want_b && (j & 3) == wave) {
+        const T rn = rb[4 * j + (lane >> 4)];
+#pragma unroll
+        for (int i = 0; i < 8; ++i) bacc[i] += (double)sA[(j * 8 + i) * 64 + lane] * (double)rn;
+      }
+    }
+    // the barrier at the top of the next iteration protects the slot that issue(st + 2) overwrites
+  }
+
+  // ---- epilogue ------------------------------------------------------------------------------------------
+  if (a.mode_out == 0) {
+    T* out = a.Gpart + ((int64_t)sidx * a.ntiles + t) * (kPB * kPB);
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+      for (int k = 0; k < 4; ++k)
+#pragma unroll
+        for (int v = 0; v < 4; ++v) {
+          const int row = 16 * (4 * wr + i) + Mfma<T>::crow(lane, v);
+          const int col = 16 * (4 * wc + k) + (lane & 15);
+          out[row * kPB + col] = acc[i][k][v];
+        }
+    if (want_b) {
+      __syncthreads();
+      const int q = lane >> 4, r = lane & 15;
+#pragma unroll
+      for (int i = 0; i < 8; ++i) red[(wave * 4 + q) * kPB + 16 * i + r] = bacc[i];
+      __syncthreads();
+      if (tid < kPB) {
+        double sum = 0.0;
+#pragma unroll
+        for (int p = 0; p < 16; ++p) sum += red[p * kPB + tid];
+        a.bpart[((int64_t)sidx * a.nblocks + I) * kPB + tid] = sum;
+      }
+    }
+  } else {
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+      for (int k = 0; k < 4; ++k)
+#pragma unroll
+        for (int v = 0; v < 4; ++v) {
+          const int row = rowA + 16 * (4 * wr + i) + Mfma<T>::crow(lane, v);
+          const int col = rowB + 16 * (4 * wc + k) + (lane & 15);
+          if (!diag_tile || col <= row) a.C[(int64_t)col * a.ldc + row] -= acc[i][k][v];
+        }
+  }
+}
+
+// ---- split reduction + prior -> Abar ---------------------------------------------------------------------------
+template <typename T>
+struct ReduceArgs {
+  const T* Gpart; const double* bpart;
+  int nsplit_total;          // data splits (+1 if a prior-factor pseudo split is present)
+  int ntiles, nblocks;       // lower-triangular macro tiles, row blocks
+  const T* Lw; int64_t ldl; int prior_kind;
+  int D, DP;
+  T* Abar; int64_t lda;      // (DP + 128) x DP
+  T* Lw_post; int64_t ldlp;  // optional full symmetric copy of A (D x D)
+};
+
+template <typename T>
+__global__ __launch_bounds__(kThreads) void gram_reduce_kernel(ReduceArgs<T> a) {
+  const int t = blockIdx.x;  // macro tile, or ntiles + I for the rhs row of block I
+  const int tid = threadIdx.x;
+  if (t < a.ntiles) {
+    int ii = 0;
+    while ((ii + 1) * (ii + 2) / 2 <= t) ++ii;
+    const int I = ii, J = t - ii * (ii + 1) / 2;
+    for (int e = tid; e < kPB * kPB; e += kThreads) {
+      const int rl = e / kPB, cl = e % kPB;  // Gpart is row-major: consecutive threads -> consecutive columns
+      const int row = I * kPB + rl, col = J * kPB + cl;
+      if (col > row) continue;
+      T sum = T(0);
+      for (int sp = 0; sp < a.nsplit_total; ++sp) sum += a.Gpart[((int64_t)sp * a.ntiles + t) * (kPB * kPB) + e];  // fixed order
+      if (row < a.D) {
+        if (a.prior_kind == PRIOR_DENSE) sum += a.Lw[(int64_t)row * a.ldl + col];  // upper entry (col, row)
+        else if (a.prior_kind == PRIOR_DIAGONAL && row == col) sum += a.Lw[row];
+      } else {
+        sum = (row == col) ? T(1) : T(0);  // padding: unit diagonal
+      }
+      a.Abar[(int64_t)col * a.lda + row] = sum;
+      if (a.Lw_post && row < a.D) {
+        a.Lw_post[(int64_t)col * a.ldlp + row] = sum;
+        a.Lw_post[(int64_t)row * a.ldlp + col] = sum;
+      }
+    }
+  } else {
+    const int I = t - a.ntiles;
+    for (int e = tid; e < kPB * kPB; e += kThreads) {  // rhs row block: row 0 = b', the rest zero
+      const int rl = e % kPB, cl = e / kPB;
+      const int col = I * kPB + cl;
+      T v = T(0);
+      if (rl == 0 && col < a.D) {
+        double sum = 0.0;
+        for (int sp = 0; sp < a.nsplit_total; ++sp) sum += a.bpart[((int64_t)sp * a.nblocks + I) * kPB + cl];
+        v = (T)sum;
+      }
+      a.Abar[(int64_t)col * a.lda + a.DP + rl] = v;
+    }
+  }
+}
+
+// ---- diagonal block factorisation --------------------------------------------------------------------------------
+template <typename T>
+__global__ __launch_bounds__(kThreads) void chol_diag_kernel(T* Abar, int64_t lda, int p, int32_t* info, int info_base) {
+  using C = SmallCfg<T, 8>;
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  T* const P = reinterpret_cast<T*>(smem);
+  const int tid = threadIdx.x;
+  if (*info != 0) return;  // an earlier panel already failed
+  T* blk = Abar + (int64_t)p * kPB * lda + (int64_t)p * kPB;
+  for (int idx = tid; idx < kPB * kPB; idx += kThreads) {
+    const int c = idx / kPB, r = idx % kPB;
+    if (r >= c) P[pidx(r, c)] = blk[(int64_t)c * lda + r];
+  }
+  __syncthreads();
+  const int rc = phase_chol<T, 8>(smem, kPB, 0);
+  if (rc != 0) {
+    if (tid == 0) *info = info_base + p * kPB + rc;
+    return;
+  }
+  for (int idx = tid; idx < kPB * kPB; idx += kThreads) {
+    const int c = idx / kPB, r = idx % kPB;
+    if (r >= c) blk[(int64_t)c * lda + r] = P[pidx(r, c)];
+  }
+}
+
+// ---- X <- X L_pp^-T for one block of RB rows below the diagonal block ------------------------------------------------
+template <typename T>
+struct TrsmCfg {
+  static constexpr int RB = (sizeof(T) == 4) ? 128 : 64;   // rows per workgroup
+  static constexpr int LDX = kPB + 1;                      // padded row stride of the X image (conflict-free)
+  static constexpr int OFF_X = ((kPB * (kPB + 1) / 2) * (int)sizeof(T) + 15) & ~15;
+  static constexpr int OFF_DI = OFF_X + RB * LDX * (int)sizeof(T);
+  static constexpr int LDS_BYTES = ((OFF_DI + kPB * (int)sizeof(T)) + 15) & ~15;
+};
+
+template <typename T>
+__global__ __launch_bounds__(kThreads) void trsm_block_kernel(T* Abar, int64_t lda, int p, int row_begin, int nrows_total,
+                                                              const int32_t* info) {
+  using Cfg = TrsmCfg<T>;
+  using acc4 = typename Mfma<T>::acc4;
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  T* const P = reinterpret_cast<T*>(smem);                    // packed lower triangle of L_pp
+  T* const Xs = reinterpret_cast<T*>(smem + Cfg::OFF_X);      // [RB][LDX]
+  T* const dinv = reinterpret_cast<T*>(smem + Cfg::OFF_DI);   // 1 / L_pp[c][c]
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = uni(tid >> 6);
+  if (*info != 0) return;
+  const int r0 = row_begin + blockIdx.x * Cfg::RB;            // first global row of this block
+  const int nr = min(Cfg::RB, nrows_total - r0);
+  const T* Lpp = Abar + (int64_t)p * kPB * lda + (int64_t)p * kPB;
+  T* Xg = Abar + (int64_t)p * kPB * lda + r0;
+  for (int idx = tid; idx < kPB * kPB; idx += kThreads) {
+    const int c = idx / kPB, r = idx % kPB;
+    if (r >= c) P[pidx(r, c)] = Lpp[(int64_t)c * lda + r];
+  }
+  for (int idx = tid; idx < Cfg::RB * kPB; idx += kThreads) {
+    const int c = idx / Cfg::RB, r = idx % Cfg::RB;            // coalesced along rows
+    Xs[r * Cfg::LDX + c] = (r < nr) ? Xg[(int64_t)c * lda + r] : T(0);
+  }
+  __syncthreads();
+  if (tid < kPB) dinv[tid] = T(1) / P[pidx(tid, tid)];
+  __syncthreads();
+
+  const int fr = lane & 15, fq = lane >> 4;
+  for (int J = 0; J < 8; ++J) {
+    // (1) left-looking update of chunk J with the already solved chunks K < J (MFMA)
+    for (int ta = wave; ta < Cfg::RB / 16; ta += kWaves) {
+      acc4 acc;
+#pragma unroll
+      for (int v = 0; v < 4; ++v) acc[v] = Xs[(16 * ta + Mfma<T>::crow(lane, v)) * Cfg::LDX + 16 * J + (lane & 15)];
+      for (int K = 0; K < J; ++K) {
+#pragma unroll
+        for (int ks = 0; ks < 4; ++ks) {
+          const T fx = Xs[(16 * ta + fr) * Cfg::LDX + 16 * K + 4 * ks + fq];
+          const T fl = P[pidx(16 * J + fr, 16 * K + 4 * ks + fq)];
+          acc = Mfma<T>::mma(-fx, fl, acc);
+        }
+      }
+      // no other wave reads chunk J before the barrier, and this wave owns these 16 rows of it
+#pragma unroll
+      for (int v = 0; v < 4; ++v) Xs[(16 * ta + Mfma<T>::crow(lane, v)) * Cfg::LDX + 16 * J + (lane & 15)] = acc[v];
+    }
+    __syncthreads();
+    // (2) inside the chunk: one row per thread, 16 columns, multipliers broadcast from LDS
+    if (tid < Cfg::RB) {
+      T x[16];
+      T* xr = Xs + tid * Cfg::LDX + 16 * J;
+#pragma unroll
+      for (int c = 0; c < 16; ++c) x[c] = xr[c];
+#pragma unroll
+      for (int c = 0; c < 16; ++c) {
+        x[c] *= dinv[16 * J + c];
+#pragma unroll
+        for (int k = c + 1; k < 16; ++k) x[k] -= x[c] * P[pidx(16 * J + k, 16 * J + c)];
+      }
+#pragma unroll
+      for (int c = 0; c < 16; ++c) xr[c] = x[c];
+    }
+    __syncthreads();
+  }
+  for (int idx = tid; idx < Cfg::RB * kPB; idx += kThreads) {
+    const int c = idx / Cfg::RB, r = idx % Cfg::RB;
+    if (r < nr) Xg[(int64_t)c * lda + r] = Xs[r * Cfg::LDX + c];
+  }
+}
+
+// ---- back substitution, evidence, posterior mean (one workgroup) -------------------------------------------------------
+template <typename T>
+struct BacksolveArgs {
+  const T* Abar; int64_t lda; int D, DP;
+  const T* mw; T* mw_post;
+  const double* qpart; const double* lpart; int nparts;
+  double logdet_Lw; const double* logdet_Lw_dev;  // one of the two (device value wins when non-NULL)
+  int noise_kind; const T* s; int N;
+  double* logpdf; int32_t* info; const int32_t* chol_info;
+  T* mwork;  // [DP] scratch for m
+};
+
+template <typename T>
+__global__ __launch_bounds__(kThreads) void backsolve_kernel(BacksolveArgs<T> a) {
+  using C = SmallCfg<T, 8>;
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  T* const P = reinterpret_cast<T*>(smem);
+  T* const bvec = reinterpret_cast<T*>(smem + C::OFF_B);
+  double* const scr = reinterpret_cast<double*>(smem + C::OFF_SCR);
+  T* const part = reinterpret_cast<T*>(smem + C::LDS_BYTES);  // 2 x 128 partial dot products (extra 2 KiB requested at launch)
+  const int tid = threadIdx.x;
+  const int D = a.D, DP = a.DP, NC = DP / kPB;
+  const double kNaN = __longlong_as_double(0x7ff8000000000000LL);
+  if (*a.chol_info != 0) {
+    if (tid == 0) { *a.info = *a.chol_info; if (a.logpdf) *a.logpdf = kNaN; }
+    return;
+  }
+  // |u|^2 and logdet A first (u = row DP of the factored Abar)
+  double uu = 0.0, ld = 0.0;
+  for (int j = tid; j < D; j += kThreads) {
+    const double u = (double)a.Abar[(int64_t)j * a.lda + DP];
+    uu += u * u;
+    ld += log((double)a.Abar[(int64_t)j * a.lda + j]);
+  }
+  uu = block_allreduce(uu, scr, tid);
+  ld = 2.0 * block_allreduce(ld, scr, tid);
+
+  for (int p = NC - 1; p >= 0; --p) {
+    // v_p = u_p - sum_{rows below the block} L[row, p-cols]' m[row]   (columns are contiguous: coalesced)
+    const int c = tid & 127, half = tid >> 7;
+    const T* colp = a.Abar + (int64_t)(p * kPB + c) * a.lda;
+    T sum = T(0);
+    for (int row = (p + 1) * kPB + half; row < DP; row += 2) sum += colp[row] * a.mwork[row];
+    part[half * kPB + c] = sum;
+    // diagonal block -> packed LDS
+    const T* blk = a.Abar + (int64_t)p * kPB * a.lda + (int64_t)p * kPB;
+    for (int idx = tid; idx < kPB * kPB; idx += kThreads) {
+      const int cc = idx / kPB, r = idx % kPB;
+      if (r >= cc) P[pidx(r, cc)] = blk[(int64_t)cc * a.lda + r];
+    }
+    __syncthreads();
+    if (tid < kPB) bvec[tid] = a.Abar[(int64_t)(p * kPB + tid) * a.lda + DP] - (part[tid] + part[kPB + tid]);
+    __syncthreads();
+    phase_backsolve<T, 8>(smem, kPB);  // bvec <- L_pp^-T bvec
+    if (tid < kPB) a.mwork[p * kPB + tid] = bvec[tid];
+    __threadfence_block();
+    __syncthreads();
+  }
+  if (a.mw_post)
+    for (int j = tid; j < D; j += kThreads) a.mw_post[j] = a.mw[j] + a.mwork[j];
+  // evidence
+  double q = 0.0, l = 0.0;
+  for (int i = tid; i < a.nparts; i += kThreads) { q += a.qpart[i]; l += a.lpart[i]; }
+  q = block_allreduce(q, scr, tid);
+  l = block_allreduce(l, scr, tid);
+  if (tid == 0) {
+    *a.info = 0;
+    if (a.logpdf) {
+      const double LOG2PI = 1.8378770664093454835606594728112;
+      const double logdet_Sy = (a.noise_kind == NOISE_DIAGONAL) ? l : (double)a.N * log((double)a.s[0]);
+      const double ldw = a.logdet_Lw_dev ? *a.logdet_Lw_dev : a.logdet_Lw;
+      *a.logpdf = -0.5 * ((double)a.N * LOG2PI + logdet_Sy + q + ld - ldw - uu);
+    }
+  }
+}
+
+// logdet of a factored (DP x DP lower, ld) matrix restricted to the first D diagonal entries: 2 sum log L_ii
+template <typename T>
+__global__ __launch_bounds__(kThreads) void logdet_kernel(const T* Lf, int64_t ld, int D, double* out) {
+  __shared__ double scr[8];
+  double v = 0.0;
+  for (int j = threadIdx.x; j < D; j += kThreads) v += log((double)Lf[(int64_t)j * ld + j]);
+  v = block_allreduce(v, scr, threadIdx.x);
+  if (threadIdx.x == 0) *out = 2.0 * v;
+}
+
+// logdet of a diagonal (kind 2) or of an upper factor's diagonal (kind 1); info = first non-positive entry
+template <typename T>
+__global__ __launch_bounds__(kThreads) void prior_diag_kernel(const T* Lw, int64_t ldl, int kind, int D, double* out,
+                                                              int32_t* info) {
+  __shared__ double scr[8];
+  __shared__ int iscr[8];
+  double v = 0.0;
+  int bad = 0x7fffffff;
+  for (int j = threadIdx.x; j < D; j += kThreads) {
+    const T d = (kind == PRIOR_DIAGONAL) ? Lw[j] : Lw[(int64_t)j * ldl + j];
+    if (d > T(0)) v += log((double)d);
+    else bad = min(bad, j + 1);
+  }
+  bad = block_min_int(bad, iscr, threadIdx.x);
+  v = block_allreduce(v, scr, threadIdx.x);
+  if (threadIdx.x == 0) {
+    *out = (kind == PRIOR_DIAGONAL) ? v : 2.0 * v;
+    *info = (bad == 0x7fffffff) ? 0 : bad;
+  }
+}
+
+// dense symmetric prior (upper triangle read) -> lower triangle of a DP x DP work matrix with unit padding
+template <typename T>
+__global__ __launch_bounds__(kThreads) void prior_copy_kernel(const T* Lw, int64_t ldl, int D, int DP, T* W, int64_t ldw) {
+  for (int64_t e = (int64_t)blockIdx.x * kThreads + threadIdx.x; e < (int64_t)DP * DP; e += (int64_t)gridDim.x * kThreads) {
+    const int col = (int)(e / DP), row = (int)(e % DP);
+    if (row < col) continue;
+    T v;
+    if (row < D) v = Lw[(int64_t)row * ldl + col];  // upper entry (col, row)
+    else v = (row == col) ? T(1) : T(0);
+    W[(int64_t)col * ldw + row] = v;
+  }
+}
+
+// T = L' : upper factor, column-major, strictly-lower part zero
+template <typename T>
+__global__ __launch_bounds__(kThreads) void transpose_out_kernel(const T* Lf, int64_t ld, int D, T* Tout, int64_t ldt) {
+  __shared__ T tile[32][33];
+  const int bx = blockIdx.x * 32, by = blockIdx.y * 32;  // bx: row block of L, by: col block of L
+  const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;
+  for (int k = ty; k < 32; k += 8) {
+    const int row = bx + tx, col = by + k;
+    tile[k][tx] = (row < D && col < D && row >= col) ? Lf[(int64_t)col * ld + row] : T(0);
+  }
+  __syncthreads();
+  for (int k = ty; k < 32; k += 8) {
+    const int trow = by + tx, tcol = bx + k;  // T[trow, tcol] = L[tcol, trow]
+    if (trow < D && tcol < D) Tout[(int64_t)tcol * ldt + trow] = tile[tx][k];
+  }
+}
+
+}  // namespace blr

@@ -502,3 +502,76 @@ def test_full_size_properties_c2_batch(B):
     torch.testing.assert_close(lhs, rhs, rtol=1e-9, atol=1e-7)
     A_ref = torch.eye(D, dtype=torch.float64, device=dev)[None] + torch.einsum("bdn,ben->bde", Xm, Xm) / 0.09
     torch.testing.assert_close(A_all, A_ref, rtol=1e-11, atol=1e-9)
+
+
+# ---- large-D path (D > 128): split-K MFMA Gram tiles + blocked global Cholesky (BASELINE configs 3 and 5) ----------
+@pytest.mark.parametrize("N,D", [(50, 129), (300, 200), (1000, 256), (700, 300), (2500, 384)])
+@pytest.mark.parametrize("prior", ["diagonal", "dense", "pdmat"])
+def test_large_d_posterior_logpdf_f64(B, N, D, prior):
+    rng = _rng(5000 + N + D)
+    X = rng.standard_normal((D, N))
+    mw = rng.standard_normal(D)
+    s = np.exp(0.5 * rng.standard_normal(N))
+    y = X.T @ rng.standard_normal(D) + np.sqrt(s) * rng.standard_normal(N)
+    if prior == "diagonal":
+        dvec = np.exp(rng.standard_normal(D))
+        Lw, Lw_arg = np.diag(dvec), B.Diagonal(dvec)
+    else:
+        Bm = rng.standard_normal((D, D)) / np.sqrt(D)
+        Lw = Bm @ Bm.T + np.eye(D)
+        Lw_arg = Lw if prior == "dense" else B.PDMat(O.chol_upper(Lw))
+    mw_o, T_o, A_o, lp_o = O.posterior_logpdf_direct(mw, Lw, X, s, y)
+    f = B.BayesianLinearRegressor(mw, Lw_arg)
+    for x in (np.asfortranarray(X), B.RowVecs(np.asfortranarray(X.T))):  # ColVecs (LDS-DMA) and RowVecs (generic) loaders
+        fx = f(x, s)
+        assert B.logpdf(fx, y) == pytest.approx(lp_o, rel=1e-10)
+        fp = B.posterior(fx, y)
+        np.testing.assert_allclose(fp.mw, mw_o, rtol=1e-8, atol=1e-10)
+        if prior == "pdmat":
+            np.testing.assert_allclose(fp.Lw.U, T_o, rtol=1e-8, atol=1e-9)
+            assert np.all(np.tril(fp.Lw.U, -1) == 0)
+        else:
+            np.testing.assert_allclose(fp.Lw.toarray(), A_o, rtol=1e-10, atol=1e-10)
+    assert B.logpdf(f(np.asfortranarray(X), 0.3), y) == pytest.approx(O.logpdf_literal(mw, Lw, X, 0.3, y), rel=1e-10)
+    # sequential conditioning through the large path, carrying the factor (reference :93)
+    if prior == "pdmat":
+        N1 = N // 2
+        f1 = B.posterior(f(np.asfortranarray(X[:, :N1]), s[:N1]), y[:N1])
+        f2 = B.posterior(f1(np.asfortranarray(X[:, N1:]), s[N1:]), y[N1:])
+        np.testing.assert_allclose(f2.mw, mw_o, rtol=1e-8, atol=1e-10)
+
+
+def test_large_d_f32_c3_shape_reduced(B):
+    # BASELINE config 3 shape family (D=1024, diagonal noise, fp32) at a reduced N the oracle finishes in seconds
+    rng = _rng(6001)
+    D, N = 1024, 8192
+    X = rng.standard_normal((D, N)).astype(np.float32)
+    s = np.exp(0.3 * rng.standard_normal(N)).astype(np.float32)
+    y = (X.T.astype(float) @ rng.standard_normal(D) / np.sqrt(D) + np.sqrt(s) * rng.standard_normal(N)).astype(np.float32)
+    mw = np.zeros(D, dtype=np.float32)
+    dvec = np.ones(D, dtype=np.float32)
+    mw_o, T_o, A_o, lp_o = O.posterior_logpdf_direct(mw.astype(float), dvec.astype(float), X.astype(float), s.astype(float),
+                                                     y.astype(float))
+    f = B.BayesianLinearRegressor(mw, B.Diagonal(dvec))
+    fx = f(B.ColVecs(np.asfortranarray(X)), s)
+    lp = B.logpdf(fx, y)
+    assert lp == pytest.approx(lp_o, rel=2e-4)
+    fp = B.posterior(fx, y)
+    np.testing.assert_allclose(fp.mw, mw_o, rtol=2e-2, atol=2e-3)
+    np.testing.assert_allclose(fp.Lw.toarray(), A_o, rtol=2e-4, atol=2e-2)
+    assert B.logpdf(fx, y) == lp  # deterministic split-K reduction
+
+
+def test_large_d_not_spd(B):
+    rng = _rng(6002)
+    D, N = 200, 64
+    X = rng.standard_normal((D, N))
+    Lw = np.eye(D)
+    Lw[150, 150] = -1e6
+    f = B.BayesianLinearRegressor(np.zeros(D), Lw)
+    with pytest.raises(B.PosDefException) as ei:
+        B.logpdf(f(X, 0.5), np.zeros(N))
+    assert ei.value.info == 151
+    with pytest.raises(B.PosDefException) as ei:
+        B.posterior(B.BayesianLinearRegressor(np.zeros(D), B.Diagonal(-np.ones(D)))(X, 0.5), np.zeros(N))
+    assert ei.value.info == 1
