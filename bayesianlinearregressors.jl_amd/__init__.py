@@ -16,6 +16,7 @@ from .regressor import (
     FiniteGP,
     Normal,
     PDMat,
+    RandomFourierFeatures,
     RowVecs,
     Symmetric,
     cov,
@@ -35,5 +36,5 @@ from .regressor import (
 __all__ = [
     "logpdf", "rand", "mean", "std", "cov", "var", "BayesianLinearRegressor", "marginals", "posterior",
     "BasisFunctionRegressor", "ColVecs", "RowVecs", "Diagonal", "Symmetric", "PDMat", "Normal", "FiniteGP",
-    "BLRFunctionSample", "mean_and_var", "mean_and_cov", "rand_b", "logpdf_columns", "BLRError", "PosDefException",
+    "BLRFunctionSample", "RandomFourierFeatures", "mean_and_var", "mean_and_cov", "rand_b", "logpdf_columns", "BLRError", "PosDefException",
 ]

@@ -71,6 +71,12 @@ for _suf in ("f64", "f32"):
         [_H, _int, _int, _i64, _i64, _i64, _vp, _i64, _int, _vp, _int, _vp, _vp, _i64, _vp, _i64, _vp, _i64, _vp, _i64], _int)
     _SIGS[f"blr_sample_weights_{_suf}"] = (
         [_H, _int, _i64, _i64, _int, _vp, _vp, _i64, _vp, _i64, _vp, _i64], _int)
+    _fp = C.c_double if _suf == "f64" else C.c_float
+    _SIGS[f"blr_rff_features_{_suf}"] = (
+        [_H, _int, _i64, _i64, _i64, _vp, _i64, _vp, _i64, _vp, _fp, _vp, _i64], _int)
+    _SIGS[f"blr_posterior_rff_{_suf}"] = (
+        [_H, _int, _i64, _i64, _i64, _vp, _i64, _vp, _i64, _vp, _fp, _vp, _int, _vp, _int, _vp, _vp, _i64,
+         _vp, _vp, _i64, _vp, _i64, _vp, _vp], _int)
 
 EXPORTED_SYMBOLS = tuple(_SIGS)
 
@@ -216,6 +222,18 @@ class Handle:
         if rc > 0:
             raise PosDefException(rc)
         return rc
+
+    def rff_features(self, dtype, memspace, Din, D, N, Xin, ldxin, Omega, ldo, phase, scale, Phi, ldphi):
+        fn = getattr(self.lib, f"blr_rff_features_{suffix(dtype)}")
+        return self.check(fn(self._h, memspace, Din, D, N, _ptr(Xin), ldxin, _ptr(Omega), ldo, _ptr(phase), float(scale),
+                             _ptr(Phi), ldphi))
+
+    def posterior_rff(self, dtype, memspace, Din, D, N, Xin, ldxin, Omega, ldo, phase, scale, y, noise_kind, s, prior_kind,
+                      mw, Lw, ldl, mw_post, T_post, ldt, Lw_post, ldlp, logpdf, info):
+        fn = getattr(self.lib, f"blr_posterior_rff_{suffix(dtype)}")
+        return self.check(fn(self._h, memspace, Din, D, N, _ptr(Xin), ldxin, _ptr(Omega), ldo, _ptr(phase), float(scale),
+                             _ptr(y), noise_kind, _ptr(s), prior_kind, _ptr(mw), _ptr(Lw), ldl, _ptr(mw_post), _ptr(T_post),
+                             ldt, _ptr(Lw_post), ldlp, _ptr(logpdf), _ptr(info)))
 
     def logpdf_sum(self, memspace, B, logpdf, total):
         return self.check(self.lib.blr_logpdf_sum(self._h, memspace, B, _ptr(logpdf), _ptr(total)))

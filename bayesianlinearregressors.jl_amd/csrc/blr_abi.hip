@@ -28,6 +28,8 @@ struct blr_handle {
   std::vector<void*> staged;  // device buffers of the current HOST-memspace call
   char* ws = nullptr;          // grow-only scratch (factors, info)
   size_t ws_bytes = 0;
+  char* feat = nullptr;        // grow-only feature matrix of blr_posterior_rff_*
+  size_t feat_bytes = 0;
 };
 
 namespace {
@@ -214,7 +216,17 @@ int posterior_large_one(blr_handle* h, const PosteriorArgs<T>& a, int64_t reg) {
   const int64_t lda = DP + kPB;
   const int ntiles = NC * (NC + 1) / 2;
   const int nstage_cols = LC::NSC;
-  int nsplit = std::max(1, std::min((768 + ntiles - 1) / ntiles, (N + nstage_cols - 1) / nstage_cols));
+  // split-K factor: fill the 2 x 256 workgroup slots of the chip in whole rounds (576 workgroups on 512 slots
+  // would take two rounds for 1.125 rounds of work)
+  const int max_split = std::max(1, std::min(64, (N + nstage_cols - 1) / nstage_cols));
+  int nsplit = 1;
+  double best = 0.0;
+  for (int sp = 1; sp <= max_split; ++sp) {
+    const int wgs = ntiles * sp;
+    const int rounds = (wgs + 511) / 512;
+    const double eff = (double)wgs / (rounds * 512.0) - 0.002 * sp;  // mild preference for fewer partials
+    if (eff > best) { best = eff; nsplit = sp; }
+  }
   const bool prior_factor = a.prior_kind == PRIOR_UPPER_FACTOR;
   const int nsplit_total = nsplit + (prior_factor ? 1 : 0);
   const int gridc = 1024;
@@ -677,6 +689,138 @@ int rand_impl(blr_handle* h, int memspace, int layout, int64_t D, int64_t N, int
   return 0;
 }
 
+
+template <typename T>
+int rff_features(blr_handle* h, int memspace, int64_t Din, int64_t D, int64_t N, const T* Xin, int64_t ldxin,
+                 const T* Omega, int64_t ldo, const T* phase, T scale, T* Phi, int64_t ldphi) {
+  if (!h) return -1;
+  h->err.clear();
+  if (memspace != BLR_MEM_HOST && memspace != BLR_MEM_DEVICE) return bad_arg(h, 2, "memspace");
+  if (Din < 1) return bad_arg(h, 3, "Din < 1");
+  if (D < 1) return bad_arg(h, 4, "D < 1");
+  if (N < 0 || N > (1 << 30)) return bad_arg(h, 5, "N out of range");
+  if (N == 0) return 0;
+  if (!Xin) return bad_arg(h, 6, "Xin is NULL");
+  if (ldxin < Din) return bad_arg(h, 7, "ldxin < Din");
+  if (!Omega) return bad_arg(h, 8, "Omega is NULL");
+  if (ldo < Din) return bad_arg(h, 9, "ldo < Din");
+  if (!phase) return bad_arg(h, 10, "phase is NULL");
+  if (!Phi) return bad_arg(h, 12, "Phi is NULL");
+  if (ldphi < D) return bad_arg(h, 13, "ldphi < D");
+  HIP_TRY(h, hipSetDevice(h->device));
+  Staging guard(h);
+  const T *Xd = Xin, *Od = Omega, *Pd = phase;
+  T* Fd = Phi;
+  int rc;
+  if (memspace == BLR_MEM_HOST) {
+    if ((rc = stage_in(h, Xin, mat_extent(Din, N, ldxin), &Xd))) return rc;
+    if ((rc = stage_in(h, Omega, mat_extent(Din, D, ldo), &Od))) return rc;
+    if ((rc = stage_in(h, phase, (size_t)D, &Pd))) return rc;
+    if ((rc = stage_out_alloc(h, Phi, mat_extent(D, N, ldphi), &Fd))) return rc;
+  }
+  dim3 grid((unsigned)((D + kThreads - 1) / kThreads), (unsigned)((N + 15) / 16));
+  hipLaunchKernelGGL(rff_features_kernel<T>, grid, dim3(kThreads), 0, h->stream, Xd, ldxin, Od, ldo, Pd, scale, (int)Din,
+                     (int)D, (int)N, Fd, ldphi);
+  HIP_TRY(h, hipGetLastError());
+  if (memspace == BLR_MEM_HOST) {
+    HIP_TRY(h, hipMemcpyAsync(Phi, Fd, mat_extent(D, N, ldphi) * sizeof(T), hipMemcpyDeviceToHost, h->stream));
+    HIP_TRY(h, hipStreamSynchronize(h->stream));
+  } else if (!h->async) {
+    HIP_TRY(h, hipStreamSynchronize(h->stream));
+  }
+  return 0;
+}
+
+template <typename T>
+int posterior_rff(blr_handle* h, int memspace, int64_t Din, int64_t D, int64_t N, const T* Xin, int64_t ldxin,
+                  const T* Omega, int64_t ldo, const T* phase, T scale, const T* y, int noise_kind, const T* s,
+                  int prior_kind, const T* mw, const T* Lw, int64_t ldl, T* mw_post, T* T_post, int64_t ldt, T* Lw_post,
+                  int64_t ldlp, double* logpdf, int32_t* info) {
+  if (!h) return -1;
+  h->err.clear();
+  if (memspace != BLR_MEM_HOST && memspace != BLR_MEM_DEVICE) return bad_arg(h, 2, "memspace");
+  if (Din < 1) return bad_arg(h, 3, "Din < 1");
+  if (D < 1 || D > kMaxLargeD) return bad_arg(h, 4, "D out of range");
+  if (N < 0 || N > (1 << 30)) return bad_arg(h, 5, "N out of range");
+  if (N > 0 && !Xin) return bad_arg(h, 6, "Xin is NULL");
+  if (ldxin < Din) return bad_arg(h, 7, "ldxin < Din");
+  if (!Omega) return bad_arg(h, 8, "Omega is NULL");
+  if (ldo < Din) return bad_arg(h, 9, "ldo < Din");
+  if (!phase) return bad_arg(h, 10, "phase is NULL");
+  HIP_TRY(h, hipSetDevice(h->device));
+  const int64_t ldphi = (D + 3) / 4 * 4;  // keeps every feature column 16-byte aligned for the LDS-DMA loader
+  const size_t need = (size_t)ldphi * (size_t)std::max<int64_t>(N, 1) * sizeof(T);
+  if (need > h->feat_bytes) {
+    if (h->feat) {
+      HIP_TRY(h, hipStreamSynchronize(h->stream));
+      HIP_TRY(h, hipFree(h->feat));
+      h->feat = nullptr;
+      h->feat_bytes = 0;
+    }
+    HIP_TRY(h, hipMalloc((void**)&h->feat, need));
+    h->feat_bytes = need;
+  }
+  T* Phi = reinterpret_cast<T*>(h->feat);
+  const bool was_async = h->async;
+  int rc;
+  {
+    Staging guard(h);
+    const T *Xd = Xin, *Od = Omega, *Pd = phase;
+    if (memspace == BLR_MEM_HOST) {
+      if ((rc = stage_in(h, Xin, mat_extent(Din, N, ldxin), &Xd))) return rc;
+      if ((rc = stage_in(h, Omega, mat_extent(Din, D, ldo), &Od))) return rc;
+      if ((rc = stage_in(h, phase, (size_t)D, &Pd))) return rc;
+    }
+    if (N > 0) {
+      dim3 grid((unsigned)((D + kThreads - 1) / kThreads), (unsigned)((N + 15) / 16));
+      hipLaunchKernelGGL(rff_features_kernel<T>, grid, dim3(kThreads), 0, h->stream, Xd, ldxin, Od, ldo, Pd, scale,
+                         (int)Din, (int)D, (int)N, Phi, ldphi);
+      HIP_TRY(h, hipGetLastError());
+    }
+    if (memspace == BLR_MEM_HOST) HIP_TRY(h, hipStreamSynchronize(h->stream));  // staged inputs die with `guard`
+  }
+  if (memspace == BLR_MEM_DEVICE) {
+    return posterior_batched<T>(h, BLR_MEM_DEVICE, BLR_LAYOUT_COLVECS, 1, D, N, Phi, ldphi, 0, y, 0, noise_kind, s, 0,
+                                prior_kind, mw, 0, Lw, ldl, 0, mw_post, D, T_post, ldt, ldt * D, Lw_post, ldlp, ldlp * D,
+                                logpdf, info);
+  }
+  // host pointers for everything except Phi: stage the rest here, then run on device pointers
+  Staging guard(h);
+  PosteriorArgs<T> a{};
+  const T *yd, *sd, *mwd, *Lwd;
+  const size_t lw_one = prior_kind == BLR_PRIOR_DIAGONAL ? (size_t)D : mat_extent(D, D, ldl);
+  if (noise_kind != BLR_NOISE_ISOTROPIC && noise_kind != BLR_NOISE_DIAGONAL) return bad_arg(h, 13, "noise_kind");
+  if (!y && N > 0) return bad_arg(h, 12, "y is NULL");
+  if (!s) return bad_arg(h, 14, "s is NULL");
+  if (!mw) return bad_arg(h, 16, "mw is NULL");
+  if (!Lw) return bad_arg(h, 17, "Lw is NULL");
+  if (!info) return bad_arg(h, 25, "info is NULL");
+  if ((rc = stage_in(h, y, (size_t)N, &yd))) return rc;
+  if ((rc = stage_in(h, s, noise_kind == BLR_NOISE_DIAGONAL ? (size_t)N : 1, &sd))) return rc;
+  if ((rc = stage_in(h, mw, (size_t)D, &mwd))) return rc;
+  if ((rc = stage_in(h, Lw, lw_one, &Lwd))) return rc;
+  T *mwp = nullptr, *Tp = nullptr, *Ap = nullptr;
+  double* lpd = nullptr;
+  int32_t* infod = nullptr;
+  if ((rc = stage_out_alloc(h, mw_post, (size_t)D, &mwp))) return rc;
+  if ((rc = stage_out_alloc(h, T_post, mat_extent(D, D, ldt), &Tp))) return rc;
+  if ((rc = stage_out_alloc(h, Lw_post, mat_extent(D, D, ldlp), &Ap))) return rc;
+  if ((rc = stage_out_alloc(h, logpdf, 1, &lpd))) return rc;
+  if ((rc = stage_out_alloc(h, info, 1, &infod))) return rc;
+  h->async = true;
+  rc = posterior_batched<T>(h, BLR_MEM_DEVICE, BLR_LAYOUT_COLVECS, 1, D, N, Phi, ldphi, 0, yd ? yd : mwd, 0, noise_kind, sd,
+                            0, prior_kind, mwd, 0, Lwd, ldl, 0, mwp, D, Tp, ldt, ldt * D, Ap, ldlp, ldlp * D, lpd, infod);
+  h->async = was_async;
+  if (rc) return rc;
+  if (mw_post) HIP_TRY(h, hipMemcpyAsync(mw_post, mwp, (size_t)D * sizeof(T), hipMemcpyDeviceToHost, h->stream));
+  if (T_post) HIP_TRY(h, hipMemcpyAsync(T_post, Tp, mat_extent(D, D, ldt) * sizeof(T), hipMemcpyDeviceToHost, h->stream));
+  if (Lw_post) HIP_TRY(h, hipMemcpyAsync(Lw_post, Ap, mat_extent(D, D, ldlp) * sizeof(T), hipMemcpyDeviceToHost, h->stream));
+  if (logpdf) HIP_TRY(h, hipMemcpyAsync(logpdf, lpd, sizeof(double), hipMemcpyDeviceToHost, h->stream));
+  HIP_TRY(h, hipMemcpyAsync(info, infod, sizeof(int32_t), hipMemcpyDeviceToHost, h->stream));
+  HIP_TRY(h, hipStreamSynchronize(h->stream));
+  return 0;
+}
+
 }  // namespace
 
 // =======================================================================================================
@@ -715,6 +859,7 @@ int blr_destroy(blr_handle* h) {
   (void)hipSetDevice(h->device);
   (void)hipStreamSynchronize(h->stream);
   if (h->ws) (void)hipFree(h->ws);
+  if (h->feat) (void)hipFree(h->feat);
   if (h->ev0) (void)hipEventDestroy(h->ev0);
   if (h->ev1) (void)hipEventDestroy(h->ev1);
   if (h->own_stream) (void)hipStreamDestroy(h->own_stream);
@@ -820,6 +965,19 @@ int blr_timer_stop(blr_handle* h, float* elapsed_ms) {
   int blr_sample_weights_##SUF(blr_handle* h, int memspace, int64_t D, int64_t S, int prior_kind, const T* mw,      \
                                const T* Lw, int64_t ldl, const T* Z, int64_t ldz, T* W, int64_t ldw) {              \
     return sample_weights<T>(h, memspace, D, S, prior_kind, mw, Lw, ldl, Z, ldz, W, ldw);                           \
+  }                                                                                                                 \
+  int blr_rff_features_##SUF(blr_handle* h, int memspace, int64_t Din, int64_t D, int64_t N, const T* Xin,          \
+                             int64_t ldxin, const T* Omega, int64_t ldo, const T* phase, T scale, T* Phi,           \
+                             int64_t ldphi) {                                                                       \
+    return rff_features<T>(h, memspace, Din, D, N, Xin, ldxin, Omega, ldo, phase, scale, Phi, ldphi);               \
+  }                                                                                                                 \
+  int blr_posterior_rff_##SUF(blr_handle* h, int memspace, int64_t Din, int64_t D, int64_t N, const T* Xin,         \
+                              int64_t ldxin, const T* Omega, int64_t ldo, const T* phase, T scale, const T* y,      \
+                              int noise_kind, const T* s, int prior_kind, const T* mw, const T* Lw, int64_t ldl,    \
+                              T* mw_post, T* T_post, int64_t ldt, T* Lw_post, int64_t ldlp, double* logpdf,         \
+                              int32_t* info) {                                                                      \
+    return posterior_rff<T>(h, memspace, Din, D, N, Xin, ldxin, Omega, ldo, phase, scale, y, noise_kind, s,         \
+                            prior_kind, mw, Lw, ldl, mw_post, T_post, ldt, Lw_post, ldlp, logpdf, info);            \
   }
 
 BLR_DEFINE(f64, double)

@@ -188,6 +188,40 @@ __global__ __launch_bounds__(kThreads) void rand_project_kernel(const T* __restr
   }
 }
 
+// ---- random-Fourier feature map (BASELINE config 5): Phi[f, n] = scale * cos(sum_k Omega[k, f] x[k, n] + phase[f]) ----
+// The reference ships no feature maps (a BasisFunctionRegressor takes any callable, basis_function_regression.jl:7-9);
+// this is the phi of config 5.  Phi is written once (D x N, column-major) and then consumed by the plain path: the
+// Gram is MFMA-bound by two orders of magnitude at D = 2048, so regenerating features per macro tile (17x the cos
+// work) would cost more than the 2 x 128 MiB of extra traffic it saves.
+template <typename T>
+__global__ __launch_bounds__(kThreads) void rff_features_kernel(const T* __restrict__ Xin, int64_t ldxin,
+                                                                const T* __restrict__ Omega, int64_t ldo,
+                                                                const T* __restrict__ phase, T scale, int Din, int D, int N,
+                                                                T* __restrict__ Phi, int64_t ldphi) {
+  constexpr int NT = 16;  // columns per thread
+  const int f = blockIdx.x * kThreads + threadIdx.x;
+  const int n0 = blockIdx.y * NT;
+  if (f >= D) return;
+  T acc[NT];
+  const T ph = phase[f];
+#pragma unroll
+  for (int j = 0; j < NT; ++j) acc[j] = ph;
+  for (int k = 0; k < Din; ++k) {
+    const T om = Omega[(int64_t)f * ldo + k];
+#pragma unroll
+    for (int j = 0; j < NT; ++j) {
+      const int n = n0 + j;
+      const T xv = (n < N) ? Xin[(int64_t)n * ldxin + k] : T(0);  // wave-uniform address: one broadcast load
+      acc[j] += om * xv;
+    }
+  }
+#pragma unroll
+  for (int j = 0; j < NT; ++j) {
+    const int n = n0 + j;
+    if (n < N) Phi[(int64_t)n * ldphi + f] = scale * cos(acc[j]);
+  }
+}
+
 // ---- fixed-order sum of logpdf[B] --------------------------------------------------------
 // One workgroup.  Thread t sums elements t, t+256, ... in order, then a fixed tree over threads: the
 // result depends only on B and the values, never on launch geometry.

@@ -108,7 +108,7 @@ struct GramTileArgs {
   int ntile_rows;            // tiles are enumerated over rows I >= J (lower) when tri != 0
   int tri;                   // 1: lower-triangular enumeration t -> (I >= J); 0: column of tiles (I = i0 + t, J = j0);
                              // 2: row of tiles (I = i0, J = j0 + t)
-  T* Gpart;                  // mode 0: [nsplit][ntiles][128*128] row-major (row = A-side row)
+  T* Gpart;                  // mode 0: [nsplit][ntiles][128*128] column-major tiles (row = A-side row)
   double* bpart;             // mode 0: [nsplit][nblocks][128]
   int ntiles, nblocks;
   T* C; int64_t ldc;         // mode 1: C[row + col*ldc] -= tile
@@ -245,7 +245,7 @@ __global__ __launch_bounds__(kThreads, 2) void gram_tile_kernel(GramTileArgs<T> 
         for (int v = 0; v < 4; ++v) {
           const int row = 16 * (4 * wr + i) + Mfma<T>::crow(lane, v);
           const int col = 16 * (4 * wc + k) + (lane & 15);
-          out[row * kPB + col] = acc[i][k][v];
+          out[col * kPB + row] = acc[i][k][v];  // column-major tile: the reduce pass is coalesced both ways
         }
     if (want_b) {
       __syncthreads();
@@ -295,7 +295,7 @@ __global__ __launch_bounds__(kThreads) void gram_reduce_kernel(ReduceArgs<T> a) 
     while ((ii + 1) * (ii + 2) / 2 <= t) ++ii;
     const int I = ii, J = t - ii * (ii + 1) / 2;
     for (int e = tid; e < kPB * kPB; e += kThreads) {
-      const int rl = e / kPB, cl = e % kPB;  // Gpart is row-major: consecutive threads -> consecutive columns
+      const int rl = e % kPB, cl = e / kPB;  // column-major tiles: consecutive threads -> consecutive rows
       const int row = I * kPB + rl, col = J * kPB + cl;
       if (col > row) continue;
       T sum = T(0);
@@ -472,12 +472,18 @@ __global__ __launch_bounds__(kThreads) void backsolve_kernel(BacksolveArgs<T> a)
   ld = 2.0 * block_allreduce(ld, scr, tid);
 
   for (int p = NC - 1; p >= 0; --p) {
-    // v_p = u_p - sum_{rows below the block} L[row, p-cols]' m[row]   (columns are contiguous: coalesced)
-    const int c = tid & 127, half = tid >> 7;
-    const T* colp = a.Abar + (int64_t)(p * kPB + c) * a.lda;
-    T sum = T(0);
-    for (int row = (p + 1) * kPB + half; row < DP; row += 2) sum += colp[row] * a.mwork[row];
-    part[half * kPB + c] = sum;
+    // v_p = u_p - sum_{rows below the block} L[row, p-cols]' m[row]: one column per wave at a time, lanes stride
+    // the (contiguous) column, fixed-order butterfly
+    {
+      const int lane = tid & 63, wave = tid >> 6;
+      for (int c = wave; c < kPB; c += kWaves) {
+        const T* colp = a.Abar + (int64_t)(p * kPB + c) * a.lda;
+        double sum = 0.0;
+        for (int row = (p + 1) * kPB + lane; row < DP; row += 64) sum += (double)colp[row] * (double)a.mwork[row];
+        sum = wave_allreduce(sum);
+        if (lane == 0) { part[c] = (T)sum; part[kPB + c] = T(0); }
+      }
+    }
     // diagonal block -> packed LDS
     const T* blk = a.Abar + (int64_t)p * kPB * a.lda + (int64_t)p * kPB;
     for (int idx = tid; idx < kPB * kPB; idx += kThreads) {

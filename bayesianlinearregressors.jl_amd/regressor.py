@@ -22,7 +22,7 @@ import numpy as np
 from . import _abi
 
 __all__ = [
-    "ColVecs", "RowVecs", "Diagonal", "Symmetric", "PDMat", "Normal",
+    "ColVecs", "RowVecs", "Diagonal", "Symmetric", "PDMat", "Normal", "RandomFourierFeatures",
     "BayesianLinearRegressor", "BasisFunctionRegressor", "BLRFunctionSample", "FiniteGP",
     "mean", "var", "cov", "std", "mean_and_var", "mean_and_cov", "marginals", "rand", "rand_b", "logpdf", "posterior",
 ]
@@ -234,6 +234,43 @@ class BasisFunctionRegressor:
         return FiniteGP(self, x, Sy)
 
 
+class RandomFourierFeatures:
+    """phi(x) = scale * cos(Omega' x + phase): the random-Fourier basis of BASELINE config 5, usable as the `phi`
+    of a BasisFunctionRegressor (the reference accepts any callable, src/basis_function_regression.jl:7-9).
+    Omega is D_in x D.  Calling it materialises the features through the device kernel; `logpdf` / `posterior`
+    on a BasisFunctionRegressor with this phi take the fused path (features never leave the GPU)."""
+
+    def __init__(self, Omega, phase, scale=None):
+        self.Omega = np.asarray(Omega)
+        self.phase = np.asarray(phase)
+        if self.Omega.ndim != 2 or self.phase.shape != (self.Omega.shape[1],):
+            raise ValueError("Omega must be D_in x D and phase of length D")
+        self.scale = float(np.sqrt(2.0 / self.Omega.shape[1])) if scale is None else float(scale)
+
+    def _operands(self, x, dtype):
+        X, layout, ldx, Din, N = _x_layout(x, dtype)
+        if layout != _abi.LAYOUT_COLVECS:  # the feature kernel reads ColVecs inputs (D_in is tiny: one small copy)
+            X = np.asfortranarray(X if X.shape[0] == Din else X.T, dtype=dtype)
+            ldx = max(Din, 1)
+        if Din != self.Omega.shape[0]:
+            raise ValueError("input dimension != rows of Omega")
+        Om = np.asfortranarray(self.Omega, dtype=dtype)
+        ph = np.ascontiguousarray(self.phase, dtype=dtype)
+        return X, ldx, Din, N, Om, ph
+
+    def __call__(self, x):
+        dtype = _dtype_of(self.Omega, x.X if hasattr(x, "X") else x)
+        X, ldx, Din, N, Om, ph = self._operands(x, dtype)
+        D = Om.shape[1]
+        Phi = np.empty((D, N), dtype=dtype, order="F")
+        _handle().rff_features(dtype, _abi.MEM_HOST, Din, D, N, X, ldx, Om, max(Din, 1), ph, self.scale, Phi, max(D, 1))
+        if isinstance(x, RowVecs):
+            return RowVecs(Phi.T)
+        if isinstance(x, ColVecs):
+            return ColVecs(Phi)
+        return Phi
+
+
 class FiniteGP:
     """AbstractGPs.FiniteGP: a regressor evaluated at inputs x with observation-noise covariance Sy."""
 
@@ -268,7 +305,37 @@ def _wrap_like(prior_Lw, T, A):
 # ---------------------------------------------------------------------------------------------------
 # AbstractGPs API
 # ---------------------------------------------------------------------------------------------------
+def _fused_rff(fx, y, want_posterior):
+    """BasisFunctionRegressor with a RandomFourierFeatures phi: features + inference in one library call."""
+    bfr, rff, blr = fx.f, fx.f.phi, fx.f.blr
+    dtype = _dtype_of(blr.mw, y, rff.Omega)
+    X, ldx, Din, N, Om, ph = rff._operands(fx.x, dtype)
+    D = Om.shape[1]
+    y = np.ascontiguousarray(y, dtype=dtype)
+    if y.ndim != 1 or y.shape[0] != N:
+        raise ValueError("length(y) != size(fx.x.X, 2)")  # reference :74
+    mw = np.ascontiguousarray(blr.mw, dtype=dtype)
+    if mw.shape[0] != D:
+        raise ValueError("length(mw) != number of features")
+    s, noise_kind = _noise(fx.Sy, N, dtype)
+    Lw, prior_kind, ldl = _prior(blr.Lw, D, dtype)
+    lp = np.zeros(1, dtype=np.float64)
+    info = np.zeros(1, dtype=np.int32)
+    mw_post = T = A = None
+    if want_posterior:
+        mw_post = np.empty(D, dtype=dtype)
+        T = np.empty((D, D), dtype=dtype, order="F")
+        A = np.empty((D, D), dtype=dtype, order="F") if not isinstance(blr.Lw, PDMat) else None
+    _handle().posterior_rff(dtype, _abi.MEM_HOST, Din, D, N, X, ldx, Om, max(Din, 1), ph, rff.scale, y, noise_kind, s,
+                            prior_kind, mw, Lw, ldl, mw_post, T, max(D, 1), A, max(D, 1), lp, info)
+    if info[0] > 0:
+        raise _abi.PosDefException(int(info[0]))
+    return float(lp[0]), mw_post, T, A
+
+
 def _fused(fx, y, want_posterior):
+    if isinstance(fx.f, BasisFunctionRegressor) and isinstance(fx.f.phi, RandomFourierFeatures):
+        return _fused_rff(fx, y, want_posterior)
     fx = _to_finite_blr(fx)
     blr = fx.f
     dtype = _dtype_of(blr.mw, y)

@@ -165,6 +165,33 @@ int blr_sample_weights_f32(blr_handle* h, int memspace, int64_t D, int64_t S,
                            int prior_kind, const float* mw, const float* Lw, int64_t ldl,
                            const float* Z, int64_t ldz, float* W, int64_t ldw);
 
+/* ---- random-Fourier basis (BASELINE config 5): phi(x) = scale * cos(Omega' x + phase) ---------------------
+ * The reference's BasisFunctionRegressor takes any callable phi (src/basis_function_regression.jl:7-9,41) and ships
+ * none; this is the feature map of config 5, applied on the device so Phi never crosses PCIe.
+ *   Xin: Din x N column-major (ColVecs of the raw inputs), Omega: Din x D column-major, phase[D];
+ *   Phi : D x N column-major (ldphi >= D).
+ * blr_posterior_rff_* = features + fused inference in one call (Phi lives in the handle's workspace):
+ * the remaining arguments are those of blr_posterior_batched_* with B = 1.
+ */
+int blr_rff_features_f64(blr_handle* h, int memspace, int64_t Din, int64_t D, int64_t N,
+                         const double* Xin, int64_t ldxin, const double* Omega, int64_t ldo, const double* phase,
+                         double scale, double* Phi, int64_t ldphi);
+int blr_rff_features_f32(blr_handle* h, int memspace, int64_t Din, int64_t D, int64_t N,
+                         const float* Xin, int64_t ldxin, const float* Omega, int64_t ldo, const float* phase,
+                         float scale, float* Phi, int64_t ldphi);
+int blr_posterior_rff_f64(blr_handle* h, int memspace, int64_t Din, int64_t D, int64_t N,
+                          const double* Xin, int64_t ldxin, const double* Omega, int64_t ldo, const double* phase,
+                          double scale, const double* y, int noise_kind, const double* s,
+                          int prior_kind, const double* mw, const double* Lw, int64_t ldl,
+                          double* mw_post, double* T_post, int64_t ldt, double* Lw_post, int64_t ldlp,
+                          double* logpdf, int32_t* info);
+int blr_posterior_rff_f32(blr_handle* h, int memspace, int64_t Din, int64_t D, int64_t N,
+                          const float* Xin, int64_t ldxin, const float* Omega, int64_t ldo, const float* phase,
+                          float scale, const float* y, int noise_kind, const float* s,
+                          int prior_kind, const float* mw, const float* Lw, int64_t ldl,
+                          float* mw_post, float* T_post, int64_t ldt, float* Lw_post, int64_t ldlp,
+                          double* logpdf, int32_t* info);
+
 /* ---- sharded log-evidence: fixed-order sum of logpdf[B] on the device ----------
  * Deterministic (no float atomics): the same bits for the same B regardless of launch geometry.
  * The cross-rank step is one RCCL all-gather of these per-rank partials done by the host framework

@@ -575,3 +575,39 @@ def test_large_d_not_spd(B):
     with pytest.raises(B.PosDefException) as ei:
         B.posterior(B.BayesianLinearRegressor(np.zeros(D), B.Diagonal(-np.ones(D)))(X, 0.5), np.zeros(N))
     assert ei.value.info == 1
+
+
+@pytest.mark.parametrize("dtype,D,N", [(np.float64, 96, 300), (np.float64, 200, 500), (np.float32, 512, 2048)])
+def test_rff_basis_config5_family(B, dtype, D, N):
+    # BASELINE config 5 family: D_in = 8 -> D random-Fourier features, fused feature map + Gram.
+    # Parity: materialise Phi on the CPU, then run the plain path.
+    rng = _rng(7000 + D)
+    Din = 8
+    Xin = rng.standard_normal((Din, N)).astype(dtype)
+    Om = rng.standard_normal((Din, D)).astype(dtype)
+    beta = (2 * np.pi * rng.random(D)).astype(dtype)
+    scale = np.sqrt(2.0 / D)
+    Phi_ref = scale * np.cos(Om.astype(float).T @ Xin.astype(float) + beta.astype(float)[:, None])
+    s = np.exp(0.3 * rng.standard_normal(N)).astype(dtype)
+    y = (Phi_ref.T @ rng.standard_normal(D) + np.sqrt(s) * rng.standard_normal(N)).astype(dtype)
+    mw = (0.1 * rng.standard_normal(D)).astype(dtype)
+    dvec = np.ones(D, dtype=dtype)
+    rff = B.RandomFourierFeatures(Om, beta)
+    tol = 1e-12 if dtype == np.float64 else 2e-6
+    Phi = rff(B.ColVecs(np.asfortranarray(Xin))).X
+    assert Phi.dtype == dtype
+    np.testing.assert_allclose(Phi, Phi_ref, rtol=0, atol=tol)
+    np.testing.assert_allclose(rff(B.RowVecs(np.ascontiguousarray(Xin.T))).X, Phi_ref.T, rtol=0, atol=tol)
+    blr = B.BayesianLinearRegressor(mw, B.Diagonal(dvec))
+    bfr = B.BasisFunctionRegressor(blr, rff)
+    mw_o, T_o, A_o, lp_o = O.posterior_logpdf_direct(mw.astype(float), dvec.astype(float), Phi_ref, s.astype(float),
+                                                     y.astype(float))
+    rt_lp, rt = (1e-10, 1e-8) if dtype == np.float64 else (2e-4, 2e-2)
+    lp = B.logpdf(bfr(B.ColVecs(np.asfortranarray(Xin)), s), y)
+    assert lp == pytest.approx(lp_o, rel=rt_lp)
+    # BFR == BLR o phi (reference test/basis_function_regression.jl:13-28)
+    assert lp == pytest.approx(B.logpdf(blr(B.ColVecs(Phi), s), y), rel=1e-12 if dtype == np.float64 else 1e-5)
+    post = B.posterior(bfr(B.ColVecs(np.asfortranarray(Xin)), s), y)
+    assert isinstance(post, B.BasisFunctionRegressor) and post.phi is rff
+    np.testing.assert_allclose(post.blr.mw, mw_o, rtol=rt, atol=rt * 0.1)
+    np.testing.assert_allclose(post.blr.Lw.toarray(), A_o, rtol=rt_lp * 10, atol=rt * 0.1)
