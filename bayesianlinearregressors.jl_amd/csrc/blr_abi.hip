@@ -241,7 +241,7 @@ int posterior_large_one(blr_handle* h, const PosteriorArgs<T>& a, int64_t reg) {
   const size_t o_r = carve((size_t)std::max(N, 1) * sizeof(T));
   const size_t o_q = carve((size_t)gridc * sizeof(double));
   const size_t o_l = carve((size_t)gridc * sizeof(double));
-  const size_t o_m = carve((size_t)DP * sizeof(T));
+  const size_t o_m = carve((size_t)DP * DP * sizeof(T));  // transposed factor for the back substitution
   const size_t o_sc = carve(64);
   int rc = ensure_ws(h, off);
   if (rc) return rc;
@@ -253,7 +253,7 @@ int posterior_large_one(blr_handle* h, const PosteriorArgs<T>& a, int64_t reg) {
   T* rvec = reinterpret_cast<T*>(ws + o_r);
   double* qpart = reinterpret_cast<double*>(ws + o_q);
   double* lpart = reinterpret_cast<double*>(ws + o_l);
-  T* mwork = reinterpret_cast<T*>(ws + o_m);
+  T* Tfull = reinterpret_cast<T*>(ws + o_m);
   double* logdetLw = reinterpret_cast<double*>(ws + o_sc);
   int32_t* info_prior = reinterpret_cast<int32_t*>(ws + o_sc + 8);
   int32_t* info_chol = reinterpret_cast<int32_t*>(ws + o_sc + 12);
@@ -266,7 +266,6 @@ int posterior_large_one(blr_handle* h, const PosteriorArgs<T>& a, int64_t reg) {
 
   HIP_TRY(h, hipMemsetAsync(ws + o_sc, 0, 64, h->stream));
   HIP_TRY(h, hipMemsetAsync(bpart, 0, (size_t)nsplit_total * NC * kPB * sizeof(double), h->stream));
-  HIP_TRY(h, hipMemsetAsync(mwork, 0, (size_t)DP * sizeof(T), h->stream));
 
   // ---- prior: SPD check + logdet (reference :78)
   if (a.prior_kind == PRIOR_DENSE) {
@@ -312,7 +311,7 @@ int posterior_large_one(blr_handle* h, const PosteriorArgs<T>& a, int64_t reg) {
     r.Gpart = Gpart; r.bpart = bpart; r.nsplit_total = nsplit_total; r.ntiles = ntiles; r.nblocks = NC;
     r.Lw = Lw; r.ldl = a.ldl; r.prior_kind = a.prior_kind; r.D = D; r.DP = DP; r.Abar = Abar; r.lda = lda;
     r.Lw_post = a.Lw_post ? a.Lw_post + reg * a.strideLp : nullptr; r.ldlp = a.ldlp;
-    hipLaunchKernelGGL(gram_reduce_kernel<T>, dim3(ntiles + NC), dim3(kThreads), 0, h->stream, r);
+    hipLaunchKernelGGL(gram_reduce_kernel<T>, dim3(ntiles + NC, 16), dim3(kThreads), 0, h->stream, r);
   }
 
   // ---- blocked Cholesky of Abar (rows DP.. = rhs) -> L, u  (reference :86, :57)
@@ -320,22 +319,22 @@ int posterior_large_one(blr_handle* h, const PosteriorArgs<T>& a, int64_t reg) {
   HIP_TRY(h, hipMemcpyAsync(info_chol, info_prior, sizeof(int32_t), hipMemcpyDeviceToDevice, h->stream));
   if ((rc = chol_large<T>(h, Abar, lda, DP, DP + kPB, info_chol))) return rc;
 
-  // ---- back substitution, posterior mean, evidence (reference :64, :68, :57)
+  // ---- T = L' (for the caller and for the AXPY-form back substitution), then m, posterior mean, evidence
+  {
+    dim3 grid((DP + 31) / 32, (DP + 31) / 32);
+    hipLaunchKernelGGL(transpose_out_kernel<T>, grid, dim3(kThreads), 0, h->stream, (const T*)Abar, lda, DP, Tfull,
+                       (int64_t)DP, a.T_post ? a.T_post + reg * a.strideT : (T*)nullptr, a.ldt, D);
+  }
   {
     BacksolveArgs<T> b{};
-    b.Abar = Abar; b.lda = lda; b.D = D; b.DP = DP; b.mw = mw;
+    b.Abar = Abar; b.lda = lda; b.D = D; b.DP = DP; b.Tf = Tfull; b.ldtf = DP; b.mw = mw;
     b.mw_post = a.mw_post ? a.mw_post + reg * a.stride_mwpost : nullptr;
-    b.qpart = qpart; b.lpart = lpart; b.nparts = gridc; b.logdet_Lw = 0.0; b.logdet_Lw_dev = logdetLw;
+    b.qpart = qpart; b.lpart = lpart; b.nparts = gridc; b.logdet_Lw_dev = logdetLw;
     b.noise_kind = a.noise_kind; b.s = s; b.N = N;
-    b.logpdf = a.logpdf ? a.logpdf + reg : nullptr; b.info = a.info + reg; b.chol_info = info_chol; b.mwork = mwork;
-    size_t lds = SC::LDS_BYTES + 2048;
+    b.logpdf = a.logpdf ? a.logpdf + reg : nullptr; b.info = a.info + reg; b.chol_info = info_chol;
+    size_t lds = SC::LDS_BYTES + (size_t)DP * sizeof(T) + 16;
     if ((rc = set_lds<T>(h, reinterpret_cast<const void*>(backsolve_kernel<T>), lds))) return rc;
     hipLaunchKernelGGL(backsolve_kernel<T>, dim3(1), dim3(kThreads), lds, h->stream, b);
-  }
-  if (a.T_post) {
-    dim3 grid((D + 31) / 32, (D + 31) / 32);
-    hipLaunchKernelGGL(transpose_out_kernel<T>, grid, dim3(kThreads), 0, h->stream, (const T*)Abar, lda, D,
-                       a.T_post + reg * a.strideT, a.ldt);
   }
   HIP_TRY(h, hipGetLastError());
   return 0;

@@ -264,13 +264,27 @@ __global__ __launch_bounds__(kThreads, 2) void gram_tile_kernel(GramTileArgs<T> 
 #pragma unroll
     for (int i = 0; i < 4; ++i)
 #pragma unroll
-      for (int k = 0; k < 4; ++k)
+      for (int k = 0; k < 4; ++k) {
+        const int col = rowB + 16 * (4 * wc + k) + (lane & 15);
+        if constexpr (sizeof(T) == 4) {
+          // f32 C layout: a lane holds 4 CONSECUTIVE rows of one column -> one 16-byte read-modify-write
+          const int row0 = rowA + 16 * (4 * wr + i) + 4 * (lane >> 4);
+          if (!diag_tile || col <= row0 + 3) {
+            typedef float f4 __attribute__((ext_vector_type(4)));
+            f4* pc = reinterpret_cast<f4*>(a.C + (int64_t)col * a.ldc + row0);
+            f4 c = *pc;
 #pragma unroll
-        for (int v = 0; v < 4; ++v) {
-          const int row = rowA + 16 * (4 * wr + i) + Mfma<T>::crow(lane, v);
-          const int col = rowB + 16 * (4 * wc + k) + (lane & 15);
-          if (!diag_tile || col <= row) a.C[(int64_t)col * a.ldc + row] -= acc[i][k][v];
+            for (int v = 0; v < 4; ++v) c[v] -= acc[i][k][v];  // rows above the diagonal of a diagonal tile: never read
+            *pc = c;
+          }
+        } else {
+#pragma unroll
+          for (int v = 0; v < 4; ++v) {
+            const int row = rowA + 16 * (4 * wr + i) + Mfma<T>::crow(lane, v);
+            if (!diag_tile || col <= row) a.C[(int64_t)col * a.ldc + row] -= acc[i][k][v];
+          }
         }
+      }
   }
 }
 
@@ -290,11 +304,13 @@ template <typename T>
 __global__ __launch_bounds__(kThreads) void gram_reduce_kernel(ReduceArgs<T> a) {
   const int t = blockIdx.x;  // macro tile, or ntiles + I for the rhs row of block I
   const int tid = threadIdx.x;
+  constexpr int kChunk = kPB * kPB / 16;  // gridDim.y = 16 chunks per tile
+  const int e_begin = blockIdx.y * kChunk, e_end = e_begin + kChunk;
   if (t < a.ntiles) {
     int ii = 0;
     while ((ii + 1) * (ii + 2) / 2 <= t) ++ii;
     const int I = ii, J = t - ii * (ii + 1) / 2;
-    for (int e = tid; e < kPB * kPB; e += kThreads) {
+    for (int e = e_begin + tid; e < e_end; e += kThreads) {
       const int rl = e % kPB, cl = e / kPB;  // column-major tiles: consecutive threads -> consecutive rows
       const int row = I * kPB + rl, col = J * kPB + cl;
       if (col > row) continue;
@@ -314,7 +330,7 @@ __global__ __launch_bounds__(kThreads) void gram_reduce_kernel(ReduceArgs<T> a) 
     }
   } else {
     const int I = t - a.ntiles;
-    for (int e = tid; e < kPB * kPB; e += kThreads) {  // rhs row block: row 0 = b', the rest zero
+    for (int e = e_begin + tid; e < e_end; e += kThreads) {  // rhs row block: row 0 = b', the rest zero
       const int rl = e % kPB, cl = e / kPB;
       const int col = I * kPB + cl;
       T v = T(0);
@@ -435,15 +451,18 @@ __global__ __launch_bounds__(kThreads) void trsm_block_kernel(T* Abar, int64_t l
 }
 
 // ---- back substitution, evidence, posterior mean (one workgroup) -------------------------------------------------------
+// m = L^-T u on the TRANSPOSED factor Tf = L' (upper, column-major: transpose_full_kernel), bottom-up by 128-column
+// panels: m_p = T_pp^-1 u_p in LDS, then u[0 : 128p] -= Tf[0 : 128p, p-cols] m_p -- an AXPY form in which every
+// thread owns rows (coalesced column reads, many loads in flight, no cross-lane reduction).
 template <typename T>
 struct BacksolveArgs {
   const T* Abar; int64_t lda; int D, DP;
+  const T* Tf; int64_t ldtf;  // DP x DP upper factor
   const T* mw; T* mw_post;
   const double* qpart; const double* lpart; int nparts;
-  double logdet_Lw; const double* logdet_Lw_dev;  // one of the two (device value wins when non-NULL)
+  const double* logdet_Lw_dev;
   int noise_kind; const T* s; int N;
   double* logpdf; int32_t* info; const int32_t* chol_info;
-  T* mwork;  // [DP] scratch for m
 };
 
 template <typename T>
@@ -453,7 +472,7 @@ __global__ __launch_bounds__(kThreads) void backsolve_kernel(BacksolveArgs<T> a)
   T* const P = reinterpret_cast<T*>(smem);
   T* const bvec = reinterpret_cast<T*>(smem + C::OFF_B);
   double* const scr = reinterpret_cast<double*>(smem + C::OFF_SCR);
-  T* const part = reinterpret_cast<T*>(smem + C::LDS_BYTES);  // 2 x 128 partial dot products (extra 2 KiB requested at launch)
+  T* const uvec = reinterpret_cast<T*>(smem + C::LDS_BYTES);  // [DP] running right-hand side, then m
   const int tid = threadIdx.x;
   const int D = a.D, DP = a.DP, NC = DP / kPB;
   const double kNaN = __longlong_as_double(0x7ff8000000000000LL);
@@ -461,45 +480,50 @@ __global__ __launch_bounds__(kThreads) void backsolve_kernel(BacksolveArgs<T> a)
     if (tid == 0) { *a.info = *a.chol_info; if (a.logpdf) *a.logpdf = kNaN; }
     return;
   }
-  // |u|^2 and logdet A first (u = row DP of the factored Abar)
+  // u = row DP of the factored Abar; |u|^2 and logdet A
   double uu = 0.0, ld = 0.0;
-  for (int j = tid; j < D; j += kThreads) {
-    const double u = (double)a.Abar[(int64_t)j * a.lda + DP];
-    uu += u * u;
-    ld += log((double)a.Abar[(int64_t)j * a.lda + j]);
+  for (int j = tid; j < DP; j += kThreads) {
+    const T uj = (j < D) ? a.Abar[(int64_t)j * a.lda + DP] : T(0);
+    uvec[j] = uj;
+    if (j < D) {
+      uu += (double)uj * (double)uj;
+      ld += log((double)a.Abar[(int64_t)j * a.lda + j]);
+    }
   }
   uu = block_allreduce(uu, scr, tid);
   ld = 2.0 * block_allreduce(ld, scr, tid);
 
   for (int p = NC - 1; p >= 0; --p) {
-    // v_p = u_p - sum_{rows below the block} L[row, p-cols]' m[row]: one column per wave at a time, lanes stride
-    // the (contiguous) column, fixed-order butterfly
-    {
-      const int lane = tid & 63, wave = tid >> 6;
-      for (int c = wave; c < kPB; c += kWaves) {
-        const T* colp = a.Abar + (int64_t)(p * kPB + c) * a.lda;
-        double sum = 0.0;
-        for (int row = (p + 1) * kPB + lane; row < DP; row += 64) sum += (double)colp[row] * (double)a.mwork[row];
-        sum = wave_allreduce(sum);
-        if (lane == 0) { part[c] = (T)sum; part[kPB + c] = T(0); }
-      }
-    }
-    // diagonal block -> packed LDS
+    // diagonal block L_pp (lower) -> packed LDS; solve L_pp' m_p = u_p
     const T* blk = a.Abar + (int64_t)p * kPB * a.lda + (int64_t)p * kPB;
     for (int idx = tid; idx < kPB * kPB; idx += kThreads) {
       const int cc = idx / kPB, r = idx % kPB;
       if (r >= cc) P[pidx(r, cc)] = blk[(int64_t)cc * a.lda + r];
     }
-    __syncthreads();
-    if (tid < kPB) bvec[tid] = a.Abar[(int64_t)(p * kPB + tid) * a.lda + DP] - (part[tid] + part[kPB + tid]);
+    if (tid < kPB) bvec[tid] = uvec[p * kPB + tid];
     __syncthreads();
     phase_backsolve<T, 8>(smem, kPB);  // bvec <- L_pp^-T bvec
-    if (tid < kPB) a.mwork[p * kPB + tid] = bvec[tid];
-    __threadfence_block();
+    if (tid < kPB) uvec[p * kPB + tid] = bvec[tid];
+    __syncthreads();
+    // u[0 : 128p] -= Tf[0 : 128p, p-cols] m_p
+    const int nrows = p * kPB;
+    for (int r0 = 0; r0 < nrows; r0 += kThreads) {
+      const int r = r0 + tid;
+      if (r < nrows) {
+        const T* tp = a.Tf + (int64_t)p * kPB * a.ldtf + r;
+        T accv[4] = {T(0), T(0), T(0), T(0)};
+#pragma unroll 8
+        for (int c = 0; c < kPB; c += 4) {
+#pragma unroll
+          for (int k = 0; k < 4; ++k) accv[k] += tp[(int64_t)(c + k) * a.ldtf] * bvec[c + k];
+        }
+        uvec[r] -= (accv[0] + accv[1]) + (accv[2] + accv[3]);
+      }
+    }
     __syncthreads();
   }
   if (a.mw_post)
-    for (int j = tid; j < D; j += kThreads) a.mw_post[j] = a.mw[j] + a.mwork[j];
+    for (int j = tid; j < D; j += kThreads) a.mw_post[j] = a.mw[j] + uvec[j];
   // evidence
   double q = 0.0, l = 0.0;
   for (int i = tid; i < a.nparts; i += kThreads) { q += a.qpart[i]; l += a.lpart[i]; }
@@ -510,8 +534,7 @@ __global__ __launch_bounds__(kThreads) void backsolve_kernel(BacksolveArgs<T> a)
     if (a.logpdf) {
       const double LOG2PI = 1.8378770664093454835606594728112;
       const double logdet_Sy = (a.noise_kind == NOISE_DIAGONAL) ? l : (double)a.N * log((double)a.s[0]);
-      const double ldw = a.logdet_Lw_dev ? *a.logdet_Lw_dev : a.logdet_Lw;
-      *a.logpdf = -0.5 * ((double)a.N * LOG2PI + logdet_Sy + q + ld - ldw - uu);
+      *a.logpdf = -0.5 * ((double)a.N * LOG2PI + logdet_Sy + q + ld - *a.logdet_Lw_dev - uu);
     }
   }
 }
@@ -560,9 +583,10 @@ __global__ __launch_bounds__(kThreads) void prior_copy_kernel(const T* Lw, int64
   }
 }
 
-// T = L' : upper factor, column-major, strictly-lower part zero
+// T = L' : upper factor, column-major, strictly-lower part zero (Tout2 optional second destination, D2 x D2)
 template <typename T>
-__global__ __launch_bounds__(kThreads) void transpose_out_kernel(const T* Lf, int64_t ld, int D, T* Tout, int64_t ldt) {
+__global__ __launch_bounds__(kThreads) void transpose_out_kernel(const T* Lf, int64_t ld, int D, T* Tout, int64_t ldt,
+                                                                 T* Tout2, int64_t ldt2, int D2) {
   __shared__ T tile[32][33];
   const int bx = blockIdx.x * 32, by = blockIdx.y * 32;  // bx: row block of L, by: col block of L
   const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;
@@ -574,6 +598,7 @@ __global__ __launch_bounds__(kThreads) void transpose_out_kernel(const T* Lf, in
   for (int k = ty; k < 32; k += 8) {
     const int trow = by + tx, tcol = bx + k;  // T[trow, tcol] = L[tcol, trow]
     if (trow < D && tcol < D) Tout[(int64_t)tcol * ldt + trow] = tile[tx][k];
+    if (Tout2 && trow < D2 && tcol < D2) Tout2[(int64_t)tcol * ldt2 + trow] = tile[tx][k];
   }
 }
 
