@@ -30,8 +30,9 @@ struct LargeCfg {
   static constexpr int SLOT = 2 * SIDE;                 // A side + B side
   static constexpr int OFF_W = 2 * SLOT * (int)sizeof(T);          // wbuf[2][NSC], rbuf[2][NSC]
   static constexpr int OFF_R = OFF_W + 2 * NSC * (int)sizeof(T);
-  static constexpr int OFF_RED = (OFF_R + 2 * NSC * (int)sizeof(T) + 15) & ~15;  // 16 x 128 doubles
-  static constexpr int LDS_BYTES = OFF_RED + 16 * 128 * 8;
+  static constexpr int OFF_RED = 0;  // 16 x 128 doubles of b partials: aliases the slots (used after the last stage)
+  static constexpr int LDS_BYTES = (OFF_R + 2 * NSC * (int)sizeof(T) + 15) & ~15;
+  static_assert(2 * SLOT * (int)sizeof(T) >= 16 * 128 * 8, "b-partial scratch must fit in the slots");
 };
 
 // ---- column statistics -------------------------------------------------------------------------------------
@@ -212,15 +213,23 @@ __global__ __launch_bounds__(kThreads, 2) void gram_tile_kernel(GramTileArgs<T> 
     const T* sB = diag_tile ? sA : sA + L::SIDE;
     const T* wb = wbuf + (st & 1) * L::NSC;
     const T* rb = rbuf + (st & 1) * L::NSC;
-#pragma unroll 2
-    for (int j = 0; j < L::KS; ++j) {
-      const T w = wb[4 * j + (lane >> 4)];
-      T fa[4], fb[4];
+    // software pipeline: fragments of k-step j+1 are requested before the 16 MFMAs of k-step j issue
+    T na[4], nb[4], nw;
+    auto load_frags = [&](int j) {
+      nw = wb[4 * j + (lane >> 4)];
 #pragma unroll
       for (int i = 0; i < 4; ++i) {
-        fa[i] = sA[(j * 8 + 4 * wr + i) * 64 + lane] * w;
-        fb[i] = sB[(j * 8 + 4 * wc + i) * 64 + lane];
+        na[i] = sA[(j * 8 + 4 * wr + i) * 64 + lane];
+        nb[i] = sB[(j * 8 + 4 * wc + i) * 64 + lane];
       }
+    };
+    load_frags(0);
+#pragma unroll
+    for (int j = 0; j < L::KS; ++j) {
+      T fa[4], fb[4];
+#pragma unroll
+      for (int i = 0; i < 4; ++i) { fa[i] = na[i] * nw; fb[i] = nb[i]; }
+      if (j + 1 < L::KS) load_frags(j + 1);
 #pragma unroll
       for (int i = 0; i < 4; ++i)
 #pragma unroll
@@ -344,6 +353,36 @@ __global__ __launch_bounds__(kThreads) void gram_reduce_kernel(ReduceArgs<T> a) 
   }
 }
 
+
+// ---- block copies with many loads in flight -----------------------------------------------------------------------
+// A plain `for (idx = tid; ...) P[..] = g[..]` loop issues ONE global load per iteration and waits for it (~1-2 us
+// each): 64 iterations serialise to ~50 us for a 128 x 128 block.  These helpers issue 16 loads before the first use.
+template <typename T>
+__device__ __forceinline__ void load_lower_block_to_packed(T* __restrict__ P, const T* __restrict__ blk, int64_t ld, int tid) {
+#pragma unroll 1
+  for (int base = 0; base < kPB * kPB; base += kThreads * 16) {
+    T v[16];
+#pragma unroll
+    for (int u = 0; u < 16; ++u) {
+      const int idx = base + u * kThreads + tid;
+      v[u] = blk[(int64_t)(idx >> 7) * ld + (idx & 127)];
+    }
+#pragma unroll
+    for (int u = 0; u < 16; ++u) {
+      const int idx = base + u * kThreads + tid;
+      const int c = idx >> 7, r = idx & 127;
+      if (r >= c) P[pidx(r, c)] = v[u];
+    }
+  }
+}
+template <typename T>
+__device__ __forceinline__ void store_packed_to_lower_block(const T* __restrict__ P, T* __restrict__ blk, int64_t ld, int tid) {
+  for (int idx = tid; idx < kPB * kPB; idx += kThreads) {
+    const int c = idx >> 7, r = idx & 127;
+    if (r >= c) blk[(int64_t)c * ld + r] = P[pidx(r, c)];
+  }
+}
+
 // ---- diagonal block factorisation --------------------------------------------------------------------------------
 template <typename T>
 __global__ __launch_bounds__(kThreads) void chol_diag_kernel(T* Abar, int64_t lda, int p, int32_t* info, int info_base) {
@@ -353,20 +392,14 @@ __global__ __launch_bounds__(kThreads) void chol_diag_kernel(T* Abar, int64_t ld
   const int tid = threadIdx.x;
   if (*info != 0) return;  // an earlier panel already failed
   T* blk = Abar + (int64_t)p * kPB * lda + (int64_t)p * kPB;
-  for (int idx = tid; idx < kPB * kPB; idx += kThreads) {
-    const int c = idx / kPB, r = idx % kPB;
-    if (r >= c) P[pidx(r, c)] = blk[(int64_t)c * lda + r];
-  }
+  load_lower_block_to_packed(P, blk, lda, tid);
   __syncthreads();
   const int rc = phase_chol<T, 8>(smem, kPB, 0);
   if (rc != 0) {
     if (tid == 0) *info = info_base + p * kPB + rc;
     return;
   }
-  for (int idx = tid; idx < kPB * kPB; idx += kThreads) {
-    const int c = idx / kPB, r = idx % kPB;
-    if (r >= c) blk[(int64_t)c * lda + r] = P[pidx(r, c)];
-  }
+  store_packed_to_lower_block(P, blk, lda, tid);
 }
 
 // ---- X <- X L_pp^-T for one block of RB rows below the diagonal block ------------------------------------------------
@@ -395,13 +428,22 @@ __global__ __launch_bounds__(kThreads) void trsm_block_kernel(T* Abar, int64_t l
   const int nr = min(Cfg::RB, nrows_total - r0);
   const T* Lpp = Abar + (int64_t)p * kPB * lda + (int64_t)p * kPB;
   T* Xg = Abar + (int64_t)p * kPB * lda + r0;
-  for (int idx = tid; idx < kPB * kPB; idx += kThreads) {
-    const int c = idx / kPB, r = idx % kPB;
-    if (r >= c) P[pidx(r, c)] = Lpp[(int64_t)c * lda + r];
-  }
-  for (int idx = tid; idx < Cfg::RB * kPB; idx += kThreads) {
-    const int c = idx / Cfg::RB, r = idx % Cfg::RB;            // coalesced along rows
-    Xs[r * Cfg::LDX + c] = (r < nr) ? Xg[(int64_t)c * lda + r] : T(0);
+  load_lower_block_to_packed(P, Lpp, lda, tid);
+#pragma unroll 1
+  for (int base = 0; base < Cfg::RB * kPB; base += kThreads * 16) {  // X block, 16 loads in flight per thread
+    T v[16];
+#pragma unroll
+    for (int u = 0; u < 16; ++u) {
+      const int idx = base + u * kThreads + tid;
+      const int c = idx / Cfg::RB, r = idx % Cfg::RB;          // coalesced along rows
+      v[u] = Xg[(int64_t)c * lda + (r < nr ? r : 0)];
+    }
+#pragma unroll
+    for (int u = 0; u < 16; ++u) {
+      const int idx = base + u * kThreads + tid;
+      const int c = idx / Cfg::RB, r = idx % Cfg::RB;
+      Xs[r * Cfg::LDX + c] = (r < nr) ? v[u] : T(0);
+    }
   }
   __syncthreads();
   if (tid < kPB) dinv[tid] = T(1) / P[pidx(tid, tid)];
@@ -433,11 +475,15 @@ __global__ __launch_bounds__(kThreads) void trsm_block_kernel(T* Abar, int64_t l
       T* xr = Xs + tid * Cfg::LDX + 16 * J;
 #pragma unroll
       for (int c = 0; c < 16; ++c) x[c] = xr[c];
+      const int j0 = 16 * J;
 #pragma unroll
       for (int c = 0; c < 16; ++c) {
-        x[c] *= dinv[16 * J + c];
+        x[c] *= dinv[j0 + c];
 #pragma unroll
-        for (int k = c + 1; k < 16; ++k) x[k] -= x[c] * P[pidx(16 * J + k, 16 * J + c)];
+        for (int k = c + 1; k < 16; ++k) {
+          // pidx(j0 + k, j0 + c) = pidx(j0, j0) + k*j0 + k(k+1)/2 + c : one runtime multiply-free base per k
+          x[k] -= x[c] * P[pidx(j0, j0) + k * j0 + (k * (k + 1)) / 2 + c];
+        }
       }
 #pragma unroll
       for (int c = 0; c < 16; ++c) xr[c] = x[c];
@@ -496,10 +542,7 @@ __global__ __launch_bounds__(kThreads) void backsolve_kernel(BacksolveArgs<T> a)
   for (int p = NC - 1; p >= 0; --p) {
     // diagonal block L_pp (lower) -> packed LDS; solve L_pp' m_p = u_p
     const T* blk = a.Abar + (int64_t)p * kPB * a.lda + (int64_t)p * kPB;
-    for (int idx = tid; idx < kPB * kPB; idx += kThreads) {
-      const int cc = idx / kPB, r = idx % kPB;
-      if (r >= cc) P[pidx(r, cc)] = blk[(int64_t)cc * a.lda + r];
-    }
+    load_lower_block_to_packed(P, blk, a.lda, tid);
     if (tid < kPB) bvec[tid] = uvec[p * kPB + tid];
     __syncthreads();
     phase_backsolve<T, 8>(smem, kPB);  // bvec <- L_pp^-T bvec
