@@ -117,4 +117,29 @@ __device__ __forceinline__ int block_min_int(int v, int* scratch, int tid) {
 
 __host__ __device__ __forceinline__ int pidx(int i, int k) { return i * (i + 1) / 2 + k; }  // packed lower, k <= i
 
+// Reciprocal / reciprocal square root for the serial pivot chain of the blocked Cholesky: hardware seed plus
+// Newton steps (f32: 1, f64: 2) instead of the ~15-20-instruction IEEE division / square-root expansions.
+// Result within 1-2 ulp for normal positive inputs, which is all the pivot of an SPD matrix can be.
+__device__ __forceinline__ float fast_rcp(float x) {
+  float r = __builtin_amdgcn_rcpf(x);
+  return __builtin_fmaf(__builtin_fmaf(-x, r, 1.0f), r, r);
+}
+__device__ __forceinline__ double fast_rcp(double x) {
+  double r = __builtin_amdgcn_rcp(x);
+  r = __builtin_fma(__builtin_fma(-x, r, 1.0), r, r);
+  return __builtin_fma(__builtin_fma(-x, r, 1.0), r, r);
+}
+__device__ __forceinline__ float fast_rsqrt(float x) {
+  float y = __builtin_amdgcn_rsqf(x);
+  float h = 0.5f * x * y;
+  return __builtin_fmaf(__builtin_fmaf(-h, y, 0.5f), y, y);
+}
+__device__ __forceinline__ double fast_rsqrt(double x) {
+  double y = __builtin_amdgcn_rsq(x);
+  double h = 0.5 * x * y;
+  y = __builtin_fma(__builtin_fma(-h, y, 0.5), y, y);
+  h = 0.5 * x * y;
+  return __builtin_fma(__builtin_fma(-h, y, 0.5), y, y);
+}
+
 }  // namespace blr

@@ -43,6 +43,21 @@
 
 namespace blr {
 
+// BLR_STAMPS: diagnostic builds only (tools/chol_bench.hip) -- per-section cycle sums of phase_chol, wave 0
+#ifdef BLR_STAMPS
+__device__ unsigned long long g_stamps[8];
+#define BLR_STAMP(slot)                                                          \
+  do {                                                                           \
+    unsigned long long t__ = __builtin_amdgcn_s_memtime();                       \
+    if (threadIdx.x == 0) g_stamps[slot] += t__ - stamp_prev;                    \
+    stamp_prev = t__;                                                            \
+  } while (0)
+#define BLR_STAMP_INIT unsigned long long stamp_prev = __builtin_amdgcn_s_memtime()
+#else
+#define BLR_STAMP(slot) do {} while (0)
+#define BLR_STAMP_INIT do {} while (0)
+#endif
+
 template <typename T>
 struct PosteriorArgs {
   const T* X; int64_t ldx, strideX;
@@ -556,8 +571,11 @@ BLR_PHASE int phase_chol(char* smem, int D_in, int with_rhs_in) {
   }
 
   int info = 0;
+  BLR_STAMP_INIT;
+  BLR_STAMP(0);
   for (int J = 0; J < nblk; ++J) {
     __syncthreads();
+    BLR_STAMP(1);
     // (a) panel tiles -> packed LDS
 #pragma unroll
     for (int i = 0; i < C::TPW; ++i) {
@@ -572,6 +590,7 @@ BLR_PHASE int phase_chol(char* smem, int D_in, int with_rhs_in) {
       }
     }
     __syncthreads();
+    BLR_STAMP(2);
     // (b) one row per lane
     const bool is_diag = lane < 16;
     const int ri = is_diag ? 16 * J + lane : 16 * (J + 1) + 48 * wave + (lane - 16);
@@ -588,6 +607,10 @@ BLR_PHASE int phase_chol(char* smem, int D_in, int with_rhs_in) {
       }
       if (with_rhs && active) bl = bvec[ri];
     }
+    // Elimination with DEFERRED scaling: column c stays unscaled while it is being used (multiplier
+    // t = a_ic / d2, update a_ik -= t * a_kc, b_i -= t * b_c), so the serial chain per column is
+    // readlane -> reciprocal -> multiply -> fma; the square root is taken off the critical path afterwards.
+    T own_rsq = T(1);
 #pragma unroll
     for (int c = 0; c < 16; ++c) {
       if (c < ncols) {
@@ -595,20 +618,21 @@ BLR_PHASE int phase_chol(char* smem, int D_in, int with_rhs_in) {
         if (!(d2 > T(0))) {  // wave-uniform (SGPR) and identical in all four waves
           if (info == 0) info = 16 * J + c + 1;
         }
-        const T d = sqrt(d2);
-        const T rinv = T(1) / d;
-        const T uc = readlane(bl, c) * rinv;
-        const T lc = arow[c] * rinv;  // column c of L for this lane's row
-        arow[c] = (lane == c) ? d : lc;
-        if (lane == c) bl = uc;
-        else if (lane > c) bl -= lc * uc;
+        const T t = arow[c] * fast_rcp(d2);
+        const T bc = readlane(bl, c);
+        if (lane > c) bl -= t * bc;
 #pragma unroll
         for (int k = c + 1; k < 16; ++k) {
-          const T lk = readlane(arow[c], k);  // L[16J + k][16J + c]
-          arow[k] -= arow[c] * lk;
+          const T akc = readlane(arow[c], k);  // unscaled A[16J + k][16J + c]
+          arow[k] -= t * akc;
         }
+        const T rsq = fast_rsqrt(d2);
+        if (lane == c) own_rsq = rsq;
+        arow[c] = (lane == c) ? d2 * rsq : arow[c] * rsq;  // L[i][c] = a_ic / sqrt(d2); diagonal = sqrt(d2)
       }
     }
+    if (is_diag) bl *= own_rsq;  // u_c = b_c / L_cc for the diagonal-block rows
+    BLR_STAMP(3);
     if (info != 0) break;  // uniform across the block: every wave factors the same diagonal rows
     if (active) {
       T* dst = P + pidx(ri, 16 * J);
@@ -618,6 +642,7 @@ BLR_PHASE int phase_chol(char* smem, int D_in, int with_rhs_in) {
       if (with_rhs && (!is_diag || wave == 0)) bvec[ri] = bl;
     }
     __syncthreads();
+    BLR_STAMP(4);
     // (c) trailing update from the finished panel
     const int r = lane & 15, q = lane >> 4;
 #pragma unroll
@@ -633,6 +658,7 @@ BLR_PHASE int phase_chol(char* smem, int D_in, int with_rhs_in) {
         }
       }
     }
+    BLR_STAMP(5);
   }
   __syncthreads();
   return info;
