@@ -124,3 +124,37 @@ def test_wrapper_type_closure_and_exports():
     Z = R._randn(np.random.default_rng(0), 3, 4, np.float64)
     assert Z.shape == (3, 4) and Z.flags.f_contiguous
     np.testing.assert_array_equal(Z.ravel(order="F"), np.random.default_rng(0).standard_normal(12))
+
+
+def test_hot_kernels_keep_two_workgroups_per_cu(tmp_path):
+    """Regression guard (measured 475 k -> 351 k updates/s): the noinline phase functions are compiled once for all
+    their callers, so ONE caller without the 2-waves-per-SIMD launch bound makes hipcc budget them for 512 registers
+    and silently halves the occupancy of the fused kernel.  Read the register counts from the code object."""
+    import shutil
+    import subprocess
+
+    objdump = "/opt/rocm/lib/llvm/bin/llvm-objdump"
+    readelf = "/opt/rocm/lib/llvm/bin/llvm-readelf"
+    if not (os.path.exists(objdump) and os.path.exists(readelf)):
+        pytest.skip("ROCm LLVM tools not installed")
+    so = shutil.copy(_abi.LIB_PATH, tmp_path / "lib.so")
+    subprocess.run([objdump, "--offloading", str(so)], check=True, capture_output=True, cwd=tmp_path)
+    cos = [p for p in os.listdir(tmp_path) if "gfx950" in p]
+    assert cos, "no gfx950 code object in the library"
+    notes = subprocess.run([readelf, "--notes", str(tmp_path / cos[0])], check=True, capture_output=True, text=True).stdout
+    kernels = {}
+    cur = {}
+    for line in notes.splitlines():
+        m = re.match(r"\s+(?:- )?\.(agpr_count|vgpr_count|name):\s+(\S+)", line)
+        if not m:
+            continue
+        if m.group(1) == "agpr_count" and cur:
+            cur = {}
+        cur[m.group(1)] = m.group(2)
+        if len(cur) == 3:
+            kernels[cur["name"]] = int(cur["vgpr_count"]) + 0  # .vgpr_count already includes the AGPRs on gfx950
+            cur = {}
+    hot = {k: v for k, v in kernels.items() if "fused_small_kernel" in k or "gram_tile_kernel" in k}
+    assert len(hot) >= 60, f"expected the fused/gram kernels in the code object, found {len(hot)}"
+    over = {k: v for k, v in hot.items() if v > 256}
+    assert not over, f"kernels above 256 registers (1 workgroup per CU): {over}"
