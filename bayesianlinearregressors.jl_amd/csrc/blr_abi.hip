@@ -482,6 +482,72 @@ int prior_factor(blr_handle* h, int64_t B, int64_t D, int prior_kind, const T* L
   return 0;
 }
 
+
+// ---- large-D marginals: mean stream + (var) tall TRSM through the factorisation's panel machinery -------------------
+template <typename T>
+int marginals_large_one(blr_handle* h, int layout, int64_t D, int64_t N, const T* X, int64_t ldx, int noise_kind,
+                        const T* s, int prior_kind, const T* mw, const T* Lw, int64_t ldl, T* mean, T* var,
+                        int32_t* info_dev) {
+  using SC = SmallCfg<T, 8>;
+  using TC = TrsmCfg<T>;
+  using LC = LargeCfg<T>;
+  const int DP = (int)((D + kPB - 1) / kPB * kPB), NC = DP / kPB;
+  const int NP = (int)((N + kPB - 1) / kPB * kPB);
+  const int64_t ldy = (int64_t)DP + NP;
+  int rc;
+  HIP_TRY(h, hipMemsetAsync(info_dev, 0, sizeof(int32_t), h->stream));
+  const bool need_tall = var && prior_kind != BLR_PRIOR_DIAGONAL;
+  T* Ybar = nullptr;
+  if (need_tall) {
+    const size_t bytes = (size_t)ldy * DP * sizeof(T);
+    if ((rc = ensure_ws(h, bytes + 256))) return rc;
+    Ybar = reinterpret_cast<T*>(h->ws);
+  }
+  {
+    MeanFillArgs<T> m{};
+    m.X = X; m.ldx = ldx; m.layout = layout; m.mw = mw; m.mean = mean; m.Ybar = Ybar; m.ldy = ldy; m.row0 = DP;
+    m.D = (int)D; m.DP = DP; m.N = (int)N;
+    if (mean || Ybar)
+      hipLaunchKernelGGL(mean_fill_kernel<T>, dim3((unsigned)(NP / 64)), dim3(kThreads), 0, h->stream, m);
+  }
+  if (var && prior_kind == BLR_PRIOR_DIAGONAL) {
+    hipLaunchKernelGGL(var_diag_prior_kernel<T>, dim3(2048), dim3(kThreads), 0, h->stream, X, ldx, layout, Lw, (int)D, (int)N, s,
+                       noise_kind, var);
+  } else if (var) {
+    // top block: L = U' (upper factor given) or chol(Lw) (dense precision, reference :41 _cholesky(Lw))
+    if (prior_kind == BLR_PRIOR_UPPER_FACTOR) {
+      dim3 grid((DP + 31) / 32, (DP + 31) / 32);
+      hipLaunchKernelGGL(factor_transpose_fill_kernel<T>, grid, dim3(kThreads), 0, h->stream, Lw, ldl, (int)D, DP, Ybar, ldy);
+    } else {
+      hipLaunchKernelGGL(prior_copy_kernel<T>, dim3(1024), dim3(kThreads), 0, h->stream, Lw, ldl, (int)D, DP, Ybar, ldy);
+      if ((rc = chol_large<T>(h, Ybar, ldy, DP, DP, info_dev))) return rc;
+    }
+    if ((rc = set_lds<T>(h, reinterpret_cast<const void*>(trsm_block_kernel<T>), TC::LDS_BYTES))) return rc;
+    if ((rc = set_lds<T>(h, reinterpret_cast<const void*>(gram_tile_kernel<T>), LC::LDS_BYTES))) return rc;
+    const int nyb = NP / kPB;  // row blocks of the input part
+    for (int p = 0; p < NC; ++p) {
+      const int nblk = (NP + TC::RB - 1) / TC::RB;
+      hipLaunchKernelGGL(trsm_block_kernel<T>, dim3(nblk), dim3(kThreads), TC::LDS_BYTES, h->stream, Ybar, ldy, p, DP, DP + NP,
+                         (const int32_t*)info_dev);
+      const int m = NC - 1 - p;
+      if (m > 0) {
+        GramTileArgs<T> g{};
+        g.X = Ybar + (int64_t)p * kPB * ldy; g.ldx = ldy; g.layout = LAYOUT_COLVECS; g.use_dma = 1;
+        g.s = nullptr; g.noise_kind = NOISE_ISOTROPIC; g.r = nullptr;
+        g.D = DP + NP; g.n_begin = 0; g.n_end = kPB; g.nsplit = 1;
+        g.tile_i0 = NC; g.tile_j0 = p + 1; g.tri = 3; g.ntile_rows = nyb; g.ntiles = nyb * m; g.nblocks = NC + nyb;
+        g.C = Ybar; g.ldc = ldy; g.mode_out = 1;
+        hipLaunchKernelGGL(gram_tile_kernel<T>, dim3(g.ntiles), dim3(kThreads), LC::LDS_BYTES, h->stream, g);
+      }
+    }
+    hipLaunchKernelGGL(row_sumsq_kernel<T>, dim3((unsigned)((N + kThreads - 1) / kThreads)), dim3(kThreads), 0, h->stream,
+                       (const T*)Ybar, ldy, DP, (int)D, (int)N, s, noise_kind, var);
+  }
+  (void)sizeof(SC);
+  HIP_TRY(h, hipGetLastError());
+  return 0;
+}
+
 template <typename T>
 int marginals_batched(blr_handle* h, int memspace, int layout, int64_t B, int64_t D, int64_t N, const T* X, int64_t ldx,
                       int64_t strideX, int noise_kind, const T* s, int64_t strides, int prior_kind, const T* mw,
@@ -492,7 +558,7 @@ int marginals_batched(blr_handle* h, int memspace, int layout, int64_t B, int64_
   if (memspace != BLR_MEM_HOST && memspace != BLR_MEM_DEVICE) return bad_arg(h, 2, "memspace");
   if (layout != BLR_LAYOUT_COLVECS && layout != BLR_LAYOUT_ROWVECS) return bad_arg(h, 3, "unknown layout (reference :26-31)");
   if (B < 0) return bad_arg(h, 4, "B < 0");
-  if (D < 1 || D > kMaxSmallD) return bad_arg(h, 5, "D out of range for this build (1..128)");
+  if (D < 1 || D > kMaxLargeD) return bad_arg(h, 5, "D out of range for this build (1..8192)");
   if (N < 0 || N > (1 << 30)) return bad_arg(h, 6, "N out of range");
   if (B == 0 || N == 0) return 0;
   if (!X) return bad_arg(h, 7, "X is NULL");
@@ -529,6 +595,24 @@ int marginals_batched(blr_handle* h, int memspace, int layout, int64_t B, int64_
     if ((rc = stage_out_alloc(h, info, (size_t)B, &info_out_dev))) return rc;
   } else {
     a.X = X; a.s = s; a.mw = mw; a.mean = mean; a.var = var;
+  }
+  if (D > kMaxSmallD) {  // large-D path, one regressor at a time
+    for (int64_t reg = 0; reg < B; ++reg) {
+      rc = marginals_large_one<T>(h, layout, D, N, a.X + reg * strideX, ldx, noise_kind, a.s ? a.s + reg * strides : nullptr,
+                                  prior_kind, a.mw + reg * stridemw, Lw_dev ? Lw_dev + reg * strideLw : nullptr, ldl,
+                                  a.mean ? a.mean + reg * stridemean : nullptr, a.var ? a.var + reg * stridevar : nullptr,
+                                  info_out_dev + reg);
+      if (rc) return rc;
+    }
+    if (memspace == BLR_MEM_HOST) {
+      if (mean) HIP_TRY(h, hipMemcpyAsync(mean, a.mean, extent(B, stridemean, (size_t)N) * sizeof(T), hipMemcpyDeviceToHost, h->stream));
+      if (var) HIP_TRY(h, hipMemcpyAsync(var, a.var, extent(B, stridevar, (size_t)N) * sizeof(T), hipMemcpyDeviceToHost, h->stream));
+      HIP_TRY(h, hipMemcpyAsync(info, info_out_dev, (size_t)B * sizeof(int32_t), hipMemcpyDeviceToHost, h->stream));
+      HIP_TRY(h, hipStreamSynchronize(h->stream));
+    } else if (!h->async) {
+      HIP_TRY(h, hipStreamSynchronize(h->stream));
+    }
+    return 0;
   }
   int32_t* chol_info = nullptr;
   int kind = prior_kind;

@@ -736,8 +736,11 @@ __device__ __forceinline__ int chol_packed(T* __restrict__ P, T* __restrict__ di
 }
 
 // ---- the kernel -----------------------------------------------------------------------------------
+// Occupancy target: D <= 64 (NB <= 4) is HBM/latency-bound -- four workgroups per CU
+// (<= 128 registers, ~35 KB of LDS each) keep 4 x 16 KB of LDS-DMA in flight per CU; D > 64 is MFMA-bound and
+// needs the registers for accumulators: two workgroups per CU.
 template <typename T, int NB, int MODE /* data loader: 0 ColVecs generic, 1 RowVecs, 3 ColVecs vector regs, 4 ColVecs LDS-DMA */>
-__global__ __launch_bounds__(kThreads, 2) void fused_small_kernel(PosteriorArgs<T> a) {
+__global__ __launch_bounds__(kThreads, (NB <= 4 ? 4 : 2)) void fused_small_kernel(PosteriorArgs<T> a) {
   using C = SmallCfg<T, NB>;
   extern __shared__ __attribute__((aligned(16))) char smem[];
   T* const P = reinterpret_cast<T*>(smem);

@@ -108,7 +108,7 @@ struct GramTileArgs {
   int tile_i0, tile_j0;      // first row-block / col-block index of the tile grid
   int ntile_rows;            // tiles are enumerated over rows I >= J (lower) when tri != 0
   int tri;                   // 1: lower-triangular enumeration t -> (I >= J); 0: column of tiles (I = i0 + t, J = j0);
-                             // 2: row of tiles (I = i0, J = j0 + t)
+                             // 2: row of tiles (I = i0, J = j0 + t); 3: rectangle of ntile_rows x (ntiles / ntile_rows) tiles
   T* Gpart;                  // mode 0: [nsplit][ntiles][128*128] column-major tiles (row = A-side row)
   double* bpart;             // mode 0: [nsplit][nblocks][128]
   int ntiles, nblocks;
@@ -140,9 +140,12 @@ __global__ __launch_bounds__(kThreads, 2) void gram_tile_kernel(GramTileArgs<T> 
   } else if (a.tri == 0) {
     I = a.tile_i0 + t;
     J = a.tile_j0;
-  } else {  // a row of tiles: fixed row block, column blocks j0 + t
+  } else if (a.tri == 2) {  // a row of tiles: fixed row block, column blocks j0 + t
     I = a.tile_i0;
     J = a.tile_j0 + t;
+  } else {  // rectangle: ntile_rows row blocks x (ntiles / ntile_rows) column blocks
+    I = a.tile_i0 + t % a.ntile_rows;
+    J = a.tile_j0 + t / a.ntile_rows;
   }
   const bool diag_tile = (I == J);
   const int rowA = I * kPB, rowB = J * kPB;
@@ -646,6 +649,131 @@ __global__ __launch_bounds__(kThreads) void transpose_out_kernel(const T* Lf, in
     const int trow = by + tx, tcol = bx + k;  // T[trow, tcol] = L[tcol, trow]
     if (trow < D && tcol < D) Tout[(int64_t)tcol * ldt + trow] = tile[tx][k];
     if (Tout2 && trow < D2 && tcol < D2) Tout2[(int64_t)tcol * ldt2 + trow] = tile[tx][k];
+  }
+}
+
+// ---- large-D marginal stream ( reference :33, :40-43 ) ------------------------------------------------------------------
+// mean_n = x_n'mw is a GEMV stream.  var_n = |L^-1 x_n|^2 + s_n with L = U' needs the triangular solve for every
+// input: the inputs are laid out as ROWS below L in one tall matrix  Ybar = [L ; X']  and pushed through the same
+// panel machinery as the rhs row of the factorisation (trsm_block_kernel + MFMA trailing updates), giving
+// Y = X' L^-T; the variance is the row sum of squares.
+
+// element (d, n) of X -> mean[n]; also (optionally) writes row DP + n of Ybar (transpose fill) -- one pass over X
+template <typename T>
+struct MeanFillArgs {
+  const T* X; int64_t ldx; int layout;
+  const T* mw; T* mean;          // mean may be NULL
+  T* Ybar; int64_t ldy; int row0;  // Ybar may be NULL
+  int D, DP, N;
+};
+
+template <typename T>
+__global__ __launch_bounds__(kThreads) void mean_fill_kernel(MeanFillArgs<T> a) {
+  __shared__ T tile[64][65];
+  const int tid = threadIdx.x;
+  const int n0 = blockIdx.x * 64;
+  const int tn = tid & 63, tq = tid >> 6;
+  double macc = 0.0;  // thread (tn, tq) accumulates mean of column n0 + tn over d = tq, tq + 4, ...
+  for (int d0 = 0; d0 < a.DP; d0 += 64) {
+    __syncthreads();
+    // load a 64 (d) x 64 (n) tile, coalesced along the contiguous axis of the layout
+    for (int e = tid; e < 64 * 64; e += kThreads) {
+      int dd, nn;
+      if (a.layout == LAYOUT_COLVECS) { dd = e & 63; nn = e >> 6; }
+      else                            { nn = e & 63; dd = e >> 6; }
+      const int d = d0 + dd, n = n0 + nn;
+      T v = T(0);
+      if (d < a.D && n < a.N) v = (a.layout == LAYOUT_COLVECS) ? a.X[(int64_t)n * a.ldx + d] : a.X[(int64_t)d * a.ldx + n];
+      tile[dd][nn] = v;
+    }
+    __syncthreads();
+    if (a.mean) {
+      for (int dd = tq; dd < 64; dd += 4) {
+        const int d = d0 + dd;
+        if (d < a.D) macc += (double)tile[dd][tn] * (double)a.mw[d];
+      }
+    }
+    if (a.Ybar) {  // Ybar[row0 + n, d]: consecutive threads -> consecutive n (rows): coalesced
+      for (int e = tid; e < 64 * 64; e += kThreads) {
+        const int nn = e & 63, dd = e >> 6;
+        const int d = d0 + dd, n = n0 + nn;
+        if (d < a.DP) a.Ybar[(int64_t)d * a.ldy + a.row0 + n] = tile[dd][nn];  // padding rows/cols are zero
+      }
+    }
+  }
+  if (a.mean) {
+    __syncthreads();
+    double* red = reinterpret_cast<double*>(&tile[0][0]);  // 4 x 64 doubles fit easily
+    red[tq * 64 + tn] = macc;
+    __syncthreads();
+    if (tq == 0 && n0 + tn < a.N) a.mean[n0 + tn] = (T)(((red[tn] + red[64 + tn]) + red[128 + tn]) + red[192 + tn]);
+  }
+}
+
+// L = U' into the top DP x DP block of Ybar (lower, unit padding); U upper column-major (ldu)
+template <typename T>
+__global__ __launch_bounds__(kThreads) void factor_transpose_fill_kernel(const T* U, int64_t ldu, int D, int DP, T* Ybar,
+                                                                         int64_t ldy) {
+  __shared__ T tile[32][33];
+  const int bx = blockIdx.x * 32, by = blockIdx.y * 32;  // bx: row block of L, by: col block of L
+  const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;
+  for (int k = ty; k < 32; k += 8) {
+    const int ur = by + tx, uc = bx + k;  // U[ur, uc] = L[uc, ur]; coalesced along ur
+    tile[k][tx] = (ur < D && uc < D && ur <= uc) ? U[(int64_t)uc * ldu + ur] : T(0);
+  }
+  __syncthreads();
+  for (int k = ty; k < 32; k += 8) {
+    const int row = bx + tx, col = by + k;  // L[row, col] = U[col, row] = tile[tx][k]
+    if (row < DP && col < DP) {
+      T v = tile[tx][k];
+      if (row >= D || col >= D) v = (row == col) ? T(1) : T(0);
+      if (row >= col) Ybar[(int64_t)col * ldy + row] = v;
+    }
+  }
+}
+
+// var[n] = sum_{d < D} Y[row0 + n, d]^2 + s_n
+template <typename T>
+__global__ __launch_bounds__(kThreads) void row_sumsq_kernel(const T* Ybar, int64_t ldy, int row0, int D, int N, const T* s,
+                                                             int noise_kind, T* var) {
+  const int n = blockIdx.x * kThreads + threadIdx.x;  // consecutive threads -> consecutive rows: coalesced per column
+  if (n >= N) return;
+  double acc[4] = {0.0, 0.0, 0.0, 0.0};
+  const T* p = Ybar + row0 + n;
+  int d = 0;
+  for (; d + 4 <= D; d += 4) {
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+      const double v = (double)p[(int64_t)(d + k) * ldy];
+      acc[k] += v * v;
+    }
+  }
+  for (; d < D; ++d) {
+    const double v = (double)p[(int64_t)d * ldy];
+    acc[0] += v * v;
+  }
+  var[n] = (T)((acc[0] + acc[1]) + (acc[2] + acc[3])) + ((noise_kind == NOISE_DIAGONAL) ? s[n] : s[0]);
+}
+
+// diagonal prior: var[n] = sum_d x[d,n]^2 / dprior[d] + s_n  (pure stream)
+template <typename T>
+__global__ __launch_bounds__(kThreads) void var_diag_prior_kernel(const T* X, int64_t ldx, int layout, const T* dprior, int D,
+                                                                  int N, const T* s, int noise_kind, T* var) {
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  if (layout == LAYOUT_COLVECS) {
+    for (int n = blockIdx.x * kWaves + wave; n < N; n += gridDim.x * kWaves) {
+      const T* col = X + (int64_t)n * ldx;
+      double acc = 0.0;
+      for (int d = lane; d < D; d += 64) { const double x = (double)col[d]; acc += x * x / (double)dprior[d]; }
+      acc = wave_allreduce(acc);
+      if (lane == 0) var[n] = (T)acc + ((noise_kind == NOISE_DIAGONAL) ? s[n] : s[0]);
+    }
+  } else {
+    for (int n = blockIdx.x * kThreads + threadIdx.x; n < N; n += gridDim.x * kThreads) {
+      double acc = 0.0;
+      for (int d = 0; d < D; ++d) { const double x = (double)X[(int64_t)d * ldx + n]; acc += x * x / (double)dprior[d]; }
+      var[n] = (T)acc + ((noise_kind == NOISE_DIAGONAL) ? s[n] : s[0]);
+    }
   }
 }
 

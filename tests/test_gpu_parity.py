@@ -611,3 +611,114 @@ def test_rff_basis_config5_family(B, dtype, D, N):
     assert isinstance(post, B.BasisFunctionRegressor) and post.phi is rff
     np.testing.assert_allclose(post.blr.mw, mw_o, rtol=rt, atol=rt * 0.1)
     np.testing.assert_allclose(post.blr.Lw.toarray(), A_o, rtol=rt_lp * 10, atol=rt * 0.1)
+
+
+# ---- edge cases: empty and ragged inputs, padded leading dimensions, shared inputs ---------------------------------
+def test_empty_and_tiny_inputs(B):
+    from blr_amd import _abi
+
+    rng = _rng(8000)
+    h = _abi.default_handle()
+    # N = 0: the posterior is the prior, the evidence of no data is 0 (log 1)
+    for D in (1, 5, 130):
+        mw = rng.standard_normal(D)
+        Bm = rng.standard_normal((D, D)) / np.sqrt(D)
+        Lw = Bm @ Bm.T + np.eye(D)
+        f = B.BayesianLinearRegressor(mw, Lw)
+        X0 = np.zeros((D, 0), order="F")
+        assert B.logpdf(f(X0, 0.3), np.zeros(0)) == pytest.approx(0.0, abs=1e-10)
+        fp = B.posterior(f(X0, 0.3), np.zeros(0))
+        np.testing.assert_allclose(fp.mw, mw, rtol=1e-13)
+        np.testing.assert_allclose(fp.Lw.toarray(), Lw, rtol=1e-12)
+        assert B.mean(f(X0, 0.3)).shape == (0,)
+    # D = 1, N = 1
+    f = B.BayesianLinearRegressor(np.array([0.5]), B.Diagonal(np.array([2.0])))
+    X = np.array([[3.0]])
+    lp = B.logpdf(f(X, 0.25), np.array([1.0]))
+    var = 9.0 / 2.0 + 0.25
+    assert lp == pytest.approx(-0.5 * (np.log(2 * np.pi) + np.log(var) + (1.0 - 1.5) ** 2 / var), rel=1e-13)
+    # B = 0 is a no-op
+    info = np.zeros(1, dtype=np.int32)
+    assert h.posterior_batched(np.float64, _abi.MEM_HOST, _abi.LAYOUT_COLVECS, 0, 4, 8, None, 4, 32, None, 8, 0, None, 0, 2,
+                               None, 4, None, 1, 4, None, 4, None, 4, 16, None, 4, 16, None, info) == 0
+
+
+@pytest.mark.parametrize("N", [1, 3, 31, 32, 33, 63, 65, 127, 129, 1000])
+def test_ragged_column_counts(B, N):
+    # column counts around the stage size (32 / 64 columns) and the k-step size (4): tails are zero-filled
+    rng = _rng(8100 + N)
+    for D in (7, 64, 128):
+        X, mw, Lw, s = O.generate_toy_problem(rng, N, D, dense_noise_cov=False)
+        y = rng.standard_normal(N)
+        f = B.BayesianLinearRegressor(mw, Lw)
+        assert B.logpdf(f(np.asfortranarray(X), s), y) == pytest.approx(O.logpdf_literal(mw, Lw, X, s, y), rel=1e-10)
+
+
+def test_padded_leading_dimensions_and_shared_inputs(B):
+    from blr_amd import _abi
+
+    rng = _rng(8200)
+    h = _abi.default_handle()
+    Bn, D, N = 5, 24, 77
+    ldx, ldt, ldlp, ldl = D + 3, D + 2, D + 5, D + 1
+    Xbuf = np.full((Bn, N, ldx), np.nan)  # rows beyond D are never read
+    Xs = rng.standard_normal((Bn, D, N))
+    for b in range(Bn):
+        Xbuf[b, :, :D] = Xs[b].T
+    y = rng.standard_normal((Bn, N))
+    s = np.exp(rng.standard_normal(N))  # shared across the batch (stride 0)
+    mw = rng.standard_normal(D)         # shared
+    Bm = rng.standard_normal((D, D)) / np.sqrt(D)
+    Lw = Bm @ Bm.T + np.eye(D)
+    Lwbuf = np.full((D, ldl), np.nan)
+    Lwbuf[:, :D] = np.triu(Lw).T  # column-major with ldl: only the UPPER triangle is provided
+    Lwbuf[:, :D][np.tril_indices(D, -1)[::-1]] = np.nan  # strictly-lower entries must never be read
+    sentinel = -777.0
+    T = np.full((Bn, D, ldt), sentinel)
+    A = np.full((Bn, D, ldlp), sentinel)
+    mwp = np.full((Bn, D), sentinel)
+    lp = np.zeros(Bn)
+    info = np.full(Bn, -1, dtype=np.int32)
+    h.posterior_batched(np.float64, _abi.MEM_HOST, _abi.LAYOUT_COLVECS, Bn, D, N, Xbuf, ldx, N * ldx, y, N,
+                        _abi.NOISE_DIAGONAL, s, 0, _abi.PRIOR_DENSE, mw, 0, Lwbuf, ldl, 0, mwp, D, T, ldt, D * ldt, A, ldlp,
+                        D * ldlp, lp, info)
+    assert np.all(info == 0)
+    for b in range(Bn):
+        mw_o, T_o, A_o, lp_o = O.posterior_logpdf_direct(mw, Lw, Xs[b], s, y[b])
+        assert lp[b] == pytest.approx(lp_o, rel=1e-11)
+        np.testing.assert_allclose(mwp[b], mw_o, rtol=1e-9)
+        np.testing.assert_allclose(T[b, :, :D].T, T_o, rtol=1e-9, atol=1e-12)
+        np.testing.assert_allclose(A[b, :, :D].T, A_o, rtol=1e-11)
+        assert np.all(T[b, :, D:] == sentinel) and np.all(A[b, :, D:] == sentinel)  # gaps keep the caller's bytes
+    # shared X, different targets: logpdf(fx, Y::Matrix) path (stride 0 on X)
+    f = B.BayesianLinearRegressor(mw, Lw)
+    Y = rng.standard_normal((N, 4))
+    lps = B.logpdf(f(np.asfortranarray(Xs[0]), s), Y)
+    for j in range(4):
+        assert lps[j] == pytest.approx(O.logpdf_literal(mw, Lw, Xs[0], s, Y[:, j]), rel=1e-10)
+
+
+@pytest.mark.parametrize("dtype,D,N", [(np.float64, 130, 77), (np.float64, 300, 1000), (np.float32, 1024, 3000)])
+def test_large_d_marginals(B, dtype, D, N):
+    # reference :33, :40-43 at D > 128: GEMV stream for the mean, tall TRSM (panel machinery of the factorisation) for var
+    rng = _rng(9000 + D)
+    X = rng.standard_normal((D, N)).astype(dtype)
+    mw = rng.standard_normal(D).astype(dtype)
+    Bm = rng.standard_normal((D, D)) / np.sqrt(D)
+    Lw = (Bm @ Bm.T + np.eye(D)).astype(dtype)
+    s = np.exp(0.3 * rng.standard_normal(N)).astype(dtype)
+    m_o = O.mean(mw.astype(float), X.astype(float))
+    v_o = O.var(mw.astype(float), Lw.astype(float), X.astype(float), s.astype(float))
+    rt = 1e-10 if dtype == np.float64 else 3e-4
+    U = O.chol_upper(Lw.astype(float)).astype(dtype)
+    for Lw_arg in (Lw, B.PDMat(U)):
+        f = B.BayesianLinearRegressor(mw, Lw_arg)
+        for x in (np.asfortranarray(X), B.RowVecs(np.asfortranarray(X.T))):
+            m, v = B.mean_and_var(f(x, s))
+            np.testing.assert_allclose(m, m_o, rtol=rt, atol=rt * 10)
+            np.testing.assert_allclose(v, v_o, rtol=rt)
+    dvec = np.exp(rng.standard_normal(D)).astype(dtype)
+    v = B.var(B.BayesianLinearRegressor(mw, B.Diagonal(dvec))(np.asfortranarray(X), dtype(0.5)))
+    np.testing.assert_allclose(v, O.var(mw.astype(float), np.diag(dvec.astype(float)), X.astype(float), 0.5), rtol=rt)
+    with pytest.raises(B.PosDefException):
+        B.var(B.BayesianLinearRegressor(mw, -Lw)(np.asfortranarray(X), s))
