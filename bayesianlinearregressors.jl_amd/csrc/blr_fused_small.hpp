@@ -296,23 +296,32 @@ struct KFrags {
   T w;
 };
 
-template <typename T, int NB>
+// WS >= 0: the wave index is a compile-time constant (NB == 8 fast path: phase_gram runs one copy of the stage
+// loop per wave), so every fragment offset is an instruction immediate and the A-side choice needs no select.
+template <typename T, int NB, int WS>
 __device__ __forceinline__ void load_kfrags(KFrags<T, NB>& fr, const WaveOps<NB>& ops, const T* __restrict__ kimg,
                                             const T* __restrict__ wbuf, int j, int wave, int lane) {
   using C = SmallCfg<T, NB>;
   fr.w = wbuf[4 * j + (lane >> 4)];
-  if constexpr (NB == 8) {
-    fr.a[0] = kimg[wave * 64 + lane];
-    fr.a[1] = kimg[(7 - wave) * 64 + lane];
+  if constexpr (NB == 8 && WS >= 0) {
+    fr.a[0] = kimg[WS * 64 + lane];
+    fr.a[1] = kimg[(7 - WS) * 64 + lane];
+#pragma unroll
+    for (int i = 0; i < C::TPW; ++i) fr.b[i] = kimg[((i <= WS) ? i : i - (WS + 1)) * 64 + lane];
   } else {
+    if constexpr (NB == 8) {
+      fr.a[0] = kimg[wave * 64 + lane];
+      fr.a[1] = kimg[(7 - wave) * 64 + lane];
+    } else {
 #pragma unroll
-    for (int i = 0; i < C::TPW; ++i) fr.a[i] = kimg[(ops.offA[i] < 0 ? 0 : ops.offA[i]) + lane];
+      for (int i = 0; i < C::TPW; ++i) fr.a[i] = kimg[(ops.offA[i] < 0 ? 0 : ops.offA[i]) + lane];
+    }
+#pragma unroll
+    for (int i = 0; i < C::TPW; ++i) fr.b[i] = kimg[(ops.offB[i] < 0 ? 0 : ops.offB[i]) + lane];
   }
-#pragma unroll
-  for (int i = 0; i < C::TPW; ++i) fr.b[i] = kimg[(ops.offB[i] < 0 ? 0 : ops.offB[i]) + lane];
 }
 
-template <typename T, int NB>
+template <typename T, int NB, int WS>
 __device__ __forceinline__ void mma_kstep(AccArr<T, NB>& acc, const KFrags<T, NB>& fr, const WaveOps<NB>& ops, int wave) {
   using C = SmallCfg<T, NB>;
 #if BLR_EXP == 2
@@ -323,8 +332,12 @@ __device__ __forceinline__ void mma_kstep(AccArr<T, NB>& acc, const KFrags<T, NB
     const T alo = fr.a[0] * fr.w, ahi = fr.a[1] * fr.w;  // Sigma_y^-1 applied on the A side only
 #pragma unroll
     for (int i = 0; i < C::TPW; ++i) {
-      const T asel = (i <= wave) ? alo : ahi;  // wave-uniform select
-      acc[i] = Mfma<T>::mma(asel, fr.b[i], acc[i]);
+      if constexpr (WS >= 0) {
+        acc[i] = Mfma<T>::mma((i <= WS) ? alo : ahi, fr.b[i], acc[i]);
+      } else {
+        const T asel = (i <= wave) ? alo : ahi;  // wave-uniform select
+        acc[i] = Mfma<T>::mma(asel, fr.b[i], acc[i]);
+      }
     }
   } else {
 #pragma unroll
@@ -334,10 +347,11 @@ __device__ __forceinline__ void mma_kstep(AccArr<T, NB>& acc, const KFrags<T, NB
   }
 }
 
-// per-column vector work for the 4 columns of one k-step: lane (r, q) holds rows 16I + r of column q
+// per-column vector work for the 4 columns of one k-step: lane (r, q) holds rows 16I + r of column q.
+// `gate` (0 or 1, wave-uniform) switches the accumulation off without a branch (prior pseudo-columns).
 template <typename T, int NB>
 __device__ __forceinline__ void vector_kstep(const T* __restrict__ kimg, T w, T yv, const T* __restrict__ mwl,
-                                             double (&bacc)[NB], double& qacc, int lane) {
+                                             double (&bacc)[NB], double& qacc, int lane, T gate) {
   T f[NB];
 #pragma unroll
   for (int I = 0; I < NB; ++I) f[I] = kimg[I * 64 + lane];
@@ -345,7 +359,7 @@ __device__ __forceinline__ void vector_kstep(const T* __restrict__ kimg, T w, T 
 #pragma unroll
   for (int I = 0; I < NB; ++I) mu += f[I] * mwl[16 * I + (lane & 15)];
   mu = row16_allreduce(mu);
-  const T delta = yv - mu;  // :82  y - mean(fx)
+  const T delta = (yv - mu) * gate;  // :82  y - mean(fx)
   const T rn = delta * w;
   if ((lane & 15) == 0) qacc += (double)delta * (double)rn;
 #pragma unroll
@@ -354,24 +368,45 @@ __device__ __forceinline__ void vector_kstep(const T* __restrict__ kimg, T w, T 
 
 // One stage (KS k-steps): MFMAs on the wave's tiles, software-pipelined one k-step deep -- the fragments of
 // k-step j+1 are requested before the MFMAs of k-step j issue, so LDS latency hides under the MFMA pipe.
-template <typename T, int NB>
+template <typename T, int NB, int WS>
 __device__ __forceinline__ void compute_stage(const T* __restrict__ slot, const T* __restrict__ ybuf,
                                               const T* __restrict__ wbuf, const WaveOps<NB>& ops, AccArr<T, NB>& acc,
                                               double (&bacc)[NB], double& qacc, const T* __restrict__ mwl, int wave,
                                               int lane, bool is_data) {
   using C = SmallCfg<T, NB>;
   KFrags<T, NB> f0, f1;
-  load_kfrags<T, NB>(f0, ops, slot, wbuf, 0, wave, lane);
+  load_kfrags<T, NB, WS>(f0, ops, slot, wbuf, 0, wave, lane);
+  if constexpr (WS >= 0) {
+    // static wave: k-steps in groups of four, the owner k-step (jj == WS) carries the column-vector work in
+    // the SAME basic block as its MFMAs so the scheduler can sink the VALU work into the MFMA shadows
+    const T gate = is_data ? T(1) : T(0);
 #pragma unroll 1
-  for (int j = 0; j < C::KS; j += 2) {
-    load_kfrags<T, NB>(f1, ops, slot + (j + 1) * NB * 64, wbuf, j + 1, wave, lane);
-    mma_kstep<T, NB>(acc, f0, ops, wave);
-    if ((j & 3) == wave && is_data && BLR_EXP != 3)
-      vector_kstep<T, NB>(slot + j * NB * 64, f0.w, ybuf[4 * j + (lane >> 4)], mwl, bacc, qacc, lane);
-    if (j + 2 < C::KS) load_kfrags<T, NB>(f0, ops, slot + (j + 2) * NB * 64, wbuf, j + 2, wave, lane);
-    mma_kstep<T, NB>(acc, f1, ops, wave);
-    if (((j + 1) & 3) == wave && is_data && BLR_EXP != 3)
-      vector_kstep<T, NB>(slot + (j + 1) * NB * 64, f1.w, ybuf[4 * (j + 1) + (lane >> 4)], mwl, bacc, qacc, lane);
+    for (int j = 0; j < C::KS; j += 4) {
+#pragma unroll
+      for (int jj = 0; jj < 4; jj += 2) {
+        load_kfrags<T, NB, WS>(f1, ops, slot + (j + jj + 1) * NB * 64, wbuf, j + jj + 1, wave, lane);
+        mma_kstep<T, NB, WS>(acc, f0, ops, wave);
+        if (jj == WS && BLR_EXP != 3)
+          vector_kstep<T, NB>(slot + (j + jj) * NB * 64, f0.w, ybuf[4 * (j + jj) + (lane >> 4)], mwl, bacc, qacc, lane, gate);
+        if (j + jj + 2 < C::KS) load_kfrags<T, NB, WS>(f0, ops, slot + (j + jj + 2) * NB * 64, wbuf, j + jj + 2, wave, lane);
+        mma_kstep<T, NB, WS>(acc, f1, ops, wave);
+        if (jj + 1 == WS && BLR_EXP != 3)
+          vector_kstep<T, NB>(slot + (j + jj + 1) * NB * 64, f1.w, ybuf[4 * (j + jj + 1) + (lane >> 4)], mwl, bacc, qacc,
+                              lane, gate);
+      }
+    }
+  } else {
+#pragma unroll 1
+    for (int j = 0; j < C::KS; j += 2) {
+      load_kfrags<T, NB, WS>(f1, ops, slot + (j + 1) * NB * 64, wbuf, j + 1, wave, lane);
+      mma_kstep<T, NB, WS>(acc, f0, ops, wave);
+      if ((j & 3) == wave && is_data && BLR_EXP != 3)
+        vector_kstep<T, NB>(slot + j * NB * 64, f0.w, ybuf[4 * j + (lane >> 4)], mwl, bacc, qacc, lane, T(1));
+      if (j + 2 < C::KS) load_kfrags<T, NB, WS>(f0, ops, slot + (j + 2) * NB * 64, wbuf, j + 2, wave, lane);
+      mma_kstep<T, NB, WS>(acc, f1, ops, wave);
+      if (((j + 1) & 3) == wave && is_data && BLR_EXP != 3)
+        vector_kstep<T, NB>(slot + (j + 1) * NB * 64, f1.w, ybuf[4 * (j + 1) + (lane >> 4)], mwl, bacc, qacc, lane, T(1));
+    }
   }
 }
 
@@ -460,6 +495,8 @@ BLR_PHASE void phase_gram(char* smem) {
   };
 
   __syncthreads();  // region 0 is free
+  auto run_stages = [&](auto ws_tag) {
+  constexpr int WS = decltype(ws_tag)::value;
   // MODE 4 with prior pseudo-stages: data stage 0 is issued after the last prior stage's barrier instead
   // (its slot is still being used by the prior stages before that)
   if (ndata_stages > 0 && !(kGlds && nprior_stages > 0)) { ring_slot = slot0 + (nprior_stages & 1) * C::SLOT; issue(0); }
@@ -490,7 +527,19 @@ BLR_PHASE void phase_gram(char* smem) {
       issue(tdn);
     }
 #endif
-    compute_stage<T, NB>(slot, ybuf + sl * C::NSC, wbuf + sl * C::NSC, ops, acc, bacc, qacc, mwl, wave, lane, is_data);
+    compute_stage<T, NB, WS>(slot, ybuf + sl * C::NSC, wbuf + sl * C::NSC, ops, acc, bacc, qacc, mwl, wave, lane, is_data);
+  }
+  };
+  // NB == 8 (the MFMA-bound headline shape): one copy of the stage loop per wave, wave index static
+  if constexpr (NB == 8) {
+    switch (wave) {
+      case 0: run_stages(std::integral_constant<int, 0>{}); break;
+      case 1: run_stages(std::integral_constant<int, 1>{}); break;
+      case 2: run_stages(std::integral_constant<int, 2>{}); break;
+      default: run_stages(std::integral_constant<int, 3>{}); break;
+    }
+  } else {
+    run_stages(std::integral_constant<int, -1>{});
   }
 
   // b partials -> LDS -> fixed-order sum
