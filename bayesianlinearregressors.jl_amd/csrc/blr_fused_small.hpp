@@ -308,6 +308,15 @@ __device__ __forceinline__ void load_kfrags(KFrags<T, NB>& fr, const WaveOps<NB>
     fr.a[1] = kimg[(7 - WS) * 64 + lane];
 #pragma unroll
     for (int i = 0; i < C::TPW; ++i) fr.b[i] = kimg[((i <= WS) ? i : i - (WS + 1)) * 64 + lane];
+  } else if constexpr (WS >= 0) {  // round-robin map, static wave: tile t = WS + 4 i
+#pragma unroll
+    for (int i = 0; i < C::TPW; ++i) {
+      const int t = WS + kWaves * i;
+      if (t < C::NT) {
+        fr.a[i] = kimg[tile_I(t) * 64 + lane];
+        fr.b[i] = kimg[tile_J(t) * 64 + lane];
+      }
+    }
   } else {
     if constexpr (NB == 8) {
       fr.a[0] = kimg[wave * 64 + lane];
@@ -338,6 +347,11 @@ __device__ __forceinline__ void mma_kstep(AccArr<T, NB>& acc, const KFrags<T, NB
         const T asel = (i <= wave) ? alo : ahi;  // wave-uniform select
         acc[i] = Mfma<T>::mma(asel, fr.b[i], acc[i]);
       }
+    }
+  } else if constexpr (WS >= 0) {
+#pragma unroll
+    for (int i = 0; i < C::TPW; ++i) {
+      if (WS + kWaves * i < C::NT) acc[i] = Mfma<T>::mma(fr.a[i] * fr.w, fr.b[i], acc[i]);  // resolved at compile time
     }
   } else {
 #pragma unroll
@@ -530,8 +544,9 @@ BLR_PHASE void phase_gram(char* smem) {
     compute_stage<T, NB, WS>(slot, ybuf + sl * C::NSC, wbuf + sl * C::NSC, ops, acc, bacc, qacc, mwl, wave, lane, is_data);
   }
   };
-  // NB == 8 (the MFMA-bound headline shape): one copy of the stage loop per wave, wave index static
-  if constexpr (NB == 8) {
+  // NB == 8 (the MFMA-bound headline shape) and NB == 4 (config 4, D = 64): one copy of the stage loop per wave,
+  // wave index static
+  if constexpr (NB == 8 || NB == 4) {
     switch (wave) {
       case 0: run_stages(std::integral_constant<int, 0>{}); break;
       case 1: run_stages(std::integral_constant<int, 1>{}); break;
