@@ -194,13 +194,14 @@ int chol_large(blr_handle* h, T* M, int64_t ld, int DP, int nrows_total, int32_t
       g.X = M + (int64_t)p * kPB * ld; g.ldx = ld; g.layout = LAYOUT_COLVECS; g.use_dma = 1;
       g.s = nullptr; g.noise_kind = NOISE_ISOTROPIC; g.r = nullptr;
       g.D = nrows_total; g.n_begin = 0; g.n_end = kPB; g.nsplit = 1;
-      g.tile_i0 = p + 1; g.tile_j0 = p + 1; g.tri = 1; g.ntiles = m * (m + 1) / 2; g.nblocks = NRB;
+      g.tile_i0 = p + 1; g.tile_j0 = p + 1; g.nblocks = NRB;
       g.C = M; g.ldc = ld; g.mode_out = 1;
-      hipLaunchKernelGGL(gram_tile_kernel<T>, dim3(g.ntiles), dim3(kThreads), LC::LDS_BYTES, h->stream, g);
-      if (NRB > NC) {  // the rhs row block: tiles (NC, p+1 .. NC-1)
-        g.tile_i0 = NC; g.tile_j0 = p + 1; g.tri = 2; g.ntiles = m;
-        hipLaunchKernelGGL(gram_tile_kernel<T>, dim3(g.ntiles), dim3(kThreads), LC::LDS_BYTES, h->stream, g);
+      if (NRB > NC) {  // triangle + the rhs row block (tiles (NC, p+1 .. NC-1)) in ONE launch
+        g.tri = 4; g.ntile_rows = m; g.extra_row = NC; g.ntiles = m * (m + 1) / 2 + m;
+      } else {
+        g.tri = 1; g.ntiles = m * (m + 1) / 2;
       }
+      hipLaunchKernelGGL(gram_tile_kernel<T>, dim3(g.ntiles), dim3(kThreads), LC::LDS_BYTES, h->stream, g);
     }
   }
   HIP_TRY(h, hipGetLastError());

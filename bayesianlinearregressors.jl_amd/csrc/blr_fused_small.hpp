@@ -752,13 +752,32 @@ BLR_PHASE void phase_backsolve(char* smem, int D_in) {
     T b1 = i1 < D ? bvec[i1] : T(0);
     double uu = (double)b0 * (double)b0 + (double)b1 * (double)b1;
     uu = wave_allreduce(uu);
-    for (int k = (BLR_EXP == 5 ? -1 : D - 1); k >= 0; --k) {
-      T src = (k < 64) ? b0 : b1;
-      T mk = readlane(src, k & 63) * dinv[k];
-      if (lane == (k & 63)) { if (k < 64) b0 = mk; else b1 = mk; }
-      const T* row = P + pidx(k, 0);
-      if (i0 < k) b0 -= row[i0] * mk;
-      if (i1 < k) b1 -= row[i1] * mk;
+    // Column-oriented back substitution, 8 pivots per block: the 8 rows of L the block needs are loaded up front
+    // (they do not depend on the running solution), so the serial chain per pivot is readlane -> multiply -> fma
+    // with no LDS latency in it.  Reciprocal pivots live in registers (one per owned row).
+    const T r0 = i0 < D ? dinv[i0] : T(0);
+    const T r1 = i1 < D ? dinv[i1] : T(0);
+    for (int kb = (BLR_EXP == 5 ? -1 : D - 1); kb >= 0; kb -= 8) {
+      T row0[8], row1[8];
+#pragma unroll
+      for (int u = 0; u < 8; ++u) {
+        const int k = kb - u;
+        const bool kv = k >= 0;
+        const T* row = P + pidx(kv ? k : 0, 0);
+        row0[u] = (kv && i0 < k) ? row[i0] : T(0);
+        row1[u] = (kv && i1 < k) ? row[i1] : T(0);
+      }
+#pragma unroll
+      for (int u = 0; u < 8; ++u) {
+        const int k = kb - u;
+        if (k >= 0) {
+          const bool lo = k < 64;
+          const T mk = readlane(lo ? b0 : b1, k & 63) * readlane(lo ? r0 : r1, k & 63);
+          if (lane == (k & 63)) { if (lo) b0 = mk; else b1 = mk; }
+          b0 -= row0[u] * mk;
+          b1 -= row1[u] * mk;
+        }
+      }
     }
     if (i0 < D) bvec[i0] = b0;
     if (i1 < D) bvec[i1] = b1;

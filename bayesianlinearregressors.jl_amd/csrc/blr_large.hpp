@@ -106,9 +106,11 @@ struct GramTileArgs {
   int n_begin, n_end;        // column range of the whole contraction
   int nsplit;                // split-K factor over [n_begin, n_end)
   int tile_i0, tile_j0;      // first row-block / col-block index of the tile grid
-  int ntile_rows;            // tiles are enumerated over rows I >= J (lower) when tri != 0
+  int ntile_rows;            // row-block count of the rectangle (tri 3) / triangle (tri 4)
+  int extra_row;             // tri 4: row block of the extra row of tiles
   int tri;                   // 1: lower-triangular enumeration t -> (I >= J); 0: column of tiles (I = i0 + t, J = j0);
-                             // 2: row of tiles (I = i0, J = j0 + t); 3: rectangle of ntile_rows x (ntiles / ntile_rows) tiles
+                             // 2: row of tiles (I = i0, J = j0 + t); 3: rectangle of ntile_rows x (ntiles / ntile_rows) tiles;
+                             // 4: lower triangle over ntile_rows blocks + one extra row of tiles (single launch)
   T* Gpart;                  // mode 0: [nsplit][ntiles][128*128] column-major tiles (row = A-side row)
   double* bpart;             // mode 0: [nsplit][nblocks][128]
   int ntiles, nblocks;
@@ -143,9 +145,20 @@ __global__ __launch_bounds__(kThreads, 2) void gram_tile_kernel(GramTileArgs<T> 
   } else if (a.tri == 2) {  // a row of tiles: fixed row block, column blocks j0 + t
     I = a.tile_i0;
     J = a.tile_j0 + t;
-  } else {  // rectangle: ntile_rows row blocks x (ntiles / ntile_rows) column blocks
+  } else if (a.tri == 3) {  // rectangle: ntile_rows row blocks x (ntiles / ntile_rows) column blocks
     I = a.tile_i0 + t % a.ntile_rows;
     J = a.tile_j0 + t / a.ntile_rows;
+  } else {  // lower triangle over ntile_rows blocks, then one extra row of tiles (row block `extra_row`)
+    const int ntri = a.ntile_rows * (a.ntile_rows + 1) / 2;
+    if (t < ntri) {
+      int ii = 0;
+      while ((ii + 1) * (ii + 2) / 2 <= t) ++ii;
+      I = a.tile_i0 + ii;
+      J = a.tile_j0 + (t - ii * (ii + 1) / 2);
+    } else {
+      I = a.extra_row;
+      J = a.tile_j0 + (t - ntri);
+    }
   }
   const bool diag_tile = (I == J);
   const int rowA = I * kPB, rowB = J * kPB;
