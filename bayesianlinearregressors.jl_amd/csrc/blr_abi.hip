@@ -627,11 +627,20 @@ int marginals_batched(blr_handle* h, int memspace, int layout, int64_t B, int64_
   a.info = chol_info;
   if (chol_info) HIP_TRY(h, hipMemcpyAsync(info_out_dev, chol_info, (size_t)B * sizeof(int32_t), hipMemcpyDeviceToDevice, h->stream));
   else HIP_TRY(h, hipMemsetAsync(info_out_dev, 0, (size_t)B * sizeof(int32_t), h->stream));
-  size_t lds = ((size_t)D * 64 + D) * sizeof(T) + 16;
-  auto kern = marginals_kernel<T>;
-  HIP_TRY(h, hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-  dim3 grid((unsigned)((N + 63) / 64), (unsigned)B);
-  hipLaunchKernelGGL(kern, grid, dim3(64), lds, h->stream, a);
+  if (var && kind == BLR_PRIOR_UPPER_FACTOR) {
+    // MFMA path: inputs as rows of an LDS block, Y = X'L^-T by the TRSM core, fused mean / row sum of squares
+    using TC = TrsmCfg<T>;
+    auto kern = marginals_mfma_kernel<T>;
+    HIP_TRY(h, hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, TC::LDS_BYTES));
+    dim3 grid((unsigned)((N + TC::RB - 1) / TC::RB), (unsigned)B);
+    hipLaunchKernelGGL(kern, grid, dim3(kThreads), TC::LDS_BYTES, h->stream, a);
+  } else {
+    size_t lds = ((size_t)D * 64 + D) * sizeof(T) + 16;
+    auto kern = marginals_kernel<T>;
+    HIP_TRY(h, hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    dim3 grid((unsigned)((N + 63) / 64), (unsigned)B);
+    hipLaunchKernelGGL(kern, grid, dim3(64), lds, h->stream, a);
+  }
   HIP_TRY(h, hipGetLastError());
   if (memspace == BLR_MEM_HOST) {
     if (mean) HIP_TRY(h, hipMemcpyAsync(mean, a.mean, extent(B, stridemean, (size_t)N) * sizeof(T), hipMemcpyDeviceToHost, h->stream));

@@ -16,6 +16,7 @@
 // of the matrix, so the panel TRSM and the trailing updates perform the forward substitution u = L^-1 b
 // without any extra kernel (same trick as the fused small-D kernel).
 #pragma once
+#include "blr_aux_kernels.hpp"
 #include "blr_fused_small.hpp"
 
 namespace blr {
@@ -432,45 +433,15 @@ struct TrsmCfg {
   static constexpr int LDS_BYTES = ((OFF_DI + kPB * (int)sizeof(T)) + 15) & ~15;
 };
 
+// X <- X L^-T on an LDS-resident block: Xs[RB][LDX] rows, L packed lower in P, dinv = 1 / diag(L); `nchunks` 16-column
+// chunks.  Left-looking: chunk J first receives  - sum_{K<J} X_K L_JK'  by MFMA, then is solved one row per thread.
 template <typename T>
-__global__ __launch_bounds__(kThreads) void trsm_block_kernel(T* Abar, int64_t lda, int p, int row_begin, int nrows_total,
-                                                              const int32_t* info) {
+__device__ __forceinline__ void trsm_core(T* __restrict__ Xs, const T* __restrict__ P, const T* __restrict__ dinv, int nchunks,
+                                          int tid, int lane, int wave) {
   using Cfg = TrsmCfg<T>;
   using acc4 = typename Mfma<T>::acc4;
-  extern __shared__ __attribute__((aligned(16))) char smem[];
-  T* const P = reinterpret_cast<T*>(smem);                    // packed lower triangle of L_pp
-  T* const Xs = reinterpret_cast<T*>(smem + Cfg::OFF_X);      // [RB][LDX]
-  T* const dinv = reinterpret_cast<T*>(smem + Cfg::OFF_DI);   // 1 / L_pp[c][c]
-  const int tid = threadIdx.x, lane = tid & 63;
-  const int wave = uni(tid >> 6);
-  if (*info != 0) return;
-  const int r0 = row_begin + blockIdx.x * Cfg::RB;            // first global row of this block
-  const int nr = min(Cfg::RB, nrows_total - r0);
-  const T* Lpp = Abar + (int64_t)p * kPB * lda + (int64_t)p * kPB;
-  T* Xg = Abar + (int64_t)p * kPB * lda + r0;
-  load_lower_block_to_packed(P, Lpp, lda, tid);
-#pragma unroll 1
-  for (int base = 0; base < Cfg::RB * kPB; base += kThreads * 16) {  // X block, 16 loads in flight per thread
-    T v[16];
-#pragma unroll
-    for (int u = 0; u < 16; ++u) {
-      const int idx = base + u * kThreads + tid;
-      const int c = idx / Cfg::RB, r = idx % Cfg::RB;          // coalesced along rows
-      v[u] = Xg[(int64_t)c * lda + (r < nr ? r : 0)];
-    }
-#pragma unroll
-    for (int u = 0; u < 16; ++u) {
-      const int idx = base + u * kThreads + tid;
-      const int c = idx / Cfg::RB, r = idx % Cfg::RB;
-      Xs[r * Cfg::LDX + c] = (r < nr) ? v[u] : T(0);
-    }
-  }
-  __syncthreads();
-  if (tid < kPB) dinv[tid] = T(1) / P[pidx(tid, tid)];
-  __syncthreads();
-
   const int fr = lane & 15, fq = lane >> 4;
-  for (int J = 0; J < 8; ++J) {
+  for (int J = 0; J < nchunks; ++J) {
     // (1) left-looking update of chunk J with the already solved chunks K < J (MFMA)
     for (int ta = wave; ta < Cfg::RB / 16; ta += kWaves) {
       acc4 acc;
@@ -510,6 +481,46 @@ __global__ __launch_bounds__(kThreads) void trsm_block_kernel(T* Abar, int64_t l
     }
     __syncthreads();
   }
+}
+
+template <typename T>
+__global__ __launch_bounds__(kThreads) void trsm_block_kernel(T* Abar, int64_t lda, int p, int row_begin, int nrows_total,
+                                                              const int32_t* info) {
+  using Cfg = TrsmCfg<T>;
+  using acc4 = typename Mfma<T>::acc4;
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  T* const P = reinterpret_cast<T*>(smem);                    // packed lower triangle of L_pp
+  T* const Xs = reinterpret_cast<T*>(smem + Cfg::OFF_X);      // [RB][LDX]
+  T* const dinv = reinterpret_cast<T*>(smem + Cfg::OFF_DI);   // 1 / L_pp[c][c]
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = uni(tid >> 6);
+  if (*info != 0) return;
+  const int r0 = row_begin + blockIdx.x * Cfg::RB;            // first global row of this block
+  const int nr = min(Cfg::RB, nrows_total - r0);
+  const T* Lpp = Abar + (int64_t)p * kPB * lda + (int64_t)p * kPB;
+  T* Xg = Abar + (int64_t)p * kPB * lda + r0;
+  load_lower_block_to_packed(P, Lpp, lda, tid);
+#pragma unroll 1
+  for (int base = 0; base < Cfg::RB * kPB; base += kThreads * 16) {  // X block, 16 loads in flight per thread
+    T v[16];
+#pragma unroll
+    for (int u = 0; u < 16; ++u) {
+      const int idx = base + u * kThreads + tid;
+      const int c = idx / Cfg::RB, r = idx % Cfg::RB;          // coalesced along rows
+      v[u] = Xg[(int64_t)c * lda + (r < nr ? r : 0)];
+    }
+#pragma unroll
+    for (int u = 0; u < 16; ++u) {
+      const int idx = base + u * kThreads + tid;
+      const int c = idx / Cfg::RB, r = idx % Cfg::RB;
+      Xs[r * Cfg::LDX + c] = (r < nr) ? v[u] : T(0);
+    }
+  }
+  __syncthreads();
+  if (tid < kPB) dinv[tid] = T(1) / P[pidx(tid, tid)];
+  __syncthreads();
+
+  trsm_core<T>(Xs, P, dinv, 8, tid, lane, wave);
   for (int idx = tid; idx < Cfg::RB * kPB; idx += kThreads) {
     const int c = idx / Cfg::RB, r = idx % Cfg::RB;
     if (r < nr) Xg[(int64_t)c * lda + r] = Xs[r * Cfg::LDX + c];
@@ -786,6 +797,89 @@ __global__ __launch_bounds__(kThreads) void var_diag_prior_kernel(const T* X, in
       double acc = 0.0;
       for (int d = 0; d < D; ++d) { const double x = (double)X[(int64_t)d * ldx + n]; acc += x * x / (double)dprior[d]; }
       var[n] = (T)acc + ((noise_kind == NOISE_DIAGONAL) ? s[n] : s[0]);
+    }
+  }
+}
+
+// ---- marginal stream for D <= 128 with an upper factor: the same TRSM core, fused with mean and row sum of squares ----
+// One workgroup per tile of RB inputs (128 in f32, 64 in f64): the inputs are the ROWS of an LDS block, L = U' is packed
+// next to it, Y = X'L^-T by trsm_core (MFMA between 16-column chunks), var_n = |Y_n|^2 + s_n, mean_n = x_n'mw (:33, :40-43).
+template <typename T>
+__global__ __launch_bounds__(kThreads) void marginals_mfma_kernel(MarginalArgs<T> a) {
+  using Cfg = TrsmCfg<T>;
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  T* const P = reinterpret_cast<T*>(smem);
+  T* const Xs = reinterpret_cast<T*>(smem + Cfg::OFF_X);
+  T* const dinv = reinterpret_cast<T*>(smem + Cfg::OFF_DI);
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = uni(tid >> 6);
+  const int D = a.D, N = a.N;
+  const int reg = blockIdx.y;
+  if (a.info && a.info[reg] != 0) return;
+  const T* X = a.X + (int64_t)reg * a.strideX;
+  const T* U = a.U + (int64_t)reg * a.strideU;
+  const T* s = a.s + (int64_t)reg * a.strides;
+  const T* mw = a.mw + (int64_t)reg * a.stridemw;
+  const int n0 = blockIdx.x * Cfg::RB;
+  const int nt = min(Cfg::RB, N - n0);
+  const int nchunks = (D + 15) >> 4, DPc = nchunks * 16;
+  // L = U' packed (padding: unit diagonal); 8 loads in flight per thread (a plain loop serialises on load latency)
+#pragma unroll 1
+  for (int base = 0; base < DPc * DPc; base += kThreads * 8) {
+    T v[8];
+#pragma unroll
+    for (int u = 0; u < 8; ++u) {
+      const int idx = base + u * kThreads + tid;
+      const int r = idx / DPc, c = idx % DPc;  // L[r][c] = U[c, r]: consecutive threads -> consecutive c
+      const bool ok = idx < DPc * DPc && c <= r && r < D;
+      v[u] = U[ok ? (int64_t)r * a.ldu + c : 0];
+    }
+#pragma unroll
+    for (int u = 0; u < 8; ++u) {
+      const int idx = base + u * kThreads + tid;
+      const int r = idx / DPc, c = idx % DPc;
+      if (idx < DPc * DPc && c <= r) P[pidx(r, c)] = (r < D) ? v[u] : (r == c ? T(1) : T(0));
+    }
+  }
+  // inputs as rows
+#pragma unroll 1
+  for (int base = 0; base < Cfg::RB * DPc; base += kThreads * 8) {
+    T v[8];
+#pragma unroll
+    for (int u = 0; u < 8; ++u) {
+      const int idx = base + u * kThreads + tid;
+      int r, c;
+      if (a.layout == LAYOUT_COLVECS) { c = idx % DPc; r = idx / DPc; }
+      else                            { r = idx % Cfg::RB; c = idx / Cfg::RB; }
+      const bool ok = idx < Cfg::RB * DPc && r < nt && c < D;
+      const int64_t addr = (a.layout == LAYOUT_COLVECS) ? (int64_t)(n0 + r) * a.ldx + c : (int64_t)c * a.ldx + n0 + r;
+      v[u] = X[ok ? addr : 0];
+    }
+#pragma unroll
+    for (int u = 0; u < 8; ++u) {
+      const int idx = base + u * kThreads + tid;
+      int r, c;
+      if (a.layout == LAYOUT_COLVECS) { c = idx % DPc; r = idx / DPc; }
+      else                            { r = idx % Cfg::RB; c = idx / Cfg::RB; }
+      if (idx < Cfg::RB * DPc) Xs[r * Cfg::LDX + c] = (r < nt && c < D) ? v[u] : T(0);
+    }
+  }
+  __syncthreads();
+  if (tid < DPc) dinv[tid] = T(1) / P[pidx(tid, tid)];
+  T m = T(0);
+  if (a.mean && tid < Cfg::RB) {
+    const T* xr = Xs + tid * Cfg::LDX;
+    for (int c = 0; c < D; ++c) m += xr[c] * mw[c];
+  }
+  __syncthreads();
+  if (a.var) trsm_core<T>(Xs, P, dinv, nchunks, tid, lane, wave);
+  if (tid < nt) {
+    if (a.mean) a.mean[(int64_t)reg * a.stridemean + n0 + tid] = m;
+    if (a.var) {
+      const T* xr = Xs + tid * Cfg::LDX;
+      T v0 = T(0), v1 = T(0);
+      for (int c = 0; c + 1 < DPc; c += 2) { v0 += xr[c] * xr[c]; v1 += xr[c + 1] * xr[c + 1]; }
+      a.var[(int64_t)reg * a.stridevar + n0 + tid] = (v0 + v1) + ((a.noise_kind == NOISE_DIAGONAL) ? s[n0 + tid] : s[0]);
     }
   }
 }
