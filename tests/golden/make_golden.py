@@ -1,0 +1,67 @@
+"""Generates tests/golden/blr_golden.json: small fixtures (inputs + expected outputs) for the posterior/logpdf path.
+
+The reference is Julia and cannot run in the build image, and its own tests hold no numeric fixtures except one doctest
+vector, so these fixtures are produced by the CPU oracle (oracle/blr_oracle.py) on the toy-problem CONSTRUCTION of
+/root/reference/test/test_utils.jl:4-10 with a seeded NumPy generator, and every log density is cross-checked against a
+50-digit mpmath evaluation of the naive N x N Gaussian formula of /root/reference/test/bayesian_linear_regression.jl:28-37
+before it is written.  Cases: (N, D) = (11, 3), (13, 7), (11, 2) as in the reference tests, the README example shape
+(10, 2) with a Diagonal prior and heteroscedastic noise, and the doctest of src/basis_function_regression.jl:11-28.
+
+    python tests/golden/make_golden.py
+"""
+import json
+import os
+import sys
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, ROOT)
+from oracle import blr_oracle as O  # noqa: E402
+
+
+def case(name, rng, N, D, prior, noise):
+    X = rng.standard_normal((D, N))
+    mw = rng.standard_normal(D)
+    if prior == "diagonal":
+        dvec = np.exp(0.5 * rng.standard_normal(D))
+        Lw = np.diag(dvec)
+    else:
+        Bm = rng.standard_normal((D, D))
+        Lw = Bm @ Bm.T + np.eye(D)
+    s = np.exp(rng.standard_normal(N)) if noise == "diagonal" else np.float64(0.37)
+    y = rng.standard_normal(N)
+    mw_p, T, A = O.posterior_literal(mw, Lw, X, s, y)
+    lp = O.logpdf_literal(mw, Lw, X, s, y)
+    lp_mp = O.logpdf_naive_mp(mw, Lw, X, s, y)
+    assert abs(lp - lp_mp) <= 1e-12 * abs(lp_mp), (name, lp, lp_mp)
+    mw_d, T_d, A_d, lp_d = O.posterior_logpdf_direct(mw, Lw, X, s, y)
+    assert np.allclose(mw_d, mw_p, rtol=1e-11) and np.allclose(T_d, T, rtol=1e-11) and abs(lp_d - lp) <= 1e-12 * abs(lp)
+    Xs = rng.standard_normal((D, 6))
+    mean, var = O.mean(mw_p, Xs), O.var(mw_p, A, Xs, 0.05)
+    Z1, Z2 = rng.standard_normal((D, 3)), rng.standard_normal((N, 3))
+    Y = O.rand(mw, Lw, X, s, Z1, Z2)
+    out = dict(name=name, N=N, D=D, prior=prior, noise=noise, X=X, mw=mw, Lw=Lw, s=np.asarray(s), y=y,
+               logpdf=lp_mp, mw_post=mw_p, T_post=T, Lw_post=A, X_star=Xs, noise_star=0.05, mean_star=mean, var_star=var,
+               Z1=Z1, Z2=Z2, Y_rand=Y)
+    return {k: (v.tolist() if isinstance(v, np.ndarray) else (float(v) if isinstance(v, (np.floating, float)) else v))
+            for k, v in out.items()}
+
+
+def main():
+    rng = np.random.Generator(np.random.PCG64(20261002))
+    cases = [
+        case("toy_11_3_dense_prior_diag_noise", rng, 11, 3, "dense", "diagonal"),
+        case("toy_13_7_dense_prior_diag_noise", rng, 13, 7, "dense", "diagonal"),
+        case("toy_11_2_dense_prior_iso_noise", rng, 11, 2, "dense", "isotropic"),
+        case("readme_10_2_diag_prior_hetero_noise", rng, 10, 2, "diagonal", "diagonal"),
+    ]
+    doctest = dict(name="doctest_basis_function_regression_jl_11_28", x=np.linspace(-1.0, 1.0, 5).tolist(),
+                   mw=[0.0, 0.0], Lw_diag=[1.0, 1.0], noise=1e-18, var=[2.0, 1.25, 1.0, 1.25, 2.0])
+    with open(os.path.join(os.path.dirname(os.path.abspath(__file__)), "blr_golden.json"), "w") as f:
+        json.dump(dict(generator="tests/golden/make_golden.py", seed=20261002, cases=cases, doctest=doctest), f, indent=0)
+    print("wrote", len(cases), "cases")
+
+
+if __name__ == "__main__":
+    main()
