@@ -32,6 +32,11 @@
 #endif
 // Phase functions: noinline (own register allocation, but the AMDGPU call ABI saves ~108 callee-saved
 // VGPRs per call to scratch) or always-inline with an opaque thread id at phase entry.
+// waves per SIMD requested for the fp32 D > 64 instantiations (fp64 needs the registers: 2).  Measured at D=128, N=4096:
+// 2 -> 0.96 M, 3 -> 1.09 M, 4 -> 1.07 M updates/s (B = 4096); 4 slows the serial panel chain of the large-D path.
+#ifndef BLR_F32_WAVES_PER_SIMD
+#define BLR_F32_WAVES_PER_SIMD 3
+#endif
 #ifndef BLR_PHASE_INLINE
 #define BLR_PHASE_INLINE 0
 #endif
@@ -823,7 +828,7 @@ __device__ __forceinline__ int chol_packed(T* __restrict__ P, T* __restrict__ di
 // (<= 128 registers, ~35 KB of LDS each) keep 4 x 16 KB of LDS-DMA in flight per CU; D > 64 is MFMA-bound and
 // needs the registers for accumulators: two workgroups per CU.
 template <typename T, int NB, int MODE /* data loader: 0 ColVecs generic, 1 RowVecs, 3 ColVecs vector regs, 4 ColVecs LDS-DMA */>
-__global__ __launch_bounds__(kThreads, (NB <= 4 ? 4 : 2)) void fused_small_kernel(PosteriorArgs<T> a) {
+__global__ __launch_bounds__(kThreads, (NB <= 4 ? 4 : (sizeof(T) == 4 ? BLR_F32_WAVES_PER_SIMD : 2))) void fused_small_kernel(PosteriorArgs<T> a) {
   using C = SmallCfg<T, NB>;
   extern __shared__ __attribute__((aligned(16))) char smem[];
   T* const P = reinterpret_cast<T*>(smem);

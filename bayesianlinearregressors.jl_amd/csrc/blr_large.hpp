@@ -406,7 +406,7 @@ __device__ __forceinline__ void store_packed_to_lower_block(const T* __restrict_
 // one unconstrained caller it budgets phase_chol for 512 registers and silently halves the occupancy of the fused
 // kernel (measured: 475 k -> 351 k updates/s at D=128, N=4096).
 template <typename T>
-__global__ __launch_bounds__(kThreads, 2) void chol_diag_kernel(T* Abar, int64_t lda, int p, int32_t* info, int info_base) {
+__global__ __launch_bounds__(kThreads, (sizeof(T) == 4 ? BLR_F32_WAVES_PER_SIMD : 2)) void chol_diag_kernel(T* Abar, int64_t lda, int p, int32_t* info, int info_base) {
   using C = SmallCfg<T, 8>;
   extern __shared__ __attribute__((aligned(16))) char smem[];
   T* const P = reinterpret_cast<T*>(smem);
@@ -543,7 +543,7 @@ struct BacksolveArgs {
 };
 
 template <typename T>
-__global__ __launch_bounds__(kThreads, 2) void backsolve_kernel(BacksolveArgs<T> a) {
+__global__ __launch_bounds__(kThreads, (sizeof(T) == 4 ? BLR_F32_WAVES_PER_SIMD : 2)) void backsolve_kernel(BacksolveArgs<T> a) {
   using C = SmallCfg<T, 8>;
   extern __shared__ __attribute__((aligned(16))) char smem[];
   T* const P = reinterpret_cast<T*>(smem);
