@@ -104,13 +104,21 @@ def main():
     import torch
 
     dist = None
+    # BLR_BENCH_BACKEND=gloo + BLR_BENCH_SAME_DEVICE=1: validation of the N > 1 code path on a ONE-GPU box (both ranks on
+    # cuda:0, the tiny collectives staged through the host).  The real runs use nccl (= RCCL over xGMI), one GPU per rank.
+    backend = os.environ.get("BLR_BENCH_BACKEND", "nccl")
+    if os.environ.get("BLR_BENCH_SAME_DEVICE") == "1":
+        local_rank = 0
     if world > 1:
         import torch.distributed as dist_mod
 
         dist = dist_mod
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group(backend="nccl", rank=rank, world_size=world,
-                                device_id=torch.device(f"cuda:{local_rank}"))
+        if backend == "nccl":
+            dist.init_process_group(backend="nccl", rank=rank, world_size=world,
+                                    device_id=torch.device(f"cuda:{local_rank}"))
+        else:
+            dist.init_process_group(backend=backend, rank=rank, world_size=world)
     torch.cuda.set_device(local_rank)
     dev = torch.device(f"cuda:{local_rank}")
 
@@ -166,7 +174,12 @@ def main():
         if dist is not None:
             # the path's only exchange: all-gather of the per-regressor log evidences (8 B each), then the SAME
             # fixed-order device sum on every rank -> identical bits for every rank count
-            dist.all_gather_into_tensor(lp_all, lp)
+            if backend == "nccl":
+                dist.all_gather_into_tensor(lp_all, lp)
+            else:  # host-staged collective (validation only)
+                host = torch.empty(B * world, dtype=torch.float64)
+                dist.all_gather_into_tensor(host, lp.cpu())
+                lp_all.copy_(host)
             h.logpdf_sum(_abi.MEM_DEVICE, B * world, lp_all.data_ptr(), lp_sum.data_ptr())
         else:
             h.logpdf_sum(_abi.MEM_DEVICE, B, lp.data_ptr(), lp_sum.data_ptr())
@@ -187,7 +200,7 @@ def main():
     torch.cuda.synchronize(dev)
     elapsed = time.perf_counter() - t0
 
-    t_el = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+    t_el = torch.tensor([elapsed], dtype=torch.float64, device=dev if backend == "nccl" else "cpu")
     if dist is not None:
         dist.all_reduce(t_el, op=dist.ReduceOp.MAX)
     elapsed = float(t_el.item())
