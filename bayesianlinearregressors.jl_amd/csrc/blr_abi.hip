@@ -243,7 +243,8 @@ int posterior_large_one(blr_handle* h, const PosteriorArgs<T>& a, int64_t reg) {
   const size_t o_q = carve((size_t)gridc * sizeof(double));
   const size_t o_l = carve((size_t)gridc * sizeof(double));
   const size_t o_m = carve((size_t)DP * DP * sizeof(T));  // transposed factor for the back substitution
-  const size_t o_sc = carve(64);
+  const size_t o_sc = carve(64 + 64 * sizeof(int));  // scalars + the back substitution's block flags
+  const size_t o_ms = carve((size_t)DP * sizeof(T));  // solution blocks exchanged between the back substitution's workgroups
   int rc = ensure_ws(h, off);
   if (rc) return rc;
   char* ws = h->ws;
@@ -265,7 +266,7 @@ int posterior_large_one(blr_handle* h, const PosteriorArgs<T>& a, int64_t reg) {
   const T* mw = a.mw + reg * a.stridemw;
   const T* Lw = a.Lw + reg * a.strideLw;
 
-  HIP_TRY(h, hipMemsetAsync(ws + o_sc, 0, 64, h->stream));
+  HIP_TRY(h, hipMemsetAsync(ws + o_sc, 0, 64 + 64 * sizeof(int), h->stream));
   HIP_TRY(h, hipMemsetAsync(bpart, 0, (size_t)nsplit_total * NC * kPB * sizeof(double), h->stream));
 
   // ---- prior: SPD check + logdet (reference :78)
@@ -327,15 +328,18 @@ int posterior_large_one(blr_handle* h, const PosteriorArgs<T>& a, int64_t reg) {
                        (int64_t)DP, a.T_post ? a.T_post + reg * a.strideT : (T*)nullptr, a.ldt, D);
   }
   {
-    BacksolveArgs<T> b{};
-    b.Abar = Abar; b.lda = lda; b.D = D; b.DP = DP; b.Tf = Tfull; b.ldtf = DP; b.mw = mw;
-    b.mw_post = a.mw_post ? a.mw_post + reg * a.stride_mwpost : nullptr;
+    WaveSolveArgs<T> b{};
+    b.Tf = Tfull; b.ldtf = DP; b.D = D; b.DP = DP;
+    b.rhs = Abar + DP; b.ldrhs = 0; b.rhs_inc = lda;  // u = row DP of the factored Abar
+    b.m = reinterpret_cast<T*>(ws + o_ms); b.ldm = DP;
+    b.flags = reinterpret_cast<int*>(ws + o_sc + 64);
+    b.add = mw; b.out = a.mw_post ? a.mw_post + reg * a.stride_mwpost : nullptr; b.ldout = 0;
     b.qpart = qpart; b.lpart = lpart; b.nparts = gridc; b.logdet_Lw_dev = logdetLw;
     b.noise_kind = a.noise_kind; b.s = s; b.N = N;
     b.logpdf = a.logpdf ? a.logpdf + reg : nullptr; b.info = a.info + reg; b.chol_info = info_chol;
-    size_t lds = SC::LDS_BYTES + (size_t)DP * sizeof(T) + 16;
-    if ((rc = set_lds<T>(h, reinterpret_cast<const void*>(backsolve_kernel<T>), lds))) return rc;
-    hipLaunchKernelGGL(backsolve_kernel<T>, dim3(1), dim3(kThreads), lds, h->stream, b);
+    const size_t lds = SC::LDS_BYTES + 3 * kPB * sizeof(T) + 16;
+    if ((rc = set_lds<T>(h, reinterpret_cast<const void*>(backsolve_wave_kernel<T>), lds))) return rc;
+    hipLaunchKernelGGL(backsolve_wave_kernel<T>, dim3(NC, 1), dim3(kThreads), lds, h->stream, b);
   }
   HIP_TRY(h, hipGetLastError());
   return 0;
@@ -653,6 +657,63 @@ int marginals_batched(blr_handle* h, int memspace, int layout, int64_t B, int64_
   return 0;
 }
 
+// D > 128: W[:, s] = mw + U^-1 Z[:, s] with U = chol(Lw).U -- the wavefront back substitution of the posterior path with
+// one grid column per draw (reference :46-52).  All pointers are device pointers.
+template <typename T>
+int sample_weights_large(blr_handle* h, int64_t D, int64_t S, int prior_kind, const T* mw, const T* Lw, int64_t ldl,
+                         const T* Z, int64_t ldz, T* W, int64_t ldw) {
+  using SC = SmallCfg<T, 8>;
+  if (prior_kind == BLR_PRIOR_DIAGONAL) {
+    hipLaunchKernelGGL(diag_sample_kernel<T>, dim3(1024), dim3(kThreads), 0, h->stream, mw, Lw, Z, ldz, W, ldw, (int)D, S);
+    HIP_TRY(h, hipGetLastError());
+    return 0;
+  }
+  const int DP = (int)((D + kPB - 1) / kPB * kPB), NC = DP / kPB;
+  const int64_t chunk = std::min<int64_t>(S, 16384);
+  size_t off = 0;
+  auto carve = [&](size_t bytes) { size_t o = off; off = (off + bytes + 255) & ~(size_t)255; return o; };
+  const size_t o_tf = carve((size_t)DP * DP * sizeof(T));
+  const size_t o_wk = carve(prior_kind == BLR_PRIOR_DENSE ? (size_t)DP * DP * sizeof(T) : 0);
+  const size_t o_m = carve((size_t)chunk * DP * sizeof(T));
+  const size_t o_fl = carve((size_t)chunk * NC * sizeof(int));
+  const size_t o_info = carve(64);
+  int rc = ensure_ws(h, off);
+  if (rc) return rc;
+  char* ws = h->ws;
+  T* Tf = reinterpret_cast<T*>(ws + o_tf);
+  int32_t* info_dev = reinterpret_cast<int32_t*>(ws + o_info);
+  if (prior_kind == BLR_PRIOR_UPPER_FACTOR) {
+    hipLaunchKernelGGL(upper_pad_kernel<T>, dim3(1024), dim3(kThreads), 0, h->stream, Lw, ldl, (int)D, DP, Tf, (int64_t)DP);
+  } else {
+    T* Wk = reinterpret_cast<T*>(ws + o_wk);
+    HIP_TRY(h, hipMemsetAsync(info_dev, 0, 64, h->stream));
+    hipLaunchKernelGGL(prior_copy_kernel<T>, dim3(1024), dim3(kThreads), 0, h->stream, Lw, ldl, (int)D, DP, Wk, (int64_t)DP);
+    if ((rc = chol_large<T>(h, Wk, DP, DP, DP, info_dev))) return rc;
+    dim3 grid((DP + 31) / 32, (DP + 31) / 32);
+    hipLaunchKernelGGL(transpose_out_kernel<T>, grid, dim3(kThreads), 0, h->stream, (const T*)Wk, (int64_t)DP, DP, Tf,
+                       (int64_t)DP, (T*)nullptr, (int64_t)0, 0);
+    int32_t hinfo = 0;
+    HIP_TRY(h, hipMemcpyAsync(&hinfo, info_dev, sizeof(int32_t), hipMemcpyDeviceToHost, h->stream));
+    HIP_TRY(h, hipStreamSynchronize(h->stream));
+    if (hinfo != 0) return hinfo;  // the prior precision is not positive definite
+  }
+  const size_t lds = SC::LDS_BYTES + 3 * kPB * sizeof(T) + 16;
+  if ((rc = set_lds<T>(h, reinterpret_cast<const void*>(backsolve_wave_kernel<T>), lds))) return rc;
+  for (int64_t s0 = 0; s0 < S; s0 += chunk) {
+    const int64_t ns = std::min(chunk, S - s0);
+    HIP_TRY(h, hipMemsetAsync(ws + o_fl, 0, (size_t)ns * NC * sizeof(int), h->stream));
+    WaveSolveArgs<T> b{};
+    b.Tf = Tf; b.ldtf = DP; b.D = (int)D; b.DP = DP;
+    b.rhs = Z + s0 * ldz; b.ldrhs = ldz; b.rhs_inc = 1;
+    b.m = reinterpret_cast<T*>(ws + o_m); b.ldm = DP;
+    b.flags = reinterpret_cast<int*>(ws + o_fl);
+    b.add = mw; b.out = W + s0 * ldw; b.ldout = ldw;
+    hipLaunchKernelGGL(backsolve_wave_kernel<T>, dim3(NC, (unsigned)ns), dim3(kThreads), lds, h->stream, b);
+  }
+  HIP_TRY(h, hipGetLastError());
+  return 0;
+}
+
 template <typename T>
 int sample_weights_impl(blr_handle* h, int memspace, int64_t D, int64_t S, int prior_kind, const T* mw, const T* Lw,
                         int64_t ldl, const T* Z, int64_t ldz, T* W, int64_t ldw, bool sync_and_copy, T** W_dev_out,
@@ -676,6 +737,19 @@ int sample_weights_impl(blr_handle* h, int memspace, int64_t D, int64_t S, int p
     h->staged.push_back(p);
     W_d = static_cast<T*>(p);
     ldw = D;
+  }
+  if (D > kMaxSmallD) {
+    if ((rc = sample_weights_large<T>(h, D, S, prior_kind, mw_d, Lw_d, ldl, Z_d, ldz, W_d, ldw))) return rc;
+    if (W_dev_out) *W_dev_out = W_d;
+    if (sync_and_copy) {
+      if (memspace == BLR_MEM_HOST) {
+        HIP_TRY(h, hipMemcpyAsync(W, W_d, mat_extent(D, S, ldw) * sizeof(T), hipMemcpyDeviceToHost, h->stream));
+        HIP_TRY(h, hipStreamSynchronize(h->stream));
+      } else if (!h->async) {
+        HIP_TRY(h, hipStreamSynchronize(h->stream));
+      }
+    }
+    return 0;
   }
   const T* U;
   int64_t ldu, strideU;
@@ -712,7 +786,7 @@ int sample_weights(blr_handle* h, int memspace, int64_t D, int64_t S, int prior_
   if (!h) return -1;
   h->err.clear();
   if (memspace != BLR_MEM_HOST && memspace != BLR_MEM_DEVICE) return bad_arg(h, 2, "memspace");
-  if (D < 1 || D > kMaxSmallD) return bad_arg(h, 3, "D out of range for this build (1..128)");
+  if (D < 1 || D > kMaxLargeD) return bad_arg(h, 3, "D out of range for this build (1..8192)");
   if (S < 0) return bad_arg(h, 4, "S < 0");
   if (S == 0) return 0;
   if (prior_kind != BLR_PRIOR_DENSE && prior_kind != BLR_PRIOR_UPPER_FACTOR && prior_kind != BLR_PRIOR_DIAGONAL)
@@ -737,7 +811,7 @@ int rand_impl(blr_handle* h, int memspace, int layout, int64_t D, int64_t N, int
   h->err.clear();
   if (memspace != BLR_MEM_HOST && memspace != BLR_MEM_DEVICE) return bad_arg(h, 2, "memspace");
   if (layout != BLR_LAYOUT_COLVECS && layout != BLR_LAYOUT_ROWVECS) return bad_arg(h, 3, "unknown layout (reference :26-31)");
-  if (D < 1 || D > kMaxSmallD) return bad_arg(h, 4, "D out of range for this build (1..128)");
+  if (D < 1 || D > kMaxLargeD) return bad_arg(h, 4, "D out of range for this build (1..8192)");
   if (N < 0 || N > (1 << 30)) return bad_arg(h, 5, "N out of range");
   if (S < 0) return bad_arg(h, 6, "S < 0");
   if (N == 0 || S == 0) return 0;

@@ -80,6 +80,13 @@ def cpu_baseline(D, N, seconds, seed):
     }
 
 
+def _config_name(D, N, dtype):
+    """BASELINE.json config the shape corresponds to (c2 is the headline; the others are secondary shapes)."""
+    table = {(128, 4096, "f64"): "c2", (2, 10, "f64"): "c1", (1024, 65536, "f32"): "c3", (64, 1024, "f64"): "c4 shape",
+             (2048, 16384, "f32"): "c5 shape (features precomputed)"}
+    return table.get((D, N, dtype), "custom")
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -252,7 +259,7 @@ def main():
             "dtype": args.dtype,
             "data": "synthetic",
             "config": {
-                "workload": f"c2: independent regressors D={D}, N={N}, ColVecs, {args.noise} noise, {args.dtype}, "
+                "workload": f"{_config_name(D, N, args.dtype)}: independent regressors D={D}, N={N}, ColVecs, {args.noise} noise, {args.dtype}, "
                             f"Lw=I, fused posterior+logpdf",
                 "D": D, "N": N, "batch_per_gpu": B, "global_batch": B * world,
                 "sharding": f"regressors x{world}, no data-path collective; one all-gather of {B * world} doubles",

@@ -722,3 +722,41 @@ def test_large_d_marginals(B, dtype, D, N):
     np.testing.assert_allclose(v, O.var(mw.astype(float), np.diag(dvec.astype(float)), X.astype(float), 0.5), rtol=rt)
     with pytest.raises(B.PosDefException):
         B.var(B.BayesianLinearRegressor(mw, -Lw)(np.asfortranarray(X), s))
+
+
+@pytest.mark.parametrize("dtype,D,N,S", [(np.float64, 130, 40, 3), (np.float64, 384, 257, 70), (np.float32, 1024, 500, 5)])
+def test_large_d_rand_and_weight_draws(B, dtype, D, N, S):
+    # reference :46-53 at D > 128: blocked factorisation of the prior + wavefront back substitution, one grid column per draw
+    from blr_amd import _abi
+
+    rng = _rng(9100 + D)
+    X = rng.standard_normal((D, N)).astype(dtype)
+    mw = rng.standard_normal(D).astype(dtype)
+    Bm = rng.standard_normal((D, D)) / np.sqrt(D)
+    Lw = (Bm @ Bm.T + np.eye(D)).astype(dtype)
+    s = np.exp(0.3 * rng.standard_normal(N)).astype(dtype)
+    Z1 = np.asfortranarray(rng.standard_normal((D, S)).astype(dtype))
+    Z2 = np.asfortranarray(rng.standard_normal((N, S)).astype(dtype))
+    f64 = lambda a: np.asarray(a, dtype=float)
+    rt = 1e-10 if dtype == np.float64 else 2e-4
+    W_o = O.sample_weights(f64(mw), f64(Lw), f64(Z1))
+    Y_o = O.rand(f64(mw), f64(Lw), f64(X), f64(s), f64(Z1), f64(Z2))
+    h = _abi.default_handle()
+    U = np.asfortranarray(O.chol_upper(f64(Lw)).astype(dtype))
+    for kind, Larg in ((_abi.PRIOR_DENSE, np.asfortranarray(Lw)), (_abi.PRIOR_UPPER_FACTOR, U)):
+        W = np.empty((D, S), dtype=dtype, order="F")
+        h.sample_weights(dtype, _abi.MEM_HOST, D, S, kind, mw, Larg, D, Z1, D, W, D)
+        np.testing.assert_allclose(W, W_o, rtol=rt, atol=rt * 10)
+        for layout, Xa, ldx in ((_abi.LAYOUT_COLVECS, np.asfortranarray(X), D), (_abi.LAYOUT_ROWVECS, np.ascontiguousarray(X), N)):
+            Y = np.empty((N, S), dtype=dtype, order="F")
+            h.rand(dtype, _abi.MEM_HOST, layout, D, N, S, Xa, ldx, _abi.NOISE_DIAGONAL, s, kind, mw, Larg, D, Z1, D, Z2, N, Y, N)
+            np.testing.assert_allclose(Y, Y_o, rtol=rt * 10, atol=rt * 100)
+    dvec = np.exp(rng.standard_normal(D)).astype(dtype)
+    W = np.empty((D, S), dtype=dtype, order="F")
+    h.sample_weights(dtype, _abi.MEM_HOST, D, S, _abi.PRIOR_DIAGONAL, mw, dvec, D, Z1, D, W, D)
+    np.testing.assert_allclose(W, f64(mw)[:, None] + f64(Z1) / np.sqrt(f64(dvec))[:, None], rtol=rt)
+    # the host mirror draws through the same path; a non-SPD prior raises like cholesky() in the reference (:50)
+    g = B.rand(np.random.default_rng(1), B.BayesianLinearRegressor(mw, Lw))
+    assert g.w.shape == (D,)
+    with pytest.raises(B.PosDefException):
+        B.rand(np.random.default_rng(1), B.BayesianLinearRegressor(mw, -Lw))
