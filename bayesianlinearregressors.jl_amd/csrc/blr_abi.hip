@@ -173,13 +173,11 @@ template <typename T>
 int chol_large(blr_handle* h, T* M, int64_t ld, int DP, int nrows_total, int32_t* info_dev) {
   using SC = SmallCfg<T, 8>;
   using TC = TrsmCfg<T>;
-  using LC = LargeCfg<T>;
   const int NC = DP / kPB;
-  const int NRB = (nrows_total + kPB - 1) / kPB;  // row blocks including the rhs block
   int rc;
   if ((rc = set_lds<T>(h, reinterpret_cast<const void*>(chol_diag_kernel<T>), SC::LDS_BYTES))) return rc;
   if ((rc = set_lds<T>(h, reinterpret_cast<const void*>(trsm_block_kernel<T>), TC::LDS_BYTES))) return rc;
-  if ((rc = set_lds<T>(h, reinterpret_cast<const void*>(gram_tile_kernel<T>), LC::LDS_BYTES))) return rc;
+  if ((rc = set_lds<T>(h, reinterpret_cast<const void*>(trail_update_kernel<T>), TrailCfg<T>::LDS_BYTES))) return rc;
   for (int p = 0; p < NC; ++p) {
     hipLaunchKernelGGL(chol_diag_kernel<T>, dim3(1), dim3(kThreads), SC::LDS_BYTES, h->stream, M, ld, p, info_dev, 0);
     const int row_begin = (p + 1) * kPB;
@@ -190,18 +188,11 @@ int chol_large(blr_handle* h, T* M, int64_t ld, int DP, int nrows_total, int32_t
     }
     const int m = NC - 1 - p;  // remaining column blocks
     if (m > 0) {
-      GramTileArgs<T> g{};
-      g.X = M + (int64_t)p * kPB * ld; g.ldx = ld; g.layout = LAYOUT_COLVECS; g.use_dma = 1;
-      g.s = nullptr; g.noise_kind = NOISE_ISOTROPIC; g.r = nullptr;
-      g.D = nrows_total; g.n_begin = 0; g.n_end = kPB; g.nsplit = 1;
-      g.tile_i0 = p + 1; g.tile_j0 = p + 1; g.nblocks = NRB;
-      g.C = M; g.ldc = ld; g.mode_out = 1;
-      if (NRB > NC) {  // triangle + the rhs row block (tiles (NC, p+1 .. NC-1)) in ONE launch
-        g.tri = 4; g.ntile_rows = m; g.extra_row = NC; g.ntiles = m * (m + 1) / 2 + m;
-      } else {
-        g.tri = 1; g.ntiles = m * (m + 1) / 2;
-      }
-      hipLaunchKernelGGL(gram_tile_kernel<T>, dim3(g.ntiles), dim3(kThreads), LC::LDS_BYTES, h->stream, g);
+      const int ntri = 2 * m;                                   // 64-row sub-blocks of the remaining triangle
+      const int nextra = (nrows_total - DP) / TrailCfg<T>::SB;  // rhs rows below the square part
+      const int ntiles = ntri * (ntri + 1) / 2 + nextra * ntri;
+      hipLaunchKernelGGL(trail_update_kernel<T>, dim3(ntiles), dim3(kThreads), TrailCfg<T>::LDS_BYTES, h->stream, M, ld, p, ntri,
+                         (p + 1) * kPB, DP, (const int32_t*)info_dev);
     }
   }
   HIP_TRY(h, hipGetLastError());
@@ -243,7 +234,7 @@ int posterior_large_one(blr_handle* h, const PosteriorArgs<T>& a, int64_t reg) {
   const size_t o_q = carve((size_t)gridc * sizeof(double));
   const size_t o_l = carve((size_t)gridc * sizeof(double));
   const size_t o_m = carve((size_t)DP * DP * sizeof(T));  // transposed factor for the back substitution
-  const size_t o_sc = carve(64 + 64 * sizeof(int));  // scalars + the back substitution's block flags
+  const size_t o_sc = carve(64 + 128 * sizeof(int));  // scalars + the back substitution's block flags and ticket
   const size_t o_ms = carve((size_t)DP * sizeof(T));  // solution blocks exchanged between the back substitution's workgroups
   int rc = ensure_ws(h, off);
   if (rc) return rc;
@@ -266,7 +257,7 @@ int posterior_large_one(blr_handle* h, const PosteriorArgs<T>& a, int64_t reg) {
   const T* mw = a.mw + reg * a.stridemw;
   const T* Lw = a.Lw + reg * a.strideLw;
 
-  HIP_TRY(h, hipMemsetAsync(ws + o_sc, 0, 64 + 64 * sizeof(int), h->stream));
+  HIP_TRY(h, hipMemsetAsync(ws + o_sc, 0, 64 + 128 * sizeof(int), h->stream));
   HIP_TRY(h, hipMemsetAsync(bpart, 0, (size_t)nsplit_total * NC * kPB * sizeof(double), h->stream));
 
   // ---- prior: SPD check + logdet (reference :78)
@@ -298,9 +289,11 @@ int posterior_large_one(blr_handle* h, const PosteriorArgs<T>& a, int64_t reg) {
     g.D = D; g.n_begin = 0; g.n_end = N; g.nsplit = nsplit;
     g.tile_i0 = 0; g.tile_j0 = 0; g.tri = 1; g.ntiles = ntiles; g.nblocks = NC;
     g.Gpart = Gpart; g.bpart = bpart; g.mode_out = 0;
+    g.xcd_swizzle = (nsplit > 1 && !getenv("BLR_MI355X_NO_XCD_SWIZZLE")) ? 1 : 0;
     hipLaunchKernelGGL(gram_tile_kernel<T>, dim3(ntiles * nsplit), dim3(kThreads), LC::LDS_BYTES, h->stream, g);
     if (prior_factor) {
       GramTileArgs<T> u = g;
+      u.xcd_swizzle = 0;
       u.X = Lw; u.ldx = a.ldl; u.layout = 2; u.use_dma = 0; u.s = nullptr; u.r = nullptr;
       u.n_begin = 0; u.n_end = D; u.nsplit = 1;
       u.Gpart = Gpart + (int64_t)nsplit * ntiles * kPB * kPB;
@@ -333,11 +326,12 @@ int posterior_large_one(blr_handle* h, const PosteriorArgs<T>& a, int64_t reg) {
     b.rhs = Abar + DP; b.ldrhs = 0; b.rhs_inc = lda;  // u = row DP of the factored Abar
     b.m = reinterpret_cast<T*>(ws + o_ms); b.ldm = DP;
     b.flags = reinterpret_cast<int*>(ws + o_sc + 64);
+    b.ticket = b.flags + 64;
     b.add = mw; b.out = a.mw_post ? a.mw_post + reg * a.stride_mwpost : nullptr; b.ldout = 0;
     b.qpart = qpart; b.lpart = lpart; b.nparts = gridc; b.logdet_Lw_dev = logdetLw;
     b.noise_kind = a.noise_kind; b.s = s; b.N = N;
     b.logpdf = a.logpdf ? a.logpdf + reg : nullptr; b.info = a.info + reg; b.chol_info = info_chol;
-    const size_t lds = SC::LDS_BYTES + 3 * kPB * sizeof(T) + 16;
+    const size_t lds = SC::LDS_BYTES + 3 * kPB * sizeof(T) + 32;
     if ((rc = set_lds<T>(h, reinterpret_cast<const void*>(backsolve_wave_kernel<T>), lds))) return rc;
     hipLaunchKernelGGL(backsolve_wave_kernel<T>, dim3(NC, 1), dim3(kThreads), lds, h->stream, b);
   }
@@ -675,7 +669,7 @@ int sample_weights_large(blr_handle* h, int64_t D, int64_t S, int prior_kind, co
   const size_t o_tf = carve((size_t)DP * DP * sizeof(T));
   const size_t o_wk = carve(prior_kind == BLR_PRIOR_DENSE ? (size_t)DP * DP * sizeof(T) : 0);
   const size_t o_m = carve((size_t)chunk * DP * sizeof(T));
-  const size_t o_fl = carve((size_t)chunk * NC * sizeof(int));
+  const size_t o_fl = carve(((size_t)chunk * NC + 1) * sizeof(int));
   const size_t o_info = carve(64);
   int rc = ensure_ws(h, off);
   if (rc) return rc;
@@ -697,16 +691,17 @@ int sample_weights_large(blr_handle* h, int64_t D, int64_t S, int prior_kind, co
     HIP_TRY(h, hipStreamSynchronize(h->stream));
     if (hinfo != 0) return hinfo;  // the prior precision is not positive definite
   }
-  const size_t lds = SC::LDS_BYTES + 3 * kPB * sizeof(T) + 16;
+  const size_t lds = SC::LDS_BYTES + 3 * kPB * sizeof(T) + 32;
   if ((rc = set_lds<T>(h, reinterpret_cast<const void*>(backsolve_wave_kernel<T>), lds))) return rc;
   for (int64_t s0 = 0; s0 < S; s0 += chunk) {
     const int64_t ns = std::min(chunk, S - s0);
-    HIP_TRY(h, hipMemsetAsync(ws + o_fl, 0, (size_t)ns * NC * sizeof(int), h->stream));
+    HIP_TRY(h, hipMemsetAsync(ws + o_fl, 0, ((size_t)ns * NC + 1) * sizeof(int), h->stream));
     WaveSolveArgs<T> b{};
     b.Tf = Tf; b.ldtf = DP; b.D = (int)D; b.DP = DP;
     b.rhs = Z + s0 * ldz; b.ldrhs = ldz; b.rhs_inc = 1;
     b.m = reinterpret_cast<T*>(ws + o_m); b.ldm = DP;
     b.flags = reinterpret_cast<int*>(ws + o_fl);
+    b.ticket = b.flags + ns * NC;
     b.add = mw; b.out = W + s0 * ldw; b.ldout = ldw;
     hipLaunchKernelGGL(backsolve_wave_kernel<T>, dim3(NC, (unsigned)ns), dim3(kThreads), lds, h->stream, b);
   }

@@ -60,7 +60,55 @@ __global__ __launch_bounds__(kThreads) void colstats_kernel(ColstatsArgs<T> a) {
   const bool diag = a.noise_kind == NOISE_DIAGONAL;
   const T s_iso = diag ? T(1) : a.s[0];
   double q = 0.0, l = 0.0;
-  if (a.layout == LAYOUT_COLVECS) {
+  typedef T vecT __attribute__((ext_vector_type(Mfma<T>::VEC)));
+  constexpr int VEC = Mfma<T>::VEC;
+  const bool vec_ok = a.layout == LAYOUT_COLVECS && (D % VEC) == 0 && (a.ldx % VEC) == 0 && ((uintptr_t)a.X % 16) == 0;
+  if (vec_ok) {
+    // two columns per wave per step, 16-byte loads, up to 8 loads in flight per lane before the first use
+    const int DV = D / VEC;
+    const vecT* mwv = reinterpret_cast<const vecT*>(mwl);
+    const int wid = blockIdx.x * kWaves + wave, nw = gridDim.x * kWaves;
+    for (int n = 2 * wid; n < N; n += 2 * nw) {
+      const bool two = n + 1 < N;
+      const vecT* c0 = reinterpret_cast<const vecT*>(a.X + (int64_t)n * a.ldx);
+      const vecT* c1 = reinterpret_cast<const vecT*>(a.X + (int64_t)(two ? n + 1 : n) * a.ldx);
+      double mu0 = 0.0, mu1 = 0.0;
+      for (int i0 = 0; i0 < DV; i0 += 256) {
+        vecT v0[4], v1[4];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+          const int i = i0 + u * 64 + lane;
+          const bool in = i < DV;
+          v0[u] = in ? c0[i] : vecT(T(0));
+          v1[u] = in ? c1[i] : vecT(T(0));
+        }
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+          const int i = i0 + u * 64 + lane;
+          if (i < DV) {
+            const vecT m = mwv[i];
+#pragma unroll
+            for (int e = 0; e < VEC; ++e) {
+              mu0 += (double)v0[u][e] * (double)m[e];
+              mu1 += (double)v1[u][e] * (double)m[e];
+            }
+          }
+        }
+      }
+      mu0 = wave_allreduce(mu0);
+      mu1 = wave_allreduce(mu1);
+      if (lane < 2 && (lane == 0 || two)) {
+        const int nn = n + lane;
+        const double mu = lane == 0 ? mu0 : mu1;
+        const T sv = diag ? a.s[nn] : s_iso;
+        const T delta = a.y[nn] - (T)mu;
+        const T rn = delta / sv;
+        a.r[nn] = rn;
+        q += (double)delta * (double)rn;
+        if (diag) l += log((double)sv);
+      }
+    }
+  } else if (a.layout == LAYOUT_COLVECS) {
     // one column per wave: lanes stride over d (coalesced), fixed-order butterfly
     for (int n = blockIdx.x * kWaves + wave; n < N; n += gridDim.x * kWaves) {
       const T* col = a.X + (int64_t)n * a.ldx;
@@ -118,6 +166,7 @@ struct GramTileArgs {
   int ntiles, nblocks;
   T* C; int64_t ldc;         // mode 1: C[row + col*ldc] -= tile
   int mode_out;
+  int xcd_swizzle;           // remap blockIdx so that one XCD owns whole N-slices (split-K launches)
 };
 
 template <typename T>
@@ -134,7 +183,15 @@ __global__ __launch_bounds__(kThreads, 2) void gram_tile_kernel(GramTileArgs<T> 
   const int wave = uni(tid >> 6);
   const int wr = wave >> 1, wc = wave & 1;
 
-  const int t = blockIdx.x % a.ntiles, sidx = blockIdx.x / a.ntiles;
+  // Workgroups are dealt round-robin over the 8 XCDs (observed, speed only): give each XCD a CONTIGUOUS range of
+  // (split, tile) work items, so that the tiles of one N-slice -- which all stream the same columns of X -- share one
+  // L2 instead of pulling the slice into all eight (bijective for any grid size).
+  int w = blockIdx.x;
+  if (a.xcd_swizzle) {
+    const int nwg = gridDim.x, xcd = w & 7, qq = nwg >> 3, rr = nwg & 7;
+    w = (xcd < rr ? xcd * (qq + 1) : rr * (qq + 1) + (xcd - rr) * qq) + (w >> 3);
+  }
+  const int t = w % a.ntiles, sidx = w / a.ntiles;
   int I, J;
   if (a.tri == 1) {
     int ii = 0;
@@ -375,50 +432,85 @@ __global__ __launch_bounds__(kThreads) void gram_reduce_kernel(ReduceArgs<T> a) 
 // ---- block copies with many loads in flight -----------------------------------------------------------------------
 // A plain `for (idx = tid; ...) P[..] = g[..]` loop issues ONE global load per iteration and waits for it (~1-2 us
 // each): 64 iterations serialise to ~50 us for a 128 x 128 block.  These helpers issue 16 loads before the first use.
-template <typename T>
-__device__ __forceinline__ void load_lower_block_to_packed(T* __restrict__ P, const T* __restrict__ blk, int64_t ld, int tid) {
-#pragma unroll 1
-  for (int base = 0; base < kPB * kPB; base += kThreads * 16) {
-    T v[16];
+// All blocks handled here are 16-byte aligned with a leading dimension that is a multiple of 128 (workspace matrices),
+// so a 128 x 128 block is fetched as 16-byte vectors with EVERY load of the thread issued before the first use.
+template <typename T, int ROWS>
+struct BlockVec {
+  static constexpr int VEC = Mfma<T>::VEC;
+  static constexpr int VPC = ROWS / VEC;                     // vectors per column
+  static constexpr int NV = kPB * ROWS / (VEC * kThreads);   // vectors per thread
+  typedef T vecT __attribute__((ext_vector_type(Mfma<T>::VEC)));
+  vecT v[NV];
+  // ROWS x 128 column-major block at blk (element (r, c) at blk[r + c*ld])
+  __device__ __forceinline__ void load(const T* __restrict__ blk, int64_t ld, int tid) {
 #pragma unroll
-    for (int u = 0; u < 16; ++u) {
-      const int idx = base + u * kThreads + tid;
-      v[u] = blk[(int64_t)(idx >> 7) * ld + (idx & 127)];
-    }
-#pragma unroll
-    for (int u = 0; u < 16; ++u) {
-      const int idx = base + u * kThreads + tid;
-      const int c = idx >> 7, r = idx & 127;
-      if (r >= c) P[pidx(r, c)] = v[u];
+    for (int u = 0; u < NV; ++u) {
+      const int vi = u * kThreads + tid;
+      v[u] = *reinterpret_cast<const vecT*>(blk + (int64_t)(vi / VPC) * ld + (vi % VPC) * VEC);
     }
   }
+  // lower triangle of a 128 x 128 block -> packed P[pidx(r, c)]
+  __device__ __forceinline__ void to_packed_lower(T* __restrict__ P, int tid) const {
+    static_assert(ROWS == kPB, "square block");
+#pragma unroll
+    for (int u = 0; u < NV; ++u) {
+      const int vi = u * kThreads + tid;
+      const int c = vi / VPC, r0 = (vi % VPC) * VEC;
+#pragma unroll
+      for (int e = 0; e < VEC; ++e)
+        if (r0 + e >= c) P[pidx(r0 + e, c)] = v[u][e];
+    }
+  }
+  // upper-stored factor block (U = L'): element (r, c) of the block is L[c][r] -> P[pidx(c, r)]
+  __device__ __forceinline__ void to_packed_from_upper(T* __restrict__ P, int tid) const {
+    static_assert(ROWS == kPB, "square block");
+#pragma unroll
+    for (int u = 0; u < NV; ++u) {
+      const int vi = u * kThreads + tid;
+      const int c = vi / VPC, r0 = (vi % VPC) * VEC;
+#pragma unroll
+      for (int e = 0; e < VEC; ++e)
+        if (c >= r0 + e) P[pidx(c, r0 + e)] = v[u][e];
+    }
+  }
+  // rows image Xs[r * ldxs + c]; rows >= nr are zero-filled
+  __device__ __forceinline__ void to_rows(T* __restrict__ Xs, int ldxs, int nr, int tid) const {
+#pragma unroll
+    for (int u = 0; u < NV; ++u) {
+      const int vi = u * kThreads + tid;
+      const int c = vi / VPC, r0 = (vi % VPC) * VEC;
+#pragma unroll
+      for (int e = 0; e < VEC; ++e) Xs[(r0 + e) * ldxs + c] = (r0 + e < nr) ? v[u][e] : T(0);
+    }
+  }
+};
+
+template <typename T>
+__device__ __forceinline__ void load_lower_block_to_packed(T* __restrict__ P, const T* __restrict__ blk, int64_t ld, int tid) {
+  BlockVec<T, kPB> b;
+  b.load(blk, ld, tid);
+  b.to_packed_lower(P, tid);
 }
 template <typename T>
 __device__ __forceinline__ void store_packed_to_lower_block(const T* __restrict__ P, T* __restrict__ blk, int64_t ld, int tid) {
-  for (int idx = tid; idx < kPB * kPB; idx += kThreads) {
-    const int c = idx >> 7, r = idx & 127;
-    if (r >= c) blk[(int64_t)c * ld + r] = P[pidx(r, c)];
+  using BV = BlockVec<T, kPB>;
+#pragma unroll 4
+  for (int u = 0; u < BV::NV; ++u) {
+    const int vi = u * kThreads + tid;
+    const int c = vi / BV::VPC, r0 = (vi % BV::VPC) * BV::VEC;
+    if (r0 + BV::VEC - 1 < c) continue;  // entirely above the diagonal
+    typename BV::vecT o;
+#pragma unroll
+    for (int e = 0; e < BV::VEC; ++e) o[e] = (r0 + e >= c) ? P[pidx(r0 + e, c)] : blk[(int64_t)c * ld + r0 + e];
+    *reinterpret_cast<typename BV::vecT*>(blk + (int64_t)c * ld + r0) = o;
   }
 }
-
 // the same packed image from an UPPER factor block (U = L'): P[pidx(r, c)] = U[c, r]
 template <typename T>
 __device__ __forceinline__ void load_upper_block_to_packed(T* __restrict__ P, const T* __restrict__ blk, int64_t ld, int tid) {
-#pragma unroll 1
-  for (int base = 0; base < kPB * kPB; base += kThreads * 16) {
-    T v[16];
-#pragma unroll
-    for (int u = 0; u < 16; ++u) {
-      const int idx = base + u * kThreads + tid;
-      v[u] = blk[(int64_t)(idx >> 7) * ld + (idx & 127)];
-    }
-#pragma unroll
-    for (int u = 0; u < 16; ++u) {
-      const int idx = base + u * kThreads + tid;
-      const int r = idx >> 7, c = idx & 127;
-      if (r >= c) P[pidx(r, c)] = v[u];
-    }
-  }
+  BlockVec<T, kPB> b;
+  b.load(blk, ld, tid);
+  b.to_packed_from_upper(P, tid);
 }
 
 // ---- diagonal block factorisation --------------------------------------------------------------------------------
@@ -442,6 +534,122 @@ __global__ __launch_bounds__(kThreads, (sizeof(T) == 4 ? BLR_F32_WAVES_PER_SIMD 
     return;
   }
   store_packed_to_lower_block(P, blk, lda, tid);
+}
+
+// ---- trailing update of the blocked Cholesky: C -= L_I L_J' for every 64 x 64 sub-tile below panel p -----------------------
+// The update has K = 128 only, so it is pure latency: one workgroup per 64 x 64 sub-tile issues ALL its loads at once
+// (both 64 x 128 operand blocks as 16-byte vectors, the C sub-tile straight into the MFMA accumulators), writes the
+// operands to LDS in fragment order, runs 32 k-steps x 4 MFMAs per wave and stores.  One barrier, no stage loop
+// (the general split-K tile kernel took ~20 us per panel for the same work).
+template <typename T>
+struct TrailCfg {
+  static constexpr int SB = 64;                                    // sub-tile edge
+  static constexpr int SIDE = (kPB / 4) * (SB / 16) * 64;          // elements of one operand image [32][4][64]
+  static constexpr int LDS_BYTES = 2 * SIDE * (int)sizeof(T);      // 64 KB (f32) / 128 KB (f64)
+};
+
+template <typename T>
+__global__ __launch_bounds__(kThreads) void trail_update_kernel(T* M, int64_t ld, int p, int ntri /* 64-row blocks in the triangle */,
+                                                                int row_tri0 /* first row of the triangle */,
+                                                                int row_extra0 /* first extra row (rhs rows) */,
+                                                                const int32_t* info) {
+  using Cfg = TrailCfg<T>;
+  using acc4 = typename Mfma<T>::acc4;
+  constexpr int VEC = Mfma<T>::VEC;
+  constexpr int SB = Cfg::SB;
+  typedef T vecT __attribute__((ext_vector_type(Mfma<T>::VEC)));
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  T* const As = reinterpret_cast<T*>(smem);
+  T* const Bs = As + Cfg::SIDE;
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = uni(tid >> 6);
+  const int wr = wave >> 1, wc = wave & 1;
+
+  // sub-tile (si, sj): lower triangle over ntri sub-blocks, then the extra row blocks x ntri columns
+  const int ntt = ntri * (ntri + 1) / 2;
+  int t = blockIdx.x, rowA, rowB;
+  bool diag = false;
+  if (t < ntt) {
+    int si = (int)((sqrtf(8.0f * (float)t + 1.0f) - 1.0f) * 0.5f);
+    while ((si + 1) * (si + 2) / 2 <= t) ++si;
+    while (si * (si + 1) / 2 > t) --si;
+    const int sj = t - si * (si + 1) / 2;
+    rowA = row_tri0 + si * SB;
+    rowB = row_tri0 + sj * SB;
+    diag = si == sj;
+  } else {
+    t -= ntt;
+    rowA = row_extra0 + (t / ntri) * SB;
+    rowB = row_tri0 + (t % ntri) * SB;
+  }
+  const T* panel = M + (int64_t)p * kPB * ld;
+
+  // ---- every load of the workgroup in flight
+  constexpr int VPC = SB / VEC;                       // vectors per operand column
+  constexpr int NV = kPB * SB / (VEC * kThreads);     // vectors per thread per operand
+  vecT va[NV], vb[NV];
+#pragma unroll
+  for (int u = 0; u < NV; ++u) {
+    const int vi = u * kThreads + tid;
+    const int64_t off = (int64_t)(vi / VPC) * ld + (vi % VPC) * VEC;
+    va[u] = *reinterpret_cast<const vecT*>(panel + rowA + off);
+    vb[u] = *reinterpret_cast<const vecT*>(panel + rowB + off);
+  }
+  acc4 acc[2][2];
+#pragma unroll
+  for (int i = 0; i < 2; ++i)
+#pragma unroll
+    for (int k = 0; k < 2; ++k) {
+      const int col = rowB + 16 * (2 * wc + k) + (lane & 15);
+      if constexpr (sizeof(T) == 4) {
+        const int row0 = rowA + 16 * (2 * wr + i) + 4 * (lane >> 4);
+        acc[i][k] = *reinterpret_cast<const acc4*>(M + (int64_t)col * ld + row0);
+      } else {
+#pragma unroll
+        for (int v = 0; v < 4; ++v)
+          acc[i][k][v] = M[(int64_t)col * ld + rowA + 16 * (2 * wr + i) + Mfma<T>::crow(lane, v)];
+      }
+    }
+  if (*info != 0) return;
+  // ---- fragment-order images: [k-step][row block][lane], lane l <-> (row 16I + (l & 15), column 4kk + (l >> 4))
+#pragma unroll
+  for (int u = 0; u < NV; ++u) {
+    const int vi = u * kThreads + tid;
+    const int k = vi / VPC, r0 = (vi % VPC) * VEC;
+    const int idx = (((k >> 2) * (SB / 16) + (r0 >> 4)) << 6) + ((k & 3) << 4) + (r0 & 15);
+    *reinterpret_cast<vecT*>(As + idx) = -va[u];
+    *reinterpret_cast<vecT*>(Bs + idx) = vb[u];
+  }
+  __syncthreads();
+#pragma unroll 8
+  for (int kk = 0; kk < kPB / 4; ++kk) {
+    T fa[2], fb[2];
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+      fa[i] = As[((kk * (SB / 16) + 2 * wr + i) << 6) + lane];
+      fb[i] = Bs[((kk * (SB / 16) + 2 * wc + i) << 6) + lane];
+    }
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+      for (int k = 0; k < 2; ++k) acc[i][k] = Mfma<T>::mma(fa[i], fb[k], acc[i][k]);
+  }
+#pragma unroll
+  for (int i = 0; i < 2; ++i)
+#pragma unroll
+    for (int k = 0; k < 2; ++k) {
+      const int col = rowB + 16 * (2 * wc + k) + (lane & 15);
+      if constexpr (sizeof(T) == 4) {
+        const int row0 = rowA + 16 * (2 * wr + i) + 4 * (lane >> 4);
+        if (!diag || col <= row0 + 3) *reinterpret_cast<acc4*>(M + (int64_t)col * ld + row0) = acc[i][k];
+      } else {
+#pragma unroll
+        for (int v = 0; v < 4; ++v) {
+          const int row = rowA + 16 * (2 * wr + i) + Mfma<T>::crow(lane, v);
+          if (!diag || col <= row) M[(int64_t)col * ld + row] = acc[i][k][v];
+        }
+      }
+    }
 }
 
 // ---- X <- X L_pp^-T for one block of RB rows below the diagonal block ------------------------------------------------
@@ -515,50 +723,47 @@ __global__ __launch_bounds__(kThreads) void trsm_block_kernel(T* Abar, int64_t l
   T* const dinv = reinterpret_cast<T*>(smem + Cfg::OFF_DI);   // 1 / L_pp[c][c]
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = uni(tid >> 6);
-  if (*info != 0) return;
   const int r0 = row_begin + blockIdx.x * Cfg::RB;            // first global row of this block
-  const int nr = min(Cfg::RB, nrows_total - r0);
+  const int nr = min(Cfg::RB, nrows_total - r0);              // a multiple of 128 rows in every caller: whole vectors
   const T* Lpp = Abar + (int64_t)p * kPB * lda + (int64_t)p * kPB;
   T* Xg = Abar + (int64_t)p * kPB * lda + r0;
-  load_lower_block_to_packed(P, Lpp, lda, tid);
-#pragma unroll 1
-  for (int base = 0; base < Cfg::RB * kPB; base += kThreads * 16) {  // X block, 16 loads in flight per thread
-    T v[16];
-#pragma unroll
-    for (int u = 0; u < 16; ++u) {
-      const int idx = base + u * kThreads + tid;
-      const int c = idx / Cfg::RB, r = idx % Cfg::RB;          // coalesced along rows
-      v[u] = Xg[(int64_t)c * lda + (r < nr ? r : 0)];
-    }
-#pragma unroll
-    for (int u = 0; u < 16; ++u) {
-      const int idx = base + u * kThreads + tid;
-      const int c = idx / Cfg::RB, r = idx % Cfg::RB;
-      Xs[r * Cfg::LDX + c] = (r < nr) ? v[u] : T(0);
-    }
+  {
+    // both blocks in flight at once (one round of memory latency instead of eight)
+    BlockVec<T, kPB> lb;
+    BlockVec<T, Cfg::RB> xb;
+    lb.load(Lpp, lda, tid);
+    xb.load(Xg, lda, tid);
+    if (*info != 0) return;
+    lb.to_packed_lower(P, tid);
+    xb.to_rows(Xs, Cfg::LDX, nr, tid);
   }
   __syncthreads();
   if (tid < kPB) dinv[tid] = T(1) / P[pidx(tid, tid)];
   __syncthreads();
 
   trsm_core<T>(Xs, P, dinv, 8, tid, lane, wave);
-  for (int idx = tid; idx < Cfg::RB * kPB; idx += kThreads) {
-    const int c = idx / Cfg::RB, r = idx % Cfg::RB;
-    if (r < nr) Xg[(int64_t)c * lda + r] = Xs[r * Cfg::LDX + c];
+  {
+    using BV = BlockVec<T, Cfg::RB>;
+#pragma unroll 4
+    for (int u = 0; u < BV::NV; ++u) {
+      const int vi = u * kThreads + tid;
+      const int c = vi / BV::VPC, rr = (vi % BV::VPC) * BV::VEC;
+      if (rr < nr) {
+        typename BV::vecT o;
+#pragma unroll
+        for (int e = 0; e < BV::VEC; ++e) o[e] = Xs[(rr + e) * Cfg::LDX + c];
+        *reinterpret_cast<typename BV::vecT*>(Xg + (int64_t)c * lda + rr) = o;
+      }
+    }
   }
 }
 
-// ---- back substitution, evidence, posterior mean (one workgroup) -------------------------------------------------------
-// m = L^-T u on the TRANSPOSED factor Tf = L' (upper, column-major: transpose_full_kernel), bottom-up by 128-column
-// panels: m_p = T_pp^-1 u_p in LDS, then u[0 : 128p] -= Tf[0 : 128p, p-cols] m_p -- an AXPY form in which every
-// thread owns rows (coalesced column reads, many loads in flight, no cross-lane reduction).
 // ---- wavefront back substitution  m = L^-T u  over NC workgroups per right-hand side -------------------------------
 // Workgroup q owns row block q: it prefetches its diagonal block, subtracts Tf[q rows, p cols] m_p for every finished
 // block p > q as soon as that block's flag is published (the Tf sub-block is already in registers by then), solves its
 // 128 x 128 triangle in LDS (phase_backsolve of the small path) and publishes m_q.  Critical path: NC x (one triangle
-// solve + one flag round trip) instead of one workgroup streaming the whole factor (measured at D = 2048, f32: 445 -> 260 us).  blockIdx.x = NC-1-q: the hardware dispatches workgroups in index order, so every workgroup a waiting
-// one depends on is already running -- no co-residency assumption.  blockIdx.y = right-hand side (posterior: 1,
-// weight draws: S).
+// solve + one flag round trip) instead of one workgroup streaming the whole factor (measured at D = 2048, f32: 445 -> 260 us).
+// Grid = NC x S workgroups (S right-hand sides: posterior 1, weight draws S); (q, rhs) come from a start-order ticket.
 template <typename T>
 struct WaveSolveArgs {
   const T* Tf; int64_t ldtf;  // DP x DP upper factor U = L' (column-major, unit padding)
@@ -566,6 +771,7 @@ struct WaveSolveArgs {
   const T* rhs; int64_t ldrhs, rhs_inc;  // rhs s, entry j: rhs[s*ldrhs + j*rhs_inc]
   T* m; int64_t ldm;                     // exchanged solution [S][DP]
   int* flags;                            // [S][NC], zero before the launch
+  int* ticket;                           // one counter, zero before the launch
   const T* add; T* out; int64_t ldout;   // out[s*ldout + j] = add[j] + m_j  (j < D); out may be NULL
   // evidence assembly (posterior; S == 1), done by the workgroup that finishes last (q = 0); logpdf may be NULL
   const double* qpart; const double* lpart; int nparts;
@@ -585,8 +791,14 @@ __global__ __launch_bounds__(kThreads, (sizeof(T) == 4 ? BLR_F32_WAVES_PER_SIMD 
   T* const part = mp + kPB;
   const int tid = threadIdx.x;
   const int D = a.D, DP = a.DP, NC = DP / kPB;
-  const int q = NC - 1 - (int)blockIdx.x;
-  const int64_t sidx = blockIdx.y;
+  // Work items are handed out by a ticket in START order, not by blockIdx: a workgroup only ever waits for tickets
+  // lower than its own, whose owners are already running -- no assumption on dispatch order or co-residency.
+  int* const tick = reinterpret_cast<int*>(smem + C::LDS_BYTES + 3 * kPB * sizeof(T));
+  if (tid == 0) *tick = atomicAdd(a.ticket, 1);
+  __syncthreads();
+  const int ticket = *tick;
+  const int q = NC - 1 - ticket % NC;
+  const int64_t sidx = ticket / NC;
   const bool evidence = a.info != nullptr && q == 0 && sidx == 0;
   const double kNaN = __longlong_as_double(0x7ff8000000000000LL);
   if (a.chol_info && *a.chol_info != 0) {  // uniform over the grid: nobody waits
