@@ -659,57 +659,88 @@ struct TrsmCfg {
   static constexpr int LDX = kPB + 1;                      // padded row stride of the X image (conflict-free)
   static constexpr int OFF_X = ((kPB * (kPB + 1) / 2) * (int)sizeof(T) + 15) & ~15;
   static constexpr int OFF_DI = OFF_X + RB * LDX * (int)sizeof(T);
-  static constexpr int LDS_BYTES = ((OFF_DI + kPB * (int)sizeof(T)) + 15) & ~15;
+  static constexpr int LDI = 17;                           // padded row stride of the 16 x 16 inverse blocks
+  static constexpr int OFF_LI = (OFF_DI + kPB * (int)sizeof(T) + 15) & ~15;
+  static constexpr int LDS_BYTES = ((OFF_LI + kPB * LDI * (int)sizeof(T)) + 15) & ~15;
 };
 
-// X <- X L^-T on an LDS-resident block: Xs[RB][LDX] rows, L packed lower in P, dinv = 1 / diag(L); `nchunks` 16-column
-// chunks.  Left-looking: chunk J first receives  - sum_{K<J} X_K L_JK'  by MFMA, then is solved one row per thread.
+// X <- X L^-T on an LDS-resident block: Xs[RB][LDX] rows, L packed lower in P, dinv = 1 / diag(L), Linv = scratch for
+// the inverses of the 16 x 16 diagonal blocks of L; `nchunks` 16-column chunks.
+// Rows are independent, so each wave owns its row tiles for the whole sweep and the chunk loop needs NO workgroup
+// barrier: chunk J first receives  - sum_{K<J} X_K L_JK'  (MFMA, left-looking), then is multiplied by inv(L_JJ)' (MFMA
+// again: the per-row substitution of the first version serialised 16 steps per chunk on the vector ALU behind two
+// barriers).  The 16 x 16 inverses are formed once per block by 16 lanes each (forward substitution of a unit column).
 template <typename T>
-__device__ __forceinline__ void trsm_core(T* __restrict__ Xs, const T* __restrict__ P, const T* __restrict__ dinv, int nchunks,
-                                          int tid, int lane, int wave) {
+__device__ __forceinline__ void trsm_core(T* __restrict__ Xs, const T* __restrict__ P, const T* __restrict__ dinv,
+                                          T* __restrict__ Linv, int nchunks, int tid, int lane, int wave) {
   using Cfg = TrsmCfg<T>;
   using acc4 = typename Mfma<T>::acc4;
+  constexpr int NT = Cfg::RB / 64;  // row tiles per wave
+  constexpr int LI = Cfg::LDI;
   const int fr = lane & 15, fq = lane >> 4;
-  for (int J = 0; J < nchunks; ++J) {
-    // (1) left-looking update of chunk J with the already solved chunks K < J (MFMA)
-    for (int ta = wave; ta < Cfg::RB / 16; ta += kWaves) {
-      acc4 acc;
+  if (tid < 16 * nchunks) {
+    const int b = tid >> 4, j = tid & 15, j0 = 16 * b;
+    T x[16];
 #pragma unroll
-      for (int v = 0; v < 4; ++v) acc[v] = Xs[(16 * ta + Mfma<T>::crow(lane, v)) * Cfg::LDX + 16 * J + (lane & 15)];
-      for (int K = 0; K < J; ++K) {
+    for (int i = 0; i < 16; ++i) {
+      T sacc = (i == j) ? T(1) : T(0);
 #pragma unroll
-        for (int ks = 0; ks < 4; ++ks) {
-          const T fx = Xs[(16 * ta + fr) * Cfg::LDX + 16 * K + 4 * ks + fq];
-          const T fl = P[pidx(16 * J + fr, 16 * K + 4 * ks + fq)];
-          acc = Mfma<T>::mma(-fx, fl, acc);
-        }
-      }
-      // no other wave reads chunk J before the barrier, and this wave owns these 16 rows of it
-#pragma unroll
-      for (int v = 0; v < 4; ++v) Xs[(16 * ta + Mfma<T>::crow(lane, v)) * Cfg::LDX + 16 * J + (lane & 15)] = acc[v];
+      for (int k = 0; k < i; ++k) sacc -= P[pidx(j0, j0) + i * j0 + (i * (i + 1)) / 2 + k] * x[k];
+      x[i] = sacc * dinv[j0 + i];
+      Linv[(j0 + i) * LI + j] = x[i];
     }
-    __syncthreads();
-    // (2) inside the chunk: one row per thread, 16 columns, multipliers broadcast from LDS
-    if (tid < Cfg::RB) {
-      T x[16];
-      T* xr = Xs + tid * Cfg::LDX + 16 * J;
-#pragma unroll
-      for (int c = 0; c < 16; ++c) x[c] = xr[c];
-      const int j0 = 16 * J;
-#pragma unroll
-      for (int c = 0; c < 16; ++c) {
-        x[c] *= dinv[j0 + c];
-#pragma unroll
-        for (int k = c + 1; k < 16; ++k) {
-          // pidx(j0 + k, j0 + c) = pidx(j0, j0) + k*j0 + k(k+1)/2 + c : one runtime multiply-free base per k
-          x[k] -= x[c] * P[pidx(j0, j0) + k * j0 + (k * (k + 1)) / 2 + c];
-        }
-      }
-#pragma unroll
-      for (int c = 0; c < 16; ++c) xr[c] = x[c];
-    }
-    __syncthreads();
   }
+  __syncthreads();
+  for (int J = 0; J < nchunks; ++J) {
+    acc4 acc[NT];
+#pragma unroll
+    for (int t = 0; t < NT; ++t)
+#pragma unroll
+      for (int v = 0; v < 4; ++v)
+        acc[t][v] = Xs[(16 * (wave + kWaves * t) + Mfma<T>::crow(lane, v)) * Cfg::LDX + 16 * J + (lane & 15)];
+    for (int K = 0; K < J; ++K) {
+      T fl[4], fx[NT][4];
+#pragma unroll
+      for (int ks = 0; ks < 4; ++ks) {
+        fl[ks] = P[pidx(16 * J + fr, 16 * K + 4 * ks + fq)];
+#pragma unroll
+        for (int t = 0; t < NT; ++t) fx[t][ks] = Xs[(16 * (wave + kWaves * t) + fr) * Cfg::LDX + 16 * K + 4 * ks + fq];
+      }
+#pragma unroll
+      for (int ks = 0; ks < 4; ++ks)
+#pragma unroll
+        for (int t = 0; t < NT; ++t) acc[t] = Mfma<T>::mma(-fx[t][ks], fl[ks], acc[t]);
+    }
+    // C layout -> LDS -> A fragments (wave-local: LDS operations of one wave complete in order)
+#pragma unroll
+    for (int t = 0; t < NT; ++t)
+#pragma unroll
+      for (int v = 0; v < 4; ++v)
+        Xs[(16 * (wave + kWaves * t) + Mfma<T>::crow(lane, v)) * Cfg::LDX + 16 * J + (lane & 15)] = acc[t][v];
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    acc4 o[NT];
+#pragma unroll
+    for (int t = 0; t < NT; ++t) o[t] = acc4{T(0), T(0), T(0), T(0)};
+#pragma unroll
+    for (int ks = 0; ks < 4; ++ks) {
+      const T fi = Linv[(16 * J + fr) * LI + 4 * ks + fq];  // B[k][j] = inv(L_JJ)[j][k]
+#pragma unroll
+      for (int t = 0; t < NT; ++t) {
+        const T fu = Xs[(16 * (wave + kWaves * t) + fr) * Cfg::LDX + 16 * J + 4 * ks + fq];
+        o[t] = Mfma<T>::mma(fu, fi, o[t]);
+      }
+    }
+    __builtin_amdgcn_wave_barrier();
+#pragma unroll
+    for (int t = 0; t < NT; ++t)
+#pragma unroll
+      for (int v = 0; v < 4; ++v)
+        Xs[(16 * (wave + kWaves * t) + Mfma<T>::crow(lane, v)) * Cfg::LDX + 16 * J + (lane & 15)] = o[t][v];
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+  }
+  __syncthreads();
 }
 
 template <typename T>
@@ -741,7 +772,7 @@ __global__ __launch_bounds__(kThreads) void trsm_block_kernel(T* Abar, int64_t l
   if (tid < kPB) dinv[tid] = T(1) / P[pidx(tid, tid)];
   __syncthreads();
 
-  trsm_core<T>(Xs, P, dinv, 8, tid, lane, wave);
+  trsm_core<T>(Xs, P, dinv, reinterpret_cast<T*>(smem + Cfg::OFF_LI), 8, tid, lane, wave);
   {
     using BV = BlockVec<T, Cfg::RB>;
 #pragma unroll 4
@@ -1160,7 +1191,7 @@ __global__ __launch_bounds__(kThreads) void marginals_mfma_kernel(MarginalArgs<T
     for (int c = 0; c < D; ++c) m += xr[c] * mw[c];
   }
   __syncthreads();
-  if (a.var) trsm_core<T>(Xs, P, dinv, nchunks, tid, lane, wave);
+  if (a.var) trsm_core<T>(Xs, P, dinv, reinterpret_cast<T*>(smem + Cfg::OFF_LI), nchunks, tid, lane, wave);
   if (tid < nt) {
     if (a.mean) a.mean[(int64_t)reg * a.stridemean + n0 + tid] = m;
     if (a.var) {
