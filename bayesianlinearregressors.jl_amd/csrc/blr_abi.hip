@@ -30,6 +30,12 @@ struct blr_handle {
   size_t ws_bytes = 0;
   char* feat = nullptr;        // grow-only feature matrix of blr_posterior_rff_*
   size_t feat_bytes = 0;
+  // wavefront back substitution (D > 128): tagged exchange buffer, start-order ticket counter, launch epoch
+  unsigned long long* xchg = nullptr;
+  size_t xchg_bytes = 0;
+  unsigned* ticket = nullptr;
+  unsigned ticket_base = 0;
+  unsigned epoch = 0;
 };
 
 namespace {
@@ -99,6 +105,45 @@ int ensure_ws(blr_handle* h, size_t bytes) {
   size_t want = std::max(bytes, (size_t)1 << 20);
   HIP_TRY(h, hipMalloc((void**)&h->ws, want));
   h->ws_bytes = want;
+  return 0;
+}
+
+// Exchange buffer of backsolve_wave_kernel: zero at allocation, afterwards only written by that kernel with launch
+// epochs that are never reused, so a stale granule can never carry the current tag.
+int ensure_xchg(blr_handle* h, size_t bytes) {
+  if (!h->ticket) {
+    HIP_TRY(h, hipMalloc((void**)&h->ticket, 64));
+    HIP_TRY(h, hipMemsetAsync(h->ticket, 0, 64, h->stream));
+    h->ticket_base = 0;
+  }
+  if (bytes <= h->xchg_bytes) return 0;
+  if (h->xchg) {
+    HIP_TRY(h, hipStreamSynchronize(h->stream));
+    HIP_TRY(h, hipFree(h->xchg));
+    h->xchg = nullptr;
+    h->xchg_bytes = 0;
+  }
+  size_t want = std::max(bytes, (size_t)1 << 18);
+  HIP_TRY(h, hipMalloc((void**)&h->xchg, want));
+  HIP_TRY(h, hipMemsetAsync(h->xchg, 0, want, h->stream));
+  h->xchg_bytes = want;
+  return 0;
+}
+template <typename T>
+constexpr size_t wave_solve_lds() {
+  return (((size_t)kPB * (kPB + 1) / 2 * sizeof(T) + 15) & ~(size_t)15) + 3 * kPB * sizeof(T) + 8 * sizeof(double) + 16;
+}
+// launches one wavefront solve of NC x S workgroups; fills the synchronisation fields of `b`
+template <typename T>
+int launch_wave_solve(blr_handle* h, WaveSolveArgs<T>& b, int NC, int64_t S) {
+  int rc = ensure_xchg(h, (size_t)S * b.DP * 2 * sizeof(unsigned long long));
+  if (rc) return rc;
+  if (++h->epoch == 0) h->epoch = 1;  // 0 is the never-written state
+  b.xchg = h->xchg; b.epoch = h->epoch; b.ticket = h->ticket; b.ticket_base = h->ticket_base;
+  h->ticket_base += (unsigned)(NC * S);
+  HIP_TRY(h, hipFuncSetAttribute(reinterpret_cast<const void*>(backsolve_wave_kernel<T>), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                 (int)wave_solve_lds<T>()));
+  hipLaunchKernelGGL(backsolve_wave_kernel<T>, dim3(NC, (unsigned)S), dim3(kThreads), wave_solve_lds<T>(), h->stream, b);
   return 0;
 }
 
@@ -234,8 +279,7 @@ int posterior_large_one(blr_handle* h, const PosteriorArgs<T>& a, int64_t reg) {
   const size_t o_q = carve((size_t)gridc * sizeof(double));
   const size_t o_l = carve((size_t)gridc * sizeof(double));
   const size_t o_m = carve((size_t)DP * DP * sizeof(T));  // transposed factor for the back substitution
-  const size_t o_sc = carve(64 + 128 * sizeof(int));  // scalars + the back substitution's block flags and ticket
-  const size_t o_ms = carve((size_t)DP * sizeof(T));  // solution blocks exchanged between the back substitution's workgroups
+  const size_t o_sc = carve(64);
   int rc = ensure_ws(h, off);
   if (rc) return rc;
   char* ws = h->ws;
@@ -257,7 +301,7 @@ int posterior_large_one(blr_handle* h, const PosteriorArgs<T>& a, int64_t reg) {
   const T* mw = a.mw + reg * a.stridemw;
   const T* Lw = a.Lw + reg * a.strideLw;
 
-  HIP_TRY(h, hipMemsetAsync(ws + o_sc, 0, 64 + 128 * sizeof(int), h->stream));
+  HIP_TRY(h, hipMemsetAsync(ws + o_sc, 0, 64, h->stream));
   HIP_TRY(h, hipMemsetAsync(bpart, 0, (size_t)nsplit_total * NC * kPB * sizeof(double), h->stream));
 
   // ---- prior: SPD check + logdet (reference :78)
@@ -324,16 +368,11 @@ int posterior_large_one(blr_handle* h, const PosteriorArgs<T>& a, int64_t reg) {
     WaveSolveArgs<T> b{};
     b.Tf = Tfull; b.ldtf = DP; b.D = D; b.DP = DP;
     b.rhs = Abar + DP; b.ldrhs = 0; b.rhs_inc = lda;  // u = row DP of the factored Abar
-    b.m = reinterpret_cast<T*>(ws + o_ms); b.ldm = DP;
-    b.flags = reinterpret_cast<int*>(ws + o_sc + 64);
-    b.ticket = b.flags + 64;
     b.add = mw; b.out = a.mw_post ? a.mw_post + reg * a.stride_mwpost : nullptr; b.ldout = 0;
     b.qpart = qpart; b.lpart = lpart; b.nparts = gridc; b.logdet_Lw_dev = logdetLw;
     b.noise_kind = a.noise_kind; b.s = s; b.N = N;
     b.logpdf = a.logpdf ? a.logpdf + reg : nullptr; b.info = a.info + reg; b.chol_info = info_chol;
-    const size_t lds = SC::LDS_BYTES + 3 * kPB * sizeof(T) + 32;
-    if ((rc = set_lds<T>(h, reinterpret_cast<const void*>(backsolve_wave_kernel<T>), lds))) return rc;
-    hipLaunchKernelGGL(backsolve_wave_kernel<T>, dim3(NC, 1), dim3(kThreads), lds, h->stream, b);
+    if ((rc = launch_wave_solve<T>(h, b, NC, 1))) return rc;
   }
   HIP_TRY(h, hipGetLastError());
   return 0;
@@ -656,20 +695,17 @@ int marginals_batched(blr_handle* h, int memspace, int layout, int64_t B, int64_
 template <typename T>
 int sample_weights_large(blr_handle* h, int64_t D, int64_t S, int prior_kind, const T* mw, const T* Lw, int64_t ldl,
                          const T* Z, int64_t ldz, T* W, int64_t ldw) {
-  using SC = SmallCfg<T, 8>;
   if (prior_kind == BLR_PRIOR_DIAGONAL) {
     hipLaunchKernelGGL(diag_sample_kernel<T>, dim3(1024), dim3(kThreads), 0, h->stream, mw, Lw, Z, ldz, W, ldw, (int)D, S);
     HIP_TRY(h, hipGetLastError());
     return 0;
   }
   const int DP = (int)((D + kPB - 1) / kPB * kPB), NC = DP / kPB;
-  const int64_t chunk = std::min<int64_t>(S, 16384);
+  const int64_t chunk = std::min<int64_t>(S, 1024);
   size_t off = 0;
   auto carve = [&](size_t bytes) { size_t o = off; off = (off + bytes + 255) & ~(size_t)255; return o; };
   const size_t o_tf = carve((size_t)DP * DP * sizeof(T));
   const size_t o_wk = carve(prior_kind == BLR_PRIOR_DENSE ? (size_t)DP * DP * sizeof(T) : 0);
-  const size_t o_m = carve((size_t)chunk * DP * sizeof(T));
-  const size_t o_fl = carve(((size_t)chunk * NC + 1) * sizeof(int));
   const size_t o_info = carve(64);
   int rc = ensure_ws(h, off);
   if (rc) return rc;
@@ -691,19 +727,13 @@ int sample_weights_large(blr_handle* h, int64_t D, int64_t S, int prior_kind, co
     HIP_TRY(h, hipStreamSynchronize(h->stream));
     if (hinfo != 0) return hinfo;  // the prior precision is not positive definite
   }
-  const size_t lds = SC::LDS_BYTES + 3 * kPB * sizeof(T) + 32;
-  if ((rc = set_lds<T>(h, reinterpret_cast<const void*>(backsolve_wave_kernel<T>), lds))) return rc;
   for (int64_t s0 = 0; s0 < S; s0 += chunk) {
     const int64_t ns = std::min(chunk, S - s0);
-    HIP_TRY(h, hipMemsetAsync(ws + o_fl, 0, ((size_t)ns * NC + 1) * sizeof(int), h->stream));
     WaveSolveArgs<T> b{};
     b.Tf = Tf; b.ldtf = DP; b.D = (int)D; b.DP = DP;
     b.rhs = Z + s0 * ldz; b.ldrhs = ldz; b.rhs_inc = 1;
-    b.m = reinterpret_cast<T*>(ws + o_m); b.ldm = DP;
-    b.flags = reinterpret_cast<int*>(ws + o_fl);
-    b.ticket = b.flags + ns * NC;
     b.add = mw; b.out = W + s0 * ldw; b.ldout = ldw;
-    hipLaunchKernelGGL(backsolve_wave_kernel<T>, dim3(NC, (unsigned)ns), dim3(kThreads), lds, h->stream, b);
+    if ((rc = launch_wave_solve<T>(h, b, NC, ns))) return rc;
   }
   HIP_TRY(h, hipGetLastError());
   return 0;
@@ -1022,6 +1052,8 @@ int blr_destroy(blr_handle* h) {
   (void)hipStreamSynchronize(h->stream);
   if (h->ws) (void)hipFree(h->ws);
   if (h->feat) (void)hipFree(h->feat);
+  if (h->xchg) (void)hipFree(h->xchg);
+  if (h->ticket) (void)hipFree(h->ticket);
   if (h->ev0) (void)hipEventDestroy(h->ev0);
   if (h->ev1) (void)hipEventDestroy(h->ev1);
   if (h->own_stream) (void)hipStreamDestroy(h->own_stream);

@@ -791,18 +791,22 @@ __global__ __launch_bounds__(kThreads) void trsm_block_kernel(T* Abar, int64_t l
 
 // ---- wavefront back substitution  m = L^-T u  over NC workgroups per right-hand side -------------------------------
 // Workgroup q owns row block q: it prefetches its diagonal block, subtracts Tf[q rows, p cols] m_p for every finished
-// block p > q as soon as that block's flag is published (the Tf sub-block is already in registers by then), solves its
-// 128 x 128 triangle in LDS (phase_backsolve of the small path) and publishes m_q.  Critical path: NC x (one triangle
-// solve + one flag round trip) instead of one workgroup streaming the whole factor (measured at D = 2048, f32: 445 -> 260 us).
-// Grid = NC x S workgroups (S right-hand sides: posterior 1, weight draws S); (q, rhs) come from a start-order ticket.
+// block p > q as soon as m_p arrives (the Tf sub-block is already in registers by then), solves its 128 x 128 triangle
+// (one wave, 8 pivots per step, rows of L prefetched, reciprocal pivots in registers) and publishes m_q.
+// Hand-off = 8-byte {payload, tag} granules written with agent-scope (write-through) stores and polled with agent-scope
+// loads by the lanes that need them: ONE memory round trip per hop, no flag, no fence, no memset -- the tag is a
+// per-launch epoch and the exchange buffer is only ever written by this kernel.  (q, rhs) come from a ticket taken in
+// START order, so a workgroup only waits for workgroups that are already running: no assumption on dispatch order or
+// co-residency.  Grid = NC x S workgroups (S right-hand sides: posterior 1, weight draws S).
+// Measured at D = 2048, f32: one streaming workgroup 445 us -> flag + fence wavefront 280 us -> this form: see DESIGN.md.
 template <typename T>
 struct WaveSolveArgs {
   const T* Tf; int64_t ldtf;  // DP x DP upper factor U = L' (column-major, unit padding)
   int D, DP;
   const T* rhs; int64_t ldrhs, rhs_inc;  // rhs s, entry j: rhs[s*ldrhs + j*rhs_inc]
-  T* m; int64_t ldm;                     // exchanged solution [S][DP]
-  int* flags;                            // [S][NC], zero before the launch
-  int* ticket;                           // one counter, zero before the launch
+  unsigned long long* xchg;              // [S][DP][2] tagged granules (handle-owned, zero at allocation)
+  unsigned epoch;                        // tag of this launch (never reused by the handle)
+  unsigned* ticket; unsigned ticket_base;  // monotonically increasing start-order counter
   const T* add; T* out; int64_t ldout;   // out[s*ldout + j] = add[j] + m_j  (j < D); out may be NULL
   // evidence assembly (posterior; S == 1), done by the workgroup that finishes last (q = 0); logpdf may be NULL
   const double* qpart; const double* lpart; int nparts;
@@ -811,21 +815,42 @@ struct WaveSolveArgs {
   double* logpdf; int32_t* info; const int32_t* chol_info;
 };
 
+__device__ __forceinline__ void xchg_put(unsigned long long* g, float v, unsigned tag) {
+  __hip_atomic_store(g, ((unsigned long long)tag << 32) | (unsigned)__float_as_int(v), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+__device__ __forceinline__ void xchg_put(unsigned long long* g, double v, unsigned tag) {
+  __hip_atomic_store(g, ((unsigned long long)tag << 32) | (unsigned)__double2loint(v), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  __hip_atomic_store(g + 1, ((unsigned long long)tag << 32) | (unsigned)__double2hiint(v), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+__device__ __forceinline__ unsigned long long xchg_poll(const unsigned long long* g, unsigned tag) {
+  unsigned long long w = __hip_atomic_load(g, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  while ((unsigned)(w >> 32) != tag) {
+    __builtin_amdgcn_s_sleep(1);
+    w = __hip_atomic_load(g, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  }
+  return w;
+}
+__device__ __forceinline__ void xchg_get(const unsigned long long* g, unsigned tag, float* v) {
+  *v = __int_as_float((int)(unsigned)xchg_poll(g, tag));
+}
+__device__ __forceinline__ void xchg_get(const unsigned long long* g, unsigned tag, double* v) {
+  const unsigned lo = (unsigned)xchg_poll(g, tag), hi = (unsigned)xchg_poll(g + 1, tag);
+  *v = __hiloint2double((int)hi, (int)lo);
+}
+
 template <typename T>
-__global__ __launch_bounds__(kThreads, (sizeof(T) == 4 ? BLR_F32_WAVES_PER_SIMD : 2)) void backsolve_wave_kernel(WaveSolveArgs<T> a) {
-  using C = SmallCfg<T, 8>;
+__global__ __launch_bounds__(kThreads, 2) void backsolve_wave_kernel(WaveSolveArgs<T> a) {
+  constexpr int P_BYTES = ((kPB * (kPB + 1) / 2) * (int)sizeof(T) + 15) & ~15;
   extern __shared__ __attribute__((aligned(16))) char smem[];
-  T* const P = reinterpret_cast<T*>(smem);
-  T* const bvec = reinterpret_cast<T*>(smem + C::OFF_B);
-  double* const scr = reinterpret_cast<double*>(smem + C::OFF_SCR);
-  T* const mp = reinterpret_cast<T*>(smem + C::LDS_BYTES);  // [128] m_p, then [256] partial sums
-  T* const part = mp + kPB;
-  const int tid = threadIdx.x;
+  T* const P = reinterpret_cast<T*>(smem);                 // packed lower triangle of L_qq
+  T* const mp = reinterpret_cast<T*>(smem + P_BYTES);      // [128] m_p
+  T* const part = mp + kPB;                                // [256] partial sums
+  double* const scr = reinterpret_cast<double*>(part + 2 * kPB);  // [8]
+  int* const tick = reinterpret_cast<int*>(scr + 8);
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = uni(tid >> 6);
   const int D = a.D, DP = a.DP, NC = DP / kPB;
-  // Work items are handed out by a ticket in START order, not by blockIdx: a workgroup only ever waits for tickets
-  // lower than its own, whose owners are already running -- no assumption on dispatch order or co-residency.
-  int* const tick = reinterpret_cast<int*>(smem + C::LDS_BYTES + 3 * kPB * sizeof(T));
-  if (tid == 0) *tick = atomicAdd(a.ticket, 1);
+  if (tid == 0) *tick = (int)(atomicAdd(a.ticket, 1u) - a.ticket_base);
   __syncthreads();
   const int ticket = *tick;
   const int q = NC - 1 - ticket % NC;
@@ -837,14 +862,16 @@ __global__ __launch_bounds__(kThreads, (sizeof(T) == 4 ? BLR_F32_WAVES_PER_SIMD 
     return;
   }
   const T* rhs = a.rhs + sidx * a.ldrhs;
-  T* mglob = a.m + sidx * a.ldm;
-  int* flags = a.flags + sidx * NC;
+  unsigned long long* xg = a.xchg + (sidx * DP) * 2;
 
   load_upper_block_to_packed(P, a.Tf + (int64_t)q * kPB * a.ldtf + (int64_t)q * kPB, a.ldtf, tid);
-  T uq = T(0);
-  if (tid < kPB) {
-    const int j = q * kPB + tid;
-    uq = (j < D) ? rhs[(int64_t)j * a.rhs_inc] : T(0);
+  // wave 0 solves: lane l owns rows l and l + 64 of the block
+  const int i0 = lane, i1 = lane + 64;
+  T b0 = T(0), b1 = T(0);
+  if (wave == 0) {
+    const int j0 = q * kPB + i0, j1 = q * kPB + i1;
+    b0 = (j0 < D) ? rhs[(int64_t)j0 * a.rhs_inc] : T(0);
+    b1 = (j1 < D) ? rhs[(int64_t)j1 * a.rhs_inc] : T(0);
   }
   double uu = 0.0, ld = 0.0, qs = 0.0, ls = 0.0;
   if (evidence) {  // |u|^2, logdet A and the column-statistics partials: off the critical path (this workgroup waits longest)
@@ -859,20 +886,26 @@ __global__ __launch_bounds__(kThreads, (sizeof(T) == 4 ? BLR_F32_WAVES_PER_SIMD 
     qs = block_allreduce(qs, scr, tid);
     ls = block_allreduce(ls, scr, tid);
   }
+  __syncthreads();  // P complete
+  T r0 = T(0), r1 = T(0);
+  if (wave == 0) {  // reciprocal pivots: off the critical path
+    r0 = T(1) / P[pidx(i0, i0)];
+    r1 = T(1) / P[pidx(i1, i1)];
+  }
 
   const int r = tid & (kPB - 1), half = tid >> 7;
   T acc = T(0);
   for (int p = NC - 1; p > q; --p) {
-    // the factor sub-block does not depend on the flag: have it in registers before waiting
+    // the factor sub-block does not depend on m_p: have it in registers before waiting
     const T* tp = a.Tf + ((int64_t)p * kPB + half * 64) * a.ldtf + (int64_t)q * kPB + r;
     T tv[64];
 #pragma unroll
     for (int c = 0; c < 64; ++c) tv[c] = tp[(int64_t)c * a.ldtf];
-    if (tid == 0) {
-      while (__hip_atomic_load(&flags[p], __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_AGENT) == 0) __builtin_amdgcn_s_sleep(1);
+    if (tid < kPB) {
+      T v;
+      xchg_get(xg + (int64_t)(p * kPB + tid) * 2, a.epoch, &v);
+      mp[tid] = v;
     }
-    __syncthreads();
-    if (tid < kPB) mp[tid] = __hip_atomic_load(&mglob[p * kPB + tid], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     __syncthreads();
     T a0 = T(0), a1 = T(0), a2 = T(0), a3 = T(0);
 #pragma unroll
@@ -887,18 +920,38 @@ __global__ __launch_bounds__(kThreads, (sizeof(T) == 4 ? BLR_F32_WAVES_PER_SIMD 
   }
   part[tid] = acc;
   __syncthreads();
-  if (tid < kPB) bvec[tid] = uq - (part[tid] + part[tid + kPB]);
-  __syncthreads();
-  phase_backsolve<T, 8>(smem, kPB);  // bvec <- L_qq^-T bvec
-  if (tid < kPB) {
-    const int j = q * kPB + tid;
-    const T mv = bvec[tid];
-    __hip_atomic_store(&mglob[j], mv, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    if (a.out && j < D) a.out[sidx * a.ldout + j] = a.add[j] + mv;
+  if (wave == 0) {
+    b0 -= part[i0] + part[kPB + i0];
+    b1 -= part[i1] + part[kPB + i1];
+    // column-oriented back substitution, 8 pivots per step: the rows of L a step needs are loaded up front, so the
+    // serial chain per pivot is readlane -> multiply -> fma with no LDS latency in it
+    for (int kb = kPB - 1; kb >= 0; kb -= 8) {
+      T row0[8], row1[8];
+#pragma unroll
+      for (int u = 0; u < 8; ++u) {
+        const int k = kb - u;
+        const T* row = P + pidx(k, 0);
+        row0[u] = (i0 < k) ? row[i0] : T(0);
+        row1[u] = (i1 < k) ? row[i1] : T(0);
+      }
+#pragma unroll
+      for (int u = 0; u < 8; ++u) {
+        const int k = kb - u;
+        const bool lo = k < 64;
+        const T mk = readlane(lo ? b0 : b1, k & 63) * readlane(lo ? r0 : r1, k & 63);
+        if (lane == (k & 63)) { if (lo) b0 = mk; else b1 = mk; }
+        b0 -= row0[u] * mk;
+        b1 -= row1[u] * mk;
+      }
+    }
+    const int j0 = q * kPB + i0, j1 = q * kPB + i1;
+    xchg_put(xg + (int64_t)j0 * 2, b0, a.epoch);
+    xchg_put(xg + (int64_t)j1 * 2, b1, a.epoch);
+    if (a.out) {
+      if (j0 < D) a.out[sidx * a.ldout + j0] = a.add[j0] + b0;
+      if (j1 < D) a.out[sidx * a.ldout + j1] = a.add[j1] + b1;
+    }
   }
-  __threadfence();
-  __syncthreads();
-  if (tid == 0) __hip_atomic_store(&flags[q], 1, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
   if (evidence && tid == 0) {
     *a.info = 0;
     if (a.logpdf) {
