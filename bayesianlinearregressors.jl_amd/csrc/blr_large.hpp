@@ -839,7 +839,7 @@ __device__ __forceinline__ void xchg_get(const unsigned long long* g, unsigned t
 }
 
 template <typename T>
-__global__ __launch_bounds__(kThreads, 2) void backsolve_wave_kernel(WaveSolveArgs<T> a) {
+__global__ __launch_bounds__(kThreads) void backsolve_wave_kernel(WaveSolveArgs<T> a) {
   constexpr int P_BYTES = ((kPB * (kPB + 1) / 2) * (int)sizeof(T) + 15) & ~15;
   extern __shared__ __attribute__((aligned(16))) char smem[];
   T* const P = reinterpret_cast<T*>(smem);                 // packed lower triangle of L_qq
