@@ -1,0 +1,75 @@
+"""Turns gpurun_out/profiles_raw/ (tools/collect_profiles.sh) into the committed profiles/ summaries of one round.
+    python tools/summarise_profiles.py r01
+"""
+import collections
+import csv
+import glob
+import json
+import os
+import shutil
+import sys
+
+tag = sys.argv[1] if len(sys.argv) > 1 else "r01"
+RAW = "gpurun_out/profiles_raw"
+DST = "profiles"
+os.makedirs(DST, exist_ok=True)
+
+
+def one(pattern):
+    g = glob.glob(pattern)
+    return g[0] if g else None
+
+
+for name in ("bench_c2_f64", "bench_c2_f32", "bench_c3_f32", "bench_c5shape_f32", "bench_c4shape_f64"):
+    src = os.path.join(RAW, name + ".json")
+    if os.path.exists(src) and os.path.getsize(src):
+        shutil.copy(src, os.path.join(DST, f"{tag}_{name}.json"))
+for cfg in ("c2", "c3", "c5"):
+    f = one(f"{RAW}/stats_{cfg}/*/*_kernel_stats.csv")
+    if f:
+        shutil.copy(f, os.path.join(DST, f"{tag}_{cfg}_kernel_stats.csv"))
+
+
+def counters(dirname, kernel_substr):
+    f = one(f"{RAW}/{dirname}/*/*_counter_collection.csv")
+    t = one(f"{RAW}/{dirname}/*/*_kernel_trace.csv")
+    if not f or not t:
+        return None
+    dur = {r["Dispatch_Id"]: int(r["End_Timestamp"]) - int(r["Start_Timestamp"]) for r in csv.DictReader(open(t))}
+    by = collections.defaultdict(dict)
+    for r in csv.DictReader(open(f)):
+        if kernel_substr in r["Kernel_Name"]:
+            by[r["Dispatch_Id"]][r["Counter_Name"]] = float(r["Counter_Value"])
+            by[r["Dispatch_Id"]]["_grid"] = int(r["Grid_Size"])
+    if not by:
+        return None
+    gmax = max(c["_grid"] for c in by.values())  # the dominant launch shape
+    sel = {d: c for d, c in by.items() if c["_grid"] == gmax}
+    out = {"dispatches": len(sel), "grid": gmax, "avg_duration_ns": sum(dur[d] for d in sel) / len(sel)}
+    names = sorted({k for c in sel.values() for k in c if not k.startswith("_")})
+    for k in names:
+        out[k] = sum(c[k] for c in sel.values()) / len(sel)
+    return out
+
+
+summary = {"note": "per-dispatch means for the dominant kernel; rocprofv3 --pmc, one counter group per pass "
+                   "(tools/collect_profiles.sh); FETCH_SIZE / WRITE_SIZE in KiB, FETCH_SIZE x2 on gfx950 "
+                   "(MI355X_MICROARCH.md, HBM/rocprofv3 section)"}
+fetch = counters("pmc_fetch_c2", "fused_small_kernel")
+write = counters("pmc_write_c2", "fused_small_kernel")
+sq2 = counters("pmc_sq_c2", "fused_small_kernel")
+sq3 = counters("pmc_sq_c3", "gram_tile_kernel")
+if fetch and write:
+    rd = fetch["FETCH_SIZE"] * 1024.0 * 2.0
+    wr = write["WRITE_SIZE"] * 1024.0
+    summary["c2_fused_small_kernel_hbm"] = {"FETCH_SIZE_KiB": fetch["FETCH_SIZE"], "WRITE_SIZE_KiB": write["WRITE_SIZE"],
+                                            "hbm_read_bytes_per_launch": rd, "hbm_write_bytes_per_launch": wr,
+                                            "hbm_bytes_per_launch": rd + wr, "units_per_launch": 1024}
+for key, c in (("c2_fused_small_kernel_sq", sq2), ("c3_gram_tile_kernel_sq", sq3)):
+    if c:
+        ns = c["avg_duration_ns"]
+        c["effective_clock_GHz"] = c["GRBM_GUI_ACTIVE"] / 8.0 / ns
+        c["mfma_busy_fraction_of_simd_cycles"] = c["SQ_VALU_MFMA_BUSY_CYCLES"] / (1024.0 * c["effective_clock_GHz"] * ns)
+        summary[key] = c
+json.dump(summary, open(os.path.join(DST, f"{tag}_pmc_summary.json"), "w"), indent=1)
+print(json.dumps(summary, indent=1)[:3000])
