@@ -31,8 +31,8 @@ PEAK_HBM_GBS = 8000.0
 PEAK_TF = {"f64": 78.6, "f32": 157.3}
 # what tools/mfma_peak.hip sustains on this pool: v_mfma_f64_16x16x4 tops out at 47.7 TF
 MEASURED_MFMA_TF = {"f64": 47.7, "f32": 155.0}
-# HBM bytes per regressor from the PMC passes of profiles/r01_bench_c2_f64_pmc.json (FETCH_SIZE x2 + WRITE_SIZE)
-PMC_TRAFFIC_BYTES_PER_UPDATE = {("f64", 128, 4096, "isotropic"): 5004456024.0 / 1024}
+# HBM bytes per regressor from the PMC passes summarised in profiles/r01_pmc_summary.json (FETCH_SIZE x2 + WRITE_SIZE)
+PMC_TRAFFIC_BYTES_PER_UPDATE = {("f64", 128, 4096, "isotropic"): 5005083360.0 / 1024}
 
 
 def algorithmic_bytes(D, N, w, diag_noise):
@@ -234,7 +234,7 @@ def main():
         per_update = PMC_TRAFFIC_BYTES_PER_UPDATE.get((args.dtype, D, N, args.noise))
         roof.update({
             "traffic": per_update * B if per_update else None,
-            "traffic_source": "rocprofv3 --pmc FETCH_SIZE (x2, gfx950) + WRITE_SIZE, profiles/r01_bench_c2_f64_pmc.json"
+            "traffic_source": "rocprofv3 --pmc FETCH_SIZE (x2, gfx950) + WRITE_SIZE, profiles/r01_pmc_summary.json"
                               if per_update else None,
             "algorithmic_bytes": by, "algorithmic_flops": fl,
             "mfma_peak_measured_TFLOPps": MEASURED_MFMA_TF[args.dtype],
