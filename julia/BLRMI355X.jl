@@ -222,4 +222,43 @@ function rand(rng::AbstractRNG, b::Union{BayesianLinearRegressor,BasisFunctionRe
     reshape([BLRFunctionSample(collect(w), ϕ) for w in eachcol(ws)], dims)
 end
 
+# ---- random-Fourier basis on the device (BASELINE config 5) -----------------------------------------
+# A BasisFunctionRegressor whose ϕ is  x -> sqrt(2/D) cos.(Ω'x .+ β)  (reference basis_function_regression.jl:41,62-65:
+# bfr(x) = blr(ϕ(x))) can hand the raw inputs to the device: the feature matrix is generated there and consumed by the
+# same fused posterior/logpdf path, never crossing PCIe.
+struct RandomFourierFeatures{T<:Elt}
+    Ω::Matrix{T}      # Din x D
+    β::Vector{T}      # D
+end
+(r::RandomFourierFeatures{T})(x::ColVecs) where {T} = ColVecs(convert(T, sqrt(2 / length(r.β))) .* cos.(r.Ω' * x.X .+ r.β))
+
+function fused_rff(blr::BayesianLinearRegressor, ϕ::RandomFourierFeatures{T}, x::ColVecs, Σy, y::AbstractVector) where {T}
+    pr = prior(blr.Λw); nz = noise(Σy)
+    (pr === nothing || nz === nothing) && return nothing
+    Lw, pk, ldl = pr; s, nk = nz
+    Din, D = size(ϕ.Ω); N = length(y)
+    Xin = convert(Matrix{T}, x.X); yv = convert(Vector{T}, y); mw = convert(Vector{T}, blr.mw)
+    mw′ = Vector{T}(undef, D); Tm = Matrix{T}(undef, D, D); A = Matrix{T}(undef, D, D)
+    lp = Ref{Cdouble}(0.0); info = Ref{Int32}(0)
+    h = handle()
+    rc = GC.@preserve Xin yv s Lw mw mw′ Tm A begin
+        if T === Float64
+            ccall((:blr_posterior_rff_f64, LIB), Cint,
+                  (Ptr{Cvoid}, Cint, Int64, Int64, Int64, Ptr{T}, Int64, Ptr{T}, Int64, Ptr{T}, T, Ptr{T}, Cint, Ptr{T},
+                   Cint, Ptr{T}, Ptr{T}, Int64, Ptr{T}, Ptr{T}, Int64, Ptr{T}, Int64, Ref{Cdouble}, Ref{Int32}),
+                  h, MEM_HOST, Din, D, N, Xin, Din, ϕ.Ω, Din, ϕ.β, sqrt(T(2) / D), yv, nk, s, pk, mw, Lw, ldl, mw′, Tm, D, A, D,
+                  lp, info)
+        else
+            ccall((:blr_posterior_rff_f32, LIB), Cint,
+                  (Ptr{Cvoid}, Cint, Int64, Int64, Int64, Ptr{T}, Int64, Ptr{T}, Int64, Ptr{T}, T, Ptr{T}, Cint, Ptr{T},
+                   Cint, Ptr{T}, Ptr{T}, Int64, Ptr{T}, Ptr{T}, Int64, Ptr{T}, Int64, Ref{Cdouble}, Ref{Int32}),
+                  h, MEM_HOST, Din, D, N, Xin, Din, ϕ.Ω, Din, ϕ.β, sqrt(T(2) / D), yv, nk, s, pk, mw, Lw, ldl, mw′, Tm, D, A, D,
+                  lp, info)
+        end
+    end
+    check(h, rc)
+    info[] > 0 && throw(PosDefException(info[]))
+    return lp[], mw′, Tm, A
+end
+
 end # module
