@@ -760,3 +760,26 @@ def test_large_d_rand_and_weight_draws(B, dtype, D, N, S):
     assert g.w.shape == (D,)
     with pytest.raises(B.PosDefException):
         B.rand(np.random.default_rng(1), B.BayesianLinearRegressor(mw, -Lw))
+
+
+@pytest.mark.timeout(300)
+@pytest.mark.parametrize("dtype,D,S", [(np.float64, 300, 2500), (np.float32, 1100, 1500)])
+def test_large_d_many_draws_wavefront_oversubscribed(B, dtype, D, S):
+    # more wavefront workgroups than the chip can hold at once (blocks x draws >> 512 slots, several launches):
+    # the start-order tickets must keep every waiting workgroup's dependencies running
+    from blr_amd import _abi
+
+    rng = _rng(9300 + D)
+    mw = rng.standard_normal(D).astype(dtype)
+    Bm = rng.standard_normal((D, D)) / np.sqrt(D)
+    Lw = (Bm @ Bm.T + np.eye(D)).astype(dtype)
+    U = np.asfortranarray(O.chol_upper(np.asarray(Lw, dtype=float)).astype(dtype))
+    Z = np.asfortranarray(rng.standard_normal((D, S)).astype(dtype))
+    W = np.empty((D, S), dtype=dtype, order="F")
+    h = _abi.default_handle()
+    for _ in range(3):  # repeated launches reuse the exchange buffer with fresh epochs
+        W[:] = 0
+        h.sample_weights(dtype, _abi.MEM_HOST, D, S, _abi.PRIOR_UPPER_FACTOR, mw, U, D, Z, D, W, D)
+        W_o = np.asarray(mw, dtype=float)[:, None] + np.linalg.solve(np.asarray(U, dtype=float), np.asarray(Z, dtype=float))
+        rt = 1e-10 if dtype == np.float64 else 2e-4
+        np.testing.assert_allclose(W, W_o, rtol=rt, atol=rt * 10)
