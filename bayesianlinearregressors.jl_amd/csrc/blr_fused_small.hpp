@@ -601,14 +601,14 @@ BLR_PHASE void phase_gram(char* smem) {
 // =========================================================================================================
 // phase 2 (noinline): blocked Cholesky of the packed lower triangle P, trailing matrix in MFMA accumulators.
 // For each block column J:
-//   (a) the owners of tiles (I, J) store them into P;
+//   (a) panel J is in P already (stored by the owners of tiles (I, J) at the end of the previous trailing update);
 //   (b) every wave loads panel rows, ONE ROW PER LANE (lanes 0-15: the 16 diagonal-block rows, held
 //       redundantly by all four waves so no cross-wave traffic is needed; lanes 16-63: 48 rows below),
 //       and eliminates the 16 columns in registers -- pivots and multipliers travel by v_readlane;
 //       the right-hand side b rides along (forward substitution u = L^-1 b for free);
 //   (c) the finished panel goes back to P and all waves apply  A_IK -= L_IJ L_KJ'  to their
 //       remaining tiles with 4 MFMAs per tile, reading both operands from P in fragment order.
-// Three barriers per block column, no LDS round trip for the trailing matrix.  On exit P holds L (A = L L'),
+// Two barriers per block column, no LDS round trip for the trailing matrix.  On exit P holds L (A = L L'),
 // bvec holds u = L^-1 b.  Returns 0 or the LAPACK-style 1-based index of the failing leading minor.
 // =========================================================================================================
 template <typename T, int NB>
@@ -643,22 +643,10 @@ BLR_PHASE int phase_chol(char* smem, int D_in, int with_rhs_in) {
   BLR_STAMP_INIT;
   BLR_STAMP(0);
   for (int J = 0; J < nblk; ++J) {
+    // (a) panel J is already in P: column 0 was never updated, and step (c) of iteration J-1 stored column J right
+    //     after updating it -- one barrier per block column instead of two
     __syncthreads();
     BLR_STAMP(1);
-    // (a) panel tiles -> packed LDS
-#pragma unroll
-    for (int i = 0; i < C::TPW; ++i) {
-      int I, K;
-      if (wave_tile(NB, wave, i, I, K) && K == J) {
-        const int col = 16 * J + (lane & 15);
-#pragma unroll
-        for (int v = 0; v < 4; ++v) {
-          const int row = 16 * I + Mfma<T>::crow(lane, v);
-          if (col <= row) P[pidx(row, col)] = acc[i][v];
-        }
-      }
-    }
-    __syncthreads();
     BLR_STAMP(2);
     // (b) one row per lane
     const bool is_diag = lane < 16;
@@ -724,6 +712,14 @@ BLR_PHASE int phase_chol(char* smem, int D_in, int with_rhs_in) {
           const T fI = P[pidx(rowI, 16 * J + 4 * ks + q)];
           const T fK = P[pidx(rowK, 16 * J + 4 * ks + q)];
           acc[i] = Mfma<T>::mma(-fI, fK, acc[i]);
+        }
+        if (K == J + 1) {  // the next panel: final now, straight to the packed triangle (column J+1 is not read by (c))
+          const int col = 16 * K + (lane & 15);
+#pragma unroll
+          for (int v = 0; v < 4; ++v) {
+            const int row = 16 * I + Mfma<T>::crow(lane, v);
+            if (col <= row) P[pidx(row, col)] = acc[i][v];
+          }
         }
       }
     }
