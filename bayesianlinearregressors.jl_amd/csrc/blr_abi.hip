@@ -229,7 +229,7 @@ int chol_large(blr_handle* h, T* M, int64_t ld, int DP, int nrows_total, int32_t
     if (row_begin < nrows_total) {
       const int nblk = (nrows_total - row_begin + TC::RB - 1) / TC::RB;
       hipLaunchKernelGGL(trsm_block_kernel<T>, dim3(nblk), dim3(kThreads), TC::LDS_BYTES, h->stream, M, ld, p, row_begin,
-                         nrows_total, (const int32_t*)info_dev);
+                         nrows_total, (const int32_t*)info_dev, RowSqArgs<T>{});
     }
     const int m = NC - 1 - p;  // remaining column blocks
     if (m > 0) {
@@ -537,7 +537,7 @@ int marginals_large_one(blr_handle* h, int layout, int64_t D, int64_t N, const T
   const bool need_tall = var && prior_kind != BLR_PRIOR_DIAGONAL;
   T* Ybar = nullptr;
   if (need_tall) {
-    const size_t bytes = (size_t)ldy * DP * sizeof(T);
+    const size_t bytes = (((size_t)ldy * DP * sizeof(T) + 255) & ~(size_t)255) + (size_t)NP * sizeof(double);
     if ((rc = ensure_ws(h, bytes + 256))) return rc;
     Ybar = reinterpret_cast<T*>(h->ws);
   }
@@ -563,10 +563,13 @@ int marginals_large_one(blr_handle* h, int layout, int64_t D, int64_t N, const T
     if ((rc = set_lds<T>(h, reinterpret_cast<const void*>(trsm_block_kernel<T>), TC::LDS_BYTES))) return rc;
     if ((rc = set_lds<T>(h, reinterpret_cast<const void*>(gram_tile_kernel<T>), LC::LDS_BYTES))) return rc;
     const int nyb = NP / kPB;  // row blocks of the input part
+    double* rowsq = reinterpret_cast<double*>(h->ws + (((size_t)ldy * DP * sizeof(T) + 255) & ~(size_t)255));
     for (int p = 0; p < NC; ++p) {
       const int nblk = (NP + TC::RB - 1) / TC::RB;
+      RowSqArgs<T> rs{};  // the row sums of squares ride on the TRSM: block p of a row is final after panel p
+      rs.acc = rowsq; rs.var = var; rs.s = s; rs.noise_kind = noise_kind; rs.N = (int)N; rs.first = p == 0; rs.last = p == NC - 1;
       hipLaunchKernelGGL(trsm_block_kernel<T>, dim3(nblk), dim3(kThreads), TC::LDS_BYTES, h->stream, Ybar, ldy, p, DP, DP + NP,
-                         (const int32_t*)info_dev);
+                         (const int32_t*)info_dev, rs);
       const int m = NC - 1 - p;
       if (m > 0) {
         GramTileArgs<T> g{};
@@ -578,8 +581,6 @@ int marginals_large_one(blr_handle* h, int layout, int64_t D, int64_t N, const T
         hipLaunchKernelGGL(gram_tile_kernel<T>, dim3(g.ntiles), dim3(kThreads), LC::LDS_BYTES, h->stream, g);
       }
     }
-    hipLaunchKernelGGL(row_sumsq_kernel<T>, dim3((unsigned)((N + kThreads - 1) / kThreads)), dim3(kThreads), 0, h->stream,
-                       (const T*)Ybar, ldy, DP, (int)D, (int)N, s, noise_kind, var);
   }
   (void)sizeof(SC);
   HIP_TRY(h, hipGetLastError());

@@ -744,8 +744,15 @@ __device__ __forceinline__ void trsm_core(T* __restrict__ Xs, const T* __restric
 }
 
 template <typename T>
+struct RowSqArgs {      // optional fused epilogue of the marginal stream: var_n = |Y_n|^2 + s_n   (:40-43)
+  double* acc;          // [N] running row sums of squares (NULL: off); panel 0 writes, later panels add
+  T* var; const T* s;   // last panel: var[n] = acc[n] + s_n
+  int noise_kind, N, first, last;
+};
+
+template <typename T>
 __global__ __launch_bounds__(kThreads) void trsm_block_kernel(T* Abar, int64_t lda, int p, int row_begin, int nrows_total,
-                                                              const int32_t* info) {
+                                                              const int32_t* info, RowSqArgs<T> rs) {
   using Cfg = TrsmCfg<T>;
   using acc4 = typename Mfma<T>::acc4;
   extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -773,6 +780,23 @@ __global__ __launch_bounds__(kThreads) void trsm_block_kernel(T* Abar, int64_t l
   __syncthreads();
 
   trsm_core<T>(Xs, P, dinv, reinterpret_cast<T*>(smem + Cfg::OFF_LI), 8, tid, lane, wave);
+  if (rs.acc != nullptr && tid < Cfg::RB) {
+    // the finished 128 columns of this row never change again: fold them into the row's sum of squares now
+    const int n = r0 - row_begin + tid;
+    if (n < rs.N) {
+      const T* xr = Xs + tid * Cfg::LDX;
+      double q0 = 0.0, q1 = 0.0, q2 = 0.0, q3 = 0.0;
+#pragma unroll 8
+      for (int c = 0; c < kPB; c += 4) {
+        const double v0 = (double)xr[c], v1 = (double)xr[c + 1], v2 = (double)xr[c + 2], v3 = (double)xr[c + 3];
+        q0 += v0 * v0; q1 += v1 * v1; q2 += v2 * v2; q3 += v3 * v3;
+      }
+      double tot = (q0 + q1) + (q2 + q3);
+      if (!rs.first) tot += rs.acc[n];
+      if (rs.last) rs.var[n] = (T)tot + ((rs.noise_kind == NOISE_DIAGONAL) ? rs.s[n] : rs.s[0]);
+      else rs.acc[n] = tot;
+    }
+  }
   {
     using BV = BlockVec<T, Cfg::RB>;
 #pragma unroll 4
@@ -1065,22 +1089,50 @@ struct MeanFillArgs {
 
 template <typename T>
 __global__ __launch_bounds__(kThreads) void mean_fill_kernel(MeanFillArgs<T> a) {
-  __shared__ T tile[64][65];
+  constexpr int VEC = Mfma<T>::VEC;
+  constexpr int LDT = 68;  // row stride: 16-byte aligned rows, 4-way (not 16-way) conflicts on the transposing writes
+  typedef T vecT __attribute__((ext_vector_type(Mfma<T>::VEC)));
+  __shared__ __attribute__((aligned(16))) T tile[64][LDT];
   const int tid = threadIdx.x;
   const int n0 = blockIdx.x * 64;
   const int tn = tid & 63, tq = tid >> 6;
   double macc = 0.0;  // thread (tn, tq) accumulates mean of column n0 + tn over d = tq, tq + 4, ...
+  // ColVecs with 16-byte aligned columns: 16-byte loads along d, 16-byte stores along n, next tile's loads in flight
+  const bool vec = a.layout == LAYOUT_COLVECS && (a.D % VEC) == 0 && (a.ldx % VEC) == 0 && ((uintptr_t)a.X % 16) == 0;
+  constexpr int VPR = 64 / VEC;                 // vectors per tile row
+  constexpr int NVT = 64 * 64 / (VEC * kThreads);  // vectors per thread per tile
+  vecT pre[NVT];
+  auto prefetch = [&](int d0) {
+#pragma unroll
+    for (int u = 0; u < NVT; ++u) {
+      const int vi = u * kThreads + tid;
+      const int d = d0 + (vi % VPR) * VEC, n = n0 + vi / VPR;
+      pre[u] = (d < a.D && n < a.N) ? *reinterpret_cast<const vecT*>(a.X + (int64_t)n * a.ldx + d) : vecT(T(0));
+    }
+  };
+  if (vec) prefetch(0);
   for (int d0 = 0; d0 < a.DP; d0 += 64) {
     __syncthreads();
-    // load a 64 (d) x 64 (n) tile, coalesced along the contiguous axis of the layout
-    for (int e = tid; e < 64 * 64; e += kThreads) {
-      int dd, nn;
-      if (a.layout == LAYOUT_COLVECS) { dd = e & 63; nn = e >> 6; }
-      else                            { nn = e & 63; dd = e >> 6; }
-      const int d = d0 + dd, n = n0 + nn;
-      T v = T(0);
-      if (d < a.D && n < a.N) v = (a.layout == LAYOUT_COLVECS) ? a.X[(int64_t)n * a.ldx + d] : a.X[(int64_t)d * a.ldx + n];
-      tile[dd][nn] = v;
+    if (vec) {
+#pragma unroll
+      for (int u = 0; u < NVT; ++u) {
+        const int vi = u * kThreads + tid;
+        const int dd0 = (vi % VPR) * VEC, nn = vi / VPR;
+#pragma unroll
+        for (int e = 0; e < VEC; ++e) tile[dd0 + e][nn] = pre[u][e];
+      }
+      if (d0 + 64 < a.DP) prefetch(d0 + 64);
+    } else {
+      // load a 64 (d) x 64 (n) tile, coalesced along the contiguous axis of the layout
+      for (int e = tid; e < 64 * 64; e += kThreads) {
+        int dd, nn;
+        if (a.layout == LAYOUT_COLVECS) { dd = e & 63; nn = e >> 6; }
+        else                            { nn = e & 63; dd = e >> 6; }
+        const int d = d0 + dd, n = n0 + nn;
+        T v = T(0);
+        if (d < a.D && n < a.N) v = (a.layout == LAYOUT_COLVECS) ? a.X[(int64_t)n * a.ldx + d] : a.X[(int64_t)d * a.ldx + n];
+        tile[dd][nn] = v;
+      }
     }
     __syncthreads();
     if (a.mean) {
@@ -1089,11 +1141,14 @@ __global__ __launch_bounds__(kThreads) void mean_fill_kernel(MeanFillArgs<T> a) 
         if (d < a.D) macc += (double)tile[dd][tn] * (double)a.mw[d];
       }
     }
-    if (a.Ybar) {  // Ybar[row0 + n, d]: consecutive threads -> consecutive n (rows): coalesced
-      for (int e = tid; e < 64 * 64; e += kThreads) {
-        const int nn = e & 63, dd = e >> 6;
-        const int d = d0 + dd, n = n0 + nn;
-        if (d < a.DP) a.Ybar[(int64_t)d * a.ldy + a.row0 + n] = tile[dd][nn];  // padding rows/cols are zero
+    if (a.Ybar) {  // Ybar[row0 + n, d]: rows contiguous -> 16-byte stores along n (row0, n0, ldy are multiples of 64)
+#pragma unroll
+      for (int u = 0; u < NVT; ++u) {
+        const int vj = u * kThreads + tid;
+        const int nn0 = (vj % VPR) * VEC, dd = vj / VPR;
+        const int d = d0 + dd;
+        if (d < a.DP)  // padding rows/cols are zero
+          *reinterpret_cast<vecT*>(a.Ybar + (int64_t)d * a.ldy + a.row0 + n0 + nn0) = *reinterpret_cast<const vecT*>(&tile[dd][nn0]);
       }
     }
   }
@@ -1126,29 +1181,6 @@ __global__ __launch_bounds__(kThreads) void factor_transpose_fill_kernel(const T
       if (row >= col) Ybar[(int64_t)col * ldy + row] = v;
     }
   }
-}
-
-// var[n] = sum_{d < D} Y[row0 + n, d]^2 + s_n
-template <typename T>
-__global__ __launch_bounds__(kThreads) void row_sumsq_kernel(const T* Ybar, int64_t ldy, int row0, int D, int N, const T* s,
-                                                             int noise_kind, T* var) {
-  const int n = blockIdx.x * kThreads + threadIdx.x;  // consecutive threads -> consecutive rows: coalesced per column
-  if (n >= N) return;
-  double acc[4] = {0.0, 0.0, 0.0, 0.0};
-  const T* p = Ybar + row0 + n;
-  int d = 0;
-  for (; d + 4 <= D; d += 4) {
-#pragma unroll
-    for (int k = 0; k < 4; ++k) {
-      const double v = (double)p[(int64_t)(d + k) * ldy];
-      acc[k] += v * v;
-    }
-  }
-  for (; d < D; ++d) {
-    const double v = (double)p[(int64_t)d * ldy];
-    acc[0] += v * v;
-  }
-  var[n] = (T)((acc[0] + acc[1]) + (acc[2] + acc[3])) + ((noise_kind == NOISE_DIAGONAL) ? s[n] : s[0]);
 }
 
 // diagonal prior: var[n] = sum_d x[d,n]^2 / dprior[d] + s_n  (pure stream)

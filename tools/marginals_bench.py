@@ -1,7 +1,7 @@
 """Timing of the batched marginal stream (mean + var) on device-resident inputs: B regressors x N inputs at dimension D."""
-import sys, time
+import os, sys, time
 import numpy as np, torch
-sys.path.insert(0, ".")
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import blr_amd
 from blr_amd import _abi
 
@@ -32,4 +32,8 @@ def run(B, D, N, dtype):
     err = ((var[0].double() - v_ref).abs() / v_ref).max().item()
     print(f"B={B} D={D} N={N} {np.dtype(dtype).name}: {dt*1e3:.3f} ms  {B*N/dt/1e6:.1f} M marginals/s  {B*N*D*D/dt/1e12:.2f} TFLOP/s  max rel err {err:.2e}")
 
-run(64, 128, 4096, np.float64); run(64, 128, 4096, np.float32); run(512, 64, 1024, np.float64)
+if __name__ == "__main__":
+    if len(sys.argv) > 1 and sys.argv[1] == "large":
+        run(1, 1024, 65536, np.float32); run(1, 2048, 16384, np.float32); run(1, 1024, 65536, np.float64)
+    else:
+        run(64, 128, 4096, np.float64); run(64, 128, 4096, np.float32); run(512, 64, 1024, np.float64)
