@@ -669,9 +669,13 @@ int marginals_batched(blr_handle* h, int memspace, int layout, int64_t B, int64_
     // MFMA path: inputs as rows of an LDS block, Y = X'L^-T by the TRSM core, fused mean / row sum of squares
     using TC = TrsmCfg<T>;
     auto kern = marginals_mfma_kernel<T>;
-    HIP_TRY(h, hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, TC::LDS_BYTES));
-    dim3 grid((unsigned)((N + TC::RB - 1) / TC::RB), (unsigned)B);
-    hipLaunchKernelGGL(kern, grid, dim3(kThreads), TC::LDS_BYTES, h->stream, a);
+    const int lds = TC::LDS_BYTES + kPB * (int)sizeof(T);
+    HIP_TRY(h, hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, lds));
+    // one workgroup per CU (LDS); every workgroup amortises its factor set-up over several tiles: aim at ~2 rounds
+    const int64_t ntiles = (N + TC::RB - 1) / TC::RB;
+    const int64_t per_reg = std::max<int64_t>(1, std::min<int64_t>(ntiles, (512 + B - 1) / B));
+    dim3 grid((unsigned)per_reg, (unsigned)B);
+    hipLaunchKernelGGL(kern, grid, dim3(kThreads), lds, h->stream, a);
   } else {
     size_t lds = ((size_t)D * 64 + D) * sizeof(T) + 16;
     auto kern = marginals_kernel<T>;

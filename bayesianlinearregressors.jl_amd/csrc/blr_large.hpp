@@ -671,15 +671,12 @@ struct TrsmCfg {
 // again: the per-row substitution of the first version serialised 16 steps per chunk on the vector ALU behind two
 // barriers).  The 16 x 16 inverses are formed once per block by 16 lanes each (forward substitution of a unit column).
 template <typename T>
-__device__ __forceinline__ void trsm_core(T* __restrict__ Xs, const T* __restrict__ P, const T* __restrict__ dinv,
-                                          T* __restrict__ Linv, int nchunks, int tid, int lane, int wave) {
+__device__ __forceinline__ void trsm_prepare(const T* __restrict__ P, const T* __restrict__ dinv, T* __restrict__ Linv, int nchunks,
+                                             int tid) {
   using Cfg = TrsmCfg<T>;
-  using acc4 = typename Mfma<T>::acc4;
-  constexpr int NT = Cfg::RB / 64;  // row tiles per wave
   constexpr int LI = Cfg::LDI;
-  const int fr = lane & 15, fq = lane >> 4;
   if (tid < 16 * nchunks) {
-    const int b = tid >> 4, j = tid & 15, j0 = 16 * b;
+    const int j = tid & 15, j0 = 16 * (tid >> 4);
     T x[16];
 #pragma unroll
     for (int i = 0; i < 16; ++i) {
@@ -691,6 +688,17 @@ __device__ __forceinline__ void trsm_core(T* __restrict__ Xs, const T* __restric
     }
   }
   __syncthreads();
+}
+
+// the sweep proper; Linv from trsm_prepare.  Ends with a workgroup barrier (Xs complete for everybody).
+template <typename T>
+__device__ __forceinline__ void trsm_sweep(T* __restrict__ Xs, const T* __restrict__ P, const T* __restrict__ Linv, int nchunks,
+                                           int lane, int wave) {
+  using Cfg = TrsmCfg<T>;
+  using acc4 = typename Mfma<T>::acc4;
+  constexpr int NT = Cfg::RB / 64;  // row tiles per wave
+  constexpr int LI = Cfg::LDI;
+  const int fr = lane & 15, fq = lane >> 4;
   for (int J = 0; J < nchunks; ++J) {
     acc4 acc[NT];
 #pragma unroll
@@ -741,6 +749,13 @@ __device__ __forceinline__ void trsm_core(T* __restrict__ Xs, const T* __restric
     __builtin_amdgcn_wave_barrier();
   }
   __syncthreads();
+}
+
+template <typename T>
+__device__ __forceinline__ void trsm_core(T* __restrict__ Xs, const T* __restrict__ P, const T* __restrict__ dinv,
+                                          T* __restrict__ Linv, int nchunks, int tid, int lane, int wave) {
+  trsm_prepare<T>(P, dinv, Linv, nchunks, tid);
+  trsm_sweep<T>(Xs, P, Linv, nchunks, lane, wave);
 }
 
 template <typename T>
@@ -1206,15 +1221,21 @@ __global__ __launch_bounds__(kThreads) void var_diag_prior_kernel(const T* X, in
 }
 
 // ---- marginal stream for D <= 128 with an upper factor: the same TRSM core, fused with mean and row sum of squares ----
-// One workgroup per tile of RB inputs (128 in f32, 64 in f64): the inputs are the ROWS of an LDS block, L = U' is packed
-// next to it, Y = X'L^-T by trsm_core (MFMA between 16-column chunks), var_n = |Y_n|^2 + s_n, mean_n = x_n'mw (:33, :40-43).
+// A workgroup owns a strided set of input tiles of ONE regressor (RB inputs each: 128 in f32, 64 in f64): L = U' is packed
+// and its 16 x 16 inverse blocks are formed once, then per tile: the inputs become the ROWS of an LDS block (the next
+// tile's loads are already in flight), Y = X'L^-T by the barrier-free MFMA sweep, var_n = |Y_n|^2 + s_n,
+// mean_n = x_n'mw (:33, :40-43).  The first version reloaded and re-inverted L for every tile (one tile per workgroup).
 template <typename T>
 __global__ __launch_bounds__(kThreads) void marginals_mfma_kernel(MarginalArgs<T> a) {
   using Cfg = TrsmCfg<T>;
+  constexpr int VEC = Mfma<T>::VEC;
+  typedef T vecT __attribute__((ext_vector_type(Mfma<T>::VEC)));
   extern __shared__ __attribute__((aligned(16))) char smem[];
   T* const P = reinterpret_cast<T*>(smem);
   T* const Xs = reinterpret_cast<T*>(smem + Cfg::OFF_X);
   T* const dinv = reinterpret_cast<T*>(smem + Cfg::OFF_DI);
+  T* const Linv = reinterpret_cast<T*>(smem + Cfg::OFF_LI);
+  T* const mwl = reinterpret_cast<T*>(smem + Cfg::LDS_BYTES);  // [128]
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = uni(tid >> 6);
   const int D = a.D, N = a.N;
@@ -1224,10 +1245,26 @@ __global__ __launch_bounds__(kThreads) void marginals_mfma_kernel(MarginalArgs<T
   const T* U = a.U + (int64_t)reg * a.strideU;
   const T* s = a.s + (int64_t)reg * a.strides;
   const T* mw = a.mw + (int64_t)reg * a.stridemw;
-  const int n0 = blockIdx.x * Cfg::RB;
-  const int nt = min(Cfg::RB, N - n0);
   const int nchunks = (D + 15) >> 4, DPc = nchunks * 16;
-  // L = U' packed (padding: unit diagonal); 8 loads in flight per thread (a plain loop serialises on load latency)
+  const int ntiles = (N + Cfg::RB - 1) / Cfg::RB;
+
+  // ---- the first tile's inputs go in flight before anything else (vector path: ColVecs, whole 16-byte vectors)
+  const bool vec = a.layout == LAYOUT_COLVECS && D == kPB && (a.ldx % VEC) == 0 && ((uintptr_t)X % 16) == 0;
+  constexpr int VPR = kPB / VEC;                           // vectors per input (row of Xs)
+  constexpr int NVT = Cfg::RB * kPB / (VEC * kThreads);    // vectors per thread per tile
+  vecT pre[NVT];
+  auto prefetch = [&](int tile) {
+    const int n0 = tile * Cfg::RB;
+#pragma unroll
+    for (int u = 0; u < NVT; ++u) {
+      const int vi = u * kThreads + tid;
+      const int r = vi / VPR, c0 = (vi % VPR) * VEC;
+      pre[u] = (n0 + r < N) ? *reinterpret_cast<const vecT*>(X + (int64_t)(n0 + r) * a.ldx + c0) : vecT(T(0));
+    }
+  };
+  if (vec && (int)blockIdx.x < ntiles) prefetch(blockIdx.x);
+
+  // ---- once per workgroup: L = U' packed (padding: unit diagonal), reciprocal pivots, inverse blocks, mw
 #pragma unroll 1
   for (int base = 0; base < DPc * DPc; base += kThreads * 8) {
     T v[8];
@@ -1245,45 +1282,69 @@ __global__ __launch_bounds__(kThreads) void marginals_mfma_kernel(MarginalArgs<T
       if (idx < DPc * DPc && c <= r) P[pidx(r, c)] = (r < D) ? v[u] : (r == c ? T(1) : T(0));
     }
   }
-  // inputs as rows
-#pragma unroll 1
-  for (int base = 0; base < Cfg::RB * DPc; base += kThreads * 8) {
-    T v[8];
-#pragma unroll
-    for (int u = 0; u < 8; ++u) {
-      const int idx = base + u * kThreads + tid;
-      int r, c;
-      if (a.layout == LAYOUT_COLVECS) { c = idx % DPc; r = idx / DPc; }
-      else                            { r = idx % Cfg::RB; c = idx / Cfg::RB; }
-      const bool ok = idx < Cfg::RB * DPc && r < nt && c < D;
-      const int64_t addr = (a.layout == LAYOUT_COLVECS) ? (int64_t)(n0 + r) * a.ldx + c : (int64_t)c * a.ldx + n0 + r;
-      v[u] = X[ok ? addr : 0];
-    }
-#pragma unroll
-    for (int u = 0; u < 8; ++u) {
-      const int idx = base + u * kThreads + tid;
-      int r, c;
-      if (a.layout == LAYOUT_COLVECS) { c = idx % DPc; r = idx / DPc; }
-      else                            { r = idx % Cfg::RB; c = idx / Cfg::RB; }
-      if (idx < Cfg::RB * DPc) Xs[r * Cfg::LDX + c] = (r < nt && c < D) ? v[u] : T(0);
-    }
-  }
+  if (tid < kPB) mwl[tid] = (tid < D) ? mw[tid] : T(0);
   __syncthreads();
   if (tid < DPc) dinv[tid] = T(1) / P[pidx(tid, tid)];
-  T m = T(0);
-  if (a.mean && tid < Cfg::RB) {
-    const T* xr = Xs + tid * Cfg::LDX;
-    for (int c = 0; c < D; ++c) m += xr[c] * mw[c];
-  }
   __syncthreads();
-  if (a.var) trsm_core<T>(Xs, P, dinv, reinterpret_cast<T*>(smem + Cfg::OFF_LI), nchunks, tid, lane, wave);
-  if (tid < nt) {
-    if (a.mean) a.mean[(int64_t)reg * a.stridemean + n0 + tid] = m;
-    if (a.var) {
+  if (a.var) trsm_prepare<T>(P, dinv, Linv, nchunks, tid);
+
+  for (int tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
+    const int n0 = tile * Cfg::RB;
+    const int nt = min(Cfg::RB, N - n0);
+    __syncthreads();  // the previous tile's readers of Xs are done
+    if (vec) {
+#pragma unroll
+      for (int u = 0; u < NVT; ++u) {
+        const int vi = u * kThreads + tid;
+        const int r = vi / VPR, c0 = (vi % VPR) * VEC;
+#pragma unroll
+        for (int e = 0; e < VEC; ++e) Xs[r * Cfg::LDX + c0 + e] = pre[u][e];
+      }
+      if (tile + (int)gridDim.x < ntiles) prefetch(tile + gridDim.x);  // in flight during this tile's sweep
+    } else {
+#pragma unroll 1
+      for (int base = 0; base < Cfg::RB * DPc; base += kThreads * 8) {
+        T v[8];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) {
+          const int idx = base + u * kThreads + tid;
+          int r, c;
+          if (a.layout == LAYOUT_COLVECS) { c = idx % DPc; r = idx / DPc; }
+          else                            { r = idx % Cfg::RB; c = idx / Cfg::RB; }
+          const bool ok = idx < Cfg::RB * DPc && r < nt && c < D;
+          const int64_t addr = (a.layout == LAYOUT_COLVECS) ? (int64_t)(n0 + r) * a.ldx + c : (int64_t)c * a.ldx + n0 + r;
+          v[u] = X[ok ? addr : 0];
+        }
+#pragma unroll
+        for (int u = 0; u < 8; ++u) {
+          const int idx = base + u * kThreads + tid;
+          int r, c;
+          if (a.layout == LAYOUT_COLVECS) { c = idx % DPc; r = idx / DPc; }
+          else                            { r = idx % Cfg::RB; c = idx / Cfg::RB; }
+          if (idx < Cfg::RB * DPc) Xs[r * Cfg::LDX + c] = (r < nt && c < D) ? v[u] : T(0);
+        }
+      }
+    }
+    __syncthreads();
+    T m = T(0);
+    if (a.mean && tid < Cfg::RB) {
       const T* xr = Xs + tid * Cfg::LDX;
-      T v0 = T(0), v1 = T(0);
-      for (int c = 0; c + 1 < DPc; c += 2) { v0 += xr[c] * xr[c]; v1 += xr[c + 1] * xr[c + 1]; }
-      a.var[(int64_t)reg * a.stridevar + n0 + tid] = (v0 + v1) + ((a.noise_kind == NOISE_DIAGONAL) ? s[n0 + tid] : s[0]);
+      T m0 = T(0), m1 = T(0);
+      for (int c = 0; c + 1 < DPc; c += 2) { m0 += xr[c] * mwl[c]; m1 += xr[c + 1] * mwl[c + 1]; }
+      m = m0 + m1;
+    }
+    if (a.var) {
+      __syncthreads();  // mean reads rows across the waves' tiles before the sweep rewrites them
+      trsm_sweep<T>(Xs, P, Linv, nchunks, lane, wave);
+    }
+    if (tid < nt) {
+      if (a.mean) a.mean[(int64_t)reg * a.stridemean + n0 + tid] = m;
+      if (a.var) {
+        const T* xr = Xs + tid * Cfg::LDX;
+        T v0 = T(0), v1 = T(0);
+        for (int c = 0; c + 1 < DPc; c += 2) { v0 += xr[c] * xr[c]; v1 += xr[c + 1] * xr[c + 1]; }
+        a.var[(int64_t)reg * a.stridevar + n0 + tid] = (v0 + v1) + ((a.noise_kind == NOISE_DIAGONAL) ? s[n0 + tid] : s[0]);
+      }
     }
   }
 }
