@@ -247,7 +247,6 @@ int chol_large(blr_handle* h, T* M, int64_t ld, int DP, int nrows_total, int32_t
 template <typename T>
 int posterior_large_one(blr_handle* h, const PosteriorArgs<T>& a, int64_t reg) {
   using LC = LargeCfg<T>;
-  using SC = SmallCfg<T, 8>;
   const int D = a.D, N = a.N;
   const int DP = (D + kPB - 1) / kPB * kPB, NC = DP / kPB;
   const int64_t lda = DP + kPB;
@@ -665,23 +664,22 @@ int marginals_batched(blr_handle* h, int memspace, int layout, int64_t B, int64_
   a.info = chol_info;
   if (chol_info) HIP_TRY(h, hipMemcpyAsync(info_out_dev, chol_info, (size_t)B * sizeof(int32_t), hipMemcpyDeviceToDevice, h->stream));
   else HIP_TRY(h, hipMemsetAsync(info_out_dev, 0, (size_t)B * sizeof(int32_t), h->stream));
-  if (var && kind == BLR_PRIOR_UPPER_FACTOR) {
-    // MFMA path: inputs as rows of an LDS block, Y = X'L^-T by the TRSM core, fused mean / row sum of squares
+  {
+    // inputs as rows of an LDS block; with a factor: Y = X'L^-T by the TRSM sweep (MFMA), fused mean / row sum of squares;
+    // mean-only and diagonal-prior calls are pure streams through the same tile loop (smaller LDS image, 2 workgroups/CU)
     using TC = TrsmCfg<T>;
     auto kern = marginals_mfma_kernel<T>;
-    const int lds = TC::LDS_BYTES + kPB * (int)sizeof(T);
-    HIP_TRY(h, hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, lds));
-    // one workgroup per CU (LDS); every workgroup amortises its factor set-up over several tiles: aim at ~2 rounds
+    const bool use_factor = var && kind == BLR_PRIOR_UPPER_FACTOR;
+    const int xs_bytes = (TC::RB * TC::LDX * (int)sizeof(T) + 15) & ~15;
+    const int lds = use_factor ? TC::LDS_BYTES + kPB * (int)sizeof(T) : xs_bytes + 2 * kPB * (int)sizeof(T) + 16;
+    HIP_TRY(h, hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                   TC::LDS_BYTES + kPB * (int)sizeof(T)));
+    // every workgroup amortises its set-up over several tiles: aim at ~2 rounds of the chip
     const int64_t ntiles = (N + TC::RB - 1) / TC::RB;
-    const int64_t per_reg = std::max<int64_t>(1, std::min<int64_t>(ntiles, (512 + B - 1) / B));
+    const int64_t slots = use_factor ? 512 : 1024;
+    const int64_t per_reg = std::max<int64_t>(1, std::min<int64_t>(ntiles, (slots + B - 1) / B));
     dim3 grid((unsigned)per_reg, (unsigned)B);
     hipLaunchKernelGGL(kern, grid, dim3(kThreads), lds, h->stream, a);
-  } else {
-    size_t lds = ((size_t)D * 64 + D) * sizeof(T) + 16;
-    auto kern = marginals_kernel<T>;
-    HIP_TRY(h, hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-    dim3 grid((unsigned)((N + 63) / 64), (unsigned)B);
-    hipLaunchKernelGGL(kern, grid, dim3(64), lds, h->stream, a);
   }
   HIP_TRY(h, hipGetLastError());
   if (memspace == BLR_MEM_HOST) {
@@ -983,7 +981,6 @@ int posterior_rff(blr_handle* h, int memspace, int64_t Din, int64_t D, int64_t N
   }
   // host pointers for everything except Phi: stage the rest here, then run on device pointers
   Staging guard(h);
-  PosteriorArgs<T> a{};
   const T *yd, *sd, *mwd, *Lwd;
   const size_t lw_one = prior_kind == BLR_PRIOR_DIAGONAL ? (size_t)D : mat_extent(D, D, ldl);
   if (noise_kind != BLR_NOISE_ISOTROPIC && noise_kind != BLR_NOISE_DIAGONAL) return bad_arg(h, 13, "noise_kind");

@@ -36,10 +36,8 @@ __global__ __launch_bounds__(kThreads) void chol_small_kernel(const T* __restric
 }
 
 // ---- marginal stream --------------------------------------------------------------------------------
-// mean_n = x_n'mw (:33), var_n = |U^-T x_n|^2 + s_n (:40-43) for a tile of 64 columns per wave-sized
-// workgroup.  The tile is staged as alpha[d][t] in LDS (coalesced for either layout) and the forward
-// substitution alpha = U^-T x runs in place, one column per lane.  prior_kind is UPPER_FACTOR (U D x D,
-// upper) or DIAGONAL (d[D]).
+// mean_n = x_n'mw (:33), var_n = |U^-T x_n|^2 + s_n (:40-43): arguments of marginals_mfma_kernel (blr_large.hpp).
+// prior_kind is UPPER_FACTOR (U D x D, upper) or DIAGONAL (d[D]); var == NULL: mean only.
 template <typename T>
 struct MarginalArgs {
   const T* X; int64_t ldx, strideX;
@@ -52,58 +50,6 @@ struct MarginalArgs {
   int layout, noise_kind, prior_kind;
   int D, N, B;
 };
-
-template <typename T>
-__global__ __launch_bounds__(64) void marginals_kernel(MarginalArgs<T> a) {
-  extern __shared__ __attribute__((aligned(16))) char smem[];
-  const int D = a.D, N = a.N;
-  T* const alpha = reinterpret_cast<T*>(smem);  // [D][64]
-  T* const mwv = alpha + (size_t)D * 64;        // [D]
-  const int lane = threadIdx.x;
-  const int reg = blockIdx.y;
-  if (a.info && a.info[reg] != 0) return;
-  const T* X = a.X + (int64_t)reg * a.strideX;
-  const T* U = a.U + (int64_t)reg * a.strideU;
-  const T* s = a.s + (int64_t)reg * a.strides;
-  const T* mw = a.mw + (int64_t)reg * a.stridemw;
-  const int n0 = blockIdx.x * 64;
-  const int nt = min(64, N - n0);
-  for (int d = lane; d < D; d += 64) mwv[d] = mw[d];
-  if (a.layout == LAYOUT_COLVECS) {
-    for (int idx = lane; idx < D * 64; idx += 64) {
-      int d = idx % D, t = idx / D;
-      alpha[d * 64 + t] = (t < nt) ? X[(int64_t)(n0 + t) * a.ldx + d] : T(0);
-    }
-  } else {
-    for (int d = 0; d < D; ++d) alpha[d * 64 + lane] = (lane < nt) ? X[(int64_t)d * a.ldx + n0 + lane] : T(0);
-  }
-  __syncthreads();
-  T m = T(0);
-  for (int d = 0; d < D; ++d) m += alpha[d * 64 + lane] * mwv[d];
-  T v = T(0);
-  if (a.var) {
-    if (a.prior_kind == PRIOR_DIAGONAL) {
-      for (int d = 0; d < D; ++d) {
-        T x = alpha[d * 64 + lane];
-        v += x * x / U[d];
-      }
-    } else {
-      for (int i = 0; i < D; ++i) {
-        T accv = alpha[i * 64 + lane];
-        const T* ucol = U + (int64_t)i * a.ldu;  // column i of U: U[k,i], k <= i (wave-uniform address)
-        for (int k = 0; k < i; ++k) accv -= ucol[k] * alpha[k * 64 + lane];
-        accv /= ucol[i];
-        alpha[i * 64 + lane] = accv;
-        v += accv * accv;
-      }
-    }
-    v += (a.noise_kind == NOISE_DIAGONAL) ? ((lane < nt) ? s[n0 + lane] : T(0)) : s[0];
-  }
-  if (lane < nt) {
-    if (a.mean) a.mean[(int64_t)reg * a.stridemean + n0 + lane] = m;
-    if (a.var) a.var[(int64_t)reg * a.stridevar + n0 + lane] = v;
-  }
-}
 
 // ---- weight draws: W = mw .+ U \ Z  (:51, sampling_functions.jl:29,35,44) -----------------------------
 // One sample per lane; back substitution in place in LDS (w[d][t]).

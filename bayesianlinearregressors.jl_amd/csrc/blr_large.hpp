@@ -520,7 +520,6 @@ __device__ __forceinline__ void load_upper_block_to_packed(T* __restrict__ P, co
 // kernel (measured: 475 k -> 351 k updates/s at D=128, N=4096).
 template <typename T>
 __global__ __launch_bounds__(kThreads, (sizeof(T) == 4 ? BLR_F32_WAVES_PER_SIMD : 2)) void chol_diag_kernel(T* Abar, int64_t lda, int p, int32_t* info, int info_base) {
-  using C = SmallCfg<T, 8>;
   extern __shared__ __attribute__((aligned(16))) char smem[];
   T* const P = reinterpret_cast<T*>(smem);
   const int tid = threadIdx.x;
@@ -769,7 +768,6 @@ template <typename T>
 __global__ __launch_bounds__(kThreads) void trsm_block_kernel(T* Abar, int64_t lda, int p, int row_begin, int nrows_total,
                                                               const int32_t* info, RowSqArgs<T> rs) {
   using Cfg = TrsmCfg<T>;
-  using acc4 = typename Mfma<T>::acc4;
   extern __shared__ __attribute__((aligned(16))) char smem[];
   T* const P = reinterpret_cast<T*>(smem);                    // packed lower triangle of L_pp
   T* const Xs = reinterpret_cast<T*>(smem + Cfg::OFF_X);      // [RB][LDX]
@@ -1231,11 +1229,15 @@ __global__ __launch_bounds__(kThreads) void marginals_mfma_kernel(MarginalArgs<T
   constexpr int VEC = Mfma<T>::VEC;
   typedef T vecT __attribute__((ext_vector_type(Mfma<T>::VEC)));
   extern __shared__ __attribute__((aligned(16))) char smem[];
+  // with a factor: [P | Xs | dinv | Linv | mw];  mean-only / diagonal prior: [Xs | dinv | mw] (two workgroups per CU)
+  const bool use_factor = a.var != nullptr && a.prior_kind == PRIOR_UPPER_FACTOR;
+  const bool diag_prior = a.var != nullptr && a.prior_kind == PRIOR_DIAGONAL;
+  constexpr int XS_BYTES = (Cfg::RB * Cfg::LDX * (int)sizeof(T) + 15) & ~15;
   T* const P = reinterpret_cast<T*>(smem);
-  T* const Xs = reinterpret_cast<T*>(smem + Cfg::OFF_X);
-  T* const dinv = reinterpret_cast<T*>(smem + Cfg::OFF_DI);
+  T* const Xs = reinterpret_cast<T*>(smem + (use_factor ? Cfg::OFF_X : 0));
+  T* const dinv = reinterpret_cast<T*>(smem + (use_factor ? Cfg::OFF_DI : XS_BYTES));
   T* const Linv = reinterpret_cast<T*>(smem + Cfg::OFF_LI);
-  T* const mwl = reinterpret_cast<T*>(smem + Cfg::LDS_BYTES);  // [128]
+  T* const mwl = reinterpret_cast<T*>(smem + (use_factor ? Cfg::LDS_BYTES : XS_BYTES + kPB * (int)sizeof(T)));  // [128]
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = uni(tid >> 6);
   const int D = a.D, N = a.N;
@@ -1266,7 +1268,7 @@ __global__ __launch_bounds__(kThreads) void marginals_mfma_kernel(MarginalArgs<T
 
   // ---- once per workgroup: L = U' packed (padding: unit diagonal), reciprocal pivots, inverse blocks, mw
 #pragma unroll 1
-  for (int base = 0; base < DPc * DPc; base += kThreads * 8) {
+  for (int base = 0; use_factor && base < DPc * DPc; base += kThreads * 8) {
     T v[8];
 #pragma unroll
     for (int u = 0; u < 8; ++u) {
@@ -1284,9 +1286,10 @@ __global__ __launch_bounds__(kThreads) void marginals_mfma_kernel(MarginalArgs<T
   }
   if (tid < kPB) mwl[tid] = (tid < D) ? mw[tid] : T(0);
   __syncthreads();
-  if (tid < DPc) dinv[tid] = T(1) / P[pidx(tid, tid)];
+  if (use_factor && tid < DPc) dinv[tid] = T(1) / P[pidx(tid, tid)];
+  if (diag_prior && tid < kPB) dinv[tid] = (tid < D) ? T(1) / U[tid] : T(0);  // U = the diagonal of the precision
   __syncthreads();
-  if (a.var) trsm_prepare<T>(P, dinv, Linv, nchunks, tid);
+  if (use_factor) trsm_prepare<T>(P, dinv, Linv, nchunks, tid);
 
   for (int tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
     const int n0 = tile * Cfg::RB;
@@ -1333,7 +1336,7 @@ __global__ __launch_bounds__(kThreads) void marginals_mfma_kernel(MarginalArgs<T
       for (int c = 0; c + 1 < DPc; c += 2) { m0 += xr[c] * mwl[c]; m1 += xr[c + 1] * mwl[c + 1]; }
       m = m0 + m1;
     }
-    if (a.var) {
+    if (use_factor) {
       __syncthreads();  // mean reads rows across the waves' tiles before the sweep rewrites them
       trsm_sweep<T>(Xs, P, Linv, nchunks, lane, wave);
     }
@@ -1342,7 +1345,11 @@ __global__ __launch_bounds__(kThreads) void marginals_mfma_kernel(MarginalArgs<T
       if (a.var) {
         const T* xr = Xs + tid * Cfg::LDX;
         T v0 = T(0), v1 = T(0);
-        for (int c = 0; c + 1 < DPc; c += 2) { v0 += xr[c] * xr[c]; v1 += xr[c + 1] * xr[c + 1]; }
+        if (use_factor) {
+          for (int c = 0; c + 1 < DPc; c += 2) { v0 += xr[c] * xr[c]; v1 += xr[c + 1] * xr[c + 1]; }
+        } else {  // diagonal precision: var_n = sum_d x_dn^2 / d_d
+          for (int c = 0; c + 1 < DPc; c += 2) { v0 += xr[c] * xr[c] * dinv[c]; v1 += xr[c + 1] * xr[c + 1] * dinv[c + 1]; }
+        }
         a.var[(int64_t)reg * a.stridevar + n0 + tid] = (v0 + v1) + ((a.noise_kind == NOISE_DIAGONAL) ? s[n0 + tid] : s[0]);
       }
     }
