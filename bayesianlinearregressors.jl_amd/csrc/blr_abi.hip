@@ -544,8 +544,15 @@ int marginals_large_one(blr_handle* h, int layout, int64_t D, int64_t N, const T
     MeanFillArgs<T> m{};
     m.X = X; m.ldx = ldx; m.layout = layout; m.mw = mw; m.mean = mean; m.Ybar = Ybar; m.ldy = ldy; m.row0 = DP;
     m.D = (int)D; m.DP = DP; m.N = (int)N;
-    if (mean || Ybar)
+    constexpr int VEC = Mfma<T>::VEC;
+    const bool stream_ok = mean && !Ybar && layout == BLR_LAYOUT_COLVECS && (D % VEC) == 0 && (ldx % VEC) == 0 &&
+                           ((uintptr_t)X % 16) == 0;
+    if (stream_ok) {  // mean only: a pure GEMV stream
+      const size_t lds = ((size_t)D * sizeof(T) + 15) & ~(size_t)15;
+      hipLaunchKernelGGL(mean_stream_kernel<T>, dim3(1024), dim3(kThreads), lds, h->stream, X, ldx, mw, mean, (int)D, (int)N);
+    } else if (mean || Ybar) {
       hipLaunchKernelGGL(mean_fill_kernel<T>, dim3((unsigned)(NP / 64)), dim3(kThreads), 0, h->stream, m);
+    }
   }
   if (var && prior_kind == BLR_PRIOR_DIAGONAL) {
     hipLaunchKernelGGL(var_diag_prior_kernel<T>, dim3(2048), dim3(kThreads), 0, h->stream, X, ldx, layout, Lw, (int)D, (int)N, s,

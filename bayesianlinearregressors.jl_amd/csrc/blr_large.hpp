@@ -1174,6 +1174,54 @@ __global__ __launch_bounds__(kThreads) void mean_fill_kernel(MeanFillArgs<T> a) 
   }
 }
 
+// mean-only stream for ColVecs with 16-byte aligned columns: two columns per wave per step, every load of a step in
+// flight before the first use (the colstats pattern); mean_n = x_n'mw accumulated in double, fixed-order butterfly
+template <typename T>
+__global__ __launch_bounds__(kThreads) void mean_stream_kernel(const T* X, int64_t ldx, const T* mw, T* mean, int D, int N) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  constexpr int VEC = Mfma<T>::VEC;
+  typedef T vecT __attribute__((ext_vector_type(Mfma<T>::VEC)));
+  T* const mwl = reinterpret_cast<T*>(smem);
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  for (int d = tid; d < D; d += kThreads) mwl[d] = mw[d];
+  __syncthreads();
+  const int DV = D / VEC;
+  const vecT* mwv = reinterpret_cast<const vecT*>(mwl);
+  const int wid = blockIdx.x * kWaves + wave, nw = gridDim.x * kWaves;
+  for (int n = 2 * wid; n < N; n += 2 * nw) {
+    const bool two = n + 1 < N;
+    const vecT* c0 = reinterpret_cast<const vecT*>(X + (int64_t)n * ldx);
+    const vecT* c1 = reinterpret_cast<const vecT*>(X + (int64_t)(two ? n + 1 : n) * ldx);
+    double mu0 = 0.0, mu1 = 0.0;
+    for (int i0 = 0; i0 < DV; i0 += 256) {
+      vecT v0[4], v1[4];
+#pragma unroll
+      for (int u = 0; u < 4; ++u) {
+        const int i = i0 + u * 64 + lane;
+        const bool in = i < DV;
+        v0[u] = in ? c0[i] : vecT(T(0));
+        v1[u] = in ? c1[i] : vecT(T(0));
+      }
+#pragma unroll
+      for (int u = 0; u < 4; ++u) {
+        const int i = i0 + u * 64 + lane;
+        if (i < DV) {
+          const vecT m = mwv[i];
+#pragma unroll
+          for (int e = 0; e < VEC; ++e) {
+            mu0 += (double)v0[u][e] * (double)m[e];
+            mu1 += (double)v1[u][e] * (double)m[e];
+          }
+        }
+      }
+    }
+    mu0 = wave_allreduce(mu0);
+    mu1 = wave_allreduce(mu1);
+    if (lane == 0) mean[n] = (T)mu0;
+    if (lane == 1 && two) mean[n + 1] = (T)mu1;
+  }
+}
+
 // L = U' into the top DP x DP block of Ybar (lower, unit padding); U upper column-major (ldu)
 template <typename T>
 __global__ __launch_bounds__(kThreads) void factor_transpose_fill_kernel(const T* U, int64_t ldu, int D, int DP, T* Ybar,

@@ -717,6 +717,7 @@ def test_large_d_marginals(B, dtype, D, N):
             m, v = B.mean_and_var(f(x, s))
             np.testing.assert_allclose(m, m_o, rtol=rt, atol=rt * 10)
             np.testing.assert_allclose(v, v_o, rtol=rt)
+            np.testing.assert_allclose(B.mean(f(x, s)), m_o, rtol=rt, atol=rt * 10)  # mean-only: the pure GEMV stream
     dvec = np.exp(rng.standard_normal(D)).astype(dtype)
     v = B.var(B.BayesianLinearRegressor(mw, B.Diagonal(dvec))(np.asfortranarray(X), dtype(0.5)))
     np.testing.assert_allclose(v, O.var(mw.astype(float), np.diag(dvec.astype(float)), X.astype(float), 0.5), rtol=rt)
