@@ -144,6 +144,11 @@ int launch_wave_solve(blr_handle* h, WaveSolveArgs<T>& b, int NC, int64_t S) {
   HIP_TRY(h, hipFuncSetAttribute(reinterpret_cast<const void*>(backsolve_wave_kernel<T>), hipFuncAttributeMaxDynamicSharedMemorySize,
                                  (int)wave_solve_lds<T>()));
   hipLaunchKernelGGL(backsolve_wave_kernel<T>, dim3(NC, (unsigned)S), dim3(kThreads), wave_solve_lds<T>(), h->stream, b);
+  const hipError_t le = hipGetLastError();
+  if (le != hipSuccess) {  // nothing ran: the ticket counter did not advance
+    h->ticket_base -= (unsigned)(NC * S);
+    return hip_fail(h, le, "launch of backsolve_wave_kernel");
+  }
   return 0;
 }
 
