@@ -92,7 +92,8 @@ template <typename T, int NB>
 struct SmallCfg {
   static constexpr int DP = 16 * NB;
   // k-steps (of 4 columns) per stage; chosen so PER is a multiple of the 16-byte vector width
-  static constexpr int KS = (NB < 3 || ((NB & 1) && sizeof(T) == 4)) ? 16 : 8;
+  // (f32, NB <= 4: 16 k-steps = 64 columns = 16 KB per stage -- these shapes are bound by bytes in flight per CU, not LDS)
+  static constexpr int KS = (NB < 3 || ((NB & 1) && sizeof(T) == 4) || (NB <= 4 && sizeof(T) == 4)) ? 16 : 8;
   static constexpr int NSC = 4 * KS;                    // columns per stage
   static constexpr int SLOT = KS * NB * 64;             // elements per LDS slot
   static constexpr int PER = SLOT / kThreads;           // elements per thread per stage
