@@ -21,6 +21,7 @@ from .regressor import (
     Symmetric,
     cov,
     logpdf,
+    logpdf_and_gradient,
     logpdf_columns,
     marginals,
     mean,
@@ -36,5 +37,5 @@ from .regressor import (
 __all__ = [
     "logpdf", "rand", "mean", "std", "cov", "var", "BayesianLinearRegressor", "marginals", "posterior",
     "BasisFunctionRegressor", "ColVecs", "RowVecs", "Diagonal", "Symmetric", "PDMat", "Normal", "FiniteGP",
-    "BLRFunctionSample", "RandomFourierFeatures", "mean_and_var", "mean_and_cov", "rand_b", "logpdf_columns", "BLRError", "PosDefException",
+    "BLRFunctionSample", "RandomFourierFeatures", "mean_and_var", "mean_and_cov", "rand_b", "logpdf_columns", "logpdf_and_gradient", "BLRError", "PosDefException",
 ]

@@ -71,6 +71,9 @@ for _suf in ("f64", "f32"):
         [_H, _int, _int, _i64, _i64, _i64, _vp, _i64, _int, _vp, _int, _vp, _vp, _i64, _vp, _i64, _vp, _i64, _vp, _i64], _int)
     _SIGS[f"blr_sample_weights_{_suf}"] = (
         [_H, _int, _i64, _i64, _int, _vp, _vp, _i64, _vp, _i64, _vp, _i64], _int)
+    _SIGS[f"blr_logpdf_grad_batched_{_suf}"] = (
+        [_H, _int, _int, _i64, _i64, _i64, _vp, _i64, _i64, _vp, _i64, _int, _vp, _i64, _int, _vp, _i64, _vp, _i64, _i64,
+         _vp, _vp, _i64, _i64, _vp, _i64, _vp, _i64, _vp, _i64, _vp, _i64, _vp, _i64, _i64, _vp], _int)
     _fp = C.c_double if _suf == "f64" else C.c_float
     _SIGS[f"blr_rff_features_{_suf}"] = (
         [_H, _int, _i64, _i64, _i64, _vp, _i64, _vp, _i64, _vp, _fp, _vp, _i64], _int)
@@ -199,6 +202,15 @@ class Handle:
         if rc > 0:
             raise PosDefException(rc)
         return rc
+
+    def logpdf_grad_batched(self, dtype, memspace, layout, B, D, N, X, ldx, strideX, y, stridey, noise_kind, s, strides,
+                            prior_kind, mw, stridemw, Lw, ldl, strideLw, logpdf, dX, lddx, stridedX, dy, stridedy, ds,
+                            strideds, dmw, stridedmw, mw_post, stride_mwpost, Ainv, ldai, strideAi, info):
+        fn = getattr(self.lib, f"blr_logpdf_grad_batched_{suffix(dtype)}")
+        return self.check(fn(self._h, memspace, layout, B, D, N, _ptr(X), ldx, strideX, _ptr(y), stridey, noise_kind,
+                             _ptr(s), strides, prior_kind, _ptr(mw), stridemw, _ptr(Lw), ldl, strideLw, _ptr(logpdf),
+                             _ptr(dX), lddx, stridedX, _ptr(dy), stridedy, _ptr(ds), strideds, _ptr(dmw), stridedmw,
+                             _ptr(mw_post), stride_mwpost, _ptr(Ainv), ldai, strideAi, _ptr(info)))
 
     def marginals_batched(self, dtype, memspace, layout, B, D, N, X, ldx, strideX, noise_kind, s, strides, prior_kind,
                           mw, stridemw, Lw, ldl, strideLw, mean, stridemean, var, stridevar, info):

@@ -705,6 +705,131 @@ int marginals_batched(blr_handle* h, int memspace, int layout, int64_t B, int64_
   return 0;
 }
 
+// ---- gradient of the log marginal likelihood (D <= 128): fused posterior, then the two-sweep gradient kernel -----------
+template <typename T>
+int logpdf_grad_batched(blr_handle* h, int memspace, int layout, int64_t B, int64_t D, int64_t N, const T* X, int64_t ldx,
+                        int64_t strideX, const T* y, int64_t stridey, int noise_kind, const T* s, int64_t strides,
+                        int prior_kind, const T* mw, int64_t stridemw, const T* Lw, int64_t ldl, int64_t strideLw,
+                        double* logpdf, T* dX, int64_t lddx, int64_t stridedX, T* dy, int64_t stridedy, T* ds,
+                        int64_t strideds, T* dmw, int64_t stridedmw, T* mw_post, int64_t stride_mwpost, T* Ainv,
+                        int64_t ldai, int64_t strideAi, int32_t* info) {
+  if (!h) return -1;
+  h->err.clear();
+  if (memspace != BLR_MEM_HOST && memspace != BLR_MEM_DEVICE) return bad_arg(h, 2, "memspace");
+  if (layout != BLR_LAYOUT_COLVECS && layout != BLR_LAYOUT_ROWVECS) return bad_arg(h, 3, "unknown layout (reference :26-31)");
+  if (B < 0) return bad_arg(h, 4, "B < 0");
+  if (D < 1 || D > kMaxSmallD) return bad_arg(h, 5, "gradients are built for D <= 128 in this round");
+  if (N < 1 || N > (1 << 30)) return bad_arg(h, 6, "N out of range (>= 1)");
+  if (B == 0) return 0;
+  if (!X) return bad_arg(h, 7, "X is NULL");
+  if (layout == BLR_LAYOUT_COLVECS ? ldx < D : ldx < N) return bad_arg(h, 8, "ldx too small");
+  if (strideX < 0) return bad_arg(h, 9, "strideX < 0");
+  if (!y) return bad_arg(h, 10, "y is NULL");
+  if (noise_kind != BLR_NOISE_ISOTROPIC && noise_kind != BLR_NOISE_DIAGONAL) return bad_arg(h, 12, "noise_kind");
+  if (!s) return bad_arg(h, 13, "s is NULL");
+  if (prior_kind != BLR_PRIOR_DENSE && prior_kind != BLR_PRIOR_UPPER_FACTOR && prior_kind != BLR_PRIOR_DIAGONAL)
+    return bad_arg(h, 15, "prior_kind");
+  if (!mw) return bad_arg(h, 16, "mw is NULL");
+  if (!Lw) return bad_arg(h, 18, "Lw is NULL");
+  if (prior_kind != BLR_PRIOR_DIAGONAL && ldl < D) return bad_arg(h, 19, "ldl < D");
+  if (dX && (layout == BLR_LAYOUT_COLVECS ? lddx < D : lddx < N)) return bad_arg(h, 23, "lddx too small");
+  if (dy && B > 1 && stridedy < N) return bad_arg(h, 26, "stridedy < N");
+  if (ds && B > 1 && strideds < N) return bad_arg(h, 28, "strideds < N");
+  if (dmw && B > 1 && stridedmw < D) return bad_arg(h, 30, "stridedmw < D");
+  if (mw_post && B > 1 && stride_mwpost < D) return bad_arg(h, 32, "stride_mwpost < D");
+  if (Ainv && ldai < D) return bad_arg(h, 34, "ldai < D");
+  if (!info) return bad_arg(h, 36, "info is NULL");
+  HIP_TRY(h, hipSetDevice(h->device));
+
+  Staging guard(h);
+  PosteriorArgs<T> a{};
+  a.ldx = ldx; a.strideX = strideX; a.stridey = stridey; a.strides = strides; a.stridemw = stridemw;
+  a.ldl = ldl; a.strideLw = strideLw;
+  a.layout = layout; a.noise_kind = noise_kind; a.prior_kind = prior_kind;
+  a.D = (int)D; a.N = (int)N; a.B = (int)B;
+  GradArgs<T> g{};
+  const size_t x_one = layout == BLR_LAYOUT_COLVECS ? mat_extent(D, N, ldx) : mat_extent(N, D, ldx);
+  const size_t dx_one = layout == BLR_LAYOUT_COLVECS ? mat_extent(D, N, lddx) : mat_extent(N, D, lddx);
+  const size_t lw_one = prior_kind == BLR_PRIOR_DIAGONAL ? (size_t)D : mat_extent(D, D, ldl);
+  const size_t s_one = noise_kind == BLR_NOISE_DIAGONAL ? (size_t)N : 1;
+  int rc;
+  T *dX_d = dX, *dy_d = dy, *ds_d = ds, *dmw_d = dmw, *mwp_d = mw_post, *Ai_d = Ainv;
+  double* lp_d = logpdf;
+  int32_t* info_d = info;
+  if (memspace == BLR_MEM_HOST) {
+    if ((rc = stage_in(h, X, extent(B, strideX, x_one), &a.X))) return rc;
+    if ((rc = stage_in(h, y, extent(B, stridey, (size_t)N), &a.y))) return rc;
+    if ((rc = stage_in(h, s, extent(B, strides, s_one), &a.s))) return rc;
+    if ((rc = stage_in(h, mw, extent(B, stridemw, (size_t)D), &a.mw))) return rc;
+    if ((rc = stage_in(h, Lw, extent(B, strideLw, lw_one), &a.Lw))) return rc;
+    if ((rc = stage_out_alloc(h, dX, extent(B, stridedX, dx_one), &dX_d))) return rc;
+    if ((rc = stage_out_alloc(h, dy, extent(B, stridedy, (size_t)N), &dy_d))) return rc;
+    if ((rc = stage_out_alloc(h, ds, extent(B, strideds, (size_t)N), &ds_d))) return rc;
+    if ((rc = stage_out_alloc(h, dmw, extent(B, stridedmw, (size_t)D), &dmw_d))) return rc;
+    if ((rc = stage_out_alloc(h, mw_post, extent(B, stride_mwpost, (size_t)D), &mwp_d))) return rc;
+    if ((rc = stage_out_alloc(h, Ainv, extent(B, strideAi, mat_extent(D, D, ldai)), &Ai_d))) return rc;
+    if ((rc = stage_out_alloc(h, logpdf, (size_t)B, &lp_d))) return rc;
+    if ((rc = stage_out_alloc(h, info, (size_t)B, &info_d))) return rc;
+  } else {
+    a.X = X; a.y = y; a.s = s; a.mw = mw; a.Lw = Lw;
+  }
+  // workspace: factor T [B][D x D], posterior mean (if the caller does not want it), dmw partials
+  using TC = TrsmCfg<T>;
+  const int64_t ntiles = (N + TC::RB - 1) / TC::RB + (Ainv ? (D + TC::RB - 1) / TC::RB : 0);
+  const int64_t per_reg = std::max<int64_t>(1, std::min<int64_t>(ntiles, (512 + B - 1) / B));
+  size_t off = 0;
+  auto carve = [&](size_t bytes) { size_t o = off; off = (off + bytes + 255) & ~(size_t)255; return o; };
+  const size_t o_T = carve((size_t)B * D * D * sizeof(T));
+  const size_t o_mp = carve(mwp_d ? 0 : (size_t)B * D * sizeof(T));
+  const size_t o_part = carve(dmw_d ? (size_t)B * per_reg * kPB * sizeof(double) : 0);
+  if ((rc = ensure_ws(h, off))) return rc;
+  T* Tf = reinterpret_cast<T*>(h->ws + o_T);
+  int64_t smp = stride_mwpost;
+  if (!mwp_d) { mwp_d = reinterpret_cast<T*>(h->ws + o_mp); smp = D; }
+  double* part = dmw_d ? reinterpret_cast<double*>(h->ws + o_part) : nullptr;
+
+  a.mw_post = mwp_d; a.stride_mwpost = smp;
+  a.T_post = Tf; a.ldt = D; a.strideT = D * D;
+  a.Lw_post = nullptr; a.ldlp = D; a.strideLp = 0;
+  a.logpdf = lp_d; a.info = info_d;
+  a.vec_ok = (layout == BLR_LAYOUT_COLVECS && D % Mfma<T>::VEC == 0 && aligned16(a.X, ldx, strideX)) ? 1 : 0;
+  if ((rc = dispatch_posterior<T>(h, a))) return rc;
+
+  g.X = a.X; g.ldx = ldx; g.strideX = strideX; g.y = a.y; g.stridey = stridey; g.s = a.s; g.strides = strides;
+  g.mwp = mwp_d; g.stridemwp = smp; g.U = Tf; g.ldu = D; g.strideU = D * D;
+  g.dX = dX_d; g.lddx = lddx; g.stridedX = stridedX; g.dy = dy_d; g.stridedy = stridedy; g.ds = ds_d; g.strideds = strideds;
+  g.dmw_part = part; g.Ainv = Ai_d; g.ldai = ldai; g.strideAi = strideAi; g.info = info_d;
+  g.layout = layout; g.noise_kind = noise_kind; g.D = (int)D; g.N = (int)N; g.B = (int)B;
+  {
+    auto kern = logpdf_grad_kernel<T>;
+    const int lds = TC::LDS_BYTES + (kPB + 3 * TC::RB) * (int)sizeof(T);
+    HIP_TRY(h, hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, lds));
+    hipLaunchKernelGGL(kern, dim3((unsigned)per_reg, (unsigned)B), dim3(kThreads), lds, h->stream, g);
+    if (dmw_d)
+      hipLaunchKernelGGL(grad_reduce_kernel<T>, dim3((unsigned)B), dim3(kPB), 0, h->stream, (const double*)part, (int)per_reg,
+                         dmw_d, stridedmw, (int)D);
+  }
+  HIP_TRY(h, hipGetLastError());
+  if (memspace == BLR_MEM_HOST) {
+    auto back = [&](void* dst, const void* src, size_t bytes) -> int {
+      if (dst && bytes) HIP_TRY(h, hipMemcpyAsync(dst, src, bytes, hipMemcpyDeviceToHost, h->stream));
+      return 0;
+    };
+    if ((rc = back(dX, dX_d, extent(B, stridedX, dx_one) * sizeof(T)))) return rc;
+    if ((rc = back(dy, dy_d, extent(B, stridedy, (size_t)N) * sizeof(T)))) return rc;
+    if ((rc = back(ds, ds_d, extent(B, strideds, (size_t)N) * sizeof(T)))) return rc;
+    if ((rc = back(dmw, dmw_d, extent(B, stridedmw, (size_t)D) * sizeof(T)))) return rc;
+    if ((rc = back(mw_post, mwp_d, extent(B, stride_mwpost, (size_t)D) * sizeof(T)))) return rc;
+    if ((rc = back(Ainv, Ai_d, extent(B, strideAi, mat_extent(D, D, ldai)) * sizeof(T)))) return rc;
+    if ((rc = back(logpdf, lp_d, (size_t)B * sizeof(double)))) return rc;
+    if ((rc = back(info, info_d, (size_t)B * sizeof(int32_t)))) return rc;
+    HIP_TRY(h, hipStreamSynchronize(h->stream));
+  } else if (!h->async) {
+    HIP_TRY(h, hipStreamSynchronize(h->stream));
+  }
+  return 0;
+}
+
 // D > 128: W[:, s] = mw + U^-1 Z[:, s] with U = chol(Lw).U -- the wavefront back substitution of the posterior path with
 // one grid column per draw (reference :46-52).  All pointers are device pointers.
 template <typename T>
@@ -1178,6 +1303,18 @@ int blr_timer_stop(blr_handle* h, float* elapsed_ms) {
                              int64_t ldxin, const T* Omega, int64_t ldo, const T* phase, T scale, T* Phi,           \
                              int64_t ldphi) {                                                                       \
     return rff_features<T>(h, memspace, Din, D, N, Xin, ldxin, Omega, ldo, phase, scale, Phi, ldphi);               \
+  }                                                                                                                 \
+  int blr_logpdf_grad_batched_##SUF(blr_handle* h, int memspace, int layout, int64_t B, int64_t D, int64_t N,      \
+                                    const T* X, int64_t ldx, int64_t strideX, const T* y, int64_t stridey,          \
+                                    int noise_kind, const T* s, int64_t strides, int prior_kind, const T* mw,       \
+                                    int64_t stridemw, const T* Lw, int64_t ldl, int64_t strideLw, double* logpdf,   \
+                                    T* dX, int64_t lddx, int64_t stridedX, T* dy, int64_t stridedy, T* ds,          \
+                                    int64_t strideds, T* dmw, int64_t stridedmw, T* mw_post, int64_t stride_mwpost, \
+                                    T* Ainv, int64_t ldai, int64_t strideAi, int32_t* info) {                       \
+    return logpdf_grad_batched<T>(h, memspace, layout, B, D, N, X, ldx, strideX, y, stridey, noise_kind, s, strides, \
+                                  prior_kind, mw, stridemw, Lw, ldl, strideLw, logpdf, dX, lddx, stridedX, dy,       \
+                                  stridedy, ds, strideds, dmw, stridedmw, mw_post, stride_mwpost, Ainv, ldai,        \
+                                  strideAi, info);                                                                  \
   }                                                                                                                 \
   int blr_posterior_rff_##SUF(blr_handle* h, int memspace, int64_t Din, int64_t D, int64_t N, const T* Xin,         \
                               int64_t ldxin, const T* Omega, int64_t ldo, const T* phase, T scale, const T* y,      \

@@ -750,6 +750,67 @@ __device__ __forceinline__ void trsm_sweep(T* __restrict__ Xs, const T* __restri
   __syncthreads();
 }
 
+// X <- X L^-1 (the OTHER triangular solve: G L = Z), same conventions as trsm_sweep; chunks from the last to the first:
+// G_J = (Z_J - sum_{K>J} G_K L_KJ) inv(L_JJ).  With trsm_sweep before it this applies A^-1 = L^-T L^-1 to every row.
+template <typename T>
+__device__ __forceinline__ void trsm_sweep_back(T* __restrict__ Xs, const T* __restrict__ P, const T* __restrict__ Linv, int nchunks,
+                                                int lane, int wave) {
+  using Cfg = TrsmCfg<T>;
+  using acc4 = typename Mfma<T>::acc4;
+  constexpr int NT = Cfg::RB / 64;
+  constexpr int LI = Cfg::LDI;
+  const int fr = lane & 15, fq = lane >> 4;
+  for (int J = nchunks - 1; J >= 0; --J) {
+    acc4 acc[NT];
+#pragma unroll
+    for (int t = 0; t < NT; ++t)
+#pragma unroll
+      for (int v = 0; v < 4; ++v)
+        acc[t][v] = Xs[(16 * (wave + kWaves * t) + Mfma<T>::crow(lane, v)) * Cfg::LDX + 16 * J + (lane & 15)];
+    for (int K = J + 1; K < nchunks; ++K) {
+      T fl[4], fx[NT][4];
+#pragma unroll
+      for (int ks = 0; ks < 4; ++ks) {
+        fl[ks] = P[pidx(16 * K + 4 * ks + fq, 16 * J + fr)];  // B[k][j] = L[16K + k][16J + j]
+#pragma unroll
+        for (int t = 0; t < NT; ++t) fx[t][ks] = Xs[(16 * (wave + kWaves * t) + fr) * Cfg::LDX + 16 * K + 4 * ks + fq];
+      }
+#pragma unroll
+      for (int ks = 0; ks < 4; ++ks)
+#pragma unroll
+        for (int t = 0; t < NT; ++t) acc[t] = Mfma<T>::mma(-fx[t][ks], fl[ks], acc[t]);
+    }
+#pragma unroll
+    for (int t = 0; t < NT; ++t)
+#pragma unroll
+      for (int v = 0; v < 4; ++v)
+        Xs[(16 * (wave + kWaves * t) + Mfma<T>::crow(lane, v)) * Cfg::LDX + 16 * J + (lane & 15)] = acc[t][v];
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    acc4 o[NT];
+#pragma unroll
+    for (int t = 0; t < NT; ++t) o[t] = acc4{T(0), T(0), T(0), T(0)};
+#pragma unroll
+    for (int ks = 0; ks < 4; ++ks) {
+      const T fi = Linv[(16 * J + 4 * ks + fq) * LI + fr];  // B[k][j] = inv(L_JJ)[k][j]
+#pragma unroll
+      for (int t = 0; t < NT; ++t) {
+        const T fu = Xs[(16 * (wave + kWaves * t) + fr) * Cfg::LDX + 16 * J + 4 * ks + fq];
+        o[t] = Mfma<T>::mma(fu, fi, o[t]);
+      }
+    }
+    __builtin_amdgcn_wave_barrier();
+#pragma unroll
+    for (int t = 0; t < NT; ++t)
+#pragma unroll
+      for (int v = 0; v < 4; ++v)
+        Xs[(16 * (wave + kWaves * t) + Mfma<T>::crow(lane, v)) * Cfg::LDX + 16 * J + (lane & 15)] = o[t][v];
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+  }
+  __syncthreads();
+}
+
 template <typename T>
 __device__ __forceinline__ void trsm_core(T* __restrict__ Xs, const T* __restrict__ P, const T* __restrict__ dinv,
                                           T* __restrict__ Linv, int nchunks, int tid, int lane, int wave) {
@@ -1402,6 +1463,188 @@ __global__ __launch_bounds__(kThreads) void marginals_mfma_kernel(MarginalArgs<T
       }
     }
   }
+}
+
+// ---- gradient of the log marginal likelihood for D <= 128 --------------------------------------
+// The reverse-mode rule of logpdf(fx, y) (reference :55-58), which AD of the reference produces and a drop-in behind a
+// ccall has to supply itself.  With S = diag(1/s), A = Lw + X S X' = L L', mw' the posterior mean, r = y - X'mw':
+//     dL/dy = -S r,   dL/dmw = X S r,   dL/dX = (mw' r' - A^-1 X) S,   dL/ds_n = -(s_n - r_n^2 - |L^-1 x_n|^2) / (2 s_n^2),
+//     dL/dLw = -(m m' + A^-1 - Lw^-1) / 2   (assembled by the caller from A^-1 and m = mw' - mw; D x D host work).
+// Same tile loop as marginals_mfma_kernel: the inputs of a tile are the ROWS of an LDS block; sweep 1 (X L^-T) gives the
+// quadratic forms, sweep 2 (X L^-1 on top of it) gives A^-1 x_n for all of them -- two MFMA sweeps per tile, no extra pass
+// over X.  A^-1 itself falls out of the same two sweeps applied to the rows of the identity (pseudo tiles).
+// dmw is reduced per workgroup in a fixed order and summed by grad_reduce_kernel (deterministic).
+template <typename T>
+struct GradArgs {
+  const T* X; int64_t ldx, strideX;
+  const T* y; int64_t stridey;
+  const T* s; int64_t strides;
+  const T* mwp; int64_t stridemwp;       // posterior mean
+  const T* U; int64_t ldu, strideU;      // upper factor T = chol(A).U
+  T* dX; int64_t lddx, stridedX;
+  T* dy; int64_t stridedy;
+  T* ds; int64_t strideds;
+  double* dmw_part;                      // [B][gridDim.x][128]
+  T* Ainv; int64_t ldai, strideAi;
+  const int32_t* info;
+  int layout, noise_kind;
+  int D, N, B;
+};
+
+template <typename T>
+__global__ __launch_bounds__(kThreads) void logpdf_grad_kernel(GradArgs<T> a) {
+  using Cfg = TrsmCfg<T>;
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  T* const P = reinterpret_cast<T*>(smem);
+  T* const Xs = reinterpret_cast<T*>(smem + Cfg::OFF_X);
+  T* const dinv = reinterpret_cast<T*>(smem + Cfg::OFF_DI);
+  T* const Linv = reinterpret_cast<T*>(smem + Cfg::OFF_LI);
+  T* const mwl = reinterpret_cast<T*>(smem + Cfg::LDS_BYTES);  // [128] posterior mean
+  T* const wrv = mwl + kPB;                                     // [RB] w_n r_n
+  T* const rvv = wrv + Cfg::RB;                                 // [RB] r_n
+  T* const wvv = rvv + Cfg::RB;                                 // [RB] w_n
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = uni(tid >> 6);
+  const int D = a.D, N = a.N;
+  const int reg = blockIdx.y;
+  const int nchunks = (D + 15) >> 4, DPc = nchunks * 16;
+  double dmw_acc = 0.0;  // thread c < 128: sum over this workgroup's tiles of x_cn w_n r_n
+  const bool ok = !(a.info && a.info[reg] != 0);
+  if (ok) {
+    const T* X = a.X + (int64_t)reg * a.strideX;
+    const T* U = a.U + (int64_t)reg * a.strideU;
+    const T* s = a.s + (int64_t)reg * a.strides;
+    const T* y = a.y + (int64_t)reg * a.stridey;
+    const T* mwp = a.mwp + (int64_t)reg * a.stridemwp;
+    const int ntiles = (N + Cfg::RB - 1) / Cfg::RB;
+    const int npseudo = a.Ainv ? (DPc + Cfg::RB - 1) / Cfg::RB : 0;
+    // ---- once per workgroup: L = U' packed (padding: unit diagonal), reciprocal pivots, inverse blocks, mw'
+#pragma unroll 1
+    for (int base = 0; base < DPc * DPc; base += kThreads * 8) {
+      T v[8];
+#pragma unroll
+      for (int u = 0; u < 8; ++u) {
+        const int idx = base + u * kThreads + tid;
+        const int r = idx / DPc, c = idx % DPc;
+        const bool in = idx < DPc * DPc && c <= r && r < D;
+        v[u] = U[in ? (int64_t)r * a.ldu + c : 0];
+      }
+#pragma unroll
+      for (int u = 0; u < 8; ++u) {
+        const int idx = base + u * kThreads + tid;
+        const int r = idx / DPc, c = idx % DPc;
+        if (idx < DPc * DPc && c <= r) P[pidx(r, c)] = (r < D) ? v[u] : (r == c ? T(1) : T(0));
+      }
+    }
+    if (tid < kPB) mwl[tid] = (tid < D) ? mwp[tid] : T(0);
+    __syncthreads();
+    if (tid < DPc) dinv[tid] = T(1) / P[pidx(tid, tid)];
+    __syncthreads();
+    trsm_prepare<T>(P, dinv, Linv, nchunks, tid);
+
+    for (int tile = blockIdx.x; tile < ntiles + npseudo; tile += gridDim.x) {
+      const bool pseudo = tile >= ntiles;
+      const int n0 = pseudo ? (tile - ntiles) * Cfg::RB : tile * Cfg::RB;  // pseudo: first identity row
+      const int nt = pseudo ? min(Cfg::RB, DPc - n0) : min(Cfg::RB, N - n0);
+      __syncthreads();  // the previous tile's readers of Xs are done
+#pragma unroll 1
+      for (int base = 0; base < Cfg::RB * DPc; base += kThreads * 8) {
+        T v[8];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) {
+          const int idx = base + u * kThreads + tid;
+          int r, c;
+          if (a.layout == LAYOUT_COLVECS) { c = idx % DPc; r = idx / DPc; }
+          else                            { r = idx % Cfg::RB; c = idx / Cfg::RB; }
+          const bool in = !pseudo && idx < Cfg::RB * DPc && r < nt && c < D;
+          const int64_t addr = (a.layout == LAYOUT_COLVECS) ? (int64_t)(n0 + r) * a.ldx + c : (int64_t)c * a.ldx + n0 + r;
+          v[u] = X[in ? addr : 0];
+        }
+#pragma unroll
+        for (int u = 0; u < 8; ++u) {
+          const int idx = base + u * kThreads + tid;
+          int r, c;
+          if (a.layout == LAYOUT_COLVECS) { c = idx % DPc; r = idx / DPc; }
+          else                            { r = idx % Cfg::RB; c = idx / Cfg::RB; }
+          if (idx < Cfg::RB * DPc) {
+            T val = (r < nt && c < D) ? v[u] : T(0);
+            if (pseudo) val = (r < nt && n0 + r == c) ? T(1) : T(0);
+            Xs[r * Cfg::LDX + c] = val;
+          }
+        }
+      }
+      __syncthreads();
+      T rr = T(0), w = T(0), sv = T(1);
+      if (!pseudo) {
+        if (tid < Cfg::RB) {
+          if (tid < nt) {
+            const T* xr = Xs + tid * Cfg::LDX;
+            T m0 = T(0), m1 = T(0);
+            for (int c = 0; c + 1 < DPc; c += 2) { m0 += xr[c] * mwl[c]; m1 += xr[c + 1] * mwl[c + 1]; }
+            sv = (a.noise_kind == NOISE_DIAGONAL) ? s[n0 + tid] : s[0];
+            w = T(1) / sv;
+            rr = y[n0 + tid] - (m0 + m1);  // posterior residual
+          }
+          wrv[tid] = w * rr;
+          rvv[tid] = rr;
+          wvv[tid] = w;
+        }
+        __syncthreads();
+        if (tid < kPB) {  // dmw_c += sum_n x_cn w_n r_n over the tile (fixed order)
+          double acc = 0.0;
+          for (int r = 0; r < Cfg::RB; ++r) acc += (double)Xs[r * Cfg::LDX + tid] * (double)wrv[r];
+          dmw_acc += acc;
+        }
+      }
+      __syncthreads();
+      trsm_sweep<T>(Xs, P, Linv, nchunks, lane, wave);       // rows z_n' = x_n' L^-T
+      T vq = T(0);
+      if (!pseudo && tid < nt) {
+        const T* xr = Xs + tid * Cfg::LDX;
+        T v0 = T(0), v1 = T(0);
+        for (int c = 0; c + 1 < DPc; c += 2) { v0 += xr[c] * xr[c]; v1 += xr[c + 1] * xr[c + 1]; }
+        vq = v0 + v1;  // x_n' A^-1 x_n
+      }
+      __syncthreads();
+      trsm_sweep_back<T>(Xs, P, Linv, nchunks, lane, wave);  // rows g_n' = x_n' A^-1
+      if (pseudo) {
+        T* Ai = a.Ainv + (int64_t)reg * a.strideAi;
+        for (int idx = tid; idx < Cfg::RB * DPc; idx += kThreads) {
+          const int r = idx % Cfg::RB, c = idx / Cfg::RB;  // consecutive threads -> consecutive rows of a column
+          if (r < nt && n0 + r < D && c < D) Ai[(int64_t)c * a.ldai + n0 + r] = Xs[r * Cfg::LDX + c];
+        }
+      } else {
+        if (tid < nt) {
+          if (a.dy) a.dy[(int64_t)reg * a.stridedy + n0 + tid] = -w * rr;
+          if (a.ds) a.ds[(int64_t)reg * a.strideds + n0 + tid] = -(sv - rr * rr - vq) / (T(2) * sv * sv);
+        }
+        if (a.dX) {
+          T* dXr = a.dX + (int64_t)reg * a.stridedX;
+          for (int idx = tid; idx < Cfg::RB * DPc; idx += kThreads) {
+            int r, c;
+            if (a.layout == LAYOUT_COLVECS) { c = idx % DPc; r = idx / DPc; }
+            else                            { r = idx % Cfg::RB; c = idx / Cfg::RB; }
+            if (r < nt && c < D) {
+              const T val = wvv[r] * (rvv[r] * mwl[c] - Xs[r * Cfg::LDX + c]);
+              const int64_t addr = (a.layout == LAYOUT_COLVECS) ? (int64_t)(n0 + r) * a.lddx + c : (int64_t)c * a.lddx + n0 + r;
+              dXr[addr] = val;
+            }
+          }
+        }
+      }
+    }
+  }
+  if (a.dmw_part && tid < kPB) a.dmw_part[((int64_t)reg * gridDim.x + blockIdx.x) * kPB + tid] = dmw_acc;
+}
+
+// dmw[reg][c] = sum over the workgroup partials, fixed order
+template <typename T>
+__global__ __launch_bounds__(kPB) void grad_reduce_kernel(const double* part, int nparts, T* dmw, int64_t stridedmw, int D) {
+  const int reg = blockIdx.x, c = threadIdx.x;
+  if (c >= D) return;
+  double acc = 0.0;
+  for (int g = 0; g < nparts; ++g) acc += part[((int64_t)reg * nparts + g) * kPB + c];
+  dmw[(int64_t)reg * stridedmw + c] = (T)acc;
 }
 
 }  // namespace blr

@@ -393,6 +393,62 @@ def logpdf_columns(fx, Y):
     return lp
 
 
+def logpdf_and_gradient(fx, y):
+    """The value of logpdf(fx, y) (reference :55-58) and its gradient with respect to every input of the path -- the
+    reverse-mode rule the reference gets from Zygote through its Julia code (README.md:56-71) and a ccall-backed logpdf
+    must provide itself.  D <= 128 in this build.
+
+    Returns ``(lp, grads)`` with ``grads`` a dict: ``X`` (same container layout as the inputs: D x N for ColVecs / a
+    matrix, N x D for RowVecs), ``y`` (N), ``noise`` (N for Diagonal noise, a scalar for isotropic noise), ``mw`` (D)
+    and ``Lw`` -- the gradient with respect to the precision: symmetric D x D for a dense / Symmetric / PDMat prior
+    (for PDMat(U) chain with dU = U (G + G')), the diagonal (D) for a Diagonal prior."""
+    fx = _to_finite_blr(fx)
+    blr = fx.f
+    dtype = _dtype_of(blr.mw, y)
+    X, layout, ldx, D, N = _x_layout(fx.x, dtype)
+    y = np.ascontiguousarray(y, dtype=dtype)
+    if y.ndim != 1 or y.shape[0] != N:
+        raise ValueError("length(y) != size(fx.x.X, 2)")  # reference :74
+    mw = np.ascontiguousarray(blr.mw, dtype=dtype)
+    s, noise_kind = _noise(fx.Sy, N, dtype)
+    Lw, prior_kind, ldl = _prior(blr.Lw, D, dtype)
+    lp = np.zeros(1, dtype=np.float64)
+    info = np.zeros(1, dtype=np.int32)
+    dX = np.empty_like(X)  # same memory order and leading dimension as the staged inputs
+    dy = np.empty(N, dtype=dtype)
+    ds = np.empty(N, dtype=dtype)
+    dmw = np.empty(D, dtype=dtype)
+    mw_post = np.empty(D, dtype=dtype)
+    Ainv = np.empty((D, D), dtype=dtype, order="F")
+    _handle().logpdf_grad_batched(dtype, _abi.MEM_HOST, layout, 1, D, N, X, ldx, 0, y, 0, noise_kind, s, 0, prior_kind, mw, 0,
+                                  Lw, ldl, 0, lp, dX, ldx, 0, dy, 0, ds, 0, dmw, 0, mw_post, 0, Ainv, D, 0, info)
+    if info[0] != 0:
+        raise _abi.PosDefException(int(info[0]))
+    # dL/dLw = -(m m' + A^-1 - Lw^-1) / 2: D x D host work on the device's A^-1 and posterior mean
+    m = (mw_post - mw).astype(np.float64)
+    Ai = np.asarray(Ainv, dtype=np.float64)
+    Ai = np.tril(Ai) + np.tril(Ai, -1).T  # symmetric by construction; use one triangle
+    if prior_kind == _abi.PRIOR_DIAGONAL:
+        gL = -0.5 * (m * m + np.diag(Ai) - 1.0 / np.asarray(Lw, dtype=np.float64))
+    else:
+        if prior_kind == _abi.PRIOR_UPPER_FACTOR:
+            U = np.triu(np.asarray(Lw, dtype=np.float64))
+            Lw_dense = U.T @ U
+        else:
+            A0 = np.asarray(Lw, dtype=np.float64)
+            Lw_dense = np.triu(A0) + np.triu(A0, 1).T
+        gL = -0.5 * (np.outer(m, m) + Ai - np.linalg.inv(Lw_dense))
+    # hand dX back in the caller's container orientation
+    x = fx.x
+    if isinstance(x, RowVecs):
+        gX = dX if dX.shape == (N, D) else dX.T
+    else:
+        gX = dX if dX.shape == (D, N) else dX.T
+    grads = {"X": np.asarray(gX), "y": dy, "noise": ds if noise_kind == _abi.NOISE_DIAGONAL else dtype(ds.sum(dtype=np.float64)),
+             "mw": dmw, "Lw": gL.astype(dtype)}
+    return float(lp[0]), grads
+
+
 def posterior(fx, y):
     """reference :60-69 (and basis_function_regression.jl:62-65): same wrapper type as the prior."""
     _, mw_post, T, A = _fused(fx, y, want_posterior=True)

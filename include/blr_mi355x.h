@@ -192,6 +192,32 @@ int blr_posterior_rff_f32(blr_handle* h, int memspace, int64_t Din, int64_t D, i
                           float* mw_post, float* T_post, int64_t ldt, float* Lw_post, int64_t ldlp,
                           double* logpdf, int32_t* info);
 
+/* ---- gradient of the log marginal likelihood (D <= 128 in this build) ------
+ * The reverse-mode rule of logpdf(fx, y) (reference src/bayesian_linear_regression.jl:55-58): what Zygote derives from
+ * the reference's Julia code (README.md:56-71, examples/nn-blr.jl:35-37) and a ccall-backed logpdf has to supply
+ * itself (a ChainRules rrule in the shim).  One call = fused posterior + two MFMA sweeps per tile of inputs.
+ *   logpdf[B]            the value itself
+ *   dX                   dL/dX, SAME layout as X (lddx, stridedX)
+ *   dy[N], ds[N]         dL/dy_n; dL/ds_n per observation (isotropic noise: the scalar gradient is their sum)
+ *   dmw[D]               dL/dmw
+ *   mw_post[D], Ainv     posterior mean and A^-1 = (Lw + X S X')^-1 (D x D, ldai): the caller forms
+ *                        dL/dLw = -(m m' + Ainv - Lw^-1)/2 with m = mw_post - mw (D x D host work)
+ * Any output except logpdf/info may be NULL.  Arguments up to strideLw are those of blr_posterior_batched_*. */
+int blr_logpdf_grad_batched_f64(blr_handle* h, int memspace, int layout, int64_t B, int64_t D, int64_t N,
+                                const double* X, int64_t ldx, int64_t strideX, const double* y, int64_t stridey,
+                                int noise_kind, const double* s, int64_t strides, int prior_kind, const double* mw,
+                                int64_t stridemw, const double* Lw, int64_t ldl, int64_t strideLw, double* logpdf,
+                                double* dX, int64_t lddx, int64_t stridedX, double* dy, int64_t stridedy, double* ds,
+                                int64_t strideds, double* dmw, int64_t stridedmw, double* mw_post,
+                                int64_t stride_mwpost, double* Ainv, int64_t ldai, int64_t strideAi, int32_t* info);
+int blr_logpdf_grad_batched_f32(blr_handle* h, int memspace, int layout, int64_t B, int64_t D, int64_t N,
+                                const float* X, int64_t ldx, int64_t strideX, const float* y, int64_t stridey,
+                                int noise_kind, const float* s, int64_t strides, int prior_kind, const float* mw,
+                                int64_t stridemw, const float* Lw, int64_t ldl, int64_t strideLw, double* logpdf,
+                                float* dX, int64_t lddx, int64_t stridedX, float* dy, int64_t stridedy, float* ds,
+                                int64_t strideds, float* dmw, int64_t stridedmw, float* mw_post,
+                                int64_t stride_mwpost, float* Ainv, int64_t ldai, int64_t strideAi, int32_t* info);
+
 /* ---- sharded log-evidence: fixed-order sum of logpdf[B] on the device ----------
  * Deterministic (no float atomics): the same bits for the same B regardless of launch geometry.
  * The cross-rank step is one RCCL all-gather of these per-rank partials done by the host framework

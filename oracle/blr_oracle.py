@@ -265,6 +265,38 @@ def posterior_logpdf_direct(mw, Lw, X, Sy, y, prior_factor=None):
     return mw + m, T, A, lp
 
 
+def logpdf_grad(mw, Lw, X, Sy, y):
+    """Closed-form gradient of the log marginal likelihood logpdf(fx, y) (reference :55-58) with respect to every input of
+    the path: what reverse-mode AD of the reference (the Zygote use of README.md:56-71) yields.
+    With S = diag(1/s), A = Lw + X S X', mw' the posterior mean, r = y - X'mw' (posterior residual):
+        dL/dy  = -S r                dL/dmw = X S r
+        dL/dX  = (mw' r' - A^-1 X) S                      (D x N)
+        dL/ds_n = -(s_n - r_n^2 - x_n'A^-1 x_n) / (2 s_n^2)
+        dL/dLw = -(m m' + A^-1 - Lw^-1) / 2,  m = mw' - mw   (symmetric D x D)
+    Returns (logpdf, dict)."""
+    D, N = X.shape
+    s = _noise_diag(Sy, N, X.dtype)
+    Lw_d = dense_precision(Lw, D, X.dtype)
+    mw_p, T, A, lp = posterior_logpdf_direct(mw, Lw_d, X, s, y)
+    r = y - X.T @ mw_p
+    w = 1.0 / s
+    Z = _solve_tri(T, X, trans=True)        # L^-1 X
+    G = _solve_tri(T, Z, trans=False)       # A^-1 X
+    v = np.sum(Z * Z, axis=0)
+    Ainv = _solve_tri(T, _solve_tri(T, np.eye(D, dtype=X.dtype), trans=True), trans=False)
+    m = mw_p - mw
+    grads = dict(
+        y=-w * r,
+        mw=X @ (w * r),
+        X=(np.outer(mw_p, r) - G) * w[None, :],
+        s=-(s - r * r - v) / (2.0 * s * s),
+        Lw=-0.5 * (np.outer(m, m) + Ainv - np.linalg.inv(Lw_d)),
+        Ainv=Ainv,
+        mw_post=mw_p,
+    )
+    return lp, grads
+
+
 def marginals_direct(mw, U, X, Sy):
     """mean_n = x_n' mw, var_n = |U^-T x_n|^2 + Sy_nn, given the upper factor U of the precision."""
     D, N = X.shape

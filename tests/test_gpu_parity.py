@@ -784,3 +784,78 @@ def test_large_d_many_draws_wavefront_oversubscribed(B, dtype, D, S):
         W_o = np.asarray(mw, dtype=float)[:, None] + np.linalg.solve(np.asarray(U, dtype=float), np.asarray(Z, dtype=float))
         rt = 1e-10 if dtype == np.float64 else 2e-4
         np.testing.assert_allclose(W, W_o, rtol=rt, atol=rt * 10)
+
+
+# ---- gradient of the log marginal likelihood: closed form vs the oracle (itself pinned against
+# ---- finite differences of the literal op sequence in tests/test_oracle_pins.py) ------------------------------------
+@pytest.mark.parametrize("N,D", [(11, 3), (200, 17), (333, 64), (777, 128), (64, 128)])
+@pytest.mark.parametrize("noise", ["diagonal", "isotropic"])
+def test_logpdf_gradient_vs_oracle_f64(B, N, D, noise):
+    rng = _rng(9500 + N + D)
+    X, mw, Lw, s = O.generate_toy_problem(rng, N, D, dense_noise_cov=False)
+    y = rng.standard_normal(N)
+    Sy = s if noise == "diagonal" else np.float64(0.37)
+    lp_o, g_o = O.logpdf_grad(mw, Lw, X, Sy, y)
+    U = O.chol_upper(Lw)
+    dvec = np.exp(0.3 * rng.standard_normal(D))
+    for prior, Lw_arg, Lw_ref in (("dense", Lw, Lw), ("pdmat", B.PDMat(U), Lw), ("diag", B.Diagonal(dvec), np.diag(dvec))):
+        lp_r, g_r = (lp_o, g_o) if prior != "diag" else O.logpdf_grad(mw, Lw_ref, X, Sy, y)
+        f = B.BayesianLinearRegressor(mw, Lw_arg)
+        for x in (np.asfortranarray(X), B.ColVecs(np.ascontiguousarray(X)), B.RowVecs(np.ascontiguousarray(X.T)),
+                  B.RowVecs(np.asfortranarray(X.T))):
+            lp, g = B.logpdf_and_gradient(f(x, Sy if noise == "diagonal" else float(Sy)), y)
+            assert lp == pytest.approx(lp_r, rel=1e-10)
+            gX = g["X"].T if isinstance(x, B.RowVecs) else g["X"]
+            scale = np.abs(g_r["X"]).max()
+            np.testing.assert_allclose(gX, g_r["X"], rtol=1e-8, atol=1e-9 * scale)
+            np.testing.assert_allclose(g["y"], g_r["y"], rtol=1e-8, atol=1e-10)
+            np.testing.assert_allclose(g["mw"], g_r["mw"], rtol=1e-8, atol=1e-9 * np.abs(g_r["mw"]).max())
+            if noise == "diagonal":
+                np.testing.assert_allclose(g["noise"], g_r["s"], rtol=1e-8, atol=1e-9 * np.abs(g_r["s"]).max())
+            else:
+                assert float(g["noise"]) == pytest.approx(float(np.sum(g_r["s"])), rel=1e-8)
+            gL_ref = np.diag(g_r["Lw"]) if prior == "diag" else g_r["Lw"]
+            np.testing.assert_allclose(g["Lw"], gL_ref, rtol=1e-7, atol=1e-9 * np.abs(gL_ref).max())
+
+
+def test_logpdf_gradient_batched_device_f32_and_errors(B):
+    import torch
+    from blr_amd import _abi
+
+    rng = _rng(9600)
+    Bn, D, N = 5, 96, 700
+    dev = torch.device("cuda:0")
+    X = torch.tensor(rng.standard_normal((Bn, N, D)), dtype=torch.float32, device=dev)  # [N, D] row-major == D x N col-major
+    y = torch.tensor(rng.standard_normal((Bn, N)), dtype=torch.float32, device=dev)
+    s = torch.tensor(np.exp(0.3 * rng.standard_normal((Bn, N))), dtype=torch.float32, device=dev)
+    mw = torch.tensor(rng.standard_normal((Bn, D)), dtype=torch.float32, device=dev)
+    d = torch.tensor(np.exp(0.2 * rng.standard_normal((Bn, D))), dtype=torch.float32, device=dev)
+    lp = torch.zeros(Bn, dtype=torch.float64, device=dev)
+    info = torch.zeros(Bn, dtype=torch.int32, device=dev)
+    dX = torch.empty_like(X); dy = torch.empty_like(y); ds = torch.empty_like(s); dmw = torch.empty_like(mw)
+    mwp = torch.empty_like(mw); Ai = torch.empty((Bn, D, D), dtype=torch.float32, device=dev)
+    h = _abi.default_handle()
+    h.logpdf_grad_batched(np.float32, _abi.MEM_DEVICE, _abi.LAYOUT_COLVECS, Bn, D, N, X.data_ptr(), D, N * D, y.data_ptr(), N,
+                          _abi.NOISE_DIAGONAL, s.data_ptr(), N, _abi.PRIOR_DIAGONAL, mw.data_ptr(), D, d.data_ptr(), 1, D,
+                          lp.data_ptr(), dX.data_ptr(), D, N * D, dy.data_ptr(), N, ds.data_ptr(), N, dmw.data_ptr(), D,
+                          mwp.data_ptr(), D, Ai.data_ptr(), D, D * D, info.data_ptr())
+    h.synchronize()
+    assert int(info.abs().sum()) == 0
+    for b in range(Bn):
+        Xb = X[b].double().cpu().numpy().T
+        args = (mw[b].double().cpu().numpy(), np.diag(d[b].double().cpu().numpy()), Xb, s[b].double().cpu().numpy(),
+                y[b].double().cpu().numpy())
+        lp_o, g_o = O.logpdf_grad(*args)
+        assert float(lp[b]) == pytest.approx(lp_o, rel=2e-4)
+        np.testing.assert_allclose(dX[b].cpu().numpy().T, g_o["X"], rtol=2e-3, atol=2e-4 * np.abs(g_o["X"]).max())
+        np.testing.assert_allclose(dy[b].cpu().numpy(), g_o["y"], rtol=2e-3, atol=1e-4)
+        np.testing.assert_allclose(ds[b].cpu().numpy(), g_o["s"], rtol=2e-3, atol=2e-4 * np.abs(g_o["s"]).max())
+        np.testing.assert_allclose(dmw[b].cpu().numpy(), g_o["mw"], rtol=2e-3, atol=2e-4 * np.abs(g_o["mw"]).max())
+        np.testing.assert_allclose(Ai[b].cpu().numpy(), g_o["Ainv"], rtol=2e-3, atol=2e-4 * np.abs(g_o["Ainv"]).max())
+        np.testing.assert_allclose(mwp[b].cpu().numpy(), g_o["mw_post"], rtol=2e-3, atol=1e-4)
+    # a non-SPD prior raises like cholesky() in the reference; D > 128 is rejected with the argument position
+    Xs, mws, Lws, ss = O.generate_toy_problem(rng, 20, 4, dense_noise_cov=False)
+    with pytest.raises(B.PosDefException):
+        B.logpdf_and_gradient(B.BayesianLinearRegressor(mws, -Lws)(Xs, ss), rng.standard_normal(20))
+    with pytest.raises(B.BLRError):
+        B.logpdf_and_gradient(B.BayesianLinearRegressor(np.zeros(130), B.Diagonal(np.ones(130)))(np.zeros((130, 8)), 0.1), np.zeros(8))

@@ -169,3 +169,39 @@ def test_var_is_diag_cov_and_length_check():
         O.logpdf_literal(mw, Lw, X, Sy, np.zeros(10))  # :74
     with pytest.raises(np.linalg.LinAlgError):
         O.logpdf_literal(mw, -Lw, X, Sy, np.zeros(11))  # PosDefException
+
+
+def test_closed_form_gradient_matches_finite_differences():
+    """The gradient formulas the GPU path implements (oracle.logpdf_grad; SURVEY.md 8f rank 1: what AD of the reference's
+    logpdf, src/bayesian_linear_regression.jl:55-58, produces) against central differences of the LITERAL op sequence."""
+    rng = np.random.default_rng(77)
+    N, D = 13, 5
+    X, mw, Lw, s = O.generate_toy_problem(rng, N, D, dense_noise_cov=False)
+    y = rng.standard_normal(N)
+    lp, g = O.logpdf_grad(mw, Lw, X, s, y)
+    assert lp == pytest.approx(O.logpdf_literal(mw, Lw, X, s, y), rel=1e-12)
+
+    def fd(fun, x0, eps=1e-6):
+        out = np.zeros_like(x0)
+        it = np.nditer(x0, flags=["multi_index"])
+        for _ in it:
+            i = it.multi_index
+            xp, xm = x0.copy(), x0.copy()
+            xp[i] += eps
+            xm[i] -= eps
+            out[i] = (fun(xp) - fun(xm)) / (2 * eps)
+        return out
+
+    tol = dict(rtol=1e-6, atol=1e-6)  # central differences with eps = 1e-6 carry ~1e-7 of noise on O(1) values
+    np.testing.assert_allclose(g["y"], fd(lambda v: O.logpdf_literal(mw, Lw, X, s, v), y), **tol)
+    np.testing.assert_allclose(g["mw"], fd(lambda v: O.logpdf_literal(v, Lw, X, s, y), mw), **tol)
+    np.testing.assert_allclose(g["X"], fd(lambda v: O.logpdf_literal(mw, Lw, v, s, y), X), **tol)
+    np.testing.assert_allclose(g["s"], fd(lambda v: O.logpdf_literal(mw, Lw, X, v, y), s), **tol)
+    # symmetric perturbations of the precision: dL = sum_ij G_ij dLw_ij with G symmetric
+    def f_sym(v):
+        return O.logpdf_literal(mw, 0.5 * (v + v.T), X, s, y)
+    np.testing.assert_allclose(g["Lw"], fd(f_sym, Lw), rtol=1e-5, atol=1e-6)
+    # isotropic noise: the scalar gradient is the sum of the per-observation ones
+    lp2, g2 = O.logpdf_grad(mw, Lw, X, np.float64(0.3), y)
+    d_iso = (O.logpdf_literal(mw, Lw, X, np.float64(0.3 + 1e-6), y) - O.logpdf_literal(mw, Lw, X, np.float64(0.3 - 1e-6), y)) / 2e-6
+    assert np.sum(g2["s"]) == pytest.approx(d_iso, rel=1e-6)
