@@ -1494,6 +1494,8 @@ struct GradArgs {
 template <typename T>
 __global__ __launch_bounds__(kThreads) void logpdf_grad_kernel(GradArgs<T> a) {
   using Cfg = TrsmCfg<T>;
+  constexpr int VEC = Mfma<T>::VEC;
+  typedef T vecT __attribute__((ext_vector_type(Mfma<T>::VEC)));
   extern __shared__ __attribute__((aligned(16))) char smem[];
   T* const P = reinterpret_cast<T*>(smem);
   T* const Xs = reinterpret_cast<T*>(smem + Cfg::OFF_X);
@@ -1518,6 +1520,22 @@ __global__ __launch_bounds__(kThreads) void logpdf_grad_kernel(GradArgs<T> a) {
     const T* mwp = a.mwp + (int64_t)reg * a.stridemwp;
     const int ntiles = (N + Cfg::RB - 1) / Cfg::RB;
     const int npseudo = a.Ainv ? (DPc + Cfg::RB - 1) / Cfg::RB : 0;
+    // vector path (ColVecs, D = 128, 16-byte aligned columns): the next tile's inputs are in flight during this tile's sweeps
+    const bool vec = a.layout == LAYOUT_COLVECS && D == kPB && (a.ldx % VEC) == 0 && ((uintptr_t)X % 16) == 0;
+    const bool vecd = vec && a.dX && (a.lddx % VEC) == 0 && ((uintptr_t)(a.dX + (int64_t)reg * a.stridedX) % 16) == 0;
+    constexpr int VPR = kPB / VEC;
+    constexpr int NVT = Cfg::RB * kPB / (VEC * kThreads);
+    vecT pre[NVT];
+    auto prefetch = [&](int tile) {
+      const int n0p = tile * Cfg::RB;
+#pragma unroll
+      for (int u = 0; u < NVT; ++u) {
+        const int vi = u * kThreads + tid;
+        const int r = vi / VPR, c0 = (vi % VPR) * VEC;
+        pre[u] = (n0p + r < N) ? *reinterpret_cast<const vecT*>(X + (int64_t)(n0p + r) * a.ldx + c0) : vecT(T(0));
+      }
+    };
+    if (vec && (int)blockIdx.x < ntiles) prefetch(blockIdx.x);
     // ---- once per workgroup: L = U' packed (padding: unit diagonal), reciprocal pivots, inverse blocks, mw'
 #pragma unroll 1
     for (int base = 0; base < DPc * DPc; base += kThreads * 8) {
@@ -1547,6 +1565,16 @@ __global__ __launch_bounds__(kThreads) void logpdf_grad_kernel(GradArgs<T> a) {
       const int n0 = pseudo ? (tile - ntiles) * Cfg::RB : tile * Cfg::RB;  // pseudo: first identity row
       const int nt = pseudo ? min(Cfg::RB, DPc - n0) : min(Cfg::RB, N - n0);
       __syncthreads();  // the previous tile's readers of Xs are done
+      if (vec && !pseudo) {
+#pragma unroll
+        for (int u = 0; u < NVT; ++u) {
+          const int vi = u * kThreads + tid;
+          const int r = vi / VPR, c0 = (vi % VPR) * VEC;
+#pragma unroll
+          for (int e = 0; e < VEC; ++e) Xs[r * Cfg::LDX + c0 + e] = pre[u][e];
+        }
+        if (tile + (int)gridDim.x < ntiles) prefetch(tile + gridDim.x);
+      } else
 #pragma unroll 1
       for (int base = 0; base < Cfg::RB * DPc; base += kThreads * 8) {
         T v[8];
@@ -1618,7 +1646,20 @@ __global__ __launch_bounds__(kThreads) void logpdf_grad_kernel(GradArgs<T> a) {
           if (a.dy) a.dy[(int64_t)reg * a.stridedy + n0 + tid] = -w * rr;
           if (a.ds) a.ds[(int64_t)reg * a.strideds + n0 + tid] = -(sv - rr * rr - vq) / (T(2) * sv * sv);
         }
-        if (a.dX) {
+        if (vecd) {
+          T* dXr = a.dX + (int64_t)reg * a.stridedX;
+#pragma unroll 4
+          for (int u = 0; u < NVT; ++u) {
+            const int vi = u * kThreads + tid;
+            const int r = vi / VPR, c0 = (vi % VPR) * VEC;
+            if (r < nt) {
+              vecT o;
+#pragma unroll
+              for (int e = 0; e < VEC; ++e) o[e] = wvv[r] * (rvv[r] * mwl[c0 + e] - Xs[r * Cfg::LDX + c0 + e]);
+              *reinterpret_cast<vecT*>(dXr + (int64_t)(n0 + r) * a.lddx + c0) = o;
+            }
+          }
+        } else if (a.dX) {
           T* dXr = a.dX + (int64_t)reg * a.stridedX;
           for (int idx = tid; idx < Cfg::RB * DPc; idx += kThreads) {
             int r, c;
