@@ -261,4 +261,40 @@ function fused_rff(blr::BayesianLinearRegressor, ϕ::RandomFourierFeatures{T}, x
     return lp[], mw′, Tm, A
 end
 
+# ---- value + gradient of the log marginal likelihood (the rule behind the ccall; SURVEY.md 8f rank 1) ---------------
+# Returns (lp, dX, dy, ds, dmw, mw_post, Ainv); see INTEGRATION.md for the ChainRules rrule built on it.  D <= 128.
+function logpdf_grad(fb, y::AbstractVector{<:Real})
+    xl, nz, pr = xlayout(fb.x), noise(fb.Σy), prior(fb.f.Λw)
+    (xl === nothing || nz === nothing || pr === nothing) && error("logpdf_grad: input types outside the device path")
+    X, layout, ldx, D, N = xl
+    T = eltype(X)
+    s, nk = nz
+    Lw, pk, ldl = pr
+    yv = convert(Vector{T}, y); mw = convert(Vector{T}, fb.f.mw)
+    dX = similar(X); dy = Vector{T}(undef, N); ds = Vector{T}(undef, N); dmw = Vector{T}(undef, D)
+    mw′ = Vector{T}(undef, D); Ai = Matrix{T}(undef, D, D)
+    lp = Ref{Cdouble}(0.0); info = Ref{Int32}(0)
+    h = handle()
+    rc = GC.@preserve X yv s Lw mw dX dy ds dmw mw′ Ai begin
+        if T === Float64
+            ccall((:blr_logpdf_grad_batched_f64, LIB), Cint,
+                  (Ptr{Cvoid}, Cint, Cint, Int64, Int64, Int64, Ptr{T}, Int64, Int64, Ptr{T}, Int64, Cint, Ptr{T}, Int64, Cint,
+                   Ptr{T}, Int64, Ptr{T}, Int64, Int64, Ref{Cdouble}, Ptr{T}, Int64, Int64, Ptr{T}, Int64, Ptr{T}, Int64,
+                   Ptr{T}, Int64, Ptr{T}, Int64, Ptr{T}, Int64, Int64, Ref{Int32}),
+                  h, MEM_HOST, layout, 1, D, N, X, ldx, 0, yv, 0, nk, s, 0, pk, mw, 0, Lw, ldl, 0, lp, dX, ldx, 0, dy, 0, ds, 0,
+                  dmw, 0, mw′, 0, Ai, D, 0, info)
+        else
+            ccall((:blr_logpdf_grad_batched_f32, LIB), Cint,
+                  (Ptr{Cvoid}, Cint, Cint, Int64, Int64, Int64, Ptr{T}, Int64, Int64, Ptr{T}, Int64, Cint, Ptr{T}, Int64, Cint,
+                   Ptr{T}, Int64, Ptr{T}, Int64, Int64, Ref{Cdouble}, Ptr{T}, Int64, Int64, Ptr{T}, Int64, Ptr{T}, Int64,
+                   Ptr{T}, Int64, Ptr{T}, Int64, Ptr{T}, Int64, Int64, Ref{Int32}),
+                  h, MEM_HOST, layout, 1, D, N, X, ldx, 0, yv, 0, nk, s, 0, pk, mw, 0, Lw, ldl, 0, lp, dX, ldx, 0, dy, 0, ds, 0,
+                  dmw, 0, mw′, 0, Ai, D, 0, info)
+        end
+    end
+    check(h, rc)
+    info[] > 0 && throw(PosDefException(info[]))
+    return lp[], dX, dy, ds, dmw, mw′, Ai
+end
+
 end # module
