@@ -705,6 +705,89 @@ int marginals_batched(blr_handle* h, int memspace, int layout, int64_t B, int64_
   return 0;
 }
 
+// ---- gradient for D > 128, one regressor: forward + backward panels over the tall matrix [F; X'; I] ----------------------
+template <typename T>
+int logpdf_grad_large_one(blr_handle* h, int layout, int64_t D, int64_t N, const T* X, int64_t ldx, const T* y, int noise_kind,
+                          const T* s, const T* mwp, const T* Tfac, int64_t ldt, T* dX, int64_t lddx, T* dy, T* ds, T* dmw,
+                          T* Ainv, int64_t ldai, int32_t* info_dev) {
+  using TC = TrsmCfg<T>;
+  using LC = LargeCfg<T>;
+  const int DP = (int)((D + kPB - 1) / kPB * kPB), NC = DP / kPB;
+  const int NP = (int)((N + kPB - 1) / kPB * kPB);
+  const int DI = Ainv ? DP : 0;
+  const int R = DP + NP + DI;
+  const int64_t ldy = R;
+  size_t off = 0;
+  auto carve = [&](size_t bytes) { size_t o = off; off = (off + bytes + 255) & ~(size_t)255; return o; };
+  const size_t o_y = carve((size_t)ldy * DP * sizeof(T));
+  const size_t o_sq = carve((size_t)(NP + DI) * sizeof(double));
+  const size_t o_mu = carve((size_t)NP * sizeof(T));
+  const size_t o_var = carve((size_t)(NP + DI) * sizeof(T));
+  const size_t o_r = carve((size_t)NP * sizeof(T));
+  const size_t o_w = carve((size_t)NP * sizeof(T));
+  const size_t o_part = carve(dmw ? (size_t)(NP / 64) * DP * sizeof(double) : 0);
+  int rc = ensure_ws(h, off);
+  if (rc) return rc;
+  T* Ybar = reinterpret_cast<T*>(h->ws + o_y);
+  double* rowsq = reinterpret_cast<double*>(h->ws + o_sq);
+  T* mu = reinterpret_cast<T*>(h->ws + o_mu);
+  T* var = reinterpret_cast<T*>(h->ws + o_var);
+  T* rvec = reinterpret_cast<T*>(h->ws + o_r);
+  T* wvec = reinterpret_cast<T*>(h->ws + o_w);
+  double* part = dmw ? reinterpret_cast<double*>(h->ws + o_part) : nullptr;
+
+  {
+    dim3 grid((DP + 31) / 32, (DP + 31) / 32);
+    hipLaunchKernelGGL(factor_sym_fill_kernel<T>, grid, dim3(kThreads), 0, h->stream, Tfac, ldt, (int)D, DP, Ybar, ldy);
+    MeanFillArgs<T> m{};
+    m.X = X; m.ldx = ldx; m.layout = layout; m.mw = mwp; m.mean = mu; m.Ybar = Ybar; m.ldy = ldy; m.row0 = DP;
+    m.D = (int)D; m.DP = DP; m.N = (int)N;
+    hipLaunchKernelGGL(mean_fill_kernel<T>, dim3((unsigned)(NP / 64)), dim3(kThreads), 0, h->stream, m);
+    if (DI) hipLaunchKernelGGL(identity_rows_kernel<T>, dim3(1024), dim3(kThreads), 0, h->stream, Ybar, ldy, DP + NP, DP);
+  }
+  if ((rc = set_lds<T>(h, reinterpret_cast<const void*>(trsm_block_kernel<T>), TC::LDS_BYTES))) return rc;
+  if ((rc = set_lds<T>(h, reinterpret_cast<const void*>(trsm_back_block_kernel<T>), TC::LDS_BYTES))) return rc;
+  if ((rc = set_lds<T>(h, reinterpret_cast<const void*>(gram_tile_kernel<T>), LC::LDS_BYTES))) return rc;
+  const int nyb = (NP + DI) / kPB;                       // row blocks below the factor block
+  const int nblk = (NP + DI + TC::RB - 1) / TC::RB;
+  auto trailing = [&](int p, int j0, int ncolblocks) {   // C(I, J) -= Y(I, p) F(J, p)' for J = j0 .. j0 + ncolblocks - 1
+    GramTileArgs<T> g{};
+    g.X = Ybar + (int64_t)p * kPB * ldy; g.ldx = ldy; g.layout = LAYOUT_COLVECS; g.use_dma = 1;
+    g.s = nullptr; g.noise_kind = NOISE_ISOTROPIC; g.r = nullptr;
+    g.D = R; g.n_begin = 0; g.n_end = kPB; g.nsplit = 1;
+    g.tile_i0 = NC; g.tile_j0 = j0; g.tri = 3; g.ntile_rows = nyb; g.ntiles = nyb * ncolblocks; g.nblocks = NC + nyb;
+    g.C = Ybar; g.ldc = ldy; g.mode_out = 1;
+    hipLaunchKernelGGL(gram_tile_kernel<T>, dim3(g.ntiles), dim3(kThreads), LC::LDS_BYTES, h->stream, g);
+  };
+  for (int p = 0; p < NC; ++p) {  // forward: rows x' -> x'L^-T, with the row sums of squares riding along
+    RowSqArgs<T> rs{};
+    rs.acc = rowsq; rs.var = var; rs.s = s; rs.noise_kind = noise_kind; rs.N = (int)N; rs.first = p == 0; rs.last = p == NC - 1;
+    hipLaunchKernelGGL(trsm_block_kernel<T>, dim3(nblk), dim3(kThreads), TC::LDS_BYTES, h->stream, Ybar, ldy, p, DP, R,
+                       (const int32_t*)info_dev, rs);
+    if (p + 1 < NC) trailing(p, p + 1, NC - 1 - p);
+  }
+  hipLaunchKernelGGL(grad_obs_kernel<T>, dim3((unsigned)((N + kThreads - 1) / kThreads)), dim3(kThreads), 0, h->stream, y,
+                     (const T*)mu, (const T*)var, s, noise_kind, (int)N, rvec, wvec, dy, ds);
+  for (int p = NC - 1; p >= 0; --p) {  // backward: x'L^-T -> x'L^-T L^-1 = x'A^-1
+    hipLaunchKernelGGL(trsm_back_block_kernel<T>, dim3(nblk), dim3(kThreads), TC::LDS_BYTES, h->stream, Ybar, ldy, p, DP, R,
+                       (const int32_t*)info_dev);
+    if (p > 0) trailing(p, 0, p);  // second operand: the UPPER triangle of the factor block (T = L')
+  }
+  if (dX || dmw) {
+    GradOutArgs<T> o{};
+    o.Ybar = Ybar; o.ldy = ldy; o.row0 = DP; o.X = X; o.ldx = ldx; o.layout = layout;
+    o.rvec = rvec; o.wvec = wvec; o.mwp = mwp; o.dX = dX; o.lddx = lddx; o.dmw_part = part;
+    o.D = (int)D; o.DP = DP; o.N = (int)N;
+    hipLaunchKernelGGL(grad_out_large_kernel<T>, dim3((unsigned)(NP / 64)), dim3(kThreads), 0, h->stream, o);
+    if (dmw)
+      hipLaunchKernelGGL(grad_reduce_large_kernel<T>, dim3((unsigned)((D + kThreads - 1) / kThreads)), dim3(kThreads), 0, h->stream,
+                         (const double*)part, NP / 64, DP, (int)D, dmw);
+  }
+  if (Ainv) hipLaunchKernelGGL(ainv_copy_kernel<T>, dim3(1024), dim3(kThreads), 0, h->stream, (const T*)Ybar, ldy, DP + NP, (int)D, Ainv, ldai);
+  HIP_TRY(h, hipGetLastError());
+  return 0;
+}
+
 // ---- gradient of the log marginal likelihood (D <= 128): fused posterior, then the two-sweep gradient kernel -----------
 template <typename T>
 int logpdf_grad_batched(blr_handle* h, int memspace, int layout, int64_t B, int64_t D, int64_t N, const T* X, int64_t ldx,
@@ -718,7 +801,7 @@ int logpdf_grad_batched(blr_handle* h, int memspace, int layout, int64_t B, int6
   if (memspace != BLR_MEM_HOST && memspace != BLR_MEM_DEVICE) return bad_arg(h, 2, "memspace");
   if (layout != BLR_LAYOUT_COLVECS && layout != BLR_LAYOUT_ROWVECS) return bad_arg(h, 3, "unknown layout (reference :26-31)");
   if (B < 0) return bad_arg(h, 4, "B < 0");
-  if (D < 1 || D > kMaxSmallD) return bad_arg(h, 5, "gradients are built for D <= 128 in this round");
+  if (D < 1 || D > kMaxLargeD) return bad_arg(h, 5, "D out of range for this build (1..8192)");
   if (N < 1 || N > (1 << 30)) return bad_arg(h, 6, "N out of range (>= 1)");
   if (B == 0) return 0;
   if (!X) return bad_arg(h, 7, "X is NULL");
@@ -772,6 +855,54 @@ int logpdf_grad_batched(blr_handle* h, int memspace, int layout, int64_t B, int6
     if ((rc = stage_out_alloc(h, info, (size_t)B, &info_d))) return rc;
   } else {
     a.X = X; a.y = y; a.s = s; a.mw = mw; a.Lw = Lw;
+  }
+  if (D > kMaxSmallD) {  // large-D path: one regressor at a time; factor and posterior mean in buffers of their own
+    T* Tf = nullptr;
+    T* mp = nullptr;
+    {
+      void* p0 = nullptr;
+      HIP_TRY(h, hipMalloc(&p0, (size_t)D * D * sizeof(T)));
+      h->staged.push_back(p0);
+      Tf = static_cast<T*>(p0);
+      void* p1 = nullptr;
+      HIP_TRY(h, hipMalloc(&p1, (size_t)D * sizeof(T)));
+      h->staged.push_back(p1);
+      mp = static_cast<T*>(p1);
+    }
+    a.vec_ok = 0;
+    for (int64_t reg = 0; reg < B; ++reg) {
+      PosteriorArgs<T> one = a;
+      one.mw_post = mwp_d ? mwp_d + reg * stride_mwpost : mp; one.stride_mwpost = 0;
+      one.T_post = Tf; one.ldt = D; one.strideT = 0;
+      one.Lw_post = nullptr; one.ldlp = D; one.strideLp = 0;
+      one.logpdf = lp_d; one.info = info_d;
+      // posterior_large_one indexes the batched arrays by `reg`: shift the outputs that are NOT batched here
+      one.mw_post -= reg * one.stride_mwpost;
+      if ((rc = posterior_large_one<T>(h, one, reg))) return rc;
+      int32_t* inf = info_d + reg;
+      if ((rc = logpdf_grad_large_one<T>(h, layout, D, N, a.X + reg * strideX, ldx, a.y + reg * stridey, noise_kind,
+                                         a.s + reg * strides, one.mw_post, Tf, D, dX_d ? dX_d + reg * stridedX : nullptr, lddx,
+                                         dy_d ? dy_d + reg * stridedy : nullptr, ds_d ? ds_d + reg * strideds : nullptr,
+                                         dmw_d ? dmw_d + reg * stridedmw : nullptr, Ai_d ? Ai_d + reg * strideAi : nullptr,
+                                         ldai, inf)))
+        return rc;
+    }
+    HIP_TRY(h, hipStreamSynchronize(h->stream));  // Tf / mp are temporaries of this call
+    if (memspace == BLR_MEM_HOST) {
+      auto back = [&](void* dst, const void* src, size_t bytes) -> int {
+        if (dst && bytes) HIP_TRY(h, hipMemcpy(dst, src, bytes, hipMemcpyDeviceToHost));
+        return 0;
+      };
+      if ((rc = back(dX, dX_d, extent(B, stridedX, dx_one) * sizeof(T)))) return rc;
+      if ((rc = back(dy, dy_d, extent(B, stridedy, (size_t)N) * sizeof(T)))) return rc;
+      if ((rc = back(ds, ds_d, extent(B, strideds, (size_t)N) * sizeof(T)))) return rc;
+      if ((rc = back(dmw, dmw_d, extent(B, stridedmw, (size_t)D) * sizeof(T)))) return rc;
+      if ((rc = back(mw_post, mwp_d, extent(B, stride_mwpost, (size_t)D) * sizeof(T)))) return rc;
+      if ((rc = back(Ainv, Ai_d, extent(B, strideAi, mat_extent(D, D, ldai)) * sizeof(T)))) return rc;
+      if ((rc = back(logpdf, lp_d, (size_t)B * sizeof(double)))) return rc;
+      if ((rc = back(info, info_d, (size_t)B * sizeof(int32_t)))) return rc;
+    }
+    return 0;
   }
   // workspace: factor T [B][D x D], posterior mean (if the caller does not want it), dmw partials
   using TC = TrsmCfg<T>;

@@ -1688,4 +1688,182 @@ __global__ __launch_bounds__(kPB) void grad_reduce_kernel(const double* part, in
   dmw[(int64_t)reg * stridedmw + c] = (T)acc;
 }
 
+// ---- gradient for D > 128: the same two sweeps through the panel machinery of the tall matrix ---------------------------
+// Tall matrix  [ F ; X' ; I ]  (ld = rows): F = the factor block with BOTH triangles filled (lower: L, upper: T = L'), the
+// inputs as rows, and (for A^-1) the rows of the identity.  Forward panels (trsm_block_kernel + MFMA trailing updates, as
+// in the marginal stream) turn every row x' into x'L^-T; backward panels (trsm_back_block_kernel + the same trailing
+// update kernel reading the UPPER triangle of F as its second operand) turn that into x'L^-T L^-1 = x'A^-1.
+
+// top block: lower triangle L = U', upper triangle U, unit padding
+template <typename T>
+__global__ __launch_bounds__(kThreads) void factor_sym_fill_kernel(const T* U, int64_t ldu, int D, int DP, T* Ybar, int64_t ldy) {
+  __shared__ T tile[32][33];
+  const int bx = blockIdx.x * 32, by = blockIdx.y * 32;
+  const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;
+  for (int k = ty; k < 32; k += 8) {
+    const int ur = by + tx, uc = bx + k;
+    tile[k][tx] = (ur < D && uc < D && ur <= uc) ? U[(int64_t)uc * ldu + ur] : T(0);
+  }
+  __syncthreads();
+  for (int k = ty; k < 32; k += 8) {
+    const int row = bx + tx, col = by + k;  // L[row, col] = U[col, row] = tile[tx][k]
+    if (row < DP && col < DP && row >= col) {
+      T v = tile[tx][k];
+      if (row >= D || col >= D) v = (row == col) ? T(1) : T(0);
+      Ybar[(int64_t)col * ldy + row] = v;                  // lower (and diagonal)
+      if (row > col) Ybar[(int64_t)row * ldy + col] = v;   // mirrored: element (col, row) of the upper triangle
+    }
+  }
+}
+
+// rows [row0, row0 + DP) of the tall matrix := identity
+template <typename T>
+__global__ __launch_bounds__(kThreads) void identity_rows_kernel(T* Ybar, int64_t ldy, int row0, int DP) {
+  for (int64_t e = (int64_t)blockIdx.x * kThreads + threadIdx.x; e < (int64_t)DP * DP; e += (int64_t)gridDim.x * kThreads) {
+    const int c = (int)(e / DP), r = (int)(e % DP);
+    Ybar[(int64_t)c * ldy + row0 + r] = (r == c) ? T(1) : T(0);
+  }
+}
+
+// X <- X L_pp^-1 for one block of RB rows (the backward panel step)
+template <typename T>
+__global__ __launch_bounds__(kThreads) void trsm_back_block_kernel(T* Abar, int64_t lda, int p, int row_begin, int nrows_total,
+                                                                   const int32_t* info) {
+  using Cfg = TrsmCfg<T>;
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  T* const P = reinterpret_cast<T*>(smem);
+  T* const Xs = reinterpret_cast<T*>(smem + Cfg::OFF_X);
+  T* const dinv = reinterpret_cast<T*>(smem + Cfg::OFF_DI);
+  T* const Linv = reinterpret_cast<T*>(smem + Cfg::OFF_LI);
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = uni(tid >> 6);
+  const int r0 = row_begin + blockIdx.x * Cfg::RB;
+  const int nr = min(Cfg::RB, nrows_total - r0);
+  const T* Lpp = Abar + (int64_t)p * kPB * lda + (int64_t)p * kPB;
+  T* Xg = Abar + (int64_t)p * kPB * lda + r0;
+  {
+    BlockVec<T, kPB> lb;
+    BlockVec<T, Cfg::RB> xb;
+    lb.load(Lpp, lda, tid);
+    xb.load(Xg, lda, tid);
+    if (*info != 0) return;
+    lb.to_packed_lower(P, tid);
+    xb.to_rows(Xs, Cfg::LDX, nr, tid);
+  }
+  __syncthreads();
+  if (tid < kPB) dinv[tid] = T(1) / P[pidx(tid, tid)];
+  __syncthreads();
+  trsm_prepare<T>(P, dinv, Linv, 8, tid);
+  trsm_sweep_back<T>(Xs, P, Linv, 8, lane, wave);
+  {
+    using BV = BlockVec<T, Cfg::RB>;
+#pragma unroll 4
+    for (int u = 0; u < BV::NV; ++u) {
+      const int vi = u * kThreads + tid;
+      const int c = vi / BV::VPC, rr = (vi % BV::VPC) * BV::VEC;
+      if (rr < nr) {
+        typename BV::vecT o;
+#pragma unroll
+        for (int e = 0; e < BV::VEC; ++e) o[e] = Xs[(rr + e) * Cfg::LDX + c];
+        *reinterpret_cast<typename BV::vecT*>(Xg + (int64_t)c * lda + rr) = o;
+      }
+    }
+  }
+}
+
+// per observation: r_n = y_n - mean_n, w_n = 1/s_n; wr_n = w_n r_n; dy_n = -w_n r_n; ds_n = -(s_n - r_n^2 - v_n)/(2 s_n^2)
+// (var_n = v_n + s_n comes from the forward panels' fused row sums of squares)
+template <typename T>
+__global__ __launch_bounds__(kThreads) void grad_obs_kernel(const T* y, const T* mean, const T* var, const T* s, int noise_kind,
+                                                            int N, T* rvec, T* wvec, T* dy, T* ds) {
+  const int n = blockIdx.x * kThreads + threadIdx.x;
+  if (n >= N) return;
+  const T sv = (noise_kind == NOISE_DIAGONAL) ? s[n] : s[0];
+  const T w = T(1) / sv, rr = y[n] - mean[n];
+  rvec[n] = rr;
+  wvec[n] = w;
+  if (dy) dy[n] = -w * rr;
+  if (ds) ds[n] = -(sv - rr * rr - (var[n] - sv)) / (T(2) * sv * sv);
+}
+
+// dX = (mw' r' - A^-1 X) S in the caller's layout from the rows g_n' = x_n'A^-1 of the tall matrix; the same 64 x 64
+// tiles also give the partial sums of  dmw_d = sum_n x_dn w_n r_n  (fixed order inside a tile; tiles summed by
+// grad_reduce_large_kernel)
+template <typename T>
+struct GradOutArgs {
+  const T* Ybar; int64_t ldy; int row0;   // rows g_n
+  const T* X; int64_t ldx; int layout;    // original inputs (for dmw)
+  const T* rvec; const T* wvec; const T* mwp;
+  T* dX; int64_t lddx;
+  double* dmw_part;                        // [gridDim.x][DP]
+  int D, DP, N;
+};
+template <typename T>
+__global__ __launch_bounds__(kThreads) void grad_out_large_kernel(GradOutArgs<T> a) {
+  __shared__ T tile[64][65];
+  __shared__ T wr[64], rr[64], ww[64];
+  const int tid = threadIdx.x;
+  const int n0 = blockIdx.x * 64;
+  if (tid < 64) {
+    const int n = n0 + tid;
+    const T r = n < a.N ? a.rvec[n] : T(0), w = n < a.N ? a.wvec[n] : T(0);
+    rr[tid] = r; ww[tid] = w; wr[tid] = w * r;
+  }
+  for (int d0 = 0; d0 < a.DP; d0 += 64) {
+    __syncthreads();
+    // g tile: rows n (contiguous in the tall matrix), columns d
+    for (int e = tid; e < 64 * 64; e += kThreads) {
+      const int nn = e & 63, dd = e >> 6;
+      tile[dd][nn] = a.Ybar[(int64_t)(d0 + dd) * a.ldy + a.row0 + n0 + nn];
+    }
+    __syncthreads();
+    if (a.dX) {
+      for (int e = tid; e < 64 * 64; e += kThreads) {
+        int dd, nn;
+        if (a.layout == LAYOUT_COLVECS) { dd = e & 63; nn = e >> 6; }
+        else                            { nn = e & 63; dd = e >> 6; }
+        const int d = d0 + dd, n = n0 + nn;
+        if (d < a.D && n < a.N) {
+          const T val = ww[nn] * (rr[nn] * a.mwp[d] - tile[dd][nn]);
+          a.dX[(a.layout == LAYOUT_COLVECS) ? (int64_t)n * a.lddx + d : (int64_t)d * a.lddx + n] = val;
+        }
+      }
+    }
+    __syncthreads();
+    if (a.dmw_part) {  // x tile, then dmw partial for these 64 d's
+      for (int e = tid; e < 64 * 64; e += kThreads) {
+        int dd, nn;
+        if (a.layout == LAYOUT_COLVECS) { dd = e & 63; nn = e >> 6; }
+        else                            { nn = e & 63; dd = e >> 6; }
+        const int d = d0 + dd, n = n0 + nn;
+        T v = T(0);
+        if (d < a.D && n < a.N) v = (a.layout == LAYOUT_COLVECS) ? a.X[(int64_t)n * a.ldx + d] : a.X[(int64_t)d * a.ldx + n];
+        tile[dd][nn] = v;
+      }
+      __syncthreads();
+      if (tid < 64) {
+        double acc = 0.0;
+        for (int nn = 0; nn < 64; ++nn) acc += (double)tile[tid][nn] * (double)wr[nn];
+        a.dmw_part[(int64_t)blockIdx.x * a.DP + d0 + tid] = acc;
+      }
+    }
+  }
+}
+template <typename T>
+__global__ __launch_bounds__(kThreads) void grad_reduce_large_kernel(const double* part, int nparts, int DP, int D, T* dmw) {
+  const int d = blockIdx.x * kThreads + threadIdx.x;
+  if (d >= D) return;
+  double acc = 0.0;
+  for (int g = 0; g < nparts; ++g) acc += part[(int64_t)g * DP + d];
+  dmw[d] = (T)acc;
+}
+// A^-1 from the identity rows of the tall matrix
+template <typename T>
+__global__ __launch_bounds__(kThreads) void ainv_copy_kernel(const T* Ybar, int64_t ldy, int row0, int D, T* Ainv, int64_t ldai) {
+  for (int64_t e = (int64_t)blockIdx.x * kThreads + threadIdx.x; e < (int64_t)D * D; e += (int64_t)gridDim.x * kThreads) {
+    const int c = (int)(e / D), r = (int)(e % D);
+    Ainv[(int64_t)c * ldai + r] = Ybar[(int64_t)c * ldy + row0 + r];
+  }
+}
+
 }  // namespace blr

@@ -396,7 +396,7 @@ def logpdf_columns(fx, Y):
 def logpdf_and_gradient(fx, y):
     """The value of logpdf(fx, y) (reference :55-58) and its gradient with respect to every input of the path -- the
     reverse-mode rule the reference gets from Zygote through its Julia code (README.md:56-71) and a ccall-backed logpdf
-    must provide itself.  D <= 128 in this build.
+    must provide itself.
 
     Returns ``(lp, grads)`` with ``grads`` a dict: ``X`` (same container layout as the inputs: D x N for ColVecs / a
     matrix, N x D for RowVecs), ``y`` (N), ``noise`` (N for Diagonal noise, a scalar for isotropic noise), ``mw`` (D)

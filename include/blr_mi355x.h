@@ -192,7 +192,7 @@ int blr_posterior_rff_f32(blr_handle* h, int memspace, int64_t Din, int64_t D, i
                           float* mw_post, float* T_post, int64_t ldt, float* Lw_post, int64_t ldlp,
                           double* logpdf, int32_t* info);
 
-/* ---- gradient of the log marginal likelihood (D <= 128 in this build) ------
+/* ---- gradient of the log marginal likelihood -------------------------------
  * The reverse-mode rule of logpdf(fx, y) (reference src/bayesian_linear_regression.jl:55-58): what Zygote derives from
  * the reference's Julia code (README.md:56-71, examples/nn-blr.jl:35-37) and a ccall-backed logpdf has to supply
  * itself (a ChainRules rrule in the shim).  One call = fused posterior + two MFMA sweeps per tile of inputs.

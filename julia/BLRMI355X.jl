@@ -262,7 +262,7 @@ function fused_rff(blr::BayesianLinearRegressor, ϕ::RandomFourierFeatures{T}, x
 end
 
 # ---- value + gradient of the log marginal likelihood (the rule behind the ccall; SURVEY.md 8f rank 1) ---------------
-# Returns (lp, dX, dy, ds, dmw, mw_post, Ainv); see INTEGRATION.md for the ChainRules rrule built on it.  D <= 128.
+# Returns (lp, dX, dy, ds, dmw, mw_post, Ainv); see INTEGRATION.md for the ChainRules rrule built on it.
 function logpdf_grad(fb, y::AbstractVector{<:Real})
     xl, nz, pr = xlayout(fb.x), noise(fb.Σy), prior(fb.f.Λw)
     (xl === nothing || nz === nothing || pr === nothing) && error("logpdf_grad: input types outside the device path")

@@ -853,9 +853,34 @@ def test_logpdf_gradient_batched_device_f32_and_errors(B):
         np.testing.assert_allclose(dmw[b].cpu().numpy(), g_o["mw"], rtol=2e-3, atol=2e-4 * np.abs(g_o["mw"]).max())
         np.testing.assert_allclose(Ai[b].cpu().numpy(), g_o["Ainv"], rtol=2e-3, atol=2e-4 * np.abs(g_o["Ainv"]).max())
         np.testing.assert_allclose(mwp[b].cpu().numpy(), g_o["mw_post"], rtol=2e-3, atol=1e-4)
-    # a non-SPD prior raises like cholesky() in the reference; D > 128 is rejected with the argument position
+    # a non-SPD prior raises like cholesky() in the reference; D > 8192 is rejected with the argument position
     Xs, mws, Lws, ss = O.generate_toy_problem(rng, 20, 4, dense_noise_cov=False)
     with pytest.raises(B.PosDefException):
         B.logpdf_and_gradient(B.BayesianLinearRegressor(mws, -Lws)(Xs, ss), rng.standard_normal(20))
     with pytest.raises(B.BLRError):
-        B.logpdf_and_gradient(B.BayesianLinearRegressor(np.zeros(130), B.Diagonal(np.ones(130)))(np.zeros((130, 8)), 0.1), np.zeros(8))
+        B.logpdf_and_gradient(B.BayesianLinearRegressor(np.zeros(9000), B.Diagonal(np.ones(9000)))(np.zeros((9000, 8)), 0.1), np.zeros(8))
+
+
+@pytest.mark.parametrize("dtype,D,N", [(np.float64, 130, 77), (np.float64, 300, 500), (np.float32, 1024, 700)])
+def test_large_d_logpdf_gradient(B, dtype, D, N):
+    # D > 128: forward + backward panel sweeps over the tall matrix [F; X'; I] (blr_large.hpp)
+    rng = _rng(9700 + D)
+    X = rng.standard_normal((D, N)).astype(dtype)
+    mw = (0.3 * rng.standard_normal(D)).astype(dtype)
+    Bm = rng.standard_normal((D, D)) / np.sqrt(D)
+    Lw = (Bm @ Bm.T + np.eye(D)).astype(dtype)
+    s = np.exp(0.3 * rng.standard_normal(N)).astype(dtype)
+    y = rng.standard_normal(N).astype(dtype)
+    f64 = lambda a: np.asarray(a, dtype=float)
+    lp_o, g_o = O.logpdf_grad(f64(mw), f64(Lw), f64(X), f64(s), f64(y))
+    rt = 1e-8 if dtype == np.float64 else 3e-3
+    f = B.BayesianLinearRegressor(mw, Lw)
+    for x in (np.asfortranarray(X), B.RowVecs(np.asfortranarray(X.T))):
+        lp, g = B.logpdf_and_gradient(f(x, s), y)
+        assert lp == pytest.approx(lp_o, rel=1e-10 if dtype == np.float64 else 3e-4)
+        gX = g["X"].T if isinstance(x, B.RowVecs) else g["X"]
+        for got, ref in ((gX, g_o["X"]), (g["y"], g_o["y"]), (g["noise"], g_o["s"]), (g["mw"], g_o["mw"]), (g["Lw"], g_o["Lw"])):
+            np.testing.assert_allclose(got, ref, rtol=rt, atol=rt * np.abs(ref).max())
+    lp, g = B.logpdf_and_gradient(f(np.asfortranarray(X), dtype(0.4)), y)  # isotropic noise: scalar gradient
+    lp_i, g_i = O.logpdf_grad(f64(mw), f64(Lw), f64(X), np.float64(dtype(0.4)), f64(y))
+    assert float(g["noise"]) == pytest.approx(float(np.sum(g_i["s"])), rel=rt * 10)
