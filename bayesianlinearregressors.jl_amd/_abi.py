@@ -74,6 +74,8 @@ for _suf in ("f64", "f32"):
     _SIGS[f"blr_logpdf_grad_batched_{_suf}"] = (
         [_H, _int, _int, _i64, _i64, _i64, _vp, _i64, _i64, _vp, _i64, _int, _vp, _i64, _int, _vp, _i64, _vp, _i64, _i64,
          _vp, _vp, _i64, _i64, _vp, _i64, _vp, _i64, _vp, _i64, _vp, _i64, _vp, _i64, _i64, _vp], _int)
+    _SIGS[f"blr_logpdf_multi_{_suf}"] = (
+        [_H, _int, _int, _i64, _i64, _i64, _vp, _i64, _vp, _i64, _int, _vp, _int, _vp, _vp, _i64, _vp, _vp, _i64, _vp], _int)
     _fp = C.c_double if _suf == "f64" else C.c_float
     _SIGS[f"blr_rff_features_{_suf}"] = (
         [_H, _int, _i64, _i64, _i64, _vp, _i64, _vp, _i64, _vp, _fp, _vp, _i64], _int)
@@ -211,6 +213,12 @@ class Handle:
                              _ptr(s), strides, prior_kind, _ptr(mw), stridemw, _ptr(Lw), ldl, strideLw, _ptr(logpdf),
                              _ptr(dX), lddx, stridedX, _ptr(dy), stridedy, _ptr(ds), strideds, _ptr(dmw), stridedmw,
                              _ptr(mw_post), stride_mwpost, _ptr(Ainv), ldai, strideAi, _ptr(info)))
+
+    def logpdf_multi(self, dtype, memspace, layout, D, N, S, X, ldx, Y, ldY, noise_kind, s, prior_kind, mw, Lw, ldl, logpdf,
+                     mw_post, ldmp, info):
+        fn = getattr(self.lib, f"blr_logpdf_multi_{suffix(dtype)}")
+        return self.check(fn(self._h, memspace, layout, D, N, S, _ptr(X), ldx, _ptr(Y), ldY, noise_kind, _ptr(s), prior_kind,
+                             _ptr(mw), _ptr(Lw), ldl, _ptr(logpdf), _ptr(mw_post), ldmp, _ptr(info)))
 
     def marginals_batched(self, dtype, memspace, layout, B, D, N, X, ldx, strideX, noise_kind, s, strides, prior_kind,
                           mw, stridemw, Lw, ldl, strideLw, mean, stridemean, var, stridevar, info):

@@ -60,12 +60,13 @@ int bad_arg(blr_handle* h, int pos, const char* why) {
   return -pos;
 }
 
-struct Staging {  // RAII for the device copies of one HOST-memspace call
+struct Staging {  // RAII for the device temporaries of one call; nests (an inner guard frees only what it added)
   blr_handle* h;
-  explicit Staging(blr_handle* hh) : h(hh) {}
+  size_t base;
+  explicit Staging(blr_handle* hh) : h(hh), base(hh->staged.size()) {}
   ~Staging() {
-    for (void* p : h->staged) (void)hipFree(p);
-    h->staged.clear();
+    for (size_t i = base; i < h->staged.size(); ++i) (void)hipFree(h->staged[i]);
+    h->staged.resize(base);
   }
 };
 
@@ -961,6 +962,185 @@ int logpdf_grad_batched(blr_handle* h, int memspace, int layout, int64_t B, int6
   return 0;
 }
 
+// ---- shared-X multi-output evidence: logpdf(fx, Y::Matrix), optional per-column posterior means ----
+template <typename T>
+int logpdf_multi(blr_handle* h, int memspace, int layout, int64_t D, int64_t N, int64_t S, const T* X, int64_t ldx, const T* Y,
+                 int64_t ldY, int noise_kind, const T* s, int prior_kind, const T* mw, const T* Lw, int64_t ldl, double* logpdf,
+                 T* mw_post, int64_t ldmp, int32_t* info) {
+  if (!h) return -1;
+  h->err.clear();
+  if (memspace != BLR_MEM_HOST && memspace != BLR_MEM_DEVICE) return bad_arg(h, 2, "memspace");
+  if (layout != BLR_LAYOUT_COLVECS && layout != BLR_LAYOUT_ROWVECS) return bad_arg(h, 3, "unknown layout (reference :26-31)");
+  if (D < 1 || D > kMaxLargeD) return bad_arg(h, 4, "D out of range for this build (1..8192)");
+  if (N < 1 || N > (1 << 30)) return bad_arg(h, 5, "N out of range (>= 1)");
+  if (S < 0 || S > 65536) return bad_arg(h, 6, "S out of range (0..65536)");
+  if (S == 0) return 0;
+  if (!X) return bad_arg(h, 7, "X is NULL");
+  if (layout == BLR_LAYOUT_COLVECS ? ldx < D : ldx < N) return bad_arg(h, 8, "ldx too small");
+  if (!Y) return bad_arg(h, 9, "Y is NULL");
+  if (ldY < N) return bad_arg(h, 10, "ldY < N (reference :74 length check)");
+  if (noise_kind != BLR_NOISE_ISOTROPIC && noise_kind != BLR_NOISE_DIAGONAL) return bad_arg(h, 11, "noise_kind");
+  if (!s) return bad_arg(h, 12, "s is NULL");
+  if (prior_kind != BLR_PRIOR_DENSE && prior_kind != BLR_PRIOR_UPPER_FACTOR && prior_kind != BLR_PRIOR_DIAGONAL)
+    return bad_arg(h, 13, "prior_kind");
+  if (!mw) return bad_arg(h, 14, "mw is NULL");
+  if (!Lw) return bad_arg(h, 15, "Lw is NULL");
+  if (prior_kind != BLR_PRIOR_DIAGONAL && ldl < D) return bad_arg(h, 16, "ldl < D");
+  if (!logpdf) return bad_arg(h, 17, "logpdf is NULL");
+  if (mw_post && ldmp < D) return bad_arg(h, 19, "ldmp < D");
+  if (!info) return bad_arg(h, 20, "info is NULL");
+  HIP_TRY(h, hipSetDevice(h->device));
+
+  using TC = TrsmCfg<T>;
+  using LC = LargeCfg<T>;
+  Staging guard(h);
+  int rc;
+  auto tmp = [&](size_t bytes, void** out) -> int {  // call-scoped device temporaries (freed by the Staging guard)
+    void* p = nullptr;
+    HIP_TRY(h, hipMalloc(&p, std::max<size_t>(bytes, 256)));
+    h->staged.push_back(p);
+    *out = p;
+    return 0;
+  };
+  const T *X_d = X, *Y_d = Y, *s_d = s, *mw_d = mw, *Lw_d = Lw;
+  double* lp_d = logpdf;
+  T* mp_d = mw_post;
+  int32_t* info_d = info;
+  if (memspace == BLR_MEM_HOST) {
+    const size_t x_one = layout == BLR_LAYOUT_COLVECS ? mat_extent(D, N, ldx) : mat_extent(N, D, ldx);
+    const size_t lw_one = prior_kind == BLR_PRIOR_DIAGONAL ? (size_t)D : mat_extent(D, D, ldl);
+    if ((rc = stage_in(h, X, x_one, &X_d))) return rc;
+    if ((rc = stage_in(h, Y, mat_extent(N, S, ldY), &Y_d))) return rc;
+    if ((rc = stage_in(h, s, noise_kind == BLR_NOISE_DIAGONAL ? (size_t)N : 1, &s_d))) return rc;
+    if ((rc = stage_in(h, mw, (size_t)D, &mw_d))) return rc;
+    if ((rc = stage_in(h, Lw, lw_one, &Lw_d))) return rc;
+    if ((rc = stage_out_alloc(h, logpdf, (size_t)S, &lp_d))) return rc;
+    if ((rc = stage_out_alloc(h, mw_post, mw_post ? mat_extent(D, S, ldmp) : 0, &mp_d))) return rc;
+    if ((rc = stage_out_alloc(h, info, (size_t)1, &info_d))) return rc;
+  }
+  const int DP = (int)((D + kPB - 1) / kPB * kPB), NC = DP / kPB;
+  const int SP = (int)((S + kPB - 1) / kPB * kPB);
+  const int NP64 = (int)((N + 63) / 64);
+  const int64_t ldy = (int64_t)DP + SP;
+  const int ntile_rows = SP / kPB, ntiles = ntile_rows * NC;
+  // split-K over N: fill the 512 workgroup slots
+  const int max_split = std::max(1, std::min<int>(64, (int)((N + LC::NSC - 1) / LC::NSC)));
+  const int nsplit = std::max(1, std::min(max_split, 512 / std::max(1, ntiles)));
+  void *vTf, *vlp0, *vmu, *vR, *vq, *vG, *vY, *vsq, *vuu, *vzero, *vinfo2;
+  const int64_t ldr = layout == BLR_LAYOUT_COLVECS ? SP : N;
+  if ((rc = tmp((size_t)D * D * sizeof(T), &vTf))) return rc;
+  if ((rc = tmp(sizeof(double), &vlp0))) return rc;
+  if ((rc = tmp((size_t)N * sizeof(T), &vmu))) return rc;
+  if ((rc = tmp((size_t)SP * N * sizeof(T), &vR))) return rc;
+  if ((rc = tmp((size_t)NP64 * SP * sizeof(double), &vq))) return rc;
+  if ((rc = tmp((size_t)nsplit * ntiles * kPB * kPB * sizeof(T), &vG))) return rc;
+  if ((rc = tmp((size_t)ldy * DP * sizeof(T), &vY))) return rc;
+  if ((rc = tmp((size_t)SP * sizeof(double), &vsq))) return rc;
+  if ((rc = tmp((size_t)SP * sizeof(T), &vuu))) return rc;
+  if ((rc = tmp(sizeof(T), &vzero))) return rc;
+  if ((rc = tmp(sizeof(int32_t), &vinfo2))) return rc;
+  T* Tf = static_cast<T*>(vTf);
+  double* lp0 = static_cast<double*>(vlp0);
+  T* mu = static_cast<T*>(vmu);
+  T* R = static_cast<T*>(vR);
+  double* qpart = static_cast<double*>(vq);
+  T* Gpart = static_cast<T*>(vG);
+  T* Ybar = static_cast<T*>(vY);
+  double* rowsq = static_cast<double*>(vsq);
+  T* uu = static_cast<T*>(vuu);
+  T* zero = static_cast<T*>(vzero);
+  int32_t* info2 = static_cast<int32_t*>(vinfo2);
+  HIP_TRY(h, hipMemsetAsync(zero, 0, sizeof(T), h->stream));
+  if (layout == BLR_LAYOUT_COLVECS) HIP_TRY(h, hipMemsetAsync(R, 0, (size_t)SP * N * sizeof(T), h->stream));
+
+  // (1) the ordinary fused update on column 0: factor T, logpdf_0, status
+  {
+    PosteriorArgs<T> a{};
+    a.X = X_d; a.ldx = ldx; a.strideX = 0; a.y = Y_d; a.stridey = 0; a.s = s_d; a.strides = 0; a.mw = mw_d; a.stridemw = 0;
+    a.Lw = Lw_d; a.ldl = ldl; a.strideLw = 0;
+    a.mw_post = nullptr; a.stride_mwpost = D; a.T_post = Tf; a.ldt = D; a.strideT = D * D;
+    a.Lw_post = nullptr; a.ldlp = D; a.strideLp = 0; a.logpdf = lp0; a.info = info_d;
+    a.layout = layout; a.noise_kind = noise_kind; a.prior_kind = prior_kind; a.D = (int)D; a.N = (int)N; a.B = 1;
+    a.vec_ok = (layout == BLR_LAYOUT_COLVECS && D % Mfma<T>::VEC == 0 && aligned16(X_d, ldx, 0)) ? 1 : 0;
+    if ((rc = dispatch_posterior<T>(h, a))) return rc;
+  }
+  // (2) mu_n = x_n'mw: the mean-only marginal stream
+  {
+    const bool was_async = h->async;
+    h->async = true;
+    rc = marginals_batched<T>(h, BLR_MEM_DEVICE, layout, 1, D, N, X_d, ldx, 0, noise_kind, s_d, 0, BLR_PRIOR_DIAGONAL, mw_d, 0,
+                              nullptr, 1, 0, mu, N, nullptr, N, info2);
+    h->async = was_async;
+    if (rc) return rc;
+  }
+  // (3) residuals R = S (Y - mu 1') in X's layout, q partials
+  {
+    MultiPrepArgs<T> p{};
+    p.Y = Y_d; p.ldY = ldY; p.mu = mu; p.s = s_d; p.noise_kind = noise_kind; p.R = R; p.ldr = ldr; p.layout = layout;
+    p.qpart = qpart; p.N = (int)N; p.S = (int)S; p.SP = SP;
+    hipLaunchKernelGGL(multi_prep_kernel<T>, dim3((unsigned)NP64), dim3(kThreads), 0, h->stream, p);
+  }
+  // (4) B' = R'X': split-K MFMA tiles, first operand R (rows s), second operand X (rows d)
+  if ((rc = set_lds<T>(h, reinterpret_cast<const void*>(gram_tile_kernel<T>), LC::LDS_BYTES))) return rc;
+  {
+    GramTileArgs<T> g{};
+    g.X = R; g.ldx = ldr; g.layout = layout; g.D = SP;
+    g.XB = X_d; g.ldxb = ldx; g.DB = (int)D;
+    g.use_dma = (layout == BLR_LAYOUT_COLVECS && ((uintptr_t)X_d % 16 == 0) && ((ldx * (int64_t)sizeof(T)) % 16 == 0)) ? 1 : 0;
+    g.s = nullptr; g.noise_kind = NOISE_ISOTROPIC; g.r = nullptr;
+    g.n_begin = 0; g.n_end = (int)N; g.nsplit = nsplit;
+    g.tile_i0 = 0; g.tile_j0 = 0; g.tri = 3; g.ntile_rows = ntile_rows; g.ntiles = ntiles; g.nblocks = NC;
+    g.Gpart = Gpart; g.bpart = nullptr; g.mode_out = 0; g.xcd_swizzle = 0;
+    hipLaunchKernelGGL(gram_tile_kernel<T>, dim3(ntiles * nsplit), dim3(kThreads), LC::LDS_BYTES, h->stream, g);
+    hipLaunchKernelGGL(multi_reduce_kernel<T>, dim3(ntiles, 16), dim3(kThreads), 0, h->stream, (const T*)Gpart, nsplit, ntiles,
+                       ntile_rows, Ybar, ldy, DP);
+  }
+  // (5) rows b_s' -> b_s'L^-T (|u_s|^2 rides along) -> (means only) b_s'A^-1
+  {
+    dim3 grid((DP + 31) / 32, (DP + 31) / 32);
+    hipLaunchKernelGGL(factor_sym_fill_kernel<T>, grid, dim3(kThreads), 0, h->stream, (const T*)Tf, D, (int)D, DP, Ybar, ldy);
+  }
+  if ((rc = set_lds<T>(h, reinterpret_cast<const void*>(trsm_block_kernel<T>), TC::LDS_BYTES))) return rc;
+  if ((rc = set_lds<T>(h, reinterpret_cast<const void*>(trsm_back_block_kernel<T>), TC::LDS_BYTES))) return rc;
+  const int R_rows = DP + SP;
+  const int nblk = (SP + TC::RB - 1) / TC::RB;
+  auto trailing = [&](int p, int j0, int ncolblocks) {
+    GramTileArgs<T> g{};
+    g.X = Ybar + (int64_t)p * kPB * ldy; g.ldx = ldy; g.layout = LAYOUT_COLVECS; g.use_dma = 1;
+    g.s = nullptr; g.noise_kind = NOISE_ISOTROPIC; g.r = nullptr;
+    g.D = R_rows; g.n_begin = 0; g.n_end = kPB; g.nsplit = 1;
+    g.tile_i0 = NC; g.tile_j0 = j0; g.tri = 3; g.ntile_rows = ntile_rows; g.ntiles = ntile_rows * ncolblocks; g.nblocks = NC + ntile_rows;
+    g.C = Ybar; g.ldc = ldy; g.mode_out = 1;
+    hipLaunchKernelGGL(gram_tile_kernel<T>, dim3(g.ntiles), dim3(kThreads), LC::LDS_BYTES, h->stream, g);
+  };
+  for (int p = 0; p < NC; ++p) {
+    RowSqArgs<T> rs{};
+    rs.acc = rowsq; rs.var = uu; rs.s = zero; rs.noise_kind = BLR_NOISE_ISOTROPIC; rs.N = (int)S; rs.first = p == 0; rs.last = p == NC - 1;
+    hipLaunchKernelGGL(trsm_block_kernel<T>, dim3(nblk), dim3(kThreads), TC::LDS_BYTES, h->stream, Ybar, ldy, p, DP, R_rows,
+                       (const int32_t*)info_d, rs);
+    if (p + 1 < NC) trailing(p, p + 1, NC - 1 - p);
+  }
+  hipLaunchKernelGGL(multi_finish_kernel<T>, dim3((unsigned)((S + kThreads - 1) / kThreads)), dim3(kThreads), 0, h->stream,
+                     (const double*)lp0, (const double*)qpart, NP64, SP, (const T*)uu, (int)S, lp_d);
+  if (mp_d) {
+    for (int p = NC - 1; p >= 0; --p) {
+      hipLaunchKernelGGL(trsm_back_block_kernel<T>, dim3(nblk), dim3(kThreads), TC::LDS_BYTES, h->stream, Ybar, ldy, p, DP, R_rows,
+                         (const int32_t*)info_d);
+      if (p > 0) trailing(p, 0, p);
+    }
+    hipLaunchKernelGGL(multi_means_kernel<T>, dim3(1024), dim3(kThreads), 0, h->stream, (const T*)Ybar, ldy, DP, mw_d, (int)D, (int)S,
+                       mp_d, ldmp);
+  }
+  HIP_TRY(h, hipGetLastError());
+  if (memspace == BLR_MEM_HOST) {
+    HIP_TRY(h, hipMemcpyAsync(logpdf, lp_d, (size_t)S * sizeof(double), hipMemcpyDeviceToHost, h->stream));
+    if (mw_post) HIP_TRY(h, hipMemcpyAsync(mw_post, mp_d, mat_extent(D, S, ldmp) * sizeof(T), hipMemcpyDeviceToHost, h->stream));
+    HIP_TRY(h, hipMemcpyAsync(info, info_d, sizeof(int32_t), hipMemcpyDeviceToHost, h->stream));
+  }
+  HIP_TRY(h, hipStreamSynchronize(h->stream));  // the temporaries of this call are freed on return
+  return 0;
+}
+
 // D > 128: W[:, s] = mw + U^-1 Z[:, s] with U = chol(Lw).U -- the wavefront back substitution of the posterior path with
 // one grid column per draw (reference :46-52).  All pointers are device pointers.
 template <typename T>
@@ -1446,6 +1626,13 @@ int blr_timer_stop(blr_handle* h, float* elapsed_ms) {
                                   prior_kind, mw, stridemw, Lw, ldl, strideLw, logpdf, dX, lddx, stridedX, dy,       \
                                   stridedy, ds, strideds, dmw, stridedmw, mw_post, stride_mwpost, Ainv, ldai,        \
                                   strideAi, info);                                                                  \
+  }                                                                                                                 \
+  int blr_logpdf_multi_##SUF(blr_handle* h, int memspace, int layout, int64_t D, int64_t N, int64_t S, const T* X,  \
+                             int64_t ldx, const T* Y, int64_t ldY, int noise_kind, const T* s, int prior_kind,      \
+                             const T* mw, const T* Lw, int64_t ldl, double* logpdf, T* mw_post, int64_t ldmp,       \
+                             int32_t* info) {                                                                       \
+    return logpdf_multi<T>(h, memspace, layout, D, N, S, X, ldx, Y, ldY, noise_kind, s, prior_kind, mw, Lw, ldl,     \
+                           logpdf, mw_post, ldmp, info);                                                            \
   }                                                                                                                 \
   int blr_posterior_rff_##SUF(blr_handle* h, int memspace, int64_t Din, int64_t D, int64_t N, const T* Xin,         \
                               int64_t ldxin, const T* Omega, int64_t ldo, const T* phase, T scale, const T* y,      \

@@ -167,6 +167,8 @@ struct GramTileArgs {
   T* C; int64_t ldc;         // mode 1: C[row + col*ldc] -= tile
   int mode_out;
   int xcd_swizzle;           // remap blockIdx so that one XCD owns whole N-slices (split-K launches)
+  const T* XB; int64_t ldxb; int DB;  // optional SECOND operand for the B side (rows rowB.. of XB, DB rows; same layout);
+                                      // NULL: B side = X (Gram / trailing updates)
 };
 
 template <typename T>
@@ -219,7 +221,7 @@ __global__ __launch_bounds__(kThreads, 2) void gram_tile_kernel(GramTileArgs<T> 
       J = a.tile_j0 + (t - ntri);
     }
   }
-  const bool diag_tile = (I == J);
+  const bool diag_tile = (I == J) && a.XB == nullptr;
   const int rowA = I * kPB, rowB = J * kPB;
   const int span = a.n_end - a.n_begin;
   const int per = ((span + a.nsplit - 1) / a.nsplit + L::NSC - 1) / L::NSC * L::NSC;  // whole stages per split
@@ -242,10 +244,10 @@ __global__ __launch_bounds__(kThreads, 2) void gram_tile_kernel(GramTileArgs<T> 
   for (int i = 0; i < 8; ++i) bacc[i] = 0.0;
 
   // stage loader: one operand side (128 rows starting at row0) into dst
-  auto load_side = [&](T* dst, int row0, int n0) {
-    const int rows = min(kPB, a.D - row0);  // may be <= 0 for padding blocks: everything zero-filled
+  auto load_side = [&](T* dst, const T* base, int64_t ldb, int Drows, int row0, int n0) {
+    const int rows = min(kPB, Drows - row0);  // may be <= 0 for padding blocks: everything zero-filled
     if (a.use_dma) {
-      stage_glds<T, 8, L::KS>(dst, a.X + row0, a.ldx, rows, c1, n0, wave, lane);
+      stage_glds<T, 8, L::KS>(dst, base + row0, ldb, rows, c1, n0, wave, lane);
     } else {
       int tt = tid;
       asm volatile("" : "+v"(tt));
@@ -256,17 +258,20 @@ __global__ __launch_bounds__(kThreads, 2) void gram_tile_kernel(GramTileArgs<T> 
         const int n = n0 + nl;
         const int dg = row0 + d;
         bool ok = d < rows && n < c1 && (a.layout != 2 || n <= dg);
-        int64_t addr = (a.layout == LAYOUT_COLVECS) ? (int64_t)n * a.ldx + dg : (int64_t)dg * a.ldx + n;
-        T v = a.X[ok ? addr : 0];
+        int64_t addr = (a.layout == LAYOUT_COLVECS) ? (int64_t)n * ldb + dg : (int64_t)dg * ldb + n;
+        T v = base[ok ? addr : 0];
         dst[frag_off(8, d, nl)] = ok ? v : T(0);
       }
     }
   };
+  const T* const baseB = a.XB ? a.XB : a.X;
+  const int64_t ldB = a.XB ? a.ldxb : a.ldx;
+  const int rowsB = a.XB ? a.DB : a.D;
   auto issue = [&](int st) {
     const int n0 = c0 + st * L::NSC;
     T* slot = slot0 + (st & 1) * L::SLOT;
-    load_side(slot, rowA, n0);
-    if (!diag_tile) load_side(slot + L::SIDE, rowB, n0);
+    load_side(slot, a.X, a.ldx, a.D, rowA, n0);
+    if (!diag_tile) load_side(slot + L::SIDE, baseB, ldB, rowsB, rowB, n0);
     if (tid < L::NSC) {
       const int n = n0 + tid;
       T wv = T(0), rv = T(0);
@@ -1863,6 +1868,106 @@ __global__ __launch_bounds__(kThreads) void ainv_copy_kernel(const T* Ybar, int6
   for (int64_t e = (int64_t)blockIdx.x * kThreads + threadIdx.x; e < (int64_t)D * D; e += (int64_t)gridDim.x * kThreads) {
     const int c = (int)(e / D), r = (int)(e % D);
     Ainv[(int64_t)c * ldai + r] = Ybar[(int64_t)c * ldy + row0 + r];
+  }
+}
+
+// ---- shared-X multi-output evidence: logpdf(fx, Y::Matrix) ---------------------------------------
+// All S columns of Y share X, hence A = Lw + X S X' and its factor: ONE Gram + Cholesky (the ordinary posterior call on
+// column 0), then per column only  q_s = delta_s' S delta_s  and  |L^-1 b_s|^2  with  b_s = X S delta_s:
+//     logpdf_s = logpdf_0 + (q_0 - |u_0|^2)/2 - (q_s - |u_s|^2)/2.
+// B = X (S Delta) is one D x N x S GEMM (gram_tile_kernel with the residual matrix as its first operand and X as its
+// second), and the solves are the tall-matrix panels of the large path applied to the rows b_s'.
+
+// R = S (Y - mu 1') in the layout of X (ColVecs: R' stored SP x N, s contiguous; RowVecs: N x SP), q partials per 64 rows
+template <typename T>
+struct MultiPrepArgs {
+  const T* Y; int64_t ldY;      // N x S column-major
+  const T* mu; const T* s; int noise_kind;
+  T* R; int64_t ldr; int layout;
+  double* qpart;                 // [gridDim.x][SP]
+  int N, S, SP;
+};
+template <typename T>
+__global__ __launch_bounds__(kThreads) void multi_prep_kernel(MultiPrepArgs<T> a) {
+  __shared__ T tile[64][65];
+  __shared__ double qt[4][64];
+  const int tid = threadIdx.x;
+  const int n0 = blockIdx.x * 64;
+  const int tn = tid & 63, tq = tid >> 6;
+  T w = T(0), m = T(0);
+  if (n0 + tn < a.N) {
+    w = T(1) / ((a.noise_kind == NOISE_DIAGONAL) ? a.s[n0 + tn] : a.s[0]);
+    m = a.mu[n0 + tn];
+  }
+  for (int s0 = 0; s0 < a.SP; s0 += 64) {
+    __syncthreads();
+    for (int k = tq; k < 64; k += 4) {  // column s0 + k, rows n0 + tn: coalesced along n
+      const int sidx = s0 + k, n = n0 + tn;
+      T r = T(0);
+      double q = 0.0;
+      if (sidx < a.S && n < a.N) {
+        const T d = a.Y[(int64_t)sidx * a.ldY + n] - m;
+        r = w * d;
+        q = (double)d * (double)r;
+      }
+      tile[k][tn] = r;
+      q = wave_allreduce(q);            // the 64 rows of this tile, fixed butterfly
+      if (tn == 0) qt[0][k] = q;
+    }
+    __syncthreads();
+    if (tid < 64) a.qpart[(int64_t)blockIdx.x * a.SP + s0 + tid] = qt[0][tid];
+    for (int e = tid; e < 64 * 64; e += kThreads) {
+      if (a.layout == LAYOUT_COLVECS) {  // R'[s + n * ldr]
+        const int ss = e & 63, nn = e >> 6;
+        if (n0 + nn < a.N) a.R[(int64_t)(n0 + nn) * a.ldr + s0 + ss] = tile[ss][nn];
+      } else {                           // R[n + s * ldr]
+        const int nn = e & 63, ss = e >> 6;
+        if (n0 + nn < a.N) a.R[(int64_t)(s0 + ss) * a.ldr + n0 + nn] = tile[ss][nn];
+      }
+    }
+  }
+}
+
+// split-K partial tiles of B' = R'X' (rows s, columns d) -> rows [row0, row0 + SP) of the tall matrix, fixed order
+template <typename T>
+__global__ __launch_bounds__(kThreads) void multi_reduce_kernel(const T* Gpart, int nsplit, int ntiles, int ntile_rows, T* Ybar,
+                                                                int64_t ldy, int row0) {
+  const int t = blockIdx.x;
+  const int I = t % ntile_rows, J = t / ntile_rows;  // tri == 3 enumeration of gram_tile_kernel
+  constexpr int kChunk = kPB * kPB / 16;
+  const int e_begin = blockIdx.y * kChunk, e_end = e_begin + kChunk;
+  for (int e = e_begin + threadIdx.x; e < e_end; e += kThreads) {
+    const int rl = e % kPB, cl = e / kPB;
+    T sum = T(0);
+    for (int sp = 0; sp < nsplit; ++sp) sum += Gpart[((int64_t)sp * ntiles + t) * (kPB * kPB) + e];
+    Ybar[(int64_t)(J * kPB + cl) * ldy + row0 + I * kPB + rl] = sum;
+  }
+}
+
+// logpdf_s from column 0's value and the per-column scalars; optional posterior means from the rows m_s
+template <typename T>
+__global__ __launch_bounds__(kThreads) void multi_finish_kernel(const double* lp0, const double* qpart, int nqparts, int SP,
+                                                                const T* uu, int S, double* logpdf) {
+  __shared__ double base[2];
+  if (threadIdx.x == 0 && blockIdx.x >= 0) {
+    double q0 = 0.0;
+    for (int g = 0; g < nqparts; ++g) q0 += qpart[(int64_t)g * SP];
+    base[0] = q0;
+    base[1] = (double)uu[0];
+  }
+  __syncthreads();
+  const int sidx = blockIdx.x * kThreads + threadIdx.x;
+  if (sidx >= S) return;
+  double q = 0.0;
+  for (int g = 0; g < nqparts; ++g) q += qpart[(int64_t)g * SP + sidx];
+  logpdf[sidx] = *lp0 + 0.5 * (base[0] - base[1]) - 0.5 * (q - (double)uu[sidx]);
+}
+template <typename T>
+__global__ __launch_bounds__(kThreads) void multi_means_kernel(const T* Ybar, int64_t ldy, int row0, const T* mw, int D, int S,
+                                                               T* mw_post, int64_t ldmp) {
+  for (int64_t e = (int64_t)blockIdx.x * kThreads + threadIdx.x; e < (int64_t)D * S; e += (int64_t)gridDim.x * kThreads) {
+    const int sidx = (int)(e / D), d = (int)(e % D);
+    mw_post[(int64_t)sidx * ldmp + d] = mw[d] + Ybar[(int64_t)d * ldy + row0 + sidx];
   }
 }
 

@@ -218,6 +218,21 @@ int blr_logpdf_grad_batched_f32(blr_handle* h, int memspace, int layout, int64_t
                                 int64_t strideds, float* dmw, int64_t stridedmw, float* mw_post,
                                 int64_t stride_mwpost, float* Ainv, int64_t ldai, int64_t strideAi, int32_t* info);
 
+/* ---- shared-X multi-output evidence -------------------------------------------
+ * logpdf(fx, Y::AbstractMatrix) of the AbstractGPs secondary API (exercised through TestUtils at reference
+ * test/bayesian_linear_regression.jl:7-9): the S columns of Y (N x S, ldY) share X, so the Gram matrix and its
+ * Cholesky factor are formed ONCE; per column only X S (y_s - X'mw) (one D x N x S GEMM) and two triangular
+ * solves remain.  logpdf[S]; mw_post (D x S, ldmp) optionally receives the posterior mean of every column
+ * (NULL: skipped); info: one status for the shared factorisation (LAPACK semantics). */
+int blr_logpdf_multi_f64(blr_handle* h, int memspace, int layout, int64_t D, int64_t N, int64_t S, const double* X,
+                         int64_t ldx, const double* Y, int64_t ldY, int noise_kind, const double* s, int prior_kind,
+                         const double* mw, const double* Lw, int64_t ldl, double* logpdf, double* mw_post, int64_t ldmp,
+                         int32_t* info);
+int blr_logpdf_multi_f32(blr_handle* h, int memspace, int layout, int64_t D, int64_t N, int64_t S, const float* X,
+                         int64_t ldx, const float* Y, int64_t ldY, int noise_kind, const float* s, int prior_kind,
+                         const float* mw, const float* Lw, int64_t ldl, double* logpdf, float* mw_post, int64_t ldmp,
+                         int32_t* info);
+
 /* ---- sharded log-evidence: fixed-order sum of logpdf[B] on the device ----------
  * Deterministic (no float atomics): the same bits for the same B regardless of launch geometry.
  * The cross-rank step is one RCCL all-gather of these per-rank partials done by the host framework

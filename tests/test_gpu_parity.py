@@ -884,3 +884,34 @@ def test_large_d_logpdf_gradient(B, dtype, D, N):
     lp, g = B.logpdf_and_gradient(f(np.asfortranarray(X), dtype(0.4)), y)  # isotropic noise: scalar gradient
     lp_i, g_i = O.logpdf_grad(f64(mw), f64(Lw), f64(X), np.float64(dtype(0.4)), f64(y))
     assert float(g["noise"]) == pytest.approx(float(np.sum(g_i["s"])), rel=rt * 10)
+
+
+@pytest.mark.parametrize("dtype,D,N,S", [(np.float64, 5, 13, 4), (np.float64, 128, 900, 70), (np.float64, 300, 700, 130),
+                                         (np.float32, 1024, 3000, 9)])
+def test_shared_x_multi_output_logpdf(B, dtype, D, N, S):
+    # AbstractGPs' logpdf(fx, Y::AbstractMatrix) (reference test/bayesian_linear_regression.jl:7-9 via TestUtils): one Gram +
+    # factorisation for all columns against the per-column literal oracle
+    rng = _rng(9800 + D)
+    X = rng.standard_normal((D, N)).astype(dtype)
+    mw = (0.5 * rng.standard_normal(D)).astype(dtype)
+    Bm = rng.standard_normal((D, D)) / np.sqrt(D)
+    Lw = (Bm @ Bm.T + np.eye(D)).astype(dtype)
+    s = np.exp(0.3 * rng.standard_normal(N)).astype(dtype)
+    Y = rng.standard_normal((N, S)).astype(dtype)
+    f64 = lambda a: np.asarray(a, dtype=float)
+    lp_o = np.array([O.logpdf_literal(f64(mw), f64(Lw), f64(X), f64(s), f64(Y[:, j])) for j in range(S)])
+    m_o = np.stack([O.posterior_logpdf_direct(f64(mw), f64(Lw), f64(X), f64(s), f64(Y[:, j]))[0] for j in range(min(S, 6))], axis=1)
+    rt = 1e-10 if dtype == np.float64 else 3e-4
+    U = O.chol_upper(f64(Lw)).astype(dtype)
+    for Lw_arg in (Lw, B.PDMat(U)):
+        f = B.BayesianLinearRegressor(mw, Lw_arg)
+        for x in (np.asfortranarray(X), B.RowVecs(np.asfortranarray(X.T))):
+            lp, M = B.logpdf_columns(f(x, s), Y, return_means=True)
+            np.testing.assert_allclose(lp, lp_o, rtol=rt)
+            np.testing.assert_allclose(M[:, :m_o.shape[1]], m_o, rtol=rt * 100, atol=rt * 100)
+            np.testing.assert_allclose(B.logpdf(f(x, s), Y), lp_o, rtol=rt)  # the matrix form of logpdf routes here
+    lp_iso = B.logpdf_columns(B.BayesianLinearRegressor(mw, Lw)(np.asfortranarray(X), dtype(0.4)), Y)
+    ref = [O.logpdf_literal(f64(mw), f64(Lw), f64(X), np.float64(dtype(0.4)), f64(Y[:, j])) for j in range(S)]
+    np.testing.assert_allclose(lp_iso, ref, rtol=rt)
+    with pytest.raises(B.PosDefException):
+        B.logpdf_columns(B.BayesianLinearRegressor(mw, -Lw)(np.asfortranarray(X), s), Y)
