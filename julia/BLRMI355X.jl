@@ -297,4 +297,35 @@ function logpdf_grad(fb, y::AbstractVector{<:Real})
     return lp[], dX, dy, ds, dmw, mw′, Ai
 end
 
+# ---- logpdf(fx, Y::AbstractMatrix): shared-X multi-output evidence (AbstractGPs' column-wise fallback) ----------------
+function AbstractGPs.logpdf(fb::FiniteBLR, Y::AbstractMatrix{<:Real})
+    xl, nz, pr = xlayout(fb.x), noise(fb.Σy), prior(fb.f.Λw)
+    (xl === nothing || nz === nothing || pr === nothing) && return [AbstractGPs.logpdf(fb, y) for y in eachcol(Y)]
+    X, layout, ldx, D, N = xl
+    T = eltype(X)
+    s, nk = nz
+    Lw, pk, ldl = pr
+    size(Y, 1) == N || throw(DimensionMismatch("length(y) != size(fx.x.X, 2)"))
+    S = size(Y, 2)
+    Ym = convert(Matrix{T}, Y); mw = convert(Vector{T}, fb.f.mw)
+    lp = Vector{Float64}(undef, S); info = Ref{Int32}(0)
+    h = handle()
+    rc = GC.@preserve X Ym s Lw mw lp begin
+        if T === Float64
+            ccall((:blr_logpdf_multi_f64, LIB), Cint,
+                  (Ptr{Cvoid}, Cint, Cint, Int64, Int64, Int64, Ptr{T}, Int64, Ptr{T}, Int64, Cint, Ptr{T}, Cint, Ptr{T}, Ptr{T},
+                   Int64, Ptr{Cdouble}, Ptr{T}, Int64, Ref{Int32}),
+                  h, MEM_HOST, layout, D, N, S, X, ldx, Ym, N, nk, s, pk, mw, Lw, ldl, lp, C_NULL, D, info)
+        else
+            ccall((:blr_logpdf_multi_f32, LIB), Cint,
+                  (Ptr{Cvoid}, Cint, Cint, Int64, Int64, Int64, Ptr{T}, Int64, Ptr{T}, Int64, Cint, Ptr{T}, Cint, Ptr{T}, Ptr{T},
+                   Int64, Ptr{Cdouble}, Ptr{T}, Int64, Ref{Int32}),
+                  h, MEM_HOST, layout, D, N, S, X, ldx, Ym, N, nk, s, pk, mw, Lw, ldl, lp, C_NULL, D, info)
+        end
+    end
+    check(h, rc)
+    info[] > 0 && throw(PosDefException(info[]))
+    return lp
+end
+
 end # module
