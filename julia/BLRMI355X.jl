@@ -298,7 +298,8 @@ function logpdf_grad(fb, y::AbstractVector{<:Real})
 end
 
 # ---- logpdf(fx, Y::AbstractMatrix): shared-X multi-output evidence (AbstractGPs' column-wise fallback) ----------------
-function AbstractGPs.logpdf(fb::FiniteBLR, Y::AbstractMatrix{<:Real})
+function AbstractGPs.logpdf(fx::FiniteGP{<:Union{BayesianLinearRegressor,BasisFunctionRegressor}}, Y::AbstractMatrix{<:Real})
+    fb = to_blr(fx)
     xl, nz, pr = xlayout(fb.x), noise(fb.Σy), prior(fb.f.Λw)
     (xl === nothing || nz === nothing || pr === nothing) && return [AbstractGPs.logpdf(fb, y) for y in eachcol(Y)]
     X, layout, ldx, D, N = xl
