@@ -158,3 +158,69 @@ def test_hot_kernels_keep_two_workgroups_per_cu(tmp_path):
     assert len(hot) >= 60, f"expected the fused/gram kernels in the code object, found {len(hot)}"
     over = {k: v for k, v in hot.items() if v > 256}
     assert not over, f"kernels above 256 registers (1 workgroup per CU): {over}"
+
+
+def test_julia_shim_ccall_signatures_match_the_header(repo_root):
+    """julia/BLRMI355X.jl cannot run in this image (no julia): at least keep every ccall's argument-type tuple and argument
+    list in step with the prototype in include/blr_mi355x.h (count and integer / pointer / floating kind per position)."""
+    header = open(os.path.join(repo_root, "include", "blr_mi355x.h")).read()
+    header = re.sub(r"/\*.*?\*/", "", header, flags=re.S)
+    protos = {}
+    for m in re.finditer(r"\b(?:int|const char\*)\s+(blr_[a-z0-9_]+)\s*\(([^;]*?)\)\s*;", header, flags=re.S):
+        params = [p.strip() for p in m.group(2).replace("\n", " ").split(",") if p.strip() and p.strip() != "void"]
+        kinds = []
+        for p in params:
+            if "*" in p:
+                kinds.append("ptr")
+            elif re.match(r"(const\s+)?(double|float)\b", p):
+                kinds.append("fp")
+            else:
+                kinds.append("int")
+        protos[m.group(1)] = kinds
+    jl = open(os.path.join(repo_root, "julia", "BLRMI355X.jl")).read()
+
+    def split_top(sarg):
+        out, depth, cur = [], 0, ""
+        for ch in sarg:
+            if ch in "([{":
+                depth += 1
+            elif ch in ")]}":
+                depth -= 1
+            if ch == "," and depth == 0:
+                out.append(cur.strip())
+                cur = ""
+            else:
+                cur += ch
+        if cur.strip():
+            out.append(cur.strip())
+        return out
+
+    seen = 0
+    for m in re.finditer(r"ccall\(\(:(blr_[a-z0-9_]+), LIB\),\s*(\w+),\s*\(", jl):
+        name = m.group(1)
+        # the type tuple: balanced parentheses starting at the match end - 1
+        i = m.end() - 1
+        depth, j = 0, i
+        while True:
+            depth += jl[j] == "("
+            depth -= jl[j] == ")"
+            j += 1
+            if depth == 0:
+                break
+        types = split_top(jl[i + 1:j - 1])
+        # the call arguments run to the parenthesis that closes ccall(
+        k, depth = j, 1
+        while depth:
+            depth += jl[k] == "("
+            depth -= jl[k] == ")"
+            k += 1
+        args = split_top(jl[j:k - 1].lstrip(", \n"))
+        assert name in protos, f"{name} is not declared in the header"
+        want = protos[name]
+        assert len(types) == len(want), f"{name}: {len(types)} ccall types vs {len(want)} parameters in the header"
+        assert len(args) == len(want), f"{name}: {len(args)} ccall arguments vs {len(want)} parameters in the header"
+        for pos, (t, kind) in enumerate(zip(types, want)):
+            got = "ptr" if t.startswith(("Ptr", "Ref", "Cstring")) else ("fp" if t in ("T", "Cdouble", "Cfloat", "Float64", "Float32") else "int")
+            assert got == kind, f"{name}: argument {pos + 1} is {t} in the shim but {kind} in the header"
+        seen += 1
+    assert seen >= 12
