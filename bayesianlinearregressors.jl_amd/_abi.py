@@ -76,6 +76,9 @@ for _suf in ("f64", "f32"):
          _vp, _vp, _i64, _i64, _vp, _i64, _vp, _i64, _vp, _i64, _vp, _i64, _vp, _i64, _i64, _vp], _int)
     _SIGS[f"blr_logpdf_multi_{_suf}"] = (
         [_H, _int, _int, _i64, _i64, _i64, _vp, _i64, _vp, _i64, _int, _vp, _int, _vp, _vp, _i64, _vp, _vp, _i64, _vp], _int)
+    _SIGS[f"blr_gram_stats_{_suf}"] = ([_H, _int, _i64, _i64, _vp, _i64, _vp, _int, _vp, _vp, _vp, _i64, _vp], _int)
+    _SIGS[f"blr_posterior_from_stats_{_suf}"] = (
+        [_H, _i64, _i64, _vp, _i64, _vp, _int, _vp, _vp, _i64, _vp, _vp, _i64, _vp, _i64, _vp, _vp], _int)
     _fp = C.c_double if _suf == "f64" else C.c_float
     _SIGS[f"blr_rff_features_{_suf}"] = (
         [_H, _int, _i64, _i64, _i64, _vp, _i64, _vp, _i64, _vp, _fp, _vp, _i64], _int)
@@ -219,6 +222,16 @@ class Handle:
         fn = getattr(self.lib, f"blr_logpdf_multi_{suffix(dtype)}")
         return self.check(fn(self._h, memspace, layout, D, N, S, _ptr(X), ldx, _ptr(Y), ldY, noise_kind, _ptr(s), prior_kind,
                              _ptr(mw), _ptr(Lw), ldl, _ptr(logpdf), _ptr(mw_post), ldmp, _ptr(info)))
+
+    def gram_stats(self, dtype, layout, D, N, X, ldx, y, noise_kind, s, mw, stats, lds, scal):
+        fn = getattr(self.lib, f"blr_gram_stats_{suffix(dtype)}")
+        return self.check(fn(self._h, layout, D, N, _ptr(X), ldx, _ptr(y), noise_kind, _ptr(s), _ptr(mw), _ptr(stats), lds, _ptr(scal)))
+
+    def posterior_from_stats(self, dtype, D, N_total, stats, lds, scal, prior_kind, mw, Lw, ldl, mw_post, T_post, ldt, Lw_post,
+                             ldlp, logpdf, info):
+        fn = getattr(self.lib, f"blr_posterior_from_stats_{suffix(dtype)}")
+        return self.check(fn(self._h, D, N_total, _ptr(stats), lds, _ptr(scal), prior_kind, _ptr(mw), _ptr(Lw), ldl,
+                             _ptr(mw_post), _ptr(T_post), ldt, _ptr(Lw_post), ldlp, _ptr(logpdf), _ptr(info)))
 
     def marginals_batched(self, dtype, memspace, layout, B, D, N, X, ldx, strideX, noise_kind, s, strides, prior_kind,
                           mw, stridemw, Lw, ldl, strideLw, mean, stridemean, var, stridevar, info):

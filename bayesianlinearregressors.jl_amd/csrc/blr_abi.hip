@@ -706,6 +706,153 @@ int marginals_batched(blr_handle* h, int memspace, int layout, int64_t B, int64_
   return 0;
 }
 
+// ---- N-sharded single regressor: additive statistics of a column block, and the finish from their sum ----
+template <typename T>
+int gram_stats(blr_handle* h, int layout, int64_t D64, int64_t N64, const T* X, int64_t ldx, const T* y, int noise_kind,
+               const T* s, const T* mw, T* stats, int64_t lds, double* scal) {
+  if (!h) return -1;
+  h->err.clear();
+  if (layout != BLR_LAYOUT_COLVECS && layout != BLR_LAYOUT_ROWVECS) return bad_arg(h, 2, "unknown layout (reference :26-31)");
+  if (D64 < 1 || D64 > kMaxLargeD) return bad_arg(h, 3, "D out of range for this build (1..8192)");
+  if (N64 < 1 || N64 > (1 << 30)) return bad_arg(h, 4, "N out of range (>= 1)");
+  const int D = (int)D64, N = (int)N64;
+  const int DP = (D + kPB - 1) / kPB * kPB, NC = DP / kPB;
+  if (!X) return bad_arg(h, 5, "X is NULL");
+  if (layout == BLR_LAYOUT_COLVECS ? ldx < D : ldx < N) return bad_arg(h, 6, "ldx too small");
+  if (!y) return bad_arg(h, 7, "y is NULL");
+  if (noise_kind != BLR_NOISE_ISOTROPIC && noise_kind != BLR_NOISE_DIAGONAL) return bad_arg(h, 8, "noise_kind");
+  if (!s) return bad_arg(h, 9, "s is NULL");
+  if (!mw) return bad_arg(h, 10, "mw is NULL");
+  if (!stats) return bad_arg(h, 11, "stats is NULL");
+  if (lds < DP + kPB) return bad_arg(h, 12, "lds < 128 ceil(D/128) + 128");
+  if (!scal) return bad_arg(h, 13, "scal is NULL");
+  HIP_TRY(h, hipSetDevice(h->device));
+  using LC = LargeCfg<T>;
+  const int ntiles = NC * (NC + 1) / 2;
+  const int max_split = std::max(1, std::min(64, (N + LC::NSC - 1) / LC::NSC));
+  int nsplit = 1;
+  double best = 0.0;
+  for (int sp = 1; sp <= max_split; ++sp) {
+    const int wgs = ntiles * sp;
+    const int rounds = (wgs + 511) / 512;
+    const double eff = (double)wgs / (rounds * 512.0) - 0.002 * sp;
+    if (eff > best) { best = eff; nsplit = sp; }
+  }
+  const int gridc = 1024;
+  size_t off = 0;
+  auto carve = [&](size_t bytes) { size_t o = off; off = (off + bytes + 255) & ~(size_t)255; return o; };
+  const size_t o_gp = carve((size_t)nsplit * ntiles * kPB * kPB * sizeof(T));
+  const size_t o_bp = carve((size_t)nsplit * NC * kPB * sizeof(double));
+  const size_t o_r = carve((size_t)N * sizeof(T));
+  const size_t o_q = carve((size_t)gridc * sizeof(double));
+  const size_t o_l = carve((size_t)gridc * sizeof(double));
+  int rc = ensure_ws(h, off);
+  if (rc) return rc;
+  char* ws = h->ws;
+  T* Gpart = reinterpret_cast<T*>(ws + o_gp);
+  double* bpart = reinterpret_cast<double*>(ws + o_bp);
+  T* rvec = reinterpret_cast<T*>(ws + o_r);
+  double* qpart = reinterpret_cast<double*>(ws + o_q);
+  double* lpart = reinterpret_cast<double*>(ws + o_l);
+  HIP_TRY(h, hipMemsetAsync(bpart, 0, (size_t)nsplit * NC * kPB * sizeof(double), h->stream));
+  {
+    ColstatsArgs<T> c{};
+    c.X = X; c.ldx = ldx; c.y = y; c.s = s; c.mw = mw; c.r = rvec; c.qpart = qpart; c.lpart = lpart;
+    c.layout = layout; c.noise_kind = noise_kind; c.D = D; c.N = N;
+    size_t ldsb = (((size_t)D * sizeof(T) + 15) & ~(size_t)15) + 64;
+    hipLaunchKernelGGL(colstats_kernel<T>, dim3(gridc), dim3(kThreads), ldsb, h->stream, c);
+    hipLaunchKernelGGL(stats_scalars_kernel<T>, dim3(1), dim3(kThreads), 0, h->stream, (const double*)qpart, (const double*)lpart, gridc,
+                       noise_kind, s, N, scal);
+  }
+  if ((rc = set_lds<T>(h, reinterpret_cast<const void*>(gram_tile_kernel<T>), LC::LDS_BYTES))) return rc;
+  {
+    GramTileArgs<T> g{};
+    g.X = X; g.ldx = ldx; g.layout = layout;
+    g.use_dma = (layout == LAYOUT_COLVECS && ((uintptr_t)X % 16 == 0) && ((ldx * (int64_t)sizeof(T)) % 16 == 0)) ? 1 : 0;
+    g.s = s; g.noise_kind = noise_kind; g.r = rvec;
+    g.D = D; g.n_begin = 0; g.n_end = N; g.nsplit = nsplit;
+    g.tile_i0 = 0; g.tile_j0 = 0; g.tri = 1; g.ntiles = ntiles; g.nblocks = NC;
+    g.Gpart = Gpart; g.bpart = bpart; g.mode_out = 0; g.xcd_swizzle = nsplit > 1 ? 1 : 0;
+    hipLaunchKernelGGL(gram_tile_kernel<T>, dim3(ntiles * nsplit), dim3(kThreads), LC::LDS_BYTES, h->stream, g);
+    ReduceArgs<T> r{};
+    r.Gpart = Gpart; r.bpart = bpart; r.nsplit_total = nsplit; r.ntiles = ntiles; r.nblocks = NC;
+    r.Lw = nullptr; r.ldl = 0; r.prior_kind = 3 /* none: the prior is added after the cross-rank sum */;
+    r.D = D; r.DP = DP; r.Abar = stats; r.lda = lds; r.Lw_post = nullptr; r.ldlp = 0;
+    hipLaunchKernelGGL(gram_reduce_kernel<T>, dim3(ntiles + NC, 16), dim3(kThreads), 0, h->stream, r);
+  }
+  HIP_TRY(h, hipGetLastError());
+  if (!h->async) HIP_TRY(h, hipStreamSynchronize(h->stream));
+  return 0;
+}
+
+template <typename T>
+int posterior_from_stats(blr_handle* h, int64_t D64, int64_t N_total, T* stats, int64_t lds, const double* scal, int prior_kind,
+                         const T* mw, const T* Lw, int64_t ldl, T* mw_post, T* T_post, int64_t ldt, T* Lw_post, int64_t ldlp,
+                         double* logpdf, int32_t* info) {
+  if (!h) return -1;
+  h->err.clear();
+  if (D64 < 1 || D64 > kMaxLargeD) return bad_arg(h, 2, "D out of range for this build (1..8192)");
+  if (N_total < 0 || N_total > ((int64_t)1 << 40)) return bad_arg(h, 3, "N_total out of range");
+  const int D = (int)D64;
+  const int DP = (D + kPB - 1) / kPB * kPB, NC = DP / kPB;
+  if (!stats) return bad_arg(h, 4, "stats is NULL");
+  if (lds < DP + kPB) return bad_arg(h, 5, "lds < 128 ceil(D/128) + 128");
+  if (!scal) return bad_arg(h, 6, "scal is NULL");
+  if (prior_kind != BLR_PRIOR_DENSE && prior_kind != BLR_PRIOR_DIAGONAL)
+    return bad_arg(h, 7, "prior_kind (dense or diagonal precision; pass a carried-forward factor as U'U)");
+  if (!mw) return bad_arg(h, 8, "mw is NULL");
+  if (!Lw) return bad_arg(h, 9, "Lw is NULL");
+  if (prior_kind == BLR_PRIOR_DENSE && ldl < D) return bad_arg(h, 10, "ldl < D");
+  if (T_post && ldt < D) return bad_arg(h, 13, "ldt < D");
+  if (Lw_post && ldlp < D) return bad_arg(h, 15, "ldlp < D");
+  if (!info) return bad_arg(h, 17, "info is NULL");
+  HIP_TRY(h, hipSetDevice(h->device));
+  size_t off = 0;
+  auto carve = [&](size_t bytes) { size_t o = off; off = (off + bytes + 255) & ~(size_t)255; return o; };
+  const size_t o_w = carve(prior_kind == BLR_PRIOR_DENSE ? (size_t)DP * DP * sizeof(T) : 0);
+  const size_t o_m = carve((size_t)DP * DP * sizeof(T));
+  const size_t o_sc = carve(64);
+  int rc = ensure_ws(h, off);
+  if (rc) return rc;
+  char* ws = h->ws;
+  T* W = reinterpret_cast<T*>(ws + o_w);
+  T* Tfull = reinterpret_cast<T*>(ws + o_m);
+  double* logdetLw = reinterpret_cast<double*>(ws + o_sc);
+  int32_t* info_prior = reinterpret_cast<int32_t*>(ws + o_sc + 8);
+  int32_t* info_chol = reinterpret_cast<int32_t*>(ws + o_sc + 12);
+  HIP_TRY(h, hipMemsetAsync(ws + o_sc, 0, 64, h->stream));
+  if (prior_kind == BLR_PRIOR_DENSE) {
+    hipLaunchKernelGGL(prior_copy_kernel<T>, dim3(1024), dim3(kThreads), 0, h->stream, Lw, ldl, D, DP, W, (int64_t)DP);
+    if ((rc = chol_large<T>(h, W, DP, DP, DP, info_prior))) return rc;
+    hipLaunchKernelGGL(logdet_kernel<T>, dim3(1), dim3(kThreads), 0, h->stream, (const T*)W, (int64_t)DP, D, logdetLw);
+  } else {
+    hipLaunchKernelGGL(prior_diag_kernel<T>, dim3(1), dim3(kThreads), 0, h->stream, Lw, ldl, prior_kind, D, logdetLw, info_prior);
+  }
+  hipLaunchKernelGGL(stats_add_prior_kernel<T>, dim3(1024), dim3(kThreads), 0, h->stream, stats, lds, D, DP, Lw, ldl, prior_kind,
+                     Lw_post, ldlp);
+  HIP_TRY(h, hipMemcpyAsync(info_chol, info_prior, sizeof(int32_t), hipMemcpyDeviceToDevice, h->stream));
+  if ((rc = chol_large<T>(h, stats, lds, DP, DP + kPB, info_chol))) return rc;
+  {
+    dim3 grid((DP + 31) / 32, (DP + 31) / 32);
+    hipLaunchKernelGGL(transpose_out_kernel<T>, grid, dim3(kThreads), 0, h->stream, (const T*)stats, lds, DP, Tfull, (int64_t)DP,
+                       T_post, ldt, D);
+  }
+  {
+    WaveSolveArgs<T> b{};
+    b.Tf = Tfull; b.ldtf = DP; b.D = D; b.DP = DP;
+    b.rhs = stats + DP; b.ldrhs = 0; b.rhs_inc = lds;
+    b.add = mw; b.out = mw_post; b.ldout = 0;
+    b.qpart = scal; b.lpart = scal + 1; b.nparts = 1; b.logdet_Lw_dev = logdetLw;
+    b.noise_kind = BLR_NOISE_DIAGONAL; b.s = mw /* unused */; b.N = (int)std::min<int64_t>(N_total, 0x7fffffff);
+    b.logpdf = logpdf; b.info = info; b.chol_info = info_chol;
+    b.n_total = (double)N_total;
+    if ((rc = launch_wave_solve<T>(h, b, NC, 1))) return rc;
+  }
+  HIP_TRY(h, hipGetLastError());
+  if (!h->async) HIP_TRY(h, hipStreamSynchronize(h->stream));
+  return 0;
+}
+
 // ---- gradient for D > 128, one regressor: forward + backward panels over the tall matrix [F; X'; I] ----------------------
 template <typename T>
 int logpdf_grad_large_one(blr_handle* h, int layout, int64_t D, int64_t N, const T* X, int64_t ldx, const T* y, int noise_kind,
@@ -1633,6 +1780,17 @@ int blr_timer_stop(blr_handle* h, float* elapsed_ms) {
                              int32_t* info) {                                                                       \
     return logpdf_multi<T>(h, memspace, layout, D, N, S, X, ldx, Y, ldY, noise_kind, s, prior_kind, mw, Lw, ldl,     \
                            logpdf, mw_post, ldmp, info);                                                            \
+  }                                                                                                                 \
+  int blr_gram_stats_##SUF(blr_handle* h, int layout, int64_t D, int64_t N, const T* X, int64_t ldx, const T* y,    \
+                           int noise_kind, const T* s, const T* mw, T* stats, int64_t lds, double* scal) {          \
+    return gram_stats<T>(h, layout, D, N, X, ldx, y, noise_kind, s, mw, stats, lds, scal);                          \
+  }                                                                                                                 \
+  int blr_posterior_from_stats_##SUF(blr_handle* h, int64_t D, int64_t N_total, T* stats, int64_t lds,              \
+                                     const double* scal, int prior_kind, const T* mw, const T* Lw, int64_t ldl,     \
+                                     T* mw_post, T* T_post, int64_t ldt, T* Lw_post, int64_t ldlp, double* logpdf,  \
+                                     int32_t* info) {                                                               \
+    return posterior_from_stats<T>(h, D, N_total, stats, lds, scal, prior_kind, mw, Lw, ldl, mw_post, T_post, ldt,   \
+                                   Lw_post, ldlp, logpdf, info);                                                    \
   }                                                                                                                 \
   int blr_posterior_rff_##SUF(blr_handle* h, int memspace, int64_t Din, int64_t D, int64_t N, const T* Xin,         \
                               int64_t ldxin, const T* Omega, int64_t ldo, const T* phase, T scale, const T* y,      \

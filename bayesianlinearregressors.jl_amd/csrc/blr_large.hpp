@@ -915,6 +915,7 @@ struct WaveSolveArgs {
   const double* qpart; const double* lpart; int nparts;
   const double* logdet_Lw_dev;
   int noise_kind; const T* s; int N;
+  double n_total;                        // > 0: number of observations behind the (summed) statistics (N-sharded finish)
   double* logpdf; int32_t* info; const int32_t* chol_info;
 };
 
@@ -1059,8 +1060,9 @@ __global__ __launch_bounds__(kThreads) void backsolve_wave_kernel(WaveSolveArgs<
     *a.info = 0;
     if (a.logpdf) {
       const double LOG2PI = 1.8378770664093454835606594728112;
-      const double logdet_Sy = (a.noise_kind == NOISE_DIAGONAL) ? ls : (double)a.N * log((double)a.s[0]);
-      *a.logpdf = -0.5 * ((double)a.N * LOG2PI + logdet_Sy + qs + ld - *a.logdet_Lw_dev - uu);
+      const double nobs = a.n_total > 0.0 ? a.n_total : (double)a.N;
+      const double logdet_Sy = (a.noise_kind == NOISE_DIAGONAL) ? ls : nobs * log((double)a.s[0]);
+      *a.logpdf = -0.5 * (nobs * LOG2PI + logdet_Sy + qs + ld - *a.logdet_Lw_dev - uu);
     }
   }
 }
@@ -1968,6 +1970,46 @@ __global__ __launch_bounds__(kThreads) void multi_means_kernel(const T* Ybar, in
   for (int64_t e = (int64_t)blockIdx.x * kThreads + threadIdx.x; e < (int64_t)D * S; e += (int64_t)gridDim.x * kThreads) {
     const int sidx = (int)(e / D), d = (int)(e % D);
     mw_post[(int64_t)sidx * ldmp + d] = mw[d] + Ybar[(int64_t)d * ldy + row0 + sidx];
+  }
+}
+
+// ---- N-sharded single regressor: sufficient statistics of a column block, summed by the host's collective ----
+// stats = the augmented matrix without the prior: lower triangle of G_r = X_r S_r X_r' in rows [0, DP), row DP = b_r';
+// scal = {delta' S delta, logdet Sigma_y} of the block.  All of it is additive over column blocks.
+template <typename T>
+__global__ __launch_bounds__(kThreads) void stats_scalars_kernel(const double* qpart, const double* lpart, int nparts, int noise_kind,
+                                                                 const T* s, int N, double* scal) {
+  __shared__ double scr[8];
+  double q = 0.0, l = 0.0;
+  for (int i = threadIdx.x; i < nparts; i += kThreads) { q += qpart[i]; l += lpart[i]; }
+  q = block_allreduce(q, scr, threadIdx.x);
+  l = block_allreduce(l, scr, threadIdx.x);
+  if (threadIdx.x == 0) {
+    scal[0] = q;
+    scal[1] = (noise_kind == NOISE_DIAGONAL) ? l : (double)N * log((double)s[0]);
+  }
+}
+// summed statistics + prior precision -> the augmented matrix the factorisation expects (padding: unit diagonal, zero rows
+// below b'); optional full symmetric copy of A for the caller
+template <typename T>
+__global__ __launch_bounds__(kThreads) void stats_add_prior_kernel(T* Abar, int64_t lda, int D, int DP, const T* Lw, int64_t ldl,
+                                                                   int prior_kind, T* Lw_post, int64_t ldlp) {
+  for (int64_t e = (int64_t)blockIdx.x * kThreads + threadIdx.x; e < (int64_t)(DP + kPB) * DP; e += (int64_t)gridDim.x * kThreads) {
+    const int col = (int)(e / (DP + kPB)), row = (int)(e % (DP + kPB));
+    T* p = Abar + (int64_t)col * lda + row;
+    if (row < DP) {
+      if (row < col) continue;  // upper triangle: unused
+      if (row >= D) { *p = (row == col) ? T(1) : T(0); continue; }
+      T v = *p;
+      if (prior_kind == PRIOR_DENSE) v += Lw[(int64_t)row * ldl + col];  // upper entry (col, row)
+      else if (prior_kind == PRIOR_DIAGONAL && row == col) v += Lw[row];
+      *p = v;
+      if (Lw_post) { Lw_post[(int64_t)col * ldlp + row] = v; Lw_post[(int64_t)row * ldlp + col] = v; }
+    } else if (row == DP) {
+      if (col >= D) *p = T(0);
+    } else {
+      *p = T(0);
+    }
   }
 }
 

@@ -43,3 +43,60 @@ def gather_logpdf(local_logpdf, total: int, group=None):
     out = torch.empty(world * nmax, dtype=local_logpdf.dtype, device=local_logpdf.device)
     dist.all_gather_into_tensor(out, padded, group=group)
     return torch.cat([out[r * nmax : r * nmax + sizes[r]] for r in range(world)])
+
+
+# ---- one large regressor, observations split over ranks (SURVEY.md 8e "one-exchange N-sharding") ---------------------
+def stats_shape(D: int) -> tuple[int, int]:
+    """(rows, cols) of the additive statistics matrix of `blr_gram_stats_*`: (DP + 128) x DP, DP = 128 ceil(D / 128)."""
+    DP = (D + 127) // 128 * 128
+    return DP + 128, DP
+
+
+def reduce_stats(stats, scal, group=None):
+    """The path's single exchange: sum the additive statistics over the ranks, in place (two all-reduces: the matrix in its
+    own dtype, the two evidence scalars in float64).  No-op without an initialised process group."""
+    import torch.distributed as dist
+
+    if dist.is_available() and dist.is_initialized() and dist.get_world_size(group) > 1:
+        dist.all_reduce(stats, op=dist.ReduceOp.SUM, group=group)
+        dist.all_reduce(scal, op=dist.ReduceOp.SUM, group=group)
+    return stats, scal
+
+
+def posterior_n_sharded(handle, X_local, y_local, noise, mw, Lw, n_total: int, group=None):
+    """posterior + logpdf of ONE regressor whose columns are split over the ranks (each rank passes its own block).
+
+    Device-resident torch tensors: ``X_local`` D x N_local column-major (i.e. a contiguous ``[N_local, D]`` tensor),
+    ``y_local`` [N_local], ``noise`` a 1-element tensor (isotropic) or [N_local] (diagonal), ``mw`` [D], ``Lw`` [D] (diagonal
+    precision) or a contiguous symmetric [D, D].  Every rank returns the same ``(mw_post [D], T_post [D, D] (row-major view of the
+    column-major upper factor, i.e. T_post.T is U), logpdf float)``.
+    """
+    import numpy as np
+    import torch
+    from . import _abi
+
+    dt = np.float64 if X_local.dtype == torch.float64 else np.float32
+    n_loc, D = X_local.shape
+    rows, cols = stats_shape(D)
+    dev = X_local.device
+    stats = torch.zeros((cols, rows), dtype=X_local.dtype, device=dev)  # column-major (rows x cols), lds = rows
+    scal = torch.zeros(2, dtype=torch.float64, device=dev)
+    diag_noise = noise.numel() > 1
+    handle.gram_stats(dt, _abi.LAYOUT_COLVECS, D, n_loc, X_local.data_ptr(), D, y_local.data_ptr(),
+                      _abi.NOISE_DIAGONAL if diag_noise else _abi.NOISE_ISOTROPIC, noise.data_ptr(), mw.data_ptr(),
+                      stats.data_ptr(), rows, scal.data_ptr())
+    handle.synchronize()
+    reduce_stats(stats, scal, group)
+    mw_post = torch.empty(D, dtype=X_local.dtype, device=dev)
+    T_post = torch.zeros((D, D), dtype=X_local.dtype, device=dev)
+    lp = torch.zeros(1, dtype=torch.float64, device=dev)
+    info = torch.zeros(1, dtype=torch.int32, device=dev)
+    dense = Lw.dim() == 2
+    handle.posterior_from_stats(dt, D, int(n_total), stats.data_ptr(), rows, scal.data_ptr(),
+                                _abi.PRIOR_DENSE if dense else _abi.PRIOR_DIAGONAL, mw.data_ptr(), Lw.data_ptr(), D if dense else 1,
+                                mw_post.data_ptr(), T_post.data_ptr(), D, None, D, lp.data_ptr(), info.data_ptr())
+    handle.synchronize()
+    code = int(info.item())
+    if code != 0:
+        raise _abi.PosDefException(code)
+    return mw_post, T_post, float(lp.item())

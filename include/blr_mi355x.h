@@ -233,6 +233,28 @@ int blr_logpdf_multi_f32(blr_handle* h, int memspace, int layout, int64_t D, int
                          const float* mw, const float* Lw, int64_t ldl, double* logpdf, float* mw_post, int64_t ldmp,
                          int32_t* info);
 
+/* ---- N-sharded single regressor ("one-exchange N-sharding") -------------------------
+ * A regressor too large for one GPU's share of time (config 3) splits its N observations over ranks.  Everything the
+ * update needs from the data is additive over column blocks:
+ *   blr_gram_stats_*            per rank, on its columns: stats = (DP + 128) x DP column-major (lds >= DP + 128,
+ *                               DP = 128 ceil(D/128)): lower triangle of X S X' in rows [0, DP), row DP = (X S (y - X'mw))';
+ *                               scal[2] = { (y - X'mw)' S (y - X'mw), logdet Sigma_y } of the block.
+ *   (host)                      ONE sum over ranks of `stats` and `scal` (RCCL all-reduce through torch.distributed /
+ *                               MPI.jl) -- the only exchange.
+ *   blr_posterior_from_stats_*  on every rank (redundant D x D work): adds the prior precision (dense or diagonal),
+ *                               factorises, solves; outputs as blr_posterior_*.  `stats` is overwritten.
+ * Device pointers only.  Works for any D (the large-D pipeline); N_total = observations over all ranks. */
+int blr_gram_stats_f64(blr_handle* h, int layout, int64_t D, int64_t N, const double* X, int64_t ldx, const double* y,
+                       int noise_kind, const double* s, const double* mw, double* stats, int64_t lds, double* scal);
+int blr_gram_stats_f32(blr_handle* h, int layout, int64_t D, int64_t N, const float* X, int64_t ldx, const float* y,
+                       int noise_kind, const float* s, const float* mw, float* stats, int64_t lds, double* scal);
+int blr_posterior_from_stats_f64(blr_handle* h, int64_t D, int64_t N_total, double* stats, int64_t lds, const double* scal,
+                                 int prior_kind, const double* mw, const double* Lw, int64_t ldl, double* mw_post,
+                                 double* T_post, int64_t ldt, double* Lw_post, int64_t ldlp, double* logpdf, int32_t* info);
+int blr_posterior_from_stats_f32(blr_handle* h, int64_t D, int64_t N_total, float* stats, int64_t lds, const double* scal,
+                                 int prior_kind, const float* mw, const float* Lw, int64_t ldl, float* mw_post,
+                                 float* T_post, int64_t ldt, float* Lw_post, int64_t ldlp, double* logpdf, int32_t* info);
+
 /* ---- sharded log-evidence: fixed-order sum of logpdf[B] on the device ----------
  * Deterministic (no float atomics): the same bits for the same B regardless of launch geometry.
  * The cross-rank step is one RCCL all-gather of these per-rank partials done by the host framework

@@ -915,3 +915,65 @@ def test_shared_x_multi_output_logpdf(B, dtype, D, N, S):
     np.testing.assert_allclose(lp_iso, ref, rtol=rt)
     with pytest.raises(B.PosDefException):
         B.logpdf_columns(B.BayesianLinearRegressor(mw, -Lw)(np.asfortranarray(X), s), Y)
+
+
+@pytest.mark.parametrize("dtype,D,N,noise,prior", [(np.float64, 5, 40, "diag", "dense"), (np.float64, 130, 500, "iso", "diag"),
+                                                   (np.float64, 300, 900, "diag", "dense"), (np.float32, 1024, 4000, "diag", "diag")])
+def test_n_sharded_single_regressor(B, dtype, D, N, noise, prior):
+    # the observations of ONE regressor split into column blocks (as over ranks); the additive statistics of the
+    # blocks are summed (here with torch, across ranks by ONE all-reduce) and every rank finishes redundantly
+    import torch
+    from blr_amd import _abi, sharding
+
+    rng = _rng(9900 + D)
+    X = rng.standard_normal((D, N)).astype(dtype)
+    mw = (0.5 * rng.standard_normal(D)).astype(dtype)
+    if prior == "dense":
+        Bm = rng.standard_normal((D, D)) / np.sqrt(D)
+        Lw = (Bm @ Bm.T + np.eye(D)).astype(dtype)
+    else:
+        Lw = np.exp(0.3 * rng.standard_normal(D)).astype(dtype)
+    s = np.exp(0.3 * rng.standard_normal(N)).astype(dtype) if noise == "diag" else np.array([0.37], dtype=dtype)
+    y = rng.standard_normal(N).astype(dtype)
+    f64 = lambda a: np.asarray(a, dtype=float)
+    Lw_ref = f64(Lw) if prior == "dense" else np.diag(f64(Lw))
+    mw_o, T_o, A_o, lp_o = O.posterior_logpdf_direct(f64(mw), Lw_ref, f64(X), f64(s) if noise == "diag" else np.float64(s[0]), f64(y))
+    dev = torch.device("cuda:0")
+    tdt = torch.float64 if dtype == np.float64 else torch.float32
+    h = _abi.default_handle()
+    rows, cols = sharding.stats_shape(D)
+    bounds = [0, N // 3, N // 3 + 1, N]  # three uneven "ranks", one of them a single column
+    tot = torch.zeros((cols, rows), dtype=tdt, device=dev)
+    sc = torch.zeros(2, dtype=torch.float64, device=dev)
+    mw_t = torch.tensor(mw, device=dev)
+    for lo, hi in zip(bounds[:-1], bounds[1:]):
+        Xl = torch.tensor(np.ascontiguousarray(X[:, lo:hi].T), device=dev)
+        yl = torch.tensor(y[lo:hi], device=dev)
+        sl = torch.tensor(s[lo:hi] if noise == "diag" else s, device=dev)
+        st = torch.zeros((cols, rows), dtype=tdt, device=dev)
+        sca = torch.zeros(2, dtype=torch.float64, device=dev)
+        h.gram_stats(dtype, _abi.LAYOUT_COLVECS, D, hi - lo, Xl.data_ptr(), D, yl.data_ptr(),
+                     _abi.NOISE_DIAGONAL if noise == "diag" else _abi.NOISE_ISOTROPIC, sl.data_ptr(), mw_t.data_ptr(), st.data_ptr(), rows,
+                     sca.data_ptr())
+        h.synchronize()
+        tot += st
+        sc += sca
+    Lw_t = torch.tensor(np.ascontiguousarray(Lw), device=dev)
+    mw_p = torch.empty(D, dtype=tdt, device=dev); Tp = torch.zeros((D, D), dtype=tdt, device=dev)
+    Ap = torch.zeros((D, D), dtype=tdt, device=dev)
+    lp = torch.zeros(1, dtype=torch.float64, device=dev); info = torch.zeros(1, dtype=torch.int32, device=dev)
+    h.posterior_from_stats(dtype, D, N, tot.data_ptr(), rows, sc.data_ptr(), _abi.PRIOR_DENSE if prior == "dense" else _abi.PRIOR_DIAGONAL,
+                           mw_t.data_ptr(), Lw_t.data_ptr(), D if prior == "dense" else 1, mw_p.data_ptr(), Tp.data_ptr(), D, Ap.data_ptr(), D,
+                           lp.data_ptr(), info.data_ptr())
+    h.synchronize()
+    assert int(info.item()) == 0
+    rt = 1e-9 if dtype == np.float64 else 3e-3
+    assert float(lp.item()) == pytest.approx(lp_o, rel=1e-10 if dtype == np.float64 else 3e-4)
+    np.testing.assert_allclose(mw_p.cpu().numpy(), mw_o, rtol=rt, atol=rt * 10)
+    np.testing.assert_allclose(Tp.cpu().numpy().T, T_o, rtol=rt, atol=rt * 10)  # column-major upper factor
+    np.testing.assert_allclose(Ap.cpu().numpy(), A_o, rtol=rt, atol=rt * 10)
+    # the helper (no process group: a single "rank" holding everything) gives the same answer
+    Xall = torch.tensor(np.ascontiguousarray(X.T), device=dev)
+    m2, T2, lp2 = sharding.posterior_n_sharded(h, Xall, torch.tensor(y, device=dev), torch.tensor(s, device=dev), mw_t, Lw_t, N)
+    assert lp2 == pytest.approx(lp_o, rel=1e-10 if dtype == np.float64 else 3e-4)
+    np.testing.assert_allclose(m2.cpu().numpy(), mw_o, rtol=rt, atol=rt * 10)

@@ -82,3 +82,42 @@ def test_gather_is_rank_count_independent():
         lp_all = _lp_all(total)
         assert raw == lp_all.tobytes(), f"rank {rank}: gathered vector differs"
         assert tot == fixed_order_sum(lp_all)  # bitwise: same order of additions for every rank count
+
+
+def _stats_worker(rank, world, port, q):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    rows, cols = sharding.stats_shape(130)
+    g = torch.Generator().manual_seed(100 + rank)
+    stats = torch.randn((cols, rows), generator=g, dtype=torch.float64)
+    scal = torch.randn(2, generator=g, dtype=torch.float64)
+    mine = (stats.clone(), scal.clone())
+    sharding.reduce_stats(stats, scal)
+    q.put((rank, mine[0].numpy().tobytes(), mine[1].numpy().tobytes(), stats.numpy().tobytes(), scal.numpy().tobytes()))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_n_sharded_statistics_are_summed_once_and_identically():
+    """The single exchange of the N-sharded path: both ranks end with the SAME sum of the additive statistics."""
+    assert sharding.stats_shape(1) == (256, 128) and sharding.stats_shape(128) == (256, 128) and sharding.stats_shape(129) == (384, 256)
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    procs = [ctx.Process(target=_stats_worker, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    res = sorted(q.get(timeout=240) for _ in range(2))
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    rows, cols = sharding.stats_shape(130)
+    own = [np.frombuffer(r[1], dtype=np.float64) for r in res]
+    own_s = [np.frombuffer(r[2], dtype=np.float64) for r in res]
+    for r in res:
+        np.testing.assert_array_equal(np.frombuffer(r[3], dtype=np.float64), own[0] + own[1])
+        np.testing.assert_array_equal(np.frombuffer(r[4], dtype=np.float64), own_s[0] + own_s[1])
+    assert res[0][3] == res[1][3] and res[0][4] == res[1][4]
