@@ -267,23 +267,35 @@ __global__ __launch_bounds__(kThreads, 2) void gram_tile_kernel(GramTileArgs<T> 
   const T* const baseB = a.XB ? a.XB : a.X;
   const int64_t ldB = a.XB ? a.ldxb : a.ldx;
   const int rowsB = a.XB ? a.DB : a.D;
+  // per-column scalars (1/s_n, r_n) of a stage travel through registers one stage ahead: loading them inside issue() and
+  // storing them to LDS right away made wave 0 sit out a full memory latency at the top of EVERY stage, with the other
+  // three waves waiting for it at the next barrier (measured: 791 -> see DESIGN.md us for the c3 Gram launch)
+  T s_reg = T(1), r_reg = T(0);
+  bool in_reg = false;
+  auto load_scalars = [&](int st) {
+    in_reg = false;
+    if (tid < L::NSC) {
+      const int n = c0 + st * L::NSC + tid;
+      if (st < nstages && n < c1) {
+        in_reg = true;
+        s_reg = a.s ? (diag_noise ? a.s[n] : s_iso) : T(1);
+        r_reg = want_b ? a.r[n] : T(0);
+      }
+    }
+  };
   auto issue = [&](int st) {
     const int n0 = c0 + st * L::NSC;
     T* slot = slot0 + (st & 1) * L::SLOT;
     load_side(slot, a.X, a.ldx, a.D, rowA, n0);
     if (!diag_tile) load_side(slot + L::SIDE, baseB, ldB, rowsB, rowB, n0);
     if (tid < L::NSC) {
-      const int n = n0 + tid;
-      T wv = T(0), rv = T(0);
-      if (n < c1) {
-        wv = a.s ? T(1) / (diag_noise ? a.s[n] : s_iso) : T(1);
-        if (want_b) rv = a.r[n];
-      }
-      wbuf[(st & 1) * L::NSC + tid] = wv;
-      rbuf[(st & 1) * L::NSC + tid] = rv;
+      wbuf[(st & 1) * L::NSC + tid] = in_reg ? T(1) / s_reg : T(0);
+      rbuf[(st & 1) * L::NSC + tid] = in_reg ? r_reg : T(0);
     }
+    load_scalars(st + 1);  // in flight until the next issue()
   };
 
+  load_scalars(0);
   if (nstages > 0) issue(0);
   for (int st = 0; st < nstages; ++st) {
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
