@@ -32,7 +32,7 @@ PEAK_TF = {"f64": 78.6, "f32": 157.3}
 # what tools/mfma_peak.hip sustains on this pool: v_mfma_f64_16x16x4 tops out at 47.7 TF
 MEASURED_MFMA_TF = {"f64": 47.7, "f32": 155.0}
 # HBM bytes per regressor from the PMC passes summarised in profiles/r01_pmc_summary.json (FETCH_SIZE x2 + WRITE_SIZE)
-PMC_TRAFFIC_BYTES_PER_UPDATE = {("f64", 128, 4096, "isotropic"): 4933346061.7 / 1024}
+PMC_TRAFFIC_BYTES_PER_UPDATE = {("f64", 128, 4096, "isotropic"): 19772626176.0 / 4096}
 
 
 def algorithmic_bytes(D, N, w, diag_noise):
@@ -92,7 +92,7 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=3)
-    ap.add_argument("--batch", type=int, default=1024, help="regressors per GPU per step")
+    ap.add_argument("--batch", type=int, default=4096, help="regressors per GPU per step (17 GB of X at the c2 shape)")
     ap.add_argument("--D", type=int, default=128)
     ap.add_argument("--N", type=int, default=4096)
     ap.add_argument("--dtype", choices=["f64", "f32"], default="f64")

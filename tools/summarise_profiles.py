@@ -64,7 +64,7 @@ if fetch and write:
     wr = write["WRITE_SIZE"] * 1024.0
     summary["c2_fused_small_kernel_hbm"] = {"FETCH_SIZE_KiB": fetch["FETCH_SIZE"], "WRITE_SIZE_KiB": write["WRITE_SIZE"],
                                             "hbm_read_bytes_per_launch": rd, "hbm_write_bytes_per_launch": wr,
-                                            "hbm_bytes_per_launch": rd + wr, "units_per_launch": 1024}
+                                            "hbm_bytes_per_launch": rd + wr, "units_per_launch": 4096}
 for key, c in (("c2_fused_small_kernel_sq", sq2), ("c3_gram_tile_kernel_sq", sq3)):
     if c:
         ns = c["avg_duration_ns"]
