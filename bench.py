@@ -98,7 +98,16 @@ def main():
     ap.add_argument("--dtype", choices=["f64", "f32"], default="f64")
     ap.add_argument("--noise", choices=["isotropic", "diagonal"], default="isotropic")
     ap.add_argument("--cpu-seconds", type=float, default=10.0, help="budget of the cpu_baseline leg (0 = skip)")
+    ap.add_argument("--config", choices=["c2", "c3", "c4", "c5"], default=None,
+                    help="BASELINE.json shape presets: c2 = the headline workload (default); c3/c4/c5 = the secondary shapes "
+                         "(c5: features precomputed -- the end-to-end RFF call is timed by tools/rff_bench.py)")
     args = ap.parse_args()
+    if args.config == "c3":
+        args.D, args.N, args.dtype, args.noise, args.batch = 1024, 65536, "f32", "diagonal", 1
+    elif args.config == "c4":
+        args.D, args.N, args.dtype, args.noise, args.batch = 64, 1024, "f64", "isotropic", 8192
+    elif args.config == "c5":
+        args.D, args.N, args.dtype, args.noise, args.batch = 2048, 16384, "f32", "isotropic", 1
 
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
