@@ -97,7 +97,8 @@ def main():
     ap.add_argument("--N", type=int, default=4096)
     ap.add_argument("--dtype", choices=["f64", "f32"], default="f64")
     ap.add_argument("--noise", choices=["isotropic", "diagonal"], default="isotropic")
-    ap.add_argument("--cpu-seconds", type=float, default=10.0, help="budget of the cpu_baseline leg (0 = skip)")
+    ap.add_argument("--cpu-seconds", type=float, default=None,
+                    help="budget of the cpu_baseline leg (0 = skip; default: 10 s at the headline shape, skipped otherwise)")
     ap.add_argument("--config", choices=["c2", "c3", "c4", "c5"], default=None,
                     help="BASELINE.json shape presets: c2 = the headline workload (default); c3/c4/c5 = the secondary shapes "
                          "(c5: features precomputed -- the end-to-end RFF call is timed by tools/rff_bench.py)")
@@ -108,6 +109,8 @@ def main():
         args.D, args.N, args.dtype, args.noise, args.batch = 64, 1024, "f64", "isotropic", 8192
     elif args.config == "c5":
         args.D, args.N, args.dtype, args.noise, args.batch = 2048, 16384, "f32", "isotropic", 1
+    if args.cpu_seconds is None:
+        args.cpu_seconds = 10.0 if (args.D, args.N) == (128, 4096) else 0.0
 
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
