@@ -1395,8 +1395,10 @@ __global__ __launch_bounds__(kThreads) void marginals_mfma_kernel(MarginalArgs<T
   if (vec && (int)blockIdx.x < ntiles) prefetch(blockIdx.x);
 
   // ---- once per workgroup: L = U' packed (padding: unit diagonal), reciprocal pivots, inverse blocks, mw
+  const bool uvec = use_factor && D == kPB && (a.ldu % VEC) == 0 && ((uintptr_t)U % 16) == 0;
+  if (uvec) load_upper_block_to_packed(P, U, a.ldu, tid);  // every load of the block in flight at once
 #pragma unroll 1
-  for (int base = 0; use_factor && base < DPc * DPc; base += kThreads * 8) {
+  for (int base = 0; use_factor && !uvec && base < DPc * DPc; base += kThreads * 8) {
     T v[8];
 #pragma unroll
     for (int u = 0; u < 8; ++u) {
@@ -1457,28 +1459,39 @@ __global__ __launch_bounds__(kThreads) void marginals_mfma_kernel(MarginalArgs<T
       }
     }
     __syncthreads();
+    // TPR threads per input row (all 256 threads busy), partial sums combined by a shuffle inside the 2- or 4-lane group
+    constexpr int TPR = kThreads / Cfg::RB;
+    const int prow = tid / TPR, ppart = tid % TPR;
     T m = T(0);
-    if (a.mean && tid < Cfg::RB) {
-      const T* xr = Xs + tid * Cfg::LDX;
+    if (a.mean) {
+      const T* xr = Xs + prow * Cfg::LDX;
       T m0 = T(0), m1 = T(0);
-      for (int c = 0; c + 1 < DPc; c += 2) { m0 += xr[c] * mwl[c]; m1 += xr[c + 1] * mwl[c + 1]; }
+      for (int c = 2 * ppart; c + 1 < DPc; c += 2 * TPR) { m0 += xr[c] * mwl[c]; m1 += xr[c + 1] * mwl[c + 1]; }
       m = m0 + m1;
+#pragma unroll
+      for (int o = 1; o < TPR; o <<= 1) m += __shfl_xor(m, o, 64);
     }
     if (use_factor) {
       __syncthreads();  // mean reads rows across the waves' tiles before the sweep rewrites them
       trsm_sweep<T>(Xs, P, Linv, nchunks, lane, wave);
     }
-    if (tid < nt) {
-      if (a.mean) a.mean[(int64_t)reg * a.stridemean + n0 + tid] = m;
+    {
+      T v = T(0);
       if (a.var) {
-        const T* xr = Xs + tid * Cfg::LDX;
+        const T* xr = Xs + prow * Cfg::LDX;
         T v0 = T(0), v1 = T(0);
         if (use_factor) {
-          for (int c = 0; c + 1 < DPc; c += 2) { v0 += xr[c] * xr[c]; v1 += xr[c + 1] * xr[c + 1]; }
+          for (int c = 2 * ppart; c + 1 < DPc; c += 2 * TPR) { v0 += xr[c] * xr[c]; v1 += xr[c + 1] * xr[c + 1]; }
         } else {  // diagonal precision: var_n = sum_d x_dn^2 / d_d
-          for (int c = 0; c + 1 < DPc; c += 2) { v0 += xr[c] * xr[c] * dinv[c]; v1 += xr[c + 1] * xr[c + 1] * dinv[c + 1]; }
+          for (int c = 2 * ppart; c + 1 < DPc; c += 2 * TPR) { v0 += xr[c] * xr[c] * dinv[c]; v1 += xr[c + 1] * xr[c + 1] * dinv[c + 1]; }
         }
-        a.var[(int64_t)reg * a.stridevar + n0 + tid] = (v0 + v1) + ((a.noise_kind == NOISE_DIAGONAL) ? s[n0 + tid] : s[0]);
+        v = v0 + v1;
+#pragma unroll
+        for (int o = 1; o < TPR; o <<= 1) v += __shfl_xor(v, o, 64);
+      }
+      if (ppart == 0 && prow < nt) {
+        if (a.mean) a.mean[(int64_t)reg * a.stridemean + n0 + prow] = m;
+        if (a.var) a.var[(int64_t)reg * a.stridevar + n0 + prow] = v + ((a.noise_kind == NOISE_DIAGONAL) ? s[n0 + prow] : s[0]);
       }
     }
   }
@@ -1556,8 +1569,10 @@ __global__ __launch_bounds__(kThreads) void logpdf_grad_kernel(GradArgs<T> a) {
     };
     if (vec && (int)blockIdx.x < ntiles) prefetch(blockIdx.x);
     // ---- once per workgroup: L = U' packed (padding: unit diagonal), reciprocal pivots, inverse blocks, mw'
+    const bool uvec = D == kPB && (a.ldu % VEC) == 0 && ((uintptr_t)U % 16) == 0;
+    if (uvec) load_upper_block_to_packed(P, U, a.ldu, tid);
 #pragma unroll 1
-    for (int base = 0; base < DPc * DPc; base += kThreads * 8) {
+    for (int base = 0; !uvec && base < DPc * DPc; base += kThreads * 8) {
       T v[8];
 #pragma unroll
       for (int u = 0; u < 8; ++u) {
@@ -1621,20 +1636,29 @@ __global__ __launch_bounds__(kThreads) void logpdf_grad_kernel(GradArgs<T> a) {
         }
       }
       __syncthreads();
+      // TPR threads per input row; the thread with ppart == 0 owns the row's scalars
+      constexpr int TPR = kThreads / Cfg::RB;
+      const int prow = tid / TPR, ppart = tid % TPR;
+      const bool owner = ppart == 0 && prow < nt;
       T rr = T(0), w = T(0), sv = T(1);
       if (!pseudo) {
-        if (tid < Cfg::RB) {
-          if (tid < nt) {
-            const T* xr = Xs + tid * Cfg::LDX;
-            T m0 = T(0), m1 = T(0);
-            for (int c = 0; c + 1 < DPc; c += 2) { m0 += xr[c] * mwl[c]; m1 += xr[c + 1] * mwl[c + 1]; }
-            sv = (a.noise_kind == NOISE_DIAGONAL) ? s[n0 + tid] : s[0];
+        {
+          const T* xr = Xs + prow * Cfg::LDX;
+          T m0 = T(0), m1 = T(0);
+          for (int c = 2 * ppart; c + 1 < DPc; c += 2 * TPR) { m0 += xr[c] * mwl[c]; m1 += xr[c + 1] * mwl[c + 1]; }
+          T mu = m0 + m1;
+#pragma unroll
+          for (int o = 1; o < TPR; o <<= 1) mu += __shfl_xor(mu, o, 64);
+          if (owner) {
+            sv = (a.noise_kind == NOISE_DIAGONAL) ? s[n0 + prow] : s[0];
             w = T(1) / sv;
-            rr = y[n0 + tid] - (m0 + m1);  // posterior residual
+            rr = y[n0 + prow] - mu;  // posterior residual
           }
-          wrv[tid] = w * rr;
-          rvv[tid] = rr;
-          wvv[tid] = w;
+          if (ppart == 0) {
+            wrv[prow] = w * rr;
+            rvv[prow] = rr;
+            wvv[prow] = w;
+          }
         }
         __syncthreads();
         if (tid < kPB) {  // dmw_c += sum_n x_cn w_n r_n over the tile (fixed order)
@@ -1646,11 +1670,13 @@ __global__ __launch_bounds__(kThreads) void logpdf_grad_kernel(GradArgs<T> a) {
       __syncthreads();
       trsm_sweep<T>(Xs, P, Linv, nchunks, lane, wave);       // rows z_n' = x_n' L^-T
       T vq = T(0);
-      if (!pseudo && tid < nt) {
-        const T* xr = Xs + tid * Cfg::LDX;
+      if (!pseudo) {
+        const T* xr = Xs + prow * Cfg::LDX;
         T v0 = T(0), v1 = T(0);
-        for (int c = 0; c + 1 < DPc; c += 2) { v0 += xr[c] * xr[c]; v1 += xr[c + 1] * xr[c + 1]; }
+        for (int c = 2 * ppart; c + 1 < DPc; c += 2 * TPR) { v0 += xr[c] * xr[c]; v1 += xr[c + 1] * xr[c + 1]; }
         vq = v0 + v1;  // x_n' A^-1 x_n
+#pragma unroll
+        for (int o = 1; o < TPR; o <<= 1) vq += __shfl_xor(vq, o, 64);
       }
       __syncthreads();
       trsm_sweep_back<T>(Xs, P, Linv, nchunks, lane, wave);  // rows g_n' = x_n' A^-1
@@ -1661,9 +1687,9 @@ __global__ __launch_bounds__(kThreads) void logpdf_grad_kernel(GradArgs<T> a) {
           if (r < nt && n0 + r < D && c < D) Ai[(int64_t)c * a.ldai + n0 + r] = Xs[r * Cfg::LDX + c];
         }
       } else {
-        if (tid < nt) {
-          if (a.dy) a.dy[(int64_t)reg * a.stridedy + n0 + tid] = -w * rr;
-          if (a.ds) a.ds[(int64_t)reg * a.strideds + n0 + tid] = -(sv - rr * rr - vq) / (T(2) * sv * sv);
+        if (owner) {
+          if (a.dy) a.dy[(int64_t)reg * a.stridedy + n0 + prow] = -w * rr;
+          if (a.ds) a.ds[(int64_t)reg * a.strideds + n0 + prow] = -(sv - rr * rr - vq) / (T(2) * sv * sv);
         }
         if (vecd) {
           T* dXr = a.dX + (int64_t)reg * a.stridedX;
