@@ -1385,11 +1385,17 @@ int sample_weights_impl(blr_handle* h, int memspace, int64_t D, int64_t S, int p
     HIP_TRY(h, hipStreamSynchronize(h->stream));
     if (hinfo != 0) return hinfo;
   }
-  size_t lds = (size_t)D * 64 * sizeof(T) + 16;
-  auto kern = sample_weights_kernel<T>;
-  HIP_TRY(h, hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-  hipLaunchKernelGGL(kern, dim3((unsigned)((S + 63) / 64)), dim3(64), lds, h->stream, mw_d, U, ldu, kind, Z_d, ldz, W_d, ldw,
-                     (int)D, S);
+  if (kind == BLR_PRIOR_DIAGONAL) {
+    hipLaunchKernelGGL(diag_sample_kernel<T>, dim3(1024), dim3(kThreads), 0, h->stream, mw_d, U, Z_d, ldz, W_d, ldw, (int)D, S);
+  } else {  // draws as rows of an LDS block, one backward MFMA sweep per tile of draws
+    using TC = TrsmCfg<T>;
+    const int lds = TC::LDS_BYTES + kPB * (int)sizeof(T);
+    auto kern = sample_weights_mfma_kernel<T>;
+    HIP_TRY(h, hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, lds));
+    const int64_t ntiles = (S + TC::RB - 1) / TC::RB;
+    hipLaunchKernelGGL(kern, dim3((unsigned)std::min<int64_t>(ntiles, 512)), dim3(kThreads), lds, h->stream, mw_d, U, ldu, Z_d, ldz,
+                       W_d, ldw, (int)D, S);
+  }
   HIP_TRY(h, hipGetLastError());
   if (W_dev_out) *W_dev_out = W_d;
   if (sync_and_copy) {

@@ -51,38 +51,6 @@ struct MarginalArgs {
   int D, N, B;
 };
 
-// ---- weight draws: W = mw .+ U \ Z  (:51, sampling_functions.jl:29,35,44) -----------------------------
-// One sample per lane; back substitution in place in LDS (w[d][t]).
-template <typename T>
-__global__ __launch_bounds__(64) void sample_weights_kernel(const T* __restrict__ mw, const T* __restrict__ U, int64_t ldu,
-                                                            int prior_kind, const T* __restrict__ Z, int64_t ldz,
-                                                            T* __restrict__ W, int64_t ldw, int D, int64_t S) {
-  extern __shared__ __attribute__((aligned(16))) char smem[];
-  T* const w = reinterpret_cast<T*>(smem);  // [D][64]
-  const int lane = threadIdx.x;
-  const int64_t s0 = (int64_t)blockIdx.x * 64;
-  const int nt = (int)min((int64_t)64, S - s0);
-  for (int idx = lane; idx < D * 64; idx += 64) {
-    int d = idx % D, t = idx / D;
-    w[d * 64 + t] = (t < nt) ? Z[(s0 + t) * ldz + d] : T(0);
-  }
-  __syncthreads();
-  if (prior_kind == PRIOR_DIAGONAL) {
-    for (int d = 0; d < D; ++d) w[d * 64 + lane] = w[d * 64 + lane] / sqrt(U[d]);
-  } else {
-    for (int i = D - 1; i >= 0; --i) {
-      T accv = w[i * 64 + lane];
-      for (int k = i + 1; k < D; ++k) accv -= U[(int64_t)k * ldu + i] * w[k * 64 + lane];
-      w[i * 64 + lane] = accv / U[(int64_t)i * ldu + i];
-    }
-  }
-  __syncthreads();
-  for (int idx = lane; idx < D * 64; idx += 64) {
-    int d = idx % D, t = idx / D;
-    if (t < nt) W[(s0 + t) * ldw + d] = mw[d] + w[d * 64 + t];
-  }
-}
-
 // ---- Y = X'W .+ sqrt.(s) .* Z2   (:52) ---------------------------------------------------------------
 // 64 x 64 output tile per workgroup, 256 threads, X and W tiles staged in LDS in chunks of 32 rows of d.
 template <typename T>

@@ -1497,6 +1497,67 @@ __global__ __launch_bounds__(kThreads) void marginals_mfma_kernel(MarginalArgs<T
   }
 }
 
+// ---- weight draws for D <= 128 with a factor: W[:, s] = mw + U^-1 Z[:, s]  (:51, sampling_functions.jl:29,35,44) ----------
+// U^-1 z = (z' L^-1)' with L = U': the draws are the ROWS of an LDS block and one backward MFMA sweep (trsm_sweep_back) solves
+// a whole tile of them -- the per-lane substitution of the first version re-read U from global memory for every multiply
+// (266 us for 64 draws at D = 128).
+template <typename T>
+__global__ __launch_bounds__(kThreads) void sample_weights_mfma_kernel(const T* __restrict__ mw, const T* __restrict__ U, int64_t ldu,
+                                                                       const T* __restrict__ Z, int64_t ldz, T* __restrict__ W,
+                                                                       int64_t ldw, int D, int64_t S) {
+  using Cfg = TrsmCfg<T>;
+  constexpr int VEC = Mfma<T>::VEC;
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  T* const P = reinterpret_cast<T*>(smem);
+  T* const Xs = reinterpret_cast<T*>(smem + Cfg::OFF_X);
+  T* const dinv = reinterpret_cast<T*>(smem + Cfg::OFF_DI);
+  T* const Linv = reinterpret_cast<T*>(smem + Cfg::OFF_LI);
+  T* const mwl = reinterpret_cast<T*>(smem + Cfg::LDS_BYTES);
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = uni(tid >> 6);
+  const int nchunks = (D + 15) >> 4, DPc = nchunks * 16;
+  const bool uvec = D == kPB && (ldu % VEC) == 0 && ((uintptr_t)U % 16) == 0;
+  if (uvec) load_upper_block_to_packed(P, U, ldu, tid);
+#pragma unroll 1
+  for (int base = 0; !uvec && base < DPc * DPc; base += kThreads * 8) {
+    T v[8];
+#pragma unroll
+    for (int u = 0; u < 8; ++u) {
+      const int idx = base + u * kThreads + tid;
+      const int r = idx / DPc, c = idx % DPc;
+      const bool in = idx < DPc * DPc && c <= r && r < D;
+      v[u] = U[in ? (int64_t)r * ldu + c : 0];
+    }
+#pragma unroll
+    for (int u = 0; u < 8; ++u) {
+      const int idx = base + u * kThreads + tid;
+      const int r = idx / DPc, c = idx % DPc;
+      if (idx < DPc * DPc && c <= r) P[pidx(r, c)] = (r < D) ? v[u] : (r == c ? T(1) : T(0));
+    }
+  }
+  if (tid < kPB) mwl[tid] = (tid < D) ? mw[tid] : T(0);
+  __syncthreads();
+  if (tid < DPc) dinv[tid] = T(1) / P[pidx(tid, tid)];
+  __syncthreads();
+  trsm_prepare<T>(P, dinv, Linv, nchunks, tid);
+  const int64_t ntiles = (S + Cfg::RB - 1) / Cfg::RB;
+  for (int64_t tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
+    const int64_t s0 = tile * Cfg::RB;
+    const int nt = (int)min((int64_t)Cfg::RB, S - s0);
+    __syncthreads();
+    for (int idx = tid; idx < Cfg::RB * DPc; idx += kThreads) {
+      const int c = idx % DPc, r = idx / DPc;  // draw r, coordinate c: contiguous along c in Z
+      Xs[r * Cfg::LDX + c] = (r < nt && c < D) ? Z[(s0 + r) * ldz + c] : T(0);
+    }
+    __syncthreads();
+    trsm_sweep_back<T>(Xs, P, Linv, nchunks, lane, wave);
+    for (int idx = tid; idx < Cfg::RB * DPc; idx += kThreads) {
+      const int c = idx % DPc, r = idx / DPc;
+      if (r < nt && c < D) W[(s0 + r) * ldw + c] = mwl[c] + Xs[r * Cfg::LDX + c];
+    }
+  }
+}
+
 // ---- gradient of the log marginal likelihood for D <= 128 --------------------------------------
 // The reverse-mode rule of logpdf(fx, y) (reference :55-58), which AD of the reference produces and a drop-in behind a
 // ccall has to supply itself.  With S = diag(1/s), A = Lw + X S X' = L L', mw' the posterior mean, r = y - X'mw':
