@@ -68,21 +68,41 @@ __global__ __launch_bounds__(kThreads) void rand_project_kernel(const T* __restr
   T accv[16];
 #pragma unroll
   for (int j = 0; j < 16; ++j) accv[j] = T(0);
-  for (int d0 = 0; d0 < D; d0 += 32) {
-    __syncthreads();
-    for (int idx = tid; idx < 32 * 64; idx += kThreads) {
+  // the next 32-row chunk of X and W is loaded into registers while the current one is consumed from LDS (the first
+  // version waited out one global-memory latency per chunk: 32 of them at D = 1024)
+  T px[8], pw[8];
+  auto prefetch = [&](int d0) {
+#pragma unroll
+    for (int u = 0; u < 8; ++u) {
+      const int idx = tid + u * kThreads;
       int dd, t;
       if (layout == LAYOUT_COLVECS) { dd = idx % 32; t = idx / 32; }
       else                          { t = idx % 64; dd = idx / 64; }
-      int d = d0 + dd, n = n0 + t;
-      T xv = T(0);
-      if (d < D && n < N) xv = (layout == LAYOUT_COLVECS) ? X[(int64_t)n * ldx + d] : X[(int64_t)d * ldx + n];
-      xs[dd][t] = xv;
-      int dd2 = idx % 32, t2 = idx / 32;
-      int d2 = d0 + dd2;
-      int64_t sidx = s0 + t2;
-      ws[dd2][t2] = (d2 < D && sidx < S) ? W[sidx * ldw + d2] : T(0);
+      const int d = d0 + dd, n = n0 + t;
+      const bool okx = d < D && n < N;
+      const T xv = X[okx ? ((layout == LAYOUT_COLVECS) ? (int64_t)n * ldx + d : (int64_t)d * ldx + n) : 0];
+      px[u] = okx ? xv : T(0);
+      const int dd2 = idx % 32, t2 = idx / 32;
+      const int d2 = d0 + dd2;
+      const int64_t sidx = s0 + t2;
+      const bool okw = d2 < D && sidx < S;
+      const T wv = W[okw ? sidx * ldw + d2 : 0];
+      pw[u] = okw ? wv : T(0);
     }
+  };
+  prefetch(0);
+  for (int d0 = 0; d0 < D; d0 += 32) {
+    __syncthreads();
+#pragma unroll
+    for (int u = 0; u < 8; ++u) {
+      const int idx = tid + u * kThreads;
+      int dd, t;
+      if (layout == LAYOUT_COLVECS) { dd = idx % 32; t = idx / 32; }
+      else                          { t = idx % 64; dd = idx / 64; }
+      xs[dd][t] = px[u];
+      ws[idx % 32][idx / 32] = pw[u];
+    }
+    if (d0 + 32 < D) prefetch(d0 + 32);
     __syncthreads();
 #pragma unroll 4
     for (int dd = 0; dd < 32; ++dd) {
