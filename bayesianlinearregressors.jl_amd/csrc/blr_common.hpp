@@ -49,6 +49,92 @@ __host__ __device__ constexpr int tile_I(int t) {
 }
 __host__ __device__ constexpr int tile_J(int t) { return t - tile_I(t) * (tile_I(t) + 1) / 2; }
 
+// ---- global address space ------------------------------------------------------------------------
+// A pointer that reaches a function through LDS or a noinline call has lost its address space: hipcc then emits
+// flat_load, and while ONE flat access is pending every s_waitcnt it inserts is vmcnt(0) + lgkmcnt(0) (flat returns
+// out of order) -- which serialises a software-pipelined LDS loop.  Cast such pointers back at the receiving end.
+#define BLR_GLOBAL __attribute__((address_space(1)))
+template <typename T>
+__device__ __forceinline__ const BLR_GLOBAL T* as_global(const T* p) { return (const BLR_GLOBAL T*)p; }
+template <typename T>
+__device__ __forceinline__ BLR_GLOBAL T* as_global(T* p) { return (BLR_GLOBAL T*)p; }
+
+// ---- LDS-DMA piece: 64 lanes x 16 bytes, global -> LDS without passing through registers ----------------------------
+// `dst` is the wave-uniform LDS address of the piece (lane l lands at dst + 16 l), `src` the per-lane global address.
+// Issued through inline asm on purpose: for the BUILTIN (__builtin_amdgcn_global_load_lds) hipcc's wait-count insertion
+// marks a "flat access pending" and from then on turns every LDS wait into lgkmcnt(0) -- in a software-pipelined loop
+// that is a wait for the reads issued one instruction earlier (measured in the fused kernel: 59 % MFMA-busy).  Hidden
+// from the compiler, its own LDS waits stay counted; the DMA itself is ordered by the explicit `s_waitcnt vmcnt(N)` +
+// barrier the stage loops already carry.  M0 is saved and restored (the compiler treats it as reserved).
+__device__ __forceinline__ void glds16(const BLR_GLOBAL void* src, const void* dst_wave_uniform) {
+  const unsigned lds_addr = (unsigned)(uintptr_t)(__attribute__((address_space(3))) void*)dst_wave_uniform;
+  unsigned keep, base;
+  asm volatile(
+      "s_mov_b32 %0, m0\n\t"
+      "v_readfirstlane_b32 %1, %2\n\t"
+      "s_mov_b32 m0, %1\n\t"
+      "s_nop 0\n\t"  // SALU write of M0 -> LDS-DMA: one wait state
+      "global_load_lds_dwordx4 %3, off\n\t"
+      "s_mov_b32 m0, %0"
+      : "=&s"(keep), "=&s"(base)
+      : "v"(lds_addr), "v"(src)
+      : "memory");
+}
+
+// The same piece with a SCALAR base: global address = saddr (SGPR pair) + voff (per-lane byte offset, 32 bits).  For a full
+// tile the per-lane part of a stage piece's address never changes, so a whole stage costs scalar adds and ONE vector
+// register instead of a 64-bit address computation per piece and lane.  SIZE = 16 (dwordx4) or 4 (dword) bytes per lane.
+template <int SIZE, int LANES = 64>
+__device__ __forceinline__ void glds_s(uint64_t saddr_uniform, unsigned voff, unsigned lds_addr_uniform) {
+  static_assert((SIZE == 16 && LANES == 64) || SIZE == 4, "LDS-DMA piece width");
+  static_assert(LANES == 64 || LANES == 32 || LANES == 16, "active lanes of the piece");
+  // Call from wave-uniform control flow.  The LDS address goes through v_readfirstlane INSIDE the asm: hipcc hands an
+  // "s" operand over in a VGPR when its own analysis calls the value divergent (the assembler then rejects the
+  // s_mov -- a build failure, never a silent one; the 64-bit base must really be scalar for the same reason).
+  // A 32-lane piece narrows EXEC inside the asm.
+  unsigned keep, m0v;
+  if constexpr (SIZE == 16) {
+    asm volatile(
+        "s_mov_b32 %0, m0\n\t"
+        "v_readfirstlane_b32 %1, %2\n\t"
+        "s_mov_b32 m0, %1\n\t"
+        "s_nop 0\n\t"
+        "global_load_lds_dwordx4 %3, %4\n\t"
+        "s_mov_b32 m0, %0"
+        : "=&s"(keep), "=&s"(m0v)
+        : "v"(lds_addr_uniform), "v"(voff), "s"(saddr_uniform)
+        : "memory");
+  } else if constexpr (LANES == 64) {
+    asm volatile(
+        "s_mov_b32 %0, m0\n\t"
+        "v_readfirstlane_b32 %1, %2\n\t"
+        "s_mov_b32 m0, %1\n\t"
+        "s_nop 0\n\t"
+        "global_load_lds_dword %3, %4\n\t"
+        "s_mov_b32 m0, %0"
+        : "=&s"(keep), "=&s"(m0v)
+        : "v"(lds_addr_uniform), "v"(voff), "s"(saddr_uniform)
+        : "memory");
+  } else {
+    uint64_t keep_exec;
+    asm volatile(
+        "s_mov_b32 %0, m0\n\t"
+        "v_readfirstlane_b32 %1, %3\n\t"
+        "s_mov_b64 %2, exec\n\t"
+        "s_mov_b32 m0, %1\n\t"
+        "s_mov_b64 exec, %6\n\t"
+        "global_load_lds_dword %4, %5\n\t"
+        "s_mov_b64 exec, %2\n\t"
+        "s_mov_b32 m0, %0"
+        : "=&s"(keep), "=&s"(m0v), "=&s"(keep_exec)
+        : "v"(lds_addr_uniform), "v"(voff), "s"(saddr_uniform), "s"((uint64_t)(LANES == 32 ? 0xffffffffull : 0xffffull))
+        : "memory");
+  }
+}
+__device__ __forceinline__ unsigned lds_addr_of(const void* p) {
+  return (unsigned)(uintptr_t)(__attribute__((address_space(3))) void*)p;
+}
+
 // ---- cross-lane helpers --------------------------------------------------------------------
 template <int CTRL>
 __device__ __forceinline__ float dpp_mov(float x) {

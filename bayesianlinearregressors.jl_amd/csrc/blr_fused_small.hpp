@@ -51,16 +51,52 @@ namespace blr {
 // BLR_STAMPS: diagnostic builds only (tools/chol_bench.hip) -- per-section cycle sums of phase_chol, wave 0
 #ifdef BLR_STAMPS
 __device__ unsigned long long g_stamps[8];
-#define BLR_STAMP(slot)                                                          \
-  do {                                                                           \
-    unsigned long long t__ = __builtin_amdgcn_s_memtime();                       \
-    if (threadIdx.x == 0) g_stamps[slot] += t__ - stamp_prev;                    \
-    stamp_prev = t__;                                                            \
+// section sums are kept in registers and flushed once (BLR_STAMP_FLUSH): a global read-modify-write per stamp would put a
+// memory round trip in front of the next barrier and show up as "barrier time"
+#define BLR_STAMP(slot)                                       \
+  do {                                                        \
+    unsigned long long t__ = __builtin_amdgcn_s_memtime();    \
+    stamp_acc[slot] += t__ - stamp_prev;                      \
+    stamp_prev = t__;                                         \
   } while (0)
-#define BLR_STAMP_INIT unsigned long long stamp_prev = __builtin_amdgcn_s_memtime()
+#define BLR_STAMP_INIT                                                  \
+  unsigned long long stamp_acc[8] = {0, 0, 0, 0, 0, 0, 0, 0};           \
+  unsigned long long stamp_prev = __builtin_amdgcn_s_memtime()
+#define BLR_STAMP_FLUSH                                                                   \
+  do {                                                                                    \
+    if (threadIdx.x == 0 && blockIdx.x == 0)                                              \
+      for (int q__ = 0; q__ < 8; ++q__) g_stamps[q__] += stamp_acc[q__];                  \
+  } while (0)
 #else
 #define BLR_STAMP(slot) do {} while (0)
 #define BLR_STAMP_INIT do {} while (0)
+#define BLR_STAMP_FLUSH do {} while (0)
+#endif
+
+// BLR_GRAM_STAMPS: diagnostic builds only (tools/fused_bench.hip) -- per-section cycle sums of the stage loop of phase_gram,
+// one row per wave of workgroup 0: [0] DMA wait, [1] barrier, [2] first fragments + DMA issue, [3] the eight k-steps
+#ifdef BLR_GRAM_STAMPS
+__device__ unsigned long long g_gstamps[4][8];
+#define BLR_GSTAMP_INIT unsigned long long gstamp_prev = __builtin_amdgcn_s_memtime()
+#define BLR_GSTAMP(slot)                                                                        \
+  do {                                                                                          \
+    unsigned long long t__ = __builtin_amdgcn_s_memtime();                                      \
+    if (blockIdx.x == 0 && (threadIdx.x & 63) == 0) g_gstamps[threadIdx.x >> 6][slot] += t__ - gstamp_prev; \
+    gstamp_prev = t__;                                                                          \
+  } while (0)
+__device__ unsigned long long g_pstamps[16];  // per-phase cycle sums of workgroup 0 (fused_small_kernel), [15] = regressors
+#define BLR_PSTAMP_INIT unsigned long long pstamp_prev = __builtin_amdgcn_s_memtime()
+#define BLR_PSTAMP(slot)                                                                   \
+  do {                                                                                     \
+    unsigned long long t__ = __builtin_amdgcn_s_memtime();                                 \
+    if (blockIdx.x == 0 && threadIdx.x == 0) g_pstamps[slot] += t__ - pstamp_prev;         \
+    pstamp_prev = t__;                                                                     \
+  } while (0)
+#else
+#define BLR_GSTAMP_INIT do {} while (0)
+#define BLR_GSTAMP(slot) do {} while (0)
+#define BLR_PSTAMP_INIT do {} while (0)
+#define BLR_PSTAMP(slot) do {} while (0)
 #endif
 
 template <typename T>
@@ -169,7 +205,7 @@ __device__ __forceinline__ int frag_off(int NB, int d, int nl) {
 }
 
 template <typename T, int NB, int MODE>
-__device__ __forceinline__ void stage_load(StageRegs<T, NB>& r, const T* __restrict__ base, int64_t ld, int D, int ncols,
+__device__ __forceinline__ void stage_load(StageRegs<T, NB>& r, const BLR_GLOBAL T* __restrict__ base, int64_t ld, int D, int ncols,
                                            int n0, int tid) {
   using C = SmallCfg<T, NB>;
   constexpr int VEC = Mfma<T>::VEC;
@@ -187,7 +223,7 @@ __device__ __forceinline__ void stage_load(StageRegs<T, NB>& r, const T* __restr
       int n = n0 + nl;
       bool ok = dv * VEC < D && n < ncols;
       int64_t addr = ok ? (int64_t)n * ld + dv * VEC : 0;
-      vecT v = *reinterpret_cast<const vecT*>(base + addr);
+      vecT v = *(const BLR_GLOBAL vecT*)(base + addr);
 #pragma unroll
       for (int c = 0; c < VEC; ++c) r.x[e * VEC + c] = ok ? v[c] : T(0);
     }
@@ -243,7 +279,7 @@ __device__ __forceinline__ void stage_store(const StageRegs<T, NB>& r, T* __rest
 // per-lane GLOBAL address does the (column, row) -> fragment permutation.  No staging registers, no ds_write.
 // Lanes whose element is outside the matrix (row >= D or column >= N) write zeros with a plain ds_write.
 template <typename T, int NB, int KS = SmallCfg<T, NB>::KS>
-__device__ __forceinline__ void stage_glds(T* __restrict__ slot, const T* __restrict__ base, int64_t ld, int D, int ncols,
+__device__ __forceinline__ void stage_glds(T* __restrict__ slot, const BLR_GLOBAL T* __restrict__ base, int64_t ld, int D, int ncols,
                                            int n0, int wave, int lane) {
   constexpr int VEC = Mfma<T>::VEC;
   constexpr int FPG = (1024 / (int)sizeof(T)) / 64;  // fragments per wave-instruction: 2 (f64) / 4 (f32)
@@ -262,15 +298,42 @@ __device__ __forceinline__ void stage_glds(T* __restrict__ slot, const T* __rest
       const int n = n0 + 4 * j + q, d = 16 * I + r;
       T* dst = slot + g * (FPG * 64);  // wave-uniform
       if (d < D && n < ncols) {
-        __builtin_amdgcn_global_load_lds(
-            (const __attribute__((address_space(1))) void*)(base + (int64_t)n * ld + d),
-            (__attribute__((address_space(3))) void*)dst, 16, 0, 0);
+        glds16((const BLR_GLOBAL void*)(base + (int64_t)n * ld + d), dst);
       } else {
         vecT z;
 #pragma unroll
         for (int c = 0; c < VEC; ++c) z[c] = T(0);
         *reinterpret_cast<vecT*>(dst + e0) = z;
       }
+    }
+  }
+}
+
+// Full tiles (D == 16 NB, the stage entirely inside the matrix, NB a multiple of the fragments per piece): piece g of a
+// stage covers fragments F = g FPG + fl with I = (g FPG) % NB + fl and j = (g FPG) / NB, so the address splits into a
+// wave-uniform part  base + ((n0 + 4 j) ld + 16 ((g FPG) % NB)) elements  and a per-lane part  q ld + 16 fl + r  that is
+// the same for every piece of every stage (`voff`, from glds_lane_offset).  No bounds checks, no per-lane 64-bit math.
+template <typename T>
+__device__ __forceinline__ unsigned glds_lane_offset(int64_t ld, int lane) {
+  constexpr int VEC = Mfma<T>::VEC;
+  const int e0 = lane * VEC;
+  const int fl = e0 >> 6, ls = e0 & 63, q = ls >> 4, r = ls & 15;
+  return (unsigned)(((int64_t)q * ld + 16 * fl + r) * (int64_t)sizeof(T));
+}
+template <typename T, int NB, int KS = SmallCfg<T, NB>::KS>
+__device__ __forceinline__ void stage_glds_full(const T* __restrict__ slot, const BLR_GLOBAL T* __restrict__ base /*uniform*/,
+                                                int64_t ld, int n0, int wave /*uniform*/, unsigned voff) {
+  constexpr int FPG = (1024 / (int)sizeof(T)) / 64;
+  constexpr int NG = KS * NB / FPG;
+  static_assert(NB % FPG == 0 && (KS * NB) % FPG == 0, "pieces must not straddle k-steps");
+  const unsigned slot_addr = uni((int)lds_addr_of(slot));
+#pragma unroll
+  for (int g0 = 0; g0 < NG; g0 += kWaves) {
+    const int g = g0 + wave;
+    if (NG % kWaves == 0 || g < NG) {
+      const int j = (g * FPG) / NB, I0 = (g * FPG) % NB;
+      const uint64_t saddr = (uint64_t)(uintptr_t)base + (uint64_t)(((int64_t)(n0 + 4 * j) * ld + 16 * I0) * (int64_t)sizeof(T));
+      glds_s<16>(uni((int64_t)saddr), voff, slot_addr + (unsigned)(g * 1024));
     }
   }
 }
@@ -430,6 +493,258 @@ __device__ __forceinline__ void compute_stage(const T* __restrict__ slot, const 
   }
 }
 
+// ---- NB == 8 (D in 113..128), static wave: the pinned-schedule stage ---------------------------------------
+// Left to itself hipcc sinks the fragment reads of k-step j+1 to just in front of their first use and waits
+// `lgkmcnt(0)` there: every k-step exposes one LDS round trip with the matrix pipe idle (measured: 59 % MFMA-busy,
+// 0.55 of the f64 matrix peak -- which IS 64 cycles per v_mfma_f64_16x16x4 with the accumulators in VGPRs,
+// profiles/r02_microbench_mfma_f64_probe.txt).  Here the order is pinned with sched_barrier: the reads of k-step j+1
+// are ISSUED before the nine MFMAs of k-step j, so their latency hides under >= 576 cycles of matrix work and the
+// wait the compiler places in front of k-step j+1's first use is a counted one that has already expired.
+// Wave W needs block rows 0 .. 7-W only (its tiles are (W, 0..W) and (7-W, 0..7-W)); the k-step it owns for the
+// column-vector work reads all eight.
+template <typename T, int WS>
+struct KF8 {
+  T fb[8];  // fragment of block row I: X[16I + (l & 15), n0 + 4j + (l >> 4)]
+  T w;      // Sigma_y^-1 of column 4j + (l >> 4)
+  T yv;     // y of that column (owner k-steps only)
+};
+
+template <typename T, int WS, bool ISO>
+__device__ __forceinline__ void load_kf8(KF8<T, WS>& f, const T* __restrict__ slot, const T* __restrict__ ybuf,
+                                         const T* __restrict__ wbuf, int j /*compile-time after unrolling*/, int lane) {
+  const bool owner = (j & 3) == WS;
+  const T* kimg = slot + j * 8 * 64;
+  if (!ISO) f.w = wbuf[4 * j + (lane >> 4)];
+  if (owner) f.yv = ybuf[4 * j + (lane >> 4)];
+#pragma unroll
+  for (int I = 0; I < 8; ++I)
+    if (owner || I <= 7 - WS) f.fb[I] = kimg[I * 64 + lane];
+}
+
+template <typename T, int WS, bool ISO>
+__device__ __forceinline__ void mma_kf8(AccArr<T, 8>& acc, const KF8<T, WS>& f) {
+  // Sigma_y^-1 on the A side only; isotropic noise: applied once to the finished accumulators instead
+  const T alo = ISO ? f.fb[WS] : f.fb[WS] * f.w;
+  const T ahi = ISO ? f.fb[7 - WS] : f.fb[7 - WS] * f.w;
+#pragma unroll
+  for (int i = 0; i < 9; ++i) acc[i] = Mfma<T>::mma((i <= WS) ? alo : ahi, f.fb[(i <= WS) ? i : i - (WS + 1)], acc[i]);
+}
+
+template <typename T, int WS, bool ISO>
+__device__ __forceinline__ void vector_kf8(const KF8<T, WS>& f, T wiso, const T (&mwf)[8], double (&bacc)[8], double& qacc,
+                                           int lane, T gate) {
+  T mu = T(0);
+#pragma unroll
+  for (int I = 0; I < 8; ++I) mu += f.fb[I] * mwf[I];
+  mu = row16_allreduce(mu);
+  const T delta = (f.yv - mu) * gate;  // :82  y - mean(fx)
+  const T rn = delta * (ISO ? wiso : f.w);
+  if ((lane & 15) == 0) qacc += (double)delta * (double)rn;
+#pragma unroll
+  for (int I = 0; I < 8; ++I) bacc[I] += (double)f.fb[I] * (double)rn;
+}
+
+// the first k-step's fragments of a stage (issued right after the stage barrier, in front of the next stage's DMA issue)
+template <typename T, int WS, bool ISO>
+__device__ __forceinline__ void stage8_prologue(KF8<T, WS>& f0, const T* __restrict__ slot, const T* __restrict__ ybuf,
+                                                const T* __restrict__ wbuf, int lane) {
+  load_kf8<T, WS, ISO>(f0, slot, ybuf, wbuf, 0, lane);
+  __builtin_amdgcn_sched_barrier(0);
+}
+
+template <typename T, int WS, bool ISO>
+__device__ __forceinline__ void stage8_body(KF8<T, WS>& f0, const T* __restrict__ slot, const T* __restrict__ ybuf,
+                                            const T* __restrict__ wbuf, AccArr<T, 8>& acc, double (&bacc)[8], double& qacc,
+                                            const T (&mwf)[8], T wiso, int lane, T gate) {
+  constexpr int KS = SmallCfg<T, 8>::KS;
+  KF8<T, WS> f1;
+#pragma unroll
+  for (int j = 0; j < KS; j += 2) {
+    load_kf8<T, WS, ISO>(f1, slot, ybuf, wbuf, j + 1, lane);
+    __builtin_amdgcn_sched_barrier(0);
+    mma_kf8<T, WS, ISO>(acc, f0);
+    if ((j & 3) == WS && BLR_EXP != 3) vector_kf8<T, WS, ISO>(f0, wiso, mwf, bacc, qacc, lane, gate);
+    __builtin_amdgcn_sched_barrier(0);
+    if (j + 2 < KS) load_kf8<T, WS, ISO>(f0, slot, ybuf, wbuf, j + 2, lane);
+    __builtin_amdgcn_sched_barrier(0);
+    mma_kf8<T, WS, ISO>(acc, f1);
+    if (((j + 1) & 3) == WS && BLR_EXP != 3) vector_kf8<T, WS, ISO>(f1, wiso, mwf, bacc, qacc, lane, gate);
+    __builtin_amdgcn_sched_barrier(0);
+  }
+}
+
+// ---- NB == 8, isotropic noise, full tiles: the ring loop ------------------------------------------------------------
+// The 64 KB staging area is a ring of FOUR half-stages (4 k-steps = 16 columns each).  While half h computes, half h+1 is
+// already visible to every wave, half h+2 is landing and the pieces of half h+3 are issued one per k-step.  A piece has >= 5
+// k-steps to land before the counted `s_waitcnt vmcnt(N)` that retires it.  ONE barrier per half, at its END: it publishes
+// half h+2 and frees the slot of half h; because half h+1 was published a barrier earlier, the first fragments of half h+1
+// are requested BEFORE the barrier and the first MFMA behind it issues at once.  Within a half every wave owns exactly one
+// k-step of column-vector work, so all waves reach the barrier together.  y travels by LDS-DMA too (wave 0, one dword piece
+// per half): the loop has no compiler-visible memory operation.
+//
+// Inside a k-step EVERYTHING that is not an MFMA is slotted, by hand, into the gaps between the nine MFMAs (sched_barrier
+// pins the order): the fragment reads of the next k-step two blocks per gap, the DMA piece in a gap of its own, the
+// column-vector work in eight short chunks.  A v_mfma_f64_16x16x4 occupies the matrix pipe for 64 cycles; whatever the
+// wave issues behind it within those 64 cycles is free, anything longer leaves the pipe idle -- measured on this loop
+// (tools/ring_probe.hip): one DMA piece issued BETWEEN two MFMA groups cost 117 cycles of a 576-cycle k-step, the reads
+// and the vector work another ~100.
+// MWZ: the prior mean is identically zero (checked once per regressor): mean(fx) = X'mw = 0 exactly, the dot products and
+// the butterfly are skipped -- bit-identical to the general path, 17 of the 27 f64 vector operations of an owned k-step gone.
+template <typename T, int WS, bool MWZ>
+struct VecWork8 {
+  T a, b, mu, rn;
+  template <int C>
+  __device__ __forceinline__ void step(const KF8<T, WS>& f, T wiso, const T (&mwf)[8], double (&bacc)[8], double& qacc, int lane) {
+    if constexpr (C == 0 && !MWZ) { a = f.fb[0] * mwf[0]; a += f.fb[1] * mwf[1]; a += f.fb[2] * mwf[2]; a += f.fb[3] * mwf[3]; }
+    if constexpr (C == 1 && !MWZ) { b = f.fb[4] * mwf[4]; b += f.fb[5] * mwf[5]; b += f.fb[6] * mwf[6]; b += f.fb[7] * mwf[7]; }
+    if constexpr (C == 2 && !MWZ) { mu = a + b; mu += dpp_mov<0xB1>(mu); }   // 16-lane butterfly (row16_allreduce), one step per chunk
+    if constexpr (C == 3 && !MWZ) { mu += dpp_mov<0x4E>(mu); }
+    if constexpr (C == 4 && !MWZ) { mu += dpp_mov<0x141>(mu); }
+    if constexpr (C == 5) {
+      if constexpr (MWZ) mu = T(0);
+      else mu += dpp_mov<0x140>(mu);
+      const T delta = f.yv - mu;  // :82  y - mean(fx)
+      rn = delta * wiso;
+      if ((lane & 15) == 0) qacc += (double)delta * (double)rn;
+    }
+    if constexpr (C == 6) {
+#pragma unroll
+      for (int I = 0; I < 4; ++I) bacc[I] += (double)f.fb[I] * (double)rn;
+    }
+    if constexpr (C == 7) {
+#pragma unroll
+      for (int I = 4; I < 8; ++I) bacc[I] += (double)f.fb[I] * (double)rn;
+    }
+  }
+};
+
+// One k-step of the ring loop.  fc: fragments of this k-step (J = its index in the half; the wave owns the column-vector
+// work iff J == WS).  fn <- fragments of the NEXT k-step, read from kimg_n / yb_n (JN = its index in its half).
+// `piece` / `piece2`: callables issuing this k-step's LDS-DMA pieces (may do nothing).
+template <typename T, int WS, bool MWZ, int J, int JN, typename P1, typename P2>
+__device__ __forceinline__ void kstep_ring(AccArr<T, 8>& acc, const KF8<T, WS>& fc, KF8<T, WS>& fn, const T* __restrict__ kimg_n,
+                                           const T* __restrict__ yb_n, T wiso, const T (&mwf)[8], double (&bacc)[8], double& qacc,
+                                           int lane, P1 piece, P2 piece2) {
+  constexpr bool OWN = (J == WS) && (BLR_EXP != 3);
+  constexpr bool OWN_N = (JN == WS);
+  constexpr int NBLK_N = OWN_N ? 8 : 8 - WS;  // blocks of the next k-step this wave needs
+  VecWork8<T, WS, MWZ> vw;
+  const T alo = fc.fb[WS], ahi = fc.fb[7 - WS];
+  auto mma = [&](auto itag) {
+    constexpr int i = decltype(itag)::value;
+    acc[i] = Mfma<T>::mma((i <= WS) ? alo : ahi, fc.fb[(i <= WS) ? i : i - (WS + 1)], acc[i]);
+  };
+  auto rd = [&](auto itag) {
+    constexpr int I = decltype(itag)::value;
+    if constexpr (I < NBLK_N) fn.fb[I] = kimg_n[I * 64 + lane];
+  };
+#define BLR_SB __builtin_amdgcn_sched_barrier(0)
+#define BLR_IC(k) std::integral_constant<int, k>{}
+  mma(BLR_IC(0)); BLR_SB;
+  rd(BLR_IC(0)); rd(BLR_IC(1));
+  if constexpr (OWN) vw.template step<0>(fc, wiso, mwf, bacc, qacc, lane);
+  BLR_SB; mma(BLR_IC(1)); BLR_SB;
+  rd(BLR_IC(2)); rd(BLR_IC(3));
+  if constexpr (OWN) vw.template step<1>(fc, wiso, mwf, bacc, qacc, lane);
+  BLR_SB; mma(BLR_IC(2)); BLR_SB;
+  rd(BLR_IC(4)); rd(BLR_IC(5));
+  if constexpr (OWN) vw.template step<2>(fc, wiso, mwf, bacc, qacc, lane);
+  BLR_SB; mma(BLR_IC(3)); BLR_SB;
+  rd(BLR_IC(6)); rd(BLR_IC(7));
+  if constexpr (OWN_N) fn.yv = yb_n[4 * JN + (lane >> 4)];
+  if constexpr (OWN) vw.template step<3>(fc, wiso, mwf, bacc, qacc, lane);
+  BLR_SB; mma(BLR_IC(4)); BLR_SB;
+  piece();
+  BLR_SB; mma(BLR_IC(5)); BLR_SB;
+  if constexpr (OWN) vw.template step<4>(fc, wiso, mwf, bacc, qacc, lane);
+  BLR_SB; mma(BLR_IC(6)); BLR_SB;
+  piece2();
+  if constexpr (OWN) vw.template step<5>(fc, wiso, mwf, bacc, qacc, lane);
+  BLR_SB; mma(BLR_IC(7)); BLR_SB;
+  if constexpr (OWN) vw.template step<6>(fc, wiso, mwf, bacc, qacc, lane);
+  BLR_SB; mma(BLR_IC(8)); BLR_SB;
+  if constexpr (OWN) vw.template step<7>(fc, wiso, mwf, bacc, qacc, lane);
+  BLR_SB;
+#undef BLR_SB
+#undef BLR_IC
+}
+
+template <typename T, int WS, bool MWZ>
+__device__ __forceinline__ void gram_iso_ring(T* __restrict__ ring, T* __restrict__ ybuf, const BLR_GLOBAL T* X /*uniform*/,
+                                              const BLR_GLOBAL T* y /*uniform*/, int64_t ldx, int N, unsigned voff, int lane,
+                                              AccArr<T, 8>& acc, double (&bacc)[8], double& qacc, const T (&mwf)[8], T wiso) {
+  constexpr int NB = 8, HK = 4;
+  constexpr int HALF = HK * NB * 64;                   // elements per half
+  constexpr int HC = 4 * HK;                           // columns per half
+  constexpr int FPG = (1024 / (int)sizeof(T)) / 64;    // fragments per 1 KiB piece
+  constexpr int PW = HK * NB / FPG / kWaves;           // pieces per wave per half: 4 (f64) / 2 (f32)
+  constexpr int PWT = PW + (WS == 0 ? 1 : 0);          // + the y piece of wave 0
+  constexpr int YL = HC * (int)sizeof(T) / 4;          // lanes of the y piece: 32 (f64) / 16 (f32)
+  unsigned ring_addr = lds_addr_of(ring), ybuf_addr = lds_addr_of(ybuf);
+  // pinned in vector registers: rematerialised in the loop they cost a scalar-memory load plus an lgkmcnt(0) wait per use
+  asm volatile("" : "+v"(ring_addr), "+v"(ybuf_addr));
+  const int nh = N / HC;
+  auto issue_piece = [&](int h, auto ptag) {
+    constexpr int p = decltype(ptag)::value;
+    constexpr int g = p * kWaves + WS, j = (g * FPG) / NB, I0 = (g * FPG) % NB;
+    const uint64_t saddr = (uint64_t)(uintptr_t)X + (uint64_t)(((int64_t)(h * HC + 4 * j) * ldx + 16 * I0) * (int64_t)sizeof(T));
+#ifndef RING_NODMA
+    glds_s<16>(uni((int64_t)saddr), voff, ring_addr + (unsigned)((h & 3) * HALF * (int)sizeof(T) + g * 1024));
+#endif
+  };
+  auto issue_y = [&](int h) {
+#ifndef RING_NODMA
+    if constexpr (WS == 0)
+      glds_s<4, YL>(uni((int64_t)(uintptr_t)(y + (int64_t)h * HC)), (unsigned)(lane * 4),
+                    ybuf_addr + (unsigned)((h & 3) * HC * (int)sizeof(T)));
+#endif
+  };
+  auto issue_half = [&](int h) {
+    issue_piece(h, std::integral_constant<int, 0>{});
+    if constexpr (PW > 1) issue_piece(h, std::integral_constant<int, 1>{});
+    if constexpr (PW > 2) issue_piece(h, std::integral_constant<int, 2>{});
+    if constexpr (PW > 3) issue_piece(h, std::integral_constant<int, 3>{});
+    issue_y(h);
+  };
+  // retire everything but the youngest `keep_halves` halves of this wave's pieces
+  auto retire = [&](int keep_halves) {
+#ifndef RING_NORETIRE
+    if (keep_halves >= 1) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(PWT) : "memory");
+    else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+#endif
+  };
+  for (int h = 0; h < 3 && h < nh; ++h) issue_half(h);
+  retire(nh > 2 ? 1 : 0);  // halves 0 and 1 landed (this wave's pieces) ...
+  __syncthreads();         // ... and everybody's: visible
+  KF8<T, WS> f0, f1;
+  load_kf8<T, WS, true>(f0, ring, ybuf, ybuf, 0, lane);
+  __builtin_amdgcn_sched_barrier(0);
+  auto none = [] {};
+#pragma unroll 1
+  for (int h = 0; h < nh; ++h) {
+    // here: halves h and h+1 are visible, f0 holds the fragments of (h, k-step 0), half h+2 is landing
+    const T* slot = ring + (h & 3) * HALF;
+    const T* yb = ybuf + (h & 3) * HC;
+    const T* slot_n = ring + ((h + 1) & 3) * HALF;
+    const T* yb_n = ybuf + ((h + 1) & 3) * HC;
+    const bool more = h + 3 < nh;  // slot (h+3) % 4 was freed by the barrier that ended half h-1
+    // all pieces of half h+3 in ONE burst inside k-step 0 (back to back they cost ~46 cycles each, one at a time ~100)
+    auto pall = [&] { if (more) issue_half(h + 3); };
+    kstep_ring<T, WS, MWZ, 0, 1>(acc, f0, f1, slot + 1 * NB * 64, yb, wiso, mwf, bacc, qacc, lane, pall, none);
+    kstep_ring<T, WS, MWZ, 1, 2>(acc, f1, f0, slot + 2 * NB * 64, yb, wiso, mwf, bacc, qacc, lane, none, none);
+    kstep_ring<T, WS, MWZ, 2, 3>(acc, f0, f1, slot + 3 * NB * 64, yb, wiso, mwf, bacc, qacc, lane, none, none);
+    // the first fragments of half h+1 (visible since the previous barrier) are requested under the last k-step's MFMAs
+    kstep_ring<T, WS, MWZ, 3, 0>(acc, f1, f0, slot_n, yb_n, wiso, mwf, bacc, qacc, lane, none, none);
+    // ---- end of half h: publish half h+2 (its pieces were issued during half h-1), free the slot of half h
+    if (h + 1 < nh) {
+      if (h + 2 < nh) retire(more ? 1 : 0);
+#ifndef RING_NOBAR
+      __syncthreads();
+#endif
+    }
+  }
+}
+
 // =========================================================================================================
 // phase 1 (noinline): streaming Gram.  On exit: packed lower triangle of A in LDS (P), b in bvec,
 // scr[4] = (y-m)' S (y-m), scr[5] = logdet Sigma_y.
@@ -452,11 +767,11 @@ BLR_PHASE void phase_gram(char* smem) {
   asm volatile("" : "+v"(tid));  // nothing derived from tid may be hoisted above this phase
   const int lane = tid & 63;
   const int wave = uni(tid >> 6);
-  const T* X = uni(ctx->X);
-  const T* y = uni(ctx->y);
-  const T* s = uni(ctx->s);
-  const T* mw = uni(ctx->mw);
-  const T* Lw = uni(ctx->Lw);
+  const BLR_GLOBAL T* X = as_global(uni(ctx->X));  // global_load, not flat_load (see as_global)
+  const BLR_GLOBAL T* y = as_global(uni(ctx->y));
+  const BLR_GLOBAL T* s = as_global(uni(ctx->s));
+  const BLR_GLOBAL T* mw = as_global(uni(ctx->mw));
+  const BLR_GLOBAL T* Lw = as_global(uni(ctx->Lw));
   const int64_t ldx = uni(ctx->ldx), ldl = uni(ctx->ldl);
   const int D = uni(ctx->D), N = uni(ctx->N);
   const int noise_kind = uni(ctx->noise_kind), prior_kind = uni(ctx->prior_kind);
@@ -464,26 +779,58 @@ BLR_PHASE void phase_gram(char* smem) {
 
   // accumulators start from the prior precision (dense: UPPER triangle of the caller's matrix, as LAPACK 'U';
   // diagonal tiles get both halves so they stay symmetric)
-  acc4 acc[C::TPW];
+  const int nprior_stages = (prior_kind == PRIOR_UPPER_FACTOR) ? (D + C::NSC - 1) / C::NSC : 0;
+  const bool diag_noise = (noise_kind == NOISE_DIAGONAL);
+  const T s_iso = diag_noise ? T(1) : s[0];
+  // NB == 8, isotropic noise, no pseudo-observation stages: the stage loop accumulates X X' unscaled and
+  // A = Lw + (1 / sigma^2) X X' is formed once at the end (two f64 multiplies fewer per k-step on the matrix pipe's datapath)
+  constexpr bool kGlds = (MODE == 4);
+  constexpr int kFPG = (1024 / (int)sizeof(T)) / 64;
+  // every stage a full tile: scalar-addressed LDS-DMA pieces (stage_glds_full)
+  const bool full_tiles = kGlds && (NB % kFPG == 0) && D == C::DP && N > 0 && (N % C::NSC) == 0 &&
+                          (3 * ldx + 64) * (int64_t)sizeof(T) < ((int64_t)1 << 31);
+  const bool iso_fast = (NB == 8) && !diag_noise && nprior_stages == 0 && full_tiles;
+  // prior precision in tile layout (dense: UPPER triangle of the caller's matrix, as LAPACK 'U'; diagonal tiles get both
+  // halves so they stay symmetric).  Unconditional loads of clamped addresses, then selects: all of a thread's loads are in
+  // flight together (one memory latency, not one per element).
+  auto load_prior = [&](acc4 (&pr)[C::TPW]) {
+    if (prior_kind == PRIOR_DENSE) {
 #pragma unroll
-  for (int i = 0; i < C::TPW; ++i) {
-    int I, K;
-    const bool tile_ok = wave_tile(NB, wave, i, I, K);
-    const int col = 16 * K + (lane & 15);
+      for (int i = 0; i < C::TPW; ++i) {
+        int I, K;
+        const bool tile_ok = wave_tile(NB, wave, i, I, K);
+        const int col = 16 * K + (lane & 15);
 #pragma unroll
-    for (int v = 0; v < 4; ++v) {
-      const int row = 16 * I + Mfma<T>::crow(lane, v);
-      T val = T(0);
-      if (tile_ok && row < D && col < D) {
-        if (prior_kind == PRIOR_DENSE) {
+        for (int v = 0; v < 4; ++v) {
+          const int row = 16 * I + Mfma<T>::crow(lane, v);
+          const bool ok = tile_ok && row < D && col < D;
           const int lo = min(row, col), hi = max(row, col);
-          val = Lw[(int64_t)hi * ldl + lo];
-        } else if (prior_kind == PRIOR_DIAGONAL && row == col) {
-          val = Lw[row];
+          const T val = Lw[ok ? (int64_t)hi * ldl + lo : 0];
+          pr[i][v] = ok ? val : T(0);
         }
       }
-      acc[i][v] = val;
+    } else {
+#pragma unroll
+      for (int i = 0; i < C::TPW; ++i) {
+        int I, K;
+        const bool tile_ok = wave_tile(NB, wave, i, I, K);
+        const int col = 16 * K + (lane & 15);
+#pragma unroll
+        for (int v = 0; v < 4; ++v) {
+          const int row = 16 * I + Mfma<T>::crow(lane, v);
+          const bool ok = tile_ok && I == K && row == col && row < D && prior_kind == PRIOR_DIAGONAL;
+          const T val = (I == K) ? Lw[ok ? row : 0] : T(0);  // I == K is wave-uniform: off-diagonal tiles load nothing
+          pr[i][v] = ok ? val : T(0);
+        }
+      }
     }
+  };
+  acc4 acc[C::TPW];
+  if (iso_fast) {
+#pragma unroll
+    for (int i = 0; i < C::TPW; ++i) acc[i] = acc4{T(0), T(0), T(0), T(0)};
+  } else {
+    load_prior(acc);
   }
   double bacc[NB];
 #pragma unroll
@@ -491,39 +838,69 @@ BLR_PHASE void phase_gram(char* smem) {
   if (tid < C::DP) mwl[tid] = tid < D ? mw[tid] : T(0);  // visible after the first stage barrier
   double qacc = 0.0, lacc = 0.0;
 
-  const int nprior_stages = (prior_kind == PRIOR_UPPER_FACTOR) ? (D + C::NSC - 1) / C::NSC : 0;
   const int ndata_stages = (N + C::NSC - 1) / C::NSC;
   const int nstages = nprior_stages + ndata_stages;
-  const bool diag_noise = (noise_kind == NOISE_DIAGONAL);
-  const T s_iso = diag_noise ? T(1) : s[0];
 
-  constexpr bool kGlds = (MODE == 4);
   StageRegs<T, kGlds ? 0 : NB> regs;  // MODE 4 keeps only yv / wv in registers
   T* ring_slot = slot0;               // where the data stage being issued lands (MODE 4)
-  auto issue = [&](int td) {  // prefetch data stage td: into registers, or (MODE 4) straight into its LDS slot
+  T* ring_ybuf = ybuf;                // ... and its y values (isotropic fast path: y travels by LDS-DMA too)
+  const unsigned voff = glds_lane_offset<T>(ldx, lane);
+  auto issue = [&](int td, auto iso_tag) {  // prefetch data stage td: into registers, or (MODE 4) straight into its LDS slot
+    constexpr bool ISO = decltype(iso_tag)::value;
     const int n0 = td * C::NSC;
-    if constexpr (kGlds) stage_glds<T, NB>(ring_slot, X, ldx, D, N, n0, wave, lane);
-    else stage_load<T, NB, MODE>(regs, X, ldx, D, N, n0, tid);
-    regs.yv = T(0);
-    regs.wv = T(0);
-    if (tid < C::NSC && n0 + tid < N) {
-      regs.yv = y[n0 + tid];
-      T sv = diag_noise ? s[n0 + tid] : s_iso;
-      regs.wv = T(1) / sv;                       // :79/:81  Sigma_y^-1 on the diagonal
-      if (diag_noise) lacc += log((double)sv);   // :84  logdet(Sigma_y)
+    if constexpr (kGlds) {
+      if constexpr (NB % kFPG == 0) {
+        if (full_tiles) stage_glds_full<T, NB>(ring_slot, X, ldx, n0, wave, voff);
+        else stage_glds<T, NB>(ring_slot, X, ldx, D, N, n0, wave, lane);
+      } else {
+        stage_glds<T, NB>(ring_slot, X, ldx, D, N, n0, wave, lane);
+      }
+    } else {
+      stage_load<T, NB, MODE>(regs, X, ldx, D, N, n0, tid);
+    }
+    if constexpr (ISO) {
+      // y of the stage: NSC elements = one dword piece (4 bytes per lane), no registers, no compiler-visible load
+      static_assert(C::NSC * (int)sizeof(T) / 4 == 64 || C::NSC * (int)sizeof(T) / 4 == 32, "one dword piece");
+      if (wave == 0)  // wave-uniform branch
+        glds_s<4, C::NSC * (int)sizeof(T) / 4>(uni((int64_t)(uintptr_t)(y + n0)), (unsigned)(lane * 4),
+                                               uni((int)lds_addr_of(ring_ybuf)));
+    } else {
+      regs.yv = T(0);
+      regs.wv = T(0);
+      if (tid < C::NSC && n0 + tid < N) {
+        regs.yv = y[n0 + tid];
+        T sv = diag_noise ? s[n0 + tid] : s_iso;
+        regs.wv = T(1) / sv;                       // :79/:81  Sigma_y^-1 on the diagonal
+        if (diag_noise) lacc += log((double)sv);   // :84  logdet(Sigma_y)
+      }
     }
   };
 
   __syncthreads();  // region 0 is free
-  auto run_stages = [&](auto ws_tag) {
+  auto run_stages = [&](auto ws_tag, auto iso_tag) {
   constexpr int WS = decltype(ws_tag)::value;
+  constexpr bool ISO = decltype(iso_tag)::value;
+  constexpr bool kPinned = (NB == 8 && WS >= 0);  // pinned-schedule stage (stage8_body)
+  constexpr int WSP = WS < 0 ? 0 : WS;
+  T mwf[8];
+  if constexpr (kPinned) {
+#pragma unroll
+    for (int I = 0; I < 8; ++I) mwf[I] = mwl[16 * I + (lane & 15)];
+  }
+  const T wiso = T(1) / s_iso;
   // MODE 4 with prior pseudo-stages: data stage 0 is issued after the last prior stage's barrier instead
   // (its slot is still being used by the prior stages before that)
-  if (ndata_stages > 0 && !(kGlds && nprior_stages > 0)) { ring_slot = slot0 + (nprior_stages & 1) * C::SLOT; issue(0); }
+  if (ndata_stages > 0 && !(kGlds && nprior_stages > 0)) {
+    ring_slot = slot0 + (nprior_stages & 1) * C::SLOT;
+    ring_ybuf = ybuf + (nprior_stages & 1) * C::NSC;
+    issue(0, iso_tag);
+  }
+  BLR_GSTAMP_INIT;
   for (int t = 0; t < nstages; ++t) {
     const int sl = t & 1;
     T* slot = slot0 + sl * C::SLOT;
     const bool is_data = t >= nprior_stages;
+    BLR_GSTAMP(4);
     if (!is_data) {
       // prior pseudo-observations (PDMat / carried-forward factor): a handful of stages, loaded synchronously
       StageRegs<T, NB> pr;
@@ -533,34 +910,102 @@ BLR_PHASE void phase_gram(char* smem) {
       pr.wv = (tid < C::NSC && n0 + tid < D) ? T(1) : T(0);
       stage_store<T, NB, 2>(pr, slot, ybuf + sl * C::NSC, wbuf + sl * C::NSC, tid);
     } else if constexpr (kGlds) {
-      if (tid < C::NSC) { ybuf[sl * C::NSC + tid] = regs.yv; wbuf[sl * C::NSC + tid] = regs.wv; }
+      if constexpr (!ISO) {
+        if (tid < C::NSC) { ybuf[sl * C::NSC + tid] = regs.yv; wbuf[sl * C::NSC + tid] = regs.wv; }
+      }
       asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // this wave's LDS-DMA pieces of stage t have landed
     } else {
       stage_store<T, NB, MODE>(regs, slot, ybuf + sl * C::NSC, wbuf + sl * C::NSC, tid);
     }
+    BLR_GSTAMP(0);
     __syncthreads();
+    BLR_GSTAMP(1);
+    // pinned schedule: the first k-step's fragments are requested before the next stage's DMA pieces are issued
+    [[maybe_unused]] KF8<T, WSP> f0;
+    if constexpr (kPinned) stage8_prologue<T, WSP, ISO>(f0, slot, ybuf + sl * C::NSC, wbuf + sl * C::NSC, lane);
     const int tdn = t + 1 - nprior_stages;  // next data stage
 #if BLR_EXP != 4
     const int tdn_min = (kGlds && nprior_stages > 0) ? 0 : 1;
     if (tdn >= tdn_min && tdn < ndata_stages) {  // in flight while this stage computes
       ring_slot = slot0 + ((t + 1) & 1) * C::SLOT;
-      issue(tdn);
+      ring_ybuf = ybuf + ((t + 1) & 1) * C::NSC;
+      issue(tdn, iso_tag);
     }
 #endif
-    compute_stage<T, NB, WS>(slot, ybuf + sl * C::NSC, wbuf + sl * C::NSC, ops, acc, bacc, qacc, mwl, wave, lane, is_data);
+    BLR_GSTAMP(2);
+    if constexpr (kPinned) {
+      __builtin_amdgcn_sched_barrier(0);
+      stage8_body<T, WSP, ISO>(f0, slot, ybuf + sl * C::NSC, wbuf + sl * C::NSC, acc, bacc, qacc, mwf, wiso, lane,
+                               is_data ? T(1) : T(0));
+    } else {
+      compute_stage<T, NB, WS>(slot, ybuf + sl * C::NSC, wbuf + sl * C::NSC, ops, acc, bacc, qacc, mwl, wave, lane, is_data);
+    }
+    BLR_GSTAMP(3);
   }
   };
   // NB == 8 (the MFMA-bound headline shape) and NB == 4 (config 4, D = 64): one copy of the stage loop per wave,
   // wave index static
-  if constexpr (NB == 8 || NB == 4) {
+  if constexpr (NB == 8) {
+    if (iso_fast) {
+      if constexpr (kGlds) {
+        T mwf[8];
+#pragma unroll
+        for (int I = 0; I < 8; ++I) mwf[I] = mwl[16 * I + (lane & 15)];
+        const T wiso = T(1) / s_iso;
+#ifdef BLR_GRAM_STAMPS
+        const unsigned long long ck0 = __builtin_amdgcn_s_memtime(), rt0 = __builtin_amdgcn_s_memrealtime();
+#endif
+        bool mwz = true;
+#pragma unroll
+        for (int I = 0; I < 8; ++I) mwz = mwz && (mwf[I] == T(0));
+        mwz = __all(mwz);  // the 64 lanes of a wave hold all 128 entries of mw: wave-uniform, and the same in every wave
+        auto ring = [&](auto ws, auto mz) {
+          gram_iso_ring<T, decltype(ws)::value, decltype(mz)::value>(slot0, ybuf, X, y, ldx, N, voff, lane, acc, bacc, qacc, mwf, wiso);
+        };
+        auto ring_w = [&](auto mz) {
+          switch (wave) {
+            case 0: ring(std::integral_constant<int, 0>{}, mz); break;
+            case 1: ring(std::integral_constant<int, 1>{}, mz); break;
+            case 2: ring(std::integral_constant<int, 2>{}, mz); break;
+            default: ring(std::integral_constant<int, 3>{}, mz); break;
+          }
+        };
+        if (mwz) ring_w(std::true_type{});
+        else ring_w(std::false_type{});
+#ifdef BLR_GRAM_STAMPS
+        if ((blockIdx.x & 255) == 0 && lane == 0) {  // whole-loop cycles and 100 MHz ticks: the clock the chip holds under this load
+          g_gstamps[wave][5] += __builtin_amdgcn_s_memtime() - ck0;
+          g_gstamps[wave][6] += __builtin_amdgcn_s_memrealtime() - rt0;
+          g_gstamps[wave][7] += 1;
+        }
+#endif
+      }
+      {
+        acc4 pr[C::TPW];
+        load_prior(pr);
+        const T winv = T(1) / s_iso;
+#pragma unroll
+        for (int i = 0; i < C::TPW; ++i)
+#pragma unroll
+          for (int v = 0; v < 4; ++v) acc[i][v] = pr[i][v] + acc[i][v] * winv;
+      }
+    } else {
+      switch (wave) {
+        case 0: run_stages(std::integral_constant<int, 0>{}, std::false_type{}); break;
+        case 1: run_stages(std::integral_constant<int, 1>{}, std::false_type{}); break;
+        case 2: run_stages(std::integral_constant<int, 2>{}, std::false_type{}); break;
+        default: run_stages(std::integral_constant<int, 3>{}, std::false_type{}); break;
+      }
+    }
+  } else if constexpr (NB == 4) {
     switch (wave) {
-      case 0: run_stages(std::integral_constant<int, 0>{}); break;
-      case 1: run_stages(std::integral_constant<int, 1>{}); break;
-      case 2: run_stages(std::integral_constant<int, 2>{}); break;
-      default: run_stages(std::integral_constant<int, 3>{}); break;
+      case 0: run_stages(std::integral_constant<int, 0>{}, std::false_type{}); break;
+      case 1: run_stages(std::integral_constant<int, 1>{}, std::false_type{}); break;
+      case 2: run_stages(std::integral_constant<int, 2>{}, std::false_type{}); break;
+      default: run_stages(std::integral_constant<int, 3>{}, std::false_type{}); break;
     }
   } else {
-    run_stages(std::integral_constant<int, -1>{});
+    run_stages(std::integral_constant<int, -1>{}, std::false_type{});
   }
 
   // b partials -> LDS -> fixed-order sum
@@ -727,6 +1172,7 @@ BLR_PHASE int phase_chol(char* smem, int D_in, int with_rhs_in) {
     BLR_STAMP(5);
   }
   __syncthreads();
+  BLR_STAMP_FLUSH;
   return info;
 }
 
@@ -857,13 +1303,13 @@ __global__ __launch_bounds__(kThreads, (NB <= 4 ? 4 : (sizeof(T) == 4 ? BLR_F32_
     }
     int info = 0;
     double logdet_Lw = 0.0;
+    BLR_PSTAMP_INIT;
 
     // ---- phase 0: prior -----------------------------------------------------------------------
     if (a.prior_kind == PRIOR_DENSE) {
-      for (int idx = tid; idx < D * D; idx += kThreads) {  // upper triangle (k <= i) of column i
-        int i = idx / D, k = idx % D;
-        if (k <= i) P[pidx(i, k)] = Lw[(int64_t)i * a.ldl + k];
-      }
+      // upper triangle (k <= i) of column i; columns over waves, rows over lanes: no per-element integer division
+      for (int i = tid >> 6; i < D; i += kWaves)
+        for (int k = tid & 63; k <= i; k += kWave) P[pidx(i, k)] = Lw[(int64_t)i * a.ldl + k];
       for (int idx = D * (D + 1) / 2 + tid; idx < C::PACKED; idx += kThreads) P[idx] = T(0);  // padded rows
       __syncthreads();
       info = phase_chol<T, NB>(smem, D, 0);  // :78
@@ -893,7 +1339,9 @@ __global__ __launch_bounds__(kThreads, (NB <= 4 ? 4 : (sizeof(T) == 4 ? BLR_F32_
 
     // ---- phase 1: streaming Gram -> P, bvec, scr[4..5] ------------------------------------------------
     __syncthreads();
+    BLR_PSTAMP(0);
     phase_gram<T, NB, MODE>(smem);
+    BLR_PSTAMP(1);
 #if BLR_EXP >= 1 && BLR_EXP <= 4
     if (tid == 0) {
       a.info[reg] = 0;
@@ -905,14 +1353,14 @@ __global__ __launch_bounds__(kThreads, (NB <= 4 ? 4 : (sizeof(T) == 4 ? BLR_F32_
 
     if (a.Lw_post) {  // posterior precision Lw' = A, full symmetric (:92)
       T* out = a.Lw_post + (int64_t)reg * a.strideLp;
-      for (int idx = tid; idx < D * D; idx += kThreads) {
-        int c = idx / D, r = idx % D;
-        out[(int64_t)c * a.ldlp + r] = (r >= c) ? P[pidx(r, c)] : P[pidx(c, r)];
-      }
+      for (int c = tid >> 6; c < D; c += kWaves)
+        for (int r = tid & 63; r < D; r += kWave) out[(int64_t)c * a.ldlp + r] = (r >= c) ? P[pidx(r, c)] : P[pidx(c, r)];
     }
 
     // ---- phase 2: blocked Cholesky + fused forward substitution ------------------------------------------
+    BLR_PSTAMP(2);
     info = phase_chol<T, NB>(smem, D, 1);  // :86; T = L' is chol(Lw + G).U (:67)
+    BLR_PSTAMP(3);
     if (info != 0) {
       if (tid == 0) {
         a.info[reg] = info;
@@ -922,14 +1370,14 @@ __global__ __launch_bounds__(kThreads, (NB <= 4 ? 4 : (sizeof(T) == 4 ? BLR_F32_
     }
     if (a.T_post) {
       T* out = a.T_post + (int64_t)reg * a.strideT;
-      for (int idx = tid; idx < D * D; idx += kThreads) {
-        int c = idx / D, r = idx % D;
-        out[(int64_t)c * a.ldt + r] = (r <= c) ? P[pidx(c, r)] : T(0);
-      }
+      for (int c = tid >> 6; c < D; c += kWaves)
+        for (int r = tid & 63; r < D; r += kWave) out[(int64_t)c * a.ldt + r] = (r <= c) ? P[pidx(c, r)] : T(0);
     }
 
     // ---- phase 3: back substitution + evidence ---------------------------------------------------------
+    BLR_PSTAMP(4);
     phase_backsolve<T, NB>(smem, D);
+    BLR_PSTAMP(5);
     if (a.mw_post && tid < D) a.mw_post[(int64_t)reg * a.stride_mwpost + tid] = mw[tid] + bvec[tid];  // :68
     if (tid == 0) {
       a.info[reg] = 0;
@@ -938,6 +1386,10 @@ __global__ __launch_bounds__(kThreads, (NB <= 4 ? 4 : (sizeof(T) == 4 ? BLR_F32_
         a.logpdf[reg] = -0.5 * ((double)N * LOG2PI + logdet_Sy + quad + scr[7] - logdet_Lw - scr[6]);  // :84 + :57
       }
     }
+    BLR_PSTAMP(6);
+#ifdef BLR_GRAM_STAMPS
+    if (blockIdx.x == 0 && tid == 0) g_pstamps[15] += 1;
+#endif
   }
 }
 

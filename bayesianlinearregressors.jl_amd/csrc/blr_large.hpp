@@ -247,7 +247,7 @@ __global__ __launch_bounds__(kThreads, 2) void gram_tile_kernel(GramTileArgs<T> 
   auto load_side = [&](T* dst, const T* base, int64_t ldb, int Drows, int row0, int n0) {
     const int rows = min(kPB, Drows - row0);  // may be <= 0 for padding blocks: everything zero-filled
     if (a.use_dma) {
-      stage_glds<T, 8, L::KS>(dst, base + row0, ldb, rows, c1, n0, wave, lane);
+      stage_glds<T, 8, L::KS>(dst, as_global(base + row0), ldb, rows, c1, n0, wave, lane);
     } else {
       int tt = tid;
       asm volatile("" : "+v"(tt));

@@ -5,6 +5,9 @@
 #include <vector>
 #include <cmath>
 #include "blr_fused_small.hpp"
+#ifndef BLR_STAMPS
+namespace blr { __device__ unsigned long long g_stamps[8]; }
+#endif
 using namespace blr;
 #define CK(x) do { hipError_t e_ = (x); if (e_ != hipSuccess) { printf("HIP error %s at %d\n", hipGetErrorString(e_), __LINE__); return 1; } } while (0)
 
