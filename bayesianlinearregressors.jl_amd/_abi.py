@@ -171,9 +171,15 @@ class Handle:
     def set_stream(self, stream_ptr):
         """Run on the caller's hipStream_t (0 / None = the HIP null stream, torch's default stream)."""
         self.check(self.lib.blr_set_stream(self._h, _vp(int(stream_ptr)) if stream_ptr else None))
+        self._caller_stream = (int(stream_ptr) if stream_ptr else 0,)
 
     def reset_stream(self):
         self.check(self.lib.blr_reset_stream(self._h))
+        self._caller_stream = None
+
+    def current_stream_setting(self):
+        """None = the handle's own stream, else a 1-tuple holding the caller stream pointer (0 = the null stream)."""
+        return getattr(self, "_caller_stream", None)
 
     def set_async(self, flag):
         self.check(self.lib.blr_set_async(self._h, int(bool(flag))))

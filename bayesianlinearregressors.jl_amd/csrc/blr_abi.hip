@@ -171,13 +171,10 @@ bool aligned16(const T* p, int64_t ld, int64_t stride) {
 template <typename T, int NB, int MODE>
 int launch_fused_small(blr_handle* h, const PosteriorArgs<T>& a) {
   using C = SmallCfg<T, NB>;
-  static bool attr_set = false;
   auto kern = fused_small_kernel<T, NB, MODE>;
-  if (!attr_set) {
-    HIP_TRY(h, hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize,
-                                   C::LDS_BYTES));
-    attr_set = true;
-  }
+  // every launch: the attribute is per DEVICE, and handles on different devices share this code (a process-wide
+  // "already set" flag left the second device at the 64 KB default)
+  HIP_TRY(h, hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, C::LDS_BYTES));
   int grid = (int)std::min<int64_t>(a.B, 1 << 20);
   hipLaunchKernelGGL(kern, dim3(grid), dim3(kThreads), C::LDS_BYTES, h->stream, a);
   HIP_TRY(h, hipGetLastError());
@@ -299,6 +296,7 @@ int posterior_large_one(blr_handle* h, const PosteriorArgs<T>& a, int64_t reg) {
   double* logdetLw = reinterpret_cast<double*>(ws + o_sc);
   int32_t* info_prior = reinterpret_cast<int32_t*>(ws + o_sc + 8);
   int32_t* info_chol = reinterpret_cast<int32_t*>(ws + o_sc + 12);
+  unsigned* info_noise = reinterpret_cast<unsigned*>(ws + o_sc + 16);
 
   const T* X = a.X + reg * a.strideX;
   const T* y = a.y + reg * a.stridey;
@@ -307,6 +305,7 @@ int posterior_large_one(blr_handle* h, const PosteriorArgs<T>& a, int64_t reg) {
   const T* Lw = a.Lw + reg * a.strideLw;
 
   HIP_TRY(h, hipMemsetAsync(ws + o_sc, 0, 64, h->stream));
+  HIP_TRY(h, hipMemsetAsync(info_noise, 0xFF, sizeof(unsigned), h->stream));
   HIP_TRY(h, hipMemsetAsync(bpart, 0, (size_t)nsplit_total * NC * kPB * sizeof(double), h->stream));
 
   // ---- prior: SPD check + logdet (reference :78)
@@ -323,6 +322,7 @@ int posterior_large_one(blr_handle* h, const PosteriorArgs<T>& a, int64_t reg) {
   {
     ColstatsArgs<T> c{};
     c.X = X; c.ldx = a.ldx; c.y = y; c.s = s; c.mw = mw; c.r = rvec; c.qpart = qpart; c.lpart = lpart;
+    c.noise_info = info_noise;
     c.layout = a.layout; c.noise_kind = a.noise_kind; c.D = D; c.N = N;
     size_t lds = (((size_t)D * sizeof(T) + 15) & ~(size_t)15) + 64;
     hipLaunchKernelGGL(colstats_kernel<T>, dim3(gridc), dim3(kThreads), lds, h->stream, c);
@@ -377,6 +377,7 @@ int posterior_large_one(blr_handle* h, const PosteriorArgs<T>& a, int64_t reg) {
     b.qpart = qpart; b.lpart = lpart; b.nparts = gridc; b.logdet_Lw_dev = logdetLw;
     b.noise_kind = a.noise_kind; b.s = s; b.N = N;
     b.logpdf = a.logpdf ? a.logpdf + reg : nullptr; b.info = a.info + reg; b.chol_info = info_chol;
+    b.prior_info = info_prior; b.noise_info = info_noise;
     if ((rc = launch_wave_solve<T>(h, b, NC, 1))) return rc;
   }
   HIP_TRY(h, hipGetLastError());
@@ -403,7 +404,7 @@ int posterior_batched(blr_handle* h, int memspace, int layout, int64_t B, int64_
   h->err.clear();
   if (memspace != BLR_MEM_HOST && memspace != BLR_MEM_DEVICE) return bad_arg(h, 2, "memspace");
   if (layout != BLR_LAYOUT_COLVECS && layout != BLR_LAYOUT_ROWVECS) return bad_arg(h, 3, "unknown layout (reference :26-31)");
-  if (B < 0) return bad_arg(h, 4, "B < 0");
+  if (B < 0 || B > (1 << 30)) return bad_arg(h, 4, "B out of range (0..2^30)");
   if (D < 1) return bad_arg(h, 5, "D < 1");
   if (D > kMaxLargeD) return bad_arg(h, 5, "D > 8192 is not supported by this build");
   if (N < 0 || N > (1 << 30)) return bad_arg(h, 6, "N out of range");
@@ -608,7 +609,7 @@ int marginals_batched(blr_handle* h, int memspace, int layout, int64_t B, int64_
   h->err.clear();
   if (memspace != BLR_MEM_HOST && memspace != BLR_MEM_DEVICE) return bad_arg(h, 2, "memspace");
   if (layout != BLR_LAYOUT_COLVECS && layout != BLR_LAYOUT_ROWVECS) return bad_arg(h, 3, "unknown layout (reference :26-31)");
-  if (B < 0) return bad_arg(h, 4, "B < 0");
+  if (B < 0 || B > (1 << 30)) return bad_arg(h, 4, "B out of range (0..2^30)");
   if (D < 1 || D > kMaxLargeD) return bad_arg(h, 5, "D out of range for this build (1..8192)");
   if (N < 0 || N > (1 << 30)) return bad_arg(h, 6, "N out of range");
   if (B == 0 || N == 0) return 0;
@@ -691,8 +692,11 @@ int marginals_batched(blr_handle* h, int memspace, int layout, int64_t B, int64_
     const int64_t ntiles = (N + TC::RB - 1) / TC::RB;
     const int64_t slots = use_factor ? 512 : 1024;
     const int64_t per_reg = std::max<int64_t>(1, std::min<int64_t>(ntiles, (slots + B - 1) / B));
-    dim3 grid((unsigned)per_reg, (unsigned)B);
-    hipLaunchKernelGGL(kern, grid, dim3(kThreads), lds, h->stream, a);
+    for (int64_t b0 = 0; b0 < B; b0 += 65535) {  // grid.y <= 65535
+      a.reg0 = (int)b0;
+      dim3 grid((unsigned)per_reg, (unsigned)std::min<int64_t>(65535, B - b0));
+      hipLaunchKernelGGL(kern, grid, dim3(kThreads), lds, h->stream, a);
+    }
   }
   HIP_TRY(h, hipGetLastError());
   if (memspace == BLR_MEM_HOST) {
@@ -948,7 +952,7 @@ int logpdf_grad_batched(blr_handle* h, int memspace, int layout, int64_t B, int6
   h->err.clear();
   if (memspace != BLR_MEM_HOST && memspace != BLR_MEM_DEVICE) return bad_arg(h, 2, "memspace");
   if (layout != BLR_LAYOUT_COLVECS && layout != BLR_LAYOUT_ROWVECS) return bad_arg(h, 3, "unknown layout (reference :26-31)");
-  if (B < 0) return bad_arg(h, 4, "B < 0");
+  if (B < 0 || B > (1 << 30)) return bad_arg(h, 4, "B out of range (0..2^30)");
   if (D < 1 || D > kMaxLargeD) return bad_arg(h, 5, "D out of range for this build (1..8192)");
   if (N < 1 || N > (1 << 30)) return bad_arg(h, 6, "N out of range (>= 1)");
   if (B == 0) return 0;
@@ -1083,7 +1087,10 @@ int logpdf_grad_batched(blr_handle* h, int memspace, int layout, int64_t B, int6
     auto kern = logpdf_grad_kernel<T>;
     const int lds = TC::LDS_BYTES + (kPB + 3 * TC::RB) * (int)sizeof(T);
     HIP_TRY(h, hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, lds));
-    hipLaunchKernelGGL(kern, dim3((unsigned)per_reg, (unsigned)B), dim3(kThreads), lds, h->stream, g);
+    for (int64_t b0 = 0; b0 < B; b0 += 65535) {  // grid.y <= 65535
+      g.reg0 = (int)b0;
+      hipLaunchKernelGGL(kern, dim3((unsigned)per_reg, (unsigned)std::min<int64_t>(65535, B - b0)), dim3(kThreads), lds, h->stream, g);
+    }
     if (dmw_d)
       hipLaunchKernelGGL(grad_reduce_kernel<T>, dim3((unsigned)B), dim3(kPB), 0, h->stream, (const double*)part, (int)per_reg,
                          dmw_d, stridedmw, (int)D);
@@ -1497,6 +1504,7 @@ int rff_features(blr_handle* h, int memspace, int64_t Din, int64_t D, int64_t N,
   if (N < 0 || N > (1 << 30)) return bad_arg(h, 5, "N out of range");
   if (N == 0) return 0;
   if (!Xin) return bad_arg(h, 6, "Xin is NULL");
+  if ((N + 15) / 16 > 65535) return bad_arg(h, 5, "N > 1048560 inputs per feature-map call (launch geometry)");
   if (ldxin < Din) return bad_arg(h, 7, "ldxin < Din");
   if (!Omega) return bad_arg(h, 8, "Omega is NULL");
   if (ldo < Din) return bad_arg(h, 9, "ldo < Din");

@@ -49,6 +49,7 @@ struct MarginalArgs {
   const int32_t* info;  // per-regressor status of a preceding factorisation (may be NULL)
   int layout, noise_kind, prior_kind;
   int D, N, B;
+  int reg0;  // first regressor of this launch (grid.y is limited to 65535)
 };
 
 // ---- Y = X'W .+ sqrt.(s) .* Z2   (:52) ---------------------------------------------------------------

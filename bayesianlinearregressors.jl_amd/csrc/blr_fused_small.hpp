@@ -837,6 +837,8 @@ BLR_PHASE void phase_gram(char* smem) {
   for (int I = 0; I < NB; ++I) bacc[I] = 0.0;
   if (tid < C::DP) mwl[tid] = tid < D ? mw[tid] : T(0);  // visible after the first stage barrier
   double qacc = 0.0, lacc = 0.0;
+  // first observation whose noise variance is not positive (reference :79, _cholesky(Sigma_y) throws PosDefException there)
+  int bad_noise = diag_noise ? 0x7fffffff : ((s_iso > T(0)) ? 0x7fffffff : 1);
 
   const int ndata_stages = (N + C::NSC - 1) / C::NSC;
   const int nstages = nprior_stages + ndata_stages;
@@ -872,6 +874,7 @@ BLR_PHASE void phase_gram(char* smem) {
         T sv = diag_noise ? s[n0 + tid] : s_iso;
         regs.wv = T(1) / sv;                       // :79/:81  Sigma_y^-1 on the diagonal
         if (diag_noise) lacc += log((double)sv);   // :84  logdet(Sigma_y)
+        if (!(sv > T(0))) bad_noise = min(bad_noise, n0 + tid + 1);  // also catches NaN
       }
     }
   };
@@ -1027,6 +1030,11 @@ BLR_PHASE void phase_gram(char* smem) {
   if (!diag_noise) logdet_Sy = (double)N * log((double)s_iso);
   // (block_allreduce's barriers also fence the reads of `red` above)
   if (tid == 0) { scr[4] = quad; scr[5] = logdet_Sy; }
+  {
+    int* const iscr = reinterpret_cast<int*>(smem + C::OFF_SCR + 64);
+    bad_noise = block_min_int(bad_noise, iscr, tid);
+    if (tid == 0) iscr[6] = bad_noise;  // read back by the kernel after the phase's final barrier
+  }
 
   // A: accumulators -> packed lower triangle
 #pragma unroll
@@ -1350,6 +1358,13 @@ __global__ __launch_bounds__(kThreads, (NB <= 4 ? 4 : (sizeof(T) == 4 ? BLR_F32_
     continue;
 #endif
     const double quad = scr[4], logdet_Sy = scr[5];
+    if (iscr[6] != 0x7fffffff) {  // Sigma_y is not positive definite (block-uniform): PosDefException(index), as :79 would throw
+      if (tid == 0) {
+        a.info[reg] = iscr[6];
+        if (a.logpdf) a.logpdf[reg] = kNaN;
+      }
+      continue;
+    }
 
     if (a.Lw_post) {  // posterior precision Lw' = A, full symmetric (:92)
       T* out = a.Lw_post + (int64_t)reg * a.strideLp;

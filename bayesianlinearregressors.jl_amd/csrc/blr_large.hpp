@@ -45,6 +45,7 @@ struct ColstatsArgs {
   T* r;               // [N]  delta_n / s_n
   double* qpart;      // [gridDim.x]
   double* lpart;      // [gridDim.x]
+  unsigned* noise_info;  // atomicMin target, 0xFFFFFFFF = every variance positive; else 1-based index of the first bad one (NULL: off)
   int layout, noise_kind, D, N;
 };
 
@@ -60,6 +61,7 @@ __global__ __launch_bounds__(kThreads) void colstats_kernel(ColstatsArgs<T> a) {
   const bool diag = a.noise_kind == NOISE_DIAGONAL;
   const T s_iso = diag ? T(1) : a.s[0];
   double q = 0.0, l = 0.0;
+  unsigned bad = 0xFFFFFFFFu;  // reference :79: _cholesky(Sigma_y) throws at the first variance that is not positive
   typedef T vecT __attribute__((ext_vector_type(Mfma<T>::VEC)));
   constexpr int VEC = Mfma<T>::VEC;
   const bool vec_ok = a.layout == LAYOUT_COLVECS && (D % VEC) == 0 && (a.ldx % VEC) == 0 && ((uintptr_t)a.X % 16) == 0;
@@ -101,6 +103,7 @@ __global__ __launch_bounds__(kThreads) void colstats_kernel(ColstatsArgs<T> a) {
         const int nn = n + lane;
         const double mu = lane == 0 ? mu0 : mu1;
         const T sv = diag ? a.s[nn] : s_iso;
+        if (!(sv > T(0))) bad = min(bad, (unsigned)(nn + 1));
         const T delta = a.y[nn] - (T)mu;
         const T rn = delta / sv;
         a.r[nn] = rn;
@@ -116,6 +119,7 @@ __global__ __launch_bounds__(kThreads) void colstats_kernel(ColstatsArgs<T> a) {
       for (int d = lane; d < D; d += 64) mu += (double)col[d] * (double)mwl[d];
       mu = wave_allreduce(mu);
       const T sv = diag ? a.s[n] : s_iso;
+      if (!(sv > T(0))) bad = min(bad, (unsigned)(n + 1));
       const T delta = a.y[n] - (T)mu;
       const T rn = delta / sv;
       if (lane == 0) {
@@ -130,6 +134,7 @@ __global__ __launch_bounds__(kThreads) void colstats_kernel(ColstatsArgs<T> a) {
       double mu = 0.0;
       for (int d = 0; d < D; ++d) mu += (double)a.X[(int64_t)d * a.ldx + n] * (double)mwl[d];
       const T sv = diag ? a.s[n] : s_iso;
+      if (!(sv > T(0))) bad = min(bad, (unsigned)(n + 1));
       const T delta = a.y[n] - (T)mu;
       const T rn = delta / sv;
       a.r[n] = rn;
@@ -140,6 +145,7 @@ __global__ __launch_bounds__(kThreads) void colstats_kernel(ColstatsArgs<T> a) {
   q = block_allreduce(q, scr, tid);
   l = block_allreduce(l, scr, tid);
   if (tid == 0) { a.qpart[blockIdx.x] = q; a.lpart[blockIdx.x] = l; }
+  if (a.noise_info && bad != 0xFFFFFFFFu) atomicMin(a.noise_info, bad);  // rare path; min is order-independent
 }
 
 // ---- 128 x 128 macro tile of a (weighted) Gram matrix ---------------------------------------------------------
@@ -929,6 +935,9 @@ struct WaveSolveArgs {
   int noise_kind; const T* s; int N;
   double n_total;                        // > 0: number of observations behind the (summed) statistics (N-sharded finish)
   double* logpdf; int32_t* info; const int32_t* chol_info;
+  // status precedence of the reference (:78 prior, :79 noise, :86 posterior): chol_info is seeded with the prior's status
+  const int32_t* prior_info;     // may be NULL
+  const unsigned* noise_info;    // colstats_kernel's atomicMin target (0xFFFFFFFF = ok); may be NULL
 };
 
 __device__ __forceinline__ void xchg_put(unsigned long long* g, float v, unsigned tag) {
@@ -973,9 +982,15 @@ __global__ __launch_bounds__(kThreads) void backsolve_wave_kernel(WaveSolveArgs<
   const int64_t sidx = ticket / NC;
   const bool evidence = a.info != nullptr && q == 0 && sidx == 0;
   const double kNaN = __longlong_as_double(0x7ff8000000000000LL);
-  if (a.chol_info && *a.chol_info != 0) {  // uniform over the grid: nobody waits
-    if (evidence && tid == 0) { *a.info = *a.chol_info; if (a.logpdf) *a.logpdf = kNaN; }
-    return;
+  {
+    int st = 0;
+    if (a.prior_info && *a.prior_info != 0) st = *a.prior_info;
+    else if (a.noise_info && *a.noise_info != 0xFFFFFFFFu) st = (int)*a.noise_info;
+    else if (a.chol_info && *a.chol_info != 0) st = *a.chol_info;
+    if (st != 0) {  // uniform over the grid: nobody waits
+      if (evidence && tid == 0) { *a.info = st; if (a.logpdf) *a.logpdf = kNaN; }
+      return;
+    }
   }
   const T* rhs = a.rhs + sidx * a.ldrhs;
   unsigned long long* xg = a.xchg + (sidx * DP) * 2;
@@ -1369,7 +1384,7 @@ __global__ __launch_bounds__(kThreads) void marginals_mfma_kernel(MarginalArgs<T
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = uni(tid >> 6);
   const int D = a.D, N = a.N;
-  const int reg = blockIdx.y;
+  const int reg = a.reg0 + blockIdx.y;  // grid.y is limited to 65535: the host launches in chunks
   if (a.info && a.info[reg] != 0) return;
   const T* X = a.X + (int64_t)reg * a.strideX;
   const T* U = a.U + (int64_t)reg * a.strideU;
@@ -1582,6 +1597,7 @@ struct GradArgs {
   const int32_t* info;
   int layout, noise_kind;
   int D, N, B;
+  int reg0;  // first regressor of this launch
 };
 
 template <typename T>
@@ -1601,7 +1617,7 @@ __global__ __launch_bounds__(kThreads) void logpdf_grad_kernel(GradArgs<T> a) {
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = uni(tid >> 6);
   const int D = a.D, N = a.N;
-  const int reg = blockIdx.y;
+  const int reg = a.reg0 + blockIdx.y;  // grid.y is limited to 65535: the host launches in chunks
   const int nchunks = (D + 15) >> 4, DPc = nchunks * 16;
   double dmw_acc = 0.0;  // thread c < 128: sum over this workgroup's tiles of x_cn w_n r_n
   const bool ok = !(a.info && a.info[reg] != 0);

@@ -153,11 +153,24 @@ def _x_layout(x, dtype):
     return M, _abi.LAYOUT_COLVECS, max(D, 1), D, N
 
 
-def _noise(Sy, N, dtype):
-    """-> (array, noise_kind).  Scalar = f(x, sigma^2); vector / Diagonal = Diagonal(v)."""
+def _first_nonpositive(v):
+    """1-based index of the first entry that is not > 0 (NaN included), 0 if all are: LAPACK `info` of a diagonal Cholesky."""
+    bad = np.flatnonzero(~(np.asarray(v) > 0))
+    return int(bad[0]) + 1 if bad.size else 0
+
+
+def _noise(Sy, N, dtype, need_cholesky=False):
+    """-> (array, noise_kind).  Scalar = f(x, sigma^2); vector / Diagonal = Diagonal(v).
+    ``need_cholesky``: the caller's reference method runs _cholesky(Sigma_y) (rand, :52) and the kernel behind it does not
+    report a non-positive variance itself -- raise PosDefException here, as the reference would (logpdf / posterior get it
+    from the kernel's info)."""
     if isinstance(Sy, Diagonal):
         Sy = Sy.diag
     Sy = np.asarray(Sy, dtype=dtype)
+    if Sy.ndim <= 1 and need_cholesky:
+        k = _first_nonpositive(Sy.reshape(-1))
+        if k:
+            raise _abi.PosDefException(k)
     if Sy.ndim == 0:
         return Sy.reshape(1).copy(), _abi.NOISE_ISOTROPIC
     if Sy.ndim == 1:
@@ -170,12 +183,26 @@ def _noise(Sy, N, dtype):
     )
 
 
-def _prior(Lw, D, dtype):
-    """-> (array, prior_kind, ldl)."""
+def _mean_vector(mw, D, dtype):
+    """The prior mean as a contiguous vector of the working dtype; its length must be the input dimension (the library copies
+    D elements from this buffer: a shorter one would be read past its end instead of raising the reference's DimensionMismatch)."""
+    mw = np.ascontiguousarray(mw, dtype=dtype)
+    if mw.ndim != 1 or mw.shape[0] != D:
+        raise ValueError(f"length(mw) = {mw.shape[0] if mw.ndim == 1 else mw.shape} != dimension of the inputs ({D})")
+    return mw
+
+
+def _prior(Lw, D, dtype, need_cholesky=False):
+    """-> (array, prior_kind, ldl).  ``need_cholesky``: see _noise (var / rand / weight draws with a Diagonal precision are
+    elementwise kernels that do not report a non-positive entry; the reference's _cholesky(Lw) at :41 / :51 throws)."""
     if isinstance(Lw, Diagonal):
         d = np.ascontiguousarray(Lw.diag, dtype=dtype)
         if d.shape[0] != D:
             raise ValueError("size of the prior precision != length(mw)")
+        if need_cholesky:
+            k = _first_nonpositive(d)
+            if k:
+                raise _abi.PosDefException(k)
         return d, _abi.PRIOR_DIAGONAL, 1
     if isinstance(Lw, PDMat):
         U = np.asfortranarray(Lw.U, dtype=dtype)
@@ -250,7 +277,10 @@ class RandomFourierFeatures:
     def _operands(self, x, dtype):
         X, layout, ldx, Din, N = _x_layout(x, dtype)
         if layout != _abi.LAYOUT_COLVECS:  # the feature kernel reads ColVecs inputs (D_in is tiny: one small copy)
-            X = np.asfortranarray(X if X.shape[0] == Din else X.T, dtype=dtype)
+            # ROWVECS layout = N x D_in column-major.  Which axis of the numpy array is N follows from the CONTAINER and the
+            # memory order that _x_layout resolved -- never from comparing shapes (a square N == D_in input is ambiguous).
+            M = X if isinstance(x, RowVecs) else X.T  # -> (N, D_in) view of the same memory
+            X = np.asfortranarray(M.T, dtype=dtype)     # (D_in, N) column-major: ColVecs
             ldx = max(Din, 1)
         if Din != self.Omega.shape[0]:
             raise ValueError("input dimension != rows of Omega")
@@ -314,9 +344,7 @@ def _fused_rff(fx, y, want_posterior):
     y = np.ascontiguousarray(y, dtype=dtype)
     if y.ndim != 1 or y.shape[0] != N:
         raise ValueError("length(y) != size(fx.x.X, 2)")  # reference :74
-    mw = np.ascontiguousarray(blr.mw, dtype=dtype)
-    if mw.shape[0] != D:
-        raise ValueError("length(mw) != number of features")
+    mw = _mean_vector(blr.mw, D, dtype)
     s, noise_kind = _noise(fx.Sy, N, dtype)
     Lw, prior_kind, ldl = _prior(blr.Lw, D, dtype)
     lp = np.zeros(1, dtype=np.float64)
@@ -345,9 +373,7 @@ def _fused(fx, y, want_posterior):
         raise ValueError("y must be a vector")
     if y.shape[0] != N:
         raise ValueError("length(y) != size(fx.x.X, 2)")  # reference :74
-    mw = np.ascontiguousarray(blr.mw, dtype=dtype)
-    if mw.shape[0] != D:
-        raise ValueError("length(mw) != dimension of the inputs")
+    mw = _mean_vector(blr.mw, D, dtype)
     s, noise_kind = _noise(fx.Sy, N, dtype)
     Lw, prior_kind, ldl = _prior(blr.Lw, D, dtype)
     lp = np.zeros(1, dtype=np.float64)
@@ -382,7 +408,7 @@ def logpdf_columns(fx, Y, return_means=False):
     if Yf.shape[0] != N:
         raise ValueError("length(y) != size(fx.x.X, 2)")
     S = Yf.shape[1]
-    mw = np.ascontiguousarray(blr.mw, dtype=dtype)
+    mw = _mean_vector(blr.mw, D, dtype)
     s, noise_kind = _noise(fx.Sy, N, dtype)
     Lw, prior_kind, ldl = _prior(blr.Lw, D, dtype)
     lp = np.zeros(S, dtype=np.float64)
@@ -421,7 +447,7 @@ def logpdf_and_gradient(fx, y):
     y = np.ascontiguousarray(y, dtype=dtype)
     if y.ndim != 1 or y.shape[0] != N:
         raise ValueError("length(y) != size(fx.x.X, 2)")  # reference :74
-    mw = np.ascontiguousarray(blr.mw, dtype=dtype)
+    mw = _mean_vector(blr.mw, D, dtype)
     s, noise_kind = _noise(fx.Sy, N, dtype)
     Lw, prior_kind, ldl = _prior(blr.Lw, D, dtype)
     lp = np.zeros(1, dtype=np.float64)
@@ -476,11 +502,9 @@ def _marginals(fx, want_mean, want_var):
     blr = fx.f
     dtype = _dtype_of(blr.mw)
     X, layout, ldx, D, N = _x_layout(fx.x, dtype)
-    mw = np.ascontiguousarray(blr.mw, dtype=dtype)
-    if mw.shape[0] != D:
-        raise ValueError("length(mw) != dimension of the inputs")
-    s, noise_kind = _noise(fx.Sy, N, dtype)
-    Lw, prior_kind, ldl = _prior(blr.Lw, D, dtype)
+    mw = _mean_vector(blr.mw, D, dtype)
+    s, noise_kind = _noise(fx.Sy, N, dtype)  # var adds diag(Sigma_y) (:43): no factorisation of the noise, no positivity check
+    Lw, prior_kind, ldl = _prior(blr.Lw, D, dtype, need_cholesky=want_var)  # :41 _cholesky(Lw)
     m = np.empty(N, dtype=dtype) if want_mean else None
     v = np.empty(N, dtype=dtype) if want_var else None
     info = np.zeros(1, dtype=np.int32)
@@ -552,8 +576,8 @@ def _blr_and_mapping(b):
 def _sample_weights(rng, blr, S):
     dtype = _dtype_of(blr.mw)
     D = blr.mw.shape[0]
-    mw = np.ascontiguousarray(blr.mw, dtype=dtype)
-    Lw, prior_kind, ldl = _prior(blr.Lw, D, dtype)
+    mw = _mean_vector(blr.mw, D, dtype)
+    Lw, prior_kind, ldl = _prior(blr.Lw, D, dtype, need_cholesky=True)  # sampling_functions.jl:29,35,44 _cholesky(Lw)
     Z = _randn(rng, D, S, dtype)
     W = np.empty((D, S), dtype=dtype, order="F")
     _handle().sample_weights(dtype, _abi.MEM_HOST, D, S, prior_kind, mw, Lw, ldl, Z, D, W, D)
@@ -597,9 +621,9 @@ def _rand_finite(rng, fx, S):
     blr = fx.f
     dtype = _dtype_of(blr.mw)
     X, layout, ldx, D, N = _x_layout(fx.x, dtype)
-    mw = np.ascontiguousarray(blr.mw, dtype=dtype)
-    s, noise_kind = _noise(fx.Sy, N, dtype)
-    Lw, prior_kind, ldl = _prior(blr.Lw, D, dtype)
+    mw = _mean_vector(blr.mw, D, dtype)
+    Lw, prior_kind, ldl = _prior(blr.Lw, D, dtype, need_cholesky=True)  # :51 _cholesky(Lw) ...
+    s, noise_kind = _noise(fx.Sy, N, dtype, need_cholesky=True)          # ... then :52 _cholesky(Sigma_y)
     Z1 = _randn(rng, D, S, dtype)  # FIRST draw  (reference :51)
     Z2 = _randn(rng, N, S, dtype)  # SECOND draw (reference :52)
     Y = np.empty((N, S), dtype=dtype, order="F")

@@ -79,6 +79,37 @@ def posterior_n_sharded(handle, X_local, y_local, noise, mw, Lw, n_total: int, g
     n_loc, D = X_local.shape
     rows, cols = stats_shape(D)
     dev = X_local.device
+    # The library runs on the handle's stream; torch produced the inputs (and zero-fills the outputs below) on ITS current
+    # stream.  Put the handle on that stream for the duration of the call so that every fill / producer is ordered before the
+    # library's kernels and the collective sees finished statistics; the handle's previous stream is restored on the way out.
+    with _on_torch_stream(handle, dev):
+        return _posterior_n_sharded(handle, X_local, y_local, noise, mw, Lw, n_total, group, dt, n_loc, D, rows, cols, dev)
+
+
+class _on_torch_stream:
+    def __init__(self, handle, dev):
+        self.handle, self.dev = handle, dev
+
+    def __enter__(self):
+        import torch
+
+        self.previous = self.handle.current_stream_setting()
+        self.handle.set_stream(torch.cuda.current_stream(self.dev).cuda_stream)
+        return self
+
+    def __exit__(self, *exc):
+        self.handle.synchronize()
+        if self.previous is None:
+            self.handle.reset_stream()
+        else:
+            self.handle.set_stream(self.previous[0])
+        return False
+
+
+def _posterior_n_sharded(handle, X_local, y_local, noise, mw, Lw, n_total, group, dt, n_loc, D, rows, cols, dev):
+    import torch
+    from . import _abi
+
     stats = torch.zeros((cols, rows), dtype=X_local.dtype, device=dev)  # column-major (rows x cols), lds = rows
     scal = torch.zeros(2, dtype=torch.float64, device=dev)
     diag_noise = noise.numel() > 1

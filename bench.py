@@ -1,22 +1,26 @@
 #!/usr/bin/env python3
 """bench.py -- posterior-updates/s of the fused MI355X posterior+logpdf path.
 
-Workload (BASELINE.json configs[1], "c2"): independent regressors at D=128, N=4096, ColVecs, isotropic
+Headline workload (BASELINE.json configs[1], "c2"): independent regressors at D=128, N=4096, ColVecs, isotropic
 noise, fp64, Lw = I, inputs resident in HBM.  One *step* = one pass of the hot path over one batch of
 `--batch` regressors per GPU: ONE launch of the fused kernel (Gram + Cholesky + solves + evidence,
 producing mw', T and logpdf for every regressor), the fixed-order device sum of the batch's log evidences,
-and -- for N > 1 ranks -- the single all-gather of the per-rank partial sums (the only collective).
+and -- for N > 1 ranks -- the single all-gather of the per-rank log evidences (the only collective).
 One "posterior update" = one regressor's full (mw', T, logpdf).
 
     python bench.py --gpus 1 --steps 20 --warmup 3
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P \
         bench.py --gpus N --steps K --warmup W
 
-Prints ONE JSON line on rank 0 (contract in the task statement) with `roofline` and `cpu_baseline`.
+Prints ONE JSON line on rank 0 (contract in the task statement) with `roofline`, `cpu_baseline` and -- at one GPU --
+`secondary`: the other BASELINE shapes (c2 in fp32, c4, c3, c5 end to end), each timed the same way in the same process.
 """
 import argparse
+import glob
 import json
 import os
+import re
+import subprocess
 import sys
 import time
 
@@ -26,36 +30,67 @@ if ROOT not in sys.path:
 
 import numpy as np  # noqa: E402
 
-# spec-sheet peaks: HBM3E 8.0 TB/s; fp64 matrix 78.6 TF; fp32 matrix 157.3 TF
+# spec-sheet peaks (/opt/skills/guides/MI355X_MICROARCH.md, chip-level parameters): HBM3E 8.0 TB/s; fp64 matrix 78.6 TF;
+# fp32 matrix 157.3 TF
 PEAK_HBM_GBS = 8000.0
 PEAK_TF = {"f64": 78.6, "f32": 157.3}
-# what tools/mfma_peak.hip sustains on this pool: v_mfma_f64_16x16x4 tops out at 47.7 TF
-MEASURED_MFMA_TF = {"f64": 47.7, "f32": 155.0}
-# HBM bytes per regressor from the PMC passes summarised in profiles/r01_pmc_summary.json (FETCH_SIZE x2 + WRITE_SIZE)
-PMC_TRAFFIC_BYTES_PER_UPDATE = {("f64", 128, 4096, "isotropic"): 19772626176.0 / 4096}
 
 
-def algorithmic_bytes(D, N, w, diag_noise):
-    """w(D N + N + N_s + 2D + 2D^2) + 8 per update."""
+def measured_matrix_peak(dtype):
+    """What the matrix pipe sustains on this pool, from the committed microbenchmark logs (profiles/*_microbench_*.txt,
+    written by tools/run_microbench.sh): f64 = tools/mfma_f64_probe.hip, all CUs, 2 waves per SIMD, accumulators in VGPRs;
+    f32 = tools/mfma_peak.hip.  None when no log is present."""
+    try:
+        if dtype == "f64":
+            f = sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_microbench_mfma_f64_probe.txt")))[-1]
+            sect = open(f).read().split("---- all CUs, 2 waves/SIMD")[1]
+            return float(re.search(r"acc VGPR\s.*?([\d.]+) TFLOP/s", sect).group(1)), os.path.relpath(f, ROOT)
+        f = sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_microbench_mfma_peak.txt")))[-1]
+        return float(re.search(r"f32 mfma 16x16x4, 2 wave/SIMD.*?([\d.]+) TFLOP/s", open(f).read()).group(1)), os.path.relpath(f, ROOT)
+    except Exception:
+        return None, None
+
+
+def pmc_traffic_per_update(key):
+    """HBM bytes per update from the committed PMC summary (rocprofv3 --pmc FETCH_SIZE x2 on gfx950, + WRITE_SIZE, separate
+    passes: tools/collect_profiles.sh -> tools/summarise_profiles.py).  None when the round's summary lacks the entry."""
+    try:
+        f = sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_pmc_summary.json")))[-1]
+        e = json.load(open(f)).get(key)
+        if not e:
+            return None, None
+        return float(e["hbm_bytes_per_launch"]) / float(e["units_per_launch"]), os.path.relpath(f, ROOT)
+    except Exception:
+        return None, None
+
+
+def algorithmic_bytes(D, N, w, diag_noise, Din=None):
+    """w(D N + N + N_s + 2D + 2D^2) + 8 per update (c5: D_in N instead of D N, plus w(D_in D + D))."""
     ns = N if diag_noise else 1
+    if Din is not None:
+        return w * (Din * N + N + ns + 2 * D + 2 * D * D + Din * D + D) + 8
     return w * (D * N + N + ns + 2 * D + 2 * D * D) + 8
 
 
-def algorithmic_flops(D, N):
-    """D(D+1)N (symmetric-half SYRK) + 4DN + D^3/3 + 3D^2 + 5N per update."""
-    return D * (D + 1) * N + 4 * D * N + D**3 / 3 + 3 * D * D + 5 * N
+def algorithmic_flops(D, N, Din=None):
+    """D(D+1)N (symmetric-half SYRK) + 4DN + D^3/3 + 3D^2 + 5N per update (c5: + 2 D_in D N)."""
+    f = D * (D + 1) * N + 4 * D * N + D**3 / 3 + 3 * D * D + 5 * N
+    return f + (2 * Din * D * N if Din is not None else 0)
 
 
-def cpu_baseline(D, N, seconds, seed):
-    """Reference algorithm restated (oracle: literal op sequence of reference :72-89 + :55-69 on OpenBLAS),
-    independent regressors spread over the host cores with one BLAS thread each (the CPU analogue of the
-    batched GPU launch).  Child processes are started BEFORE this process touches the GPU."""
-    import subprocess
+def physical_cores():
+    try:
+        out = subprocess.run(["lscpu"], capture_output=True, text=True, timeout=10).stdout
+        cps = int(re.search(r"Core\(s\) per socket:\s+(\d+)", out).group(1))
+        sk = int(re.search(r"Socket\(s\):\s+(\d+)", out).group(1))
+        return max(1, cps * sk)
+    except Exception:
+        return max(1, (os.cpu_count() or 2) // 2)
 
-    workers = max(1, min((os.cpu_count() or 2) // 2, 64))
+
+def _cpu_leg(D, N, seconds, seed, form, workers, threads):
     script = os.path.join(ROOT, "oracle", "cpu_baseline_worker.py")
-    t0 = time.perf_counter()
-    procs = [subprocess.Popen([sys.executable, script, str(D), str(N), str(seconds), str(seed + i)],
+    procs = [subprocess.Popen([sys.executable, script, str(D), str(N), str(seconds), str(seed + i), form, str(threads)],
                               stdout=subprocess.PIPE, text=True) for i in range(workers)]
     res = []
     for p in procs:
@@ -63,28 +98,126 @@ def cpu_baseline(D, N, seconds, seed):
         if p.returncode == 0 and out.strip():
             d, t = out.split()
             res.append((int(d), float(t)))
+    return res
+
+
+def cpu_baseline(D, N, seconds, seed):
+    """The reference's algorithm restated (oracle/, NumPy/SciPy on OpenBLAS -- Julia is not installed), timed on the host:
+      value                = literal op sequence (logpdf + posterior, reference :55-89), one process per PHYSICAL core x 1 BLAS thread
+      direct_gram_value    = the one-pass Gram form (what a tuned CPU code would run), same process layout
+      threaded_blas_value  = literal sequence, ONE process with OpenBLAS on all cores (how a single Julia session runs it)
+    Child processes are started BEFORE this process touches the GPU; about `seconds` of wall time in total."""
+    cores = physical_cores()
+    per = max(1.0, seconds / 3.0)
+    t0 = time.perf_counter()
+    lit = _cpu_leg(D, N, per, seed, "literal", cores, 1)
+    dirr = _cpu_leg(D, N, per, seed, "direct", cores, 1)
+    thr = _cpu_leg(D, N, per, seed, "literal", 1, cores)
     wall = time.perf_counter() - t0
-    if not res:
+    if not lit:
         return None
-    rate = sum(d / t for d, t in res)
-    single = rate / len(res)
+    rate = lambda res: sum(d / t for d, t in res) if res else None
     return {
-        "value": rate,
+        "value": rate(lit),
         "unit": "posterior-updates/s",
-        "cores": len(res),
+        "cores": len(lit),
         "kind": "port",
-        "sample": f"{sum(d for d, _ in res)} regressors at D={D}, N={N}, fp64: oracle (NumPy/SciPy on OpenBLAS) running the "
-                  f"reference's literal op sequence logpdf+posterior, {len(res)} worker processes x 1 BLAS thread for "
-                  f"{seconds:.0f} s each ({single:.1f} updates/s per core; {os.cpu_count()} hardware threads on the host; "
-                  f"{wall:.0f} s wall incl. start-up)",
+        "direct_gram_value": rate(dirr),
+        "threaded_blas_value": rate(thr),
+        "sample": f"D={D}, N={N}, fp64, oracle (NumPy/SciPy on OpenBLAS): {sum(d for d, _ in lit)} regressors through the reference's "
+                  f"literal op sequence logpdf+posterior on {len(lit)} processes x 1 BLAS thread (= physical cores of the host, "
+                  f"{os.cpu_count()} hardware threads) for {per:.0f} s each; direct_gram_value: the same layout on the one-pass Gram "
+                  f"form; threaded_blas_value: one process, OpenBLAS on {cores} threads; {wall:.0f} s wall in total",
     }
 
 
-def _config_name(D, N, dtype):
-    """BASELINE.json config the shape corresponds to (c2 is the headline; the others are secondary shapes)."""
-    table = {(128, 4096, "f64"): "c2", (2, 10, "f64"): "c1", (1024, 65536, "f32"): "c3", (64, 1024, "f64"): "c4 shape",
-             (2048, 16384, "f32"): "c5 shape (features precomputed)"}
-    return table.get((D, N, dtype), "custom")
+class Workload:
+    """One BASELINE shape resident on the device + the call that runs one step of it."""
+
+    def __init__(self, torch, _abi, h, dev, name, B, D, N, dtype, noise, seed, Din=None):
+        self.name, self.B, self.D, self.N, self.dtype, self.noise, self.Din = name, B, D, N, dtype, noise, Din
+        self.torch, self._abi, self.h = torch, _abi, h
+        t_dt = torch.float64 if dtype == "f64" else torch.float32
+        self.np_dt = np.float64 if dtype == "f64" else np.float32
+        self.w_bytes = 8 if dtype == "f64" else 4
+        diag = noise == "diagonal"
+        g = torch.Generator(device=dev).manual_seed(seed)
+        # synthetic ColVecs design matrices (SURVEY.md 8d): X ~ N(0,1), y = X'w* + sqrt(s) eps, prior mw = 0, Lw = I
+        if Din is None:
+            self.X = torch.randn((B, N, D), generator=g, dtype=t_dt, device=dev)  # [N, D] row-major == D x N column-major
+            wstar = torch.randn((B, D), generator=g, dtype=t_dt, device=dev)
+            mean = torch.einsum("bnd,bd->bn", self.X, wstar) if B * N * D < (1 << 32) else torch.stack(
+                [self.X[b] @ wstar[b] for b in range(B)])
+        else:  # c5: raw inputs D_in x N, random-Fourier basis on the device
+            self.X = torch.randn((B, N, Din), generator=g, dtype=t_dt, device=dev)
+            self.Omega = torch.randn((D, Din), generator=g, dtype=t_dt, device=dev)  # [D, Din] row-major == Din x D column-major
+            self.phase = 2 * np.pi * torch.rand((D,), generator=g, dtype=t_dt, device=dev)
+            mean = torch.zeros((B, N), dtype=t_dt, device=dev)
+        if diag:
+            self.s = torch.exp(torch.randn((B, N), generator=g, dtype=t_dt, device=dev))
+            sd = torch.sqrt(self.s)
+        else:
+            self.s = torch.full((1,), 0.1, dtype=t_dt, device=dev)
+            sd = torch.sqrt(self.s)
+        self.y = mean + sd * torch.randn((B, N), generator=g, dtype=t_dt, device=dev)
+        self.mw = torch.zeros((B, D), dtype=t_dt, device=dev)
+        self.dprior = torch.ones((D,), dtype=t_dt, device=dev)
+        self.mw_post = torch.empty((B, D), dtype=t_dt, device=dev)
+        self.T_post = torch.empty((B, D, D), dtype=t_dt, device=dev)
+        self.lp = torch.empty((B,), dtype=torch.float64, device=dev)
+        self.info = torch.empty((B,), dtype=torch.int32, device=dev)
+        self.noise_kind = _abi.NOISE_DIAGONAL if diag else _abi.NOISE_ISOTROPIC
+        self.diag = diag
+
+    def launch(self):
+        a, B, D, N = self._abi, self.B, self.D, self.N
+        if self.Din is None:
+            self.h.posterior_batched(self.np_dt, a.MEM_DEVICE, a.LAYOUT_COLVECS, B, D, N, self.X.data_ptr(), D, N * D, self.y.data_ptr(), N,
+                                     self.noise_kind, self.s.data_ptr(), N if self.diag else 0, a.PRIOR_DIAGONAL, self.mw.data_ptr(), D,
+                                     self.dprior.data_ptr(), 1, 0, self.mw_post.data_ptr(), D, self.T_post.data_ptr(), D, D * D, None, D,
+                                     D * D, self.lp.data_ptr(), self.info.data_ptr())
+        else:
+            self.h.posterior_rff(self.np_dt, a.MEM_DEVICE, self.Din, D, N, self.X.data_ptr(), self.Din, self.Omega.data_ptr(), self.Din,
+                                 self.phase.data_ptr(), float(np.sqrt(2.0 / D)), self.y.data_ptr(), self.noise_kind, self.s.data_ptr(),
+                                 a.PRIOR_DIAGONAL, self.mw.data_ptr(), self.dprior.data_ptr(), 1, self.mw_post.data_ptr(),
+                                 self.T_post.data_ptr(), D, None, D, self.lp.data_ptr(), self.info.data_ptr())
+
+    def kernel_name(self):
+        t = "double" if self.dtype == "f64" else "float"
+        if self.D <= 128:
+            return f"fused_small_kernel<{t}, {(self.D + 15) // 16}, 4>"  # MODE 4: ColVecs through LDS-DMA
+        return f"gram_tile_kernel<{t}>"
+
+    def roofline(self, ms):
+        fl = algorithmic_flops(self.D, self.N, self.Din) * self.B
+        by = algorithmic_bytes(self.D, self.N, self.w_bytes, self.diag, self.Din) * self.B
+        tf = fl / (ms * 1e-3) / 1e12
+        gbs = by / (ms * 1e-3) / 1e9
+        t_hbm = by / (PEAK_HBM_GBS * 1e9)
+        t_mfma = fl / (PEAK_TF[self.dtype] * 1e12)
+        if t_mfma >= t_hbm:
+            r = {"bound": "mfma", "achieved": tf, "peak": PEAK_TF[self.dtype], "unit": "TFLOP/s", "frac": tf / PEAK_TF[self.dtype]}
+        else:
+            r = {"bound": "hbm", "achieved": gbs, "peak": PEAK_HBM_GBS, "unit": "GB/s", "frac": gbs / PEAK_HBM_GBS}
+        r.update({"kernel": self.kernel_name(), "kernel_ms_avg": ms, "units_per_launch": self.B, "algorithmic_bytes": by,
+                  "algorithmic_flops": fl, "hbm_GBps": gbs, "hbm_frac": gbs / PEAK_HBM_GBS, "mfma_TFLOPps": tf,
+                  "mfma_frac": tf / PEAK_TF[self.dtype]})
+        return r
+
+
+def timed(torch, stream, dev, fn, steps, warmup):
+    """(wall seconds for `steps` calls, mean ms between HIP events recorded around each call ON THE LAUNCH STREAM)"""
+    for _ in range(warmup):
+        fn()
+    torch.cuda.synchronize(dev)
+    ev = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(steps)]
+    t0 = time.perf_counter()
+    for a, b in ev:
+        a.record(stream)
+        fn()
+        b.record(stream)
+    torch.cuda.synchronize(dev)
+    return time.perf_counter() - t0, float(np.mean([a.elapsed_time(b) for a, b in ev]))
 
 
 def main():
@@ -98,25 +231,30 @@ def main():
     ap.add_argument("--dtype", choices=["f64", "f32"], default="f64")
     ap.add_argument("--noise", choices=["isotropic", "diagonal"], default="isotropic")
     ap.add_argument("--cpu-seconds", type=float, default=None,
-                    help="budget of the cpu_baseline leg (0 = skip; default: 10 s at the headline shape, skipped otherwise)")
+                    help="wall budget of the cpu_baseline leg (0 = skip; default: 24 s at the headline shape, skipped otherwise)")
+    ap.add_argument("--secondary", type=int, default=None,
+                    help="1: also time the other BASELINE shapes (default at one GPU on the headline workload), 0: skip")
     ap.add_argument("--config", choices=["c2", "c3", "c4", "c5"], default=None,
-                    help="BASELINE.json shape presets: c2 = the headline workload (default); c3/c4/c5 = the secondary shapes "
-                         "(c5: features precomputed -- the end-to-end RFF call is timed by tools/rff_bench.py)")
+                    help="make one of the secondary BASELINE shapes the measured workload (development)")
     args = ap.parse_args()
+    Din = None
     if args.config == "c3":
         args.D, args.N, args.dtype, args.noise, args.batch = 1024, 65536, "f32", "diagonal", 1
     elif args.config == "c4":
         args.D, args.N, args.dtype, args.noise, args.batch = 64, 1024, "f64", "isotropic", 8192
     elif args.config == "c5":
-        args.D, args.N, args.dtype, args.noise, args.batch = 2048, 16384, "f32", "isotropic", 1
+        args.D, args.N, args.dtype, args.noise, args.batch, Din = 2048, 16384, "f32", "isotropic", 1, 8
+    headline = (args.D, args.N, args.dtype, args.noise, Din) == (128, 4096, "f64", "isotropic", None)
     if args.cpu_seconds is None:
-        args.cpu_seconds = 10.0 if (args.D, args.N) == (128, 4096) else 0.0
+        args.cpu_seconds = 24.0 if headline else 0.0
 
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     if world != args.gpus and world > 1:
         raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}")
+    if args.secondary is None:
+        args.secondary = 1 if (headline and world == 1) else 0
     cpu_leg = None
     if args.cpu_seconds > 0 and world == 1 and rank == 0:
         cpu_leg = cpu_baseline(args.D, args.N, args.cpu_seconds, 123456)  # before any GPU initialisation
@@ -141,7 +279,7 @@ def main():
     torch.cuda.set_device(local_rank)
     dev = torch.device(f"cuda:{local_rank}")
 
-    import blr_amd
+    import blr_amd  # noqa: F401
     from blr_amd import _abi
 
     h = _abi.Handle(local_rank)  # raises if the HIP extension or the GPU is missing: no fallback
@@ -150,58 +288,30 @@ def main():
     h.set_async(True)
 
     B, D, N = args.batch, args.D, args.N
-    np_dt = np.float64 if args.dtype == "f64" else np.float32
-    t_dt = torch.float64 if args.dtype == "f64" else torch.float32
-    w_bytes = 8 if args.dtype == "f64" else 4
-    diag = args.noise == "diagonal"
-
-    # synthetic ColVecs design matrices: X ~ N(0,1), y = X'w* + sqrt(s) eps, prior mw = 0, Lw = I
-    g = torch.Generator(device=dev).manual_seed(123456 + 1 + rank)
-    X = torch.randn((B, N, D), generator=g, dtype=t_dt, device=dev)  # [N, D] row-major == D x N column-major
-    wstar = torch.randn((B, D), generator=g, dtype=t_dt, device=dev)
-    if diag:
-        s = torch.exp(torch.randn((B, N), generator=g, dtype=t_dt, device=dev))
-        sd = torch.sqrt(s)
-    else:
-        s = torch.full((1,), 0.1, dtype=t_dt, device=dev)
-        sd = torch.sqrt(s)
-    y = torch.einsum("bnd,bd->bn", X, wstar) + sd * torch.randn((B, N), generator=g, dtype=t_dt, device=dev)
-    mw = torch.zeros((B, D), dtype=t_dt, device=dev)
-    dprior = torch.ones((D,), dtype=t_dt, device=dev)
-    mw_post = torch.empty((B, D), dtype=t_dt, device=dev)
-    T_post = torch.empty((B, D, D), dtype=t_dt, device=dev)
-    lp = torch.empty((B,), dtype=torch.float64, device=dev)
-    info = torch.empty((B,), dtype=torch.int32, device=dev)
+    cfg = {(128, 4096, "f64"): "c2", (1024, 65536, "f32"): "c3", (64, 1024, "f64"): "c4 shape", (2048, 16384, "f32"): "c5"}
+    wl = Workload(torch, _abi, h, dev, cfg.get((D, N, args.dtype), "custom"), B, D, N, args.dtype, args.noise, 123456 + 1 + rank, Din)
     lp_sum = torch.zeros((1,), dtype=torch.float64, device=dev)
     lp_all = torch.empty((B * world,), dtype=torch.float64, device=dev)
     torch.cuda.synchronize(dev)
 
-    noise_kind = _abi.NOISE_DIAGONAL if diag else _abi.NOISE_ISOTROPIC
-
-    def fused_launch():
-        h.posterior_batched(np_dt, _abi.MEM_DEVICE, _abi.LAYOUT_COLVECS, B, D, N, X.data_ptr(), D, N * D, y.data_ptr(), N,
-                            noise_kind, s.data_ptr(), N if diag else 0, _abi.PRIOR_DIAGONAL, mw.data_ptr(), D,
-                            dprior.data_ptr(), 1, 0, mw_post.data_ptr(), D, T_post.data_ptr(), D, D * D, None, D, D * D,
-                            lp.data_ptr(), info.data_ptr())
-
     def step(ev=None):
         if ev is not None:
             ev[0].record(stream)
-        fused_launch()
+        wl.launch()
         if ev is not None:
             ev[1].record(stream)
         if dist is not None:
             # the path's only exchange: all-gather of the per-regressor log evidences (8 B each), then the SAME
             # fixed-order device sum on every rank -> identical bits for every rank count
             if backend == "nccl":
-                dist.all_gather_into_tensor(lp_all, lp)
+                dist.all_gather_into_tensor(lp_all, wl.lp)
             else:  # host-staged collective (validation only)
                 host = torch.empty(B * world, dtype=torch.float64)
-                dist.all_gather_into_tensor(host, lp.cpu())
+                dist.all_gather_into_tensor(host, wl.lp.cpu())
                 lp_all.copy_(host)
             h.logpdf_sum(_abi.MEM_DEVICE, B * world, lp_all.data_ptr(), lp_sum.data_ptr())
         else:
-            h.logpdf_sum(_abi.MEM_DEVICE, B, lp.data_ptr(), lp_sum.data_ptr())
+            h.logpdf_sum(_abi.MEM_DEVICE, B, wl.lp.data_ptr(), lp_sum.data_ptr())
 
     for _ in range(args.warmup):
         step()
@@ -226,36 +336,22 @@ def main():
     kern_ms = float(np.mean([a.elapsed_time(b) for a, b in events]))
 
     # sanity: the timed work produced valid results
-    assert int(info.abs().sum().item()) == 0, "a regressor failed to factorise"
+    assert int(wl.info.abs().sum().item()) == 0, "a regressor failed to factorise"
     total_evidence = float(lp_sum.item())
     assert np.isfinite(total_evidence)
 
+    out = None
     if rank == 0:
         value = B * world * args.steps / elapsed
-        fl = algorithmic_flops(D, N) * B
-        by = algorithmic_bytes(D, N, w_bytes, diag) * B
-        tf = fl / (kern_ms * 1e-3) / 1e12
-        gbs = by / (kern_ms * 1e-3) / 1e9
-        t_hbm = by / (PEAK_HBM_GBS * 1e9)
-        t_mfma = fl / (PEAK_TF[args.dtype] * 1e12)
-        if t_mfma >= t_hbm:
-            roof = {"bound": "mfma", "achieved": tf, "peak": PEAK_TF[args.dtype], "unit": "TFLOP/s",
-                    "frac": tf / PEAK_TF[args.dtype]}
-        else:
-            roof = {"bound": "hbm", "achieved": gbs, "peak": PEAK_HBM_GBS, "unit": "GB/s", "frac": gbs / PEAK_HBM_GBS}
-        per_update = PMC_TRAFFIC_BYTES_PER_UPDATE.get((args.dtype, D, N, args.noise))
+        roof = wl.roofline(kern_ms)
+        per_update, src = pmc_traffic_per_update("c2_fused_small_kernel_hbm") if headline else (None, None)
+        peak_meas, peak_src = measured_matrix_peak(args.dtype)
         roof.update({
             "traffic": per_update * B if per_update else None,
-            "traffic_source": "rocprofv3 --pmc FETCH_SIZE (x2, gfx950) + WRITE_SIZE, profiles/r01_pmc_summary.json"
-                              if per_update else None,
-            "algorithmic_bytes": by, "algorithmic_flops": fl,
-            "mfma_peak_measured_TFLOPps": MEASURED_MFMA_TF[args.dtype],
-            "mfma_frac_of_measured_peak": tf / MEASURED_MFMA_TF[args.dtype],
-            "kernel": "fused_small_kernel",
-            "kernel_ms_avg": kern_ms,
-            "units_per_launch": B,
-            "hbm_GBps": gbs, "hbm_frac": gbs / PEAK_HBM_GBS,
-            "mfma_TFLOPps": tf, "mfma_frac": tf / PEAK_TF[args.dtype],
+            "traffic_source": src,
+            "matrix_peak_measured_TFLOPps": peak_meas,
+            "matrix_peak_measured_source": peak_src,
+            "mfma_frac_of_measured_peak": (roof["mfma_TFLOPps"] / peak_meas) if peak_meas else None,
         })
         out = {
             "metric": "posterior-updates/sec + logpdf/sec at (D,N)",
@@ -271,8 +367,8 @@ def main():
             "dtype": args.dtype,
             "data": "synthetic",
             "config": {
-                "workload": f"{_config_name(D, N, args.dtype)}: independent regressors D={D}, N={N}, ColVecs, {args.noise} noise, {args.dtype}, "
-                            f"Lw=I, fused posterior+logpdf",
+                "workload": f"{wl.name}: independent regressors D={D}, N={N}, ColVecs, {args.noise} noise, {args.dtype}, "
+                            f"Lw=I, fused posterior+logpdf" + (f", random-Fourier basis D_in={Din} on the device" if Din else ""),
                 "D": D, "N": N, "batch_per_gpu": B, "global_batch": B * world,
                 "sharding": f"regressors x{world}, no data-path collective; one all-gather of {B * world} doubles",
             },
@@ -281,6 +377,33 @@ def main():
         }
         if cpu_leg is not None:
             out["cpu_baseline"] = cpu_leg
+
+    # ---- the other BASELINE shapes, same process, same timing method (one GPU only) ---------------------------------
+    if args.secondary and world == 1 and rank == 0:
+        del wl, lp_all
+        torch.cuda.empty_cache()
+        sec = {}
+        shapes = [("c2_f32", 4096, 128, 4096, "f32", "isotropic", None, 10),
+                  ("c4_f64", 8192, 64, 1024, "f64", "isotropic", None, 10),
+                  ("c4_f32", 8192, 64, 1024, "f32", "isotropic", None, 10),
+                  ("c3_f32", 1, 1024, 65536, "f32", "diagonal", None, 10),
+                  ("c5_f32_end_to_end", 1, 2048, 16384, "f32", "isotropic", 8, 10)]
+        for name, b, d, n, dt, noise, din, steps in shapes:
+            try:
+                w2 = Workload(torch, _abi, h, dev, name, b, d, n, dt, noise, 123456 + 7, din)
+                torch.cuda.synchronize(dev)
+                wall, ms = timed(torch, stream, dev, w2.launch, steps, 2)
+                assert int(w2.info.abs().sum().item()) == 0 and bool(torch.isfinite(w2.lp).all().item())
+                r = w2.roofline(ms)
+                sec[name] = {"workload": f"B={b}, D={d}, N={n}, {dt}, {noise} noise" + (f", D_in={din} random-Fourier features" if din else ""),
+                             "ms": ms, "updates_per_s": b / (ms * 1e-3), "wall_updates_per_s": b * steps / wall,
+                             "roofline": {k: r[k] for k in ("bound", "achieved", "peak", "unit", "frac", "kernel", "hbm_frac", "mfma_frac")}}
+                del w2
+                torch.cuda.empty_cache()
+            except Exception as e:  # a secondary shape must never take the headline line down
+                sec[name] = {"error": f"{type(e).__name__}: {e}"}
+        out["secondary"] = sec
+    if rank == 0:
         print(json.dumps(out), flush=True)
     if dist is not None:
         dist.barrier()
