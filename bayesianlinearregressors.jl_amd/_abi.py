@@ -16,7 +16,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("BLR_MI355X_LIB") or os.path.join(_HERE, "csrc", "libblr_mi355x.so")
 
 LAYOUT_COLVECS, LAYOUT_ROWVECS = 0, 1
-NOISE_ISOTROPIC, NOISE_DIAGONAL = 0, 1
+NOISE_ISOTROPIC, NOISE_DIAGONAL, NOISE_DENSE = 0, 1, 2
 PRIOR_DENSE, PRIOR_UPPER_FACTOR, PRIOR_DIAGONAL = 0, 1, 2
 MEM_HOST, MEM_DEVICE = 0, 1
 
@@ -79,6 +79,12 @@ for _suf in ("f64", "f32"):
     _SIGS[f"blr_gram_stats_{_suf}"] = ([_H, _int, _i64, _i64, _vp, _i64, _vp, _int, _vp, _vp, _vp, _i64, _vp], _int)
     _SIGS[f"blr_posterior_from_stats_{_suf}"] = (
         [_H, _i64, _i64, _vp, _i64, _vp, _int, _vp, _vp, _i64, _vp, _vp, _i64, _vp, _i64, _vp, _vp], _int)
+    _SIGS[f"blr_posterior_dense_noise_{_suf}"] = (
+        [_H, _int, _int, _i64, _i64, _vp, _i64, _vp, _vp, _i64, _int, _vp, _vp, _i64, _vp, _vp, _i64, _vp, _i64, _vp, _vp], _int)
+    _SIGS[f"blr_mean_and_cov_{_suf}"] = (
+        [_H, _int, _int, _i64, _i64, _vp, _i64, _int, _vp, _i64, _int, _vp, _vp, _i64, _vp, _vp, _i64, _vp], _int)
+    _SIGS[f"blr_rand_dense_noise_{_suf}"] = (
+        [_H, _int, _int, _i64, _i64, _i64, _vp, _i64, _vp, _i64, _int, _vp, _vp, _i64, _vp, _i64, _vp, _i64, _vp, _i64], _int)
     _fp = C.c_double if _suf == "f64" else C.c_float
     _SIGS[f"blr_rff_features_{_suf}"] = (
         [_H, _int, _i64, _i64, _i64, _vp, _i64, _vp, _i64, _vp, _fp, _vp, _i64], _int)
@@ -273,6 +279,25 @@ class Handle:
         return self.check(fn(self._h, memspace, Din, D, N, _ptr(Xin), ldxin, _ptr(Omega), ldo, _ptr(phase), float(scale),
                              _ptr(y), noise_kind, _ptr(s), prior_kind, _ptr(mw), _ptr(Lw), ldl, _ptr(mw_post), _ptr(T_post),
                              ldt, _ptr(Lw_post), ldlp, _ptr(logpdf), _ptr(info)))
+
+    def posterior_dense_noise(self, dtype, memspace, layout, D, N, X, ldx, y, Sy, ldsy, prior_kind, mw, Lw, ldl, mw_post, T_post, ldt,
+                              Lw_post, ldlp, logpdf, info):
+        fn = getattr(self.lib, f"blr_posterior_dense_noise_{suffix(dtype)}")
+        return self.check(fn(self._h, memspace, layout, D, N, _ptr(X), ldx, _ptr(y), _ptr(Sy), ldsy, prior_kind, _ptr(mw), _ptr(Lw), ldl,
+                             _ptr(mw_post), _ptr(T_post), ldt, _ptr(Lw_post), ldlp, _ptr(logpdf), _ptr(info)))
+
+    def mean_and_cov(self, dtype, memspace, layout, D, N, X, ldx, noise_kind, s, lds, prior_kind, mw, Lw, ldl, mean, Cov, ldc, info):
+        fn = getattr(self.lib, f"blr_mean_and_cov_{suffix(dtype)}")
+        return self.check(fn(self._h, memspace, layout, D, N, _ptr(X), ldx, noise_kind, _ptr(s), lds, prior_kind, _ptr(mw), _ptr(Lw), ldl,
+                             _ptr(mean), _ptr(Cov), ldc, _ptr(info)))
+
+    def rand_dense_noise(self, dtype, memspace, layout, D, N, S, X, ldx, Sy, ldsy, prior_kind, mw, Lw, ldl, Z1, ldz1, Z2, ldz2, Y, ldy):
+        fn = getattr(self.lib, f"blr_rand_dense_noise_{suffix(dtype)}")
+        rc = self.check(fn(self._h, memspace, layout, D, N, S, _ptr(X), ldx, _ptr(Sy), ldsy, prior_kind, _ptr(mw), _ptr(Lw), ldl,
+                           _ptr(Z1), ldz1, _ptr(Z2), ldz2, _ptr(Y), ldy))
+        if rc > 0:
+            raise PosDefException(rc)
+        return rc
 
     def logpdf_sum(self, memspace, B, logpdf, total):
         return self.check(self.lib.blr_logpdf_sum(self._h, memspace, B, _ptr(logpdf), _ptr(total)))

@@ -15,6 +15,7 @@
 #include "blr_aux_kernels.hpp"
 #include "blr_fused_small.hpp"
 #include "blr_large.hpp"
+#include "blr_dense.hpp"
 
 using namespace blr;
 
@@ -1624,6 +1625,308 @@ int posterior_rff(blr_handle* h, int memspace, int64_t Din, int64_t D, int64_t N
   return 0;
 }
 
+
+// ================================================================================================================
+// Dense Sigma_y and full predictive covariance: see blr_dense.hpp for the scheme
+// ================================================================================================================
+constexpr int64_t kMaxDenseN = 16384;  // N x N work matrices: 2 GiB in fp64 at this size
+
+template <typename T>
+int dev_alloc_tmp(blr_handle* h, size_t count, T** out) {  // freed by the enclosing Staging guard
+  void* p = nullptr;
+  HIP_TRY(h, hipMalloc(&p, std::max<size_t>(count, 1) * sizeof(T)));
+  h->staged.push_back(p);
+  *out = static_cast<T*>(p);
+  return 0;
+}
+
+// x_n' mw for D <= 128 (one thread per input; the mean of mean_and_cov -- N <= 16384, not a hot path)
+template <typename T>
+__global__ __launch_bounds__(kThreads) void mean_small_kernel(const T* __restrict__ X, int64_t ldx, int layout, const T* __restrict__ mw, int D,
+                                                              int N, T* __restrict__ mean) {
+  const int n = blockIdx.x * kThreads + threadIdx.x;
+  if (n >= N) return;
+  double acc = 0.0;
+  for (int d = 0; d < D; ++d)
+    acc += (double)((layout == LAYOUT_COLVECS) ? X[(int64_t)n * ldx + d] : X[(int64_t)d * ldx + n]) * (double)mw[d];
+  mean[n] = (T)acc;
+}
+
+// Sigma_y = L L' in the top NP x NP block of M (lower, unit padding), R extra rows carried through; info_dev: status
+template <typename T>
+int chol_noise(blr_handle* h, const T* Sy_dev, int64_t ldsy, int N, int NP, int R, T* M, int64_t ld, int32_t* info_dev) {
+  HIP_TRY(h, hipMemsetAsync(info_dev, 0, sizeof(int32_t), h->stream));
+  hipLaunchKernelGGL(prior_copy_kernel<T>, dim3(2048), dim3(kThreads), 0, h->stream, Sy_dev, ldsy, N, NP, M, ld);
+  return chol_large<T>(h, M, ld, NP, NP + R, info_dev);
+}
+
+template <typename T>
+int posterior_dense_noise(blr_handle* h, int memspace, int layout, int64_t D64, int64_t N64, const T* X, int64_t ldx, const T* y,
+                          const T* Sy, int64_t ldsy, int prior_kind, const T* mw, const T* Lw, int64_t ldl, T* mw_post, T* T_post,
+                          int64_t ldt, T* Lw_post, int64_t ldlp, double* logpdf, int32_t* info) {
+  if (!h) return -1;
+  h->err.clear();
+  if (memspace != BLR_MEM_HOST && memspace != BLR_MEM_DEVICE) return bad_arg(h, 2, "memspace");
+  if (layout != BLR_LAYOUT_COLVECS && layout != BLR_LAYOUT_ROWVECS) return bad_arg(h, 3, "unknown layout (reference :26-31)");
+  if (D64 < 1 || D64 > kMaxLargeD) return bad_arg(h, 4, "D out of range for this build (1..8192)");
+  if (N64 < 1 || N64 > kMaxDenseN) return bad_arg(h, 5, "N out of range for a dense noise covariance (1..16384)");
+  if (!X) return bad_arg(h, 6, "X is NULL");
+  if (layout == BLR_LAYOUT_COLVECS ? ldx < D64 : ldx < N64) return bad_arg(h, 7, "ldx too small");
+  if (!y) return bad_arg(h, 8, "y is NULL (reference :74 length check)");
+  if (!Sy) return bad_arg(h, 9, "Sy is NULL");
+  if (ldsy < N64) return bad_arg(h, 10, "ldsy < N");
+  if (prior_kind != BLR_PRIOR_DENSE && prior_kind != BLR_PRIOR_UPPER_FACTOR && prior_kind != BLR_PRIOR_DIAGONAL)
+    return bad_arg(h, 11, "prior_kind");
+  if (!mw) return bad_arg(h, 12, "mw is NULL");
+  if (!Lw) return bad_arg(h, 13, "Lw is NULL");
+  if (prior_kind != BLR_PRIOR_DIAGONAL && ldl < D64) return bad_arg(h, 14, "ldl < D");
+  if (T_post && ldt < D64) return bad_arg(h, 17, "ldt < D");
+  if (Lw_post && ldlp < D64) return bad_arg(h, 19, "ldlp < D");
+  if (!info) return bad_arg(h, 21, "info is NULL");
+  HIP_TRY(h, hipSetDevice(h->device));
+  const int D = (int)D64, N = (int)N64;
+  const int NP = (N + kPB - 1) / kPB * kPB;
+  const int R = (D + 1 + kPB - 1) / kPB * kPB;  // X rows + the y row, padded to whole TRSM row blocks
+  const int64_t ld = (int64_t)NP + R;
+  Staging guard(h);
+  int rc;
+  const T *X_d = X, *y_d = y, *Sy_d = Sy, *mw_d = mw, *Lw_d = Lw;
+  T *mwp_d = mw_post, *Tp_d = T_post, *Lp_d = Lw_post;
+  double* lp_d = logpdf;
+  int32_t* info_d = info;
+  if (memspace == BLR_MEM_HOST) {
+    const size_t x_one = layout == BLR_LAYOUT_COLVECS ? mat_extent(D, N, ldx) : mat_extent(N, D, ldx);
+    const size_t lw_one = prior_kind == BLR_PRIOR_DIAGONAL ? (size_t)D : mat_extent(D, D, ldl);
+    if ((rc = stage_in(h, X, x_one, &X_d))) return rc;
+    if ((rc = stage_in(h, y, (size_t)N, &y_d))) return rc;
+    if ((rc = stage_in(h, Sy, mat_extent(N, N, ldsy), &Sy_d))) return rc;
+    if ((rc = stage_in(h, mw, (size_t)D, &mw_d))) return rc;
+    if ((rc = stage_in(h, Lw, lw_one, &Lw_d))) return rc;
+    if ((rc = stage_out_alloc(h, mw_post, (size_t)D, &mwp_d))) return rc;
+    if ((rc = stage_out_alloc(h, T_post, mat_extent(D, D, ldt), &Tp_d))) return rc;
+    if ((rc = stage_out_alloc(h, Lw_post, mat_extent(D, D, ldlp), &Lp_d))) return rc;
+    if ((rc = stage_out_alloc(h, logpdf, (size_t)1, &lp_d))) return rc;
+    if ((rc = stage_out_alloc(h, info, (size_t)1, &info_d))) return rc;
+  }
+  T *M = nullptr, *ytil = nullptr, *one = nullptr;
+  double* logdet = nullptr;
+  int32_t* noise_info = nullptr;
+  if ((rc = dev_alloc_tmp(h, (size_t)ld * NP, &M))) return rc;
+  if ((rc = dev_alloc_tmp(h, (size_t)N, &ytil))) return rc;
+  if ((rc = dev_alloc_tmp(h, 1, &one))) return rc;
+  if ((rc = dev_alloc_tmp(h, 1, &logdet))) return rc;
+  if ((rc = dev_alloc_tmp(h, 1, &noise_info))) return rc;
+  double* lp_tmp = lp_d;
+  if (!lp_tmp && (rc = dev_alloc_tmp(h, 1, &lp_tmp))) return rc;
+  const T one_h = T(1);
+  HIP_TRY(h, hipMemcpyAsync(one, &one_h, sizeof(T), hipMemcpyHostToDevice, h->stream));
+  // [Sigma_y; X; y'] -> [L; X L^-T; (L^-1 y)']   (reference :79, :81 outer solve, :82)
+  hipLaunchKernelGGL(whiten_fill_kernel<T>, dim3(2048), dim3(kThreads), 0, h->stream, X_d, ldx, layout, y_d, D, N, NP, R, M, ld, NP);
+  if ((rc = chol_noise<T>(h, Sy_d, ldsy, N, NP, R, M, ld, noise_info))) return rc;
+  hipLaunchKernelGGL(logdet_kernel<T>, dim3(1), dim3(kThreads), 0, h->stream, (const T*)M, ld, N, logdet);
+  hipLaunchKernelGGL(row_extract_kernel<T>, dim3(256), dim3(kThreads), 0, h->stream, (const T*)M, ld, NP + D, N, ytil);
+  // the whitened problem: ColVecs X~ = rows NP .. NP+D of M (leading dimension ld), y~, unit isotropic noise
+  PosteriorArgs<T> a{};
+  a.X = M + NP; a.ldx = ld; a.strideX = 0; a.y = ytil; a.stridey = 0; a.s = one; a.strides = 0;
+  a.mw = mw_d; a.stridemw = 0; a.Lw = Lw_d; a.ldl = ldl; a.strideLw = 0;
+  a.mw_post = mwp_d; a.stride_mwpost = D; a.T_post = Tp_d; a.ldt = ldt; a.strideT = 0; a.Lw_post = Lp_d; a.ldlp = ldlp; a.strideLp = 0;
+  a.logpdf = lp_tmp; a.info = info_d;
+  a.layout = BLR_LAYOUT_COLVECS; a.noise_kind = BLR_NOISE_ISOTROPIC; a.prior_kind = prior_kind;
+  a.D = D; a.N = N; a.B = 1;
+  a.vec_ok = (D % Mfma<T>::VEC == 0 && aligned16(a.X, ld, (int64_t)0)) ? 1 : 0;
+  if ((rc = dispatch_posterior<T>(h, a))) return rc;
+  hipLaunchKernelGGL(dense_finish_kernel, dim3(1), dim3(64), 0, h->stream, lp_tmp, info_d, (const double*)logdet, (const int32_t*)noise_info);
+  HIP_TRY(h, hipGetLastError());
+  if (memspace == BLR_MEM_HOST) {
+    if (mw_post) HIP_TRY(h, hipMemcpyAsync(mw_post, mwp_d, (size_t)D * sizeof(T), hipMemcpyDeviceToHost, h->stream));
+    if (T_post) HIP_TRY(h, hipMemcpyAsync(T_post, Tp_d, mat_extent(D, D, ldt) * sizeof(T), hipMemcpyDeviceToHost, h->stream));
+    if (Lw_post) HIP_TRY(h, hipMemcpyAsync(Lw_post, Lp_d, mat_extent(D, D, ldlp) * sizeof(T), hipMemcpyDeviceToHost, h->stream));
+    if (logpdf) HIP_TRY(h, hipMemcpyAsync(logpdf, lp_d, sizeof(double), hipMemcpyDeviceToHost, h->stream));
+    HIP_TRY(h, hipMemcpyAsync(info, info_d, sizeof(int32_t), hipMemcpyDeviceToHost, h->stream));
+  }
+  HIP_TRY(h, hipStreamSynchronize(h->stream));  // temporaries are freed on return
+  return 0;
+}
+
+// Y = X' Lw^-T (N rows x D columns, column-major with leading dimension ldy, rows [DP, DP + NP) of Ybar) for a factored or
+// dense prior: the tall-matrix panel sweep of the marginal path, keeping Y instead of folding it into row sums.
+template <typename T>
+int tall_solve_rows(blr_handle* h, int layout, int D, int N, const T* X, int64_t ldx, int prior_kind, const T* Lw, int64_t ldl,
+                    T* Ybar, int64_t ldy, int DP, int NP, int32_t* info_dev) {
+  using TC = TrsmCfg<T>;
+  using LC = LargeCfg<T>;
+  const int NC = DP / kPB;
+  int rc;
+  HIP_TRY(h, hipMemsetAsync(info_dev, 0, sizeof(int32_t), h->stream));
+  {
+    MeanFillArgs<T> m{};
+    m.X = X; m.ldx = ldx; m.layout = layout; m.mw = nullptr; m.mean = nullptr; m.Ybar = Ybar; m.ldy = ldy; m.row0 = DP;
+    m.D = D; m.DP = DP; m.N = N;
+    hipLaunchKernelGGL(mean_fill_kernel<T>, dim3((unsigned)(NP / 64)), dim3(kThreads), 0, h->stream, m);
+  }
+  if (prior_kind == BLR_PRIOR_UPPER_FACTOR) {
+    dim3 grid((DP + 31) / 32, (DP + 31) / 32);
+    hipLaunchKernelGGL(factor_transpose_fill_kernel<T>, grid, dim3(kThreads), 0, h->stream, Lw, ldl, D, DP, Ybar, ldy);
+  } else {
+    hipLaunchKernelGGL(prior_copy_kernel<T>, dim3(1024), dim3(kThreads), 0, h->stream, Lw, ldl, D, DP, Ybar, ldy);
+    if ((rc = chol_large<T>(h, Ybar, ldy, DP, DP, info_dev))) return rc;
+  }
+  if ((rc = set_lds<T>(h, reinterpret_cast<const void*>(trsm_block_kernel<T>), TC::LDS_BYTES))) return rc;
+  if ((rc = set_lds<T>(h, reinterpret_cast<const void*>(gram_tile_kernel<T>), LC::LDS_BYTES))) return rc;
+  const int nyb = NP / kPB;
+  for (int p = 0; p < NC; ++p) {
+    const int nblk = (NP + TC::RB - 1) / TC::RB;
+    hipLaunchKernelGGL(trsm_block_kernel<T>, dim3(nblk), dim3(kThreads), TC::LDS_BYTES, h->stream, Ybar, ldy, p, DP, DP + NP,
+                       (const int32_t*)info_dev, RowSqArgs<T>{});
+    const int m = NC - 1 - p;
+    if (m > 0) {
+      GramTileArgs<T> g{};
+      g.X = Ybar + (int64_t)p * kPB * ldy; g.ldx = ldy; g.layout = LAYOUT_COLVECS; g.use_dma = 1;
+      g.s = nullptr; g.noise_kind = NOISE_ISOTROPIC; g.r = nullptr;
+      g.D = DP + NP; g.n_begin = 0; g.n_end = kPB; g.nsplit = 1;
+      g.tile_i0 = NC; g.tile_j0 = p + 1; g.tri = 3; g.ntile_rows = nyb; g.ntiles = nyb * m; g.nblocks = NC + nyb;
+      g.C = Ybar; g.ldc = ldy; g.mode_out = 1;
+      hipLaunchKernelGGL(gram_tile_kernel<T>, dim3(g.ntiles), dim3(kThreads), LC::LDS_BYTES, h->stream, g);
+    }
+  }
+  HIP_TRY(h, hipGetLastError());
+  return 0;
+}
+
+template <typename T>
+int mean_and_cov(blr_handle* h, int memspace, int layout, int64_t D64, int64_t N64, const T* X, int64_t ldx, int noise_kind, const T* s,
+                 int64_t lds, int prior_kind, const T* mw, const T* Lw, int64_t ldl, T* mean, T* C, int64_t ldc, int32_t* info) {
+  if (!h) return -1;
+  h->err.clear();
+  if (memspace != BLR_MEM_HOST && memspace != BLR_MEM_DEVICE) return bad_arg(h, 2, "memspace");
+  if (layout != BLR_LAYOUT_COLVECS && layout != BLR_LAYOUT_ROWVECS) return bad_arg(h, 3, "unknown layout (reference :26-31)");
+  if (D64 < 1 || D64 > kMaxLargeD) return bad_arg(h, 4, "D out of range for this build (1..8192)");
+  if (N64 < 1 || N64 > kMaxDenseN) return bad_arg(h, 5, "N out of range for an N x N covariance (1..16384)");
+  if (!X) return bad_arg(h, 6, "X is NULL");
+  if (layout == BLR_LAYOUT_COLVECS ? ldx < D64 : ldx < N64) return bad_arg(h, 7, "ldx too small");
+  if (noise_kind != BLR_NOISE_ISOTROPIC && noise_kind != BLR_NOISE_DIAGONAL && noise_kind != BLR_NOISE_DENSE) return bad_arg(h, 8, "noise_kind");
+  if (!s) return bad_arg(h, 9, "s is NULL");
+  if (noise_kind == BLR_NOISE_DENSE && lds < N64) return bad_arg(h, 10, "lds < N");
+  if (prior_kind != BLR_PRIOR_DENSE && prior_kind != BLR_PRIOR_UPPER_FACTOR && prior_kind != BLR_PRIOR_DIAGONAL)
+    return bad_arg(h, 11, "prior_kind");
+  if (mean && !mw) return bad_arg(h, 12, "mw is NULL");
+  if (!Lw) return bad_arg(h, 13, "Lw is NULL");
+  if (prior_kind != BLR_PRIOR_DIAGONAL && ldl < D64) return bad_arg(h, 14, "ldl < D");
+  if (!C) return bad_arg(h, 16, "C is NULL");
+  if (ldc < N64) return bad_arg(h, 17, "ldc < N");
+  if (!info) return bad_arg(h, 18, "info is NULL");
+  HIP_TRY(h, hipSetDevice(h->device));
+  const int D = (int)D64, N = (int)N64;
+  const int DP = (D + kPB - 1) / kPB * kPB, NP = (N + kPB - 1) / kPB * kPB;
+  const int64_t ldy = (int64_t)DP + NP;
+  Staging guard(h);
+  int rc;
+  const T *X_d = X, *s_d = s, *mw_d = mw, *Lw_d = Lw;
+  T *mean_d = mean, *C_d = C;
+  int32_t* info_d = info;
+  if (memspace == BLR_MEM_HOST) {
+    const size_t x_one = layout == BLR_LAYOUT_COLVECS ? mat_extent(D, N, ldx) : mat_extent(N, D, ldx);
+    const size_t lw_one = prior_kind == BLR_PRIOR_DIAGONAL ? (size_t)D : mat_extent(D, D, ldl);
+    const size_t s_one = noise_kind == BLR_NOISE_DENSE ? mat_extent(N, N, lds) : (noise_kind == BLR_NOISE_DIAGONAL ? (size_t)N : 1);
+    if ((rc = stage_in(h, X, x_one, &X_d))) return rc;
+    if ((rc = stage_in(h, s, s_one, &s_d))) return rc;
+    if ((rc = stage_in(h, mw, mw ? (size_t)D : 0, &mw_d))) return rc;
+    if ((rc = stage_in(h, Lw, lw_one, &Lw_d))) return rc;
+    if ((rc = stage_out_alloc(h, mean, (size_t)N, &mean_d))) return rc;
+    if ((rc = stage_out_alloc(h, C, mat_extent(N, N, ldc), &C_d))) return rc;
+    if ((rc = stage_out_alloc(h, info, (size_t)1, &info_d))) return rc;
+  }
+  T *Ybar = nullptr, *Gpart = nullptr;
+  double* scratch = nullptr;
+  const int nb = NP / kPB, ntiles = nb * (nb + 1) / 2;
+  if ((rc = dev_alloc_tmp(h, (size_t)ldy * DP, &Ybar))) return rc;
+  if ((rc = dev_alloc_tmp(h, (size_t)ntiles * kPB * kPB, &Gpart))) return rc;
+  if ((rc = dev_alloc_tmp(h, 1, &scratch))) return rc;
+  // ---- Y = alpha' = X' Uw^-1   (reference :36 alpha = Uw' \ X)
+  if (prior_kind == BLR_PRIOR_DIAGONAL) {
+    hipLaunchKernelGGL(prior_diag_kernel<T>, dim3(1), dim3(kThreads), 0, h->stream, Lw_d, (int64_t)1, prior_kind, D, scratch, info_d);
+    hipLaunchKernelGGL(diag_prior_rows_kernel<T>, dim3(2048), dim3(kThreads), 0, h->stream, X_d, ldx, layout, Lw_d, D, N, NP, DP, Ybar + DP, ldy);
+  } else {
+    if ((rc = tall_solve_rows<T>(h, layout, D, N, X_d, ldx, prior_kind, Lw_d, ldl, Ybar, ldy, DP, NP, info_d))) return rc;
+  }
+  // ---- Y Y' by the Gram kernel with the roles swapped: NP "rows", D "observations" (columns of Y are contiguous)
+  {
+    using LC = LargeCfg<T>;
+    if ((rc = set_lds<T>(h, reinterpret_cast<const void*>(gram_tile_kernel<T>), LC::LDS_BYTES))) return rc;
+    GramTileArgs<T> g{};
+    g.X = Ybar + DP; g.ldx = ldy; g.layout = LAYOUT_COLVECS; g.use_dma = 1;
+    g.s = nullptr; g.noise_kind = NOISE_ISOTROPIC; g.r = nullptr;
+    g.D = NP; g.n_begin = 0; g.n_end = DP; g.nsplit = 1;
+    g.tile_i0 = 0; g.tile_j0 = 0; g.tri = 1; g.ntiles = ntiles; g.nblocks = nb;
+    g.Gpart = Gpart; g.bpart = nullptr; g.mode_out = 0; g.xcd_swizzle = 0;
+    hipLaunchKernelGGL(gram_tile_kernel<T>, dim3(ntiles), dim3(kThreads), LC::LDS_BYTES, h->stream, g);
+    hipLaunchKernelGGL(cov_assemble_kernel<T>, dim3(ntiles, 16), dim3(kThreads), 0, h->stream, (const T*)Gpart, ntiles, N, noise_kind, s_d,
+                       lds, C_d, ldc);
+  }
+  // ---- mean = X' mw   (reference :33)
+  if (mean)
+    hipLaunchKernelGGL(mean_small_kernel<T>, dim3((unsigned)((N + 255) / 256)), dim3(kThreads), 0, h->stream, X_d, ldx, layout, mw_d, D, N, mean_d);
+  HIP_TRY(h, hipGetLastError());
+  if (memspace == BLR_MEM_HOST) {
+    if (mean) HIP_TRY(h, hipMemcpyAsync(mean, mean_d, (size_t)N * sizeof(T), hipMemcpyDeviceToHost, h->stream));
+    HIP_TRY(h, hipMemcpyAsync(C, C_d, mat_extent(N, N, ldc) * sizeof(T), hipMemcpyDeviceToHost, h->stream));
+    HIP_TRY(h, hipMemcpyAsync(info, info_d, sizeof(int32_t), hipMemcpyDeviceToHost, h->stream));
+  }
+  HIP_TRY(h, hipStreamSynchronize(h->stream));
+  return 0;
+}
+
+// rand with a dense noise covariance: Y = X'(mw + Uw \ Z1) + Us' Z2   (reference :49-53).  Returns info (> 0: Sigma_y or Lw
+// not positive definite).
+template <typename T>
+int rand_dense_noise(blr_handle* h, int memspace, int layout, int64_t D, int64_t N, int64_t S, const T* X, int64_t ldx, const T* Sy,
+                     int64_t ldsy, int prior_kind, const T* mw, const T* Lw, int64_t ldl, const T* Z1, int64_t ldz1, const T* Z2,
+                     int64_t ldz2, T* Y, int64_t ldy) {
+  if (!h) return -1;
+  h->err.clear();
+  if (N < 1 || N > kMaxDenseN) return bad_arg(h, 5, "N out of range for a dense noise covariance (1..16384)");
+  if (!Sy) return bad_arg(h, 9, "Sy is NULL");
+  if (ldsy < N) return bad_arg(h, 10, "ldsy < N");
+  if (S < 0) return bad_arg(h, 6, "S < 0");
+  if (S == 0) return 0;
+  // X' W with the noise term switched off (sigma^2 = 0), through the ordinary entry point (validates everything else)
+  const T zero = T(0);
+  Staging guard(h);
+  int rc;
+  const T* zero_d = &zero;
+  if (memspace == BLR_MEM_DEVICE) {
+    T* z = nullptr;
+    HIP_TRY(h, hipSetDevice(h->device));
+    if ((rc = dev_alloc_tmp(h, 1, &z))) return rc;
+    HIP_TRY(h, hipMemsetAsync(z, 0, sizeof(T), h->stream));
+    zero_d = z;
+  }
+  rc = rand_impl<T>(h, memspace, layout, D, N, S, X, ldx, BLR_NOISE_ISOTROPIC, zero_d, prior_kind, mw, Lw, ldl, Z1, ldz1, Z2, ldz2, Y, ldy);
+  if (rc) return rc;
+  // + L Z2 with L L' = Sigma_y
+  const int NP = (int)((N + kPB - 1) / kPB * kPB);
+  const T *Sy_d = Sy, *Z2_d = Z2;
+  T* Y_d = Y;
+  if (memspace == BLR_MEM_HOST) {
+    if ((rc = stage_in(h, Sy, mat_extent(N, N, ldsy), &Sy_d))) return rc;
+    if ((rc = stage_in(h, Z2, mat_extent(N, S, ldz2), &Z2_d))) return rc;
+    if ((rc = stage_out_alloc(h, Y, mat_extent(N, S, ldy), &Y_d))) return rc;  // copies the X'W part back in
+  }
+  T* M = nullptr;
+  int32_t* ninfo = nullptr;
+  if ((rc = dev_alloc_tmp(h, (size_t)NP * NP, &M))) return rc;
+  if ((rc = dev_alloc_tmp(h, 1, &ninfo))) return rc;
+  if ((rc = chol_noise<T>(h, Sy_d, ldsy, (int)N, NP, 0, M, (int64_t)NP, ninfo))) return rc;
+  dim3 grid((unsigned)((N + 63) / 64), (unsigned)((S + 15) / 16));
+  hipLaunchKernelGGL(lower_mult_add_kernel<T>, grid, dim3(kThreads), 0, h->stream, (const T*)M, (int64_t)NP, (int)N, Z2_d, ldz2, Y_d, ldy, S);
+  HIP_TRY(h, hipGetLastError());
+  int32_t hinfo = 0;
+  HIP_TRY(h, hipMemcpyAsync(&hinfo, ninfo, sizeof(int32_t), hipMemcpyDeviceToHost, h->stream));
+  if (memspace == BLR_MEM_HOST) HIP_TRY(h, hipMemcpyAsync(Y, Y_d, mat_extent(N, S, ldy) * sizeof(T), hipMemcpyDeviceToHost, h->stream));
+  HIP_TRY(h, hipStreamSynchronize(h->stream));
+  return hinfo;
+}
+
 }  // namespace
 
 // =======================================================================================================
@@ -1813,6 +2116,26 @@ int blr_timer_stop(blr_handle* h, float* elapsed_ms) {
                               int32_t* info) {                                                                      \
     return posterior_rff<T>(h, memspace, Din, D, N, Xin, ldxin, Omega, ldo, phase, scale, y, noise_kind, s,         \
                             prior_kind, mw, Lw, ldl, mw_post, T_post, ldt, Lw_post, ldlp, logpdf, info);            \
+  }                                                                                                                 \
+  int blr_posterior_dense_noise_##SUF(blr_handle* h, int memspace, int layout, int64_t D, int64_t N, const T* X,    \
+                                      int64_t ldx, const T* y, const T* Sy, int64_t ldsy, int prior_kind,           \
+                                      const T* mw, const T* Lw, int64_t ldl, T* mw_post, T* T_post, int64_t ldt,    \
+                                      T* Lw_post, int64_t ldlp, double* logpdf, int32_t* info) {                    \
+    return posterior_dense_noise<T>(h, memspace, layout, D, N, X, ldx, y, Sy, ldsy, prior_kind, mw, Lw, ldl,        \
+                                    mw_post, T_post, ldt, Lw_post, ldlp, logpdf, info);                             \
+  }                                                                                                                 \
+  int blr_mean_and_cov_##SUF(blr_handle* h, int memspace, int layout, int64_t D, int64_t N, const T* X,             \
+                             int64_t ldx, int noise_kind, const T* s, int64_t lds, int prior_kind, const T* mw,     \
+                             const T* Lw, int64_t ldl, T* mean, T* C, int64_t ldc, int32_t* info) {                 \
+    return mean_and_cov<T>(h, memspace, layout, D, N, X, ldx, noise_kind, s, lds, prior_kind, mw, Lw, ldl, mean,    \
+                           C, ldc, info);                                                                           \
+  }                                                                                                                 \
+  int blr_rand_dense_noise_##SUF(blr_handle* h, int memspace, int layout, int64_t D, int64_t N, int64_t S,          \
+                                 const T* X, int64_t ldx, const T* Sy, int64_t ldsy, int prior_kind, const T* mw,   \
+                                 const T* Lw, int64_t ldl, const T* Z1, int64_t ldz1, const T* Z2, int64_t ldz2,    \
+                                 T* Y, int64_t ldy) {                                                               \
+    return rand_dense_noise<T>(h, memspace, layout, D, N, S, X, ldx, Sy, ldsy, prior_kind, mw, Lw, ldl, Z1, ldz1,   \
+                               Z2, ldz2, Y, ldy);                                                                   \
   }
 
 BLR_DEFINE(f64, double)

@@ -177,10 +177,11 @@ def _noise(Sy, N, dtype, need_cholesky=False):
         if Sy.shape[0] != N:
             raise ValueError("length of the noise diagonal != number of inputs")
         return np.ascontiguousarray(Sy), _abi.NOISE_DIAGONAL
-    raise NotImplementedError(
-        "a dense N x N noise covariance is outside the MI355X hot path (SURVEY.md 2 #19): "
-        "only isotropic and Diagonal noise are offloaded"
-    )
+    if Sy.ndim == 2:  # dense N x N covariance (the reference's own toy problems, test/test_utils.jl:7-8)
+        if Sy.shape != (N, N):
+            raise ValueError("size of the noise covariance != number of inputs")
+        return np.asfortranarray(Sy), _abi.NOISE_DENSE
+    raise ValueError("noise covariance must be a scalar, a vector / Diagonal, or an N x N matrix")
 
 
 def _mean_vector(mw, D, dtype):
@@ -383,6 +384,13 @@ def _fused(fx, y, want_posterior):
         A = np.empty((D, D), dtype=dtype, order="F") if not isinstance(blr.Lw, PDMat) else None
     else:
         mw_post = T = A = None
+    if noise_kind == _abi.NOISE_DENSE:  # reference :79-82 general branch: whitened on the device (blr_posterior_dense_noise_*)
+        info = np.zeros(1, dtype=np.int32)
+        _handle().posterior_dense_noise(dtype, _abi.MEM_HOST, layout, D, N, X, ldx, y, s, max(N, 1), prior_kind, mw, Lw, ldl, mw_post, T,
+                                        max(D, 1), A, max(D, 1), lp, info)
+        if info[0] > 0:
+            raise _abi.PosDefException(int(info[0]))
+        return float(lp[0]), mw_post, T, A
     _handle().posterior(dtype, layout, D, N, X, ldx, y, noise_kind, s, prior_kind, mw, Lw, ldl, mw_post, T, max(D, 1),
                         A, max(D, 1), lp)
     return float(lp[0]), mw_post, T, A
@@ -410,6 +418,13 @@ def logpdf_columns(fx, Y, return_means=False):
     S = Yf.shape[1]
     mw = _mean_vector(blr.mw, D, dtype)
     s, noise_kind = _noise(fx.Sy, N, dtype)
+    if noise_kind == _abi.NOISE_DENSE:  # AbstractGPs' column-wise fallback (each column re-whitens; test sizes only)
+        lps, means = [], []
+        for j in range(S):
+            lp_j, m_j, _, _ = _fused(fx, Yf[:, j], want_posterior=return_means)
+            lps.append(lp_j)
+            means.append(m_j)
+        return (np.array(lps), np.stack(means, axis=1)) if return_means else np.array(lps)
     Lw, prior_kind, ldl = _prior(blr.Lw, D, dtype)
     lp = np.zeros(S, dtype=np.float64)
     if D <= 128 and S <= 256 and not return_means:
@@ -449,6 +464,8 @@ def logpdf_and_gradient(fx, y):
         raise ValueError("length(y) != size(fx.x.X, 2)")  # reference :74
     mw = _mean_vector(blr.mw, D, dtype)
     s, noise_kind = _noise(fx.Sy, N, dtype)
+    if noise_kind == _abi.NOISE_DENSE:
+        raise NotImplementedError("logpdf_and_gradient: closed-form rule implemented for isotropic / Diagonal noise only")
     Lw, prior_kind, ldl = _prior(blr.Lw, D, dtype)
     lp = np.zeros(1, dtype=np.float64)
     info = np.zeros(1, dtype=np.int32)
@@ -504,6 +521,8 @@ def _marginals(fx, want_mean, want_var):
     X, layout, ldx, D, N = _x_layout(fx.x, dtype)
     mw = _mean_vector(blr.mw, D, dtype)
     s, noise_kind = _noise(fx.Sy, N, dtype)  # var adds diag(Sigma_y) (:43): no factorisation of the noise, no positivity check
+    if noise_kind == _abi.NOISE_DENSE:
+        s, noise_kind = np.ascontiguousarray(np.diag(s)), _abi.NOISE_DIAGONAL
     Lw, prior_kind, ldl = _prior(blr.Lw, D, dtype, need_cholesky=want_var)  # :41 _cholesky(Lw)
     m = np.empty(N, dtype=dtype) if want_mean else None
     v = np.empty(N, dtype=dtype) if want_var else None
@@ -536,14 +555,33 @@ def marginals(fx):
     return [Normal(mi, math.sqrt(vi)) for mi, vi in zip(m, v)]
 
 
+def _mean_and_cov(fx, want_mean):
+    fx = _to_finite_blr(fx)
+    blr = fx.f
+    dtype = _dtype_of(blr.mw)
+    X, layout, ldx, D, N = _x_layout(fx.x, dtype)
+    mw = _mean_vector(blr.mw, D, dtype)
+    s, noise_kind = _noise(fx.Sy, N, dtype)
+    Lw, prior_kind, ldl = _prior(blr.Lw, D, dtype, need_cholesky=True)  # :36 _cholesky(Lw)
+    m = np.empty(N, dtype=dtype) if want_mean else None
+    Cv = np.empty((N, N), dtype=dtype, order="F")
+    info = np.zeros(1, dtype=np.int32)
+    _handle().mean_and_cov(dtype, _abi.MEM_HOST, layout, D, N, X, ldx, noise_kind, s, max(N, 1), prior_kind, mw, Lw, ldl, m, Cv,
+                           max(N, 1), info)
+    if info[0] > 0:
+        raise _abi.PosDefException(int(info[0]))
+    return m, Cv
+
+
 def cov(fx):
-    """reference :35-38.  The N x N predictive covariance is excluded from the GPU scope
-    (SURVEY.md 8 a10); use var(fx) / marginals(fx) for the streamed diagonal."""
-    raise NotImplementedError("cov(fx) (N x N) is outside the MI355X hot path; use var(fx)")
+    """reference :35-38: Symmetric(alpha' alpha + Sigma_y), alpha = Uw' \\ X -- the full N x N predictive covariance
+    (blr_mean_and_cov_*; moderate N, <= 16384)."""
+    return _mean_and_cov(fx, False)[1]
 
 
 def mean_and_cov(fx):
-    raise NotImplementedError("mean_and_cov(fx) (N x N) is outside the MI355X hot path; use mean_and_var(fx)")
+    """reference :45"""
+    return _mean_and_cov(fx, True)
 
 
 def _randn(rng, rows, cols, dtype):
@@ -627,6 +665,9 @@ def _rand_finite(rng, fx, S):
     Z1 = _randn(rng, D, S, dtype)  # FIRST draw  (reference :51)
     Z2 = _randn(rng, N, S, dtype)  # SECOND draw (reference :52)
     Y = np.empty((N, S), dtype=dtype, order="F")
+    if noise_kind == _abi.NOISE_DENSE:
+        _handle().rand_dense_noise(dtype, _abi.MEM_HOST, layout, D, N, S, X, ldx, s, max(N, 1), prior_kind, mw, Lw, ldl, Z1, D, Z2, N, Y, N)
+        return Y
     _handle().rand(dtype, _abi.MEM_HOST, layout, D, N, S, X, ldx, noise_kind, s, prior_kind, mw, Lw, ldl, Z1, D, Z2, N,
                    Y, N)
     return Y

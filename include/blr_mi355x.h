@@ -45,7 +45,8 @@ extern "C" {
 /* observation-noise covariance Sigma_y (FiniteGP field, reference :79) */
 #define BLR_NOISE_ISOTROPIC 0 /* s points to ONE variance  (AbstractGPs f(x, sigma^2))  */
 #define BLR_NOISE_DIAGONAL 1  /* s[N] variances            (Diagonal(v))                */
-/* a dense N x N Sigma_y is outside the GPU scope: callers keep their CPU path */
+#define BLR_NOISE_DENSE 2     /* N x N symmetric matrix (upper triangle read, as LAPACK 'U'), column-major: only the
+                                 *_dense_noise entry points and blr_mean_and_cov_* take it (moderate N, <= 16384) */
 
 /* prior precision Lambda_w (struct field, reference :11-14; _cholesky at :78) */
 #define BLR_PRIOR_DENSE 0        /* Lw: D x D symmetric, UPPER triangle read (as LAPACK potrf 'U'), ldl >= D */
@@ -254,6 +255,36 @@ int blr_posterior_from_stats_f64(blr_handle* h, int64_t D, int64_t N_total, doub
 int blr_posterior_from_stats_f32(blr_handle* h, int64_t D, int64_t N_total, float* stats, int64_t lds, const double* scal,
                                  int prior_kind, const float* mw, const float* Lw, int64_t ldl, float* mw_post,
                                  float* T_post, int64_t ldt, float* Lw_post, int64_t ldlp, double* logpdf, int32_t* info);
+
+/* ---- dense noise covariance and full predictive covariance -------------------------
+ * reference src/bayesian_linear_regression.jl:79-82 (the general _cholesky(Sigma_y) branch of the shared quantities -- what
+ * the reference's own toy problems use, test/test_utils.jl:7-8), :35-38 / :45 (cov, mean_and_cov), :52 (rand).
+ * A dense Sigma_y (N x N, ldsy >= N, upper triangle read) is whitened away on the device: blocked Cholesky L L' = Sigma_y with
+ * X and y carried through the panel solves (X L^-T, L^-1 y), then the ordinary update with unit noise; logpdf gets
+ * -logdet(Sigma_y)/2.  N <= 16384.  Outputs as blr_posterior_*; info > 0: Sigma_y, Lw or Lw + X Sy^-1 X' not positive definite.
+ *   blr_mean_and_cov_*   mean[N] (may be NULL) and C = X' Lw^-1 X + Sigma_y as the FULL symmetric N x N matrix (ldc >= N);
+ *                        noise_kind ISOTROPIC / DIAGONAL / DENSE (s = the scalar, the N variances, or the N x N matrix with lds)
+ *   blr_rand_dense_noise_*   Y = X'(mw + Uw \ Z1) + Us' Z2 with Us = chol(Sigma_y).U; RETURNS info (0, or k > 0) */
+int blr_posterior_dense_noise_f64(blr_handle* h, int memspace, int layout, int64_t D, int64_t N, const double* X, int64_t ldx,
+                                  const double* y, const double* Sy, int64_t ldsy, int prior_kind, const double* mw,
+                                  const double* Lw, int64_t ldl, double* mw_post, double* T_post, int64_t ldt, double* Lw_post,
+                                  int64_t ldlp, double* logpdf, int32_t* info);
+int blr_posterior_dense_noise_f32(blr_handle* h, int memspace, int layout, int64_t D, int64_t N, const float* X, int64_t ldx,
+                                  const float* y, const float* Sy, int64_t ldsy, int prior_kind, const float* mw,
+                                  const float* Lw, int64_t ldl, float* mw_post, float* T_post, int64_t ldt, float* Lw_post,
+                                  int64_t ldlp, double* logpdf, int32_t* info);
+int blr_mean_and_cov_f64(blr_handle* h, int memspace, int layout, int64_t D, int64_t N, const double* X, int64_t ldx,
+                         int noise_kind, const double* s, int64_t lds, int prior_kind, const double* mw, const double* Lw,
+                         int64_t ldl, double* mean, double* C, int64_t ldc, int32_t* info);
+int blr_mean_and_cov_f32(blr_handle* h, int memspace, int layout, int64_t D, int64_t N, const float* X, int64_t ldx,
+                         int noise_kind, const float* s, int64_t lds, int prior_kind, const float* mw, const float* Lw,
+                         int64_t ldl, float* mean, float* C, int64_t ldc, int32_t* info);
+int blr_rand_dense_noise_f64(blr_handle* h, int memspace, int layout, int64_t D, int64_t N, int64_t S, const double* X,
+                             int64_t ldx, const double* Sy, int64_t ldsy, int prior_kind, const double* mw, const double* Lw,
+                             int64_t ldl, const double* Z1, int64_t ldz1, const double* Z2, int64_t ldz2, double* Y, int64_t ldy);
+int blr_rand_dense_noise_f32(blr_handle* h, int memspace, int layout, int64_t D, int64_t N, int64_t S, const float* X,
+                             int64_t ldx, const float* Sy, int64_t ldsy, int prior_kind, const float* mw, const float* Lw,
+                             int64_t ldl, const float* Z1, int64_t ldz1, const float* Z2, int64_t ldz2, float* Y, int64_t ldy);
 
 /* ---- sharded log-evidence: fixed-order sum of logpdf[B] on the device ----------
  * Deterministic (no float atomics): the same bits for the same B regardless of launch geometry.

@@ -91,8 +91,16 @@ def test_noise_and_prior_classification():
     assert kind == _abi.NOISE_DIAGONAL and s.dtype == np.float32
     with pytest.raises(ValueError):
         R._noise(np.ones(6), 7, np.float64)
-    with pytest.raises(NotImplementedError):
-        R._noise(np.eye(7), 7, np.float64)
+    s, kind = R._noise(np.eye(7), 7, np.float64)  # dense Sigma_y: whitened on the device (blr_posterior_dense_noise_*)
+    assert kind == _abi.NOISE_DENSE and s.flags.f_contiguous and s.shape == (7, 7)
+    with pytest.raises(ValueError):
+        R._noise(np.eye(6), 7, np.float64)
+    # the mirror checks positivity where the reference factorises and the kernel behind the call does not report it
+    with pytest.raises(_abi.PosDefException) as ei:
+        R._noise(np.array([1.0, 2.0, 0.0, -1.0, 1.0, 1.0, 1.0]), 7, np.float64, need_cholesky=True)
+    assert ei.value.info == 3
+    with pytest.raises(ValueError):  # length(mw) != input dimension: never a read past the end of mw
+        R._mean_vector(np.zeros(3), 5, np.float64)
     A = np.array([[2.0, 1.0], [1.0, 3.0]])
     for Lw, want in ((A, _abi.PRIOR_DENSE), (R.Symmetric(A), _abi.PRIOR_DENSE), (R.PDMat(np.linalg.cholesky(A).T),
                                                                                  _abi.PRIOR_UPPER_FACTOR)):

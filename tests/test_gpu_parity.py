@@ -1162,3 +1162,145 @@ def test_rff_square_rowvecs_input(B):
         np.testing.assert_allclose(rff(B.RowVecs(arr)).X, Phi_ref.T, atol=1e-12)
     np.testing.assert_allclose(rff(B.ColVecs(np.ascontiguousarray(Xin))).X, Phi_ref, atol=1e-12)
 
+
+# ---- dense Sigma_y and cov(fx) on the device: the reference's own toy problems, unmodified --------
+# /root/reference/test/test_utils.jl:4-10 builds every toy problem with a DENSE Sigma_y = C C' + I; the tests below are the
+# reference's testsets (test/bayesian_linear_regression.jl) on that construction, for Matrix / ColVecs / RowVecs inputs.
+def _toy_inputs(B, X):
+    return {"matrix": np.asfortranarray(X), "colvecs": B.ColVecs(np.asfortranarray(X)), "rowvecs": B.RowVecs(np.ascontiguousarray(X.T))}
+
+
+@pytest.mark.parametrize("Tx", ["matrix", "colvecs", "rowvecs"])
+def test_reference_testsets_dense_noise(B, Tx):
+    # logpdf: test/bayesian_linear_regression.jl:22-38 (N=13, D=7, independent N x N Gaussian formula)
+    rng = _rng(12000)
+    N, D = 13, 7
+    X, mw, Lw, Sy = O.generate_toy_problem(rng, N, D)  # dense Sigma_y
+    f = B.BayesianLinearRegressor(mw, Lw)
+    x = _toy_inputs(B, X)[Tx]
+    y = B.rand(rng, f(x, Sy))
+    assert y.shape == (N,)
+    m = X.T @ mw
+    Sig = X.T @ np.linalg.solve(Lw, X) + Sy
+    d = y - m
+    naive = -(N * np.log(2 * np.pi) + np.linalg.slogdet(Sig)[1] + d @ np.linalg.solve(Sig, d)) / 2
+    assert B.logpdf(f(x, Sy), y) == pytest.approx(naive, rel=1e-10)
+    assert B.logpdf(f(x, Sy), y) == pytest.approx(O.logpdf_literal(mw, Lw, X, Sy, y), rel=1e-11)
+    # posterior, low noise: :40-48 -- mean at X reproduces y, every entry of the predictive covariance < 1000 eps
+    eps = np.finfo(float).eps
+    y0 = B.rand(rng, f(x, eps))
+    fp = B.posterior(f(x, eps), y0)
+    m0 = B.mean(fp(x, eps))
+    assert np.linalg.norm(m0 - y0) <= np.sqrt(eps) * max(np.linalg.norm(m0), np.linalg.norm(y0))  # Julia's `isapprox` (rtol = sqrt(eps), norm-wise)
+    assert np.all(B.cov(fp(x, eps)) < 1000 * eps)
+    # posterior vs the literal oracle on the dense problem (:60-69, :79-82)
+    mw_o, T_o, A_o = O.posterior_literal(mw, Lw, X, Sy, y)
+    fq = B.posterior(f(x, Sy), y)
+    np.testing.assert_allclose(fq.mw, mw_o, rtol=1e-9, atol=1e-11)
+    np.testing.assert_allclose(fq.Lw.toarray(), A_o, rtol=1e-9, atol=1e-11)
+    # repeated conditioning: :49-70 -- block-diagonal dense Sigma_y, two sequential updates == one shot
+    N1 = N - 3
+    S1, S2 = Sy[:N1, :N1], Sy[N1:, N1:]
+    Sblk = np.zeros((N, N))
+    Sblk[:N1, :N1], Sblk[N1:, N1:] = S1, S2
+    X1, X2 = X[:, :N1], X[:, N1:]
+    x1, x2 = _toy_inputs(B, X1)[Tx], _toy_inputs(B, X2)[Tx]
+    f1 = B.posterior(f(x1, S1), y[:N1])
+    f2 = B.posterior(f1(x2, S2), y[N1:])
+    f12 = B.posterior(f(x, Sblk), y)
+    Xp = rng.standard_normal((D, 9))
+    xp = _toy_inputs(B, Xp)[Tx]
+    np.testing.assert_allclose(B.mean(f2(xp, 0.1)), B.mean(f12(xp, 0.1)), rtol=1e-8, atol=1e-10)
+    np.testing.assert_allclose(B.cov(f2(xp, 0.1)), B.cov(f12(xp, 0.1)), rtol=1e-8, atol=1e-10)
+
+
+@pytest.mark.parametrize("N,D,prior", [(11, 3, "dense"), (40, 16, "pdmat"), (300, 64, "diagonal"), (200, 128, "dense"), (513, 130, "dense")])
+def test_finitegp_interface_cov(B, N, D, prior):
+    # what AbstractGPs.TestUtils.test_finitegp_primary_and_secondary_public_interface checks (test/...:3-10): cov is symmetric
+    # PSD, var == diag(cov), mean_and_cov / mean_and_var agree with the separate calls, marginals carry mean and sqrt(var)
+    rng = _rng(12100 + N)
+    X, mw, Lw, Sy = O.generate_toy_problem(rng, N, D)
+    if prior == "diagonal":
+        dvec = np.exp(0.3 * rng.standard_normal(D))
+        Lw, Lw_arg = np.diag(dvec), B.Diagonal(dvec)
+    else:
+        Lw_arg = Lw if prior == "dense" else B.PDMat(O.chol_upper(Lw))
+    f = B.BayesianLinearRegressor(mw, Lw_arg)
+    for noise in (Sy, np.exp(0.2 * rng.standard_normal(N)), 0.3):
+        fx = f(np.asfortranarray(X), noise)
+        Cv = B.cov(fx)
+        C_o = O.cov(mw, Lw, X, noise)
+        np.testing.assert_allclose(Cv, C_o, rtol=1e-9, atol=1e-10)
+        assert np.array_equal(Cv, Cv.T) and np.min(np.linalg.eigvalsh(Cv)) > 0
+        np.testing.assert_allclose(B.var(fx), np.diag(Cv), rtol=1e-9)
+        m, C2 = B.mean_and_cov(fx)
+        np.testing.assert_allclose(m, X.T @ mw, rtol=1e-10, atol=1e-12)
+        np.testing.assert_array_equal(C2, Cv)
+        m2, v2 = B.mean_and_var(fx)
+        np.testing.assert_allclose(m2, m, rtol=1e-10, atol=1e-12)
+        ms = B.marginals(fx)
+        np.testing.assert_allclose([n.mu for n in ms], m, rtol=1e-10, atol=1e-12)
+        np.testing.assert_allclose(B.std(ms) ** 2, np.diag(Cv), rtol=1e-9)
+    Cr = B.cov(f(B.RowVecs(np.ascontiguousarray(X.T)), Sy))
+    np.testing.assert_allclose(Cr, O.cov(mw, Lw, X, Sy), rtol=1e-9, atol=1e-10)
+    # logpdf(fx, Y::Matrix) == column-wise logpdfs (TestUtils), dense noise
+    Y = rng.standard_normal((N, 3))
+    lps = B.logpdf(f(np.asfortranarray(X), Sy), Y)
+    for j in range(3):
+        assert lps[j] == pytest.approx(O.logpdf_literal(mw, Lw, X, Sy, Y[:, j]), rel=1e-10)
+
+
+def test_rand_dense_noise_given_normals_and_moments(B):
+    from blr_amd import _abi
+
+    rng = _rng(12200)
+    N, D, S = 11, 3, 5
+    X, mw, Lw, Sy = O.generate_toy_problem(rng, N, D)
+    Z1, Z2 = rng.standard_normal((D, S)), rng.standard_normal((N, S))
+    Y = np.empty((N, S), order="F")
+    _abi.default_handle().rand_dense_noise(np.float64, _abi.MEM_HOST, _abi.LAYOUT_COLVECS, D, N, S, np.asfortranarray(X), D,
+                                           np.asfortranarray(Sy), N, _abi.PRIOR_DENSE, mw, np.asfortranarray(Lw), D,
+                                           np.asfortranarray(Z1), D, np.asfortranarray(Z2), N, Y, N)
+    np.testing.assert_allclose(Y, O.rand(mw, Lw, X, Sy, Z1, Z2), rtol=1e-10, atol=1e-12)
+    # test/bayesian_linear_regression.jl:11-21: empirical moments of many draws vs mean(fx) / cov(fx)
+    f = B.BayesianLinearRegressor(mw, Lw)
+    fx = f(np.asfortranarray(X), Sy)
+    ys = B.rand(rng, fx, 400_000)
+    np.testing.assert_allclose(ys.mean(axis=1), B.mean(fx), atol=2e-2, rtol=2e-2)
+    np.testing.assert_allclose(np.cov(ys), B.cov(fx), atol=2e-2, rtol=2e-2)
+    # a Sigma_y that is not positive definite: PosDefException from rand, logpdf and posterior (:52, :79)
+    bad = Sy.copy()
+    bad[4, 4] = -3.0
+    y = rng.standard_normal(N)
+    for call in (lambda: B.rand(rng, f(np.asfortranarray(X), bad)), lambda: B.logpdf(f(np.asfortranarray(X), bad), y),
+                 lambda: B.posterior(f(np.asfortranarray(X), bad), y)):
+        with pytest.raises(B.PosDefException) as ei:
+            call()
+        assert ei.value.info == 5
+
+
+@pytest.mark.parametrize("dtype,N,D", [(np.float64, 1000, 64), (np.float64, 700, 300), (np.float32, 2048, 128)])
+def test_dense_noise_moderate_sizes(B, dtype, N, D):
+    rng = _rng(12300 + N)
+    X = rng.standard_normal((D, N)).astype(dtype)
+    Cm = 0.1 * rng.standard_normal((N, N)) / np.sqrt(N / 16)
+    Sy = (Cm @ Cm.T + np.diag(np.exp(0.2 * rng.standard_normal(N)))).astype(dtype)
+    mw = (0.2 * rng.standard_normal(D)).astype(dtype)
+    dvec = np.exp(0.2 * rng.standard_normal(D)).astype(dtype)
+    y = (X.T.astype(float) @ rng.standard_normal(D) / np.sqrt(D) + rng.standard_normal(N)).astype(dtype)
+    f64 = lambda a: np.asarray(a, dtype=float)
+    lp_o = O.logpdf_literal(f64(mw), np.diag(f64(dvec)), f64(X), f64(Sy), f64(y))
+    mw_o, T_o, A_o = O.posterior_literal(f64(mw), np.diag(f64(dvec)), f64(X), f64(Sy), f64(y))
+    f = B.BayesianLinearRegressor(mw, B.Diagonal(dvec))
+    fx = f(np.asfortranarray(X), Sy)
+    lp = B.logpdf(fx, y)
+    fp = B.posterior(fx, y)
+    if dtype == np.float64:
+        assert lp == pytest.approx(lp_o, rel=1e-10)
+        np.testing.assert_allclose(fp.mw, mw_o, rtol=1e-8, atol=1e-10)
+        np.testing.assert_allclose(fp.Lw.toarray(), A_o, rtol=1e-9, atol=1e-9)
+    else:
+        assert lp == pytest.approx(lp_o, rel=2e-4)
+        assert np.linalg.norm(fp.mw - mw_o) <= 2e-4 * np.linalg.norm(mw_o)
+        assert np.max(np.abs(fp.Lw.toarray() - A_o)) <= 1e-4 * np.max(np.abs(A_o))
+
