@@ -57,6 +57,13 @@ _SIGS = {
     "blr_timer_start": ([_H], _int),
     "blr_timer_stop": ([_H, C.POINTER(C.c_float)], _int),
     "blr_logpdf_sum": ([_H, _int, _i64, _vp, _vp], _int),
+    "blr_comm_unique_id": ([_vp], _int),
+    "blr_comm_init": ([_H, _int, _int, _vp], _int),
+    "blr_comm_destroy": ([_H], _int),
+    "blr_comm_size": ([_H], _int),
+    "blr_comm_rank": ([_H], _int),
+    "blr_logpdf_allgather_sum": ([_H, _i64, _vp, _vp, _vp], _int),
+    "blr_allreduce_sum": ([_H, _int, _vp, _i64], _int),
 }
 for _suf in ("f64", "f32"):
     _SIGS[f"blr_posterior_batched_{_suf}"] = (
@@ -298,6 +305,35 @@ class Handle:
         if rc > 0:
             raise PosDefException(rc)
         return rc
+
+    # -- RCCL called directly (one rank per handle) ------------------------------------------------------------------
+    @staticmethod
+    def comm_unique_id():
+        """128 opaque bytes (rank 0 calls this and ships them to the other ranks)."""
+        buf = C.create_string_buffer(128)
+        rc = load_library().blr_comm_unique_id(C.cast(buf, _vp))
+        if rc != 0:
+            raise BLRError(rc, "blr_comm_unique_id failed (librccl missing?)")
+        return buf.raw
+
+    def comm_init(self, nranks, rank, unique_id):
+        buf = C.create_string_buffer(bytes(unique_id), 128)
+        return self.check(self.lib.blr_comm_init(self._h, int(nranks), int(rank), C.cast(buf, _vp)))
+
+    def comm_destroy(self):
+        return self.check(self.lib.blr_comm_destroy(self._h))
+
+    def comm_size(self):
+        return self.lib.blr_comm_size(self._h)
+
+    def comm_rank(self):
+        return self.lib.blr_comm_rank(self._h)
+
+    def logpdf_allgather_sum(self, count, logpdf_local, logpdf_all, total):
+        return self.check(self.lib.blr_logpdf_allgather_sum(self._h, count, _ptr(logpdf_local), _ptr(logpdf_all), _ptr(total)))
+
+    def allreduce_sum(self, is_f64, buf, count):
+        return self.check(self.lib.blr_allreduce_sum(self._h, int(bool(is_f64)), _ptr(buf), count))
 
     def logpdf_sum(self, memspace, B, logpdf, total):
         return self.check(self.lib.blr_logpdf_sum(self._h, memspace, B, _ptr(logpdf), _ptr(total)))

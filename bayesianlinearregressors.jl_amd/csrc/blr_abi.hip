@@ -3,6 +3,8 @@
 #include "../../include/blr_mi355x.h"
 
 #include <hip/hip_runtime.h>
+#include <rccl/rccl.h>  // types only: the symbols are resolved with dlopen / dlsym on first use
+#include <dlfcn.h>
 
 #include <algorithm>
 #include <cstdio>
@@ -37,9 +39,52 @@ struct blr_handle {
   unsigned* ticket = nullptr;
   unsigned ticket_base = 0;
   unsigned epoch = 0;
+  // RCCL communicator of blr_comm_init (one rank per handle / GPU); NULL until then
+  ncclComm_t comm = nullptr;
+  int comm_size = 0, comm_rank = 0;
 };
 
 namespace {
+
+// ---- RCCL, bound at run time -------------------------------------------------------------------------------------
+// The library has no link-time dependency on librccl: a single-GPU host never loads it, and a process that already has a
+// RCCL (PyTorch ships one) gets that one.  Only the calls of the path's single exchange are bound.
+struct RcclApi {
+  ncclResult_t (*GetUniqueId)(ncclUniqueId*) = nullptr;
+  ncclResult_t (*CommInitRank)(ncclComm_t*, int, ncclUniqueId, int) = nullptr;
+  ncclResult_t (*CommDestroy)(ncclComm_t) = nullptr;
+  ncclResult_t (*AllGather)(const void*, void*, size_t, ncclDataType_t, ncclComm_t, hipStream_t) = nullptr;
+  ncclResult_t (*AllReduce)(const void*, void*, size_t, ncclDataType_t, ncclRedOp_t, ncclComm_t, hipStream_t) = nullptr;
+  const char* (*GetErrorString)(ncclResult_t) = nullptr;
+  bool ok = false;
+  std::string why;
+};
+RcclApi& rccl() {
+  static RcclApi api = [] {
+    RcclApi a;
+    void* lib = nullptr;
+    for (const char* name : {"librccl.so.1", "librccl.so", "/opt/rocm/lib/librccl.so.1"}) {
+      lib = dlopen(name, RTLD_NOW | RTLD_GLOBAL);
+      if (lib) break;
+    }
+    if (!lib) { a.why = std::string("librccl not found: ") + dlerror(); return a; }
+    auto sym = [&](const char* n) { return dlsym(lib, n); };
+    a.GetUniqueId = reinterpret_cast<decltype(a.GetUniqueId)>(sym("ncclGetUniqueId"));
+    a.CommInitRank = reinterpret_cast<decltype(a.CommInitRank)>(sym("ncclCommInitRank"));
+    a.CommDestroy = reinterpret_cast<decltype(a.CommDestroy)>(sym("ncclCommDestroy"));
+    a.AllGather = reinterpret_cast<decltype(a.AllGather)>(sym("ncclAllGather"));
+    a.AllReduce = reinterpret_cast<decltype(a.AllReduce)>(sym("ncclAllReduce"));
+    a.GetErrorString = reinterpret_cast<decltype(a.GetErrorString)>(sym("ncclGetErrorString"));
+    a.ok = a.GetUniqueId && a.CommInitRank && a.CommDestroy && a.AllGather && a.AllReduce && a.GetErrorString;
+    if (!a.ok) a.why = "librccl lacks a required symbol";
+    return a;
+  }();
+  return api;
+}
+int rccl_fail(blr_handle* h, ncclResult_t r, const char* what) {
+  if (h) h->err = std::string(what) + ": " + (rccl().GetErrorString ? rccl().GetErrorString(r) : "RCCL error");
+  return -(2000 + (int)r);
+}
 
 constexpr int kMaxSmallD = 128;
 constexpr int kMaxLargeD = 8192;
@@ -1964,6 +2009,7 @@ int blr_destroy(blr_handle* h) {
   if (!h) return 0;
   (void)hipSetDevice(h->device);
   (void)hipStreamSynchronize(h->stream);
+  if (h->comm && rccl().ok) (void)rccl().CommDestroy(h->comm);
   if (h->ws) (void)hipFree(h->ws);
   if (h->feat) (void)hipFree(h->feat);
   if (h->xchg) (void)hipFree(h->xchg);
@@ -2140,6 +2186,86 @@ int blr_timer_stop(blr_handle* h, float* elapsed_ms) {
 
 BLR_DEFINE(f64, double)
 BLR_DEFINE(f32, float)
+
+// ---- multi-GPU exchange: RCCL called directly ------------------------------------------------------
+int blr_comm_unique_id(void* id128) {
+  if (!id128) return -1;
+  if (!rccl().ok) return -2001;
+  ncclUniqueId id;
+  static_assert(sizeof(ncclUniqueId) == BLR_UNIQUE_ID_BYTES, "ncclUniqueId is 128 bytes");
+  ncclResult_t r = rccl().GetUniqueId(&id);
+  if (r != ncclSuccess) return -(2000 + (int)r);
+  memcpy(id128, &id, sizeof id);
+  return 0;
+}
+
+int blr_comm_init(blr_handle* h, int nranks, int rank, const void* id128) {
+  if (!h) return -1;
+  h->err.clear();
+  if (nranks < 1) return bad_arg(h, 2, "nranks < 1");
+  if (rank < 0 || rank >= nranks) return bad_arg(h, 3, "rank out of range");
+  if (!id128) return bad_arg(h, 4, "unique id is NULL");
+  if (h->comm) return bad_arg(h, 1, "the handle already has a communicator (blr_comm_destroy first)");
+  if (!rccl().ok) { h->err = rccl().why; return -2001; }
+  HIP_TRY(h, hipSetDevice(h->device));
+  ncclUniqueId id;
+  memcpy(&id, id128, sizeof id);
+  ncclResult_t r = rccl().CommInitRank(&h->comm, nranks, id, rank);
+  if (r != ncclSuccess) { h->comm = nullptr; return rccl_fail(h, r, "ncclCommInitRank"); }
+  h->comm_size = nranks;
+  h->comm_rank = rank;
+  return 0;
+}
+
+int blr_comm_destroy(blr_handle* h) {
+  if (!h) return -1;
+  if (!h->comm) return 0;
+  (void)hipSetDevice(h->device);
+  (void)hipStreamSynchronize(h->stream);
+  ncclResult_t r = rccl().CommDestroy(h->comm);
+  h->comm = nullptr;
+  h->comm_size = 0;
+  h->comm_rank = 0;
+  return r == ncclSuccess ? 0 : rccl_fail(h, r, "ncclCommDestroy");
+}
+
+int blr_comm_size(blr_handle* h) { return h && h->comm ? h->comm_size : (h ? 1 : -1); }
+int blr_comm_rank(blr_handle* h) { return h && h->comm ? h->comm_rank : (h ? 0 : -1); }
+
+int blr_logpdf_allgather_sum(blr_handle* h, int64_t count, const double* logpdf_local, double* logpdf_all, double* total) {
+  if (!h) return -1;
+  h->err.clear();
+  if (count < 0 || count > ((int64_t)1 << 30)) return bad_arg(h, 2, "count out of range");
+  if (count > 0 && !logpdf_local) return bad_arg(h, 3, "logpdf_local is NULL");
+  if (!logpdf_all) return bad_arg(h, 4, "logpdf_all is NULL");
+  if (!total) return bad_arg(h, 5, "total is NULL");
+  HIP_TRY(h, hipSetDevice(h->device));
+  const int64_t world = h->comm ? h->comm_size : 1;
+  if (h->comm) {
+    ncclResult_t r = rccl().AllGather(logpdf_local, logpdf_all, (size_t)count, ncclDouble, h->comm, h->stream);
+    if (r != ncclSuccess) return rccl_fail(h, r, "ncclAllGather");
+  } else if (count > 0 && logpdf_all != logpdf_local) {
+    HIP_TRY(h, hipMemcpyAsync(logpdf_all, logpdf_local, (size_t)count * sizeof(double), hipMemcpyDeviceToDevice, h->stream));
+  }
+  // the SAME fixed-order sum over the SAME gathered vector on every rank: identical bits for any rank count
+  hipLaunchKernelGGL(logpdf_sum_kernel, dim3(1), dim3(kThreads), 0, h->stream, (const double*)logpdf_all, count * world, total);
+  HIP_TRY(h, hipGetLastError());
+  if (!h->async) HIP_TRY(h, hipStreamSynchronize(h->stream));
+  return 0;
+}
+
+int blr_allreduce_sum(blr_handle* h, int is_f64, void* buf, int64_t count) {
+  if (!h) return -1;
+  h->err.clear();
+  if (!buf) return bad_arg(h, 3, "buf is NULL");
+  if (count < 0) return bad_arg(h, 4, "count < 0");
+  if (!h->comm || count == 0) return 0;  // one rank: the sum over ranks is the buffer itself
+  HIP_TRY(h, hipSetDevice(h->device));
+  ncclResult_t r = rccl().AllReduce(buf, buf, (size_t)count, is_f64 ? ncclDouble : ncclFloat, ncclSum, h->comm, h->stream);
+  if (r != ncclSuccess) return rccl_fail(h, r, "ncclAllReduce");
+  if (!h->async) HIP_TRY(h, hipStreamSynchronize(h->stream));
+  return 0;
+}
 
 int blr_logpdf_sum(blr_handle* h, int memspace, int64_t B, const double* logpdf, double* total) {
   if (!h) return -1;

@@ -292,6 +292,27 @@ int blr_rand_dense_noise_f32(blr_handle* h, int memspace, int layout, int64_t D,
  * (torch.distributed / MPI.jl); the data path has no other collective. */
 int blr_logpdf_sum(blr_handle* h, int memspace, int64_t B, const double* logpdf, double* total);
 
+/* ---- the exchange itself, RCCL called directly (SURVEY.md 8b contract, 8e) ---------------------------------------
+ * For hosts without a collective library of their own (a Julia session per GPU): one process per GPU, one handle per
+ * process.  Rank 0 obtains 128 opaque bytes with blr_comm_unique_id and ships them to the other ranks by any means (a file,
+ * Distributed.jl, MPI, a socket); every rank then calls blr_comm_init(h, nranks, rank, id) -- collective, like
+ * ncclCommInitRank.  librccl is loaded on first use (no link-time dependency; a single-GPU host never needs it).
+ *   blr_logpdf_allgather_sum   every rank passes its `count` per-regressor log evidences (device); logpdf_all (device,
+ *                              nranks * count doubles, rank order == regressor order) receives the all-gather and *total
+ *                              (device) the fixed-order sum of it -- the same bits on every rank and for every rank count.
+ *                              Without a communicator (nranks = 1) it degenerates to copy + blr_logpdf_sum.
+ *   blr_allreduce_sum          in-place sum over ranks of a device buffer (the `stats` / `scal` exchange of the N-sharded
+ *                              single regressor below: is_f64 = 0 for float, 1 for double)
+ * Errors: -(2000 + ncclResult_t); -2001 when librccl cannot be loaded; text via blr_last_error. */
+#define BLR_UNIQUE_ID_BYTES 128
+int blr_comm_unique_id(void* id128);
+int blr_comm_init(blr_handle* h, int nranks, int rank, const void* id128);
+int blr_comm_destroy(blr_handle* h);
+int blr_comm_size(blr_handle* h);
+int blr_comm_rank(blr_handle* h);
+int blr_logpdf_allgather_sum(blr_handle* h, int64_t count, const double* logpdf_local, double* logpdf_all, double* total);
+int blr_allreduce_sum(blr_handle* h, int is_f64, void* buf, int64_t count);
+
 #ifdef __cplusplus
 }
 #endif

@@ -231,4 +231,18 @@ def test_julia_shim_ccall_signatures_match_the_header(repo_root):
             got = "ptr" if t.startswith(("Ptr", "Ref", "Cstring")) else ("fp" if t in ("T", "Cdouble", "Cfloat", "Float64", "Float32") else "int")
             assert got == kind, f"{name}: argument {pos + 1} is {t} in the shim but {kind} in the header"
         seen += 1
-    assert seen >= 12
+    assert seen >= 34  # every entry point a Julia host needs, incl. dense noise, cov, batched device form and the RCCL exchange
+
+
+def test_comm_entry_points_validate_without_a_gpu():
+    """blr_comm_* / blr_logpdf_allgather_sum (RCCL called directly): argument checks need no device."""
+    from blr_amd import _abi
+
+    lib = _abi.load_library()
+    assert lib.blr_comm_init(None, 2, 0, None) == -1
+    assert lib.blr_comm_size(None) == -1 and lib.blr_comm_rank(None) == -1
+    assert lib.blr_comm_destroy(None) == -1
+    assert lib.blr_logpdf_allgather_sum(None, 4, None, None, None) == -1
+    assert lib.blr_allreduce_sum(None, 1, None, 4) == -1
+    assert lib.blr_comm_unique_id(None) == -1
+

@@ -371,10 +371,13 @@ def test_error_paths(B):
     assert ei.value.info == 4
     with pytest.raises(B.PosDefException):
         B.var(B.BayesianLinearRegressor(mw, -Lw)(X, s))
-    with pytest.raises(NotImplementedError):  # dense Sigma_y is rejected, not silently computed elsewhere
-        B.logpdf(f(X, np.eye(N)), np.zeros(N))
-    with pytest.raises(NotImplementedError):
-        B.cov(f(X, s))
+    # dense Sigma_y and cov(fx) run on the device since round 2 (blr_posterior_dense_noise_*, blr_mean_and_cov_*)
+    assert B.logpdf(f(X, np.eye(N)), np.zeros(N)) == pytest.approx(O.logpdf_literal(mw, Lw, X, np.eye(N), np.zeros(N)), rel=1e-11)
+    np.testing.assert_allclose(B.cov(f(X, s)), O.cov(mw, Lw, X, s), rtol=1e-10, atol=1e-12)
+    with pytest.raises(ValueError):  # a noise covariance of the wrong size
+        B.logpdf(f(X, np.eye(N + 1)), np.zeros(N))
+    with pytest.raises(NotImplementedError):  # the closed-form gradient covers isotropic / Diagonal noise only
+        B.logpdf_and_gradient(f(X, np.eye(N)), np.zeros(N))
 
 
 def test_abi_argument_errors(B):
@@ -1303,4 +1306,45 @@ def test_dense_noise_moderate_sizes(B, dtype, N, D):
         assert lp == pytest.approx(lp_o, rel=2e-4)
         assert np.linalg.norm(fp.mw - mw_o) <= 2e-4 * np.linalg.norm(mw_o)
         assert np.max(np.abs(fp.Lw.toarray() - A_o)) <= 1e-4 * np.max(np.abs(A_o))
+
+
+# ---- the exchange through RCCL called directly from the C ABI (blr_comm_*, blr_logpdf_allgather_sum) --------------------
+def test_rccl_direct_single_rank(B):
+    import torch
+    from blr_amd import _abi
+
+    dev = torch.device("cuda:0")
+    h = _abi.Handle(0)
+    try:
+        assert h.comm_size() == 1 and h.comm_rank() == 0  # no communicator yet
+        lp = torch.randn(1000, dtype=torch.float64, device=dev)
+        allv = torch.zeros(1000, dtype=torch.float64, device=dev)
+        tot = torch.zeros(1, dtype=torch.float64, device=dev)
+        ref = torch.zeros(1, dtype=torch.float64, device=dev)
+        torch.cuda.synchronize()
+        h.logpdf_allgather_sum(1000, lp.data_ptr(), allv.data_ptr(), tot.data_ptr())  # degenerate form: copy + fixed-order sum
+        h.logpdf_sum(_abi.MEM_DEVICE, 1000, lp.data_ptr(), ref.data_ptr())
+        h.synchronize()
+        assert torch.equal(allv, lp) and tot.item() == ref.item()
+        # a real communicator of one rank: ncclCommInitRank / ncclAllGather / ncclAllReduce run on the handle's stream
+        uid = _abi.Handle.comm_unique_id()
+        assert len(uid) == 128
+        h.comm_init(1, 0, uid)
+        assert h.comm_size() == 1 and h.comm_rank() == 0
+        allv.zero_(); tot.zero_()
+        torch.cuda.synchronize()
+        h.logpdf_allgather_sum(1000, lp.data_ptr(), allv.data_ptr(), tot.data_ptr())
+        h.synchronize()
+        assert torch.equal(allv, lp) and tot.item() == ref.item()  # bit-identical to the local fixed-order sum
+        st = torch.arange(64, dtype=torch.float32, device=dev)
+        torch.cuda.synchronize()
+        h.allreduce_sum(False, st.data_ptr(), 64)
+        h.synchronize()
+        assert torch.equal(st, torch.arange(64, dtype=torch.float32, device=dev))
+        with pytest.raises(_abi.BLRError):
+            h.comm_init(1, 0, uid)  # already has a communicator
+        h.comm_destroy()
+        assert h.comm_size() == 1
+    finally:
+        h.close()
 
