@@ -9,7 +9,7 @@ import os
 import shutil
 import sys
 
-tag = sys.argv[1] if len(sys.argv) > 1 else "r01"
+tag = sys.argv[1] if len(sys.argv) > 1 else "r02"
 RAW = "gpurun_out/profiles_raw"
 DST = "profiles"
 os.makedirs(DST, exist_ok=True)
@@ -20,11 +20,11 @@ def one(pattern):
     return g[0] if g else None
 
 
-for name in ("bench_c2_f64", "bench_c2_f32", "bench_c3_f32", "bench_c5shape_f32", "bench_c4shape_f64"):
+for name in ("bench_c2_f64", "bench_c2_f32", "bench_c3_f32", "bench_c5_f32", "bench_c4_f64"):
     src = os.path.join(RAW, name + ".json")
     if os.path.exists(src) and os.path.getsize(src):
         shutil.copy(src, os.path.join(DST, f"{tag}_{name}.json"))
-for cfg in ("c2", "c3", "c5"):
+for cfg in ("c2", "c3", "c5", "c4"):
     f = one(f"{RAW}/stats_{cfg}/*/*_kernel_stats.csv")
     if f:
         shutil.copy(f, os.path.join(DST, f"{tag}_{cfg}_kernel_stats.csv"))
@@ -65,7 +65,16 @@ if fetch and write:
     summary["c2_fused_small_kernel_hbm"] = {"FETCH_SIZE_KiB": fetch["FETCH_SIZE"], "WRITE_SIZE_KiB": write["WRITE_SIZE"],
                                             "hbm_read_bytes_per_launch": rd, "hbm_write_bytes_per_launch": wr,
                                             "hbm_bytes_per_launch": rd + wr, "units_per_launch": 4096}
-for key, c in (("c2_fused_small_kernel_sq", sq2), ("c3_gram_tile_kernel_sq", sq3)):
+sq2f = counters("pmc_sq_c2f32", "fused_small_kernel")
+f4 = counters("pmc_fetch_c4", "fused_small_kernel")
+w4 = counters("pmc_write_c4", "fused_small_kernel")
+if f4 and w4:
+    rd = f4["FETCH_SIZE"] * 1024.0 * 2.0
+    wr = w4["WRITE_SIZE"] * 1024.0
+    summary["c4_fused_small_kernel_hbm"] = {"FETCH_SIZE_KiB": f4["FETCH_SIZE"], "WRITE_SIZE_KiB": w4["WRITE_SIZE"],
+                                            "hbm_read_bytes_per_launch": rd, "hbm_write_bytes_per_launch": wr,
+                                            "hbm_bytes_per_launch": rd + wr, "units_per_launch": 8192}
+for key, c in (("c2_fused_small_kernel_sq", sq2), ("c2_f32_fused_small_kernel_sq", sq2f), ("c3_gram_tile_kernel_sq", sq3)):
     if c:
         ns = c["avg_duration_ns"]
         c["effective_clock_GHz"] = c["GRBM_GUI_ACTIVE"] / 8.0 / ns
