@@ -42,6 +42,11 @@ struct blr_handle {
   // RCCL communicator of blr_comm_init (one rank per handle / GPU); NULL until then
   ncclComm_t comm = nullptr;
   int comm_size = 0, comm_rank = 0;
+  // pipelined large-D update: the Gram block columns are built on s_gram[] while the factorisation follows on s_chain
+  hipStream_t s_chain = nullptr, s_reduce = nullptr, s_gram[2] = {nullptr, nullptr};
+  bool partitioned = false;  // CU masks in force: 32 CUs chain / 224 CUs Gram
+  hipEvent_t ev_fork = nullptr, ev_join = nullptr;
+  std::vector<hipEvent_t> ev_col;
 };
 
 namespace {
@@ -293,6 +298,63 @@ int chol_large(blr_handle* h, T* M, int64_t ld, int DP, int nrows_total, int32_t
   return 0;
 }
 
+// side streams of the pipelined large-D update (created on first use; the chain stream gets the highest priority the
+// device offers so that its few, latency-critical workgroups are dispatched ahead of the Gram launches' backlog)
+int pipeline_streams(blr_handle* h, int ncols) {
+  if (!h->s_chain) {
+    // The chain's kernels are one or a few workgroups each and latency-bound; co-resident with two Gram workgroups they run
+    // 2x slower (measured: chol_diag 33 -> 70 us).  So the chip is PARTITIONED with CU masks: one CU of every shader engine
+    // of every XCD (32 in all) belongs to the chain stream, the other 224 to the Gram streams.  Measured with
+    // tools/cumask_probe.hip on MI355X: mask bit i lands in XCD i % 8, and within the XCD bit i / 8 lands in shader engine
+    // (i / 8) % 4 -- so bits 224..255 are one CU per (XCD, SE).  A partition that is NOT balanced over the shader engines
+    // (e.g. 4 CUs of one SE) halves the throughput of the other side: the dispatcher deals workgroups evenly to the SEs.
+    static const bool no_mask = getenv("BLR_MI355X_NO_CUMASK") != nullptr;
+    hipDeviceProp_t prop;
+    HIP_TRY(h, hipGetDeviceProperties(&prop, h->device));
+    bool masked = false;
+    if (!no_mask && prop.multiProcessorCount == 256) {
+      uint32_t chain_mask[8], gram_mask[8];
+      for (int w = 0; w < 8; ++w) chain_mask[w] = 0;
+      for (int i = 0; i < 256; ++i)
+        if (i >= 224) chain_mask[i / 32] |= 1u << (i % 32);
+      for (int w = 0; w < 8; ++w) gram_mask[w] = ~chain_mask[w];
+      masked = hipExtStreamCreateWithCUMask(&h->s_chain, 8, chain_mask) == hipSuccess;
+      for (hipStream_t& g : h->s_gram) masked = masked && hipExtStreamCreateWithCUMask(&g, 8, gram_mask) == hipSuccess;
+      masked = masked && hipExtStreamCreateWithCUMask(&h->s_reduce, 8, chain_mask) == hipSuccess;
+      if (!masked) {
+        (void)hipGetLastError();
+        if (h->s_chain) (void)hipStreamDestroy(h->s_chain);
+  if (h->s_reduce) (void)hipStreamDestroy(h->s_reduce);
+        for (hipStream_t& g : h->s_gram) { if (g) (void)hipStreamDestroy(g); g = nullptr; }
+        if (h->s_reduce) (void)hipStreamDestroy(h->s_reduce);
+        h->s_chain = h->s_reduce = nullptr;
+      }
+    }
+    if (!masked) {
+      int least = 0, greatest = 0;
+      HIP_TRY(h, hipDeviceGetStreamPriorityRange(&least, &greatest));
+      HIP_TRY(h, hipStreamCreateWithPriority(&h->s_chain, hipStreamNonBlocking, greatest));
+      HIP_TRY(h, hipStreamCreateWithPriority(&h->s_reduce, hipStreamNonBlocking, greatest));
+      for (hipStream_t& g : h->s_gram) HIP_TRY(h, hipStreamCreateWithPriority(&g, hipStreamNonBlocking, least));
+    }
+    h->partitioned = masked;
+    HIP_TRY(h, hipEventCreateWithFlags(&h->ev_fork, hipEventDisableTiming));
+    HIP_TRY(h, hipEventCreateWithFlags(&h->ev_join, hipEventDisableTiming));
+  }
+  while ((int)h->ev_col.size() < 2 * ncols) {  // [2J]: Gram tiles of column J written, [2J + 1]: column J reduced into Abar
+    hipEvent_t e = nullptr;
+    HIP_TRY(h, hipEventCreateWithFlags(&e, hipEventDisableTiming));
+    h->ev_col.push_back(e);
+  }
+  return 0;
+}
+
+struct StreamSwap {  // run helpers that launch on h->stream on another stream for a scope
+  blr_handle* h; hipStream_t saved;
+  StreamSwap(blr_handle* hh, hipStream_t s) : h(hh), saved(hh->stream) { hh->stream = s; }
+  ~StreamSwap() { h->stream = saved; }
+};
+
 template <typename T>
 int posterior_large_one(blr_handle* h, const PosteriorArgs<T>& a, int64_t reg) {
   using LC = LargeCfg<T>;
@@ -303,7 +365,8 @@ int posterior_large_one(blr_handle* h, const PosteriorArgs<T>& a, int64_t reg) {
   const int nstage_cols = LC::NSC;
   // split-K factor: fill the 2 x 256 workgroup slots of the chip in whole rounds (576 workgroups on 512 slots
   // would take two rounds for 1.125 rounds of work)
-  const int max_split = std::max(1, std::min(64, (N + nstage_cols - 1) / nstage_cols));
+  const int max_split_cols = std::max(1, (N + nstage_cols - 1) / nstage_cols);
+  const int max_split = std::min(64, max_split_cols);
   int nsplit = 1;
   double best = 0.0;
   for (int sp = 1; sp <= max_split; ++sp) {
@@ -313,16 +376,46 @@ int posterior_large_one(blr_handle* h, const PosteriorArgs<T>& a, int64_t reg) {
     if (eff > best) { best = eff; nsplit = sp; }
   }
   const bool prior_factor = a.prior_kind == PRIOR_UPPER_FACTOR;
-  const int nsplit_total = nsplit + (prior_factor ? 1 : 0);
+  const int pf = prior_factor ? 1 : 0;
+  const int nsplit_total = nsplit + pf;
   const int gridc = 1024;
+
+  // Pipelined schedule (EXPERIMENT, off unless BLR_MI355X_PIPELINE is set): the Gram matrix is built block column by block
+  // column on two side streams while a left-looking blocked Cholesky follows on a third, so that the ~60 us / panel chain
+  // of small kernels runs in the shadow of the Gram launches.  Measured on MI355X ("pipelined large-D update"):
+  // c3 1.87 ms against 1.30 ms serial -- per-column launches keep only ~87 % of the slots busy, every cross-stream event
+  // costs ~30 us, and the chain's kernels need their own CUs (CU masks: -12.5 % Gram capacity) or run 2x slower when
+  // co-resident with Gram workgroups.  Kept for the next step (one column-ordered Gram launch + in-kernel column flags).
+  static const bool want_pipeline = getenv("BLR_MI355X_PIPELINE") != nullptr;
+  const bool pipelined = NC >= 2 && want_pipeline;
+  static const int kColWgs = getenv("BLR_MI355X_COL_WGS") ? atoi(getenv("BLR_MI355X_COL_WGS")) : 224;
+  std::vector<int> col_split(NC, 0);
+  std::vector<int64_t> col_gp(NC + 1, 0);  // first partial tile of each column's Gpart region
+  int max_split_total = nsplit_total;
+  size_t upart_elems = 0;
+  if (pipelined) {
+    max_split_total = 0;
+    for (int J = 0; J < NC; ++J) {
+      const int tiles = NC - J;
+      // every block column = one launch of <= 256 workgroups: two of them (one per Gram stream) fill the 512 slots of the
+      // chip in a single round (a 257th workgroup would run in a second round and double the launch's duration)
+      col_split[J] = std::max(1, std::min(std::min(max_split_cols, 64), kColWgs / std::min(tiles, kColWgs)));
+      col_gp[J + 1] = col_gp[J] + (int64_t)(col_split[J] + pf) * tiles;
+      max_split_total = std::max(max_split_total, col_split[J] + pf);
+      const int nr = (DP + 64 - J * kPB) / 64;
+      upart_elems = std::max(upart_elems, (size_t)J * (2 * nr - 1) * 64 * 64);
+    }
+  }
+  const int64_t gp_tiles = pipelined ? col_gp[NC] : (int64_t)nsplit_total * ntiles;
 
   // workspace carve
   size_t off = 0;
   auto carve = [&](size_t bytes) { size_t o = off; off = (off + bytes + 255) & ~(size_t)255; return o; };
   const size_t o_abar = carve((size_t)lda * DP * sizeof(T));
   const size_t o_w = carve(a.prior_kind == PRIOR_DENSE ? (size_t)DP * DP * sizeof(T) : 0);
-  const size_t o_gp = carve((size_t)nsplit_total * ntiles * kPB * kPB * sizeof(T));
-  const size_t o_bp = carve((size_t)nsplit_total * NC * kPB * sizeof(double));
+  const size_t o_gp = carve((size_t)gp_tiles * kPB * kPB * sizeof(T));
+  const size_t o_up = carve(upart_elems * sizeof(T));
+  const size_t o_bp = carve((size_t)max_split_total * NC * kPB * sizeof(double));
   const size_t o_r = carve((size_t)std::max(N, 1) * sizeof(T));
   const size_t o_q = carve((size_t)gridc * sizeof(double));
   const size_t o_l = carve((size_t)gridc * sizeof(double));
@@ -352,7 +445,7 @@ int posterior_large_one(blr_handle* h, const PosteriorArgs<T>& a, int64_t reg) {
 
   HIP_TRY(h, hipMemsetAsync(ws + o_sc, 0, 64, h->stream));
   HIP_TRY(h, hipMemsetAsync(info_noise, 0xFF, sizeof(unsigned), h->stream));
-  HIP_TRY(h, hipMemsetAsync(bpart, 0, (size_t)nsplit_total * NC * kPB * sizeof(double), h->stream));
+  HIP_TRY(h, hipMemsetAsync(bpart, 0, (size_t)max_split_total * NC * kPB * sizeof(double), h->stream));
 
   // ---- prior: SPD check + logdet (reference :78)
   if (a.prior_kind == PRIOR_DENSE) {
@@ -376,40 +469,94 @@ int posterior_large_one(blr_handle* h, const PosteriorArgs<T>& a, int64_t reg) {
 
   // ---- Gram (reference :86) : split-K partial tiles, then the prior factor as pseudo-observations
   if ((rc = set_lds<T>(h, reinterpret_cast<const void*>(gram_tile_kernel<T>), LC::LDS_BYTES))) return rc;
-  {
-    GramTileArgs<T> g{};
-    g.X = X; g.ldx = a.ldx; g.layout = a.layout;
-    g.use_dma = (a.layout == LAYOUT_COLVECS && ((uintptr_t)X % 16 == 0) && ((a.ldx * (int64_t)sizeof(T)) % 16 == 0)) ? 1 : 0;
-    g.s = s; g.noise_kind = a.noise_kind; g.r = rvec;
-    g.D = D; g.n_begin = 0; g.n_end = N; g.nsplit = nsplit;
-    g.tile_i0 = 0; g.tile_j0 = 0; g.tri = 1; g.ntiles = ntiles; g.nblocks = NC;
-    g.Gpart = Gpart; g.bpart = bpart; g.mode_out = 0;
-    g.xcd_swizzle = (nsplit > 1 && !getenv("BLR_MI355X_NO_XCD_SWIZZLE")) ? 1 : 0;
-    hipLaunchKernelGGL(gram_tile_kernel<T>, dim3(ntiles * nsplit), dim3(kThreads), LC::LDS_BYTES, h->stream, g);
+  // a failed prior factorisation short-circuits everything: seed info_chol with it
+  HIP_TRY(h, hipMemcpyAsync(info_chol, info_prior, sizeof(int32_t), hipMemcpyDeviceToDevice, h->stream));
+  GramTileArgs<T> g{};
+  g.X = X; g.ldx = a.ldx; g.layout = a.layout;
+  g.use_dma = (a.layout == LAYOUT_COLVECS && ((uintptr_t)X % 16 == 0) && ((a.ldx * (int64_t)sizeof(T)) % 16 == 0)) ? 1 : 0;
+  g.s = s; g.noise_kind = a.noise_kind; g.r = rvec;
+  g.D = D; g.n_begin = 0; g.n_end = N; g.nblocks = NC; g.bpart = bpart; g.mode_out = 0;
+  static const bool no_swizzle = getenv("BLR_MI355X_NO_XCD_SWIZZLE") != nullptr;
+  ReduceArgs<T> r{};
+  r.bpart = bpart; r.nblocks = NC;
+  r.Lw = Lw; r.ldl = a.ldl; r.prior_kind = a.prior_kind; r.D = D; r.DP = DP; r.Abar = Abar; r.lda = lda;
+  r.Lw_post = a.Lw_post ? a.Lw_post + reg * a.strideLp : nullptr; r.ldlp = a.ldlp;
+  // launches the tiles described by g (+ the prior-factor pseudo split) and their reduction on `st`
+  auto gram_tiles = [&](hipStream_t st, int nsp, int nt, T* gp) {
+    g.nsplit = nsp; g.ntiles = nt; g.Gpart = gp;
+    g.xcd_swizzle = (nsp > 1 && !no_swizzle) ? 1 : 0;
+    hipLaunchKernelGGL(gram_tile_kernel<T>, dim3(nt * nsp), dim3(kThreads), LC::LDS_BYTES, st, g);
     if (prior_factor) {
       GramTileArgs<T> u = g;
       u.xcd_swizzle = 0;
       u.X = Lw; u.ldx = a.ldl; u.layout = 2; u.use_dma = 0; u.s = nullptr; u.r = nullptr;
       u.n_begin = 0; u.n_end = D; u.nsplit = 1;
-      u.Gpart = Gpart + (int64_t)nsplit * ntiles * kPB * kPB;
-      u.bpart = bpart + (int64_t)nsplit * NC * kPB;
-      hipLaunchKernelGGL(gram_tile_kernel<T>, dim3(ntiles), dim3(kThreads), LC::LDS_BYTES, h->stream, u);
+      u.Gpart = gp + (int64_t)nsp * nt * kPB * kPB;
+      u.bpart = bpart + (int64_t)nsp * NC * kPB;
+      hipLaunchKernelGGL(gram_tile_kernel<T>, dim3(nt), dim3(kThreads), LC::LDS_BYTES, st, u);
     }
-  }
-  {
-    ReduceArgs<T> r{};
-    r.Gpart = Gpart; r.bpart = bpart; r.nsplit_total = nsplit_total; r.ntiles = ntiles; r.nblocks = NC;
-    r.Lw = Lw; r.ldl = a.ldl; r.prior_kind = a.prior_kind; r.D = D; r.DP = DP; r.Abar = Abar; r.lda = lda;
-    r.Lw_post = a.Lw_post ? a.Lw_post + reg * a.strideLp : nullptr; r.ldlp = a.ldlp;
-    hipLaunchKernelGGL(gram_reduce_kernel<T>, dim3(ntiles + NC, 16), dim3(kThreads), 0, h->stream, r);
-  }
+  };
+  auto gram_reduce = [&](hipStream_t st, int nsp, int nt, T* gp, int reduce_blocks) {
+    r.Gpart = gp; r.nsplit_total = nsp + pf; r.ntiles = nt;
+    hipLaunchKernelGGL(gram_reduce_kernel<T>, dim3(nt + reduce_blocks, 16), dim3(kThreads), 0, st, r);
+  };
 
-  // ---- blocked Cholesky of Abar (rows DP.. = rhs) -> L, u  (reference :86, :57)
-  // a failed prior factorisation short-circuits everything: seed info_chol with it
-  HIP_TRY(h, hipMemcpyAsync(info_chol, info_prior, sizeof(int32_t), hipMemcpyDeviceToDevice, h->stream));
-  if ((rc = chol_large<T>(h, Abar, lda, DP, DP + kPB, info_chol))) return rc;
+  if (!pipelined) {
+    g.tile_i0 = 0; g.tile_j0 = 0; g.tri = 1;
+    r.col_mode = 0;
+    gram_tiles(h->stream, nsplit, ntiles, Gpart);
+    gram_reduce(h->stream, nsplit, ntiles, Gpart, NC);
+    // ---- blocked Cholesky of Abar (rows DP.. = rhs) -> L, u  (reference :86, :57)
+    if ((rc = chol_large<T>(h, Abar, lda, DP, DP + kPB, info_chol))) return rc;
+  } else {
+    using SC = SmallCfg<T, 8>;
+    using TC = TrsmCfg<T>;
+    using acc4 = typename Mfma<T>::acc4;
+    if ((rc = pipeline_streams(h, NC))) return rc;
+    if ((rc = set_lds<T>(h, reinterpret_cast<const void*>(chol_diag_kernel<T>), SC::LDS_BYTES))) return rc;
+    if ((rc = set_lds<T>(h, reinterpret_cast<const void*>(trsm_block_kernel<T>), TC::LDS_BYTES))) return rc;
+    if ((rc = set_lds<T>(h, reinterpret_cast<const void*>(left_update_kernel<T>), TrailCfg<T>::LDS_BYTES))) return rc;
+    HIP_TRY(h, hipEventRecord(h->ev_fork, h->stream));
+    HIP_TRY(h, hipStreamWaitEvent(h->s_chain, h->ev_fork, 0));
+    for (hipStream_t gs : h->s_gram) HIP_TRY(h, hipStreamWaitEvent(gs, h->ev_fork, 0));
+    HIP_TRY(h, hipStreamWaitEvent(h->s_reduce, h->ev_fork, 0));
+    // Gram block columns, alternating between the two Gram streams (two launches in flight fill the 512 workgroup slots)
+    for (int J = 0; J < NC; ++J) {
+      hipStream_t gs = h->s_gram[((J & 3) == 0 || (J & 3) == 3) ? 0 : 1];  // 8+5+4+1 = 7+6+3+2 tiles: balanced streams
+      g.tile_i0 = J; g.tile_j0 = J; g.tri = 0;
+      r.col_mode = 1; r.tile_i0 = J; r.tile_j0 = J;
+      T* gp = Gpart + col_gp[J] * (kPB * kPB);
+      gram_tiles(gs, col_split[J], NC - J, gp);
+      HIP_TRY(h, hipEventRecord(h->ev_col[2 * J], gs));
+      // the split reduction runs on its own stream: the Gram streams go straight on to their next column
+      HIP_TRY(h, hipStreamWaitEvent(h->s_reduce, h->ev_col[2 * J], 0));
+      gram_reduce(h->s_reduce, col_split[J], NC - J, gp, 1);
+      HIP_TRY(h, hipEventRecord(h->ev_col[2 * J + 1], h->s_reduce));
+    }
+    // left-looking blocked Cholesky (reference :86, :57), one block column behind the Gram streams at the earliest
+    acc4* Upart = reinterpret_cast<acc4*>(ws + o_up);
+    const int nrows_total = DP + kPB;
+    for (int p = 0; p < NC; ++p) {
+      HIP_TRY(h, hipStreamWaitEvent(h->s_chain, h->ev_col[2 * p + 1], 0));
+      if (p > 0) {
+        const int nsub = 2 * ((DP + 64 - p * kPB) / 64) - 1;
+        hipLaunchKernelGGL(left_update_kernel<T>, dim3(nsub, p), dim3(kThreads), TrailCfg<T>::LDS_BYTES, h->s_chain, (const T*)Abar, lda, p,
+                           Upart, (const int32_t*)info_chol);
+        hipLaunchKernelGGL(left_reduce_kernel<T>, dim3(nsub), dim3(kThreads), 0, h->s_chain, Abar, lda, p, p, (const acc4*)Upart,
+                           (const int32_t*)info_chol);
+      }
+      hipLaunchKernelGGL(chol_diag_kernel<T>, dim3(1), dim3(kThreads), SC::LDS_BYTES, h->s_chain, Abar, lda, p, info_chol, 0);
+      const int row_begin = (p + 1) * kPB;
+      const int nblk = (nrows_total - row_begin + TC::RB - 1) / TC::RB;
+      hipLaunchKernelGGL(trsm_block_kernel<T>, dim3(nblk), dim3(kThreads), TC::LDS_BYTES, h->s_chain, Abar, lda, p, row_begin,
+                         nrows_total, (const int32_t*)info_chol, RowSqArgs<T>{});
+    }
+    HIP_TRY(h, hipGetLastError());
+  }
 
   // ---- T = L' (for the caller and for the AXPY-form back substitution), then m, posterior mean, evidence
+  {
+    StreamSwap on_chain(h, pipelined ? h->s_chain : h->stream);
   {
     dim3 grid((DP + 31) / 32, (DP + 31) / 32);
     hipLaunchKernelGGL(transpose_out_kernel<T>, grid, dim3(kThreads), 0, h->stream, (const T*)Abar, lda, DP, Tfull,
@@ -425,6 +572,11 @@ int posterior_large_one(blr_handle* h, const PosteriorArgs<T>& a, int64_t reg) {
     b.logpdf = a.logpdf ? a.logpdf + reg : nullptr; b.info = a.info + reg; b.chol_info = info_chol;
     b.prior_info = info_prior; b.noise_info = info_noise;
     if ((rc = launch_wave_solve<T>(h, b, NC, 1))) return rc;
+  }
+  }
+  if (pipelined) {
+    HIP_TRY(h, hipEventRecord(h->ev_join, h->s_chain));
+    HIP_TRY(h, hipStreamWaitEvent(h->stream, h->ev_join, 0));
   }
   HIP_TRY(h, hipGetLastError());
   return 0;
@@ -2016,6 +2168,12 @@ int blr_destroy(blr_handle* h) {
   if (h->ticket) (void)hipFree(h->ticket);
   if (h->ev0) (void)hipEventDestroy(h->ev0);
   if (h->ev1) (void)hipEventDestroy(h->ev1);
+  if (h->s_chain) (void)hipStreamDestroy(h->s_chain);
+  if (h->s_reduce) (void)hipStreamDestroy(h->s_reduce);
+  for (hipStream_t g : h->s_gram) if (g) (void)hipStreamDestroy(g);
+  if (h->ev_fork) (void)hipEventDestroy(h->ev_fork);
+  if (h->ev_join) (void)hipEventDestroy(h->ev_join);
+  for (hipEvent_t e : h->ev_col) (void)hipEventDestroy(e);
   if (h->own_stream) (void)hipStreamDestroy(h->own_stream);
   delete h;
   return 0;

@@ -405,6 +405,8 @@ struct ReduceArgs {
   int D, DP;
   T* Abar; int64_t lda;      // (DP + 128) x DP
   T* Lw_post; int64_t ldlp;  // optional full symmetric copy of A (D x D)
+  int col_mode, tile_i0, tile_j0;  // col_mode 1 (pipelined path): tiles (tile_i0 + t, tile_j0), t < ntiles, Gpart local to the column;
+                                   // blockIdx.x == ntiles: the rhs row of block tile_j0
 };
 
 template <typename T>
@@ -414,29 +416,54 @@ __global__ __launch_bounds__(kThreads) void gram_reduce_kernel(ReduceArgs<T> a) 
   constexpr int kChunk = kPB * kPB / 16;  // gridDim.y = 16 chunks per tile
   const int e_begin = blockIdx.y * kChunk, e_end = e_begin + kChunk;
   if (t < a.ntiles) {
-    int ii = 0;
-    while ((ii + 1) * (ii + 2) / 2 <= t) ++ii;
-    const int I = ii, J = t - ii * (ii + 1) / 2;
-    for (int e = e_begin + tid; e < e_end; e += kThreads) {
+    int I, J;
+    if (a.col_mode) {
+      I = a.tile_i0 + t; J = a.tile_j0;
+    } else {
+      int ii = 0;
+      while ((ii + 1) * (ii + 2) / 2 <= t) ++ii;
+      I = ii; J = t - ii * (ii + 1) / 2;
+    }
+    // one 16-byte vector of 4 (f32) / 2 (f64) consecutive rows per thread and pass; the partials of 8 splits are requested
+    // before the first is used (one load per split and a dependent add behind it made this kernel a ~50 us latency chain)
+    constexpr int VEC = Mfma<T>::VEC;
+    typedef T vecT __attribute__((ext_vector_type(Mfma<T>::VEC)));
+    const int64_t sstride = (int64_t)a.ntiles * (kPB * kPB);
+    for (int e = e_begin + tid * VEC; e < e_end; e += kThreads * VEC) {
       const int rl = e % kPB, cl = e / kPB;  // column-major tiles: consecutive threads -> consecutive rows
-      const int row = I * kPB + rl, col = J * kPB + cl;
-      if (col > row) continue;
-      T sum = T(0);
-      for (int sp = 0; sp < a.nsplit_total; ++sp) sum += a.Gpart[((int64_t)sp * a.ntiles + t) * (kPB * kPB) + e];  // fixed order
-      if (row < a.D) {
-        if (a.prior_kind == PRIOR_DENSE) sum += a.Lw[(int64_t)row * a.ldl + col];  // upper entry (col, row)
-        else if (a.prior_kind == PRIOR_DIAGONAL && row == col) sum += a.Lw[row];
-      } else {
-        sum = (row == col) ? T(1) : T(0);  // padding: unit diagonal
+      const int row0 = I * kPB + rl, col = J * kPB + cl;
+      if (col > row0 + VEC - 1) continue;
+      const T* src = a.Gpart + (int64_t)t * (kPB * kPB) + e;
+      vecT sum = vecT(T(0));
+      int sp = 0;
+      for (; sp + 8 <= a.nsplit_total; sp += 8) {
+        vecT v[8];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) v[u] = *reinterpret_cast<const vecT*>(src + (sp + u) * sstride);
+#pragma unroll
+        for (int u = 0; u < 8; ++u) sum += v[u];  // fixed order
       }
-      a.Abar[(int64_t)col * a.lda + row] = sum;
-      if (a.Lw_post && row < a.D) {
-        a.Lw_post[(int64_t)col * a.ldlp + row] = sum;
-        a.Lw_post[(int64_t)row * a.ldlp + col] = sum;
+      for (; sp < a.nsplit_total; ++sp) sum += *reinterpret_cast<const vecT*>(src + sp * sstride);
+#pragma unroll
+      for (int q = 0; q < VEC; ++q) {
+        const int row = row0 + q;
+        if (col > row) continue;
+        T val = sum[q];
+        if (row < a.D) {
+          if (a.prior_kind == PRIOR_DENSE) val += a.Lw[(int64_t)row * a.ldl + col];  // upper entry (col, row)
+          else if (a.prior_kind == PRIOR_DIAGONAL && row == col) val += a.Lw[row];
+        } else {
+          val = (row == col) ? T(1) : T(0);  // padding: unit diagonal
+        }
+        a.Abar[(int64_t)col * a.lda + row] = val;
+        if (a.Lw_post && row < a.D) {
+          a.Lw_post[(int64_t)col * a.ldlp + row] = val;
+          a.Lw_post[(int64_t)row * a.ldlp + col] = val;
+        }
       }
     }
   } else {
-    const int I = t - a.ntiles;
+    const int I = a.col_mode ? a.tile_j0 : t - a.ntiles;
     for (int e = e_begin + tid; e < e_end; e += kThreads) {  // rhs row block: row 0 = b', the rest zero
       const int rl = e % kPB, cl = e / kPB;
       const int col = I * kPB + cl;
@@ -543,6 +570,7 @@ __device__ __forceinline__ void load_upper_block_to_packed(T* __restrict__ P, co
 // kernel (measured: 475 k -> 351 k updates/s at D=128, N=4096).
 template <typename T>
 __global__ __launch_bounds__(kThreads, (sizeof(T) == 4 ? BLR_F32_WAVES_PER_SIMD : 2)) void chol_diag_kernel(T* Abar, int64_t lda, int p, int32_t* info, int info_base) {
+  __builtin_amdgcn_s_setprio(3);  // latency-critical chain kernel: issue ahead of co-resident Gram waves
   extern __shared__ __attribute__((aligned(16))) char smem[];
   T* const P = reinterpret_cast<T*>(smem);
   const int tid = threadIdx.x;
@@ -674,10 +702,137 @@ __global__ __launch_bounds__(kThreads) void trail_update_kernel(T* M, int64_t ld
     }
 }
 
+// ---- left-looking update of ONE block column (pipelined large-D path) ---------------------------------------------------
+// The right-looking sweep above cannot start before the WHOLE Gram matrix exists.  The pipelined path (blr_abi.hip,
+// posterior_large_one) builds the Gram matrix block column by block column on its own streams and lets the factorisation
+// follow it: block column p needs only ITS Gram tiles plus the finished panels k < p,
+//     A[rows >= 128p, cols of block p]  -=  sum_{k<p}  L[rows, panel k] L[block p, panel k]'.
+// One workgroup = one 64 x 64 sub-tile x ONE panel k (every load in flight at once, as trail_update_kernel); the p partial
+// products of a sub-tile are summed in FIXED order by left_reduce_kernel (bitwise run-to-run reproducible).
+// Sub-tiles of the column: idx 0 -> (r, c) = (0, 0); idx >= 1 -> r = (idx + 1) / 2, c = (idx + 1) % 2  (the block (0, 1) lies
+// above the diagonal); rows 128p + 64r (the rhs rows follow the square part contiguously), columns 128p + 64c.
+// Partials are stored in accumulator order: Upart[((k * nsub + idx) * 16 + wave * 4 + 2i + kk) * 64 + lane] (one acc4 each).
+template <typename T>
+__global__ __launch_bounds__(kThreads) void left_update_kernel(const T* __restrict__ M, int64_t ld, int p,
+                                                               typename Mfma<T>::acc4* __restrict__ Upart, const int32_t* info) {
+  __builtin_amdgcn_s_setprio(3);  // latency-critical chain kernel: issue ahead of co-resident Gram waves
+  using Cfg = TrailCfg<T>;
+  using acc4 = typename Mfma<T>::acc4;
+  constexpr int VEC = Mfma<T>::VEC;
+  constexpr int SB = Cfg::SB;
+  typedef T vecT __attribute__((ext_vector_type(Mfma<T>::VEC)));
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  T* const As = reinterpret_cast<T*>(smem);
+  T* const Bs = As + Cfg::SIDE;
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = uni(tid >> 6);
+  const int wr = wave >> 1, wc = wave & 1;
+  const int idx = blockIdx.x, k = blockIdx.y, nsub = gridDim.x;
+  const int r = idx == 0 ? 0 : (idx + 1) >> 1, c = idx == 0 ? 0 : (idx + 1) & 1;
+  const int rowA = p * kPB + r * SB, rowB = p * kPB + c * SB;
+  const T* panel = M + (int64_t)k * kPB * ld;
+  constexpr int VPC = SB / VEC;
+  constexpr int NV = kPB * SB / (VEC * kThreads);
+  vecT va[NV], vb[NV];
+#pragma unroll
+  for (int u = 0; u < NV; ++u) {
+    const int vi = u * kThreads + tid;
+    const int64_t off = (int64_t)(vi / VPC) * ld + (vi % VPC) * VEC;
+    va[u] = *reinterpret_cast<const vecT*>(panel + rowA + off);
+    vb[u] = *reinterpret_cast<const vecT*>(panel + rowB + off);
+  }
+  if (*info != 0) return;
+#pragma unroll
+  for (int u = 0; u < NV; ++u) {
+    const int vi = u * kThreads + tid;
+    const int kc = vi / VPC, r0 = (vi % VPC) * VEC;
+    const int di = (((kc >> 2) * (SB / 16) + (r0 >> 4)) << 6) + ((kc & 3) << 4) + (r0 & 15);
+    *reinterpret_cast<vecT*>(As + di) = va[u];
+    *reinterpret_cast<vecT*>(Bs + di) = vb[u];
+  }
+  acc4 acc[2][2];
+#pragma unroll
+  for (int i = 0; i < 2; ++i)
+#pragma unroll
+    for (int kk = 0; kk < 2; ++kk) acc[i][kk] = acc4{T(0), T(0), T(0), T(0)};
+  __syncthreads();
+#pragma unroll 8
+  for (int ks = 0; ks < kPB / 4; ++ks) {
+    T fa[2], fb[2];
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+      fa[i] = As[((ks * (SB / 16) + 2 * wr + i) << 6) + lane];
+      fb[i] = Bs[((ks * (SB / 16) + 2 * wc + i) << 6) + lane];
+    }
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+      for (int kk = 0; kk < 2; ++kk) acc[i][kk] = Mfma<T>::mma(fa[i], fb[kk], acc[i][kk]);
+  }
+  acc4* out = Upart + (((int64_t)k * nsub + idx) * 16 + wave * 4) * 64 + lane;
+#pragma unroll
+  for (int i = 0; i < 2; ++i)
+#pragma unroll
+    for (int kk = 0; kk < 2; ++kk) out[(2 * i + kk) * 64] = acc[i][kk];
+}
+
+// M[sub-tile] -= sum_{k < nsplit} Upart[k][sub-tile]   (k ascending; same thread <-> element map as left_update_kernel)
+template <typename T>
+__global__ __launch_bounds__(kThreads) void left_reduce_kernel(T* __restrict__ M, int64_t ld, int p, int nsplit,
+                                                               const typename Mfma<T>::acc4* __restrict__ Upart, const int32_t* info) {
+  __builtin_amdgcn_s_setprio(3);  // latency-critical chain kernel: issue ahead of co-resident Gram waves
+  using acc4 = typename Mfma<T>::acc4;
+  constexpr int SB = TrailCfg<T>::SB;
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = uni(tid >> 6);
+  const int wr = wave >> 1, wc = wave & 1;
+  const int idx = blockIdx.x, nsub = gridDim.x;
+  const int r = idx == 0 ? 0 : (idx + 1) >> 1, c = idx == 0 ? 0 : (idx + 1) & 1;
+  const int rowA = p * kPB + r * SB, rowB = p * kPB + c * SB;
+  const bool diag = rowA == rowB;
+  if (*info != 0) return;
+  acc4 sum[4];
+#pragma unroll
+  for (int q = 0; q < 4; ++q) sum[q] = acc4{T(0), T(0), T(0), T(0)};
+  const acc4* in = Upart + ((int64_t)idx * 16 + wave * 4) * 64 + lane;
+  const int64_t kstride = (int64_t)nsub * 16 * 64;
+#pragma unroll 4
+  for (int k = 0; k < nsplit; ++k) {
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+      const acc4 v = in[k * kstride + q * 64];
+#pragma unroll
+      for (int e = 0; e < 4; ++e) sum[q][e] += v[e];
+    }
+  }
+#pragma unroll
+  for (int i = 0; i < 2; ++i)
+#pragma unroll
+    for (int kk = 0; kk < 2; ++kk) {
+      const int col = rowB + 16 * (2 * wc + kk) + (lane & 15);
+      if constexpr (sizeof(T) == 4) {
+        const int row0 = rowA + 16 * (2 * wr + i) + 4 * (lane >> 4);
+        if (!diag || col <= row0 + 3) {
+          acc4* pc = reinterpret_cast<acc4*>(M + (int64_t)col * ld + row0);
+          acc4 cv = *pc;
+#pragma unroll
+          for (int e = 0; e < 4; ++e) cv[e] -= sum[2 * i + kk][e];
+          *pc = cv;
+        }
+      } else {
+#pragma unroll
+        for (int v = 0; v < 4; ++v) {
+          const int row = rowA + 16 * (2 * wr + i) + Mfma<T>::crow(lane, v);
+          if (!diag || col <= row) M[(int64_t)col * ld + row] -= sum[2 * i + kk][v];
+        }
+      }
+    }
+}
+
 // ---- X <- X L_pp^-T for one block of RB rows below the diagonal block ------------------------------------------------
 template <typename T>
 struct TrsmCfg {
-  static constexpr int RB = (sizeof(T) == 4) ? 128 : 64;   // rows per workgroup
+  static constexpr int RB = 64;                            // rows per workgroup (f32 at 128 rows needs 108 KB of LDS: cannot share a CU with a Gram workgroup)
   static constexpr int LDX = kPB + 1;                      // padded row stride of the X image (conflict-free)
   static constexpr int OFF_X = ((kPB * (kPB + 1) / 2) * (int)sizeof(T) + 15) & ~15;
   static constexpr int OFF_DI = OFF_X + RB * LDX * (int)sizeof(T);
@@ -851,6 +1006,7 @@ struct RowSqArgs {      // optional fused epilogue of the marginal stream: var_n
 template <typename T>
 __global__ __launch_bounds__(kThreads) void trsm_block_kernel(T* Abar, int64_t lda, int p, int row_begin, int nrows_total,
                                                               const int32_t* info, RowSqArgs<T> rs) {
+  __builtin_amdgcn_s_setprio(3);  // latency-critical chain kernel: issue ahead of co-resident Gram waves
   using Cfg = TrsmCfg<T>;
   extern __shared__ __attribute__((aligned(16))) char smem[];
   T* const P = reinterpret_cast<T*>(smem);                    // packed lower triangle of L_pp

@@ -283,6 +283,8 @@ def main():
     from blr_amd import _abi
 
     h = _abi.Handle(local_rank)  # raises if the HIP extension or the GPU is missing: no fallback
+    if os.environ.get("BLR_BENCH_SIDE_STREAM"):  # experiments: a non-default torch stream instead of the null stream
+        torch.cuda.set_stream(torch.cuda.Stream(dev))
     stream = torch.cuda.current_stream(dev)
     h.set_stream(stream.cuda_stream)  # 0 = the HIP null stream = torch's default stream
     h.set_async(True)
