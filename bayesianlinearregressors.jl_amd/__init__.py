@@ -17,6 +17,7 @@ from .regressor import (
     Normal,
     PDMat,
     RandomFourierFeatures,
+    ResidentPosterior,
     RowVecs,
     Symmetric,
     cov,
@@ -37,5 +38,5 @@ from .regressor import (
 __all__ = [
     "logpdf", "rand", "mean", "std", "cov", "var", "BayesianLinearRegressor", "marginals", "posterior",
     "BasisFunctionRegressor", "ColVecs", "RowVecs", "Diagonal", "Symmetric", "PDMat", "Normal", "FiniteGP",
-    "BLRFunctionSample", "RandomFourierFeatures", "mean_and_var", "mean_and_cov", "rand_b", "logpdf_columns", "logpdf_and_gradient", "BLRError", "PosDefException",
+    "BLRFunctionSample", "RandomFourierFeatures", "mean_and_var", "mean_and_cov", "rand_b", "logpdf_columns", "logpdf_and_gradient", "BLRError", "PosDefException", "ResidentPosterior",
 ]

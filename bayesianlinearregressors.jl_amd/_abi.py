@@ -69,6 +69,8 @@ for _suf in ("f64", "f32"):
     _SIGS[f"blr_posterior_batched_{_suf}"] = (
         [_H, _int, _int, _i64, _i64, _i64, _vp, _i64, _i64, _vp, _i64, _int, _vp, _i64, _int, _vp, _i64, _vp, _i64, _i64,
          _vp, _i64, _vp, _i64, _i64, _vp, _i64, _i64, _vp, _vp], _int)
+    _SIGS[f"blr_update_factor_{_suf}"] = (
+        [_H, _int, _int, _i64, _i64, _i64, _vp, _i64, _i64, _vp, _i64, _int, _vp, _i64, _vp, _i64, _vp, _i64, _i64, _vp, _vp], _int)
     _SIGS[f"blr_posterior_{_suf}"] = (
         [_H, _int, _i64, _i64, _vp, _i64, _vp, _int, _vp, _int, _vp, _vp, _i64, _vp, _vp, _i64, _vp, _i64, _vp], _int)
     _SIGS[f"blr_marginals_batched_{_suf}"] = (
@@ -217,6 +219,13 @@ class Handle:
                              _ptr(s), strides, prior_kind, _ptr(mw), stridemw, _ptr(Lw), ldl, strideLw,
                              _ptr(mw_post), stride_mwpost, _ptr(T_post), ldt, strideT, _ptr(Lw_post), ldlp, strideLp,
                              _ptr(logpdf), _ptr(info)))
+
+    def update_factor(self, dtype, memspace, layout, B, D, k, X, ldx, strideX, y, stridey, noise_kind, s, strides, mw, stridemw,
+                      T, ldt, strideT, logpdf, info):
+        """In-place rank-k update of the resident state (mw, T); include/blr_mi355x.h blr_update_factor_*."""
+        fn = getattr(self.lib, f"blr_update_factor_{suffix(dtype)}")
+        return self.check(fn(self._h, memspace, layout, B, D, k, _ptr(X), ldx, strideX, _ptr(y), stridey, noise_kind, _ptr(s),
+                             strides, _ptr(mw), stridemw, _ptr(T), ldt, strideT, _ptr(logpdf), _ptr(info)))
 
     def posterior(self, dtype, layout, D, N, X, ldx, y, noise_kind, s, prior_kind, mw, Lw, ldl, mw_post, T_post, ldt,
                   Lw_post, ldlp, logpdf):

@@ -18,6 +18,7 @@
 #include "blr_fused_small.hpp"
 #include "blr_large.hpp"
 #include "blr_dense.hpp"
+#include "blr_update.hpp"
 
 using namespace blr;
 
@@ -2124,6 +2125,87 @@ int rand_dense_noise(blr_handle* h, int memspace, int layout, int64_t D, int64_t
   return hinfo;
 }
 
+// ---- rank-k update of a resident state (blr_update.hpp) ---------------------------------------------------------------
+template <typename T>
+int update_factor(blr_handle* h, int memspace, int layout, int64_t B, int64_t D, int64_t k, const T* X, int64_t ldx,
+                  int64_t strideX, const T* y, int64_t stridey, int noise_kind, const T* s, int64_t strides, T* mw,
+                  int64_t stridemw, T* Tf, int64_t ldt, int64_t strideT, double* logpdf, int32_t* info) {
+  if (!h) return -1;
+  h->err.clear();
+  // Route (measured, tools/update_bench.py, DESIGN.md "rank-k update"): a sweep costs ~40 us per observation at D = 128
+  // (a serial chain of D rotations), the in-place re-factorisation ~99 us per CALL whatever k is -- the sweep wins for a
+  // single new observation (1.1x at B = 1, 1.5-2x batched) and for two when D <= 64 and the batch fills the chip.
+  // BLR_MI355X_SWEEP=always / never overrides (tests exercise both routes on the same inputs).
+  const char* mode = getenv("BLR_MI355X_SWEEP");
+  const bool can_sweep = D >= 1 && D <= kSweepMaxD && k >= 0 && k <= kSweepMaxK;
+  bool sweep = can_sweep && (k <= 1 || (D <= 64 && k <= 2 && B >= 64));
+  if (mode && !strcmp(mode, "always")) sweep = can_sweep;
+  if (mode && !strcmp(mode, "never")) sweep = false;
+  if (!sweep) {
+    // k-independent cost: the SAME state re-factored in place, the old factor entering as D pseudo-observations
+    // (reads of T and mw complete before the first write in both the fused and the large-D path)
+    if (!mw) return bad_arg(h, 15, "mw is NULL");
+    if (!Tf) return bad_arg(h, 17, "T is NULL");
+    return posterior_batched<T>(h, memspace, layout, B, D, k, X, ldx, strideX, y, stridey, noise_kind, s, strides,
+                                BLR_PRIOR_UPPER_FACTOR, mw, stridemw, Tf, ldt, strideT, mw, stridemw, Tf, ldt, strideT,
+                                (T*)nullptr, 0, 0, logpdf, info);
+  }
+  if (memspace != BLR_MEM_HOST && memspace != BLR_MEM_DEVICE) return bad_arg(h, 2, "memspace");
+  if (layout != BLR_LAYOUT_COLVECS && layout != BLR_LAYOUT_ROWVECS) return bad_arg(h, 3, "unknown layout (reference :26-31)");
+  if (B < 0 || B > (1 << 30)) return bad_arg(h, 4, "B out of range (0..2^30)");
+  if (B == 0) return 0;
+  if (k > 0 && !X) return bad_arg(h, 7, "X is NULL");
+  if (layout == BLR_LAYOUT_COLVECS ? ldx < D : ldx < std::max<int64_t>(k, 1)) return bad_arg(h, 8, "ldx too small");
+  if (strideX < 0) return bad_arg(h, 9, "strideX < 0");
+  if (k > 0 && !y) return bad_arg(h, 10, "y is NULL (reference :74 length check)");
+  if (stridey < 0) return bad_arg(h, 11, "stridey < 0");
+  if (noise_kind != BLR_NOISE_ISOTROPIC && noise_kind != BLR_NOISE_DIAGONAL) return bad_arg(h, 12, "noise_kind");
+  if (!s) return bad_arg(h, 13, "s is NULL");
+  if (strides < 0) return bad_arg(h, 14, "strides < 0");
+  if (!mw) return bad_arg(h, 15, "mw is NULL");
+  if (B > 1 && stridemw < D) return bad_arg(h, 16, "stridemw < D");
+  if (!Tf) return bad_arg(h, 17, "T is NULL");
+  if (ldt < D) return bad_arg(h, 18, "ldt < D");
+  if (B > 1 && strideT < (int64_t)mat_extent(D, D, ldt)) return bad_arg(h, 19, "strideT too small");
+  if (!info) return bad_arg(h, 21, "info is NULL");
+  HIP_TRY(h, hipSetDevice(h->device));
+  SweepArgs<T> a{};
+  a.ldx = ldx; a.strideX = strideX; a.layout = layout; a.stridey = stridey; a.strides = strides; a.noise_kind = noise_kind;
+  a.stridemw = stridemw; a.ldt = ldt; a.strideT = strideT; a.D = (int)D; a.k = (int)k;
+  const int lds = sweep_lds_bytes<T>((int)D);
+  HIP_TRY(h, hipFuncSetAttribute(reinterpret_cast<const void*>(rank1_sweep_kernel<T>), hipFuncAttributeMaxDynamicSharedMemorySize, lds));
+  if (memspace == BLR_MEM_DEVICE) {
+    a.X = X; a.y = y; a.s = s; a.mw = mw; a.Tf = Tf; a.logpdf = logpdf; a.info = info;
+    hipLaunchKernelGGL(rank1_sweep_kernel<T>, dim3((unsigned)B), dim3(kThreads), lds, h->stream, a);
+    HIP_TRY(h, hipGetLastError());
+    if (!h->async) HIP_TRY(h, hipStreamSynchronize(h->stream));
+    return 0;
+  }
+  Staging guard(h);
+  const size_t x_one = layout == BLR_LAYOUT_COLVECS ? mat_extent(D, k, ldx) : mat_extent(k, D, ldx);
+  const size_t s_one = noise_kind == BLR_NOISE_DIAGONAL ? (size_t)k : 1;
+  const size_t n_mw = extent(B, stridemw, (size_t)D), n_T = extent(B, strideT, mat_extent(D, D, ldt));
+  int rc;
+  const T *dmw = nullptr, *dT = nullptr;
+  if ((rc = stage_in(h, X, extent(B, strideX, x_one), &a.X))) return rc;
+  if ((rc = stage_in(h, y, extent(B, stridey, (size_t)k), &a.y))) return rc;
+  if ((rc = stage_in(h, s, extent(B, strides, s_one), &a.s))) return rc;
+  if ((rc = stage_in(h, (const T*)mw, n_mw, &dmw))) return rc;
+  if ((rc = stage_in(h, (const T*)Tf, n_T, &dT))) return rc;
+  a.mw = const_cast<T*>(dmw); a.Tf = const_cast<T*>(dT);
+  if ((rc = stage_out_alloc(h, logpdf, (size_t)B, &a.logpdf))) return rc;
+  if ((rc = stage_out_alloc(h, info, (size_t)B, &a.info))) return rc;
+  if (k == 0) { if (!a.X) a.X = a.mw; if (!a.y) a.y = a.mw; }
+  hipLaunchKernelGGL(rank1_sweep_kernel<T>, dim3((unsigned)B), dim3(kThreads), lds, h->stream, a);
+  HIP_TRY(h, hipGetLastError());
+  HIP_TRY(h, hipMemcpyAsync(mw, a.mw, n_mw * sizeof(T), hipMemcpyDeviceToHost, h->stream));
+  HIP_TRY(h, hipMemcpyAsync(Tf, a.Tf, n_T * sizeof(T), hipMemcpyDeviceToHost, h->stream));
+  if (logpdf) HIP_TRY(h, hipMemcpyAsync(logpdf, a.logpdf, (size_t)B * sizeof(double), hipMemcpyDeviceToHost, h->stream));
+  HIP_TRY(h, hipMemcpyAsync(info, a.info, (size_t)B * sizeof(int32_t), hipMemcpyDeviceToHost, h->stream));
+  HIP_TRY(h, hipStreamSynchronize(h->stream));
+  return 0;
+}
+
 }  // namespace
 
 // =======================================================================================================
@@ -2253,6 +2335,13 @@ int blr_timer_stop(blr_handle* h, float* elapsed_ms) {
     return posterior_batched<T>(h, memspace, layout, B, D, N, X, ldx, strideX, y, stridey, noise_kind, s, strides,  \
                                 prior_kind, mw, stridemw, Lw, ldl, strideLw, mw_post, stride_mwpost, T_post, ldt,    \
                                 strideT, Lw_post, ldlp, strideLp, logpdf, info);                                    \
+  }                                                                                                                 \
+  int blr_update_factor_##SUF(blr_handle* h, int memspace, int layout, int64_t B, int64_t D, int64_t k, const T* X, \
+                              int64_t ldx, int64_t strideX, const T* y, int64_t stridey, int noise_kind, const T* s, \
+                              int64_t strides, T* mw, int64_t stridemw, T* Tf, int64_t ldt, int64_t strideT,         \
+                              double* logpdf, int32_t* info) {                                                       \
+    return update_factor<T>(h, memspace, layout, B, D, k, X, ldx, strideX, y, stridey, noise_kind, s, strides, mw,   \
+                            stridemw, Tf, ldt, strideT, logpdf, info);                                               \
   }                                                                                                                 \
   int blr_posterior_##SUF(blr_handle* h, int layout, int64_t D, int64_t N, const T* X, int64_t ldx, const T* y,     \
                           int noise_kind, const T* s, int prior_kind, const T* mw, const T* Lw, int64_t ldl,        \

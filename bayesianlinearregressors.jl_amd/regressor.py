@@ -514,6 +514,70 @@ def posterior(fx, y):
     return post
 
 
+class ResidentPosterior:
+    """A posterior kept as its state (mw, T) -- T the upper factor of the precision -- and conditioned IN PLACE on further
+    batches: the "repeated conditioning" pattern of reference test/bayesian_linear_regression.jl:49-70
+    (``posterior(f'1(X2, S2), y2)``) without re-deriving reference :72-89 from a D x D precision every time
+    (blr_update_factor_*: O(k D^2) Givens sweeps for small batches, in-place re-factorisation otherwise).
+
+        st = ResidentPosterior(posterior(f(X1, S1), y1))      # or a prior: ResidentPosterior(f)
+        lp2 = st.condition(X2, S2, y2)                         # log p(y2 | y1); state now = posterior given y1 and y2
+        f12 = st.regressor()                                   # BayesianLinearRegressor(mw, PDMat(T))
+
+    The arrays live on the host here (the library stages them); a device-resident state uses Handle.update_factor with
+    MEM_DEVICE pointers directly (tests/test_gpu_parity.py, julia/BLRMI355X.jl update_factor!)."""
+
+    def __init__(self, f):
+        base = f.blr if isinstance(f, BasisFunctionRegressor) else f
+        if not isinstance(base, BayesianLinearRegressor):
+            raise TypeError("ResidentPosterior wraps a BayesianLinearRegressor")
+        dtype = _dtype_of(base.mw)
+        D = base.mw.shape[0]
+        self.dtype = dtype
+        self.mw = np.array(_mean_vector(base.mw, D, dtype))
+        Lw = base.Lw
+        if isinstance(Lw, PDMat):
+            T = np.triu(np.asarray(Lw.U, dtype=dtype))
+        elif isinstance(Lw, Diagonal):
+            k = _first_nonpositive(Lw.diag)
+            if k:
+                raise _abi.PosDefException(k)
+            T = np.diag(np.sqrt(np.asarray(Lw.diag, dtype=dtype)))
+        else:  # dense precision: one D x D factorisation when the state is created (reference :78)
+            A = Lw.toarray() if isinstance(Lw, Symmetric) else np.asarray(Lw)
+            try:
+                T = np.linalg.cholesky(np.asarray(A, dtype=np.float64)).T.astype(dtype)
+            except np.linalg.LinAlgError:
+                raise _abi.PosDefException(-1) from None
+        if T.shape != (D, D):
+            raise ValueError("size of the prior precision != length(mw)")
+        self.T = np.asfortranarray(T)
+
+    def condition(self, x, Sy, y):
+        """In-place update with the observations (x, Sy, y); returns log p(y | everything conditioned on so far)."""
+        dtype = self.dtype
+        X, layout, ldx, D, k = _x_layout(x, dtype)
+        if D != self.mw.shape[0]:
+            raise ValueError(f"dimension of the inputs ({D}) != length(mw) = {self.mw.shape[0]}")
+        y = np.ascontiguousarray(y, dtype=dtype)
+        if y.shape != (k,):
+            raise ValueError("length(y) != number of inputs")  # reference :74
+        s, noise_kind = _noise(Sy, k, dtype)
+        if noise_kind == _abi.NOISE_DENSE:
+            raise NotImplementedError("ResidentPosterior.condition takes scalar or diagonal noise (whiten a dense block first)")
+        lp = np.zeros(1, dtype=np.float64)
+        info = np.zeros(1, dtype=np.int32)
+        _handle().update_factor(dtype, _abi.MEM_HOST, layout, 1, D, k, X, ldx, 0, y, 0, noise_kind, s, 0, self.mw, 0, self.T,
+                                max(D, 1), 0, lp, info)
+        if info[0] != 0:
+            raise _abi.PosDefException(int(info[0]))
+        return float(lp[0])
+
+    def regressor(self):
+        """The current state as a BayesianLinearRegressor (precision carried by its factor, reference :93)."""
+        return BayesianLinearRegressor(self.mw.copy(), PDMat(np.triu(self.T)))
+
+
 def _marginals(fx, want_mean, want_var):
     fx = _to_finite_blr(fx)
     blr = fx.f

@@ -286,6 +286,28 @@ int blr_rand_dense_noise_f32(blr_handle* h, int memspace, int layout, int64_t D,
                              int64_t ldx, const float* Sy, int64_t ldsy, int prior_kind, const float* mw, const float* Lw,
                              int64_t ldl, const float* Z1, int64_t ldz1, const float* Z2, int64_t ldz2, float* Y, int64_t ldy);
 
+/* ---- rank-k update of a RESIDENT posterior state ----------------------------------------------
+ * Replaces: reference test/bayesian_linear_regression.jl:49-70 ("repeated conditioning", posterior(f'1(X2, S2), y2)) and
+ * src/bayesian_linear_regression.jl:93 (the posterior carries mw', Lw' forward; every further call re-derives :72-89 from
+ * Lw' at O(D^3)).
+ * State, updated IN PLACE: mw[B][D] and the upper factor T[B] (D x D, ldt, T'T = precision; the strictly-lower part is not
+ * read and may be overwritten with zeros) -- exactly the (mw_post, T_post) pair blr_posterior_batched_* writes.
+ * k new observations per regressor: X (D x k ColVecs / k x D RowVecs), y[k], isotropic or diagonal noise s.
+ * logpdf[B] (may be NULL) = log p(y_k | state before the call), the evidence increment: summing it over successive calls
+ * gives the evidence of all the data (chain rule).  info[B]: 0; i > 0: s_i is not positive (reference :79) or the leading
+ * minor of order i is not positive definite; -1: T has a non-positive diagonal entry.
+ * D <= 128 and k <= 16: k sweeps of D Givens rotations over the factor held in LDS -- O(k D^2), orthogonal transformations
+ * only; the state is untouched when info != 0.  Otherwise: the same state re-factored in place with the old factor entering
+ * as pseudo-observations (cost independent of k; for D > 128 the state is undefined when info != 0). */
+int blr_update_factor_f64(blr_handle* h, int memspace, int layout, int64_t B, int64_t D, int64_t k, const double* X,
+                          int64_t ldx, int64_t strideX, const double* y, int64_t stridey, int noise_kind, const double* s,
+                          int64_t strides, double* mw, int64_t stridemw, double* T, int64_t ldt, int64_t strideT,
+                          double* logpdf, int32_t* info);
+int blr_update_factor_f32(blr_handle* h, int memspace, int layout, int64_t B, int64_t D, int64_t k, const float* X,
+                          int64_t ldx, int64_t strideX, const float* y, int64_t stridey, int noise_kind, const float* s,
+                          int64_t strides, float* mw, int64_t stridemw, float* T, int64_t ldt, int64_t strideT,
+                          double* logpdf, int32_t* info);
+
 /* ---- sharded log-evidence: fixed-order sum of logpdf[B] on the device ----------
  * Deterministic (no float atomics): the same bits for the same B regardless of launch geometry.
  * The cross-rank step is one RCCL all-gather of these per-rank partials done by the host framework

@@ -515,6 +515,35 @@ function posterior_batched!(mw_post::DeviceArray{T}, T_post::DeviceArray{T}, lp:
     return nothing
 end
 
+"""
+    update_factor!(mw, T, logpdf, info, X, y, s; D, k, B, isotropic)
+
+Condition B device-resident posterior states IN PLACE on k further observations each -- the "repeated conditioning" of
+reference `test/bayesian_linear_regression.jl:49-70` without going back through a D×D precision (`:93`, `:72-89`):
+mw is D×B, T D×D×B (upper factors, exactly what `posterior_batched!` wrote), X D×k×B, y k×B, s one variance (`isotropic`) or
+k×B.  `logpdf[b]` = log p(y_b | state before the call) -- the evidence increment of the chain rule.
+"""
+function update_factor!(mw::DeviceArray{T}, Tf::DeviceArray{T}, lp::DeviceArray{Float64}, info::DeviceArray{Int32},
+                        X::DeviceArray{T}, y::DeviceArray{T}, s::DeviceArray{T}; D::Int, k::Int, B::Int, isotropic::Bool) where {T<:Elt}
+    h = handle()
+    nk = isotropic ? ISOTROPIC : DIAGONALN
+    rc = if T === Float64
+        ccall((:blr_update_factor_f64, LIB), Cint,
+              (Ptr{Cvoid}, Cint, Cint, Int64, Int64, Int64, Ptr{T}, Int64, Int64, Ptr{T}, Int64, Cint, Ptr{T}, Int64, Ptr{T}, Int64,
+               Ptr{T}, Int64, Int64, Ptr{Cdouble}, Ptr{Int32}),
+              h, MEM_DEVICE, COLVECS, B, D, k, X.ptr, D, D * k, y.ptr, k, nk, s.ptr, isotropic ? 0 : k, mw.ptr, D, Tf.ptr, D, D * D,
+              lp.ptr, info.ptr)
+    else
+        ccall((:blr_update_factor_f32, LIB), Cint,
+              (Ptr{Cvoid}, Cint, Cint, Int64, Int64, Int64, Ptr{T}, Int64, Int64, Ptr{T}, Int64, Cint, Ptr{T}, Int64, Ptr{T}, Int64,
+               Ptr{T}, Int64, Int64, Ptr{Cdouble}, Ptr{Int32}),
+              h, MEM_DEVICE, COLVECS, B, D, k, X.ptr, D, D * k, y.ptr, k, nk, s.ptr, isotropic ? 0 : k, mw.ptr, D, Tf.ptr, D, D * D,
+              lp.ptr, info.ptr)
+    end
+    check(h, rc)
+    return nothing
+end
+
 # ---- one Julia process per GPU: the path's single exchange through RCCL, called directly (SURVEY.md 8e) ------------------
 "rank 0: 128 opaque bytes to ship to the other ranks (Distributed.jl, a file, MPI ...)"
 function comm_unique_id()

@@ -1348,3 +1348,116 @@ def test_rccl_direct_single_rank(B):
     finally:
         h.close()
 
+
+
+# ---- rank-k update of a resident state (blr_update_factor_*) -----------------------------------
+@pytest.mark.parametrize("route", ["always", "never"])
+def test_update_factor_repeated_conditioning_10_plus_3(B, route, monkeypatch):
+    monkeypatch.setenv("BLR_MI355X_SWEEP", route)  # Givens sweep / in-place re-factorisation: same answers
+    # reference test/bayesian_linear_regression.jl:49-70 (13 = 10 + 3 split) through the resident state, against the ONE-SHOT
+    # oracle on all 13 observations; the second batch (k = 3) goes through the O(k D^2) Givens sweep
+    rng = _rng(71)
+    N, D = 13, 7
+    X, mw, Lw, s = O.generate_toy_problem(rng, N, D, dense_noise_cov=False)
+    Xp = rng.standard_normal((D, N))
+    f = B.BayesianLinearRegressor(mw, Lw)
+    y = B.rand(rng, f(X, s))
+    N1 = N - 3
+    st = B.ResidentPosterior(B.posterior(f(X[:, :N1], s[:N1]), y[:N1]))
+    lp2 = st.condition(X[:, N1:], s[N1:], y[N1:])
+    f2 = st.regressor()
+    mw_o, T_o, L_o = O.posterior_literal(mw, Lw, X, s, y)
+    np.testing.assert_allclose(f2.mw, mw_o, rtol=1e-9)
+    np.testing.assert_allclose(f2.Lw.toarray(), L_o, rtol=1e-9, atol=1e-12)
+    np.testing.assert_allclose(B.mean(f2(Xp, s)), O.mean(mw_o, Xp), rtol=1e-9)
+    np.testing.assert_allclose(B.cov(f2(Xp, s)), O.cov(mw_o, L_o, Xp, s), rtol=1e-9, atol=1e-12)
+    # evidence increment = log p(y2 | y1) (chain rule against the oracle's two evidences)
+    lp_o = O.logpdf_literal(mw, Lw, X, s, y) - O.logpdf_literal(mw, Lw, X[:, :N1], s[:N1], y[:N1])
+    assert lp2 == pytest.approx(lp_o, rel=1e-9)
+    # starting from the PRIOR as the resident state and feeding everything in three batches gives the same posterior
+    st0 = B.ResidentPosterior(f)
+    tot = st0.condition(X[:, :5], s[:5], y[:5]) + st0.condition(X[:, 5:N1], s[5:N1], y[5:N1]) + st0.condition(X[:, N1:], s[N1:], y[N1:])
+    np.testing.assert_allclose(st0.regressor().mw, mw_o, rtol=1e-9)
+    np.testing.assert_allclose(st0.regressor().Lw.toarray(), L_o, rtol=1e-9, atol=1e-12)
+    assert tot == pytest.approx(O.logpdf_literal(mw, Lw, X, s, y), rel=1e-9)
+
+
+@pytest.mark.parametrize("dtype", [np.float64, np.float32])
+@pytest.mark.parametrize("D,k", [(1, 1), (5, 3), (16, 16), (64, 7), (100, 1), (128, 16), (128, 3), (128, 64), (37, 40), (200, 5)])
+@pytest.mark.parametrize("noise", ["diagonal", "isotropic"])
+@pytest.mark.parametrize("route", ["always", "auto"])
+def test_update_factor_device_batched(B, dtype, D, k, noise, route, monkeypatch):
+    if route == "always":
+        monkeypatch.setenv("BLR_MI355X_SWEEP", "always")
+    else:
+        monkeypatch.delenv("BLR_MI355X_SWEEP", raising=False)
+    # device-resident batched state: every (D, k) class -- sweep (D <= 128, k <= 16), fused re-factorisation (k > 16) and the
+    # large-D path (D > 128) -- against the oracle's one-shot posterior from the same prior state
+    import torch
+
+    a = B._abi
+    h = a.default_handle()
+    rng = _rng(72 + D + 3 * k)
+    nb = 3 if D <= 128 else 1
+    dev = torch.device("cuda:0")
+    tdt = torch.float64 if dtype == np.float64 else torch.float32
+    X = rng.standard_normal((nb, k, D))  # [k, D] row-major == D x k ColVecs
+    mw = rng.standard_normal((nb, D))
+    U = np.triu(rng.standard_normal((nb, D, D))) * (0.3 / np.sqrt(D))  # well-conditioned: random triangular factors are not
+    for b in range(nb):
+        U[b][np.diag_indices(D)] = 1.0 + np.abs(U[b][np.diag_indices(D)])
+    s = np.exp(0.3 * rng.standard_normal((nb, k))) if noise == "diagonal" else np.full((1,), 0.37)
+    y = rng.standard_normal((nb, k))
+    Xd, mwd, yd = (torch.tensor(v, dtype=tdt, device=dev) for v in (X, mw, y))
+    sd = torch.tensor(s, dtype=tdt, device=dev)
+    Td = torch.tensor(np.transpose(U, (0, 2, 1)).copy(), dtype=tdt, device=dev)  # column-major upper factor per regressor
+    lp = torch.zeros(nb, dtype=torch.float64, device=dev)
+    info = torch.full((nb,), 7, dtype=torch.int32, device=dev)
+    kind = a.NOISE_DIAGONAL if noise == "diagonal" else a.NOISE_ISOTROPIC
+    h.update_factor(dtype, a.MEM_DEVICE, a.LAYOUT_COLVECS, nb, D, k, Xd.data_ptr(), D, k * D, yd.data_ptr(), k, kind, sd.data_ptr(),
+                    k if noise == "diagonal" else 0, mwd.data_ptr(), D, Td.data_ptr(), D, D * D, lp.data_ptr(), info.data_ptr())
+    torch.cuda.synchronize()
+    assert info.cpu().tolist() == [0] * nb
+    rtol = 1e-9 if dtype == np.float64 else 2e-4
+    for b in range(nb):
+        Ub = U[b].astype(dtype).astype(np.float64)
+        Xb, yb, mb = X[b].T.astype(dtype).astype(np.float64), y[b].astype(dtype).astype(np.float64), mw[b].astype(dtype).astype(np.float64)
+        sb = (s[b] if noise == "diagonal" else np.full(k, s[0])).astype(dtype).astype(np.float64)
+        mw_o, T_o, L_o = O.posterior_literal(mb, Ub.T @ Ub, Xb, sb, yb)
+        Tn = np.triu(Td[b].cpu().numpy().T.astype(np.float64))
+        scale = np.abs(L_o).max()
+        np.testing.assert_allclose(Tn.T @ Tn, L_o, rtol=rtol, atol=rtol * scale)
+        np.testing.assert_allclose(mwd[b].cpu().numpy(), mw_o, rtol=50 * rtol, atol=rtol * np.abs(mw_o).max())
+        assert lp[b].item() == pytest.approx(O.logpdf_literal(mb, Ub.T @ Ub, Xb, sb, yb), rel=10 * rtol, abs=10 * rtol)
+
+
+@pytest.mark.parametrize("route", ["always", "never"])
+def test_update_factor_leaves_the_state_alone_on_failure(B, route, monkeypatch):
+    import torch
+
+    monkeypatch.setenv("BLR_MI355X_SWEEP", route)
+
+    a = B._abi
+    h = a.default_handle()
+    rng = _rng(73)
+    D, k = 9, 4
+    dev = torch.device("cuda:0")
+    U = np.triu(rng.standard_normal((D, D))) + 3 * np.eye(D)
+    U[np.diag_indices(D)] = np.abs(U[np.diag_indices(D)])
+    Td = torch.tensor(U.T.copy(), dtype=torch.float64, device=dev)
+    mwd = torch.tensor(rng.standard_normal(D), dtype=torch.float64, device=dev)
+    T0, m0 = Td.clone(), mwd.clone()
+    Xd = torch.tensor(rng.standard_normal((k, D)), dtype=torch.float64, device=dev)
+    yd = torch.tensor(rng.standard_normal(k), dtype=torch.float64, device=dev)
+    sd = torch.tensor([0.5, 0.2, -0.1, 0.3], dtype=torch.float64, device=dev)
+    lp = torch.zeros(1, dtype=torch.float64, device=dev)
+    info = torch.zeros(1, dtype=torch.int32, device=dev)
+    h.update_factor(np.float64, a.MEM_DEVICE, a.LAYOUT_COLVECS, 1, D, k, Xd.data_ptr(), D, 0, yd.data_ptr(), 0, a.NOISE_DIAGONAL,
+                    sd.data_ptr(), 0, mwd.data_ptr(), 0, Td.data_ptr(), D, 0, lp.data_ptr(), info.data_ptr())
+    torch.cuda.synchronize()
+    assert info.item() == 3 and np.isnan(lp.item())  # reference :79: PosDefException at the third variance
+    assert torch.equal(Td, T0) and torch.equal(mwd, m0)
+    st = B.ResidentPosterior(B.BayesianLinearRegressor(np.zeros(3), B.Diagonal(np.ones(3))))
+    with pytest.raises(B.PosDefException):
+        st.condition(np.ones((3, 2)), np.array([1.0, 0.0]), np.zeros(2))
+    np.testing.assert_array_equal(st.mw, np.zeros(3))
