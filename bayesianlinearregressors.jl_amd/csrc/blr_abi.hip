@@ -19,6 +19,7 @@
 #include "blr_large.hpp"
 #include "blr_dense.hpp"
 #include "blr_update.hpp"
+#include "blr_fused_wave.hpp"
 
 using namespace blr;
 
@@ -244,9 +245,27 @@ int launch_fused_small_mode(blr_handle* h, const PosteriorArgs<T>& a) {
   return launch_fused_small<T, NB, 0>(h, a);
 }
 
+// D = 32 / 64, ColVecs with aligned columns, diagonal prior: one wavefront per regressor (blr_fused_wave.hpp)
+template <typename T, int NB>
+int launch_fused_wave(blr_handle* h, const PosteriorArgs<T>& a) {
+  using C = WaveCfg<T, NB>;
+  const int grid = (int)std::min<int64_t>(a.B, 256 * 8);  // 8 waves per CU (18 KB of LDS each)
+  hipLaunchKernelGGL((fused_wave_kernel<T, NB>), dim3(grid), dim3(64), C::LDS_BYTES, h->stream, a);
+  HIP_TRY(h, hipGetLastError());
+  return 0;
+}
+
 template <typename T>
 int dispatch_fused_small(blr_handle* h, const PosteriorArgs<T>& a) {
   int NB = (a.D + 15) / 16;
+  static const bool no_wave = getenv("BLR_MI355X_NO_WAVE_KERNEL") != nullptr;
+  if (!no_wave && a.layout == BLR_LAYOUT_COLVECS && a.vec_ok && a.prior_kind == PRIOR_DIAGONAL && a.D == 16 * NB &&
+      (3 * a.ldx + 64) * (int64_t)sizeof(T) < ((int64_t)1 << 31)) {
+    if (NB == 4) return launch_fused_wave<T, 4>(h, a);
+    if constexpr (sizeof(T) == 8) {
+      if (NB == 2) return launch_fused_wave<T, 2>(h, a);
+    }
+  }
   switch (NB) {
     case 1: return launch_fused_small_mode<T, 1>(h, a);
     case 2: return launch_fused_small_mode<T, 2>(h, a);

@@ -846,6 +846,7 @@ BLR_PHASE void phase_gram(char* smem) {
   StageRegs<T, kGlds ? 0 : NB> regs;  // MODE 4 keeps only yv / wv in registers
   T* ring_slot = slot0;               // where the data stage being issued lands (MODE 4)
   T* ring_ybuf = ybuf;                // ... and its y values (isotropic fast path: y travels by LDS-DMA too)
+  int pending_n0 = 0;                 // first column of the stage whose y / variance sit in regs
   const unsigned voff = glds_lane_offset<T>(ldx, lane);
   auto issue = [&](int td, auto iso_tag) {  // prefetch data stage td: into registers, or (MODE 4) straight into its LDS slot
     constexpr bool ISO = decltype(iso_tag)::value;
@@ -867,14 +868,33 @@ BLR_PHASE void phase_gram(char* smem) {
         glds_s<4, C::NSC * (int)sizeof(T) / 4>(uni((int64_t)(uintptr_t)(y + n0)), (unsigned)(lane * 4),
                                                uni((int)lds_addr_of(ring_ybuf)));
     } else {
+      // y and the noise variance of the stage travel through registers UNTOUCHED until the stage is consumed: a division or
+      // a log right behind the loads makes wave 0 sit out a full memory latency inside issue() -- behind the DMA pieces it
+      // has just queued -- with the other three waves waiting for it at the next barrier (measured at D = 64: 1.9 k of the
+      // 10.5 k cycles of every stage)
       regs.yv = T(0);
-      regs.wv = T(0);
+      regs.wv = T(1);
+      pending_n0 = n0;
       if (tid < C::NSC && n0 + tid < N) {
         regs.yv = y[n0 + tid];
-        T sv = diag_noise ? s[n0 + tid] : s_iso;
-        regs.wv = T(1) / sv;                       // :79/:81  Sigma_y^-1 on the diagonal
-        if (diag_noise) lacc += log((double)sv);   // :84  logdet(Sigma_y)
-        if (!(sv > T(0))) bad_noise = min(bad_noise, n0 + tid + 1);  // also catches NaN
+        if (diag_noise) regs.wv = s[n0 + tid];
+      }
+    }
+  };
+  // raw variance -> weight, log-determinant and positivity (reference :79-84); called when the stage is consumed
+  const T w_iso_const = T(1) / s_iso;
+  auto finish_scalars = [&]() {
+    if (tid < C::NSC) {
+      const bool valid = pending_n0 + tid < N;
+      const T sv = regs.wv;
+      if (diag_noise) {
+        regs.wv = valid ? T(1) / sv : T(0);                  // :79/:81  Sigma_y^-1 on the diagonal
+        if (valid) {
+          lacc += log((double)sv);                           // :84  logdet(Sigma_y)
+          if (!(sv > T(0))) bad_noise = min(bad_noise, pending_n0 + tid + 1);  // also catches NaN
+        }
+      } else {
+        regs.wv = valid ? w_iso_const : T(0);
       }
     }
   };
@@ -914,10 +934,12 @@ BLR_PHASE void phase_gram(char* smem) {
       stage_store<T, NB, 2>(pr, slot, ybuf + sl * C::NSC, wbuf + sl * C::NSC, tid);
     } else if constexpr (kGlds) {
       if constexpr (!ISO) {
+        finish_scalars();
         if (tid < C::NSC) { ybuf[sl * C::NSC + tid] = regs.yv; wbuf[sl * C::NSC + tid] = regs.wv; }
       }
       asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // this wave's LDS-DMA pieces of stage t have landed
     } else {
+      finish_scalars();
       stage_store<T, NB, MODE>(regs, slot, ybuf + sl * C::NSC, wbuf + sl * C::NSC, tid);
     }
     BLR_GSTAMP(0);

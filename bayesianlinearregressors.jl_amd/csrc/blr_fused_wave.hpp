@@ -1,0 +1,475 @@
+// One WAVEFRONT per regressor: the fused posterior update for D = 32 / 64 (config 4 of BASELINE.json: batches of small
+// independent regressors), ColVecs data with 16-byte aligned columns, diagonal prior precision.
+//
+//   reference src/bayesian_linear_regression.jl:55-69, :72-89 (logpdf + posterior; the same direct Gram form as
+//   blr_fused_small.hpp:  A = Lw + X S^-1 X',  b = X S^-1 (y - X'mw),  A = L L',  u = L^-1 b,  m = L^-T u)
+//
+// Why a second kernel: with four waves per regressor (blr_fused_small.hpp) a D = 64 update spends more time in workgroup
+// barriers, in waiting for its slowest wave and in re-reading fragments than in the matrix pipe -- 10 lower-triangular
+// tiles do not divide over 4 waves (3 + 3 + 2 + 2), each wave reads 7 fragments for 3 MFMAs, and every stage of 8 k-steps
+// pays a vmcnt(0) + s_barrier convoy (measured, tools/fused_bench -DBLR_GRAM_STAMPS: 10.5 k cycles per stage for 1.5 k
+// cycles of MFMA per wave; 47 % MFMA-busy with 4 workgroups per CU).  Here ONE wave owns all 10 tiles:
+//   * 4 fragment reads per k-step feed 10 MFMAs (the A and B side of a tile are the same 4 row-block fragments) and the
+//     column-vector work (delta, b, quadratic form) reuses the same registers -- LDS traffic per k-step drops 7x;
+//   * no workgroup barrier anywhere: the wave stages its own X through a two-slot ring with LDS-DMA and waits on vmcnt;
+//   * the 64 rows of a panel of the blocked Cholesky are exactly one row per lane;
+//   * 18 KB of LDS per wave -> 8 waves per CU, two per SIMD: while one factors / substitutes on the vector ALU the other
+//     keeps the matrix pipe busy.
+// Anything outside the fast path (RowVecs, unaligned or ragged D, dense / factor priors) stays on blr_fused_small.hpp.
+#pragma once
+#include "blr_fused_small.hpp"
+
+namespace blr {
+
+template <typename T, int NB>
+struct WaveCfg {
+  static constexpr int DP = 16 * NB;
+  static constexpr int NT = NB * (NB + 1) / 2;
+  static constexpr int KS = 64 / (NB * (int)sizeof(T));  // k-steps per stage: every stage is 4 KiB of X
+  static constexpr int NSC = 4 * KS;                   // columns per stage
+  static constexpr int DEPTH = 4;                      // ring slots: three stages in flight while one is consumed
+  static constexpr int SLOT = KS * NB * 64;            // elements per ring slot (fragment order [k-step][row block][lane])
+  static constexpr int PACKED = DP * (DP + 1) / 2;
+  static constexpr int RING_BYTES = DEPTH * SLOT * (int)sizeof(T);
+  static constexpr int P_BYTES = PACKED * (int)sizeof(T);
+  static constexpr int REGION0 = ((RING_BYTES > P_BYTES ? RING_BYTES : P_BYTES) + 15) & ~15;  // P aliases the ring
+  static constexpr int OFF_Y = REGION0;                                      // ybuf[DEPTH][NSC]  (LDS-DMA target)
+  static constexpr int OFF_S = OFF_Y + DEPTH * NSC * (int)sizeof(T);         // sbuf[DEPTH][NSC]  (LDS-DMA target, diagonal noise)
+  static constexpr int OFF_W = OFF_S + DEPTH * NSC * (int)sizeof(T);         // wbuf[NSC]
+  static constexpr int OFF_B = OFF_W + NSC * (int)sizeof(T);                 // bvec[DP]
+  static constexpr int OFF_SCR = (OFF_B + DP * (int)sizeof(T) + 15) & ~15;   // 4 doubles + 4 ints
+  static constexpr int LDS_BYTES = OFF_SCR + 48;
+  static constexpr int FPG = (1024 / (int)sizeof(T)) / 64;               // fragments per 1 KiB LDS-DMA piece
+  static constexpr int NG = KS * NB / FPG;                               // X pieces per stage
+  static constexpr int YL = NSC * (int)sizeof(T) / 4;                    // dword lanes of the y / s piece of a stage
+  static_assert(NB % FPG == 0, "pieces must not straddle k-steps");
+  static_assert(KS >= 1 && KS * NB * 16 * 4 * (int)sizeof(T) == 4096, "4 KiB stages");
+  static_assert(YL == 16 || YL == 32, "y piece");
+};
+
+// The three phases are separate NOINLINE functions that hand their results over through LDS (as blr_fused_small.hpp does):
+// in one function body the compiler keeps the 80 accumulator registers of the Gram loop alive across the fully unrolled
+// elimination and spills ~400 SGPRs and ~50 VGPRs; split, each phase gets the whole register file to itself.
+
+// ---- phase 1: streaming Gram.  Out: P = lower triangle of A = Lw + X S^-1 X' (packed), bvec = X S^-1 (y - X'mw),
+//      scr[0] = quadratic form, scr[1] = logdet Sigma_y, iscr[0] = first bad variance (0x7fffffff: none)
+// The wave keeps THREE 4 KiB stages in flight while it consumes a fourth (with one stage of look-ahead the HBM stream cost
+// 0.47 ms of a 1.21 ms launch at config 4: every wave sat out a memory latency per stage).  Everything a stage needs -- X,
+// y and, for diagonal noise, the variances -- travels by LDS-DMA issued from inline asm, so the only vector-memory
+// operations in the loop are these pieces and the stage's arrival is a COUNTED s_waitcnt vmcnt(2 x pieces-per-stage).
+template <typename T, int NB, bool DIAG>
+BLR_PHASE void wave_gram(char* smem, const BLR_GLOBAL T* X, int64_t ldx, const BLR_GLOBAL T* y, const BLR_GLOBAL T* s,
+                         const BLR_GLOBAL T* mw, T dpr, int N) {
+  using C = WaveCfg<T, NB>;
+  using acc4 = typename Mfma<T>::acc4;
+  constexpr int VEC = Mfma<T>::VEC;
+  constexpr int PPS = C::NG + 1 + (DIAG ? 1 : 0);  // LDS-DMA instructions per stage
+  T* const ring = reinterpret_cast<T*>(smem);
+  T* const P = reinterpret_cast<T*>(smem);  // after the loop
+  T* const ybuf = reinterpret_cast<T*>(smem + C::OFF_Y);
+  T* const sbuf = reinterpret_cast<T*>(smem + C::OFF_S);
+  T* const wbuf = reinterpret_cast<T*>(smem + C::OFF_W);
+  T* const bvec = reinterpret_cast<T*>(smem + C::OFF_B);
+  double* const scr = reinterpret_cast<double*>(smem + C::OFF_SCR);
+  int* const iscr = reinterpret_cast<int*>(smem + C::OFF_SCR + 32);
+  int lane = threadIdx.x;
+  asm volatile("" : "+v"(lane));
+  const int r16 = lane & 15, q4 = lane >> 4;
+  N = uni(N);
+  const unsigned voff = glds_lane_offset<T>(ldx, lane);
+  const unsigned ring_addr = uni((int)lds_addr_of(ring));
+  const unsigned ybuf_addr = uni((int)lds_addr_of(ybuf)), sbuf_addr = uni((int)lds_addr_of(sbuf));
+  X = uni(X); y = uni(y); s = uni(s);
+
+  T mwf[NB];
+  bool mwz = true;
+#pragma unroll
+  for (int I = 0; I < NB; ++I) { mwf[I] = mw[16 * I + r16]; mwz = mwz && (mwf[I] == T(0)); }
+  mwz = __all(mwz);
+  T s_iso = DIAG ? T(1) : s[0];
+  int bad_noise = (DIAG || s_iso > T(0)) ? 0x7fffffff : 1;
+  // every compiler-visible load has been consumed before the loop: hipcc must not park an s_waitcnt vmcnt(0) inside it
+#pragma unroll
+  for (int I = 0; I < NB; ++I) asm volatile("" : "+v"(mwf[I]));
+  asm volatile("" : "+v"(s_iso));
+
+  acc4 acc[C::NT];
+#pragma unroll
+  for (int t = 0; t < C::NT; ++t) acc[t] = acc4{T(0), T(0), T(0), T(0)};
+  double bacc[NB];
+#pragma unroll
+  for (int I = 0; I < NB; ++I) bacc[I] = 0.0;
+  double qacc = 0.0, lacc = 0.0;
+  const int nfull = N / C::NSC;  // whole stages; a ragged tail is handled after the pipeline has drained
+  auto issue = [&](int td) {     // exactly PPS LDS-DMA instructions
+    const int n0 = td * C::NSC, sl = td & (C::DEPTH - 1);
+    const unsigned slot_addr = ring_addr + (unsigned)(sl * C::SLOT * (int)sizeof(T));
+#pragma unroll
+    for (int g = 0; g < C::NG; ++g) {
+      const int j = (g * C::FPG) / NB, I0 = (g * C::FPG) % NB;
+      const uint64_t saddr = (uint64_t)(uintptr_t)X + (uint64_t)(((int64_t)(n0 + 4 * j) * ldx + 16 * I0) * (int64_t)sizeof(T));
+      glds_s<16>(uni((int64_t)saddr), voff, slot_addr + (unsigned)(g * 1024));
+    }
+    glds_s<4, C::YL>(uni((int64_t)(uintptr_t)(y + n0)), (unsigned)(lane * 4), ybuf_addr + (unsigned)(sl * C::NSC * (int)sizeof(T)));
+    if constexpr (DIAG)
+      glds_s<4, C::YL>(uni((int64_t)(uintptr_t)(s + n0)), (unsigned)(lane * 4), sbuf_addr + (unsigned)(sl * C::NSC * (int)sizeof(T)));
+  };
+  // one stage of compute: KS k-steps on the slot image, y from yb, weights from wbuf (DIAG)
+  auto compute = [&](const T* slot, const T* yb) {
+#pragma unroll
+    for (int j = 0; j < C::KS; ++j) {
+      T f[NB];
+#pragma unroll
+      for (int I = 0; I < NB; ++I) f[I] = slot[(j * NB + I) * 64 + lane];
+      const T yv = yb[4 * j + q4];
+      T w = T(1);
+      if constexpr (DIAG) w = wbuf[4 * j + q4];
+      T fa[NB];
+#pragma unroll
+      for (int I = 0; I < NB; ++I) fa[I] = DIAG ? f[I] * w : f[I];
+#pragma unroll
+      for (int I = 0; I < NB; ++I)
+#pragma unroll
+        for (int K = 0; K <= I; ++K) {
+#if BLR_EXP == 2
+          acc[I * (I + 1) / 2 + K][0] += fa[I] * f[K];
+#else
+          acc[I * (I + 1) / 2 + K] = Mfma<T>::mma(fa[I], f[K], acc[I * (I + 1) / 2 + K]);
+#endif
+        }
+      // column-vector work on the same registers: delta_n, b += x_n w_n delta_n, quadratic form   (:82-84, :57)
+#if BLR_EXP == 3
+      bacc[0] += (double)w + (double)yv; continue;
+#endif
+      T mu = T(0);
+      if (!mwz) {
+#pragma unroll
+        for (int I = 0; I < NB; ++I) mu += f[I] * mwf[I];
+        mu = row16_allreduce(mu);
+      }
+      const T delta = yv - mu;
+      const T rn = DIAG ? delta * w : delta;
+      if (r16 == 0) qacc += (double)delta * (double)rn;
+#pragma unroll
+      for (int I = 0; I < NB; ++I) bacc[I] += (double)f[I] * (double)rn;
+    }
+  };
+  // variances of the stage in sbuf -> weights in wbuf, log-determinant, positivity (reference :79-84)
+  auto weights = [&](const T* sb, int n0) {
+    if (lane < C::NSC) {
+      const T sv = sb[lane];
+      wbuf[lane] = T(1) / sv;
+      lacc += log((double)sv);
+      if (!(sv > T(0))) bad_noise = min(bad_noise, n0 + lane + 1);
+    }
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+  };
+
+#if BLR_EXP != 4
+  for (int td = 0; td < C::DEPTH - 1 && td < nfull; ++td) issue(td);
+#endif
+#pragma unroll 1
+  for (int t = 0; t < nfull; ++t) {
+    const int sl = t & (C::DEPTH - 1);
+    const int rem = nfull - 1 - t;  // stages issued after stage t: min(rem, 2)
+    if (rem >= 2) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(2 * PPS) : "memory");
+    else if (rem == 1) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(PPS) : "memory");
+    else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __builtin_amdgcn_wave_barrier();
+#if BLR_EXP != 4
+    if (t + C::DEPTH - 1 < nfull) issue(t + C::DEPTH - 1);  // into the slot stage t - 1 was read from
+#endif
+    if constexpr (DIAG) weights(sbuf + sl * C::NSC, t * C::NSC);
+    compute(ring + sl * C::SLOT, ybuf + sl * C::NSC);
+  }
+  asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+  __builtin_amdgcn_wave_barrier();
+  if (nfull * C::NSC < N) {
+    // ragged tail (N not a multiple of the stage width): loaded synchronously, lane by lane, zeros beyond N
+    typedef T vecT __attribute__((ext_vector_type(Mfma<T>::VEC)));
+    const int n0 = nfull * C::NSC;
+    T* slot = ring;
+    const int e0 = lane * VEC;
+    const int fl = e0 >> 6, ls = e0 & 63, q = ls >> 4, r = ls & 15;
+#pragma unroll
+    for (int g = 0; g < C::NG; ++g) {
+      const int F = g * C::FPG + fl;
+      const int j = F / NB, I = F - j * NB;
+      const int n = n0 + 4 * j + q, d = 16 * I + r;
+      T* dst = slot + g * (C::FPG * 64);
+      if (n < N) {
+        glds16((const BLR_GLOBAL void*)(X + (int64_t)n * ldx + d), dst);
+      } else {
+        vecT z;
+#pragma unroll
+        for (int c = 0; c < VEC; ++c) z[c] = T(0);
+        *reinterpret_cast<vecT*>(dst + e0) = z;
+      }
+    }
+    if (lane < C::NSC) {
+      const bool valid = n0 + lane < N;
+      ybuf[lane] = valid ? y[n0 + lane] : T(0);
+      if constexpr (DIAG) {
+        const T sv = valid ? s[n0 + lane] : T(1);
+        wbuf[lane] = valid ? T(1) / sv : T(0);
+        if (valid) {
+          lacc += log((double)sv);
+          if (!(sv > T(0))) bad_noise = min(bad_noise, n0 + lane + 1);
+        }
+      }
+    }
+    asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+    __builtin_amdgcn_wave_barrier();
+    compute(slot, ybuf);
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    __builtin_amdgcn_wave_barrier();
+  }
+
+  // ---- reductions: b (over the 4 column groups of the lanes), quadratic form, logdet Sigma_y, noise check
+  const T w_iso = T(1) / s_iso;
+  double quad = wave_allreduce(qacc);
+  const double logdet_Sy = DIAG ? wave_allreduce(lacc) : (double)N * log((double)s_iso);
+  if (!DIAG) quad *= (double)w_iso;
+  {
+    int bn = bad_noise;
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) bn = min(bn, __shfl_xor(bn, off));
+    bad_noise = bn;
+  }
+#pragma unroll
+  for (int I = 0; I < NB; ++I) {
+    double v = bacc[I];
+    v += __shfl_xor(v, 16);
+    v += __shfl_xor(v, 32);
+    if (!DIAG) v *= (double)w_iso;
+    if (q4 == 0) bvec[16 * I + r16] = (T)v;  // b = X S^-1 (y - X'mw)
+  }
+  if (lane == 0) { scr[0] = quad; scr[1] = logdet_Sy; iscr[0] = bad_noise; }
+  // A = Lw + (1/s) X X'  (isotropic) -- the prior sits on the diagonal of the diagonal tiles -- -> packed lower triangle
+#pragma unroll
+  for (int I = 0; I < NB; ++I) {
+    const T dvI = __shfl(dpr, 16 * I + r16);  // Lw[16 I + r]: lane (r, q) holds column r of the tile
+#pragma unroll
+    for (int K = 0; K <= I; ++K) {
+      const int t = I * (I + 1) / 2 + K;
+      const int col = 16 * K + r16;
+#pragma unroll
+      for (int v = 0; v < 4; ++v) {
+        T val = DIAG ? acc[t][v] : acc[t][v] * w_iso;
+        const int rl = Mfma<T>::crow(lane, v);
+        if (I == K && rl == r16) val += dvI;
+        const int row = 16 * I + rl;
+        if (col <= row) P[pidx(row, col)] = val;
+      }
+    }
+  }
+  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+  __builtin_amdgcn_wave_barrier();
+}
+
+// ---- phase 2: blocked Cholesky of P, one row per lane, trailing matrix in the accumulators (see phase_chol), with the
+//      forward substitution u = L^-1 b riding along.  Out: P = L, bvec = u.  Returns 0 or the failing leading minor.
+template <typename T, int NB>
+BLR_PHASE int wave_chol(char* smem) {
+  using C = WaveCfg<T, NB>;
+  using acc4 = typename Mfma<T>::acc4;
+  T* const P = reinterpret_cast<T*>(smem);
+  T* const bvec = reinterpret_cast<T*>(smem + C::OFF_B);
+  int lane = threadIdx.x;
+  asm volatile("" : "+v"(lane));
+  const int r16 = lane & 15, q4 = lane >> 4;
+  constexpr int D = C::DP;
+  // trailing tiles (I, K), K >= 1, from P (diagonal tiles: both halves, so the tile is symmetric)
+  acc4 acc[C::NT];
+#pragma unroll
+  for (int I = 1; I < NB; ++I)
+#pragma unroll
+    for (int K = 1; K <= I; ++K) {
+      const int t = I * (I + 1) / 2 + K;
+      const int col = 16 * K + r16;
+#pragma unroll
+      for (int v = 0; v < 4; ++v) {
+        const int row = 16 * I + Mfma<T>::crow(lane, v);
+        acc[t][v] = P[pidx(max(row, col), min(row, col))];
+      }
+    }
+  int info = 0;
+#pragma unroll 1
+  for (int J = 0; J < NB; ++J) {
+    const bool is_diag = lane < 16;
+    const int ri = is_diag ? 16 * J + lane : 16 * (J + 1) + (lane - 16);
+    const bool active = ri < D;
+    T arow[16];
+    T bl = T(0);
+    {
+      const T* src = P + pidx(active ? ri : 0, 16 * J);
+#pragma unroll
+      for (int c = 0; c < 16; ++c) {
+        const bool ok = active && (!is_diag || c <= lane);
+        arow[c] = ok ? src[c] : T(0);
+      }
+      if (active) bl = bvec[ri];
+    }
+    T own_rsq = T(1);
+#pragma unroll
+    for (int c = 0; c < 16; ++c) {
+      const T d2 = readlane(arow[c], c);
+      if (!(d2 > T(0)) && info == 0) info = 16 * J + c + 1;  // wave-uniform
+      const T tm = arow[c] * fast_rcp(d2);
+      const T bc = readlane(bl, c);
+      if (lane > c) bl -= tm * bc;
+#pragma unroll
+      for (int k = c + 1; k < 16; ++k) {
+        const T akc = readlane(arow[c], k);
+        arow[k] -= tm * akc;
+      }
+      const T rsq = fast_rsqrt(d2);
+      if (lane == c) own_rsq = rsq;
+      arow[c] = (lane == c) ? d2 * rsq : arow[c] * rsq;
+    }
+    if (is_diag) bl *= own_rsq;
+    if (info != 0) break;
+    if (active) {
+      T* dst = P + pidx(ri, 16 * J);
+#pragma unroll
+      for (int c = 0; c < 16; ++c)
+        if (!is_diag || c <= lane) dst[c] = arow[c];
+      bvec[ri] = bl;
+    }
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    // trailing update from the finished panel; block column J + 1 goes straight back to P
+#pragma unroll
+    for (int I = 1; I < NB; ++I)
+#pragma unroll
+      for (int K = 1; K <= I; ++K) {
+        if (K <= J) continue;  // wave-uniform
+        const int t = I * (I + 1) / 2 + K;
+#pragma unroll
+        for (int ks = 0; ks < 4; ++ks) {
+          const T fI = P[pidx(16 * I + r16, 16 * J + 4 * ks + q4)];
+          const T fK = P[pidx(16 * K + r16, 16 * J + 4 * ks + q4)];
+          acc[t] = Mfma<T>::mma(-fI, fK, acc[t]);
+        }
+        if (K == J + 1) {
+          const int col = 16 * K + r16;
+#pragma unroll
+          for (int v = 0; v < 4; ++v) {
+            const int row = 16 * I + Mfma<T>::crow(lane, v);
+            if (col <= row) P[pidx(row, col)] = acc[t][v];
+          }
+        }
+      }
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+  }
+  return info;
+}
+
+template <typename T, int NB>
+__global__ __launch_bounds__(64, 2) void fused_wave_kernel(PosteriorArgs<T> a) {
+  using C = WaveCfg<T, NB>;
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  T* const P = reinterpret_cast<T*>(smem);
+  T* const bvec = reinterpret_cast<T*>(smem + C::OFF_B);
+  double* const scr = reinterpret_cast<double*>(smem + C::OFF_SCR);
+  int* const iscr = reinterpret_cast<int*>(smem + C::OFF_SCR + 32);
+  const int lane = threadIdx.x;
+  constexpr int D = C::DP;
+  const int N = a.N;
+  const double kNaN = __longlong_as_double(0x7ff8000000000000LL);
+
+  for (int64_t reg = blockIdx.x; reg < a.B; reg += gridDim.x) {
+    const BLR_GLOBAL T* mw = as_global(a.mw + reg * a.stridemw);
+    const BLR_GLOBAL T* Lw = as_global(a.Lw + reg * a.strideLw);
+
+    // ---- prior: diagonal precision (reference :78: positive entries, logdet)
+    T dpr = T(1);
+    double logdet_Lw = 0.0;
+    int info = 0;
+    {
+      const bool in = lane < D;
+      if (in) dpr = Lw[lane];
+      const bool ok = !in || (dpr > T(0));
+      const unsigned long long badm = __ballot(!ok);
+      if (badm) info = __ffsll((long long)badm);
+      logdet_Lw = wave_allreduce((in && ok) ? log((double)dpr) : 0.0);
+    }
+    if (info != 0) {  // wave-uniform
+      if (lane == 0) { a.info[reg] = info; if (a.logpdf) a.logpdf[reg] = kNaN; }
+      continue;
+    }
+    if (a.noise_kind == NOISE_DIAGONAL)
+      wave_gram<T, NB, true>(smem, as_global(a.X + reg * a.strideX), a.ldx, as_global(a.y + reg * a.stridey),
+                             as_global(a.s + reg * a.strides), mw, dpr, N);
+    else
+      wave_gram<T, NB, false>(smem, as_global(a.X + reg * a.strideX), a.ldx, as_global(a.y + reg * a.stridey),
+                              as_global(a.s + reg * a.strides), mw, dpr, N);
+    const double quad = scr[0], logdet_Sy = scr[1];
+    if (iscr[0] != 0x7fffffff) {  // Sigma_y is not positive definite: PosDefException(index), as :79 would throw
+      if (lane == 0) { a.info[reg] = iscr[0]; if (a.logpdf) a.logpdf[reg] = kNaN; }
+      __builtin_amdgcn_wave_barrier();
+      continue;
+    }
+#if BLR_EXP >= 1 && BLR_EXP <= 4
+    if (lane == 0) { a.info[reg] = 0; if (a.logpdf) a.logpdf[reg] = quad + (double)P[lane]; }
+    continue;
+#endif
+    if (a.Lw_post) {  // posterior precision Lw' = A, full symmetric (:92)
+      T* out = a.Lw_post + reg * a.strideLp;
+      for (int c = 0; c < D; ++c)
+        if (lane < D) out[(int64_t)c * a.ldlp + lane] = (lane >= c) ? P[pidx(lane, c)] : P[pidx(c, lane)];
+    }
+    info = wave_chol<T, NB>(smem);
+    if (info != 0) {
+      if (lane == 0) { a.info[reg] = info; if (a.logpdf) a.logpdf[reg] = kNaN; }
+      __builtin_amdgcn_wave_barrier();
+      continue;
+    }
+    if (a.T_post) {  // T = L' (upper, column-major), strictly-lower part zero
+      T* out = a.T_post + reg * a.strideT;
+      for (int c = 0; c < D; ++c)
+        if (lane < D) out[(int64_t)c * a.ldt + lane] = (lane <= c) ? P[pidx(c, lane)] : T(0);
+    }
+
+    // ---- m = L^-T u (column-oriented, 8 pivots per block of prefetched rows), |u|^2, logdet A
+    {
+      const bool in = lane < D;
+      T b0 = in ? bvec[lane] : T(0);
+      const T lii = in ? P[pidx(lane, lane)] : T(1);
+      const T r0 = fast_rcp(lii);
+      const double uu = wave_allreduce((double)b0 * (double)b0);
+      const double logdetA = 2.0 * wave_allreduce(in ? log((double)lii) : 0.0);
+      for (int kb = D - 1; kb >= 0; kb -= 8) {
+        T row[8];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) {
+          const int k = kb - u;
+          row[u] = (k >= 0 && lane < k) ? P[pidx(k, 0) + lane] : T(0);
+        }
+#pragma unroll
+        for (int u = 0; u < 8; ++u) {
+          const int k = kb - u;
+          if (k >= 0) {
+            const T mk = readlane(b0, k) * readlane(r0, k);
+            if (lane == k) b0 = mk;
+            b0 -= row[u] * mk;
+          }
+        }
+      }
+      if (a.mw_post && in) a.mw_post[reg * a.stride_mwpost + lane] = mw[lane] + b0;  // :68
+      if (lane == 0) {
+        a.info[reg] = 0;
+        if (a.logpdf) {
+          const double LOG2PI = 1.8378770664093454835606594728112;
+          a.logpdf[reg] = -0.5 * ((double)N * LOG2PI + logdet_Sy + quad + logdetA - logdet_Lw - uu);  // :84 + :57
+        }
+      }
+    }
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();  // P / ring reuse by the next regressor
+  }
+}
+
+}  // namespace blr

@@ -1461,3 +1461,64 @@ def test_update_factor_leaves_the_state_alone_on_failure(B, route, monkeypatch):
     with pytest.raises(B.PosDefException):
         st.condition(np.ones((3, 2)), np.array([1.0, 0.0]), np.zeros(2))
     np.testing.assert_array_equal(st.mw, np.zeros(3))
+
+
+# ---- one wavefront per regressor (blr_fused_wave.hpp): D = 32 / 64, ColVecs, diagonal prior ------------------------------
+@pytest.mark.parametrize("dtype", [np.float64, np.float32])
+@pytest.mark.parametrize("D", [32, 64])
+@pytest.mark.parametrize("N", [0, 1, 7, 8, 16, 17, 100, 1000, 1024])
+@pytest.mark.parametrize("noise", ["diagonal", "isotropic"])
+def test_wave_kernel_shapes_vs_oracle(B, dtype, D, N, noise):
+    # the shapes blr_abi.hip routes to fused_wave_kernel (f64: D = 32 and 64; f32: D = 64; D = 32 in f32 stays on the four-wave
+    # kernel and runs here as its cross-check): whole 4 KiB stages, ragged tails, no data at all, non-zero prior mean
+    a = B._abi
+    h = a.default_handle()
+    rng = _rng(90 + D + N)
+    nb = 5
+    X = rng.standard_normal((nb, N, D)).astype(dtype)  # [N, D] row-major == D x N ColVecs
+    mw = rng.standard_normal((nb, D)).astype(dtype)
+    dpr = np.exp(0.5 * rng.standard_normal((nb, D))).astype(dtype)
+    s = (np.exp(0.4 * rng.standard_normal((nb, max(N, 1)))) if noise == "diagonal" else np.full((nb, 1), 0.3)).astype(dtype)
+    y = rng.standard_normal((nb, max(N, 1))).astype(dtype)
+    mw_post = np.zeros((nb, D), dtype=dtype)
+    T_post = np.zeros((nb, D, D), dtype=dtype)
+    Lw_post = np.zeros((nb, D, D), dtype=dtype)
+    lp = np.zeros(nb)
+    info = np.full(nb, 9, dtype=np.int32)
+    kind = a.NOISE_DIAGONAL if noise == "diagonal" else a.NOISE_ISOTROPIC
+    h.posterior_batched(dtype, a.MEM_HOST, a.LAYOUT_COLVECS, nb, D, N, X, D, N * D, y, max(N, 1), kind, s, s.shape[1], a.PRIOR_DIAGONAL,
+                        mw, D, dpr, 1, D, mw_post, D, T_post, D, D * D, Lw_post, D, D * D, lp, info)
+    assert info.tolist() == [0] * nb
+    rtol = 1e-10 if dtype == np.float64 else 3e-4
+    for b in range(nb):
+        Xb = X[b].T.astype(np.float64)
+        sb = (s[b, :N] if noise == "diagonal" else np.full(N, s[b, 0])).astype(np.float64)
+        mw_o, T_o, L_o = O.posterior_literal(mw[b].astype(np.float64), dpr[b].astype(np.float64), Xb, sb, y[b, :N].astype(np.float64))
+        np.testing.assert_allclose(Lw_post[b].T, L_o, rtol=rtol, atol=rtol * np.abs(L_o).max())
+        Tn = np.triu(T_post[b].T.astype(np.float64))
+        np.testing.assert_allclose(Tn.T @ Tn, L_o, rtol=rtol, atol=rtol * np.abs(L_o).max())
+        assert np.all(np.tril(T_post[b].T, -1) == 0)
+        np.testing.assert_allclose(mw_post[b], mw_o, rtol=100 * rtol, atol=10 * rtol * np.abs(mw_o).max())
+        lp_o = O.logpdf_literal(mw[b].astype(np.float64), dpr[b].astype(np.float64), Xb, sb, y[b, :N].astype(np.float64))
+        assert lp[b] == pytest.approx(lp_o, rel=20 * rtol, abs=20 * rtol)
+
+
+def test_wave_kernel_reports_bad_inputs_per_regressor(B):
+    a = B._abi
+    h = a.default_handle()
+    rng = _rng(91)
+    nb, D, N = 4, 64, 40
+    X = rng.standard_normal((nb, N, D))
+    mw = np.zeros((nb, D))
+    dpr = np.ones((nb, D))
+    dpr[1, 10] = -1.0                       # prior precision not positive definite: info = 11 (reference :78)
+    s = np.exp(0.2 * rng.standard_normal((nb, N)))
+    s[2, 17] = 0.0                          # variance not positive: info = 18 (reference :79)
+    y = rng.standard_normal((nb, N))
+    mw_post = np.zeros((nb, D)); T_post = np.zeros((nb, D, D)); lp = np.zeros(nb); info = np.zeros(nb, dtype=np.int32)
+    h.posterior_batched(np.float64, a.MEM_HOST, a.LAYOUT_COLVECS, nb, D, N, X, D, N * D, y, N, a.NOISE_DIAGONAL, s, N, a.PRIOR_DIAGONAL,
+                        mw, D, dpr, 1, D, mw_post, D, T_post, D, D * D, None, D, D * D, lp, info)
+    assert info.tolist() == [0, 11, 18, 0]
+    assert np.isnan(lp[1]) and np.isnan(lp[2]) and np.isfinite(lp[0]) and np.isfinite(lp[3])
+    lp_o = O.logpdf_literal(mw[3], dpr[3], X[3].T, s[3], y[3])
+    assert lp[3] == pytest.approx(lp_o, rel=1e-10)

@@ -9,6 +9,9 @@
 #include <cstdlib>
 #include <vector>
 #include "blr_fused_small.hpp"
+#ifdef FB_WAVE
+#include "blr_fused_wave.hpp"
+#endif
 using namespace blr;
 #define CK(x) do { hipError_t e_ = (x); if (e_ != hipSuccess) { printf("HIP error %s at %d\n", hipGetErrorString(e_), __LINE__); return 1; } } while (0)
 
@@ -89,13 +92,19 @@ int main(int argc, char** argv) {
   a.mw_post = dmwp; a.stride_mwpost = D; a.T_post = dT; a.ldt = D; a.strideT = D * D; a.Lw_post = nullptr;
   a.logpdf = dlp; a.info = dinfo; a.layout = LAYOUT_COLVECS; a.noise_kind = diag ? NOISE_DIAGONAL : NOISE_ISOTROPIC;
   a.prior_kind = PRIOR_DIAGONAL; a.D = D; a.N = N; a.B = B; a.vec_ok = 1;
+#ifdef FB_WAVE
+  auto kern = fused_wave_kernel<T, NB>;
+  const int kLds = WaveCfg<T, NB>::LDS_BYTES, kBlock = 64, kGrid = std::min(B, 2048);
+#else
   auto kern = fused_small_kernel<T, NB, 4>;
+  const int kLds = C::LDS_BYTES, kBlock = kThreads, kGrid = B;
   CK(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, C::LDS_BYTES));
+#endif
   hipEvent_t e0, e1; CK(hipEventCreate(&e0)); CK(hipEventCreate(&e1));
-  for (int w = 0; w < 2; ++w) hipLaunchKernelGGL(kern, dim3(B), dim3(kThreads), C::LDS_BYTES, 0, a);
+  for (int w = 0; w < 2; ++w) hipLaunchKernelGGL(kern, dim3(kGrid), dim3(kBlock), kLds, 0, a);
   CK(hipDeviceSynchronize());
   CK(hipEventRecord(e0));
-  for (int r = 0; r < reps; ++r) hipLaunchKernelGGL(kern, dim3(B), dim3(kThreads), C::LDS_BYTES, 0, a);
+  for (int r = 0; r < reps; ++r) hipLaunchKernelGGL(kern, dim3(kGrid), dim3(kBlock), kLds, 0, a);
   CK(hipEventRecord(e1)); CK(hipEventSynchronize(e1));
   float ms; CK(hipEventElapsedTime(&ms, e0, e1));
   ms /= reps;
@@ -105,7 +114,7 @@ int main(int argc, char** argv) {
     CK(hipMemcpyToSymbol(HIP_SYMBOL(g_gstamps), zero, sizeof(zero)));
     unsigned long long zero16[16] = {};
     CK(hipMemcpyToSymbol(HIP_SYMBOL(g_pstamps), zero16, sizeof(zero16)));
-    hipLaunchKernelGGL(kern, dim3(B), dim3(kThreads), C::LDS_BYTES, 0, a);
+    hipLaunchKernelGGL(kern, dim3(kGrid), dim3(kBlock), kLds, 0, a);
     CK(hipDeviceSynchronize());
     unsigned long long stp[4][8];
     CK(hipMemcpyFromSymbol(stp, HIP_SYMBOL(g_gstamps), sizeof(stp)));
