@@ -181,7 +181,11 @@ BLR_PHASE void wave_gram(char* smem, const BLR_GLOBAL T* X, int64_t ldx, const B
     if (t + C::DEPTH - 1 < nfull) issue(t + C::DEPTH - 1);  // into the slot stage t - 1 was read from
 #endif
     if constexpr (DIAG) weights(sbuf + sl * C::NSC, t * C::NSC);
+#if BLR_EXP == 5  // streaming only: what the memory system delivers to this access pattern
+    qacc += (double)ring[sl * C::SLOT + lane];
+#else
     compute(ring + sl * C::SLOT, ybuf + sl * C::NSC);
+#endif
   }
   asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
   __builtin_amdgcn_wave_barrier();
@@ -412,7 +416,7 @@ __global__ __launch_bounds__(64, 2) void fused_wave_kernel(PosteriorArgs<T> a) {
       __builtin_amdgcn_wave_barrier();
       continue;
     }
-#if BLR_EXP >= 1 && BLR_EXP <= 4
+#if BLR_EXP >= 1 && BLR_EXP <= 5
     if (lane == 0) { a.info[reg] = 0; if (a.logpdf) a.logpdf[reg] = quad + (double)P[lane]; }
     continue;
 #endif
