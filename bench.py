@@ -184,6 +184,8 @@ class Workload:
 
     def kernel_name(self):
         t = "double" if self.dtype == "f64" else "float"
+        if self.D == 64 or (self.D == 32 and self.dtype == "f64"):
+            return f"fused_wave_kernel<{t}, {self.D // 16}>"  # one wavefront per regressor (diagonal prior, aligned ColVecs)
         if self.D <= 128:
             return f"fused_small_kernel<{t}, {(self.D + 15) // 16}, 4>"  # MODE 4: ColVecs through LDS-DMA
         return f"gram_tile_kernel<{t}>"

@@ -24,6 +24,7 @@ rocprofv3 --pmc WRITE_SIZE --kernel-trace --output-format csv -d $OUT/pmc_write_
 rocprofv3 --pmc $SQ --kernel-trace --output-format csv -d $OUT/pmc_sq_c2 -- $B --steps 5 --warmup 2 > /dev/null 2>&1
 rocprofv3 --pmc $SQ --kernel-trace --output-format csv -d $OUT/pmc_sq_c2f32 -- $B --dtype f32 --steps 5 --warmup 2 > /dev/null 2>&1
 rocprofv3 --pmc $SQ --kernel-trace --output-format csv -d $OUT/pmc_sq_c3 -- $B --config c3 --steps 5 --warmup 2 > /dev/null 2>&1
+rocprofv3 --pmc $SQ --kernel-trace --output-format csv -d $OUT/pmc_sq_c4 -- $B --config c4 --steps 5 --warmup 2 > /dev/null 2>&1
 rocprofv3 --pmc FETCH_SIZE --kernel-trace --output-format csv -d $OUT/pmc_fetch_c4 -- $B --config c4 --steps 5 --warmup 2 > /dev/null 2>&1
 rocprofv3 --pmc WRITE_SIZE --kernel-trace --output-format csv -d $OUT/pmc_write_c4 -- $B --config c4 --steps 5 --warmup 2 > /dev/null 2>&1
 find $OUT -name "*agent_info*" -delete

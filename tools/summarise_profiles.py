@@ -66,15 +66,17 @@ if fetch and write:
                                             "hbm_read_bytes_per_launch": rd, "hbm_write_bytes_per_launch": wr,
                                             "hbm_bytes_per_launch": rd + wr, "units_per_launch": 4096}
 sq2f = counters("pmc_sq_c2f32", "fused_small_kernel")
-f4 = counters("pmc_fetch_c4", "fused_small_kernel")
-w4 = counters("pmc_write_c4", "fused_small_kernel")
+f4 = counters("pmc_fetch_c4", "fused_wave_kernel")
+w4 = counters("pmc_write_c4", "fused_wave_kernel")
 if f4 and w4:
     rd = f4["FETCH_SIZE"] * 1024.0 * 2.0
     wr = w4["WRITE_SIZE"] * 1024.0
-    summary["c4_fused_small_kernel_hbm"] = {"FETCH_SIZE_KiB": f4["FETCH_SIZE"], "WRITE_SIZE_KiB": w4["WRITE_SIZE"],
+    summary["c4_fused_wave_kernel_hbm"] = {"FETCH_SIZE_KiB": f4["FETCH_SIZE"], "WRITE_SIZE_KiB": w4["WRITE_SIZE"],
                                             "hbm_read_bytes_per_launch": rd, "hbm_write_bytes_per_launch": wr,
                                             "hbm_bytes_per_launch": rd + wr, "units_per_launch": 8192}
-for key, c in (("c2_fused_small_kernel_sq", sq2), ("c2_f32_fused_small_kernel_sq", sq2f), ("c3_gram_tile_kernel_sq", sq3)):
+sq4 = counters("pmc_sq_c4", "fused_wave_kernel")
+for key, c in (("c2_fused_small_kernel_sq", sq2), ("c2_f32_fused_small_kernel_sq", sq2f), ("c3_gram_tile_kernel_sq", sq3),
+               ("c4_fused_wave_kernel_sq", sq4)):
     if c:
         ns = c["avg_duration_ns"]
         c["effective_clock_GHz"] = c["GRBM_GUI_ACTIVE"] / 8.0 / ns
