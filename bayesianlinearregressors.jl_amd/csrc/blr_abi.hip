@@ -407,26 +407,30 @@ int posterior_large_one(blr_handle* h, const PosteriorArgs<T>& a, int64_t reg) {
   // costs ~30 us, and the chain's kernels need their own CUs (CU masks: -12.5 % Gram capacity) or run 2x slower when
   // co-resident with Gram workgroups.  Kept for the next step (one column-ordered Gram launch + in-kernel column flags).
   static const bool want_pipeline = getenv("BLR_MI355X_PIPELINE") != nullptr;
-  const bool pipelined = NC >= 2 && want_pipeline;
-  static const int kColWgs = getenv("BLR_MI355X_COL_WGS") ? atoi(getenv("BLR_MI355X_COL_WGS")) : 224;
+  const bool pipelined = NC >= 2 && want_pipeline && !prior_factor;
   std::vector<int> col_split(NC, 0);
-  std::vector<int64_t> col_gp(NC + 1, 0);  // first partial tile of each column's Gpart region
+  std::vector<int64_t> col_gp(NC + 1, 0);
   int max_split_total = nsplit_total;
   size_t upart_elems = 0;
+  int pipe_split = 1;
   if (pipelined) {
-    max_split_total = 0;
-    for (int J = 0; J < NC; ++J) {
-      const int tiles = NC - J;
-      // every block column = one launch of <= 256 workgroups: two of them (one per Gram stream) fill the 512 slots of the
-      // chip in a single round (a 257th workgroup would run in a second round and double the launch's duration)
-      col_split[J] = std::max(1, std::min(std::min(max_split_cols, 64), kColWgs / std::min(tiles, kColWgs)));
-      col_gp[J + 1] = col_gp[J] + (int64_t)(col_split[J] + pf) * tiles;
-      max_split_total = std::max(max_split_total, col_split[J] + pf);
+    // ONE column-ordered Gram launch on the 224-CU partition (448 workgroup slots): the largest split factor whose
+    // ntiles x nsplit workgroups fill whole rounds of those slots
+    const int slots = 448;
+    double bestp = 0.0;
+    for (int sp = 1; sp <= max_split; ++sp) {
+      const int wgs = ntiles * sp;
+      const int rounds = (wgs + slots - 1) / slots;
+      const double eff = (double)wgs / (rounds * (double)slots) - 0.002 * sp + (rounds >= 2 ? 0.05 : 0.0);  // >= 2 rounds: columns finish early
+      if (eff > bestp) { bestp = eff; pipe_split = sp; }
+    }
+    max_split_total = pipe_split;
+    for (int J = 1; J < NC; ++J) {
       const int nr = (DP + 64 - J * kPB) / 64;
       upart_elems = std::max(upart_elems, (size_t)J * (2 * nr - 1) * 64 * 64);
     }
   }
-  const int64_t gp_tiles = pipelined ? col_gp[NC] : (int64_t)nsplit_total * ntiles;
+  const int64_t gp_tiles = pipelined ? (int64_t)pipe_split * ntiles : (int64_t)nsplit_total * ntiles;
 
   // workspace carve
   size_t off = 0;
@@ -440,6 +444,7 @@ int posterior_large_one(blr_handle* h, const PosteriorArgs<T>& a, int64_t reg) {
   const size_t o_q = carve((size_t)gridc * sizeof(double));
   const size_t o_l = carve((size_t)gridc * sizeof(double));
   const size_t o_m = carve((size_t)DP * DP * sizeof(T));  // transposed factor for the back substitution
+  const size_t o_cnt = carve(pipelined ? (size_t)(ntiles + NC) * sizeof(unsigned) : 0);
   const size_t o_sc = carve(64);
   int rc = ensure_ws(h, off);
   if (rc) return rc;
@@ -536,28 +541,25 @@ int posterior_large_one(blr_handle* h, const PosteriorArgs<T>& a, int64_t reg) {
     if ((rc = set_lds<T>(h, reinterpret_cast<const void*>(chol_diag_kernel<T>), SC::LDS_BYTES))) return rc;
     if ((rc = set_lds<T>(h, reinterpret_cast<const void*>(trsm_block_kernel<T>), TC::LDS_BYTES))) return rc;
     if ((rc = set_lds<T>(h, reinterpret_cast<const void*>(left_update_kernel<T>), TrailCfg<T>::LDS_BYTES))) return rc;
+    unsigned* tile_count = reinterpret_cast<unsigned*>(ws + o_cnt);
+    unsigned* col_done = tile_count + ntiles;
+    HIP_TRY(h, hipMemsetAsync(tile_count, 0, (size_t)(ntiles + NC) * sizeof(unsigned), h->stream));
     HIP_TRY(h, hipEventRecord(h->ev_fork, h->stream));
     HIP_TRY(h, hipStreamWaitEvent(h->s_chain, h->ev_fork, 0));
-    for (hipStream_t gs : h->s_gram) HIP_TRY(h, hipStreamWaitEvent(gs, h->ev_fork, 0));
-    HIP_TRY(h, hipStreamWaitEvent(h->s_reduce, h->ev_fork, 0));
-    // Gram block columns, alternating between the two Gram streams (two launches in flight fill the 512 workgroup slots)
-    for (int J = 0; J < NC; ++J) {
-      hipStream_t gs = h->s_gram[((J & 3) == 0 || (J & 3) == 3) ? 0 : 1];  // 8+5+4+1 = 7+6+3+2 tiles: balanced streams
-      g.tile_i0 = J; g.tile_j0 = J; g.tri = 0;
-      r.col_mode = 1; r.tile_i0 = J; r.tile_j0 = J;
-      T* gp = Gpart + col_gp[J] * (kPB * kPB);
-      gram_tiles(gs, col_split[J], NC - J, gp);
-      HIP_TRY(h, hipEventRecord(h->ev_col[2 * J], gs));
-      // the split reduction runs on its own stream: the Gram streams go straight on to their next column
-      HIP_TRY(h, hipStreamWaitEvent(h->s_reduce, h->ev_col[2 * J], 0));
-      gram_reduce(h->s_reduce, col_split[J], NC - J, gp, 1);
-      HIP_TRY(h, hipEventRecord(h->ev_col[2 * J + 1], h->s_reduce));
-    }
+    HIP_TRY(h, hipStreamWaitEvent(h->s_gram[0], h->ev_fork, 0));
+    // ONE Gram launch, tiles column by column; the last partial of a tile triggers its reduction inside the kernel
+    g.tile_i0 = 0; g.tile_j0 = 0; g.tri = 5;
+    g.nsplit = pipe_split; g.ntiles = ntiles; g.Gpart = Gpart; g.xcd_swizzle = 0;
+    g.tile_count = tile_count; g.col_done = col_done;
+    g.Lw = Lw; g.ldl = a.ldl; g.prior_kind = a.prior_kind; g.Abar = Abar; g.lda = lda; g.DP = DP;
+    g.Lw_post = a.Lw_post ? a.Lw_post + reg * a.strideLp : nullptr; g.ldlp = a.ldlp;
+    hipLaunchKernelGGL(gram_tile_kernel<T>, dim3(ntiles * pipe_split), dim3(kThreads), LC::LDS_BYTES, h->s_gram[0], g);
+    HIP_TRY(h, hipEventRecord(h->ev_col[0], h->s_gram[0]));
     // left-looking blocked Cholesky (reference :86, :57), one block column behind the Gram streams at the earliest
     acc4* Upart = reinterpret_cast<acc4*>(ws + o_up);
     const int nrows_total = DP + kPB;
     for (int p = 0; p < NC; ++p) {
-      HIP_TRY(h, hipStreamWaitEvent(h->s_chain, h->ev_col[2 * p + 1], 0));
+      hipLaunchKernelGGL(wait_count_kernel, dim3(1), dim3(64), 0, h->s_chain, (const unsigned*)(col_done + p), (unsigned)(NC - p), info_chol);
       if (p > 0) {
         const int nsub = 2 * ((DP + 64 - p * kPB) / 64) - 1;
         hipLaunchKernelGGL(left_update_kernel<T>, dim3(nsub, p), dim3(kThreads), TrailCfg<T>::LDS_BYTES, h->s_chain, (const T*)Abar, lda, p,
@@ -597,6 +599,7 @@ int posterior_large_one(blr_handle* h, const PosteriorArgs<T>& a, int64_t reg) {
   if (pipelined) {
     HIP_TRY(h, hipEventRecord(h->ev_join, h->s_chain));
     HIP_TRY(h, hipStreamWaitEvent(h->stream, h->ev_join, 0));
+    HIP_TRY(h, hipStreamWaitEvent(h->stream, h->ev_col[0], 0));
   }
   HIP_TRY(h, hipGetLastError());
   return 0;

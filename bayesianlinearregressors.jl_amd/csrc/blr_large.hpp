@@ -151,6 +151,32 @@ __global__ __launch_bounds__(kThreads) void colstats_kernel(ColstatsArgs<T> a) {
 // ---- 128 x 128 macro tile of a (weighted) Gram matrix ---------------------------------------------------------
 // mode_out 0: write the tile (and, for diagonal tiles with r != NULL, b_I) to the split-partial workspace
 // mode_out 1: subtract the tile in place from C (trailing update of the blocked Cholesky; single split)
+// ---- agent-coherent 8-byte accesses (pipelined schedule) ----------------------------------------------------------------
+// On this multi-XCD part an agent-scope FENCE writes back and invalidates the issuing XCD's whole L2: one per workgroup of a
+// Gram launch turned the launch memory-bound (765 -> 1380 us at config 3).  The split-K hand-off therefore uses relaxed
+// agent-scope 8-byte stores / loads (sc1: through the L2 to the coherent level, no fence) for exactly the data that crosses
+// workgroups, with s_waitcnt vmcnt(0) between the data and the counter that publishes it -- the mechanism the wavefront
+// back substitution already uses for its hops.
+__device__ __forceinline__ void st_agent(void* p, unsigned long long v) {
+  __hip_atomic_store(reinterpret_cast<unsigned long long*>(p), v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+__device__ __forceinline__ unsigned long long ld_agent(const void* p) {
+  return __hip_atomic_load(reinterpret_cast<const unsigned long long*>(p), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+template <typename T> struct Word8;  // 8 bytes = 2 floats / 1 double
+template <> struct Word8<float> {
+  static constexpr int N = 2;
+  static __device__ __forceinline__ unsigned long long pack(float a, float b) {
+    return (unsigned long long)__float_as_uint(a) | ((unsigned long long)__float_as_uint(b) << 32);
+  }
+  static __device__ __forceinline__ float get(unsigned long long w, int i) { return __uint_as_float((unsigned)(w >> (32 * i))); }
+};
+template <> struct Word8<double> {
+  static constexpr int N = 1;
+  static __device__ __forceinline__ unsigned long long pack(double a, double) { return (unsigned long long)__double_as_longlong(a); }
+  static __device__ __forceinline__ double get(unsigned long long w, int) { return __longlong_as_double((long long)w); }
+};
+
 template <typename T>
 struct GramTileArgs {
   const T* X; int64_t ldx;   // operand matrix; element (d, n) at X[d + n*ldx] (ColVecs) or X[n + d*ldx] (RowVecs)
@@ -175,6 +201,14 @@ struct GramTileArgs {
   int xcd_swizzle;           // remap blockIdx so that one XCD owns whole N-slices (split-K launches)
   const T* XB; int64_t ldxb; int DB;  // optional SECOND operand for the B side (rows rowB.. of XB, DB rows; same layout);
                                       // NULL: B side = X (Gram / trailing updates)
+  // Pipelined schedule (tri 5, mode 0): tiles are enumerated COLUMN by column (all splits of a tile adjacent, so block column
+  // J of the Gram matrix completes while later columns are still being computed); the workgroup that delivers the LAST
+  // partial of a tile reduces it in fixed split order into Abar (as gram_reduce_kernel) and bumps col_done[J].
+  unsigned* tile_count;      // [ntiles] arrival counters, zeroed by the host (NULL: off)
+  unsigned* col_done;        // [nblocks] finished tiles per block column
+  const T* Lw; int64_t ldl; int prior_kind;  // prior precision added by the reducing workgroup
+  T* Abar; int64_t lda; int DP;
+  T* Lw_post; int64_t ldlp;
 };
 
 template <typename T>
@@ -199,9 +233,19 @@ __global__ __launch_bounds__(kThreads, 2) void gram_tile_kernel(GramTileArgs<T> 
     const int nwg = gridDim.x, xcd = w & 7, qq = nwg >> 3, rr = nwg & 7;
     w = (xcd < rr ? xcd * (qq + 1) : rr * (qq + 1) + (xcd - rr) * qq) + (w >> 3);
   }
-  const int t = w % a.ntiles, sidx = w / a.ntiles;
+  int t = w % a.ntiles, sidx = w / a.ntiles;
   int I, J;
-  if (a.tri == 1) {
+  if (a.tri == 5) {
+    // block column by block column; inside a column the tiles run fastest and the N-slices slowest, so that workgroups
+    // dispatched together stream the SAME columns of X (one L2 fill serves the whole block column, as in the tri 1 order)
+    int jj = 0, off = 0;  // off = tiles in the columns before jj
+    while ((off + (a.nblocks - jj)) * a.nsplit <= w) { off += a.nblocks - jj; ++jj; }
+    const int rem = w - off * a.nsplit, nt_col = a.nblocks - jj;
+    sidx = rem / nt_col;
+    J = jj;
+    I = jj + rem % nt_col;
+    t = off + (I - J);
+  } else if (a.tri == 1) {
     int ii = 0;
     while ((ii + 1) * (ii + 2) / 2 <= t) ++ii;
     I = a.tile_i0 + ii;
@@ -344,16 +388,30 @@ __global__ __launch_bounds__(kThreads, 2) void gram_tile_kernel(GramTileArgs<T> 
   // ---- epilogue ------------------------------------------------------------------------------------------
   if (a.mode_out == 0) {
     T* out = a.Gpart + ((int64_t)sidx * a.ntiles + t) * (kPB * kPB);
+    const bool coherent = a.tile_count != nullptr;
 #pragma unroll
     for (int i = 0; i < 4; ++i)
 #pragma unroll
-      for (int k = 0; k < 4; ++k)
+      for (int k = 0; k < 4; ++k) {
+        const int col = 16 * (4 * wc + k) + (lane & 15);
+        if (coherent) {
+          if constexpr (sizeof(T) == 4) {  // f32 C layout: 4 consecutive rows per lane = two 8-byte words
+            const int row0 = 16 * (4 * wr + i) + 4 * (lane >> 4);
+            st_agent(out + col * kPB + row0, Word8<T>::pack(acc[i][k][0], acc[i][k][1]));
+            st_agent(out + col * kPB + row0 + 2, Word8<T>::pack(acc[i][k][2], acc[i][k][3]));
+          } else {
 #pragma unroll
-        for (int v = 0; v < 4; ++v) {
-          const int row = 16 * (4 * wr + i) + Mfma<T>::crow(lane, v);
-          const int col = 16 * (4 * wc + k) + (lane & 15);
-          out[col * kPB + row] = acc[i][k][v];  // column-major tile: the reduce pass is coalesced both ways
+            for (int v = 0; v < 4; ++v)
+              st_agent(out + col * kPB + 16 * (4 * wr + i) + Mfma<T>::crow(lane, v), Word8<T>::pack(acc[i][k][v], T(0)));
+          }
+        } else {
+#pragma unroll
+          for (int v = 0; v < 4; ++v) {
+            const int row = 16 * (4 * wr + i) + Mfma<T>::crow(lane, v);
+            out[col * kPB + row] = acc[i][k][v];  // column-major tile: the reduce pass is coalesced both ways
+          }
         }
+      }
     if (want_b) {
       __syncthreads();
       const int q = lane >> 4, r = lane & 15;
@@ -364,7 +422,85 @@ __global__ __launch_bounds__(kThreads, 2) void gram_tile_kernel(GramTileArgs<T> 
         double sum = 0.0;
 #pragma unroll
         for (int p = 0; p < 16; ++p) sum += red[p * kPB + tid];
-        a.bpart[((int64_t)sidx * a.nblocks + I) * kPB + tid] = sum;
+        if (coherent) st_agent(a.bpart + ((int64_t)sidx * a.nblocks + I) * kPB + tid, (unsigned long long)__double_as_longlong(sum));
+        else a.bpart[((int64_t)sidx * a.nblocks + I) * kPB + tid] = sum;
+      }
+    }
+    if (a.tile_count != nullptr) {
+      // last arriver reduces the tile (fixed split order: the result does not depend on who arrives last).  No fences: the
+      // partials went out as agent-coherent stores, vmcnt(0) orders them before the counter, the reducer reads them back
+      // with agent-coherent loads and publishes Abar the same way.
+      __shared__ int s_last;
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      __syncthreads();
+      if (tid == 0)
+        s_last = (__hip_atomic_fetch_add(&a.tile_count[t], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == (unsigned)(a.nsplit - 1)) ? 1 : 0;
+      __syncthreads();
+      if (s_last) {
+        constexpr int VW = Word8<T>::N;
+        const int64_t sstride = (int64_t)a.ntiles * (kPB * kPB);
+        const T* src0 = a.Gpart + (int64_t)t * (kPB * kPB);
+        for (int e = tid * VW; e < kPB * kPB; e += kThreads * VW) {
+          const int rl = e % kPB, cl = e / kPB;
+          const int row0 = I * kPB + rl, col = J * kPB + cl;
+          if (col > row0 + VW - 1) continue;
+          const T* src = src0 + e;
+          T sum[VW];
+#pragma unroll
+          for (int q = 0; q < VW; ++q) sum[q] = T(0);
+          int sp = 0;
+          for (; sp + 8 <= a.nsplit; sp += 8) {
+            unsigned long long v[8];
+#pragma unroll
+            for (int u = 0; u < 8; ++u) v[u] = ld_agent(src + (sp + u) * sstride);
+#pragma unroll
+            for (int u = 0; u < 8; ++u)
+#pragma unroll
+              for (int q = 0; q < VW; ++q) sum[q] += Word8<T>::get(v[u], q);
+          }
+          for (; sp < a.nsplit; ++sp) {
+            const unsigned long long v = ld_agent(src + sp * sstride);
+#pragma unroll
+            for (int q = 0; q < VW; ++q) sum[q] += Word8<T>::get(v, q);
+          }
+          T val[2] = {T(0), T(0)};
+#pragma unroll
+          for (int q = 0; q < VW; ++q) {
+            const int row = row0 + q;
+            T x = sum[q];
+            if (row < a.D) {
+              if (col <= row) {
+                if (a.prior_kind == PRIOR_DENSE) x += a.Lw[(int64_t)row * a.ldl + col];
+                else if (a.prior_kind == PRIOR_DIAGONAL && row == col) x += a.Lw[row];
+              }
+            } else {
+              x = (row == col) ? T(1) : T(0);
+            }
+            val[q] = x;
+            if (a.Lw_post && row < a.D && col <= row) {
+              a.Lw_post[(int64_t)col * a.ldlp + row] = x;
+              a.Lw_post[(int64_t)row * a.ldlp + col] = x;
+            }
+          }
+          st_agent(a.Abar + (int64_t)col * a.lda + row0, Word8<T>::pack(val[0], val[1]));  // entries above the diagonal: never read
+        }
+        if (I == J) {  // rhs row block of block column J: row 0 = b', the rest zero
+          for (int e = tid * VW; e < kPB * kPB; e += kThreads * VW) {
+            const int rl = e % kPB, cl = e / kPB;
+            const int col = J * kPB + cl;
+            T v0 = T(0);
+            if (rl == 0 && col < a.D) {
+              double sum = 0.0;
+              for (int sp = 0; sp < a.nsplit; ++sp)
+                sum += __longlong_as_double((long long)ld_agent(a.bpart + ((int64_t)sp * a.nblocks + J) * kPB + cl));
+              v0 = (T)sum;
+            }
+            st_agent(a.Abar + (int64_t)col * a.lda + a.DP + rl, Word8<T>::pack(v0, T(0)));
+          }
+        }
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // Abar before the column counter
+        __syncthreads();
+        if (tid == 0) __hip_atomic_fetch_add(&a.col_done[J], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
       }
     }
   } else {
@@ -700,6 +836,20 @@ __global__ __launch_bounds__(kThreads) void trail_update_kernel(T* M, int64_t ld
         }
       }
     }
+}
+
+// the chain stream's gate: returns when `*cnt >= target` (block column complete).  One lane spins with s_sleep; bounded, so a
+// logic error upstream becomes info = -999 instead of a hung GPU.
+__global__ void wait_count_kernel(const unsigned* cnt, unsigned target, int32_t* info) {
+  if (threadIdx.x != 0) return;
+  long long spins = 0;
+  while (__hip_atomic_load(cnt, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < target) {  // relaxed: no cache invalidation per poll
+    __builtin_amdgcn_s_sleep(64);
+    if (++spins > 4000000LL) {  // ~ seconds
+      if (*info == 0) *info = -999;
+      break;
+    }
+  }
 }
 
 // ---- left-looking update of ONE block column (pipelined large-D path) ---------------------------------------------------
