@@ -294,10 +294,18 @@ __global__ __launch_bounds__(kThreads, 2) void gram_tile_kernel(GramTileArgs<T> 
   for (int i = 0; i < 8; ++i) bacc[i] = 0.0;
 
   // stage loader: one operand side (128 rows starting at row0) into dst
-  auto load_side = [&](T* dst, const T* base, int64_t ldb, int Drows, int row0, int n0) {
+  // full tiles (128 rows, the whole stage inside the column range): scalar-addressed LDS-DMA pieces -- one SGPR base per
+  // piece plus a per-lane offset that never changes -- instead of a bounds-checked 64-bit address per lane and piece (the
+  // piece-issue cost was the measured 18 % of this kernel)
+  const unsigned voffA = glds_lane_offset<T>(a.ldx, lane);
+  const unsigned voffB = glds_lane_offset<T>(a.XB ? a.ldxb : a.ldx, lane);
+  auto load_side = [&](T* dst, const T* base, int64_t ldb, int Drows, int row0, int n0, unsigned voff) {
     const int rows = min(kPB, Drows - row0);  // may be <= 0 for padding blocks: everything zero-filled
     if (a.use_dma) {
-      stage_glds<T, 8, L::KS>(dst, as_global(base + row0), ldb, rows, c1, n0, wave, lane);
+      if (rows == kPB && n0 + L::NSC <= c1 && (3 * ldb + 64) * (int64_t)sizeof(T) < ((int64_t)1 << 31))
+        stage_glds_full<T, 8, L::KS>(dst, as_global(base + row0), ldb, n0, wave, voff);
+      else
+        stage_glds<T, 8, L::KS>(dst, as_global(base + row0), ldb, rows, c1, n0, wave, lane);
     } else {
       int tt = tid;
       asm volatile("" : "+v"(tt));
@@ -336,12 +344,15 @@ __global__ __launch_bounds__(kThreads, 2) void gram_tile_kernel(GramTileArgs<T> 
   auto issue = [&](int st) {
     const int n0 = c0 + st * L::NSC;
     T* slot = slot0 + (st & 1) * L::SLOT;
-    load_side(slot, a.X, a.ldx, a.D, rowA, n0);
-    if (!diag_tile) load_side(slot + L::SIDE, baseB, ldB, rowsB, rowB, n0);
+    // the scalars first: consuming them makes hipcc wait vmcnt(0) (it cannot see the asm-issued pieces), which is free HERE
+    // -- nothing is in flight right after the stage barrier -- and a full memory latency if it comes after this stage's pieces
     if (tid < L::NSC) {
       wbuf[(st & 1) * L::NSC + tid] = in_reg ? T(1) / s_reg : T(0);
       rbuf[(st & 1) * L::NSC + tid] = in_reg ? r_reg : T(0);
     }
+    asm volatile("" ::: "memory");
+    load_side(slot, a.X, a.ldx, a.D, rowA, n0, voffA);
+    if (!diag_tile) load_side(slot + L::SIDE, baseB, ldB, rowsB, rowB, n0, voffB);
     load_scalars(st + 1);  // in flight until the next issue()
   };
 
