@@ -281,6 +281,9 @@ __global__ __launch_bounds__(kThreads, 2) void gram_tile_kernel(GramTileArgs<T> 
   const bool diag_noise = a.noise_kind == NOISE_DIAGONAL;
   const T s_iso = (a.s && !diag_noise) ? a.s[0] : T(1);
   const bool want_b = diag_tile && a.r != nullptr && a.mode_out == 0;
+  // the 64 x 64 quadrant above the diagonal of a diagonal macro tile is never read (the reduction and the in-place update
+  // skip col > row): its wave stays in the barriers and the staging but leaves the matrix pipe to the co-resident workgroup
+  const bool upper_quadrant = diag_tile && wr == 0 && wc == 1;
 
   acc4 acc[4][4];
 #pragma unroll
@@ -383,10 +386,12 @@ __global__ __launch_bounds__(kThreads, 2) void gram_tile_kernel(GramTileArgs<T> 
 #pragma unroll
       for (int i = 0; i < 4; ++i) { fa[i] = na[i] * nw; fb[i] = nb[i]; }
       if (j + 1 < L::KS) load_frags(j + 1);
+      if (!upper_quadrant) {
 #pragma unroll
-      for (int i = 0; i < 4; ++i)
+        for (int i = 0; i < 4; ++i)
 #pragma unroll
-        for (int k = 0; k < 4; ++k) acc[i][k] = Mfma<T>::mma(fa[i], fb[k], acc[i][k]);
+          for (int k = 0; k < 4; ++k) acc[i][k] = Mfma<T>::mma(fa[i], fb[k], acc[i][k]);
+      }
       if (want_b && (j & 3) == wave) {
         const T rn = rb[4 * j + (lane >> 4)];
 #pragma unroll
