@@ -87,7 +87,7 @@ __device__ __forceinline__ void glds16(const BLR_GLOBAL void* src, const void* d
 template <int SIZE, int LANES = 64>
 __device__ __forceinline__ void glds_s(uint64_t saddr_uniform, unsigned voff, unsigned lds_addr_uniform) {
   static_assert((SIZE == 16 && LANES == 64) || SIZE == 4, "LDS-DMA piece width");
-  static_assert(LANES == 64 || LANES == 32 || LANES == 16, "active lanes of the piece");
+  static_assert(LANES == 64 || LANES == 32 || LANES == 16 || LANES == 8, "active lanes of the piece");
   // Call from wave-uniform control flow.  The LDS address goes through v_readfirstlane INSIDE the asm: hipcc hands an
   // "s" operand over in a VGPR when its own analysis calls the value divergent (the assembler then rejects the
   // s_mov -- a build failure, never a silent one; the 64-bit base must really be scalar for the same reason).
@@ -127,7 +127,7 @@ __device__ __forceinline__ void glds_s(uint64_t saddr_uniform, unsigned voff, un
         "s_mov_b64 exec, %2\n\t"
         "s_mov_b32 m0, %0"
         : "=&s"(keep), "=&s"(m0v), "=&s"(keep_exec)
-        : "v"(lds_addr_uniform), "v"(voff), "s"(saddr_uniform), "s"((uint64_t)(LANES == 32 ? 0xffffffffull : 0xffffull))
+        : "v"(lds_addr_uniform), "v"(voff), "s"(saddr_uniform), "s"((uint64_t)(LANES == 32 ? 0xffffffffull : (LANES == 16 ? 0xffffull : 0xffull)))
         : "memory");
   }
 }

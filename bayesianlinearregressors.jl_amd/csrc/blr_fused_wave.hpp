@@ -25,9 +25,12 @@ template <typename T, int NB>
 struct WaveCfg {
   static constexpr int DP = 16 * NB;
   static constexpr int NT = NB * (NB + 1) / 2;
-  static constexpr int KS = 64 / (NB * (int)sizeof(T));  // k-steps per stage: every stage is 4 KiB of X
+#ifndef BLR_WAVE_STAGE_BYTES
+#define BLR_WAVE_STAGE_BYTES 4096
+#endif
+  static constexpr int KS = (BLR_WAVE_STAGE_BYTES / 64) / (NB * (int)sizeof(T));  // k-steps per stage: every stage is 4 KiB of X
   static constexpr int NSC = 4 * KS;                   // columns per stage
-  static constexpr int DEPTH = 4;                      // ring slots: three stages in flight while one is consumed
+  static constexpr int DEPTH = 16384 / BLR_WAVE_STAGE_BYTES;  // ring slots (16 KiB): all but one in flight while one is consumed
   static constexpr int SLOT = KS * NB * 64;            // elements per ring slot (fragment order [k-step][row block][lane])
   static constexpr int PACKED = DP * (DP + 1) / 2;
   static constexpr int RING_BYTES = DEPTH * SLOT * (int)sizeof(T);
@@ -43,8 +46,8 @@ struct WaveCfg {
   static constexpr int NG = KS * NB / FPG;                               // X pieces per stage
   static constexpr int YL = NSC * (int)sizeof(T) / 4;                    // dword lanes of the y / s piece of a stage
   static_assert(NB % FPG == 0, "pieces must not straddle k-steps");
-  static_assert(KS >= 1 && KS * NB * 16 * 4 * (int)sizeof(T) == 4096, "4 KiB stages");
-  static_assert(YL == 16 || YL == 32, "y piece");
+  static_assert(KS >= 1 && KS * NB * 16 * 4 * (int)sizeof(T) == BLR_WAVE_STAGE_BYTES, "whole stages");
+  static_assert(YL == 8 || YL == 16 || YL == 32, "y piece");
 };
 
 // The three phases are separate NOINLINE functions that hand their results over through LDS (as blr_fused_small.hpp does):
@@ -172,10 +175,18 @@ BLR_PHASE void wave_gram(char* smem, const BLR_GLOBAL T* X, int64_t ldx, const B
 #pragma unroll 1
   for (int t = 0; t < nfull; ++t) {
     const int sl = t & (C::DEPTH - 1);
-    const int rem = nfull - 1 - t;  // stages issued after stage t: min(rem, 2)
-    if (rem >= 2) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(2 * PPS) : "memory");
-    else if (rem == 1) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(PPS) : "memory");
-    else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    const int rem = nfull - 1 - t;  // stages issued after stage t: min(rem, DEPTH - 2)
+    if (rem >= C::DEPTH - 2) asm volatile("s_waitcnt vmcnt(%0)" ::"n"((C::DEPTH - 2) * PPS) : "memory");
+    else if constexpr (C::DEPTH > 4) {
+      if (rem >= 4) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(4 * PPS) : "memory");
+      else if (rem == 3) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(3 * PPS) : "memory");
+      else if (rem == 2) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(2 * PPS) : "memory");
+      else if (rem == 1) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(PPS) : "memory");
+      else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    } else {
+      if (rem == 1) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(PPS) : "memory");
+      else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    }
     __builtin_amdgcn_wave_barrier();
 #if BLR_EXP != 4
     if (t + C::DEPTH - 1 < nfull) issue(t + C::DEPTH - 1);  // into the slot stage t - 1 was read from
