@@ -16,9 +16,10 @@
 // Orthogonal transformations only: T' stays a valid factor however ill-conditioned A is (no downdating anywhere).
 //
 // One workgroup per regressor (four waves load / store, wave 0 sweeps); T lives in LDS as packed upper rows with the u column appended (row j: columns j..D), the
-// rotation of step j is a readlane + 2 FMAs per owned column.  The sweep is a serial chain of D steps per observation
-// (~120 cycles each), so it wins for SMALL k only: blr_update_factor_* routes k > kSweepMaxK (and D > 128) to the in-place
-// re-factorisation of the same state (PRIOR_UPPER_FACTOR), whose cost does not depend on k.  Measured crossover: DESIGN.md.
+// rotation of step j is a readlane + 2 FMAs per owned column.  The sweep is a serial chain of D dependent rotations per
+// observation (measured ~40 us per observation at D = 128: readlane -> a^2 + b^2 -> rsqrt -> c, s -> FMA), so it wins for a
+// single new observation only; blr_update_factor_* routes everything else to the in-place re-factorisation of the same state
+// (PRIOR_UPPER_FACTOR), whose cost does not depend on k.  Measured crossover: DESIGN.md K10, tools/update_bench.py.
 #pragma once
 #include "blr_common.hpp"
 
