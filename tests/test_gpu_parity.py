@@ -1522,3 +1522,33 @@ def test_wave_kernel_reports_bad_inputs_per_regressor(B):
     assert np.isnan(lp[1]) and np.isnan(lp[2]) and np.isfinite(lp[0]) and np.isfinite(lp[3])
     lp_o = O.logpdf_literal(mw[3], dpr[3], X[3].T, s[3], y[3])
     assert lp[3] == pytest.approx(lp_o, rel=1e-10)
+
+
+def test_wave_kernel_is_bitwise_reproducible(B):
+    # fixed accumulation order, no atomics: the same inputs give the same bits, whatever wave of whatever CU picks a regressor up
+    import torch
+
+    a = B._abi
+    h = a.default_handle()
+    dev = torch.device("cuda:0")
+    nb, D, N = 3000, 64, 333
+    g = torch.Generator(device=dev).manual_seed(5)
+    X = torch.randn((nb, N, D), generator=g, dtype=torch.float64, device=dev)
+    y = torch.randn((nb, N), generator=g, dtype=torch.float64, device=dev)
+    s = torch.exp(0.3 * torch.randn((nb, N), generator=g, dtype=torch.float64, device=dev))
+    mw = torch.randn((nb, D), generator=g, dtype=torch.float64, device=dev)
+    dpr = torch.ones((D,), dtype=torch.float64, device=dev)
+    outs = []
+    for _ in range(2):
+        mp = torch.empty((nb, D), dtype=torch.float64, device=dev)
+        Tp = torch.empty((nb, D, D), dtype=torch.float64, device=dev)
+        lp = torch.empty((nb,), dtype=torch.float64, device=dev)
+        info = torch.empty((nb,), dtype=torch.int32, device=dev)
+        h.posterior_batched(np.float64, a.MEM_DEVICE, a.LAYOUT_COLVECS, nb, D, N, X.data_ptr(), D, N * D, y.data_ptr(), N, a.NOISE_DIAGONAL,
+                            s.data_ptr(), N, a.PRIOR_DIAGONAL, mw.data_ptr(), D, dpr.data_ptr(), 1, 0, mp.data_ptr(), D, Tp.data_ptr(), D,
+                            D * D, None, D, D * D, lp.data_ptr(), info.data_ptr())
+        torch.cuda.synchronize()
+        assert int(info.abs().sum().item()) == 0
+        outs.append((mp, Tp, lp))
+    for u, v in zip(outs[0], outs[1]):
+        assert torch.equal(u, v)
