@@ -69,6 +69,8 @@ for _suf in ("f64", "f32"):
     _SIGS[f"blr_posterior_batched_{_suf}"] = (
         [_H, _int, _int, _i64, _i64, _i64, _vp, _i64, _i64, _vp, _i64, _int, _vp, _i64, _int, _vp, _i64, _vp, _i64, _i64,
          _vp, _i64, _vp, _i64, _i64, _vp, _i64, _i64, _vp, _vp], _int)
+    _SIGS[f"blr_posterior_nsharded_{_suf}"] = (
+        [_H, _int, _i64, _i64, _i64, _vp, _i64, _vp, _int, _vp, _int, _vp, _vp, _i64, _vp, _i64, _vp, _vp, _vp, _i64, _vp, _i64, _vp, _vp], _int)
     _SIGS[f"blr_update_factor_{_suf}"] = (
         [_H, _int, _int, _i64, _i64, _i64, _vp, _i64, _i64, _vp, _i64, _int, _vp, _i64, _vp, _i64, _vp, _i64, _i64, _vp, _vp], _int)
     _SIGS[f"blr_posterior_{_suf}"] = (
@@ -218,6 +220,14 @@ class Handle:
         return self.check(fn(self._h, memspace, layout, B, D, N, _ptr(X), ldx, strideX, _ptr(y), stridey, noise_kind,
                              _ptr(s), strides, prior_kind, _ptr(mw), stridemw, _ptr(Lw), ldl, strideLw,
                              _ptr(mw_post), stride_mwpost, _ptr(T_post), ldt, strideT, _ptr(Lw_post), ldlp, strideLp,
+                             _ptr(logpdf), _ptr(info)))
+
+    def posterior_nsharded(self, dtype, layout, D, N_local, N_total, X, ldx, y, noise_kind, s, prior_kind, mw, Lw, ldl, stats, lds,
+                           scal, mw_post, T_post, ldt, Lw_post, ldlp, logpdf, info):
+        """One regressor with its observations split over the ranks of comm_init (device pointers); blr_posterior_nsharded_*."""
+        fn = getattr(self.lib, f"blr_posterior_nsharded_{suffix(dtype)}")
+        return self.check(fn(self._h, layout, D, N_local, N_total, _ptr(X), ldx, _ptr(y), noise_kind, _ptr(s), prior_kind, _ptr(mw),
+                             _ptr(Lw), ldl, _ptr(stats), lds, _ptr(scal), _ptr(mw_post), _ptr(T_post), ldt, _ptr(Lw_post), ldlp,
                              _ptr(logpdf), _ptr(info)))
 
     def update_factor(self, dtype, memspace, layout, B, D, k, X, ldx, strideX, y, stridey, noise_kind, s, strides, mw, stridemw,

@@ -2536,6 +2536,26 @@ int blr_allreduce_sum(blr_handle* h, int is_f64, void* buf, int64_t count) {
   return 0;
 }
 
+// One regressor, its observations split over the ranks of the handle's communicator: statistics of the local columns, ONE
+// in-place all-reduce of the (DP + 128) x DP statistics matrix and one of the two scalars, redundant finish on every rank.
+#define BLR_DEFINE_NSHARDED(SUF, T, IS64)                                                                               \
+  int blr_posterior_nsharded_##SUF(blr_handle* h, int layout, int64_t D, int64_t N_local, int64_t N_total, const T* X,  \
+                                   int64_t ldx, const T* y, int noise_kind, const T* s, int prior_kind, const T* mw,    \
+                                   const T* Lw, int64_t ldl, T* stats, int64_t lds, double* scal, T* mw_post,           \
+                                   T* T_post, int64_t ldt, T* Lw_post, int64_t ldlp, double* logpdf, int32_t* info) {   \
+    if (!h) return -1;                                                                                                  \
+    const int64_t DP = (D + 127) / 128 * 128;                                                                           \
+    int rc = gram_stats<T>(h, layout, D, N_local, X, ldx, y, noise_kind, s, mw, stats, lds, scal);                     \
+    if (rc) return rc;                                                                                                  \
+    if ((rc = blr_allreduce_sum(h, IS64, stats, lds * DP))) return rc;                                                  \
+    if ((rc = blr_allreduce_sum(h, 1, scal, 2))) return rc;                                                             \
+    return posterior_from_stats<T>(h, D, N_total, stats, lds, scal, prior_kind, mw, Lw, ldl, mw_post, T_post, ldt,      \
+                                   Lw_post, ldlp, logpdf, info);                                                        \
+  }
+BLR_DEFINE_NSHARDED(f64, double, 1)
+BLR_DEFINE_NSHARDED(f32, float, 0)
+#undef BLR_DEFINE_NSHARDED
+
 int blr_logpdf_sum(blr_handle* h, int memspace, int64_t B, const double* logpdf, double* total) {
   if (!h) return -1;
   h->err.clear();

@@ -334,6 +334,20 @@ int blr_comm_size(blr_handle* h);
 int blr_comm_rank(blr_handle* h);
 int blr_logpdf_allgather_sum(blr_handle* h, int64_t count, const double* logpdf_local, double* logpdf_all, double* total);
 int blr_allreduce_sum(blr_handle* h, int is_f64, void* buf, int64_t count);
+/* The N-sharded single regressor in ONE call per rank: blr_gram_stats_* on this rank's N_local columns, the
+ * in-place all-reduce of `stats` (lds * DP elements, DP = 128 ceil(D/128)) and `scal` over the handle's communicator, then
+ * blr_posterior_from_stats_* -- every rank ends with the same posterior and evidence of all N_total observations.  `stats`
+ * ((DP + 128) x DP, lds >= DP + 128) and `scal` (2 doubles) are caller-provided device scratch; all pointers device.
+ * Without a communicator it is the single-GPU update through the statistics path. */
+int blr_posterior_nsharded_f64(blr_handle* h, int layout, int64_t D, int64_t N_local, int64_t N_total, const double* X,
+                               int64_t ldx, const double* y, int noise_kind, const double* s, int prior_kind,
+                               const double* mw, const double* Lw, int64_t ldl, double* stats, int64_t lds, double* scal,
+                               double* mw_post, double* T_post, int64_t ldt, double* Lw_post, int64_t ldlp, double* logpdf,
+                               int32_t* info);
+int blr_posterior_nsharded_f32(blr_handle* h, int layout, int64_t D, int64_t N_local, int64_t N_total, const float* X,
+                               int64_t ldx, const float* y, int noise_kind, const float* s, int prior_kind, const float* mw,
+                               const float* Lw, int64_t ldl, float* stats, int64_t lds, double* scal, float* mw_post,
+                               float* T_post, int64_t ldt, float* Lw_post, int64_t ldlp, double* logpdf, int32_t* info);
 
 #ifdef __cplusplus
 }

@@ -557,6 +557,37 @@ function comm_init!(nranks::Integer, rank::Integer, id::Vector{UInt8})
     GC.@preserve id check(h, ccall((:blr_comm_init, LIB), Cint, (Ptr{Cvoid}, Cint, Cint, Ptr{Cvoid}), h, nranks, rank, id))
 end
 comm_destroy!() = (h = handle(); check(h, ccall((:blr_comm_destroy, LIB), Cint, (Ptr{Cvoid},), h)))
+
+"""
+    posterior_nsharded!(mw_post, T_post, logpdf, info, stats, scal, X, y, s, mw, Λdiag; D, N_local, N_total)
+
+ONE regressor whose observations are split over the ranks of `comm_init!` (SURVEY §8e): this rank's `N_local` columns of X
+(D×N_local, device), diagonal noise `s`, diagonal prior `Λdiag`; `stats` ((128⌈D/128⌉+128) × 128⌈D/128⌉) and `scal` (2 Float64)
+are device scratch.  Every rank ends with the same posterior (`mw_post`, upper factor `T_post`) and evidence of all `N_total`
+observations: local statistics, one in-place all-reduce, redundant D×D finish.
+"""
+function posterior_nsharded!(mw_post::DeviceArray{T}, T_post::DeviceArray{T}, lp::DeviceArray{Float64}, info::DeviceArray{Int32},
+                             stats::DeviceArray{T}, scal::DeviceArray{Float64}, X::DeviceArray{T}, y::DeviceArray{T},
+                             s::DeviceArray{T}, mw::DeviceArray{T}, Λdiag::DeviceArray{T}; D::Int, N_local::Int, N_total::Int) where {T<:Elt}
+    h = handle()
+    lds = 128 * cld(D, 128) + 128
+    rc = if T === Float64
+        ccall((:blr_posterior_nsharded_f64, LIB), Cint,
+              (Ptr{Cvoid}, Cint, Int64, Int64, Int64, Ptr{T}, Int64, Ptr{T}, Cint, Ptr{T}, Cint, Ptr{T}, Ptr{T}, Int64, Ptr{T}, Int64,
+               Ptr{Cdouble}, Ptr{T}, Ptr{T}, Int64, Ptr{T}, Int64, Ptr{Cdouble}, Ptr{Int32}),
+              h, COLVECS, D, N_local, N_total, X.ptr, D, y.ptr, DIAGONALN, s.ptr, P_DIAG, mw.ptr, Λdiag.ptr, 1, stats.ptr, lds,
+              scal.ptr, mw_post.ptr, T_post.ptr, D, Ptr{T}(C_NULL), D, lp.ptr, info.ptr)
+    else
+        ccall((:blr_posterior_nsharded_f32, LIB), Cint,
+              (Ptr{Cvoid}, Cint, Int64, Int64, Int64, Ptr{T}, Int64, Ptr{T}, Cint, Ptr{T}, Cint, Ptr{T}, Ptr{T}, Int64, Ptr{T}, Int64,
+               Ptr{Cdouble}, Ptr{T}, Ptr{T}, Int64, Ptr{T}, Int64, Ptr{Cdouble}, Ptr{Int32}),
+              h, COLVECS, D, N_local, N_total, X.ptr, D, y.ptr, DIAGONALN, s.ptr, P_DIAG, mw.ptr, Λdiag.ptr, 1, stats.ptr, lds,
+              scal.ptr, mw_post.ptr, T_post.ptr, D, Ptr{T}(C_NULL), D, lp.ptr, info.ptr)
+    end
+    check(h, rc)
+    return nothing
+end
+
 comm_size() = ccall((:blr_comm_size, LIB), Cint, (Ptr{Cvoid},), handle())
 comm_rank() = ccall((:blr_comm_rank, LIB), Cint, (Ptr{Cvoid},), handle())
 "all-gather of every rank's `count` log evidences + the same fixed-order sum on every rank; returns the total"

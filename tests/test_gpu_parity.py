@@ -1552,3 +1552,53 @@ def test_wave_kernel_is_bitwise_reproducible(B):
         outs.append((mp, Tp, lp))
     for u, v in zip(outs[0], outs[1]):
         assert torch.equal(u, v)
+
+
+@pytest.mark.parametrize("with_comm", [False, True])
+@pytest.mark.parametrize("D,N,dtype", [(300, 700, np.float64), (64, 333, np.float64), (200, 1000, np.float32)])
+def test_posterior_nsharded_one_call(B, with_comm, D, N, dtype):
+    # blr_posterior_nsharded_*: statistics -> all-reduce over the handle's communicator -> finish, in one call per rank.  One
+    # rank here (with and without a real 1-rank RCCL communicator); the multi-rank sum itself is covered by the gloo tests.
+    import torch
+    from blr_amd import _abi
+
+    dev = torch.device("cuda:0")
+    tdt = torch.float64 if dtype == np.float64 else torch.float32
+    rng = _rng(95 + D)
+    X = rng.standard_normal((D, N)).astype(dtype)
+    mw = rng.standard_normal(D).astype(dtype)
+    dpr = np.exp(0.3 * rng.standard_normal(D)).astype(dtype)
+    s = np.exp(0.3 * rng.standard_normal(N)).astype(dtype)
+    y = rng.standard_normal(N).astype(dtype)
+    DP = (D + 127) // 128 * 128
+    lds = DP + 128
+    h = _abi.Handle(0)
+    try:
+        if with_comm:
+            h.comm_init(1, 0, _abi.Handle.comm_unique_id())
+        Xd = torch.tensor(X.T.copy(), dtype=tdt, device=dev)  # [N, D] row-major == D x N ColVecs
+        yd, sd, mwd, dd = (torch.tensor(v, dtype=tdt, device=dev) for v in (y, s, mw, dpr))
+        stats = torch.zeros((DP, lds), dtype=tdt, device=dev)
+        scal = torch.zeros(2, dtype=torch.float64, device=dev)
+        mp = torch.zeros(D, dtype=tdt, device=dev)
+        Tp = torch.zeros((D, D), dtype=tdt, device=dev)
+        lp = torch.zeros(1, dtype=torch.float64, device=dev)
+        info = torch.full((1,), 5, dtype=torch.int32, device=dev)
+        torch.cuda.synchronize()
+        h.posterior_nsharded(dtype, _abi.LAYOUT_COLVECS, D, N, N, Xd.data_ptr(), D, yd.data_ptr(), _abi.NOISE_DIAGONAL, sd.data_ptr(),
+                             _abi.PRIOR_DIAGONAL, mwd.data_ptr(), dd.data_ptr(), 1, stats.data_ptr(), lds, scal.data_ptr(), mp.data_ptr(),
+                             Tp.data_ptr(), D, None, D, lp.data_ptr(), info.data_ptr())
+        h.synchronize()
+        assert info.item() == 0
+        f64 = lambda a: np.asarray(a, dtype=np.float64)
+        mw_o, T_o, L_o = O.posterior_literal(f64(mw), f64(dpr), f64(X), f64(s), f64(y))
+        lp_o = O.logpdf_literal(f64(mw), f64(dpr), f64(X), f64(s), f64(y))
+        rtol = 1e-9 if dtype == np.float64 else 3e-4
+        Tn = np.triu(Tp.cpu().numpy().T.astype(np.float64))
+        np.testing.assert_allclose(Tn.T @ Tn, L_o, rtol=rtol, atol=rtol * np.abs(L_o).max())
+        np.testing.assert_allclose(mp.cpu().numpy(), mw_o, rtol=100 * rtol, atol=10 * rtol * np.abs(mw_o).max())
+        assert lp.item() == pytest.approx(lp_o, rel=20 * rtol)
+        if with_comm:
+            h.comm_destroy()
+    finally:
+        h.close()
