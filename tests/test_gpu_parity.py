@@ -1538,6 +1538,7 @@ def test_wave_kernel_is_bitwise_reproducible(B):
     s = torch.exp(0.3 * torch.randn((nb, N), generator=g, dtype=torch.float64, device=dev))
     mw = torch.randn((nb, D), generator=g, dtype=torch.float64, device=dev)
     dpr = torch.ones((D,), dtype=torch.float64, device=dev)
+    torch.cuda.synchronize()  # the inputs were produced on torch's stream, the handle launches on its own
     outs = []
     for _ in range(2):
         mp = torch.empty((nb, D), dtype=torch.float64, device=dev)
