@@ -1414,6 +1414,7 @@ def test_update_factor_device_batched(B, dtype, D, k, noise, route, monkeypatch)
     lp = torch.zeros(nb, dtype=torch.float64, device=dev)
     info = torch.full((nb,), 7, dtype=torch.int32, device=dev)
     kind = a.NOISE_DIAGONAL if noise == "diagonal" else a.NOISE_ISOTROPIC
+    torch.cuda.synchronize()  # torch's fills / copies before the handle's stream touches the buffers
     h.update_factor(dtype, a.MEM_DEVICE, a.LAYOUT_COLVECS, nb, D, k, Xd.data_ptr(), D, k * D, yd.data_ptr(), k, kind, sd.data_ptr(),
                     k if noise == "diagonal" else 0, mwd.data_ptr(), D, Td.data_ptr(), D, D * D, lp.data_ptr(), info.data_ptr())
     torch.cuda.synchronize()
@@ -1452,6 +1453,7 @@ def test_update_factor_leaves_the_state_alone_on_failure(B, route, monkeypatch):
     sd = torch.tensor([0.5, 0.2, -0.1, 0.3], dtype=torch.float64, device=dev)
     lp = torch.zeros(1, dtype=torch.float64, device=dev)
     info = torch.zeros(1, dtype=torch.int32, device=dev)
+    torch.cuda.synchronize()
     h.update_factor(np.float64, a.MEM_DEVICE, a.LAYOUT_COLVECS, 1, D, k, Xd.data_ptr(), D, 0, yd.data_ptr(), 0, a.NOISE_DIAGONAL,
                     sd.data_ptr(), 0, mwd.data_ptr(), 0, Td.data_ptr(), D, 0, lp.data_ptr(), info.data_ptr())
     torch.cuda.synchronize()
