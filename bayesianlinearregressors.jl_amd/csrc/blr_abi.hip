@@ -245,7 +245,7 @@ int launch_fused_small_mode(blr_handle* h, const PosteriorArgs<T>& a) {
   return launch_fused_small<T, NB, 0>(h, a);
 }
 
-// D = 32 / 64, ColVecs with aligned columns, diagonal prior: one wavefront per regressor (blr_fused_wave.hpp)
+// D = 32 / 64, ColVecs with aligned columns: one wavefront per regressor (blr_fused_wave.hpp)
 template <typename T, int NB>
 int launch_fused_wave(blr_handle* h, const PosteriorArgs<T>& a) {
   using C = WaveCfg<T, NB>;
@@ -259,7 +259,7 @@ template <typename T>
 int dispatch_fused_small(blr_handle* h, const PosteriorArgs<T>& a) {
   int NB = (a.D + 15) / 16;
   static const bool no_wave = getenv("BLR_MI355X_NO_WAVE_KERNEL") != nullptr;
-  if (!no_wave && a.layout == BLR_LAYOUT_COLVECS && a.vec_ok && a.prior_kind == PRIOR_DIAGONAL && a.D == 16 * NB &&
+  if (!no_wave && a.layout == BLR_LAYOUT_COLVECS && a.vec_ok && a.D == 16 * NB &&
       (3 * a.ldx + 64) * (int64_t)sizeof(T) < ((int64_t)1 << 31)) {
     if (NB == 4) return launch_fused_wave<T, 4>(h, a);
     if constexpr (sizeof(T) == 8) {
@@ -2154,13 +2154,13 @@ int update_factor(blr_handle* h, int memspace, int layout, int64_t B, int64_t D,
                   int64_t stridemw, T* Tf, int64_t ldt, int64_t strideT, double* logpdf, int32_t* info) {
   if (!h) return -1;
   h->err.clear();
-  // Route (measured, tools/update_bench.py, DESIGN.md "rank-k update"): a sweep costs ~40 us per observation at D = 128
-  // (a serial chain of D rotations), the in-place re-factorisation ~99 us per CALL whatever k is -- the sweep wins for a
-  // single new observation (1.1x at B = 1, 1.5-2x batched) and for two when D <= 64 and the batch fills the chip.
-  // BLR_MI355X_SWEEP=always / never overrides (tests exercise both routes on the same inputs).
+  // Route (measured, tools/update_bench.py): a sweep costs ~40 us per observation at D = 128 (a serial chain
+  // of D rotations), the in-place re-factorisation ~99 us per CALL whatever k is (45 us at D = 64, where batches run on the
+  // one-wave-per-regressor kernel at 27 M updates/s) -- the sweep wins for a single new observation, except in large
+  // batches at D <= 64.  BLR_MI355X_SWEEP=always / never overrides (tests exercise both routes on the same inputs).
   const char* mode = getenv("BLR_MI355X_SWEEP");
   const bool can_sweep = D >= 1 && D <= kSweepMaxD && k >= 0 && k <= kSweepMaxK;
-  bool sweep = can_sweep && (k <= 1 || (D <= 64 && k <= 2 && B >= 64));
+  bool sweep = can_sweep && k <= 1 && (D > 64 || B < 256);
   if (mode && !strcmp(mode, "always")) sweep = can_sweep;
   if (mode && !strcmp(mode, "never")) sweep = false;
   if (!sweep) {

@@ -1,5 +1,5 @@
 // One WAVEFRONT per regressor: the fused posterior update for D = 32 / 64 (config 4 of BASELINE.json: batches of small
-// independent regressors), ColVecs data with 16-byte aligned columns, diagonal prior precision.
+// independent regressors), ColVecs data with 16-byte aligned columns; every prior kind.
 //
 //   reference src/bayesian_linear_regression.jl:55-69, :72-89 (logpdf + posterior; the same direct Gram form as
 //   blr_fused_small.hpp:  A = Lw + X S^-1 X',  b = X S^-1 (y - X'mw),  A = L L',  u = L^-1 b,  m = L^-T u)
@@ -15,7 +15,7 @@
 //   * the 64 rows of a panel of the blocked Cholesky are exactly one row per lane;
 //   * 18 KB of LDS per wave -> 8 waves per CU, two per SIMD: while one factors / substitutes on the vector ALU the other
 //     keeps the matrix pipe busy.
-// Anything outside the fast path (RowVecs, unaligned or ragged D, dense / factor priors) stays on blr_fused_small.hpp.
+// Anything outside the fast path (RowVecs, unaligned columns, D not 32 / 64) stays on blr_fused_small.hpp.
 #pragma once
 #include "blr_fused_small.hpp"
 
@@ -62,7 +62,7 @@ struct WaveCfg {
 // operations in the loop are these pieces and the stage's arrival is a COUNTED s_waitcnt vmcnt(2 x pieces-per-stage).
 template <typename T, int NB, bool DIAG>
 BLR_PHASE void wave_gram(char* smem, const BLR_GLOBAL T* X, int64_t ldx, const BLR_GLOBAL T* y, const BLR_GLOBAL T* s,
-                         const BLR_GLOBAL T* mw, T dpr, int N) {
+                         const BLR_GLOBAL T* mw, T dpr, int N, int prior_kind, const BLR_GLOBAL T* Lw, int64_t ldl) {
   using C = WaveCfg<T, NB>;
   using acc4 = typename Mfma<T>::acc4;
   constexpr int VEC = Mfma<T>::VEC;
@@ -118,7 +118,7 @@ BLR_PHASE void wave_gram(char* smem, const BLR_GLOBAL T* X, int64_t ldx, const B
       glds_s<4, C::YL>(uni((int64_t)(uintptr_t)(s + n0)), (unsigned)(lane * 4), sbuf_addr + (unsigned)(sl * C::NSC * (int)sizeof(T)));
   };
   // one stage of compute: KS k-steps on the slot image, y from yb, weights from wbuf (DIAG)
-  auto compute = [&](const T* slot, const T* yb) {
+  auto compute = [&](const T* slot, const T* yb, bool data) {
 #pragma unroll
     for (int j = 0; j < C::KS; ++j) {
       T f[NB];
@@ -150,7 +150,7 @@ BLR_PHASE void wave_gram(char* smem, const BLR_GLOBAL T* X, int64_t ldx, const B
         for (int I = 0; I < NB; ++I) mu += f[I] * mwf[I];
         mu = row16_allreduce(mu);
       }
-      const T delta = yv - mu;
+      const T delta = data ? yv - mu : T(0);  // pseudo-observations of a factor prior enter the Gram matrix only
       const T rn = DIAG ? delta * w : delta;
       if (r16 == 0) qacc += (double)delta * (double)rn;
 #pragma unroll
@@ -169,6 +169,28 @@ BLR_PHASE void wave_gram(char* smem, const BLR_GLOBAL T* X, int64_t ldx, const B
     __builtin_amdgcn_wave_barrier();
   };
 
+  prior_kind = uni(prior_kind);
+  if (prior_kind == PRIOR_UPPER_FACTOR) {
+    // a carried-forward factor U (PDMat prior, blr_update_factor_*): U'U = sum_j u_j u_j' with u_j = row j of U, i.e. D
+    // pseudo-observation columns with element (d, j) = U[j + d ldl] for j <= d.  Isotropic noise accumulates X X' unscaled and
+    // divides by s once at the end, so the pseudo-columns carry sqrt(s) here.  A handful of stages, loaded synchronously.
+    const T pscale = DIAG ? T(1) : sqrt(s_iso);
+    for (int j0 = 0; j0 < C::DP; j0 += C::NSC) {
+      T* slot = ring;
+      for (int e = lane; e < C::SLOT; e += 64) {
+        const int F = e >> 6, l = e & 63;          // fragment F = kstep * NB + I, lane l = (r, q)
+        const int jj = F / NB, I = F - jj * NB;
+        const int d = 16 * I + (l & 15), j = j0 + 4 * jj + (l >> 4);
+        slot[e] = (j <= d) ? Lw[(int64_t)d * ldl + j] * pscale : T(0);
+      }
+      if (lane < C::NSC) { ybuf[lane] = T(0); if constexpr (DIAG) wbuf[lane] = T(1); }
+      asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+      __builtin_amdgcn_wave_barrier();
+      compute(slot, ybuf, false);
+      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+      __builtin_amdgcn_wave_barrier();
+    }
+  }
 #if BLR_EXP != 4
   for (int td = 0; td < C::DEPTH - 1 && td < nfull; ++td) issue(td);
 #endif
@@ -195,7 +217,7 @@ BLR_PHASE void wave_gram(char* smem, const BLR_GLOBAL T* X, int64_t ldx, const B
 #if BLR_EXP == 5  // streaming only: what the memory system delivers to this access pattern
     qacc += (double)ring[sl * C::SLOT + lane];
 #else
-    compute(ring + sl * C::SLOT, ybuf + sl * C::NSC);
+    compute(ring + sl * C::SLOT, ybuf + sl * C::NSC, true);
 #endif
   }
   asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
@@ -236,7 +258,7 @@ BLR_PHASE void wave_gram(char* smem, const BLR_GLOBAL T* X, int64_t ldx, const B
     }
     asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
     __builtin_amdgcn_wave_barrier();
-    compute(slot, ybuf);
+    compute(slot, ybuf, true);
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
     __builtin_amdgcn_wave_barrier();
   }
@@ -264,7 +286,7 @@ BLR_PHASE void wave_gram(char* smem, const BLR_GLOBAL T* X, int64_t ldx, const B
   // A = Lw + (1/s) X X'  (isotropic) -- the prior sits on the diagonal of the diagonal tiles -- -> packed lower triangle
 #pragma unroll
   for (int I = 0; I < NB; ++I) {
-    const T dvI = __shfl(dpr, 16 * I + r16);  // Lw[16 I + r]: lane (r, q) holds column r of the tile
+    const T dvI = __shfl(dpr, 16 * I + r16);  // Lw[16 I + r] (diagonal prior): lane (r, q) holds column r of the tile
 #pragma unroll
     for (int K = 0; K <= I; ++K) {
       const int t = I * (I + 1) / 2 + K;
@@ -273,8 +295,12 @@ BLR_PHASE void wave_gram(char* smem, const BLR_GLOBAL T* X, int64_t ldx, const B
       for (int v = 0; v < 4; ++v) {
         T val = DIAG ? acc[t][v] : acc[t][v] * w_iso;
         const int rl = Mfma<T>::crow(lane, v);
-        if (I == K && rl == r16) val += dvI;
         const int row = 16 * I + rl;
+        if (prior_kind == PRIOR_DIAGONAL) {
+          if (I == K && rl == r16) val += dvI;
+        } else if (prior_kind == PRIOR_DENSE) {
+          if (col <= row) val += Lw[(int64_t)row * ldl + col];  // UPPER triangle of the caller's matrix, as LAPACK 'U'
+        }
         if (col <= row) P[pidx(row, col)] = val;
       }
     }
@@ -399,17 +425,28 @@ __global__ __launch_bounds__(64, 2) void fused_wave_kernel(PosteriorArgs<T> a) {
     const BLR_GLOBAL T* mw = as_global(a.mw + reg * a.stridemw);
     const BLR_GLOBAL T* Lw = as_global(a.Lw + reg * a.strideLw);
 
-    // ---- prior: diagonal precision (reference :78: positive entries, logdet)
+    // ---- prior (reference :78): positive definite, logdet.  Diagonal: entries; carried-forward factor: its diagonal;
+    //      dense: the blocked Cholesky below on a copy in the packed triangle
     T dpr = T(1);
     double logdet_Lw = 0.0;
     int info = 0;
-    {
+    if (a.prior_kind == PRIOR_DENSE) {
+      for (int c = 0; c < D; ++c)
+        if (lane <= c) P[pidx(c, lane)] = Lw[(int64_t)c * a.ldl + lane];  // upper entry (lane, c) -> lower (c, lane)
+      if (lane < D) bvec[lane] = T(0);
+      __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+      __builtin_amdgcn_wave_barrier();
+      info = wave_chol<T, NB>(smem);
+      logdet_Lw = 2.0 * wave_allreduce((info == 0 && lane < D) ? log((double)P[pidx(lane, lane)]) : 0.0);
+      __builtin_amdgcn_wave_barrier();
+    } else {
       const bool in = lane < D;
-      if (in) dpr = Lw[lane];
+      if (in) dpr = (a.prior_kind == PRIOR_DIAGONAL) ? Lw[lane] : Lw[(int64_t)lane * a.ldl + lane];
       const bool ok = !in || (dpr > T(0));
       const unsigned long long badm = __ballot(!ok);
       if (badm) info = __ffsll((long long)badm);
       logdet_Lw = wave_allreduce((in && ok) ? log((double)dpr) : 0.0);
+      if (a.prior_kind != PRIOR_DIAGONAL) logdet_Lw *= 2.0;
     }
     if (info != 0) {  // wave-uniform
       if (lane == 0) { a.info[reg] = info; if (a.logpdf) a.logpdf[reg] = kNaN; }
@@ -417,10 +454,10 @@ __global__ __launch_bounds__(64, 2) void fused_wave_kernel(PosteriorArgs<T> a) {
     }
     if (a.noise_kind == NOISE_DIAGONAL)
       wave_gram<T, NB, true>(smem, as_global(a.X + reg * a.strideX), a.ldx, as_global(a.y + reg * a.stridey),
-                             as_global(a.s + reg * a.strides), mw, dpr, N);
+                             as_global(a.s + reg * a.strides), mw, dpr, N, a.prior_kind, Lw, a.ldl);
     else
       wave_gram<T, NB, false>(smem, as_global(a.X + reg * a.strideX), a.ldx, as_global(a.y + reg * a.stridey),
-                              as_global(a.s + reg * a.strides), mw, dpr, N);
+                              as_global(a.s + reg * a.strides), mw, dpr, N, a.prior_kind, Lw, a.ldl);
     const double quad = scr[0], logdet_Sy = scr[1];
     if (iscr[0] != 0x7fffffff) {  // Sigma_y is not positive definite: PosDefException(index), as :79 would throw
       if (lane == 0) { a.info[reg] = iscr[0]; if (a.logpdf) a.logpdf[reg] = kNaN; }

@@ -1470,7 +1470,8 @@ def test_update_factor_leaves_the_state_alone_on_failure(B, route, monkeypatch):
 @pytest.mark.parametrize("D", [32, 64])
 @pytest.mark.parametrize("N", [0, 1, 7, 8, 16, 17, 100, 1000, 1024])
 @pytest.mark.parametrize("noise", ["diagonal", "isotropic"])
-def test_wave_kernel_shapes_vs_oracle(B, dtype, D, N, noise):
+@pytest.mark.parametrize("prior", ["diagonal", "dense", "factor"])
+def test_wave_kernel_shapes_vs_oracle(B, dtype, D, N, noise, prior):
     # the shapes blr_abi.hip routes to fused_wave_kernel (f64: D = 32 and 64; f32: D = 64; D = 32 in f32 stays on the four-wave
     # kernel and runs here as its cross-check): whole 4 KiB stages, ragged tails, no data at all, non-zero prior mean
     a = B._abi
@@ -1480,6 +1481,23 @@ def test_wave_kernel_shapes_vs_oracle(B, dtype, D, N, noise):
     X = rng.standard_normal((nb, N, D)).astype(dtype)  # [N, D] row-major == D x N ColVecs
     mw = rng.standard_normal((nb, D)).astype(dtype)
     dpr = np.exp(0.5 * rng.standard_normal((nb, D))).astype(dtype)
+    if prior == "diagonal":
+        Lw_arg, pk, ldl, strideLw = dpr, a.PRIOR_DIAGONAL, 1, D
+        Lw_dense = [np.diag(dpr[b].astype(np.float64)) for b in range(nb)]
+    else:
+        Bm = rng.standard_normal((nb, D, D)) / np.sqrt(D)
+        Lw_dense = [Bm[b] @ Bm[b].T + np.eye(D) for b in range(nb)]
+        if prior == "dense":
+            Lw_arg = np.stack([np.asfortranarray(Lw_dense[b]).T for b in range(nb)]).astype(dtype)  # [b] = column-major D x D
+            Lw_dense = [np.asarray(Lw_arg[b].T, dtype=np.float64) for b in range(nb)]
+            Lw_dense = [np.triu(M) + np.triu(M, 1).T for M in Lw_dense]  # the upper triangle is what is read
+            pk = a.PRIOR_DENSE
+        else:
+            U = [O.chol_upper(Lw_dense[b]).astype(dtype) for b in range(nb)]
+            Lw_arg = np.stack([U[b].T.copy() for b in range(nb)])  # column-major upper factor
+            Lw_dense = [U[b].astype(np.float64).T @ U[b].astype(np.float64) for b in range(nb)]
+            pk = a.PRIOR_UPPER_FACTOR
+        ldl, strideLw = D, D * D
     s = (np.exp(0.4 * rng.standard_normal((nb, max(N, 1)))) if noise == "diagonal" else np.full((nb, 1), 0.3)).astype(dtype)
     y = rng.standard_normal((nb, max(N, 1))).astype(dtype)
     mw_post = np.zeros((nb, D), dtype=dtype)
@@ -1488,20 +1506,21 @@ def test_wave_kernel_shapes_vs_oracle(B, dtype, D, N, noise):
     lp = np.zeros(nb)
     info = np.full(nb, 9, dtype=np.int32)
     kind = a.NOISE_DIAGONAL if noise == "diagonal" else a.NOISE_ISOTROPIC
-    h.posterior_batched(dtype, a.MEM_HOST, a.LAYOUT_COLVECS, nb, D, N, X, D, N * D, y, max(N, 1), kind, s, s.shape[1], a.PRIOR_DIAGONAL,
-                        mw, D, dpr, 1, D, mw_post, D, T_post, D, D * D, Lw_post, D, D * D, lp, info)
+    h.posterior_batched(dtype, a.MEM_HOST, a.LAYOUT_COLVECS, nb, D, N, X, D, N * D, y, max(N, 1), kind, s, s.shape[1], pk,
+                        mw, D, Lw_arg, ldl, strideLw, mw_post, D, T_post, D, D * D, Lw_post, D, D * D, lp, info)
     assert info.tolist() == [0] * nb
     rtol = 1e-10 if dtype == np.float64 else 3e-4
     for b in range(nb):
         Xb = X[b].T.astype(np.float64)
         sb = (s[b, :N] if noise == "diagonal" else np.full(N, s[b, 0])).astype(np.float64)
-        mw_o, T_o, L_o = O.posterior_literal(mw[b].astype(np.float64), dpr[b].astype(np.float64), Xb, sb, y[b, :N].astype(np.float64))
+        Lb = np.diag(Lw_dense[b]) if prior == "diagonal" else Lw_dense[b]
+        mw_o, T_o, L_o = O.posterior_literal(mw[b].astype(np.float64), Lb, Xb, sb, y[b, :N].astype(np.float64))
         np.testing.assert_allclose(Lw_post[b].T, L_o, rtol=rtol, atol=rtol * np.abs(L_o).max())
         Tn = np.triu(T_post[b].T.astype(np.float64))
         np.testing.assert_allclose(Tn.T @ Tn, L_o, rtol=rtol, atol=rtol * np.abs(L_o).max())
         assert np.all(np.tril(T_post[b].T, -1) == 0)
         np.testing.assert_allclose(mw_post[b], mw_o, rtol=100 * rtol, atol=10 * rtol * np.abs(mw_o).max())
-        lp_o = O.logpdf_literal(mw[b].astype(np.float64), dpr[b].astype(np.float64), Xb, sb, y[b, :N].astype(np.float64))
+        lp_o = O.logpdf_literal(mw[b].astype(np.float64), Lb, Xb, sb, y[b, :N].astype(np.float64))
         assert lp[b] == pytest.approx(lp_o, rel=20 * rtol, abs=20 * rtol)
 
 
