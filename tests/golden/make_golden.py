@@ -79,6 +79,28 @@ def case(name, rng, N, D, prior, noise):
             for k, v in out.items()}
 
 
+def seeded_inputs(seed, D, N):
+    """Synthetic ColVecs problem of SURVEY.md 8d from a seed (shared with tests/test_golden.py)."""
+    rng = np.random.Generator(np.random.PCG64(seed))
+    X = rng.standard_normal((D, N))
+    w = rng.standard_normal(D)
+    s = 0.1
+    y = X.T @ w + np.sqrt(s) * rng.standard_normal(N)
+    return X, y, s, np.zeros(D), np.ones(D)  # prior: mw = 0, Lw = I (diagonal)
+
+
+def checksums(mw_post, T, A, lp):
+    return dict(logpdf=float(lp), sum_mw=float(mw_post.sum()), sumsq_mw=float((mw_post ** 2).sum()), trace_A=float(np.trace(A)),
+                fro_A=float(np.sqrt((A ** 2).sum())), logdet_A=float(2.0 * np.log(np.diag(T)).sum()))
+
+
+def seeded_case(name, seed, D, N):
+    X, y, s, mw, dpr = seeded_inputs(seed, D, N)
+    mw_p, T, A = O.posterior_literal(mw, dpr, X, s, y)
+    lp = O.logpdf_literal(mw, dpr, X, s, y)
+    return dict(name=name, seed=seed, D=D, N=N, noise_var=s, checksums=checksums(mw_p, T, A, lp))
+
+
 def main():
     rng = np.random.Generator(np.random.PCG64(20261002))
     cases = [
@@ -88,10 +110,13 @@ def main():
         case("readme_10_2_diag_prior_hetero_noise", rng, 10, 2, "diagonal", "diagonal"),
         case("toy_13_7_dense_prior_dense_noise", rng, 13, 7, "dense", "dense"),
     ]
+    # full-size shapes of BASELINE.json as seed + checksums: the inputs are regenerated from the seed, the
+    # expected numbers come from the fp64 oracle (literal op sequence; the direct form agrees to 1e-11, asserted by the test)
+    seeded = [seeded_case("c2_128_4096_iso", 424242, 128, 4096), seeded_case("c4_64_1024_iso", 434343, 64, 1024)]
     doctest = dict(name="doctest_basis_function_regression_jl_11_28", x=np.linspace(-1.0, 1.0, 5).tolist(),
                    mw=[0.0, 0.0], Lw_diag=[1.0, 1.0], noise=1e-18, var=[2.0, 1.25, 1.0, 1.25, 2.0])
     with open(os.path.join(os.path.dirname(os.path.abspath(__file__)), "blr_golden.json"), "w") as f:
-        json.dump(dict(generator="tests/golden/make_golden.py", seed=20261002, cases=cases, doctest=doctest), f, indent=0)
+        json.dump(dict(generator="tests/golden/make_golden.py", seed=20261002, cases=cases, doctest=doctest, seeded=seeded), f, indent=0)
     print("wrote", len(cases), "cases")
 
 
