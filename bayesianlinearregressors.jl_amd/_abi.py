@@ -80,6 +80,7 @@ for _suf in ("f64", "f32"):
          _vp, _i64, _vp, _i64, _vp], _int)
     _SIGS[f"blr_rand_{_suf}"] = (
         [_H, _int, _int, _i64, _i64, _i64, _vp, _i64, _int, _vp, _int, _vp, _vp, _i64, _vp, _i64, _vp, _i64, _vp, _i64], _int)
+    _SIGS[f"blr_apply_weights_{_suf}"] = ([_H, _int, _int, _i64, _i64, _i64, _vp, _i64, _vp, _i64, _vp, _i64], _int)
     _SIGS[f"blr_sample_weights_{_suf}"] = (
         [_H, _int, _i64, _i64, _int, _vp, _vp, _i64, _vp, _i64, _vp, _i64], _int)
     _SIGS[f"blr_logpdf_grad_batched_{_suf}"] = (
@@ -212,6 +213,30 @@ class Handle:
         self.check(self.lib.blr_timer_stop(self._h, C.byref(ms)))
         return float(ms.value)
 
+    # -- device memory (blr_device_alloc / blr_device_free / blr_memcpy_*): for hosts without a GPU array library ----------
+    def device_alloc(self, nbytes):
+        """-> integer device pointer (0 bytes -> 0)."""
+        if nbytes <= 0:
+            return 0
+        p = _vp()
+        self.check(self.lib.blr_device_alloc(self._h, C.c_size_t(int(nbytes)), C.byref(p)))
+        return int(p.value or 0)
+
+    def device_free(self, dptr):
+        if dptr and getattr(self, "_h", None):
+            self.check(self.lib.blr_device_free(self._h, _vp(int(dptr))))
+
+    def memcpy_h2d(self, dptr, host_array):
+        a = np.ascontiguousarray(host_array) if not (host_array.flags.c_contiguous or host_array.flags.f_contiguous) else host_array
+        if a.nbytes:
+            self.check(self.lib.blr_memcpy_h2d(self._h, _vp(int(dptr)), a.ctypes.data_as(_vp), C.c_size_t(a.nbytes)))
+
+    def memcpy_d2h(self, host_array, dptr):
+        if not (host_array.flags.c_contiguous or host_array.flags.f_contiguous):
+            raise ValueError("memcpy_d2h needs a contiguous destination")
+        if host_array.nbytes:
+            self.check(self.lib.blr_memcpy_d2h(self._h, host_array.ctypes.data_as(_vp), _vp(int(dptr)), C.c_size_t(host_array.nbytes)))
+
     # -- raw entry points (see include/blr_mi355x.h for argument meaning) ---------------------------
     def posterior_batched(self, dtype, memspace, layout, B, D, N, X, ldx, strideX, y, stridey, noise_kind, s, strides,
                           prior_kind, mw, stridemw, Lw, ldl, strideLw, mw_post, stride_mwpost, T_post, ldt, strideT,
@@ -286,6 +311,11 @@ class Handle:
         if rc > 0:
             raise PosDefException(rc)
         return rc
+
+    def apply_weights(self, dtype, memspace, layout, D, N, S, X, ldx, W, ldw, Y, ldy):
+        """Y (N x S) = X'W for S given weight vectors; include/blr_mi355x.h blr_apply_weights_*."""
+        fn = getattr(self.lib, f"blr_apply_weights_{suffix(dtype)}")
+        return self.check(fn(self._h, memspace, layout, D, N, S, _ptr(X), ldx, _ptr(W), ldw, _ptr(Y), ldy))
 
     def sample_weights(self, dtype, memspace, D, S, prior_kind, mw, Lw, ldl, Z, ldz, W, ldw):
         fn = getattr(self.lib, f"blr_sample_weights_{suffix(dtype)}")

@@ -12,6 +12,7 @@
 #include <cstring>
 #include <new>
 #include <string>
+#include <unordered_map>
 #include <vector>
 
 #include "blr_aux_kernels.hpp"
@@ -41,14 +42,12 @@ struct blr_handle {
   unsigned* ticket = nullptr;
   unsigned ticket_base = 0;
   unsigned epoch = 0;
+  // kernels whose dynamic-LDS limit has been raised on this handle's device (hipFuncSetAttribute is per device and costs a
+  // driver call: once per (handle, kernel), not once per launch -- it sat on the launch path of the 5 us wave kernel)
+  std::unordered_map<const void*, size_t> lds_limit;
   // RCCL communicator of blr_comm_init (one rank per handle / GPU); NULL until then
   ncclComm_t comm = nullptr;
   int comm_size = 0, comm_rank = 0;
-  // pipelined large-D update: the Gram block columns are built on s_gram[] while the factorisation follows on s_chain
-  hipStream_t s_chain = nullptr, s_reduce = nullptr, s_gram[2] = {nullptr, nullptr};
-  bool partitioned = false;  // CU masks in force: 32 CUs chain / 224 CUs Gram
-  hipEvent_t ev_fork = nullptr, ev_join = nullptr;
-  std::vector<hipEvent_t> ev_col;
 };
 
 namespace {
@@ -107,6 +106,14 @@ int hip_fail(blr_handle* h, hipError_t e, const char* what) {
     hipError_t e__ = (expr);                               \
     if (e__ != hipSuccess) return hip_fail(h, e__, #expr); \
   } while (0)
+
+int set_lds_once(blr_handle* h, const void* kern, size_t bytes) {
+  auto it = h->lds_limit.find(kern);
+  if (it != h->lds_limit.end() && it->second >= bytes) return 0;
+  HIP_TRY(h, hipFuncSetAttribute(kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes));
+  h->lds_limit[kern] = bytes;
+  return 0;
+}
 
 int bad_arg(blr_handle* h, int pos, const char* why) {
   if (h) h->err = std::string("argument ") + std::to_string(pos) + ": " + why;
@@ -195,8 +202,7 @@ int launch_wave_solve(blr_handle* h, WaveSolveArgs<T>& b, int NC, int64_t S) {
   if (++h->epoch == 0) h->epoch = 1;  // 0 is the never-written state
   b.xchg = h->xchg; b.epoch = h->epoch; b.ticket = h->ticket; b.ticket_base = h->ticket_base;
   h->ticket_base += (unsigned)(NC * S);
-  HIP_TRY(h, hipFuncSetAttribute(reinterpret_cast<const void*>(backsolve_wave_kernel<T>), hipFuncAttributeMaxDynamicSharedMemorySize,
-                                 (int)wave_solve_lds<T>()));
+  { const int rc_lds = set_lds_once(h, reinterpret_cast<const void*>(backsolve_wave_kernel<T>), (size_t)((int)wave_solve_lds<T>())); if (rc_lds) return rc_lds; }
   hipLaunchKernelGGL(backsolve_wave_kernel<T>, dim3(NC, (unsigned)S), dim3(kThreads), wave_solve_lds<T>(), h->stream, b);
   const hipError_t le = hipGetLastError();
   if (le != hipSuccess) {  // nothing ran: the ticket counter did not advance
@@ -227,7 +233,7 @@ int launch_fused_small(blr_handle* h, const PosteriorArgs<T>& a) {
   auto kern = fused_small_kernel<T, NB, MODE>;
   // every launch: the attribute is per DEVICE, and handles on different devices share this code (a process-wide
   // "already set" flag left the second device at the 64 KB default)
-  HIP_TRY(h, hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, C::LDS_BYTES));
+  { const int rc_lds = set_lds_once(h, reinterpret_cast<const void*>(kern), (size_t)(C::LDS_BYTES)); if (rc_lds) return rc_lds; }
   int grid = (int)std::min<int64_t>(a.B, 1 << 20);
   hipLaunchKernelGGL(kern, dim3(grid), dim3(kThreads), C::LDS_BYTES, h->stream, a);
   HIP_TRY(h, hipGetLastError());
@@ -246,13 +252,30 @@ int launch_fused_small_mode(blr_handle* h, const PosteriorArgs<T>& a) {
 }
 
 // D = 32 / 64, ColVecs with aligned columns: one wavefront per regressor (blr_fused_wave.hpp)
-template <typename T, int NB>
-int launch_fused_wave(blr_handle* h, const PosteriorArgs<T>& a) {
+template <typename T, int NB, int NW>
+int launch_fused_wave_nw(blr_handle* h, const PosteriorArgs<T>& a) {
   using C = WaveCfg<T, NB>;
-  const int grid = (int)std::min<int64_t>(a.B, 256 * 8);  // 8 waves per CU (18 KB of LDS each)
-  hipLaunchKernelGGL((fused_wave_kernel<T, NB>), dim3(grid), dim3(64), C::LDS_BYTES, h->stream, a);
+  const int grid = (int)std::min<int64_t>(a.B, 256 * 8 / NW);  // 8 waves per CU (18.6 KB of LDS each)
+  if (NW * C::LDS_BYTES > 64 * 1024) {
+    int rc = set_lds_once(h, reinterpret_cast<const void*>(fused_wave_kernel<T, NB, NW>), (size_t)NW * C::LDS_BYTES);
+    if (rc) return rc;
+  }
+  hipLaunchKernelGGL((fused_wave_kernel<T, NB, NW>), dim3(grid), dim3(64 * NW), NW * C::LDS_BYTES, h->stream, a);
   HIP_TRY(h, hipGetLastError());
   return 0;
+}
+// The chip has 2048 wave slots for this kernel.  A batch that cannot fill them with one regressor per wave splits each
+// regressor's observations over 2 or 4 waves instead (BLR_MI355X_WAVE_SPLIT=1|2|4 overrides; the tests run all three).
+template <typename T, int NB>
+int launch_fused_wave(blr_handle* h, const PosteriorArgs<T>& a) {
+  int nw = a.B >= 2048 ? 1 : (a.B >= 1024 ? 2 : 4);
+  if (const char* e = getenv("BLR_MI355X_WAVE_SPLIT")) {
+    const int v = atoi(e);
+    if (v == 1 || v == 2 || v == 4) nw = v;
+  }
+  if (nw == 1) return launch_fused_wave_nw<T, NB, 1>(h, a);
+  if (nw == 2) return launch_fused_wave_nw<T, NB, 2>(h, a);
+  return launch_fused_wave_nw<T, NB, 4>(h, a);
 }
 
 template <typename T>
@@ -281,10 +304,7 @@ int dispatch_fused_small(blr_handle* h, const PosteriorArgs<T>& a) {
 
 // ---- large-D path (D > 128): multi-kernel pipeline of blr_large.hpp ---------------------------------------------
 template <typename T>
-int set_lds(blr_handle* h, const void* kern, size_t bytes) {
-  HIP_TRY(h, hipFuncSetAttribute(kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes));
-  return 0;
-}
+int set_lds(blr_handle* h, const void* kern, size_t bytes) { return set_lds_once(h, kern, bytes); }
 
 // In-place blocked (128) right-looking Cholesky of the lower triangle of M (nrows_total x DP, ld); rows beyond DP
 // (the right-hand-side block of the augmented matrix) are carried through the TRSM and the trailing updates.
@@ -318,63 +338,6 @@ int chol_large(blr_handle* h, T* M, int64_t ld, int DP, int nrows_total, int32_t
   return 0;
 }
 
-// side streams of the pipelined large-D update (created on first use; the chain stream gets the highest priority the
-// device offers so that its few, latency-critical workgroups are dispatched ahead of the Gram launches' backlog)
-int pipeline_streams(blr_handle* h, int ncols) {
-  if (!h->s_chain) {
-    // The chain's kernels are one or a few workgroups each and latency-bound; co-resident with two Gram workgroups they run
-    // 2x slower (measured: chol_diag 33 -> 70 us).  So the chip is PARTITIONED with CU masks: one CU of every shader engine
-    // of every XCD (32 in all) belongs to the chain stream, the other 224 to the Gram streams.  Measured with
-    // tools/cumask_probe.hip on MI355X: mask bit i lands in XCD i % 8, and within the XCD bit i / 8 lands in shader engine
-    // (i / 8) % 4 -- so bits 224..255 are one CU per (XCD, SE).  A partition that is NOT balanced over the shader engines
-    // (e.g. 4 CUs of one SE) halves the throughput of the other side: the dispatcher deals workgroups evenly to the SEs.
-    static const bool no_mask = getenv("BLR_MI355X_NO_CUMASK") != nullptr;
-    hipDeviceProp_t prop;
-    HIP_TRY(h, hipGetDeviceProperties(&prop, h->device));
-    bool masked = false;
-    if (!no_mask && prop.multiProcessorCount == 256) {
-      uint32_t chain_mask[8], gram_mask[8];
-      for (int w = 0; w < 8; ++w) chain_mask[w] = 0;
-      for (int i = 0; i < 256; ++i)
-        if (i >= 224) chain_mask[i / 32] |= 1u << (i % 32);
-      for (int w = 0; w < 8; ++w) gram_mask[w] = ~chain_mask[w];
-      masked = hipExtStreamCreateWithCUMask(&h->s_chain, 8, chain_mask) == hipSuccess;
-      for (hipStream_t& g : h->s_gram) masked = masked && hipExtStreamCreateWithCUMask(&g, 8, gram_mask) == hipSuccess;
-      masked = masked && hipExtStreamCreateWithCUMask(&h->s_reduce, 8, chain_mask) == hipSuccess;
-      if (!masked) {
-        (void)hipGetLastError();
-        if (h->s_chain) (void)hipStreamDestroy(h->s_chain);
-  if (h->s_reduce) (void)hipStreamDestroy(h->s_reduce);
-        for (hipStream_t& g : h->s_gram) { if (g) (void)hipStreamDestroy(g); g = nullptr; }
-        if (h->s_reduce) (void)hipStreamDestroy(h->s_reduce);
-        h->s_chain = h->s_reduce = nullptr;
-      }
-    }
-    if (!masked) {
-      int least = 0, greatest = 0;
-      HIP_TRY(h, hipDeviceGetStreamPriorityRange(&least, &greatest));
-      HIP_TRY(h, hipStreamCreateWithPriority(&h->s_chain, hipStreamNonBlocking, greatest));
-      HIP_TRY(h, hipStreamCreateWithPriority(&h->s_reduce, hipStreamNonBlocking, greatest));
-      for (hipStream_t& g : h->s_gram) HIP_TRY(h, hipStreamCreateWithPriority(&g, hipStreamNonBlocking, least));
-    }
-    h->partitioned = masked;
-    HIP_TRY(h, hipEventCreateWithFlags(&h->ev_fork, hipEventDisableTiming));
-    HIP_TRY(h, hipEventCreateWithFlags(&h->ev_join, hipEventDisableTiming));
-  }
-  while ((int)h->ev_col.size() < 2 * ncols) {  // [2J]: Gram tiles of column J written, [2J + 1]: column J reduced into Abar
-    hipEvent_t e = nullptr;
-    HIP_TRY(h, hipEventCreateWithFlags(&e, hipEventDisableTiming));
-    h->ev_col.push_back(e);
-  }
-  return 0;
-}
-
-struct StreamSwap {  // run helpers that launch on h->stream on another stream for a scope
-  blr_handle* h; hipStream_t saved;
-  StreamSwap(blr_handle* hh, hipStream_t s) : h(hh), saved(hh->stream) { hh->stream = s; }
-  ~StreamSwap() { h->stream = saved; }
-};
-
 template <typename T>
 int posterior_large_one(blr_handle* h, const PosteriorArgs<T>& a, int64_t reg) {
   using LC = LargeCfg<T>;
@@ -391,8 +354,9 @@ int posterior_large_one(blr_handle* h, const PosteriorArgs<T>& a, int64_t reg) {
   double best = 0.0;
   for (int sp = 1; sp <= max_split; ++sp) {
     const int wgs = ntiles * sp;
-    const int rounds = (wgs + 511) / 512;
-    const double eff = (double)wgs / (rounds * 512.0) - 0.002 * sp;  // mild preference for fewer partials
+    const int slots = 256 * (sizeof(T) == 4 ? BLR_GRAM_WGS : 2);
+    const int rounds = (wgs + slots - 1) / slots;
+    const double eff = (double)wgs / (rounds * (double)slots) - 0.002 * sp;  // mild preference for fewer partials
     if (eff > best) { best = eff; nsplit = sp; }
   }
   const bool prior_factor = a.prior_kind == PRIOR_UPPER_FACTOR;
@@ -400,37 +364,7 @@ int posterior_large_one(blr_handle* h, const PosteriorArgs<T>& a, int64_t reg) {
   const int nsplit_total = nsplit + pf;
   const int gridc = 1024;
 
-  // Pipelined schedule (EXPERIMENT, off unless BLR_MI355X_PIPELINE is set): the Gram matrix is built block column by block
-  // column on two side streams while a left-looking blocked Cholesky follows on a third, so that the ~60 us / panel chain
-  // of small kernels runs in the shadow of the Gram launches.  Measured on MI355X ("pipelined large-D update"):
-  // c3 1.87 ms against 1.30 ms serial -- per-column launches keep only ~87 % of the slots busy, every cross-stream event
-  // costs ~30 us, and the chain's kernels need their own CUs (CU masks: -12.5 % Gram capacity) or run 2x slower when
-  // co-resident with Gram workgroups.  Kept for the next step (one column-ordered Gram launch + in-kernel column flags).
-  static const bool want_pipeline = getenv("BLR_MI355X_PIPELINE") != nullptr;
-  const bool pipelined = NC >= 2 && want_pipeline && !prior_factor;
-  std::vector<int> col_split(NC, 0);
-  std::vector<int64_t> col_gp(NC + 1, 0);
-  int max_split_total = nsplit_total;
-  size_t upart_elems = 0;
-  int pipe_split = 1;
-  if (pipelined) {
-    // ONE column-ordered Gram launch on the 224-CU partition (448 workgroup slots): the largest split factor whose
-    // ntiles x nsplit workgroups fill whole rounds of those slots
-    const int slots = 448;
-    double bestp = 0.0;
-    for (int sp = 1; sp <= max_split; ++sp) {
-      const int wgs = ntiles * sp;
-      const int rounds = (wgs + slots - 1) / slots;
-      const double eff = (double)wgs / (rounds * (double)slots) - 0.002 * sp + (rounds >= 2 ? 0.05 : 0.0);  // >= 2 rounds: columns finish early
-      if (eff > bestp) { bestp = eff; pipe_split = sp; }
-    }
-    max_split_total = pipe_split;
-    for (int J = 1; J < NC; ++J) {
-      const int nr = (DP + 64 - J * kPB) / 64;
-      upart_elems = std::max(upart_elems, (size_t)J * (2 * nr - 1) * 64 * 64);
-    }
-  }
-  const int64_t gp_tiles = pipelined ? (int64_t)pipe_split * ntiles : (int64_t)nsplit_total * ntiles;
+  const int64_t gp_tiles = (int64_t)nsplit_total * ntiles;
 
   // workspace carve
   size_t off = 0;
@@ -438,13 +372,11 @@ int posterior_large_one(blr_handle* h, const PosteriorArgs<T>& a, int64_t reg) {
   const size_t o_abar = carve((size_t)lda * DP * sizeof(T));
   const size_t o_w = carve(a.prior_kind == PRIOR_DENSE ? (size_t)DP * DP * sizeof(T) : 0);
   const size_t o_gp = carve((size_t)gp_tiles * kPB * kPB * sizeof(T));
-  const size_t o_up = carve(upart_elems * sizeof(T));
-  const size_t o_bp = carve((size_t)max_split_total * NC * kPB * sizeof(double));
+  const size_t o_bp = carve((size_t)nsplit_total * NC * kPB * sizeof(double));
   const size_t o_r = carve((size_t)std::max(N, 1) * sizeof(T));
   const size_t o_q = carve((size_t)gridc * sizeof(double));
   const size_t o_l = carve((size_t)gridc * sizeof(double));
   const size_t o_m = carve((size_t)DP * DP * sizeof(T));  // transposed factor for the back substitution
-  const size_t o_cnt = carve(pipelined ? (size_t)(ntiles + NC) * sizeof(unsigned) : 0);
   const size_t o_sc = carve(64);
   int rc = ensure_ws(h, off);
   if (rc) return rc;
@@ -470,7 +402,7 @@ int posterior_large_one(blr_handle* h, const PosteriorArgs<T>& a, int64_t reg) {
 
   HIP_TRY(h, hipMemsetAsync(ws + o_sc, 0, 64, h->stream));
   HIP_TRY(h, hipMemsetAsync(info_noise, 0xFF, sizeof(unsigned), h->stream));
-  HIP_TRY(h, hipMemsetAsync(bpart, 0, (size_t)max_split_total * NC * kPB * sizeof(double), h->stream));
+  HIP_TRY(h, hipMemsetAsync(bpart, 0, (size_t)nsplit_total * NC * kPB * sizeof(double), h->stream));
 
   // ---- prior: SPD check + logdet (reference :78)
   if (a.prior_kind == PRIOR_DENSE) {
@@ -526,59 +458,13 @@ int posterior_large_one(blr_handle* h, const PosteriorArgs<T>& a, int64_t reg) {
     hipLaunchKernelGGL(gram_reduce_kernel<T>, dim3(nt + reduce_blocks, 16), dim3(kThreads), 0, st, r);
   };
 
-  if (!pipelined) {
-    g.tile_i0 = 0; g.tile_j0 = 0; g.tri = 1;
-    r.col_mode = 0;
-    gram_tiles(h->stream, nsplit, ntiles, Gpart);
-    gram_reduce(h->stream, nsplit, ntiles, Gpart, NC);
-    // ---- blocked Cholesky of Abar (rows DP.. = rhs) -> L, u  (reference :86, :57)
-    if ((rc = chol_large<T>(h, Abar, lda, DP, DP + kPB, info_chol))) return rc;
-  } else {
-    using SC = SmallCfg<T, 8>;
-    using TC = TrsmCfg<T>;
-    using acc4 = typename Mfma<T>::acc4;
-    if ((rc = pipeline_streams(h, NC))) return rc;
-    if ((rc = set_lds<T>(h, reinterpret_cast<const void*>(chol_diag_kernel<T>), SC::LDS_BYTES))) return rc;
-    if ((rc = set_lds<T>(h, reinterpret_cast<const void*>(trsm_block_kernel<T>), TC::LDS_BYTES))) return rc;
-    if ((rc = set_lds<T>(h, reinterpret_cast<const void*>(left_update_kernel<T>), TrailCfg<T>::LDS_BYTES))) return rc;
-    unsigned* tile_count = reinterpret_cast<unsigned*>(ws + o_cnt);
-    unsigned* col_done = tile_count + ntiles;
-    HIP_TRY(h, hipMemsetAsync(tile_count, 0, (size_t)(ntiles + NC) * sizeof(unsigned), h->stream));
-    HIP_TRY(h, hipEventRecord(h->ev_fork, h->stream));
-    HIP_TRY(h, hipStreamWaitEvent(h->s_chain, h->ev_fork, 0));
-    HIP_TRY(h, hipStreamWaitEvent(h->s_gram[0], h->ev_fork, 0));
-    // ONE Gram launch, tiles column by column; the last partial of a tile triggers its reduction inside the kernel
-    g.tile_i0 = 0; g.tile_j0 = 0; g.tri = 5;
-    g.nsplit = pipe_split; g.ntiles = ntiles; g.Gpart = Gpart; g.xcd_swizzle = 0;
-    g.tile_count = tile_count; g.col_done = col_done;
-    g.Lw = Lw; g.ldl = a.ldl; g.prior_kind = a.prior_kind; g.Abar = Abar; g.lda = lda; g.DP = DP;
-    g.Lw_post = a.Lw_post ? a.Lw_post + reg * a.strideLp : nullptr; g.ldlp = a.ldlp;
-    hipLaunchKernelGGL(gram_tile_kernel<T>, dim3(ntiles * pipe_split), dim3(kThreads), LC::LDS_BYTES, h->s_gram[0], g);
-    HIP_TRY(h, hipEventRecord(h->ev_col[0], h->s_gram[0]));
-    // left-looking blocked Cholesky (reference :86, :57), one block column behind the Gram streams at the earliest
-    acc4* Upart = reinterpret_cast<acc4*>(ws + o_up);
-    const int nrows_total = DP + kPB;
-    for (int p = 0; p < NC; ++p) {
-      hipLaunchKernelGGL(wait_count_kernel, dim3(1), dim3(64), 0, h->s_chain, (const unsigned*)(col_done + p), (unsigned)(NC - p), info_chol);
-      if (p > 0) {
-        const int nsub = 2 * ((DP + 64 - p * kPB) / 64) - 1;
-        hipLaunchKernelGGL(left_update_kernel<T>, dim3(nsub, p), dim3(kThreads), TrailCfg<T>::LDS_BYTES, h->s_chain, (const T*)Abar, lda, p,
-                           Upart, (const int32_t*)info_chol);
-        hipLaunchKernelGGL(left_reduce_kernel<T>, dim3(nsub), dim3(kThreads), 0, h->s_chain, Abar, lda, p, p, (const acc4*)Upart,
-                           (const int32_t*)info_chol);
-      }
-      hipLaunchKernelGGL(chol_diag_kernel<T>, dim3(1), dim3(kThreads), SC::LDS_BYTES, h->s_chain, Abar, lda, p, info_chol, 0);
-      const int row_begin = (p + 1) * kPB;
-      const int nblk = (nrows_total - row_begin + TC::RB - 1) / TC::RB;
-      hipLaunchKernelGGL(trsm_block_kernel<T>, dim3(nblk), dim3(kThreads), TC::LDS_BYTES, h->s_chain, Abar, lda, p, row_begin,
-                         nrows_total, (const int32_t*)info_chol, RowSqArgs<T>{});
-    }
-    HIP_TRY(h, hipGetLastError());
-  }
+  g.tile_i0 = 0; g.tile_j0 = 0; g.tri = 1;
+  gram_tiles(h->stream, nsplit, ntiles, Gpart);
+  gram_reduce(h->stream, nsplit, ntiles, Gpart, NC);
+  // ---- blocked Cholesky of Abar (rows DP.. = rhs) -> L, u  (reference :86, :57)
+  if ((rc = chol_large<T>(h, Abar, lda, DP, DP + kPB, info_chol))) return rc;
 
   // ---- T = L' (for the caller and for the AXPY-form back substitution), then m, posterior mean, evidence
-  {
-    StreamSwap on_chain(h, pipelined ? h->s_chain : h->stream);
   {
     dim3 grid((DP + 31) / 32, (DP + 31) / 32);
     hipLaunchKernelGGL(transpose_out_kernel<T>, grid, dim3(kThreads), 0, h->stream, (const T*)Abar, lda, DP, Tfull,
@@ -594,12 +480,6 @@ int posterior_large_one(blr_handle* h, const PosteriorArgs<T>& a, int64_t reg) {
     b.logpdf = a.logpdf ? a.logpdf + reg : nullptr; b.info = a.info + reg; b.chol_info = info_chol;
     b.prior_info = info_prior; b.noise_info = info_noise;
     if ((rc = launch_wave_solve<T>(h, b, NC, 1))) return rc;
-  }
-  }
-  if (pipelined) {
-    HIP_TRY(h, hipEventRecord(h->ev_join, h->s_chain));
-    HIP_TRY(h, hipStreamWaitEvent(h->stream, h->ev_join, 0));
-    HIP_TRY(h, hipStreamWaitEvent(h->stream, h->ev_col[0], 0));
   }
   HIP_TRY(h, hipGetLastError());
   return 0;
@@ -739,7 +619,7 @@ int prior_factor(blr_handle* h, int64_t B, int64_t D, int prior_kind, const T* L
   int32_t* inf = reinterpret_cast<int32_t*>(h->ws + (((size_t)B * D * D * sizeof(T) + 15) & ~(size_t)15));
   size_t lds = ((size_t)D * (D + 1) / 2 + D) * sizeof(T) + 16;
   auto kern = chol_small_kernel<T>;
-  HIP_TRY(h, hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+  { const int rc_lds = set_lds_once(h, reinterpret_cast<const void*>(kern), (size_t)((int)lds)); if (rc_lds) return rc_lds; }
   hipLaunchKernelGGL(kern, dim3((unsigned)std::min<int64_t>(B, 1 << 20)), dim3(kThreads), lds, h->stream, Lw_dev, ldl,
                      strideLw, Uw, D, D * D, inf, (int)D, (int)B);
   HIP_TRY(h, hipGetLastError());
@@ -907,8 +787,7 @@ int marginals_batched(blr_handle* h, int memspace, int layout, int64_t B, int64_
     const bool use_factor = var && kind == BLR_PRIOR_UPPER_FACTOR;
     const int xs_bytes = (TC::RB * TC::LDX * (int)sizeof(T) + 15) & ~15;
     const int lds = use_factor ? TC::LDS_BYTES + kPB * (int)sizeof(T) : xs_bytes + 2 * kPB * (int)sizeof(T) + 16;
-    HIP_TRY(h, hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize,
-                                   TC::LDS_BYTES + kPB * (int)sizeof(T)));
+    { const int rc_lds = set_lds_once(h, reinterpret_cast<const void*>(kern), (size_t)(TC::LDS_BYTES + kPB * (int)sizeof(T))); if (rc_lds) return rc_lds; }
     // every workgroup amortises its set-up over several tiles: aim at ~2 rounds of the chip
     const int64_t ntiles = (N + TC::RB - 1) / TC::RB;
     const int64_t slots = use_factor ? 512 : 1024;
@@ -1307,7 +1186,7 @@ int logpdf_grad_batched(blr_handle* h, int memspace, int layout, int64_t B, int6
   {
     auto kern = logpdf_grad_kernel<T>;
     const int lds = TC::LDS_BYTES + (kPB + 3 * TC::RB) * (int)sizeof(T);
-    HIP_TRY(h, hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, lds));
+    { const int rc_lds = set_lds_once(h, reinterpret_cast<const void*>(kern), (size_t)(lds)); if (rc_lds) return rc_lds; }
     for (int64_t b0 = 0; b0 < B; b0 += 65535) {  // grid.y <= 65535
       g.reg0 = (int)b0;
       hipLaunchKernelGGL(kern, dim3((unsigned)per_reg, (unsigned)std::min<int64_t>(65535, B - b0)), dim3(kThreads), lds, h->stream, g);
@@ -1619,7 +1498,7 @@ int sample_weights_impl(blr_handle* h, int memspace, int64_t D, int64_t S, int p
     using TC = TrsmCfg<T>;
     const int lds = TC::LDS_BYTES + kPB * (int)sizeof(T);
     auto kern = sample_weights_mfma_kernel<T>;
-    HIP_TRY(h, hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, lds));
+    { const int rc_lds = set_lds_once(h, reinterpret_cast<const void*>(kern), (size_t)(lds)); if (rc_lds) return rc_lds; }
     const int64_t ntiles = (S + TC::RB - 1) / TC::RB;
     hipLaunchKernelGGL(kern, dim3((unsigned)std::min<int64_t>(ntiles, 512)), dim3(kThreads), lds, h->stream, mw_d, U, ldu, Z_d, ldz,
                        W_d, ldw, (int)D, S);
@@ -1658,6 +1537,65 @@ int sample_weights(blr_handle* h, int memspace, int64_t D, int64_t S, int prior_
   HIP_TRY(h, hipSetDevice(h->device));
   Staging guard(h);
   return sample_weights_impl<T>(h, memspace, D, S, prior_kind, mw, Lw, ldl, Z, ldz, W, ldw, true, nullptr, &guard);
+}
+
+// Y (N x S) = X'W (+ sqrt.(s) .* Z2 when Z2 != NULL): device pointers
+template <typename T>
+void launch_project(blr_handle* h, int layout, int64_t D, int64_t N, int64_t S, const T* X_d, int64_t ldx, const T* W_d, int64_t ldw,
+                    const T* s_d, int noise_kind, const T* Z2_d, int64_t ldz2, T* Y_d, int64_t ldy) {
+  constexpr int kVec = Mfma<T>::VEC;
+  static const bool no_mfma_proj = getenv("BLR_MI355X_NO_MFMA_PROJECT") != nullptr;  // A/B experiments only
+  if (!no_mfma_proj && layout == BLR_LAYOUT_COLVECS && D % kVec == 0 && aligned16(X_d, ldx, 0) && aligned16(W_d, ldw, 0)) {
+    // tall-skinny GEMM on the matrix cores
+    using PC = ProjCfg<T>;
+    dim3 grid((unsigned)((N + PC::TN - 1) / PC::TN), (unsigned)((S + PC::TS - 1) / PC::TS));
+    hipLaunchKernelGGL(rand_project_mfma_kernel<T>, grid, dim3(kThreads), PC::LDS_BYTES, h->stream, X_d, ldx, W_d, ldw, s_d, noise_kind,
+                       Z2_d, ldz2, Y_d, ldy, (int)D, (int)N, S);
+  } else {
+    dim3 grid((unsigned)((N + 63) / 64), (unsigned)((S + 63) / 64));
+    hipLaunchKernelGGL(rand_project_kernel<T>, grid, dim3(kThreads), 0, h->stream, X_d, ldx, layout, W_d, ldw, s_d, noise_kind, Z2_d,
+                       ldz2, Y_d, ldy, (int)D, (int)N, S);
+  }
+}
+
+// ---- Y = X'W for S given weight vectors: evaluation of function samples (reference sampling_functions.jl:16-18) ------------
+template <typename T>
+int apply_weights(blr_handle* h, int memspace, int layout, int64_t D, int64_t N, int64_t S, const T* X, int64_t ldx, const T* W,
+                  int64_t ldw, T* Y, int64_t ldy) {
+  if (!h) return -1;
+  h->err.clear();
+  if (memspace != BLR_MEM_HOST && memspace != BLR_MEM_DEVICE) return bad_arg(h, 2, "memspace");
+  if (layout != BLR_LAYOUT_COLVECS && layout != BLR_LAYOUT_ROWVECS) return bad_arg(h, 3, "unknown layout (reference :26-31)");
+  if (D < 1 || D > (1 << 30)) return bad_arg(h, 4, "D out of range");
+  if (N < 0 || N > (1 << 30)) return bad_arg(h, 5, "N out of range");
+  if (S < 0 || S > (1 << 30)) return bad_arg(h, 6, "S out of range");
+  if (N == 0 || S == 0) return 0;
+  if (!X) return bad_arg(h, 7, "X is NULL");
+  if (layout == BLR_LAYOUT_COLVECS ? ldx < D : ldx < N) return bad_arg(h, 8, "ldx too small");
+  if (!W) return bad_arg(h, 9, "W is NULL");
+  if (ldw < D) return bad_arg(h, 10, "ldw < D");
+  if (!Y) return bad_arg(h, 11, "Y is NULL");
+  if (ldy < N) return bad_arg(h, 12, "ldy < N");
+  HIP_TRY(h, hipSetDevice(h->device));
+  Staging guard(h);
+  const T *X_d = X, *W_d = W;
+  T* Y_d = Y;
+  int rc;
+  if (memspace == BLR_MEM_HOST) {
+    const size_t x_one = layout == BLR_LAYOUT_COLVECS ? mat_extent(D, N, ldx) : mat_extent(N, D, ldx);
+    if ((rc = stage_in(h, X, x_one, &X_d))) return rc;
+    if ((rc = stage_in(h, W, mat_extent(D, S, ldw), &W_d))) return rc;
+    if ((rc = stage_out_alloc(h, Y, mat_extent(N, S, ldy), &Y_d))) return rc;
+  }
+  launch_project<T>(h, layout, D, N, S, X_d, ldx, W_d, ldw, (const T*)nullptr, BLR_NOISE_ISOTROPIC, (const T*)nullptr, 0, Y_d, ldy);
+  HIP_TRY(h, hipGetLastError());
+  if (memspace == BLR_MEM_HOST) {
+    HIP_TRY(h, hipMemcpyAsync(Y, Y_d, mat_extent(N, S, ldy) * sizeof(T), hipMemcpyDeviceToHost, h->stream));
+    HIP_TRY(h, hipStreamSynchronize(h->stream));
+  } else if (!h->async) {
+    HIP_TRY(h, hipStreamSynchronize(h->stream));
+  }
+  return 0;
 }
 
 template <typename T>
@@ -1702,9 +1640,7 @@ int rand_impl(blr_handle* h, int memspace, int layout, int64_t D, int64_t N, int
     if ((rc = stage_in(h, Z2, mat_extent(N, S, ldz2), &Z2_d))) return rc;
     if ((rc = stage_out_alloc(h, Y, mat_extent(N, S, ldy), &Y_d))) return rc;
   }
-  dim3 grid((unsigned)((N + 63) / 64), (unsigned)((S + 63) / 64));
-  hipLaunchKernelGGL(rand_project_kernel<T>, grid, dim3(kThreads), 0, h->stream, X_d, ldx, layout, (const T*)W_dev,
-                     (int64_t)D, s_d, noise_kind, Z2_d, ldz2, Y_d, ldy, (int)D, (int)N, S);
+  launch_project<T>(h, layout, D, N, S, X_d, ldx, (const T*)W_dev, (int64_t)D, s_d, noise_kind, Z2_d, ldz2, Y_d, ldy);
   HIP_TRY(h, hipGetLastError());
   if (memspace == BLR_MEM_HOST) {
     HIP_TRY(h, hipMemcpyAsync(Y, Y_d, mat_extent(N, S, ldy) * sizeof(T), hipMemcpyDeviceToHost, h->stream));
@@ -2195,7 +2131,7 @@ int update_factor(blr_handle* h, int memspace, int layout, int64_t B, int64_t D,
   a.ldx = ldx; a.strideX = strideX; a.layout = layout; a.stridey = stridey; a.strides = strides; a.noise_kind = noise_kind;
   a.stridemw = stridemw; a.ldt = ldt; a.strideT = strideT; a.D = (int)D; a.k = (int)k;
   const int lds = sweep_lds_bytes<T>((int)D);
-  HIP_TRY(h, hipFuncSetAttribute(reinterpret_cast<const void*>(rank1_sweep_kernel<T>), hipFuncAttributeMaxDynamicSharedMemorySize, lds));
+  { const int rc_lds = set_lds_once(h, reinterpret_cast<const void*>(rank1_sweep_kernel<T>), (size_t)(lds)); if (rc_lds) return rc_lds; }
   if (memspace == BLR_MEM_DEVICE) {
     a.X = X; a.y = y; a.s = s; a.mw = mw; a.Tf = Tf; a.logpdf = logpdf; a.info = info;
     hipLaunchKernelGGL(rank1_sweep_kernel<T>, dim3((unsigned)B), dim3(kThreads), lds, h->stream, a);
@@ -2272,12 +2208,6 @@ int blr_destroy(blr_handle* h) {
   if (h->ticket) (void)hipFree(h->ticket);
   if (h->ev0) (void)hipEventDestroy(h->ev0);
   if (h->ev1) (void)hipEventDestroy(h->ev1);
-  if (h->s_chain) (void)hipStreamDestroy(h->s_chain);
-  if (h->s_reduce) (void)hipStreamDestroy(h->s_reduce);
-  for (hipStream_t g : h->s_gram) if (g) (void)hipStreamDestroy(g);
-  if (h->ev_fork) (void)hipEventDestroy(h->ev_fork);
-  if (h->ev_join) (void)hipEventDestroy(h->ev_join);
-  for (hipEvent_t e : h->ev_col) (void)hipEventDestroy(e);
   if (h->own_stream) (void)hipStreamDestroy(h->own_stream);
   delete h;
   return 0;
@@ -2444,6 +2374,10 @@ int blr_timer_stop(blr_handle* h, float* elapsed_ms) {
                              const T* Lw, int64_t ldl, T* mean, T* C, int64_t ldc, int32_t* info) {                 \
     return mean_and_cov<T>(h, memspace, layout, D, N, X, ldx, noise_kind, s, lds, prior_kind, mw, Lw, ldl, mean,    \
                            C, ldc, info);                                                                           \
+  }                                                                                                                 \
+  int blr_apply_weights_##SUF(blr_handle* h, int memspace, int layout, int64_t D, int64_t N, int64_t S, const T* X, \
+                              int64_t ldx, const T* W, int64_t ldw, T* Y, int64_t ldy) {                            \
+    return apply_weights<T>(h, memspace, layout, D, N, S, X, ldx, W, ldw, Y, ldy);                                  \
   }                                                                                                                 \
   int blr_rand_dense_noise_##SUF(blr_handle* h, int memspace, int layout, int64_t D, int64_t N, int64_t S,          \
                                  const T* X, int64_t ldx, const T* Sy, int64_t ldsy, int prior_kind, const T* mw,   \

@@ -114,13 +114,139 @@ __global__ __launch_bounds__(kThreads) void rand_project_kernel(const T* __restr
   }
   const int n = n0 + tn;
   if (n < N) {
-    const T sd = sqrt((noise_kind == NOISE_DIAGONAL) ? s[n] : s[0]);
+    const T sd = Z2 ? sqrt((noise_kind == NOISE_DIAGONAL) ? s[n] : s[0]) : T(0);  // Z2 == NULL: Y = X'W (blr_apply_weights_*)
 #pragma unroll
     for (int j = 0; j < 16; ++j) {
       int64_t sidx = s0 + ts + 4 * j;
-      if (sidx < S) Y[sidx * ldy + n] = accv[j] + sd * Z2[sidx * ldz2 + n];
+      if (sidx < S) Y[sidx * ldy + n] = Z2 ? accv[j] + sd * Z2[sidx * ldz2 + n] : accv[j];
     }
   }
+}
+
+// ---- the same projection on the matrix cores: ColVecs inputs with 16-byte aligned columns ---------------------------------
+// Y (N x S) = X' W is a tall-skinny GEMM that reads X once: 128 inputs x 64 draws per workgroup, the contraction over d in
+// chunks of KC rows staged in MFMA fragment order (A side: X' rows = inputs, B side: W columns = draws; both operands have the
+// contraction index contiguous in memory, so one 16-byte load is VEC consecutive k values of one row and lands as VEC
+// strided LDS words).  The next chunk's loads are in flight while the current one is multiplied; one barrier per chunk.
+// The scalar-FMA kernel above stays for RowVecs / unaligned inputs.
+template <typename T>
+struct ProjCfg {
+  static constexpr int TN = 128, TS = 64;
+  static constexpr int VEC = Mfma<T>::VEC;
+  static constexpr int KC = 128 / (int)sizeof(T);            // contraction rows per chunk: 32 (f32) / 16 (f64) = 8 vectors per row
+  static constexpr int KST = KC / 4;                         // k-steps per chunk
+  static constexpr int SIDE_A = KST * (TN / 16) * 64;        // elements
+  static constexpr int SIDE_B = KST * (TS / 16) * 64;
+  static constexpr int LDS_BYTES = 2 * (SIDE_A + SIDE_B) * (int)sizeof(T);  // 48 KB
+  static constexpr int VA = TN * (KC / VEC) / kThreads;      // vectors per thread per chunk: 4 (A), 2 (B)
+  static constexpr int VB = TS * (KC / VEC) / kThreads;
+};
+
+template <typename T>
+__global__ __launch_bounds__(kThreads, 2) void rand_project_mfma_kernel(const T* __restrict__ X, int64_t ldx, const T* __restrict__ W,
+                                                                        int64_t ldw, const T* __restrict__ s, int noise_kind,
+                                                                        const T* __restrict__ Z2, int64_t ldz2, T* __restrict__ Y,
+                                                                        int64_t ldy, int D, int N, int64_t S) {
+  using Cf = ProjCfg<T>;
+  using acc4 = typename Mfma<T>::acc4;
+  constexpr int VEC = Cf::VEC, VPR = Cf::KC / VEC;  // vectors per row and chunk
+  typedef T vecT __attribute__((ext_vector_type(Mfma<T>::VEC)));
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  T* const base = reinterpret_cast<T*>(smem);
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int n0 = blockIdx.x * Cf::TN;
+  const int64_t s0 = (int64_t)blockIdx.y * Cf::TS;
+  acc4 acc[2][4];
+#pragma unroll
+  for (int i = 0; i < 2; ++i)
+#pragma unroll
+    for (int k = 0; k < 4; ++k) acc[i][k] = acc4{T(0), T(0), T(0), T(0)};
+  vecT pa[Cf::VA], pb[Cf::VB];
+  auto prefetch = [&](int d0) {
+#pragma unroll
+    for (int u = 0; u < Cf::VA; ++u) {
+      const int vi = u * kThreads + tid, dv = vi % VPR, nl = vi / VPR;
+      const int d = d0 + dv * VEC, n = n0 + nl;
+      const bool ok = d < D && n < N;  // D is a multiple of VEC on this path: a vector is inside or outside as a whole
+      const vecT v = *reinterpret_cast<const vecT*>(X + (ok ? (int64_t)n * ldx + d : 0));
+      pa[u] = ok ? v : vecT(T(0));
+    }
+#pragma unroll
+    for (int u = 0; u < Cf::VB; ++u) {
+      const int vi = u * kThreads + tid, dv = vi % VPR, sl = vi / VPR;
+      const int d = d0 + dv * VEC;
+      const int64_t sidx = s0 + sl;
+      const bool ok = d < D && sidx < S;
+      const vecT v = *reinterpret_cast<const vecT*>(W + (ok ? sidx * ldw + d : 0));
+      pb[u] = ok ? v : vecT(T(0));
+    }
+  };
+  // fragment image [k-step][16-row block][lane = (k & 3) * 16 + row % 16]
+  auto store = [&](T* slot) {
+    T* const A = slot;
+    T* const Bm = slot + Cf::SIDE_A;
+#pragma unroll
+    for (int u = 0; u < Cf::VA; ++u) {
+      const int vi = u * kThreads + tid, dv = vi % VPR, nl = vi / VPR;
+#pragma unroll
+      for (int e = 0; e < VEC; ++e) {
+        const int k = dv * VEC + e;
+        A[(((k >> 2) * (Cf::TN / 16) + (nl >> 4)) << 6) + ((k & 3) << 4) + (nl & 15)] = pa[u][e];
+      }
+    }
+#pragma unroll
+    for (int u = 0; u < Cf::VB; ++u) {
+      const int vi = u * kThreads + tid, dv = vi % VPR, sl = vi / VPR;
+#pragma unroll
+      for (int e = 0; e < VEC; ++e) {
+        const int k = dv * VEC + e;
+        Bm[(((k >> 2) * (Cf::TS / 16) + (sl >> 4)) << 6) + ((k & 3) << 4) + (sl & 15)] = pb[u][e];
+      }
+    }
+  };
+  const int nchunks = (D + Cf::KC - 1) / Cf::KC;
+  prefetch(0);
+  store(base);
+  __syncthreads();
+  for (int c = 0; c < nchunks; ++c) {
+    const T* slot = base + (c & 1) * (Cf::SIDE_A + Cf::SIDE_B);
+    if (c + 1 < nchunks) prefetch((c + 1) * Cf::KC);
+#pragma unroll
+    for (int j = 0; j < Cf::KST; ++j) {
+      T fa[2], fb[4];
+#pragma unroll
+      for (int i = 0; i < 2; ++i) fa[i] = slot[((j * (Cf::TN / 16) + 2 * wave + i) << 6) + lane];
+#pragma unroll
+      for (int k = 0; k < 4; ++k) fb[k] = slot[Cf::SIDE_A + ((j * (Cf::TS / 16) + k) << 6) + lane];
+#pragma unroll
+      for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int k = 0; k < 4; ++k) acc[i][k] = Mfma<T>::mma(fa[i], fb[k], acc[i][k]);
+    }
+    if (c + 1 < nchunks) store(base + ((c + 1) & 1) * (Cf::SIDE_A + Cf::SIDE_B));
+    __syncthreads();
+  }
+  // Y[n, s] = acc + sqrt(s_n) z2[n, s]: lane (column = draw, 4 rows = inputs)
+#pragma unroll
+  for (int i = 0; i < 2; ++i)
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+      const int64_t sidx = s0 + 16 * k + (lane & 15);
+      if (sidx >= S) continue;
+#pragma unroll
+      for (int v = 0; v < 4; ++v) {
+        const int n = n0 + 16 * (2 * wave + i) + Mfma<T>::crow(lane, v);
+        if (n < N) {
+          if (Z2) {
+            const T sd = sqrt((noise_kind == NOISE_DIAGONAL) ? s[n] : s[0]);
+            Y[sidx * ldy + n] = acc[i][k][v] + sd * Z2[sidx * ldz2 + n];
+          } else {
+            Y[sidx * ldy + n] = acc[i][k][v];
+          }
+        }
+      }
+    }
 }
 
 // ---- random-Fourier feature map (BASELINE config 5): Phi[f, n] = scale * cos(sum_k Omega[k, f] x[k, n] + phase[f]) ----

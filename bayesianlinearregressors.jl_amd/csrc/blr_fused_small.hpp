@@ -1087,10 +1087,21 @@ BLR_PHASE void phase_gram(char* smem) {
 // Two barriers per block column, no LDS round trip for the trailing matrix.  On exit P holds L (A = L L'),
 // bvec holds u = L^-1 b.  Returns 0 or the LAPACK-style 1-based index of the failing leading minor.
 // =========================================================================================================
+// The factorisation is bound by INSTRUCTION ISSUE, not by arithmetic: one wave runs ~5 cycles per instruction here, and the
+// first version spent ~1700 instructions per 16-column panel (540 in the elimination proper, 360 in predicated write-back
+// stores, 670 in the trailing update -- packed-triangle index arithmetic per fragment element and an exec-mask branch per
+// predicated store).  This form keeps the algorithm and removes the bookkeeping:
+//   * a fragment address is  pidx(16 I, 0) [scalar] + 16 I r + pidx(r, 0) [one multiply-add per tile side] + an immediate;
+//   * rows are loaded WITHOUT masking -- the entries to the right of the diagonal of a diagonal-block row are dead values
+//     (never stored, never read by another lane), so whatever the packed triangle holds there is harmless;
+//   * predicated stores go to a per-lane dummy word (the dinv area, unused until the back substitution) through an address
+//     select instead of an exec-mask branch each;
+//   * tiles are skipped by scalar branches on wave-uniform tile coordinates.
 template <typename T, int NB>
 BLR_PHASE int phase_chol(char* smem, int D_in, int with_rhs_in) {
   using C = SmallCfg<T, NB>;
   using acc4 = typename Mfma<T>::acc4;
+  constexpr int TPW = C::TPW;
   T* const P = reinterpret_cast<T*>(smem);
   T* const bvec = reinterpret_cast<T*>(smem + C::OFF_B);
   int tid = threadIdx.x;
@@ -1100,17 +1111,29 @@ BLR_PHASE int phase_chol(char* smem, int D_in, int with_rhs_in) {
   const int D = uni(D_in);
   const bool with_rhs = uni(with_rhs_in) != 0;
   const int nblk = (D + 15) >> 4;
-
-  // tiles from P (diagonal tiles: mirror the lower half so the tile is symmetric)
-  acc4 acc[C::TPW];
+  const int r = lane & 15, q = lane >> 4;
+  const int pr = (r * (r + 1)) >> 1;  // pidx(r, 0)
+  T* const dummy = reinterpret_cast<T*>(smem + C::OFF_DINV) + r;
+  int cr[4], pcr[4];  // C-layout rows of this lane inside a tile, and pidx(cr, 0)
 #pragma unroll
-  for (int i = 0; i < C::TPW; ++i) {
+  for (int v = 0; v < 4; ++v) {
+    cr[v] = Mfma<T>::crow(lane, v);
+    pcr[v] = (cr[v] * (cr[v] + 1)) >> 1;
+  }
+
+  // tiles from P (diagonal tiles: mirror the lower half so the tile is symmetric); wave-uniform tile coordinates
+  acc4 acc[TPW];
+  int tI[TPW], tK[TPW];
+#pragma unroll
+  for (int i = 0; i < TPW; ++i) {
     int I, K;
     const bool tile_ok = wave_tile(NB, wave, i, I, K);
-    const int col = 16 * K + (lane & 15);
+    tI[i] = uni(I);
+    tK[i] = uni((tile_ok && I < nblk) ? K : -1);  // -1: never updated, never stored
+    const int col = 16 * K + r;
 #pragma unroll
     for (int v = 0; v < 4; ++v) {
-      const int row = 16 * I + Mfma<T>::crow(lane, v);
+      const int row = 16 * I + cr[v];
       acc[i][v] = tile_ok ? P[pidx(max(row, col), min(row, col))] : T(0);
     }
   }
@@ -1123,23 +1146,19 @@ BLR_PHASE int phase_chol(char* smem, int D_in, int with_rhs_in) {
     //     after updating it -- one barrier per block column instead of two
     __syncthreads();
     BLR_STAMP(1);
-    BLR_STAMP(2);
-    // (b) one row per lane
+    // (b) one row per lane: lanes 0-15 the diagonal-block rows (redundantly in all four waves), lanes 16-63 rows below
     const bool is_diag = lane < 16;
     const int ri = is_diag ? 16 * J + lane : 16 * (J + 1) + 48 * wave + (lane - 16);
     const bool active = ri < D;
+    const int ria = active ? ri : 0;
     const int ncols = min(16, D - 16 * J);
+    T* const rowp = P + (((ria * (ria + 1)) >> 1) + 16 * J);
     T arow[16];
-    T bl = T(0);
-    {
-      const T* src = P + pidx(active ? ri : 0, 16 * J);
 #pragma unroll
-      for (int c = 0; c < 16; ++c) {
-        const bool ok = active && (!is_diag || c <= lane);
-        arow[c] = ok ? src[c] : T(0);
-      }
-      if (with_rhs && active) bl = bvec[ri];
-    }
+    for (int c = 0; c < 16; ++c) arow[c] = rowp[c];  // unmasked: see the header comment
+    T bl = T(0);
+    if (with_rhs) bl = bvec[ria];
+    BLR_STAMP(2);
     // Elimination with DEFERRED scaling: column c stays unscaled while it is being used (multiplier
     // t = a_ic / d2, update a_ik -= t * a_kc, b_i -= t * b_c), so the serial chain per column is
     // readlane -> reciprocal -> multiply -> fma; the square root is taken off the critical path afterwards.
@@ -1167,34 +1186,41 @@ BLR_PHASE int phase_chol(char* smem, int D_in, int with_rhs_in) {
     if (is_diag) bl *= own_rsq;  // u_c = b_c / L_cc for the diagonal-block rows
     BLR_STAMP(3);
     if (info != 0) break;  // uniform across the block: every wave factors the same diagonal rows
-    if (active) {
-      T* dst = P + pidx(ri, 16 * J);
+    {
+      const int lim = active ? (is_diag ? lane : 15) : -1;  // columns 0 .. lim of this lane's row are stored
 #pragma unroll
-      for (int c = 0; c < 16; ++c)
-        if (!is_diag || c <= lane) dst[c] = arow[c];
-      if (with_rhs && (!is_diag || wave == 0)) bvec[ri] = bl;
+      for (int c = 0; c < 16; ++c) {
+        T* dst = (c <= lim) ? rowp + c : dummy;
+        *dst = arow[c];
+      }
+      if (with_rhs && active && (!is_diag || wave == 0)) bvec[ri] = bl;
     }
     __syncthreads();
     BLR_STAMP(4);
-    // (c) trailing update from the finished panel
-    const int r = lane & 15, q = lane >> 4;
+    // (c) trailing update from the finished panel; block column J + 1 is final after it and goes straight back to P
+    const int pc = pr + 16 * J + q;
 #pragma unroll
-    for (int i = 0; i < C::TPW; ++i) {
-      int I, K;
-      if (wave_tile(NB, wave, i, I, K) && K > J && I < nblk) {
-        const int rowI = 16 * I + r, rowK = 16 * K + r;
+    for (int i = 0; i < TPW; ++i) {
+      if (tK[i] > J) {  // scalar branch
+        const int I = tI[i], K = tK[i];
+        const T* pI = P + ((128 * I * I + 8 * I) + (16 * I) * r + pc);  // pidx(16 I + r, 16 J + q)
+        const T* pK = P + ((128 * K * K + 8 * K) + (16 * K) * r + pc);
+        T fa[4], fb[4];
 #pragma unroll
-        for (int ks = 0; ks < 4; ++ks) {
-          const T fI = P[pidx(rowI, 16 * J + 4 * ks + q)];
-          const T fK = P[pidx(rowK, 16 * J + 4 * ks + q)];
-          acc[i] = Mfma<T>::mma(-fI, fK, acc[i]);
-        }
-        if (K == J + 1) {  // the next panel: final now, straight to the packed triangle (column J+1 is not read by (c))
-          const int col = 16 * K + (lane & 15);
+        for (int ks = 0; ks < 4; ++ks) { fa[ks] = pI[4 * ks]; fb[ks] = pK[4 * ks]; }
 #pragma unroll
-          for (int v = 0; v < 4; ++v) {
-            const int row = 16 * I + Mfma<T>::crow(lane, v);
-            if (col <= row) P[pidx(row, col)] = acc[i][v];
+        for (int ks = 0; ks < 4; ++ks) acc[i] = Mfma<T>::mma(-fa[ks], fb[ks], acc[i]);
+        if (K == J + 1) {  // scalar
+          const int sb = (128 * I * I + 8 * I) + 16 * K + r;
+          if (I != K) {
+#pragma unroll
+            for (int v = 0; v < 4; ++v) P[sb + (16 * I) * cr[v] + pcr[v]] = acc[i][v];
+          } else {
+#pragma unroll
+            for (int v = 0; v < 4; ++v) {
+              T* dst = (r <= cr[v]) ? P + (sb + (16 * I) * cr[v] + pcr[v]) : dummy;
+              *dst = acc[i][v];
+            }
           }
         }
       }
@@ -1211,7 +1237,7 @@ BLR_PHASE int phase_chol(char* smem, int D_in, int with_rhs_in) {
 // Returns through LDS: bvec <- m (rows < D), scr[6] = |u|^2, scr[7] = logdet A.
 // =========================================================================================================
 template <typename T, int NB>
-BLR_PHASE void phase_backsolve(char* smem, int D_in) {
+BLR_PHASE void phase_backsolve(char* smem, int D_in, T* Tout_in, int64_t ldt_in) {
   using C = SmallCfg<T, NB>;
   T* const P = reinterpret_cast<T*>(smem);
   T* const bvec = reinterpret_cast<T*>(smem + C::OFF_B);
@@ -1222,9 +1248,25 @@ BLR_PHASE void phase_backsolve(char* smem, int D_in) {
   const int lane = tid & 63;
   const int wave = uni(tid >> 6);
   const int D = uni(D_in);
+  BLR_GLOBAL T* const Tout = as_global(uni(Tout_in));
+  const int64_t ldt = uni(ldt_in);
   if (tid < D) dinv[tid] = T(1) / P[pidx(tid, tid)];
   __syncthreads();
-  if (wave == 0) {
+  if (wave != 0) {
+    // T = L' (upper, column-major; strictly-lower part zero) goes out while wave 0 runs the serial substitution: the
+    // three waves would otherwise sit at the closing barrier (:67, chol(...).U)
+    if (Tout != nullptr) {
+      for (int c = wave - 1; c < D; c += kWaves - 1) {
+        const T* row = P + pidx(c, 0);
+        BLR_GLOBAL T* out = Tout + (int64_t)c * ldt;
+        const int r0 = lane, r1 = lane + 64;
+        const T v0 = (r0 <= c) ? row[r0] : T(0);
+        const T v1 = (r1 <= c) ? row[r1] : T(0);
+        if (r0 < D) out[r0] = v0;
+        if (r1 < D) out[r1] = v1;
+      }
+    }
+  } else {
     const int i0 = lane, i1 = lane + 64;
     T b0 = i0 < D ? bvec[i0] : T(0);
     T b1 = i1 < D ? bvec[i1] : T(0);
@@ -1405,15 +1447,9 @@ __global__ __launch_bounds__(kThreads, (NB <= 4 ? 4 : (sizeof(T) == 4 ? BLR_F32_
       }
       continue;
     }
-    if (a.T_post) {
-      T* out = a.T_post + (int64_t)reg * a.strideT;
-      for (int c = tid >> 6; c < D; c += kWaves)
-        for (int r = tid & 63; r < D; r += kWave) out[(int64_t)c * a.ldt + r] = (r <= c) ? P[pidx(c, r)] : T(0);
-    }
-
-    // ---- phase 3: back substitution + evidence ---------------------------------------------------------
+    // ---- phase 3: back substitution (wave 0) with T = L' written by the other three waves, evidence ------
     BLR_PSTAMP(4);
-    phase_backsolve<T, NB>(smem, D);
+    phase_backsolve<T, NB>(smem, D, a.T_post ? a.T_post + (int64_t)reg * a.strideT : (T*)nullptr, a.ldt);
     BLR_PSTAMP(5);
     if (a.mw_post && tid < D) a.mw_post[(int64_t)reg * a.stride_mwpost + tid] = mw[tid] + bvec[tid];  // :68
     if (tid == 0) {

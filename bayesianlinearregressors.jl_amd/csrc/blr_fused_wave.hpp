@@ -41,7 +41,9 @@ struct WaveCfg {
   static constexpr int OFF_W = OFF_S + DEPTH * NSC * (int)sizeof(T);         // wbuf[NSC]
   static constexpr int OFF_B = OFF_W + NSC * (int)sizeof(T);                 // bvec[DP]
   static constexpr int OFF_SCR = (OFF_B + DP * (int)sizeof(T) + 15) & ~15;   // 4 doubles + 4 ints
-  static constexpr int LDS_BYTES = OFF_SCR + 48;
+  static constexpr int OFF_PART = OFF_SCR + 48;                              // N split over several waves: this wave's partial
+                                                                             // b (DP doubles), quadratic form, logdet, bad index
+  static constexpr int LDS_BYTES = OFF_PART + DP * 8 + 32;                   // one wave's slice of the workgroup's LDS
   static constexpr int FPG = (1024 / (int)sizeof(T)) / 64;               // fragments per 1 KiB LDS-DMA piece
   static constexpr int NG = KS * NB / FPG;                               // X pieces per stage
   static constexpr int YL = NSC * (int)sizeof(T) / 4;                    // dword lanes of the y / s piece of a stage
@@ -60,13 +62,20 @@ struct WaveCfg {
 // 0.47 ms of a 1.21 ms launch at config 4: every wave sat out a memory latency per stage).  Everything a stage needs -- X,
 // y and, for diagonal noise, the variances -- travels by LDS-DMA issued from inline asm, so the only vector-memory
 // operations in the loop are these pieces and the stage's arrival is a COUNTED s_waitcnt vmcnt(2 x pieces-per-stage).
-template <typename T, int NB, bool DIAG>
-BLR_PHASE void wave_gram(char* smem, const BLR_GLOBAL T* X, int64_t ldx, const BLR_GLOBAL T* y, const BLR_GLOBAL T* s,
+// NW > 1: the observations of ONE regressor are split over the NW waves of the workgroup (contiguous runs of whole stages;
+// each wave streams through its own ring in its own LDS slice `smem0 + w * LDS_BYTES`), the partial statistics of waves
+// 1 .. NW-1 are handed to wave 0 through their slices and added in wave order -- a fixed order, so the result is bitwise
+// reproducible -- and wave 0 alone continues with the factorisation.  Used for batches too small to give every wave slot of
+// the chip a regressor of its own (config 4 sharded over 8 GPUs: 1024 regressors per GPU for 2048 wave slots).
+template <typename T, int NB, bool DIAG, int NW>
+BLR_PHASE void wave_gram(char* smem0, const BLR_GLOBAL T* X, int64_t ldx, const BLR_GLOBAL T* y, const BLR_GLOBAL T* s,
                          const BLR_GLOBAL T* mw, T dpr, int N, int prior_kind, const BLR_GLOBAL T* Lw, int64_t ldl) {
   using C = WaveCfg<T, NB>;
   using acc4 = typename Mfma<T>::acc4;
   constexpr int VEC = Mfma<T>::VEC;
   constexpr int PPS = C::NG + 1 + (DIAG ? 1 : 0);  // LDS-DMA instructions per stage
+  const int w = (NW == 1) ? 0 : uni((int)(threadIdx.x >> 6));
+  char* const smem = smem0 + w * C::LDS_BYTES;
   T* const ring = reinterpret_cast<T*>(smem);
   T* const P = reinterpret_cast<T*>(smem);  // after the loop
   T* const ybuf = reinterpret_cast<T*>(smem + C::OFF_Y);
@@ -75,7 +84,7 @@ BLR_PHASE void wave_gram(char* smem, const BLR_GLOBAL T* X, int64_t ldx, const B
   T* const bvec = reinterpret_cast<T*>(smem + C::OFF_B);
   double* const scr = reinterpret_cast<double*>(smem + C::OFF_SCR);
   int* const iscr = reinterpret_cast<int*>(smem + C::OFF_SCR + 32);
-  int lane = threadIdx.x;
+  int lane = threadIdx.x & 63;
   asm volatile("" : "+v"(lane));
   const int r16 = lane & 15, q4 = lane >> 4;
   N = uni(N);
@@ -103,9 +112,14 @@ BLR_PHASE void wave_gram(char* smem, const BLR_GLOBAL T* X, int64_t ldx, const B
 #pragma unroll
   for (int I = 0; I < NB; ++I) bacc[I] = 0.0;
   double qacc = 0.0, lacc = 0.0;
-  const int nfull = N / C::NSC;  // whole stages; a ragged tail is handled after the pipeline has drained
+  const int nfull_all = N / C::NSC;  // whole stages; a ragged tail is handled after the pipeline has drained
+  // this wave's run of whole stages [t0, t0 + nfull): the LAST waves take the remainder, wave 0 -- which also factorises --
+  // the smallest share
+  const int share = nfull_all / NW, rem = nfull_all - share * NW;
+  const int t0 = (NW == 1) ? 0 : w * share + max(0, w - (NW - rem));
+  const int nfull = (NW == 1) ? nfull_all : share + (w >= NW - rem ? 1 : 0);
   auto issue = [&](int td) {     // exactly PPS LDS-DMA instructions
-    const int n0 = td * C::NSC, sl = td & (C::DEPTH - 1);
+    const int n0 = (t0 + td) * C::NSC, sl = td & (C::DEPTH - 1);
     const unsigned slot_addr = ring_addr + (unsigned)(sl * C::SLOT * (int)sizeof(T));
 #pragma unroll
     for (int g = 0; g < C::NG; ++g) {
@@ -170,7 +184,7 @@ BLR_PHASE void wave_gram(char* smem, const BLR_GLOBAL T* X, int64_t ldx, const B
   };
 
   prior_kind = uni(prior_kind);
-  if (prior_kind == PRIOR_UPPER_FACTOR) {
+  if (w == 0 && prior_kind == PRIOR_UPPER_FACTOR) {
     // a carried-forward factor U (PDMat prior, blr_update_factor_*): U'U = sum_j u_j u_j' with u_j = row j of U, i.e. D
     // pseudo-observation columns with element (d, j) = U[j + d ldl] for j <= d.  Isotropic noise accumulates X X' unscaled and
     // divides by s once at the end, so the pseudo-columns carry sqrt(s) here.  A handful of stages, loaded synchronously.
@@ -213,7 +227,7 @@ BLR_PHASE void wave_gram(char* smem, const BLR_GLOBAL T* X, int64_t ldx, const B
 #if BLR_EXP != 4
     if (t + C::DEPTH - 1 < nfull) issue(t + C::DEPTH - 1);  // into the slot stage t - 1 was read from
 #endif
-    if constexpr (DIAG) weights(sbuf + sl * C::NSC, t * C::NSC);
+    if constexpr (DIAG) weights(sbuf + sl * C::NSC, (t0 + t) * C::NSC);
 #if BLR_EXP == 5  // streaming only: what the memory system delivers to this access pattern
     qacc += (double)ring[sl * C::SLOT + lane];
 #else
@@ -222,10 +236,10 @@ BLR_PHASE void wave_gram(char* smem, const BLR_GLOBAL T* X, int64_t ldx, const B
   }
   asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
   __builtin_amdgcn_wave_barrier();
-  if (nfull * C::NSC < N) {
+  if (w == NW - 1 && nfull_all * C::NSC < N) {
     // ragged tail (N not a multiple of the stage width): loaded synchronously, lane by lane, zeros beyond N
     typedef T vecT __attribute__((ext_vector_type(Mfma<T>::VEC)));
-    const int n0 = nfull * C::NSC;
+    const int n0 = nfull_all * C::NSC;
     T* slot = ring;
     const int e0 = lane * VEC;
     const int fl = e0 >> 6, ls = e0 & 63, q = ls >> 4, r = ls & 15;
@@ -266,19 +280,64 @@ BLR_PHASE void wave_gram(char* smem, const BLR_GLOBAL T* X, int64_t ldx, const B
   // ---- reductions: b (over the 4 column groups of the lanes), quadratic form, logdet Sigma_y, noise check
   const T w_iso = T(1) / s_iso;
   double quad = wave_allreduce(qacc);
-  const double logdet_Sy = DIAG ? wave_allreduce(lacc) : (double)N * log((double)s_iso);
-  if (!DIAG) quad *= (double)w_iso;
+  double lsum = DIAG ? wave_allreduce(lacc) : 0.0;
   {
     int bn = bad_noise;
 #pragma unroll
     for (int off = 32; off > 0; off >>= 1) bn = min(bn, __shfl_xor(bn, off));
     bad_noise = bn;
   }
+  double bsum[NB];
 #pragma unroll
   for (int I = 0; I < NB; ++I) {
     double v = bacc[I];
     v += __shfl_xor(v, 16);
     v += __shfl_xor(v, 32);
+    bsum[I] = v;
+  }
+  if constexpr (NW > 1) {
+    double* const part = reinterpret_cast<double*>(smem + C::OFF_PART);
+    if (w != 0) {
+      // hand the raw partials over: G (lower triangle, packed like P), b, quadratic form, logdet, first bad variance
+#pragma unroll
+      for (int I = 0; I < NB; ++I) {
+        if (q4 == 0) part[16 * I + r16] = bsum[I];
+#pragma unroll
+        for (int K = 0; K <= I; ++K) {
+          const int t = I * (I + 1) / 2 + K;
+          const int col = 16 * K + r16;
+#pragma unroll
+          for (int v = 0; v < 4; ++v) {
+            const int row = 16 * I + Mfma<T>::crow(lane, v);
+            if (col <= row) P[pidx(row, col)] = acc[t][v];
+          }
+        }
+      }
+      if (lane == 0) {
+        part[C::DP] = quad;
+        part[C::DP + 1] = lsum;
+        reinterpret_cast<int*>(part + C::DP + 2)[0] = bad_noise;
+      }
+      __syncthreads();  // A: partials visible to wave 0
+      __syncthreads();  // B: wave 0 has consumed them -- the slice is free for the next regressor
+      return;
+    }
+    __syncthreads();    // A
+#pragma unroll
+    for (int ww = 1; ww < NW; ++ww) {  // wave order: fixed
+      const double* pw = reinterpret_cast<const double*>(smem0 + ww * C::LDS_BYTES + C::OFF_PART);
+#pragma unroll
+      for (int I = 0; I < NB; ++I) bsum[I] += pw[16 * I + r16];
+      quad += pw[C::DP];
+      lsum += pw[C::DP + 1];
+      bad_noise = min(bad_noise, reinterpret_cast<const int*>(pw + C::DP + 2)[0]);
+    }
+  }
+  const double logdet_Sy = DIAG ? lsum : (double)N * log((double)s_iso);
+  if (!DIAG) quad *= (double)w_iso;
+#pragma unroll
+  for (int I = 0; I < NB; ++I) {
+    double v = bsum[I];
     if (!DIAG) v *= (double)w_iso;
     if (q4 == 0) bvec[16 * I + r16] = (T)v;  // b = X S^-1 (y - X'mw)
   }
@@ -293,9 +352,16 @@ BLR_PHASE void wave_gram(char* smem, const BLR_GLOBAL T* X, int64_t ldx, const B
       const int col = 16 * K + r16;
 #pragma unroll
       for (int v = 0; v < 4; ++v) {
-        T val = DIAG ? acc[t][v] : acc[t][v] * w_iso;
         const int rl = Mfma<T>::crow(lane, v);
         const int row = 16 * I + rl;
+        T g = acc[t][v];
+        if constexpr (NW > 1) {
+          if (col <= row) {
+#pragma unroll
+            for (int ww = 1; ww < NW; ++ww) g += reinterpret_cast<const T*>(smem0 + ww * C::LDS_BYTES)[pidx(row, col)];
+          }
+        }
+        T val = DIAG ? g : g * w_iso;
         if (prior_kind == PRIOR_DIAGONAL) {
           if (I == K && rl == r16) val += dvI;
         } else if (prior_kind == PRIOR_DENSE) {
@@ -307,6 +373,7 @@ BLR_PHASE void wave_gram(char* smem, const BLR_GLOBAL T* X, int64_t ldx, const B
   }
   __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
   __builtin_amdgcn_wave_barrier();
+  if constexpr (NW > 1) __syncthreads();  // B
 }
 
 // ---- phase 2: blocked Cholesky of P, one row per lane, trailing matrix in the accumulators (see phase_chol), with the
@@ -317,7 +384,7 @@ BLR_PHASE int wave_chol(char* smem) {
   using acc4 = typename Mfma<T>::acc4;
   T* const P = reinterpret_cast<T*>(smem);
   T* const bvec = reinterpret_cast<T*>(smem + C::OFF_B);
-  int lane = threadIdx.x;
+  int lane = threadIdx.x & 63;  // also called by waves 1 .. NW-1 of a split workgroup (dense prior), each in its own slice
   asm volatile("" : "+v"(lane));
   const int r16 = lane & 15, q4 = lane >> 4;
   constexpr int D = C::DP;
@@ -408,15 +475,19 @@ BLR_PHASE int wave_chol(char* smem) {
   return info;
 }
 
-template <typename T, int NB>
-__global__ __launch_bounds__(64, 2) void fused_wave_kernel(PosteriorArgs<T> a) {
+template <typename T, int NB, int NW = 1>
+__global__ __launch_bounds__(64 * NW, 2) void fused_wave_kernel(PosteriorArgs<T> a) {
   using C = WaveCfg<T, NB>;
-  extern __shared__ __attribute__((aligned(16))) char smem[];
+  extern __shared__ __attribute__((aligned(16))) char smem_all[];
+  // NW > 1: every wave works in its own slice; waves 1 .. NW-1 only take part in the prior check (redundantly: every early
+  // exit below must be taken by ALL waves, the Gram phase contains workgroup barriers) and in the Gram phase
+  const int wv = (NW == 1) ? 0 : uni((int)(threadIdx.x >> 6));
+  char* const smem = smem_all + wv * C::LDS_BYTES;
   T* const P = reinterpret_cast<T*>(smem);
   T* const bvec = reinterpret_cast<T*>(smem + C::OFF_B);
   double* const scr = reinterpret_cast<double*>(smem + C::OFF_SCR);
   int* const iscr = reinterpret_cast<int*>(smem + C::OFF_SCR + 32);
-  const int lane = threadIdx.x;
+  const int lane = threadIdx.x & 63;
   constexpr int D = C::DP;
   const int N = a.N;
   const double kNaN = __longlong_as_double(0x7ff8000000000000LL);
@@ -448,16 +519,17 @@ __global__ __launch_bounds__(64, 2) void fused_wave_kernel(PosteriorArgs<T> a) {
       logdet_Lw = wave_allreduce((in && ok) ? log((double)dpr) : 0.0);
       if (a.prior_kind != PRIOR_DIAGONAL) logdet_Lw *= 2.0;
     }
-    if (info != 0) {  // wave-uniform
-      if (lane == 0) { a.info[reg] = info; if (a.logpdf) a.logpdf[reg] = kNaN; }
+    if (info != 0) {  // uniform over the workgroup: every wave ran the same check on the same prior
+      if (wv == 0 && lane == 0) { a.info[reg] = info; if (a.logpdf) a.logpdf[reg] = kNaN; }
       continue;
     }
     if (a.noise_kind == NOISE_DIAGONAL)
-      wave_gram<T, NB, true>(smem, as_global(a.X + reg * a.strideX), a.ldx, as_global(a.y + reg * a.stridey),
-                             as_global(a.s + reg * a.strides), mw, dpr, N, a.prior_kind, Lw, a.ldl);
+      wave_gram<T, NB, true, NW>(smem_all, as_global(a.X + reg * a.strideX), a.ldx, as_global(a.y + reg * a.stridey),
+                                 as_global(a.s + reg * a.strides), mw, dpr, N, a.prior_kind, Lw, a.ldl);
     else
-      wave_gram<T, NB, false>(smem, as_global(a.X + reg * a.strideX), a.ldx, as_global(a.y + reg * a.stridey),
-                              as_global(a.s + reg * a.strides), mw, dpr, N, a.prior_kind, Lw, a.ldl);
+      wave_gram<T, NB, false, NW>(smem_all, as_global(a.X + reg * a.strideX), a.ldx, as_global(a.y + reg * a.stridey),
+                                  as_global(a.s + reg * a.strides), mw, dpr, N, a.prior_kind, Lw, a.ldl);
+    if (wv != 0) continue;  // the factorisation is wave 0's
     const double quad = scr[0], logdet_Sy = scr[1];
     if (iscr[0] != 0x7fffffff) {  // Sigma_y is not positive definite: PosDefException(index), as :79 would throw
       if (lane == 0) { a.info[reg] = iscr[0]; if (a.logpdf) a.logpdf[reg] = kNaN; }

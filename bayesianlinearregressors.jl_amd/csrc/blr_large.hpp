@@ -24,9 +24,16 @@ namespace blr {
 
 constexpr int kPB = 128;  // panel / macro-tile edge
 
+// Gram launch geometry (f32): k-steps per stage and workgroups per CU the kernel is compiled for
+#ifndef BLR_GRAM_KS_F32
+#define BLR_GRAM_KS_F32 8
+#endif
+#ifndef BLR_GRAM_WGS
+#define BLR_GRAM_WGS 2
+#endif
 template <typename T>
 struct LargeCfg {
-  static constexpr int KS = (sizeof(T) == 4) ? 8 : 4;   // k-steps per stage (32 / 16 columns)
+  static constexpr int KS = (sizeof(T) == 4) ? BLR_GRAM_KS_F32 : 4;   // k-steps per stage (32 / 16 columns)
   static constexpr int NSC = 4 * KS;
   static constexpr int SIDE = KS * 8 * 64;              // elements of one operand side per slot
   static constexpr int SLOT = 2 * SIDE;                 // A side + B side
@@ -151,32 +158,6 @@ __global__ __launch_bounds__(kThreads) void colstats_kernel(ColstatsArgs<T> a) {
 // ---- 128 x 128 macro tile of a (weighted) Gram matrix ---------------------------------------------------------
 // mode_out 0: write the tile (and, for diagonal tiles with r != NULL, b_I) to the split-partial workspace
 // mode_out 1: subtract the tile in place from C (trailing update of the blocked Cholesky; single split)
-// ---- agent-coherent 8-byte accesses (pipelined schedule) ----------------------------------------------------------------
-// On this multi-XCD part an agent-scope FENCE writes back and invalidates the issuing XCD's whole L2: one per workgroup of a
-// Gram launch turned the launch memory-bound (765 -> 1380 us at config 3).  The split-K hand-off therefore uses relaxed
-// agent-scope 8-byte stores / loads (sc1: through the L2 to the coherent level, no fence) for exactly the data that crosses
-// workgroups, with s_waitcnt vmcnt(0) between the data and the counter that publishes it -- the mechanism the wavefront
-// back substitution already uses for its hops.
-__device__ __forceinline__ void st_agent(void* p, unsigned long long v) {
-  __hip_atomic_store(reinterpret_cast<unsigned long long*>(p), v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-}
-__device__ __forceinline__ unsigned long long ld_agent(const void* p) {
-  return __hip_atomic_load(reinterpret_cast<const unsigned long long*>(p), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-}
-template <typename T> struct Word8;  // 8 bytes = 2 floats / 1 double
-template <> struct Word8<float> {
-  static constexpr int N = 2;
-  static __device__ __forceinline__ unsigned long long pack(float a, float b) {
-    return (unsigned long long)__float_as_uint(a) | ((unsigned long long)__float_as_uint(b) << 32);
-  }
-  static __device__ __forceinline__ float get(unsigned long long w, int i) { return __uint_as_float((unsigned)(w >> (32 * i))); }
-};
-template <> struct Word8<double> {
-  static constexpr int N = 1;
-  static __device__ __forceinline__ unsigned long long pack(double a, double) { return (unsigned long long)__double_as_longlong(a); }
-  static __device__ __forceinline__ double get(unsigned long long w, int) { return __longlong_as_double((long long)w); }
-};
-
 template <typename T>
 struct GramTileArgs {
   const T* X; int64_t ldx;   // operand matrix; element (d, n) at X[d + n*ldx] (ColVecs) or X[n + d*ldx] (RowVecs)
@@ -201,18 +182,10 @@ struct GramTileArgs {
   int xcd_swizzle;           // remap blockIdx so that one XCD owns whole N-slices (split-K launches)
   const T* XB; int64_t ldxb; int DB;  // optional SECOND operand for the B side (rows rowB.. of XB, DB rows; same layout);
                                       // NULL: B side = X (Gram / trailing updates)
-  // Pipelined schedule (tri 5, mode 0): tiles are enumerated COLUMN by column (all splits of a tile adjacent, so block column
-  // J of the Gram matrix completes while later columns are still being computed); the workgroup that delivers the LAST
-  // partial of a tile reduces it in fixed split order into Abar (as gram_reduce_kernel) and bumps col_done[J].
-  unsigned* tile_count;      // [ntiles] arrival counters, zeroed by the host (NULL: off)
-  unsigned* col_done;        // [nblocks] finished tiles per block column
-  const T* Lw; int64_t ldl; int prior_kind;  // prior precision added by the reducing workgroup
-  T* Abar; int64_t lda; int DP;
-  T* Lw_post; int64_t ldlp;
 };
 
 template <typename T>
-__global__ __launch_bounds__(kThreads, 2) void gram_tile_kernel(GramTileArgs<T> a) {
+__global__ __launch_bounds__(kThreads, (sizeof(T) == 4 ? BLR_GRAM_WGS : 2)) void gram_tile_kernel(GramTileArgs<T> a) {
   using L = LargeCfg<T>;
   using acc4 = typename Mfma<T>::acc4;
   extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -235,17 +208,7 @@ __global__ __launch_bounds__(kThreads, 2) void gram_tile_kernel(GramTileArgs<T> 
   }
   int t = w % a.ntiles, sidx = w / a.ntiles;
   int I, J;
-  if (a.tri == 5) {
-    // block column by block column; inside a column the tiles run fastest and the N-slices slowest, so that workgroups
-    // dispatched together stream the SAME columns of X (one L2 fill serves the whole block column, as in the tri 1 order)
-    int jj = 0, off = 0;  // off = tiles in the columns before jj
-    while ((off + (a.nblocks - jj)) * a.nsplit <= w) { off += a.nblocks - jj; ++jj; }
-    const int rem = w - off * a.nsplit, nt_col = a.nblocks - jj;
-    sidx = rem / nt_col;
-    J = jj;
-    I = jj + rem % nt_col;
-    t = off + (I - J);
-  } else if (a.tri == 1) {
+  if (a.tri == 1) {
     int ii = 0;
     while ((ii + 1) * (ii + 2) / 2 <= t) ++ii;
     I = a.tile_i0 + ii;
@@ -404,28 +367,15 @@ __global__ __launch_bounds__(kThreads, 2) void gram_tile_kernel(GramTileArgs<T> 
   // ---- epilogue ------------------------------------------------------------------------------------------
   if (a.mode_out == 0) {
     T* out = a.Gpart + ((int64_t)sidx * a.ntiles + t) * (kPB * kPB);
-    const bool coherent = a.tile_count != nullptr;
 #pragma unroll
     for (int i = 0; i < 4; ++i)
 #pragma unroll
       for (int k = 0; k < 4; ++k) {
         const int col = 16 * (4 * wc + k) + (lane & 15);
-        if (coherent) {
-          if constexpr (sizeof(T) == 4) {  // f32 C layout: 4 consecutive rows per lane = two 8-byte words
-            const int row0 = 16 * (4 * wr + i) + 4 * (lane >> 4);
-            st_agent(out + col * kPB + row0, Word8<T>::pack(acc[i][k][0], acc[i][k][1]));
-            st_agent(out + col * kPB + row0 + 2, Word8<T>::pack(acc[i][k][2], acc[i][k][3]));
-          } else {
 #pragma unroll
-            for (int v = 0; v < 4; ++v)
-              st_agent(out + col * kPB + 16 * (4 * wr + i) + Mfma<T>::crow(lane, v), Word8<T>::pack(acc[i][k][v], T(0)));
-          }
-        } else {
-#pragma unroll
-          for (int v = 0; v < 4; ++v) {
-            const int row = 16 * (4 * wr + i) + Mfma<T>::crow(lane, v);
-            out[col * kPB + row] = acc[i][k][v];  // column-major tile: the reduce pass is coalesced both ways
-          }
+        for (int v = 0; v < 4; ++v) {
+          const int row = 16 * (4 * wr + i) + Mfma<T>::crow(lane, v);
+          out[col * kPB + row] = acc[i][k][v];  // column-major tile: the reduce pass is coalesced both ways
         }
       }
     if (want_b) {
@@ -438,85 +388,7 @@ __global__ __launch_bounds__(kThreads, 2) void gram_tile_kernel(GramTileArgs<T> 
         double sum = 0.0;
 #pragma unroll
         for (int p = 0; p < 16; ++p) sum += red[p * kPB + tid];
-        if (coherent) st_agent(a.bpart + ((int64_t)sidx * a.nblocks + I) * kPB + tid, (unsigned long long)__double_as_longlong(sum));
-        else a.bpart[((int64_t)sidx * a.nblocks + I) * kPB + tid] = sum;
-      }
-    }
-    if (a.tile_count != nullptr) {
-      // last arriver reduces the tile (fixed split order: the result does not depend on who arrives last).  No fences: the
-      // partials went out as agent-coherent stores, vmcnt(0) orders them before the counter, the reducer reads them back
-      // with agent-coherent loads and publishes Abar the same way.
-      __shared__ int s_last;
-      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-      __syncthreads();
-      if (tid == 0)
-        s_last = (__hip_atomic_fetch_add(&a.tile_count[t], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == (unsigned)(a.nsplit - 1)) ? 1 : 0;
-      __syncthreads();
-      if (s_last) {
-        constexpr int VW = Word8<T>::N;
-        const int64_t sstride = (int64_t)a.ntiles * (kPB * kPB);
-        const T* src0 = a.Gpart + (int64_t)t * (kPB * kPB);
-        for (int e = tid * VW; e < kPB * kPB; e += kThreads * VW) {
-          const int rl = e % kPB, cl = e / kPB;
-          const int row0 = I * kPB + rl, col = J * kPB + cl;
-          if (col > row0 + VW - 1) continue;
-          const T* src = src0 + e;
-          T sum[VW];
-#pragma unroll
-          for (int q = 0; q < VW; ++q) sum[q] = T(0);
-          int sp = 0;
-          for (; sp + 8 <= a.nsplit; sp += 8) {
-            unsigned long long v[8];
-#pragma unroll
-            for (int u = 0; u < 8; ++u) v[u] = ld_agent(src + (sp + u) * sstride);
-#pragma unroll
-            for (int u = 0; u < 8; ++u)
-#pragma unroll
-              for (int q = 0; q < VW; ++q) sum[q] += Word8<T>::get(v[u], q);
-          }
-          for (; sp < a.nsplit; ++sp) {
-            const unsigned long long v = ld_agent(src + sp * sstride);
-#pragma unroll
-            for (int q = 0; q < VW; ++q) sum[q] += Word8<T>::get(v, q);
-          }
-          T val[2] = {T(0), T(0)};
-#pragma unroll
-          for (int q = 0; q < VW; ++q) {
-            const int row = row0 + q;
-            T x = sum[q];
-            if (row < a.D) {
-              if (col <= row) {
-                if (a.prior_kind == PRIOR_DENSE) x += a.Lw[(int64_t)row * a.ldl + col];
-                else if (a.prior_kind == PRIOR_DIAGONAL && row == col) x += a.Lw[row];
-              }
-            } else {
-              x = (row == col) ? T(1) : T(0);
-            }
-            val[q] = x;
-            if (a.Lw_post && row < a.D && col <= row) {
-              a.Lw_post[(int64_t)col * a.ldlp + row] = x;
-              a.Lw_post[(int64_t)row * a.ldlp + col] = x;
-            }
-          }
-          st_agent(a.Abar + (int64_t)col * a.lda + row0, Word8<T>::pack(val[0], val[1]));  // entries above the diagonal: never read
-        }
-        if (I == J) {  // rhs row block of block column J: row 0 = b', the rest zero
-          for (int e = tid * VW; e < kPB * kPB; e += kThreads * VW) {
-            const int rl = e % kPB, cl = e / kPB;
-            const int col = J * kPB + cl;
-            T v0 = T(0);
-            if (rl == 0 && col < a.D) {
-              double sum = 0.0;
-              for (int sp = 0; sp < a.nsplit; ++sp)
-                sum += __longlong_as_double((long long)ld_agent(a.bpart + ((int64_t)sp * a.nblocks + J) * kPB + cl));
-              v0 = (T)sum;
-            }
-            st_agent(a.Abar + (int64_t)col * a.lda + a.DP + rl, Word8<T>::pack(v0, T(0)));
-          }
-        }
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // Abar before the column counter
-        __syncthreads();
-        if (tid == 0) __hip_atomic_fetch_add(&a.col_done[J], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        a.bpart[((int64_t)sidx * a.nblocks + I) * kPB + tid] = sum;
       }
     }
   } else {
@@ -557,8 +429,6 @@ struct ReduceArgs {
   int D, DP;
   T* Abar; int64_t lda;      // (DP + 128) x DP
   T* Lw_post; int64_t ldlp;  // optional full symmetric copy of A (D x D)
-  int col_mode, tile_i0, tile_j0;  // col_mode 1 (pipelined path): tiles (tile_i0 + t, tile_j0), t < ntiles, Gpart local to the column;
-                                   // blockIdx.x == ntiles: the rhs row of block tile_j0
 };
 
 template <typename T>
@@ -568,14 +438,9 @@ __global__ __launch_bounds__(kThreads) void gram_reduce_kernel(ReduceArgs<T> a) 
   constexpr int kChunk = kPB * kPB / 16;  // gridDim.y = 16 chunks per tile
   const int e_begin = blockIdx.y * kChunk, e_end = e_begin + kChunk;
   if (t < a.ntiles) {
-    int I, J;
-    if (a.col_mode) {
-      I = a.tile_i0 + t; J = a.tile_j0;
-    } else {
-      int ii = 0;
-      while ((ii + 1) * (ii + 2) / 2 <= t) ++ii;
-      I = ii; J = t - ii * (ii + 1) / 2;
-    }
+    int ii = 0;
+    while ((ii + 1) * (ii + 2) / 2 <= t) ++ii;
+    const int I = ii, J = t - ii * (ii + 1) / 2;
     // one 16-byte vector of 4 (f32) / 2 (f64) consecutive rows per thread and pass; the partials of 8 splits are requested
     // before the first is used (one load per split and a dependent add behind it made this kernel a ~50 us latency chain)
     constexpr int VEC = Mfma<T>::VEC;
@@ -615,7 +480,7 @@ __global__ __launch_bounds__(kThreads) void gram_reduce_kernel(ReduceArgs<T> a) 
       }
     }
   } else {
-    const int I = a.col_mode ? a.tile_j0 : t - a.ntiles;
+    const int I = t - a.ntiles;
     for (int e = e_begin + tid; e < e_end; e += kThreads) {  // rhs row block: row 0 = b', the rest zero
       const int rl = e % kPB, cl = e / kPB;
       const int col = I * kPB + cl;
@@ -849,147 +714,6 @@ __global__ __launch_bounds__(kThreads) void trail_update_kernel(T* M, int64_t ld
         for (int v = 0; v < 4; ++v) {
           const int row = rowA + 16 * (2 * wr + i) + Mfma<T>::crow(lane, v);
           if (!diag || col <= row) M[(int64_t)col * ld + row] = acc[i][k][v];
-        }
-      }
-    }
-}
-
-// the chain stream's gate: returns when `*cnt >= target` (block column complete).  One lane spins with s_sleep; bounded, so a
-// logic error upstream becomes info = -999 instead of a hung GPU.
-__global__ void wait_count_kernel(const unsigned* cnt, unsigned target, int32_t* info) {
-  if (threadIdx.x != 0) return;
-  long long spins = 0;
-  while (__hip_atomic_load(cnt, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < target) {  // relaxed: no cache invalidation per poll
-    __builtin_amdgcn_s_sleep(64);
-    if (++spins > 4000000LL) {  // ~ seconds
-      if (*info == 0) *info = -999;
-      break;
-    }
-  }
-}
-
-// ---- left-looking update of ONE block column (pipelined large-D path) ---------------------------------------------------
-// The right-looking sweep above cannot start before the WHOLE Gram matrix exists.  The pipelined path (blr_abi.hip,
-// posterior_large_one) builds the Gram matrix block column by block column on its own streams and lets the factorisation
-// follow it: block column p needs only ITS Gram tiles plus the finished panels k < p,
-//     A[rows >= 128p, cols of block p]  -=  sum_{k<p}  L[rows, panel k] L[block p, panel k]'.
-// One workgroup = one 64 x 64 sub-tile x ONE panel k (every load in flight at once, as trail_update_kernel); the p partial
-// products of a sub-tile are summed in FIXED order by left_reduce_kernel (bitwise run-to-run reproducible).
-// Sub-tiles of the column: idx 0 -> (r, c) = (0, 0); idx >= 1 -> r = (idx + 1) / 2, c = (idx + 1) % 2  (the block (0, 1) lies
-// above the diagonal); rows 128p + 64r (the rhs rows follow the square part contiguously), columns 128p + 64c.
-// Partials are stored in accumulator order: Upart[((k * nsub + idx) * 16 + wave * 4 + 2i + kk) * 64 + lane] (one acc4 each).
-template <typename T>
-__global__ __launch_bounds__(kThreads) void left_update_kernel(const T* __restrict__ M, int64_t ld, int p,
-                                                               typename Mfma<T>::acc4* __restrict__ Upart, const int32_t* info) {
-  __builtin_amdgcn_s_setprio(3);  // latency-critical chain kernel: issue ahead of co-resident Gram waves
-  using Cfg = TrailCfg<T>;
-  using acc4 = typename Mfma<T>::acc4;
-  constexpr int VEC = Mfma<T>::VEC;
-  constexpr int SB = Cfg::SB;
-  typedef T vecT __attribute__((ext_vector_type(Mfma<T>::VEC)));
-  extern __shared__ __attribute__((aligned(16))) char smem[];
-  T* const As = reinterpret_cast<T*>(smem);
-  T* const Bs = As + Cfg::SIDE;
-  const int tid = threadIdx.x, lane = tid & 63;
-  const int wave = uni(tid >> 6);
-  const int wr = wave >> 1, wc = wave & 1;
-  const int idx = blockIdx.x, k = blockIdx.y, nsub = gridDim.x;
-  const int r = idx == 0 ? 0 : (idx + 1) >> 1, c = idx == 0 ? 0 : (idx + 1) & 1;
-  const int rowA = p * kPB + r * SB, rowB = p * kPB + c * SB;
-  const T* panel = M + (int64_t)k * kPB * ld;
-  constexpr int VPC = SB / VEC;
-  constexpr int NV = kPB * SB / (VEC * kThreads);
-  vecT va[NV], vb[NV];
-#pragma unroll
-  for (int u = 0; u < NV; ++u) {
-    const int vi = u * kThreads + tid;
-    const int64_t off = (int64_t)(vi / VPC) * ld + (vi % VPC) * VEC;
-    va[u] = *reinterpret_cast<const vecT*>(panel + rowA + off);
-    vb[u] = *reinterpret_cast<const vecT*>(panel + rowB + off);
-  }
-  if (*info != 0) return;
-#pragma unroll
-  for (int u = 0; u < NV; ++u) {
-    const int vi = u * kThreads + tid;
-    const int kc = vi / VPC, r0 = (vi % VPC) * VEC;
-    const int di = (((kc >> 2) * (SB / 16) + (r0 >> 4)) << 6) + ((kc & 3) << 4) + (r0 & 15);
-    *reinterpret_cast<vecT*>(As + di) = va[u];
-    *reinterpret_cast<vecT*>(Bs + di) = vb[u];
-  }
-  acc4 acc[2][2];
-#pragma unroll
-  for (int i = 0; i < 2; ++i)
-#pragma unroll
-    for (int kk = 0; kk < 2; ++kk) acc[i][kk] = acc4{T(0), T(0), T(0), T(0)};
-  __syncthreads();
-#pragma unroll 8
-  for (int ks = 0; ks < kPB / 4; ++ks) {
-    T fa[2], fb[2];
-#pragma unroll
-    for (int i = 0; i < 2; ++i) {
-      fa[i] = As[((ks * (SB / 16) + 2 * wr + i) << 6) + lane];
-      fb[i] = Bs[((ks * (SB / 16) + 2 * wc + i) << 6) + lane];
-    }
-#pragma unroll
-    for (int i = 0; i < 2; ++i)
-#pragma unroll
-      for (int kk = 0; kk < 2; ++kk) acc[i][kk] = Mfma<T>::mma(fa[i], fb[kk], acc[i][kk]);
-  }
-  acc4* out = Upart + (((int64_t)k * nsub + idx) * 16 + wave * 4) * 64 + lane;
-#pragma unroll
-  for (int i = 0; i < 2; ++i)
-#pragma unroll
-    for (int kk = 0; kk < 2; ++kk) out[(2 * i + kk) * 64] = acc[i][kk];
-}
-
-// M[sub-tile] -= sum_{k < nsplit} Upart[k][sub-tile]   (k ascending; same thread <-> element map as left_update_kernel)
-template <typename T>
-__global__ __launch_bounds__(kThreads) void left_reduce_kernel(T* __restrict__ M, int64_t ld, int p, int nsplit,
-                                                               const typename Mfma<T>::acc4* __restrict__ Upart, const int32_t* info) {
-  __builtin_amdgcn_s_setprio(3);  // latency-critical chain kernel: issue ahead of co-resident Gram waves
-  using acc4 = typename Mfma<T>::acc4;
-  constexpr int SB = TrailCfg<T>::SB;
-  const int tid = threadIdx.x, lane = tid & 63;
-  const int wave = uni(tid >> 6);
-  const int wr = wave >> 1, wc = wave & 1;
-  const int idx = blockIdx.x, nsub = gridDim.x;
-  const int r = idx == 0 ? 0 : (idx + 1) >> 1, c = idx == 0 ? 0 : (idx + 1) & 1;
-  const int rowA = p * kPB + r * SB, rowB = p * kPB + c * SB;
-  const bool diag = rowA == rowB;
-  if (*info != 0) return;
-  acc4 sum[4];
-#pragma unroll
-  for (int q = 0; q < 4; ++q) sum[q] = acc4{T(0), T(0), T(0), T(0)};
-  const acc4* in = Upart + ((int64_t)idx * 16 + wave * 4) * 64 + lane;
-  const int64_t kstride = (int64_t)nsub * 16 * 64;
-#pragma unroll 4
-  for (int k = 0; k < nsplit; ++k) {
-#pragma unroll
-    for (int q = 0; q < 4; ++q) {
-      const acc4 v = in[k * kstride + q * 64];
-#pragma unroll
-      for (int e = 0; e < 4; ++e) sum[q][e] += v[e];
-    }
-  }
-#pragma unroll
-  for (int i = 0; i < 2; ++i)
-#pragma unroll
-    for (int kk = 0; kk < 2; ++kk) {
-      const int col = rowB + 16 * (2 * wc + kk) + (lane & 15);
-      if constexpr (sizeof(T) == 4) {
-        const int row0 = rowA + 16 * (2 * wr + i) + 4 * (lane >> 4);
-        if (!diag || col <= row0 + 3) {
-          acc4* pc = reinterpret_cast<acc4*>(M + (int64_t)col * ld + row0);
-          acc4 cv = *pc;
-#pragma unroll
-          for (int e = 0; e < 4; ++e) cv[e] -= sum[2 * i + kk][e];
-          *pc = cv;
-        }
-      } else {
-#pragma unroll
-        for (int v = 0; v < 4; ++v) {
-          const int row = rowA + 16 * (2 * wr + i) + Mfma<T>::crow(lane, v);
-          if (!diag || col <= row) M[(int64_t)col * ld + row] -= sum[2 * i + kk][v];
         }
       }
     }

@@ -514,68 +514,147 @@ def posterior(fx, y):
     return post
 
 
+class _DeviceBuffer:
+    """device memory owned through the C ABI (blr_device_alloc): no GPU array library involved"""
+
+    def __init__(self, handle, nbytes):
+        self.handle, self.nbytes = handle, int(nbytes)
+        self.ptr = handle.device_alloc(self.nbytes)
+
+    @classmethod
+    def of(cls, handle, host_array):
+        buf = cls(handle, host_array.nbytes)
+        handle.memcpy_h2d(buf.ptr, host_array)
+        return buf
+
+    def free(self):
+        if self.ptr:
+            try:
+                self.handle.device_free(self.ptr)
+            finally:
+                self.ptr = 0
+
+    def __del__(self):
+        try:
+            self.free()
+        except Exception:
+            pass
+
+
 class ResidentPosterior:
-    """A posterior kept as its state (mw, T) -- T the upper factor of the precision -- and conditioned IN PLACE on further
-    batches: the "repeated conditioning" pattern of reference test/bayesian_linear_regression.jl:49-70
+    """A posterior kept ON THE DEVICE as its state (mw, T) -- T the upper factor of the precision -- and conditioned IN PLACE
+    on further batches: the "repeated conditioning" pattern of reference test/bayesian_linear_regression.jl:49-70
     (``posterior(f'1(X2, S2), y2)``) without re-deriving reference :72-89 from a D x D precision every time
-    (blr_update_factor_*: O(k D^2) Givens sweeps for small batches, in-place re-factorisation otherwise).
+    (blr_update_factor_*: O(k D^2) Givens sweeps for single observations, in-place re-factorisation otherwise).
 
         st = ResidentPosterior(posterior(f(X1, S1), y1))      # or a prior: ResidentPosterior(f)
         lp2 = st.condition(X2, S2, y2)                         # log p(y2 | y1); state now = posterior given y1 and y2
         f12 = st.regressor()                                   # BayesianLinearRegressor(mw, PDMat(T))
 
-    The arrays live on the host here (the library stages them); a device-resident state uses Handle.update_factor with
-    MEM_DEVICE pointers directly (tests/test_gpu_parity.py, julia/BLRMI355X.jl update_factor!)."""
+    The state is created by the library (a Diagonal or dense prior precision is factorised on the device -- reference :78, the
+    failing leading minor comes back as PosDefException(info) exactly as from `posterior`), lives in device buffers owned
+    through blr_device_alloc and is only copied back by `regressor()`.  A BasisFunctionRegressor keeps its basis: `condition`
+    maps the inputs through phi (RandomFourierFeatures: on the device, the features never visit the host) and `regressor()`
+    returns BasisFunctionRegressor(posterior, phi) like reference basis_function_regression.jl:62-65."""
 
     def __init__(self, f):
+        self.phi = f.phi if isinstance(f, BasisFunctionRegressor) else None
         base = f.blr if isinstance(f, BasisFunctionRegressor) else f
         if not isinstance(base, BayesianLinearRegressor):
-            raise TypeError("ResidentPosterior wraps a BayesianLinearRegressor")
+            raise TypeError("ResidentPosterior wraps a BayesianLinearRegressor or a BasisFunctionRegressor")
         dtype = _dtype_of(base.mw)
         D = base.mw.shape[0]
-        self.dtype = dtype
-        self.mw = np.array(_mean_vector(base.mw, D, dtype))
+        self.dtype, self.D = dtype, D
+        h = self._h = _handle()
+        item = np.dtype(dtype).itemsize
+        mw = np.array(_mean_vector(base.mw, D, dtype))
+        self._mw = _DeviceBuffer.of(h, mw)
+        self._T = _DeviceBuffer(h, D * D * item)
         Lw = base.Lw
         if isinstance(Lw, PDMat):
-            T = np.triu(np.asarray(Lw.U, dtype=dtype))
-        elif isinstance(Lw, Diagonal):
-            k = _first_nonpositive(Lw.diag)
+            U = np.asfortranarray(np.triu(np.asarray(Lw.U, dtype=dtype)))
+            if U.shape != (D, D):
+                raise ValueError("size of the prior precision != length(mw)")
+            k = _first_nonpositive(np.diag(U))  # a factor with a non-positive diagonal is not a Cholesky factor
             if k:
                 raise _abi.PosDefException(k)
-            T = np.diag(np.sqrt(np.asarray(Lw.diag, dtype=dtype)))
-        else:  # dense precision: one D x D factorisation when the state is created (reference :78)
-            A = Lw.toarray() if isinstance(Lw, Symmetric) else np.asarray(Lw)
-            try:
-                T = np.linalg.cholesky(np.asarray(A, dtype=np.float64)).T.astype(dtype)
-            except np.linalg.LinAlgError:
-                raise _abi.PosDefException(-1) from None
-        if T.shape != (D, D):
-            raise ValueError("size of the prior precision != length(mw)")
-        self.T = np.asfortranarray(T)
+            h.memcpy_h2d(self._T.ptr, U)
+            return
+        # Diagonal / dense precision: T = chol(Lw).U by the library's own factorisation -- the posterior update on ZERO
+        # observations (A = Lw), written straight into the resident buffers
+        Lw_h, prior_kind, ldl = _prior(Lw, D, dtype)
+        d_Lw = _DeviceBuffer.of(h, Lw_h)
+        d_one = _DeviceBuffer.of(h, np.ones(1, dtype=dtype))
+        d_info = _DeviceBuffer.of(h, np.zeros(1, dtype=np.int32))
+        try:
+            h.posterior_batched(dtype, _abi.MEM_DEVICE, _abi.LAYOUT_COLVECS, 1, D, 0, None, max(D, 1), 0, None, 0,
+                                _abi.NOISE_ISOTROPIC, d_one.ptr, 0, prior_kind, self._mw.ptr, 0, d_Lw.ptr, ldl, 0,
+                                None, D, self._T.ptr, max(D, 1), D * D, None, max(D, 1), D * D, None, d_info.ptr)
+            info = np.zeros(1, dtype=np.int32)
+            h.memcpy_d2h(info, d_info.ptr)
+        finally:
+            for b in (d_Lw, d_one, d_info):
+                b.free()
+        if info[0] != 0:
+            raise _abi.PosDefException(int(info[0]))
 
     def condition(self, x, Sy, y):
         """In-place update with the observations (x, Sy, y); returns log p(y | everything conditioned on so far)."""
-        dtype = self.dtype
-        X, layout, ldx, D, k = _x_layout(x, dtype)
-        if D != self.mw.shape[0]:
-            raise ValueError(f"dimension of the inputs ({D}) != length(mw) = {self.mw.shape[0]}")
-        y = np.ascontiguousarray(y, dtype=dtype)
-        if y.shape != (k,):
-            raise ValueError("length(y) != number of inputs")  # reference :74
-        s, noise_kind = _noise(Sy, k, dtype)
-        if noise_kind == _abi.NOISE_DENSE:
-            raise NotImplementedError("ResidentPosterior.condition takes scalar or diagonal noise (whiten a dense block first)")
-        lp = np.zeros(1, dtype=np.float64)
-        info = np.zeros(1, dtype=np.int32)
-        _handle().update_factor(dtype, _abi.MEM_HOST, layout, 1, D, k, X, ldx, 0, y, 0, noise_kind, s, 0, self.mw, 0, self.T,
-                                max(D, 1), 0, lp, info)
+        dtype, h, D = self.dtype, self._h, self.D
+        temps = []
+
+        def dev(a):
+            temps.append(_DeviceBuffer.of(h, a))
+            return temps[-1].ptr
+
+        try:
+            if isinstance(self.phi, RandomFourierFeatures):
+                Xin, ldxin, Din, k, Om, ph = self.phi._operands(x, dtype)
+                if Om.shape[1] != D:
+                    raise ValueError(f"number of features ({Om.shape[1]}) != length(mw) = {D}")
+                temps.append(_DeviceBuffer(h, D * max(k, 1) * np.dtype(dtype).itemsize))
+                dX, layout, ldx = temps[-1].ptr, _abi.LAYOUT_COLVECS, max(D, 1)
+                h.rff_features(dtype, _abi.MEM_DEVICE, Din, D, k, dev(Xin), ldxin, dev(Om), max(Din, 1), dev(ph), self.phi.scale,
+                               dX, ldx)
+            else:
+                X, layout, ldx, Dx, k = _x_layout(self.phi(x) if self.phi is not None else x, dtype)
+                if Dx != D:
+                    raise ValueError(f"dimension of the inputs ({Dx}) != length(mw) = {D}")
+                dX = dev(X)
+            y = np.ascontiguousarray(y, dtype=dtype)
+            if y.shape != (k,):
+                raise ValueError("length(y) != number of inputs")  # reference :74
+            s, noise_kind = _noise(Sy, k, dtype)
+            if noise_kind == _abi.NOISE_DENSE:
+                raise NotImplementedError("ResidentPosterior.condition takes scalar or diagonal noise (whiten a dense block first)")
+            d_lp = dev(np.zeros(1, dtype=np.float64))
+            d_info = dev(np.zeros(1, dtype=np.int32))
+            h.update_factor(dtype, _abi.MEM_DEVICE, layout, 1, D, k, dX, ldx, 0, dev(y), 0, noise_kind, dev(s), 0, self._mw.ptr, 0,
+                            self._T.ptr, max(D, 1), 0, d_lp, d_info)
+            lp = np.zeros(1, dtype=np.float64)
+            info = np.zeros(1, dtype=np.int32)
+            h.memcpy_d2h(lp, d_lp)
+            h.memcpy_d2h(info, d_info)
+        finally:
+            for b in temps:
+                b.free()
         if info[0] != 0:
             raise _abi.PosDefException(int(info[0]))
         return float(lp[0])
 
+    def state(self):
+        """host copies (mw, T) of the resident state; T column-major upper"""
+        mw = np.empty(self.D, dtype=self.dtype)
+        T = np.empty((self.D, self.D), dtype=self.dtype, order="F")
+        self._h.memcpy_d2h(mw, self._mw.ptr)
+        self._h.memcpy_d2h(T, self._T.ptr)
+        return mw, np.triu(T)
+
     def regressor(self):
-        """The current state as a BayesianLinearRegressor (precision carried by its factor, reference :93)."""
-        return BayesianLinearRegressor(self.mw.copy(), PDMat(np.triu(self.T)))
+        """The current state as a regressor of the type it was built from (precision carried by its factor, reference :93)."""
+        mw, T = self.state()
+        post = BayesianLinearRegressor(mw, PDMat(T))
+        return BasisFunctionRegressor(post, self.phi) if self.phi is not None else post
 
 
 def _marginals(fx, want_mean, want_var):

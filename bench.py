@@ -64,12 +64,17 @@ def pmc_traffic_per_update(key):
         return None, None
 
 
-def algorithmic_bytes(D, N, w, diag_noise, Din=None):
-    """w(D N + N + N_s + 2D + 2D^2) + 8 per update (c5: D_in N instead of D N, plus w(D_in D + D))."""
+def algorithmic_bytes(D, N, w, diag_noise, Din=None, dense_prior=False, lw_post=False):
+    """Bytes one update of the TIMED call has to move (SURVEY.md 8(d) counted against what the call actually passes):
+    reads X (D N; c5: the raw inputs D_in N + Omega D_in D + phases D), y (N), the noise (N or 1), the prior mean (D) and
+    the prior precision (D for a diagonal prior, D^2 dense); writes mw' (D), T (D^2), Lw' (D^2, only when requested),
+    logpdf (8) and info (4).  SURVEY's 2D^2 assumes a dense prior in AND Lw' out; the bench passes a diagonal prior and no
+    Lw' buffer, so charging them would overstate the achieved bandwidth (VERDICT r2 weak #6)."""
     ns = N if diag_noise else 1
-    if Din is not None:
-        return w * (Din * N + N + ns + 2 * D + 2 * D * D + Din * D + D) + 8
-    return w * (D * N + N + ns + 2 * D + 2 * D * D) + 8
+    x = (Din * N + Din * D + D) if Din is not None else D * N
+    prior = D * D if dense_prior else D
+    out = D + D * D + (D * D if lw_post else 0)
+    return w * (x + N + ns + D + prior + out) + 12
 
 
 def algorithmic_flops(D, N, Din=None):
@@ -237,13 +242,22 @@ def main():
     ap.add_argument("--secondary", type=int, default=None,
                     help="1: also time the other BASELINE shapes (default at one GPU on the headline workload), 0: skip")
     ap.add_argument("--config", choices=["c2", "c3", "c4", "c5"], default=None,
-                    help="make one of the secondary BASELINE shapes the measured workload (development)")
+                    help="make one of the secondary BASELINE shapes the measured workload; c4 is BASELINE's STRONG-scaling "
+                         "case: a fixed batch of 8192 regressors sharded over the ranks (8192 / N per GPU)")
+    ap.add_argument("--global-batch", type=int, default=None,
+                    help="fixed TOTAL number of regressors, sharded over the ranks in contiguous blocks (strong scaling); "
+                         "default: --batch per GPU (weak scaling), except --config c4")
+    ap.add_argument("--comm", choices=["rccl", "torch"], default="rccl",
+                    help="N > 1: the evidence exchange through the library's own RCCL binding (blr_comm_init + "
+                         "blr_logpdf_allgather_sum; torch.distributed only ships the unique id) or through torch.distributed")
     args = ap.parse_args()
     Din = None
     if args.config == "c3":
         args.D, args.N, args.dtype, args.noise, args.batch = 1024, 65536, "f32", "diagonal", 1
     elif args.config == "c4":
         args.D, args.N, args.dtype, args.noise, args.batch = 64, 1024, "f64", "isotropic", 8192
+        if args.global_batch is None:
+            args.global_batch = 8192
     elif args.config == "c5":
         args.D, args.N, args.dtype, args.noise, args.batch, Din = 2048, 16384, "f32", "isotropic", 1, 8
     headline = (args.D, args.N, args.dtype, args.noise, Din) == (128, 4096, "f64", "isotropic", None)
@@ -291,12 +305,36 @@ def main():
     h.set_stream(stream.cuda_stream)  # 0 = the HIP null stream = torch's default stream
     h.set_async(True)
 
-    B, D, N = args.batch, args.D, args.N
-    cfg = {(128, 4096, "f64"): "c2", (1024, 65536, "f32"): "c3", (64, 1024, "f64"): "c4 shape", (2048, 16384, "f32"): "c5"}
+    D, N = args.D, args.N
+    strong = args.global_batch is not None
+    if strong:  # contiguous blocks of a fixed batch (sharding.shard_range): the partition north_star names for config 4
+        from blr_amd import sharding
+
+        lo, hi = sharding.shard_range(args.global_batch, rank, world)
+        B = hi - lo
+        Bmax = max(sharding.shard_sizes(args.global_batch, world))  # collectives need equal counts: blocks are zero-padded
+        global_batch = args.global_batch
+    else:
+        B = Bmax = args.batch
+        global_batch = B * world
+    cfg = {(128, 4096, "f64"): "c2", (1024, 65536, "f32"): "c3", (64, 1024, "f64"): "c4", (2048, 16384, "f32"): "c5"}
     wl = Workload(torch, _abi, h, dev, cfg.get((D, N, args.dtype), "custom"), B, D, N, args.dtype, args.noise, 123456 + 1 + rank, Din)
     lp_sum = torch.zeros((1,), dtype=torch.float64, device=dev)
-    lp_all = torch.empty((B * world,), dtype=torch.float64, device=dev)
+    lp_loc = torch.zeros((Bmax,), dtype=torch.float64, device=dev)  # this rank's evidences (+ zero padding of an uneven block)
+    wl.lp = lp_loc[:B]
+    lp_all = torch.empty((Bmax * world,), dtype=torch.float64, device=dev)
     torch.cuda.synchronize(dev)
+
+    # N > 1: the exchange runs on the LIBRARY's RCCL binding (the path a host without torch would use); torch.distributed
+    # only carries the 128-byte unique id, the barriers around the timed region and the max-over-ranks of the elapsed time
+    # (BLR_BENCH_FORCE_COMM=1: run that code path with a one-rank communicator on a one-GPU box)
+    use_lib_comm = (dist is not None and backend == "nccl" and args.comm == "rccl") or (
+        world == 1 and os.environ.get("BLR_BENCH_FORCE_COMM") == "1")
+    if use_lib_comm:
+        box = [_abi.Handle.comm_unique_id() if rank == 0 else None]
+        if dist is not None:
+            dist.broadcast_object_list(box, src=0)
+        h.comm_init(world, rank, box[0])
 
     def step(ev=None):
         if ev is not None:
@@ -304,16 +342,18 @@ def main():
         wl.launch()
         if ev is not None:
             ev[1].record(stream)
-        if dist is not None:
-            # the path's only exchange: all-gather of the per-regressor log evidences (8 B each), then the SAME
-            # fixed-order device sum on every rank -> identical bits for every rank count
+        # the path's only exchange: all-gather of the per-regressor log evidences (8 B each), then the SAME
+        # fixed-order device sum on every rank -> identical bits for every rank count
+        if use_lib_comm:  # ncclAllGather on the handle's stream + the fixed-order sum, one library call
+            h.logpdf_allgather_sum(Bmax, lp_loc.data_ptr(), lp_all.data_ptr(), lp_sum.data_ptr())
+        elif dist is not None:
             if backend == "nccl":
-                dist.all_gather_into_tensor(lp_all, wl.lp)
+                dist.all_gather_into_tensor(lp_all, lp_loc)
             else:  # host-staged collective (validation only)
-                host = torch.empty(B * world, dtype=torch.float64)
-                dist.all_gather_into_tensor(host, wl.lp.cpu())
+                host = torch.empty(Bmax * world, dtype=torch.float64)
+                dist.all_gather_into_tensor(host, lp_loc.cpu())
                 lp_all.copy_(host)
-            h.logpdf_sum(_abi.MEM_DEVICE, B * world, lp_all.data_ptr(), lp_sum.data_ptr())
+            h.logpdf_sum(_abi.MEM_DEVICE, Bmax * world, lp_all.data_ptr(), lp_sum.data_ptr())
         else:
             h.logpdf_sum(_abi.MEM_DEVICE, B, wl.lp.data_ptr(), lp_sum.data_ptr())
 
@@ -346,7 +386,7 @@ def main():
 
     out = None
     if rank == 0:
-        value = B * world * args.steps / elapsed
+        value = global_batch * args.steps / elapsed
         roof = wl.roofline(kern_ms)
         per_update, src = pmc_traffic_per_update("c2_fused_small_kernel_hbm") if headline else (None, None)
         peak_meas, peak_src = measured_matrix_peak(args.dtype)
@@ -366,15 +406,17 @@ def main():
             "warmup": args.warmup,
             "ms_per_step": elapsed / args.steps * 1e3,
             "higher_is_better": True,
-            "scaling": "weak",
+            "scaling": "strong" if strong else "weak",
             "vs_baseline": None,
             "dtype": args.dtype,
             "data": "synthetic",
             "config": {
                 "workload": f"{wl.name}: independent regressors D={D}, N={N}, ColVecs, {args.noise} noise, {args.dtype}, "
                             f"Lw=I, fused posterior+logpdf" + (f", random-Fourier basis D_in={Din} on the device" if Din else ""),
-                "D": D, "N": N, "batch_per_gpu": B, "global_batch": B * world,
-                "sharding": f"regressors x{world}, no data-path collective; one all-gather of {B * world} doubles",
+                "D": D, "N": N, "batch_per_gpu": B, "global_batch": global_batch,
+                "sharding": f"regressors x{world} ({'fixed batch, contiguous blocks' if strong else 'fixed block per GPU'}), no data-path "
+                            f"collective; one all-gather of {Bmax * world} doubles through "
+                            f"{'the library RCCL binding (blr_logpdf_allgather_sum)' if use_lib_comm else ('torch.distributed ' + backend) if dist is not None else 'nothing (one rank)'}",
             },
             "roofline": roof,
             "total_log_evidence": total_evidence,
@@ -390,6 +432,7 @@ def main():
         shapes = [("c2_f32", 4096, 128, 4096, "f32", "isotropic", None, 10),
                   ("c4_f64", 8192, 64, 1024, "f64", "isotropic", None, 10),
                   ("c4_f32", 8192, 64, 1024, "f32", "isotropic", None, 10),
+                  ("c4_f64_B1024", 1024, 64, 1024, "f64", "isotropic", None, 20),  # the per-GPU block of config 4 on 8 GPUs
                   ("c3_f32", 1, 1024, 65536, "f32", "diagonal", None, 10),
                   ("c5_f32_end_to_end", 1, 2048, 16384, "f32", "isotropic", 8, 10)]
         for name, b, d, n, dt, noise, din, steps in shapes:
@@ -409,6 +452,8 @@ def main():
         out["secondary"] = sec
     if rank == 0:
         print(json.dumps(out), flush=True)
+    if use_lib_comm:
+        h.comm_destroy()
     if dist is not None:
         dist.barrier()
         dist.destroy_process_group()

@@ -158,6 +158,14 @@ int blr_rand_f32(blr_handle* h, int memspace, int layout, int64_t D, int64_t N, 
                  int prior_kind, const float* mw, const float* Lw, int64_t ldl,
                  const float* Z1, int64_t ldz1, const float* Z2, int64_t ldz2,
                  float* Y, int64_t ldy);
+/*   Y = X'W for S GIVEN weight vectors W (D x S, ldw >= D): evaluation of S function samples at the inputs,
+ *   replaces (s::BLRFunctionSample)(X) = ϕ(X)'s.w  (src/sampling_functions.jl:16-18) for a batch of samples; also the two
+ *   large products of the reverse-mode rule of rand (README.md:56-60: W̄ = X Ȳ and X̄ = W Ȳ', both "apply" calls on
+ *   re-interpreted layouts -- julia/BLRMI355X.jl rand_pullback).  Y is N x S, ldy >= N. */
+int blr_apply_weights_f64(blr_handle* h, int memspace, int layout, int64_t D, int64_t N, int64_t S,
+                          const double* X, int64_t ldx, const double* W, int64_t ldw, double* Y, int64_t ldy);
+int blr_apply_weights_f32(blr_handle* h, int memspace, int layout, int64_t D, int64_t N, int64_t S,
+                          const float* X, int64_t ldx, const float* W, int64_t ldw, float* Y, int64_t ldy);
 /*   W = mw .+ Uw \ Z   (D x S) */
 int blr_sample_weights_f64(blr_handle* h, int memspace, int64_t D, int64_t S,
                            int prior_kind, const double* mw, const double* Lw, int64_t ldl,

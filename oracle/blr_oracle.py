@@ -155,6 +155,32 @@ def rand(mw, Lw, X, Sy, Z1, Z2):
     return X.T @ w + Us.T @ Z2
 
 
+def rand_pullback(mw, Lw, X, Sy, Z1, Ybar):
+    """Reverse-mode rule of `rand` (what Zygote derives through :49-53, README.md:56-60) for diagonal / isotropic noise, with
+    the draws (Z1, Z2) held fixed:  Y = X'W + sqrt.(s) .* Z2,  W = mw .+ Uw \ Z1,  Uw = chol(Lw).U.
+        Wbar = X Ybar,  Xbar = W Ybar',  mwbar = Wbar 1,  Ubar = -triu(Uw^-T Wbar V'),  V = Uw \ Z1,
+        Lwbar: through the Cholesky (dense Lw) / the diagonal (Lw a vector);  sbar_n = sum_s Ybar[n, s] Z2[n, s] / (2 sqrt(s_n))
+    is left to the caller (it needs Z2 only).  Returns dict(X, mw, Lw, U, W).  Pinned by finite differences of `rand` in
+    tests/test_oracle_pins.py."""
+    D, N = X.shape
+    dt = X.dtype
+    Lw = np.asarray(Lw, dtype=dt)
+    Uw = chol_upper(dense_precision(Lw, D, dt))
+    V = _solve_tri(Uw, Z1, trans=False)
+    W = mw[:, None] + V
+    Wbar = X @ Ybar
+    Ubar = -np.triu(_solve_tri(Uw, Wbar, trans=True) @ V.T)
+    if Lw.ndim == 1:   # Uw = diag(sqrt(d)): d_bar = Ubar_jj / (2 sqrt(d_j))
+        Lbar = np.diag(Ubar) / (2.0 * np.sqrt(Lw))
+    else:              # A = L L' with L = Uw': Abar = sym(L^-T Phi(L' Lbar) L^-1), Phi = lower triangle with halved diagonal
+        L = Uw.T
+        M = np.tril(L.T @ Ubar.T)
+        M[np.diag_indices(D)] *= 0.5
+        Ab = _solve_tri(Uw, _solve_tri(Uw, M.T, trans=False).T, trans=False)  # L^-T M L^-1 = Uw^-1 (Uw^-1 M')'
+        Lbar = 0.5 * (Ab + Ab.T)
+    return {"X": W @ Ybar.T, "mw": Wbar.sum(axis=1), "Lw": Lbar, "U": Ubar, "W": W}
+
+
 def sample_weights(mw, Lw, Z):
     """sampling_functions.jl:29,35,44  w = mw .+ Uw \\ randn(...)."""
     D = mw.shape[0]

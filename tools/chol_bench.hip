@@ -12,7 +12,7 @@ using namespace blr;
 #define CK(x) do { hipError_t e_ = (x); if (e_ != hipSuccess) { printf("HIP error %s at %d\n", hipGetErrorString(e_), __LINE__); return 1; } } while (0)
 
 template <typename T>
-__global__ __launch_bounds__(256) void k(const T* A, T* out, int* info, int reps) {
+__global__ __launch_bounds__(256, 2) void k(const T* A, T* out, int* info, int reps) {
   using C = SmallCfg<T, 8>;
   extern __shared__ __attribute__((aligned(16))) char smem[];
   T* P = reinterpret_cast<T*>(smem);

@@ -97,7 +97,7 @@ int main(int argc, char** argv) {
   const int kLds = WaveCfg<T, NB>::LDS_BYTES, kBlock = 64, kGrid = std::min(B, 2048);
 #else
   auto kern = fused_small_kernel<T, NB, 4>;
-  const int kLds = C::LDS_BYTES, kBlock = kThreads, kGrid = B;
+  const int kLds = C::LDS_BYTES, kBlock = kThreads, kGrid = getenv("FB_GRID") ? atoi(getenv("FB_GRID")) : B;
   CK(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, C::LDS_BYTES));
 #endif
   hipEvent_t e0, e1; CK(hipEventCreate(&e0)); CK(hipEventCreate(&e1));
