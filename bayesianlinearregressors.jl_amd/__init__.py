@@ -21,6 +21,7 @@ from .regressor import (
     RowVecs,
     Symmetric,
     cov,
+    evaluate,
     logpdf,
     logpdf_and_gradient,
     logpdf_columns,
@@ -30,6 +31,7 @@ from .regressor import (
     mean_and_var,
     posterior,
     rand,
+    rand_and_pullback,
     rand_b,
     std,
     var,
@@ -38,5 +40,5 @@ from .regressor import (
 __all__ = [
     "logpdf", "rand", "mean", "std", "cov", "var", "BayesianLinearRegressor", "marginals", "posterior",
     "BasisFunctionRegressor", "ColVecs", "RowVecs", "Diagonal", "Symmetric", "PDMat", "Normal", "FiniteGP",
-    "BLRFunctionSample", "RandomFourierFeatures", "mean_and_var", "mean_and_cov", "rand_b", "logpdf_columns", "logpdf_and_gradient", "BLRError", "PosDefException", "ResidentPosterior",
+    "BLRFunctionSample", "RandomFourierFeatures", "mean_and_var", "mean_and_cov", "rand_b", "rand_and_pullback", "evaluate", "logpdf_columns", "logpdf_and_gradient", "BLRError", "PosDefException", "ResidentPosterior",
 ]

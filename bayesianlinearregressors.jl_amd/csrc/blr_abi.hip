@@ -668,6 +668,9 @@ int marginals_large_one(blr_handle* h, int layout, int64_t D, int64_t N, const T
   } else if (var) {
     // top block: L = U' (upper factor given) or chol(Lw) (dense precision, reference :41 _cholesky(Lw))
     if (prior_kind == BLR_PRIOR_UPPER_FACTOR) {
+      // a factor with a non-positive diagonal entry is not a Cholesky factor: LAPACK-style index instead of Inf / NaN variances
+      hipLaunchKernelGGL(prior_diag_kernel<T>, dim3(1), dim3(kThreads), 0, h->stream, Lw, ldl, (int)PRIOR_UPPER_FACTOR, (int)D,
+                         (double*)nullptr, info_dev);
       dim3 grid((DP + 31) / 32, (DP + 31) / 32);
       hipLaunchKernelGGL(factor_transpose_fill_kernel<T>, grid, dim3(kThreads), 0, h->stream, Lw, ldl, (int)D, DP, Ybar, ldy);
     } else {
@@ -1890,8 +1893,19 @@ int posterior_dense_noise(blr_handle* h, int memspace, int layout, int64_t D64, 
   a.layout = BLR_LAYOUT_COLVECS; a.noise_kind = BLR_NOISE_ISOTROPIC; a.prior_kind = prior_kind;
   a.D = D; a.N = N; a.B = 1;
   a.vec_ok = (D % Mfma<T>::VEC == 0 && aligned16(a.X, ld, (int64_t)0)) ? 1 : 0;
+  // status precedence of the reference: the prior is factored first (:78), then Sigma_y (:79), then the posterior (:86).  The
+  // inner update cannot tell a prior failure from a posterior one once the whitened data are garbage, so the prior's status
+  // comes from an update on ZERO observations (A = Lw: D^3 / 3 flops, nothing next to the N^3 / 3 of the whitening)
+  int32_t* prior_info = nullptr;
+  if ((rc = dev_alloc_tmp(h, 1, &prior_info))) return rc;
+  {
+    PosteriorArgs<T> p0 = a;
+    p0.N = 0; p0.mw_post = nullptr; p0.T_post = nullptr; p0.Lw_post = nullptr; p0.logpdf = nullptr; p0.info = prior_info;
+    if ((rc = dispatch_posterior<T>(h, p0))) return rc;
+  }
   if ((rc = dispatch_posterior<T>(h, a))) return rc;
-  hipLaunchKernelGGL(dense_finish_kernel, dim3(1), dim3(64), 0, h->stream, lp_tmp, info_d, (const double*)logdet, (const int32_t*)noise_info);
+  hipLaunchKernelGGL(dense_finish_kernel, dim3(1), dim3(64), 0, h->stream, lp_tmp, info_d, (const double*)logdet, (const int32_t*)noise_info,
+                     (const int32_t*)prior_info);
   HIP_TRY(h, hipGetLastError());
   if (memspace == BLR_MEM_HOST) {
     if (mw_post) HIP_TRY(h, hipMemcpyAsync(mw_post, mwp_d, (size_t)D * sizeof(T), hipMemcpyDeviceToHost, h->stream));
@@ -1921,6 +1935,10 @@ int tall_solve_rows(blr_handle* h, int layout, int D, int N, const T* X, int64_t
     hipLaunchKernelGGL(mean_fill_kernel<T>, dim3((unsigned)(NP / 64)), dim3(kThreads), 0, h->stream, m);
   }
   if (prior_kind == BLR_PRIOR_UPPER_FACTOR) {
+    // a PDMat whose factor has a non-positive diagonal entry is not a Cholesky factor: report it (LAPACK-style index) instead
+    // of returning Inf / NaN with info = 0; the panel kernels below return early on a non-zero status
+    hipLaunchKernelGGL(prior_diag_kernel<T>, dim3(1), dim3(kThreads), 0, h->stream, Lw, ldl, (int)PRIOR_UPPER_FACTOR, D, (double*)nullptr,
+                       info_dev);
     dim3 grid((DP + 31) / 32, (DP + 31) / 32);
     hipLaunchKernelGGL(factor_transpose_fill_kernel<T>, grid, dim3(kThreads), 0, h->stream, Lw, ldl, D, DP, Ybar, ldy);
   } else {

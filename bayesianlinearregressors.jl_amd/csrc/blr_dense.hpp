@@ -40,9 +40,13 @@ __global__ __launch_bounds__(kThreads) void row_extract_kernel(const T* __restri
 
 // evidence of the whitened problem -> evidence of the original one; a Sigma_y that is not positive definite wins over whatever
 // the inner update reported on the garbage it was given (reference :79 throws before :86 is reached)
-__global__ void dense_finish_kernel(double* logpdf, int32_t* info, const double* logdet_Sy, const int32_t* noise_info) {
+__global__ void dense_finish_kernel(double* logpdf, int32_t* info, const double* logdet_Sy, const int32_t* noise_info,
+                                    const int32_t* prior_info) {
   if (threadIdx.x != 0 || blockIdx.x != 0) return;
-  if (*noise_info != 0) {
+  if (*prior_info != 0) {  // reference :78 comes before :79
+    *info = *prior_info;
+    if (logpdf) *logpdf = __longlong_as_double(0x7ff8000000000000LL);
+  } else if (*noise_info != 0) {
     *info = *noise_info;
     if (logpdf) *logpdf = __longlong_as_double(0x7ff8000000000000LL);
   } else if (logpdf && *info == 0) {

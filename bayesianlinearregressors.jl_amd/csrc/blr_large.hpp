@@ -1166,7 +1166,7 @@ __global__ __launch_bounds__(kThreads) void prior_diag_kernel(const T* Lw, int64
   bad = block_min_int(bad, iscr, threadIdx.x);
   v = block_allreduce(v, scr, threadIdx.x);
   if (threadIdx.x == 0) {
-    *out = (kind == PRIOR_DIAGONAL) ? v : 2.0 * v;
+    if (out) *out = (kind == PRIOR_DIAGONAL) ? v : 2.0 * v;
     *info = (bad == 0x7fffffff) ? 0 : bad;
   }
 }

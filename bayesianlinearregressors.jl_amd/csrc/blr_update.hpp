@@ -56,19 +56,19 @@ __global__ __launch_bounds__(kThreads) void rank1_sweep_kernel(SweepArgs<T> a) {
   const T* Tg = a.Tf + reg * a.strideT;
   T* mg = a.mw + reg * a.stridemw;
   // ---- load (all four waves): the D x D block column by column, every load independent of the others
-  if (tid == 0) iscr[0] = 0;
+  if (tid == 0) iscr[0] = 0x7fffffff;
   __syncthreads();
   for (int e = tid; e < D * D; e += kThreads) {
     const int c = e / D, j = e - c * D;
     if (j <= c) {
       const T v = Tg[(int64_t)c * a.ldt + j];
       R[off(j) + c] = v;
-      if (j == c && !(v > T(0))) iscr[0] = 1;  // benign race: every writer stores 1
+      if (j == c && !(v > T(0))) atomicMin(&iscr[0], c + 1);  // first non-positive diagonal entry of the factor
     }
   }
   for (int j = tid; j < D; j += kThreads) { R[off(j) + D] = T(0); mv[j] = mg[j]; }
   __syncthreads();
-  const bool bad_factor = iscr[0] != 0;
+  const bool bad_factor = iscr[0] != 0x7fffffff;
   int bad_noise = 0;
   double logpdf = 0.0;
   if (wave == 0) {
@@ -141,7 +141,7 @@ __global__ __launch_bounds__(kThreads) void rank1_sweep_kernel(SweepArgs<T> a) {
   }
   __syncthreads();
   // ---- write the state back (all four waves); untouched when anything failed
-  const int bad = bad_factor ? -1 : iscr[1];
+  const int bad = bad_factor ? iscr[0] : iscr[1];  // the same code the re-factorisation route reports for a bad factor
   if (bad == 0) {
     for (int e = tid; e < D * D; e += kThreads) {
       const int c = e / D, j = e - c * D;

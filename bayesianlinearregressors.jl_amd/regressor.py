@@ -745,6 +745,25 @@ class BLRFunctionSample:
         return _marginals(FiniteGP(f, x, 0.0), True, False)[0]  # phi(X)' w through the mean-only stream
 
 
+def evaluate(samples, X):
+    """Every function sample of `samples` (BLRFunctionSamples of ONE regressor, e.g. ``rand(rng, f, S)``) at the inputs X in one
+    pass over phi(X): an N x S matrix whose column j is ``samples[j](X)`` -- reference sampling_functions.jl:16-18 for a batch
+    (blr_apply_weights_*)."""
+    flat = list(np.asarray(samples, dtype=object).reshape(-1, order="F"))
+    if not flat:
+        raise ValueError("no samples")
+    phi = flat[0].phi
+    x = phi(X) if phi is not None else X
+    dtype = _dtype_of(*[f.w for f in flat])
+    Xa, layout, ldx, D, N = _x_layout(x, dtype)
+    W = np.asfortranarray(np.stack([np.asarray(f.w, dtype=dtype) for f in flat], axis=1))
+    if W.shape[0] != D:
+        raise ValueError("dimension of the inputs != length of the sampled weights")
+    Y = np.empty((N, len(flat)), dtype=dtype, order="F")
+    _handle().apply_weights(dtype, _abi.MEM_HOST, layout, D, N, len(flat), Xa, ldx, W, max(D, 1), Y, max(N, 1))
+    return Y
+
+
 def _blr_and_mapping(b):
     """reference src/sampling_functions.jl:51-52"""
     if isinstance(b, BasisFunctionRegressor):
@@ -795,6 +814,82 @@ def rand_b(rng, A, f):
         flat[i] = BLRFunctionSample(W[:, i].copy(), phi)
     A[...] = flat.reshape(A.shape, order="F")
     return A
+
+
+def rand_and_pullback(rng, fx, S):
+    """(Y, pullback): the draws of `rand(rng, fx, S)` and their reverse-mode rule -- what Zygote derives through reference
+    :49-53 in README.md:56-60 (``Zygote.pullback((X, Σ, mw, Λw) -> rand(rng, BLR(mw, Λw)(X, Σ), S), ...)``); a ccall is opaque
+    to it, so the rule is spelled out here (julia/BLRMI355X.jl: the rrule of rand).  ``pullback(Ybar)`` with Ybar N x S returns
+    dict(X, noise, mw, Lw): X in the layout of the primal container, noise a vector (Diagonal) or a scalar (isotropic), Lw a
+    vector (Diagonal), the upper-factor tangent (PDMat: what flows into ``chol.factors``) or a symmetric matrix (dense).
+
+    The two O(D N S) products run on the device as `blr_apply_weights_*` calls on re-interpreted layouts
+    (Wbar = X Ybar, Xbar = W Ybar'); what is left is O(D^2 S) bookkeeping of the rule."""
+    fxb = _to_finite_blr(fx)
+    blr = fxb.f
+    dtype = _dtype_of(blr.mw)
+    X, layout, ldx, D, N = _x_layout(fxb.x, dtype)
+    mw = _mean_vector(blr.mw, D, dtype)
+    Lw, prior_kind, ldl = _prior(blr.Lw, D, dtype, need_cholesky=True)
+    s, noise_kind = _noise(fxb.Sy, N, dtype, need_cholesky=True)
+    if noise_kind == _abi.NOISE_DENSE:
+        raise NotImplementedError("rand_and_pullback takes scalar or diagonal noise")
+    Z1 = _randn(rng, D, S, dtype)  # FIRST draw  (reference :51)
+    Z2 = _randn(rng, N, S, dtype)  # SECOND draw (reference :52)
+    h = _handle()
+    W = np.empty((D, S), dtype=dtype, order="F")
+    h.sample_weights(dtype, _abi.MEM_HOST, D, S, prior_kind, mw, Lw, ldl, Z1, D, W, D)
+    Y = np.empty((N, S), dtype=dtype, order="F")
+    h.rand(dtype, _abi.MEM_HOST, layout, D, N, S, X, ldx, noise_kind, s, prior_kind, mw, Lw, ldl, Z1, D, Z2, N, Y, N)
+    flip = _abi.LAYOUT_ROWVECS if layout == _abi.LAYOUT_COLVECS else _abi.LAYOUT_COLVECS
+
+    def pullback(Ybar):
+        Ybar = np.asarray(Ybar, dtype=dtype)
+        if Ybar.shape != (N, S):
+            raise ValueError("the cotangent must have the shape of the draws (N x S)")
+        # Wbar (D x S) = X Ybar: the same memory read as the design matrix of N "features" at D "inputs" (layout flipped)
+        Yb_f = np.asfortranarray(Ybar)
+        Wbar = np.empty((D, S), dtype=dtype, order="F")
+        h.apply_weights(dtype, _abi.MEM_HOST, flip, N, D, S, X, ldx, Yb_f, max(N, 1), Wbar, max(D, 1))
+        # Xbar = W Ybar' in the layout of X: contraction over the S draws
+        if layout == _abi.LAYOUT_COLVECS:   # out[d + n D]: "inputs" d, "draws" n, design matrix W read as S x D RowVecs
+            Xbar = np.empty((D, N), dtype=dtype, order="F")
+            Yb_t = np.ascontiguousarray(Ybar)  # (N, S) C order == S x N column-major
+            h.apply_weights(dtype, _abi.MEM_HOST, _abi.LAYOUT_ROWVECS, S, D, N, W, max(D, 1), Yb_t, max(S, 1), Xbar, max(D, 1))
+        else:                               # out[n + d N]: "inputs" n, "draws" d, design matrix Ybar read as S x N RowVecs
+            Xbar = np.empty((N, D), dtype=dtype, order="F")
+            W_t = np.ascontiguousarray(W)      # (D, S) C order == S x D column-major
+            h.apply_weights(dtype, _abi.MEM_HOST, _abi.LAYOUT_ROWVECS, S, N, D, Yb_f, max(N, 1), W_t, max(S, 1), Xbar, max(N, 1))
+        gX = Xbar if Xbar.shape == np.shape(X) else Xbar.T
+        dmw = Wbar.sum(axis=1, dtype=np.float64).astype(dtype)
+        V = W - mw[:, None]  # Uw \ Z1
+        if prior_kind == _abi.PRIOR_DIAGONAL:
+            gL = (-0.5 * np.sum(Wbar.astype(np.float64) * V, axis=1) / Lw).astype(dtype)  # Uw = diag(sqrt(d))
+        else:
+            if prior_kind == _abi.PRIOR_UPPER_FACTOR:
+                U = np.triu(Lw).astype(np.float64)
+            else:  # Uw = chol(Lw).U from the library: the posterior update on zero observations (as ResidentPosterior does)
+                Tf = np.zeros((D, D), dtype=dtype, order="F")
+                lp0 = np.zeros(1)
+                rc = h.posterior(dtype, _abi.LAYOUT_COLVECS, D, 0, None, max(D, 1), None, _abi.NOISE_ISOTROPIC, np.ones(1, dtype=dtype),
+                                 prior_kind, mw, Lw, ldl, None, Tf, max(D, 1), None, max(D, 1), lp0)
+                if rc > 0:
+                    raise _abi.PosDefException(rc)
+                U = np.triu(Tf).astype(np.float64)
+            # D x D bookkeeping of the rule on the host (like the prior tangent of logpdf_and_gradient): Ubar = -triu(Uw^-T Wbar V')
+            Ubar = -np.triu(np.linalg.solve(U.T, Wbar.astype(np.float64)) @ V.T)
+            if prior_kind == _abi.PRIOR_UPPER_FACTOR:
+                gL = Ubar.astype(dtype)
+            else:  # through the Cholesky A = L L', L = Uw': Abar = sym(L^-T Phi(L' Lbar) L^-1), Phi = lower triangle, halved diagonal
+                M = np.tril(U @ Ubar.T)
+                M[np.diag_indices(D)] *= 0.5
+                Ab = np.linalg.solve(U, np.linalg.solve(U, M.T).T)
+                gL = (0.5 * (Ab + Ab.T)).astype(dtype)
+        sd = np.sum(Ybar.astype(np.float64) * Z2, axis=1) / (2.0 * np.sqrt(np.broadcast_to(s, (N,)).astype(np.float64)))
+        gs = sd.astype(dtype) if noise_kind == _abi.NOISE_DIAGONAL else dtype(sd.sum())
+        return {"X": np.asarray(gX), "noise": gs, "mw": dmw, "Lw": gL}
+
+    return Y, pullback
 
 
 def _rand_finite(rng, fx, S):

@@ -302,11 +302,16 @@ int blr_rand_dense_noise_f32(blr_handle* h, int memspace, int layout, int64_t D,
  * read and may be overwritten with zeros) -- exactly the (mw_post, T_post) pair blr_posterior_batched_* writes.
  * k new observations per regressor: X (D x k ColVecs / k x D RowVecs), y[k], isotropic or diagonal noise s.
  * logpdf[B] (may be NULL) = log p(y_k | state before the call), the evidence increment: summing it over successive calls
- * gives the evidence of all the data (chain rule).  info[B]: 0; i > 0: s_i is not positive (reference :79) or the leading
- * minor of order i is not positive definite; -1: T has a non-positive diagonal entry.
- * D <= 128 and k <= 16: k sweeps of D Givens rotations over the factor held in LDS -- O(k D^2), orthogonal transformations
- * only; the state is untouched when info != 0.  Otherwise: the same state re-factored in place with the old factor entering
- * as pseudo-observations (cost independent of k; for D > 128 the state is undefined when info != 0). */
+ * gives the evidence of all the data (chain rule).  info[B]: 0, or LAPACK-style i > 0 on BOTH routes, checked in the
+ * reference's order (:78 prior, :79 noise, :86 posterior): T has a non-positive diagonal entry i (the state is not a Cholesky
+ * factor), else s_i is not positive, else the leading minor of order i of the updated precision is not positive definite.
+ * Routes (measured; BLR_MI355X_SWEEP=always|never overrides, "always" meaning D <= 128 and k <= 16):
+ *   k <= 1, D <= 128 (and D > 64 or B < 256): one sweep of D Givens rotations over the factor held in LDS -- O(D^2),
+ *     orthogonal transformations only; the state is untouched when info != 0;
+ *   otherwise: the same state re-factored in place by blr_posterior_batched_* with the old factor entering as D
+ *     pseudo-observations (cost independent of k; that entry point supports mw_post == mw and T_post == Lw for
+ *     BLR_PRIOR_UPPER_FACTOR: every read of the old state completes before the first write).  D <= 128: the state is
+ *     untouched when info != 0; D > 128: undefined when info != 0. */
 int blr_update_factor_f64(blr_handle* h, int memspace, int layout, int64_t B, int64_t D, int64_t k, const double* X,
                           int64_t ldx, int64_t strideX, const double* y, int64_t stridey, int noise_kind, const double* s,
                           int64_t strides, double* mw, int64_t stridemw, double* T, int64_t ldt, int64_t strideT,

@@ -25,7 +25,7 @@ using AbstractGPs: FiniteGP
 using BayesianLinearRegressors: BayesianLinearRegressor, BasisFunctionRegressor, BLRFunctionSample
 import BayesianLinearRegressors as REF
 import ChainRulesCore
-using ChainRulesCore: NoTangent, Tangent, ZeroTangent, @not_implemented
+using ChainRulesCore: NoTangent, Tangent, ZeroTangent
 
 const LIB = get(ENV, "BLR_MI355X_LIB", "libblr_mi355x")
 
@@ -361,8 +361,96 @@ function rand!(rng::AbstractRNG, A::AbstractArray{<:BLRFunctionSample}, b::BLRLi
     end
     return A
 end
-# Random API hooks (sampling_functions.jl:23-25): `rand(rng, f)` / `rand(rng, f, dims...)` on the regressor itself
-sampler(rng::AbstractRNG, b::BLRLike) = Random.SamplerTrivial(b)
+
+# ---- Y = X'W for S given weight vectors (blr_apply_weights_*): a batch of function samples evaluated at the inputs,
+#      sampling_functions.jl:16-18; `layout`, `D`, `N` describe X as the library reads it (see xlayout)
+function apply_weights!(Y::Matrix{T}, X::Array{T}, layout::Integer, ldx::Integer, D::Integer, N::Integer, W::Matrix{T}) where {T<:Elt}
+    S = size(W, 2)
+    h = handle()
+    rc = GC.@preserve X W Y begin
+        if T === Float64
+            ccall((:blr_apply_weights_f64, LIB), Cint,
+                  (Ptr{Cvoid}, Cint, Cint, Int64, Int64, Int64, Ptr{T}, Int64, Ptr{T}, Int64, Ptr{T}, Int64),
+                  h, MEM_HOST, layout, D, N, S, X, ldx, W, size(W, 1), Y, size(Y, 1))
+        else
+            ccall((:blr_apply_weights_f32, LIB), Cint,
+                  (Ptr{Cvoid}, Cint, Cint, Int64, Int64, Int64, Ptr{T}, Int64, Ptr{T}, Int64, Ptr{T}, Int64),
+                  h, MEM_HOST, layout, D, N, S, X, ldx, W, size(W, 1), Y, size(Y, 1))
+        end
+    end
+    check(h, rc)
+    return Y
+end
+"""
+    evaluate(samples, x) -> Matrix (N x S)
+
+Every function sample of `samples` (an array of `BLRFunctionSample`s drawn from ONE regressor, e.g. `rand(rng, f, S)`) at the
+inputs `x`, in one pass over ϕ(x): column j is `samples[j](x)` (reference sampling_functions.jl:16-18).
+"""
+function evaluate(samples::AbstractArray{<:BLRFunctionSample}, x::AbstractVector)
+    ϕx = first(samples).ϕ(x)
+    xl = xlayout(ϕx)
+    xl === nothing && return reduce(hcat, [smp(x) for smp in samples])
+    X, layout, ldx, D, N = xl
+    T = eltype(X)
+    W = Matrix{T}(undef, D, length(samples))
+    for (j, smp) in enumerate(samples)
+        W[:, j] .= smp.w
+    end
+    return apply_weights!(Matrix{T}(undef, N, length(samples)), X, layout, ldx, D, N, W)
+end
+
+# ---- reverse-mode rule of rand(rng, fx, S) (README.md:56-60 differentiates it w.r.t. X, Σ, mw, Λw through Zygote) -------------
+#   Y = X'W .+ sqrt.(s) .* Z2,  W = mw .+ U \ Z1   (reference :49-53), the draws held fixed:
+#   W̄ = X Ȳ,  X̄ = W Ȳ',  m̄w = W̄ 1,  Ū = -triu(U'^-1 W̄ V'), V = U \ Z1,  s̄_n = Σ_s Ȳ[n,s] Z2[n,s] / (2 sqrt(s_n)).
+# The two O(D N S) products are blr_apply_weights_* calls on re-interpreted layouts (the design matrix read with rows and
+# columns swapped / the weights as the design matrix of an S-feature problem); the rest is D x D bookkeeping.
+function ChainRulesCore.rrule(::typeof(rand), rng::AbstractRNG, fx::FiniteGP{<:BayesianLinearRegressor}, S::Int)
+    xl, nz, pr = xlayout(fx.x), noise(fx.Σy), prior(fx.f.Λw)
+    (xl === nothing || nz === nothing || pr === nothing || nz[2] == DENSEN) && error("rrule(rand): input types outside the device path")
+    X, layout, ldx, D, N = xl
+    T = eltype(X)
+    mw = convert(Vector{T}, fx.f.mw)
+    s, nk, _ = nz
+    Lw, pk, ldl = pr
+    rng0 = copy(rng)
+    Y = rand(rng, fx, S)                        # consumes Z1 = randn(rng, T, D, S), then Z2 = randn(rng, T, N, S)
+    Z1 = randn(rng0, T, D, S); Z2 = randn(rng0, T, N, S)
+    U = UpperTriangular(Matrix{T}(AbstractGPs._cholesky(fx.f.Λw).U))
+    V = U \ Z1
+    W = mw .+ V
+    function rand_pullback(Ȳ0)
+        Ȳ = convert(Matrix{T}, ChainRulesCore.unthunk(Ȳ0))
+        flip = layout == COLVECS ? ROWVECS : COLVECS
+        W̄ = apply_weights!(Matrix{T}(undef, D, S), X, flip, ldx, N, D, Ȳ)                              # X Ȳ
+        X̄ = if layout == COLVECS                                                                       # W Ȳ' as D x N
+            apply_weights!(Matrix{T}(undef, D, N), W, ROWVECS, D, S, D, Matrix{T}(Ȳ'))
+        else                                                                                            # ... as N x D
+            apply_weights!(Matrix{T}(undef, N, D), Ȳ, ROWVECS, N, S, N, Matrix{T}(W'))
+        end
+        Ū = -triu(U' \ (W̄ * V'))
+        Λ = fx.f.Λw
+        dΛ = if Λ isa Diagonal
+            Diagonal(diag(Ū) ./ (2 .* sqrt.(Λ.diag)))
+        elseif Λ isa AbstractPDMat
+            Tangent{typeof(Λ)}(chol = Tangent{typeof(Λ.chol)}(factors = UpperTriangular(Ū)))
+        else
+            M = tril(U * Ū'); M[diagind(M)] ./= 2                                                       # Φ(L' L̄), L = U'
+            Ab = U \ (U \ M')'
+            (Ab .+ Ab') ./ 2
+        end
+        sv = nk == DIAGONALN ? s : fill(s[1], N)
+        s̄ = vec(sum(Ȳ .* Z2; dims=2)) ./ (2 .* sqrt.(sv))
+        dΣ = fx.Σy isa Diagonal{<:Any,<:AbstractGPs.FillArrays.Fill} ?
+             Tangent{typeof(fx.Σy)}(diag = Tangent{typeof(fx.Σy.diag)}(value = sum(s̄))) : Diagonal(s̄)
+        df = Tangent{typeof(fx.f)}(mw = vec(sum(W̄; dims=2)), Λw = dΛ)
+        dx = Tangent{typeof(fx.x)}(X = X̄)
+        return NoTangent(), NoTangent(), Tangent{typeof(fx)}(f = df, x = dx, Σy = dΣ), NoTangent()
+    end
+    return Y, rand_pullback
+end
+ChainRulesCore.rrule(::typeof(AbstractGPs.rand), rng::AbstractRNG, fx::FiniteGP{<:BayesianLinearRegressor}, S::Int) =
+    ChainRulesCore.rrule(rand, rng, fx, S)
 
 # ---- value + gradient of the log marginal likelihood (the rule behind the ccall; SURVEY.md 8f rank 1) ---------------
 # Returns (lp, dX, dy, ds, dmw, mw_post, Ainv).
@@ -413,7 +501,11 @@ function ChainRulesCore.rrule(::typeof(logpdf), fx::FiniteGP{<:BayesianLinearReg
         dΛ = if Λ isa Diagonal
             Diagonal(δ .* (-(m .^ 2 .+ diag(Ai) .- inv.(Λ.diag)) ./ 2))
         elseif Λ isa AbstractPDMat
-            @not_implemented("chain dU = U (G + G') with G = -(m m' + A^-1 - Λw^-1)/2 for a PDMat prior")
+            # the reference reads a PDMat prior through its factor (_cholesky(Λw) = Λw.chol, :78), so the cotangent belongs to
+            # chol.factors: Λw = U'U  =>  dU = U (G + G') with G = dL/dΛw = -(m m' + A^-1 - Λw^-1) / 2 (symmetric), upper part
+            G = -(m * m' .+ Ai .- inv(Λ.chol)) ./ 2
+            dU = UpperTriangular(δ .* (Matrix(Λ.chol.U) * (G .+ G')))
+            Tangent{typeof(Λ)}(chol = Tangent{typeof(Λ.chol)}(factors = dU))
         else
             δ .* (-(m * m' .+ Ai .- inv(Matrix(Λ))) ./ 2)
         end
@@ -631,7 +723,9 @@ function install_overrides!()
         end
     end
     @eval begin
-        Random.rand(rng::AbstractRNG, b::Random.SamplerTrivial{<:BLRLike}) = BLRMI355X.rand(rng, b[])
+        # the reference's Sampler hook returns the regressor ITSELF (sampling_functions.jl:23-25), so `rand(rng, f)` dispatches
+        # on the regressor type (:27), not on a SamplerTrivial
+        Random.rand(rng::AbstractRNG, b::BLRLike) = BLRMI355X.rand(rng, b)
         Random.rand(rng::AbstractRNG, b::BLRLike, dims::Dims) = BLRMI355X.rand(rng, b, dims)
         Random.rand!(rng::AbstractRNG, A::AbstractArray{<:BLRFunctionSample}, b::BLRLike) = BLRMI355X.rand!(rng, A, b)
     end

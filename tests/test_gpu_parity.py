@@ -1523,6 +1523,17 @@ def test_update_factor_leaves_the_state_alone_on_failure(B, route, monkeypatch):
     torch.cuda.synchronize()
     assert info.item() == 3 and np.isnan(lp.item())  # reference :79: PosDefException at the third variance
     assert torch.equal(Td, T0) and torch.equal(mwd, m0)
+    # a state that is not a Cholesky factor (non-positive diagonal entry) is reported with the SAME code by both routes --
+    # the 1-based index of the entry -- and wins over a bad variance (the reference factors the prior, :78, before the noise, :79)
+    Tbad = T0.clone()
+    Tbad[5, 5] = -2.0
+    Tb0 = Tbad.clone()
+    torch.cuda.synchronize()
+    h.update_factor(np.float64, a.MEM_DEVICE, a.LAYOUT_COLVECS, 1, D, k, Xd.data_ptr(), D, 0, yd.data_ptr(), 0, a.NOISE_DIAGONAL,
+                    sd.data_ptr(), 0, mwd.data_ptr(), 0, Tbad.data_ptr(), D, 0, lp.data_ptr(), info.data_ptr())
+    torch.cuda.synchronize()
+    assert info.item() == 6 and np.isnan(lp.item())
+    assert torch.equal(Tbad, Tb0) and torch.equal(mwd, m0)
     st = B.ResidentPosterior(B.BayesianLinearRegressor(np.zeros(3), B.Diagonal(np.ones(3))))
     with pytest.raises(B.PosDefException):
         st.condition(np.ones((3, 2)), np.array([1.0, 0.0]), np.zeros(2))
@@ -1777,3 +1788,82 @@ def test_posterior_nsharded_one_call(B, with_comm, D, N, dtype):
             h.comm_destroy()
     finally:
         h.close()
+
+
+# ---- reverse-mode rule of rand (README.md:56-60) and blr_apply_weights_* --------------------------------------------------------
+@pytest.mark.parametrize("dtype", [np.float64, np.float32])
+@pytest.mark.parametrize("layout", ["colvecs", "rowvecs"])
+@pytest.mark.parametrize("D,N,S", [(2, 10, 5), (7, 13, 3), (128, 300, 64), (300, 77, 9)])
+def test_apply_weights_vs_oracle(B, dtype, layout, D, N, S):
+    # Y = X'W for S given weight vectors: evaluation of function samples, reference sampling_functions.jl:16-18
+    a = B._abi
+    rng = _rng(31000 + D + N)
+    X = rng.standard_normal((D, N)).astype(dtype)
+    W = np.asfortranarray(rng.standard_normal((D, S)).astype(dtype))
+    Y = np.full((N, S), np.nan, dtype=dtype, order="F")
+    if layout == "colvecs":
+        Xa, lay, ldx = np.asfortranarray(X), a.LAYOUT_COLVECS, D
+    else:
+        Xa, lay, ldx = np.asfortranarray(X.T), a.LAYOUT_ROWVECS, N
+    a.default_handle().apply_weights(dtype, a.MEM_HOST, lay, D, N, S, Xa, ldx, W, D, Y, N)
+    ref = X.astype(np.float64).T @ W.astype(np.float64)
+    tol = 1e-13 if dtype == np.float64 else 4 * np.finfo(np.float32).eps
+    assert np.max(np.abs(Y - ref)) <= tol * np.sqrt(D) * np.max(np.abs(ref))
+
+
+@pytest.mark.parametrize("prior", ["diagonal", "dense", "factor"])
+@pytest.mark.parametrize("container", ["colvecs", "rowvecs"])
+@pytest.mark.parametrize("noise", ["diagonal", "isotropic"])
+def test_rand_pullback_vs_oracle(B, prior, container, noise):
+    rng = _rng(32000)
+    N, D, S = 40, 9, 6
+    X, mw, Lw, s = O.generate_toy_problem(rng, N, D, dense_noise_cov=False)
+    if noise == "isotropic":
+        s = np.float64(0.37)
+    if prior == "diagonal":
+        Lw_o = np.exp(0.3 * rng.standard_normal(D))
+        Lw_b = B.Diagonal(Lw_o)
+    elif prior == "dense":
+        Lw_o, Lw_b = Lw, Lw
+    else:
+        U = O.chol_upper(Lw)
+        Lw_o, Lw_b = U.T @ U, B.PDMat(U)
+    x = B.ColVecs(np.asfortranarray(X)) if container == "colvecs" else B.RowVecs(np.ascontiguousarray(X.T))
+    fx = B.BayesianLinearRegressor(mw, Lw_b)(x, B.Diagonal(s) if noise == "diagonal" else float(s))
+    state = rng.bit_generator.state
+    Y, pb = B.rand_and_pullback(rng, fx, S)
+    rng.bit_generator.state = state
+    Z1 = rng.standard_normal((S, D)).T  # the draws rand_and_pullback made, in the reference's order (:51 then :52), filled
+    Z2 = rng.standard_normal((S, N)).T  # column by column like Julia's randn(rng, D, S)
+    s_vec = np.broadcast_to(np.asarray(s, dtype=float), (N,))
+    np.testing.assert_allclose(Y, O.rand(mw, Lw_o, X, s_vec, Z1, Z2), rtol=1e-10, atol=1e-11)
+    Yb = rng.standard_normal((N, S))
+    g = pb(Yb)
+    go = O.rand_pullback(mw, Lw_o, X, s_vec, Z1, Yb)
+    gX = g["X"] if container == "colvecs" else g["X"].T
+    np.testing.assert_allclose(gX, go["X"], rtol=1e-9, atol=1e-10)
+    np.testing.assert_allclose(g["mw"], go["mw"], rtol=1e-9, atol=1e-10)
+    np.testing.assert_allclose(g["Lw"], go["U"] if prior == "factor" else go["Lw"], rtol=1e-8, atol=1e-10)
+    sb = np.sum(Yb * Z2, axis=1) / (2 * np.sqrt(s_vec))
+    np.testing.assert_allclose(g["noise"], sb if noise == "diagonal" else sb.sum(), rtol=1e-10)
+
+
+def test_evaluate_function_samples_in_one_pass(B):
+    # reference sampling_functions.jl:16-18 for a batch of samples: column j == samples[j](X), through a basis too
+    rng = _rng(33000)
+    D, N = 6, 50
+    X = rng.standard_normal((D, N))
+    f = B.BayesianLinearRegressor(rng.standard_normal(D), B.Diagonal(np.exp(rng.standard_normal(D))))
+    smp = B.rand(rng, f, 4)
+    Y = B.evaluate(smp, B.ColVecs(np.asfortranarray(X)))
+    assert Y.shape == (N, 4)
+    for j in range(4):
+        np.testing.assert_allclose(Y[:, j], X.T @ smp[j].w, rtol=1e-12, atol=1e-13)
+        np.testing.assert_allclose(Y[:, j], smp[j](B.ColVecs(np.asfortranarray(X))), rtol=1e-12, atol=1e-13)
+    phi = lambda x: B.ColVecs(np.asfortranarray(np.vstack([x.X, x.X ** 2])))
+    bfr = B.BasisFunctionRegressor(B.BayesianLinearRegressor(np.zeros(2 * D), B.Diagonal(np.ones(2 * D))), phi)
+    smp = B.rand(rng, bfr, (2, 3))
+    Y = B.evaluate(smp, B.ColVecs(np.asfortranarray(X)))
+    flat = smp.reshape(-1, order="F")
+    for j in range(6):
+        np.testing.assert_allclose(Y[:, j], np.vstack([X, X ** 2]).T @ flat[j].w, rtol=1e-12, atol=1e-12)

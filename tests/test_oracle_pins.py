@@ -205,3 +205,42 @@ def test_closed_form_gradient_matches_finite_differences():
     lp2, g2 = O.logpdf_grad(mw, Lw, X, np.float64(0.3), y)
     d_iso = (O.logpdf_literal(mw, Lw, X, np.float64(0.3 + 1e-6), y) - O.logpdf_literal(mw, Lw, X, np.float64(0.3 - 1e-6), y)) / 2e-6
     assert np.sum(g2["s"]) == pytest.approx(d_iso, rel=1e-6)
+
+
+def test_rand_pullback_matches_finite_differences():
+    """The reverse-mode rule of rand (oracle.rand_pullback; what Zygote derives through src/bayesian_linear_regression.jl:49-53 in
+    README.md:56-60) against central differences of the LITERAL rand with the draws held fixed: dense, PDMat-factor and diagonal
+    prior precision."""
+    rng = np.random.default_rng(78)
+    N, D, S = 9, 5, 3
+    X, mw, Lw, s = O.generate_toy_problem(rng, N, D, dense_noise_cov=False)
+    Z1, Z2, Yb = rng.standard_normal((D, S)), rng.standard_normal((N, S)), rng.standard_normal((N, S))
+    f = lambda mw_, Lw_, X_: float(np.sum(Yb * O.rand(mw_, Lw_, X_, s, Z1, Z2)))
+
+    def fd(fun, x0, eps=1e-6):
+        out = np.zeros_like(x0)
+        it = np.nditer(x0, flags=["multi_index"])
+        for _ in it:
+            i = it.multi_index
+            xp, xm = x0.copy(), x0.copy()
+            xp[i] += eps
+            xm[i] -= eps
+            out[i] = (fun(xp) - fun(xm)) / (2 * eps)
+        return out
+
+    tol = dict(rtol=1e-6, atol=1e-6)
+    g = O.rand_pullback(mw, Lw, X, s, Z1, Yb)
+    np.testing.assert_allclose(g["X"], fd(lambda v: f(mw, Lw, v), X), **tol)
+    np.testing.assert_allclose(g["mw"], fd(lambda v: f(v, Lw, X), mw), **tol)
+    np.testing.assert_allclose(g["Lw"], fd(lambda v: f(mw, 0.5 * (v + v.T), X), Lw), rtol=1e-5, atol=1e-6)  # symmetric perturbations
+    # the factor tangent (PDMat prior: what flows into chol.factors): perturb U itself, Lw = U'U
+    U = O.chol_upper(Lw)
+    gU = fd(lambda v: f(mw, np.triu(v).T @ np.triu(v), X), U)
+    np.testing.assert_allclose(g["U"], np.triu(gU), rtol=1e-5, atol=1e-6)
+    # diagonal precision
+    d = np.exp(0.3 * rng.standard_normal(D))
+    gd = O.rand_pullback(mw, d, X, s, Z1, Yb)
+    np.testing.assert_allclose(gd["Lw"], fd(lambda v: f(mw, v, X), d), **tol)
+    # noise: sbar_n = sum_s Ybar[n, s] Z2[n, s] / (2 sqrt(s_n))
+    fs = lambda v: float(np.sum(Yb * O.rand(mw, Lw, X, v, Z1, Z2)))
+    np.testing.assert_allclose(np.sum(Yb * Z2, axis=1) / (2 * np.sqrt(s)), fd(fs, s), **tol)
