@@ -430,7 +430,8 @@ int posterior_large_one(blr_handle* h, const PosteriorArgs<T>& a, int64_t reg) {
   HIP_TRY(h, hipMemcpyAsync(info_chol, info_prior, sizeof(int32_t), hipMemcpyDeviceToDevice, h->stream));
   GramTileArgs<T> g{};
   g.X = X; g.ldx = a.ldx; g.layout = a.layout;
-  g.use_dma = (a.layout == LAYOUT_COLVECS && ((uintptr_t)X % 16 == 0) && ((a.ldx * (int64_t)sizeof(T)) % 16 == 0)) ? 1 : 0;
+  static const bool no_ring = getenv("BLR_MI355X_NO_GRAM_RING") != nullptr;  // A/B experiments only
+  g.use_dma = (a.layout == LAYOUT_COLVECS && ((uintptr_t)X % 16 == 0) && ((a.ldx * (int64_t)sizeof(T)) % 16 == 0)) ? (no_ring ? 2 : 1) : 0;
   g.s = s; g.noise_kind = a.noise_kind; g.r = rvec;
   g.D = D; g.n_begin = 0; g.n_end = N; g.nblocks = NC; g.bpart = bpart; g.mode_out = 0;
   static const bool no_swizzle = getenv("BLR_MI355X_NO_XCD_SWIZZLE") != nullptr;

@@ -86,12 +86,21 @@ __device__ unsigned long long g_gstamps[4][8];
   } while (0)
 __device__ unsigned long long g_pstamps[16];  // per-phase cycle sums of workgroup 0 (fused_small_kernel), [15] = regressors
 #define BLR_PSTAMP_INIT unsigned long long pstamp_prev = __builtin_amdgcn_s_memtime()
+#ifdef BLR_PSTAMP_ALL  /* every workgroup, atomically */
+#define BLR_PSTAMP(slot)                                                                   \
+  do {                                                                                     \
+    unsigned long long t__ = __builtin_amdgcn_s_memtime();                                 \
+    if (threadIdx.x == 0) atomicAdd(&g_pstamps[slot], t__ - pstamp_prev);                  \
+    pstamp_prev = t__;                                                                     \
+  } while (0)
+#else
 #define BLR_PSTAMP(slot)                                                                   \
   do {                                                                                     \
     unsigned long long t__ = __builtin_amdgcn_s_memtime();                                 \
     if (blockIdx.x == 0 && threadIdx.x == 0) g_pstamps[slot] += t__ - pstamp_prev;         \
     pstamp_prev = t__;                                                                     \
   } while (0)
+#endif
 #else
 #define BLR_GSTAMP_INIT do {} while (0)
 #define BLR_GSTAMP(slot) do {} while (0)
@@ -669,11 +678,17 @@ __device__ __forceinline__ void kstep_ring(AccArr<T, 8>& acc, const KF8<T, WS>& 
 #undef BLR_IC
 }
 
-template <typename T, int WS, bool MWZ>
+// NH = ring slots: 4 (the pipeline described above) or 3 (48 KB: half h+2 is issued during half h into the slot the barrier at
+// the end of half h-1 freed, and must have landed by the end of half h -- enough when three workgroups share the CU and a
+// half lasts three times as long)
+template <typename T, int WS, bool MWZ, int NH = 4>
 __device__ __forceinline__ void gram_iso_ring(T* __restrict__ ring, T* __restrict__ ybuf, const BLR_GLOBAL T* X /*uniform*/,
                                               const BLR_GLOBAL T* y /*uniform*/, int64_t ldx, int N, unsigned voff, int lane,
                                               AccArr<T, 8>& acc, double (&bacc)[8], double& qacc, const T (&mwf)[8], T wiso) {
+  static_assert(NH == 3 || NH == 4, "ring depth");
   constexpr int NB = 8, HK = 4;
+  constexpr int LA = NH - 1;                           // issue distance in halves
+  auto slot_of = [](int h) { return NH == 4 ? (h & 3) : (h % 3); };
   constexpr int HALF = HK * NB * 64;                   // elements per half
   constexpr int HC = 4 * HK;                           // columns per half
   constexpr int FPG = (1024 / (int)sizeof(T)) / 64;    // fragments per 1 KiB piece
@@ -689,14 +704,14 @@ __device__ __forceinline__ void gram_iso_ring(T* __restrict__ ring, T* __restric
     constexpr int g = p * kWaves + WS, j = (g * FPG) / NB, I0 = (g * FPG) % NB;
     const uint64_t saddr = (uint64_t)(uintptr_t)X + (uint64_t)(((int64_t)(h * HC + 4 * j) * ldx + 16 * I0) * (int64_t)sizeof(T));
 #ifndef RING_NODMA
-    glds_s<16>(uni((int64_t)saddr), voff, ring_addr + (unsigned)((h & 3) * HALF * (int)sizeof(T) + g * 1024));
+    glds_s<16>(uni((int64_t)saddr), voff, ring_addr + (unsigned)(slot_of(h) * HALF * (int)sizeof(T) + g * 1024));
 #endif
   };
   auto issue_y = [&](int h) {
 #ifndef RING_NODMA
     if constexpr (WS == 0)
       glds_s<4, YL>(uni((int64_t)(uintptr_t)(y + (int64_t)h * HC)), (unsigned)(lane * 4),
-                    ybuf_addr + (unsigned)((h & 3) * HC * (int)sizeof(T)));
+                    ybuf_addr + (unsigned)(slot_of(h) * HC * (int)sizeof(T)));
 #endif
   };
   auto issue_half = [&](int h) {
@@ -713,9 +728,9 @@ __device__ __forceinline__ void gram_iso_ring(T* __restrict__ ring, T* __restric
     else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
 #endif
   };
-  for (int h = 0; h < 3 && h < nh; ++h) issue_half(h);
-  retire(nh > 2 ? 1 : 0);  // halves 0 and 1 landed (this wave's pieces) ...
-  __syncthreads();         // ... and everybody's: visible
+  for (int h = 0; h < LA && h < nh; ++h) issue_half(h);
+  retire((NH == 4 && nh > 2) ? 1 : 0);  // halves 0 and 1 landed (this wave's pieces) ...
+  __syncthreads();                      // ... and everybody's: visible
   KF8<T, WS> f0, f1;
   load_kf8<T, WS, true>(f0, ring, ybuf, ybuf, 0, lane);
   __builtin_amdgcn_sched_barrier(0);
@@ -723,13 +738,13 @@ __device__ __forceinline__ void gram_iso_ring(T* __restrict__ ring, T* __restric
 #pragma unroll 1
   for (int h = 0; h < nh; ++h) {
     // here: halves h and h+1 are visible, f0 holds the fragments of (h, k-step 0), half h+2 is landing
-    const T* slot = ring + (h & 3) * HALF;
-    const T* yb = ybuf + (h & 3) * HC;
-    const T* slot_n = ring + ((h + 1) & 3) * HALF;
-    const T* yb_n = ybuf + ((h + 1) & 3) * HC;
-    const bool more = h + 3 < nh;  // slot (h+3) % 4 was freed by the barrier that ended half h-1
-    // all pieces of half h+3 in ONE burst inside k-step 0 (back to back they cost ~46 cycles each, one at a time ~100)
-    auto pall = [&] { if (more) issue_half(h + 3); };
+    const T* slot = ring + slot_of(h) * HALF;
+    const T* yb = ybuf + slot_of(h) * HC;
+    const T* slot_n = ring + slot_of(h + 1) * HALF;
+    const T* yb_n = ybuf + slot_of(h + 1) * HC;
+    const bool more = h + LA < nh;  // slot (h + LA) % NH was freed by the barrier that ended half h-1
+    // all pieces of half h+LA in ONE burst inside k-step 0 (back to back they cost ~46 cycles each, one at a time ~100)
+    auto pall = [&] { if (more) issue_half(h + LA); };
     kstep_ring<T, WS, MWZ, 0, 1>(acc, f0, f1, slot + 1 * NB * 64, yb, wiso, mwf, bacc, qacc, lane, pall, none);
     kstep_ring<T, WS, MWZ, 1, 2>(acc, f1, f0, slot + 2 * NB * 64, yb, wiso, mwf, bacc, qacc, lane, none, none);
     kstep_ring<T, WS, MWZ, 2, 3>(acc, f0, f1, slot + 3 * NB * 64, yb, wiso, mwf, bacc, qacc, lane, none, none);
@@ -737,7 +752,7 @@ __device__ __forceinline__ void gram_iso_ring(T* __restrict__ ring, T* __restric
     kstep_ring<T, WS, MWZ, 3, 0>(acc, f1, f0, slot_n, yb_n, wiso, mwf, bacc, qacc, lane, none, none);
     // ---- end of half h: publish half h+2 (its pieces were issued during half h-1), free the slot of half h
     if (h + 1 < nh) {
-      if (h + 2 < nh) retire(more ? 1 : 0);
+      if (h + 2 < nh) retire((NH == 4 && more) ? 1 : 0);
 #ifndef RING_NOBAR
       __syncthreads();
 #endif
@@ -1461,7 +1476,11 @@ __global__ __launch_bounds__(kThreads, (NB <= 4 ? 4 : (sizeof(T) == 4 ? BLR_F32_
     }
     BLR_PSTAMP(6);
 #ifdef BLR_GRAM_STAMPS
+#ifdef BLR_PSTAMP_ALL
+    if (tid == 0) atomicAdd(&g_pstamps[15], 1ull);
+#else
     if (blockIdx.x == 0 && tid == 0) g_pstamps[15] += 1;
+#endif
 #endif
   }
 }

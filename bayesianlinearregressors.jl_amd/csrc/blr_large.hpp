@@ -158,11 +158,191 @@ __global__ __launch_bounds__(kThreads) void colstats_kernel(ColstatsArgs<T> a) {
 // ---- 128 x 128 macro tile of a (weighted) Gram matrix ---------------------------------------------------------
 // mode_out 0: write the tile (and, for diagonal tiles with r != NULL, b_I) to the split-partial workspace
 // mode_out 1: subtract the tile in place from C (trailing update of the blocked Cholesky; single split)
+// ---- f32, full off-diagonal macro tile, LDS-DMA: the ring loop of the D = 128 kernel (gram_iso_ring) carried over ----------
+// The stage loop of gram_tile_kernel waits vmcnt(0) + s_barrier once per 8 k-steps, issues the next stage's 8 LDS-DMA pieces per
+// wave in one go right behind the barrier and leaves the order of fragment reads and MFMAs to hipcc: 68 % of the f32 matrix
+// peak on the tiles it computes (config 3, PMC: SQ_VALU_MFMA_BUSY 69 %).  Here the 64 KB staging area is a ring of FOUR
+// half-stages (4 k-steps = 16 columns, A side + B side 16 KB); while half h computes, half h+1 is visible, h+2 is landing and
+// the four pieces (+ the weights piece of wave 0) of half h+3 are issued in one burst from inline asm; arrival is a counted
+// s_waitcnt vmcnt(n) at the END of a half, one barrier per half.  Inside a k-step the order is pinned with sched_barrier: the
+// 9 fragment reads of the NEXT k-step and the DMA burst sit between the 16 MFMAs of this one.
+template <typename T>
+struct GFrag {
+  T a[4], b[4];
+};
+
+// one k-step: the 16 MFMAs of `fc` (A side scaled by w: Sigma_y^-1 of this lane's column, 1 when SCALE is off) with the reads of
+// the next k-step's fragments and one slot of side work (`side`: LDS-DMA pieces, weight reads / reciprocals) between them
+template <typename T, bool SCALE, typename P>
+__device__ __forceinline__ void gram_kstep_ring(typename Mfma<T>::acc4 (&acc)[4][4], const GFrag<T>& fc, GFrag<T>& fn, T w,
+                                                const T* __restrict__ kA_n, const T* __restrict__ kB_n, P side) {
+  T fa[4];
+#pragma unroll
+  for (int i = 0; i < 4; ++i) fa[i] = SCALE ? fc.a[i] * w : fc.a[i];  // Sigma_y^-1 on the A side only
+  auto mma = [&](auto mtag) {
+    constexpr int m = decltype(mtag)::value;
+    acc[m >> 2][m & 3] = Mfma<T>::mma(fa[m >> 2], fc.b[m & 3], acc[m >> 2][m & 3]);
+  };
+#define BLR_SB __builtin_amdgcn_sched_barrier(0)
+#define BLR_IC(k) std::integral_constant<int, k>{}
+  BLR_SB; mma(BLR_IC(0)); BLR_SB;
+  fn.a[0] = kA_n[0]; fn.a[1] = kA_n[64];
+  BLR_SB; mma(BLR_IC(1)); BLR_SB;
+  fn.a[2] = kA_n[128]; fn.a[3] = kA_n[192];
+  BLR_SB; mma(BLR_IC(2)); BLR_SB;
+  fn.b[0] = kB_n[0]; fn.b[1] = kB_n[64];
+  BLR_SB; mma(BLR_IC(3)); BLR_SB;
+  fn.b[2] = kB_n[128]; fn.b[3] = kB_n[192];
+  BLR_SB; mma(BLR_IC(4)); BLR_SB;
+  side();
+  BLR_SB; mma(BLR_IC(5)); BLR_SB; mma(BLR_IC(6)); BLR_SB; mma(BLR_IC(7)); BLR_SB;
+  mma(BLR_IC(8)); BLR_SB; mma(BLR_IC(9)); BLR_SB; mma(BLR_IC(10)); BLR_SB; mma(BLR_IC(11)); BLR_SB;
+  mma(BLR_IC(12)); BLR_SB; mma(BLR_IC(13)); BLR_SB; mma(BLR_IC(14)); BLR_SB; mma(BLR_IC(15)); BLR_SB;
+#undef BLR_SB
+#undef BLR_IC
+}
+
+// columns [c0, c0 + 16 nh) of the operand rows rowA.. (A side) and rowB.. (B side); baseA / baseB point at (row, column 0).
+// DIAGT: diagonal macro tile -- one side only (B = A), and the wave of the quadrant above the diagonal (wr = 0, wc = 1), whose
+// tiles nobody reads, leaves the matrix pipe alone and accumulates b_I = X_I r instead (r != NULL) while it keeps taking part
+// in the DMA issue and the barriers.
+template <typename T, bool SCALE, bool DIAGT>
+__device__ __forceinline__ void gram_ring_loop(T* __restrict__ ring, T* __restrict__ wring, T* __restrict__ rring,
+                                               const BLR_GLOBAL T* baseA, int64_t ldA, const BLR_GLOBAL T* baseB, int64_t ldB,
+                                               const BLR_GLOBAL T* s /* + c0; SCALE */, const BLR_GLOBAL T* r /* + c0 or NULL; DIAGT */,
+                                               int c0, int nh, unsigned voffA, unsigned voffB, int lane, int wave /*uniform*/,
+                                               typename Mfma<T>::acc4 (&acc)[4][4], double (&bacc)[8]) {
+  static_assert(sizeof(T) == 4, "four halves of 16 KB: f32 only");
+  constexpr int SIDE = 4 * 8 * 64;                   // elements of one side of a half
+  constexpr int HALF = 2 * SIDE;
+  constexpr int HC = 16;                             // columns per half
+  const int wr = wave >> 1, wc = wave & 1;
+  unsigned ring_addr = lds_addr_of(ring), wring_addr = lds_addr_of(wring), rring_addr = lds_addr_of(rring);
+  asm volatile("" : "+v"(ring_addr), "+v"(wring_addr), "+v"(rring_addr));  // pinned in VGPRs (see gram_iso_ring)
+  const bool w_piece = SCALE && wave == 0;
+  const bool b_wave = DIAGT && wave == 1;            // the idle quadrant's wave
+  const bool r_piece = b_wave && r != nullptr;
+  const int npieces = 2 + (DIAGT ? 0 : 2) + (w_piece ? 1 : 0) + (r_piece ? 1 : 0);  // LDS-DMA instructions of this wave per half
+  // this wave's pieces of a half: g = wave (k-step wave / 2, row blocks 4 (wave & 1) ..) and g = 4 + wave, on both sides.  Their
+  // global addresses advance by 16 columns per half: 64-bit scalar adds, no multiplications in the loop
+  const int jp = wave >> 1, I0 = 4 * (wave & 1);
+  uint64_t nextA = (uint64_t)(uintptr_t)baseA + (uint64_t)(((int64_t)(c0 + 4 * jp) * ldA + 16 * I0) * (int64_t)sizeof(T));
+  uint64_t nextB = (uint64_t)(uintptr_t)baseB + (uint64_t)(((int64_t)(c0 + 4 * jp) * ldB + 16 * I0) * (int64_t)sizeof(T));
+  uint64_t nextS = (uint64_t)(uintptr_t)s, nextR = (uint64_t)(uintptr_t)r;
+  const uint64_t stepA = (uint64_t)(16 * ldA * (int64_t)sizeof(T)), stepB = (uint64_t)(16 * ldB * (int64_t)sizeof(T));
+  const uint64_t p1A = (uint64_t)(8 * ldA * (int64_t)sizeof(T)), p1B = (uint64_t)(8 * ldB * (int64_t)sizeof(T));  // g + 4: two k-steps on
+  int hi = 0;  // half the next issue belongs to
+  auto issue_first = [&]() {   // pieces g = wave of both sides (+ the variances / the residuals)
+    const unsigned slot = ring_addr + (unsigned)((hi & 3) * HALF * (int)sizeof(T) + wave * 1024);
+    glds_s<16>(uni((int64_t)nextA), voffA, slot);
+    if constexpr (!DIAGT) glds_s<16>(uni((int64_t)nextB), voffB, slot + (unsigned)(SIDE * (int)sizeof(T)));
+    if constexpr (SCALE) {
+      if (w_piece)  // the 16 raw variances of the half: one dword piece
+        glds_s<4, 16>(uni((int64_t)nextS), (unsigned)(lane * 4), wring_addr + (unsigned)((hi & 3) * HC * (int)sizeof(T)));
+    }
+    if constexpr (DIAGT) {
+      if (r_piece) glds_s<4, 16>(uni((int64_t)nextR), (unsigned)(lane * 4), rring_addr + (unsigned)((hi & 3) * HC * (int)sizeof(T)));
+    }
+  };
+  auto issue_second = [&]() {  // pieces g = 4 + wave, then on to the next half
+    const unsigned slot = ring_addr + (unsigned)((hi & 3) * HALF * (int)sizeof(T) + (4 + wave) * 1024);
+    glds_s<16>(uni((int64_t)(nextA + p1A)), voffA, slot);
+    if constexpr (!DIAGT) glds_s<16>(uni((int64_t)(nextB + p1B)), voffB, slot + (unsigned)(SIDE * (int)sizeof(T)));
+    nextA += stepA; nextB += stepB; nextS += HC * sizeof(T); nextR += HC * sizeof(T);
+    ++hi;
+  };
+  auto retire = [&](bool keep_one) {  // wait for everything but the youngest half of this wave's pieces
+    if (!keep_one) { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); return; }
+    switch (npieces) {  // wave-uniform
+      case 2: asm volatile("s_waitcnt vmcnt(2)" ::: "memory"); break;
+      case 3: asm volatile("s_waitcnt vmcnt(3)" ::: "memory"); break;
+      case 4: asm volatile("s_waitcnt vmcnt(4)" ::: "memory"); break;
+      default: asm volatile("s_waitcnt vmcnt(5)" ::: "memory"); break;
+    }
+  };
+  for (int h = 0; h < 3 && h < nh; ++h) { issue_first(); issue_second(); }
+  retire(nh > 2);
+  __syncthreads();
+  if (b_wave) {
+    // no MFMAs for this wave: per k-step 8 fragment reads and 8 f64 FMAs of the b partials (or nothing), DMA issue, barriers
+#pragma unroll 1
+    for (int h = 0; h < nh; ++h) {
+      const T* slot = ring + (h & 3) * HALF;
+      const T* rb = rring + (h & 3) * HC + (lane >> 4);
+      if (h + 3 < nh) { issue_first(); issue_second(); }
+      if (r != nullptr) {
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+          const T rn = rb[4 * j];
+#pragma unroll
+          for (int i = 0; i < 8; ++i) bacc[i] += (double)slot[(j * 8 + i) * 64 + lane] * (double)rn;
+        }
+      }
+      if (h + 1 < nh) {
+        if (h + 2 < nh) retire(h + 3 < nh);
+        __syncthreads();
+      }
+    }
+    return;
+  }
+  GFrag<T> f0, f1;
+  // weights of this lane's column in the four k-steps of the current half (wcur) and of the next one (wnxt): every wave turns
+  // the raw variances into reciprocals itself, half a stage ahead of their use, off the MFMA issue path
+  T wcur[4] = {T(1), T(1), T(1), T(1)}, wnxt[4] = {T(1), T(1), T(1), T(1)};
+  const int offB = DIAGT ? 0 : SIDE;  // diagonal tile: both operands come from the one side
+  {
+    const T* kA = ring + (4 * wr) * 64 + lane;
+    const T* kB = ring + offB + (4 * wc) * 64 + lane;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) { f0.a[i] = kA[i * 64]; f0.b[i] = kB[i * 64]; }
+    if constexpr (SCALE) {
+#pragma unroll
+      for (int j = 0; j < 4; ++j) wcur[j] = fast_rcp(wring[4 * j + (lane >> 4)]);
+    }
+  }
+  __builtin_amdgcn_sched_barrier(0);
+#pragma unroll 1
+  for (int h = 0; h < nh; ++h) {
+    // here: halves h and h+1 are visible, f0 = fragments of (h, k-step 0), half h+2 is landing
+    const T* slot = ring + (h & 3) * HALF;
+    const T* slot_n = ring + ((h + 1) & 3) * HALF;
+    const T* kA = slot + (4 * wr) * 64 + lane;
+    const T* kB = slot + offB + (4 * wc) * 64 + lane;
+    const T* wv_n = wring + ((h + 1) & 3) * HC + (lane >> 4);
+    const bool more = h + 3 < nh;  // slot (h + 3) % 4 was freed by the barrier that ended half h-1
+    auto side0 = [&] { if (more) issue_first(); };
+    auto side1 = [&] { if (more) issue_second(); };
+    auto side2 = [&] {
+      if constexpr (SCALE) {
+#pragma unroll
+        for (int j = 0; j < 4; ++j) wnxt[j] = wv_n[4 * j];  // raw variances of half h+1 (visible since the last barrier)
+      }
+    };
+    auto side3 = [&] {
+      if constexpr (SCALE) {
+#pragma unroll
+        for (int j = 0; j < 4; ++j) wnxt[j] = fast_rcp(wnxt[j]);
+      }
+    };
+    gram_kstep_ring<T, SCALE>(acc, f0, f1, wcur[0], kA + 1 * 512, kB + 1 * 512, side0);
+    gram_kstep_ring<T, SCALE>(acc, f1, f0, wcur[1], kA + 2 * 512, kB + 2 * 512, side1);
+    gram_kstep_ring<T, SCALE>(acc, f0, f1, wcur[2], kA + 3 * 512, kB + 3 * 512, side2);
+    gram_kstep_ring<T, SCALE>(acc, f1, f0, wcur[3], slot_n + (4 * wr) * 64 + lane, slot_n + offB + (4 * wc) * 64 + lane, side3);
+#pragma unroll
+    for (int j = 0; j < 4; ++j) wcur[j] = wnxt[j];
+    // ---- end of half h: publish half h+2, free the slot of half h
+    if (h + 1 < nh) {
+      if (h + 2 < nh) retire(more);
+      __syncthreads();
+    }
+  }
+}
+
 template <typename T>
 struct GramTileArgs {
   const T* X; int64_t ldx;   // operand matrix; element (d, n) at X[d + n*ldx] (ColVecs) or X[n + d*ldx] (RowVecs)
   int layout;                // LAYOUT_COLVECS / LAYOUT_ROWVECS / 2 = upper factor as pseudo-columns (mask n <= d)
-  int use_dma;               // ColVecs, 16-byte aligned: LDS-DMA staging
+  int use_dma;               // ColVecs, 16-byte aligned: LDS-DMA staging (1: + the ring loop for full off-diagonal f32 tiles, 2: stage loop only)
   const T* s; int noise_kind;  // weights w_n = 1/s_n; s == NULL: w = 1
   const T* r;                // delta_n / s_n for the b partials (NULL: skip)
   int D;                     // rows of the operand
@@ -322,9 +502,43 @@ __global__ __launch_bounds__(kThreads, (sizeof(T) == 4 ? BLR_GRAM_WGS : 2)) void
     load_scalars(st + 1);  // in flight until the next issue()
   };
 
+  bool ring_done = false;
+  if constexpr (sizeof(T) == 4) {
+    // full macro tiles through the ring loop (gram_ring_loop); everything else -- partial tiles, ragged column ranges,
+    // register staging, f64 -- stays on the stage loop below
+    const int ncol = c1 - c0;
+    const bool ring_ok = a.use_dma == 1 && ncol >= 16 && (ncol & 15) == 0 && min(kPB, a.D - rowA) == kPB &&
+                         (diag_tile || min(kPB, rowsB - rowB) == kPB) && (3 * a.ldx + 64) * (int64_t)sizeof(T) < ((int64_t)1 << 31) &&
+                         (3 * ldB + 64) * (int64_t)sizeof(T) < ((int64_t)1 << 31);
+    if (ring_ok) {  // block-uniform
+      const BLR_GLOBAL T* bA = as_global(a.X + rowA);
+      const BLR_GLOBAL T* bB = as_global(baseB + rowB);
+      const bool scale = a.s != nullptr && diag_noise;
+      const BLR_GLOBAL T* sp = scale ? as_global(a.s + c0) : (const BLR_GLOBAL T*)nullptr;
+      const BLR_GLOBAL T* rp = want_b ? as_global(a.r + c0) : (const BLR_GLOBAL T*)nullptr;
+      const int nh = ncol >> 4;
+      if (diag_tile) {
+        if (scale) gram_ring_loop<T, true, true>(slot0, wbuf, rbuf, bA, a.ldx, bB, ldB, sp, rp, c0, nh, voffA, voffB, lane, wave, acc, bacc);
+        else gram_ring_loop<T, false, true>(slot0, wbuf, rbuf, bA, a.ldx, bB, ldB, sp, rp, c0, nh, voffA, voffB, lane, wave, acc, bacc);
+      } else {
+        if (scale) gram_ring_loop<T, true, false>(slot0, wbuf, rbuf, bA, a.ldx, bB, ldB, sp, rp, c0, nh, voffA, voffB, lane, wave, acc, bacc);
+        else gram_ring_loop<T, false, false>(slot0, wbuf, rbuf, bA, a.ldx, bB, ldB, sp, rp, c0, nh, voffA, voffB, lane, wave, acc, bacc);
+      }
+      if (a.s != nullptr && !diag_noise) {  // isotropic noise: applied once to the finished tile
+        const T wi = T(1) / s_iso;
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+#pragma unroll
+          for (int k = 0; k < 4; ++k)
+#pragma unroll
+            for (int v = 0; v < 4; ++v) acc[i][k][v] *= wi;
+      }
+      ring_done = true;
+    }
+  }
   load_scalars(0);
-  if (nstages > 0) issue(0);
-  for (int st = 0; st < nstages; ++st) {
+  if (nstages > 0 && !ring_done) issue(0);
+  for (int st = 0; st < (ring_done ? 0 : nstages); ++st) {
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
     if (st + 1 < nstages) issue(st + 1);

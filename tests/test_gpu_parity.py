@@ -1867,3 +1867,4 @@ def test_evaluate_function_samples_in_one_pass(B):
     flat = smp.reshape(-1, order="F")
     for j in range(6):
         np.testing.assert_allclose(Y[:, j], np.vstack([X, X ** 2]).T @ flat[j].w, rtol=1e-12, atol=1e-12)
+

@@ -12,6 +12,9 @@
 #ifdef FB_WAVE
 #include "blr_fused_wave.hpp"
 #endif
+#ifdef FB_D128
+#include "blr_fused_d128_experiment.hpp"
+#endif
 using namespace blr;
 #define CK(x) do { hipError_t e_ = (x); if (e_ != hipSuccess) { printf("HIP error %s at %d\n", hipGetErrorString(e_), __LINE__); return 1; } } while (0)
 
@@ -92,7 +95,13 @@ int main(int argc, char** argv) {
   a.mw_post = dmwp; a.stride_mwpost = D; a.T_post = dT; a.ldt = D; a.strideT = D * D; a.Lw_post = nullptr;
   a.logpdf = dlp; a.info = dinfo; a.layout = LAYOUT_COLVECS; a.noise_kind = diag ? NOISE_DIAGONAL : NOISE_ISOTROPIC;
   a.prior_kind = PRIOR_DIAGONAL; a.D = D; a.N = N; a.B = B; a.vec_ok = 1;
-#ifdef FB_WAVE
+#if defined(FB_D128)
+  const int kLds = D128Cfg<T>::LDS_BYTES, kBlock = kThreads, kGrid = std::min(B, getenv("FB_GRID") ? atoi(getenv("FB_GRID")) : 768);
+  T* dscr; CK(hipMalloc((void**)&dscr, (size_t)kGrid * D128Cfg<T>::WG_SCRATCH * sizeof(T)));
+  auto kern = [&](PosteriorArgs<T> aa) {};
+  (void)kern;
+#define FB_LAUNCH() hipLaunchKernelGGL(fused_d128_kernel<T>, dim3(kGrid), dim3(kBlock), kLds, 0, a, dscr)
+#elif defined(FB_WAVE)
   auto kern = fused_wave_kernel<T, NB>;
   const int kLds = WaveCfg<T, NB>::LDS_BYTES, kBlock = 64, kGrid = std::min(B, 2048);
 #else
@@ -100,11 +109,14 @@ int main(int argc, char** argv) {
   const int kLds = C::LDS_BYTES, kBlock = kThreads, kGrid = getenv("FB_GRID") ? atoi(getenv("FB_GRID")) : B;
   CK(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, C::LDS_BYTES));
 #endif
+#ifndef FB_LAUNCH
+#define FB_LAUNCH() hipLaunchKernelGGL(kern, dim3(kGrid), dim3(kBlock), kLds, 0, a)
+#endif
   hipEvent_t e0, e1; CK(hipEventCreate(&e0)); CK(hipEventCreate(&e1));
-  for (int w = 0; w < 2; ++w) hipLaunchKernelGGL(kern, dim3(kGrid), dim3(kBlock), kLds, 0, a);
+  for (int w = 0; w < 2; ++w) FB_LAUNCH();
   CK(hipDeviceSynchronize());
   CK(hipEventRecord(e0));
-  for (int r = 0; r < reps; ++r) hipLaunchKernelGGL(kern, dim3(kGrid), dim3(kBlock), kLds, 0, a);
+  for (int r = 0; r < reps; ++r) FB_LAUNCH();
   CK(hipEventRecord(e1)); CK(hipEventSynchronize(e1));
   float ms; CK(hipEventElapsedTime(&ms, e0, e1));
   ms /= reps;
@@ -114,7 +126,7 @@ int main(int argc, char** argv) {
     CK(hipMemcpyToSymbol(HIP_SYMBOL(g_gstamps), zero, sizeof(zero)));
     unsigned long long zero16[16] = {};
     CK(hipMemcpyToSymbol(HIP_SYMBOL(g_pstamps), zero16, sizeof(zero16)));
-    hipLaunchKernelGGL(kern, dim3(kGrid), dim3(kBlock), kLds, 0, a);
+    FB_LAUNCH();
     CK(hipDeviceSynchronize());
     unsigned long long stp[4][8];
     CK(hipMemcpyFromSymbol(stp, HIP_SYMBOL(g_gstamps), sizeof(stp)));

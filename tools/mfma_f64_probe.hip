@@ -18,7 +18,7 @@ struct Stamp { unsigned long long cyc, rt; };
 constexpr int NACC = 8;
 
 enum { M_VGPR = 0, M_AGPR_ACC = 1, M_NOP = 2, M_ZERO = 3, M_4X4 = 4, M_CHAIN = 5, M_AGPR_AB = 6, M_MIX_F32 = 7, M_MIX_F64 = 8,
-       M_NOP_LONG = 9, M_MIX_F64x4 = 10 };
+       M_NOP_LONG = 9, M_MIX_F64x4 = 10, M_RANDOM = 11 };
 
 template <int MODE>
 __global__ __launch_bounds__(256) void k_probe(double* out, Stamp* st, int iters, double a0, double b0) {
@@ -28,6 +28,16 @@ __global__ __launch_bounds__(256) void k_probe(double* out, Stamp* st, int iters
   for (int i = 0; i < NACC; ++i) sc[i] = 0.0;
   double a = a0 + threadIdx.x * 1e-9, b = b0 - threadIdx.x * 1e-9;
   if (MODE == M_ZERO) { a = 0.0; b = 0.0; }
+  // M_RANDOM: a different uniformly random operand pair per accumulator and lane -- every mantissa bit of the multiplier inputs
+  // toggles from one MFMA to the next (the clock the part holds depends on it: DVFS)
+  double ra[NACC], rb[NACC];
+  for (int i = 0; i < NACC; ++i) {
+    unsigned long long z = ((unsigned long long)(blockIdx.x * blockDim.x + threadIdx.x) * NACC + i + 1) * 0x9E3779B97F4A7C15ull;
+    z ^= z >> 29; z *= 0xBF58476D1CE4E5B9ull; z ^= z >> 32;
+    ra[i] = (double)(long long)(z >> 11) * (1.0 / 4503599627370496.0) - 1.0;
+    z *= 0x94D049BB133111EBull; z ^= z >> 31;
+    rb[i] = (double)(long long)(z >> 11) * (1.0 / 4503599627370496.0) - 1.0;
+  }
   float f[8];
   for (int i = 0; i < 8; ++i) f[i] = (float)threadIdx.x + i;
   double g[8];
@@ -40,6 +50,8 @@ __global__ __launch_bounds__(256) void k_probe(double* out, Stamp* st, int iters
         asm volatile("v_mfma_f64_16x16x4_f64 %0, %1, %2, %0" : "+a"(acc[i]) : "v"(a), "v"(b));
       } else if constexpr (MODE == M_AGPR_AB) {
         asm volatile("v_mfma_f64_16x16x4_f64 %0, %1, %2, %0" : "+v"(acc[i]) : "a"(a), "a"(b));
+      } else if constexpr (MODE == M_RANDOM) {
+        asm volatile("v_mfma_f64_16x16x4_f64 %0, %1, %2, %0" : "+v"(acc[i]) : "v"(ra[i]), "v"(rb[i]));
       } else if constexpr (MODE == M_4X4) {
         sc[i] = __builtin_amdgcn_mfma_f64_4x4x4f64(a, b, sc[i], 0, 0, 0);
       } else if constexpr (MODE == M_CHAIN) {
@@ -117,6 +129,7 @@ int main(int argc, char** argv) {
     run<M_AGPR_ACC>("acc AGPR", g.grid, g.block, iters, buf, st, F16);
     run<M_AGPR_AB>("A/B AGPR, acc VGPR", g.grid, g.block, iters, buf, st, F16);
     run<M_ZERO>("zero operands", g.grid, g.block, iters, buf, st, F16);
+    run<M_RANDOM>("random operands", g.grid, g.block, iters, buf, st, F16);
     run<M_NOP>("+ s_nop 15 per MFMA", g.grid, g.block, iters, buf, st, F16);
     run<M_NOP_LONG>("+ 3 x s_nop 15 per MFMA", g.grid, g.block, iters, buf, st, F16);
     run<M_CHAIN>("dependent chain (1 acc)", g.grid, g.block, iters, buf, st, F16);

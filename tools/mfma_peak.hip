@@ -43,6 +43,31 @@ __global__ __launch_bounds__(256) void k_f32(float* out, Stamp* st, int iters, f
   out[blockIdx.x * blockDim.x + threadIdx.x] = s;
   if (threadIdx.x == 0) { st[blockIdx.x].cyc = c1 - c0; st[blockIdx.x].rt = r1 - r0; }
 }
+// the same f32 loop on RANDOM operands (a different pair per accumulator and lane): the clock the part holds under a matrix
+// load depends on how many datapath bits toggle (DVFS); near-constant operands flatter it
+template <int NACC>
+__global__ __launch_bounds__(256) void k_f32_random(float* out, Stamp* st, int iters) {
+  f4 acc[NACC];
+  float ra[NACC], rb[NACC];
+  for (int i = 0; i < NACC; ++i) {
+    acc[i] = f4{0, 0, 0, 0};
+    unsigned long long z = ((unsigned long long)(blockIdx.x * blockDim.x + threadIdx.x) * NACC + i + 1) * 0x9E3779B97F4A7C15ull;
+    z ^= z >> 29; z *= 0xBF58476D1CE4E5B9ull; z ^= z >> 32;
+    ra[i] = (float)((double)(long long)(z >> 11) * (1.0 / 4503599627370496.0) - 1.0);
+    z *= 0x94D049BB133111EBull; z ^= z >> 31;
+    rb[i] = (float)((double)(long long)(z >> 11) * (1.0 / 4503599627370496.0) - 1.0);
+  }
+  unsigned long long c0 = __builtin_amdgcn_s_memtime(), r0 = __builtin_amdgcn_s_memrealtime();
+  for (int it = 0; it < iters; ++it) {
+#pragma unroll
+    for (int i = 0; i < NACC; ++i) asm volatile("v_mfma_f32_16x16x4_f32 %0, %1, %2, %0" : "+v"(acc[i]) : "v"(ra[i]), "v"(rb[i]));
+  }
+  unsigned long long c1 = __builtin_amdgcn_s_memtime(), r1 = __builtin_amdgcn_s_memrealtime();
+  float s = 0;
+  for (int i = 0; i < NACC; ++i) s += acc[i][0] + acc[i][1] + acc[i][2] + acc[i][3];
+  out[blockIdx.x * blockDim.x + threadIdx.x] = s;
+  if (threadIdx.x == 0) { st[blockIdx.x].cyc = c1 - c0; st[blockIdx.x].rt = r1 - r0; }
+}
 __global__ __launch_bounds__(256) void k_fma64(double* out, Stamp* st, int iters, double a0) {
   double x[16];
   for (int i = 0; i < 16; ++i) x[i] = a0 + i + threadIdx.x;
@@ -96,6 +121,8 @@ int main(int argc, char** argv) {
     char lab[128];
     snprintf(lab, sizeof lab, "f32 mfma 16x16x4, %d wave/SIMD, 9 acc", w);
     RUN(lab, (double)grid * 4 * iters * 9 * 2048.0, (k_f32<9><<<grid, 256>>>((float*)buf, st, iters, 1.0f, 2.0f)));
+    snprintf(lab, sizeof lab, "f32 mfma 16x16x4 RANDOM, %d wave/SIMD, 9 acc", w);
+    RUN(lab, (double)grid * 4 * iters * 9 * 2048.0, (k_f32_random<9><<<grid, 256>>>((float*)buf, st, iters)));
   }
   for (int w = 1; w <= 8; w *= 2) {
     int grid = cus * w;
