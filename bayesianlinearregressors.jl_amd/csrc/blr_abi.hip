@@ -39,8 +39,9 @@ struct blr_handle {
   // wavefront back substitution (D > 128): tagged exchange buffer, start-order ticket counter, launch epoch
   unsigned long long* xchg = nullptr;
   size_t xchg_bytes = 0;
-  unsigned* ticket = nullptr;
+  unsigned* ticket = nullptr;     // [0]: start-order tickets of the wavefront solve, [1]: arrivals of panel_factor_kernel
   unsigned ticket_base = 0;
+  unsigned arrive_base = 0;
   unsigned epoch = 0;
   // kernels whose dynamic-LDS limit has been raised on this handle's device (hipFuncSetAttribute is per device and costs a
   // driver call: once per (handle, kernel), not once per launch -- it sat on the launch path of the 5 us wave kernel)
@@ -310,21 +311,19 @@ int set_lds(blr_handle* h, const void* kern, size_t bytes) { return set_lds_once
 // (the right-hand-side block of the augmented matrix) are carried through the TRSM and the trailing updates.
 template <typename T>
 int chol_large(blr_handle* h, T* M, int64_t ld, int DP, int nrows_total, int32_t* info_dev) {
-  using SC = SmallCfg<T, 8>;
-  using TC = TrsmCfg<T>;
+  using PC = PanelCfg<T>;
   const int NC = DP / kPB;
   int rc;
-  if ((rc = set_lds<T>(h, reinterpret_cast<const void*>(chol_diag_kernel<T>), SC::LDS_BYTES))) return rc;
-  if ((rc = set_lds<T>(h, reinterpret_cast<const void*>(trsm_block_kernel<T>), TC::LDS_BYTES))) return rc;
+  if ((rc = ensure_xchg(h, 0))) return rc;  // the handle's counter words (ticket[1]: arrivals of panel_factor_kernel)
+  if ((rc = set_lds<T>(h, reinterpret_cast<const void*>(panel_factor_kernel<T>), PC::LDS_BYTES))) return rc;
   if ((rc = set_lds<T>(h, reinterpret_cast<const void*>(trail_update_kernel<T>), TrailCfg<T>::LDS_BYTES))) return rc;
   for (int p = 0; p < NC; ++p) {
-    hipLaunchKernelGGL(chol_diag_kernel<T>, dim3(1), dim3(kThreads), SC::LDS_BYTES, h->stream, M, ld, p, info_dev, 0);
-    const int row_begin = (p + 1) * kPB;
-    if (row_begin < nrows_total) {
-      const int nblk = (nrows_total - row_begin + TC::RB - 1) / TC::RB;
-      hipLaunchKernelGGL(trsm_block_kernel<T>, dim3(nblk), dim3(kThreads), TC::LDS_BYTES, h->stream, M, ld, p, row_begin,
-                         nrows_total, (const int32_t*)info_dev, RowSqArgs<T>{});
-    }
+    // L_pp and X <- X L_pp^-T for the rows below, 64 rows per workgroup (one workgroup when nothing is below)
+    const int nbelow = nrows_total - (p + 1) * kPB;
+    const int nwg = std::max(1, (nbelow + PC::ER - 1) / PC::ER);
+    h->arrive_base += (unsigned)nwg;  // monotonic arrival counter: never reset, wrap-around safe (signed difference in the kernel)
+    hipLaunchKernelGGL(panel_factor_kernel<T>, dim3(nwg), dim3(kThreads), PC::LDS_BYTES, h->stream, M, ld, p, nrows_total, info_dev,
+                       h->ticket + 1, h->arrive_base);
     const int m = NC - 1 - p;  // remaining column blocks
     if (m > 0) {
       const int ntri = 2 * m;                                   // 64-row sub-blocks of the remaining triangle
