@@ -1682,7 +1682,7 @@ int rff_features(blr_handle* h, int memspace, int64_t Din, int64_t D, int64_t N,
     if ((rc = stage_in(h, phase, (size_t)D, &Pd))) return rc;
     if ((rc = stage_out_alloc(h, Phi, mat_extent(D, N, ldphi), &Fd))) return rc;
   }
-  dim3 grid((unsigned)((D + kThreads - 1) / kThreads), (unsigned)((N + 15) / 16));
+  dim3 grid((unsigned)((D + kThreads - 1) / kThreads), (unsigned)((N + 31) / 32));  // 32 columns per workgroup (rff_features_kernel NT)
   hipLaunchKernelGGL(rff_features_kernel<T>, grid, dim3(kThreads), 0, h->stream, Xd, ldxin, Od, ldo, Pd, scale, (int)Din,
                      (int)D, (int)N, Fd, ldphi);
   HIP_TRY(h, hipGetLastError());
@@ -1736,7 +1736,7 @@ int posterior_rff(blr_handle* h, int memspace, int64_t Din, int64_t D, int64_t N
       if ((rc = stage_in(h, phase, (size_t)D, &Pd))) return rc;
     }
     if (N > 0) {
-      dim3 grid((unsigned)((D + kThreads - 1) / kThreads), (unsigned)((N + 15) / 16));
+      dim3 grid((unsigned)((D + kThreads - 1) / kThreads), (unsigned)((N + 31) / 32));  // 32 columns per workgroup (rff_features_kernel NT)
       hipLaunchKernelGGL(rff_features_kernel<T>, grid, dim3(kThreads), 0, h->stream, Xd, ldxin, Od, ldo, Pd, scale,
                          (int)Din, (int)D, (int)N, Phi, ldphi);
       HIP_TRY(h, hipGetLastError());

@@ -254,32 +254,51 @@ __global__ __launch_bounds__(kThreads, 2) void rand_project_mfma_kernel(const T*
 // this is the phi of config 5.  Phi is written once (D x N, column-major) and then consumed by the plain path: the
 // Gram is MFMA-bound by two orders of magnitude at D = 2048, so regenerating features per macro tile (17x the cos
 // work) would cost more than the 2 x 128 MiB of extra traffic it saves.
+// cos of the feature phase.  f32: the phase in revolutions, reduced to [-1/2, 1/2] by subtracting the nearest integer, then the
+// hardware cosine (v_cos_f32 takes revolutions) -- the argument's own fp32 rounding (|phase| 1e-7) dominates the error either
+// way, and the library cosine's generic range reduction made this kernel 4 % of config 5 (74 us for 33.5 M features).
+__device__ __forceinline__ double rff_cos(double x) { return cos(x); }
+__device__ __forceinline__ float rff_cos(float x) {
+  const float rev = x * 0.15915494309189535f;  // 1 / (2 pi)
+  return __builtin_amdgcn_cosf(rev - __builtin_rintf(rev));
+}
+
 template <typename T>
 __global__ __launch_bounds__(kThreads) void rff_features_kernel(const T* __restrict__ Xin, int64_t ldxin,
                                                                 const T* __restrict__ Omega, int64_t ldo,
                                                                 const T* __restrict__ phase, T scale, int Din, int D, int N,
                                                                 T* __restrict__ Phi, int64_t ldphi) {
-  constexpr int NT = 16;  // columns per thread
+  constexpr int NT = 32;   // columns per workgroup (one thread: one feature, NT columns)
+  constexpr int KT = 16;   // input dimensions per LDS tile
+  __shared__ T xs[KT][NT];  // the workgroup's tile of inputs: read once, then LDS broadcasts (the first version issued one
+                            // wave-uniform global load per (k, column) and thread: a chain of 128 dependent-latency loads)
   const int f = blockIdx.x * kThreads + threadIdx.x;
   const int n0 = blockIdx.y * NT;
-  if (f >= D) return;
+  const bool fin = f < D;
   T acc[NT];
-  const T ph = phase[f];
+  const T ph = fin ? phase[f] : T(0);
 #pragma unroll
   for (int j = 0; j < NT; ++j) acc[j] = ph;
-  for (int k = 0; k < Din; ++k) {
-    const T om = Omega[(int64_t)f * ldo + k];
+  for (int k0 = 0; k0 < Din; k0 += KT) {
+    __syncthreads();
+    for (int idx = threadIdx.x; idx < KT * NT; idx += kThreads) {
+      const int kk = idx % KT, j = idx / KT;  // consecutive threads: consecutive k of one column (contiguous in memory)
+      const int k = k0 + kk, n = n0 + j;
+      xs[kk][j] = (k < Din && n < N) ? Xin[(int64_t)n * ldxin + k] : T(0);
+    }
+    __syncthreads();
+    const int kend = min(KT, Din - k0);
+    for (int kk = 0; kk < kend; ++kk) {
+      const T om = fin ? Omega[(int64_t)f * ldo + k0 + kk] : T(0);
 #pragma unroll
-    for (int j = 0; j < NT; ++j) {
-      const int n = n0 + j;
-      const T xv = (n < N) ? Xin[(int64_t)n * ldxin + k] : T(0);  // wave-uniform address: one broadcast load
-      acc[j] += om * xv;
+      for (int j = 0; j < NT; ++j) acc[j] += om * xs[kk][j];
     }
   }
+  if (!fin) return;
 #pragma unroll
   for (int j = 0; j < NT; ++j) {
     const int n = n0 + j;
-    if (n < N) Phi[(int64_t)n * ldphi + f] = scale * cos(acc[j]);
+    if (n < N) Phi[(int64_t)n * ldphi + f] = scale * rff_cos(acc[j]);
   }
 }
 

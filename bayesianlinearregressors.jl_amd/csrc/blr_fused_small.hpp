@@ -699,27 +699,28 @@ __device__ __forceinline__ void gram_iso_ring(T* __restrict__ ring, T* __restric
   // pinned in vector registers: rematerialised in the loop they cost a scalar-memory load plus an lgkmcnt(0) wait per use
   asm volatile("" : "+v"(ring_addr), "+v"(ybuf_addr));
   const int nh = N / HC;
-  auto issue_piece = [&](int h, auto ptag) {
-    constexpr int p = decltype(ptag)::value;
-    constexpr int g = p * kWaves + WS, j = (g * FPG) / NB, I0 = (g * FPG) % NB;
-    const uint64_t saddr = (uint64_t)(uintptr_t)X + (uint64_t)(((int64_t)(h * HC + 4 * j) * ldx + 16 * I0) * (int64_t)sizeof(T));
+  // Halves are issued strictly in order, so the global address of a piece is a running 64-bit scalar plus a per-piece constant:
+  // two scalar adds per piece (the 64-bit multiplications of (16 h + 4 j) ldx per piece were a dozen scalar instructions each,
+  // in the gap between two MFMAs)
+  uint64_t nextX = (uint64_t)(uintptr_t)X, nextY = (uint64_t)(uintptr_t)y;
+  const uint64_t stepX = (uint64_t)((int64_t)HC * ldx * (int64_t)sizeof(T));
+  uint64_t offp[PW];
+#pragma unroll
+  for (int p = 0; p < PW; ++p) {
+    const int g = p * kWaves + WS, j = (g * FPG) / NB, I0 = (g * FPG) % NB;
+    offp[p] = (uint64_t)(((int64_t)(4 * j) * ldx + 16 * I0) * (int64_t)sizeof(T));
+  }
+  auto issue_half = [&](int h) {  // h only selects the ring slot; the addresses follow the call order
 #ifndef RING_NODMA
-    glds_s<16>(uni((int64_t)saddr), voff, ring_addr + (unsigned)(slot_of(h) * HALF * (int)sizeof(T) + g * 1024));
-#endif
-  };
-  auto issue_y = [&](int h) {
-#ifndef RING_NODMA
+    const unsigned slot = ring_addr + (unsigned)(slot_of(h) * HALF * (int)sizeof(T));
+#pragma unroll
+    for (int p = 0; p < PW; ++p)
+      glds_s<16>(uni((int64_t)(nextX + offp[p])), voff, slot + (unsigned)((p * kWaves + WS) * 1024));
     if constexpr (WS == 0)
-      glds_s<4, YL>(uni((int64_t)(uintptr_t)(y + (int64_t)h * HC)), (unsigned)(lane * 4),
-                    ybuf_addr + (unsigned)(slot_of(h) * HC * (int)sizeof(T)));
+      glds_s<4, YL>(uni((int64_t)nextY), (unsigned)(lane * 4), ybuf_addr + (unsigned)(slot_of(h) * HC * (int)sizeof(T)));
 #endif
-  };
-  auto issue_half = [&](int h) {
-    issue_piece(h, std::integral_constant<int, 0>{});
-    if constexpr (PW > 1) issue_piece(h, std::integral_constant<int, 1>{});
-    if constexpr (PW > 2) issue_piece(h, std::integral_constant<int, 2>{});
-    if constexpr (PW > 3) issue_piece(h, std::integral_constant<int, 3>{});
-    issue_y(h);
+    nextX += stepX;
+    nextY += (uint64_t)(HC * sizeof(T));
   };
   // retire everything but the youngest `keep_halves` halves of this wave's pieces
   auto retire = [&](int keep_halves) {
