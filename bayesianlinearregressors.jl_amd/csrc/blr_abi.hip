@@ -2109,9 +2109,12 @@ int update_factor(blr_handle* h, int memspace, int layout, int64_t B, int64_t D,
   if (!h) return -1;
   h->err.clear();
   // Route (measured, tools/update_bench.py): a sweep costs ~40 us per observation at D = 128 (a serial chain
-  // of D rotations), the in-place re-factorisation ~99 us per CALL whatever k is (45 us at D = 64, where batches run on the
+  // of D rotations), the in-place re-factorisation ~90 us per CALL whatever k is (45 us at D = 64, where batches run on the
   // one-wave-per-regressor kernel at 27 M updates/s) -- the sweep wins for a single new observation, except in large
-  // batches at D <= 64.  BLR_MI355X_SWEEP=always / never overrides (tests exercise both routes on the same inputs).
+  // batches at D <= 64.  A blocked (Householder) sweep that eliminates up to 16 rows in one chain of D reflections was built
+  // and measured in round 3: 92 / 115 / 144 / 205 us at k = 1 / 3 / 8 / 16 against 90 us -- the k + 1-term dot products and
+  // three reciprocal chains per step cost more than the rotations they replace -- and was not kept.
+  // BLR_MI355X_SWEEP=always / never overrides (tests exercise both routes on the same inputs).
   const char* mode = getenv("BLR_MI355X_SWEEP");
   const bool can_sweep = D >= 1 && D <= kSweepMaxD && k >= 0 && k <= kSweepMaxK;
   bool sweep = can_sweep && k <= 1 && (D > 64 || B < 256);

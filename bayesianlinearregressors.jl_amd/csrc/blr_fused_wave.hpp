@@ -30,7 +30,10 @@ struct WaveCfg {
 #endif
   static constexpr int KS = (BLR_WAVE_STAGE_BYTES / 64) / (NB * (int)sizeof(T));  // k-steps per stage: every stage is 4 KiB of X
   static constexpr int NSC = 4 * KS;                   // columns per stage
-  static constexpr int DEPTH = 16384 / BLR_WAVE_STAGE_BYTES;  // ring slots (16 KiB): all but one in flight while one is consumed
+#ifndef BLR_WAVE_RING_BYTES
+#define BLR_WAVE_RING_BYTES 16384
+#endif
+  static constexpr int DEPTH = BLR_WAVE_RING_BYTES / BLR_WAVE_STAGE_BYTES;  // ring slots (16 KiB): all but one in flight while one is consumed
   static constexpr int SLOT = KS * NB * 64;            // elements per ring slot (fragment order [k-step][row block][lane])
   static constexpr int PACKED = DP * (DP + 1) / 2;
   static constexpr int RING_BYTES = DEPTH * SLOT * (int)sizeof(T);
@@ -118,18 +121,27 @@ BLR_PHASE void wave_gram(char* smem0, const BLR_GLOBAL T* X, int64_t ldx, const 
   const int share = nfull_all / NW, rem = nfull_all - share * NW;
   const int t0 = (NW == 1) ? 0 : w * share + max(0, w - (NW - rem));
   const int nfull = (NW == 1) ? nfull_all : share + (w >= NW - rem ? 1 : 0);
-  auto issue = [&](int td) {     // exactly PPS LDS-DMA instructions
-    const int n0 = (t0 + td) * C::NSC, sl = td & (C::DEPTH - 1);
+  // Stages are issued strictly in order, so a piece's global address is a running 64-bit scalar plus a per-piece constant
+  // (two scalar adds; the (n0 + 4 j) ldx multiplications per piece were a dozen scalar instructions each, in front of the MFMAs)
+  uint64_t nextX = (uint64_t)(uintptr_t)(X + (int64_t)t0 * C::NSC * ldx);
+  uint64_t nextY = (uint64_t)(uintptr_t)(y + (int64_t)t0 * C::NSC), nextS = (uint64_t)(uintptr_t)(s + (DIAG ? (int64_t)t0 * C::NSC : 0));
+  const uint64_t stepX = (uint64_t)((int64_t)C::NSC * ldx * (int64_t)sizeof(T));
+  uint64_t offg[C::NG];
+#pragma unroll
+  for (int g = 0; g < C::NG; ++g) {
+    const int j = (g * C::FPG) / NB, I0 = (g * C::FPG) % NB;
+    offg[g] = (uint64_t)(((int64_t)(4 * j) * ldx + 16 * I0) * (int64_t)sizeof(T));
+  }
+  auto issue = [&](int td) {     // exactly PPS LDS-DMA instructions; td only selects the ring slot
+    const int sl = td & (C::DEPTH - 1);
     const unsigned slot_addr = ring_addr + (unsigned)(sl * C::SLOT * (int)sizeof(T));
 #pragma unroll
-    for (int g = 0; g < C::NG; ++g) {
-      const int j = (g * C::FPG) / NB, I0 = (g * C::FPG) % NB;
-      const uint64_t saddr = (uint64_t)(uintptr_t)X + (uint64_t)(((int64_t)(n0 + 4 * j) * ldx + 16 * I0) * (int64_t)sizeof(T));
-      glds_s<16>(uni((int64_t)saddr), voff, slot_addr + (unsigned)(g * 1024));
-    }
-    glds_s<4, C::YL>(uni((int64_t)(uintptr_t)(y + n0)), (unsigned)(lane * 4), ybuf_addr + (unsigned)(sl * C::NSC * (int)sizeof(T)));
-    if constexpr (DIAG)
-      glds_s<4, C::YL>(uni((int64_t)(uintptr_t)(s + n0)), (unsigned)(lane * 4), sbuf_addr + (unsigned)(sl * C::NSC * (int)sizeof(T)));
+    for (int g = 0; g < C::NG; ++g) glds_s<16>(uni((int64_t)(nextX + offg[g])), voff, slot_addr + (unsigned)(g * 1024));
+    glds_s<4, C::YL>(uni((int64_t)nextY), (unsigned)(lane * 4), ybuf_addr + (unsigned)(sl * C::NSC * (int)sizeof(T)));
+    if constexpr (DIAG) glds_s<4, C::YL>(uni((int64_t)nextS), (unsigned)(lane * 4), sbuf_addr + (unsigned)(sl * C::NSC * (int)sizeof(T)));
+    nextX += stepX;
+    nextY += (uint64_t)(C::NSC * sizeof(T));
+    if constexpr (DIAG) nextS += (uint64_t)(C::NSC * sizeof(T));
   };
   // one stage of compute: KS k-steps on the slot image, y from yb, weights from wbuf (DIAG)
   auto compute = [&](const T* slot, const T* yb, bool data) {

@@ -442,9 +442,15 @@ def main():
                 wall, ms = timed(torch, stream, dev, w2.launch, steps, 2)
                 assert int(w2.info.abs().sum().item()) == 0 and bool(torch.isfinite(w2.lp).all().item())
                 r = w2.roofline(ms)
+                pmc_key = {"c2_f32": "c2_f32_fused_small_kernel_hbm", "c4_f64": "c4_fused_wave_kernel_hbm", "c3_f32": "c3_gram_tile_kernel_hbm",
+                           "c5_f32_end_to_end": "c5_gram_tile_kernel_hbm"}.get(name)
+                per_update, src = pmc_traffic_per_update(pmc_key) if pmc_key else (None, None)
+                r["traffic"] = per_update * (b if pmc_key in ("c2_f32_fused_small_kernel_hbm", "c4_fused_wave_kernel_hbm") else 1) if per_update else None
+                r["traffic_source"] = src
                 sec[name] = {"workload": f"B={b}, D={d}, N={n}, {dt}, {noise} noise" + (f", D_in={din} random-Fourier features" if din else ""),
                              "ms": ms, "updates_per_s": b / (ms * 1e-3), "wall_updates_per_s": b * steps / wall,
-                             "roofline": {k: r[k] for k in ("bound", "achieved", "peak", "unit", "frac", "kernel", "hbm_frac", "mfma_frac")}}
+                             "roofline": {k: r[k] for k in ("bound", "achieved", "peak", "unit", "frac", "kernel", "hbm_frac", "mfma_frac", "traffic",
+                                                           "traffic_source")}}
                 del w2
                 torch.cuda.empty_cache()
             except Exception as e:  # a secondary shape must never take the headline line down

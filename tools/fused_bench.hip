@@ -75,7 +75,11 @@ int main(int argc, char** argv) {
   for (auto& v : y) v = (T)(3.0 * gauss());
   if (diag) for (auto& v : s) v = (T)std::exp(0.5 * gauss()); else s[0] = (T)0.1;
   T *dX, *dy, *ds, *dmw, *dpri, *dmwp, *dT; double* dlp; int32_t* dinfo;
-  CK(hipMalloc((void**)&dX, (size_t)B * N * D * sizeof(T)));
+  // FB_PAD: extra elements between consecutive regressors (a power-of-two stride makes every wave hit the same memory channel
+  // bits at the same time -- partition camping -- when the waves run in lockstep)
+  const size_t pad = getenv("FB_PAD") ? (size_t)atoll(getenv("FB_PAD")) : 0;
+  const size_t strideXe = (size_t)N * D + pad;
+  CK(hipMalloc((void**)&dX, (size_t)B * strideXe * sizeof(T)));
   CK(hipMalloc((void**)&dy, (size_t)B * N * sizeof(T)));
   CK(hipMalloc((void**)&ds, s.size() * (diag ? (size_t)B / BU + 1 : 1) * sizeof(T)));
   CK(hipMalloc((void**)&dmw, D * sizeof(T))); CK(hipMalloc((void**)&dpri, D * sizeof(T)));
@@ -83,14 +87,15 @@ int main(int argc, char** argv) {
   CK(hipMalloc((void**)&dlp, (size_t)B * 8)); CK(hipMalloc((void**)&dinfo, (size_t)B * 4));
   for (int b0 = 0; b0 < B; b0 += BU) {
     const int nb = std::min(BU, B - b0);
-    CK(hipMemcpy(dX + (size_t)b0 * N * D, X.data(), (size_t)nb * N * D * sizeof(T), hipMemcpyHostToDevice));
+    for (int bb = 0; bb < nb; ++bb)
+      CK(hipMemcpy(dX + (size_t)(b0 + bb) * strideXe, X.data() + (size_t)bb * N * D, (size_t)N * D * sizeof(T), hipMemcpyHostToDevice));
     CK(hipMemcpy(dy + (size_t)b0 * N, y.data(), (size_t)nb * N * sizeof(T), hipMemcpyHostToDevice));
   }
   CK(hipMemcpy(ds, s.data(), s.size() * sizeof(T), hipMemcpyHostToDevice));
   CK(hipMemcpy(dmw, mw.data(), D * sizeof(T), hipMemcpyHostToDevice));
   CK(hipMemcpy(dpri, dpr.data(), D * sizeof(T), hipMemcpyHostToDevice));
   PosteriorArgs<T> a{};
-  a.X = dX; a.ldx = D; a.strideX = shareX ? 0 : (int64_t)N * D; a.y = dy; a.stridey = N; a.s = ds; a.strides = 0;  // noise shared (diag: of regressor 0)
+  a.X = dX; a.ldx = D; a.strideX = shareX ? 0 : (int64_t)strideXe; a.y = dy; a.stridey = N; a.s = ds; a.strides = 0;  // noise shared (diag: of regressor 0)
   a.mw = dmw; a.stridemw = 0; a.Lw = dpri; a.ldl = 1; a.strideLw = 0;
   a.mw_post = dmwp; a.stride_mwpost = D; a.T_post = dT; a.ldt = D; a.strideT = D * D; a.Lw_post = nullptr;
   a.logpdf = dlp; a.info = dinfo; a.layout = LAYOUT_COLVECS; a.noise_kind = diag ? NOISE_DIAGONAL : NOISE_ISOTROPIC;
@@ -103,7 +108,7 @@ int main(int argc, char** argv) {
 #define FB_LAUNCH() hipLaunchKernelGGL(fused_d128_kernel<T>, dim3(kGrid), dim3(kBlock), kLds, 0, a, dscr)
 #elif defined(FB_WAVE)
   auto kern = fused_wave_kernel<T, NB>;
-  const int kLds = WaveCfg<T, NB>::LDS_BYTES, kBlock = 64, kGrid = std::min(B, 2048);
+  const int kLds = WaveCfg<T, NB>::LDS_BYTES, kBlock = 64, kGrid = std::min(B, getenv("FB_GRID") ? atoi(getenv("FB_GRID")) : 2048);
 #else
   auto kern = fused_small_kernel<T, NB, 4>;
   const int kLds = C::LDS_BYTES, kBlock = kThreads, kGrid = getenv("FB_GRID") ? atoi(getenv("FB_GRID")) : B;

@@ -9,7 +9,7 @@ import os
 import shutil
 import sys
 
-tag = sys.argv[1] if len(sys.argv) > 1 else "r02"
+tag = sys.argv[1] if len(sys.argv) > 1 else "r03"
 RAW = "gpurun_out/profiles_raw"
 DST = "profiles"
 os.makedirs(DST, exist_ok=True)
@@ -75,8 +75,22 @@ if f4 and w4:
                                             "hbm_read_bytes_per_launch": rd, "hbm_write_bytes_per_launch": wr,
                                             "hbm_bytes_per_launch": rd + wr, "units_per_launch": 8192}
 sq4 = counters("pmc_sq_c4", "fused_wave_kernel")
+sq5 = counters("pmc_sq_c5", "gram_tile_kernel")
+for key, d, kern, units in (("c2_f32_fused_small_kernel_hbm", "c2f32", "fused_small_kernel", 4096), ("c3_gram_tile_kernel_hbm", "c3", "gram_tile_kernel", 1),
+                            ("c5_gram_tile_kernel_hbm", "c5", "gram_tile_kernel", 1)):
+    fe, wr_ = counters(f"pmc_fetch_{d}", kern), counters(f"pmc_write_{d}", kern)
+    if fe and wr_:
+        rd = fe["FETCH_SIZE"] * 1024.0 * 2.0
+        wr = wr_["WRITE_SIZE"] * 1024.0
+        summary[key] = {"FETCH_SIZE_KiB": fe["FETCH_SIZE"], "WRITE_SIZE_KiB": wr_["WRITE_SIZE"], "hbm_read_bytes_per_launch": rd,
+                        "hbm_write_bytes_per_launch": wr, "hbm_bytes_per_launch": rd + wr, "units_per_launch": units,
+                        "kernel": kern, "avg_duration_ns": fe["avg_duration_ns"]}
+for extra in ("ring_probe.txt", "power_probe.txt"):
+    src = os.path.join(RAW, extra)
+    if os.path.exists(src) and os.path.getsize(src):
+        shutil.copy(src, os.path.join(DST, f"{tag}_microbench_{extra}"))
 for key, c in (("c2_fused_small_kernel_sq", sq2), ("c2_f32_fused_small_kernel_sq", sq2f), ("c3_gram_tile_kernel_sq", sq3),
-               ("c4_fused_wave_kernel_sq", sq4)):
+               ("c4_fused_wave_kernel_sq", sq4), ("c5_gram_tile_kernel_sq", sq5)):
     if c:
         ns = c["avg_duration_ns"]
         c["effective_clock_GHz"] = c["GRBM_GUI_ACTIVE"] / 8.0 / ns
