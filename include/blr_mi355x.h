@@ -88,6 +88,9 @@ int blr_timer_stop(blr_handle* h, float* elapsed_ms); /* records, synchronises, 
  * Outputs (each may be NULL to skip it):
  *   mw_post[D]; T_post D x D upper factor (strictly-lower part written as zero), ldt >= D;
  *   Lw_post D x D full symmetric A, ldlp >= D; logpdf (double).
+ * In-place form: with prior_kind = BLR_PRIOR_UPPER_FACTOR, mw_post == mw and T_post == Lw are allowed (every read of the
+ * prior state completes before the first write; blr_update_factor_* relies on it).  For D <= 128 mw_post and T_post of a regressor
+ * whose info != 0 are left untouched (Lw_post may already hold A); for D > 128 the outputs are undefined then.
  * Batched form: regressor i reads X + i*strideX, y + i*stridey, s + i*strides, mw + i*stridemw,
  * Lw + i*strideLw and writes the outputs at their strides; a stride of 0 shares an input.
  */
@@ -351,7 +354,10 @@ int blr_allreduce_sum(blr_handle* h, int is_f64, void* buf, int64_t count);
  * in-place all-reduce of `stats` (lds * DP elements, DP = 128 ceil(D/128)) and `scal` over the handle's communicator, then
  * blr_posterior_from_stats_* -- every rank ends with the same posterior and evidence of all N_total observations.  `stats`
  * ((DP + 128) x DP, lds >= DP + 128) and `scal` (2 doubles) are caller-provided device scratch; all pointers device.
- * Without a communicator it is the single-GPU update through the statistics path. */
+ * Without a communicator it is the single-GPU update through the statistics path.
+ * Reproducibility: every rank gets the SAME bits, but -- unlike blr_logpdf_allgather_sum (all-gather + one fixed-order sum) --
+ * the statistics go through ncclAllReduce, a floating-point sum whose order depends on the rank count and the ring: results
+ * for different numbers of ranks agree to rounding, not bit for bit. */
 int blr_posterior_nsharded_f64(blr_handle* h, int layout, int64_t D, int64_t N_local, int64_t N_total, const double* X,
                                int64_t ldx, const double* y, int noise_kind, const double* s, int prior_kind,
                                const double* mw, const double* Lw, int64_t ldl, double* stats, int64_t lds, double* scal,

@@ -16,8 +16,8 @@ os.makedirs(DST, exist_ok=True)
 
 
 def one(pattern):
-    g = glob.glob(pattern)
-    return g[0] if g else None
+    g = glob.glob(pattern)  # gpurun merges into gpurun_out/: an earlier collection's files may still sit next to the new ones
+    return max(g, key=os.path.getmtime) if g else None
 
 
 for name in ("bench_c2_f64", "bench_c2_f32", "bench_c3_f32", "bench_c5_f32", "bench_c4_f64"):
@@ -31,20 +31,31 @@ for cfg in ("c2", "c3", "c5", "c4"):
 
 
 def counters(dirname, kernel_substr):
-    f = one(f"{RAW}/{dirname}/*/*_counter_collection.csv")
-    t = one(f"{RAW}/{dirname}/*/*_kernel_trace.csv")
-    if not f or not t:
+    f_new = one(f"{RAW}/{dirname}/*/*_counter_collection.csv")
+    if not f_new:
         return None
-    dur = {r["Dispatch_Id"]: int(r["End_Timestamp"]) - int(r["Start_Timestamp"]) for r in csv.DictReader(open(t))}
+    fs = [f_new]
+    ts = [f_new.replace("_counter_collection.csv", "_kernel_trace.csv")]
+    if not os.path.exists(ts[0]):
+        return None
+    dur = {}
+    for t in ts:  # one file per traced process; dispatch ids are unique within a process directory
+        key = os.path.dirname(t)
+        for r in csv.DictReader(open(t)):
+            dur[(key, r["Dispatch_Id"])] = int(r["End_Timestamp"]) - int(r["Start_Timestamp"])
     by = collections.defaultdict(dict)
-    for r in csv.DictReader(open(f)):
-        if kernel_substr in r["Kernel_Name"]:
-            by[r["Dispatch_Id"]][r["Counter_Name"]] = float(r["Counter_Value"])
-            by[r["Dispatch_Id"]]["_grid"] = int(r["Grid_Size"])
+    for f in fs:
+        key = os.path.dirname(f)
+        for r in csv.DictReader(open(f)):
+            if kernel_substr in r["Kernel_Name"]:
+                by[(key, r["Dispatch_Id"])][r["Counter_Name"]] = float(r["Counter_Value"])
+                by[(key, r["Dispatch_Id"])]["_grid"] = int(r["Grid_Size"])
     if not by:
         return None
     gmax = max(c["_grid"] for c in by.values())  # the dominant launch shape
-    sel = {d: c for d, c in by.items() if c["_grid"] == gmax}
+    sel = {d: c for d, c in by.items() if c["_grid"] == gmax and d in dur}
+    if not sel:
+        return None
     out = {"dispatches": len(sel), "grid": gmax, "avg_duration_ns": sum(dur[d] for d in sel) / len(sel)}
     names = sorted({k for c in sel.values() for k in c if not k.startswith("_")})
     for k in names:
