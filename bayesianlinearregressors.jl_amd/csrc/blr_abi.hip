@@ -311,18 +311,19 @@ int set_lds(blr_handle* h, const void* kern, size_t bytes) { return set_lds_once
 // (the right-hand-side block of the augmented matrix) are carried through the TRSM and the trailing updates.
 template <typename T>
 int chol_large(blr_handle* h, T* M, int64_t ld, int DP, int nrows_total, int32_t* info_dev) {
-  using PC = PanelCfg<T>;
+  constexpr int NW = BLR_PANEL_WAVES;
+  using CC = ChainCfg<T, NW>;
   const int NC = DP / kPB;
   int rc;
-  if ((rc = ensure_xchg(h, 0))) return rc;  // the handle's counter words (ticket[1]: arrivals of panel_factor_kernel)
-  if ((rc = set_lds<T>(h, reinterpret_cast<const void*>(panel_factor_kernel<T>), PC::LDS_BYTES))) return rc;
+  if ((rc = ensure_xchg(h, 0))) return rc;  // the handle's counter words (ticket[1]: arrivals of panel_chain_kernel)
+  if ((rc = set_lds<T>(h, reinterpret_cast<const void*>(panel_chain_kernel<T, NW>), CC::LDS_BYTES))) return rc;
   if ((rc = set_lds<T>(h, reinterpret_cast<const void*>(trail_update_kernel<T>), TrailCfg<T>::LDS_BYTES))) return rc;
   for (int p = 0; p < NC; ++p) {
-    // L_pp and X <- X L_pp^-T for the rows below, 64 rows per workgroup (one workgroup when nothing is below)
+    // L_pp and X <- X L_pp^-T for the rows below, ER rows per workgroup (one workgroup when nothing is below)
     const int nbelow = nrows_total - (p + 1) * kPB;
-    const int nwg = std::max(1, (nbelow + PC::ER - 1) / PC::ER);
+    const int nwg = std::max(1, (nbelow + CC::ER - 1) / CC::ER);
     h->arrive_base += (unsigned)nwg;  // monotonic arrival counter: never reset, wrap-around safe (signed difference in the kernel)
-    hipLaunchKernelGGL(panel_factor_kernel<T>, dim3(nwg), dim3(kThreads), PC::LDS_BYTES, h->stream, M, ld, p, nrows_total, info_dev,
+    hipLaunchKernelGGL((panel_chain_kernel<T, NW>), dim3(nwg), dim3(64 * NW), CC::LDS_BYTES, h->stream, M, ld, p, nrows_total, info_dev,
                        h->ticket + 1, h->arrive_base);
     const int m = NC - 1 - p;  // remaining column blocks
     if (m > 0) {

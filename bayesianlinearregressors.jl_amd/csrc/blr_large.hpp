@@ -4,7 +4,7 @@
 //   gram_tile_kernel     128x128 macro tile of  sum_n x_n w_n x_n'  over one N-slice (split-K), MFMA 16x16x4,
 //                        X staged in fragment order by LDS-DMA; diagonal tiles also give  b_I = X_I r      (:86, :57)
 //   gram_reduce_kernel   fixed-order sum of the split partials + prior precision -> augmented matrix Abar
-//   panel_factor_kernel  in-LDS blocked Cholesky of one 128x128 diagonal block (the scheme of phase_chol) with 64 rows of the
+//   panel_chain_kernel   (blr_panel.hpp) wave-specialised Cholesky of one 128x128 diagonal block with 64 rows of the
 //                        block column below riding along per workgroup: L_pp and X <- X L_pp^-T in ONE launch
 //   trsm_block_kernel    X <- X L_pp^-T for row blocks against an already factored L_pp (tall-matrix sweeps of the marginal /
 //                        gradient / multi-output paths): left-looking 16-column chunks on MFMA
@@ -20,6 +20,7 @@
 #pragma once
 #include "blr_aux_kernels.hpp"
 #include "blr_fused_small.hpp"
+#include "blr_panel.hpp"
 
 namespace blr {
 
@@ -795,226 +796,7 @@ __device__ __forceinline__ void load_upper_block_to_packed(T* __restrict__ P, co
   b.to_packed_from_upper(P, tid);
 }
 
-// ---- panel factorisation: diagonal block AND the rows below it in one launch ------------------------------------------------
-// The chain of a panel used to be three dependent launches: factor L_pp (one workgroup, ~32 us), X <- X L_pp^-T for the rows
-// below (trsm_block_kernel, ~11.5 us: every workgroup loads L_pp again, inverts its 16 x 16 diagonal blocks and sweeps eight
-// column chunks), trailing update.  The row-per-lane elimination of the factorisation has idle lanes, and a row of X needs exactly
-// the operations a row of the diagonal block below the current panel gets -- so here EVERY workgroup factors L_pp (redundantly:
-// the critical path is that factorisation whoever runs it) and carries 64 rows of X along in lanes 48-63 of its four waves:
-// their 16-column tiles live in MFMA accumulators like the block's own trailing tiles and receive the same updates.  The TRSM
-// launch, its reload of L_pp and its chunk sweep disappear from the chain (per panel 32 + 11.5 + trailing -> ~34 + trailing).
-//   lanes  0-15: the diagonal-block rows of the current 16-column panel (in all four waves);
-//   lanes 16-47: rows of the diagonal block below it, 32 per wave (<= 112 needed);
-//   lanes 48-63: this wave's 16 rows of X (image E in LDS, row stride 129).
-// Workgroup 0 writes L_pp back; it does so only after every workgroup has read A_pp (arrival counter, see panel_factor_kernel).
-template <typename T>
-struct PanelCfg {
-  using SC = SmallCfg<T, 8>;
-  static constexpr int ER = 64;                      // rows of X per workgroup
-  static constexpr int LDE = kPB + 1;                // row stride of their LDS image
-  static constexpr int OFF_E = (SC::LDS_BYTES + 15) & ~15;
-  static constexpr int LDS_BYTES = OFF_E + ((ER * LDE * (int)sizeof(T) + 15) & ~15);
-};
-
-template <typename T>
-BLR_PHASE int phase_chol_ext(char* smem) {
-  using C = SmallCfg<T, 8>;
-  using PC = PanelCfg<T>;
-  using acc4 = typename Mfma<T>::acc4;
-  constexpr int TPW = C::TPW, LDE = PC::LDE;
-  T* const P = reinterpret_cast<T*>(smem);
-  T* const E = reinterpret_cast<T*>(smem + PC::OFF_E);
-  int tid = threadIdx.x;
-  asm volatile("" : "+v"(tid));
-  const int lane = tid & 63;
-  const int wave = uni(tid >> 6);
-  const int r = lane & 15, q = lane >> 4;
-  const int pr = (r * (r + 1)) >> 1;  // pidx(r, 0)
-  T* const dummy = reinterpret_cast<T*>(smem + C::OFF_DINV) + r;
-  int cr[4], pcr[4];
-#pragma unroll
-  for (int v = 0; v < 4; ++v) {
-    cr[v] = Mfma<T>::crow(lane, v);
-    pcr[v] = (cr[v] * (cr[v] + 1)) >> 1;
-  }
-  // the diagonal block's tiles (as phase_chol) ...
-  acc4 acc[TPW];
-  int tI[TPW], tK[TPW];
-#pragma unroll
-  for (int i = 0; i < TPW; ++i) {
-    int I, K;
-    wave_tile(8, wave, i, I, K);
-    tI[i] = uni(I);
-    tK[i] = uni(K);
-    const int col = 16 * K + r;
-#pragma unroll
-    for (int v = 0; v < 4; ++v) {
-      const int row = 16 * I + cr[v];
-      acc[i][v] = P[pidx(max(row, col), min(row, col))];
-    }
-  }
-  // ... and this wave's 16 rows of X: eight 16 x 16 tiles
-  T* const Ew = E + (16 * wave) * LDE;
-  acc4 ext[8];
-#pragma unroll
-  for (int K = 0; K < 8; ++K)
-#pragma unroll
-    for (int v = 0; v < 4; ++v) ext[K][v] = Ew[cr[v] * LDE + 16 * K + r];
-
-  int info = 0;
-  for (int J = 0; J < 8; ++J) {
-    // block column J of the X rows: registers -> image (the image still holds the values from before the updates)
-#pragma unroll
-    for (int K = 0; K < 8; ++K) {
-      if (K == J) {  // scalar branch
-#pragma unroll
-        for (int v = 0; v < 4; ++v) Ew[cr[v] * LDE + 16 * K + r] = ext[K][v];
-      }
-    }
-    __syncthreads();  // ... and block column J of P, stored by the trailing update of panel J-1
-    const bool is_diag = lane < 16, is_ext = lane >= 48;
-    const int ri = is_diag ? 16 * J + lane : 16 * (J + 1) + 32 * wave + (lane - 16);
-    const bool active = is_ext || ri < kPB;
-    const int ria = (is_ext || ri >= kPB) ? 0 : ri;
-    T* const rowp = is_ext ? Ew + (lane - 48) * LDE + 16 * J : P + (((ria * (ria + 1)) >> 1) + 16 * J);
-    T arow[16];
-#pragma unroll
-    for (int c = 0; c < 16; ++c) arow[c] = rowp[c];  // unmasked (see phase_chol)
-#pragma unroll
-    for (int c = 0; c < 16; ++c) {
-      const T d2 = readlane(arow[c], c);
-      if (!(d2 > T(0))) {  // wave-uniform and identical in every wave of every workgroup
-        if (info == 0) info = 16 * J + c + 1;
-      }
-      const T t = arow[c] * fast_rcp(d2);
-#pragma unroll
-      for (int k = c + 1; k < 16; ++k) {
-        const T akc = readlane(arow[c], k);
-        arow[k] -= t * akc;
-      }
-      const T rsq = fast_rsqrt(d2);
-      arow[c] = (lane == c) ? d2 * rsq : arow[c] * rsq;
-    }
-    if (info != 0) break;
-    {
-      const int lim = active ? (is_diag ? lane : 15) : -1;
-#pragma unroll
-      for (int c = 0; c < 16; ++c) {
-        T* dst = (c <= lim) ? rowp + c : dummy;
-        *dst = arow[c];
-      }
-    }
-    __syncthreads();
-    // trailing update from the finished panel: the block's own tiles ...
-    const int pc = pr + 16 * J + q;
-#pragma unroll
-    for (int i = 0; i < TPW; ++i) {
-      if (tK[i] > J) {  // scalar branch
-        const int I = tI[i], K = tK[i];
-        const T* pI = P + ((128 * I * I + 8 * I) + (16 * I) * r + pc);
-        const T* pK = P + ((128 * K * K + 8 * K) + (16 * K) * r + pc);
-        T fa[4], fb[4];
-#pragma unroll
-        for (int ks = 0; ks < 4; ++ks) { fa[ks] = pI[4 * ks]; fb[ks] = pK[4 * ks]; }
-#pragma unroll
-        for (int ks = 0; ks < 4; ++ks) acc[i] = Mfma<T>::mma(-fa[ks], fb[ks], acc[i]);
-        if (K == J + 1) {
-          const int sb = (128 * I * I + 8 * I) + 16 * K + r;
-          if (I != K) {
-#pragma unroll
-            for (int v = 0; v < 4; ++v) P[sb + (16 * I) * cr[v] + pcr[v]] = acc[i][v];
-          } else {
-#pragma unroll
-            for (int v = 0; v < 4; ++v) {
-              T* dst = (r <= cr[v]) ? P + (sb + (16 * I) * cr[v] + pcr[v]) : dummy;
-              *dst = acc[i][v];
-            }
-          }
-        }
-      }
-    }
-    // ... and the X rows' tiles to the right of block column J: X_K -= X_J L_KJ'
-    {
-      const T* pX = Ew + r * LDE + 16 * J + q;
-      T fx[4];
-#pragma unroll
-      for (int ks = 0; ks < 4; ++ks) fx[ks] = pX[4 * ks];
-#pragma unroll
-      for (int K = 1; K < 8; ++K) {
-        if (K > J) {  // scalar branch
-          const T* pK = P + ((128 * K * K + 8 * K) + (16 * K) * r + pc);
-          T fb[4];
-#pragma unroll
-          for (int ks = 0; ks < 4; ++ks) fb[ks] = pK[4 * ks];
-#pragma unroll
-          for (int ks = 0; ks < 4; ++ks) ext[K] = Mfma<T>::mma(-fx[ks], fb[ks], ext[K]);
-        }
-      }
-    }
-  }
-  __syncthreads();
-  return info;
-}
-
-template <typename T>
-__global__ __launch_bounds__(kThreads, 2) void panel_factor_kernel(T* Abar, int64_t lda, int p, int nrows_total, int32_t* info,
-                                                                   unsigned* arrive, unsigned arrive_target) {
-  __builtin_amdgcn_s_setprio(3);  // latency-critical chain kernel
-  using PC = PanelCfg<T>;
-  extern __shared__ __attribute__((aligned(16))) char smem[];
-  T* const P = reinterpret_cast<T*>(smem);
-  T* const E = reinterpret_cast<T*>(smem + PC::OFF_E);
-  const int tid = threadIdx.x;
-  T* blk = Abar + (int64_t)p * kPB * lda + (int64_t)p * kPB;
-  const int r0 = (p + 1) * kPB + blockIdx.x * PC::ER;     // first row of this workgroup's slice of X
-  const int nr = max(0, min(PC::ER, nrows_total - r0));   // 0 (nothing below the block) or 64: callers pad to 128 rows
-  T* Xg = Abar + (int64_t)p * kPB * lda + r0;
-  const bool failed = *info != 0;  // an earlier panel already failed (uniform over the launch)
-  {
-    BlockVec<T, kPB> lb;
-    BlockVec<T, PC::ER> xb;
-    lb.load(blk, lda, tid);
-    if (nr > 0) xb.load(Xg, lda, tid);
-    else for (int u = 0; u < BlockVec<T, PC::ER>::NV; ++u) xb.v[u] = typename BlockVec<T, PC::ER>::vecT(T(0));
-    lb.to_packed_lower(P, tid);
-    xb.to_rows(E, PC::LDE, nr, tid);
-  }
-  __syncthreads();
-  // A_pp has been read (its values sit in LDS): arrive.  Workgroup 0 overwrites it with L_pp only after everybody has.
-  // (all workgroups of this launch are co-resident: at most (rows below) / 64 <= 130 of them)
-  if (tid == 0) __hip_atomic_fetch_add(arrive, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-  if (failed) return;
-  const int rc = phase_chol_ext<T>(smem);
-  if (rc != 0) {
-    if (blockIdx.x == 0 && tid == 0) *info = p * kPB + rc;
-    return;
-  }
-  if (blockIdx.x == 0) {
-    if (tid == 0) {
-      long long spins = 0;
-      while ((int)(__hip_atomic_load(arrive, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) - arrive_target) < 0) {
-        __builtin_amdgcn_s_sleep(8);
-        if (++spins > 20000000LL) break;  // a logic error upstream must not hang the GPU
-      }
-    }
-    __syncthreads();
-    store_packed_to_lower_block(P, blk, lda, tid);
-  }
-  if (nr > 0) {
-    using BV = BlockVec<T, PC::ER>;
-#pragma unroll 4
-    for (int u = 0; u < BV::NV; ++u) {
-      const int vi = u * kThreads + tid;
-      const int c = vi / BV::VPC, rr = (vi % BV::VPC) * BV::VEC;
-      if (rr < nr) {
-        typename BV::vecT o;
-#pragma unroll
-        for (int e = 0; e < BV::VEC; ++e) o[e] = E[(rr + e) * PC::LDE + c];
-        *reinterpret_cast<typename BV::vecT*>(Xg + (int64_t)c * lda + rr) = o;
-      }
-    }
-  }
-}
+// ---- panel factorisation (diagonal block AND the rows below it in one launch): panel_chain_kernel, blr_panel.hpp ------------
 
 // ---- trailing update of the blocked Cholesky: C -= L_I L_J' for every 64 x 64 sub-tile below panel p -----------------------
 // The update has K = 128 only, so it is pure latency: one workgroup per 64 x 64 sub-tile issues ALL its loads at once
