@@ -400,18 +400,28 @@ int posterior_large_one(blr_handle* h, const PosteriorArgs<T>& a, int64_t reg) {
   const T* mw = a.mw + reg * a.stridemw;
   const T* Lw = a.Lw + reg * a.strideLw;
 
-  HIP_TRY(h, hipMemsetAsync(ws + o_sc, 0, 64, h->stream));
-  HIP_TRY(h, hipMemsetAsync(info_noise, 0xFF, sizeof(unsigned), h->stream));
-  HIP_TRY(h, hipMemsetAsync(bpart, 0, (size_t)nsplit_total * NC * kPB * sizeof(double), h->stream));
-
   // ---- prior: SPD check + logdet (reference :78)
   if (a.prior_kind == PRIOR_DENSE) {
+    HIP_TRY(h, hipMemsetAsync(ws + o_sc, 0, 64, h->stream));
+    HIP_TRY(h, hipMemsetAsync(info_noise, 0xFF, sizeof(unsigned), h->stream));
+    HIP_TRY(h, hipMemsetAsync(bpart, 0, (size_t)nsplit_total * NC * kPB * sizeof(double), h->stream));
     hipLaunchKernelGGL(prior_copy_kernel<T>, dim3(1024), dim3(kThreads), 0, h->stream, Lw, a.ldl, D, DP, W, (int64_t)DP);
     if ((rc = chol_large<T>(h, W, DP, DP, DP, info_prior))) return rc;
     hipLaunchKernelGGL(logdet_kernel<T>, dim3(1), dim3(kThreads), 0, h->stream, (const T*)W, (int64_t)DP, D, logdetLw);
+    // a failed prior factorisation short-circuits everything: seed info_chol with it
+    HIP_TRY(h, hipMemcpyAsync(info_chol, info_prior, sizeof(int32_t), hipMemcpyDeviceToDevice, h->stream));
   } else {
-    hipLaunchKernelGGL(prior_diag_kernel<T>, dim3(1), dim3(kThreads), 0, h->stream, Lw, a.ldl, a.prior_kind, D, logdetLw,
-                       info_prior);
+    // one launch: the scratch words, the noise flag and the b partials are cleared, the prior's diagonal is checked, and its
+    // status seeds info_chol (a failed prior short-circuits the factorisation)
+    ScratchInit init;
+    init.words16 = reinterpret_cast<unsigned*>(ws + o_sc);
+    init.ones = info_noise;
+    init.zeros = bpart;
+    init.nzeros = (long long)nsplit_total * NC * kPB;
+    init.info_copy = info_chol;
+    const int gridp = (int)std::min<long long>(64, 1 + init.nzeros / (8 * kThreads));
+    hipLaunchKernelGGL(prior_diag_kernel<T>, dim3(gridp), dim3(kThreads), 0, h->stream, Lw, a.ldl, a.prior_kind, D, logdetLw,
+                       info_prior, init);
   }
 
   // ---- column statistics (reference :82-84)
@@ -426,8 +436,6 @@ int posterior_large_one(blr_handle* h, const PosteriorArgs<T>& a, int64_t reg) {
 
   // ---- Gram (reference :86) : split-K partial tiles, then the prior factor as pseudo-observations
   if ((rc = set_lds<T>(h, reinterpret_cast<const void*>(gram_tile_kernel<T>), LC::LDS_BYTES))) return rc;
-  // a failed prior factorisation short-circuits everything: seed info_chol with it
-  HIP_TRY(h, hipMemcpyAsync(info_chol, info_prior, sizeof(int32_t), hipMemcpyDeviceToDevice, h->stream));
   GramTileArgs<T> g{};
   g.X = X; g.ldx = a.ldx; g.layout = a.layout;
   static const bool no_ring = getenv("BLR_MI355X_NO_GRAM_RING") != nullptr;  // A/B experiments only

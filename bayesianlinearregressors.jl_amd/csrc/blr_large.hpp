@@ -1346,9 +1346,25 @@ __global__ __launch_bounds__(kThreads) void logdet_kernel(const T* Lf, int64_t l
 }
 
 // logdet of a diagonal (kind 2) or of an upper factor's diagonal (kind 1); info = first non-positive entry
+// Scratch initialisation that rides along with prior_diag_kernel (every dependent dispatch costs ~5 us on this part: three
+// hipMemsetAsync and a 4-byte device-to-device copy were 20 us of an update).  All pointers optional.
+struct ScratchInit {
+  unsigned* words16 = nullptr;   // 16 words set to zero BEFORE the kernel's own results land in them
+  unsigned* ones = nullptr;      // one word set to 0xFFFFFFFF
+  double* zeros = nullptr;       // nzeros doubles set to zero (all workgroups of the launch share the work)
+  long long nzeros = 0;
+  int32_t* info_copy = nullptr;  // receives the same status as `info`
+};
+
 template <typename T>
 __global__ __launch_bounds__(kThreads) void prior_diag_kernel(const T* Lw, int64_t ldl, int kind, int D, double* out,
-                                                              int32_t* info) {
+                                                              int32_t* info, ScratchInit init = ScratchInit()) {
+  for (long long i = (long long)blockIdx.x * kThreads + threadIdx.x; i < init.nzeros; i += (long long)gridDim.x * kThreads)
+    init.zeros[i] = 0.0;
+  if (blockIdx.x != 0) return;
+  if (init.words16 && threadIdx.x < 16) init.words16[threadIdx.x] = (init.words16 + threadIdx.x == init.ones) ? 0xFFFFFFFFu : 0u;
+  if (init.ones && threadIdx.x == 0 && (init.words16 == nullptr || init.ones < init.words16 || init.ones >= init.words16 + 16))
+    *init.ones = 0xFFFFFFFFu;
   __shared__ double scr[8];
   __shared__ int iscr[8];
   double v = 0.0;
@@ -1358,15 +1374,15 @@ __global__ __launch_bounds__(kThreads) void prior_diag_kernel(const T* Lw, int64
     if (d > T(0)) v += log((double)d);
     else bad = min(bad, j + 1);
   }
-  bad = block_min_int(bad, iscr, threadIdx.x);
+  bad = block_min_int(bad, iscr, threadIdx.x);  // (barriers: the words above are zero before thread 0 writes below)
   v = block_allreduce(v, scr, threadIdx.x);
   if (threadIdx.x == 0) {
     if (out) *out = (kind == PRIOR_DIAGONAL) ? v : 2.0 * v;
     *info = (bad == 0x7fffffff) ? 0 : bad;
+    if (init.info_copy) *init.info_copy = (bad == 0x7fffffff) ? 0 : bad;
   }
 }
 
-// dense symmetric prior (upper triangle read) -> lower triangle of a DP x DP work matrix with unit padding
 template <typename T>
 __global__ __launch_bounds__(kThreads) void prior_copy_kernel(const T* Lw, int64_t ldl, int D, int DP, T* W, int64_t ldw) {
   for (int64_t e = (int64_t)blockIdx.x * kThreads + threadIdx.x; e < (int64_t)DP * DP; e += (int64_t)gridDim.x * kThreads) {

@@ -173,14 +173,15 @@ __device__ __forceinline__ void col_fill(float (&a)[16], float ln) {
   }
 }
 template <int C, bool NEWTON>
-__device__ __forceinline__ void tile_factor_col_f32(float (&a)[16], float (&y)[4], float ln, float rs, int r, float half) {
+__device__ __forceinline__ void tile_factor_col_f32(float (&a)[16], float (&y)[4], float ln, float rs, const uint64_t (&below)[16],
+                                                    float half) {
   // on entry: a[C] = L(r, C) past its wait states, ln = -a[C], rs = 1 / L(C, C)
   float t;
   if constexpr (C < 15) {
     constexpr int n = C + 1;
     vfmac_bc16<n>(a[n], a[C], ln);                                                                  // chain
     BLR_VA("v_mul_f32 %0, %1, %2" : "=v"(t) : "v"(ln), "v"(rs));                                    // (wait state)
-    BLR_VA("v_cmp_lt_u32 vcc, %1, %2\n\tv_cndmask_b32 %0, 0, %0, vcc" : "+v"(t) : "n"(C), "v"(r) : "vcc");  // rows below C
+    BLR_VA("v_cndmask_b32 %0, 0, %0, %1" : "+v"(t) : "s"(below[C]));                                // rows below C only
     float rsn, lnn;
     BLR_VA("v_rsq_f32_dpp %0, %1 row_newbcast:%2 row_mask:0xf bank_mask:0xf" : "=v"(rsn) : "v"(a[n]), "n"(n));  // chain
     if constexpr (NEWTON) {
@@ -204,10 +205,10 @@ __device__ __forceinline__ void tile_factor_col_f32(float (&a)[16], float (&y)[4
     for (int j = 0; j < 4; ++j)
       if (4 * j <= C) vfmac_bc16<C>(y[j], y[j], t);
     col_fill<C, NEWTON ? C + 6 : C + 4, 16>(a, ln);
-    tile_factor_col_f32<C + 1, NEWTON>(a, y, lnn, rsn, r, half);
+    tile_factor_col_f32<C + 1, NEWTON>(a, y, lnn, rsn, below, half);
   } else {
     BLR_VA("v_mul_f32 %0, %1, %2" : "=v"(t) : "v"(ln), "v"(rs));
-    BLR_VA("v_cmp_lt_u32 vcc, %1, %2\n\tv_cndmask_b32 %0, 0, %0, vcc" : "+v"(t) : "n"(C), "v"(r) : "vcc");
+    BLR_VA("v_cndmask_b32 %0, 0, %0, %1" : "+v"(t) : "s"(below[C]));
 #pragma unroll
     for (int j = 0; j < 4; ++j) vfmac_bc16<C>(y[j], y[j], t);
   }
@@ -216,8 +217,13 @@ __device__ __forceinline__ void tile_factor_col_f32(float (&a)[16], float (&y)[4
 #ifndef BLR_PANEL_NEWTON
 #define BLR_PANEL_NEWTON 0
 #endif
+// below[C]: lanes whose row (lane & 15) lies below row C -- wave-uniform masks, made once per kernel
+__device__ __forceinline__ void tile_row_masks(uint64_t (&below)[16], int lane) {
+#pragma unroll
+  for (int c = 0; c < 16; ++c) below[c] = __ballot((lane & 15) > c);
+}
 template <typename T>
-__device__ __forceinline__ void tile_factor_invert(T (&a)[16], T (&y)[4], int lane) {
+__device__ __forceinline__ void tile_factor_invert(T (&a)[16], T (&y)[4], const uint64_t (&below)[16], int lane) {
   const int r = lane & 15, q = lane >> 4;
 #pragma unroll
   for (int j = 0; j < 4; ++j) y[j] = (r == 4 * j + q) ? T(1) : T(0);
@@ -235,7 +241,7 @@ __device__ __forceinline__ void tile_factor_invert(T (&a)[16], T (&y)[4], int la
     }
     BLR_VA("v_mul_f32 %0, -%1, %2" : "=v"(ln) : "v"(a[0]), "v"(rs));
     BLR_VA("v_mul_f32 %0, %0, %1\n\ts_nop 1" : "+v"(a[0]) : "v"(rs));
-    tile_factor_col_f32<0, BLR_PANEL_NEWTON != 0>(a, y, ln, rs, r, half);
+    tile_factor_col_f32<0, BLR_PANEL_NEWTON != 0>(a, y, ln, rs, below, half);
   } else {
     const T d2 = mov_bc16_gap<0>(a[0]);
     const T rs = fast_rsqrt(d2);
@@ -459,6 +465,8 @@ __global__ __launch_bounds__(64 * NW, 1) void panel_chain_kernel(T* Abar, int64_
     acc4 d1 = tile_from_global<T>(blk, lda, 16, 16, lane);
 #pragma unroll
     for (int e = 0; e < 4; ++e) { d[e] = -d[e]; d1[e] = -d1[e]; }
+    uint64_t below[16];
+    tile_row_masks(below, lane);
     BLR_STAMP(0);
     BLR_TL(0);
 #pragma unroll 1
@@ -477,7 +485,7 @@ __global__ __launch_bounds__(64 * NW, 1) void panel_chain_kernel(T* Abar, int64_
         for (int e = 0; e < V; ++e) a[V * u + e] = t[e];
       }
       BLR_STAMP(1);
-      tile_factor_invert<T>(a, y, lane);
+      tile_factor_invert<T>(a, y, below, lane);
       BLR_STAMP(2);
       BLR_TL(1 + 4 * J);
       // publish: the row-scaled inverse as B-fragments and the factor's rows (write-back, diagonal for the solves)
@@ -493,6 +501,10 @@ __global__ __launch_bounds__(64 * NW, 1) void panel_chain_kernel(T* Abar, int64_
         }
       }
       const T dgv = LDIAG[(J * 16 + r) * C::LDD + r];  // (own write: no barrier needed)
+      const T sc = -fast_rcp(dgv);
+      T ys[4];  // -Linv(r, 4 ks + q): the inverse with its row scaling divided out and the sign of the negated images folded in
+#pragma unroll
+      for (int ks = 0; ks < 4; ++ks) ys[ks] = y[ks] * sc;
       __syncthreads();  // B1: the inverse of tile J and the pre-solve images of column J are there
       // A_pp and X have been read by now (the update waves waited for their loads before B1 of step 0): arrive.
       if (J == 0 && tid == 0) __hip_atomic_fetch_add(arrive, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
@@ -501,21 +513,43 @@ __global__ __launch_bounds__(64 * NW, 1) void panel_chain_kernel(T* Abar, int64_
       BLR_STAMP(3);
       BLR_TL(2 + 4 * J);
       if (J < 7) {
-        // the one sub-diagonal tile that the next diagonal tile waits for: L(J+1, J) = A(J+1, J) Linv_J'
+        // the one sub-diagonal tile that the next diagonal tile waits for, L(J+1, J) = A(J+1, J) Linv_J', then tile J+1 -= L L'
         acc4 dn;
         if (J == 0) dn = d1;
         else dn = tile_from_image<T>(DIN + ((J + 1) & 1) * 256, lane);
-        const acc4 z = solve_tile<T>(PRE + J * 256, y, -fast_rcp(dgv), fo);
-        tile_to_image<T>(CSCR, z, lane);
-        T f[4];
-        load_frags<T>(CSCR, fo, f);
-        acc4 w = {T(0), T(0), T(0), T(0)};
-        dn = Mfma<T>::mma(f[0], f[0], dn);
-        w = Mfma<T>::mma(f[1], f[1], w);
-        dn = Mfma<T>::mma(f[2], f[2], dn);
-        w = Mfma<T>::mma(f[3], f[3], w);
+        T fa[4], f[4];
+        load_frags<T>(PRE + J * 256, fo, fa);
+        if constexpr (sizeof(T) == 4) {
+          // computed TRANSPOSED (Linv_J A'): the accumulator then holds L(c, 4 q + e), and swapping the roles of the 16-lane
+          // row index q and the register index e -- four v_permlane swaps -- makes register e fragment e.  No LDS round trip.
+          acc4 z0 = {T(0), T(0), T(0), T(0)}, z1 = {T(0), T(0), T(0), T(0)};
+          z0 = Mfma<T>::mma(ys[0], fa[0], z0);
+          z1 = Mfma<T>::mma(ys[1], fa[1], z1);
+          z0 = Mfma<T>::mma(ys[2], fa[2], z0);
+          z1 = Mfma<T>::mma(ys[3], fa[3], z1);
+          unsigned w[4];
 #pragma unroll
-        for (int e = 0; e < 4; ++e) d[e] = dn[e] + w[e];
+          for (int e = 0; e < 4; ++e) w[e] = __float_as_uint(z0[e] + z1[e]);
+          auto p01 = __builtin_amdgcn_permlane16_swap(w[0], w[1], false, false);
+          auto p23 = __builtin_amdgcn_permlane16_swap(w[2], w[3], false, false);
+          auto p02 = __builtin_amdgcn_permlane32_swap(p01[0], p23[0], false, false);
+          auto p13 = __builtin_amdgcn_permlane32_swap(p01[1], p23[1], false, false);
+          f[0] = __uint_as_float(p02[0]);
+          f[2] = __uint_as_float(p02[1]);
+          f[1] = __uint_as_float(p13[0]);
+          f[3] = __uint_as_float(p13[1]);
+        } else {
+          const acc4 z = solve_tile<T>(PRE + J * 256, y, sc, fo);
+          tile_to_image<T>(CSCR, z, lane);
+          load_frags<T>(CSCR, fo, f);
+        }
+        acc4 w2 = {T(0), T(0), T(0), T(0)};
+        dn = Mfma<T>::mma(f[0], f[0], dn);
+        w2 = Mfma<T>::mma(f[1], f[1], w2);
+        dn = Mfma<T>::mma(f[2], f[2], dn);
+        w2 = Mfma<T>::mma(f[3], f[3], w2);
+#pragma unroll
+        for (int e = 0; e < 4; ++e) d[e] = dn[e] + w2[e];
       }
       BLR_STAMP(4);
       BLR_TL(3 + 4 * J);
@@ -674,22 +708,20 @@ __global__ __launch_bounds__(64 * NW, 1) void panel_chain_kernel(T* Abar, int64_
     }
   }
   __syncthreads();  // B3
-  if (wave == 0) {
+  // the eight diagonal tiles (lower triangles) from the rows the chain wave left in LDIAG, one tile per wave ...
+  for (int K = wave; K < 8; K += NW) {
 #pragma unroll
-    for (int h = 0; h < 2; ++h) {
-      const int K = q + 4 * h;
-#pragma unroll
-      for (int c = 0; c < 16; ++c)
-        if (c <= r) blk[(int64_t)(16 * K + c) * lda + 16 * K + r] = LDIAG[(K * 16 + r) * C::LDD + c];
+    for (int e = 0; e < 4; ++e) {
+      const int rho = Mfma<T>::crow(lane, e);
+      if (r <= rho) blk[(int64_t)(16 * K + r) * lda + 16 * K + rho] = LDIAG[(K * 16 + rho) * C::LDD + r];
     }
-  } else {
-    // the 28 off-diagonal tiles of the block from their output image: tile (row id R, column J) at LOUT[J * 7 + R]
-    for (int t = wave - 1; t < 49; t += C::NU) {
-      const int J = t / 7, R = t % 7;
-      if (R >= J) {
-        const acc4 v = tile_from_image<T>(LOUT + C::lout(J, R) * 256, lane);
-        tile_to_global<T>(blk, lda, 16 * (R + 1), 16 * J, v, lane);
-      }
+  }
+  // ... and the 28 off-diagonal tiles of the block from their output image
+  for (int t = wave; t < 49; t += NW) {
+    const int J = t / 7, R = t % 7;
+    if (R >= J) {
+      const acc4 v = tile_from_image<T>(LOUT + C::lout(J, R) * 256, lane);
+      tile_to_global<T>(blk, lda, 16 * (R + 1), 16 * J, v, lane);
     }
   }
   BLR_TL(34);
