@@ -65,8 +65,13 @@ __global__ __launch_bounds__(kThreads) void colstats_kernel(ColstatsArgs<T> a) {
   double* const scr = reinterpret_cast<double*>(smem + (((size_t)a.D * sizeof(T) + 15) & ~(size_t)15));
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int D = a.D, N = a.N;
-  for (int d = tid; d < D; d += kThreads) mwl[d] = a.mw[d];
-  __syncthreads();
+  int mw_nonzero = 0;
+  for (int d = tid; d < D; d += kThreads) {
+    const T m = a.mw[d];
+    mwl[d] = m;
+    mw_nonzero |= (m != T(0));  // (NaN counts as non-zero: the general path propagates it)
+  }
+  mw_nonzero = __syncthreads_or(mw_nonzero);
   const bool diag = a.noise_kind == NOISE_DIAGONAL;
   const T s_iso = diag ? T(1) : a.s[0];
   double q = 0.0, l = 0.0;
@@ -74,7 +79,19 @@ __global__ __launch_bounds__(kThreads) void colstats_kernel(ColstatsArgs<T> a) {
   typedef T vecT __attribute__((ext_vector_type(Mfma<T>::VEC)));
   constexpr int VEC = Mfma<T>::VEC;
   const bool vec_ok = a.layout == LAYOUT_COLVECS && (D % VEC) == 0 && (a.ldx % VEC) == 0 && ((uintptr_t)a.X % 16) == 0;
-  if (vec_ok) {
+  if (!mw_nonzero) {
+    // zero prior mean (the reference's usual prior, and SURVEY 8(d)'s): X'mw = 0 exactly, so delta = y and this pass does not
+    // have to read X at all (42 us of HBM streaming at D = 1024, N = 65536)
+    for (int n = blockIdx.x * kThreads + tid; n < N; n += gridDim.x * kThreads) {
+      const T sv = diag ? a.s[n] : s_iso;
+      if (!(sv > T(0))) bad = min(bad, (unsigned)(n + 1));
+      const T delta = a.y[n];
+      const T rn = delta / sv;
+      a.r[n] = rn;
+      q += (double)delta * (double)rn;
+      if (diag) l += log((double)sv);
+    }
+  } else if (vec_ok) {
     // two columns per wave per step, 16-byte loads, up to 8 loads in flight per lane before the first use
     const int DV = D / VEC;
     const vecT* mwv = reinterpret_cast<const vecT*>(mwl);
