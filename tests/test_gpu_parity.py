@@ -551,6 +551,50 @@ def test_large_d_posterior_logpdf_f64(B, N, D, prior):
         np.testing.assert_allclose(f2.mw, mw_o, rtol=1e-8, atol=1e-10)
 
 
+@pytest.mark.parametrize("dtype", [np.float64, np.float32])
+@pytest.mark.parametrize("noise", ["iso", "diag"])
+def test_large_d_zero_prior_mean(B, dtype, noise):
+    # A zero prior mean takes the branch of the column-statistics kernel that never reads X (delta = y exactly); the result
+    # has to be the oracle's all the same, in both layouts, and has to agree with a prior mean that is merely tiny.
+    rng = _rng(5151)
+    D, N = 320, 900
+    X = rng.standard_normal((D, N)).astype(dtype)
+    s = np.exp(0.4 * rng.standard_normal(N)).astype(dtype) if noise == "diag" else dtype(0.37)
+    y = (X.T.astype(float) @ rng.standard_normal(D) / np.sqrt(D) + rng.standard_normal(N)).astype(dtype)
+    dvec = np.exp(0.3 * rng.standard_normal(D)).astype(dtype)
+    s_full = s if noise == "diag" else np.full(N, float(s))
+    mw_o, T_o, A_o, lp_o = O.posterior_logpdf_direct(np.zeros(D), np.diag(dvec.astype(float)), X.astype(float), np.asarray(s_full, float),
+                                                     y.astype(float))
+    f = B.BayesianLinearRegressor(np.zeros(D, dtype), B.Diagonal(dvec))
+    tol = 1e-9 if dtype == np.float64 else 2e-3
+    for x in (np.asfortranarray(X), B.RowVecs(np.asfortranarray(X.T))):
+        fx = f(x, s)
+        assert B.logpdf(fx, y) == pytest.approx(lp_o, rel=tol)
+        np.testing.assert_allclose(B.posterior(fx, y).mw, mw_o, rtol=tol * 10, atol=tol)
+    f_tiny = B.BayesianLinearRegressor(np.full(D, 1e-30, dtype), B.Diagonal(dvec))  # the general branch, same numbers
+    assert B.logpdf(f_tiny(np.asfortranarray(X), s), y) == pytest.approx(B.logpdf(f(np.asfortranarray(X), s), y), rel=tol)
+
+
+@pytest.mark.parametrize("dtype", [np.float64, np.float32])
+@pytest.mark.parametrize("col", [0, 5, 16, 130, 255, 300, 329])
+def test_large_d_factorisation_names_the_first_bad_pivot(B, dtype, col):
+    # The panel kernel finds a non-positive pivot as a NaN on the factor's diagonal and has to name its column (1-based, as
+    # LAPACK's info) wherever it falls: first tile of the first panel, a tile boundary, a later panel, the ragged last one.
+    rng = _rng(5200 + col)
+    D, N = 330, 400
+    X = rng.standard_normal((D, N)).astype(dtype)
+    Bm = rng.standard_normal((D, D)) / np.sqrt(D)
+    Lw = Bm @ Bm.T + np.eye(D)
+    # make the leading minor of order col + 1 the first that is not positive definite
+    Lc = np.linalg.cholesky(Lw)
+    Lc[col, col] = 0.0
+    Lw_bad = Lc @ Lc.T
+    Lw_bad[col, col] -= 1.0
+    with pytest.raises(B.PosDefException) as ei:
+        B.posterior(B.BayesianLinearRegressor(np.zeros(D, dtype), Lw_bad.astype(dtype))(np.asfortranarray(X), dtype(0.5)), np.zeros(N, dtype))
+    assert ei.value.info == col + 1
+
+
 def test_large_d_f32_c3_shape_reduced(B):
     # BASELINE config 3 shape family (D=1024, diagonal noise, fp32) at a reduced N the oracle finishes in seconds
     rng = _rng(6001)
