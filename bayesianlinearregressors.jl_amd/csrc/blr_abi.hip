@@ -359,9 +359,45 @@ int posterior_large_one(blr_handle* h, const PosteriorArgs<T>& a, int64_t reg) {
     const double eff = (double)wgs / (rounds * (double)slots) - 0.002 * sp;  // mild preference for fewer partials
     if (eff > best) { best = eff; nsplit = sp; }
   }
+  // Diagonal macro tiles cost less per column than off-diagonal ones in the ring loop (only the 36 tiles of 16 x 16 on or below
+  // the diagonal are computed: 10 MFMAs per k-step on the critical waves instead of 16; measured ~11.5 with the b partials
+  // riding along), so in a single-round launch they get their OWN split factor: fewer, longer column ranges, and the
+  // workgroup slots that frees go to the off-diagonal tiles.  Chosen so that the longest workgroup is shortest
+  // (c3: 36 x 14 -> 28 x 15 + 8 x 11, i.e. 16 N / 14 -> 16 N / 15 per workgroup on 508 of 512 slots: 0.963 -> 0.935 ms;
+  // tools/scan_splits.sh).  Multi-round launches (c5: 136 tiles x 15) keep one factor: there the dispatcher balances.
+  constexpr double kDiagCost = 11.5;
+  int nsplit_diag = 0;  // 0: one factor for all tiles
+  {
+    const int slots = 256 * (sizeof(T) == 4 ? BLR_GRAM_WGS : 2);
+    // (only where the diagonal tiles will go through the ring loop: f32, LDS-DMA staging, whole row blocks)
+    const T* X0 = a.X + reg * a.strideX;
+    const bool dealt = sizeof(T) == 4 && a.layout == LAYOUT_COLVECS && ((uintptr_t)X0 % 16 == 0) &&
+                       ((a.ldx * (int64_t)sizeof(T)) % 16 == 0) && getenv("BLR_MI355X_NO_GRAM_RING") == nullptr &&
+                       getenv("BLR_MI355X_NO_DIAG_SPLIT") == nullptr && D % kPB == 0 && NC >= 2 && ntiles * nsplit <= slots;
+    if (dealt) {
+      auto cols = [&](int sp) { return (double)(((N + sp - 1) / sp + nstage_cols - 1) / nstage_cols * nstage_cols); };
+      const int n_off = ntiles - NC;
+      double best_t = 16.0 * cols(nsplit);  // today's longest workgroup (diagonal tiles shorter, off-diagonal ones set the time)
+      int bo = 0, bd = 0;
+      for (int so = 1; so <= max_split; ++so)
+        for (int sd = 1; sd <= so; ++sd) {
+          if (n_off * so + NC * sd > slots) break;
+          const double t = std::max(16.0 * cols(so), kDiagCost * cols(sd)) * (1.0 + 0.002 * so);
+          if (t < best_t * 0.995) { best_t = t; bo = so; bd = sd; }
+        }
+      if (bo > 0) { nsplit = bo; nsplit_diag = bd; }
+      if (const char* e = getenv("BLR_MI355X_GRAM_SPLITS")) {  // "off-diagonal,diagonal": measurements only
+        int so = 0, sd = 0;
+        if (sscanf(e, "%d,%d", &so, &sd) == 2 && so >= 1 && sd >= 1 && sd <= so && so <= max_split && n_off * so + NC * sd <= 2 * slots) {
+          nsplit = so;
+          nsplit_diag = sd;
+        }
+      }
+    }
+  }
   const bool prior_factor = a.prior_kind == PRIOR_UPPER_FACTOR;
   const int pf = prior_factor ? 1 : 0;
-  const int nsplit_total = nsplit + pf;
+  const int nsplit_total = nsplit + pf;  // (nsplit_diag <= nsplit: the partial workspace is laid out for the larger factor)
   const int gridc = 1024;
 
   const int64_t gp_tiles = (int64_t)nsplit_total * ntiles;
@@ -450,13 +486,15 @@ int posterior_large_one(blr_handle* h, const PosteriorArgs<T>& a, int64_t reg) {
   // launches the tiles described by g (+ the prior-factor pseudo split) and their reduction on `st`
   auto gram_tiles = [&](hipStream_t st, int nsp, int nt, T* gp) {
     g.nsplit = nsp; g.ntiles = nt; g.Gpart = gp;
+    g.nsplit_diag = nsplit_diag;
     g.xcd_swizzle = (nsp > 1 && !no_swizzle) ? 1 : 0;
-    hipLaunchKernelGGL(gram_tile_kernel<T>, dim3(nt * nsp), dim3(kThreads), LC::LDS_BYTES, st, g);
+    const int nwg = nsplit_diag ? (nt - NC) * nsp + NC * nsplit_diag : nt * nsp;
+    hipLaunchKernelGGL(gram_tile_kernel<T>, dim3(nwg), dim3(kThreads), LC::LDS_BYTES, st, g);
     if (prior_factor) {
       GramTileArgs<T> u = g;
       u.xcd_swizzle = 0;
       u.X = Lw; u.ldx = a.ldl; u.layout = 2; u.use_dma = 0; u.s = nullptr; u.r = nullptr;
-      u.n_begin = 0; u.n_end = D; u.nsplit = 1;
+      u.n_begin = 0; u.n_end = D; u.nsplit = 1; u.nsplit_diag = 0;
       u.Gpart = gp + (int64_t)nsp * nt * kPB * kPB;
       u.bpart = bpart + (int64_t)nsp * NC * kPB;
       hipLaunchKernelGGL(gram_tile_kernel<T>, dim3(nt), dim3(kThreads), LC::LDS_BYTES, st, u);
@@ -464,6 +502,7 @@ int posterior_large_one(blr_handle* h, const PosteriorArgs<T>& a, int64_t reg) {
   };
   auto gram_reduce = [&](hipStream_t st, int nsp, int nt, T* gp, int reduce_blocks) {
     r.Gpart = gp; r.nsplit_total = nsp + pf; r.ntiles = nt;
+    r.nsplit_diag = nsplit_diag; r.pseudo_split = pf;
     hipLaunchKernelGGL(gram_reduce_kernel<T>, dim3(nt + reduce_blocks, 16), dim3(kThreads), 0, st, r);
   };
 

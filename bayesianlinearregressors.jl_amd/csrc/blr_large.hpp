@@ -190,41 +190,77 @@ struct GFrag {
   T a[4], b[4];
 };
 
-// one k-step: the 16 MFMAs of `fc` (A side scaled by w: Sigma_y^-1 of this lane's column, 1 when SCALE is off) with the reads of
-// the next k-step's fragments and one slot of side work (`side`: LDS-DMA pieces, weight reads / reciprocals) between them
-template <typename T, bool SCALE, typename P>
+// one k-step: the MFMAs of `fc` (A side scaled by w: Sigma_y^-1 of this lane's column, 1 when SCALE is off) with the reads of
+// the next k-step's fragments and one slot of side work (`side`: LDS-DMA pieces, weight reads / reciprocals) between them.
+// ROLE 0: all 16 tiles of the wave's 64 x 64 quadrant.  Diagonal macro tiles (only their lower triangle is ever read) deal
+// their 36 useful 16 x 16 tiles as 10 + 10 + 8 + 8:  ROLE 1 (the two diagonal quadrants): the 10 tiles with k <= i;
+// ROLE 2 (the quadrant below the diagonal, shared by two waves): tile rows 0, 1 of the wave's half, 8 tiles, fn.a[0..1] only;
+// `side2(piece)`, pieces 0..3, is more side work dealt between its last MFMAs (the b partials of the wave that used to sit out).
+template <typename T, bool SCALE, int ROLE, typename P, typename P2>
 __device__ __forceinline__ void gram_kstep_ring(typename Mfma<T>::acc4 (&acc)[4][4], const GFrag<T>& fc, GFrag<T>& fn, T w,
-                                                const T* __restrict__ kA_n, const T* __restrict__ kB_n, P side) {
+                                                const T* __restrict__ kA_n, const T* __restrict__ kB_n, P side, P2 side2) {
   T fa[4];
 #pragma unroll
   for (int i = 0; i < 4; ++i) fa[i] = SCALE ? fc.a[i] * w : fc.a[i];  // Sigma_y^-1 on the A side only
-  auto mma = [&](auto mtag) {
-    constexpr int m = decltype(mtag)::value;
-    acc[m >> 2][m & 3] = Mfma<T>::mma(fa[m >> 2], fc.b[m & 3], acc[m >> 2][m & 3]);
+  auto mma = [&](auto itag, auto ktag) {
+    constexpr int i = decltype(itag)::value, k = decltype(ktag)::value;
+    acc[i][k] = Mfma<T>::mma(fa[i], fc.b[k], acc[i][k]);
   };
 #define BLR_SB __builtin_amdgcn_sched_barrier(0)
-#define BLR_IC(k) std::integral_constant<int, k>{}
-  BLR_SB; mma(BLR_IC(0)); BLR_SB;
-  fn.a[0] = kA_n[0]; fn.a[1] = kA_n[64];
-  BLR_SB; mma(BLR_IC(1)); BLR_SB;
-  fn.a[2] = kA_n[128]; fn.a[3] = kA_n[192];
-  BLR_SB; mma(BLR_IC(2)); BLR_SB;
-  fn.b[0] = kB_n[0]; fn.b[1] = kB_n[64];
-  BLR_SB; mma(BLR_IC(3)); BLR_SB;
-  fn.b[2] = kB_n[128]; fn.b[3] = kB_n[192];
-  BLR_SB; mma(BLR_IC(4)); BLR_SB;
-  side();
-  BLR_SB; mma(BLR_IC(5)); BLR_SB; mma(BLR_IC(6)); BLR_SB; mma(BLR_IC(7)); BLR_SB;
-  mma(BLR_IC(8)); BLR_SB; mma(BLR_IC(9)); BLR_SB; mma(BLR_IC(10)); BLR_SB; mma(BLR_IC(11)); BLR_SB;
-  mma(BLR_IC(12)); BLR_SB; mma(BLR_IC(13)); BLR_SB; mma(BLR_IC(14)); BLR_SB; mma(BLR_IC(15)); BLR_SB;
+#define BLR_M(i, k) BLR_SB; mma(std::integral_constant<int, i>{}, std::integral_constant<int, k>{}); BLR_SB
+  if constexpr (ROLE == 0) {
+    BLR_M(0, 0);
+    fn.a[0] = kA_n[0]; fn.a[1] = kA_n[64];
+    BLR_M(0, 1);
+    fn.a[2] = kA_n[128]; fn.a[3] = kA_n[192];
+    BLR_M(0, 2);
+    fn.b[0] = kB_n[0]; fn.b[1] = kB_n[64];
+    BLR_M(0, 3);
+    fn.b[2] = kB_n[128]; fn.b[3] = kB_n[192];
+    BLR_M(1, 0);
+    side();
+    BLR_M(1, 1); BLR_M(1, 2); BLR_M(1, 3);
+    BLR_M(2, 0); BLR_M(2, 1); BLR_M(2, 2); BLR_M(2, 3);
+    BLR_M(3, 0); BLR_M(3, 1); BLR_M(3, 2); BLR_M(3, 3);
+  } else if constexpr (ROLE == 1) {
+    BLR_M(0, 0);
+    fn.a[0] = kA_n[0]; fn.a[1] = kA_n[64];
+    BLR_M(1, 0);
+    fn.a[2] = kA_n[128]; fn.a[3] = kA_n[192];
+    BLR_M(1, 1);
+    fn.b[0] = kB_n[0]; fn.b[1] = kB_n[64];
+    BLR_M(2, 0);
+    fn.b[2] = kB_n[128]; fn.b[3] = kB_n[192];
+    BLR_M(2, 1);
+    side();
+    BLR_M(2, 2); BLR_M(3, 0); BLR_M(3, 1); BLR_M(3, 2); BLR_M(3, 3);
+  } else {
+    BLR_M(0, 0);
+    fn.a[0] = kA_n[0]; fn.a[1] = kA_n[64];
+    BLR_M(0, 1);
+    fn.b[0] = kB_n[0]; fn.b[1] = kB_n[64];
+    BLR_M(0, 2);
+    fn.b[2] = kB_n[128]; fn.b[3] = kB_n[192];
+    BLR_M(0, 3);
+    side();
+    BLR_M(1, 0);
+    side2(std::integral_constant<int, 0>{});
+    BLR_M(1, 1);
+    side2(std::integral_constant<int, 1>{});
+    BLR_M(1, 2);
+    side2(std::integral_constant<int, 2>{});
+    BLR_M(1, 3);
+    side2(std::integral_constant<int, 3>{});
+  }
 #undef BLR_SB
-#undef BLR_IC
+#undef BLR_M
 }
 
 // columns [c0, c0 + 16 nh) of the operand rows rowA.. (A side) and rowB.. (B side); baseA / baseB point at (row, column 0).
-// DIAGT: diagonal macro tile -- one side only (B = A), and the wave of the quadrant above the diagonal (wr = 0, wc = 1), whose
-// tiles nobody reads, leaves the matrix pipe alone and accumulates b_I = X_I r instead (r != NULL) while it keeps taking part
-// in the DMA issue and the barriers.
+// DIAGT: diagonal macro tile -- one side only (B = A) and only the 36 tiles of 16 x 16 on or below the diagonal: waves 0 and 3
+// take the 10 of their diagonal quadrant (acc[i][k], k <= i), waves 2 and 1 share the quadrant below the diagonal (its tile rows
+// 0-1 / 2-3, acc[0..1][k]); wave 1 -- which used to sit out -- also accumulates b_I = X_I r (r != NULL).  10 MFMAs per k-step
+// on the critical waves instead of 16: the host gives diagonal tiles longer column ranges (fewer splits) to match.
 template <typename T, bool SCALE, bool DIAGT>
 __device__ __forceinline__ void gram_ring_loop(T* __restrict__ ring, T* __restrict__ wring, T* __restrict__ rring,
                                                const BLR_GLOBAL T* baseA, int64_t ldA, const BLR_GLOBAL T* baseB, int64_t ldB,
@@ -239,7 +275,7 @@ __device__ __forceinline__ void gram_ring_loop(T* __restrict__ ring, T* __restri
   unsigned ring_addr = lds_addr_of(ring), wring_addr = lds_addr_of(wring), rring_addr = lds_addr_of(rring);
   asm volatile("" : "+v"(ring_addr), "+v"(wring_addr), "+v"(rring_addr));  // pinned in VGPRs (see gram_iso_ring)
   const bool w_piece = SCALE && wave == 0;
-  const bool b_wave = DIAGT && wave == 1;            // the idle quadrant's wave
+  const bool b_wave = DIAGT && wave == 1;            // the wave that also accumulates the b partials
   const bool r_piece = b_wave && r != nullptr;
   const int npieces = 2 + (DIAGT ? 0 : 2) + (w_piece ? 1 : 0) + (r_piece ? 1 : 0);  // LDS-DMA instructions of this wave per half
   // this wave's pieces of a half: g = wave (k-step wave / 2, row blocks 4 (wave & 1) ..) and g = 4 + wave, on both sides.  Their
@@ -282,78 +318,97 @@ __device__ __forceinline__ void gram_ring_loop(T* __restrict__ ring, T* __restri
   for (int h = 0; h < 3 && h < nh; ++h) { issue_first(); issue_second(); }
   retire(nh > 2);
   __syncthreads();
-  if (b_wave) {
-    // no MFMAs for this wave: per k-step 8 fragment reads and 8 f64 FMAs of the b partials (or nothing), DMA issue, barriers
+  // the main loop, once per wave role (the role is wave-uniform; each instance is its own pinned instruction stream)
+  auto run = [&](auto role_tag) {
+    constexpr int ROLE = decltype(role_tag)::value;
+    GFrag<T> f0 = {}, f1 = {};
+    // weights of this lane's column in the four k-steps of the current half (wcur) and of the next one (wnxt): every wave turns
+    // the raw variances into reciprocals itself, half a stage ahead of their use, off the MFMA issue path
+    T wcur[4] = {T(1), T(1), T(1), T(1)}, wnxt[4] = {T(1), T(1), T(1), T(1)};
+    const int offB = DIAGT ? 0 : SIDE;  // diagonal tile: both operands come from the one side
+    // first tile row (A side) and first tile column (B side) of this wave's fragments
+    const int rowA0 = ROLE == 2 ? 4 + 2 * (wave == 1 ? 1 : 0) : 4 * wr;
+    const int colB0 = ROLE == 2 ? 0 : 4 * wc;
+    constexpr int NA = ROLE == 2 ? 2 : 4;
+    // b partials (ROLE 2, wave 1): the eight A-side fragments of a k-step and this lane's r, read one k-step ahead of their use
+    T bf[8] = {T(0), T(0), T(0), T(0), T(0), T(0), T(0), T(0)};
+    T brn = T(0), brn_next = T(0);
+    const bool do_b = ROLE == 2 && b_wave && r != nullptr;
+    {
+      const T* kA = ring + rowA0 * 64 + lane;
+      const T* kB = ring + offB + colB0 * 64 + lane;
+#pragma unroll
+      for (int i = 0; i < 4; ++i) { f0.a[i] = i < NA ? kA[i * 64] : T(0); f0.b[i] = kB[i * 64]; }
+      if constexpr (SCALE) {
+#pragma unroll
+        for (int j = 0; j < 4; ++j) wcur[j] = fast_rcp(wring[4 * j + (lane >> 4)]);
+      }
+    }
+    __builtin_amdgcn_sched_barrier(0);
 #pragma unroll 1
     for (int h = 0; h < nh; ++h) {
+      // here: halves h and h+1 are visible, f0 = fragments of (h, k-step 0), half h+2 is landing
       const T* slot = ring + (h & 3) * HALF;
+      const T* slot_n = ring + ((h + 1) & 3) * HALF;
+      const T* kA = slot + rowA0 * 64 + lane;
+      const T* kB = slot + offB + colB0 * 64 + lane;
+      const T* wv_n = wring + ((h + 1) & 3) * HC + (lane >> 4);
       const T* rb = rring + (h & 3) * HC + (lane >> 4);
-      if (h + 3 < nh) { issue_first(); issue_second(); }
-      if (r != nullptr) {
+      const bool more = h + 3 < nh;  // slot (h + 3) % 4 was freed by the barrier that ended half h-1
+      auto side0 = [&] { if (more) issue_first(); };
+      auto side1 = [&] { if (more) issue_second(); };
+      auto side2 = [&] {
+        if constexpr (SCALE) {
 #pragma unroll
-        for (int j = 0; j < 4; ++j) {
-          const T rn = rb[4 * j];
-#pragma unroll
-          for (int i = 0; i < 8; ++i) bacc[i] += (double)slot[(j * 8 + i) * 64 + lane] * (double)rn;
+          for (int j = 0; j < 4; ++j) wnxt[j] = wv_n[4 * j];  // raw variances of half h+1 (visible since the last barrier)
         }
-      }
+      };
+      auto side3 = [&] {
+        if constexpr (SCALE) {
+#pragma unroll
+          for (int j = 0; j < 4; ++j) wnxt[j] = fast_rcp(wnxt[j]);
+        }
+      };
+      // b partials, two tile rows per piece: use what the previous k-step read, then read this k-step's fragments and r
+      auto bpiece = [&](int j, auto ptag) {
+        constexpr int pc = decltype(ptag)::value;
+        if constexpr (ROLE == 2) {
+          if (do_b) {
+#pragma unroll
+            for (int i = 2 * pc; i < 2 * pc + 2; ++i) {
+              bacc[i] += (double)bf[i] * (double)brn;
+              bf[i] = slot[(j * 8 + i) * 64 + lane];
+            }
+            if constexpr (pc == 0) brn_next = rb[4 * j];
+            if constexpr (pc == 3) brn = brn_next;
+          }
+        }
+      };
+      gram_kstep_ring<T, SCALE, ROLE>(acc, f0, f1, wcur[0], kA + 1 * 512, kB + 1 * 512, side0, [&](auto pt) { bpiece(0, pt); });
+      gram_kstep_ring<T, SCALE, ROLE>(acc, f1, f0, wcur[1], kA + 2 * 512, kB + 2 * 512, side1, [&](auto pt) { bpiece(1, pt); });
+      gram_kstep_ring<T, SCALE, ROLE>(acc, f0, f1, wcur[2], kA + 3 * 512, kB + 3 * 512, side2, [&](auto pt) { bpiece(2, pt); });
+      gram_kstep_ring<T, SCALE, ROLE>(acc, f1, f0, wcur[3], slot_n + rowA0 * 64 + lane, slot_n + offB + colB0 * 64 + lane, side3,
+                                      [&](auto pt) { bpiece(3, pt); });
+#pragma unroll
+      for (int j = 0; j < 4; ++j) wcur[j] = wnxt[j];
+      // ---- end of half h: publish half h+2, free the slot of half h
       if (h + 1 < nh) {
-        if (h + 2 < nh) retire(h + 3 < nh);
+        if (h + 2 < nh) retire(more);
         __syncthreads();
       }
     }
-    return;
-  }
-  GFrag<T> f0, f1;
-  // weights of this lane's column in the four k-steps of the current half (wcur) and of the next one (wnxt): every wave turns
-  // the raw variances into reciprocals itself, half a stage ahead of their use, off the MFMA issue path
-  T wcur[4] = {T(1), T(1), T(1), T(1)}, wnxt[4] = {T(1), T(1), T(1), T(1)};
-  const int offB = DIAGT ? 0 : SIDE;  // diagonal tile: both operands come from the one side
-  {
-    const T* kA = ring + (4 * wr) * 64 + lane;
-    const T* kB = ring + offB + (4 * wc) * 64 + lane;
+    if constexpr (ROLE == 2) {
+      if (do_b) {
 #pragma unroll
-    for (int i = 0; i < 4; ++i) { f0.a[i] = kA[i * 64]; f0.b[i] = kB[i * 64]; }
-    if constexpr (SCALE) {
-#pragma unroll
-      for (int j = 0; j < 4; ++j) wcur[j] = fast_rcp(wring[4 * j + (lane >> 4)]);
-    }
-  }
-  __builtin_amdgcn_sched_barrier(0);
-#pragma unroll 1
-  for (int h = 0; h < nh; ++h) {
-    // here: halves h and h+1 are visible, f0 = fragments of (h, k-step 0), half h+2 is landing
-    const T* slot = ring + (h & 3) * HALF;
-    const T* slot_n = ring + ((h + 1) & 3) * HALF;
-    const T* kA = slot + (4 * wr) * 64 + lane;
-    const T* kB = slot + offB + (4 * wc) * 64 + lane;
-    const T* wv_n = wring + ((h + 1) & 3) * HC + (lane >> 4);
-    const bool more = h + 3 < nh;  // slot (h + 3) % 4 was freed by the barrier that ended half h-1
-    auto side0 = [&] { if (more) issue_first(); };
-    auto side1 = [&] { if (more) issue_second(); };
-    auto side2 = [&] {
-      if constexpr (SCALE) {
-#pragma unroll
-        for (int j = 0; j < 4; ++j) wnxt[j] = wv_n[4 * j];  // raw variances of half h+1 (visible since the last barrier)
+        for (int i = 0; i < 8; ++i) bacc[i] += (double)bf[i] * (double)brn;
       }
-    };
-    auto side3 = [&] {
-      if constexpr (SCALE) {
-#pragma unroll
-        for (int j = 0; j < 4; ++j) wnxt[j] = fast_rcp(wnxt[j]);
-      }
-    };
-    gram_kstep_ring<T, SCALE>(acc, f0, f1, wcur[0], kA + 1 * 512, kB + 1 * 512, side0);
-    gram_kstep_ring<T, SCALE>(acc, f1, f0, wcur[1], kA + 2 * 512, kB + 2 * 512, side1);
-    gram_kstep_ring<T, SCALE>(acc, f0, f1, wcur[2], kA + 3 * 512, kB + 3 * 512, side2);
-    gram_kstep_ring<T, SCALE>(acc, f1, f0, wcur[3], slot_n + (4 * wr) * 64 + lane, slot_n + offB + (4 * wc) * 64 + lane, side3);
-#pragma unroll
-    for (int j = 0; j < 4; ++j) wcur[j] = wnxt[j];
-    // ---- end of half h: publish half h+2, free the slot of half h
-    if (h + 1 < nh) {
-      if (h + 2 < nh) retire(more);
-      __syncthreads();
     }
+  };
+  if constexpr (!DIAGT) {
+    run(std::integral_constant<int, 0>{});
+  } else {
+    if (wave == 0 || wave == 3) run(std::integral_constant<int, 1>{});
+    else run(std::integral_constant<int, 2>{});
   }
 }
 
@@ -367,6 +422,8 @@ struct GramTileArgs {
   int D;                     // rows of the operand
   int n_begin, n_end;        // column range of the whole contraction
   int nsplit;                // split-K factor over [n_begin, n_end)
+  int nsplit_diag;           // tri 1 only, 0 = nsplit: the diagonal macro tiles' own (smaller) split factor; the launch then
+                             // holds (ntiles - nblocks) nsplit off-diagonal work items followed by nblocks nsplit_diag diagonal ones
   int tile_i0, tile_j0;      // first row-block / col-block index of the tile grid
   int ntile_rows;            // row-block count of the rectangle (tri 3) / triangle (tri 4)
   int extra_row;             // tri 4: row block of the extra row of tiles
@@ -406,8 +463,29 @@ __global__ __launch_bounds__(kThreads, (sizeof(T) == 4 ? BLR_GRAM_WGS : 2)) void
     w = (xcd < rr ? xcd * (qq + 1) : rr * (qq + 1) + (xcd - rr) * qq) + (w >> 3);
   }
   int t = w % a.ntiles, sidx = w / a.ntiles;
+  int nsplit_here = a.nsplit;
   int I, J;
-  if (a.tri == 1) {
+  if (a.tri == 1 && a.nsplit_diag > 0) {
+    // two kinds of work items: the strictly lower tiles o = I (I - 1) / 2 + J with a.nsplit column ranges each, then the
+    // diagonal tiles with a.nsplit_diag
+    const int n_off = a.ntiles - a.nblocks;
+    if (w < n_off * a.nsplit) {
+      const int o = w % n_off;
+      sidx = w / n_off;
+      int ii = 1;
+      while ((ii + 1) * ii / 2 <= o) ++ii;
+      I = ii;
+      J = o - ii * (ii - 1) / 2;
+    } else {
+      const int wd = w - n_off * a.nsplit;
+      I = J = wd % a.nblocks;
+      sidx = wd / a.nblocks;
+      nsplit_here = a.nsplit_diag;
+    }
+    t = I * (I + 1) / 2 + J;
+    I += a.tile_i0;
+    J += a.tile_j0;
+  } else if (a.tri == 1) {
     int ii = 0;
     while ((ii + 1) * (ii + 2) / 2 <= t) ++ii;
     I = a.tile_i0 + ii;
@@ -436,7 +514,7 @@ __global__ __launch_bounds__(kThreads, (sizeof(T) == 4 ? BLR_GRAM_WGS : 2)) void
   const bool diag_tile = (I == J) && a.XB == nullptr;
   const int rowA = I * kPB, rowB = J * kPB;
   const int span = a.n_end - a.n_begin;
-  const int per = ((span + a.nsplit - 1) / a.nsplit + L::NSC - 1) / L::NSC * L::NSC;  // whole stages per split
+  const int per = ((span + nsplit_here - 1) / nsplit_here + L::NSC - 1) / L::NSC * L::NSC;  // whole stages per split
   const int c0 = a.n_begin + sidx * per;
   const int c1 = min(a.n_end, c0 + per);
   const int nstages = c1 > c0 ? (c1 - c0 + L::NSC - 1) / L::NSC : 0;
@@ -600,14 +678,20 @@ __global__ __launch_bounds__(kThreads, (sizeof(T) == 4 ? BLR_GRAM_WGS : 2)) void
   // ---- epilogue ------------------------------------------------------------------------------------------
   if (a.mode_out == 0) {
     T* out = a.Gpart + ((int64_t)sidx * a.ntiles + t) * (kPB * kPB);
+    // which 16 x 16 tile acc[i][k] is: the wave's quadrant, or -- diagonal macro tile through the ring loop -- the dealing of
+    // gram_ring_loop (waves 0, 3: k <= i of their diagonal quadrant; waves 2, 1: tile rows 4-5 / 6-7, columns 0-3)
+    const bool dealt = ring_done && diag_tile;
+    const bool half_role = dealt && (wave == 1 || wave == 2);
+    const int tr0 = half_role ? 4 + 2 * (wave == 1 ? 1 : 0) : 4 * wr, tc0 = half_role ? 0 : 4 * wc;
 #pragma unroll
     for (int i = 0; i < 4; ++i)
 #pragma unroll
       for (int k = 0; k < 4; ++k) {
-        const int col = 16 * (4 * wc + k) + (lane & 15);
+        if (dealt && (half_role ? i >= 2 : k > i)) continue;  // wave-uniform
+        const int col = 16 * (tc0 + k) + (lane & 15);
 #pragma unroll
         for (int v = 0; v < 4; ++v) {
-          const int row = 16 * (4 * wr + i) + Mfma<T>::crow(lane, v);
+          const int row = 16 * (tr0 + i) + Mfma<T>::crow(lane, v);
           out[col * kPB + row] = acc[i][k][v];  // column-major tile: the reduce pass is coalesced both ways
         }
       }
@@ -657,6 +741,8 @@ template <typename T>
 struct ReduceArgs {
   const T* Gpart; const double* bpart;
   int nsplit_total;          // data splits (+1 if a prior-factor pseudo split is present)
+  int nsplit_diag;           // 0, or the number of data splits of the DIAGONAL tiles (< the others'; see GramTileArgs)
+  int pseudo_split;          // 1: the last of the nsplit_total partials is the prior factor's (present for every tile)
   int ntiles, nblocks;       // lower-triangular macro tiles, row blocks
   const T* Lw; int64_t ldl; int prior_kind;
   int D, DP;
@@ -685,15 +771,19 @@ __global__ __launch_bounds__(kThreads) void gram_reduce_kernel(ReduceArgs<T> a) 
       if (col > row0 + VEC - 1) continue;
       const T* src = a.Gpart + (int64_t)t * (kPB * kPB) + e;
       vecT sum = vecT(T(0));
+      // a diagonal tile with its own split factor: its data partials, then (if present) the pseudo split at the END of the stack
+      const bool short_stack = a.nsplit_diag > 0 && I == J;
+      const int ndata = short_stack ? a.nsplit_diag : a.nsplit_total;
       int sp = 0;
-      for (; sp + 8 <= a.nsplit_total; sp += 8) {
+      for (; sp + 8 <= ndata; sp += 8) {
         vecT v[8];
 #pragma unroll
         for (int u = 0; u < 8; ++u) v[u] = *reinterpret_cast<const vecT*>(src + (sp + u) * sstride);
 #pragma unroll
         for (int u = 0; u < 8; ++u) sum += v[u];  // fixed order
       }
-      for (; sp < a.nsplit_total; ++sp) sum += *reinterpret_cast<const vecT*>(src + sp * sstride);
+      for (; sp < ndata; ++sp) sum += *reinterpret_cast<const vecT*>(src + sp * sstride);
+      if (short_stack && a.pseudo_split) sum += *reinterpret_cast<const vecT*>(src + (a.nsplit_total - 1) * sstride);
 #pragma unroll
       for (int q = 0; q < VEC; ++q) {
         const int row = row0 + q;
