@@ -350,14 +350,17 @@ int posterior_large_one(blr_handle* h, const PosteriorArgs<T>& a, int64_t reg) {
   // would take two rounds for 1.125 rounds of work)
   const int max_split_cols = std::max(1, (N + nstage_cols - 1) / nstage_cols);
   const int max_split = std::min(64, max_split_cols);
+  // model of the launch: rounds x (columns per workgroup + 256) -- the 256 stands for a workgroup's fixed costs (pipeline fill,
+  // the 64 KB partial it writes and the reduction reads back), fitted on c5 (136 tiles: 15 splits 1.232 ms, 11: 1.204, 7: 1.210)
   int nsplit = 1;
-  double best = 0.0;
+  double best = 1e300;
   for (int sp = 1; sp <= max_split; ++sp) {
     const int wgs = ntiles * sp;
     const int slots = 256 * (sizeof(T) == 4 ? BLR_GRAM_WGS : 2);
     const int rounds = (wgs + slots - 1) / slots;
-    const double eff = (double)wgs / (rounds * (double)slots) - 0.002 * sp;  // mild preference for fewer partials
-    if (eff > best) { best = eff; nsplit = sp; }
+    const int cols_sp = ((N + sp - 1) / sp + nstage_cols - 1) / nstage_cols * nstage_cols;
+    const double cost = (double)rounds * (cols_sp + 256.0);
+    if (cost < best) { best = cost; nsplit = sp; }
   }
   // Diagonal macro tiles cost less per column than off-diagonal ones in the ring loop (only the 36 tiles of 16 x 16 on or below
   // the diagonal are computed: 10 MFMAs per k-step on the critical waves instead of 16; measured ~11.5 with the b partials
@@ -373,8 +376,14 @@ int posterior_large_one(blr_handle* h, const PosteriorArgs<T>& a, int64_t reg) {
     const T* X0 = a.X + reg * a.strideX;
     const bool dealt = sizeof(T) == 4 && a.layout == LAYOUT_COLVECS && ((uintptr_t)X0 % 16 == 0) &&
                        ((a.ldx * (int64_t)sizeof(T)) % 16 == 0) && getenv("BLR_MI355X_NO_GRAM_RING") == nullptr &&
-                       getenv("BLR_MI355X_NO_DIAG_SPLIT") == nullptr && D % kPB == 0 && NC >= 2 && ntiles * nsplit <= slots;
-    if (dealt) {
+                       getenv("BLR_MI355X_NO_DIAG_SPLIT") == nullptr && D % kPB == 0 && NC >= 2 && (ntiles * nsplit <= slots || getenv("BLR_MI355X_GRAM_SPLITS") != nullptr);
+    if (const char* e = getenv("BLR_MI355X_GRAM_SPLITS")) {  // "off-diagonal,diagonal" (equal: one factor): measurements only
+      int so = 0, sd = 0;
+      if (sscanf(e, "%d,%d", &so, &sd) == 2 && so >= 1 && sd >= 1 && sd <= so && so <= max_split) {
+        nsplit = so;
+        nsplit_diag = (sd < so && dealt) ? sd : 0;
+      }
+    } else if (dealt) {
       auto cols = [&](int sp) { return (double)(((N + sp - 1) / sp + nstage_cols - 1) / nstage_cols * nstage_cols); };
       const int n_off = ntiles - NC;
       double best_t = 16.0 * cols(nsplit);  // today's longest workgroup (diagonal tiles shorter, off-diagonal ones set the time)
@@ -386,13 +395,6 @@ int posterior_large_one(blr_handle* h, const PosteriorArgs<T>& a, int64_t reg) {
           if (t < best_t * 0.995) { best_t = t; bo = so; bd = sd; }
         }
       if (bo > 0) { nsplit = bo; nsplit_diag = bd; }
-      if (const char* e = getenv("BLR_MI355X_GRAM_SPLITS")) {  // "off-diagonal,diagonal": measurements only
-        int so = 0, sd = 0;
-        if (sscanf(e, "%d,%d", &so, &sd) == 2 && so >= 1 && sd >= 1 && sd <= so && so <= max_split && n_off * so + NC * sd <= 2 * slots) {
-          nsplit = so;
-          nsplit_diag = sd;
-        }
-      }
     }
   }
   const bool prior_factor = a.prior_kind == PRIOR_UPPER_FACTOR;
