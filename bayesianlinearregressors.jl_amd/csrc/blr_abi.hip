@@ -309,22 +309,34 @@ int set_lds(blr_handle* h, const void* kern, size_t bytes) { return set_lds_once
 
 // In-place blocked (128) right-looking Cholesky of the lower triangle of M (nrows_total x DP, ld); rows beyond DP
 // (the right-hand-side block of the augmented matrix) are carried through the TRSM and the trailing updates.
+template <typename T, int ER>
+int launch_panel(blr_handle* h, T* M, int64_t ld, int p, int nrows_total, int nbelow, int32_t* info_dev) {
+  constexpr int NW = BLR_PANEL_WAVES;
+  using CC = ChainCfg<T, NW, ER>;
+  int rc;
+  if ((rc = set_lds<T>(h, reinterpret_cast<const void*>(panel_chain_kernel<T, NW, ER>), CC::LDS_BYTES))) return rc;
+  const int nwg = std::max(1, (nbelow + ER - 1) / ER);
+  h->arrive_base += (unsigned)nwg;  // monotonic arrival counter: never reset, wrap-around safe (signed difference in the kernel)
+  hipLaunchKernelGGL((panel_chain_kernel<T, NW, ER>), dim3(nwg), dim3(64 * NW), CC::LDS_BYTES, h->stream, M, ld, p, nrows_total,
+                     info_dev, h->ticket + 1, h->arrive_base);
+  return 0;
+}
+
 template <typename T>
 int chol_large(blr_handle* h, T* M, int64_t ld, int DP, int nrows_total, int32_t* info_dev) {
-  constexpr int NW = BLR_PANEL_WAVES;
-  using CC = ChainCfg<T, NW>;
   const int NC = DP / kPB;
   int rc;
   if ((rc = ensure_xchg(h, 0))) return rc;  // the handle's counter words (ticket[1]: arrivals of panel_chain_kernel)
-  if ((rc = set_lds<T>(h, reinterpret_cast<const void*>(panel_chain_kernel<T, NW>), CC::LDS_BYTES))) return rc;
   if ((rc = set_lds<T>(h, reinterpret_cast<const void*>(trail_update_kernel<T>), TrailCfg<T>::LDS_BYTES))) return rc;
   for (int p = 0; p < NC; ++p) {
-    // L_pp and X <- X L_pp^-T for the rows below, ER rows per workgroup (one workgroup when nothing is below)
+    // L_pp and X <- X L_pp^-T for the rows below.  Every workgroup factors L_pp and takes 16, 32 or 64 of those rows along:
+    // the fewer, the shorter the launch (the update waves are its bottleneck) -- as long as every workgroup has a CU to itself
     const int nbelow = nrows_total - (p + 1) * kPB;
-    const int nwg = std::max(1, (nbelow + CC::ER - 1) / CC::ER);
-    h->arrive_base += (unsigned)nwg;  // monotonic arrival counter: never reset, wrap-around safe (signed difference in the kernel)
-    hipLaunchKernelGGL((panel_chain_kernel<T, NW>), dim3(nwg), dim3(64 * NW), CC::LDS_BYTES, h->stream, M, ld, p, nrows_total, info_dev,
-                       h->ticket + 1, h->arrive_base);
+    const int cus = 256;
+    if (nbelow <= 16 * cus) rc = launch_panel<T, 16>(h, M, ld, p, nrows_total, nbelow, info_dev);
+    else if (nbelow <= 32 * cus) rc = launch_panel<T, 32>(h, M, ld, p, nrows_total, nbelow, info_dev);
+    else rc = launch_panel<T, 64>(h, M, ld, p, nrows_total, nbelow, info_dev);
+    if (rc) return rc;
     const int m = NC - 1 - p;  // remaining column blocks
     if (m > 0) {
       const int ntri = 2 * m;                                   // 64-row sub-blocks of the remaining triangle

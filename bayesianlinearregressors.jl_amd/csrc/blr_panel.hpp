@@ -24,13 +24,18 @@
 #define BLR_PANEL_WAVES 8  // 1 chain wave + 7 update waves (tools/panel_bench: 4 waves 41 us, 8 waves 20 us per f32 panel)
 #endif
 
+#ifndef BLR_PANEL_ER
+#define BLR_PANEL_ER 16    // rows of X per workgroup where the chip has a CU for every workgroup (tools/panel_bench, 1920 rows
+#endif                     // below the block: 64 rows x 30 workgroups 20.0 us, 32 x 60 18.6, 16 x 120 17.0; f64 47 / 42 / 37)
+
 namespace blr {
 
-template <typename T, int NW_>
+template <typename T, int NW_, int ER_ = BLR_PANEL_ER>
 struct ChainCfg {
   static constexpr int NW = NW_;             // waves per workgroup: wave 0 = chain wave
   static constexpr int NU = NW_ - 1;         // update waves
-  static constexpr int ER = 64;              // rows of X per workgroup
+  static constexpr int ER = ER_;             // rows of X per workgroup (16, 32 or 64)
+  static_assert(ER_ == 16 || ER_ == 32 || ER_ == 64, "at most two tiles of a column per update wave");
   static constexpr int XT = ER / 16;         // ... as 16-row tiles
   static constexpr int NR = 7 + XT;          // row ids of a panel image: block row tiles 1..7 (ids 0..6), then the X row tiles
   // update-wave tiles in column order: column K holds the row ids R0(K) .. NR-1, R0 = K for K < 2 and K - 1 (the diagonal
@@ -418,10 +423,10 @@ __device__ __forceinline__ typename Mfma<T>::acc4 solve_tile(const T* pre_tile, 
   return z;
 }
 
-template <typename T, int NW>
+template <typename T, int NW, int ER = BLR_PANEL_ER>
 __global__ __launch_bounds__(64 * NW, 1) void panel_chain_kernel(T* Abar, int64_t lda, int p, int nrows_total, int32_t* info,
                                                                  unsigned* arrive, unsigned arrive_target) {
-  using C = ChainCfg<T, NW>;
+  using C = ChainCfg<T, NW, ER>;
   using acc4 = typename Mfma<T>::acc4;
   static_assert(C::col_begin(8) == C::NT, "tile enumeration");
   constexpr int kPBc = 128;

@@ -18,7 +18,7 @@ using namespace blr;
 
 template <typename T>
 int run(const char* name, int nwg) {
-  const int nrows = 128 + 64 * nwg;
+  const int nrows = 128 + ChainCfg<T, PB_NW>::ER * nwg;
   const int64_t lda = nrows;
   std::vector<double> A((size_t)lda * 128);
   srand(7);
