@@ -342,8 +342,9 @@ int chol_large(blr_handle* h, T* M, int64_t ld, int DP, int nrows_total, int32_t
       const int ntri = 2 * m;                                   // 64-row sub-blocks of the remaining triangle
       const int nextra = (nrows_total - DP) / TrailCfg<T>::SB;  // rhs rows below the square part
       const int ntiles = ntri * (ntri + 1) / 2 + nextra * ntri;
-      hipLaunchKernelGGL(trail_update_kernel<T>, dim3(ntiles), dim3(kThreads), TrailCfg<T>::LDS_BYTES, h->stream, M, ld, p, ntri,
-                         (p + 1) * kPB, DP, (const int32_t*)info_dev);
+      const int slots = 256 * (TrailCfg<T>::LDS_BYTES <= 80 * 1024 ? 2 : 1);  // sub-tiles the chip holds at once
+      hipLaunchKernelGGL(trail_update_kernel<T>, dim3(std::min(ntiles, slots)), dim3(kThreads), TrailCfg<T>::LDS_BYTES, h->stream, M, ld,
+                         p, ntri, (p + 1) * kPB, DP, (const int32_t*)info_dev, ntiles);
     }
   }
   HIP_TRY(h, hipGetLastError());

@@ -921,7 +921,7 @@ template <typename T>
 __global__ __launch_bounds__(kThreads) void trail_update_kernel(T* M, int64_t ld, int p, int ntri /* 64-row blocks in the triangle */,
                                                                 int row_tri0 /* first row of the triangle */,
                                                                 int row_extra0 /* first extra row (rhs rows) */,
-                                                                const int32_t* info) {
+                                                                const int32_t* info, int ntiles /* all sub-tiles of the launch */) {
   using Cfg = TrailCfg<T>;
   using acc4 = typename Mfma<T>::acc4;
   constexpr int VEC = Mfma<T>::VEC;
@@ -936,7 +936,10 @@ __global__ __launch_bounds__(kThreads) void trail_update_kernel(T* M, int64_t ld
 
   // sub-tile (si, sj): lower triangle over ntri sub-blocks, then the extra row blocks x ntri columns
   const int ntt = ntri * (ntri + 1) / 2;
-  int t = blockIdx.x, rowA, rowB;
+  // (a launch of more than two sub-tiles per CU -- c5's first panels: 525 -- runs as 512 workgroups, some taking a second
+  // sub-tile, instead of a second round of a dozen workgroups that doubles the latency of the step)
+  for (int t0 = blockIdx.x; t0 < ntiles; t0 += gridDim.x) {
+  int t = t0, rowA, rowB;
   bool diag = false;
   if (t < ntt) {
     int si = (int)((sqrtf(8.0f * (float)t + 1.0f) - 1.0f) * 0.5f);
@@ -1019,6 +1022,8 @@ __global__ __launch_bounds__(kThreads) void trail_update_kernel(T* M, int64_t ld
         }
       }
     }
+  __syncthreads();  // the operand images are rewritten by the next sub-tile
+  }
 }
 
 // ---- X <- X L_pp^-T for one block of RB rows below the diagonal block ------------------------------------------------

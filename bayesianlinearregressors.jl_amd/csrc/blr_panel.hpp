@@ -35,9 +35,10 @@ struct ChainCfg {
   static constexpr int NW = NW_;             // waves per workgroup: wave 0 = chain wave
   static constexpr int NU = NW_ - 1;         // update waves
   static constexpr int ER = ER_;             // rows of X per workgroup (16, 32 or 64)
-  static_assert(ER_ == 16 || ER_ == 32 || ER_ == 64, "at most two tiles of a column per update wave");
+  static_assert(ER_ == 16 || ER_ == 32 || ER_ == 64, "whole 16-row tiles, callers pad the rows below the block to 64");
   static constexpr int XT = ER / 16;         // ... as 16-row tiles
   static constexpr int NR = 7 + XT;          // row ids of a panel image: block row tiles 1..7 (ids 0..6), then the X row tiles
+  static_assert(7 + ER_ / 16 <= 2 * (NW_ - 1), "the solve handles at most two tiles of a column per update wave");
   // update-wave tiles in column order: column K holds the row ids R0(K) .. NR-1, R0 = K for K < 2 and K - 1 (the diagonal
   // tile, row tile K = id K - 1) from K = 2 on
   static constexpr int NT = 8 * NR - 28 + 6;
