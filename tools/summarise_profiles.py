@@ -96,6 +96,9 @@ for key, d, kern, units in (("c2_f32_fused_small_kernel_hbm", "c2f32", "fused_sm
         summary[key] = {"FETCH_SIZE_KiB": fe["FETCH_SIZE"], "WRITE_SIZE_KiB": wr_["WRITE_SIZE"], "hbm_read_bytes_per_launch": rd,
                         "hbm_write_bytes_per_launch": wr, "hbm_bytes_per_launch": rd + wr, "units_per_launch": units,
                         "kernel": kern, "avg_duration_ns": fe["avg_duration_ns"]}
+for src in sorted(glob.glob(os.path.join(os.path.dirname(RAW), "microbench", "*.txt"))):  # tools/run_microbench.sh
+    if os.path.getsize(src):
+        shutil.copy(src, os.path.join(DST, f"{tag}_microbench_{os.path.basename(src)}"))
 for extra in ("ring_probe.txt", "power_probe.txt"):
     src = os.path.join(RAW, extra)
     if os.path.exists(src) and os.path.getsize(src):
