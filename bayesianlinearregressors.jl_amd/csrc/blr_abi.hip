@@ -317,7 +317,7 @@ int launch_panel(blr_handle* h, T* M, int64_t ld, int p, int nrows_total, int nb
   if ((rc = set_lds<T>(h, reinterpret_cast<const void*>(panel_chain_kernel<T, NW, ER>), CC::LDS_BYTES))) return rc;
   const int nwg = std::max(1, (nbelow + ER - 1) / ER);
   h->arrive_base += (unsigned)nwg;  // monotonic arrival counter: never reset, wrap-around safe (signed difference in the kernel)
-  hipLaunchKernelGGL((panel_chain_kernel<T, NW, ER>), dim3(nwg), dim3(64 * NW), CC::LDS_BYTES, h->stream, M, ld, p, nrows_total,
+  hipLaunchKernelGGL((panel_chain_kernel<T, NW, ER>), dim3(nwg), dim3(64 * NW), CC::LDS_BYTES, h->stream, M, ld, p * kPB, nrows_total,
                      info_dev, h->ticket + 1, h->arrive_base);
   return 0;
 }

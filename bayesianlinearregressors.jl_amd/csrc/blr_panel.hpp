@@ -30,18 +30,22 @@
 
 namespace blr {
 
-template <typename T, int NW_, int ER_ = BLR_PANEL_ER>
+template <typename T, int NW_, int ER_ = BLR_PANEL_ER, int NBT_ = 8>
 struct ChainCfg {
   static constexpr int NW = NW_;             // waves per workgroup: wave 0 = chain wave
   static constexpr int NU = NW_ - 1;         // update waves
+  static constexpr int NBT = NBT_;           // 16 x 16 tiles along the edge of the diagonal block
+  static constexpr int W = 16 * NBT_;        // columns of the panel
   static constexpr int ER = ER_;             // rows of X per workgroup (16, 32 or 64)
   static_assert(ER_ == 16 || ER_ == 32 || ER_ == 64, "whole 16-row tiles, callers pad the rows below the block to 64");
+  static_assert(NBT_ == 8, "panel width: 128 columns (a 256-column instance measured 45 us against 2 x 15: its update waves fall behind)");
   static constexpr int XT = ER / 16;         // ... as 16-row tiles
-  static constexpr int NR = 7 + XT;          // row ids of a panel image: block row tiles 1..7 (ids 0..6), then the X row tiles
-  static_assert(7 + ER_ / 16 <= 2 * (NW_ - 1), "the solve handles at most two tiles of a column per update wave");
+  static constexpr int NB1 = NBT - 1;        // row ids 0 .. NB1-1: block row tiles 1 .. NBT-1; from NB1 on: the X row tiles
+  static constexpr int NR = NB1 + XT;        // row ids of a panel image
+  static_assert(NB1 + ER_ / 16 <= 3 * (NW_ - 1), "the solve handles at most three tiles of a column per update wave");
   // update-wave tiles in column order: column K holds the row ids R0(K) .. NR-1, R0 = K for K < 2 and K - 1 (the diagonal
   // tile, row tile K = id K - 1) from K = 2 on
-  static constexpr int NT = 8 * NR - 28 + 6;
+  static constexpr int NT = NBT * NR - NBT * (NBT - 1) / 2 + (NBT - 2);
   static constexpr int SLOTS = (NT + NU - 1) / NU;
   static constexpr int NPAIR = (SLOTS + 1) / 2;
   static constexpr int IMG = NR * 256;       // elements of one panel image (tiles column-major 16 x 16)
@@ -54,13 +58,10 @@ struct ChainCfg {
   static constexpr int OFF_CSCR = OFF_DIN + 2 * 256 * S;     // [256]         chain wave: its own solved sub-diagonal tile
   static constexpr int OFF_ZERO = OFF_CSCR + 256 * S;        // [256]         zeros (A operand of a slot that sits out)
   static constexpr int OFF_DSCR = OFF_ZERO + 256 * S;        // [16][LDD]     chain wave: accumulator -> one row per lane
-  static constexpr int OFF_LDIAG = OFF_DSCR + 16 * LDD * S;  // [8][16][LDD]  rows of the factored diagonal tiles
-  static constexpr int OFF_LOUT = OFF_LDIAG + 8 * 16 * LDD * S;  // [28][256]    solved tiles of the block (write-back of workgroup 0)
-  static constexpr int OFF_DUMMY = OFF_LOUT + 28 * 256 * S;      // [256]        where a slot that is not due writes
-  static constexpr int OFF_INFO = OFF_DUMMY + 256 * S;
-  static constexpr int OFF_TAB = OFF_INFO + 16;                  // [NU][8] first solved row id of wave u in column J
-  static constexpr int LDS_BYTES = OFF_TAB + NU * 8 * 4;
-  __host__ __device__ static constexpr int lout(int J, int R) { return J * 7 - J * (J - 1) / 2 + (R - J); }  // R >= J, R < 7
+  static constexpr int OFF_LDIAG = OFF_DSCR + 16 * LDD * S;  // [NBT][16][LDD] rows of the factored diagonal tiles
+  static constexpr int OFF_INFO = OFF_LDIAG + NBT * 16 * LDD * S;
+  static constexpr int OFF_TAB = OFF_INFO + 16;              // [NU][NBT] first solved row id of wave u in column J
+  static constexpr int LDS_BYTES = OFF_TAB + NU * NBT * 4;
   __host__ __device__ static constexpr int col_begin(int K) {  // first tile of column K in the enumeration
     return K == 0 ? 0 : (K == 1 ? NR : 2 * NR - 1 + (K - 2) * (NR + 1) - ((K - 1) * K / 2 - 1));
   }
@@ -68,7 +69,7 @@ struct ChainCfg {
 
 #ifdef BLR_STAMPS
 __device__ unsigned long long g_stamps2[8];
-__device__ unsigned long long g_tl[8][40];   // raw time line, workgroup 0: [wave][event]
+__device__ unsigned long long g_tl[8][80];   // raw time line, workgroup 0: [wave][event]
 #define BLR_TL(ev) do { if (blockIdx.x == 0 && lane == 0) g_tl[wave][ev] = __builtin_amdgcn_s_memtime(); } while (0)  // tools/panel_bench: section sums of update wave 0 (the chain wave uses g_stamps)
 #define BLR_USTAMP(slot) do { if (u == 0) { unsigned long long t__ = __builtin_amdgcn_s_memtime(); ust[slot] += t__ - uprev; uprev = t__; } } while (0)
 #else
@@ -355,7 +356,7 @@ template <typename C>
 __device__ __forceinline__ void chain_tile(int g, int& K, int& R) {
   int k = 0, b = 0;
 #pragma unroll
-  for (int c = 1; c < 8; ++c)
+  for (int c = 1; c < C::NBT; ++c)
     if (g >= C::col_begin(c)) { k = c; b = C::col_begin(c); }
   K = k;
   R = (k < 2 ? k : k - 1) + (g - b);
@@ -374,7 +375,7 @@ __device__ __forceinline__ void trail_load(const T* img, const T* zero, const in
       const int s = (base + h < C::SLOTS) ? base + h : 0;
       const bool act = sK[s] > J;
       const T* ta = act ? img + sR[s] * 256 : zero;
-      const T* tb = img + max(min(sK[s], 8) - 1, 0) * 256;
+      const T* tb = img + max(min(sK[s], C::NBT) - 1, 0) * 256;
       T fa[4], fb[4];
       load_frags<T>(ta, fo, fa);
       load_frags<T>(tb, fo, fb);
@@ -424,13 +425,14 @@ __device__ __forceinline__ typename Mfma<T>::acc4 solve_tile(const T* pre_tile, 
   return z;
 }
 
-template <typename T, int NW, int ER = BLR_PANEL_ER>
-__global__ __launch_bounds__(64 * NW, 1) void panel_chain_kernel(T* Abar, int64_t lda, int p, int nrows_total, int32_t* info,
-                                                                 unsigned* arrive, unsigned arrive_target) {
-  using C = ChainCfg<T, NW, ER>;
+template <typename T, int NW, int ER = BLR_PANEL_ER, int NBT = 8>
+__global__ __launch_bounds__(64 * NW, 1) void panel_chain_kernel(T* Abar, int64_t lda, int col0 /* first column of the panel */,
+                                                                 int nrows_total, int32_t* info, unsigned* arrive,
+                                                                 unsigned arrive_target) {
+  using C = ChainCfg<T, NW, ER, NBT>;
   using acc4 = typename Mfma<T>::acc4;
-  static_assert(C::col_begin(8) == C::NT, "tile enumeration");
-  constexpr int kPBc = 128;
+  static_assert(C::col_begin(NBT) == C::NT, "tile enumeration");
+  constexpr int NB1 = C::NB1;
   extern __shared__ __attribute__((aligned(16))) char smem[];
   T* const IMG = reinterpret_cast<T*>(smem + C::OFF_IMG);
   T* const PRE = reinterpret_cast<T*>(smem + C::OFF_PRE);
@@ -440,7 +442,6 @@ __global__ __launch_bounds__(64 * NW, 1) void panel_chain_kernel(T* Abar, int64_
   T* const ZERO = reinterpret_cast<T*>(smem + C::OFF_ZERO);
   T* const DSCR = reinterpret_cast<T*>(smem + C::OFF_DSCR);
   T* const LDIAG = reinterpret_cast<T*>(smem + C::OFF_LDIAG);
-  T* const LOUT = reinterpret_cast<T*>(smem + C::OFF_LOUT);
   int* const INFO = reinterpret_cast<int*>(smem + C::OFF_INFO);
   int* const TAB = reinterpret_cast<int*>(smem + C::OFF_TAB);
   const int tid = threadIdx.x, lane = tid & 63;
@@ -448,10 +449,10 @@ __global__ __launch_bounds__(64 * NW, 1) void panel_chain_kernel(T* Abar, int64_
   const int r = lane & 15, q = lane >> 4;
   const FragOff<T> fo(lane);
 
-  T* const blk = Abar + (int64_t)p * kPBc * lda + (int64_t)p * kPBc;
-  const int r0 = (p + 1) * kPBc + blockIdx.x * C::ER;   // first row of this workgroup's slice of X
-  const int nr = max(0, min(C::ER, nrows_total - r0));  // 0 (nothing below the block) or ER: callers pad to 128 rows
-  T* const Xg = Abar + (int64_t)p * kPBc * lda + r0;    // X(row, col) at Xg[col * lda + row]
+  T* const blk = Abar + (int64_t)col0 * lda + col0;      // the diagonal block
+  const int r0 = col0 + C::W + blockIdx.x * C::ER;      // first row of this workgroup's slice of X
+  const int nr = max(0, min(C::ER, nrows_total - r0));  // 0 (nothing below the block) or ER: callers pad to 64 rows
+  T* const Xg = Abar + (int64_t)col0 * lda + r0;        // X(row, col) at Xg[col * lda + row]
   const bool failed = *info != 0;                       // an earlier panel already failed (uniform over the launch)
   if (failed) {  // nothing to do, but the arrival count must still add up
     if (tid == 0) __hip_atomic_fetch_add(arrive, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
@@ -476,7 +477,7 @@ __global__ __launch_bounds__(64 * NW, 1) void panel_chain_kernel(T* Abar, int64_
     BLR_STAMP(0);
     BLR_TL(0);
 #pragma unroll 1
-    for (int J = 0; J < 8; ++J) {
+    for (int J = 0; J < NBT; ++J) {
       const int par = J & 1;
       // tile J (negated; only its lower triangle means anything) -> one row per lane
 #pragma unroll
@@ -515,10 +516,10 @@ __global__ __launch_bounds__(64 * NW, 1) void panel_chain_kernel(T* Abar, int64_
       // A_pp and X have been read by now (the update waves waited for their loads before B1 of step 0): arrive.
       if (J == 0 && tid == 0) __hip_atomic_fetch_add(arrive, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
       // (the answer is not needed before the write-back: the load's latency disappears behind the last steps)
-      if (J == 5 && tid == 0 && blockIdx.x == 0) arrived = __hip_atomic_load(arrive, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      if (J == NBT - 3 && tid == 0 && blockIdx.x == 0) arrived = __hip_atomic_load(arrive, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
       BLR_STAMP(3);
       BLR_TL(2 + 4 * J);
-      if (J < 7) {
+      if (J < NBT - 1) {
         // the one sub-diagonal tile that the next diagonal tile waits for, L(J+1, J) = A(J+1, J) Linv_J', then tile J+1 -= L L'
         acc4 dn;
         if (J == 0) dn = d1;
@@ -582,7 +583,7 @@ __global__ __launch_bounds__(64 * NW, 1) void panel_chain_kernel(T* Abar, int64_
       const int tKv = !live ? 100 : (isdiag ? Kv - 2 : Kv - 1);
       const int tOv = isdiag ? C::OFF_DIN / C::S + ((Kv - 2) & 1) * 256 : C::OFF_PRE / C::S + Rv * 256;
       // element offset of the tile from blk: rows of the block, or this workgroup's rows of X (r0 - p 128 further down)
-      const int rowv = Rv < 7 ? 16 * (Rv + 1) : (nr > 0 ? (r0 - p * kPBc) + 16 * (Rv - 7) : 0);
+      const int rowv = Rv < NB1 ? 16 * (Rv + 1) : (nr > 0 ? (r0 - col0) + 16 * (Rv - NB1) : 0);
       const int offv = (live ? 16 * Kv : 0) * (int)lda + rowv;
       const int lane_off = r * (int)lda + (sizeof(T) == 4 ? 4 * q : 0);
 #pragma unroll
@@ -602,22 +603,20 @@ __global__ __launch_bounds__(64 * NW, 1) void panel_chain_kernel(T* Abar, int64_
       if (nr == 0) {  // no rows below the block: those tiles are zero
 #pragma unroll
         for (int s = 0; s < C::SLOTS; ++s)
-          if (sR[s] >= 7) acc[s] = acc4{T(0), T(0), T(0), T(0)};
+          if (sR[s] >= NB1) acc[s] = acc4{T(0), T(0), T(0), T(0)};
       }
     }
-    // this wave's tiles of column J that are solved (row ids >= J): the first one, TAB[u][J]; the second is NU further on
-    if (lane < 8) {
+    // this wave's tiles of column J that are solved (row ids >= J): the first one, TAB[u][J]; the others are NU, 2 NU further on
+    if (lane < NBT) {
       const int J = lane;
       const int R0 = J < 2 ? J : J - 1;
-      const int first = C::col_begin(0) + 0;  // (col_begin is constexpr only; evaluate it per J below)
-      (void)first;
       int cb = 0;
 #pragma unroll
-      for (int c = 1; c < 8; ++c)
+      for (int c = 1; c < NBT; ++c)
         if (J == c) cb = C::col_begin(c);
       const int g0 = cb + (J - R0);                        // enumeration index of the tile with row id J
       const int x = ((u - g0) % C::NU + C::NU) % C::NU;   // first tile at or after it that is dealt to wave u
-      TAB[u * 8 + J] = J + x;
+      TAB[u * NBT + J] = J + x;
     }
 #pragma unroll
     for (int s = 0; s < C::SLOTS; ++s)
@@ -634,17 +633,22 @@ __global__ __launch_bounds__(64 * NW, 1) void panel_chain_kernel(T* Abar, int64_
 #pragma unroll
     for (int s = 0; s < C::SLOTS; ++s)
       if (tK[s] == -1) tile_to_image<T>(S0 + tO[s], acc[s], lane);
+    // Workgroup 0 writes the block's solved tiles back over A_pp one step after they were solved (their image lives two steps) --
+    // not before every workgroup has read A_pp: the arrival counter is read behind the barrier of step 1 and needed a
+    // trailing update later
+    unsigned arrived_u = arrive_target;
 #pragma unroll 1
-    for (int J = 0; J < 8; ++J) {
+    for (int J = 0; J < NBT; ++J) {
       const int par = J & 1;
       T* const img = IMG + par * C::IMG;
       BLR_USTAMP(0);
-      const int R1 = chain_uni(TAB[u * 8 + J]);
+      const int R1 = chain_uni(TAB[u * NBT + J]);
       BLR_USTAMP(1);
       BLR_TL(1 + 4 * J);
       __syncthreads();  // B1
       BLR_USTAMP(2);
       BLR_TL(2 + 4 * J);
+      if (J == 1 && blockIdx.x == 0 && lane == 0) arrived_u = __hip_atomic_load(arrive, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
       {
         T fl[4];
 #pragma unroll
@@ -656,23 +660,28 @@ __global__ __launch_bounds__(64 * NW, 1) void panel_chain_kernel(T* Abar, int64_
           if (okm != 0xFFFFull && lane == 0 && INFO[0] == 0) INFO[0] = 16 * J + __builtin_ctzll(~okm) + 1;
         }
         const T sc = -fast_rcp(dgv);
-        const int R2 = R1 + C::NU;
-        // solved tiles go to the column image (everybody's trailing update), to the block's output image (row tiles of the
-        // block) or straight to memory (rows of X: nobody else reads them)
-        if (R2 < C::NR) {  // two tiles
+        // solved tiles go to the column image (everybody's trailing update; the block's own tiles are written back from it a
+        // step later) and, rows of X, straight to memory: nobody else reads them
+        auto put = [&](int R, const acc4& z) {
+          tile_to_image<T>(img + R * 256, z, lane);
+          if (R >= NB1 && nr > 0) tile_to_global<T>(Xg, lda, 16 * (R - NB1), 16 * J, z, lane);
+        };
+        const int R2 = R1 + C::NU, R3 = R1 + 2 * C::NU;
+        if (R3 < C::NR) {  // three tiles
           const acc4 za = solve_tile<T>(PRE + R1 * 256, fl, sc, fo);
           const acc4 zb = solve_tile<T>(PRE + R2 * 256, fl, sc, fo);
-          tile_to_image<T>(img + R1 * 256, za, lane);
-          tile_to_image<T>(img + R2 * 256, zb, lane);
-          if (R1 < 7) tile_to_image<T>(LOUT + C::lout(J, R1) * 256, za, lane);
-          else if (nr > 0) tile_to_global<T>(Xg, lda, 16 * (R1 - 7), 16 * J, za, lane);
-          if (R2 < 7) tile_to_image<T>(LOUT + C::lout(J, R2) * 256, zb, lane);
-          else if (nr > 0) tile_to_global<T>(Xg, lda, 16 * (R2 - 7), 16 * J, zb, lane);
+          const acc4 zc = solve_tile<T>(PRE + R3 * 256, fl, sc, fo);
+          put(R1, za);
+          put(R2, zb);
+          put(R3, zc);
+        } else if (R2 < C::NR) {  // two
+          const acc4 za = solve_tile<T>(PRE + R1 * 256, fl, sc, fo);
+          const acc4 zb = solve_tile<T>(PRE + R2 * 256, fl, sc, fo);
+          put(R1, za);
+          put(R2, zb);
         } else if (R1 < C::NR) {
           const acc4 za = solve_tile<T>(PRE + R1 * 256, fl, sc, fo);
-          tile_to_image<T>(img + R1 * 256, za, lane);
-          if (R1 < 7) tile_to_image<T>(LOUT + C::lout(J, R1) * 256, za, lane);
-          else if (nr > 0) tile_to_global<T>(Xg, lda, 16 * (R1 - 7), 16 * J, za, lane);
+          put(R1, za);
         }
       }
       BLR_USTAMP(3);
@@ -687,6 +696,23 @@ __global__ __launch_bounds__(64 * NW, 1) void panel_chain_kernel(T* Abar, int64_
         trail_walk<T, C, C::NPAIR - 1>(img, ZERO, sK, sR, J, fo, acc, f0, f1);
       }
       BLR_USTAMP(5);
+      // workgroup 0: column J - 1 of the block (row tiles J .. NBT-1, ids J-1 .. NB1-1) from its image to memory
+      if (blockIdx.x == 0 && J >= 1) {
+        if (J == 1) {
+          unsigned a = (unsigned)__builtin_amdgcn_readfirstlane((int)arrived_u);
+          long long spins = 0;
+          while ((int)(a - arrive_target) < 0) {  // somebody has not read A_pp yet (a workgroup that started late)
+            __builtin_amdgcn_s_sleep(8);
+            a = __hip_atomic_load(arrive, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            if (++spins > 20000000LL) break;  // a logic error upstream must not hang the GPU
+          }
+        }
+        const T* const pimg = IMG + (par ^ 1) * C::IMG;
+        for (int R = J - 1 + u; R < NB1; R += C::NU) {
+          const acc4 v = tile_from_image<T>(pimg + R * 256, lane);
+          tile_to_global<T>(blk, lda, 16 * (R + 1), 16 * (J - 1), v, lane);
+        }
+      }
       // publish pass: what is due after this step's trailing update (pre-solve images of column J + 1, diagonal tile J + 2)
 #pragma unroll
       for (int s = 0; s < C::SLOTS; ++s)
@@ -698,11 +724,12 @@ __global__ __launch_bounds__(64 * NW, 1) void panel_chain_kernel(T* Abar, int64_
 #endif
   }
 
-  // ---- write-back of the block (workgroup 0, once everybody has read A_pp); the rows of X went out as they were solved
-  BLR_TL(33);
+  // ---- the diagonal tiles (workgroup 0; its off-diagonal tiles went out a step after they were solved, the rows of X at once).
+  // A failed factorisation leaves NaNs behind its first bad pivot; the status says so.
+  BLR_TL(72);
   const int bad = INFO[0];
   if (bad != 0) {
-    if (blockIdx.x == 0 && tid == 0) *info = p * kPBc + bad;
+    if (blockIdx.x == 0 && tid == 0) *info = col0 + bad;
     return;
   }
   if (blockIdx.x != 0) return;
@@ -714,23 +741,15 @@ __global__ __launch_bounds__(64 * NW, 1) void panel_chain_kernel(T* Abar, int64_
     }
   }
   __syncthreads();  // B3
-  // the eight diagonal tiles (lower triangles) from the rows the chain wave left in LDIAG, one tile per wave ...
-  for (int K = wave; K < 8; K += NW) {
+  // lower triangles, from the rows the chain wave left in LDIAG, one tile per wave
+  for (int K = wave; K < NBT; K += NW) {
 #pragma unroll
     for (int e = 0; e < 4; ++e) {
       const int rho = Mfma<T>::crow(lane, e);
       if (r <= rho) blk[(int64_t)(16 * K + r) * lda + 16 * K + rho] = LDIAG[(K * 16 + rho) * C::LDD + r];
     }
   }
-  // ... and the 28 off-diagonal tiles of the block from their output image
-  for (int t = wave; t < 49; t += NW) {
-    const int J = t / 7, R = t % 7;
-    if (R >= J) {
-      const acc4 v = tile_from_image<T>(LOUT + C::lout(J, R) * 256, lane);
-      tile_to_global<T>(blk, lda, 16 * (R + 1), 16 * J, v, lane);
-    }
-  }
-  BLR_TL(34);
+  BLR_TL(73);
 }
 
 }  // namespace blr

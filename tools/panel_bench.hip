@@ -15,27 +15,31 @@ using namespace blr;
 #ifndef PB_NW
 #define PB_NW BLR_PANEL_WAVES
 #endif
+#ifndef PB_NBT
+#define PB_NBT 8   // 16 x 16 tiles along the block's edge (128-column panel)
+#endif
 
 template <typename T>
 int run(const char* name, int nwg) {
-  const int nrows = 128 + ChainCfg<T, PB_NW>::ER * nwg;
+  constexpr int W = 16 * PB_NBT;  // panel width
+  const int nrows = W + ChainCfg<T, PB_NW, BLR_PANEL_ER, PB_NBT>::ER * nwg;
   const int64_t lda = nrows;
-  std::vector<double> A((size_t)lda * 128);
+  std::vector<double> A((size_t)lda * W);
   srand(7);
-  // SPD block: G G' / 128 + I, rows below random
-  std::vector<double> G(128 * 128);
+  // SPD block: G G' / 16 + I, rows below random
+  std::vector<double> G(W * W);
   for (auto& g : G) g = (rand() / (double)RAND_MAX) - 0.5;
-  for (int c = 0; c < 128; ++c)
-    for (int r2 = 0; r2 < 128; ++r2) {
+  for (int c = 0; c < W; ++c)
+    for (int r2 = 0; r2 < W; ++r2) {
       double s = 0;
-      for (int k = 0; k < 128; ++k) s += G[r2 * 128 + k] * G[c * 128 + k];
+      for (int k = 0; k < W; ++k) s += G[r2 * W + k] * G[c * W + k];
       A[(size_t)c * lda + r2] = s / 16.0 + (r2 == c ? 1.0 : 0.0);
     }
-  for (int c = 0; c < 128; ++c)
-    for (int r2 = 128; r2 < nrows; ++r2) A[(size_t)c * lda + r2] = (rand() / (double)RAND_MAX) - 0.5;
+  for (int c = 0; c < W; ++c)
+    for (int r2 = W; r2 < nrows; ++r2) A[(size_t)c * lda + r2] = (rand() / (double)RAND_MAX) - 0.5;
   // host reference
   std::vector<double> R = A;
-  for (int c = 0; c < 128; ++c) {
+  for (int c = 0; c < W; ++c) {
     double d = R[(size_t)c * lda + c];
     for (int k = 0; k < c; ++k) d -= R[(size_t)k * lda + c] * R[(size_t)k * lda + c];
     d = std::sqrt(d);
@@ -58,8 +62,8 @@ int run(const char* name, int nwg) {
   CK(hipMemcpy(dA, hA.data(), hA.size() * sizeof(T), hipMemcpyHostToDevice));
   CK(hipMemset(dinfo, 0, 64));
   CK(hipMemset(darr, 0, 64));
-  using CC = ChainCfg<T, PB_NW>;
-  CK(hipFuncSetAttribute(reinterpret_cast<const void*>(panel_chain_kernel<T, PB_NW>), hipFuncAttributeMaxDynamicSharedMemorySize, CC::LDS_BYTES));
+  using CC = ChainCfg<T, PB_NW, BLR_PANEL_ER, PB_NBT>;
+  CK(hipFuncSetAttribute(reinterpret_cast<const void*>(panel_chain_kernel<T, PB_NW, BLR_PANEL_ER, PB_NBT>), hipFuncAttributeMaxDynamicSharedMemorySize, CC::LDS_BYTES));
   hipEvent_t e0, e1;
   CK(hipEventCreate(&e0));
   CK(hipEventCreate(&e1));
@@ -72,7 +76,7 @@ int run(const char* name, int nwg) {
       CK(hipMemcpy(dW, dA, hA.size() * sizeof(T), hipMemcpyDeviceToDevice));
       target += (unsigned)nwg;
       CK(hipEventRecord(e0));
-      panel_chain_kernel<T, PB_NW><<<nwg, 64 * PB_NW, CC::LDS_BYTES>>>(dW, lda, 0, nrows, dinfo, darr, target);
+      panel_chain_kernel<T, PB_NW, BLR_PANEL_ER, PB_NBT><<<nwg, 64 * PB_NW, CC::LDS_BYTES>>>(dW, lda, 0, nrows, dinfo, darr, target);
       CK(hipEventRecord(e1));
       CK(hipEventSynchronize(e1));
       float ms;
@@ -85,7 +89,7 @@ int run(const char* name, int nwg) {
     CK(hipMemcpy(&info, dinfo, 4, hipMemcpyDeviceToHost));
     double maxerr = 0, maxref = 0;
     size_t worst = 0;
-    for (int c = 0; c < 128; ++c)
+    for (int c = 0; c < W; ++c)
       for (int r2 = c; r2 < nrows; ++r2) {
         const size_t i = (size_t)c * lda + r2;
         const double e = std::fabs((double)out[i] - R[i]);
@@ -108,7 +112,7 @@ int run(const char* name, int nwg) {
              st[0] / n, st[1] / n, st[2] / n, st[3] / n, st[4] / n, st[5] / n);
     }
     if (which == 1 && sizeof(T) == 4) {
-      static unsigned long long tl[8][40];
+      static unsigned long long tl[8][80];
       CK(hipMemcpyFromSymbol(tl, HIP_SYMBOL(g_tl), sizeof(tl)));
       unsigned long long t0 = ~0ull;
       for (int w = 0; w < PB_NW; ++w) if (tl[w][0] && tl[w][0] < t0) t0 = tl[w][0];
@@ -116,8 +120,8 @@ int run(const char* name, int nwg) {
       printf("  wave  start | per step J: [ready for B1, past B1, ready for B2, past B2] ... | loop end, kernel end\n");
       for (int w = 0; w < PB_NW; ++w) {
         printf("  w%d %6llu |", w, tl[w][0] - t0);
-        for (int J = 0; J < 8; ++J) printf(" [%llu %llu %llu %llu]", tl[w][1 + 4 * J] - t0, tl[w][2 + 4 * J] - t0, tl[w][3 + 4 * J] - t0, tl[w][4 + 4 * J] - t0);
-        printf(" | %llu %llu\n", tl[w][33] - t0, tl[w][34] - t0);
+        for (int J = 0; J < PB_NBT; ++J) printf(" [%llu %llu %llu %llu]", tl[w][1 + 4 * J] - t0, tl[w][2 + 4 * J] - t0, tl[w][3 + 4 * J] - t0, tl[w][4 + 4 * J] - t0);
+        printf(" | %llu %llu\n", tl[w][72] - t0, tl[w][73] - t0);
       }
     }
     { unsigned long long zero[8] = {0}; CK(hipMemcpyToSymbol(HIP_SYMBOL(g_stamps), zero, sizeof(zero))); CK(hipMemcpyToSymbol(HIP_SYMBOL(g_stamps2), zero, sizeof(zero))); }
@@ -131,7 +135,7 @@ int run(const char* name, int nwg) {
     hB[(size_t)37 * lda + 37] = (T)-1.0;
     CK(hipMemcpy(dW, hB.data(), hB.size() * sizeof(T), hipMemcpyHostToDevice));
     target += (unsigned)nwg;
-    panel_chain_kernel<T, PB_NW><<<nwg, 64 * PB_NW, CC::LDS_BYTES>>>(dW, lda, 0, nrows, dinfo, darr, target);
+    panel_chain_kernel<T, PB_NW, BLR_PANEL_ER, PB_NBT><<<nwg, 64 * PB_NW, CC::LDS_BYTES>>>(dW, lda, 0, nrows, dinfo, darr, target);
     CK(hipDeviceSynchronize());
     int info;
     CK(hipMemcpy(&info, dinfo, 4, hipMemcpyDeviceToHost));
