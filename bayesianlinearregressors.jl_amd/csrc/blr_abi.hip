@@ -525,7 +525,9 @@ int posterior_large_one(blr_handle* h, const PosteriorArgs<T>& a, int64_t reg) {
   gram_tiles(h->stream, nsplit, ntiles, Gpart);
   gram_reduce(h->stream, nsplit, ntiles, Gpart, NC);
   // ---- blocked Cholesky of Abar (rows DP.. = rhs) -> L, u  (reference :86, :57)
-  if ((rc = chol_large<T>(h, Abar, lda, DP, DP + kPB, info_chol))) return rc;
+  // (only the first 64 of the 128 padding rows ride along: row DP is b', the others are zero and nobody reads them back --
+  // half the right-hand-side sub-tiles of every trailing update, and c5's first trailing updates fit one round)
+  if ((rc = chol_large<T>(h, Abar, lda, DP, DP + TrailCfg<T>::SB, info_chol))) return rc;
 
   // ---- T = L' (for the caller and for the AXPY-form back substitution), then m, posterior mean, evidence
   {
@@ -1001,7 +1003,7 @@ int posterior_from_stats(blr_handle* h, int64_t D64, int64_t N_total, T* stats, 
   hipLaunchKernelGGL(stats_add_prior_kernel<T>, dim3(1024), dim3(kThreads), 0, h->stream, stats, lds, D, DP, Lw, ldl, prior_kind,
                      Lw_post, ldlp);
   HIP_TRY(h, hipMemcpyAsync(info_chol, info_prior, sizeof(int32_t), hipMemcpyDeviceToDevice, h->stream));
-  if ((rc = chol_large<T>(h, stats, lds, DP, DP + kPB, info_chol))) return rc;
+  if ((rc = chol_large<T>(h, stats, lds, DP, DP + TrailCfg<T>::SB, info_chol))) return rc;  // (see posterior_large_one)
   {
     dim3 grid((DP + 31) / 32, (DP + 31) / 32);
     hipLaunchKernelGGL(transpose_out_kernel<T>, grid, dim3(kThreads), 0, h->stream, (const T*)stats, lds, DP, Tfull, (int64_t)DP,
