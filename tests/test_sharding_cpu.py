@@ -84,6 +84,56 @@ def test_gather_is_rank_count_independent():
         assert tot == fixed_order_sum(lp_all)  # bitwise: same order of additions for every rank count
 
 
+def _padded_worker(rank, world, port, q):
+    # bench.py --config c4 (strong scaling): every rank evaluates its contiguous block, pads it with zeros to the largest
+    # block (collectives want equal counts) and the ranks all-gather the padded blocks; the total is the fixed-order sum
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    for total in (8192, 8191, 1001, 3):
+        lp_all = _lp_all(total)
+        lo, hi = sharding.shard_range(total, rank, world)
+        bmax = max(sharding.shard_sizes(total, world))
+        mine = torch.zeros(bmax, dtype=torch.float64)
+        mine[: hi - lo] = torch.from_numpy(lp_all[lo:hi].copy())
+        gathered = torch.empty(bmax * world, dtype=torch.float64)
+        dist.all_gather_into_tensor(gathered, mine)
+        q.put((rank, total, gathered.numpy().tobytes(), fixed_order_sum(gathered.numpy())))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_padded_blocks_of_a_fixed_batch_sum_to_the_same_total_on_every_rank():
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    procs = [ctx.Process(target=_padded_worker, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    res = [q.get(timeout=240) for _ in range(2 * 4)]
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    by_total = {}
+    for rank, total, raw, tot in res:
+        by_total.setdefault(total, []).append((raw, tot))
+    for total, items in by_total.items():
+        assert len(items) == 2 and items[0] == items[1], "the ranks disagree on the gathered vector or its sum"
+        g = np.frombuffer(items[0][0])
+        lp_all = _lp_all(total)
+        sizes = sharding.shard_sizes(total, 2)
+        bmax = max(sizes)
+        # every block sits at rank * bmax, the padding is zero, nothing is lost or counted twice
+        off = 0
+        for r_, n in enumerate(sizes):
+            assert g[r_ * bmax: r_ * bmax + n].tobytes() == lp_all[off: off + n].tobytes()
+            assert not g[r_ * bmax + n: (r_ + 1) * bmax].any()
+            off += n
+        assert items[0][1] == pytest.approx(float(np.sum(lp_all)), rel=1e-13)
+
+
 def _stats_worker(rank, world, port, q):
     os.environ["MASTER_ADDR"] = "127.0.0.1"
     os.environ["MASTER_PORT"] = str(port)
