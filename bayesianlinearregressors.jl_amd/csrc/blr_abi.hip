@@ -40,9 +40,6 @@ struct blr_handle {
   unsigned long long* xchg = nullptr;
   size_t xchg_bytes = 0;
   unsigned* ticket = nullptr;     // [0]: start-order tickets of the wavefront solve, [1]: arrivals of panel_factor_kernel
-  unsigned ticket_base = 0;
-  unsigned arrive_base = 0;
-  unsigned epoch = 0;
   // kernels whose dynamic-LDS limit has been raised on this handle's device (hipFuncSetAttribute is per device and costs a
   // driver call: once per (handle, kernel), not once per launch -- it sat on the launch path of the 5 us wave kernel)
   std::unordered_map<const void*, size_t> lds_limit;
@@ -176,7 +173,6 @@ int ensure_xchg(blr_handle* h, size_t bytes) {
   if (!h->ticket) {
     HIP_TRY(h, hipMalloc((void**)&h->ticket, 64));
     HIP_TRY(h, hipMemsetAsync(h->ticket, 0, 64, h->stream));
-    h->ticket_base = 0;
   }
   if (bytes <= h->xchg_bytes) return 0;
   if (h->xchg) {
@@ -200,16 +196,11 @@ template <typename T>
 int launch_wave_solve(blr_handle* h, WaveSolveArgs<T>& b, int NC, int64_t S) {
   int rc = ensure_xchg(h, (size_t)S * b.DP * 2 * sizeof(unsigned long long));
   if (rc) return rc;
-  if (++h->epoch == 0) h->epoch = 1;  // 0 is the never-written state
-  b.xchg = h->xchg; b.epoch = h->epoch; b.ticket = h->ticket; b.ticket_base = h->ticket_base;
-  h->ticket_base += (unsigned)(NC * S);
+  b.xchg = h->xchg; b.ticket = h->ticket;  // tickets, the launch count behind the granule tags: device-side (WaveSolveArgs)
   { const int rc_lds = set_lds_once(h, reinterpret_cast<const void*>(backsolve_wave_kernel<T>), (size_t)((int)wave_solve_lds<T>())); if (rc_lds) return rc_lds; }
   hipLaunchKernelGGL(backsolve_wave_kernel<T>, dim3(NC, (unsigned)S), dim3(kThreads), wave_solve_lds<T>(), h->stream, b);
   const hipError_t le = hipGetLastError();
-  if (le != hipSuccess) {  // nothing ran: the ticket counter did not advance
-    h->ticket_base -= (unsigned)(NC * S);
-    return hip_fail(h, le, "launch of backsolve_wave_kernel");
-  }
+  if (le != hipSuccess) return hip_fail(h, le, "launch of backsolve_wave_kernel");  // nothing ran: the counters did not move
   return 0;
 }
 
@@ -316,9 +307,9 @@ int launch_panel(blr_handle* h, T* M, int64_t ld, int p, int nrows_total, int nb
   int rc;
   if ((rc = set_lds<T>(h, reinterpret_cast<const void*>(panel_chain_kernel<T, NW, ER>), CC::LDS_BYTES))) return rc;
   const int nwg = std::max(1, (nbelow + ER - 1) / ER);
-  h->arrive_base += (unsigned)nwg;  // monotonic arrival counter: never reset, wrap-around safe (signed difference in the kernel)
+  // arrival counter: counts up to nwg during the launch, zeroed again by workgroup 0 on its way out (replayable as it is)
   hipLaunchKernelGGL((panel_chain_kernel<T, NW, ER>), dim3(nwg), dim3(64 * NW), CC::LDS_BYTES, h->stream, M, ld, p * kPB, nrows_total,
-                     info_dev, h->ticket + 1, h->arrive_base);
+                     info_dev, h->ticket + 1, (unsigned)nwg);
   return 0;
 }
 

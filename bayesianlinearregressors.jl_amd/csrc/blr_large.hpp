@@ -1279,8 +1279,10 @@ struct WaveSolveArgs {
   int D, DP;
   const T* rhs; int64_t ldrhs, rhs_inc;  // rhs s, entry j: rhs[s*ldrhs + j*rhs_inc]
   unsigned long long* xchg;              // [S][DP][2] tagged granules (handle-owned, zero at allocation)
-  unsigned epoch;                        // tag of this launch (never reused by the handle)
-  unsigned* ticket; unsigned ticket_base;  // monotonically increasing start-order counter
+  unsigned* ticket;                      // the handle's counter words, all device-side so that a captured launch can be REPLAYED:
+                                         // [0] start-order tickets, [2] finished workgroups, [3] launches so far (tag of the
+                                         // exchange granules = [3] + 1); the workgroup that finishes last zeroes [0] and [2]
+                                         // and bumps [3]
   const T* add; T* out; int64_t ldout;   // out[s*ldout + j] = add[j] + m_j  (j < D); out may be NULL
   // evidence assembly (posterior; S == 1), done by the workgroup that finishes last (q = 0); logpdf may be NULL
   const double* qpart; const double* lpart; int nparts;
@@ -1328,9 +1330,25 @@ __global__ __launch_bounds__(kThreads) void backsolve_wave_kernel(WaveSolveArgs<
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = uni(tid >> 6);
   const int D = a.D, DP = a.DP, NC = DP / kPB;
-  if (tid == 0) *tick = (int)(atomicAdd(a.ticket, 1u) - a.ticket_base);
+  if (tid == 0) {
+    tick[0] = (int)atomicAdd(a.ticket, 1u);
+    tick[1] = (int)__hip_atomic_load(a.ticket + 3, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);  // stable until the launch's last exit
+  }
   __syncthreads();
-  const int ticket = *tick;
+  const int ticket = tick[0];
+  const unsigned epoch = (unsigned)tick[1] % 0xFFFFFFFFu + 1u;  // never 0: that is the never-written state of a granule
+  // every exit goes through here: the last workgroup out re-arms the counters for the next launch (or the next replay)
+  auto leave = [&]() {
+    __syncthreads();
+    if (tid == 0) {
+      const unsigned total = gridDim.x * gridDim.y;
+      if (atomicAdd(a.ticket + 2, 1u) == total - 1u) {
+        __hip_atomic_store(a.ticket + 0, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        __hip_atomic_store(a.ticket + 2, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        __hip_atomic_store(a.ticket + 3, (unsigned)tick[1] + 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      }
+    }
+  };
   const int q = NC - 1 - ticket % NC;
   const int64_t sidx = ticket / NC;
   const bool evidence = a.info != nullptr && q == 0 && sidx == 0;
@@ -1342,6 +1360,7 @@ __global__ __launch_bounds__(kThreads) void backsolve_wave_kernel(WaveSolveArgs<
     else if (a.chol_info && *a.chol_info != 0) st = *a.chol_info;
     if (st != 0) {  // uniform over the grid: nobody waits
       if (evidence && tid == 0) { *a.info = st; if (a.logpdf) *a.logpdf = kNaN; }
+      leave();
       return;
     }
   }
@@ -1387,7 +1406,7 @@ __global__ __launch_bounds__(kThreads) void backsolve_wave_kernel(WaveSolveArgs<
     for (int c = 0; c < 64; ++c) tv[c] = tp[(int64_t)c * a.ldtf];
     if (tid < kPB) {
       T v;
-      xchg_get(xg + (int64_t)(p * kPB + tid) * 2, a.epoch, &v);
+      xchg_get(xg + (int64_t)(p * kPB + tid) * 2, epoch, &v);
       mp[tid] = v;
     }
     __syncthreads();
@@ -1429,8 +1448,8 @@ __global__ __launch_bounds__(kThreads) void backsolve_wave_kernel(WaveSolveArgs<
       }
     }
     const int j0 = q * kPB + i0, j1 = q * kPB + i1;
-    xchg_put(xg + (int64_t)j0 * 2, b0, a.epoch);
-    xchg_put(xg + (int64_t)j1 * 2, b1, a.epoch);
+    xchg_put(xg + (int64_t)j0 * 2, b0, epoch);
+    xchg_put(xg + (int64_t)j1 * 2, b1, epoch);
     if (a.out) {
       if (j0 < D) a.out[sidx * a.ldout + j0] = a.add[j0] + b0;
       if (j1 < D) a.out[sidx * a.ldout + j1] = a.add[j1] + b1;
@@ -1445,6 +1464,7 @@ __global__ __launch_bounds__(kThreads) void backsolve_wave_kernel(WaveSolveArgs<
       *a.logpdf = -0.5 * (nobs * LOG2PI + logdet_Sy + qs + ld - *a.logdet_Lw_dev - uu);
     }
   }
+  leave();
 }
 
 // logdet of a factored (DP x DP lower, ld) matrix restricted to the first D diagonal entries: 2 sum log L_ii

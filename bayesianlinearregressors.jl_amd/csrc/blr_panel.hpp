@@ -453,11 +453,9 @@ __global__ __launch_bounds__(64 * NW, 1) void panel_chain_kernel(T* Abar, int64_
   const int r0 = col0 + C::W + blockIdx.x * C::ER;      // first row of this workgroup's slice of X
   const int nr = max(0, min(C::ER, nrows_total - r0));  // 0 (nothing below the block) or ER: callers pad to 64 rows
   T* const Xg = Abar + (int64_t)col0 * lda + r0;        // X(row, col) at Xg[col * lda + row]
-  const bool failed = *info != 0;                       // an earlier panel already failed (uniform over the launch)
-  if (failed) {  // nothing to do, but the arrival count must still add up
-    if (tid == 0) __hip_atomic_fetch_add(arrive, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    return;
-  }
+  // `arrive` counts the workgroups that have read A_pp, 0 .. arrive_target = gridDim.x within a launch; workgroup 0 zeroes it
+  // again on its way out, so the launch can be replayed from a captured graph as it is.
+  if (*info != 0) return;  // an earlier panel already failed (uniform over the launch): nothing to do, nobody counts or waits
   if (tid == 0) INFO[0] = 0;
   if (tid < 256) ZERO[tid] = T(0);
   unsigned arrived = arrive_target - 1u;  // workgroup 0, thread 0: the arrival counter as read a few steps before the end
@@ -728,18 +726,19 @@ __global__ __launch_bounds__(64 * NW, 1) void panel_chain_kernel(T* Abar, int64_
   // A failed factorisation leaves NaNs behind its first bad pivot; the status says so.
   BLR_TL(72);
   const int bad = INFO[0];
-  if (bad != 0) {
-    if (blockIdx.x == 0 && tid == 0) *info = col0 + bad;
-    return;
-  }
   if (blockIdx.x != 0) return;
-  if (tid == 0 && (int)(arrived - arrive_target) < 0) {
-    long long spins = 0;
-    while ((int)(__hip_atomic_load(arrive, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) - arrive_target) < 0) {
-      __builtin_amdgcn_s_sleep(8);
-      if (++spins > 20000000LL) break;  // a logic error upstream must not hang the GPU
+  if (tid == 0) {
+    if ((int)(arrived - arrive_target) < 0) {
+      long long spins = 0;
+      while ((int)(__hip_atomic_load(arrive, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) - arrive_target) < 0) {
+        __builtin_amdgcn_s_sleep(8);
+        if (++spins > 20000000LL) break;  // a logic error upstream must not hang the GPU
+      }
     }
+    __hip_atomic_store(arrive, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);  // everybody has arrived: re-arm
+    if (bad != 0) *info = col0 + bad;
   }
+  if (bad != 0) return;
   __syncthreads();  // B3
   // lower triangles, from the rows the chain wave left in LDIAG, one tile per wave
   for (int K = wave; K < NBT; K += NW) {

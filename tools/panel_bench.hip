@@ -67,16 +67,14 @@ int run(const char* name, int nwg) {
   hipEvent_t e0, e1;
   CK(hipEventCreate(&e0));
   CK(hipEventCreate(&e1));
-  unsigned target = 0;
   for (int which = 1; which < 2; ++which) {
     double tot = 0;
     const int reps = 20;
     std::vector<T> out(hA.size());
     for (int it = 0; it < reps + 2; ++it) {
       CK(hipMemcpy(dW, dA, hA.size() * sizeof(T), hipMemcpyDeviceToDevice));
-      target += (unsigned)nwg;
       CK(hipEventRecord(e0));
-      panel_chain_kernel<T, PB_NW, BLR_PANEL_ER, PB_NBT><<<nwg, 64 * PB_NW, CC::LDS_BYTES>>>(dW, lda, 0, nrows, dinfo, darr, target);
+      panel_chain_kernel<T, PB_NW, BLR_PANEL_ER, PB_NBT><<<nwg, 64 * PB_NW, CC::LDS_BYTES>>>(dW, lda, 0, nrows, dinfo, darr, (unsigned)nwg);
       CK(hipEventRecord(e1));
       CK(hipEventSynchronize(e1));
       float ms;
@@ -134,8 +132,7 @@ int run(const char* name, int nwg) {
     std::vector<T> hB = hA;
     hB[(size_t)37 * lda + 37] = (T)-1.0;
     CK(hipMemcpy(dW, hB.data(), hB.size() * sizeof(T), hipMemcpyHostToDevice));
-    target += (unsigned)nwg;
-    panel_chain_kernel<T, PB_NW, BLR_PANEL_ER, PB_NBT><<<nwg, 64 * PB_NW, CC::LDS_BYTES>>>(dW, lda, 0, nrows, dinfo, darr, target);
+    panel_chain_kernel<T, PB_NW, BLR_PANEL_ER, PB_NBT><<<nwg, 64 * PB_NW, CC::LDS_BYTES>>>(dW, lda, 0, nrows, dinfo, darr, (unsigned)nwg);
     CK(hipDeviceSynchronize());
     int info;
     CK(hipMemcpy(&info, dinfo, 4, hipMemcpyDeviceToHost));
