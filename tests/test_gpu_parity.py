@@ -1237,6 +1237,69 @@ def test_nonpositive_noise_does_not_poison_a_device_batch(B):
         assert lpc[r] == pytest.approx(O.logpdf_literal(np.zeros(D), np.ones(D), Xh[r].T, sh[r], yh[r]), rel=1e-10)
 
 
+@pytest.mark.parametrize("dtype", [np.float64, np.float32])
+def test_large_d_repeated_calls_on_resident_buffers(B, dtype):
+    # The large-D chain keeps its synchronisation state on the device (arrival counter of the panel kernel, tickets and
+    # exchange tags of the wavefront solve), re-armed by the kernels themselves: call after call on the same buffers with
+    # new contents has to see the new contents, report a failure and recover from it, and survive a differently shaped
+    # call in between.
+    import torch
+    from blr_amd import _abi
+
+    dev = torch.device("cuda:0")
+    tdt = torch.float64 if dtype == np.float64 else torch.float32
+    D, N = 384, 700
+    rng = _rng(5300)
+    h = _abi.default_handle()
+    X = torch.empty((N, D), dtype=tdt, device=dev)   # ColVecs: column n = X[n, :]
+    y = torch.empty((N,), dtype=tdt, device=dev)
+    s = torch.empty((N,), dtype=tdt, device=dev)
+    mw = torch.zeros((D,), dtype=tdt, device=dev)
+    dpr = torch.ones((D,), dtype=tdt, device=dev)
+    mwp = torch.empty((D,), dtype=tdt, device=dev)
+    Tp = torch.empty((D, D), dtype=tdt, device=dev)
+    lp = torch.zeros((1,), dtype=torch.float64, device=dev)
+    info = torch.full((1,), -77, dtype=torch.int32, device=dev)
+
+    def call():
+        h.posterior_batched(dtype, _abi.MEM_DEVICE, _abi.LAYOUT_COLVECS, 1, D, N, X.data_ptr(), D, 0, y.data_ptr(), 0,
+                            _abi.NOISE_DIAGONAL, s.data_ptr(), 0, _abi.PRIOR_DIAGONAL, mw.data_ptr(), 0, dpr.data_ptr(), 1, 0,
+                            mwp.data_ptr(), D, Tp.data_ptr(), D, D * D, None, D, D * D, lp.data_ptr(), info.data_ptr())
+        h.synchronize()
+
+    tol = 1e-9 if dtype == np.float64 else 3e-3
+    for it in range(7):
+        Xh = rng.standard_normal((D, N))
+        sh = np.exp(0.3 * rng.standard_normal(N))
+        yh = Xh.T @ rng.standard_normal(D) / np.sqrt(D) + np.sqrt(sh) * rng.standard_normal(N)
+        dh = np.exp(0.2 * rng.standard_normal(D))
+        mh = 0.1 * rng.standard_normal(D) if it % 2 else np.zeros(D)
+        bad = it == 4
+        if bad:
+            dh[200] = -1e9  # the prior is not positive: the replayed sequence has to say so and stay usable
+        X.copy_(torch.from_numpy(np.ascontiguousarray(Xh.T)).to(tdt))
+        y.copy_(torch.from_numpy(yh).to(tdt))
+        s.copy_(torch.from_numpy(sh).to(tdt))
+        dpr.copy_(torch.from_numpy(dh).to(tdt))
+        mw.copy_(torch.from_numpy(mh).to(tdt))
+        info.fill_(-77)
+        call()
+        if bad:
+            assert int(info.cpu()[0]) == 201
+            continue
+        assert int(info.cpu()[0]) == 0
+        Xr, yr, sr = X.cpu().numpy().astype(float).T, y.cpu().numpy().astype(float), s.cpu().numpy().astype(float)
+        mw_o, T_o, A_o, lp_o = O.posterior_logpdf_direct(mw.cpu().numpy().astype(float), np.diag(dpr.cpu().numpy().astype(float)), Xr, sr, yr)
+        assert float(lp.cpu()[0]) == pytest.approx(lp_o, rel=tol)
+        np.testing.assert_allclose(mwp.cpu().numpy(), mw_o, rtol=10 * tol, atol=tol)
+        if it == 2:  # another shape through the same handle (may grow the workspace)
+            f2 = B.BayesianLinearRegressor(np.zeros(520, dtype), B.Diagonal(np.ones(520, dtype)))
+            X2 = rng.standard_normal((520, 300)).astype(dtype)
+            y2 = rng.standard_normal(300).astype(dtype)
+            lp2 = O.logpdf_literal(np.zeros(520), np.ones(520), X2.astype(float), 0.5, y2.astype(float))
+            assert B.logpdf(f2(np.asfortranarray(X2), dtype(0.5)), y2) == pytest.approx(lp2, rel=tol)
+
+
 def test_mean_length_mismatch_is_rejected(B):
     # a regressor of dimension 3 applied to 5-dimensional inputs: DimensionMismatch in the reference, never a read past mw
     rng = _rng(11500)
