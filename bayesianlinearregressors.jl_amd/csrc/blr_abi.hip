@@ -320,13 +320,13 @@ int chol_large(blr_handle* h, T* M, int64_t ld, int DP, int nrows_total, int32_t
   if ((rc = ensure_xchg(h, 0))) return rc;  // the handle's counter words (ticket[1]: arrivals of panel_chain_kernel)
   if ((rc = set_lds<T>(h, reinterpret_cast<const void*>(trail_update_kernel<T>), TrailCfg<T>::LDS_BYTES))) return rc;
   for (int p = 0; p < NC; ++p) {
-    // L_pp and X <- X L_pp^-T for the rows below.  Every workgroup factors L_pp and takes 16, 32 or 64 of those rows along:
-    // the fewer, the shorter the launch (the update waves are its bottleneck) -- as long as every workgroup has a CU to itself
+    // L_pp and X <- X L_pp^-T for the rows below.  Every workgroup factors L_pp and takes 16 or 32 of those rows along: the
+    // fewer, the shorter the launch (the update waves are its bottleneck) -- as long as every workgroup has a CU to itself
+    // (D <= 8192: at most 8128 rows below a block, 254 workgroups of 32)
     const int nbelow = nrows_total - (p + 1) * kPB;
     const int cus = 256;
     if (nbelow <= 16 * cus) rc = launch_panel<T, 16>(h, M, ld, p, nrows_total, nbelow, info_dev);
-    else if (nbelow <= 32 * cus) rc = launch_panel<T, 32>(h, M, ld, p, nrows_total, nbelow, info_dev);
-    else rc = launch_panel<T, 64>(h, M, ld, p, nrows_total, nbelow, info_dev);
+    else rc = launch_panel<T, 32>(h, M, ld, p, nrows_total, nbelow, info_dev);
     if (rc) return rc;
     const int m = NC - 1 - p;  // remaining column blocks
     if (m > 0) {

@@ -595,6 +595,25 @@ def test_large_d_factorisation_names_the_first_bad_pivot(B, dtype, col):
     assert ei.value.info == col + 1
 
 
+@pytest.mark.parametrize("dtype", [np.float64, np.float32])
+def test_large_d_beyond_4096_rows_below_a_panel(B, dtype):
+    # More than 16 x 256 rows below the first blocks: those panels run with 32 rows of the block column per workgroup instead
+    # of 16 (chol_large), the later ones with 16.  Evidence and posterior mean against the oracle.
+    rng = _rng(5400)
+    D, N = 4224, 160
+    X = (rng.standard_normal((D, N)) / np.sqrt(D)).astype(dtype)
+    y = rng.standard_normal(N).astype(dtype)
+    dvec = np.exp(0.2 * rng.standard_normal(D)).astype(dtype)
+    mw = (0.05 * rng.standard_normal(D)).astype(dtype)
+    f = B.BayesianLinearRegressor(mw, B.Diagonal(dvec))
+    fx = f(np.asfortranarray(X), dtype(0.25))
+    mw_o, T_o, A_o, lp_o = O.posterior_logpdf_direct(mw.astype(float), np.diag(dvec.astype(float)), X.astype(float), np.full(N, 0.25),
+                                                     y.astype(float))
+    tol = 1e-9 if dtype == np.float64 else 2e-3
+    assert B.logpdf(fx, y) == pytest.approx(lp_o, rel=tol)
+    np.testing.assert_allclose(B.posterior(fx, y).mw, mw_o, rtol=10 * tol, atol=tol)
+
+
 def test_large_d_f32_c3_shape_reduced(B):
     # BASELINE config 3 shape family (D=1024, diagonal noise, fp32) at a reduced N the oracle finishes in seconds
     rng = _rng(6001)
