@@ -146,7 +146,19 @@ struct SmallCfg {
   static constexpr int TPW = (NB == 8) ? 9 : (NT + kWaves - 1) / kWaves;  // accumulator tiles per wave
   static constexpr int PACKED = DP * (DP + 1) / 2;
   static constexpr int RED_BYTES = 16 * DP * 8;          // b partials: 4 waves x 4 lane-rows x DP doubles
-  static constexpr int REGION0_A = 2 * SLOT * (int)sizeof(T);
+  // staging area: two stage slots, or (NB == 8) the ring of gram_iso_ring: RING_NH halves of RING_HK k-steps.  f64: 4 x 4.
+  // f32, measured back to back on one box (c2 shape, M updates/s): 4 halves of 4 k-steps 1.220, 3 halves of 8 (twice the MFMA
+  // time between two barriers) 1.241, 4 halves of 8 (64 KB: two workgroups per CU instead of four) 0.981, **3 halves of 4: 1.354**
+#ifndef BLR_RING_F32_HK
+#define BLR_RING_F32_HK 4
+#endif
+#ifndef BLR_RING_F32_NH
+#define BLR_RING_F32_NH 3
+#endif
+  static constexpr int RING_HK = sizeof(T) == 4 ? BLR_RING_F32_HK : 4;
+  static constexpr int RING_NH = sizeof(T) == 4 ? BLR_RING_F32_NH : 4;
+  static constexpr int RING_BYTES = (NB == 8) ? RING_NH * RING_HK * NB * 64 * (int)sizeof(T) : 0;
+  static constexpr int REGION0_A = (2 * SLOT * (int)sizeof(T) > RING_BYTES) ? 2 * SLOT * (int)sizeof(T) : RING_BYTES;
   static constexpr int REGION0_B = PACKED * (int)sizeof(T);
   static constexpr int REGION0_C = RED_BYTES;
   static constexpr int REGION0 =
@@ -154,7 +166,7 @@ struct SmallCfg {
                               : (REGION0_B > REGION0_C ? REGION0_B : REGION0_C)) + 15) & ~15;
   // after region 0: ybuf[2][NSC], wbuf[2][NSC], bvec[DP], dinv[DP], mw[DP] (T); scratch; context
   static constexpr int OFF_Y = REGION0;
-  static constexpr int OFF_W = OFF_Y + 2 * NSC * (int)sizeof(T);
+  static constexpr int OFF_W = OFF_Y + (2 * NSC > 128 ? 2 * NSC : 128) * (int)sizeof(T);  // (the ring keeps y for four halves of 32 columns)
   static constexpr int OFF_B = OFF_W + 2 * NSC * (int)sizeof(T);
   static constexpr int OFF_DINV = OFF_B + DP * (int)sizeof(T);
   static constexpr int OFF_MW = OFF_DINV + DP * (int)sizeof(T);
@@ -634,8 +646,8 @@ template <typename T, int WS, bool MWZ, int J, int JN, typename P1, typename P2>
 __device__ __forceinline__ void kstep_ring(AccArr<T, 8>& acc, const KF8<T, WS>& fc, KF8<T, WS>& fn, const T* __restrict__ kimg_n,
                                            const T* __restrict__ yb_n, T wiso, const T (&mwf)[8], double (&bacc)[8], double& qacc,
                                            int lane, P1 piece, P2 piece2) {
-  constexpr bool OWN = (J == WS) && (BLR_EXP != 3);
-  constexpr bool OWN_N = (JN == WS);
+  constexpr bool OWN = ((J & 3) == WS) && (BLR_EXP != 3);   // (f32: halves of 8 k-steps, two of them a wave's own)
+  constexpr bool OWN_N = ((JN & 3) == WS);
   constexpr int NBLK_N = OWN_N ? 8 : 8 - WS;  // blocks of the next k-step this wave needs
   VecWork8<T, WS, MWZ> vw;
   const T alo = fc.fb[WS], ahi = fc.fb[7 - WS];
@@ -681,12 +693,12 @@ __device__ __forceinline__ void kstep_ring(AccArr<T, 8>& acc, const KF8<T, WS>& 
 // NH = ring slots: 4 (the pipeline described above) or 3 (48 KB: half h+2 is issued during half h into the slot the barrier at
 // the end of half h-1 freed, and must have landed by the end of half h -- enough when three workgroups share the CU and a
 // half lasts three times as long)
-template <typename T, int WS, bool MWZ, int NH = 4>
+template <typename T, int WS, bool MWZ, int NH = SmallCfg<T, 8>::RING_NH>
 __device__ __forceinline__ void gram_iso_ring(T* __restrict__ ring, T* __restrict__ ybuf, const BLR_GLOBAL T* X /*uniform*/,
                                               const BLR_GLOBAL T* y /*uniform*/, int64_t ldx, int N, unsigned voff, int lane,
                                               AccArr<T, 8>& acc, double (&bacc)[8], double& qacc, const T (&mwf)[8], T wiso) {
   static_assert(NH == 3 || NH == 4, "ring depth");
-  constexpr int NB = 8, HK = 4;
+  constexpr int NB = 8, HK = SmallCfg<T, 8>::RING_HK;
   constexpr int LA = NH - 1;                           // issue distance in halves
   auto slot_of = [](int h) { return NH == 4 ? (h & 3) : (h % 3); };
   constexpr int HALF = HK * NB * 64;                   // elements per half
@@ -749,8 +761,16 @@ __device__ __forceinline__ void gram_iso_ring(T* __restrict__ ring, T* __restric
     kstep_ring<T, WS, MWZ, 0, 1>(acc, f0, f1, slot + 1 * NB * 64, yb, wiso, mwf, bacc, qacc, lane, pall, none);
     kstep_ring<T, WS, MWZ, 1, 2>(acc, f1, f0, slot + 2 * NB * 64, yb, wiso, mwf, bacc, qacc, lane, none, none);
     kstep_ring<T, WS, MWZ, 2, 3>(acc, f0, f1, slot + 3 * NB * 64, yb, wiso, mwf, bacc, qacc, lane, none, none);
-    // the first fragments of half h+1 (visible since the previous barrier) are requested under the last k-step's MFMAs
-    kstep_ring<T, WS, MWZ, 3, 0>(acc, f1, f0, slot_n, yb_n, wiso, mwf, bacc, qacc, lane, none, none);
+    if constexpr (HK == 8) {
+      kstep_ring<T, WS, MWZ, 3, 4>(acc, f1, f0, slot + 4 * NB * 64, yb, wiso, mwf, bacc, qacc, lane, none, none);
+      kstep_ring<T, WS, MWZ, 4, 5>(acc, f0, f1, slot + 5 * NB * 64, yb, wiso, mwf, bacc, qacc, lane, none, none);
+      kstep_ring<T, WS, MWZ, 5, 6>(acc, f1, f0, slot + 6 * NB * 64, yb, wiso, mwf, bacc, qacc, lane, none, none);
+      kstep_ring<T, WS, MWZ, 6, 7>(acc, f0, f1, slot + 7 * NB * 64, yb, wiso, mwf, bacc, qacc, lane, none, none);
+      // the first fragments of half h+1 (visible since the previous barrier) are requested under the last k-step's MFMAs
+      kstep_ring<T, WS, MWZ, 7, 0>(acc, f1, f0, slot_n, yb_n, wiso, mwf, bacc, qacc, lane, none, none);
+    } else {
+      kstep_ring<T, WS, MWZ, 3, 0>(acc, f1, f0, slot_n, yb_n, wiso, mwf, bacc, qacc, lane, none, none);
+    }
     // ---- end of half h: publish half h+2 (its pieces were issued during half h-1), free the slot of half h
     if (h + 1 < nh) {
       if (h + 2 < nh) retire((NH == 4 && more) ? 1 : 0);
