@@ -156,7 +156,10 @@ struct SmallCfg {
 #define BLR_RING_F32_NH 3
 #endif
   static constexpr int RING_HK = sizeof(T) == 4 ? BLR_RING_F32_HK : 4;
-  static constexpr int RING_NH = sizeof(T) == 4 ? BLR_RING_F32_NH : 4;
+#ifndef BLR_RING_F64_NH
+#define BLR_RING_F64_NH 4
+#endif
+  static constexpr int RING_NH = sizeof(T) == 4 ? BLR_RING_F32_NH : BLR_RING_F64_NH;
   static constexpr int RING_BYTES = (NB == 8) ? RING_NH * RING_HK * NB * 64 * (int)sizeof(T) : 0;
   static constexpr int REGION0_A = (2 * SLOT * (int)sizeof(T) > RING_BYTES) ? 2 * SLOT * (int)sizeof(T) : RING_BYTES;
   static constexpr int REGION0_B = PACKED * (int)sizeof(T);
