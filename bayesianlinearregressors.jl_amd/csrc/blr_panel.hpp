@@ -16,7 +16,10 @@
 //     update 4 MFMAs per tile from a column-major LDS image of the finished column (one image = A- and B-fragments alike).
 //   * accumulators hold the NEGATED matrix, so the trailing update is a plain multiply-accumulate with no sign flips.
 // Two workgroup barriers per 16 columns.  Every workgroup factors L_pp redundantly (the chain is that factorisation whoever
-// runs it); workgroup 0 writes it back once an arrival counter says every workgroup has read A_pp.
+// runs it) and takes ER rows of X along, which go back to memory as they are solved; workgroup 0 writes L_pp back -- a column's
+// tiles one step after they were solved, the diagonal tiles at the end -- once an arrival counter says every workgroup has
+// read A_pp.  The counter lives on the device and workgroup 0 zeroes it on its way out: the host keeps no state for it.
+// Measured in isolation by tools/panel_bench.hip (against a host factorisation; -DBLR_STAMPS: section sums and a time line).
 #pragma once
 #include "blr_common.hpp"
 
