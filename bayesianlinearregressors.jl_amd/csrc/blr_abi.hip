@@ -26,6 +26,7 @@ using namespace blr;
 
 struct blr_handle {
   int device = 0;
+  int cus = 256;  // compute units of the device (MI355X: 256; a partitioned part reports its share)
   hipStream_t own_stream = nullptr;
   hipStream_t stream = nullptr;
   bool async = false;
@@ -324,7 +325,7 @@ int chol_large(blr_handle* h, T* M, int64_t ld, int DP, int nrows_total, int32_t
     // fewer, the shorter the launch (the update waves are its bottleneck) -- as long as every workgroup has a CU to itself
     // (D <= 8192: at most 8128 rows below a block, 254 workgroups of 32)
     const int nbelow = nrows_total - (p + 1) * kPB;
-    const int cus = 256;
+    const int cus = h->cus;
     if (nbelow <= 16 * cus) rc = launch_panel<T, 16>(h, M, ld, p, nrows_total, nbelow, info_dev);
     else rc = launch_panel<T, 32>(h, M, ld, p, nrows_total, nbelow, info_dev);
     if (rc) return rc;
@@ -2270,6 +2271,8 @@ int blr_create(int device, blr_handle** out) {
     return -(1000 + (int)e);
   }
   h->stream = h->own_stream;
+  int cus = 0;
+  if (hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, device) == hipSuccess && cus > 0) h->cus = cus;
   *out = h;
   return 0;
 }
