@@ -9,15 +9,15 @@ from oracle import blr_oracle as O
 
 
 def one(rng, case):
-    D = int(rng.choice([1, 2, 3, 7, 15, 16, 17, 31, 33, 48, 63, 64, 65, 100, 127, 128, 129, 130, 200, 255, 256, 257, 300]))
-    N = int(rng.choice([1, 2, 3, 5, 31, 32, 33, 63, 64, 65, 100, 127, 128, 129, 255, 257, 400, 777]))
+    D = int(rng.choice([1, 2, 3, 7, 15, 16, 17, 31, 33, 48, 63, 64, 65, 100, 127, 128, 129, 130, 200, 255, 256, 257, 300, 384, 385, 512, 640, 1000, 1024]))
+    N = int(rng.choice([1, 2, 3, 5, 31, 32, 33, 63, 64, 65, 100, 127, 128, 129, 255, 257, 400, 777, 1024, 2048]))
     dtype = np.float64 if rng.random() < 0.7 else np.float32
     layout = _abi.LAYOUT_COLVECS if rng.random() < 0.6 else _abi.LAYOUT_ROWVECS
     pad = int(rng.choice([0, 0, 1, 3, 8]))
     noise = "diag" if rng.random() < 0.6 else "iso"
     prior = rng.choice(["dense", "diag", "factor"])
     X = rng.standard_normal((D, N))
-    mw = 0.5 * rng.standard_normal(D)
+    mw = 0.5 * rng.standard_normal(D) if rng.random() < 0.7 else np.zeros(D)  # (a zero prior mean takes its own branch at D > 128)
     Bm = rng.standard_normal((D, D)) / np.sqrt(D)
     Lw = Bm @ Bm.T + np.eye(D)
     if prior == "diag":
