@@ -1318,6 +1318,67 @@ __device__ __forceinline__ void xchg_get(const unsigned long long* g, unsigned t
   *v = __hiloint2double((int)hi, (int)lo);
 }
 
+// ---- 16 x 16 upper-triangular tiles inverted in registers: one row per lane, the four 16-lane DPP rows of a wave each on their
+// own tile.  u[k] = U(c, k) (k >= c; the lane's row c), dinv = 1 / U(c, c); out: v[k] = Uinv(c, k).  Row C of the scaled inverse
+// V~ = diag(U) Uinv is final once the rows below it have been folded in (C runs down), and every broadcast of it is the DPP
+// source of the multiply-add itself (blr_panel.hpp).
+template <typename T, int C>
+__device__ __forceinline__ void tri16_inv_col(const T (&u)[16], T (&v)[16], T dinv, int c) {
+  if constexpr (C >= 1) {
+    const T rsC = mov_bc16_gap<C>(dinv);
+    const T t = (c < C) ? -u[C] * rsC : T(0);  // -U(c, C) / U(C, C) for the rows above row C
+#pragma unroll
+    for (int k = C; k < 16; ++k) fmac_bc16_gap<C>(v[k], v[k], t);
+    tri16_inv_col<T, C - 1>(u, v, dinv, c);
+  }
+}
+template <typename T>
+__device__ __forceinline__ void tri16_inv(const T (&u)[16], T (&v)[16], T dinv, int c) {
+#pragma unroll
+  for (int k = 0; k < 16; ++k) v[k] = (k == c) ? T(1) : T(0);
+  tri16_inv_col<T, 15>(u, v, dinv, c);
+#pragma unroll
+  for (int k = 0; k < 16; ++k) v[k] *= dinv;
+}
+// x(c) = sum_k Uinv(c, k) r(k) for the tile whose 16 right-hand-side entries sit in this lane's DPP row of `rr`
+template <typename T>
+__device__ __forceinline__ T tri16_apply(const T (&v)[16], T rr) {
+  T x0 = T(0), x1 = T(0), x2 = T(0), x3 = T(0);
+  fmac_bc16_gap<0>(x0, rr, v[0]);   fmac_bc16<1>(x1, rr, v[1]);   fmac_bc16<2>(x2, rr, v[2]);   fmac_bc16<3>(x3, rr, v[3]);
+  fmac_bc16<4>(x0, rr, v[4]);       fmac_bc16<5>(x1, rr, v[5]);   fmac_bc16<6>(x2, rr, v[6]);   fmac_bc16<7>(x3, rr, v[7]);
+  fmac_bc16<8>(x0, rr, v[8]);       fmac_bc16<9>(x1, rr, v[9]);   fmac_bc16<10>(x2, rr, v[10]); fmac_bc16<11>(x3, rr, v[11]);
+  fmac_bc16<12>(x0, rr, v[12]);     fmac_bc16<13>(x1, rr, v[13]); fmac_bc16<14>(x2, rr, v[14]); fmac_bc16<15>(x3, rr, v[15]);
+  return (x0 + x1) + (x2 + x3);
+}
+// one 16-row tile of the back substitution of a 128-row block (wave 0; b0 / b1: rows lane and 64 + lane of the right-hand side).
+// The tile's solution comes from its inverted diagonal tile; the rows above the tile then take the tile's 16 columns of U in
+// one go (their entries of L are requested before the solution exists, so only readlane + multiply-add follow it).
+template <typename T, int TT>
+__device__ __forceinline__ void back_tile(const T* __restrict__ P, const T (&vA)[16], const T (&vB)[16], T& b0, T& b1, int lane) {
+  constexpr bool HI = TT >= 4;
+  T l0[16], l1[16];
+  if constexpr (TT >= 1) {
+#pragma unroll
+    for (int c = 0; c < 16; ++c) l0[c] = P[pidx(16 * TT + c, 0) + lane];       // L(16 TT + c, lane): rows 0..63 (masked below)
+  }
+  if constexpr (TT >= 5) {
+#pragma unroll
+    for (int c = 0; c < 16; ++c) l1[c] = P[pidx(16 * TT + c, 0) + 64 + lane];  // rows 64..127
+  }
+  T& rr = HI ? b1 : b0;
+  const T x = tri16_apply<T>(HI ? vB : vA, rr);
+  if ((lane >> 4) == (TT & 3)) rr = x;
+  T d0 = T(0), d1 = T(0);
+#pragma unroll
+  for (int c = 0; c < 16; ++c) {
+    const T xc = readlane(x, 16 * (TT & 3) + c);
+    if constexpr (TT >= 1) d0 += l0[c] * xc;
+    if constexpr (TT >= 5) d1 += l1[c] * xc;
+  }
+  if constexpr (TT >= 1) { if (lane < (TT >= 4 ? 64 : 16 * TT)) b0 -= d0; }
+  if constexpr (TT >= 5) { if (lane < 16 * (TT - 4)) b1 -= d1; }
+}
+
 template <typename T>
 __global__ __launch_bounds__(kThreads) void backsolve_wave_kernel(WaveSolveArgs<T> a) {
   constexpr int P_BYTES = ((kPB * (kPB + 1) / 2) * (int)sizeof(T) + 15) & ~15;
@@ -1390,10 +1451,22 @@ __global__ __launch_bounds__(kThreads) void backsolve_wave_kernel(WaveSolveArgs<
     ls = block_allreduce(ls, scr, tid);
   }
   __syncthreads();  // P complete
-  T r0 = T(0), r1 = T(0);
-  if (wave == 0) {  // reciprocal pivots: off the critical path
-    r0 = T(1) / P[pidx(i0, i0)];
-    r1 = T(1) / P[pidx(i1, i1)];
+  // the eight 16 x 16 diagonal tiles of U_qq inverted (wave 0, DPP row t % 4 holds tile t: vA tiles 0-3, vB tiles 4-7): off the
+  // critical path -- this workgroup waits for its predecessors anyway -- and it takes the 128 serial pivots (3.8 us of a
+  // 6 us hop) out of the chain
+  T vA[16], vB[16];
+  if (wave == 0) {
+    const int c = lane & 15, tq = lane >> 4;
+#pragma unroll
+    for (int pass = 0; pass < 2; ++pass) {
+      const int d0 = 16 * (tq + 4 * pass);  // first row / column of this lane's tile
+      T u[16];
+#pragma unroll
+      for (int k = 0; k < 16; ++k) u[k] = (k >= c) ? P[pidx(d0 + k, d0 + c)] : T(0);  // U(c, k) = L(k, c)
+      const T dinv = T(1) / P[pidx(d0 + c, d0 + c)];
+      if (pass == 0) tri16_inv<T>(u, vA, dinv, c);
+      else tri16_inv<T>(u, vB, dinv, c);
+    }
   }
 
   const int r = tid & (kPB - 1), half = tid >> 7;
@@ -1426,27 +1499,15 @@ __global__ __launch_bounds__(kThreads) void backsolve_wave_kernel(WaveSolveArgs<
   if (wave == 0) {
     b0 -= part[i0] + part[kPB + i0];
     b1 -= part[i1] + part[kPB + i1];
-    // column-oriented back substitution, 8 pivots per step: the rows of L a step needs are loaded up front, so the
-    // serial chain per pivot is readlane -> multiply -> fma with no LDS latency in it
-    for (int kb = kPB - 1; kb >= 0; kb -= 8) {
-      T row0[8], row1[8];
-#pragma unroll
-      for (int u = 0; u < 8; ++u) {
-        const int k = kb - u;
-        const T* row = P + pidx(k, 0);
-        row0[u] = (i0 < k) ? row[i0] : T(0);
-        row1[u] = (i1 < k) ? row[i1] : T(0);
-      }
-#pragma unroll
-      for (int u = 0; u < 8; ++u) {
-        const int k = kb - u;
-        const bool lo = k < 64;
-        const T mk = readlane(lo ? b0 : b1, k & 63) * readlane(lo ? r0 : r1, k & 63);
-        if (lane == (k & 63)) { if (lo) b0 = mk; else b1 = mk; }
-        b0 -= row0[u] * mk;
-        b1 -= row1[u] * mk;
-      }
-    }
+    // back substitution, 16 rows at a time from the last tile up
+    back_tile<T, 7>(P, vA, vB, b0, b1, lane);
+    back_tile<T, 6>(P, vA, vB, b0, b1, lane);
+    back_tile<T, 5>(P, vA, vB, b0, b1, lane);
+    back_tile<T, 4>(P, vA, vB, b0, b1, lane);
+    back_tile<T, 3>(P, vA, vB, b0, b1, lane);
+    back_tile<T, 2>(P, vA, vB, b0, b1, lane);
+    back_tile<T, 1>(P, vA, vB, b0, b1, lane);
+    back_tile<T, 0>(P, vA, vB, b0, b1, lane);
     const int j0 = q * kPB + i0, j1 = q * kPB + i1;
     xchg_put(xg + (int64_t)j0 * 2, b0, epoch);
     xchg_put(xg + (int64_t)j1 * 2, b1, epoch);
