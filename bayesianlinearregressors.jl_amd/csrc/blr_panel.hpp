@@ -65,6 +65,7 @@ struct ChainCfg {
   static constexpr int OFF_INFO = OFF_LDIAG + NBT * 16 * LDD * S;
   static constexpr int OFF_TAB = OFF_INFO + 16;              // [NU][NBT] first solved row id of wave u in column J
   static constexpr int LDS_BYTES = OFF_TAB + NU * NBT * 4;
+  static_assert(LDS_BYTES <= 160 * 1024, "one workgroup per CU must fit the 160 KB of LDS");
   __host__ __device__ static constexpr int col_begin(int K) {  // first tile of column K in the enumeration
     return K == 0 ? 0 : (K == 1 ? NR : 2 * NR - 1 + (K - 2) * (NR + 1) - ((K - 1) * K / 2 - 1));
   }
