@@ -40,7 +40,7 @@ struct blr_handle {
   // wavefront back substitution (D > 128): tagged exchange buffer, start-order ticket counter, launch epoch
   unsigned long long* xchg = nullptr;
   size_t xchg_bytes = 0;
-  unsigned* ticket = nullptr;     // [0]: start-order tickets of the wavefront solve, [1]: arrivals of panel_factor_kernel
+  unsigned* ticket = nullptr;     // [0], [2], [3]: wavefront solve (tickets, done, launch count); [8 + g]: arrivals of panel_chain_kernel
   // kernels whose dynamic-LDS limit has been raised on this handle's device (hipFuncSetAttribute is per device and costs a
   // driver call: once per (handle, kernel), not once per launch -- it sat on the launch path of the 5 us wave kernel)
   std::unordered_map<const void*, size_t> lds_limit;
@@ -302,23 +302,31 @@ int set_lds(blr_handle* h, const void* kern, size_t bytes) { return set_lds_once
 // In-place blocked (128) right-looking Cholesky of the lower triangle of M (nrows_total x DP, ld); rows beyond DP
 // (the right-hand-side block of the augmented matrix) are carried through the TRSM and the trailing updates.
 template <typename T, int ER>
-int launch_panel(blr_handle* h, T* M, int64_t ld, int p, int nrows_total, int nbelow, int32_t* info_dev) {
+int launch_panel(blr_handle* h, T* M, int64_t ld, int p, int nrows_total, int nbelow, int32_t* info_dev, int G, int64_t batch_stride,
+                 int info_stride) {
   constexpr int NW = BLR_PANEL_WAVES;
   using CC = ChainCfg<T, NW, ER>;
   int rc;
   if ((rc = set_lds<T>(h, reinterpret_cast<const void*>(panel_chain_kernel<T, NW, ER>), CC::LDS_BYTES))) return rc;
   const int nwg = std::max(1, (nbelow + ER - 1) / ER);
-  // arrival counter: counts up to nwg during the launch, zeroed again by workgroup 0 on its way out (replayable as it is)
-  hipLaunchKernelGGL((panel_chain_kernel<T, NW, ER>), dim3(nwg), dim3(64 * NW), CC::LDS_BYTES, h->stream, M, ld, p * kPB, nrows_total,
-                     info_dev, h->ticket + 1, (unsigned)nwg);
+  // arrival counters (one per factorisation of the launch): count up to nwg during the launch, zeroed again by workgroup 0
+  // on its way out (replayable as it is)
+  hipLaunchKernelGGL((panel_chain_kernel<T, NW, ER>), dim3(nwg, G), dim3(64 * NW), CC::LDS_BYTES, h->stream, M, ld, p * kPB, nrows_total,
+                     info_dev, h->ticket + 8, (unsigned)nwg, batch_stride, info_stride);
   return 0;
 }
 
+constexpr int kChainBatch = 4;  // factorisations that step through their panels in shared launches (arrival words ticket[8..15])
+
+// Blocked Cholesky of G independent matrices M + g * batch_stride (status words info_dev + g * info_stride), panel by panel,
+// every step ONE launch over all of them.
 template <typename T>
-int chol_large(blr_handle* h, T* M, int64_t ld, int DP, int nrows_total, int32_t* info_dev) {
+int chol_large(blr_handle* h, T* M, int64_t ld, int DP, int nrows_total, int32_t* info_dev, int G = 1, int64_t batch_stride = 0,
+               int info_stride = 0) {
   const int NC = DP / kPB;
   int rc;
-  if ((rc = ensure_xchg(h, 0))) return rc;  // the handle's counter words (ticket[1]: arrivals of panel_chain_kernel)
+  if (G < 1 || G > 8) return hip_fail(h, hipErrorInvalidValue, "chol_large: 1..8 factorisations per launch");
+  if ((rc = ensure_xchg(h, 0))) return rc;  // the handle's counter words (ticket[8 + g]: arrivals of panel_chain_kernel)
   if ((rc = set_lds<T>(h, reinterpret_cast<const void*>(trail_update_kernel<T>), TrailCfg<T>::LDS_BYTES))) return rc;
   for (int p = 0; p < NC; ++p) {
     // L_pp and X <- X L_pp^-T for the rows below.  Every workgroup factors L_pp and takes 16 or 32 of those rows along: the
@@ -326,8 +334,8 @@ int chol_large(blr_handle* h, T* M, int64_t ld, int DP, int nrows_total, int32_t
     // (D <= 8192: at most 8128 rows below a block, 254 workgroups of 32)
     const int nbelow = nrows_total - (p + 1) * kPB;
     const int cus = h->cus;
-    if (nbelow <= 16 * cus) rc = launch_panel<T, 16>(h, M, ld, p, nrows_total, nbelow, info_dev);
-    else rc = launch_panel<T, 32>(h, M, ld, p, nrows_total, nbelow, info_dev);
+    if ((int64_t)G * ((nbelow + 15) / 16) <= cus) rc = launch_panel<T, 16>(h, M, ld, p, nrows_total, nbelow, info_dev, G, batch_stride, info_stride);
+    else rc = launch_panel<T, 32>(h, M, ld, p, nrows_total, nbelow, info_dev, G, batch_stride, info_stride);
     if (rc) return rc;
     const int m = NC - 1 - p;  // remaining column blocks
     if (m > 0) {
@@ -335,8 +343,9 @@ int chol_large(blr_handle* h, T* M, int64_t ld, int DP, int nrows_total, int32_t
       const int nextra = (nrows_total - DP) / TrailCfg<T>::SB;  // rhs rows below the square part
       const int ntiles = ntri * (ntri + 1) / 2 + nextra * ntri;
       const int slots = 256 * (TrailCfg<T>::LDS_BYTES <= 80 * 1024 ? 2 : 1);  // sub-tiles the chip holds at once
-      hipLaunchKernelGGL(trail_update_kernel<T>, dim3(std::min(ntiles, slots)), dim3(kThreads), TrailCfg<T>::LDS_BYTES, h->stream, M, ld,
-                         p, ntri, (p + 1) * kPB, DP, (const int32_t*)info_dev, ntiles);
+      const int gx = std::min(ntiles, std::max(1, slots / G));
+      hipLaunchKernelGGL(trail_update_kernel<T>, dim3(gx, G), dim3(kThreads), TrailCfg<T>::LDS_BYTES, h->stream, M, ld,
+                         p, ntri, (p + 1) * kPB, DP, (const int32_t*)info_dev, ntiles, batch_stride, info_stride);
     }
   }
   HIP_TRY(h, hipGetLastError());
@@ -344,7 +353,11 @@ int chol_large(blr_handle* h, T* M, int64_t ld, int DP, int nrows_total, int32_t
 }
 
 template <typename T>
-int posterior_large_one(blr_handle* h, const PosteriorArgs<T>& a, int64_t reg) {
+// `G` regressors reg0 .. reg0 + G - 1 of the batch, each with its own copy of the workspace: statistics and Gram launches one
+// regressor after the other (they fill the chip), then ONE blocked factorisation over all of them (its ~2 dispatches per panel
+// are latency, not throughput: panel_chain_kernel / trail_update_kernel take the regressor from blockIdx.y), then the
+// back substitutions.  G = 1 is the single-regressor path as it always was.
+int posterior_large_group(blr_handle* h, const PosteriorArgs<T>& a, int64_t reg0, int G) {
   using LC = LargeCfg<T>;
   const int D = a.D, N = a.N;
   const int DP = (D + kPB - 1) / kPB * kPB, NC = DP / kPB;
@@ -378,7 +391,7 @@ int posterior_large_one(blr_handle* h, const PosteriorArgs<T>& a, int64_t reg) {
   {
     const int slots = 256 * (sizeof(T) == 4 ? BLR_GRAM_WGS : 2);
     // (only where the diagonal tiles will go through the ring loop: f32, LDS-DMA staging, whole row blocks)
-    const T* X0 = a.X + reg * a.strideX;
+    const T* X0 = a.X + reg0 * a.strideX;
     const bool dealt = sizeof(T) == 4 && a.layout == LAYOUT_COLVECS && ((uintptr_t)X0 % 16 == 0) &&
                        ((a.ldx * (int64_t)sizeof(T)) % 16 == 0) && getenv("BLR_MI355X_NO_GRAM_RING") == nullptr &&
                        getenv("BLR_MI355X_NO_DIAG_SPLIT") == nullptr && D % kPB == 0 && NC >= 2 && (ntiles * nsplit <= slots || getenv("BLR_MI355X_GRAM_SPLITS") != nullptr);
@@ -421,9 +434,12 @@ int posterior_large_one(blr_handle* h, const PosteriorArgs<T>& a, int64_t reg) {
   const size_t o_l = carve((size_t)gridc * sizeof(double));
   const size_t o_m = carve((size_t)DP * DP * sizeof(T));  // transposed factor for the back substitution
   const size_t o_sc = carve(64);
-  int rc = ensure_ws(h, off);
+  const size_t per = off;  // one regressor's workspace (a multiple of 256 bytes)
+  int rc = ensure_ws(h, per * (size_t)G);
   if (rc) return rc;
-  char* ws = h->ws;
+  for (int gi = 0; gi < G; ++gi) {
+  const int64_t reg = reg0 + gi;
+  char* ws = h->ws + (size_t)gi * per;
   T* Abar = reinterpret_cast<T*>(ws + o_abar);
   T* W = reinterpret_cast<T*>(ws + o_w);
   T* Gpart = reinterpret_cast<T*>(ws + o_gp);
@@ -431,7 +447,6 @@ int posterior_large_one(blr_handle* h, const PosteriorArgs<T>& a, int64_t reg) {
   T* rvec = reinterpret_cast<T*>(ws + o_r);
   double* qpart = reinterpret_cast<double*>(ws + o_q);
   double* lpart = reinterpret_cast<double*>(ws + o_l);
-  T* Tfull = reinterpret_cast<T*>(ws + o_m);
   double* logdetLw = reinterpret_cast<double*>(ws + o_sc);
   int32_t* info_prior = reinterpret_cast<int32_t*>(ws + o_sc + 8);
   int32_t* info_chol = reinterpret_cast<int32_t*>(ws + o_sc + 12);
@@ -516,10 +531,27 @@ int posterior_large_one(blr_handle* h, const PosteriorArgs<T>& a, int64_t reg) {
   g.tile_i0 = 0; g.tile_j0 = 0; g.tri = 1;
   gram_tiles(h->stream, nsplit, ntiles, Gpart);
   gram_reduce(h->stream, nsplit, ntiles, Gpart, NC);
+  }
   // ---- blocked Cholesky of Abar (rows DP.. = rhs) -> L, u  (reference :86, :57)
   // (only the first 64 of the 128 padding rows ride along: row DP is b', the others are zero and nobody reads them back --
   // half the right-hand-side sub-tiles of every trailing update, and c5's first trailing updates fit one round)
-  if ((rc = chol_large<T>(h, Abar, lda, DP, DP + TrailCfg<T>::SB, info_chol))) return rc;
+  if ((rc = chol_large<T>(h, reinterpret_cast<T*>(h->ws + o_abar), lda, DP, DP + TrailCfg<T>::SB,
+                          reinterpret_cast<int32_t*>(h->ws + o_sc + 12), G, (int64_t)(per / sizeof(T)), (int)(per / sizeof(int32_t)))))
+    return rc;
+
+  for (int gi = 0; gi < G; ++gi) {
+  const int64_t reg = reg0 + gi;
+  char* ws = h->ws + (size_t)gi * per;
+  T* Abar = reinterpret_cast<T*>(ws + o_abar);
+  double* qpart = reinterpret_cast<double*>(ws + o_q);
+  double* lpart = reinterpret_cast<double*>(ws + o_l);
+  T* Tfull = reinterpret_cast<T*>(ws + o_m);
+  double* logdetLw = reinterpret_cast<double*>(ws + o_sc);
+  int32_t* info_prior = reinterpret_cast<int32_t*>(ws + o_sc + 8);
+  int32_t* info_chol = reinterpret_cast<int32_t*>(ws + o_sc + 12);
+  unsigned* info_noise = reinterpret_cast<unsigned*>(ws + o_sc + 16);
+  const T* s = a.s + reg * a.strides;
+  const T* mw = a.mw + reg * a.stridemw;
 
   // ---- T = L' (for the caller and for the AXPY-form back substitution), then m, posterior mean, evidence
   {
@@ -538,15 +570,24 @@ int posterior_large_one(blr_handle* h, const PosteriorArgs<T>& a, int64_t reg) {
     b.prior_info = info_prior; b.noise_info = info_noise;
     if ((rc = launch_wave_solve<T>(h, b, NC, 1))) return rc;
   }
+  }
   HIP_TRY(h, hipGetLastError());
   return 0;
 }
 
 template <typename T>
+int posterior_large_one(blr_handle* h, const PosteriorArgs<T>& a, int64_t reg) { return posterior_large_group<T>(h, a, reg, 1); }
+
+template <typename T>
 int dispatch_posterior(blr_handle* h, const PosteriorArgs<T>& a) {
   if (a.D <= kMaxSmallD) return dispatch_fused_small<T>(h, a);
-  for (int64_t reg = 0; reg < a.B; ++reg) {
-    int rc = posterior_large_one<T>(h, a, reg);
+  // regressors of a batch go through the blocked factorisation in groups (posterior_large_group); the regressors of a group
+  // must see the same alignment of X (one split / staging decision per group)
+  int gmax = a.D <= 2048 ? kChainBatch : (a.D <= 4096 ? 2 : 1);
+  if (const char* e = getenv("BLR_MI355X_CHAIN_BATCH")) gmax = std::max(1, std::min(8, atoi(e)));  // measurements only
+  if ((a.strideX * (int64_t)sizeof(T)) % 16 != 0) gmax = 1;
+  for (int64_t reg = 0; reg < a.B; reg += gmax) {
+    int rc = posterior_large_group<T>(h, a, reg, (int)std::min<int64_t>(gmax, a.B - reg));
     if (rc) return rc;
   }
   return 0;

@@ -921,8 +921,11 @@ template <typename T>
 __global__ __launch_bounds__(kThreads) void trail_update_kernel(T* M, int64_t ld, int p, int ntri /* 64-row blocks in the triangle */,
                                                                 int row_tri0 /* first row of the triangle */,
                                                                 int row_extra0 /* first extra row (rhs rows) */,
-                                                                const int32_t* info, int ntiles /* all sub-tiles of the launch */) {
+                                                                const int32_t* info, int ntiles /* all sub-tiles of the launch */,
+                                                                int64_t batch_stride = 0, int info_stride = 0) {
   using Cfg = TrailCfg<T>;
+  M += (int64_t)blockIdx.y * batch_stride;  // blockIdx.y: independent factorisations stepping together (panel_chain_kernel)
+  info += (int64_t)blockIdx.y * info_stride;
   using acc4 = typename Mfma<T>::acc4;
   constexpr int VEC = Mfma<T>::VEC;
   constexpr int SB = Cfg::SB;

@@ -432,8 +432,14 @@ __device__ __forceinline__ typename Mfma<T>::acc4 solve_tile(const T* pre_tile, 
 template <typename T, int NW, int ER = BLR_PANEL_ER, int NBT = 8>
 __global__ __launch_bounds__(64 * NW, 1) void panel_chain_kernel(T* Abar, int64_t lda, int col0 /* first column of the panel */,
                                                                  int nrows_total, int32_t* info, unsigned* arrive,
-                                                                 unsigned arrive_target) {
+                                                                 unsigned arrive_target, int64_t batch_stride = 0,
+                                                                 int info_stride = 0) {
   using C = ChainCfg<T, NW, ER, NBT>;
+  // blockIdx.y: one of several independent factorisations that step through their panels together (regressors of a batch
+  // at D > 128: every launch of the chain is latency, not throughput, so G matrices cost little more than one)
+  Abar += (int64_t)blockIdx.y * batch_stride;
+  info += (int64_t)blockIdx.y * info_stride;
+  arrive += blockIdx.y;
   using acc4 = typename Mfma<T>::acc4;
   static_assert(C::col_begin(NBT) == C::NT, "tile enumeration");
   constexpr int NB1 = C::NB1;

@@ -1257,6 +1257,79 @@ def test_nonpositive_noise_does_not_poison_a_device_batch(B):
 
 
 @pytest.mark.parametrize("dtype", [np.float64, np.float32])
+@pytest.mark.parametrize("nb,D,N,prior", [(2, 200, 300, "diagonal"), (3, 384, 500, "dense"), (5, 330, 260, "pdmat"), (6, 640, 900, "diagonal"),
+                                          (9, 130, 64, "dense")])
+def test_large_d_batched_regressors_share_the_factorisation_launches(B, dtype, nb, D, N, prior, monkeypatch):
+    # B > 1 at D > 128: groups of up to four regressors step through the blocked factorisation in shared launches
+    # (posterior_large_group; blockIdx.y of the panel and trailing-update kernels).  Every regressor against the oracle, a
+    # regressor whose system is not positive definite must fail alone (its neighbours in the group untouched), and the
+    # result has to be bit-for-bit what one-regressor-at-a-time launches give (same kernels, same data, no atomics).
+    a = B._abi
+    h = a.default_handle()
+    rng = _rng(6100 + nb + D)
+    X = rng.standard_normal((nb, N, D)).astype(dtype)
+    mw = (0.1 * rng.standard_normal((nb, D))).astype(dtype)
+    s = np.exp(0.3 * rng.standard_normal((nb, N))).astype(dtype)
+    y = rng.standard_normal((nb, N)).astype(dtype)
+    bad = 1 if nb > 2 else None
+    kb = D - 60  # where the bad regressor's prior breaks (0-based)
+    if prior == "diagonal":
+        Lw_arg = np.exp(0.3 * rng.standard_normal((nb, D))).astype(dtype)
+        if bad is not None:
+            Lw_arg[bad, kb] = -4.0
+        Lw_dense = [np.diag(Lw_arg[b].astype(np.float64)) for b in range(nb)]
+        pk, ldl, strideLw = a.PRIOR_DIAGONAL, 1, D
+    else:
+        Ms = []
+        for b in range(nb):
+            Bm = rng.standard_normal((D, D)) / np.sqrt(D)
+            Ms.append(Bm @ Bm.T + np.eye(D))
+        if prior == "dense":
+            if bad is not None:
+                Lc = np.linalg.cholesky(Ms[bad]); Lc[kb, kb] = 0.0
+                Ms[bad] = Lc @ Lc.T; Ms[bad][kb, kb] -= 1.0
+            Lw_arg = np.stack([M.astype(dtype) for M in Ms])  # symmetric: either order
+            Lw_dense = [np.asarray(Lw_arg[b], dtype=np.float64) for b in range(nb)]
+            pk = a.PRIOR_DENSE
+        else:
+            U = [O.chol_upper(M).astype(dtype) for M in Ms]
+            if bad is not None:
+                U[bad][7, 7] = 0.0  # a singular factor: reported as column 8 of the prior
+            Lw_arg = np.stack([U[b].T.copy() for b in range(nb)])
+            Lw_dense = [U[b].astype(np.float64).T @ U[b].astype(np.float64) for b in range(nb)]
+            pk = a.PRIOR_UPPER_FACTOR
+        ldl, strideLw = D, D * D
+
+    def run():
+        mw_post = np.zeros((nb, D), dtype=dtype); T_post = np.zeros((nb, D, D), dtype=dtype); Lw_post = np.zeros((nb, D, D), dtype=dtype)
+        lp = np.zeros(nb); info = np.full(nb, 9, dtype=np.int32)
+        h.posterior_batched(dtype, a.MEM_HOST, a.LAYOUT_COLVECS, nb, D, N, X, D, N * D, y, N, a.NOISE_DIAGONAL, s, N, pk,
+                            mw, D, Lw_arg, ldl, strideLw, mw_post, D, T_post, D, D * D, Lw_post, D, D * D, lp, info)
+        return mw_post, T_post, Lw_post, lp, info
+
+    mw_post, T_post, Lw_post, lp, info = run()
+    want = [0] * nb
+    if bad is not None:
+        want[bad] = {"diagonal": kb + 1, "dense": kb + 1, "pdmat": 8}[prior]
+    assert info.tolist() == want
+    tol = 1e-9 if dtype == np.float64 else 3e-3
+    for b in range(nb):
+        if b == bad:
+            assert np.isnan(lp[b])
+            continue
+        mw_o, T_o, A_o, lp_o = O.posterior_logpdf_direct(mw[b].astype(float), Lw_dense[b], X[b].T.astype(float), s[b].astype(float), y[b].astype(float))
+        assert lp[b] == pytest.approx(lp_o, rel=tol)
+        np.testing.assert_allclose(mw_post[b], mw_o, rtol=10 * tol, atol=tol * np.abs(mw_o).max())
+        Tn = np.triu(T_post[b].T.astype(np.float64))
+        np.testing.assert_allclose(Tn.T @ Tn, A_o, rtol=tol, atol=tol * np.abs(A_o).max())
+    monkeypatch.setenv("BLR_MI355X_CHAIN_BATCH", "1")
+    mw1, T1, L1, lp1, info1 = run()
+    assert info1.tolist() == want
+    ok = [b for b in range(nb) if b != bad]
+    assert np.array_equal(mw1[ok], mw_post[ok]) and np.array_equal(T1[ok], T_post[ok]) and np.array_equal(lp1[ok], lp[ok])
+
+
+@pytest.mark.parametrize("dtype", [np.float64, np.float32])
 def test_large_d_repeated_calls_on_resident_buffers(B, dtype):
     # The large-D chain keeps its synchronisation state on the device (arrival counter of the panel kernel, tickets and
     # exchange tags of the wavefront solve), re-armed by the kernels themselves: call after call on the same buffers with
