@@ -40,7 +40,7 @@ struct blr_handle {
   // wavefront back substitution (D > 128): tagged exchange buffer, start-order ticket counter, launch epoch
   unsigned long long* xchg = nullptr;
   size_t xchg_bytes = 0;
-  unsigned* ticket = nullptr;     // [0], [2], [3]: wavefront solve (tickets, done, launch count); [8 + g]: arrivals of panel_chain_kernel
+  unsigned* ticket = nullptr;     // [0], [2], [3]: wavefront solve (tickets, done, launch count); [16 + g]: arrivals of panel_chain_kernel
   // kernels whose dynamic-LDS limit has been raised on this handle's device (hipFuncSetAttribute is per device and costs a
   // driver call: once per (handle, kernel), not once per launch -- it sat on the launch path of the 5 us wave kernel)
   std::unordered_map<const void*, size_t> lds_limit;
@@ -172,8 +172,8 @@ int ensure_ws(blr_handle* h, size_t bytes) {
 // epochs that are never reused, so a stale granule can never carry the current tag.
 int ensure_xchg(blr_handle* h, size_t bytes) {
   if (!h->ticket) {
-    HIP_TRY(h, hipMalloc((void**)&h->ticket, 64));
-    HIP_TRY(h, hipMemsetAsync(h->ticket, 0, 64, h->stream));
+    HIP_TRY(h, hipMalloc((void**)&h->ticket, 256));
+    HIP_TRY(h, hipMemsetAsync(h->ticket, 0, 256, h->stream));
   }
   if (bytes <= h->xchg_bytes) return 0;
   if (h->xchg) {
@@ -312,11 +312,12 @@ int launch_panel(blr_handle* h, T* M, int64_t ld, int p, int nrows_total, int nb
   // arrival counters (one per factorisation of the launch): count up to nwg during the launch, zeroed again by workgroup 0
   // on its way out (replayable as it is)
   hipLaunchKernelGGL((panel_chain_kernel<T, NW, ER>), dim3(nwg, G), dim3(64 * NW), CC::LDS_BYTES, h->stream, M, ld, p * kPB, nrows_total,
-                     info_dev, h->ticket + 8, (unsigned)nwg, batch_stride, info_stride);
+                     info_dev, h->ticket + 16, (unsigned)nwg, batch_stride, info_stride);
   return 0;
 }
 
-constexpr int kChainBatch = 4;  // factorisations that step through their panels in shared launches (arrival words ticket[8..15])
+constexpr size_t kChainWorkspace = (size_t)8 << 30;  // ... as long as their workspaces fit this many bytes
+constexpr int kChainBatchMax = 32;  // factorisations that step through their panels in shared launches (arrival words ticket[16..47])
 
 // Blocked Cholesky of G independent matrices M + g * batch_stride (status words info_dev + g * info_stride), panel by panel,
 // every step ONE launch over all of them.
@@ -325,8 +326,8 @@ int chol_large(blr_handle* h, T* M, int64_t ld, int DP, int nrows_total, int32_t
                int info_stride = 0) {
   const int NC = DP / kPB;
   int rc;
-  if (G < 1 || G > 8) return hip_fail(h, hipErrorInvalidValue, "chol_large: 1..8 factorisations per launch");
-  if ((rc = ensure_xchg(h, 0))) return rc;  // the handle's counter words (ticket[8 + g]: arrivals of panel_chain_kernel)
+  if (G < 1 || G > kChainBatchMax) return hip_fail(h, hipErrorInvalidValue, "chol_large: too many factorisations per launch");
+  if ((rc = ensure_xchg(h, 0))) return rc;  // the handle's counter words (ticket[16 + g]: arrivals of panel_chain_kernel)
   if ((rc = set_lds<T>(h, reinterpret_cast<const void*>(trail_update_kernel<T>), TrailCfg<T>::LDS_BYTES))) return rc;
   for (int p = 0; p < NC; ++p) {
     // L_pp and X <- X L_pp^-T for the rows below.  Every workgroup factors L_pp and takes 16 or 32 of those rows along: the
@@ -357,7 +358,7 @@ template <typename T>
 // regressor after the other (they fill the chip), then ONE blocked factorisation over all of them (its ~2 dispatches per panel
 // are latency, not throughput: panel_chain_kernel / trail_update_kernel take the regressor from blockIdx.y), then the
 // back substitutions.  G = 1 is the single-regressor path as it always was.
-int posterior_large_group(blr_handle* h, const PosteriorArgs<T>& a, int64_t reg0, int G) {
+int posterior_large_group(blr_handle* h, const PosteriorArgs<T>& a, int64_t reg0, int G, int* G_done = nullptr) {
   using LC = LargeCfg<T>;
   const int D = a.D, N = a.N;
   const int DP = (D + kPB - 1) / kPB * kPB, NC = DP / kPB;
@@ -435,6 +436,8 @@ int posterior_large_group(blr_handle* h, const PosteriorArgs<T>& a, int64_t reg0
   const size_t o_m = carve((size_t)DP * DP * sizeof(T));  // transposed factor for the back substitution
   const size_t o_sc = carve(64);
   const size_t per = off;  // one regressor's workspace (a multiple of 256 bytes)
+  G = (int)std::max<size_t>(1, std::min<size_t>((size_t)G, kChainWorkspace / per));
+  if (G_done) *G_done = G;
   int rc = ensure_ws(h, per * (size_t)G);
   if (rc) return rc;
   for (int gi = 0; gi < G; ++gi) {
@@ -539,37 +542,28 @@ int posterior_large_group(blr_handle* h, const PosteriorArgs<T>& a, int64_t reg0
                           reinterpret_cast<int32_t*>(h->ws + o_sc + 12), G, (int64_t)(per / sizeof(T)), (int)(per / sizeof(int32_t)))))
     return rc;
 
-  for (int gi = 0; gi < G; ++gi) {
-  const int64_t reg = reg0 + gi;
-  char* ws = h->ws + (size_t)gi * per;
-  T* Abar = reinterpret_cast<T*>(ws + o_abar);
-  double* qpart = reinterpret_cast<double*>(ws + o_q);
-  double* lpart = reinterpret_cast<double*>(ws + o_l);
-  T* Tfull = reinterpret_cast<T*>(ws + o_m);
-  double* logdetLw = reinterpret_cast<double*>(ws + o_sc);
-  int32_t* info_prior = reinterpret_cast<int32_t*>(ws + o_sc + 8);
-  int32_t* info_chol = reinterpret_cast<int32_t*>(ws + o_sc + 12);
-  unsigned* info_noise = reinterpret_cast<unsigned*>(ws + o_sc + 16);
-  const T* s = a.s + reg * a.strides;
-  const T* mw = a.mw + reg * a.stridemw;
-
-  // ---- T = L' (for the caller and for the AXPY-form back substitution), then m, posterior mean, evidence
+  // ---- T = L' (for the caller and for the AXPY-form back substitution), then m, posterior mean, evidence: one launch each
+  // over the group (blockIdx.z / WaveSolveArgs::group)
   {
-    dim3 grid((DP + 31) / 32, (DP + 31) / 32);
+    char* ws = h->ws;
+    T* Abar = reinterpret_cast<T*>(ws + o_abar);
+    T* Tfull = reinterpret_cast<T*>(ws + o_m);
+    dim3 grid((DP + 31) / 32, (DP + 31) / 32, G);
     hipLaunchKernelGGL(transpose_out_kernel<T>, grid, dim3(kThreads), 0, h->stream, (const T*)Abar, lda, DP, Tfull,
-                       (int64_t)DP, a.T_post ? a.T_post + reg * a.strideT : (T*)nullptr, a.ldt, D);
-  }
-  {
+                       (int64_t)DP, a.T_post ? a.T_post + reg0 * a.strideT : (T*)nullptr, a.ldt, D, (int64_t)(per / sizeof(T)), a.strideT);
     WaveSolveArgs<T> b{};
     b.Tf = Tfull; b.ldtf = DP; b.D = D; b.DP = DP;
-    b.rhs = Abar + DP; b.ldrhs = 0; b.rhs_inc = lda;  // u = row DP of the factored Abar
-    b.add = mw; b.out = a.mw_post ? a.mw_post + reg * a.stride_mwpost : nullptr; b.ldout = 0;
-    b.qpart = qpart; b.lpart = lpart; b.nparts = gridc; b.logdet_Lw_dev = logdetLw;
-    b.noise_kind = a.noise_kind; b.s = s; b.N = N;
-    b.logpdf = a.logpdf ? a.logpdf + reg : nullptr; b.info = a.info + reg; b.chol_info = info_chol;
-    b.prior_info = info_prior; b.noise_info = info_noise;
-    if ((rc = launch_wave_solve<T>(h, b, NC, 1))) return rc;
-  }
+    b.rhs = Abar + DP; b.ldrhs = G > 1 ? (int64_t)(per / sizeof(T)) : 0; b.rhs_inc = lda;  // u = row DP of the factored Abar
+    b.add = a.mw + reg0 * a.stridemw; b.out = a.mw_post ? a.mw_post + reg0 * a.stride_mwpost : nullptr;
+    b.ldout = G > 1 ? a.stride_mwpost : 0;
+    b.qpart = reinterpret_cast<double*>(ws + o_q); b.lpart = reinterpret_cast<double*>(ws + o_l); b.nparts = gridc;
+    b.logdet_Lw_dev = reinterpret_cast<double*>(ws + o_sc);
+    b.noise_kind = a.noise_kind; b.s = a.s + reg0 * a.strides; b.N = N;
+    b.logpdf = a.logpdf ? a.logpdf + reg0 : nullptr; b.info = a.info + reg0;
+    b.chol_info = reinterpret_cast<int32_t*>(ws + o_sc + 12);
+    b.prior_info = reinterpret_cast<int32_t*>(ws + o_sc + 8); b.noise_info = reinterpret_cast<unsigned*>(ws + o_sc + 16);
+    if (G > 1) { b.group = G; b.ws_stride = (int64_t)per; b.add_stride = a.stridemw; b.s_stride = a.strides; }
+    if ((rc = launch_wave_solve<T>(h, b, NC, G))) return rc;
   }
   HIP_TRY(h, hipGetLastError());
   return 0;
@@ -583,12 +577,16 @@ int dispatch_posterior(blr_handle* h, const PosteriorArgs<T>& a) {
   if (a.D <= kMaxSmallD) return dispatch_fused_small<T>(h, a);
   // regressors of a batch go through the blocked factorisation in groups (posterior_large_group); the regressors of a group
   // must see the same alignment of X (one split / staging decision per group)
-  int gmax = a.D <= 2048 ? kChainBatch : (a.D <= 4096 ? 2 : 1);
-  if (const char* e = getenv("BLR_MI355X_CHAIN_BATCH")) gmax = std::max(1, std::min(8, atoi(e)));  // measurements only
+  // (the more the better wherever measured -- D = 256 .. 4096, tools/chain_batch_scan.sh -- with little left beyond 16)
+  int gmax = 16;
+  if (const char* e = getenv("BLR_MI355X_CHAIN_BATCH")) gmax = std::max(1, std::min(kChainBatchMax, atoi(e)));  // measurements only
   if ((a.strideX * (int64_t)sizeof(T)) % 16 != 0) gmax = 1;
-  for (int64_t reg = 0; reg < a.B; reg += gmax) {
-    int rc = posterior_large_group<T>(h, a, reg, (int)std::min<int64_t>(gmax, a.B - reg));
+  gmax = (int)((a.B + (a.B + gmax - 1) / gmax - 1) / std::max<int64_t>(1, (a.B + gmax - 1) / gmax));  // even groups: 17 -> 9 + 8, not 16 + 1
+  for (int64_t reg = 0; reg < a.B;) {
+    int done = 1;
+    int rc = posterior_large_group<T>(h, a, reg, (int)std::min<int64_t>(gmax, a.B - reg), &done);
     if (rc) return rc;
+    reg += done;
   }
   return 0;
 }

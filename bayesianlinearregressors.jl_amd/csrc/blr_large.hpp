@@ -1296,8 +1296,19 @@ struct WaveSolveArgs {
   // status precedence of the reference (:78 prior, :79 noise, :86 posterior): chol_info is seeded with the prior's status
   const int32_t* prior_info;     // may be NULL
   const unsigned* noise_info;    // colstats_kernel's atomicMin target (0xFFFFFFFF = ok); may be NULL
+  // a group of regressors in one launch (posterior_large_group): system g of `group` has its OWN factor and statistics.
+  // 0: one factor, gridDim.y right-hand sides.  Otherwise the pointers above are regressor 0's and regressor g's are
+  // ws_stride bytes further for everything that lives in the per-regressor workspace (Tf, rhs, qpart, lpart,
+  // logdet_Lw_dev, chol_info, prior_info, noise_info), add_stride / s_stride elements for the caller's arrays, out by
+  // ldout, logpdf and info by one.
+  int group;
+  int64_t ws_stride, add_stride, s_stride;
 };
 
+template <typename P>
+__device__ __forceinline__ const P* byte_shift(const P* p, int64_t bytes) {
+  return p ? reinterpret_cast<const P*>(reinterpret_cast<const char*>(p) + bytes) : p;
+}
 __device__ __forceinline__ void xchg_put(unsigned long long* g, float v, unsigned tag) {
   __hip_atomic_store(g, ((unsigned long long)tag << 32) | (unsigned)__float_as_int(v), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 }
@@ -1415,7 +1426,17 @@ __global__ __launch_bounds__(kThreads) void backsolve_wave_kernel(WaveSolveArgs<
   };
   const int q = NC - 1 - ticket % NC;
   const int64_t sidx = ticket / NC;
-  const bool evidence = a.info != nullptr && q == 0 && sidx == 0;
+  if (a.group) {  // this workgroup's regressor of the group (uniform over the workgroup)
+    const int64_t wb = sidx * a.ws_stride;
+    a.Tf = byte_shift(a.Tf, wb); a.qpart = byte_shift(a.qpart, wb); a.lpart = byte_shift(a.lpart, wb);
+    a.logdet_Lw_dev = byte_shift(a.logdet_Lw_dev, wb); a.chol_info = byte_shift(a.chol_info, wb);
+    a.prior_info = byte_shift(a.prior_info, wb); a.noise_info = byte_shift(a.noise_info, wb);
+    a.add += sidx * a.add_stride;
+    if (a.s) a.s += sidx * a.s_stride;
+    if (a.logpdf) a.logpdf += sidx;
+    if (a.info) a.info += sidx;
+  }
+  const bool evidence = a.info != nullptr && q == 0 && (sidx == 0 || a.group);
   const double kNaN = __longlong_as_double(0x7ff8000000000000LL);
   {
     int st = 0;
@@ -1594,8 +1615,12 @@ __global__ __launch_bounds__(kThreads) void prior_copy_kernel(const T* Lw, int64
 // T = L' : upper factor, column-major, strictly-lower part zero (Tout2 optional second destination, D2 x D2)
 template <typename T>
 __global__ __launch_bounds__(kThreads) void transpose_out_kernel(const T* Lf, int64_t ld, int D, T* Tout, int64_t ldt,
-                                                                 T* Tout2, int64_t ldt2, int D2) {
+                                                                 T* Tout2, int64_t ldt2, int D2, int64_t zstride = 0,
+                                                                 int64_t zstride2 = 0) {
   __shared__ T tile[32][33];
+  Lf += (int64_t)blockIdx.z * zstride;  // blockIdx.z: regressor of a group (Lf and Tout in per-regressor workspaces)
+  Tout += (int64_t)blockIdx.z * zstride;
+  if (Tout2) Tout2 += (int64_t)blockIdx.z * zstride2;
   const int bx = blockIdx.x * 32, by = blockIdx.y * 32;  // bx: row block of L, by: col block of L
   const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;
   for (int k = ty; k < 32; k += 8) {
