@@ -374,7 +374,7 @@ int posterior_large_group(blr_handle* h, const PosteriorArgs<T>& a, int64_t reg0
   int nsplit = 1;
   double best = 1e300;
   for (int sp = 1; sp <= max_split; ++sp) {
-    const int wgs = ntiles * sp;
+    const int wgs = ntiles * sp * G;  // (the whole group's tiles are one launch)
     const int slots = 256 * (sizeof(T) == 4 ? BLR_GRAM_WGS : 2);
     const int rounds = (wgs + slots - 1) / slots;
     const int cols_sp = ((N + sp - 1) / sp + nstage_cols - 1) / nstage_cols * nstage_cols;
@@ -395,7 +395,7 @@ int posterior_large_group(blr_handle* h, const PosteriorArgs<T>& a, int64_t reg0
     const T* X0 = a.X + reg0 * a.strideX;
     const bool dealt = sizeof(T) == 4 && a.layout == LAYOUT_COLVECS && ((uintptr_t)X0 % 16 == 0) &&
                        ((a.ldx * (int64_t)sizeof(T)) % 16 == 0) && getenv("BLR_MI355X_NO_GRAM_RING") == nullptr &&
-                       getenv("BLR_MI355X_NO_DIAG_SPLIT") == nullptr && D % kPB == 0 && NC >= 2 && (ntiles * nsplit <= slots || getenv("BLR_MI355X_GRAM_SPLITS") != nullptr);
+                       getenv("BLR_MI355X_NO_DIAG_SPLIT") == nullptr && D % kPB == 0 && NC >= 2 && (ntiles * nsplit * G <= slots || getenv("BLR_MI355X_GRAM_SPLITS") != nullptr);
     if (const char* e = getenv("BLR_MI355X_GRAM_SPLITS")) {  // "off-diagonal,diagonal" (equal: one factor): measurements only
       int so = 0, sd = 0;
       if (sscanf(e, "%d,%d", &so, &sd) == 2 && so >= 1 && sd >= 1 && sd <= so && so <= max_split) {
@@ -409,7 +409,7 @@ int posterior_large_group(blr_handle* h, const PosteriorArgs<T>& a, int64_t reg0
       int bo = 0, bd = 0;
       for (int so = 1; so <= max_split; ++so)
         for (int sd = 1; sd <= so; ++sd) {
-          if (n_off * so + NC * sd > slots) break;
+          if ((n_off * so + NC * sd) * G > slots) break;
           const double t = std::max(16.0 * cols(so), kDiagCost * cols(sd)) * (1.0 + 0.002 * so);
           if (t < best_t * 0.995) { best_t = t; bo = so; bd = sd; }
         }
@@ -440,9 +440,10 @@ int posterior_large_group(blr_handle* h, const PosteriorArgs<T>& a, int64_t reg0
   if (G_done) *G_done = G;
   int rc = ensure_ws(h, per * (size_t)G);
   if (rc) return rc;
-  for (int gi = 0; gi < G; ++gi) {
-  const int64_t reg = reg0 + gi;
-  char* ws = h->ws + (size_t)gi * per;
+  // Every launch below covers the whole group: regressor g from blockIdx.y / .z, its caller-side arrays by the batch strides
+  // and its workspace `per` bytes after its predecessor's (the pointers here are regressor reg0's).
+  const int64_t reg = reg0;
+  char* ws = h->ws;
   T* Abar = reinterpret_cast<T*>(ws + o_abar);
   T* W = reinterpret_cast<T*>(ws + o_w);
   T* Gpart = reinterpret_cast<T*>(ws + o_gp);
@@ -454,6 +455,8 @@ int posterior_large_group(blr_handle* h, const PosteriorArgs<T>& a, int64_t reg0
   int32_t* info_prior = reinterpret_cast<int32_t*>(ws + o_sc + 8);
   int32_t* info_chol = reinterpret_cast<int32_t*>(ws + o_sc + 12);
   unsigned* info_noise = reinterpret_cast<unsigned*>(ws + o_sc + 16);
+  const int64_t wsb = (int64_t)per;                  // byte stride between the regressors' workspaces
+  const int64_t wse = (int64_t)(per / sizeof(T));    // the same in elements (per is a multiple of 256)
 
   const T* X = a.X + reg * a.strideX;
   const T* y = a.y + reg * a.stridey;
@@ -461,28 +464,28 @@ int posterior_large_group(blr_handle* h, const PosteriorArgs<T>& a, int64_t reg0
   const T* mw = a.mw + reg * a.stridemw;
   const T* Lw = a.Lw + reg * a.strideLw;
 
-  // ---- prior: SPD check + logdet (reference :78)
-  if (a.prior_kind == PRIOR_DENSE) {
-    HIP_TRY(h, hipMemsetAsync(ws + o_sc, 0, 64, h->stream));
-    HIP_TRY(h, hipMemsetAsync(info_noise, 0xFF, sizeof(unsigned), h->stream));
-    HIP_TRY(h, hipMemsetAsync(bpart, 0, (size_t)nsplit_total * NC * kPB * sizeof(double), h->stream));
-    hipLaunchKernelGGL(prior_copy_kernel<T>, dim3(1024), dim3(kThreads), 0, h->stream, Lw, a.ldl, D, DP, W, (int64_t)DP);
-    if ((rc = chol_large<T>(h, W, DP, DP, DP, info_prior))) return rc;
-    hipLaunchKernelGGL(logdet_kernel<T>, dim3(1), dim3(kThreads), 0, h->stream, (const T*)W, (int64_t)DP, D, logdetLw);
-    // a failed prior factorisation short-circuits everything: seed info_chol with it
-    HIP_TRY(h, hipMemcpyAsync(info_chol, info_prior, sizeof(int32_t), hipMemcpyDeviceToDevice, h->stream));
-  } else {
-    // one launch: the scratch words, the noise flag and the b partials are cleared, the prior's diagonal is checked, and its
-    // status seeds info_chol (a failed prior short-circuits the factorisation)
+  // ---- prior: SPD check + logdet (reference :78).  One launch clears the scratch words, sets the noise flag and zeroes the
+  // b partials; for a diagonal / factor prior it also checks the diagonal and seeds info_chol with the prior's status (a failed
+  // prior short-circuits the factorisation), for a dense one the blocked factorisation of W does that.
+  {
+    const bool dense = a.prior_kind == PRIOR_DENSE;
     ScratchInit init;
     init.words16 = reinterpret_cast<unsigned*>(ws + o_sc);
     init.ones = info_noise;
     init.zeros = bpart;
     init.nzeros = (long long)nsplit_total * NC * kPB;
-    init.info_copy = info_chol;
+    init.info_copy = dense ? nullptr : info_chol;
     const int gridp = (int)std::min<long long>(64, 1 + init.nzeros / (8 * kThreads));
-    hipLaunchKernelGGL(prior_diag_kernel<T>, dim3(gridp), dim3(kThreads), 0, h->stream, Lw, a.ldl, a.prior_kind, D, logdetLw,
-                       info_prior, init);
+    // (dense: the kernel's own look at Lw's diagonal is not the answer -- status and logdet go to spare scratch words)
+    hipLaunchKernelGGL(prior_diag_kernel<T>, dim3(gridp, G), dim3(kThreads), 0, h->stream, Lw, a.ldl, a.prior_kind, D,
+                       dense ? reinterpret_cast<double*>(ws + o_sc + 40) : logdetLw,
+                       dense ? reinterpret_cast<int32_t*>(ws + o_sc + 32) : info_prior, init, a.strideLw, wsb);
+    if (dense) {
+      hipLaunchKernelGGL(prior_copy_kernel<T>, dim3(1024, G), dim3(kThreads), 0, h->stream, Lw, a.ldl, D, DP, W, (int64_t)DP, a.strideLw, wse);
+      if ((rc = chol_large<T>(h, W, DP, DP, DP, info_prior, G, wse, (int)(per / sizeof(int32_t))))) return rc;
+      hipLaunchKernelGGL(logdet_kernel<T>, dim3(G), dim3(kThreads), 0, h->stream, (const T*)W, (int64_t)DP, D, logdetLw, wsb,
+                         (const int32_t*)info_prior, info_chol);
+    }
   }
 
   // ---- column statistics (reference :82-84)
@@ -491,8 +494,9 @@ int posterior_large_group(blr_handle* h, const PosteriorArgs<T>& a, int64_t reg0
     c.X = X; c.ldx = a.ldx; c.y = y; c.s = s; c.mw = mw; c.r = rvec; c.qpart = qpart; c.lpart = lpart;
     c.noise_info = info_noise;
     c.layout = a.layout; c.noise_kind = a.noise_kind; c.D = D; c.N = N;
+    c.grp_X = a.strideX; c.grp_y = a.stridey; c.grp_s = a.strides; c.grp_mw = a.stridemw; c.grp_ws = wsb;
     size_t lds = (((size_t)D * sizeof(T) + 15) & ~(size_t)15) + 64;
-    hipLaunchKernelGGL(colstats_kernel<T>, dim3(gridc), dim3(kThreads), lds, h->stream, c);
+    hipLaunchKernelGGL(colstats_kernel<T>, dim3(gridc, G), dim3(kThreads), lds, h->stream, c);
   }
 
   // ---- Gram (reference :86) : split-K partial tiles, then the prior factor as pseudo-observations
@@ -503,44 +507,44 @@ int posterior_large_group(blr_handle* h, const PosteriorArgs<T>& a, int64_t reg0
   g.use_dma = (a.layout == LAYOUT_COLVECS && ((uintptr_t)X % 16 == 0) && ((a.ldx * (int64_t)sizeof(T)) % 16 == 0)) ? (no_ring ? 2 : 1) : 0;
   g.s = s; g.noise_kind = a.noise_kind; g.r = rvec;
   g.D = D; g.n_begin = 0; g.n_end = N; g.nblocks = NC; g.bpart = bpart; g.mode_out = 0;
+  g.grp_X = a.strideX; g.grp_s = a.strides; g.grp_ws = wsb;
   static const bool no_swizzle = getenv("BLR_MI355X_NO_XCD_SWIZZLE") != nullptr;
   ReduceArgs<T> r{};
   r.bpart = bpart; r.nblocks = NC;
   r.Lw = Lw; r.ldl = a.ldl; r.prior_kind = a.prior_kind; r.D = D; r.DP = DP; r.Abar = Abar; r.lda = lda;
   r.Lw_post = a.Lw_post ? a.Lw_post + reg * a.strideLp : nullptr; r.ldlp = a.ldlp;
+  r.grp_Lw = a.strideLw; r.grp_Lp = a.strideLp; r.grp_ws = wsb;
   // launches the tiles described by g (+ the prior-factor pseudo split) and their reduction on `st`
   auto gram_tiles = [&](hipStream_t st, int nsp, int nt, T* gp) {
     g.nsplit = nsp; g.ntiles = nt; g.Gpart = gp;
     g.nsplit_diag = nsplit_diag;
     g.xcd_swizzle = (nsp > 1 && !no_swizzle) ? 1 : 0;
     const int nwg = nsplit_diag ? (nt - NC) * nsp + NC * nsplit_diag : nt * nsp;
-    hipLaunchKernelGGL(gram_tile_kernel<T>, dim3(nwg), dim3(kThreads), LC::LDS_BYTES, st, g);
+    hipLaunchKernelGGL(gram_tile_kernel<T>, dim3(nwg, G), dim3(kThreads), LC::LDS_BYTES, st, g);
     if (prior_factor) {
       GramTileArgs<T> u = g;
       u.xcd_swizzle = 0;
       u.X = Lw; u.ldx = a.ldl; u.layout = 2; u.use_dma = 0; u.s = nullptr; u.r = nullptr;
+      u.grp_X = a.strideLw; u.grp_s = 0;
       u.n_begin = 0; u.n_end = D; u.nsplit = 1; u.nsplit_diag = 0;
       u.Gpart = gp + (int64_t)nsp * nt * kPB * kPB;
       u.bpart = bpart + (int64_t)nsp * NC * kPB;
-      hipLaunchKernelGGL(gram_tile_kernel<T>, dim3(nt), dim3(kThreads), LC::LDS_BYTES, st, u);
+      hipLaunchKernelGGL(gram_tile_kernel<T>, dim3(nt, G), dim3(kThreads), LC::LDS_BYTES, st, u);
     }
   };
   auto gram_reduce = [&](hipStream_t st, int nsp, int nt, T* gp, int reduce_blocks) {
     r.Gpart = gp; r.nsplit_total = nsp + pf; r.ntiles = nt;
     r.nsplit_diag = nsplit_diag; r.pseudo_split = pf;
-    hipLaunchKernelGGL(gram_reduce_kernel<T>, dim3(nt + reduce_blocks, 16), dim3(kThreads), 0, st, r);
+    hipLaunchKernelGGL(gram_reduce_kernel<T>, dim3(nt + reduce_blocks, 16, G), dim3(kThreads), 0, st, r);
   };
 
   g.tile_i0 = 0; g.tile_j0 = 0; g.tri = 1;
   gram_tiles(h->stream, nsplit, ntiles, Gpart);
   gram_reduce(h->stream, nsplit, ntiles, Gpart, NC);
-  }
   // ---- blocked Cholesky of Abar (rows DP.. = rhs) -> L, u  (reference :86, :57)
   // (only the first 64 of the 128 padding rows ride along: row DP is b', the others are zero and nobody reads them back --
   // half the right-hand-side sub-tiles of every trailing update, and c5's first trailing updates fit one round)
-  if ((rc = chol_large<T>(h, reinterpret_cast<T*>(h->ws + o_abar), lda, DP, DP + TrailCfg<T>::SB,
-                          reinterpret_cast<int32_t*>(h->ws + o_sc + 12), G, (int64_t)(per / sizeof(T)), (int)(per / sizeof(int32_t)))))
-    return rc;
+  if ((rc = chol_large<T>(h, Abar, lda, DP, DP + TrailCfg<T>::SB, info_chol, G, wse, (int)(per / sizeof(int32_t))))) return rc;
 
   // ---- T = L' (for the caller and for the AXPY-form back substitution), then m, posterior mean, evidence: one launch each
   // over the group (blockIdx.z / WaveSolveArgs::group)

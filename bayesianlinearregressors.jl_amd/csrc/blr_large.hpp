@@ -46,6 +46,12 @@ struct LargeCfg {
   static_assert(2 * SLOT * (int)sizeof(T) >= 16 * 128 * 8, "b-partial scratch must fit in the slots");
 };
 
+// Regressor g of a group (posterior_large_group): pointers into the per-regressor workspaces move by a byte stride
+template <typename P>
+__device__ __forceinline__ P* ws_shift(P* p, int64_t bytes) {
+  return p ? reinterpret_cast<P*>(reinterpret_cast<uintptr_t>(p) + (uintptr_t)bytes) : p;
+}
+
 // ---- column statistics -------------------------------------------------------------------------------------
 template <typename T>
 struct ColstatsArgs {
@@ -56,6 +62,8 @@ struct ColstatsArgs {
   double* lpart;      // [gridDim.x]
   unsigned* noise_info;  // atomicMin target, 0xFFFFFFFF = every variance positive; else 1-based index of the first bad one (NULL: off)
   int layout, noise_kind, D, N;
+  // blockIdx.y = regressor of a group: element strides of the caller's arrays, byte stride of r / qpart / lpart / noise_info
+  int64_t grp_X, grp_y, grp_s, grp_mw, grp_ws;
 };
 
 template <typename T>
@@ -65,6 +73,11 @@ __global__ __launch_bounds__(kThreads) void colstats_kernel(ColstatsArgs<T> a) {
   double* const scr = reinterpret_cast<double*>(smem + (((size_t)a.D * sizeof(T) + 15) & ~(size_t)15));
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int D = a.D, N = a.N;
+  if (const int64_t g = blockIdx.y) {
+    a.X += g * a.grp_X; a.y += g * a.grp_y; a.s += g * a.grp_s; a.mw += g * a.grp_mw;
+    a.r = ws_shift(a.r, g * a.grp_ws); a.qpart = ws_shift(a.qpart, g * a.grp_ws); a.lpart = ws_shift(a.lpart, g * a.grp_ws);
+    a.noise_info = ws_shift(a.noise_info, g * a.grp_ws);
+  }
   int mw_nonzero = 0;
   for (int d = tid; d < D; d += kThreads) {
     const T m = a.mw[d];
@@ -438,6 +451,8 @@ struct GramTileArgs {
   int xcd_swizzle;           // remap blockIdx so that one XCD owns whole N-slices (split-K launches)
   const T* XB; int64_t ldxb; int DB;  // optional SECOND operand for the B side (rows rowB.. of XB, DB rows; same layout);
                                       // NULL: B side = X (Gram / trailing updates)
+  // gridDim.y regressors of a group in one launch: element strides of X and s, byte stride of r / Gpart / bpart
+  int64_t grp_X, grp_s, grp_ws;
 };
 
 template <typename T>
@@ -457,10 +472,17 @@ __global__ __launch_bounds__(kThreads, (sizeof(T) == 4 ? BLR_GRAM_WGS : 2)) void
   // Workgroups are dealt round-robin over the 8 XCDs (observed, speed only): give each XCD a CONTIGUOUS range of
   // (split, tile) work items, so that the tiles of one N-slice -- which all stream the same columns of X -- share one
   // L2 instead of pulling the slice into all eight (bijective for any grid size).
-  int w = blockIdx.x;
+  int w = blockIdx.x + blockIdx.y * gridDim.x;  // (dispatch order: x fastest)
   if (a.xcd_swizzle) {
-    const int nwg = gridDim.x, xcd = w & 7, qq = nwg >> 3, rr = nwg & 7;
+    const int nwg = gridDim.x * gridDim.y, xcd = w & 7, qq = nwg >> 3, rr = nwg & 7;
     w = (xcd < rr ? xcd * (qq + 1) : rr * (qq + 1) + (xcd - rr) * qq) + (w >> 3);
+  }
+  if (gridDim.y > 1) {  // regressor of the group, then the work item within it
+    const int64_t g = w / (int)gridDim.x;
+    w -= (int)g * (int)gridDim.x;
+    a.X += g * a.grp_X;
+    if (a.s) a.s += g * a.grp_s;
+    a.r = ws_shift(a.r, g * a.grp_ws); a.Gpart = ws_shift(a.Gpart, g * a.grp_ws); a.bpart = ws_shift(a.bpart, g * a.grp_ws);
   }
   int t = w % a.ntiles, sidx = w / a.ntiles;
   int nsplit_here = a.nsplit;
@@ -748,6 +770,7 @@ struct ReduceArgs {
   int D, DP;
   T* Abar; int64_t lda;      // (DP + 128) x DP
   T* Lw_post; int64_t ldlp;  // optional full symmetric copy of A (D x D)
+  int64_t grp_Lw, grp_Lp, grp_ws;  // blockIdx.z = regressor of a group: element strides of Lw / Lw_post, byte stride of Gpart / bpart / Abar
 };
 
 template <typename T>
@@ -756,6 +779,11 @@ __global__ __launch_bounds__(kThreads) void gram_reduce_kernel(ReduceArgs<T> a) 
   const int tid = threadIdx.x;
   constexpr int kChunk = kPB * kPB / 16;  // gridDim.y = 16 chunks per tile
   const int e_begin = blockIdx.y * kChunk, e_end = e_begin + kChunk;
+  if (const int64_t g = blockIdx.z) {
+    a.Gpart = ws_shift(a.Gpart, g * a.grp_ws); a.bpart = ws_shift(a.bpart, g * a.grp_ws); a.Abar = ws_shift(a.Abar, g * a.grp_ws);
+    a.Lw += g * a.grp_Lw;
+    if (a.Lw_post) a.Lw_post += g * a.grp_Lp;
+  }
   if (t < a.ntiles) {
     int ii = 0;
     while ((ii + 1) * (ii + 2) / 2 <= t) ++ii;
@@ -1305,10 +1333,6 @@ struct WaveSolveArgs {
   int64_t ws_stride, add_stride, s_stride;
 };
 
-template <typename P>
-__device__ __forceinline__ const P* byte_shift(const P* p, int64_t bytes) {
-  return p ? reinterpret_cast<const P*>(reinterpret_cast<const char*>(p) + bytes) : p;
-}
 __device__ __forceinline__ void xchg_put(unsigned long long* g, float v, unsigned tag) {
   __hip_atomic_store(g, ((unsigned long long)tag << 32) | (unsigned)__float_as_int(v), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 }
@@ -1428,9 +1452,9 @@ __global__ __launch_bounds__(kThreads) void backsolve_wave_kernel(WaveSolveArgs<
   const int64_t sidx = ticket / NC;
   if (a.group) {  // this workgroup's regressor of the group (uniform over the workgroup)
     const int64_t wb = sidx * a.ws_stride;
-    a.Tf = byte_shift(a.Tf, wb); a.qpart = byte_shift(a.qpart, wb); a.lpart = byte_shift(a.lpart, wb);
-    a.logdet_Lw_dev = byte_shift(a.logdet_Lw_dev, wb); a.chol_info = byte_shift(a.chol_info, wb);
-    a.prior_info = byte_shift(a.prior_info, wb); a.noise_info = byte_shift(a.noise_info, wb);
+    a.Tf = ws_shift(a.Tf, wb); a.qpart = ws_shift(a.qpart, wb); a.lpart = ws_shift(a.lpart, wb);
+    a.logdet_Lw_dev = ws_shift(a.logdet_Lw_dev, wb); a.chol_info = ws_shift(a.chol_info, wb);
+    a.prior_info = ws_shift(a.prior_info, wb); a.noise_info = ws_shift(a.noise_info, wb);
     a.add += sidx * a.add_stride;
     if (a.s) a.s += sidx * a.s_stride;
     if (a.logpdf) a.logpdf += sidx;
@@ -1554,12 +1578,20 @@ __global__ __launch_bounds__(kThreads) void backsolve_wave_kernel(WaveSolveArgs<
 
 // logdet of a factored (DP x DP lower, ld) matrix restricted to the first D diagonal entries: 2 sum log L_ii
 template <typename T>
-__global__ __launch_bounds__(kThreads) void logdet_kernel(const T* Lf, int64_t ld, int D, double* out) {
+__global__ __launch_bounds__(kThreads) void logdet_kernel(const T* Lf, int64_t ld, int D, double* out, int64_t grp_ws = 0,
+                                                          const int32_t* info_src = nullptr, int32_t* info_dst = nullptr) {
+  if (const int64_t g = blockIdx.x) {  // regressor of a group: everything lives in its workspace (byte stride)
+    Lf = ws_shift(Lf, g * grp_ws); out = ws_shift(out, g * grp_ws);
+    info_src = ws_shift(info_src, g * grp_ws); info_dst = ws_shift(info_dst, g * grp_ws);
+  }
   __shared__ double scr[8];
   double v = 0.0;
   for (int j = threadIdx.x; j < D; j += kThreads) v += log((double)Lf[(int64_t)j * ld + j]);
   v = block_allreduce(v, scr, threadIdx.x);
-  if (threadIdx.x == 0) *out = 2.0 * v;
+  if (threadIdx.x == 0) {
+    *out = 2.0 * v;
+    if (info_dst) *info_dst = *info_src;  // (the status of this factorisation seeds the next one's)
+  }
 }
 
 // logdet of a diagonal (kind 2) or of an upper factor's diagonal (kind 1); info = first non-positive entry
@@ -1575,7 +1607,14 @@ struct ScratchInit {
 
 template <typename T>
 __global__ __launch_bounds__(kThreads) void prior_diag_kernel(const T* Lw, int64_t ldl, int kind, int D, double* out,
-                                                              int32_t* info, ScratchInit init = ScratchInit()) {
+                                                              int32_t* info, ScratchInit init = ScratchInit(), int64_t grp_Lw = 0,
+                                                              int64_t grp_ws = 0) {
+  if (const int64_t g = blockIdx.y) {  // regressor of a group: Lw by elements, everything else lives in its workspace
+    Lw += g * grp_Lw;
+    out = ws_shift(out, g * grp_ws); info = ws_shift(info, g * grp_ws);
+    init.words16 = ws_shift(init.words16, g * grp_ws); init.ones = ws_shift(init.ones, g * grp_ws);
+    init.zeros = ws_shift(init.zeros, g * grp_ws); init.info_copy = ws_shift(init.info_copy, g * grp_ws);
+  }
   for (long long i = (long long)blockIdx.x * kThreads + threadIdx.x; i < init.nzeros; i += (long long)gridDim.x * kThreads)
     init.zeros[i] = 0.0;
   if (blockIdx.x != 0) return;
@@ -1601,7 +1640,10 @@ __global__ __launch_bounds__(kThreads) void prior_diag_kernel(const T* Lw, int64
 }
 
 template <typename T>
-__global__ __launch_bounds__(kThreads) void prior_copy_kernel(const T* Lw, int64_t ldl, int D, int DP, T* W, int64_t ldw) {
+__global__ __launch_bounds__(kThreads) void prior_copy_kernel(const T* Lw, int64_t ldl, int D, int DP, T* W, int64_t ldw,
+                                                              int64_t grp_Lw = 0, int64_t grp_W = 0) {
+  Lw += (int64_t)blockIdx.y * grp_Lw;  // blockIdx.y: regressor of a group
+  W += (int64_t)blockIdx.y * grp_W;
   for (int64_t e = (int64_t)blockIdx.x * kThreads + threadIdx.x; e < (int64_t)DP * DP; e += (int64_t)gridDim.x * kThreads) {
     const int col = (int)(e / DP), row = (int)(e % DP);
     if (row < col) continue;

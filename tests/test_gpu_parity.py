@@ -1263,7 +1263,8 @@ def test_large_d_batched_regressors_share_the_factorisation_launches(B, dtype, n
     # B > 1 at D > 128: groups of up to four regressors step through the blocked factorisation in shared launches
     # (posterior_large_group; blockIdx.y of the panel and trailing-update kernels).  Every regressor against the oracle, a
     # regressor whose system is not positive definite must fail alone (its neighbours in the group untouched), and the
-    # result has to be bit-for-bit what one-regressor-at-a-time launches give (same kernels, same data, no atomics).
+    # result has to be what one-regressor-at-a-time launches give up to the summation order of the Gram partials (the
+    # split-K factor is chosen for the whole group's launch).
     a = B._abi
     h = a.default_handle()
     rng = _rng(6100 + nb + D)
@@ -1326,7 +1327,10 @@ def test_large_d_batched_regressors_share_the_factorisation_launches(B, dtype, n
     mw1, T1, L1, lp1, info1 = run()
     assert info1.tolist() == want
     ok = [b for b in range(nb) if b != bad]
-    assert np.array_equal(mw1[ok], mw_post[ok]) and np.array_equal(T1[ok], T_post[ok]) and np.array_equal(lp1[ok], lp[ok])
+    eps = 1e-12 if dtype == np.float64 else 2e-5
+    np.testing.assert_allclose(lp1[ok], lp[ok], rtol=eps * 10)
+    np.testing.assert_allclose(mw1[ok], mw_post[ok], rtol=0, atol=eps * 100 * np.abs(mw1[ok]).max())
+    np.testing.assert_allclose(T1[ok], T_post[ok], rtol=0, atol=eps * 10 * np.abs(T1[ok]).max())
 
 
 @pytest.mark.parametrize("dtype", [np.float64, np.float32])
