@@ -434,7 +434,10 @@ def main():
                   ("c4_f32", 8192, 64, 1024, "f32", "isotropic", None, 20),
                   ("c4_f64_B1024", 1024, 64, 1024, "f64", "isotropic", None, 20),  # the per-GPU block of config 4 on 8 GPUs
                   ("c3_f32", 1, 1024, 65536, "f32", "diagonal", None, 20),
-                  ("c5_f32_end_to_end", 1, 2048, 16384, "f32", "isotropic", 8, 20)]
+                  ("c5_f32_end_to_end", 1, 2048, 16384, "f32", "isotropic", 8, 20),
+                  # batches at D > 128: the regressors go through every launch of the update together (posterior_large_group)
+                  ("c3_f32_B8", 8, 1024, 65536, "f32", "diagonal", None, 10),
+                  ("c5_shape_f32_B8", 8, 2048, 16384, "f32", "isotropic", None, 10)]
         for name, b, d, n, dt, noise, din, steps in shapes:
             try:
                 w2 = Workload(torch, _abi, h, dev, name, b, d, n, dt, noise, 123456 + 7, din)

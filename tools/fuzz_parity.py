@@ -1,5 +1,6 @@
 """Randomised parity sweep through the C ABI against the oracle (shapes, leading dimensions, layouts, priors, noise kinds).
-Not part of the test suite (minutes of GPU time): python tools/fuzz_parity.py [cases] [seed]"""
+Not part of the test suite (minutes of GPU time): python tools/fuzz_parity.py [cases] [seed] [group]
+("group": batches of regressors at D > 128 instead of single updates)"""
 import os, sys
 import numpy as np
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
@@ -72,12 +73,93 @@ def one(rng, case):
     return tag
 
 
+def group(rng, case):
+    """Batched regressors at D > 128 (posterior_large_group): strides with gaps, both layouts, one regressor in the batch may
+    carry a prior or a noise vector that is not positive."""
+    nb = int(rng.choice([2, 3, 5, 8, 16, 17, 23, 33]))
+    D = int(rng.choice([129, 130, 200, 256, 257, 300, 384, 512]))
+    N = int(rng.choice([1, 5, 64, 100, 257, 400, 777, 1500]))
+    dtype = np.float64 if rng.random() < 0.6 else np.float32
+    layout = _abi.LAYOUT_COLVECS if rng.random() < 0.6 else _abi.LAYOUT_ROWVECS
+    pad = int(rng.choice([0, 0, 1, 4]))
+    gap = int(rng.choice([0, 0, 4, 8, 3]))  # extra elements between the regressors' X blocks (3: the group path steps aside)
+    noise = "diag" if rng.random() < 0.6 else "iso"
+    prior = str(rng.choice(["dense", "diag", "factor"]))
+    rows, cols = (D, N) if layout == _abi.LAYOUT_COLVECS else (N, D)
+    ldx = rows + pad
+    strideX = ldx * cols + gap
+    Xbuf = np.zeros(nb * strideX, dtype=dtype)
+    Xs = []
+    for b in range(nb):
+        Xb = rng.standard_normal((D, N)).astype(dtype)
+        Xs.append(Xb)
+        blk = Xbuf[b * strideX:b * strideX + ldx * cols].reshape((cols, ldx))  # column-major (ldx x cols)
+        blk[:, :rows] = Xb.T if layout == _abi.LAYOUT_COLVECS else Xb
+    mw = (0.3 * rng.standard_normal((nb, D))).astype(dtype)
+    y = rng.standard_normal((nb, N)).astype(dtype)
+    ns = N if noise == "diag" else 1
+    sv = (np.exp(0.4 * rng.standard_normal((nb, ns))) if noise == "diag" else 0.3 + rng.random((nb, 1))).astype(dtype)
+    bad = int(rng.integers(nb)) if rng.random() < 0.4 else None
+    bad_kind = str(rng.choice(["prior", "noise"])) if noise == "diag" else "prior"
+    want = [0] * nb
+    if prior == "diag":
+        Larg = np.exp(0.3 * rng.standard_normal((nb, D))).astype(dtype)
+        if bad is not None and bad_kind == "prior":
+            k = int(rng.integers(D)); Larg[bad, k] = 0.0; want[bad] = k + 1
+        Ld = [np.diag(Larg[b].astype(float)) for b in range(nb)]
+        pk, ldl, strideL = _abi.PRIOR_DIAGONAL, 1, D
+    else:
+        Ms = []
+        for b in range(nb):
+            Bm = rng.standard_normal((D, D)) / np.sqrt(D)
+            Ms.append(Bm @ Bm.T + np.eye(D))
+        if prior == "dense":
+            if bad is not None and bad_kind == "prior":
+                k = int(rng.integers(D)); Lc = np.linalg.cholesky(Ms[bad]); Lc[k, k] = 0.0
+                Ms[bad] = Lc @ Lc.T; Ms[bad][k, k] -= 1.0; want[bad] = k + 1
+            Larg = np.stack([M.astype(dtype) for M in Ms])
+            Ld = [Larg[b].astype(float) for b in range(nb)]
+            pk = _abi.PRIOR_DENSE
+        else:
+            U = [O.chol_upper(M).astype(dtype) for M in Ms]
+            if bad is not None and bad_kind == "prior":
+                k = int(rng.integers(D)); U[bad][k, k] = -1.0; want[bad] = k + 1
+            Larg = np.stack([u.T.copy() for u in U])
+            Ld = [u.astype(float).T @ u.astype(float) for u in U]
+            pk = _abi.PRIOR_UPPER_FACTOR
+        ldl, strideL = D, D * D
+    if bad is not None and bad_kind == "noise":
+        k = int(rng.integers(N)); sv[bad, k] = -0.5; want[bad] = k + 1
+    nk = _abi.NOISE_DIAGONAL if noise == "diag" else _abi.NOISE_ISOTROPIC
+    h = _abi.default_handle()
+    mw_p = np.zeros((nb, D), dtype=dtype); Tp = np.zeros((nb, D, D), dtype=dtype); Ap = np.zeros((nb, D, D), dtype=dtype)
+    lp = np.zeros(nb); info = np.full(nb, 7, dtype=np.int32)
+    h.posterior_batched(dtype, _abi.MEM_HOST, layout, nb, D, N, Xbuf, ldx, strideX, y, N, nk, sv, ns, pk, mw, D, Larg, ldl, strideL,
+                        mw_p, D, Tp, D, D * D, Ap, D, D * D, lp, info)
+    tag = f"group case {case}: B={nb} D={D} N={N} {np.dtype(dtype).name} layout={layout} pad={pad} gap={gap} noise={noise} prior={prior} bad={bad}/{bad_kind}"
+    assert info.tolist() == want, (tag, info.tolist(), want)
+    tol = 1e-9 if dtype == np.float64 else 5e-3
+    f64 = lambda a: np.asarray(a, dtype=float)
+    for b in range(nb):
+        if want[b]:
+            assert np.isnan(lp[b]), tag
+            continue
+        sb = f64(sv[b]) if noise == "diag" else np.float64(sv[b, 0])
+        mw_o, T_o, A_o, lp_o = O.posterior_logpdf_direct(f64(mw[b]), Ld[b], f64(Xs[b]), sb, f64(y[b]))
+        assert abs(lp[b] - lp_o) <= (1e-10 if dtype == np.float64 else 5e-4) * max(1.0, abs(lp_o)), (tag, b, lp[b], lp_o)
+        np.testing.assert_allclose(mw_p[b], mw_o, rtol=tol, atol=tol * 10, err_msg=tag)
+        np.testing.assert_allclose(Tp[b].T, T_o, rtol=tol, atol=tol * 10, err_msg=tag)
+        np.testing.assert_allclose(Ap[b].T, A_o, rtol=tol, atol=tol * 10, err_msg=tag)
+    return tag
+
+
 if __name__ == "__main__":
     cases = int(sys.argv[1]) if len(sys.argv) > 1 else 200
     rng = np.random.default_rng(int(sys.argv[2]) if len(sys.argv) > 2 else 2026)
+    fn = group if (len(sys.argv) > 3 and sys.argv[3] == "group") else one
     for c in range(cases):
         try:
-            one(rng, c)
+            fn(rng, c)
         except Exception as e:  # noqa: BLE001
             print("FAIL", type(e).__name__, str(e)[:600])
             raise SystemExit(1)
