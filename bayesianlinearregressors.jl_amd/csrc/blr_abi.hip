@@ -172,8 +172,8 @@ int ensure_ws(blr_handle* h, size_t bytes) {
 // epochs that are never reused, so a stale granule can never carry the current tag.
 int ensure_xchg(blr_handle* h, size_t bytes) {
   if (!h->ticket) {
-    HIP_TRY(h, hipMalloc((void**)&h->ticket, 256));
-    HIP_TRY(h, hipMemsetAsync(h->ticket, 0, 256, h->stream));
+    HIP_TRY(h, hipMalloc((void**)&h->ticket, 1024));
+    HIP_TRY(h, hipMemsetAsync(h->ticket, 0, 1024, h->stream));
   }
   if (bytes <= h->xchg_bytes) return 0;
   if (h->xchg) {
@@ -317,7 +317,7 @@ int launch_panel(blr_handle* h, T* M, int64_t ld, int p, int nrows_total, int nb
 }
 
 constexpr size_t kChainWorkspace = (size_t)8 << 30;  // ... as long as their workspaces fit this many bytes
-constexpr int kChainBatchMax = 32;  // factorisations that step through their panels in shared launches (arrival words ticket[16..47])
+constexpr int kChainBatchMax = 128;  // factorisations that step through their panels in shared launches (arrival words ticket[16..143])
 
 // Blocked Cholesky of G independent matrices M + g * batch_stride (status words info_dev + g * info_stride), panel by panel,
 // every step ONE launch over all of them.
@@ -581,8 +581,9 @@ int dispatch_posterior(blr_handle* h, const PosteriorArgs<T>& a) {
   if (a.D <= kMaxSmallD) return dispatch_fused_small<T>(h, a);
   // regressors of a batch go through the blocked factorisation in groups (posterior_large_group); the regressors of a group
   // must see the same alignment of X (one split / staging decision per group)
-  // (the more the better wherever measured -- D = 256 .. 4096, tools/chain_batch_scan.sh -- with little left beyond 16)
-  int gmax = 16;
+  // (the more the better wherever measured -- D = 256 .. 4096, groups of up to 128, tools/chain_batch_scan.sh -- so the bound is
+  // the workspace: kChainWorkspace)
+  int gmax = kChainBatchMax;
   if (const char* e = getenv("BLR_MI355X_CHAIN_BATCH")) gmax = std::max(1, std::min(kChainBatchMax, atoi(e)));  // measurements only
   if ((a.strideX * (int64_t)sizeof(T)) % 16 != 0) gmax = 1;
   gmax = (int)((a.B + (a.B + gmax - 1) / gmax - 1) / std::max<int64_t>(1, (a.B + gmax - 1) / gmax));  // even groups: 17 -> 9 + 8, not 16 + 1

@@ -1260,7 +1260,7 @@ def test_nonpositive_noise_does_not_poison_a_device_batch(B):
 @pytest.mark.parametrize("nb,D,N,prior", [(2, 200, 300, "diagonal"), (3, 384, 500, "dense"), (5, 330, 260, "pdmat"), (6, 640, 900, "diagonal"),
                                           (9, 130, 64, "dense"), (21, 160, 90, "diagonal")])
 def test_large_d_batched_regressors_share_the_factorisation_launches(B, dtype, nb, D, N, prior, monkeypatch):
-    # B > 1 at D > 128: groups of up to four regressors step through the blocked factorisation in shared launches
+    # B > 1 at D > 128: groups of regressors step through every launch of the update together
     # (posterior_large_group; blockIdx.y of the panel and trailing-update kernels).  Every regressor against the oracle, a
     # regressor whose system is not positive definite must fail alone (its neighbours in the group untouched), and the
     # result has to be what one-regressor-at-a-time launches give up to the summation order of the Gram partials (the

@@ -10,11 +10,8 @@ run() {  # D N batch dtype groups...
       | python -c "import sys, json; d = json.loads(sys.stdin.readlines()[-1]); print('%.3f ms/step, %.1f updates/s' % (d['ms_per_step'], d['value']))"
   done
 }
-run 256 4096 32 f32 1 16
-run 512 16384 16 f32 1 16
-run 1024 16384 8 f32 1 8
-run 1024 65536 8 f32 1 8
-run 2048 16384 8 f32 1 8
-run 4096 8192 4 f32 1 4
-run 1024 16384 8 f64 1 8
-run 2048 8192 4 f64 1 4
+run 256 4096 128 f32 8 16 32 64 128
+run 384 4096 128 f32 16 32 64
+run 512 16384 64 f32 16 32 64
+run 1024 16384 32 f32 8 16 32
+run 256 4096 128 f64 16 32 64
