@@ -17,6 +17,9 @@ rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/stats_c2 -- $B > /d
 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/stats_c3 -- $B --config c3 --steps 20 --warmup 3 > /dev/null 2>&1
 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/stats_c5 -- $B --config c5 --steps 20 --warmup 3 > /dev/null 2>&1
 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/stats_c4 -- $B --config c4 > /dev/null 2>&1
+# 8 regressors of c3's shape in one call: every launch of the update covers the group (posterior_large_group)
+$B --D 1024 --N 65536 --dtype f32 --noise diagonal --batch 8 --steps 10 --warmup 2 > $OUT/bench_c3_f32_B8.json 2>/dev/null
+rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/stats_c3b8 -- $B --D 1024 --N 65536 --dtype f32 --noise diagonal --batch 8 --steps 10 --warmup 2 > /dev/null 2>&1
 # PMC: separate passes (TCC FETCH_SIZE and WRITE_SIZE do not fit one pass), kernel-trace only
 SQ="GRBM_GUI_ACTIVE SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_VALU_MFMA_BUSY_CYCLES SQ_WAIT_INST_LDS SQ_LDS_BANK_CONFLICT"
 rocprofv3 --pmc FETCH_SIZE --kernel-trace --output-format csv -d $OUT/pmc_fetch_c2 -- $B --steps 5 --warmup 2 > /dev/null 2>&1

@@ -20,11 +20,11 @@ def one(pattern):
     return max(g, key=os.path.getmtime) if g else None
 
 
-for name in ("bench_c2_f64", "bench_c2_f32", "bench_c3_f32", "bench_c5_f32", "bench_c4_f64"):
+for name in ("bench_c2_f64", "bench_c2_f32", "bench_c3_f32", "bench_c5_f32", "bench_c4_f64", "bench_c3_f32_B8"):
     src = os.path.join(RAW, name + ".json")
     if os.path.exists(src) and os.path.getsize(src):
         shutil.copy(src, os.path.join(DST, f"{tag}_{name}.json"))
-for cfg in ("c2", "c3", "c5", "c4"):
+for cfg in ("c2", "c3", "c5", "c4", "c3b8"):
     f = one(f"{RAW}/stats_{cfg}/*/*_kernel_stats.csv")
     if f:
         shutil.copy(f, os.path.join(DST, f"{tag}_{cfg}_kernel_stats.csv"))
