@@ -25,11 +25,13 @@ from .regressor import (
     logpdf,
     logpdf_and_gradient,
     logpdf_columns,
+    logpdf_map,
     marginals,
     mean,
     mean_and_cov,
     mean_and_var,
     posterior,
+    posterior_map,
     rand,
     rand_and_pullback,
     rand_b,
@@ -40,5 +42,5 @@ from .regressor import (
 __all__ = [
     "logpdf", "rand", "mean", "std", "cov", "var", "BayesianLinearRegressor", "marginals", "posterior",
     "BasisFunctionRegressor", "ColVecs", "RowVecs", "Diagonal", "Symmetric", "PDMat", "Normal", "FiniteGP",
-    "BLRFunctionSample", "RandomFourierFeatures", "mean_and_var", "mean_and_cov", "rand_b", "rand_and_pullback", "evaluate", "logpdf_columns", "logpdf_and_gradient", "BLRError", "PosDefException", "ResidentPosterior",
+    "BLRFunctionSample", "RandomFourierFeatures", "mean_and_var", "mean_and_cov", "rand_b", "rand_and_pullback", "evaluate", "logpdf_columns", "logpdf_and_gradient", "logpdf_map", "posterior_map", "BLRError", "PosDefException", "ResidentPosterior",
 ]

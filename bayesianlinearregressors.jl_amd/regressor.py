@@ -514,6 +514,88 @@ def posterior(fx, y):
     return post
 
 
+# ---------------------------------------------------------------------------------------------------
+# many independent regressors in ONE library call: what `map(posterior, fxs, ys)` / `logpdf.(fxs, ys)` are in the reference
+# (config 4 of BASELINE.json is this with 8192 regressors; at D > 128 the regressors share every launch of the update)
+# ---------------------------------------------------------------------------------------------------
+def _fused_many(fxs, ys, want_posterior):
+    """[(logpdf, mw', T, A)] for equally shaped problems through blr_posterior_batched_*; shapes, layouts, noise or prior
+    kinds that differ (or a dense noise covariance, or a fused random-Fourier basis) fall back to one call per problem.
+    The first problem (in order) whose prior, noise or posterior precision is not positive definite raises
+    PosDefException, as the map over the reference's methods would; its position is the exception's ``index``."""
+    fxs, ys = list(fxs), list(ys)
+    if len(fxs) != len(ys):
+        raise ValueError("as many observation vectors as finite regressors are needed")
+    if not fxs:
+        return []
+    one_by_one = lambda: [_fused(fx, y, want_posterior) for fx, y in zip(fxs, ys)]  # noqa: E731
+    if any(isinstance(fx.f, BasisFunctionRegressor) and isinstance(fx.f.phi, RandomFourierFeatures) for fx in fxs):
+        return one_by_one()
+    fbs = [_to_finite_blr(fx) for fx in fxs]
+    dtype = np.float32 if all(_dtype_of(fb.f.mw, y) == np.float32 for fb, y in zip(fbs, ys)) else np.float64
+    probs = []
+    for fb, y in zip(fbs, ys):
+        X, layout, ldx, D, N = _x_layout(fb.x, dtype)
+        y = np.ascontiguousarray(y, dtype=dtype)
+        if y.ndim != 1:
+            raise ValueError("y must be a vector")
+        if y.shape[0] != N:
+            raise ValueError("length(y) != size(fx.x.X, 2)")  # reference :74
+        s, noise_kind = _noise(fb.Sy, N, dtype)
+        Lw, prior_kind, ldl = _prior(fb.f.Lw, D, dtype)
+        probs.append((X, layout, ldx, D, N, y, s, noise_kind, _mean_vector(fb.f.mw, D, dtype), Lw, prior_kind, ldl,
+                      isinstance(fb.f.Lw, PDMat)))
+    sig = {(q[0].shape, q[0].flags.f_contiguous, q[1], q[3], q[4], q[7], q[10], q[12]) for q in probs}
+    if len(sig) != 1 or probs[0][7] == _abi.NOISE_DENSE or probs[0][3] == 0 or probs[0][4] == 0:
+        return one_by_one()
+    X0, layout, ldx, D, N, _, s0, noise_kind, _, _, prior_kind, ldl, pdmat = probs[0]
+    nb = len(probs)
+    # one contiguous block per operand: problem b at b * stride (each X already is ldx x cols column-major in memory)
+    Xb = np.stack([q[0].reshape(-1, order="A") for q in probs])
+    yb = np.stack([q[5] for q in probs])
+    sb = np.stack([q[6] for q in probs])
+    mwb = np.stack([q[8] for q in probs])
+    Lb = np.stack([q[9].reshape(-1, order="A") for q in probs])  # D, or D x D column-major
+    lp = np.zeros(nb, dtype=np.float64)
+    info = np.zeros(nb, dtype=np.int32)
+    if want_posterior:
+        mw_post = np.empty((nb, D), dtype=dtype)
+        Tb = np.empty((nb, D * D), dtype=dtype)
+        Ab = np.empty((nb, D * D), dtype=dtype) if not pdmat else None
+    else:
+        mw_post = Tb = Ab = None
+    _handle().posterior_batched(dtype, _abi.MEM_HOST, layout, nb, D, N, Xb, ldx, Xb.shape[1], yb, yb.shape[1], noise_kind, sb,
+                                sb.shape[1], prior_kind, mwb, D, Lb, ldl, Lb.shape[1], mw_post, D, Tb, D, D * D, Ab, D, D * D, lp, info)
+    bad = np.flatnonzero(info > 0)
+    if bad.size:
+        e = _abi.PosDefException(int(info[bad[0]]))
+        e.index = int(bad[0])
+        raise e
+    out = []
+    for b in range(nb):
+        if want_posterior:
+            out.append((float(lp[b]), mw_post[b], Tb[b].reshape((D, D), order="F"), Ab[b].reshape((D, D), order="F") if Ab is not None else None))
+        else:
+            out.append((float(lp[b]), None, None, None))
+    return out
+
+
+def logpdf_map(fxs, ys):
+    """[logpdf(fx, y) for fx, y in zip(fxs, ys)] (reference :55-58 under a map) in one library call."""
+    return [r[0] for r in _fused_many(fxs, ys, want_posterior=False)]
+
+
+def posterior_map(fxs, ys):
+    """[posterior(fx, y) for fx, y in zip(fxs, ys)] (reference :60-69 under a map) in one library call."""
+    fxs = list(fxs)
+    posts = []
+    for fx, (_, mw_post, T, A) in zip(fxs, _fused_many(fxs, ys, want_posterior=True)):
+        base = fx.f.blr if isinstance(fx.f, BasisFunctionRegressor) else fx.f
+        post = BayesianLinearRegressor(mw_post, _wrap_like(base.Lw, T, A))
+        posts.append(BasisFunctionRegressor(post, fx.f.phi) if isinstance(fx.f, BasisFunctionRegressor) else post)
+    return posts
+
+
 class _DeviceBuffer:
     """device memory owned through the C ABI (blr_device_alloc): no GPU array library involved"""
 

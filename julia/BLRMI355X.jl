@@ -11,7 +11,7 @@
 # plus what the reference gets from Zygote and a ccall cannot give by itself:
 #     ChainRulesCore.rrule(logpdf, fx, y)                                                     (README.md:56-71, examples/nn-blr.jl:35-37)
 # and what only a device library can offer:
-#     device-resident batches (posterior_batched!), the RCCL exchange for one Julia process per GPU (comm_init!, logpdf_allgather_sum!).
+#     maps over collections of problems in one call (logpdf_map, posterior_map), device-resident batches (posterior_batched!), the RCCL exchange for one Julia process per GPU (comm_init!, logpdf_allgather_sum!).
 # Anything else (exotic element types, unknown containers) falls back to the reference's own CPU methods.
 #
 # Two ways to use it -- both spelled out in INTEGRATION.md:
@@ -192,6 +192,92 @@ function posterior(fx::FiniteGP, y::AbstractVector{<:Real})
     blr0 = fx.f isa BasisFunctionRegressor ? fx.f.blr : fx.f
     post = BayesianLinearRegressor(mw_post, build_Λ(typeof(blr0.Λw), Tp, Ap))
     fx.f isa BasisFunctionRegressor ? BasisFunctionRegressor(post, fx.f.ϕ) : post           # :62-65
+end
+
+# ---- many equally shaped problems in ONE library call: `map(posterior, fxs, ys)` / `logpdf.(fxs, ys)` -------------------
+# (BASELINE config 4 is this with 8192 regressors; at D > 128 the regressors share every launch of the update.)  Host arrays
+# are packed side by side -- problem b at b * stride -- and handed to blr_posterior_batched_* with BLR_MEM_HOST.  Collections
+# the batched entry point does not take (mixed shapes / layouts / kinds, dense noise, a fused random-Fourier basis) are
+# mapped one by one.  The first problem that is not positive definite throws PosDefException, as the map would.
+function fused_many(fxs::AbstractVector{<:FiniteGP}, ys::AbstractVector{<:AbstractVector{<:Real}}, want_posterior::Bool)
+    length(fxs) == length(ys) || throw(DimensionMismatch("as many observation vectors as finite regressors are needed"))
+    B = length(fxs)
+    B == 0 && return Tuple[]
+    any(fx -> fx.f isa BasisFunctionRegressor && fx.f.ϕ isa RandomFourierFeatures, fxs) && return nothing
+    fbs = map(to_blr, fxs)
+    xls, nzs, prs = map(fb -> xlayout(fb.x), fbs), map(fb -> noise(fb.Σy), fbs), map(fb -> prior(fb.f.Λw), fbs)
+    (any(isnothing, xls) || any(isnothing, nzs) || any(isnothing, prs)) && return nothing
+    X1, layout, _, D, N = xls[1]
+    T = eltype(X1)
+    nk, pk = nzs[1][2], prs[1][2]
+    (nk == DENSEN || D == 0 || N == 0) && return nothing
+    same = all(b -> eltype(xls[b][1]) === T && xls[b][2] == layout && xls[b][4] == D && xls[b][5] == N && nzs[b][2] == nk &&
+                    prs[b][2] == pk && length(ys[b]) == N && length(fbs[b].f.mw) == D, 1:B)
+    same || return nothing
+    rows, cols = layout == COLVECS ? (D, N) : (N, D)
+    Xb = Array{T}(undef, rows, cols, B)
+    for b in 1:B
+        copyto!(view(Xb, :, :, b), xls[b][1])
+    end
+    yb = Matrix{T}(undef, N, B)
+    for b in 1:B
+        yb[:, b] .= ys[b]
+    end
+    ns = nk == ISOTROPIC ? 1 : N
+    sb = Matrix{T}(undef, ns, B)
+    for b in 1:B
+        sb[:, b] .= view(nzs[b][1], 1:ns)
+    end
+    mwb = Matrix{T}(undef, D, B)
+    for b in 1:B
+        mwb[:, b] .= fbs[b].f.mw
+    end
+    Lb = pk == P_DIAG ? Matrix{T}(undef, D, B) : Array{T}(undef, D, D, B)
+    for b in 1:B
+        pk == P_DIAG ? (Lb[:, b] .= prs[b][1]) : copyto!(view(Lb, :, :, b), prs[b][1])
+    end
+    ldl, strideL = pk == P_DIAG ? (1, D) : (D, D * D)
+    mw_post = want_posterior ? Matrix{T}(undef, D, B) : Ptr{T}(C_NULL)
+    Tp = want_posterior ? Array{T}(undef, D, D, B) : Ptr{T}(C_NULL)
+    Ap = (want_posterior && pk != P_UPPER) ? Array{T}(undef, D, D, B) : Ptr{T}(C_NULL)
+    lp = zeros(Cdouble, B)
+    info = zeros(Int32, B)
+    h = handle()
+    rc = GC.@preserve Xb yb sb mwb Lb mw_post Tp Ap lp info begin
+        if T === Float64
+            ccall((:blr_posterior_batched_f64, LIB), Cint,
+                  (Ptr{Cvoid}, Cint, Cint, Int64, Int64, Int64, Ptr{T}, Int64, Int64, Ptr{T}, Int64, Cint, Ptr{T}, Int64, Cint, Ptr{T}, Int64,
+                   Ptr{T}, Int64, Int64, Ptr{T}, Int64, Ptr{T}, Int64, Int64, Ptr{T}, Int64, Int64, Ptr{Cdouble}, Ptr{Int32}),
+                  h, MEM_HOST, layout, B, D, N, Xb, rows, rows * cols, yb, N, nk, sb, ns, pk, mwb, D, Lb, ldl, strideL,
+                  mw_post, D, Tp, D, D * D, Ap, D, D * D, lp, info)
+        else
+            ccall((:blr_posterior_batched_f32, LIB), Cint,
+                  (Ptr{Cvoid}, Cint, Cint, Int64, Int64, Int64, Ptr{T}, Int64, Int64, Ptr{T}, Int64, Cint, Ptr{T}, Int64, Cint, Ptr{T}, Int64,
+                   Ptr{T}, Int64, Int64, Ptr{T}, Int64, Ptr{T}, Int64, Int64, Ptr{T}, Int64, Int64, Ptr{Cdouble}, Ptr{Int32}),
+                  h, MEM_HOST, layout, B, D, N, Xb, rows, rows * cols, yb, N, nk, sb, ns, pk, mwb, D, Lb, ldl, strideL,
+                  mw_post, D, Tp, D, D * D, Ap, D, D * D, lp, info)
+        end
+    end
+    check(h, rc)
+    bad = findfirst(>(0), info)
+    bad === nothing || throw(PosDefException(Int(info[bad])))
+    want_posterior || return [(lp[b], nothing, nothing, nothing) for b in 1:B]
+    return [(lp[b], mw_post[:, b], Tp[:, :, b], Ap isa Ptr ? Ap : Ap[:, :, b]) for b in 1:B]
+end
+
+function logpdf_map(fxs::AbstractVector{<:FiniteGP}, ys::AbstractVector{<:AbstractVector{<:Real}})
+    r = fused_many(fxs, ys, false)
+    r === nothing ? map(logpdf, fxs, ys) : Float64[q[1] for q in r]
+end
+
+function posterior_map(fxs::AbstractVector{<:FiniteGP}, ys::AbstractVector{<:AbstractVector{<:Real}})
+    r = fused_many(fxs, ys, true)
+    r === nothing && return map(posterior, fxs, ys)
+    map(fxs, r) do fx, (_, mw_post, Tp, Ap)
+        blr0 = fx.f isa BasisFunctionRegressor ? fx.f.blr : fx.f
+        post = BayesianLinearRegressor(mw_post, build_Λ(typeof(blr0.Λw), Tp, Ap))
+        fx.f isa BasisFunctionRegressor ? BasisFunctionRegressor(post, fx.f.ϕ) : post
+    end
 end
 
 # The reference's own methods stay reachable after install_overrides! has replaced them: the fallbacks run in the world age

@@ -1333,6 +1333,58 @@ def test_large_d_batched_regressors_share_the_factorisation_launches(B, dtype, n
     np.testing.assert_allclose(T1[ok], T_post[ok], rtol=0, atol=eps * 10 * np.abs(T1[ok]).max())
 
 
+@pytest.mark.parametrize("D,N", [(3, 11), (64, 130), (128, 300), (200, 260)])
+@pytest.mark.parametrize("prior", ["diagonal", "dense", "pdmat"])
+def test_map_over_regressors_is_one_batched_call(B, D, N, prior):
+    # logpdf_map / posterior_map: the reference's methods mapped over a collection of finite regressors (:55-69), served by
+    # ONE blr_posterior_batched_* call when the problems have one shape.  Same results as the one-at-a-time calls (which are
+    # pinned to the oracle above), same wrapper types, the first failing problem raises with its position, and collections
+    # that cannot be batched (mixed layouts / priors) still work.
+    rng = _rng(7000 + D)
+    nb = 5
+    fxs, ys = [], []
+    for b in range(nb):
+        X = rng.standard_normal((D, N))
+        if prior == "diagonal":
+            Lw = B.Diagonal(np.exp(0.3 * rng.standard_normal(D)))
+        else:
+            Bm = rng.standard_normal((D, D)) / np.sqrt(D)
+            M = Bm @ Bm.T + np.eye(D)
+            Lw = M if prior == "dense" else B.PDMat(O.chol_upper(M))
+        f = B.BayesianLinearRegressor(0.2 * rng.standard_normal(D), Lw)
+        fxs.append(f(B.ColVecs(np.asfortranarray(X)), np.exp(0.2 * rng.standard_normal(N))))
+        ys.append(rng.standard_normal(N))
+    lps = B.logpdf_map(fxs, ys)
+    posts = B.posterior_map(fxs, ys)
+    for fx, y, lp, fp in zip(fxs, ys, lps, posts):
+        assert lp == pytest.approx(B.logpdf(fx, y), rel=1e-12)
+        one = B.posterior(fx, y)
+        np.testing.assert_allclose(fp.mw, one.mw, rtol=1e-10, atol=1e-12)
+        assert type(fp.Lw) is type(one.Lw)
+        if prior == "pdmat":
+            np.testing.assert_allclose(fp.Lw.U, one.Lw.U, rtol=1e-10, atol=1e-12)
+        else:
+            np.testing.assert_allclose(fp.Lw.toarray(), one.Lw.toarray(), rtol=1e-10, atol=1e-10)
+    # a basis-function regressor maps through its feature map and comes back wrapped
+    phi = lambda x: B.ColVecs(np.asfortranarray(np.tanh(x.X)))  # noqa: E731
+    bfs = [B.BasisFunctionRegressor(fx.f, phi)(fx.x, fx.Sy) for fx in fxs]
+    pb = B.posterior_map(bfs, ys)
+    assert all(isinstance(p_, B.BasisFunctionRegressor) for p_ in pb)
+    np.testing.assert_allclose(pb[2].blr.mw, B.posterior(bfs[2], ys[2]).blr.mw, rtol=1e-10, atol=1e-12)
+    # the first problem that is not positive definite raises, and says which one it was
+    s_bad = np.ones(N); s_bad[min(4, N - 1)] = -1.0
+    broken = list(fxs)
+    broken[3] = fxs[3].f(fxs[3].x, s_bad)
+    with pytest.raises(B.PosDefException) as ei:
+        B.logpdf_map(broken, ys)
+    assert ei.value.info == min(4, N - 1) + 1 and ei.value.index == 3
+    # mixed collection (a RowVecs problem among ColVecs ones): no batch, same answers
+    mixed = list(fxs)
+    mixed[1] = fxs[1].f(B.RowVecs(np.asfortranarray(fxs[1].x.X.T)), fxs[1].Sy)
+    np.testing.assert_allclose(B.logpdf_map(mixed, ys), lps, rtol=1e-12)
+    assert B.logpdf_map([], []) == []
+
+
 @pytest.mark.parametrize("dtype", [np.float64, np.float32])
 def test_large_d_repeated_calls_on_resident_buffers(B, dtype):
     # The large-D chain keeps its synchronisation state on the device (arrival counter of the panel kernel, tickets and
