@@ -552,11 +552,17 @@ int posterior_large_group(blr_handle* h, const PosteriorArgs<T>& a, int64_t reg0
     char* ws = h->ws;
     T* Abar = reinterpret_cast<T*>(ws + o_abar);
     T* Tfull = reinterpret_cast<T*>(ws + o_m);
-    dim3 grid((DP + 31) / 32, (DP + 31) / 32, G);
-    hipLaunchKernelGGL(transpose_out_kernel<T>, grid, dim3(kThreads), 0, h->stream, (const T*)Abar, lda, DP, Tfull,
-                       (int64_t)DP, a.T_post ? a.T_post + reg0 * a.strideT : (T*)nullptr, a.ldt, D, (int64_t)(per / sizeof(T)), a.strideT);
+    // logpdf alone (no posterior mean, no factor wanted): the evidence is complete with the factorisation -- no transpose, no
+    // back substitution, the launch below only assembles the scalars
+    const bool evidence_only = a.mw_post == nullptr && a.T_post == nullptr;
+    if (!evidence_only) {
+      dim3 grid((DP + 31) / 32, (DP + 31) / 32, G);
+      hipLaunchKernelGGL(transpose_out_kernel<T>, grid, dim3(kThreads), 0, h->stream, (const T*)Abar, lda, DP, Tfull,
+                         (int64_t)DP, a.T_post ? a.T_post + reg0 * a.strideT : (T*)nullptr, a.ldt, D, (int64_t)(per / sizeof(T)), a.strideT);
+    }
     WaveSolveArgs<T> b{};
     b.Tf = Tfull; b.ldtf = DP; b.D = D; b.DP = DP;
+    if (evidence_only) { b.Tf = Abar; b.ldtf = lda; b.evidence_only = 1; }  // (diagonal of L = diagonal of T)
     b.rhs = Abar + DP; b.ldrhs = G > 1 ? (int64_t)(per / sizeof(T)) : 0; b.rhs_inc = lda;  // u = row DP of the factored Abar
     b.add = a.mw + reg0 * a.stridemw; b.out = a.mw_post ? a.mw_post + reg0 * a.stride_mwpost : nullptr;
     b.ldout = G > 1 ? a.stride_mwpost : 0;

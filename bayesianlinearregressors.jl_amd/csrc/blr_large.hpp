@@ -1331,6 +1331,9 @@ struct WaveSolveArgs {
   // ldout, logpdf and info by one.
   int group;
   int64_t ws_stride, add_stride, s_stride;
+  // 1: nobody wants m (logpdf without posterior: out == NULL) -- the evidence needs |u|^2 and the factor's diagonal only, both
+  // there once the factorisation is; Tf may then be the LOWER factor itself (only its diagonal is read), no hop is made
+  int evidence_only;
 };
 
 __device__ __forceinline__ void xchg_put(unsigned long long* g, float v, unsigned tag) {
@@ -1475,8 +1478,12 @@ __global__ __launch_bounds__(kThreads) void backsolve_wave_kernel(WaveSolveArgs<
   }
   const T* rhs = a.rhs + sidx * a.ldrhs;
   unsigned long long* xg = a.xchg + (sidx * DP) * 2;
+  if (a.evidence_only && !evidence) {  // (uniform over the workgroup; nobody waits for anybody in this mode)
+    leave();
+    return;
+  }
 
-  load_upper_block_to_packed(P, a.Tf + (int64_t)q * kPB * a.ldtf + (int64_t)q * kPB, a.ldtf, tid);
+  if (!a.evidence_only) load_upper_block_to_packed(P, a.Tf + (int64_t)q * kPB * a.ldtf + (int64_t)q * kPB, a.ldtf, tid);
   // wave 0 solves: lane l owns rows l and l + 64 of the block
   const int i0 = lane, i1 = lane + 64;
   T b0 = T(0), b1 = T(0);
@@ -1497,6 +1504,20 @@ __global__ __launch_bounds__(kThreads) void backsolve_wave_kernel(WaveSolveArgs<
     ld = 2.0 * block_allreduce(ld, scr, tid);
     qs = block_allreduce(qs, scr, tid);
     ls = block_allreduce(ls, scr, tid);
+  }
+  auto write_evidence = [&]() {
+    *a.info = 0;
+    if (a.logpdf) {
+      const double LOG2PI = 1.8378770664093454835606594728112;
+      const double nobs = a.n_total > 0.0 ? a.n_total : (double)a.N;
+      const double logdet_Sy = (a.noise_kind == NOISE_DIAGONAL) ? ls : nobs * log((double)a.s[0]);
+      *a.logpdf = -0.5 * (nobs * LOG2PI + logdet_Sy + qs + ld - *a.logdet_Lw_dev - uu);
+    }
+  };
+  if (a.evidence_only) {  // (only the evidence workgroup of each system gets here)
+    if (tid == 0) write_evidence();
+    leave();
+    return;
   }
   __syncthreads();  // P complete
   // the eight 16 x 16 diagonal tiles of U_qq inverted (wave 0, DPP row t % 4 holds tile t: vA tiles 0-3, vB tiles 4-7): off the
@@ -1564,15 +1585,7 @@ __global__ __launch_bounds__(kThreads) void backsolve_wave_kernel(WaveSolveArgs<
       if (j1 < D) a.out[sidx * a.ldout + j1] = a.add[j1] + b1;
     }
   }
-  if (evidence && tid == 0) {
-    *a.info = 0;
-    if (a.logpdf) {
-      const double LOG2PI = 1.8378770664093454835606594728112;
-      const double nobs = a.n_total > 0.0 ? a.n_total : (double)a.N;
-      const double logdet_Sy = (a.noise_kind == NOISE_DIAGONAL) ? ls : nobs * log((double)a.s[0]);
-      *a.logpdf = -0.5 * (nobs * LOG2PI + logdet_Sy + qs + ld - *a.logdet_Lw_dev - uu);
-    }
-  }
+  if (evidence && tid == 0) write_evidence();
   leave();
 }
 

@@ -590,8 +590,12 @@ def test_large_d_factorisation_names_the_first_bad_pivot(B, dtype, col):
     Lc[col, col] = 0.0
     Lw_bad = Lc @ Lc.T
     Lw_bad[col, col] -= 1.0
+    fx_bad = B.BayesianLinearRegressor(np.zeros(D, dtype), Lw_bad.astype(dtype))(np.asfortranarray(X), dtype(0.5))
     with pytest.raises(B.PosDefException) as ei:
-        B.posterior(B.BayesianLinearRegressor(np.zeros(D, dtype), Lw_bad.astype(dtype))(np.asfortranarray(X), dtype(0.5)), np.zeros(N, dtype))
+        B.posterior(fx_bad, np.zeros(N, dtype))
+    assert ei.value.info == col + 1
+    with pytest.raises(B.PosDefException) as ei:  # logpdf alone: no back substitution is launched, the status still arrives
+        B.logpdf(fx_bad, np.zeros(N, dtype))
     assert ei.value.info == col + 1
 
 
