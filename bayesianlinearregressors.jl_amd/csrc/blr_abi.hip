@@ -592,7 +592,10 @@ int dispatch_posterior(blr_handle* h, const PosteriorArgs<T>& a) {
   int gmax = kChainBatchMax;
   if (const char* e = getenv("BLR_MI355X_CHAIN_BATCH")) gmax = std::max(1, std::min(kChainBatchMax, atoi(e)));  // measurements only
   if ((a.strideX * (int64_t)sizeof(T)) % 16 != 0) gmax = 1;
-  gmax = (int)((a.B + (a.B + gmax - 1) / gmax - 1) / std::max<int64_t>(1, (a.B + gmax - 1) / gmax));  // even groups: 17 -> 9 + 8, not 16 + 1
+  {  // even groups: 129 regressors run as 65 + 64, not 128 + 1
+    const int64_t ngroups = std::max<int64_t>(1, (a.B + gmax - 1) / gmax);
+    gmax = (int)((a.B + ngroups - 1) / ngroups);
+  }
   for (int64_t reg = 0; reg < a.B;) {
     int done = 1;
     int rc = posterior_large_group<T>(h, a, reg, (int)std::min<int64_t>(gmax, a.B - reg), &done);
