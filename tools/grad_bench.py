@@ -37,7 +37,9 @@ def run(B, D, N, dtype):
 
 
 if __name__ == "__main__":
-    if len(sys.argv) > 1 and sys.argv[1] == "large":
+    if len(sys.argv) > 1 and sys.argv[1] == "batch":  # batches at D > 128
+        run(16, 256, 4096, np.float32); run(8, 512, 4096, np.float32); run(8, 1024, 16384, np.float32); run(8, 512, 4096, np.float64)
+    elif len(sys.argv) > 1 and sys.argv[1] == "large":
         run(1, 1024, 65536, np.float32); run(1, 2048, 16384, np.float32); run(1, 1024, 65536, np.float64)
     else:
         run(1024, 128, 4096, np.float64); run(1024, 128, 4096, np.float32); run(8192, 64, 1024, np.float64)
