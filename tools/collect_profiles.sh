@@ -38,6 +38,7 @@ for c in c3 c5; do
   rocprofv3 --pmc WRITE_SIZE --kernel-trace --output-format csv -d $OUT/pmc_write_$c -- $B --config $c --steps 5 --warmup 2 > /dev/null 2>&1
 done
 rocprofv3 --pmc $SQ --kernel-trace --output-format csv -d $OUT/pmc_sq_c5 -- $B --config c5 --steps 5 --warmup 2 > /dev/null 2>&1
+rocprofv3 --pmc $SQ --kernel-trace --output-format csv -d $OUT/pmc_sq_c3b8 -- $B --D 1024 --N 65536 --dtype f32 --noise diagonal --batch 8 --steps 5 --warmup 2 > /dev/null 2>&1
 # the clock the part holds: ring loop of the headline kernel on zero / random operands, cache-resident / streamed
 ( cd $R/tools && [ -x ./ring_probe ] || /opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -std=c++17 -DRING_MWZ=true -I$R/bayesianlinearregressors.jl_amd/csrc ring_probe.hip -o ring_probe 2>/dev/null
   { echo "# tools/ring_probe 8192 0 (zero operands)"; ./ring_probe 8192 0; echo "# tools/ring_probe 8192 1 (random operands)"; ./ring_probe 8192 1; } > $OUT/ring_probe.txt 2>&1

@@ -87,6 +87,7 @@ if f4 and w4:
                                             "hbm_bytes_per_launch": rd + wr, "units_per_launch": 8192}
 sq4 = counters("pmc_sq_c4", "fused_wave_kernel")
 sq5 = counters("pmc_sq_c5", "gram_tile_kernel")
+sq3b8 = counters("pmc_sq_c3b8", "gram_tile_kernel")  # 8 regressors of c3's shape in one launch
 for key, d, kern, units in (("c2_f32_fused_small_kernel_hbm", "c2f32", "fused_small_kernel", 4096), ("c3_gram_tile_kernel_hbm", "c3", "gram_tile_kernel", 1),
                             ("c5_gram_tile_kernel_hbm", "c5", "gram_tile_kernel", 1)):
     fe, wr_ = counters(f"pmc_fetch_{d}", kern), counters(f"pmc_write_{d}", kern)
@@ -104,7 +105,7 @@ for extra in ("ring_probe.txt", "power_probe.txt"):
     if os.path.exists(src) and os.path.getsize(src):
         shutil.copy(src, os.path.join(DST, f"{tag}_microbench_{extra}"))
 for key, c in (("c2_fused_small_kernel_sq", sq2), ("c2_f32_fused_small_kernel_sq", sq2f), ("c3_gram_tile_kernel_sq", sq3),
-               ("c4_fused_wave_kernel_sq", sq4), ("c5_gram_tile_kernel_sq", sq5)):
+               ("c4_fused_wave_kernel_sq", sq4), ("c5_gram_tile_kernel_sq", sq5), ("c3_B8_gram_tile_kernel_sq", sq3b8)):
     if c:
         ns = c["avg_duration_ns"]
         c["effective_clock_GHz"] = c["GRBM_GUI_ACTIVE"] / 8.0 / ns
