@@ -436,10 +436,19 @@ int posterior_large_group(blr_handle* h, const PosteriorArgs<T>& a, int64_t reg0
   const size_t o_m = carve((size_t)DP * DP * sizeof(T));  // transposed factor for the back substitution
   const size_t o_sc = carve(64);
   const size_t per = off;  // one regressor's workspace (a multiple of 256 bytes)
-  G = (int)std::max<size_t>(1, std::min<size_t>((size_t)G, kChainWorkspace / per));
-  if (G_done) *G_done = G;
-  int rc = ensure_ws(h, per * (size_t)G);
+  size_t ws_cap = kChainWorkspace;
+  if (const char* e = getenv("BLR_MI355X_CHAIN_WS_MB")) ws_cap = (size_t)std::max(1L, atol(e)) << 20;  // tests: small groups
+  G = (int)std::max<size_t>(1, std::min<size_t>((size_t)G, ws_cap / per));
+  int rc;
+  for (;;) {  // (a device too full for the whole group's workspace: smaller groups, down to one regressor at a time)
+    rc = ensure_ws(h, per * (size_t)G);
+    if (rc == 0 || G == 1) break;
+    (void)hipGetLastError();
+    h->err.clear();
+    G = (G + 1) / 2;
+  }
   if (rc) return rc;
+  if (G_done) *G_done = G;
   // Every launch below covers the whole group: regressor g from blockIdx.y / .z, its caller-side arrays by the batch strides
   // and its workspace `per` bytes after its predecessor's (the pointers here are regressor reg0's).
   const int64_t reg = reg0;

@@ -1335,6 +1335,13 @@ def test_large_d_batched_regressors_share_the_factorisation_launches(B, dtype, n
     np.testing.assert_allclose(lp1[ok], lp[ok], rtol=eps * 10)
     np.testing.assert_allclose(mw1[ok], mw_post[ok], rtol=0, atol=eps * 100 * np.abs(mw1[ok]).max())
     np.testing.assert_allclose(T1[ok], T_post[ok], rtol=0, atol=eps * 10 * np.abs(T1[ok]).max())
+    # a workspace bound that holds only a few regressors: the batch runs as several groups, the last one smaller
+    monkeypatch.delenv("BLR_MI355X_CHAIN_BATCH")
+    monkeypatch.setenv("BLR_MI355X_CHAIN_WS_MB", "12")
+    mw2, T2, L2, lp2, info2 = run()
+    assert info2.tolist() == want
+    np.testing.assert_allclose(lp2[ok], lp[ok], rtol=eps * 10)
+    np.testing.assert_allclose(mw2[ok], mw_post[ok], rtol=0, atol=eps * 100 * np.abs(mw1[ok]).max())
 
 
 @pytest.mark.parametrize("D,N", [(3, 11), (64, 130), (128, 300), (200, 260)])
