@@ -7,6 +7,10 @@
 #include <dlfcn.h>
 
 #include <algorithm>
+#include <array>
+#include <functional>
+#include <map>
+#include <queue>
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
@@ -44,6 +48,8 @@ struct blr_handle {
   // kernels whose dynamic-LDS limit has been raised on this handle's device (hipFuncSetAttribute is per device and costs a
   // driver call: once per (handle, kernel), not once per launch -- it sat on the launch path of the 5 us wave kernel)
   std::unordered_map<const void*, size_t> lds_limit;
+  // multi-round Gram launches: (row blocks, N, slots) -> (off-diagonal ranges, diagonal ranges, tiles with one range less)
+  std::map<std::array<int, 3>, std::array<int, 3>> gram_plans;
   // RCCL communicator of blr_comm_init (one rank per handle / GPU); NULL until then
   ncclComm_t comm = nullptr;
   int comm_size = 0, comm_rank = 0;
@@ -353,11 +359,63 @@ int chol_large(blr_handle* h, T* M, int64_t ld, int DP, int nrows_total, int32_t
   return 0;
 }
 
+// Multi-round Gram launch of ONE regressor (c5: 136 tiles on 512 slots): with one split factor the launch takes whole rounds of
+// the off-diagonal workgroup length (952 workgroups = 2 rounds at 93 % fill).  Three kinds of work items, dispatched longest
+// first -- diagonal tiles with `sd` column ranges, `nlong` strictly lower tiles with so - 1 ranges, the others with so -- let
+// a second round of SHORTER workgroups follow a first round of longer ones (c5: 64 x 3205 + 448 x 2597, then 448 x 2304 column
+// units instead of 2 x 2597 everywhere).  The plan is the makespan of list scheduling on `slots` slots over a small neighbourhood
+// of the one-factor choice s0 (10 ms of host time, once per shape and handle); `unit` = cost of a diagonal column / off-diagonal.
+struct GramPlan { int so, sd, nlong; double makespan; };
+inline double gram_makespan(int n_off, int NC, int so, int sd, int nlong, int N, int nsc, int slots, double unit, bool interleaved) {
+  auto cols = [&](int sp) { return (double)(((N + sp - 1) / sp + nsc - 1) / nsc * nsc); };
+  std::priority_queue<double, std::vector<double>, std::greater<double>> free_at;
+  for (int i = 0; i < slots; ++i) free_at.push(0.0);
+  double end = 0.0;
+  auto run = [&](double cost) { double t = free_at.top() + cost; free_at.pop(); free_at.push(t); end = std::max(end, t); };
+  if (interleaved) {  // one factor: item w -> tile w % ntiles, diagonal tiles spread over the launch
+    const int ntiles = n_off + NC;
+    for (int w = 0; w < ntiles * so; ++w) {
+      const int t = w % ntiles;
+      int ii = 0;
+      while ((ii + 1) * (ii + 2) / 2 <= t) ++ii;
+      const bool diag = t - ii * (ii + 1) / 2 == ii;
+      run((diag ? unit : 1.0) * cols(so) + 256.0);
+    }
+    return end;
+  }
+  for (int i = 0; i < NC * sd; ++i) run(unit * cols(sd) + 256.0);
+  for (int i = 0; i < nlong * (so - 1); ++i) run(cols(so - 1) + 256.0);
+  for (int i = 0; i < (n_off - nlong) * so; ++i) run(cols(so) + 256.0);
+  return end;
+}
+inline GramPlan plan_gram_rounds(int n_off, int NC, int s0, int N, int nsc, int slots, int max_split, double unit) {
+  const double base = gram_makespan(n_off, NC, s0, s0, 0, N, nsc, slots, unit, true);
+  // Candidates are the family that measured well on c5 (tools/scan_splits.sh): one or two ranges more than the one-factor choice,
+  // diagonal tiles with as many ranges as the short tiles or half as many, the long tiles in sixteenths of the triangle.
+  // (Measured against the model at D = 2048, N = 16384, ms per update: 7 | 7 -> 1.045; 8 | 8, 64 long -> 0.999; 8 | 4, 64 ->
+  // 0.997; 8 | 6, 56 -> 0.999; 8 | 8, 56 (1032 workgroups: a third round) -> 1.065; 8 | 7, 64 -> 1.076 against a modelled tie.)
+  GramPlan best{s0, 0, 0, base};
+  for (int so = std::max(2, s0); so <= std::min(max_split, s0 + 2); ++so)
+    for (int sd : {so, so / 2}) {
+      if (sd < 1) continue;
+      // the run of nlong values that tie for the best makespan of this (so, sd): take its middle (both ends sit next to a cliff)
+      double m_best = 1e300;
+      int first = -1, last = -1;
+      for (int f = 0; f <= 16; ++f) {
+        const double m = gram_makespan(n_off, NC, so, sd, n_off * f / 16, N, nsc, slots, unit, false);
+        if (m < m_best * 0.995) { m_best = m; first = last = f; }
+        else if (m <= m_best * 1.005 && f == last + 1) last = f;
+      }
+      if (m_best < best.makespan * 0.995) best = GramPlan{so, sd, n_off * ((first + last) / 2) / 16, m_best};
+    }
+  if (best.sd == 0 || best.makespan > 0.96 * base) return GramPlan{s0, 0, 0, base};  // not worth leaving the one-factor launch
+  return best;
+}
+
+// `G` regressors reg0 .. reg0 + G - 1 of the batch, each with its own copy of the workspace, in every launch of the update
+// (regressor from blockIdx.y / .z): the ~2 dispatches per panel of the factorisation are latency, not throughput, and so are
+// the small kernels around the Gram launch.  G = 1 is the single-regressor path.
 template <typename T>
-// `G` regressors reg0 .. reg0 + G - 1 of the batch, each with its own copy of the workspace: statistics and Gram launches one
-// regressor after the other (they fill the chip), then ONE blocked factorisation over all of them (its ~2 dispatches per panel
-// are latency, not throughput: panel_chain_kernel / trail_update_kernel take the regressor from blockIdx.y), then the
-// back substitutions.  G = 1 is the single-regressor path as it always was.
 int posterior_large_group(blr_handle* h, const PosteriorArgs<T>& a, int64_t reg0, int G, int* G_done = nullptr) {
   using LC = LargeCfg<T>;
   const int D = a.D, N = a.N;
@@ -389,6 +447,7 @@ int posterior_large_group(blr_handle* h, const PosteriorArgs<T>& a, int64_t reg0
   // tools/scan_splits.sh).  Multi-round launches (c5: 136 tiles x 15) keep one factor: there the dispatcher balances.
   constexpr double kDiagCost = 11.5;
   int nsplit_diag = 0;  // 0: one factor for all tiles
+  int nlong = 0;        // strictly lower tiles with one column range less (multi-round launches)
   {
     const int slots = 256 * (sizeof(T) == 4 ? BLR_GRAM_WGS : 2);
     // (only where the diagonal tiles will go through the ring loop: f32, LDS-DMA staging, whole row blocks)
@@ -397,10 +456,12 @@ int posterior_large_group(blr_handle* h, const PosteriorArgs<T>& a, int64_t reg0
                        ((a.ldx * (int64_t)sizeof(T)) % 16 == 0) && getenv("BLR_MI355X_NO_GRAM_RING") == nullptr &&
                        getenv("BLR_MI355X_NO_DIAG_SPLIT") == nullptr && D % kPB == 0 && NC >= 2 && (ntiles * nsplit * G <= slots || getenv("BLR_MI355X_GRAM_SPLITS") != nullptr);
     if (const char* e = getenv("BLR_MI355X_GRAM_SPLITS")) {  // "off-diagonal,diagonal" (equal: one factor): measurements only
-      int so = 0, sd = 0;
-      if (sscanf(e, "%d,%d", &so, &sd) == 2 && so >= 1 && sd >= 1 && sd <= so && so <= max_split) {
+      int so = 0, sd = 0, nl = 0;
+      const int nf = sscanf(e, "%d,%d,%d", &so, &sd, &nl);
+      if (nf >= 2 && so >= 1 && sd >= 1 && sd <= so && so <= max_split) {
         nsplit = so;
-        nsplit_diag = (sd < so && dealt) ? sd : 0;
+        nsplit_diag = ((sd < so || nf == 3) && dealt) ? sd : 0;
+        if (nf == 3 && nsplit_diag > 0 && so >= 2) nlong = std::max(0, std::min(nl, ntiles - NC));
       }
     } else if (dealt) {
       auto cols = [&](int sp) { return (double)(((N + sp - 1) / sp + nstage_cols - 1) / nstage_cols * nstage_cols); };
@@ -414,6 +475,22 @@ int posterior_large_group(blr_handle* h, const PosteriorArgs<T>& a, int64_t reg0
           if (t < best_t * 0.995) { best_t = t; bo = so; bd = sd; }
         }
       if (bo > 0) { nsplit = bo; nsplit_diag = bd; }
+    }
+    // multi-round launch of one regressor: three kinds of work items (plan_gram_rounds)
+    const bool ring_ok = sizeof(T) == 4 && a.layout == LAYOUT_COLVECS && ((uintptr_t)X0 % 16 == 0) &&
+                         ((a.ldx * (int64_t)sizeof(T)) % 16 == 0) && getenv("BLR_MI355X_NO_GRAM_RING") == nullptr &&
+                         getenv("BLR_MI355X_NO_DIAG_SPLIT") == nullptr && getenv("BLR_MI355X_GRAM_SPLITS") == nullptr && D % kPB == 0 && NC >= 2;
+    if (ring_ok && G == 1 && nsplit_diag == 0 && ntiles * nsplit > slots && nsplit >= 2) {
+      const std::array<int, 3> key{NC, N, slots};
+      auto it = h->gram_plans.find(key);
+      if (it == h->gram_plans.end()) {
+        const GramPlan pl = plan_gram_rounds(ntiles - NC, NC, nsplit, N, nstage_cols, slots, max_split, kDiagCost / 16.0);
+        it = h->gram_plans.emplace(key, std::array<int, 3>{pl.so, pl.sd, pl.nlong}).first;
+        if (getenv("BLR_MI355X_PLAN_DEBUG"))
+          fprintf(stderr, "blr: Gram plan for %d row blocks, N = %d: one factor %d -> ranges %d (off-diagonal, %d tiles with %d) / %d (diagonal), "
+                          "modelled makespan %.0f column units\n", NC, N, nsplit, pl.so, pl.nlong, pl.so - 1, pl.sd, pl.makespan);
+      }
+      if (it->second[1] > 0) { nsplit = it->second[0]; nsplit_diag = it->second[1]; nlong = it->second[2]; }
     }
   }
   const bool prior_factor = a.prior_kind == PRIOR_UPPER_FACTOR;
@@ -526,16 +603,16 @@ int posterior_large_group(blr_handle* h, const PosteriorArgs<T>& a, int64_t reg0
   // launches the tiles described by g (+ the prior-factor pseudo split) and their reduction on `st`
   auto gram_tiles = [&](hipStream_t st, int nsp, int nt, T* gp) {
     g.nsplit = nsp; g.ntiles = nt; g.Gpart = gp;
-    g.nsplit_diag = nsplit_diag;
-    g.xcd_swizzle = (nsp > 1 && !no_swizzle) ? 1 : 0;
-    const int nwg = nsplit_diag ? (nt - NC) * nsp + NC * nsplit_diag : nt * nsp;
+    g.nsplit_diag = nsplit_diag; g.nlong = nlong;
+    g.xcd_swizzle = (nsp > 1 && !no_swizzle && nlong == 0) ? 1 : 0;  // (three kinds of work items: dispatch order IS the plan)
+    const int nwg = nsplit_diag ? (nt - NC) * nsp - nlong + NC * nsplit_diag : nt * nsp;
     hipLaunchKernelGGL(gram_tile_kernel<T>, dim3(nwg, G), dim3(kThreads), LC::LDS_BYTES, st, g);
     if (prior_factor) {
       GramTileArgs<T> u = g;
       u.xcd_swizzle = 0;
       u.X = Lw; u.ldx = a.ldl; u.layout = 2; u.use_dma = 0; u.s = nullptr; u.r = nullptr;
       u.grp_X = a.strideLw; u.grp_s = 0;
-      u.n_begin = 0; u.n_end = D; u.nsplit = 1; u.nsplit_diag = 0;
+      u.n_begin = 0; u.n_end = D; u.nsplit = 1; u.nsplit_diag = 0; u.nlong = 0;
       u.Gpart = gp + (int64_t)nsp * nt * kPB * kPB;
       u.bpart = bpart + (int64_t)nsp * NC * kPB;
       hipLaunchKernelGGL(gram_tile_kernel<T>, dim3(nt, G), dim3(kThreads), LC::LDS_BYTES, st, u);
@@ -543,7 +620,7 @@ int posterior_large_group(blr_handle* h, const PosteriorArgs<T>& a, int64_t reg0
   };
   auto gram_reduce = [&](hipStream_t st, int nsp, int nt, T* gp, int reduce_blocks) {
     r.Gpart = gp; r.nsplit_total = nsp + pf; r.ntiles = nt;
-    r.nsplit_diag = nsplit_diag; r.pseudo_split = pf;
+    r.nsplit_diag = nsplit_diag; r.pseudo_split = pf; r.nlong = nlong;
     hipLaunchKernelGGL(gram_reduce_kernel<T>, dim3(nt + reduce_blocks, 16, G), dim3(kThreads), 0, st, r);
   };
 

@@ -437,6 +437,8 @@ struct GramTileArgs {
   int nsplit;                // split-K factor over [n_begin, n_end)
   int nsplit_diag;           // tri 1 only, 0 = nsplit: the diagonal macro tiles' own (smaller) split factor; the launch then
                              // holds (ntiles - nblocks) nsplit off-diagonal work items followed by nblocks nsplit_diag diagonal ones
+  int nlong;                 // with nsplit_diag > 0: the first `nlong` strictly lower tiles have nsplit - 1 (longer) column ranges;
+                             // work items in dispatch order: diagonal tiles, long ranges, short ranges (GramPlan, blr_abi.hip)
   int tile_i0, tile_j0;      // first row-block / col-block index of the tile grid
   int ntile_rows;            // row-block count of the rectangle (tri 3) / triangle (tri 4)
   int extra_row;             // tri 4: row block of the extra row of tiles
@@ -488,21 +490,31 @@ __global__ __launch_bounds__(kThreads, (sizeof(T) == 4 ? BLR_GRAM_WGS : 2)) void
   int nsplit_here = a.nsplit;
   int I, J;
   if (a.tri == 1 && a.nsplit_diag > 0) {
-    // two kinds of work items: the strictly lower tiles o = I (I - 1) / 2 + J with a.nsplit column ranges each, then the
-    // diagonal tiles with a.nsplit_diag
+    // three kinds of work items, longest first: the diagonal tiles with a.nsplit_diag column ranges each, then the strictly
+    // lower tiles o = I (I - 1) / 2 + J: those with o < a.nlong have a.nsplit - 1 ranges, the others a.nsplit
     const int n_off = a.ntiles - a.nblocks;
-    if (w < n_off * a.nsplit) {
-      const int o = w % n_off;
-      sidx = w / n_off;
+    const int nd = a.nblocks * a.nsplit_diag;
+    if (w < nd) {
+      I = J = w % a.nblocks;
+      sidx = w / a.nblocks;
+      nsplit_here = a.nsplit_diag;
+    } else {
+      const int nl = a.nlong * (a.nsplit - 1);
+      int o;
+      if (w < nd + nl) {
+        const int wl = w - nd;
+        o = wl % a.nlong;
+        sidx = wl / a.nlong;
+        nsplit_here = a.nsplit - 1;
+      } else {
+        const int ws = w - nd - nl, ns = n_off - a.nlong;
+        o = a.nlong + ws % ns;
+        sidx = ws / ns;
+      }
       int ii = 1;
       while ((ii + 1) * ii / 2 <= o) ++ii;
       I = ii;
       J = o - ii * (ii - 1) / 2;
-    } else {
-      const int wd = w - n_off * a.nsplit;
-      I = J = wd % a.nblocks;
-      sidx = wd / a.nblocks;
-      nsplit_here = a.nsplit_diag;
     }
     t = I * (I + 1) / 2 + J;
     I += a.tile_i0;
@@ -765,6 +777,7 @@ struct ReduceArgs {
   int nsplit_total;          // data splits (+1 if a prior-factor pseudo split is present)
   int nsplit_diag;           // 0, or the number of data splits of the DIAGONAL tiles (< the others'; see GramTileArgs)
   int pseudo_split;          // 1: the last of the nsplit_total partials is the prior factor's (present for every tile)
+  int nlong;                 // strictly lower tiles o < nlong hold one data partial less (see GramTileArgs)
   int ntiles, nblocks;       // lower-triangular macro tiles, row blocks
   const T* Lw; int64_t ldl; int prior_kind;
   int D, DP;
@@ -800,8 +813,9 @@ __global__ __launch_bounds__(kThreads) void gram_reduce_kernel(ReduceArgs<T> a) 
       const T* src = a.Gpart + (int64_t)t * (kPB * kPB) + e;
       vecT sum = vecT(T(0));
       // a diagonal tile with its own split factor: its data partials, then (if present) the pseudo split at the END of the stack
-      const bool short_stack = a.nsplit_diag > 0 && I == J;
-      const int ndata = short_stack ? a.nsplit_diag : a.nsplit_total;
+      const bool long_tile = a.nlong > 0 && I != J && I * (I - 1) / 2 + J < a.nlong;
+      const bool short_stack = (a.nsplit_diag > 0 && I == J) || long_tile;
+      const int ndata = !short_stack ? a.nsplit_total : (long_tile ? a.nsplit_total - a.pseudo_split - 1 : a.nsplit_diag);
       int sp = 0;
       for (; sp + 8 <= ndata; sp += 8) {
         vecT v[8];

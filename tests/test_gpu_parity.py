@@ -1396,6 +1396,36 @@ def test_map_over_regressors_is_one_batched_call(B, D, N, prior):
     assert B.logpdf_map([], []) == []
 
 
+@pytest.mark.parametrize("splits", ["1,1", "3,3", "4,2", "3,3,1", "4,2,2", "5,5,3", "2,1,3", "6,3,5", "4,4,6"])
+@pytest.mark.parametrize("prior", ["diagonal", "pdmat"])
+def test_large_d_gram_split_plans(B, splits, prior, monkeypatch):
+    # The Gram launch of the large-D path cuts every macro tile's columns into ranges: one factor for all tiles, the diagonal
+    # tiles with their own (single-round launches), or three kinds of work items in planned dispatch order (multi-round launches:
+    # "off-diagonal, diagonal, tiles with one range less").  Whatever the plan -- forced here through the measurement switch,
+    # incl. ranges that come out empty -- the partials have to add up to the same posterior (fp32, the ring-loop path).
+    rng = _rng(7300)
+    D, N = 512, 700
+    X = rng.standard_normal((D, N)).astype(np.float32)
+    s = np.exp(0.3 * rng.standard_normal(N)).astype(np.float32)
+    y = rng.standard_normal(N).astype(np.float32)
+    mw = (0.1 * rng.standard_normal(D)).astype(np.float32)
+    if prior == "diagonal":
+        dvec = np.exp(0.3 * rng.standard_normal(D)).astype(np.float32)
+        Lw_d, Lw_arg = np.diag(dvec.astype(float)), B.Diagonal(dvec)
+    else:
+        Bm = rng.standard_normal((D, D)) / np.sqrt(D)
+        U = O.chol_upper(Bm @ Bm.T + np.eye(D)).astype(np.float32)
+        Lw_d, Lw_arg = U.astype(float).T @ U.astype(float), B.PDMat(U)
+    mw_o, T_o, A_o, lp_o = O.posterior_logpdf_direct(mw.astype(float), Lw_d, X.astype(float), s.astype(float), y.astype(float))
+    monkeypatch.setenv("BLR_MI355X_GRAM_SPLITS", splits)
+    fx = B.BayesianLinearRegressor(mw, Lw_arg)(np.asfortranarray(X), s)
+    assert B.logpdf(fx, y) == pytest.approx(lp_o, rel=2e-4)
+    fp = B.posterior(fx, y)
+    np.testing.assert_allclose(fp.mw, mw_o, rtol=0, atol=2e-3 * np.abs(mw_o).max())
+    A = fp.Lw.toarray() if prior == "diagonal" else fp.Lw.U.astype(float).T @ fp.Lw.U.astype(float)
+    np.testing.assert_allclose(A, A_o, rtol=0, atol=2e-5 * np.abs(A_o).max())
+
+
 @pytest.mark.parametrize("dtype", [np.float64, np.float32])
 def test_large_d_repeated_calls_on_resident_buffers(B, dtype):
     # The large-D chain keeps its synchronisation state on the device (arrival counter of the panel kernel, tickets and
