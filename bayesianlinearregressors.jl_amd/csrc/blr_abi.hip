@@ -508,6 +508,7 @@ int posterior_large_group(blr_handle* h, const PosteriorArgs<T>& a, int64_t reg0
   const size_t o_gp = carve((size_t)gp_tiles * kPB * kPB * sizeof(T));
   const size_t o_bp = carve((size_t)nsplit_total * NC * kPB * sizeof(double));
   const size_t o_r = carve((size_t)std::max(N, 1) * sizeof(T));
+  const size_t o_wv = carve(a.noise_kind == NOISE_DIAGONAL ? (size_t)std::max(N, 1) * sizeof(T) : 0);  // 1 / s_n for the Gram launch
   const size_t o_q = carve((size_t)gridc * sizeof(double));
   const size_t o_l = carve((size_t)gridc * sizeof(double));
   const size_t o_m = carve((size_t)DP * DP * sizeof(T));  // transposed factor for the back substitution
@@ -535,6 +536,7 @@ int posterior_large_group(blr_handle* h, const PosteriorArgs<T>& a, int64_t reg0
   T* Gpart = reinterpret_cast<T*>(ws + o_gp);
   double* bpart = reinterpret_cast<double*>(ws + o_bp);
   T* rvec = reinterpret_cast<T*>(ws + o_r);
+  T* wvec = a.noise_kind == NOISE_DIAGONAL ? reinterpret_cast<T*>(ws + o_wv) : nullptr;
   double* qpart = reinterpret_cast<double*>(ws + o_q);
   double* lpart = reinterpret_cast<double*>(ws + o_l);
   double* logdetLw = reinterpret_cast<double*>(ws + o_sc);
@@ -577,7 +579,7 @@ int posterior_large_group(blr_handle* h, const PosteriorArgs<T>& a, int64_t reg0
   // ---- column statistics (reference :82-84)
   {
     ColstatsArgs<T> c{};
-    c.X = X; c.ldx = a.ldx; c.y = y; c.s = s; c.mw = mw; c.r = rvec; c.qpart = qpart; c.lpart = lpart;
+    c.X = X; c.ldx = a.ldx; c.y = y; c.s = s; c.mw = mw; c.r = rvec; c.w = wvec; c.qpart = qpart; c.lpart = lpart;
     c.noise_info = info_noise;
     c.layout = a.layout; c.noise_kind = a.noise_kind; c.D = D; c.N = N;
     c.grp_X = a.strideX; c.grp_y = a.stridey; c.grp_s = a.strides; c.grp_mw = a.stridemw; c.grp_ws = wsb;
@@ -591,7 +593,7 @@ int posterior_large_group(blr_handle* h, const PosteriorArgs<T>& a, int64_t reg0
   g.X = X; g.ldx = a.ldx; g.layout = a.layout;
   static const bool no_ring = getenv("BLR_MI355X_NO_GRAM_RING") != nullptr;  // A/B experiments only
   g.use_dma = (a.layout == LAYOUT_COLVECS && ((uintptr_t)X % 16 == 0) && ((a.ldx * (int64_t)sizeof(T)) % 16 == 0)) ? (no_ring ? 2 : 1) : 0;
-  g.s = s; g.noise_kind = a.noise_kind; g.r = rvec;
+  g.s = s; g.noise_kind = a.noise_kind; g.r = rvec; g.wpre = wvec;
   g.D = D; g.n_begin = 0; g.n_end = N; g.nblocks = NC; g.bpart = bpart; g.mode_out = 0;
   g.grp_X = a.strideX; g.grp_s = a.strides; g.grp_ws = wsb;
   static const bool no_swizzle = getenv("BLR_MI355X_NO_XCD_SWIZZLE") != nullptr;
@@ -610,7 +612,7 @@ int posterior_large_group(blr_handle* h, const PosteriorArgs<T>& a, int64_t reg0
     if (prior_factor) {
       GramTileArgs<T> u = g;
       u.xcd_swizzle = 0;
-      u.X = Lw; u.ldx = a.ldl; u.layout = 2; u.use_dma = 0; u.s = nullptr; u.r = nullptr;
+      u.X = Lw; u.ldx = a.ldl; u.layout = 2; u.use_dma = 0; u.s = nullptr; u.r = nullptr; u.wpre = nullptr;
       u.grp_X = a.strideLw; u.grp_s = 0;
       u.n_begin = 0; u.n_end = D; u.nsplit = 1; u.nsplit_diag = 0; u.nlong = 0;
       u.Gpart = gp + (int64_t)nsp * nt * kPB * kPB;

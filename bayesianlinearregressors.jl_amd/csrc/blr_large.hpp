@@ -58,6 +58,8 @@ struct ColstatsArgs {
   const T* X; int64_t ldx;
   const T* y; const T* s; const T* mw;
   T* r;               // [N]  delta_n / s_n
+  T* w;               // [N]  1 / s_n for the Gram launch (diagonal noise; may be NULL): an exact division here instead of a
+                      //      reciprocal approximation per wave and half-stage inside the matrix loop
   double* qpart;      // [gridDim.x]
   double* lpart;      // [gridDim.x]
   unsigned* noise_info;  // atomicMin target, 0xFFFFFFFF = every variance positive; else 1-based index of the first bad one (NULL: off)
@@ -75,7 +77,7 @@ __global__ __launch_bounds__(kThreads) void colstats_kernel(ColstatsArgs<T> a) {
   const int D = a.D, N = a.N;
   if (const int64_t g = blockIdx.y) {
     a.X += g * a.grp_X; a.y += g * a.grp_y; a.s += g * a.grp_s; a.mw += g * a.grp_mw;
-    a.r = ws_shift(a.r, g * a.grp_ws); a.qpart = ws_shift(a.qpart, g * a.grp_ws); a.lpart = ws_shift(a.lpart, g * a.grp_ws);
+    a.r = ws_shift(a.r, g * a.grp_ws); a.w = ws_shift(a.w, g * a.grp_ws); a.qpart = ws_shift(a.qpart, g * a.grp_ws); a.lpart = ws_shift(a.lpart, g * a.grp_ws);
     a.noise_info = ws_shift(a.noise_info, g * a.grp_ws);
   }
   int mw_nonzero = 0;
@@ -101,6 +103,7 @@ __global__ __launch_bounds__(kThreads) void colstats_kernel(ColstatsArgs<T> a) {
       const T delta = a.y[n];
       const T rn = delta / sv;
       a.r[n] = rn;
+      if (a.w) a.w[n] = T(1) / sv;
       q += (double)delta * (double)rn;
       if (diag) l += log((double)sv);
     }
@@ -146,6 +149,7 @@ __global__ __launch_bounds__(kThreads) void colstats_kernel(ColstatsArgs<T> a) {
         const T delta = a.y[nn] - (T)mu;
         const T rn = delta / sv;
         a.r[nn] = rn;
+        if (a.w) a.w[nn] = T(1) / sv;
         q += (double)delta * (double)rn;
         if (diag) l += log((double)sv);
       }
@@ -163,6 +167,7 @@ __global__ __launch_bounds__(kThreads) void colstats_kernel(ColstatsArgs<T> a) {
       const T rn = delta / sv;
       if (lane == 0) {
         a.r[n] = rn;
+        if (a.w) a.w[n] = T(1) / sv;
         q += (double)delta * (double)rn;
         if (diag) l += log((double)sv);
       }
@@ -177,6 +182,7 @@ __global__ __launch_bounds__(kThreads) void colstats_kernel(ColstatsArgs<T> a) {
       const T delta = a.y[n] - (T)mu;
       const T rn = delta / sv;
       a.r[n] = rn;
+      if (a.w) a.w[n] = T(1) / sv;
       q += (double)delta * (double)rn;
       if (diag) l += log((double)sv);
     }
@@ -274,7 +280,7 @@ __device__ __forceinline__ void gram_kstep_ring(typename Mfma<T>::acc4 (&acc)[4]
 // take the 10 of their diagonal quadrant (acc[i][k], k <= i), waves 2 and 1 share the quadrant below the diagonal (its tile rows
 // 0-1 / 2-3, acc[0..1][k]); wave 1 -- which used to sit out -- also accumulates b_I = X_I r (r != NULL).  10 MFMAs per k-step
 // on the critical waves instead of 16: the host gives diagonal tiles longer column ranges (fewer splits) to match.
-template <typename T, bool SCALE, bool DIAGT>
+template <typename T, bool SCALE, bool DIAGT, bool PRE = false /* s holds the weights 1 / s_n themselves */>
 __device__ __forceinline__ void gram_ring_loop(T* __restrict__ ring, T* __restrict__ wring, T* __restrict__ rring,
                                                const BLR_GLOBAL T* baseA, int64_t ldA, const BLR_GLOBAL T* baseB, int64_t ldB,
                                                const BLR_GLOBAL T* s /* + c0; SCALE */, const BLR_GLOBAL T* r /* + c0 or NULL; DIAGT */,
@@ -354,7 +360,7 @@ __device__ __forceinline__ void gram_ring_loop(T* __restrict__ ring, T* __restri
       for (int i = 0; i < 4; ++i) { f0.a[i] = i < NA ? kA[i * 64] : T(0); f0.b[i] = kB[i * 64]; }
       if constexpr (SCALE) {
 #pragma unroll
-        for (int j = 0; j < 4; ++j) wcur[j] = fast_rcp(wring[4 * j + (lane >> 4)]);
+        for (int j = 0; j < 4; ++j) wcur[j] = PRE ? wring[4 * j + (lane >> 4)] : fast_rcp(wring[4 * j + (lane >> 4)]);
       }
     }
     __builtin_amdgcn_sched_barrier(0);
@@ -377,7 +383,7 @@ __device__ __forceinline__ void gram_ring_loop(T* __restrict__ ring, T* __restri
         }
       };
       auto side3 = [&] {
-        if constexpr (SCALE) {
+        if constexpr (SCALE && !PRE) {
 #pragma unroll
           for (int j = 0; j < 4; ++j) wnxt[j] = fast_rcp(wnxt[j]);
         }
@@ -432,6 +438,7 @@ struct GramTileArgs {
   int use_dma;               // ColVecs, 16-byte aligned: LDS-DMA staging (1: + the ring loop for full off-diagonal f32 tiles, 2: stage loop only)
   const T* s; int noise_kind;  // weights w_n = 1/s_n; s == NULL: w = 1
   const T* r;                // delta_n / s_n for the b partials (NULL: skip)
+  const T* wpre;             // diagonal noise: 1 / s_n precomputed (colstats_kernel), used by the ring loop instead of s; may be NULL
   int D;                     // rows of the operand
   int n_begin, n_end;        // column range of the whole contraction
   int nsplit;                // split-K factor over [n_begin, n_end)
@@ -484,7 +491,8 @@ __global__ __launch_bounds__(kThreads, (sizeof(T) == 4 ? BLR_GRAM_WGS : 2)) void
     w -= (int)g * (int)gridDim.x;
     a.X += g * a.grp_X;
     if (a.s) a.s += g * a.grp_s;
-    a.r = ws_shift(a.r, g * a.grp_ws); a.Gpart = ws_shift(a.Gpart, g * a.grp_ws); a.bpart = ws_shift(a.bpart, g * a.grp_ws);
+    a.r = ws_shift(a.r, g * a.grp_ws); a.wpre = ws_shift(a.wpre, g * a.grp_ws); a.Gpart = ws_shift(a.Gpart, g * a.grp_ws);
+    a.bpart = ws_shift(a.bpart, g * a.grp_ws);
   }
   int t = w % a.ntiles, sidx = w / a.ntiles;
   int nsplit_here = a.nsplit;
@@ -645,16 +653,21 @@ __global__ __launch_bounds__(kThreads, (sizeof(T) == 4 ? BLR_GRAM_WGS : 2)) void
       const BLR_GLOBAL T* bA = as_global(a.X + rowA);
       const BLR_GLOBAL T* bB = as_global(baseB + rowB);
       const bool scale = a.s != nullptr && diag_noise;
-      const BLR_GLOBAL T* sp = scale ? as_global(a.s + c0) : (const BLR_GLOBAL T*)nullptr;
+      const bool pre = scale && a.wpre != nullptr;
+      const BLR_GLOBAL T* sp = scale ? as_global((pre ? a.wpre : a.s) + c0) : (const BLR_GLOBAL T*)nullptr;
       const BLR_GLOBAL T* rp = want_b ? as_global(a.r + c0) : (const BLR_GLOBAL T*)nullptr;
       const int nh = ncol >> 4;
+#define BLR_RING(SC, DG, PR) gram_ring_loop<T, SC, DG, PR>(slot0, wbuf, rbuf, bA, a.ldx, bB, ldB, sp, rp, c0, nh, voffA, voffB, lane, wave, acc, bacc)
       if (diag_tile) {
-        if (scale) gram_ring_loop<T, true, true>(slot0, wbuf, rbuf, bA, a.ldx, bB, ldB, sp, rp, c0, nh, voffA, voffB, lane, wave, acc, bacc);
-        else gram_ring_loop<T, false, true>(slot0, wbuf, rbuf, bA, a.ldx, bB, ldB, sp, rp, c0, nh, voffA, voffB, lane, wave, acc, bacc);
+        if (pre) BLR_RING(true, true, true);
+        else if (scale) BLR_RING(true, true, false);
+        else BLR_RING(false, true, false);
       } else {
-        if (scale) gram_ring_loop<T, true, false>(slot0, wbuf, rbuf, bA, a.ldx, bB, ldB, sp, rp, c0, nh, voffA, voffB, lane, wave, acc, bacc);
-        else gram_ring_loop<T, false, false>(slot0, wbuf, rbuf, bA, a.ldx, bB, ldB, sp, rp, c0, nh, voffA, voffB, lane, wave, acc, bacc);
+        if (pre) BLR_RING(true, false, true);
+        else if (scale) BLR_RING(true, false, false);
+        else BLR_RING(false, false, false);
       }
+#undef BLR_RING
       if (a.s != nullptr && !diag_noise) {  // isotropic noise: applied once to the finished tile
         const T wi = T(1) / s_iso;
 #pragma unroll
