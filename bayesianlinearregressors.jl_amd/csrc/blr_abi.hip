@@ -1049,6 +1049,7 @@ int gram_stats(blr_handle* h, int layout, int64_t D64, int64_t N64, const T* X, 
   const size_t o_gp = carve((size_t)nsplit * ntiles * kPB * kPB * sizeof(T));
   const size_t o_bp = carve((size_t)nsplit * NC * kPB * sizeof(double));
   const size_t o_r = carve((size_t)N * sizeof(T));
+  const size_t o_wv = carve(noise_kind == BLR_NOISE_DIAGONAL ? (size_t)N * sizeof(T) : 0);  // 1 / s_n for the Gram launch
   const size_t o_q = carve((size_t)gridc * sizeof(double));
   const size_t o_l = carve((size_t)gridc * sizeof(double));
   int rc = ensure_ws(h, off);
@@ -1057,12 +1058,13 @@ int gram_stats(blr_handle* h, int layout, int64_t D64, int64_t N64, const T* X, 
   T* Gpart = reinterpret_cast<T*>(ws + o_gp);
   double* bpart = reinterpret_cast<double*>(ws + o_bp);
   T* rvec = reinterpret_cast<T*>(ws + o_r);
+  T* wvec = noise_kind == BLR_NOISE_DIAGONAL ? reinterpret_cast<T*>(ws + o_wv) : nullptr;
   double* qpart = reinterpret_cast<double*>(ws + o_q);
   double* lpart = reinterpret_cast<double*>(ws + o_l);
   HIP_TRY(h, hipMemsetAsync(bpart, 0, (size_t)nsplit * NC * kPB * sizeof(double), h->stream));
   {
     ColstatsArgs<T> c{};
-    c.X = X; c.ldx = ldx; c.y = y; c.s = s; c.mw = mw; c.r = rvec; c.qpart = qpart; c.lpart = lpart;
+    c.X = X; c.ldx = ldx; c.y = y; c.s = s; c.mw = mw; c.r = rvec; c.w = wvec; c.qpart = qpart; c.lpart = lpart;
     c.layout = layout; c.noise_kind = noise_kind; c.D = D; c.N = N;
     size_t ldsb = (((size_t)D * sizeof(T) + 15) & ~(size_t)15) + 64;
     hipLaunchKernelGGL(colstats_kernel<T>, dim3(gridc), dim3(kThreads), ldsb, h->stream, c);
@@ -1074,7 +1076,7 @@ int gram_stats(blr_handle* h, int layout, int64_t D64, int64_t N64, const T* X, 
     GramTileArgs<T> g{};
     g.X = X; g.ldx = ldx; g.layout = layout;
     g.use_dma = (layout == LAYOUT_COLVECS && ((uintptr_t)X % 16 == 0) && ((ldx * (int64_t)sizeof(T)) % 16 == 0)) ? 1 : 0;
-    g.s = s; g.noise_kind = noise_kind; g.r = rvec;
+    g.s = s; g.noise_kind = noise_kind; g.r = rvec; g.wpre = wvec;
     g.D = D; g.n_begin = 0; g.n_end = N; g.nsplit = nsplit;
     g.tile_i0 = 0; g.tile_j0 = 0; g.tri = 1; g.ntiles = ntiles; g.nblocks = NC;
     g.Gpart = Gpart; g.bpart = bpart; g.mode_out = 0; g.xcd_swizzle = nsplit > 1 ? 1 : 0;
