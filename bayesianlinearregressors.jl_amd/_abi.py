@@ -50,6 +50,7 @@ _SIGS = {
     "blr_reset_stream": ([_H], _int),
     "blr_set_async": ([_H, _int], _int),
     "blr_synchronize": ([_H], _int),
+    "blr_set_option": ([_H, C.c_char_p, C.c_char_p], _int),
     "blr_device_alloc": ([_H, C.c_size_t, C.POINTER(_vp)], _int),
     "blr_device_free": ([_H, _vp], _int),
     "blr_memcpy_h2d": ([_H, _vp, _vp, C.c_size_t], _int),
@@ -204,6 +205,10 @@ class Handle:
 
     def synchronize(self):
         self.check(self.lib.blr_synchronize(self._h))
+
+    def set_option(self, key, value=None):
+        """Run-time switch of this handle (include/blr_mi355x.h blr_set_option); value None = the built-in default."""
+        self.check(self.lib.blr_set_option(self._h, str(key).encode(), None if value is None else str(value).encode()))
 
     def timer_start(self):
         self.check(self.lib.blr_timer_start(self._h))

@@ -28,7 +28,58 @@
 
 using namespace blr;
 
+// Run-time switches (A/B experiments and tests; the defaults are the measured best).  Read from the environment ONCE, when the
+// handle is created (BLR_MI355X_<KEY>), and settable per handle with blr_set_option: no getenv on any launch path.
+struct BlrOptions {
+  bool no_ldsdma = false, no_wave_kernel = false, no_gram_ring = false, no_diag_split = false, no_xcd_swizzle = false,
+       no_mfma_project = false, plan_debug = false;
+  int wave_split = 0;     // waves per regressor of the wave kernel: 0 = router, else 1 | 2 | 4
+  int chain_batch = 0;    // regressors per shared launch at D > 128: 0 = as many as the workspace holds
+  long chain_ws_mb = 0;   // workspace bound of such a group in MiB: 0 = kChainWorkspace
+  int sweep = 0;          // blr_update_factor_* route: 0 = router, 1 = always the Givens sweep, 2 = never
+  int gs_fields = 0, gs_so = 0, gs_sd = 0, gs_nl = 0;  // GRAM_SPLITS = "off-diagonal,diagonal[,nlong]" (gs_fields = numbers parsed)
+  // -> 0, or -1 for an unknown key / malformed value.  value NULL or "" = the built-in default
+  int set(const char* key, const char* value) {
+    if (!key) return -1;
+    if (!strncmp(key, "BLR_MI355X_", 11)) key += 11;
+    const bool on = value && *value;
+    auto flag = [&](bool& f) { f = on; return 0; };
+    if (!strcmp(key, "NO_LDSDMA")) return flag(no_ldsdma);
+    if (!strcmp(key, "NO_WAVE_KERNEL")) return flag(no_wave_kernel);
+    if (!strcmp(key, "NO_GRAM_RING")) return flag(no_gram_ring);
+    if (!strcmp(key, "NO_DIAG_SPLIT")) return flag(no_diag_split);
+    if (!strcmp(key, "NO_XCD_SWIZZLE")) return flag(no_xcd_swizzle);
+    if (!strcmp(key, "NO_MFMA_PROJECT")) return flag(no_mfma_project);
+    if (!strcmp(key, "PLAN_DEBUG")) return flag(plan_debug);
+    if (!strcmp(key, "WAVE_SPLIT")) {
+      const int v = on ? atoi(value) : 0;
+      wave_split = (v == 1 || v == 2 || v == 4) ? v : 0;
+      return (!on || wave_split) ? 0 : -1;
+    }
+    if (!strcmp(key, "CHAIN_BATCH")) { chain_batch = on ? std::max(1, atoi(value)) : 0; return 0; }
+    if (!strcmp(key, "CHAIN_WS_MB")) { chain_ws_mb = on ? std::max(1L, atol(value)) : 0; return 0; }
+    if (!strcmp(key, "SWEEP")) {
+      sweep = !on ? 0 : (!strcmp(value, "always") ? 1 : (!strcmp(value, "never") ? 2 : 0));
+      return (!on || sweep || !strcmp(value, "auto")) ? 0 : -1;
+    }
+    if (!strcmp(key, "GRAM_SPLITS")) {
+      gs_fields = gs_so = gs_sd = gs_nl = 0;
+      if (on) gs_fields = sscanf(value, "%d,%d,%d", &gs_so, &gs_sd, &gs_nl);
+      return (!on || gs_fields >= 2) ? 0 : -1;
+    }
+    return -1;
+  }
+  void from_environment() {
+    for (const char* k : {"NO_LDSDMA", "NO_WAVE_KERNEL", "NO_GRAM_RING", "NO_DIAG_SPLIT", "NO_XCD_SWIZZLE", "NO_MFMA_PROJECT", "PLAN_DEBUG",
+                          "WAVE_SPLIT", "CHAIN_BATCH", "CHAIN_WS_MB", "SWEEP", "GRAM_SPLITS"}) {
+      const std::string name = std::string("BLR_MI355X_") + k;
+      if (const char* v = getenv(name.c_str())) (void)set(k, *v ? v : "1");  // (an empty variable still switches a flag on)
+    }
+  }
+};
+
 struct blr_handle {
+  BlrOptions opt;
   int device = 0;
   int cus = 256;  // compute units of the device (MI355X: 256; a partitioned part reports its share)
   hipStream_t own_stream = nullptr;
@@ -44,7 +95,8 @@ struct blr_handle {
   // wavefront back substitution (D > 128): tagged exchange buffer, start-order ticket counter, launch epoch
   unsigned long long* xchg = nullptr;
   size_t xchg_bytes = 0;
-  unsigned* ticket = nullptr;     // [0], [2], [3]: wavefront solve (tickets, done, launch count); [16 + g]: arrivals of panel_chain_kernel
+  unsigned* ticket = nullptr;     // [0], [2], [3]: wavefront solve (tickets, done, launch count); [16 + 128 bank + g]: arrivals of panel_chain_kernel
+  unsigned panel_launches = 0;    // parity = the bank of arrival words the next panel launch counts in (it clears the other one)
   // kernels whose dynamic-LDS limit has been raised on this handle's device (hipFuncSetAttribute is per device and costs a
   // driver call: once per (handle, kernel), not once per launch -- it sat on the launch path of the 5 us wave kernel)
   std::unordered_map<const void*, size_t> lds_limit;
@@ -178,8 +230,8 @@ int ensure_ws(blr_handle* h, size_t bytes) {
 // epochs that are never reused, so a stale granule can never carry the current tag.
 int ensure_xchg(blr_handle* h, size_t bytes) {
   if (!h->ticket) {
-    HIP_TRY(h, hipMalloc((void**)&h->ticket, 1024));
-    HIP_TRY(h, hipMemsetAsync(h->ticket, 0, 1024, h->stream));
+    HIP_TRY(h, hipMalloc((void**)&h->ticket, 2048));
+    HIP_TRY(h, hipMemsetAsync(h->ticket, 0, 2048, h->stream));
   }
   if (bytes <= h->xchg_bytes) return 0;
   if (h->xchg) {
@@ -243,8 +295,7 @@ template <typename T, int NB>
 int launch_fused_small_mode(blr_handle* h, const PosteriorArgs<T>& a) {
   if (a.layout == BLR_LAYOUT_ROWVECS) return launch_fused_small<T, NB, 1>(h, a);
   if (a.vec_ok) {
-    static const bool force_regs = getenv("BLR_MI355X_NO_LDSDMA") != nullptr;  // A/B experiments only
-    if (force_regs) return launch_fused_small<T, NB, 3>(h, a);
+    if (h->opt.no_ldsdma) return launch_fused_small<T, NB, 3>(h, a);  // A/B experiments only
     return launch_fused_small<T, NB, 4>(h, a);
   }
   return launch_fused_small<T, NB, 0>(h, a);
@@ -254,7 +305,7 @@ int launch_fused_small_mode(blr_handle* h, const PosteriorArgs<T>& a) {
 template <typename T, int NB, int NW>
 int launch_fused_wave_nw(blr_handle* h, const PosteriorArgs<T>& a) {
   using C = WaveCfg<T, NB>;
-  const int grid = (int)std::min<int64_t>(a.B, 256 * 8 / NW);  // 8 waves per CU (18.6 KB of LDS each)
+  const int grid = (int)std::min<int64_t>(a.B, (int64_t)h->cus * 8 / NW);  // 8 waves per CU (18.6 KB of LDS each)
   if (NW * C::LDS_BYTES > 64 * 1024) {
     int rc = set_lds_once(h, reinterpret_cast<const void*>(fused_wave_kernel<T, NB, NW>), (size_t)NW * C::LDS_BYTES);
     if (rc) return rc;
@@ -268,10 +319,7 @@ int launch_fused_wave_nw(blr_handle* h, const PosteriorArgs<T>& a) {
 template <typename T, int NB>
 int launch_fused_wave(blr_handle* h, const PosteriorArgs<T>& a) {
   int nw = a.B >= 2048 ? 1 : (a.B >= 1024 ? 2 : 4);
-  if (const char* e = getenv("BLR_MI355X_WAVE_SPLIT")) {
-    const int v = atoi(e);
-    if (v == 1 || v == 2 || v == 4) nw = v;
-  }
+  if (h->opt.wave_split) nw = h->opt.wave_split;
   if (nw == 1) return launch_fused_wave_nw<T, NB, 1>(h, a);
   if (nw == 2) return launch_fused_wave_nw<T, NB, 2>(h, a);
   return launch_fused_wave_nw<T, NB, 4>(h, a);
@@ -280,8 +328,7 @@ int launch_fused_wave(blr_handle* h, const PosteriorArgs<T>& a) {
 template <typename T>
 int dispatch_fused_small(blr_handle* h, const PosteriorArgs<T>& a) {
   int NB = (a.D + 15) / 16;
-  static const bool no_wave = getenv("BLR_MI355X_NO_WAVE_KERNEL") != nullptr;
-  if (!no_wave && a.layout == BLR_LAYOUT_COLVECS && a.vec_ok && a.D == 16 * NB &&
+  if (!h->opt.no_wave_kernel && a.layout == BLR_LAYOUT_COLVECS && a.vec_ok && a.D == 16 * NB &&
       (3 * a.ldx + 64) * (int64_t)sizeof(T) < ((int64_t)1 << 31)) {
     if (NB == 4) return launch_fused_wave<T, 4>(h, a);
     if constexpr (sizeof(T) == 8) {
@@ -302,6 +349,7 @@ int dispatch_fused_small(blr_handle* h, const PosteriorArgs<T>& a) {
 }
 
 // ---- large-D path (D > 128): multi-kernel pipeline of blr_large.hpp ---------------------------------------------
+constexpr int kChainBatchMaxWords = 128;  // = kChainBatchMax below
 template <typename T>
 int set_lds(blr_handle* h, const void* kern, size_t bytes) { return set_lds_once(h, kern, bytes); }
 
@@ -315,15 +363,24 @@ int launch_panel(blr_handle* h, T* M, int64_t ld, int p, int nrows_total, int nb
   int rc;
   if ((rc = set_lds<T>(h, reinterpret_cast<const void*>(panel_chain_kernel<T, NW, ER>), CC::LDS_BYTES))) return rc;
   const int nwg = std::max(1, (nbelow + ER - 1) / ER);
-  // arrival counters (one per factorisation of the launch): count up to nwg during the launch, zeroed again by workgroup 0
-  // on its way out (replayable as it is)
+  // arrival counters (one per factorisation of the launch): count up to nwg during the launch.  Two banks, used alternately
+  // by the launches of this handle (= of its stream, in order); a launch clears the bank of its successor (blr_panel.hpp).
+  // Forward progress of the wait inside the kernel: workgroup 0 waits for workgroups of ITS OWN launch only, every one of
+  // which arrives after its loads without waiting for anybody -- so it holds for any dispatch order as long as each
+  // workgroup is eventually scheduled, which a grid of at most one workgroup per CU (callers: G * nwg <= cus, or ER = 32
+  // and D <= 8192) always is; beyond that the bounded spin reports -999 instead of a wrong factor.
+  static_assert(kChainBatchMaxWords == kPanelArriveWords, "one arrival word per factorisation of a group");
+  unsigned* const bank = h->ticket + 16 + kPanelArriveWords * (h->panel_launches & 1u);
+  unsigned* const next = h->ticket + 16 + kPanelArriveWords * ((h->panel_launches & 1u) ^ 1u);
+  ++h->panel_launches;
   hipLaunchKernelGGL((panel_chain_kernel<T, NW, ER>), dim3(nwg, G), dim3(64 * NW), CC::LDS_BYTES, h->stream, M, ld, p * kPB, nrows_total,
-                     info_dev, h->ticket + 16, (unsigned)nwg, batch_stride, info_stride);
+                     info_dev, bank, (unsigned)nwg, batch_stride, info_stride, next);
+  HIP_TRY(h, hipGetLastError());
   return 0;
 }
 
 constexpr size_t kChainWorkspace = (size_t)8 << 30;  // ... as long as their workspaces fit this many bytes
-constexpr int kChainBatchMax = 128;  // factorisations that step through their panels in shared launches (arrival words ticket[16..143])
+constexpr int kChainBatchMax = kChainBatchMaxWords;  // factorisations that step through their panels in shared launches (one arrival word each per bank)
 
 // Blocked Cholesky of G independent matrices M + g * batch_stride (status words info_dev + g * info_stride), panel by panel,
 // every step ONE launch over all of them.
@@ -349,10 +406,11 @@ int chol_large(blr_handle* h, T* M, int64_t ld, int DP, int nrows_total, int32_t
       const int ntri = 2 * m;                                   // 64-row sub-blocks of the remaining triangle
       const int nextra = (nrows_total - DP) / TrailCfg<T>::SB;  // rhs rows below the square part
       const int ntiles = ntri * (ntri + 1) / 2 + nextra * ntri;
-      const int slots = 256 * (TrailCfg<T>::LDS_BYTES <= 80 * 1024 ? 2 : 1);  // sub-tiles the chip holds at once
+      const int slots = h->cus * (TrailCfg<T>::LDS_BYTES <= 80 * 1024 ? 2 : 1);  // sub-tiles the chip holds at once
       const int gx = std::min(ntiles, std::max(1, slots / G));
       hipLaunchKernelGGL(trail_update_kernel<T>, dim3(gx, G), dim3(kThreads), TrailCfg<T>::LDS_BYTES, h->stream, M, ld,
                          p, ntri, (p + 1) * kPB, DP, (const int32_t*)info_dev, ntiles, batch_stride, info_stride);
+      HIP_TRY(h, hipGetLastError());
     }
   }
   HIP_TRY(h, hipGetLastError());
@@ -433,7 +491,7 @@ int posterior_large_group(blr_handle* h, const PosteriorArgs<T>& a, int64_t reg0
   double best = 1e300;
   for (int sp = 1; sp <= max_split; ++sp) {
     const int wgs = ntiles * sp * G;  // (the whole group's tiles are one launch)
-    const int slots = 256 * (sizeof(T) == 4 ? BLR_GRAM_WGS : 2);
+    const int slots = h->cus * (sizeof(T) == 4 ? BLR_GRAM_WGS : 2);
     const int rounds = (wgs + slots - 1) / slots;
     const int cols_sp = ((N + sp - 1) / sp + nstage_cols - 1) / nstage_cols * nstage_cols;
     const double cost = (double)rounds * (cols_sp + 256.0);
@@ -449,15 +507,14 @@ int posterior_large_group(blr_handle* h, const PosteriorArgs<T>& a, int64_t reg0
   int nsplit_diag = 0;  // 0: one factor for all tiles
   int nlong = 0;        // strictly lower tiles with one column range less (multi-round launches)
   {
-    const int slots = 256 * (sizeof(T) == 4 ? BLR_GRAM_WGS : 2);
+    const int slots = h->cus * (sizeof(T) == 4 ? BLR_GRAM_WGS : 2);
     // (only where the diagonal tiles will go through the ring loop: f32, LDS-DMA staging, whole row blocks)
     const T* X0 = a.X + reg0 * a.strideX;
     const bool dealt = sizeof(T) == 4 && a.layout == LAYOUT_COLVECS && ((uintptr_t)X0 % 16 == 0) &&
-                       ((a.ldx * (int64_t)sizeof(T)) % 16 == 0) && getenv("BLR_MI355X_NO_GRAM_RING") == nullptr &&
-                       getenv("BLR_MI355X_NO_DIAG_SPLIT") == nullptr && D % kPB == 0 && NC >= 2 && (ntiles * nsplit * G <= slots || getenv("BLR_MI355X_GRAM_SPLITS") != nullptr);
-    if (const char* e = getenv("BLR_MI355X_GRAM_SPLITS")) {  // "off-diagonal,diagonal" (equal: one factor): measurements only
-      int so = 0, sd = 0, nl = 0;
-      const int nf = sscanf(e, "%d,%d,%d", &so, &sd, &nl);
+                       ((a.ldx * (int64_t)sizeof(T)) % 16 == 0) && !h->opt.no_gram_ring &&
+                       !h->opt.no_diag_split && D % kPB == 0 && NC >= 2 && (ntiles * nsplit * G <= slots || h->opt.gs_fields >= 2);
+    if (h->opt.gs_fields >= 2) {  // "off-diagonal,diagonal" (equal: one factor): measurements only
+      const int so = h->opt.gs_so, sd = h->opt.gs_sd, nl = h->opt.gs_nl, nf = h->opt.gs_fields;
       if (nf >= 2 && so >= 1 && sd >= 1 && sd <= so && so <= max_split) {
         nsplit = so;
         nsplit_diag = ((sd < so || nf == 3) && dealt) ? sd : 0;
@@ -478,15 +535,15 @@ int posterior_large_group(blr_handle* h, const PosteriorArgs<T>& a, int64_t reg0
     }
     // multi-round launch of one regressor: three kinds of work items (plan_gram_rounds)
     const bool ring_ok = sizeof(T) == 4 && a.layout == LAYOUT_COLVECS && ((uintptr_t)X0 % 16 == 0) &&
-                         ((a.ldx * (int64_t)sizeof(T)) % 16 == 0) && getenv("BLR_MI355X_NO_GRAM_RING") == nullptr &&
-                         getenv("BLR_MI355X_NO_DIAG_SPLIT") == nullptr && getenv("BLR_MI355X_GRAM_SPLITS") == nullptr && D % kPB == 0 && NC >= 2;
+                         ((a.ldx * (int64_t)sizeof(T)) % 16 == 0) && !h->opt.no_gram_ring &&
+                         !h->opt.no_diag_split && h->opt.gs_fields < 2 && D % kPB == 0 && NC >= 2;
     if (ring_ok && G == 1 && nsplit_diag == 0 && ntiles * nsplit > slots && nsplit >= 2) {
       const std::array<int, 3> key{NC, N, slots};
       auto it = h->gram_plans.find(key);
       if (it == h->gram_plans.end()) {
         const GramPlan pl = plan_gram_rounds(ntiles - NC, NC, nsplit, N, nstage_cols, slots, max_split, kDiagCost / 16.0);
         it = h->gram_plans.emplace(key, std::array<int, 3>{pl.so, pl.sd, pl.nlong}).first;
-        if (getenv("BLR_MI355X_PLAN_DEBUG"))
+        if (h->opt.plan_debug)
           fprintf(stderr, "blr: Gram plan for %d row blocks, N = %d: one factor %d -> ranges %d (off-diagonal, %d tiles with %d) / %d (diagonal), "
                           "modelled makespan %.0f column units\n", NC, N, nsplit, pl.so, pl.nlong, pl.so - 1, pl.sd, pl.makespan);
       }
@@ -515,7 +572,7 @@ int posterior_large_group(blr_handle* h, const PosteriorArgs<T>& a, int64_t reg0
   const size_t o_sc = carve(64);
   const size_t per = off;  // one regressor's workspace (a multiple of 256 bytes)
   size_t ws_cap = kChainWorkspace;
-  if (const char* e = getenv("BLR_MI355X_CHAIN_WS_MB")) ws_cap = (size_t)std::max(1L, atol(e)) << 20;  // tests: small groups
+  if (h->opt.chain_ws_mb > 0) ws_cap = (size_t)h->opt.chain_ws_mb << 20;  // tests: small groups
   G = (int)std::max<size_t>(1, std::min<size_t>((size_t)G, ws_cap / per));
   int rc;
   for (;;) {  // (a device too full for the whole group's workspace: smaller groups, down to one regressor at a time)
@@ -591,12 +648,12 @@ int posterior_large_group(blr_handle* h, const PosteriorArgs<T>& a, int64_t reg0
   if ((rc = set_lds<T>(h, reinterpret_cast<const void*>(gram_tile_kernel<T>), LC::LDS_BYTES))) return rc;
   GramTileArgs<T> g{};
   g.X = X; g.ldx = a.ldx; g.layout = a.layout;
-  static const bool no_ring = getenv("BLR_MI355X_NO_GRAM_RING") != nullptr;  // A/B experiments only
+  const bool no_ring = h->opt.no_gram_ring;  // A/B experiments only
   g.use_dma = (a.layout == LAYOUT_COLVECS && ((uintptr_t)X % 16 == 0) && ((a.ldx * (int64_t)sizeof(T)) % 16 == 0)) ? (no_ring ? 2 : 1) : 0;
   g.s = s; g.noise_kind = a.noise_kind; g.r = rvec; g.wpre = wvec;
   g.D = D; g.n_begin = 0; g.n_end = N; g.nblocks = NC; g.bpart = bpart; g.mode_out = 0;
   g.grp_X = a.strideX; g.grp_s = a.strides; g.grp_ws = wsb;
-  static const bool no_swizzle = getenv("BLR_MI355X_NO_XCD_SWIZZLE") != nullptr;
+  const bool no_swizzle = h->opt.no_xcd_swizzle;
   ReduceArgs<T> r{};
   r.bpart = bpart; r.nblocks = NC;
   r.Lw = Lw; r.ldl = a.ldl; r.prior_kind = a.prior_kind; r.D = D; r.DP = DP; r.Abar = Abar; r.lda = lda;
@@ -646,7 +703,8 @@ int posterior_large_group(blr_handle* h, const PosteriorArgs<T>& a, int64_t reg0
     if (!evidence_only) {
       dim3 grid((DP + 31) / 32, (DP + 31) / 32, G);
       hipLaunchKernelGGL(transpose_out_kernel<T>, grid, dim3(kThreads), 0, h->stream, (const T*)Abar, lda, DP, Tfull,
-                         (int64_t)DP, a.T_post ? a.T_post + reg0 * a.strideT : (T*)nullptr, a.ldt, D, (int64_t)(per / sizeof(T)), a.strideT);
+                         (int64_t)DP, a.T_post ? a.T_post + reg0 * a.strideT : (T*)nullptr, a.ldt, D, (int64_t)(per / sizeof(T)), a.strideT,
+                         (const int32_t*)info_prior, (const unsigned*)info_noise, (const int32_t*)info_chol, (int64_t)per);
     }
     WaveSolveArgs<T> b{};
     b.Tf = Tfull; b.ldtf = DP; b.D = D; b.DP = DP;
@@ -678,7 +736,7 @@ int dispatch_posterior(blr_handle* h, const PosteriorArgs<T>& a) {
   // (the more the better wherever measured -- D = 256 .. 4096, groups of up to 128, tools/chain_batch_scan.sh -- so the bound is
   // the workspace: kChainWorkspace)
   int gmax = kChainBatchMax;
-  if (const char* e = getenv("BLR_MI355X_CHAIN_BATCH")) gmax = std::max(1, std::min(kChainBatchMax, atoi(e)));  // measurements only
+  if (h->opt.chain_batch > 0) gmax = std::min(kChainBatchMax, h->opt.chain_batch);  // measurements only
   if ((a.strideX * (int64_t)sizeof(T)) % 16 != 0) gmax = 1;
   {  // even groups: 129 regressors run as 65 + 64, not 128 + 1
     const int64_t ngroups = std::max<int64_t>(1, (a.B + gmax - 1) / gmax);
@@ -1142,7 +1200,8 @@ int posterior_from_stats(blr_handle* h, int64_t D64, int64_t N_total, T* stats, 
   {
     dim3 grid((DP + 31) / 32, (DP + 31) / 32);
     hipLaunchKernelGGL(transpose_out_kernel<T>, grid, dim3(kThreads), 0, h->stream, (const T*)stats, lds, DP, Tfull, (int64_t)DP,
-                       T_post, ldt, D);
+                       T_post, ldt, D, (int64_t)0, (int64_t)0, (const int32_t*)nullptr, (const unsigned*)nullptr, (const int32_t*)info_chol,
+                       (int64_t)0);  // (info_chol carries the prior's status too)
   }
   {
     WaveSolveArgs<T> b{};
@@ -1747,7 +1806,7 @@ template <typename T>
 void launch_project(blr_handle* h, int layout, int64_t D, int64_t N, int64_t S, const T* X_d, int64_t ldx, const T* W_d, int64_t ldw,
                     const T* s_d, int noise_kind, const T* Z2_d, int64_t ldz2, T* Y_d, int64_t ldy) {
   constexpr int kVec = Mfma<T>::VEC;
-  static const bool no_mfma_proj = getenv("BLR_MI355X_NO_MFMA_PROJECT") != nullptr;  // A/B experiments only
+  const bool no_mfma_proj = h->opt.no_mfma_project;  // A/B experiments only
   if (!no_mfma_proj && layout == BLR_LAYOUT_COLVECS && D % kVec == 0 && aligned16(X_d, ldx, 0) && aligned16(W_d, ldw, 0)) {
     // tall-skinny GEMM on the matrix cores
     using PC = ProjCfg<T>;
@@ -2315,11 +2374,11 @@ int update_factor(blr_handle* h, int memspace, int layout, int64_t B, int64_t D,
   // and measured in round 3: 92 / 115 / 144 / 205 us at k = 1 / 3 / 8 / 16 against 90 us -- the k + 1-term dot products and
   // three reciprocal chains per step cost more than the rotations they replace -- and was not kept.
   // BLR_MI355X_SWEEP=always / never overrides (tests exercise both routes on the same inputs).
-  const char* mode = getenv("BLR_MI355X_SWEEP");
+  const int mode = h->opt.sweep;
   const bool can_sweep = D >= 1 && D <= kSweepMaxD && k >= 0 && k <= kSweepMaxK;
   bool sweep = can_sweep && k <= 1 && (D > 64 || B < 256);
-  if (mode && !strcmp(mode, "always")) sweep = can_sweep;
-  if (mode && !strcmp(mode, "never")) sweep = false;
+  if (mode == 1) sweep = can_sweep;
+  if (mode == 2) sweep = false;
   if (!sweep) {
     // k-independent cost: the SAME state re-factored in place, the old factor entering as D pseudo-observations
     // (reads of T and mw complete before the first write in both the fused and the large-D path)
@@ -2414,6 +2473,7 @@ int blr_create(int device, blr_handle** out) {
     return -(1000 + (int)e);
   }
   h->stream = h->own_stream;
+  h->opt.from_environment();  // the only getenv calls of the library
   int cus = 0;
   if (hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, device) == hipSuccess && cus > 0) h->cus = cus;
   *out = h;
@@ -2437,6 +2497,14 @@ int blr_destroy(blr_handle* h) {
 }
 
 const char* blr_last_error(blr_handle* h) { return h ? h->err.c_str() : "null handle"; }
+
+int blr_set_option(blr_handle* h, const char* key, const char* value) {
+  if (!h) return -1;
+  h->err.clear();
+  if (h->opt.set(key, value) != 0) return bad_arg(h, key ? 3 : 2, "unknown option or malformed value");
+  h->gram_plans.clear();  // (cached launch plans were made under the old switches)
+  return 0;
+}
 
 int blr_set_stream(blr_handle* h, void* hip_stream) {
   if (!h) return -1;

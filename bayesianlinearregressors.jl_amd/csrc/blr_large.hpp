@@ -1698,11 +1698,23 @@ __global__ __launch_bounds__(kThreads) void prior_copy_kernel(const T* Lw, int64
 template <typename T>
 __global__ __launch_bounds__(kThreads) void transpose_out_kernel(const T* Lf, int64_t ld, int D, T* Tout, int64_t ldt,
                                                                  T* Tout2, int64_t ldt2, int D2, int64_t zstride = 0,
-                                                                 int64_t zstride2 = 0) {
+                                                                 int64_t zstride2 = 0, const int32_t* st_prior = nullptr,
+                                                                 const unsigned* st_noise = nullptr, const int32_t* st_chol = nullptr,
+                                                                 int64_t st_stride = 0) {
   __shared__ T tile[32][33];
   Lf += (int64_t)blockIdx.z * zstride;  // blockIdx.z: regressor of a group (Lf and Tout in per-regressor workspaces)
   Tout += (int64_t)blockIdx.z * zstride;
   if (Tout2) Tout2 += (int64_t)blockIdx.z * zstride2;
+  // the CALLER's factor is written only for a regressor whose update succeeded (status words of its workspace, byte stride
+  // st_stride): a failed update leaves mw_post / T_post as they were, at every D (include/blr_mi355x.h; the in-place state of
+  // blr_update_factor_* survives a bad batch)
+  if (Tout2) {
+    const int64_t sb = (int64_t)blockIdx.z * st_stride;
+    const int32_t* p0 = ws_shift(st_prior, sb);
+    const unsigned* p1 = ws_shift(st_noise, sb);
+    const int32_t* p2 = ws_shift(st_chol, sb);
+    if ((p0 && *p0 != 0) || (p1 && *p1 != 0xFFFFFFFFu) || (p2 && *p2 != 0)) Tout2 = nullptr;
+  }
   const int bx = blockIdx.x * 32, by = blockIdx.y * 32;  // bx: row block of L, by: col block of L
   const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;
   for (int k = ty; k < 32; k += 8) {

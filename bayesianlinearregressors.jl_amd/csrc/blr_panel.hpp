@@ -33,6 +33,9 @@
 
 namespace blr {
 
+// counters per bank of panel_chain_kernel's arrival words (one per factorisation of a grouped launch; blr_abi.hip kChainBatchMax)
+constexpr int kPanelArriveWords = 128;
+
 template <typename T, int NW_, int ER_ = BLR_PANEL_ER, int NBT_ = 8>
 struct ChainCfg {
   static constexpr int NW = NW_;             // waves per workgroup: wave 0 = chain wave
@@ -433,7 +436,7 @@ template <typename T, int NW, int ER = BLR_PANEL_ER, int NBT = 8>
 __global__ __launch_bounds__(64 * NW, 1) void panel_chain_kernel(T* Abar, int64_t lda, int col0 /* first column of the panel */,
                                                                  int nrows_total, int32_t* info, unsigned* arrive,
                                                                  unsigned arrive_target, int64_t batch_stride = 0,
-                                                                 int info_stride = 0) {
+                                                                 int info_stride = 0, unsigned* arrive_next = nullptr) {
   using C = ChainCfg<T, NW, ER, NBT>;
   // blockIdx.y: one of several independent factorisations that step through their panels together (regressors of a batch
   // at D > 128: every launch of the chain is latency, not throughput, so G matrices cost little more than one)
@@ -463,8 +466,14 @@ __global__ __launch_bounds__(64 * NW, 1) void panel_chain_kernel(T* Abar, int64_
   const int r0 = col0 + C::W + blockIdx.x * C::ER;      // first row of this workgroup's slice of X
   const int nr = max(0, min(C::ER, nrows_total - r0));  // 0 (nothing below the block) or ER: callers pad to 64 rows
   T* const Xg = Abar + (int64_t)col0 * lda + r0;        // X(row, col) at Xg[col * lda + row]
-  // `arrive` counts the workgroups that have read A_pp, 0 .. arrive_target = gridDim.x within a launch; workgroup 0 zeroes it
-  // again on its way out, so the launch can be replayed from a captured graph as it is.
+  // `arrive` counts the workgroups that have read A_pp, 0 .. arrive_target = gridDim.x within a launch.  Nobody re-arms it:
+  // consecutive launches of a stream alternate between two banks of kPanelArriveWords counters, and every launch clears the
+  // bank of its SUCCESSOR (`arrive_next`; all 128 words, whatever the group sizes) -- that bank's last user has completed, with
+  // every increment it was ever going to make, before this launch started.  A wait that times out (bounded spins: a logic
+  // error upstream must not hang the GPU) therefore cannot leave a pre-advanced counter behind; it reports status -999 and
+  // the block is not written back.
+  if (arrive_next != nullptr && blockIdx.x == 0 && blockIdx.y == 0 && threadIdx.x < kPanelArriveWords)
+    __hip_atomic_store(arrive_next + threadIdx.x, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
   if (*info != 0) return;  // an earlier panel already failed (uniform over the launch): nothing to do, nobody counts or waits
   if (tid == 0) INFO[0] = 0;
   if (tid < 256) ZERO[tid] = T(0);
@@ -645,6 +654,7 @@ __global__ __launch_bounds__(64 * NW, 1) void panel_chain_kernel(T* Abar, int64_
     // not before every workgroup has read A_pp: the arrival counter is read behind the barrier of step 1 and needed a
     // trailing update later
     unsigned arrived_u = arrive_target;
+    bool timed_out = false;  // (wave-uniform)
 #pragma unroll 1
     for (int J = 0; J < NBT; ++J) {
       const int par = J & 1;
@@ -712,11 +722,15 @@ __global__ __launch_bounds__(64 * NW, 1) void panel_chain_kernel(T* Abar, int64_
           while ((int)(a - arrive_target) < 0) {  // somebody has not read A_pp yet (a workgroup that started late)
             __builtin_amdgcn_s_sleep(8);
             a = __hip_atomic_load(arrive, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            if (++spins > 20000000LL) break;  // a logic error upstream must not hang the GPU
+            if (++spins > 20000000LL) {  // a logic error upstream must not hang the GPU -- and must not pass for a result
+              timed_out = true;
+              if (lane == 0) __hip_atomic_store(info, -999, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+              break;
+            }
           }
         }
         const T* const pimg = IMG + (par ^ 1) * C::IMG;
-        for (int R = J - 1 + u; R < NB1; R += C::NU) {
+        for (int R = J - 1 + u; R < NB1 && !timed_out; R += C::NU) {
           const acc4 v = tile_from_image<T>(pimg + R * 256, lane);
           tile_to_global<T>(blk, lda, 16 * (R + 1), 16 * (J - 1), v, lane);
         }
@@ -738,18 +752,21 @@ __global__ __launch_bounds__(64 * NW, 1) void panel_chain_kernel(T* Abar, int64_
   const int bad = INFO[0];
   if (blockIdx.x != 0) return;
   if (tid == 0) {
+    int late = 0;
     if ((int)(arrived - arrive_target) < 0) {
       long long spins = 0;
       while ((int)(__hip_atomic_load(arrive, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) - arrive_target) < 0) {
         __builtin_amdgcn_s_sleep(8);
-        if (++spins > 20000000LL) break;  // a logic error upstream must not hang the GPU
+        if (++spins > 20000000LL) { late = 1; break; }  // (see the head of the kernel)
       }
     }
-    __hip_atomic_store(arrive, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);  // everybody has arrived: re-arm
-    if (bad != 0) *info = col0 + bad;
+    if (late) __hip_atomic_store(info, -999, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    else if (bad != 0) *info = col0 + bad;
+    INFO[1] = late;
   }
   if (bad != 0) return;
   __syncthreads();  // B3
+  if (INFO[1] != 0) return;  // somebody may still be reading A_pp: leave it alone
   // lower triangles, from the rows the chain wave left in LDIAG, one tile per wave
   for (int K = wave; K < NBT; K += NW) {
 #pragma unroll

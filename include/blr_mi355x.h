@@ -69,6 +69,13 @@ int blr_set_stream(blr_handle* h, void* hip_stream); /* run on the caller's hipS
 int blr_reset_stream(blr_handle* h);              /* back to the handle's own (non-blocking) stream      */
 int blr_set_async(blr_handle* h, int async);      /* 1: DEVICE-memspace calls return after enqueue       */
 int blr_synchronize(blr_handle* h);
+/* Run-time switches of the handle (A/B measurements and tests; the defaults are the measured best).  `key` is one of NO_LDSDMA,
+ * NO_WAVE_KERNEL, NO_GRAM_RING, NO_DIAG_SPLIT, NO_XCD_SWIZZLE, NO_MFMA_PROJECT, PLAN_DEBUG (flags: any non-empty value = on),
+ * WAVE_SPLIT = 1|2|4, CHAIN_BATCH = 1..128, CHAIN_WS_MB, SWEEP = always|never|auto, GRAM_SPLITS = "o,d[,nlong]" (README.md);
+ * a "BLR_MI355X_" prefix is accepted.  value NULL or "" restores the built-in default.  The environment variables
+ * BLR_MI355X_<KEY> are read ONCE, by blr_create -- no entry point reads the environment.  -> 0, or -2 / -3 (unknown key /
+ * malformed value). */
+int blr_set_option(blr_handle* h, const char* key, const char* value);
 
 /* ---- device memory helpers (so a host language needs no HIP binding of its own) -------------- */
 int blr_device_alloc(blr_handle* h, size_t bytes, void** dptr);
@@ -89,8 +96,8 @@ int blr_timer_stop(blr_handle* h, float* elapsed_ms); /* records, synchronises, 
  *   mw_post[D]; T_post D x D upper factor (strictly-lower part written as zero), ldt >= D;
  *   Lw_post D x D full symmetric A, ldlp >= D; logpdf (double).
  * In-place form: with prior_kind = BLR_PRIOR_UPPER_FACTOR, mw_post == mw and T_post == Lw are allowed (every read of the
- * prior state completes before the first write; blr_update_factor_* relies on it).  For D <= 128 mw_post and T_post of a regressor
- * whose info != 0 are left untouched (Lw_post may already hold A); for D > 128 the outputs are undefined then.
+ * prior state completes before the first write; blr_update_factor_* relies on it).  mw_post and T_post of a regressor whose
+ * info != 0 are left untouched at every D (Lw_post may already hold A): a resident state survives a bad batch.
  * Batched form: regressor i reads X + i*strideX, y + i*stridey, s + i*strides, mw + i*stridemw,
  * Lw + i*strideLw and writes the outputs at their strides; a stride of 0 shares an input.
  */
@@ -308,13 +315,13 @@ int blr_rand_dense_noise_f32(blr_handle* h, int memspace, int layout, int64_t D,
  * gives the evidence of all the data (chain rule).  info[B]: 0, or LAPACK-style i > 0 on BOTH routes, checked in the
  * reference's order (:78 prior, :79 noise, :86 posterior): T has a non-positive diagonal entry i (the state is not a Cholesky
  * factor), else s_i is not positive, else the leading minor of order i of the updated precision is not positive definite.
- * Routes (measured; BLR_MI355X_SWEEP=always|never overrides, "always" meaning D <= 128 and k <= 16):
+ * Routes (measured; BLR_MI355X_SWEEP=always|never at blr_create, or blr_set_option(h, "SWEEP", ...), overrides, "always" meaning D <= 128 and k <= 16):
  *   k <= 1, D <= 128 (and D > 64 or B < 256): one sweep of D Givens rotations over the factor held in LDS -- O(D^2),
  *     orthogonal transformations only; the state is untouched when info != 0;
  *   otherwise: the same state re-factored in place by blr_posterior_batched_* with the old factor entering as D
  *     pseudo-observations (cost independent of k; that entry point supports mw_post == mw and T_post == Lw for
- *     BLR_PRIOR_UPPER_FACTOR: every read of the old state completes before the first write).  D <= 128: the state is
- *     untouched when info != 0; D > 128: undefined when info != 0. */
+ *     BLR_PRIOR_UPPER_FACTOR: every read of the old state completes before the first write).  The state is untouched
+ *     when info != 0, at every D. */
 int blr_update_factor_f64(blr_handle* h, int memspace, int layout, int64_t B, int64_t D, int64_t k, const double* X,
                           int64_t ldx, int64_t strideX, const double* y, int64_t stridey, int noise_kind, const double* s,
                           int64_t strides, double* mw, int64_t stridemw, double* T, int64_t ldt, int64_t strideT,

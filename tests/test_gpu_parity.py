@@ -20,6 +20,22 @@ def B():
     return blr_amd
 
 
+@pytest.fixture
+def opt(B):
+    """Run-time switches of the process-wide handle (blr_set_option), restored to their defaults after the test.  The library
+    reads BLR_MI355X_* from the environment only once, in blr_create -- never on a launch path -- so tests set them here."""
+    h = B._abi.default_handle()
+    touched = []
+
+    def set_(key, value):
+        h.set_option(key, value)
+        touched.append(key)
+
+    yield set_
+    for key in touched:
+        h.set_option(key, None)
+
+
 def _rng(i=0):
     return np.random.Generator(np.random.PCG64(987654 + i))
 
@@ -1263,7 +1279,7 @@ def test_nonpositive_noise_does_not_poison_a_device_batch(B):
 @pytest.mark.parametrize("dtype", [np.float64, np.float32])
 @pytest.mark.parametrize("nb,D,N,prior", [(2, 200, 300, "diagonal"), (3, 384, 500, "dense"), (5, 330, 260, "pdmat"), (6, 640, 900, "diagonal"),
                                           (9, 130, 64, "dense"), (21, 160, 90, "diagonal")])
-def test_large_d_batched_regressors_share_the_factorisation_launches(B, dtype, nb, D, N, prior, monkeypatch):
+def test_large_d_batched_regressors_share_the_factorisation_launches(B, dtype, nb, D, N, prior, opt):
     # B > 1 at D > 128: groups of regressors step through every launch of the update together
     # (posterior_large_group; blockIdx.y of the panel and trailing-update kernels).  Every regressor against the oracle, a
     # regressor whose system is not positive definite must fail alone (its neighbours in the group untouched), and the
@@ -1327,7 +1343,7 @@ def test_large_d_batched_regressors_share_the_factorisation_launches(B, dtype, n
         np.testing.assert_allclose(mw_post[b], mw_o, rtol=10 * tol, atol=tol * np.abs(mw_o).max())
         Tn = np.triu(T_post[b].T.astype(np.float64))
         np.testing.assert_allclose(Tn.T @ Tn, A_o, rtol=tol, atol=tol * np.abs(A_o).max())
-    monkeypatch.setenv("BLR_MI355X_CHAIN_BATCH", "1")
+    opt("CHAIN_BATCH", "1")
     mw1, T1, L1, lp1, info1 = run()
     assert info1.tolist() == want
     ok = [b for b in range(nb) if b != bad]
@@ -1336,8 +1352,8 @@ def test_large_d_batched_regressors_share_the_factorisation_launches(B, dtype, n
     np.testing.assert_allclose(mw1[ok], mw_post[ok], rtol=0, atol=eps * 100 * np.abs(mw1[ok]).max())
     np.testing.assert_allclose(T1[ok], T_post[ok], rtol=0, atol=eps * 10 * np.abs(T1[ok]).max())
     # a workspace bound that holds only a few regressors: the batch runs as several groups, the last one smaller
-    monkeypatch.delenv("BLR_MI355X_CHAIN_BATCH")
-    monkeypatch.setenv("BLR_MI355X_CHAIN_WS_MB", "12")
+    opt("CHAIN_BATCH", None)
+    opt("CHAIN_WS_MB", "12")
     mw2, T2, L2, lp2, info2 = run()
     assert info2.tolist() == want
     np.testing.assert_allclose(lp2[ok], lp[ok], rtol=eps * 10)
@@ -1398,7 +1414,7 @@ def test_map_over_regressors_is_one_batched_call(B, D, N, prior):
 
 @pytest.mark.parametrize("splits", ["1,1", "3,3", "4,2", "3,3,1", "4,2,2", "5,5,3", "2,1,3", "6,3,5", "4,4,6"])
 @pytest.mark.parametrize("prior", ["diagonal", "pdmat"])
-def test_large_d_gram_split_plans(B, splits, prior, monkeypatch):
+def test_large_d_gram_split_plans(B, splits, prior, opt):
     # The Gram launch of the large-D path cuts every macro tile's columns into ranges: one factor for all tiles, the diagonal
     # tiles with their own (single-round launches), or three kinds of work items in planned dispatch order (multi-round launches:
     # "off-diagonal, diagonal, tiles with one range less").  Whatever the plan -- forced here through the measurement switch,
@@ -1417,7 +1433,7 @@ def test_large_d_gram_split_plans(B, splits, prior, monkeypatch):
         U = O.chol_upper(Bm @ Bm.T + np.eye(D)).astype(np.float32)
         Lw_d, Lw_arg = U.astype(float).T @ U.astype(float), B.PDMat(U)
     mw_o, T_o, A_o, lp_o = O.posterior_logpdf_direct(mw.astype(float), Lw_d, X.astype(float), s.astype(float), y.astype(float))
-    monkeypatch.setenv("BLR_MI355X_GRAM_SPLITS", splits)
+    opt("GRAM_SPLITS", splits)
     fx = B.BayesianLinearRegressor(mw, Lw_arg)(np.asfortranarray(X), s)
     assert B.logpdf(fx, y) == pytest.approx(lp_o, rel=2e-4)
     fp = B.posterior(fx, y)
@@ -1703,8 +1719,8 @@ def test_rccl_direct_single_rank(B):
 
 # ---- rank-k update of a resident state (blr_update_factor_*) -----------------------------------
 @pytest.mark.parametrize("route", ["always", "never"])
-def test_update_factor_repeated_conditioning_10_plus_3(B, route, monkeypatch):
-    monkeypatch.setenv("BLR_MI355X_SWEEP", route)  # Givens sweep / in-place re-factorisation: same answers
+def test_update_factor_repeated_conditioning_10_plus_3(B, route, opt):
+    opt("SWEEP", route)  # Givens sweep / in-place re-factorisation: same answers
     # reference test/bayesian_linear_regression.jl:49-70 (13 = 10 + 3 split) through the resident state, against the ONE-SHOT
     # oracle on all 13 observations; the second batch (k = 3) goes through the O(k D^2) Givens sweep
     rng = _rng(71)
@@ -1737,11 +1753,11 @@ def test_update_factor_repeated_conditioning_10_plus_3(B, route, monkeypatch):
 @pytest.mark.parametrize("D,k", [(1, 1), (5, 3), (16, 16), (64, 7), (100, 1), (128, 16), (128, 3), (128, 64), (37, 40), (200, 5)])
 @pytest.mark.parametrize("noise", ["diagonal", "isotropic"])
 @pytest.mark.parametrize("route", ["always", "auto"])
-def test_update_factor_device_batched(B, dtype, D, k, noise, route, monkeypatch):
+def test_update_factor_device_batched(B, dtype, D, k, noise, route, opt):
     if route == "always":
-        monkeypatch.setenv("BLR_MI355X_SWEEP", "always")
+        opt("SWEEP", "always")
     else:
-        monkeypatch.delenv("BLR_MI355X_SWEEP", raising=False)
+        opt("SWEEP", None)
     # device-resident batched state: every (D, k) class -- sweep (D <= 128, k <= 16), fused re-factorisation (k > 16) and the
     # large-D path (D > 128) -- against the oracle's one-shot posterior from the same prior state
     import torch
@@ -1793,15 +1809,18 @@ def test_update_factor_device_batched(B, dtype, D, k, noise, route, monkeypatch)
 
 
 @pytest.mark.parametrize("route", ["always", "never"])
-def test_update_factor_leaves_the_state_alone_on_failure(B, route, monkeypatch):
+@pytest.mark.parametrize("D", [9, 200])
+def test_update_factor_leaves_the_state_alone_on_failure(B, route, opt, D):
+    # D = 200: the large-D pipeline writes the caller's factor from its transpose launch only when the status words are clean
+    # (include/blr_mi355x.h: "the state is untouched when info != 0, at every D")
     import torch
 
-    monkeypatch.setenv("BLR_MI355X_SWEEP", route)
+    opt("SWEEP", route)
 
     a = B._abi
     h = a.default_handle()
     rng = _rng(73)
-    D, k = 9, 4
+    k = 4
     dev = torch.device("cuda:0")
     U = np.triu(rng.standard_normal((D, D))) + 3 * np.eye(D)
     U[np.diag_indices(D)] = np.abs(U[np.diag_indices(D)])
@@ -1909,14 +1928,14 @@ def test_resident_posterior_keeps_the_basis(B, basis):
 @pytest.mark.parametrize("noise", ["diagonal", "isotropic"])
 @pytest.mark.parametrize("prior", ["diagonal", "dense", "factor"])
 @pytest.mark.parametrize("split", ["auto", "1", "2"])
-def test_wave_kernel_shapes_vs_oracle(B, dtype, D, N, noise, prior, split, monkeypatch):
+def test_wave_kernel_shapes_vs_oracle(B, dtype, D, N, noise, prior, split, opt):
     # the shapes blr_abi.hip routes to fused_wave_kernel (f64: D = 32 and 64; f32: D = 64; D = 32 in f32 stays on the four-wave
     # kernel and runs here as its cross-check): whole 4 KiB stages, ragged tails, no data at all, non-zero prior mean.
     # split: waves per regressor -- "auto" is the router's choice (4 for a batch of 5), 1 and 2 are forced
     if split == "auto":
-        monkeypatch.delenv("BLR_MI355X_WAVE_SPLIT", raising=False)
+        opt("WAVE_SPLIT", None)
     else:
-        monkeypatch.setenv("BLR_MI355X_WAVE_SPLIT", split)
+        opt("WAVE_SPLIT", split)
     a = B._abi
     h = a.default_handle()
     rng = _rng(90 + D + N)

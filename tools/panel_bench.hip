@@ -58,10 +58,11 @@ int run(const char* name, int nwg) {
   CK(hipMalloc((void**)&dA, hA.size() * sizeof(T)));
   CK(hipMalloc((void**)&dW, hA.size() * sizeof(T)));
   CK(hipMalloc((void**)&dinfo, 64));
-  CK(hipMalloc((void**)&darr, 64));
+  CK(hipMalloc((void**)&darr, 2 * 128 * 4));  // two banks of arrival words (blr_panel.hpp)
   CK(hipMemcpy(dA, hA.data(), hA.size() * sizeof(T), hipMemcpyHostToDevice));
   CK(hipMemset(dinfo, 0, 64));
-  CK(hipMemset(darr, 0, 64));
+  CK(hipMemset(darr, 0, 2 * 128 * 4));
+  unsigned launches = 0;
   using CC = ChainCfg<T, PB_NW, BLR_PANEL_ER, PB_NBT>;
   CK(hipFuncSetAttribute(reinterpret_cast<const void*>(panel_chain_kernel<T, PB_NW, BLR_PANEL_ER, PB_NBT>), hipFuncAttributeMaxDynamicSharedMemorySize, CC::LDS_BYTES));
   hipEvent_t e0, e1;
@@ -74,7 +75,7 @@ int run(const char* name, int nwg) {
     for (int it = 0; it < reps + 2; ++it) {
       CK(hipMemcpy(dW, dA, hA.size() * sizeof(T), hipMemcpyDeviceToDevice));
       CK(hipEventRecord(e0));
-      panel_chain_kernel<T, PB_NW, BLR_PANEL_ER, PB_NBT><<<nwg, 64 * PB_NW, CC::LDS_BYTES>>>(dW, lda, 0, nrows, dinfo, darr, (unsigned)nwg);
+      panel_chain_kernel<T, PB_NW, BLR_PANEL_ER, PB_NBT><<<nwg, 64 * PB_NW, CC::LDS_BYTES>>>(dW, lda, 0, nrows, dinfo, darr + 128 * (launches & 1), (unsigned)nwg, 0, 0, darr + 128 * ((launches & 1) ^ 1)); ++launches;
       CK(hipEventRecord(e1));
       CK(hipEventSynchronize(e1));
       float ms;
@@ -132,7 +133,7 @@ int run(const char* name, int nwg) {
     std::vector<T> hB = hA;
     hB[(size_t)37 * lda + 37] = (T)-1.0;
     CK(hipMemcpy(dW, hB.data(), hB.size() * sizeof(T), hipMemcpyHostToDevice));
-    panel_chain_kernel<T, PB_NW, BLR_PANEL_ER, PB_NBT><<<nwg, 64 * PB_NW, CC::LDS_BYTES>>>(dW, lda, 0, nrows, dinfo, darr, (unsigned)nwg);
+    panel_chain_kernel<T, PB_NW, BLR_PANEL_ER, PB_NBT><<<nwg, 64 * PB_NW, CC::LDS_BYTES>>>(dW, lda, 0, nrows, dinfo, darr + 128 * (launches & 1), (unsigned)nwg, 0, 0, darr + 128 * ((launches & 1) ^ 1)); ++launches;
     CK(hipDeviceSynchronize());
     int info;
     CK(hipMemcpy(&info, dinfo, 4, hipMemcpyDeviceToHost));

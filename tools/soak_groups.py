@@ -32,11 +32,11 @@ def main():
         bad = int(rng.integers(nb)) if rng.random() < 0.3 else None
         if bad is not None:
             d[bad, int(rng.integers(D))] = -1.0
-        os.environ.pop("BLR_MI355X_CHAIN_BATCH", None)
+        h.set_option("CHAIN_BATCH", None)
         mp, T, lp, info = batched(h, dtype, nb, D, N, X, y, s, mw, d)
-        os.environ["BLR_MI355X_CHAIN_BATCH"] = "1"
+        h.set_option("CHAIN_BATCH", "1")
         mp1, T1, lp1, info1 = batched(h, dtype, nb, D, N, X, y, s, mw, d)
-        os.environ.pop("BLR_MI355X_CHAIN_BATCH", None)
+        h.set_option("CHAIN_BATCH", None)
         tag = f"round {it}: B={nb} D={D} N={N} {np.dtype(dtype).name} bad={bad}"
         assert info.tolist() == info1.tolist(), (tag, info.tolist(), info1.tolist())
         ok = info == 0
