@@ -85,6 +85,7 @@ __device__ unsigned long long g_gstamps[4][8];
     gstamp_prev = t__;                                                                          \
   } while (0)
 __device__ unsigned long long g_pstamps[16];  // per-phase cycle sums of workgroup 0 (fused_small_kernel), [15] = regressors
+__device__ unsigned long long g_wgclk[8192][2];  // per workgroup (wave 0): shader cycles and 100 MHz ticks of its last ring loop
 #define BLR_PSTAMP_INIT unsigned long long pstamp_prev = __builtin_amdgcn_s_memtime()
 #ifdef BLR_PSTAMP_ALL  /* every workgroup, atomically */
 #define BLR_PSTAMP(slot)                                                                   \
@@ -1041,6 +1042,10 @@ BLR_PHASE void phase_gram(char* smem) {
           g_gstamps[wave][5] += __builtin_amdgcn_s_memtime() - ck0;
           g_gstamps[wave][6] += __builtin_amdgcn_s_memrealtime() - rt0;
           g_gstamps[wave][7] += 1;
+        }
+        if (wave == 0 && lane == 0 && blockIdx.x < 8192) {
+          g_wgclk[blockIdx.x][0] = __builtin_amdgcn_s_memtime() - ck0;
+          g_wgclk[blockIdx.x][1] = __builtin_amdgcn_s_memrealtime() - rt0;
         }
 #endif
       }

@@ -139,33 +139,56 @@ def cpu_baseline(D, N, seconds, seed):
 class Workload:
     """One BASELINE shape resident on the device + the call that runs one step of it."""
 
-    def __init__(self, torch, _abi, h, dev, name, B, D, N, dtype, noise, seed, Din=None):
+    def __init__(self, torch, _abi, h, dev, name, B, D, N, dtype, noise, seed, Din=None, mw_random=False, logpdf_only=False, block=None):
         self.name, self.B, self.D, self.N, self.dtype, self.noise, self.Din = name, B, D, N, dtype, noise, Din
+        self.logpdf_only = logpdf_only
         self.torch, self._abi, self.h = torch, _abi, h
         t_dt = torch.float64 if dtype == "f64" else torch.float32
         self.np_dt = np.float64 if dtype == "f64" else np.float32
         self.w_bytes = 8 if dtype == "f64" else 4
         diag = noise == "diagonal"
-        g = torch.Generator(device=dev).manual_seed(seed)
         # synthetic ColVecs design matrices (SURVEY.md 8d): X ~ N(0,1), y = X'w* + sqrt(s) eps, prior mw = 0, Lw = I
-        if Din is None:
-            self.X = torch.randn((B, N, D), generator=g, dtype=t_dt, device=dev)  # [N, D] row-major == D x N column-major
-            wstar = torch.randn((B, D), generator=g, dtype=t_dt, device=dev)
-            mean = torch.einsum("bnd,bd->bn", self.X, wstar) if B * N * D < (1 << 32) else torch.stack(
-                [self.X[b] @ wstar[b] for b in range(B)])
-        else:  # c5: raw inputs D_in x N, random-Fourier basis on the device
-            self.X = torch.randn((B, N, Din), generator=g, dtype=t_dt, device=dev)
+        def gen(nb, g):
+            if Din is None:
+                X = torch.randn((nb, N, D), generator=g, dtype=t_dt, device=dev)  # [N, D] row-major == D x N column-major
+                wstar = torch.randn((nb, D), generator=g, dtype=t_dt, device=dev)
+                mean = torch.einsum("bnd,bd->bn", X, wstar) if nb * N * D < (1 << 32) else torch.stack([X[b] @ wstar[b] for b in range(nb)])
+            else:  # c5: raw inputs D_in x N, random-Fourier basis on the device
+                X = torch.randn((nb, N, Din), generator=g, dtype=t_dt, device=dev)
+                mean = torch.zeros((nb, N), dtype=t_dt, device=dev)
+            if diag:
+                sv = torch.exp(torch.randn((nb, N), generator=g, dtype=t_dt, device=dev))
+                sd = torch.sqrt(sv)
+            else:
+                sv, sd = None, float(np.sqrt(0.1))
+            return X, sv, mean + sd * torch.randn((nb, N), generator=g, dtype=t_dt, device=dev)
+
+        g = torch.Generator(device=dev).manual_seed(seed)
+        if Din is not None:
             self.Omega = torch.randn((D, Din), generator=g, dtype=t_dt, device=dev)  # [D, Din] row-major == Din x D column-major
             self.phase = 2 * np.pi * torch.rand((D,), generator=g, dtype=t_dt, device=dev)
-            mean = torch.zeros((B, N), dtype=t_dt, device=dev)
-        if diag:
-            self.s = torch.exp(torch.randn((B, N), generator=g, dtype=t_dt, device=dev))
-            sd = torch.sqrt(self.s)
+        if block is None:
+            self.X, sv, self.y = gen(B, g)
         else:
-            self.s = torch.full((1,), 0.1, dtype=t_dt, device=dev)
-            sd = torch.sqrt(self.s)
-        self.y = mean + sd * torch.randn((B, N), generator=g, dtype=t_dt, device=dev)
-        self.mw = torch.zeros((B, D), dtype=t_dt, device=dev)
+            # strong scaling: this rank's contiguous block [lo, hi) of a FIXED global batch.  Regressor i is the same on every
+            # rank count: chunk c of `ch` regressors is drawn from a generator seeded with seed + c, whoever holds it.
+            lo, hi, ch = block
+            assert hi - lo == B
+            self.X = torch.empty((B, N, D if Din is None else Din), dtype=t_dt, device=dev)
+            self.y = torch.empty((B, N), dtype=t_dt, device=dev)
+            sv = torch.empty((B, N), dtype=t_dt, device=dev) if diag else None
+            for c in range(lo // ch, (hi + ch - 1) // ch):
+                Xc, sc, yc = gen(ch, torch.Generator(device=dev).manual_seed(seed + 1000 + c))
+                a0, a1 = max(lo, c * ch), min(hi, (c + 1) * ch)
+                self.X[a0 - lo:a1 - lo] = Xc[a0 - c * ch:a1 - c * ch]
+                self.y[a0 - lo:a1 - lo] = yc[a0 - c * ch:a1 - c * ch]
+                if diag:
+                    sv[a0 - lo:a1 - lo] = sc[a0 - c * ch:a1 - c * ch]
+                del Xc, sc, yc
+        self.s = sv if diag else torch.full((1,), 0.1, dtype=t_dt, device=dev)
+        # prior mean: 0 (SURVEY.md 8(d) first variant: the zero-mean fast paths) or ~ N(0, I) (second variant; the reference's toy
+        # problems draw mw = randn(D), test/test_utils.jl:6)
+        self.mw = torch.randn((B, D), generator=g, dtype=t_dt, device=dev) if mw_random else torch.zeros((B, D), dtype=t_dt, device=dev)
         self.dprior = torch.ones((D,), dtype=t_dt, device=dev)
         self.mw_post = torch.empty((B, D), dtype=t_dt, device=dev)
         self.T_post = torch.empty((B, D, D), dtype=t_dt, device=dev)
@@ -179,7 +202,8 @@ class Workload:
         if self.Din is None:
             self.h.posterior_batched(self.np_dt, a.MEM_DEVICE, a.LAYOUT_COLVECS, B, D, N, self.X.data_ptr(), D, N * D, self.y.data_ptr(), N,
                                      self.noise_kind, self.s.data_ptr(), N if self.diag else 0, a.PRIOR_DIAGONAL, self.mw.data_ptr(), D,
-                                     self.dprior.data_ptr(), 1, 0, self.mw_post.data_ptr(), D, self.T_post.data_ptr(), D, D * D, None, D,
+                                     self.dprior.data_ptr(), 1, 0, None if self.logpdf_only else self.mw_post.data_ptr(), D,
+                                     None if self.logpdf_only else self.T_post.data_ptr(), D, D * D, None, D,
                                      D * D, self.lp.data_ptr(), self.info.data_ptr())
         else:
             self.h.posterior_rff(self.np_dt, a.MEM_DEVICE, self.Din, D, N, self.X.data_ptr(), self.Din, self.Omega.data_ptr(), self.Din,
@@ -198,6 +222,8 @@ class Workload:
     def roofline(self, ms):
         fl = algorithmic_flops(self.D, self.N, self.Din) * self.B
         by = algorithmic_bytes(self.D, self.N, self.w_bytes, self.diag, self.Din) * self.B
+        if self.logpdf_only:  # no mw', no T written
+            by -= self.w_bytes * (self.D + self.D * self.D) * self.B
         tf = fl / (ms * 1e-3) / 1e12
         gbs = by / (ms * 1e-3) / 1e9
         t_hbm = by / (PEAK_HBM_GBS * 1e9)
@@ -210,6 +236,251 @@ class Workload:
                   "algorithmic_flops": fl, "hbm_GBps": gbs, "hbm_frac": gbs / PEAK_HBM_GBS, "mfma_TFLOPps": tf,
                   "mfma_frac": tf / PEAK_TF[self.dtype]})
         return r
+
+
+def roofline_of(flops, nbytes, dtype, ms, kernel):
+    """bound = whichever of t_HBM (8 TB/s) and t_MFMA (dense matrix peak of the dtype) is longer for the ALGORITHMIC bytes / flops
+    of one call (stated per entry in DESIGN.md 4, "secondary entries"); frac = that time / measured time."""
+    tf = flops / (ms * 1e-3) / 1e12
+    gbs = nbytes / (ms * 1e-3) / 1e9
+    if flops / (PEAK_TF[dtype] * 1e12) >= nbytes / (PEAK_HBM_GBS * 1e9):
+        r = {"bound": "mfma", "achieved": tf, "peak": PEAK_TF[dtype], "unit": "TFLOP/s", "frac": tf / PEAK_TF[dtype]}
+    else:
+        r = {"bound": "hbm", "achieved": gbs, "peak": PEAK_HBM_GBS, "unit": "GB/s", "frac": gbs / PEAK_HBM_GBS}
+    r.update({"kernel": kernel, "hbm_frac": gbs / PEAK_HBM_GBS, "mfma_frac": tf / PEAK_TF[dtype], "algorithmic_bytes": nbytes,
+              "algorithmic_flops": flops})
+    return r
+
+
+class Op:
+    """One secondary hot-path operation: `fn` enqueues ONE call on the launch stream; units / flops / nbytes are per call."""
+
+    def __init__(self, workload, fn, units, unit, flops, nbytes, dtype, kernel, check, steps=20, keep=()):
+        self.workload, self.fn, self.units, self.unit, self.flops, self.nbytes = workload, fn, units, unit, flops, nbytes
+        self.dtype, self.kernel, self.check, self.steps, self.keep = dtype, kernel, check, steps, keep
+
+
+def secondary_ops(torch, _abi, h, dev):
+    """name -> builder of an Op.  Every hot-path row of SURVEY.md 8(a) other than `posterior` (a7 mean, a8 var, a9 rand, a4 logpdf
+    alone) and the 8(f) rows (gradient, shared-X evidence, rank-k update of a resident state), on device-resident synthetic inputs."""
+    a = _abi
+
+    def tdt(dt):
+        return (torch.float64, np.float64, 8) if dt == "f64" else (torch.float32, np.float32, 4)
+
+    def factor(g, B, D, t):  # well-conditioned upper factors U (column-major storage), as tools/marginals_bench.py
+        U = torch.triu(torch.randn((B, D, D), generator=g, dtype=t, device=dev)) / D**0.5 + 2 * torch.eye(D, dtype=t, device=dev)
+        return U, U.transpose(1, 2).contiguous()
+
+    def marginals(B, D, N, dt, mean_only):
+        t, nd, w = tdt(dt)
+        g = torch.Generator(device=dev).manual_seed(11)
+        X = torch.randn((B, N, D), generator=g, dtype=t, device=dev)
+        mw = torch.randn((B, D), generator=g, dtype=t, device=dev)
+        U, Ucm = factor(g, B, D, t)
+        s = torch.full((1,), 0.1, dtype=t, device=dev)
+        mean = torch.empty((B, N), dtype=t, device=dev)
+        var = torch.empty((B, N), dtype=t, device=dev)
+        info = torch.zeros(B, dtype=torch.int32, device=dev)
+
+        def fn():
+            h.marginals_batched(nd, a.MEM_DEVICE, a.LAYOUT_COLVECS, B, D, N, X.data_ptr(), D, N * D, a.NOISE_ISOTROPIC, s.data_ptr(), 0,
+                                a.PRIOR_UPPER_FACTOR, mw.data_ptr(), D, Ucm.data_ptr(), D, D * D, mean.data_ptr(), N,
+                                None if mean_only else var.data_ptr(), N, info.data_ptr())
+
+        def check():
+            m_ref = X[0].double() @ mw[0].double()
+            assert float((mean[0].double() - m_ref).abs().max() / m_ref.abs().max()) < (1e-12 if dt == "f64" else 1e-4)
+            if not mean_only:
+                al = torch.linalg.solve_triangular(U[0].double().T, X[0].T.double(), upper=False)
+                v_ref = (al * al).sum(0) + 0.1
+                assert float(((var[0].double() - v_ref).abs() / v_ref).max()) < (1e-11 if dt == "f64" else 2e-4)
+
+        # mean: 2DN flops on DN elements (a7, pure bandwidth); var: the D^2 N triangular solve (a8: D^2 flops per input) + 2DN
+        flops = B * N * (2 * D if mean_only else D * D + 4 * D)
+        nbytes = w * B * (N * D + D + (0 if mean_only else D * D) + N * (1 if mean_only else 2))
+        kern = ("mean_stream_kernel" if mean_only else "trsm_block_kernel + trail_update_kernel") if D > 128 else "marginals_mfma_kernel"
+        return Op(f"B={B}, D={D}, N={N}, {dt}: {'mean' if mean_only else 'mean + var'} of the marginals, factor prior (PDMat / posterior)",
+                  fn, B * N, "marginals/s", flops, nbytes, dt, kern, check, keep=(X, mw, Ucm, s, mean, var, info))
+
+    def rand(D, N, S, dt):
+        t, nd, w = tdt(dt)
+        g = torch.Generator(device=dev).manual_seed(12)
+        X = torch.randn((N, D), generator=g, dtype=t, device=dev)
+        Z1 = torch.randn((S, D), generator=g, dtype=t, device=dev)
+        Z2 = torch.randn((S, N), generator=g, dtype=t, device=dev)
+        Y = torch.empty((S, N), dtype=t, device=dev)
+        s = torch.full((1,), 0.1, dtype=t, device=dev)
+        mw = torch.randn((D,), generator=g, dtype=t, device=dev)
+        U, Ucm = factor(g, 1, D, t)
+
+        def fn():
+            h.rand(nd, a.MEM_DEVICE, a.LAYOUT_COLVECS, D, N, S, X.data_ptr(), D, a.NOISE_ISOTROPIC, s.data_ptr(), a.PRIOR_UPPER_FACTOR,
+                   mw.data_ptr(), Ucm.data_ptr(), D, Z1.data_ptr(), D, Z2.data_ptr(), N, Y.data_ptr(), N)
+
+        def check():
+            W = mw.double()[:, None] + torch.linalg.solve_triangular(U[0].double(), Z1.double().T, upper=True)
+            ref = X.double() @ W + (0.1 ** 0.5) * Z2.double().T
+            assert float((Y.double().T - ref).abs().max() / ref.abs().max()) < (1e-11 if dt == "f64" else 2e-4)
+
+        return Op(f"D={D}, N={N}, {S} draws, {dt}: rand(rng, fx, S) with the normals on the device (weight solve + projection + noise)", fn,
+                  N * S, "outputs/s", 2.0 * D * N * S + D * D * S, w * (D * N + 2 * N * S + 2 * D * S + D * D + D), dt,
+                  "rand_project_mfma_kernel", check, keep=(X, Z1, Z2, Y, s, mw, Ucm))
+
+    def grad(B, D, N, dt):
+        t, nd, w = tdt(dt)
+        g = torch.Generator(device=dev).manual_seed(13)
+        X = torch.randn((B, N, D), generator=g, dtype=t, device=dev)
+        y = torch.randn((B, N), generator=g, dtype=t, device=dev)
+        s = torch.full((1,), 0.1, dtype=t, device=dev)
+        mw = torch.randn((B, D), generator=g, dtype=t, device=dev)
+        d = torch.ones((D,), dtype=t, device=dev)
+        lp = torch.zeros(B, dtype=torch.float64, device=dev)
+        info = torch.zeros(B, dtype=torch.int32, device=dev)
+        dX, dy, ds, dmw, mwp = torch.empty_like(X), torch.empty_like(y), torch.empty_like(y), torch.empty_like(mw), torch.empty_like(mw)
+        Ai = torch.empty((B, D, D), dtype=t, device=dev)
+
+        def fn():
+            h.logpdf_grad_batched(nd, a.MEM_DEVICE, a.LAYOUT_COLVECS, B, D, N, X.data_ptr(), D, N * D, y.data_ptr(), N, a.NOISE_ISOTROPIC,
+                                  s.data_ptr(), 0, a.PRIOR_DIAGONAL, mw.data_ptr(), D, d.data_ptr(), 1, 0, lp.data_ptr(), dX.data_ptr(), D,
+                                  N * D, dy.data_ptr(), N, ds.data_ptr(), N, dmw.data_ptr(), D, mwp.data_ptr(), D, Ai.data_ptr(), D, D * D,
+                                  info.data_ptr())
+
+        def check():
+            assert int(info.abs().sum().item()) == 0 and bool(torch.isfinite(lp).all().item()) and bool(torch.isfinite(dX).all().item())
+
+        # value (SYRK half D(D+1)N + 4DN + chol D^3/3) + A^-1 (2D^3/3) + the dX pass (A^-1 X: 2 D^2 N) + O(DN) vector work
+        flops = B * (D * (D + 1) * N + 2.0 * D * D * N + D**3 + 12.0 * D * N)
+        nbytes = w * B * (2 * N * D + 4 * N + D * D + 4 * D)
+        return Op(f"B={B}, D={D}, N={N}, {dt}: value + gradient of the log marginal likelihood w.r.t. X, y, s, mw (+ A^-1)", fn, B,
+                  "evaluations/s", flops, nbytes, dt, "logpdf_grad_kernel", check, steps=10, keep=(X, y, s, mw, d, lp, info, dX, dy, ds, dmw, mwp, Ai))
+
+    def multi(D, N, S, dt):
+        t, nd, w = tdt(dt)
+        g = torch.Generator(device=dev).manual_seed(14)
+        X = torch.randn((N, D), generator=g, dtype=t, device=dev)
+        Y = torch.randn((S, N), generator=g, dtype=t, device=dev)
+        s = torch.full((1,), 0.1, dtype=t, device=dev)
+        mw = torch.randn((D,), generator=g, dtype=t, device=dev)
+        d = torch.ones((D,), dtype=t, device=dev)
+        lp = torch.zeros(S, dtype=torch.float64, device=dev)
+        info = torch.zeros(S, dtype=torch.int32, device=dev)
+
+        def fn():
+            h.logpdf_multi(nd, a.MEM_DEVICE, a.LAYOUT_COLVECS, D, N, S, X.data_ptr(), D, Y.data_ptr(), N, a.NOISE_ISOTROPIC, s.data_ptr(),
+                           a.PRIOR_DIAGONAL, mw.data_ptr(), d.data_ptr(), 1, lp.data_ptr(), None, D, info.data_ptr())
+
+        def check():
+            assert int(info.abs().sum().item()) == 0 and bool(torch.isfinite(lp).all().item())
+
+        flops = D * (D + 1) * N + 2.0 * D * N * S + D**3 / 3 + 2.0 * D * D * S + 4.0 * D * N
+        return Op(f"D={D}, N={N}, S={S} columns of Y sharing X, {dt}: logpdf(fx, Y::Matrix)", fn, S, "evidences/s", flops,
+                  w * (D * N + N * S + 2 * D + 1) + 8 * S, dt, "gram_tile_kernel", check, steps=10, keep=(X, Y, s, mw, d, lp, info))
+
+    def update(B, D, k, dt):
+        t, nd, w = tdt(dt)
+        g = torch.Generator(device=dev).manual_seed(15)
+        U = torch.triu(torch.randn((B, D, D), generator=g, dtype=t, device=dev)) * (0.3 / D**0.5)
+        U = U + torch.diag_embed(1.0 + U.diagonal(dim1=1, dim2=2).abs())
+        T0 = U.transpose(1, 2).contiguous()
+        Tm = T0.clone()
+        X = torch.randn((B, k, D), generator=g, dtype=t, device=dev)
+        y = torch.randn((B, k), generator=g, dtype=t, device=dev)
+        s = torch.full((1,), 0.5, dtype=t, device=dev)
+        mw = torch.zeros((B, D), dtype=t, device=dev)
+        lp = torch.zeros(B, dtype=torch.float64, device=dev)
+        info = torch.zeros(B, dtype=torch.int32, device=dev)
+
+        def fn():  # the state keeps absorbing the same k observations: precision grows, always positive definite
+            h.update_factor(nd, a.MEM_DEVICE, a.LAYOUT_COLVECS, B, D, k, X.data_ptr(), D, k * D, y.data_ptr(), k, a.NOISE_ISOTROPIC, s.data_ptr(),
+                            0, mw.data_ptr(), D, Tm.data_ptr(), D, D * D, lp.data_ptr(), info.data_ptr())
+
+        def check():
+            assert int(info.abs().sum().item()) == 0 and bool(torch.isfinite(lp).all().item()) and bool(torch.isfinite(Tm).all().item())
+
+        # state read + written in place (upper triangle of T, mw) + the k new columns; the re-factorisation route costs D^3/3 + k D^2
+        nbytes = w * B * (D * (D + 1) + 2 * D + k * D + 2 * k) + 12 * B
+        flops = B * (D**3 / 3 + 2.0 * k * D * D + 3.0 * D * D)
+        return Op(f"B={B}, D={D}, k={k}, {dt}: in-place rank-k update of a resident posterior (mw, T) + evidence increment", fn, B,
+                  "updates/s", flops, nbytes, dt, "rank1_sweep_kernel" if k <= 1 else "fused_small_kernel (factor prior, in place)", check,
+                  keep=(Tm, T0, X, y, s, mw, lp, info))
+
+    def post(name, b, d, n, dt, noise, din=None, steps=20, **kw):
+        def build():
+            w2 = Workload(torch, a, h, dev, name, b, d, n, dt, noise, 123456 + 7, din, **kw)
+
+            def check():
+                assert int(w2.info.abs().sum().item()) == 0 and bool(torch.isfinite(w2.lp).all().item())
+
+            r = w2.roofline(1.0)
+            tag = (", prior mean ~ N(0, I)" if kw.get("mw_random") else "") + (", logpdf only (no mw', no T)" if kw.get("logpdf_only") else "")
+            return Op(f"B={b}, D={d}, N={n}, {dt}, {noise} noise" + (f", D_in={din} random-Fourier features" if din else "") + tag,
+                      w2.launch, b, "updates/s", r["algorithmic_flops"], r["algorithmic_bytes"], dt, w2.kernel_name(), check, steps=steps, keep=(w2,))
+        return build
+
+    ops = {
+        "c2_f32": post("c2_f32", 4096, 128, 4096, "f32", "isotropic"),
+        "c2_f64_mw": post("c2_f64_mw", 4096, 128, 4096, "f64", "isotropic", mw_random=True),
+        "c2_f64_diag_noise": post("c2_f64_diag", 4096, 128, 4096, "f64", "diagonal"),
+        "c4_f64": post("c4_f64", 8192, 64, 1024, "f64", "isotropic"),
+        "c4_f32": post("c4_f32", 8192, 64, 1024, "f32", "isotropic"),
+        # the per-GPU blocks of config 4 (8192 regressors) on 2 / 4 / 8 GPUs: the expected strong-scaling curve (DESIGN.md 5)
+        "c4_f64_B4096": post("c4_f64_B4096", 4096, 64, 1024, "f64", "isotropic"),
+        "c4_f64_B2048": post("c4_f64_B2048", 2048, 64, 1024, "f64", "isotropic"),
+        "c4_f64_B1024": post("c4_f64_B1024", 1024, 64, 1024, "f64", "isotropic"),
+        "c3_f32": post("c3_f32", 1, 1024, 65536, "f32", "diagonal"),
+        "c3_f32_mw": post("c3_f32_mw", 1, 1024, 65536, "f32", "diagonal", mw_random=True),
+        "logpdf_only_c3_f32": post("logpdf_only_c3", 1, 1024, 65536, "f32", "diagonal", logpdf_only=True),
+        "c5_f32_end_to_end": post("c5_f32_end_to_end", 1, 2048, 16384, "f32", "isotropic", 8),
+        # batches at D > 128: the regressors go through every launch of the update together (posterior_large_group)
+        "c3_f32_B8": post("c3_f32_B8", 8, 1024, 65536, "f32", "diagonal", steps=10),
+        "c5_shape_f32_B8": post("c5_shape_f32_B8", 8, 2048, 16384, "f32", "isotropic", steps=10),
+        "marginals_mean_c2_f64": lambda: marginals(64, 128, 4096, "f64", True),
+        "marginals_var_c2_f64": lambda: marginals(64, 128, 4096, "f64", False),
+        "marginals_var_c2_f32": lambda: marginals(64, 128, 4096, "f32", False),
+        "marginals_mean_c3_f32": lambda: marginals(1, 1024, 65536, "f32", True),
+        "marginals_var_c3_f32": lambda: marginals(1, 1024, 65536, "f32", False),
+        "rand_c2_f64_S64": lambda: rand(128, 4096, 64, "f64"),
+        "rand_c3_f32_S64": lambda: rand(1024, 65536, 64, "f32"),
+        "logpdf_grad_c2_f64": lambda: grad(1024, 128, 4096, "f64"),
+        "logpdf_multi_c3_f32_S64": lambda: multi(1024, 65536, 64, "f32"),
+        "update_factor_D128_k1_f64": lambda: update(2048, 128, 1, "f64"),
+        "update_factor_D128_k16_f64": lambda: update(2048, 128, 16, "f64"),
+    }
+    return ops
+
+
+def run_secondary(torch, _abi, h, dev, stream, only=None):
+    sec = {}
+    for name, build in secondary_ops(torch, _abi, h, dev).items():
+        if only is not None and name not in only:
+            continue
+        try:
+            op = build()
+            torch.cuda.synchronize(dev)
+            wall, ms = timed(torch, stream, dev, op.fn, op.steps, 3)
+            op.check()
+            r = roofline_of(op.flops, op.nbytes, op.dtype, ms, op.kernel)
+            # HBM bytes of one CALL by PMC (all of the call's kernels; tools/collect_profiles.sh runs `--secondary-only <name>` under
+            # rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE); summaries of earlier rounds hold the dominant kernel of four entries per update
+            per_call, src = pmc_traffic_per_update(name + "_hbm")
+            legacy = {"c2_f32": "c2_f32_fused_small_kernel_hbm", "c4_f64": "c4_fused_wave_kernel_hbm", "c3_f32": "c3_gram_tile_kernel_hbm",
+                      "c5_f32_end_to_end": "c5_gram_tile_kernel_hbm"}
+            if per_call is None and name in legacy:
+                per_call, src = pmc_traffic_per_update(legacy[name])
+                if per_call is not None and name in ("c2_f32", "c4_f64"):
+                    per_call *= op.units
+            r["traffic"], r["traffic_source"] = per_call, src
+            sec[name] = {"workload": op.workload, "ms": ms, "unit": op.unit, "per_s": op.units / (ms * 1e-3),
+                         "wall_per_s": op.units * op.steps / wall, "roofline": r}
+            if op.unit == "updates/s":
+                sec[name]["updates_per_s"] = sec[name]["per_s"]
+            del op
+            torch.cuda.empty_cache()
+        except Exception as e:  # a secondary entry must never take the headline line down
+            sec[name] = {"error": f"{type(e).__name__}: {e}"}
+            torch.cuda.empty_cache()
+    return sec
 
 
 def timed(torch, stream, dev, fn, steps, warmup):
@@ -241,6 +512,9 @@ def main():
                     help="wall budget of the cpu_baseline leg (0 = skip; default: 24 s at the headline shape, skipped otherwise)")
     ap.add_argument("--secondary", type=int, default=None,
                     help="1: also time the other BASELINE shapes (default at one GPU on the headline workload), 0: skip")
+    ap.add_argument("--secondary-only", default=None,
+                    help="comma-separated names of secondary entries (or 'all'): time ONLY those (no headline workload, no CPU leg) and "
+                         "print {\"secondary\": ...}; tools/collect_profiles.sh profiles them one by one this way")
     ap.add_argument("--config", choices=["c2", "c3", "c4", "c5"], default=None,
                     help="make one of the secondary BASELINE shapes the measured workload; c4 is BASELINE's STRONG-scaling "
                          "case: a fixed batch of 8192 regressors sharded over the ranks (8192 / N per GPU)")
@@ -263,6 +537,8 @@ def main():
     headline = (args.D, args.N, args.dtype, args.noise, Din) == (128, 4096, "f64", "isotropic", None)
     if args.cpu_seconds is None:
         args.cpu_seconds = 24.0 if headline else 0.0
+    if args.secondary_only:
+        args.cpu_seconds = 0.0
 
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
@@ -305,6 +581,11 @@ def main():
     h.set_stream(stream.cuda_stream)  # 0 = the HIP null stream = torch's default stream
     h.set_async(True)
 
+    if args.secondary_only:
+        only = None if args.secondary_only == "all" else set(args.secondary_only.split(","))
+        print(json.dumps({"secondary": run_secondary(torch, _abi, h, dev, stream, only)}), flush=True)
+        h.close()
+        return
     D, N = args.D, args.N
     strong = args.global_batch is not None
     if strong:  # contiguous blocks of a fixed batch (sharding.shard_range): the partition north_star names for config 4
@@ -318,7 +599,8 @@ def main():
         B = Bmax = args.batch
         global_batch = B * world
     cfg = {(128, 4096, "f64"): "c2", (1024, 65536, "f32"): "c3", (64, 1024, "f64"): "c4", (2048, 16384, "f32"): "c5"}
-    wl = Workload(torch, _abi, h, dev, cfg.get((D, N, args.dtype), "custom"), B, D, N, args.dtype, args.noise, 123456 + 1 + rank, Din)
+    wl = Workload(torch, _abi, h, dev, cfg.get((D, N, args.dtype), "custom"), B, D, N, args.dtype, args.noise,
+                  123456 + 1 + (0 if strong else rank), Din, block=(lo, hi, 1024) if strong else None)
     lp_sum = torch.zeros((1,), dtype=torch.float64, device=dev)
     lp_loc = torch.zeros((Bmax,), dtype=torch.float64, device=dev)  # this rank's evidences (+ zero padding of an uneven block)
     wl.lp = lp_loc[:B]
@@ -343,7 +625,8 @@ def main():
         if ev is not None:
             ev[1].record(stream)
         # the path's only exchange: all-gather of the per-regressor log evidences (8 B each), then the SAME
-        # fixed-order device sum on every rank -> identical bits for every rank count
+        # fixed-order device sum on every rank -> identical bits for every rank count that divides the batch (SURVEY.md 8e;
+        # uneven blocks are zero-padded, which regroups the sum: equal to rounding only)
         if use_lib_comm:  # ncclAllGather on the handle's stream + the fixed-order sum, one library call
             h.logpdf_allgather_sum(Bmax, lp_loc.data_ptr(), lp_all.data_ptr(), lp_sum.data_ptr())
         elif dist is not None:
@@ -424,41 +707,12 @@ def main():
         if cpu_leg is not None:
             out["cpu_baseline"] = cpu_leg
 
-    # ---- the other BASELINE shapes, same process, same timing method (one GPU only) ---------------------------------
+    # ---- the other BASELINE shapes and the other hot-path rows (mean / var / rand / gradient / ...), same process, same timing
+    # method (one GPU only)
     if args.secondary and world == 1 and rank == 0:
         del wl, lp_all
         torch.cuda.empty_cache()
-        sec = {}
-        shapes = [("c2_f32", 4096, 128, 4096, "f32", "isotropic", None, 20),
-                  ("c4_f64", 8192, 64, 1024, "f64", "isotropic", None, 20),
-                  ("c4_f32", 8192, 64, 1024, "f32", "isotropic", None, 20),
-                  ("c4_f64_B1024", 1024, 64, 1024, "f64", "isotropic", None, 20),  # the per-GPU block of config 4 on 8 GPUs
-                  ("c3_f32", 1, 1024, 65536, "f32", "diagonal", None, 20),
-                  ("c5_f32_end_to_end", 1, 2048, 16384, "f32", "isotropic", 8, 20),
-                  # batches at D > 128: the regressors go through every launch of the update together (posterior_large_group)
-                  ("c3_f32_B8", 8, 1024, 65536, "f32", "diagonal", None, 10),
-                  ("c5_shape_f32_B8", 8, 2048, 16384, "f32", "isotropic", None, 10)]
-        for name, b, d, n, dt, noise, din, steps in shapes:
-            try:
-                w2 = Workload(torch, _abi, h, dev, name, b, d, n, dt, noise, 123456 + 7, din)
-                torch.cuda.synchronize(dev)
-                wall, ms = timed(torch, stream, dev, w2.launch, steps, 3)
-                assert int(w2.info.abs().sum().item()) == 0 and bool(torch.isfinite(w2.lp).all().item())
-                r = w2.roofline(ms)
-                pmc_key = {"c2_f32": "c2_f32_fused_small_kernel_hbm", "c4_f64": "c4_fused_wave_kernel_hbm", "c3_f32": "c3_gram_tile_kernel_hbm",
-                           "c5_f32_end_to_end": "c5_gram_tile_kernel_hbm"}.get(name)
-                per_update, src = pmc_traffic_per_update(pmc_key) if pmc_key else (None, None)
-                r["traffic"] = per_update * (b if pmc_key in ("c2_f32_fused_small_kernel_hbm", "c4_fused_wave_kernel_hbm") else 1) if per_update else None
-                r["traffic_source"] = src
-                sec[name] = {"workload": f"B={b}, D={d}, N={n}, {dt}, {noise} noise" + (f", D_in={din} random-Fourier features" if din else ""),
-                             "ms": ms, "updates_per_s": b / (ms * 1e-3), "wall_updates_per_s": b * steps / wall,
-                             "roofline": {k: r[k] for k in ("bound", "achieved", "peak", "unit", "frac", "kernel", "hbm_frac", "mfma_frac", "traffic",
-                                                           "traffic_source")}}
-                del w2
-                torch.cuda.empty_cache()
-            except Exception as e:  # a secondary shape must never take the headline line down
-                sec[name] = {"error": f"{type(e).__name__}: {e}"}
-        out["secondary"] = sec
+        out["secondary"] = run_secondary(torch, _abi, h, dev, stream)
     if rank == 0:
         print(json.dumps(out), flush=True)
     if use_lib_comm:

@@ -344,7 +344,10 @@ int blr_logpdf_sum(blr_handle* h, int memspace, int64_t B, const double* logpdf,
  * ncclCommInitRank.  librccl is loaded on first use (no link-time dependency; a single-GPU host never needs it).
  *   blr_logpdf_allgather_sum   every rank passes its `count` per-regressor log evidences (device); logpdf_all (device,
  *                              nranks * count doubles, rank order == regressor order) receives the all-gather and *total
- *                              (device) the fixed-order sum of it -- the same bits on every rank and for every rank count.
+ *                              (device) the fixed-order sum of it -- the same bits on every rank, and for every rank count
+ *                              that gathers the SAME vector (a batch divisible by the rank count; uneven blocks are
+ *                              zero-padded to equal counts by the caller, which moves elements between the lanes of the
+ *                              sum: the totals then agree to rounding only).
  *                              Without a communicator (nranks = 1) it degenerates to copy + blr_logpdf_sum.
  *   blr_allreduce_sum          in-place sum over ranks of a device buffer (the `stats` / `scal` exchange of the N-sharded
  *                              single regressor below: is_f64 = 0 for float, 1 for double)

@@ -1,5 +1,9 @@
+import json
 import os
+import socket
+import subprocess
 import sys
+import tempfile
 
 import pytest
 
@@ -15,3 +19,62 @@ def pytest_configure(config):
 @pytest.fixture(scope="session")
 def repo_root():
     return ROOT
+
+
+# ---- bench.py with two ranks on a one-GPU box (tests/test_gpu_parity.py::test_bench_two_ranks_...) -------------------------------
+# The launcher and its workers must be STARTED before this process touches the GPU (a process that has initialised HIP must
+# not fork + exec on this pool), so they are spawned here, right after collection and before the first test runs; the test
+# itself only waits for them and reads their output.  torch.cuda.device_count() does not initialise the GPU.
+_BENCH_RUNS = {}
+
+
+def _free_port():
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        return s.getsockname()[1]
+
+
+def pytest_collection_finish(session):
+    if not any(item.name.startswith("test_bench_two_ranks") for item in session.items):
+        return
+    try:
+        import torch
+
+        if torch.cuda.device_count() < 1:
+            return
+    except Exception:
+        return
+    tmp = tempfile.mkdtemp(prefix="blr_bench2_")
+    common = ["bench.py", "--config", "c4", "--steps", "3", "--warmup", "1", "--cpu-seconds", "0", "--secondary", "0"]
+    env = dict(os.environ, BLR_BENCH_BACKEND="gloo", BLR_BENCH_SAME_DEVICE="1", MASTER_ADDR="127.0.0.1")
+    runs = {
+        "two": [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
+                "--master-port", str(_free_port())] + common + ["--gpus", "2"],
+        "one": [sys.executable] + common + ["--gpus", "1"],
+    }
+    for key, cmd in runs.items():
+        out = open(os.path.join(tmp, key + ".out"), "w")
+        err = open(os.path.join(tmp, key + ".err"), "w")
+        _BENCH_RUNS[key] = (subprocess.Popen(cmd, cwd=ROOT, env=env, stdout=out, stderr=err), out.name, err.name)
+
+
+@pytest.fixture(scope="session")
+def bench_two_rank_runs():
+    """-> {"one": json line of the 1-rank run, "two": json line of the 2-rank run} (both at --config c4), or skips."""
+    if not _BENCH_RUNS:
+        pytest.skip("the bench runs were not started (no GPU visible at collection time)")
+    res = {}
+    for key, (proc, out, err) in _BENCH_RUNS.items():
+        rc = proc.wait(timeout=900)
+        text = open(out).read()
+        assert rc == 0, f"bench ({key}) exited {rc}: {open(err).read()[-2000:]}"
+        lines = [ln for ln in text.splitlines() if ln.startswith("{")]
+        assert len(lines) == 1, f"bench ({key}) must print ONE JSON line, got {len(lines)}"
+        res[key] = json.loads(lines[0])
+    return res
+
+
+def pytest_sessionfinish(session, exitstatus):
+    for proc, _, _ in _BENCH_RUNS.values():
+        if proc.poll() is None:
+            proc.kill()

@@ -2055,6 +2055,55 @@ def test_wave_kernel_is_bitwise_reproducible(B):
         np.testing.assert_allclose(Tn.T @ Tn, L_o, rtol=1e-10, atol=1e-10 * np.abs(L_o).max())
 
 
+@pytest.mark.parametrize("nb", [8192, 1024])
+def test_c4_at_its_stated_batch_vs_literal_oracle(B, nb):
+    # BASELINE config 4 exactly as stated -- 8192 x (D = 64, N = 1024), fp64, isotropic noise, Lw = I -- and the 1024-regressor
+    # block one of 8 GPUs gets (the router's 2-wave split).  Nine regressors, from every round of the grid-stride loop (2048
+    # wave slots: rounds of 2048 regressors at one wave each, of 1024 at two), against the reference's LITERAL op sequence;
+    # all of them finite with info = 0; the same bits when the call is repeated.
+    import torch
+
+    a = B._abi
+    h = a.default_handle()
+    dev = torch.device("cuda:0")
+    D, N = 64, 1024
+    g = torch.Generator(device=dev).manual_seed(2024 + nb)
+    X = torch.randn((nb, N, D), generator=g, dtype=torch.float64, device=dev)
+    wstar = torch.randn((nb, D), generator=g, dtype=torch.float64, device=dev)
+    y = torch.einsum("bnd,bd->bn", X, wstar) + (0.1 ** 0.5) * torch.randn((nb, N), generator=g, dtype=torch.float64, device=dev)
+    s = torch.full((1,), 0.1, dtype=torch.float64, device=dev)
+    mw = torch.randn((nb, D), generator=g, dtype=torch.float64, device=dev)  # test/test_utils.jl:6: mw = randn(D)
+    dpr = torch.ones((D,), dtype=torch.float64, device=dev)
+    torch.cuda.synchronize()
+    outs = []
+    for _ in range(2):
+        mp = torch.empty((nb, D), dtype=torch.float64, device=dev)
+        Tp = torch.empty((nb, D, D), dtype=torch.float64, device=dev)
+        lp = torch.empty((nb,), dtype=torch.float64, device=dev)
+        info = torch.full((nb,), 7, dtype=torch.int32, device=dev)
+        h.posterior_batched(np.float64, a.MEM_DEVICE, a.LAYOUT_COLVECS, nb, D, N, X.data_ptr(), D, N * D, y.data_ptr(), N, a.NOISE_ISOTROPIC,
+                            s.data_ptr(), 0, a.PRIOR_DIAGONAL, mw.data_ptr(), D, dpr.data_ptr(), 1, 0, mp.data_ptr(), D, Tp.data_ptr(), D,
+                            D * D, None, D, D * D, lp.data_ptr(), info.data_ptr())
+        torch.cuda.synchronize()
+        assert int(info.abs().sum().item()) == 0
+        assert bool(torch.isfinite(lp).all().item()) and bool(torch.isfinite(mp).all().item())
+        outs.append((mp, Tp, lp))
+    for u, v in zip(outs[0], outs[1]):
+        assert torch.equal(u, v)
+    mp, Tp, lp = outs[0]
+    per_round = 2048 if nb >= 2048 else 1024  # wave slots per round at the router's split
+    picks = sorted({0, 1, per_round - 1, per_round % nb, (per_round + 1) % nb, (2 * per_round + 3) % nb, (3 * per_round + 17) % nb,
+                    nb // 2 + 5, nb - 1})
+    for b in picks:
+        Xb = X[b].cpu().numpy().T
+        args = (mw[b].cpu().numpy(), np.ones(D), Xb, 0.1, y[b].cpu().numpy())
+        mw_o, T_o, L_o = O.posterior_literal(*args)
+        assert lp[b].item() == pytest.approx(O.logpdf_literal(*args), rel=1e-10), b
+        np.testing.assert_allclose(mp[b].cpu().numpy(), mw_o, rtol=1e-8, atol=1e-10)
+        Tn = np.triu(Tp[b].cpu().numpy().T)
+        np.testing.assert_allclose(Tn.T @ Tn, L_o, rtol=1e-10, atol=1e-10 * np.abs(L_o).max())
+
+
 @pytest.mark.parametrize("with_comm", [False, True])
 @pytest.mark.parametrize("D,N,dtype", [(300, 700, np.float64), (64, 333, np.float64), (200, 1000, np.float32)])
 def test_posterior_nsharded_one_call(B, with_comm, D, N, dtype):
@@ -2183,3 +2232,22 @@ def test_evaluate_function_samples_in_one_pass(B):
     for j in range(6):
         np.testing.assert_allclose(Y[:, j], np.vstack([X, X ** 2]).T @ flat[j].w, rtol=1e-12, atol=1e-12)
 
+
+
+# ---- bench.py --gpus 2 on ONE GPU: the N > 1 code path of the measurement itself ----------------------------------
+def test_bench_two_ranks_strong_scaling_line(bench_two_rank_runs):
+    # `python -m torch.distributed.run --nproc-per-node 2 bench.py --config c4 --gpus 2` with both ranks on cuda:0 and the 64 KiB
+    # all-gather staged through gloo (tests/conftest.py starts it, and a one-rank run of the same fixed batch, before this process
+    # touches the GPU).  The line must describe BASELINE's strong-scaling case -- 8192 regressors in two contiguous blocks -- and
+    # the total log evidence must have the SAME BITS as the one-rank run: same regressors (chunk-seeded generation), same
+    # per-regressor kernel results wherever a regressor lives, one fixed-order sum over the gathered vector.
+    one, two = bench_two_rank_runs["one"], bench_two_rank_runs["two"]
+    assert two["n_gpus"] == 2 and one["n_gpus"] == 1
+    assert two["scaling"] == "strong" and one["scaling"] == "strong"
+    assert two["config"]["global_batch"] == 8192 and one["config"]["global_batch"] == 8192
+    assert two["config"]["batch_per_gpu"] == 4096
+    assert two["steps"] == 3 and two["warmup"] == 1
+    assert two["unit"] == "posterior-updates/s" and two["value"] > 0
+    assert np.isfinite(two["total_log_evidence"])
+    assert two["total_log_evidence"] == one["total_log_evidence"]  # bit for bit
+    assert two["roofline"]["frac"] > 0 and two["roofline"]["kernel"].startswith("fused_wave_kernel")

@@ -1,10 +1,15 @@
 // Microbenchmark: gram_iso_ring (the fused kernel's NB == 8 isotropic Gram loop) alone -- real LDS-DMA stream from HBM, real
 // barriers, no other phase.  Cycles per k-step per wave by s_memtime; 576 = nine back-to-back v_mfma_f64_16x16x4.
 //   hipcc --offload-arch=gfx950 -O3 -std=c++17 [-DRING_NOBAR] [-DRING_NORETIRE] -I../bayesianlinearregressors.jl_amd/csrc ring_probe.hip
+//   ./ring_probe N random(0|1) [sustain_seconds]
+// sustain_seconds > 0 (MI355X_MICROARCH.md, DVFS give-back item 6): each configuration is launched back to back for that
+// long BEFORE anything is read; the clock is the MEDIAN over workgroups of delta s_memtime / delta s_memrealtime x 100 MHz of
+// the LAST launch, the TFLOP/s come from HIP events around the last quarter of the launches.
 #include <hip/hip_runtime.h>
 #include <cstdio>
 #include <cstdlib>
 #include <vector>
+#include <algorithm>
 #include "blr_fused_small.hpp"
 using namespace blr;
 #ifndef RING_MWZ
@@ -66,6 +71,7 @@ int main(int argc, char** argv) {
   CK(hipGetDeviceProperties(&p, 0));
   const int cus = p.multiProcessorCount;
   const int N = argc > 1 ? atoi(argv[1]) : 16384;
+  const double sustain = argc > 3 ? atof(argv[3]) : 0.0;
   const int maxB = cus * RING_WPS;
   double *X, *y, *out; Stamp* st;
   CK(hipMalloc((void**)&X, (size_t)maxB * N * 128 * 8)); CK(hipMemset(X, 0, (size_t)maxB * N * 128 * 8));
@@ -85,18 +91,38 @@ int main(int argc, char** argv) {
       const int grid = cus * wps;
       hipEvent_t e0, e1; CK(hipEventCreate(&e0)); CK(hipEventCreate(&e1));
       float ms = 0;
-      for (int rep = 0; rep < 3; ++rep) {
+      int launches = 3;
+      if (sustain > 0) {
+        // calibrate, then queue `sustain` seconds of back-to-back launches (nothing synchronises in between); the events
+        // bracket the last quarter
         CK(hipEventRecord(e0));
         k_ring<<<grid, 256, kLds>>>(X, y, N, share ? 0 : (int64_t)N * 128, out, st);
         CK(hipEventRecord(e1)); CK(hipEventSynchronize(e1)); CK(hipEventElapsedTime(&ms, e0, e1));
+        launches = (int)(sustain * 1e3 / ms) + 4;
+        const int tail = launches / 4;
+        for (int rep = 0; rep < launches; ++rep) {
+          if (rep == launches - tail) CK(hipEventRecord(e0));
+          k_ring<<<grid, 256, kLds>>>(X, y, N, share ? 0 : (int64_t)N * 128, out, st);
+        }
+        CK(hipEventRecord(e1)); CK(hipEventSynchronize(e1)); CK(hipEventElapsedTime(&ms, e0, e1));
+        ms /= tail;
+      } else {
+        for (int rep = 0; rep < 3; ++rep) {
+          CK(hipEventRecord(e0));
+          k_ring<<<grid, 256, kLds>>>(X, y, N, share ? 0 : (int64_t)N * 128, out, st);
+          CK(hipEventRecord(e1)); CK(hipEventSynchronize(e1)); CK(hipEventElapsedTime(&ms, e0, e1));
+        }
       }
       std::vector<Stamp> h(grid * 4);
       CK(hipMemcpy(h.data(), st, h.size() * sizeof(Stamp), hipMemcpyDeviceToHost));
       double c = 0, r = 0;
-      for (auto& s : h) { c += (double)s.cyc; r += (double)s.rt; }
-      printf("ring loop, N=%d, %d WG/CU, X %s: %8.3f ms  %7.1f cycles/k-step/wave  clock %.2f GHz  %6.1f TFLOP/s (matrix)  %5.2f TB/s\n", N, wps,
-             share ? "shared (cache)" : "streamed (HBM)", ms, c / h.size() / (N / 4), c / r * 0.1, (double)grid * 4 * (N / 4) * 9 * 2048.0 / ms / 1e9,
-             share ? 0.0 : (double)grid * N * 1024.0 / ms / 1e9);
+      std::vector<double> clk;
+      for (auto& s : h) { c += (double)s.cyc; r += (double)s.rt; clk.push_back((double)s.cyc / (double)s.rt * 0.1); }
+      std::sort(clk.begin(), clk.end());
+      printf("ring loop, N=%d, %d WG/CU, X %s: %8.3f ms  %7.1f cycles/k-step/wave  clock %.2f GHz (median over %zu waves %.3f, min %.3f, max %.3f)  %6.1f TFLOP/s (matrix)  %5.2f TB/s  [%d launches back to back%s]\n", N, wps,
+             share ? "shared (cache)" : "streamed (HBM)", ms, c / h.size() / (N / 4), c / r * 0.1, clk.size(), clk[clk.size() / 2], clk.front(), clk.back(),
+             (double)grid * 4 * (N / 4) * 9 * 2048.0 / ms / 1e9, share ? 0.0 : (double)grid * N * 1024.0 / ms / 1e9, launches,
+             sustain > 0 ? ", timed over the last quarter" : "");
     }
   return 0;
 }
