@@ -25,6 +25,7 @@
 #include "blr_dense.hpp"
 #include "blr_update.hpp"
 #include "blr_fused_wave.hpp"
+#include "blr_fused_i8.hpp"
 
 using namespace blr;
 
@@ -32,7 +33,7 @@ using namespace blr;
 // handle is created (BLR_MI355X_<KEY>), and settable per handle with blr_set_option: no getenv on any launch path.
 struct BlrOptions {
   bool no_ldsdma = false, no_wave_kernel = false, no_gram_ring = false, no_diag_split = false, no_xcd_swizzle = false,
-       no_mfma_project = false, plan_debug = false;
+       no_mfma_project = false, plan_debug = false, no_i8_gram = false;
   int wave_split = 0;     // waves per regressor of the wave kernel: 0 = router, else 1 | 2 | 4
   int chain_batch = 0;    // regressors per shared launch at D > 128: 0 = as many as the workspace holds
   long chain_ws_mb = 0;   // workspace bound of such a group in MiB: 0 = kChainWorkspace
@@ -51,6 +52,7 @@ struct BlrOptions {
     if (!strcmp(key, "NO_XCD_SWIZZLE")) return flag(no_xcd_swizzle);
     if (!strcmp(key, "NO_MFMA_PROJECT")) return flag(no_mfma_project);
     if (!strcmp(key, "PLAN_DEBUG")) return flag(plan_debug);
+    if (!strcmp(key, "NO_I8_GRAM")) return flag(no_i8_gram);
     if (!strcmp(key, "WAVE_SPLIT")) {
       const int v = on ? atoi(value) : 0;
       wave_split = (v == 1 || v == 2 || v == 4) ? v : 0;
@@ -71,7 +73,7 @@ struct BlrOptions {
   }
   void from_environment() {
     for (const char* k : {"NO_LDSDMA", "NO_WAVE_KERNEL", "NO_GRAM_RING", "NO_DIAG_SPLIT", "NO_XCD_SWIZZLE", "NO_MFMA_PROJECT", "PLAN_DEBUG",
-                          "WAVE_SPLIT", "CHAIN_BATCH", "CHAIN_WS_MB", "SWEEP", "GRAM_SPLITS"}) {
+                          "NO_I8_GRAM", "WAVE_SPLIT", "CHAIN_BATCH", "CHAIN_WS_MB", "SWEEP", "GRAM_SPLITS"}) {
       const std::string name = std::string("BLR_MI355X_") + k;
       if (const char* v = getenv(name.c_str())) (void)set(k, *v ? v : "1");  // (an empty variable still switches a flag on)
     }
@@ -325,9 +327,40 @@ int launch_fused_wave(blr_handle* h, const PosteriorArgs<T>& a) {
   return launch_fused_wave_nw<T, NB, 4>(h, a);
 }
 
+// D = 128, fp64, aligned ColVecs, isotropic noise, diagonal prior, whole 32-column k-steps: the Gram matrix on the int8 matrix
+// cores (blr_fused_i8.hpp), followed by the fp64 kernel in retry-only mode for the regressors the fast path handed back
+// (non-zero prior mean, a row bound broken, non-finite input): every regressor leaves with the status and the numbers of an
+// fp64-accurate update, none is computed twice on the fast path.
+int launch_fused_i8(blr_handle* h, const PosteriorArgs<double>& a) {
+  int rc = set_lds_once(h, reinterpret_cast<const void*>(fused_i8_kernel), (size_t)I8Cfg::LDS_BYTES);
+  if (rc) return rc;
+  const int grid = (int)std::min<int64_t>(a.B, 1 << 20);
+  for (int64_t b0 = 0; b0 < a.B; b0 += grid) {  // (one workgroup per regressor: batches beyond 2^20 in slices)
+    PosteriorArgs<double> s = a;
+    const int nb = (int)std::min<int64_t>(grid, a.B - b0);
+    s.B = nb;
+    s.X += b0 * a.strideX; s.y += b0 * a.stridey; s.s += b0 * a.strides; s.mw += b0 * a.stridemw; s.Lw += b0 * a.strideLw;
+    if (s.mw_post) s.mw_post += b0 * a.stride_mwpost;
+    if (s.T_post) s.T_post += b0 * a.strideT;
+    if (s.Lw_post) s.Lw_post += b0 * a.strideLp;
+    if (s.logpdf) s.logpdf += b0;
+    s.info += b0;
+    hipLaunchKernelGGL(fused_i8_kernel, dim3(nb), dim3(kI8Threads), I8Cfg::LDS_BYTES, h->stream, s, 0, 0);
+    HIP_TRY(h, hipGetLastError());
+    s.retry_only = 1;
+    if ((rc = launch_fused_small<double, 8, 4>(h, s))) return rc;
+  }
+  return 0;
+}
+
 template <typename T>
 int dispatch_fused_small(blr_handle* h, const PosteriorArgs<T>& a) {
   int NB = (a.D + 15) / 16;
+  if constexpr (sizeof(T) == 8) {
+    if (!h->opt.no_i8_gram && !h->opt.no_ldsdma && a.D == 128 && a.layout == BLR_LAYOUT_COLVECS && a.vec_ok && a.noise_kind == BLR_NOISE_ISOTROPIC &&
+        a.prior_kind == BLR_PRIOR_DIAGONAL && a.N >= kI8MinN && a.N <= kI8MaxN && a.N % I8Cfg::KC == 0 && a.ldx * 8 * I8Cfg::KC < ((int64_t)1 << 31))
+      return launch_fused_i8(h, a);
+  }
   if (!h->opt.no_wave_kernel && a.layout == BLR_LAYOUT_COLVECS && a.vec_ok && a.D == 16 * NB &&
       (3 * a.ldx + 64) * (int64_t)sizeof(T) < ((int64_t)1 << 31)) {
     if (NB == 4) return launch_fused_wave<T, 4>(h, a);

@@ -124,7 +124,9 @@ struct PosteriorArgs {
   int layout, noise_kind, prior_kind;
   int D, N, B;
   int vec_ok;  // ColVecs, 16-byte aligned columns: vector loads allowed
+  int retry_only;  // fused_small_kernel: take only the regressors whose info word says kI8Retry (follow-up of fused_i8_kernel)
 };
+constexpr int kI8RetryCode = (int)0x80000007u;  // == kI8Retry (blr_fused_i8.hpp)
 
 // per-regressor context handed to the phase functions through LDS (uniform values)
 template <typename T>
@@ -1401,6 +1403,7 @@ __global__ __launch_bounds__(kThreads, (NB <= 4 ? 4 : (sizeof(T) == 4 ? BLR_F32_
   const double kNaN = __longlong_as_double(0x7ff8000000000000LL);
 
   for (int reg = blockIdx.x; reg < a.B; reg += gridDim.x) {
+    if (a.retry_only && a.info[reg] != kI8RetryCode) continue;  // (uniform; the int8 kernel finished this regressor)
     const T* mw = a.mw + (int64_t)reg * a.stridemw;
     const T* Lw = a.Lw + (int64_t)reg * a.strideLw;
     __syncthreads();  // previous regressor fully done with LDS

@@ -1,0 +1,137 @@
+// Development harness for fused_i8_kernel (blr_fused_i8.hpp): B synthetic regressors at D = 128, fp64, aligned ColVecs, isotropic
+// noise, diagonal prior; timed with HIP events; every output compared with fused_small_kernel<double, 8, 4> on the same inputs
+// (and the first regressors' evidence with a plain host evaluation).  Not part of the product.
+//   hipcc --offload-arch=gfx950 -O3 -std=c++17 -I../bayesianlinearregressors.jl_amd/csrc i8_gram.hip -o i8_gram
+//   ./i8_gram [B] [N] [reps] [mode]     mode 0: N(0,1) inputs   1: one outlier per regressor (retry path)   2: rows of very different scale
+#include <hip/hip_runtime.h>
+#include <algorithm>
+#include <cmath>
+#include <cstdio>
+#include <cstdlib>
+#include <vector>
+#include "blr_fused_i8.hpp"
+using namespace blr;
+#define CK(x) do { hipError_t e_ = (x); if (e_ != hipSuccess) { printf("HIP error %s at %d\n", hipGetErrorString(e_), __LINE__); return 1; } } while (0)
+
+int main(int argc, char** argv) {
+  typedef double T;
+  constexpr int D = 128;
+  const int B = argc > 1 ? atoi(argv[1]) : 4096;
+  const int N = argc > 2 ? atoi(argv[2]) : 4096;
+  const int reps = argc > 3 ? atoi(argv[3]) : 10;
+  const int mode = argc > 4 ? atoi(argv[4]) : 0;
+  const int BU = std::min(B, 32);
+  std::vector<T> X((size_t)BU * N * D), y((size_t)BU * N), mw(D, T(0)), dpr(D);
+  unsigned long long st = 88172645463325252ULL;
+  auto rnd = [&]() { st ^= st << 13; st ^= st >> 7; st ^= st << 17; return (double)(st >> 11) / 9007199254740992.0; };
+  auto gauss = [&]() { return std::sqrt(-2.0 * std::log(rnd() + 1e-300)) * std::cos(6.283185307179586 * rnd()); };
+  for (auto& v : X) v = gauss();
+  for (auto& v : y) v = 3.0 * gauss();
+  for (int i = 0; i < D; ++i) dpr[i] = 0.5 + rnd();
+  if (mode == 2)
+    for (int b = 0; b < BU; ++b)
+      for (int n = 0; n < N; ++n)
+        for (int i = 0; i < D; ++i) X[((size_t)b * N + n) * D + i] *= std::ldexp(1.0, (i % 7) * 9 - 27);  // rows from 2^-27 to 2^27
+  if (mode == 1)
+    for (int b = 0; b < BU; b += 2) X[((size_t)b * N + N / 2) * D + 5] = 1.0e6;  // breaks the row bound of every other regressor
+  const T s_iso = 0.1;
+  T *dX, *dy, *ds, *dmw, *dpri; CK(hipMalloc((void**)&dX, (size_t)B * N * D * 8)); CK(hipMalloc((void**)&dy, (size_t)B * N * 8));
+  CK(hipMalloc((void**)&ds, 8)); CK(hipMalloc((void**)&dmw, D * 8)); CK(hipMalloc((void**)&dpri, D * 8));
+  for (int b0 = 0; b0 < B; b0 += BU) {
+    const int nb = std::min(BU, B - b0);
+    CK(hipMemcpy(dX + (size_t)b0 * N * D, X.data(), (size_t)nb * N * D * 8, hipMemcpyHostToDevice));
+    CK(hipMemcpy(dy + (size_t)b0 * N, y.data(), (size_t)nb * N * 8, hipMemcpyHostToDevice));
+  }
+  CK(hipMemcpy(ds, &s_iso, 8, hipMemcpyHostToDevice)); CK(hipMemcpy(dmw, mw.data(), D * 8, hipMemcpyHostToDevice));
+  CK(hipMemcpy(dpri, dpr.data(), D * 8, hipMemcpyHostToDevice));
+  struct Out { T *mwp, *Tp, *Lp; double* lp; int32_t* info; } o[2];
+  for (int k = 0; k < 2; ++k) {
+    CK(hipMalloc((void**)&o[k].mwp, (size_t)B * D * 8)); CK(hipMalloc((void**)&o[k].Tp, (size_t)B * D * D * 8));
+    CK(hipMalloc((void**)&o[k].Lp, (size_t)BU * D * D * 8));
+    CK(hipMalloc((void**)&o[k].lp, (size_t)B * 8)); CK(hipMalloc((void**)&o[k].info, (size_t)B * 4));
+    CK(hipMemset(o[k].info, 0xff, (size_t)B * 4));
+  }
+  auto args = [&](int k) {
+    PosteriorArgs<T> a{};
+    a.X = dX; a.ldx = D; a.strideX = (int64_t)N * D; a.y = dy; a.stridey = N; a.s = ds; a.strides = 0;
+    a.mw = dmw; a.stridemw = 0; a.Lw = dpri; a.ldl = 1; a.strideLw = 0;
+    a.mw_post = o[k].mwp; a.stride_mwpost = D; a.T_post = o[k].Tp; a.ldt = D; a.strideT = D * D; a.Lw_post = nullptr;
+    a.logpdf = o[k].lp; a.info = o[k].info; a.layout = LAYOUT_COLVECS; a.noise_kind = NOISE_ISOTROPIC;
+    a.prior_kind = PRIOR_DIAGONAL; a.D = D; a.N = N; a.B = B; a.vec_ok = 1;
+    return a;
+  };
+  using SC = SmallCfg<T, 8>;
+  auto k64 = fused_small_kernel<T, 8, 4>;
+  CK(hipFuncSetAttribute(reinterpret_cast<const void*>(k64), hipFuncAttributeMaxDynamicSharedMemorySize, SC::LDS_BYTES));
+  CK(hipFuncSetAttribute(reinterpret_cast<const void*>(fused_i8_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, I8Cfg::LDS_BYTES));
+  const int stag_first = getenv("I8_STAG_FIRST") ? atoi(getenv("I8_STAG_FIRST")) : (B >= 1024 ? 256 : 0);
+  const int stag_ticks = getenv("I8_STAG_TICKS") ? atoi(getenv("I8_STAG_TICKS")) : 25000;  // 250 us
+  auto run_i8 = [&](bool lp_only) {
+    PosteriorArgs<T> a = args(0);
+    if (lp_only) { a.mw_post = nullptr; a.T_post = nullptr; }
+    hipLaunchKernelGGL(fused_i8_kernel, dim3(B), dim3(kI8Threads), I8Cfg::LDS_BYTES, 0, a, stag_first, stag_ticks);
+    a.retry_only = 1;
+    hipLaunchKernelGGL(k64, dim3(B), dim3(kThreads), SC::LDS_BYTES, 0, a);
+  };
+  auto run_f64 = [&]() { PosteriorArgs<T> a = args(1); hipLaunchKernelGGL(k64, dim3(B), dim3(kThreads), SC::LDS_BYTES, 0, a); };
+  hipEvent_t e0, e1; CK(hipEventCreate(&e0)); CK(hipEventCreate(&e1));
+  float ms_i8, ms_f64;
+  for (int w = 0; w < 2; ++w) run_i8(false);
+  CK(hipDeviceSynchronize()); CK(hipGetLastError());
+  CK(hipEventRecord(e0));
+  for (int r = 0; r < reps; ++r) run_i8(false);
+  CK(hipEventRecord(e1)); CK(hipEventSynchronize(e1)); CK(hipEventElapsedTime(&ms_i8, e0, e1)); ms_i8 /= reps;
+  { PosteriorArgs<T> a = args(0); a.Lw_post = o[0].Lp; a.ldlp = D; a.strideLp = D * D; a.B = BU;
+    hipLaunchKernelGGL(fused_i8_kernel, dim3(BU), dim3(kI8Threads), I8Cfg::LDS_BYTES, 0, a, 0, 0); a.retry_only = 1;
+    hipLaunchKernelGGL(k64, dim3(BU), dim3(kThreads), SC::LDS_BYTES, 0, a); }
+  run_f64(); CK(hipDeviceSynchronize());
+  CK(hipEventRecord(e0));
+  for (int r = 0; r < std::max(1, reps / 3); ++r) run_f64();
+  CK(hipEventRecord(e1)); CK(hipEventSynchronize(e1)); CK(hipEventElapsedTime(&ms_f64, e0, e1)); ms_f64 /= std::max(1, reps / 3);
+  { PosteriorArgs<T> a = args(1); a.Lw_post = o[1].Lp; a.ldlp = D; a.strideLp = D * D; a.B = BU; hipLaunchKernelGGL(k64, dim3(BU), dim3(kThreads), SC::LDS_BYTES, 0, a); }
+  CK(hipDeviceSynchronize());
+#ifdef BLR_I8_STAMPS
+  {
+    unsigned long long z[8][8] = {};
+    CK(hipMemcpyToSymbol(HIP_SYMBOL(g_i8stamps), z, sizeof(z)));
+    PosteriorArgs<T> a = args(0);
+    hipLaunchKernelGGL(fused_i8_kernel, dim3(B), dim3(kI8Threads), I8Cfg::LDS_BYTES, 0, a, 0, 0);
+    CK(hipDeviceSynchronize());
+    CK(hipMemcpyFromSymbol(z, HIP_SYMBOL(g_i8stamps), sizeof(z)));
+    const double nk = N / 32;
+    for (int w = 0; w < 8; ++w)
+      printf("  wave %d of WG 0, cycles per k-step: MFMA %6.0f | slicing %6.0f | DMA wait + barrier %6.0f | DMA issue %5.0f || stream %8llu | hand-over + conversion %7llu | chol %7llu | backsolve + out %7llu\n",
+             w, z[w][0] / nk, z[w][1] / nk, z[w][2] / nk, z[w][3] / nk, z[w][4], z[w][5], z[w][6], z[w][7]);
+  }
+#endif
+  // compare
+  std::vector<double> lp0(B), lp1(B); std::vector<int32_t> i0(B), i1(B);
+  CK(hipMemcpy(lp0.data(), o[0].lp, (size_t)B * 8, hipMemcpyDeviceToHost)); CK(hipMemcpy(lp1.data(), o[1].lp, (size_t)B * 8, hipMemcpyDeviceToHost));
+  CK(hipMemcpy(i0.data(), o[0].info, (size_t)B * 4, hipMemcpyDeviceToHost)); CK(hipMemcpy(i1.data(), o[1].info, (size_t)B * 4, hipMemcpyDeviceToHost));
+  std::vector<T> m0((size_t)BU * D), m1((size_t)BU * D), T0((size_t)BU * D * D), T1((size_t)BU * D * D), A0((size_t)BU * D * D), A1((size_t)BU * D * D);
+  CK(hipMemcpy(m0.data(), o[0].mwp, m0.size() * 8, hipMemcpyDeviceToHost)); CK(hipMemcpy(m1.data(), o[1].mwp, m1.size() * 8, hipMemcpyDeviceToHost));
+  CK(hipMemcpy(T0.data(), o[0].Tp, T0.size() * 8, hipMemcpyDeviceToHost)); CK(hipMemcpy(T1.data(), o[1].Tp, T1.size() * 8, hipMemcpyDeviceToHost));
+  CK(hipMemcpy(A0.data(), o[0].Lp, A0.size() * 8, hipMemcpyDeviceToHost)); CK(hipMemcpy(A1.data(), o[1].Lp, A1.size() * 8, hipMemcpyDeviceToHost));
+  double e_lp = 0, e_m = 0, e_T = 0, e_A = 0; int bad = 0, exact_lp = 0;
+  for (int b = 0; b < B; ++b) {
+    if (i0[b] != i1[b] || i0[b] != 0) ++bad;
+    e_lp = std::max(e_lp, std::fabs(lp0[b] - lp1[b]) / std::fabs(lp1[b]));
+    if (lp0[b] == lp1[b]) ++exact_lp;
+    if (lp0[b] != lp0[b % BU]) ++bad;  // replicas of one input must agree bit for bit
+  }
+  for (int b = 0; b < BU; ++b) {
+    double mm = 0, tm = 0, am = 0;
+    for (int i = 0; i < D; ++i) mm = std::max(mm, std::fabs(m1[(size_t)b * D + i]));
+    for (size_t i = 0; i < (size_t)D * D; ++i) { tm = std::max(tm, std::fabs(T1[(size_t)b * D * D + i])); am = std::max(am, std::fabs(A1[(size_t)b * D * D + i])); }
+    for (int i = 0; i < D; ++i) e_m = std::max(e_m, std::fabs(m0[(size_t)b * D + i] - m1[(size_t)b * D + i]) / mm);
+    for (size_t i = 0; i < (size_t)D * D; ++i) {
+      e_T = std::max(e_T, std::fabs(T0[(size_t)b * D * D + i] - T1[(size_t)b * D * D + i]) / tm);
+      e_A = std::max(e_A, std::fabs(A0[(size_t)b * D * D + i] - A1[(size_t)b * D * D + i]) / am);
+    }
+  }
+  printf("D=128 N=%d B=%d mode %d: int8 path %.3f ms/launch = %.3f M updates/s (%.2f TB/s of X) | fp64 kernel %.3f ms = %.3f M updates/s\n", N, B, mode,
+         ms_i8, B / ms_i8 / 1e3, (double)B * N * D * 8 / ms_i8 / 1e9, ms_f64, B / ms_f64 / 1e3);
+  printf("  int8 vs fp64 kernel: logpdf max rel diff %.2e (%d of %d bit-equal) | A = Lw' max |diff| / max|A| %.2e | mw' %.2e | T %.2e | status/replica mismatches %d\n",
+         e_lp, exact_lp, B, e_A, e_m, e_T, bad);
+  return bad != 0 || !(e_lp < 1e-11) || !(e_m < 1e-9) || !(e_T < 1e-9);
+}
