@@ -345,7 +345,7 @@ int launch_fused_i8(blr_handle* h, const PosteriorArgs<double>& a) {
     if (s.Lw_post) s.Lw_post += b0 * a.strideLp;
     if (s.logpdf) s.logpdf += b0;
     s.info += b0;
-    hipLaunchKernelGGL(fused_i8_kernel, dim3(nb), dim3(kI8Threads), I8Cfg::LDS_BYTES, h->stream, s, 0, 0);
+    hipLaunchKernelGGL(fused_i8_kernel, dim3(nb), dim3(kI8Threads), I8Cfg::LDS_BYTES, h->stream, s);
     HIP_TRY(h, hipGetLastError());
     s.retry_only = 1;
     if ((rc = launch_fused_small<double, 8, 4>(h, s))) return rc;

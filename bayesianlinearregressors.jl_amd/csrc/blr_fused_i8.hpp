@@ -2,8 +2,8 @@
 // prior) with the Gram matrix on the INT8 matrix cores: an Ozaki-style exact splitting of the fp64 inputs.
 //
 // Why: the f64 matrix pipe (v_mfma_f64_16x16x4, 78.6 TF spec) bounds fused_small_kernel at ~0.75 M updates/s at the clock
-// the part holds under that load (profiles/r04_microbench_ring_probe_sustained.txt); the same Gram costs 1/4 of the matrix-pipe
-// time on v_mfma_i32_32x32x32_i8 and is then bound by the HBM stream of X (4.2 MB per update).
+// the part holds under that load (profiles/r04_microbench_ring_probe_sustained.txt); the same Gram costs a third of the
+// matrix-pipe time on v_mfma_i32_32x32x32_i8 and is then bound by the HBM stream of X (4.2 MB per update).
 //
 // Arithmetic (reference src/bayesian_linear_regression.jl:86, G = X X'):
 //   per row i of X a power of two 2^e_i bounds every |x_in| (e_i = exponent of the row's largest entry in the first 32
@@ -15,24 +15,33 @@
 //   ones are stored as a_s = d_s - 128 (one XOR) so that every operand of the signed int8 MFMA fits;
 //   sum_n Q_in Q_jn = sum_{s,t} 2^(8 (10 - s - t)) sum_n (a_is + o_s)(a_jt + o_t),  o_0 = 0, o_s = 128:
 //       the products sum_n a_is a_jt come out of the matrix cores EXACTLY (int32, |.| < 2^29 for N <= 16384), grouped by
-//       k = s + t (one accumulator per group: 21 digit pairs with k <= 5, the dropped ones are below 2^-46 of the row scales);
-//       the offset terms are rank-one: 128 (sum_{s<k} R_s(i) + sum_{t<k} R_t(j)) + 16384 N max(0, k - 1), with the digit row
-//       sums R_s(i) = sum_n a_is from one v_dot4 per packed dword;
-//   G_ij = 2^(e_i + e_j - 94) sum_k 2^(80 - 8k) [P_k(i,j) + V_k(i) + V_k(j) + c_k], evaluated once per regressor in fp64.
-// Error: |x_in - 2^(e_i - 47) Q_in| <= 2^(e_i - 48), unbiased; for N(0,1) inputs the Gram matrix is within ~4e-15 of its
-// diagonal scale -- the same order as the fp64 summation error of the reference's SYRK (parity tests unchanged, fp64
-// tolerances: logpdf 1e-11, mw', T 1e-9).
+//       k = s + t, one accumulator per group, for the 26 digit pairs with k <= 6;
+//       the offset terms are rank-one -- 128 (sum_s R_s(i) + sum_t R_t(j)) over the partners of group k, + 16384 N per pair of
+//       offset digits, with the digit row sums R_s(i) = sum_n a_is from one v_dot4 per packed dword -- and are kept for ALL
+//       36 pairs (the unsigned digits have mean 127.5: the dropped pairs' offset parts are systematic, their centred
+//       products are zero-mean);
+//   G_ij = 2^(e_i + e_j - 94) sum_k 2^(80 - 8k) [P_k(i,j) + V_k(i) + V_k(j)], evaluated once per regressor in fp64.
+// Error: rounding |x_in - 2^(e_i - 47) Q_in| <= 2^(e_i - 48), unbiased (6e-15 of the diagonal scale on N(0,1) inputs);
+// dropped: centred products of the groups k >= 7, 2^-52 of the diagonal scale.  (With k <= 5 only -- 21 pairs, the first
+// version -- the dropped group 6 is 2^-43: 1.5e-13 of the diagonal scale, which costs the evidence three digits whenever
+// the data are well explained, y'Sy and |u|^2 cancelling; measured, tools/i8_gram.hip.)
 //
-// Structure: ONE 512-thread workgroup per regressor and CU (8 waves, two per SIMD, <= 256 registers each).
+// Structure: ONE 512-thread workgroup per regressor and CU (8 waves, two per SIMD, <= 256 registers each): the 10 lower 32 x 32
+// tiles x 7 digit groups are 70 accumulators of 16 registers, at most 9 per wave.
 //   * X streams HBM -> LDS by LDS-DMA, one 1 KiB piece per column, through a ring of three 32-column slots (two in flight);
 //   * every thread owns one row and 8 columns of a 32-column k-step: magic add, byte transposition with v_perm_b32, digit
 //     planes to LDS in MFMA fragment order (double-buffered), b += x y in fp64 on the way;
-//   * the 10 lower 32 x 32 tiles x 6 digit groups are dealt to the 8 waves so that the two waves of every SIMD carry 52-53
-//     MFMAs per k-step between them and no wave more than 8 accumulators (table in I8Items);
-//   * inside a k-step the ~100 vector instructions of a wave's slicing are dealt into the shadows of its own MFMAs
-//     (sched_group_barrier); ONE workgroup barrier per k-step;
+//   * (tile, group range) items are dealt to the 8 waves so that the two waves of a SIMD (w, w + 4) carry 64 - 67 MFMAs per k-step
+//     between them (table in I8Items);
+//   * inside a k-step the order is pinned by hand: MFMA, then (in its 32-cycle shadow) the fragment reads two MFMAs ahead
+//     and one of 14 chunks of the slicing; ONE workgroup barrier per k-step;
 //   * after the stream: accumulators -> fp64 -> packed triangle of A in LDS; waves 4-7 exit; waves 0-3 run the phases of
 //     fused_small_kernel (blocked Cholesky, substitutions, evidence) unchanged.
+// (Measured alternatives, tools/i8_gram.hip: four waves with the whole register file each -- no register pressure, but one wave
+// per SIMD cannot keep the matrix pipe fed next to the slicing and the DMA issue: 4000 cycles per k-step against 3000; the
+// factorisations as a second launch with two workgroups per CU: 4.9 ms per 4096 updates against 4.7, the stream-only kernel
+// runs at a lower clock; staggered starts of the workgroups, static priority for waves 4-7, cache-warming touches three
+// k-steps ahead: no gain or a loss.  The stream is bound by what one CU pulls from HBM, ~25 GB/s.)
 #pragma once
 #include "blr_fused_small.hpp"
 
@@ -40,12 +49,12 @@ namespace blr {
 
 constexpr int kI8Threads = 512;
 constexpr int kI8Retry = kI8RetryCode;  // info: "this regressor must be redone by the fp64 kernel" (never returned to callers)
-constexpr int kI8Margin = 3;                // binades of headroom above the first block's row maximum
-constexpr int kI8MaxN = 16384;              // int32 accumulators: 6 N 2^14 < 2^31
-constexpr int kI8MinN = 512;                // below, the fixed costs of the fast path buy nothing
+constexpr int kI8Margin = 3;            // binades of headroom above the first block's row maximum
+constexpr int kI8MaxN = 16384;          // int32 accumulators: 6 N 2^14 < 2^31
+constexpr int kI8MinN = 512;            // below, the fixed costs of the fast path buy nothing
 
 // BLR_I8_STAMPS: diagnostic builds only (tools/i8_gram.hip): cycle sums of workgroup 0, one row per wave --
-//   [0] MFMAs of the k-steps  [1] slicing  [2] DMA wait + barrier  [3] DMA issue  [4] whole stream  [5] hand-over + conversion
+//   [0] the k-steps (MFMAs + slicing)  [2] DMA wait + barrier  [4] whole stream  [5] hand-over + conversion
 //   [6] factorisation  [7] back substitution + outputs
 #ifdef BLR_I8_STAMPS
 __device__ unsigned long long g_i8stamps[8][8];
@@ -74,75 +83,85 @@ struct I8Cfg {
   static constexpr int OFF_YB = OFF_DIG + 2 * DIG_BUF;          // y ring: NSLOT x 32 doubles
   static constexpr int OFF_XCH = OFF_YB + NSLOT * KC * 8;       // exchange: 4 x 6 x 128 ints (row sums; row maxima first)
   static constexpr int OFF_FLAG = OFF_XCH + 4 * 6 * 128 * 4;    // 16 ints
-  static constexpr int OFF_SINK = OFF_FLAG + 64;                // 4 x 256 B nobody reads: destination of the cache-warming touches
-  static constexpr int LDS_BYTES = OFF_SINK + 4 * 256;
+  static constexpr int LDS_BYTES = OFF_FLAG + 64;
   // after the stream the ring is dead: P, bvec, ... of SmallCfg<double, 8> live there (phase_chol / phase_backsolve layout);
   // the conversion tables live in the digit area
   static constexpr int OFF_VTAB = OFF_DIG;                      // offset-term tables TA, TB, TC: 3 x 128 doubles
   static constexpr int OFF_SC = OFF_VTAB + 3 * 128 * 8;         // 2^(e_i - 47): 128 doubles
   static constexpr int OFF_BRED = OFF_SC + 128 * 8;             // b partials: 4 x 128 doubles
-  static constexpr int OFF_SQ3 = OFF_BRED + 4 * 128 * 8;        // sum_n a_3^2 partials: 4 x 128 ints
   static_assert(SmallCfg<double, 8>::LDS_BYTES <= RING_BYTES, "the phase functions' LDS image must fit in the dead ring");
-  static_assert(OFF_SQ3 + 4 * 128 * 4 <= OFF_YB, "conversion tables must fit in the digit area");
+  static_assert(OFF_BRED + 4 * 128 * 8 <= OFF_YB, "conversion tables must fit in the digit area");
   static_assert(LDS_BYTES <= 160 * 1024, "LDS of one CU");
 };
 
 // ---- which (tile, digit groups) a wave owns ------------------------------------------------------------------------------------
-// item = tile (I, K) of 32 x 32 (I >= K), groups k0..k1 (k = s + t).  Work of a group = k + 1 MFMAs per k-step, 16 registers.
-// 10 tiles x 6 groups = 60 accumulators of 16 registers = 210 MFMAs per k-step, dealt so that no wave holds more than 8
-// accumulators (128 registers: the slicing shares the register file) and the two waves of a SIMD (w and w + 4) carry 52 or 53
-// MFMAs between them:
-//   waves 0-3: a whole diagonal tile (21) + groups 4, 5 of an off-diagonal tile of a neighbouring row block (11): 32, 8 accumulators,
-//              12 fragments per k-step (the off-diagonal tile's B side IS the diagonal tile's row block or its A side)
-//   waves 4-5: groups 0..3 of two of those off-diagonal tiles (10 + 10): 8 accumulators
-//   waves 6-7: a whole off-diagonal tile (21): 6 accumulators
-// `second`: the item ADDS to entries another wave's item has stored (the other half of the same tile), one barrier later.
-struct I8Item { int I, K, k0, k1, second; };
+// item = tile (I, K) of 32 x 32 (I >= K), groups k0..k1 (k = s + t; s, t <= 5).  Work of group k = min(k, 5) - max(0, k - 5) + 1
+// MFMAs per k-step (1 2 3 4 5 6 5: 26 per tile), 16 registers.  70 accumulators, 260 MFMAs per k-step, dealt by a small search
+// (at most 9 accumulators per wave -- the slicing shares the 256 registers -- and SIMD partners w, w + 4 balanced):
+//   MFMAs:  w0 35 + w4 29 | w1 35 + w5 29 | w2 33 + w6 32 | w3 34 + w7 33        accumulators: 9 9 9 9 | 9 9 8 8
+// `phase`: a tile whose groups are split over waves is assembled in up to three rounds, a barrier between them -- the
+// phase-0 item stores (with the prior), the others add.
+struct I8Item { int I, K, k0, k1, phase; };
 template <int W> struct I8Items;
-template <> struct I8Items<0> { static constexpr int N = 2; static constexpr I8Item it[2] = {{0, 0, 0, 5, 0}, {1, 0, 4, 5, 1}}; };
-template <> struct I8Items<1> { static constexpr int N = 2; static constexpr I8Item it[2] = {{1, 1, 0, 5, 0}, {2, 1, 4, 5, 1}}; };
-template <> struct I8Items<2> { static constexpr int N = 2; static constexpr I8Item it[2] = {{2, 2, 0, 5, 0}, {3, 2, 4, 5, 1}}; };
-template <> struct I8Items<3> { static constexpr int N = 2; static constexpr I8Item it[2] = {{3, 3, 0, 5, 0}, {3, 0, 4, 5, 1}}; };
-template <> struct I8Items<4> { static constexpr int N = 2; static constexpr I8Item it[2] = {{1, 0, 0, 3, 0}, {2, 1, 0, 3, 0}}; };
-template <> struct I8Items<5> { static constexpr int N = 2; static constexpr I8Item it[2] = {{3, 2, 0, 3, 0}, {3, 0, 0, 3, 0}}; };
-template <> struct I8Items<6> { static constexpr int N = 1; static constexpr I8Item it[2] = {{2, 0, 0, 5, 0}, {0, 0, 0, -1, 0}}; };
-template <> struct I8Items<7> { static constexpr int N = 1; static constexpr I8Item it[2] = {{3, 1, 0, 5, 0}, {0, 0, 0, -1, 0}}; };
+template <> struct I8Items<0> { static constexpr int N = 2; static constexpr I8Item it[3] = {{0, 0, 0, 6, 0}, {2, 0, 3, 4, 1}, {0, 0, 0, -1, 0}}; };
+template <> struct I8Items<1> { static constexpr int N = 2; static constexpr I8Item it[3] = {{1, 1, 0, 6, 0}, {3, 1, 3, 4, 1}, {0, 0, 0, -1, 0}}; };
+template <> struct I8Items<2> { static constexpr int N = 2; static constexpr I8Item it[3] = {{3, 0, 2, 6, 0}, {1, 0, 0, 3, 0}, {0, 0, 0, -1, 0}}; };
+template <> struct I8Items<3> { static constexpr int N = 3; static constexpr I8Item it[3] = {{3, 2, 2, 6, 0}, {2, 0, 0, 2, 0}, {2, 1, 6, 6, 1}}; };
+template <> struct I8Items<4> { static constexpr int N = 2; static constexpr I8Item it[3] = {{2, 2, 0, 6, 0}, {3, 0, 0, 1, 1}, {0, 0, 0, -1, 0}}; };
+template <> struct I8Items<5> { static constexpr int N = 2; static constexpr I8Item it[3] = {{3, 3, 0, 6, 0}, {3, 2, 0, 1, 1}, {0, 0, 0, -1, 0}}; };
+template <> struct I8Items<6> { static constexpr int N = 2; static constexpr I8Item it[3] = {{2, 1, 0, 5, 0}, {2, 0, 5, 6, 2}, {0, 0, 0, -1, 0}}; };
+template <> struct I8Items<7> { static constexpr int N = 3; static constexpr I8Item it[3] = {{1, 0, 4, 6, 1}, {3, 1, 5, 6, 2}, {3, 1, 0, 2, 0}}; };
 
+struct I8Mma { int item, s, t; };
+struct I8PlanTable {
+  int nm = 0;
+  I8Mma mm[96] = {};
+  int first_use[4][6] = {};
+  int acc_index[96] = {};
+  int acc_base[4] = {};
+  int nacc = 0;
+};
 template <int W>
-struct I8Acc {
-  static constexpr int G0 = I8Items<W>::it[0].k1 - I8Items<W>::it[0].k0 + 1;
-  static constexpr int G1 = I8Items<W>::N > 1 ? I8Items<W>::it[1].k1 - I8Items<W>::it[1].k0 + 1 : 0;
-  i32x16 a[G0 + (G1 > 0 ? G1 : 1)];
+struct I8Plan {
+  static constexpr int NI = I8Items<W>::N;
+  // the k-step's MFMA list, built ONCE at compile time: items in order, inside an item s-major from the highest slice
+  // (fragment live ranges stay short)
+  static constexpr I8PlanTable build() {
+    I8PlanTable p;
+    for (int IT = 0; IT < NI; ++IT) {
+      const I8Item it = I8Items<W>::it[IT];
+      p.acc_base[IT] = p.nacc;
+      for (int s = 5; s >= 0; --s)
+        for (int t = 0; t <= 5; ++t)
+          if (s + t >= it.k0 && s + t <= it.k1) {
+            p.mm[p.nm] = I8Mma{IT, s, t};
+            p.acc_index[p.nm] = p.nacc + s + t - it.k0;
+            ++p.nm;
+          }
+      p.nacc += it.k1 - it.k0 + 1;
+    }
+    p.acc_base[NI] = p.nacc;
+    for (int rb = 0; rb < 4; ++rb)
+      for (int sl = 0; sl < 6; ++sl) {
+        p.first_use[rb][sl] = p.nm;
+        for (int i = p.nm - 1; i >= 0; --i) {
+          const I8Item it = I8Items<W>::it[p.mm[i].item];
+          if ((it.I == rb && p.mm[i].s == sl) || (it.K == rb && p.mm[i].t == sl)) p.first_use[rb][sl] = i;
+        }
+      }
+    return p;
+  }
+  static constexpr I8PlanTable T = build();
+  static constexpr int NM = T.nm;
+  static constexpr int NACC = T.nacc;
+  static constexpr int acc_base(int IT) { return T.acc_base[IT]; }
+  static constexpr int rowblock(int i, int side) { return side == 0 ? I8Items<W>::it[T.mm[i].item].I : I8Items<W>::it[T.mm[i].item].K; }
+  static constexpr int slice(int i, int side) { return side == 0 ? T.mm[i].s : T.mm[i].t; }
+  static constexpr int first_use(int rb, int sl) { return T.first_use[rb][sl]; }
+  static constexpr int acc_index(int i) { return T.acc_index[i]; }
 };
 
 __device__ __forceinline__ i32x4 lds_read_b128(const char* p) { return *reinterpret_cast<const i32x4*>(p); }
-
-// MFMAs of one item on one digit buffer.  Fragment (slice s, row block I) = 1 KiB, lane l at byte 16 l: rows l & 31, the
-// k half l >> 5 -- the same shape for the A and the B operand (both are rows of the digit matrix).
-template <int W, int IT>
-__device__ __forceinline__ void i8_item_mma(const char* __restrict__ dig, int lane, i32x16* __restrict__ acc) {
-  constexpr I8Item it = I8Items<W>::it[IT];
-  if constexpr (it.k1 >= it.k0) {
-    // s-major, highest slice first: fa[s] is dead after its row of pairs and fb[t] is first needed at s = k1 - t, so at most
-    // k1 + 2 fragments are live at a time (28 registers instead of 48 -- the slicing shares the register file)
-    i32x4 fb[6];
-#pragma unroll
-    for (int s = it.k1; s >= 0; --s) {
-      if constexpr (it.I != it.K) fb[it.k1 - s] = lds_read_b128(dig + ((it.k1 - s) * 4 + it.K) * 1024 + lane * 16);
-      const i32x4 fa = lds_read_b128(dig + (s * 4 + it.I) * 1024 + lane * 16);
-      if constexpr (it.I == it.K) {
-        // diagonal tile: the B operand is the same fragment family -- fb[t] = fragment t of the SAME row block
-        if (s == it.k1) {
-#pragma unroll
-          for (int t = 0; t <= it.k1; ++t) fb[t] = (t == it.k1) ? fa : lds_read_b128(dig + (t * 4 + it.K) * 1024 + lane * 16);
-        }
-      }
-#pragma unroll
-      for (int t = 0; t <= it.k1 - s; ++t)
-        if (s + t >= it.k0) acc[s + t - it.k0] = __builtin_amdgcn_mfma_i32_32x32x32_i8(fa, fb[t], acc[s + t - it.k0], 0, 0, 0);
-    }
-  }
-}
 
 // per-thread slicing state: row r = tid & 127, column octet cq = tid >> 7 of every k-step
 struct I8Slice {
@@ -150,74 +169,86 @@ struct I8Slice {
   unsigned limit;    // high word of 2^(e_r - 1): every |x| must stay below it
   unsigned amax;     // running maximum of the high words of |x|
   int rs[6];         // digit row sums of this thread's columns
-  int sq3;           // sum_n a_3(n)^2 of this thread's columns (the one dropped digit pair that is not zero-mean on the diagonal)
   double b;          // sum_n x_rn y_n over this thread's columns
   double q;          // sum_n y_n^2 over this thread's columns (waves that hold row 0 only)
 };
 
-// One k-step of slicing: raw block `raw` (32 columns x 128 rows fp64, column-major) -> digit buffer `dig`.
+// The slicing of one 32-column block in 14 chunks (state between chunks in this struct).
+//   x + C: rounded to a multiple of 2^(e_r - 47), its integer Q in the low mantissa bits; bytes 0..3 of Q are bytes 0..3 of the
+//   low word, bytes 4, 5 are bytes 0, 1 of the high word; slice s holds byte 5 - s.  4 x 4 byte transposition of a column quad
+//   with v_perm_b32 (D = perm(S0, S1, sel): selector values 0-3 take bytes of S1, 4-7 bytes of S0).
 template <bool WITH_Q>
-__device__ __forceinline__ void i8_slice_block(const char* __restrict__ raw, const double* __restrict__ yb, char* __restrict__ dig, int r, int cq,
-                                               I8Slice& st) {
-  const double* col = reinterpret_cast<const double*>(raw) + (cq * 8) * 128 + r;
-  // bytes 0..3 of Q are bytes 0..3 of the low word of x + C, bytes 4, 5 are bytes 0, 1 of its high word.  Slice s holds byte 5 - s.
-  // 4 x 4 byte transposition of a column quad with v_perm_b32 (D = perm(S0, S1, sel): selector values 0-3 take bytes of S1,
-  // 4-7 bytes of S0).  One quad at a time: the MFMAs of the k-step share the register file.
-  unsigned p[2][6];
+struct I8SliceSteps {
+  double x[2][4], y[2][4];  // two column quads: the second quad's LDS reads are in flight while the first is sliced
+  unsigned lo[4], hi[4], u[6], p[2][6];
+  template <int Q>
+  __device__ __forceinline__ void load(const char* __restrict__ raw, const double* __restrict__ yb, int r, int cq) {
+    const double* col = reinterpret_cast<const double*>(raw) + (cq * 8 + 4 * Q) * 128 + r;
 #pragma unroll
-  for (int h = 0; h < 2; ++h) {
-    unsigned lo[4], hi[4];
+    for (int j = 0; j < 4; ++j) { x[Q][j] = col[j * 128]; y[Q][j] = yb[cq * 8 + 4 * Q + j]; }  // (y: one address per wave, a broadcast)
+  }
+  // chunk 0: reads of quad 0; chunks 1 + 6 q + c: quad q -- c = 0 reads of quad q + 1, c = 1, 2 magic add / bound check / b and q (two
+  // columns each), c = 3, 4 byte transposition, c = 5 digit row sums; chunk 13: digit planes out
+  template <int C>
+  __device__ __forceinline__ void step(const char* __restrict__ raw, const double* __restrict__ yb, char* __restrict__ dig, int r, int cq, I8Slice& st) {
+    if constexpr (C == 0) {
+      load<0>(raw, yb, r, cq);
+    } else if constexpr (C < 13) {
+      constexpr int q = (C - 1) / 6, c = (C - 1) % 6;  // column quad q of the thread's 8 columns
+      if constexpr (c == 0 && q < 1) load<q + 1>(raw, yb, r, cq);
+      if constexpr (c == 1 || c == 2) {
+        constexpr int j0 = c == 1 ? 0 : 2;
 #pragma unroll
-    for (int j = 0; j < 4; ++j) {
-      const double x = col[(4 * h + j) * 128];
-      const double y = yb[cq * 8 + 4 * h + j];  // (same address in every lane: broadcast)
-      const double t = x + st.C;  // :86 operand, rounded to a multiple of 2^(e_r - 47): its integer is in the low mantissa bits
-      lo[j] = (unsigned)__double2loint(t);
-      hi[j] = (unsigned)__double2hiint(t);
-      const unsigned ax = (unsigned)__double2hiint(x) & 0x7fffffffu;
-      st.amax = ax > st.amax ? ax : st.amax;
-      st.b = __builtin_fma(x, y, st.b);
-      if constexpr (WITH_Q) st.q = __builtin_fma(y, y, st.q);
+        for (int j = j0; j < j0 + 2; ++j) {
+          const double xv = x[q][j], yv = y[q][j];
+          const double t = xv + st.C;
+          lo[j] = (unsigned)__double2loint(t);
+          hi[j] = (unsigned)__double2hiint(t);
+          const unsigned ax = (unsigned)__double2hiint(xv) & 0x7fffffffu;
+          st.amax = ax > st.amax ? ax : st.amax;
+          st.b = __builtin_fma(xv, yv, st.b);
+          if constexpr (WITH_Q) st.q = __builtin_fma(yv, yv, st.q);
+        }
+        // (pinned: nothing reads these sums before the end of the stream, and hipcc would sink their updates out of the
+        // MFMA shadows to behind the k-step's barrier)
+        asm volatile("" : "+v"(st.amax), "+v"(st.b));
+        if constexpr (WITH_Q) asm volatile("" : "+v"(st.q));
+      }
+      if constexpr (c == 3) {  // byte transposition, first stage
+        u[0] = __builtin_amdgcn_perm(lo[1], lo[0], 0x05010400u);  // b0(l0) b0(l1) b1(l0) b1(l1)
+        u[1] = __builtin_amdgcn_perm(lo[1], lo[0], 0x07030602u);  // b2(l0) b2(l1) b3(l0) b3(l1)
+        u[2] = __builtin_amdgcn_perm(lo[3], lo[2], 0x05010400u);
+        u[3] = __builtin_amdgcn_perm(lo[3], lo[2], 0x07030602u);
+        u[4] = __builtin_amdgcn_perm(hi[1], hi[0], 0x05010400u);  // b4(0) b4(1) b5(0) b5(1)
+        u[5] = __builtin_amdgcn_perm(hi[3], hi[2], 0x05010400u);
+      }
+      if constexpr (c == 4) {  // second stage; the unsigned digits are stored minus 128 (one XOR), the top digit is signed as it is
+        p[q][5] = __builtin_amdgcn_perm(u[2], u[0], 0x05040100u) ^ 0x80808080u;
+        p[q][4] = __builtin_amdgcn_perm(u[2], u[0], 0x07060302u) ^ 0x80808080u;
+        p[q][3] = __builtin_amdgcn_perm(u[3], u[1], 0x05040100u) ^ 0x80808080u;
+        p[q][2] = __builtin_amdgcn_perm(u[3], u[1], 0x07060302u) ^ 0x80808080u;
+        p[q][1] = __builtin_amdgcn_perm(u[5], u[4], 0x05040100u) ^ 0x80808080u;
+        p[q][0] = __builtin_amdgcn_perm(u[5], u[4], 0x07060302u);
+      }
+      if constexpr (c == 5) {  // digit row sums
+#pragma unroll
+        for (int s = 0; s < 6; ++s) st.rs[s] = __builtin_amdgcn_sdot4((int)p[q][s], 0x01010101, st.rs[s], false);
+        asm volatile("" : "+v"(st.rs[0]), "+v"(st.rs[1]), "+v"(st.rs[2]), "+v"(st.rs[3]), "+v"(st.rs[4]), "+v"(st.rs[5]));
+      }
+    } else {  // C == 13: digit planes out.  Fragment (s, I = r >> 5): lane (half = cq >> 1, row r & 31) at byte 16 (32 half + (r & 31));
+              // this thread's 8 columns are bytes 8 (cq & 1) .. + 8 of the lane's 16
+      char* dst = dig + (r >> 5) * 1024 + (((cq >> 1) * 32 + (r & 31)) * 16) + (cq & 1) * 8;
+#pragma unroll
+      for (int s = 0; s < 6; ++s) {
+        uint2 v;
+        v.x = p[0][s]; v.y = p[1][s];
+        *reinterpret_cast<uint2*>(dst + s * 4096) = v;
+      }
     }
-    const unsigned u01l = __builtin_amdgcn_perm(lo[1], lo[0], 0x05010400u);  // b0(l0) b0(l1) b1(l0) b1(l1)
-    const unsigned u01h = __builtin_amdgcn_perm(lo[1], lo[0], 0x07030602u);  // b2(l0) b2(l1) b3(l0) b3(l1)
-    const unsigned u23l = __builtin_amdgcn_perm(lo[3], lo[2], 0x05010400u);
-    const unsigned u23h = __builtin_amdgcn_perm(lo[3], lo[2], 0x07030602u);
-    const unsigned q0 = __builtin_amdgcn_perm(u23l, u01l, 0x05040100u);  // byte 0 of the four columns
-    const unsigned q1 = __builtin_amdgcn_perm(u23l, u01l, 0x07060302u);
-    const unsigned q2 = __builtin_amdgcn_perm(u23h, u01h, 0x05040100u);
-    const unsigned q3 = __builtin_amdgcn_perm(u23h, u01h, 0x07060302u);
-    const unsigned v01 = __builtin_amdgcn_perm(hi[1], hi[0], 0x05010400u);  // b4(0) b4(1) b5(0) b5(1)
-    const unsigned v23 = __builtin_amdgcn_perm(hi[3], hi[2], 0x05010400u);
-    const unsigned q4 = __builtin_amdgcn_perm(v23, v01, 0x05040100u);
-    const unsigned q5 = __builtin_amdgcn_perm(v23, v01, 0x07060302u);
-    p[h][0] = q5;                  // signed top digit
-    p[h][1] = q4 ^ 0x80808080u;    // unsigned digits, stored minus 128
-    p[h][2] = q3 ^ 0x80808080u;
-    p[h][3] = q2 ^ 0x80808080u;
-    p[h][4] = q1 ^ 0x80808080u;
-    p[h][5] = q0 ^ 0x80808080u;
   }
-#pragma unroll
-  for (int s = 0; s < 6; ++s) {
-    st.rs[s] = __builtin_amdgcn_sdot4((int)p[0][s], 0x01010101, st.rs[s], false);
-    st.rs[s] = __builtin_amdgcn_sdot4((int)p[1][s], 0x01010101, st.rs[s], false);
-  }
-  st.sq3 = __builtin_amdgcn_sdot4((int)p[0][3], (int)p[0][3], st.sq3, false);
-  st.sq3 = __builtin_amdgcn_sdot4((int)p[1][3], (int)p[1][3], st.sq3, false);
-  // fragment (s, I = r >> 5): lane (half = cq >> 1, row r & 31) at byte 16 (32 half + (r & 31)); this thread's 8 columns are bytes
-  // 8 (cq & 1) .. + 8 of the lane's 16
-  char* dst = dig + (r >> 5) * 1024 + (((cq >> 1) * 32 + (r & 31)) * 16) + (cq & 1) * 8;
-#pragma unroll
-  for (int s = 0; s < 6; ++s) {
-    uint2 v;
-    v.x = p[0][s];
-    v.y = p[1][s];
-    *reinterpret_cast<uint2*>(dst + s * 4096) = v;
-  }
-}
+};
+constexpr int kI8SliceChunks = 14;
 
-// ---- the stream: on exit the wave's accumulators, the slicing state, everything else untouched -------------------------------------
 // four consecutive 1 KiB LDS-DMA pieces whose global sources are consecutive too (ldx = 128: the columns of X are contiguous):
 // ONE M0 set-up, the instruction offset moves the global and the LDS address together
 __device__ __forceinline__ void glds_s_4x1k(uint64_t saddr_uniform, unsigned voff, unsigned lds_addr_uniform) {
@@ -239,137 +270,17 @@ __device__ __forceinline__ void glds_s_4x1k(uint64_t saddr_uniform, unsigned vof
 
 // ---- one k-step, order pinned by hand ---------------------------------------------------------------------------------------------
 // A 32 x 32 x 32 int8 MFMA holds the matrix pipe for 32 cycles; about five single-issue instructions fit in its shadow.  Left
-// to itself hipcc emits the k-step's MFMAs back to back and the ~100 vector instructions of the slicing behind them (and
+// to itself hipcc emits the k-step's MFMAs back to back and the vector instructions of the slicing behind them (and
 // sched_group_barrier does not move them: the slicing hangs off LDS reads the group solver leaves where they are).  So the
-// k-step is written as a compile-time list: MFMA i, then (fenced with sched_barrier) the fragment reads MFMA i + 2 is the first
-// to need and one of 13 slicing chunks -- reads of the raw columns first, their arithmetic two MFMAs later.
-struct I8Mma { int item, s, t; };
-template <int W>
-struct I8Plan {
-  static constexpr int count_item(int IT) {
-    const I8Item it = I8Items<W>::it[IT];
-    return it.k1 < it.k0 ? 0 : (it.k1 + 1) * (it.k1 + 2) / 2 - it.k0 * (it.k0 + 1) / 2;
-  }
-  static constexpr int NM = count_item(0) + (I8Items<W>::N > 1 ? count_item(1) : 0);
-  // MFMA i of the k-step: items in order, inside an item s-major from the highest slice (fragment live ranges stay short)
-  static constexpr I8Mma mma(int i) {
-    int n = 0;
-    for (int IT = 0; IT < I8Items<W>::N; ++IT) {
-      const I8Item it = I8Items<W>::it[IT];
-      for (int s = it.k1; s >= 0; --s)
-        for (int t = 0; t <= it.k1 - s; ++t)
-          if (s + t >= it.k0) {
-            if (n == i) return I8Mma{IT, s, t};
-            ++n;
-          }
-    }
-    return I8Mma{-1, 0, 0};
-  }
-  static constexpr int rowblock(int i, int side) {  // row block of MFMA i's A (side 0) / B (side 1) fragment
-    const I8Mma m = mma(i);
-    return side == 0 ? I8Items<W>::it[m.item].I : I8Items<W>::it[m.item].K;
-  }
-  static constexpr int slice(int i, int side) { return side == 0 ? mma(i).s : mma(i).t; }
-  // first MFMA that uses fragment (row block rb, slice sl); NM if none
-  static constexpr int first_use(int rb, int sl) {
-    for (int i = 0; i < NM; ++i)
-      for (int side = 0; side < 2; ++side)
-        if (rowblock(i, side) == rb && slice(i, side) == sl) return i;
-    return NM;
-  }
-  static constexpr int acc_index(int i) {
-    const I8Mma m = mma(i);
-    const I8Item it = I8Items<W>::it[m.item];
-    return (m.item == 0 ? 0 : I8Acc<W>::G0) + m.s + m.t - it.k0;
-  }
-};
-
-// the slicing of one 32-column block in 13 chunks (state between chunks in this struct; see i8_slice_block for the arithmetic)
-template <bool WITH_Q>
-struct I8SliceSteps {
-  double x[8], y[8];
-  unsigned lo[4], hi[4], u[6], p[2][6];
-  template <int C>
-  __device__ __forceinline__ void step(const char* __restrict__ raw, const double* __restrict__ yb, char* __restrict__ dig, int r, int cq, I8Slice& st) {
-    const double* col = reinterpret_cast<const double*>(raw) + (cq * 8) * 128 + r;
-    if constexpr (C == 0 || C == 1) {  // LDS reads of a column quad (and its y, the same address in every lane: broadcast)
-      constexpr int h = C;
-#pragma unroll
-      for (int j = 0; j < 4; ++j) { x[4 * h + j] = col[(4 * h + j) * 128]; y[4 * h + j] = yb[cq * 8 + 4 * h + j]; }
-    }
-    if constexpr (C == 2 || C == 3 || C == 7 || C == 8) {  // magic add, bound check, b and q: two columns per chunk
-      constexpr int h = C >= 7 ? 1 : 0, j0 = (C == 2 || C == 7) ? 0 : 2;
-#pragma unroll
-      for (int j = j0; j < j0 + 2; ++j) {
-        const double xv = x[4 * h + j], yv = y[4 * h + j];
-        const double t = xv + st.C;
-        lo[j] = (unsigned)__double2loint(t);
-        hi[j] = (unsigned)__double2hiint(t);
-        const unsigned ax = (unsigned)__double2hiint(xv) & 0x7fffffffu;
-        st.amax = ax > st.amax ? ax : st.amax;
-        st.b = __builtin_fma(xv, yv, st.b);
-        if constexpr (WITH_Q) st.q = __builtin_fma(yv, yv, st.q);
-      }
-      // (pinned: nothing reads these sums before the end of the stream, and hipcc would sink their updates out of the
-      // MFMA shadows to behind the k-step's barrier)
-      asm volatile("" : "+v"(st.amax), "+v"(st.b));
-      if constexpr (WITH_Q) asm volatile("" : "+v"(st.q));
-    }
-    if constexpr (C == 4 || C == 9) {  // byte transposition, first stage
-      u[0] = __builtin_amdgcn_perm(lo[1], lo[0], 0x05010400u);
-      u[1] = __builtin_amdgcn_perm(lo[1], lo[0], 0x07030602u);
-      u[2] = __builtin_amdgcn_perm(lo[3], lo[2], 0x05010400u);
-      u[3] = __builtin_amdgcn_perm(lo[3], lo[2], 0x07030602u);
-      u[4] = __builtin_amdgcn_perm(hi[1], hi[0], 0x05010400u);
-      u[5] = __builtin_amdgcn_perm(hi[3], hi[2], 0x05010400u);
-    }
-    if constexpr (C == 5 || C == 10) {  // second stage + the offset XOR
-      constexpr int h = C == 10 ? 1 : 0;
-      p[h][5] = __builtin_amdgcn_perm(u[2], u[0], 0x05040100u) ^ 0x80808080u;
-      p[h][4] = __builtin_amdgcn_perm(u[2], u[0], 0x07060302u) ^ 0x80808080u;
-      p[h][3] = __builtin_amdgcn_perm(u[3], u[1], 0x05040100u) ^ 0x80808080u;
-      p[h][2] = __builtin_amdgcn_perm(u[3], u[1], 0x07060302u) ^ 0x80808080u;
-      p[h][1] = __builtin_amdgcn_perm(u[5], u[4], 0x05040100u) ^ 0x80808080u;
-      p[h][0] = __builtin_amdgcn_perm(u[5], u[4], 0x07060302u);
-    }
-    if constexpr (C == 6 || C == 11) {  // digit row sums, the (3, 3) square
-      constexpr int h = C == 11 ? 1 : 0;
-#pragma unroll
-      for (int s = 0; s < 6; ++s) st.rs[s] = __builtin_amdgcn_sdot4((int)p[h][s], 0x01010101, st.rs[s], false);
-      st.sq3 = __builtin_amdgcn_sdot4((int)p[h][3], (int)p[h][3], st.sq3, false);
-      asm volatile("" : "+v"(st.rs[0]), "+v"(st.rs[1]), "+v"(st.rs[2]), "+v"(st.rs[3]), "+v"(st.rs[4]), "+v"(st.rs[5]), "+v"(st.sq3));
-    }
-    if constexpr (C == 12) {  // digit planes out, fragment order
-      char* dst = dig + (r >> 5) * 1024 + (((cq >> 1) * 32 + (r & 31)) * 16) + (cq & 1) * 8;
-#pragma unroll
-      for (int s = 0; s < 6; ++s) {
-        uint2 v;
-        v.x = p[0][s];
-        v.y = p[1][s];
-        *reinterpret_cast<uint2*>(dst + s * 4096) = v;
-      }
-    }
-  }
-};
-
+// k-step is a compile-time list: MFMA i, then (fenced with sched_barrier) the fragment reads MFMA i + 2 is the first to need
+// and the slicing chunks whose turn it is -- reads of the raw columns first, their arithmetic two MFMAs later.
 template <int W, bool SLICE, bool WITH_Q, typename IssueFn>
 __device__ __forceinline__ void i8_kstep(const char* __restrict__ dig, const char* __restrict__ raw, const double* __restrict__ yb,
-                                         char* __restrict__ dign, int lane, int r, int cq, I8Acc<W>& A, I8Slice& st, IssueFn issue_next) {
-#ifdef BLR_I8_NO_INTERLEAVE
-  issue_next();
-  if constexpr (W < 4) {
-    i8_item_mma<W, 0>(dig, lane, &A.a[0]);
-    i8_item_mma<W, 1>(dig, lane, &A.a[I8Acc<W>::G0]);
-    if constexpr (SLICE) i8_slice_block<WITH_Q>(raw, yb, dign, r, cq, st);
-  } else {
-    if constexpr (SLICE) i8_slice_block<WITH_Q>(raw, yb, dign, r, cq, st);
-    i8_item_mma<W, 0>(dig, lane, &A.a[0]);
-    i8_item_mma<W, 1>(dig, lane, &A.a[I8Acc<W>::G0]);
-  }
-#else
+                                         char* __restrict__ dign, int lane, int r, int cq, i32x16 (&A)[I8Plan<W>::NACC], I8Slice& st,
+                                         IssueFn issue_next) {
   using PL = I8Plan<W>;
   constexpr int NM = PL::NM;
-  constexpr int NCH = 13;   // slicing chunks
+  constexpr int NCH = kI8SliceChunks;
   constexpr int LEAD = 2;   // a fragment is requested this many MFMAs before its first use
   i32x4 F[4][6];            // fragment (row block, slice): only the ones this wave uses ever get registers
   I8SliceSteps<WITH_Q> sl;
@@ -396,8 +307,7 @@ __device__ __forceinline__ void i8_kstep(const char* __restrict__ dig, const cha
   };
   auto unit = [&](auto itag) {
     constexpr int i = decltype(itag)::value;
-    // reads for MFMA i + LEAD (and, at the head, everything up to LEAD)
-    if constexpr (i == 0) {
+    if constexpr (i == 0) {  // at the head: everything the first LEAD MFMAs need
       frag_loads(std::integral_constant<int, 0>{});
       frag_loads(std::integral_constant<int, 1>{});
     }
@@ -406,14 +316,14 @@ __device__ __forceinline__ void i8_kstep(const char* __restrict__ dig, const cha
     constexpr int ai = PL::acc_index(i);
     constexpr int ra = PL::rowblock(i, 0), sa = PL::slice(i, 0), rbk = PL::rowblock(i, 1), sb = PL::slice(i, 1);
 #if defined(BLR_I8_EXP) && BLR_I8_EXP == 2  /* timing experiment: no MFMA */
-    A.a[ai][0] += F[ra][sa][0] + F[rbk][sb][1];
+    A[ai][0] += F[ra][sa][0] + F[rbk][sb][1];
 #else
-    A.a[ai] = __builtin_amdgcn_mfma_i32_32x32x32_i8(F[ra][sa], F[rbk][sb], A.a[ai], 0, 0, 0);
+    A[ai] = __builtin_amdgcn_mfma_i32_32x32x32_i8(F[ra][sa], F[rbk][sb], A[ai], 0, 0, 0);
 #endif
     __builtin_amdgcn_sched_barrier(0);
-    // the LDS-DMA pieces of the k-step three ahead go out behind the second MFMA (their slot was freed by the barrier that
-    // opened this k-step; ~60 cycles of issue per piece, beside the partner wave's MFMAs instead of behind the barrier)
-    if constexpr (i == 1) issue_next();
+    // the LDS-DMA pieces of the k-step three ahead (their slot was freed by the barrier that opened this k-step) go out one at a
+    // time, every sixth MFMA (~60 cycles of issue each: beside the partner wave's MFMAs, not in a bunch behind the barrier)
+    if constexpr (i >= 2 && (i - 2) % 6 == 0 && (i - 2) / 6 < 5) issue_next(std::integral_constant<int, (i - 2) / 6>{});
     // slicing chunks c with floor(c NM / NCH) == i
     constexpr int c_lo = (i * NCH + NM - 1) / NM, c_hi = ((i + 1) * NCH + NM - 1) / NM;
     if constexpr (c_lo < c_hi) chunk(std::integral_constant<int, c_lo>{});
@@ -428,12 +338,12 @@ __device__ __forceinline__ void i8_kstep(const char* __restrict__ dig, const cha
     }
   };
   run_units(run_units, std::integral_constant<int, 0>{});
-#endif
 }
 
+// ---- the stream: on exit the wave's accumulators and the slicing state --------------------------------------------------------------
 template <int W>
 __device__ __forceinline__ void i8_gram_stream(char* smem, const BLR_GLOBAL double* X /*uniform*/, const BLR_GLOBAL double* y /*uniform*/,
-                                               int64_t ldx, int N, int tid, I8Acc<W>& A, I8Slice& st, int& ok) {
+                                               int64_t ldx, int N, int tid, i32x16 (&A)[I8Plan<W>::NACC], I8Slice& st, int& ok) {
   using C = I8Cfg;
   const int lane = tid & 63;
   const int r = tid & 127, cq = tid >> 7;
@@ -442,48 +352,33 @@ __device__ __forceinline__ void i8_gram_stream(char* smem, const BLR_GLOBAL doub
   double* const yring = reinterpret_cast<double*>(smem + C::OFF_YB);
   int* const xch = reinterpret_cast<int*>(smem + C::OFF_XCH);
   const int nk = N / C::KC;
-#ifndef BLR_I8_TOUCH
-#define BLR_I8_TOUCH 0  /* measured: 5.42 ms per 4096 updates with the touches three k-steps ahead, 4.80 without */
-#endif
-  // Cache-warming touches: the ring holds two k-steps in flight (64 KB per CU), and at the latency the memory system has under
-  // this load that bounds the stream at ~3.6 TB/s (measured: 4.73 ms per 4096 updates with the DMA, 2.56 ms without).  LDS
-  // is full, the caches are not: waves 0-3 each read ONE dword from each of 64 of the 256 lines of the k-step BLR_I8_TOUCH
-  // further ahead (LDS-DMA into a sink nobody reads: no register is waiting for it), so that the real pieces of that k-step
-  // find their lines in L2 / the Infinity Cache.
-  constexpr int kTouch = BLR_I8_TOUCH;
-  constexpr bool kToucher = kTouch > 0 && W < 4;
-  constexpr int PW = 4 + (W == 0 ? 1 : 0) + (kToucher ? 1 : 0);  // LDS-DMA pieces per wave and k-step: 4 columns (+ the y piece of wave 0, + a touch)
-  const unsigned sink_addr = lds_addr_of(smem + C::OFF_SINK + (W & 3) * 256);
-  const int tq = (W & 3) * 64 + lane;  // line of the touched k-step: column tq >> 3, 128-byte line tq & 7
-  const unsigned touch_off = (unsigned)((tq >> 3) * (int)(ldx * 8) + (tq & 7) * 128);
-
+  constexpr int PW = 4 + (W == 0 ? 1 : 0);  // LDS-DMA pieces per wave and k-step: 4 columns (+ the y piece of wave 0)
   unsigned ring_addr = lds_addr_of(ring), y_addr = lds_addr_of(yring);
   asm volatile("" : "+v"(ring_addr), "+v"(y_addr));
   const uint64_t colbytes = (uint64_t)ldx * 8u;
   uint64_t nextX = (uint64_t)(uintptr_t)X + (uint64_t)(4 * W) * colbytes;  // this wave's four columns of the k-step being issued
   uint64_t nextY = (uint64_t)(uintptr_t)y;
   const unsigned voff = (unsigned)lane * 16u;
-  const bool contig = ldx == 128;  // (uniform)
-  auto issue = [&](int t) {  // k-step t -> ring slot t % 3 (calls are in k-step order: the global addresses just run on)
+  // piece c of k-step t -> ring slot t % 3: c = 0 .. 3 this wave's four columns, c = 4 the y values (wave 0) and the advance to the
+  // next k-step (pieces are issued in order: the global addresses just run on)
+  auto issue_piece = [&](int t, auto ctag) {
+    constexpr int c = decltype(ctag)::value;
 #if defined(BLR_I8_EXP) && BLR_I8_EXP == 1  /* timing experiment: no DMA after the first three k-steps (the ring keeps them) */
     if (t >= 3) return;
 #endif
-    const unsigned slot = ring_addr + (unsigned)((t % C::NSLOT) * C::SLOT_BYTES) + (unsigned)(4 * W * 1024);
-    if (contig) {
-      glds_s_4x1k(uni((int64_t)nextX), voff, slot);
+    if constexpr (c < 4) {
+      const unsigned slot = ring_addr + (unsigned)((t % C::NSLOT) * C::SLOT_BYTES) + (unsigned)((4 * W + c) * 1024);
+      glds_s<16>(uni((int64_t)(nextX + (uint64_t)c * colbytes)), voff, slot);
     } else {
-#pragma unroll
-      for (int c = 0; c < 4; ++c) glds_s<16>(uni((int64_t)(nextX + (uint64_t)c * colbytes)), voff, slot + (unsigned)(c * 1024));
+      if constexpr (W == 0) glds_s<4, 64>(uni((int64_t)nextY), (unsigned)lane * 4u, y_addr + (unsigned)((t % C::NSLOT) * C::KC * 8));
+      nextX += (uint64_t)C::KC * colbytes;
+      nextY += (uint64_t)C::KC * 8u;
     }
-    if constexpr (W == 0) glds_s<4, 64>(uni((int64_t)nextY), (unsigned)lane * 4u, y_addr + (unsigned)((t % C::NSLOT) * C::KC * 8));
-    if constexpr (kToucher) {
-      // (always issued, so that the counted waits see the same number of operations per k-step: past the end of X it touches
-      // the last k-step again)
-      const int tt = t + kTouch < nk ? t + kTouch : nk - 1;
-      glds_s<4, 64>(uni((int64_t)((uint64_t)(uintptr_t)X + (uint64_t)tt * (uint64_t)C::KC * colbytes)), touch_off, sink_addr);
-    }
-    nextX += (uint64_t)C::KC * colbytes;
-    nextY += (uint64_t)C::KC * 8u;
+  };
+  auto issue = [&](int t) {
+    issue_piece(t, std::integral_constant<int, 0>{}); issue_piece(t, std::integral_constant<int, 1>{});
+    issue_piece(t, std::integral_constant<int, 2>{}); issue_piece(t, std::integral_constant<int, 3>{});
+    issue_piece(t, std::integral_constant<int, 4>{});
   };
   auto wait_keep = [&](int groups) {  // all but the youngest `groups` issued k-steps of THIS wave have landed
     if (groups >= 2) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(2 * PW) : "memory");
@@ -491,9 +386,9 @@ __device__ __forceinline__ void i8_gram_stream(char* smem, const BLR_GLOBAL doub
     else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
   };
 #pragma unroll
-  for (int g = 0; g < (I8Acc<W>::G0 + (I8Acc<W>::G1 > 0 ? I8Acc<W>::G1 : 1)); ++g)
+  for (int g = 0; g < I8Plan<W>::NACC; ++g)
 #pragma unroll
-    for (int v = 0; v < 16; ++v) A.a[g][v] = 0;
+    for (int v = 0; v < 16; ++v) A[g][v] = 0;
 
   const int nissue0 = nk < 3 ? nk : 3;
   for (int t = 0; t < nissue0; ++t) issue(t);
@@ -526,17 +421,21 @@ __device__ __forceinline__ void i8_gram_stream(char* smem, const BLR_GLOBAL doub
     st.q = 0.0;
 #pragma unroll
     for (int s = 0; s < 6; ++s) st.rs[s] = 0;
-    st.sq3 = 0;
   }
-  constexpr bool kQ = (W & 1) == 0;  // waves whose rows start at 0 or 128-multiples... (rows 64 (W & 1) + lane): row 0 lives in even waves
-  i8_slice_block<kQ>(ring, yring, dig0, r, cq, st);
+  constexpr bool kQ = (W & 1) == 0;  // (rows 64 (W & 1) + lane: row 0 lives in the even waves)
+  {  // block 0 -> digit buffer 0 (nothing to overlap with yet)
+    I8SliceSteps<kQ> sl;
+    auto rec = [&](auto self, auto ctag) -> void {
+      constexpr int c = decltype(ctag)::value;
+      if constexpr (c < kI8SliceChunks) {
+        sl.template step<c>(ring, yring, dig0, r, cq, st);
+        self(self, std::integral_constant<int, c + 1>{});
+      }
+    };
+    rec(rec, std::integral_constant<int, 0>{});
+  }
   if (nk > 1) wait_keep(nissue0 - 2 > 0 ? nissue0 - 2 : 0);
   __syncthreads();  // digits of block 0 and raw block 1 visible; raw block 0 consumed by everyone
-  // waves 4-7 are the younger partner on every SIMD and lose the vector-issue arbitration on every k-step (measured: they
-  // finished their k-steps 300 cycles behind waves 0-3 although they carry 11 MFMAs fewer): static priority for that half
-#ifdef BLR_I8_PRIO  /* measured: no gain (0.857 against 0.856-0.870 M updates/s), the priority only swaps who waits */
-  if constexpr (W >= 4) __builtin_amdgcn_s_setprio(1);
-#endif
   I8_STAMP_DECL;
   // (the last k-step has nothing to slice: peeled, so that the loop body is ONE basic block and the accumulators stay in place)
 #pragma unroll 1
@@ -546,17 +445,14 @@ __device__ __forceinline__ void i8_gram_stream(char* smem, const BLR_GLOBAL doub
     const char* raw = ring + ((j + 1) % C::NSLOT) * C::SLOT_BYTES;
     const double* yb = yring + ((j + 1) % C::NSLOT) * C::KC;
     // k-step j + 3 goes into the slot of block j, which everybody has sliced before the barrier that ended k-step j - 1
-    i8_kstep<W, true, kQ>(dig, raw, yb, dign, lane, r, cq, A, st, [&] { if (j + 3 < nk) issue(j + 3); });
+    i8_kstep<W, true, kQ>(dig, raw, yb, dign, lane, r, cq, A, st, [&](auto ctag) { if (j + 3 < nk) issue_piece(j + 3, ctag); });
     I8_STAMP(0);
     // end of k-step j: raw block j + 2 must have landed (k-step j + 3 may stay in flight), then everybody's is visible
     if (j + 2 < nk) wait_keep(j + 3 < nk ? 1 : 0);
     __syncthreads();
     I8_STAMP(2);
   }
-  i8_kstep<W, false, kQ>(dig0 + ((nk - 1) & 1) * C::DIG_BUF, ring, yring, dig0, lane, r, cq, A, st, [] {});
-#ifdef BLR_I8_PRIO
-  if constexpr (W >= 4) __builtin_amdgcn_s_setprio(0);
-#endif
+  i8_kstep<W, false, kQ>(dig0 + ((nk - 1) & 1) * C::DIG_BUF, ring, yring, dig0, lane, r, cq, A, st, [](auto) {});
   I8_STAMP_FLUSH(W);
   if (st.amax >= st.limit) ok = 0;
 #ifdef BLR_I8_EXP
@@ -567,11 +463,7 @@ __device__ __forceinline__ void i8_gram_stream(char* smem, const BLR_GLOBAL doub
 // =========================================================================================================
 // the kernel
 // =========================================================================================================
-// `stagger_first` / `stagger_ticks`: with one workgroup per CU and equal work per regressor all CUs would stream together and
-// factorise together -- HBM oversubscribed (7.5 TB/s wanted) for 3/4 of the time and idle for the rest.  The first
-// `stagger_first` workgroups (the first round, one per CU) therefore start (blockIdx.x / 8) % 4 quarters of `stagger_ticks`
-// (100 MHz ticks ~ one regressor's duration) late; equal durations keep the four groups out of phase for the whole launch.
-__global__ __launch_bounds__(kI8Threads, 2) void fused_i8_kernel(PosteriorArgs<double> a, int stagger_first, int stagger_ticks) {
+__global__ __launch_bounds__(kI8Threads, 2) void fused_i8_kernel(PosteriorArgs<double> a) {
   using T = double;
   using C = I8Cfg;
   using SC = SmallCfg<double, 8>;
@@ -587,7 +479,6 @@ __global__ __launch_bounds__(kI8Threads, 2) void fused_i8_kernel(PosteriorArgs<d
   double* const tabC = tabA + 256;
   double* const sctab = reinterpret_cast<double*>(smem + C::OFF_SC);
   double* const bred = reinterpret_cast<double*>(smem + C::OFF_BRED);
-  int* const sq3x = reinterpret_cast<int*>(smem + C::OFF_SQ3);
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = uni(tid >> 6);
   const int reg = blockIdx.x;
@@ -600,14 +491,6 @@ __global__ __launch_bounds__(kI8Threads, 2) void fused_i8_kernel(PosteriorArgs<d
   const BLR_GLOBAL T* Lw = as_global(a.Lw + (int64_t)reg * a.strideLw);
   const T s_iso = as_global(a.s + (int64_t)reg * a.strides)[0];
 
-  if ((int)blockIdx.x < stagger_first) {
-    const int phase = ((int)blockIdx.x >> 3) & 3;  // (blockIdx.x % 8 picks the XCD: every XCD gets all four phases)
-    if (phase != 0) {
-      const unsigned long long t0 = __builtin_amdgcn_s_memrealtime();
-      const unsigned long long wait = (unsigned long long)stagger_ticks * (unsigned)phase / 4u;
-      while (__builtin_amdgcn_s_memrealtime() - t0 < wait) __builtin_amdgcn_s_sleep(32);
-    }
-  }
   // the fast path takes a zero prior mean only (mean(fx) = X'mw = 0 exactly, delta = y): anything else -> fp64 kernel
   int ok = 1;
   if (tid < D && mw[tid] != T(0)) ok = 0;
@@ -618,7 +501,8 @@ __global__ __launch_bounds__(kI8Threads, 2) void fused_i8_kernel(PosteriorArgs<d
   // one copy of the stream per wave: the tile / group table is static
   auto run = [&](auto wtag) {
     constexpr int W = decltype(wtag)::value;
-    I8Acc<W> A;
+    using PL = I8Plan<W>;
+    i32x16 A[PL::NACC];
     i8_gram_stream<W>(smem, X, y, a.ldx, N, tid, A, st, ok);
     I8_KSTAMP(4);
     // ---- hand-over: validity, digit row sums, b partials, row scales (all through the exchange area / the dead digit area)
@@ -627,19 +511,16 @@ __global__ __launch_bounds__(kI8Threads, 2) void fused_i8_kernel(PosteriorArgs<d
     for (int s = 0; s < 6; ++s) xch[((tid >> 7) * 6 + s) * 128 + (tid & 127)] = st.rs[s];
     __syncthreads();  // ring and digit buffers are dead from here on
     bred[(tid >> 7) * 128 + (tid & 127)] = st.b;
-    sq3x[(tid >> 7) * 128 + (tid & 127)] = st.sq3;
     if (tid < 128) {
       int R[6];
 #pragma unroll
-      for (int s = 0; s < 6; ++s) R[s] = (xch[(0 * 6 + s) * 128 + tid] + xch[(1 * 6 + s) * 128 + tid]) + (xch[(2 * 6 + s) * 128 + tid] + xch[(3 * 6 + s) * 128 + tid]);
+      for (int s = 0; s < 6; ++s) R[s] = (xch[s * 128 + tid] + xch[(6 + s) * 128 + tid]) + (xch[(12 + s) * 128 + tid] + xch[(18 + s) * 128 + tid]);
       // Offset terms of digit group k (header comment), per row:  V_k(i) = 128 sum_s R_s(i) over the s that pair with an OFFSET
-      // digit t = k - s in 1 .. 5 (k <= 5: s = 0 .. k - 1; k = 6 .. 10, the groups whose PRODUCTS are dropped: s = k - 5 .. 5 --
-      // their offset terms are kept: the unsigned digits have mean 127.5, leaving them out would bias the result by 2^-35;
-      // what IS dropped are zero-mean products of the centred digits, 2^-45), plus half of the constant
-      // c_k = 16384 N #{(s, t): s, t >= 1, s + t = k} (the other half comes in with the column index).  Exact integers.
-      // Folded over k with the group scales 2^(80 - 8k) into three tables so that the conversion adds 2 x 3 numbers per entry:
-      //   TA = groups 1, 2 (exact: 35 significant bits)   TB = group 3   TC = groups 4 .. 10 (rounded at 2^-53 of ITS size,
-      //   2^-65 of the result)
+      // digit t = k - s in 1 .. 5 (s = max(0, k - 5) .. min(5, k - 1)), for ALL groups k = 1 .. 10 -- also those whose products are
+      // dropped -- plus half of the constant c_k = 16384 N #{(s, t): s, t >= 1, s + t = k} (the other half comes in with the
+      // column index).  Exact integers.  Folded over k with the group scales 2^(80 - 8k) into three tables so that the
+      // conversion adds 2 x 3 numbers per entry:  TA = groups 1, 2 (exact: 35 significant bits)   TB = group 3
+      // TC = groups 4 .. 10 (rounded at 2^-53 of ITS size, 2^-65 of the result)
       double ta = 0.0, tb = 0.0, tc = 0.0;
 #pragma unroll
       for (int k = 10; k >= 1; --k) {
@@ -663,50 +544,48 @@ __global__ __launch_bounds__(kI8Threads, 2) void fused_i8_kernel(PosteriorArgs<d
     double qsum = 0.0;
     if ((tid & 127) == 0) qsum = st.q;  // the four threads of row 0 hold the four column octets' shares
     __syncthreads();
-    // q: fixed order over the four octet threads (tid = 0, 128, 256, 384), through the exchange area
     if ((tid & 127) == 0) reinterpret_cast<double*>(xch)[tid >> 7] = qsum;
     const int valid = flag[0];
     // ---- accumulators -> fp64 -> packed lower triangle of A = Lw + G / sigma^2 (diagonal prior), first items store, second add
     const T winv = T(1) / s_iso;
-    auto convert = [&](auto ittag, i32x16* acc) {
+    auto convert = [&](auto ittag) {
       constexpr int IT = decltype(ittag)::value;
       constexpr I8Item it = I8Items<W>::it[IT];
-      if constexpr (it.k1 >= it.k0) {
-        const int j = 32 * it.K + (lane & 31);
-        const double scj = sctab[j] * winv;
-        const double tAj = tabA[j], tBj = tabB[j], tCj = tabC[j];
+      constexpr int base = PL::acc_base(IT);
+      const int j = 32 * it.K + (lane & 31);
+      const double scj = sctab[j] * winv;
+      const double tAj = tabA[j], tBj = tabB[j], tCj = tabC[j];
 #pragma unroll
-        for (int v = 0; v < 16; ++v) {
-          const int i = 32 * it.I + 8 * (v >> 2) + 4 * (lane >> 5) + (v & 3);
-          double sum = 0.0;
-          if constexpr (it.k1 == 5) {  // (one item per tile ends with group 5: it carries the offset terms of groups 4 .. 10)
-            sum = tabC[i] + tCj;
-            // the one dropped product that is not zero-mean: a digit times ITSELF -- pair (3, 3), group 6 -- on the diagonal of G
-            if (i == j) sum += (double)((sq3x[i] + sq3x[128 + i]) + (sq3x[256 + i] + sq3x[384 + i])) * __hiloint2double((1023 + 32) << 20, 0);
-          }
+      for (int v = 0; v < 16; ++v) {
+        const int i = 32 * it.I + 8 * (v >> 2) + 4 * (lane >> 5) + (v & 3);
+        double sum = 0.0;
+        if constexpr (it.k1 == 6) sum = tabC[i] + tCj;  // (one item per tile ends with group 6: it carries the offset terms of groups 4 .. 10)
 #pragma unroll
-          for (int k = it.k1; k >= it.k0; --k) {  // smallest scale first
-            sum = __builtin_fma((double)acc[k - it.k0][v], __hiloint2double((1023 + 80 - 8 * k) << 20, 0), sum);
-            if (k == 3) sum += tabB[i] + tBj;
-            if (k == 1) sum += tabA[i] + tAj;
-          }
-          const double g = sum * sctab[i] * scj;
-          if (i >= j) {
-            if constexpr (it.second) P[pidx(i, j)] += g;
-            else P[pidx(i, j)] = g + ((i == j) ? Lw[i] : T(0));
-          }
-          __builtin_amdgcn_sched_barrier(0);  // one entry at a time: hoisting 16 entries' table reads costs 100 registers
+        for (int k = it.k1; k >= it.k0; --k) {  // smallest scale first
+          sum = __builtin_fma((double)A[base + k - it.k0][v], __hiloint2double((1023 + 80 - 8 * k) << 20, 0), sum);
+          if (k == 3) sum += tabB[i] + tBj;
+          if (k == 1) sum += tabA[i] + tAj;
         }
+        const double g = sum * sctab[i] * scj;
+        if (i >= j) {
+          if constexpr (it.phase != 0) P[pidx(i, j)] += g;
+          else P[pidx(i, j)] = g + ((i == j) ? Lw[i] : T(0));
+        }
+        __builtin_amdgcn_sched_barrier(0);  // one entry at a time
       }
     };
-    if (valid) {
-      convert(std::integral_constant<int, 0>{}, &A.a[0]);
-      if constexpr (I8Items<W>::N > 1 && !I8Items<W>::it[1].second) convert(std::integral_constant<int, 1>{}, &A.a[I8Acc<W>::G0]);
-    }
+    auto convert_all = [&](auto self, auto ittag, auto phase_tag) -> void {
+      constexpr int IT = decltype(ittag)::value;
+      if constexpr (IT < PL::NI) {
+        if constexpr (I8Items<W>::it[IT].phase == decltype(phase_tag)::value) convert(ittag);
+        self(self, std::integral_constant<int, IT + 1>{}, phase_tag);
+      }
+    };
+    if (valid) convert_all(convert_all, std::integral_constant<int, 0>{}, std::integral_constant<int, 0>{});
     __syncthreads();
-    if (valid) {
-      if constexpr (I8Items<W>::N > 1 && I8Items<W>::it[1].second) convert(std::integral_constant<int, 1>{}, &A.a[I8Acc<W>::G0]);
-    }
+    if (valid) convert_all(convert_all, std::integral_constant<int, 0>{}, std::integral_constant<int, 1>{});
+    __syncthreads();
+    if (valid) convert_all(convert_all, std::integral_constant<int, 0>{}, std::integral_constant<int, 2>{});
   };
   switch (wave) {
     case 0: run(std::integral_constant<int, 0>{}); break;

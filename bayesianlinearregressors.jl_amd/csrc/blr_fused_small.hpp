@@ -1143,7 +1143,9 @@ BLR_PHASE void phase_gram(char* smem) {
 //   * predicated stores go to a per-lane dummy word (the dinv area, unused until the back substitution) through an address
 //     select instead of an exec-mask branch each;
 //   * tiles are skipped by scalar branches on wave-uniform tile coordinates.
-template <typename T, int NB>
+// TAG: a caller compiled for a different register budget (fused_i8_kernel: one wave per SIMD) instantiates its OWN copy -- a
+// noinline function is compiled once per instantiation for the largest budget among its callers (traps)
+template <typename T, int NB, int TAG = 0>
 BLR_PHASE int phase_chol(char* smem, int D_in, int with_rhs_in) {
   using C = SmallCfg<T, NB>;
   using acc4 = typename Mfma<T>::acc4;
@@ -1282,7 +1284,7 @@ BLR_PHASE int phase_chol(char* smem, int D_in, int with_rhs_in) {
 // phase 3 (noinline, wave 0 does the serial part): m = L^-T u by column-oriented back substitution.
 // Returns through LDS: bvec <- m (rows < D), scr[6] = |u|^2, scr[7] = logdet A.
 // =========================================================================================================
-template <typename T, int NB>
+template <typename T, int NB, int TAG = 0>
 BLR_PHASE void phase_backsolve(char* smem, int D_in, T* Tout_in, int64_t ldt_in) {
   using C = SmallCfg<T, NB>;
   T* const P = reinterpret_cast<T*>(smem);

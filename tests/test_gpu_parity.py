@@ -2055,6 +2055,119 @@ def test_wave_kernel_is_bitwise_reproducible(B):
         np.testing.assert_allclose(Tn.T @ Tn, L_o, rtol=1e-10, atol=1e-10 * np.abs(L_o).max())
 
 
+# ---- the int8-sliced Gram of the headline shape (blr_fused_i8.hpp): D = 128, fp64, aligned ColVecs, isotropic noise, diagonal prior ----
+def _i8_case(rng, nb, N, kind):
+    D = 128
+    X = rng.standard_normal((nb, N, D))  # [N, D] row-major == D x N ColVecs
+    rowscale = np.ones(D)
+    if kind == "scales":      # rows from 2^-12 to 2^12: every row has its own power-of-two bound (y stays O(1): the weights scale back)
+        rowscale = np.ldexp(1.0, (np.arange(D) % 7) * 4 - 12)
+        X *= rowscale[None, None, :]
+    elif kind == "zero_row":  # a feature that is identically zero, and one that only wakes up late
+        X[:, :, 17] = 0.0
+        X[1::2, : N // 2, 40] = 0.0
+    elif kind == "tiny":      # denormal-range and zero entries mixed with ordinary ones
+        X[:, ::3, 9] *= 1e-310
+    w = rng.standard_normal((nb, D)) / rowscale[None, :]
+    y = np.einsum("bnd,bd->bn", X, w) + np.sqrt(0.1) * rng.standard_normal((nb, N))
+    if kind == "outlier":     # one entry far above its row's bound, in the middle of the stream: the fast path must hand the regressor
+        X[::2, N // 2, 5] = 1.0e3  # back (y is left as it was: an outlier in y would only make the evidence ill-conditioned for everybody)
+    return X, y
+
+
+@pytest.mark.parametrize("kind", ["gauss", "scales", "outlier", "zero_row", "tiny"])
+@pytest.mark.parametrize("N", [512, 4096])
+def test_i8_gram_path_vs_oracle_and_fp64_kernel(B, opt, kind, N):
+    # the SAME call with the fast path on (default) and off (NO_I8_GRAM: fused_small_kernel, the fp64 matrix pipe), both against
+    # the oracle's direct form at the fp64 tolerances of test_c2_shape_fp64; the two device paths must agree far inside them:
+    # the digit splitting keeps 48 bits of every entry relative to its row's bound and every digit-pair product down to
+    # 2^-52 of the result (Gram entries within 3e-14 of sqrt(G_ii G_jj)).  Outliers / non-finite input / a prior mean send a regressor back to the fp64 kernel: then
+    # the bits must be the fp64 kernel's.
+    a = B._abi
+    h = a.default_handle()
+    rng = _rng(4200 + N + len(kind))
+    nb, D = 6, 128
+    X, y = _i8_case(rng, nb, N, kind)
+    dpr = np.exp(0.3 * rng.standard_normal((nb, D)))
+    mw = np.zeros((nb, D))
+    s = np.array([0.1])
+
+    def run():
+        mp = np.zeros((nb, D)); Tp = np.zeros((nb, D, D)); Ap = np.zeros((nb, D, D)); lp = np.zeros(nb); info = np.full(nb, 9, dtype=np.int32)
+        h.posterior_batched(np.float64, a.MEM_HOST, a.LAYOUT_COLVECS, nb, D, N, X, D, N * D, y, N, a.NOISE_ISOTROPIC, s, 0, a.PRIOR_DIAGONAL,
+                            mw, D, dpr, 1, D, mp, D, Tp, D, D * D, Ap, D, D * D, lp, info)
+        return mp, Tp, Ap, lp, info
+
+    fast = run()
+    again = run()
+    for u, v in zip(fast, again):
+        np.testing.assert_array_equal(u, v)  # fixed accumulation order on the fast path too
+    opt("NO_I8_GRAM", "1")
+    slow = run()
+    assert fast[4].tolist() == [0] * nb and slow[4].tolist() == [0] * nb
+    for b in range(nb):
+        mw_o, T_o, A_o, lp_o = O.posterior_logpdf_direct(mw[b], dpr[b], X[b].T, 0.1, y[b])
+        scale = np.abs(A_o).max()
+        for mp, Tp, Ap, lp, _ in (fast, slow):
+            assert lp[b] == pytest.approx(lp_o, rel=1e-11)
+            np.testing.assert_allclose(mp[b] * np.sqrt(np.diag(A_o)), mw_o * np.sqrt(np.diag(A_o)), rtol=1e-8, atol=1e-9 * np.abs(mw_o * np.sqrt(np.diag(A_o))).max())
+            # entries of A against the scale of their row and column (rows of very different magnitude: "scales")
+            dA = np.sqrt(np.diag(A_o))
+            assert (np.abs(Ap[b] - A_o) / np.outer(dA, dA)).max() <= 1e-12
+            Tn = np.triu(Tp[b].T)
+            assert (np.abs(Tn.T @ Tn - A_o) / np.outer(dA, dA)).max() <= 1e-10
+        # (the evidence is a difference of two terms ~1e3 times its size on well-explained data -- y'Sy against |u|^2: one ulp of
+        # those is 1e-12 of the evidence, on either path)
+        assert fast[3][b] == pytest.approx(slow[3][b], rel=1e-11)
+        dsc = np.sqrt(np.diag(O.posterior_logpdf_direct(mw[b], dpr[b], X[b].T, 0.1, y[b])[2]))
+        assert np.abs((fast[0][b] - slow[0][b]) * dsc).max() <= 1e-10 * np.abs(slow[0][b] * dsc).max()
+        if kind == "outlier" and b % 2 == 0:  # handed back: the fp64 kernel's bits
+            assert fast[3][b] == slow[3][b]
+            np.testing.assert_array_equal(fast[0][b], slow[0][b])
+            np.testing.assert_array_equal(fast[1][b], slow[1][b])
+
+
+def test_i8_gram_path_hands_back_what_it_cannot_do(B, opt):
+    # prior mean != 0, NaN / Inf in X, a bad noise variance, a non-positive prior entry: status, NaN evidence and untouched
+    # outputs exactly as the fp64 kernel reports them (the fast path either reproduces the status or hands the regressor back)
+    a = B._abi
+    h = a.default_handle()
+    rng = _rng(4300)
+    nb, D, N = 8, 128, 1024
+    X, y = _i8_case(rng, nb, N, "gauss")
+    dpr = np.ones((nb, D))
+    mw = np.zeros((nb, D))
+    mw[1] = rng.standard_normal(D)          # a prior mean
+    X[2, 100, 3] = np.nan                   # NaN in the stream
+    X[3, 900, 127] = np.inf                 # Inf late in the stream
+    dpr[4, 77] = -1.0                       # prior not positive definite: info = 78
+    X[5, 0, 0] = np.nan                     # NaN in the block the row bounds come from
+    s = np.array([0.1])
+
+    def run(svar):
+        mp = np.full((nb, D), 7.0); Tp = np.full((nb, D, D), 7.0); lp = np.zeros(nb); info = np.full(nb, 9, dtype=np.int32)
+        h.posterior_batched(np.float64, a.MEM_HOST, a.LAYOUT_COLVECS, nb, D, N, X, D, N * D, y, N, a.NOISE_ISOTROPIC, svar, 0, a.PRIOR_DIAGONAL,
+                            mw, D, dpr, 1, D, mp, D, Tp, D, D * D, None, D, D * D, lp, info)
+        return mp, Tp, lp, info
+
+    fast = run(s)
+    opt("NO_I8_GRAM", "1")
+    slow = run(s)
+    opt("NO_I8_GRAM", None)
+    assert fast[3].tolist() == slow[3].tolist()
+    assert fast[3][4] == 78 and fast[3][0] == 0 and fast[3][1] == 0
+    for b in range(nb):
+        if b in (1, 2, 3, 4, 5):  # handed back or failed before any arithmetic: identical bits / identical NaN pattern
+            np.testing.assert_array_equal(fast[0][b], slow[0][b])
+            np.testing.assert_array_equal(fast[1][b], slow[1][b])
+            assert (fast[2][b] == slow[2][b]) or (np.isnan(fast[2][b]) and np.isnan(slow[2][b]))
+        else:
+            assert fast[2][b] == pytest.approx(slow[2][b], rel=1e-11)
+    assert np.all(fast[0][4] == 7.0) and np.all(fast[1][4] == 7.0)  # failed regressor: outputs untouched
+    bad = run(np.array([-0.5]))  # sigma^2 <= 0: PosDefException(1) at reference :79 for every regressor whose prior is fine
+    assert bad[3].tolist() == [1, 1, 1, 1, 78, 1, 1, 1] and np.all(np.isnan(bad[2]))
+
+
 @pytest.mark.parametrize("nb", [8192, 1024])
 def test_c4_at_its_stated_batch_vs_literal_oracle(B, nb):
     # BASELINE config 4 exactly as stated -- 8192 x (D = 64, N = 1024), fp64, isotropic noise, Lw = I -- and the 1024-regressor
