@@ -26,6 +26,7 @@
 #include "blr_update.hpp"
 #include "blr_fused_wave.hpp"
 #include "blr_fused_i8.hpp"
+#include "blr_marginals.hpp"
 
 using namespace blr;
 
@@ -33,7 +34,7 @@ using namespace blr;
 // handle is created (BLR_MI355X_<KEY>), and settable per handle with blr_set_option: no getenv on any launch path.
 struct BlrOptions {
   bool no_ldsdma = false, no_wave_kernel = false, no_gram_ring = false, no_diag_split = false, no_xcd_swizzle = false,
-       no_mfma_project = false, plan_debug = false, no_i8_gram = false;
+       no_mfma_project = false, plan_debug = false, no_i8_gram = false, no_marg_gemm = false;
   int wave_split = 0;     // waves per regressor of the wave kernel: 0 = router, else 1 | 2 | 4
   int chain_batch = 0;    // regressors per shared launch at D > 128: 0 = as many as the workspace holds
   long chain_ws_mb = 0;   // workspace bound of such a group in MiB: 0 = kChainWorkspace
@@ -53,6 +54,7 @@ struct BlrOptions {
     if (!strcmp(key, "NO_MFMA_PROJECT")) return flag(no_mfma_project);
     if (!strcmp(key, "PLAN_DEBUG")) return flag(plan_debug);
     if (!strcmp(key, "NO_I8_GRAM")) return flag(no_i8_gram);
+    if (!strcmp(key, "NO_MARG_GEMM")) return flag(no_marg_gemm);
     if (!strcmp(key, "WAVE_SPLIT")) {
       const int v = on ? atoi(value) : 0;
       wave_split = (v == 1 || v == 2 || v == 4) ? v : 0;
@@ -73,7 +75,7 @@ struct BlrOptions {
   }
   void from_environment() {
     for (const char* k : {"NO_LDSDMA", "NO_WAVE_KERNEL", "NO_GRAM_RING", "NO_DIAG_SPLIT", "NO_XCD_SWIZZLE", "NO_MFMA_PROJECT", "PLAN_DEBUG",
-                          "NO_I8_GRAM", "WAVE_SPLIT", "CHAIN_BATCH", "CHAIN_WS_MB", "SWEEP", "GRAM_SPLITS"}) {
+                          "NO_I8_GRAM", "NO_MARG_GEMM", "WAVE_SPLIT", "CHAIN_BATCH", "CHAIN_WS_MB", "SWEEP", "GRAM_SPLITS"}) {
       const std::string name = std::string("BLR_MI355X_") + k;
       if (const char* v = getenv(name.c_str())) (void)set(k, *v ? v : "1");  // (an empty variable still switches a flag on)
     }
@@ -94,6 +96,8 @@ struct blr_handle {
   size_t ws_bytes = 0;
   char* feat = nullptr;        // grow-only feature matrix of blr_posterior_rff_*
   size_t feat_bytes = 0;
+  char* aux = nullptr;         // grow-only: triangular-inverse images of the marginal stream (blr_marginals.hpp)
+  size_t aux_bytes = 0;
   // wavefront back substitution (D > 128): tagged exchange buffer, start-order ticket counter, launch epoch
   unsigned long long* xchg = nullptr;
   size_t xchg_bytes = 0;
@@ -225,6 +229,19 @@ int ensure_ws(blr_handle* h, size_t bytes) {
   size_t want = std::max(bytes, (size_t)1 << 20);
   HIP_TRY(h, hipMalloc((void**)&h->ws, want));
   h->ws_bytes = want;
+  return 0;
+}
+
+int ensure_aux(blr_handle* h, size_t bytes) {
+  if (bytes <= h->aux_bytes) return 0;
+  if (h->aux) {
+    HIP_TRY(h, hipStreamSynchronize(h->stream));
+    HIP_TRY(h, hipFree(h->aux));
+    h->aux = nullptr;
+    h->aux_bytes = 0;
+  }
+  HIP_TRY(h, hipMalloc((void**)&h->aux, bytes));
+  h->aux_bytes = bytes;
   return 0;
 }
 
@@ -1071,7 +1088,30 @@ int marginals_batched(blr_handle* h, int memspace, int layout, int64_t B, int64_
   a.info = chol_info;
   if (chol_info) HIP_TRY(h, hipMemcpyAsync(info_out_dev, chol_info, (size_t)B * sizeof(int32_t), hipMemcpyDeviceToDevice, h->stream));
   else HIP_TRY(h, hipMemsetAsync(info_out_dev, 0, (size_t)B * sizeof(int32_t), h->stream));
-  {
+  // D = 128 with a factor, aligned ColVecs: the triangular inverse once per regressor, then a dependency-free product
+  // (blr_marginals.hpp); regressors in chunks whose images fit 256 MiB
+  if (var && kind == BLR_PRIOR_UPPER_FACTOR && !h->opt.no_marg_gemm && D == kPB && layout == BLR_LAYOUT_COLVECS && N >= 64 &&
+      (ldx % Mfma<T>::VEC) == 0 && ((uintptr_t)a.X % 16) == 0 && ((strideX * (int64_t)sizeof(T)) % 16) == 0) {
+    using G = MargGemmCfg<T>;
+    using TC = TrsmCfg<T>;
+    const int64_t chunk = std::min<int64_t>(std::min<int64_t>(B, 65535), ((int64_t)256 << 20) / (G::IMG_ELEMS * (int64_t)sizeof(T)));
+    if ((rc = ensure_aux(h, (size_t)chunk * G::IMG_ELEMS * sizeof(T)))) return rc;
+    if ((rc = set_lds_once(h, reinterpret_cast<const void*>(marg_image_kernel<T>), (size_t)TC::LDS_BYTES))) return rc;
+    if ((rc = set_lds_once(h, reinterpret_cast<const void*>(marginals_gemm_kernel<T>), (size_t)G::LDS_BYTES))) return rc;
+    T* const img = reinterpret_cast<T*>(h->aux);
+    const int64_t ntiles = (N + 15) / 16;
+    for (int64_t b0 = 0; b0 < B; b0 += chunk) {
+      const int64_t nb = std::min<int64_t>(chunk, B - b0);
+      // (the kernels index regressor reg0 + blockIdx; the images of a chunk start at its first regressor)
+      hipLaunchKernelGGL(marg_image_kernel<T>, dim3((unsigned)nb, 2), dim3(kThreads), TC::LDS_BYTES, h->stream, a.U, a.ldu, a.strideU, (int)D,
+                         img - b0 * G::IMG_ELEMS, a.info, (int)b0);
+      // two workgroups per CU; every workgroup copies the 74 KB image once: give it at least four tiles per wave
+      const int64_t per_reg = std::max<int64_t>(1, std::min<int64_t>((ntiles + 15) / 16, (2 * (int64_t)h->cus * 2 + nb - 1) / nb));
+      a.reg0 = (int)b0;
+      hipLaunchKernelGGL(marginals_gemm_kernel<T>, dim3((unsigned)per_reg, (unsigned)nb), dim3(kThreads), G::LDS_BYTES, h->stream, a,
+                         (const T*)(img - b0 * G::IMG_ELEMS));
+    }
+  } else {
     // inputs as rows of an LDS block; with a factor: Y = X'L^-T by the TRSM sweep (MFMA), fused mean / row sum of squares;
     // mean-only and diagonal-prior calls are pure streams through the same tile loop (smaller LDS image, 2 workgroups/CU)
     using TC = TrsmCfg<T>;
@@ -2520,6 +2560,7 @@ int blr_destroy(blr_handle* h) {
   if (h->comm && rccl().ok) (void)rccl().CommDestroy(h->comm);
   if (h->ws) (void)hipFree(h->ws);
   if (h->feat) (void)hipFree(h->feat);
+  if (h->aux) (void)hipFree(h->aux);
   if (h->xchg) (void)hipFree(h->xchg);
   if (h->ticket) (void)hipFree(h->ticket);
   if (h->ev0) (void)hipEventDestroy(h->ev0);
