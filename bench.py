@@ -142,6 +142,7 @@ class Workload:
     def __init__(self, torch, _abi, h, dev, name, B, D, N, dtype, noise, seed, Din=None, mw_random=False, logpdf_only=False, block=None):
         self.name, self.B, self.D, self.N, self.dtype, self.noise, self.Din = name, B, D, N, dtype, noise, Din
         self.logpdf_only = logpdf_only
+        self.mw_random = mw_random
         self.torch, self._abi, self.h = torch, _abi, h
         t_dt = torch.float64 if dtype == "f64" else torch.float32
         self.np_dt = np.float64 if dtype == "f64" else np.float32
@@ -215,6 +216,9 @@ class Workload:
         t = "double" if self.dtype == "f64" else "float"
         if self.D == 64 or (self.D == 32 and self.dtype == "f64"):
             return f"fused_wave_kernel<{t}, {self.D // 16}>"  # one wavefront per regressor (diagonal prior, aligned ColVecs)
+        if self.D == 128 and self.dtype == "f64" and not self.diag and self.N % 32 == 0 and 512 <= self.N <= 16384 and not self.mw_random \
+                and os.environ.get("BLR_MI355X_NO_I8_GRAM") is None:
+            return "fused_i8_kernel"  # Gram on the int8 matrix cores (blr_fused_i8.hpp); its retry pass is an empty launch here
         if self.D <= 128:
             return f"fused_small_kernel<{t}, {(self.D + 15) // 16}, 4>"  # MODE 4: ColVecs through LDS-DMA
         return f"gram_tile_kernel<{t}>"
@@ -232,6 +236,19 @@ class Workload:
             r = {"bound": "mfma", "achieved": tf, "peak": PEAK_TF[self.dtype], "unit": "TFLOP/s", "frac": tf / PEAK_TF[self.dtype]}
         else:
             r = {"bound": "hbm", "achieved": gbs, "peak": PEAK_HBM_GBS, "unit": "GB/s", "frac": gbs / PEAK_HBM_GBS}
+        if self.kernel_name() == "fused_i8_kernel":
+            # The Gram of this path runs on the INT8 matrix cores: 26 digit-pair products per 32 x 32 tile, 10 lower tiles, 2 x 32 x 32
+            # operations per column and product (blr_fused_i8.hpp) against the dense int8 peak (2 x the bf16 peak per clock:
+            # 5 POP/s, MI355X_MICROARCH.md matrix-core table).  That takes less time than streaming X at 8 TB/s, so the binding
+            # roofline of the update is HBM; the fp64-equivalent rate stays in mfma_TFLOPps for comparison with the fp64 kernel.
+            ops = 26 * 10 * 2048.0 * self.N * self.B
+            t_i8 = ops / 5.0e15
+            i8 = {"int8_ops": ops, "int8_TOPps": ops / (ms * 1e-3) / 1e12, "int8_peak_TOPps": 5000.0, "int8_frac": ops / (ms * 1e-3) / 5.0e15}
+            if t_hbm >= t_i8:
+                r = {"bound": "hbm", "achieved": gbs, "peak": PEAK_HBM_GBS, "unit": "GB/s", "frac": gbs / PEAK_HBM_GBS}
+            else:
+                r = {"bound": "mfma", "achieved": i8["int8_TOPps"], "peak": 5000.0, "unit": "TOP/s (int8)", "frac": i8["int8_frac"]}
+            r.update(i8)
         r.update({"kernel": self.kernel_name(), "kernel_ms_avg": ms, "units_per_launch": self.B, "algorithmic_bytes": by,
                   "algorithmic_flops": fl, "hbm_GBps": gbs, "hbm_frac": gbs / PEAK_HBM_GBS, "mfma_TFLOPps": tf,
                   "mfma_frac": tf / PEAK_TF[self.dtype]})
@@ -472,7 +489,7 @@ def run_secondary(torch, _abi, h, dev, stream, only=None):
                     per_call *= op.units
             r["traffic"], r["traffic_source"] = per_call, src
             sec[name] = {"workload": op.workload, "ms": ms, "unit": op.unit, "per_s": op.units / (ms * 1e-3),
-                         "wall_per_s": op.units * op.steps / wall, "roofline": r}
+                         "wall_per_s": op.units * op.steps / wall, "calls": op.steps + 3, "roofline": r}
             if op.unit == "updates/s":
                 sec[name]["updates_per_s"] = sec[name]["per_s"]
             del op
@@ -671,7 +688,9 @@ def main():
     if rank == 0:
         value = global_batch * args.steps / elapsed
         roof = wl.roofline(kern_ms)
-        per_update, src = pmc_traffic_per_update("c2_fused_small_kernel_hbm") if headline else (None, None)
+        per_update, src = (None, None)
+        if headline:
+            per_update, src = pmc_traffic_per_update("c2_fused_i8_kernel_hbm" if roof["kernel"] == "fused_i8_kernel" else "c2_fused_small_kernel_hbm")
         peak_meas, peak_src = measured_matrix_peak(args.dtype)
         roof.update({
             "traffic": per_update * B if per_update else None,

@@ -42,7 +42,22 @@ rocprofv3 --pmc $SQ --kernel-trace --output-format csv -d $OUT/pmc_sq_c3b8 -- $B
 # the clock the part holds: ring loop of the headline kernel on zero / random operands, cache-resident / streamed
 ( cd $R/tools && [ -x ./ring_probe ] || /opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -std=c++17 -DRING_MWZ=true -I$R/bayesianlinearregressors.jl_amd/csrc ring_probe.hip -o ring_probe 2>/dev/null
   { echo "# tools/ring_probe 8192 0 (zero operands)"; ./ring_probe 8192 0; echo "# tools/ring_probe 8192 1 (random operands)"; ./ring_probe 8192 1; } > $OUT/ring_probe.txt 2>&1
-  python3 $R/tools/power_probe.py > $OUT/power_probe.txt 2>&1 )
+  python3 $R/tools/power_probe.py > $OUT/power_probe.txt 2>&1
+  # int8-sliced Gram against the fp64 kernel, same inputs: rates, agreement, the retry path (mode 1), per-phase cycle stamps
+  { for m in 0 2; do ./i8_gram 4096 4096 10 $m; done; ./i8_gram 512 4096 3 1; ./i8_gram 512 1024 3 0; [ -x ./i8_gram_st ] && ./i8_gram_st 4096 4096 4 0 | grep "wave"; } > $OUT/i8_gram.txt 2>&1 )
+# every secondary entry of the driver line: kernel stats of the hot-path rows, HBM bytes per CALL (all of a call's kernels) by PMC
+for e in marginals_var_c2_f64 marginals_var_c3_f32 rand_c2_f64_S64 rand_c3_f32_S64 logpdf_grad_c2_f64; do
+  rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/stats_$e -- $B --secondary-only $e > /dev/null 2>&1
+done
+for e in c2_f64_mw c2_f64_diag_noise c4_f32 c4_f64_B1024 c3_f32_mw logpdf_only_c3_f32 c3_f32_B8 c5_shape_f32_B8 marginals_mean_c2_f64 marginals_var_c2_f64 \
+         marginals_var_c2_f32 marginals_mean_c3_f32 marginals_var_c3_f32 rand_c2_f64_S64 rand_c3_f32_S64 logpdf_grad_c2_f64 logpdf_multi_c3_f32_S64 \
+         update_factor_D128_k1_f64 update_factor_D128_k16_f64; do
+  rocprofv3 --pmc FETCH_SIZE --kernel-trace --output-format csv -d $OUT/sec_fetch_$e -- $B --secondary-only $e > $OUT/sec_fetch_$e.json 2>/dev/null
+  rocprofv3 --pmc WRITE_SIZE --kernel-trace --output-format csv -d $OUT/sec_write_$e -- $B --secondary-only $e > $OUT/sec_write_$e.json 2>/dev/null
+done
+# the headline kernels of this round: int8-sliced Gram (default) and the fp64 kernel (BLR_MI355X_NO_I8_GRAM=1)
+BLR_MI355X_NO_I8_GRAM=1 python3 $R/bench.py --cpu-seconds 0 --secondary 0 > $OUT/bench_c2_f64_fp64kernel.json 2>/dev/null
+rocprofv3 --pmc $SQ --kernel-trace --output-format csv -d $OUT/pmc_sq_c2_i8 -- $B --steps 5 --warmup 2 > /dev/null 2>&1
 find $OUT -name "*agent_info*" -delete
 ls -R $OUT | head -80
 cat $OUT/bench_c2_f64.json | cut -c1-400

@@ -9,7 +9,7 @@ import os
 import shutil
 import sys
 
-tag = sys.argv[1] if len(sys.argv) > 1 else "r03"
+tag = sys.argv[1] if len(sys.argv) > 1 else "r04"
 RAW = "gpurun_out/profiles_raw"
 DST = "profiles"
 os.makedirs(DST, exist_ok=True)
@@ -20,11 +20,11 @@ def one(pattern):
     return max(g, key=os.path.getmtime) if g else None
 
 
-for name in ("bench_c2_f64", "bench_c2_f32", "bench_c3_f32", "bench_c5_f32", "bench_c4_f64", "bench_c3_f32_B8"):
+for name in ("bench_c2_f64", "bench_c2_f32", "bench_c3_f32", "bench_c5_f32", "bench_c4_f64", "bench_c3_f32_B8", "bench_c2_f64_fp64kernel"):
     src = os.path.join(RAW, name + ".json")
     if os.path.exists(src) and os.path.getsize(src):
         shutil.copy(src, os.path.join(DST, f"{tag}_{name}.json"))
-for cfg in ("c2", "c3", "c5", "c4", "c3b8"):
+for cfg in ("c2", "c3", "c5", "c4", "c3b8", "marginals_var_c2_f64", "marginals_var_c3_f32", "rand_c2_f64_S64", "rand_c3_f32_S64", "logpdf_grad_c2_f64"):
     f = one(f"{RAW}/stats_{cfg}/*/*_kernel_stats.csv")
     if f:
         shutil.copy(f, os.path.join(DST, f"{tag}_{cfg}_kernel_stats.csv"))
@@ -100,7 +100,7 @@ for key, d, kern, units in (("c2_f32_fused_small_kernel_hbm", "c2f32", "fused_sm
 for src in sorted(glob.glob(os.path.join(os.path.dirname(RAW), "microbench", "*.txt"))):  # tools/run_microbench.sh
     if os.path.getsize(src):
         shutil.copy(src, os.path.join(DST, f"{tag}_microbench_{os.path.basename(src)}"))
-for extra in ("ring_probe.txt", "power_probe.txt"):
+for extra in ("ring_probe.txt", "power_probe.txt", "i8_gram.txt"):
     src = os.path.join(RAW, extra)
     if os.path.exists(src) and os.path.getsize(src):
         shutil.copy(src, os.path.join(DST, f"{tag}_microbench_{extra}"))
@@ -111,5 +111,46 @@ for key, c in (("c2_fused_small_kernel_sq", sq2), ("c2_f32_fused_small_kernel_sq
         c["effective_clock_GHz"] = c["GRBM_GUI_ACTIVE"] / 8.0 / ns
         c["mfma_busy_fraction_of_simd_cycles"] = c["SQ_VALU_MFMA_BUSY_CYCLES"] / (1024.0 * c["effective_clock_GHz"] * ns)
         summary[key] = c
+
+
+def call_bytes(dirname, counter):
+    """sum of a counter over every blr:: dispatch of a `bench.py --secondary-only <entry>` run"""
+    f_new = one(f"{RAW}/{dirname}/*/*_counter_collection.csv")
+    if not f_new:
+        return None
+    tot = 0.0
+    for r in csv.DictReader(open(f_new)):
+        if "blr::" in r["Kernel_Name"] and r["Counter_Name"] == counter:
+            tot += float(r["Counter_Value"])
+    return tot
+
+
+for f in sorted(glob.glob(f"{RAW}/sec_fetch_*.json")):
+    e = os.path.basename(f)[len("sec_fetch_"):-len(".json")]
+    try:
+        calls = json.load(open(f))["secondary"][e]["calls"]
+    except Exception:
+        continue
+    fe, wr = call_bytes(f"sec_fetch_{e}", "FETCH_SIZE"), call_bytes(f"sec_write_{e}", "WRITE_SIZE")
+    if fe is None or wr is None:
+        continue
+    rd, wb = fe * 1024.0 * 2.0 / calls, wr * 1024.0 / calls  # (FETCH_SIZE x 2 on gfx950, as above)
+    summary[e + "_hbm"] = {"hbm_read_bytes_per_launch": rd, "hbm_write_bytes_per_launch": wb, "hbm_bytes_per_launch": rd + wb,
+                           "units_per_launch": 1, "calls_profiled": calls,
+                           "note": "all blr:: kernels of one call (bench.py --secondary-only), warm-up calls included in the mean"}
+sq_i8 = counters("pmc_sq_c2_i8", "fused_i8_kernel")
+if sq_i8:
+    ns = sq_i8["avg_duration_ns"]
+    sq_i8["effective_clock_GHz"] = sq_i8["GRBM_GUI_ACTIVE"] / 8.0 / ns
+    sq_i8["mfma_busy_fraction_of_simd_cycles"] = sq_i8["SQ_VALU_MFMA_BUSY_CYCLES"] / (1024.0 * sq_i8["effective_clock_GHz"] * ns)
+    summary["c2_fused_i8_kernel_sq"] = sq_i8
+for key, d in (("c2_fused_i8_kernel_hbm", "c2"),):
+    fe, wr_ = counters(f"pmc_fetch_{d}", "fused_i8_kernel"), counters(f"pmc_write_{d}", "fused_i8_kernel")
+    if fe and wr_:
+        rd = fe["FETCH_SIZE"] * 1024.0 * 2.0
+        wr = wr_["WRITE_SIZE"] * 1024.0
+        summary[key] = {"FETCH_SIZE_KiB": fe["FETCH_SIZE"], "WRITE_SIZE_KiB": wr_["WRITE_SIZE"], "hbm_read_bytes_per_launch": rd,
+                        "hbm_write_bytes_per_launch": wr, "hbm_bytes_per_launch": rd + wr, "units_per_launch": 4096,
+                        "kernel": "fused_i8_kernel", "avg_duration_ns": fe["avg_duration_ns"]}
 json.dump(summary, open(os.path.join(DST, f"{tag}_pmc_summary.json"), "w"), indent=1)
 print(json.dumps(summary, indent=1)[:3000])
