@@ -51,6 +51,7 @@ _SIGS = {
     "blr_set_async": ([_H, _int], _int),
     "blr_synchronize": ([_H], _int),
     "blr_set_option": ([_H, C.c_char_p, C.c_char_p], _int),
+    "blr_release_workspace": ([_H], _int),
     "blr_device_alloc": ([_H, C.c_size_t, C.POINTER(_vp)], _int),
     "blr_device_free": ([_H, _vp], _int),
     "blr_memcpy_h2d": ([_H, _vp, _vp, C.c_size_t], _int),
@@ -205,6 +206,10 @@ class Handle:
 
     def synchronize(self):
         self.check(self.lib.blr_synchronize(self._h))
+
+    def release_workspace(self):
+        """Free the handle's grow-only device scratch (include/blr_mi355x.h blr_release_workspace)."""
+        self.check(self.lib.blr_release_workspace(self._h))
 
     def set_option(self, key, value=None):
         """Run-time switch of this handle (include/blr_mi355x.h blr_set_option); value None = the built-in default."""

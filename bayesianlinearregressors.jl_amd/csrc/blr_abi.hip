@@ -429,7 +429,9 @@ int launch_panel(blr_handle* h, T* M, int64_t ld, int p, int nrows_total, int nb
   return 0;
 }
 
-constexpr size_t kChainWorkspace = (size_t)8 << 30;  // ... as long as their workspaces fit this many bytes
+// ... as long as their workspaces fit this many bytes (per handle; option CHAIN_WS_MB lowers the bound, blr_release_workspace
+// hands the memory back: the scratch buffers of a handle only ever grow otherwise)
+constexpr size_t kChainWorkspace = (size_t)8 << 30;
 constexpr int kChainBatchMax = kChainBatchMaxWords;  // factorisations that step through their panels in shared launches (one arrival word each per bank)
 
 // Blocked Cholesky of G independent matrices M + g * batch_stride (status words info_dev + g * info_stride), panel by panel,
@@ -531,77 +533,101 @@ int posterior_large_group(blr_handle* h, const PosteriorArgs<T>& a, int64_t reg0
   const int64_t lda = DP + kPB;
   const int ntiles = NC * (NC + 1) / 2;
   const int nstage_cols = LC::NSC;
-  // split-K factor: fill the 2 x 256 workgroup slots of the chip in whole rounds (576 workgroups on 512 slots
-  // would take two rounds for 1.125 rounds of work)
+  // The split plan depends on how many regressors share the launch -- and the workspace one regressor needs depends on the
+  // plan.  Plan for the requested group first, clamp the group to the workspace bound, then plan AGAIN for the group that will
+  // really run (a clamped group used to run with the split of the larger one: under-split, fewer rounds than modelled).
+  int nsplit = 1, nsplit_diag = 0, nlong = 0;
   const int max_split_cols = std::max(1, (N + nstage_cols - 1) / nstage_cols);
   const int max_split = std::min(64, max_split_cols);
-  // model of the launch: rounds x (columns per workgroup + 256) -- the 256 stands for a workgroup's fixed costs (pipeline fill,
-  // the 64 KB partial it writes and the reduction reads back), fitted on c5 (136 tiles: 15 splits 1.232 ms, 11: 1.204, 7: 1.210)
-  int nsplit = 1;
-  double best = 1e300;
-  for (int sp = 1; sp <= max_split; ++sp) {
-    const int wgs = ntiles * sp * G;  // (the whole group's tiles are one launch)
-    const int slots = h->cus * (sizeof(T) == 4 ? BLR_GRAM_WGS : 2);
-    const int rounds = (wgs + slots - 1) / slots;
-    const int cols_sp = ((N + sp - 1) / sp + nstage_cols - 1) / nstage_cols * nstage_cols;
-    const double cost = (double)rounds * (cols_sp + 256.0);
-    if (cost < best) { best = cost; nsplit = sp; }
-  }
-  // Diagonal macro tiles cost less per column than off-diagonal ones in the ring loop (only the 36 tiles of 16 x 16 on or below
-  // the diagonal are computed: 10 MFMAs per k-step on the critical waves instead of 16; measured ~11.5 with the b partials
-  // riding along), so in a single-round launch they get their OWN split factor: fewer, longer column ranges, and the
-  // workgroup slots that frees go to the off-diagonal tiles.  Chosen so that the longest workgroup is shortest
-  // (c3: 36 x 14 -> 28 x 15 + 8 x 11, i.e. 16 N / 14 -> 16 N / 15 per workgroup on 508 of 512 slots: 0.963 -> 0.935 ms;
-  // tools/scan_splits.sh).  Multi-round launches (c5: 136 tiles x 15) keep one factor: there the dispatcher balances.
-  constexpr double kDiagCost = 11.5;
-  int nsplit_diag = 0;  // 0: one factor for all tiles
-  int nlong = 0;        // strictly lower tiles with one column range less (multi-round launches)
-  {
-    const int slots = h->cus * (sizeof(T) == 4 ? BLR_GRAM_WGS : 2);
-    // (only where the diagonal tiles will go through the ring loop: f32, LDS-DMA staging, whole row blocks)
-    const T* X0 = a.X + reg0 * a.strideX;
-    const bool dealt = sizeof(T) == 4 && a.layout == LAYOUT_COLVECS && ((uintptr_t)X0 % 16 == 0) &&
-                       ((a.ldx * (int64_t)sizeof(T)) % 16 == 0) && !h->opt.no_gram_ring &&
-                       !h->opt.no_diag_split && D % kPB == 0 && NC >= 2 && (ntiles * nsplit * G <= slots || h->opt.gs_fields >= 2);
-    if (h->opt.gs_fields >= 2) {  // "off-diagonal,diagonal" (equal: one factor): measurements only
-      const int so = h->opt.gs_so, sd = h->opt.gs_sd, nl = h->opt.gs_nl, nf = h->opt.gs_fields;
-      if (nf >= 2 && so >= 1 && sd >= 1 && sd <= so && so <= max_split) {
-        nsplit = so;
-        nsplit_diag = ((sd < so || nf == 3) && dealt) ? sd : 0;
-        if (nf == 3 && nsplit_diag > 0 && so >= 2) nlong = std::max(0, std::min(nl, ntiles - NC));
-      }
-    } else if (dealt) {
-      auto cols = [&](int sp) { return (double)(((N + sp - 1) / sp + nstage_cols - 1) / nstage_cols * nstage_cols); };
-      const int n_off = ntiles - NC;
-      double best_t = 16.0 * cols(nsplit);  // today's longest workgroup (diagonal tiles shorter, off-diagonal ones set the time)
-      int bo = 0, bd = 0;
-      for (int so = 1; so <= max_split; ++so)
-        for (int sd = 1; sd <= so; ++sd) {
-          if ((n_off * so + NC * sd) * G > slots) break;
-          const double t = std::max(16.0 * cols(so), kDiagCost * cols(sd)) * (1.0 + 0.002 * so);
-          if (t < best_t * 0.995) { best_t = t; bo = so; bd = sd; }
-        }
-      if (bo > 0) { nsplit = bo; nsplit_diag = bd; }
+  auto plan_splits = [&](int G) {
+    // split-K factor: fill the 2 x 256 workgroup slots of the chip in whole rounds (576 workgroups on 512 slots
+    // would take two rounds for 1.125 rounds of work)
+    // model of the launch: rounds x (columns per workgroup + 256) -- the 256 stands for a workgroup's fixed costs (pipeline fill,
+    // the 64 KB partial it writes and the reduction reads back), fitted on c5 (136 tiles: 15 splits 1.232 ms, 11: 1.204, 7: 1.210)
+    nsplit = 1;
+    double best = 1e300;
+    for (int sp = 1; sp <= max_split; ++sp) {
+      const int wgs = ntiles * sp * G;  // (the whole group's tiles are one launch)
+      const int slots = h->cus * (sizeof(T) == 4 ? BLR_GRAM_WGS : 2);
+      const int rounds = (wgs + slots - 1) / slots;
+      const int cols_sp = ((N + sp - 1) / sp + nstage_cols - 1) / nstage_cols * nstage_cols;
+      const double cost = (double)rounds * (cols_sp + 256.0);
+      if (cost < best) { best = cost; nsplit = sp; }
     }
-    // multi-round launch of one regressor: three kinds of work items (plan_gram_rounds)
-    const bool ring_ok = sizeof(T) == 4 && a.layout == LAYOUT_COLVECS && ((uintptr_t)X0 % 16 == 0) &&
+    // Diagonal macro tiles cost less per column than off-diagonal ones in the ring loop (only the 36 tiles of 16 x 16 on or below
+    // the diagonal are computed: 10 MFMAs per k-step on the critical waves instead of 16; measured ~11.5 with the b partials
+    // riding along), so in a single-round launch they get their OWN split factor: fewer, longer column ranges, and the
+    // workgroup slots that frees go to the off-diagonal tiles.  Chosen so that the longest workgroup is shortest
+    // (c3: 36 x 14 -> 28 x 15 + 8 x 11, i.e. 16 N / 14 -> 16 N / 15 per workgroup on 508 of 512 slots: 0.963 -> 0.935 ms;
+    // tools/scan_splits.sh).  Multi-round launches (c5: 136 tiles x 15) keep one factor: there the dispatcher balances.
+    constexpr double kDiagCost = 11.5;
+    nsplit_diag = 0;  // 0: one factor for all tiles
+    nlong = 0;        // strictly lower tiles with one column range less (multi-round launches)
+    {
+      const int slots = h->cus * (sizeof(T) == 4 ? BLR_GRAM_WGS : 2);
+      // (only where the diagonal tiles will go through the ring loop: f32, LDS-DMA staging, whole row blocks)
+      const T* X0 = a.X + reg0 * a.strideX;
+      const bool dealt = sizeof(T) == 4 && a.layout == LAYOUT_COLVECS && ((uintptr_t)X0 % 16 == 0) &&
                          ((a.ldx * (int64_t)sizeof(T)) % 16 == 0) && !h->opt.no_gram_ring &&
-                         !h->opt.no_diag_split && h->opt.gs_fields < 2 && D % kPB == 0 && NC >= 2;
-    if (ring_ok && G == 1 && nsplit_diag == 0 && ntiles * nsplit > slots && nsplit >= 2) {
-      const std::array<int, 3> key{NC, N, slots};
-      auto it = h->gram_plans.find(key);
-      if (it == h->gram_plans.end()) {
-        const GramPlan pl = plan_gram_rounds(ntiles - NC, NC, nsplit, N, nstage_cols, slots, max_split, kDiagCost / 16.0);
-        it = h->gram_plans.emplace(key, std::array<int, 3>{pl.so, pl.sd, pl.nlong}).first;
-        if (h->opt.plan_debug)
-          fprintf(stderr, "blr: Gram plan for %d row blocks, N = %d: one factor %d -> ranges %d (off-diagonal, %d tiles with %d) / %d (diagonal), "
-                          "modelled makespan %.0f column units\n", NC, N, nsplit, pl.so, pl.nlong, pl.so - 1, pl.sd, pl.makespan);
+                         !h->opt.no_diag_split && D % kPB == 0 && NC >= 2 && (ntiles * nsplit * G <= slots || h->opt.gs_fields >= 2);
+      if (h->opt.gs_fields >= 2) {  // "off-diagonal,diagonal" (equal: one factor): measurements only
+        const int so = h->opt.gs_so, sd = h->opt.gs_sd, nl = h->opt.gs_nl, nf = h->opt.gs_fields;
+        if (nf >= 2 && so >= 1 && sd >= 1 && sd <= so && so <= max_split) {
+          nsplit = so;
+          nsplit_diag = ((sd < so || nf == 3) && dealt) ? sd : 0;
+          if (nf == 3 && nsplit_diag > 0 && so >= 2) nlong = std::max(0, std::min(nl, ntiles - NC));
+        }
+      } else if (dealt) {
+        auto cols = [&](int sp) { return (double)(((N + sp - 1) / sp + nstage_cols - 1) / nstage_cols * nstage_cols); };
+        const int n_off = ntiles - NC;
+        double best_t = 16.0 * cols(nsplit);  // today's longest workgroup (diagonal tiles shorter, off-diagonal ones set the time)
+        int bo = 0, bd = 0;
+        for (int so = 1; so <= max_split; ++so)
+          for (int sd = 1; sd <= so; ++sd) {
+            if ((n_off * so + NC * sd) * G > slots) break;
+            const double t = std::max(16.0 * cols(so), kDiagCost * cols(sd)) * (1.0 + 0.002 * so);
+            if (t < best_t * 0.995) { best_t = t; bo = so; bd = sd; }
+          }
+        if (bo > 0) { nsplit = bo; nsplit_diag = bd; }
       }
-      if (it->second[1] > 0) { nsplit = it->second[0]; nsplit_diag = it->second[1]; nlong = it->second[2]; }
+      // multi-round launch of one regressor: three kinds of work items (plan_gram_rounds)
+      const bool ring_ok = sizeof(T) == 4 && a.layout == LAYOUT_COLVECS && ((uintptr_t)X0 % 16 == 0) &&
+                           ((a.ldx * (int64_t)sizeof(T)) % 16 == 0) && !h->opt.no_gram_ring &&
+                           !h->opt.no_diag_split && h->opt.gs_fields < 2 && D % kPB == 0 && NC >= 2;
+      if (ring_ok && G == 1 && nsplit_diag == 0 && ntiles * nsplit > slots && nsplit >= 2) {
+        const std::array<int, 3> key{NC, N, slots};
+        auto it = h->gram_plans.find(key);
+        if (it == h->gram_plans.end()) {
+          const GramPlan pl = plan_gram_rounds(ntiles - NC, NC, nsplit, N, nstage_cols, slots, max_split, kDiagCost / 16.0);
+          it = h->gram_plans.emplace(key, std::array<int, 3>{pl.so, pl.sd, pl.nlong}).first;
+          if (h->opt.plan_debug)
+            fprintf(stderr, "blr: Gram plan for %d row blocks, N = %d: one factor %d -> ranges %d (off-diagonal, %d tiles with %d) / %d (diagonal), "
+                            "modelled makespan %.0f column units\n", NC, N, nsplit, pl.so, pl.nlong, pl.so - 1, pl.sd, pl.makespan);
+        }
+        if (it->second[1] > 0) { nsplit = it->second[0]; nsplit_diag = it->second[1]; nlong = it->second[2]; }
+      }
     }
-  }
+  };
+  plan_splits(G);
   const bool prior_factor = a.prior_kind == PRIOR_UPPER_FACTOR;
   const int pf = prior_factor ? 1 : 0;
+  size_t ws_cap = kChainWorkspace;
+  if (h->opt.chain_ws_mb > 0) ws_cap = (size_t)h->opt.chain_ws_mb << 20;  // tests: small groups
+  {
+    auto al = [](size_t b) { return (b + 255) & ~(size_t)255; };
+    auto per_for = [&](int nsp) {  // the carve below, as a function of the split factor
+      const size_t nst = (size_t)(nsp + pf);
+      return al((size_t)lda * DP * sizeof(T)) + al(a.prior_kind == PRIOR_DENSE ? (size_t)DP * DP * sizeof(T) : 0) +
+             al(nst * ntiles * kPB * kPB * sizeof(T)) + al(nst * NC * kPB * sizeof(double)) + al((size_t)std::max(N, 1) * sizeof(T)) +
+             al(a.noise_kind == NOISE_DIAGONAL ? (size_t)std::max(N, 1) * sizeof(T) : 0) + 2 * al((size_t)1024 * sizeof(double)) +
+             al((size_t)DP * DP * sizeof(T)) + al(64);
+    };
+    const int Gc = (int)std::max<size_t>(1, std::min<size_t>((size_t)G, ws_cap / per_for(nsplit)));
+    if (Gc != G) {
+      G = Gc;
+      plan_splits(G);
+    }
+  }
   const int nsplit_total = nsplit + pf;  // (nsplit_diag <= nsplit: the partial workspace is laid out for the larger factor)
   const int gridc = 1024;
 
@@ -621,9 +647,7 @@ int posterior_large_group(blr_handle* h, const PosteriorArgs<T>& a, int64_t reg0
   const size_t o_m = carve((size_t)DP * DP * sizeof(T));  // transposed factor for the back substitution
   const size_t o_sc = carve(64);
   const size_t per = off;  // one regressor's workspace (a multiple of 256 bytes)
-  size_t ws_cap = kChainWorkspace;
-  if (h->opt.chain_ws_mb > 0) ws_cap = (size_t)h->opt.chain_ws_mb << 20;  // tests: small groups
-  G = (int)std::max<size_t>(1, std::min<size_t>((size_t)G, ws_cap / per));
+  G = (int)std::max<size_t>(1, std::min<size_t>((size_t)G, ws_cap / per));  // (the re-planned split may need a little more per regressor)
   int rc;
   for (;;) {  // (a device too full for the whole group's workspace: smaller groups, down to one regressor at a time)
     rc = ensure_ws(h, per * (size_t)G);
@@ -2571,6 +2595,17 @@ int blr_destroy(blr_handle* h) {
 }
 
 const char* blr_last_error(blr_handle* h) { return h ? h->err.c_str() : "null handle"; }
+
+int blr_release_workspace(blr_handle* h) {
+  if (!h) return -1;
+  h->err.clear();
+  HIP_TRY(h, hipSetDevice(h->device));
+  HIP_TRY(h, hipStreamSynchronize(h->stream));
+  if (h->ws) { HIP_TRY(h, hipFree(h->ws)); h->ws = nullptr; h->ws_bytes = 0; }
+  if (h->feat) { HIP_TRY(h, hipFree(h->feat)); h->feat = nullptr; h->feat_bytes = 0; }
+  if (h->aux) { HIP_TRY(h, hipFree(h->aux)); h->aux = nullptr; h->aux_bytes = 0; }
+  return 0;
+}
 
 int blr_set_option(blr_handle* h, const char* key, const char* value) {
   if (!h) return -1;

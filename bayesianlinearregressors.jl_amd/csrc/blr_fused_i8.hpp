@@ -494,6 +494,10 @@ __global__ __launch_bounds__(kI8Threads, 2) void fused_i8_kernel(PosteriorArgs<d
   // the fast path takes a zero prior mean only (mean(fx) = X'mw = 0 exactly, delta = y): anything else -> fp64 kernel
   int ok = 1;
   if (tid < D && mw[tid] != T(0)) ok = 0;
+  if (__syncthreads_or(!ok)) {  // handed back BEFORE the stream: the fp64 kernel reads X once, nobody reads it twice
+    if (tid == 0) a.info[reg] = kI8Retry;
+    return;
+  }
   if (tid == 0) flag[0] = 1;
 
   I8Slice st;

@@ -446,6 +446,28 @@ def logpdf_columns(fx, Y, return_means=False):
     return (lp, M) if return_means else lp
 
 
+def _upper_inverse_on_device(h, dtype, prior_kind, Lw, D):
+    """Uw^-1 (D x D, float64) for Uw = chol(Lw).U or the given upper factor: blr_sample_weights_* on the identity (w = 0 + Uw^-1 z
+    per column, reference sampling_functions.jl:29) -- the library factorises a dense prior itself; no host LAPACK."""
+    eye = np.asfortranarray(np.eye(D, dtype=dtype))
+    W = np.zeros((D, D), dtype=dtype, order="F")
+    Lw_arr = np.asfortranarray(np.asarray(Lw, dtype=dtype))
+    h.sample_weights(dtype, _abi.MEM_HOST, D, D, prior_kind, np.zeros(D, dtype=dtype), Lw_arr, max(D, 1), eye, D, W, D)
+    return W.astype(np.float64)
+
+
+def _prior_inverse_on_device(h, dtype, prior_kind, Lw, D):
+    """Lw^-1 = Uw^-1 Uw^-T for a dense precision or an upper factor, by two triangular-solve calls on the device (the second one
+    solves against the rows of the first result); used by the prior tangent of the evidence gradient."""
+    Ui = _upper_inverse_on_device(h, dtype, prior_kind, Lw, D)
+    Z = np.asfortranarray(Ui.T.astype(dtype))
+    W = np.zeros((D, D), dtype=dtype, order="F")
+    Lw_arr = np.asfortranarray(np.asarray(Lw, dtype=dtype))
+    h.sample_weights(dtype, _abi.MEM_HOST, D, D, prior_kind, np.zeros(D, dtype=dtype), Lw_arr, max(D, 1), Z, D, W, D)
+    Wd = W.astype(np.float64)
+    return 0.5 * (Wd + Wd.T)
+
+
 def logpdf_and_gradient(fx, y):
     """The value of logpdf(fx, y) (reference :55-58) and its gradient with respect to every input of the path -- the
     reverse-mode rule the reference gets from Zygote through its Julia code (README.md:56-71) and a ccall-backed logpdf
@@ -492,7 +514,7 @@ def logpdf_and_gradient(fx, y):
         else:
             A0 = np.asarray(Lw, dtype=np.float64)
             Lw_dense = np.triu(A0) + np.triu(A0, 1).T
-        gL = -0.5 * (np.outer(m, m) + Ai - np.linalg.inv(Lw_dense))
+        gL = -0.5 * (np.outer(m, m) + Ai - _prior_inverse_on_device(_handle(), dtype, prior_kind, Lw, D))
     # hand dX back in the caller's container orientation
     x = fx.x
     if isinstance(x, RowVecs):
@@ -959,13 +981,14 @@ def rand_and_pullback(rng, fx, S):
                     raise _abi.PosDefException(rc)
                 U = np.triu(Tf).astype(np.float64)
             # D x D bookkeeping of the rule on the host (like the prior tangent of logpdf_and_gradient): Ubar = -triu(Uw^-T Wbar V')
-            Ubar = -np.triu(np.linalg.solve(U.T, Wbar.astype(np.float64)) @ V.T)
+            Ui = _upper_inverse_on_device(h, dtype, _abi.PRIOR_UPPER_FACTOR, U.astype(dtype), D)  # Uw^-1 from the device; the rest is D x D products
+            Ubar = -np.triu(Ui.T @ Wbar.astype(np.float64) @ V.T)
             if prior_kind == _abi.PRIOR_UPPER_FACTOR:
                 gL = Ubar.astype(dtype)
             else:  # through the Cholesky A = L L', L = Uw': Abar = sym(L^-T Phi(L' Lbar) L^-1), Phi = lower triangle, halved diagonal
                 M = np.tril(U @ Ubar.T)
                 M[np.diag_indices(D)] *= 0.5
-                Ab = np.linalg.solve(U, np.linalg.solve(U, M.T).T)
+                Ab = Ui @ (Ui @ M.T).T
                 gL = (0.5 * (Ab + Ab.T)).astype(dtype)
         sd = np.sum(Ybar.astype(np.float64) * Z2, axis=1) / (2.0 * np.sqrt(np.broadcast_to(s, (N,)).astype(np.float64)))
         gs = sd.astype(dtype) if noise_kind == _abi.NOISE_DIAGONAL else dtype(sd.sum())

@@ -76,6 +76,10 @@ int blr_synchronize(blr_handle* h);
  * BLR_MI355X_<KEY> are read ONCE, by blr_create -- no entry point reads the environment.  -> 0, or -2 / -3 (unknown key /
  * malformed value). */
 int blr_set_option(blr_handle* h, const char* key, const char* value);
+/* The handle's device scratch (factorisation workspaces of D > 128 calls -- up to 8 GiB for a large batched call, see CHAIN_WS_MB --
+ * the feature matrix of blr_posterior_rff_*, the int8 / marginal side buffers) only ever GROWS between calls; this drains the
+ * stream and frees all of it.  The next call allocates what it needs again. */
+int blr_release_workspace(blr_handle* h);
 
 /* ---- device memory helpers (so a host language needs no HIP binding of its own) -------------- */
 int blr_device_alloc(blr_handle* h, size_t bytes, void** dptr);
