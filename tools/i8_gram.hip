@@ -2,7 +2,7 @@
 // noise, diagonal prior; timed with HIP events; every output compared with fused_small_kernel<double, 8, 4> on the same inputs
 // (and the first regressors' evidence with a plain host evaluation).  Not part of the product.
 //   hipcc --offload-arch=gfx950 -O3 -std=c++17 -I../bayesianlinearregressors.jl_amd/csrc i8_gram.hip -o i8_gram
-//   ./i8_gram [B] [N] [reps] [mode]     mode 0: N(0,1) inputs   1: one outlier per regressor (retry path)   2: rows of very different scale
+//   ./i8_gram [B] [N] [reps] [mode]     mode 0: N(0,1) inputs   1: one outlier per regressor (retry path)   2: rows of very different scale   3: X = 0
 #include <hip/hip_runtime.h>
 #include <algorithm>
 #include <cmath>
@@ -32,6 +32,7 @@ int main(int argc, char** argv) {
     for (int b = 0; b < BU; ++b)
       for (int n = 0; n < N; ++n)
         for (int i = 0; i < D; ++i) X[((size_t)b * N + n) * D + i] *= std::ldexp(1.0, (i % 7) * 9 - 27);  // rows from 2^-27 to 2^27
+  if (mode == 3) std::fill(X.begin(), X.end(), 0.0);  // zero operands: what the clock does without data toggling
   if (mode == 1)
     for (int b = 0; b < BU; b += 2) X[((size_t)b * N + N / 2) * D + 5] = 1.0e6;  // breaks the row bound of every other regressor
   const T s_iso = 0.1;
