@@ -971,6 +971,50 @@ int marginals_large_one(blr_handle* h, int layout, int64_t D, int64_t N, const T
   const int64_t ldy = (int64_t)DP + NP;
   int rc;
   HIP_TRY(h, hipMemsetAsync(info_dev, 0, sizeof(int32_t), h->stream));
+  {
+    // Block forward substitution on LDS-resident tiles of 32 inputs (marg_blocksub_kernel): X is read once, nothing but the
+    // outputs is written.  Needs the tile in LDS (D <= 1152 in fp32, 576 in fp64) and 16-byte loads along d from X and U.
+    using MB = MargBlockCfg<T>;
+    using MG = MargGemmCfg<T>;
+    constexpr int VEC = Mfma<T>::VEC;
+    const bool u_given = prior_kind == BLR_PRIOR_UPPER_FACTOR;
+    if (var && prior_kind != BLR_PRIOR_DIAGONAL && !h->opt.no_marg_gemm && layout == BLR_LAYOUT_COLVECS && D % 16 == 0 &&
+        MB::lds_bytes(DP) <= MB::kMaxLds && ldx % VEC == 0 && ((uintptr_t)X % 16) == 0 && N >= 1 &&
+        (!u_given || (ldl % VEC == 0 && ((uintptr_t)Lw % 16) == 0))) {
+      const T* U = Lw;
+      int64_t ldu = ldl;
+      if (u_given) {  // a factor with a non-positive diagonal entry is not a Cholesky factor: LAPACK-style index
+        hipLaunchKernelGGL(prior_diag_kernel<T>, dim3(1), dim3(kThreads), 0, h->stream, Lw, ldl, (int)PRIOR_UPPER_FACTOR, (int)D,
+                           (double*)nullptr, info_dev);
+      } else {  // dense precision: L = chol(Lw) (reference :41), then U = L' with the contraction index contiguous
+        const size_t mat = (((size_t)DP * DP * sizeof(T)) + 255) & ~(size_t)255;
+        if ((rc = ensure_ws(h, 2 * mat + 256))) return rc;
+        T* Lf = reinterpret_cast<T*>(h->ws);
+        T* Ut = reinterpret_cast<T*>(h->ws + mat);
+        hipLaunchKernelGGL(prior_copy_kernel<T>, dim3(1024), dim3(kThreads), 0, h->stream, Lw, ldl, (int)D, DP, Lf, (int64_t)DP);
+        if ((rc = chol_large<T>(h, Lf, DP, DP, DP, info_dev))) return rc;
+        dim3 tg((DP + 31) / 32, (DP + 31) / 32);
+        hipLaunchKernelGGL(transpose_out_kernel<T>, tg, dim3(kThreads), 0, h->stream, (const T*)Lf, (int64_t)DP, DP, Ut, (int64_t)DP,
+                           (T*)nullptr, (int64_t)0, 0);
+        U = Ut;
+        ldu = DP;
+      }
+      if ((rc = ensure_aux(h, (size_t)NC * MG::IMG_ELEMS * sizeof(T)))) return rc;
+      T* const img = reinterpret_cast<T*>(h->aux);
+      if ((rc = set_lds_once(h, reinterpret_cast<const void*>(marg_image_kernel<T>), (size_t)TrsmCfg<T>::LDS_BYTES))) return rc;
+      if ((rc = set_lds_once(h, reinterpret_cast<const void*>(marg_blocksub_kernel<T>), (size_t)MB::kMaxLds))) return rc;
+      hipLaunchKernelGGL(marg_image_kernel<T>, dim3((unsigned)NC, 2), dim3(kThreads), TrsmCfg<T>::LDS_BYTES, h->stream, U, ldu,
+                         (int64_t)kPB * (ldu + 1), (int)kPB, img, (const int32_t*)info_dev, 0, u_given ? (int)D : DP);
+      MargBlockArgs<T> m{};
+      m.X = X; m.ldx = ldx; m.U = U; m.ldu = ldu; m.img = img; m.mw = mw; m.s = s; m.noise_kind = noise_kind;
+      m.mean = mean; m.var = var; m.info = info_dev; m.D = u_given ? (int)D : DP; m.Dx = (int)D; m.DP = DP; m.N = (int)N;
+      const int64_t ntiles = (N + MB::RT - 1) / MB::RT;
+      hipLaunchKernelGGL(marg_blocksub_kernel<T>, dim3((unsigned)std::min<int64_t>(ntiles, h->cus)), dim3(MB::THREADS),
+                         (size_t)MB::lds_bytes(DP), h->stream, m);
+      HIP_TRY(h, hipGetLastError());
+      return 0;
+    }
+  }
   const bool need_tall = var && prior_kind != BLR_PRIOR_DIAGONAL;
   T* Ybar = nullptr;
   if (need_tall) {

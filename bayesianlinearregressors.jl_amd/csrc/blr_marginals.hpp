@@ -35,7 +35,7 @@ struct MargGemmCfg {
 // ---- M = L^-T in B-fragment order, two workgroups per regressor (blockIdx.y: rows 0..63 / 64..127 of M) ----------------------------
 template <typename T>
 __global__ __launch_bounds__(kThreads) void marg_image_kernel(const T* __restrict__ U, int64_t ldu, int64_t strideU, int D, T* __restrict__ img,
-                                                              const int32_t* __restrict__ info, int reg0) {
+                                                              const int32_t* __restrict__ info, int reg0, int Dtotal = 0) {
   using Cfg = TrsmCfg<T>;
   using G = MargGemmCfg<T>;
   constexpr int VEC = Mfma<T>::VEC;
@@ -47,7 +47,12 @@ __global__ __launch_bounds__(kThreads) void marg_image_kernel(const T* __restric
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = uni(tid >> 6);
   const int reg = reg0 + blockIdx.x;
-  if (info && info[reg] != 0) return;
+  if (Dtotal) {  // the "regressors" are the diagonal 128-blocks of ONE factor of order Dtotal (marg_blocksub_kernel): one status word
+    if (info && info[0] != 0) return;
+    D = min(kPB, Dtotal - kPB * reg);
+  } else if (info && info[reg] != 0) {
+    return;
+  }
   U += (int64_t)reg * strideU;
   img += (int64_t)reg * G::IMG_ELEMS;
   const int nchunks = kPB / 16;
@@ -90,7 +95,9 @@ __global__ __launch_bounds__(kThreads) void marg_image_kernel(const T* __restric
       while (G::frag0(J + 1) <= f) ++J;
       const int m = f - G::frag0(J);
       const int d = G::d_of(m, l >> 4);
-      if ((d >> 6) == half) img[e] = Xs[(d & 63) * Cfg::LDX + 16 * J + (l & 15)];
+      // (diagonal blocks of a large factor: the VEC fragments one 16-byte load of the inputs feeds sit next to each other per lane)
+      const int at = Dtotal ? ((f / VEC) * 64 + l) * VEC + (f % VEC) : e;
+      if ((d >> 6) == half) img[at] = Xs[(d & 63) * Cfg::LDX + 16 * J + (l & 15)];
     }
   }
 }
@@ -175,6 +182,361 @@ __global__ __launch_bounds__(kThreads, 2) void marginals_gemm_kernel(MarginalArg
       for (int u = 0; u < NL; ++u) av[u] = an[u];
     }
   }
+}
+
+// =====================================================================================================================================
+// D > 128: block forward substitution on an LDS-resident tile of inputs
+// =====================================================================================================================================
+// The tall-matrix route (mean_fill_kernel + one trsm_block_kernel + trailing gram_tile_kernel launch per 128-column panel) writes
+// the inputs out as rows of a tall matrix and reads / rewrites the remaining columns once per panel: 4.15 GB of traffic for 277 MB of
+// inputs at D = 1024, N = 65536 (fp32).  Rows are independent, so the whole substitution of a tile of inputs can stay on one CU:
+//   tile of 32 inputs x D in LDS (128 KB at D = 1024, fp32), overwritten in place block by block:
+//     Z_J = (X_J - sum_{K<J} Z_K L_JK') L_JJ^-T ,   L = U'
+//   - the sum is a plain product: A operands = finished blocks Z_K from LDS, B operands = 16-byte loads straight from the caller's
+//     U (L_JK'[d][j] = U[d + j ldu]: the contraction index is contiguous) -- 2 MB of L2-resident factor per tile, each fragment
+//     feeding both 16-row halves of the tile;
+//   - L_JJ^-T comes from marg_image_kernel (the D = 128 image, one per diagonal block), 144 MFMAs per 16 rows;
+//   - var_n = |z_n|^2 + s_n from the accumulators, mean_n = x_n'mw from the tile: X is read ONCE, nothing is written but the outputs.
+// Eight waves: in the product wave w owns column tile w of block J for both row halves; in the diagonal step (4 (j + 1) MFMAs for
+// column tile j) the jobs are dealt (rows 0..15, tile w) + (rows 16..31, tile 7 - w): 36 MFMAs each.  Three barriers per block.
+#ifdef BLR_MB_STAMPS
+__device__ unsigned long long g_mbstamps[8][8];
+#define MB_T0 unsigned long long mbt_prev = __builtin_amdgcn_s_memtime(), mbt_acc[8] = {0, 0, 0, 0, 0, 0, 0, 0}
+#define MB_T(slot) do { const unsigned long long t__ = __builtin_amdgcn_s_memtime(); mbt_acc[slot] += t__ - mbt_prev; mbt_prev = t__; } while (0)
+#define MB_TFLUSH() do { if (blockIdx.x == 0 && (threadIdx.x & 63) == 0) for (int q__ = 0; q__ < 8; ++q__) g_mbstamps[threadIdx.x >> 6][q__] = mbt_acc[q__]; } while (0)
+#else
+#define MB_T0 do {} while (0)
+#define MB_T(slot) do {} while (0)
+#define MB_TFLUSH() do {} while (0)
+#endif
+#if defined(BLR_MB_EXP) && (BLR_MB_EXP & 16)
+#define MB_SYNC() do {} while (0)
+#else
+#define MB_SYNC() __syncthreads()
+#endif
+template <typename T>
+struct MargBlockCfg {
+  static constexpr int RT = 32, WAVES = 8, THREADS = 512;
+  static constexpr int VEC = Mfma<T>::VEC;
+  static constexpr int CH = 4 * VEC;               // contraction indices per 16-byte load of the four lane groups: 16 (f32) / 8 (f64)
+  static constexpr int NCH = kPB / CH;             // such chunks per 128-block
+  // row stride = 32 bytes mod 256: ds_read_b128 serves lanes {0-3, 12-15, 20-27} (rows 0-3, 12-15 of lane group g, rows 4-11 of
+  // g + 1; MI355X_MICROARCH.md, LDS) in one cycle if their 16-byte slots differ: slot = 2 row + g -- evens and odds
+  static constexpr int PAD = 32 / (int)sizeof(T);
+  __host__ __device__ static constexpr int ld(int DP) { return DP + PAD; }
+  __host__ __device__ static constexpr int off_red(int DP) { return RT * ld(DP) * (int)sizeof(T); }
+  __host__ __device__ static constexpr int off_mw(int DP) { return off_red(DP) + WAVES * RT * (int)sizeof(double); }
+  __host__ __device__ static constexpr int lds_bytes(int DP) { return off_mw(DP) + DP * (int)sizeof(T); }
+  static constexpr int kMaxLds = 156 * 1024;
+};
+
+template <typename T>
+struct MargBlockArgs {
+  const T* X; int64_t ldx;  // ColVecs, 16-byte aligned columns
+  const T* U; int64_t ldu;  // upper factor, column-major, 16-byte aligned columns
+  const T* img;             // L_JJ^-T images of the diagonal blocks (MargGemmCfg<T>::IMG_ELEMS each)
+  const T* mw; const T* s; int noise_kind;
+  T* mean; T* var;
+  const int32_t* info;
+  int D, DP, N;  // D: order of the factor (a dense prior's padded Cholesky factor: DP)
+  int Dx;        // features of an input (<= D; the tile is zero beyond)
+};
+
+// 16-byte global loads the compiler does not see, and the waits that go with them.  hipcc retires in-order memory counters
+// conservatively: at the head of a loop it waits for EVERYTHING (vmcnt(0)) -- here that is a wait for the inputs' next block from HBM
+// at the start of every product.  Issued from inline asm the loads are invisible to its wait insertion; the waits are counted by hand
+// (the counter retires in order: "at most N outstanding" = everything but the N youngest has arrived) and carry the loaded registers
+// as operands, so no use can be scheduled ahead of them.
+template <typename V>
+__device__ __forceinline__ void mb_load16(V& dst, const BLR_GLOBAL void* p) {
+  asm volatile("global_load_dwordx4 %0, %1, off" : "=v"(dst) : "v"(p) : "memory");
+}
+template <typename V>
+__device__ __forceinline__ void mb_load16_nt(V& dst, const BLR_GLOBAL void* p) {
+  asm volatile("global_load_dwordx4 %0, %1, off nt" : "=v"(dst) : "v"(p) : "memory");
+}
+template <int N>
+__device__ __forceinline__ void mb_wait() {
+  asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory");
+}
+template <typename V, int K>
+__device__ __forceinline__ void mb_pin(V (&r)[K]) {  // (after an mb_wait: uses of r stay behind it)
+#pragma unroll
+  for (int k = 0; k < K; ++k) asm volatile("" : "+v"(r[k]));
+}
+
+template <typename T>
+__global__ __launch_bounds__(MargBlockCfg<T>::THREADS) void marg_blocksub_kernel(MargBlockArgs<T> a) {
+  using C = MargBlockCfg<T>;
+  using G = MargGemmCfg<T>;
+  using acc4 = typename Mfma<T>::acc4;
+  constexpr int VEC = C::VEC, CH = C::CH, NCH = C::NCH;
+  constexpr int RL = 8;                          // chunks of the factor per group (one wait per group): 128 (f32) / 64 (f64) rows
+  constexpr int NU = 8 * (16 / CH);              // 16-byte chunks of R_J behind the widest column tile of a diagonal block
+  constexpr int BV = kPB / VEC;                  // 16-byte vectors per row of a 128-column block: 32 (f32) / 64 (f64)
+  constexpr int XV = C::RT * BV / C::THREADS;    // ... per thread: 2 / 4
+  // loads per wave and phase, in issue order: R factor chunks for the next product | I image vectors for the next diagonal step |
+  // XV input vectors for the block after next  (always that many: out-of-range ones re-read a valid address)
+  constexpr int NI = 9 * (16 / CH);              // chunks of the two jobs of a wave together: (jA + 1) + (jB + 1) = 9 column-tile heights
+  constexpr int R = RL, I = NI;
+  typedef T vecT __attribute__((ext_vector_type(Mfma<T>::VEC)));
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  T* const tile = reinterpret_cast<T*>(smem);
+  double* const red = reinterpret_cast<double*>(smem + C::off_red(a.DP));
+  T* const mws = reinterpret_cast<T*>(smem + C::off_mw(a.DP));  // the prior mean (no compiler-visible global load inside the phases)
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = uni(tid >> 6);
+  const int g = lane >> 4, li = lane & 15;
+  if (a.info && a.info[0] != 0) return;
+  const int D = a.D, N = a.N, NC = a.DP / kPB, LD = C::ld(a.DP);
+  const BLR_GLOBAL T* X = as_global(a.X);
+  const BLR_GLOBAL T* U = as_global(a.U);
+  const BLR_GLOBAL T* img = as_global(a.img);
+  const BLR_GLOBAL T* mw = as_global(a.mw);
+  const BLR_GLOBAL T* s = as_global(a.s);
+  const int ntiles = (N + C::RT - 1) / C::RT;
+  const int jA = wave, jB = 7 - wave;  // diagonal-step jobs: rows 0..15 x column tile jA, rows 16..31 x column tile jB
+  // The inputs arrive one 128-column block at a time: thread -> row tid / 16 of the tile, vectors tid % 16 + 16 k of the block (a
+  // thread keeps its row: mean_n = x_n'mw is accumulated from the same registers).  Requested at the end of a phase, stored at
+  // the end of the next one; non-temporal: 256 MB of inputs must not push the 2 MB of factor out of the L2.
+  const int xrow = tid >> 4, xv0 = tid & 15;
+  vecT xbuf[XV];
+  unsigned xvalid = 0;  // bit k: xbuf[k] holds data (not a re-read of something else)
+  auto fetch_block = [&](int t, int Jb) {
+    const bool tile_ok = t < ntiles;
+    const int n = min((tile_ok ? t : 0) * C::RT + xrow, N - 1);  // (inputs past the end repeat the last one; never stored)
+    const BLR_GLOBAL vecT* row = reinterpret_cast<const BLR_GLOBAL vecT*>(X + (int64_t)n * a.ldx);
+    xvalid = 0;
+#pragma unroll
+    for (int k = 0; k < XV; ++k) {
+      const int d0 = kPB * Jb + VEC * (xv0 + 16 * k);
+      const bool ok = tile_ok && d0 < a.Dx;
+      if (ok) xvalid |= 1u << k;
+#if defined(BLR_MB_EXP) && (BLR_MB_EXP & 1)
+      mb_load16_nt(xbuf[k], row);
+#else
+      mb_load16_nt(xbuf[k], row + (ok ? d0 / VEC : 0));
+#endif
+    }
+  };
+  double macc = 0.0;
+  auto store_block = [&](int Jb) {  // (the caller has waited for xbuf)
+    vecT* dst = reinterpret_cast<vecT*>(tile + xrow * LD + kPB * Jb);
+#pragma unroll
+    for (int k = 0; k < XV; ++k) {
+      vecT v = xbuf[k];
+      if (!((xvalid >> k) & 1u)) {
+#pragma unroll
+        for (int c = 0; c < VEC; ++c) v[c] = T(0);
+      }
+      dst[xv0 + 16 * k] = v;
+      if (a.mean) {
+        const int d0 = kPB * Jb + VEC * (xv0 + 16 * k);
+        if (d0 < a.Dx) {
+#pragma unroll
+          for (int c = 0; c < VEC; ++c) macc += (double)v[c] * (double)mws[d0 + c];
+        }
+      }
+    }
+  };
+  // fragments of L_JJ^-T for this wave's two jobs, one 16-byte load per chunk of R_J (the image's vector layout): job A's
+  // nuA = (jA + 1) 16 / CH chunks first, then job B's NI - nuA  (a job whose column tile lies beyond D re-reads the image's
+  // first vector: the count of loads stays NI)
+  vecT f[NI];
+  const int nuA = (jA + 1) * (16 / CH);
+  auto fetch_image = [&](int J) {
+    const int ncolt = min(8, (D - kPB * J) / 16);
+    const BLR_GLOBAL vecT* im = reinterpret_cast<const BLR_GLOBAL vecT*>(img + (int64_t)J * G::IMG_ELEMS) + lane;
+    const BLR_GLOBAL vecT* pa = jA < ncolt ? im + (G::frag0(jA) / VEC) * 64 : im;
+    const BLR_GLOBAL vecT* pb = jB < ncolt ? im + (G::frag0(jB) / VEC) * 64 : im;
+    const int sa = jA < ncolt ? 64 : 0, sb = jB < ncolt ? 64 : 0;
+#pragma unroll
+    for (int u = 0; u < NI; ++u) mb_load16(f[u], u < nuA ? pa + u * sa : pb + (u - nuA) * sb);
+  };
+  vecT b[RL];
+  auto fetch_factor = [&](const BLR_GLOBAL T* p) {
+#pragma unroll
+    for (int u = 0; u < RL; ++u) mb_load16(b[u], p + CH * u);
+  };
+  const int tstride = gridDim.x;
+  if (a.mean) {
+    for (int e = tid; e < a.Dx; e += C::THREADS) mws[e] = mw[e];  // (visible after the first barrier of the tile loop)
+    __syncthreads();
+  }
+  MB_T0;
+  {
+    fetch_block(blockIdx.x, 0);
+    mb_wait<0>();
+    mb_pin(xbuf);
+    store_block(0);
+    fetch_image(0);              // (issue order of a phase: image, then inputs)
+    fetch_block(blockIdx.x, 1);  // (D > 128: at least two blocks)
+  }
+  for (int t = blockIdx.x; t < ntiles; t += tstride) {
+    const int n0 = t * C::RT;
+    __syncthreads();  // block 0 of this tile is in place (stored at the end of the previous tile / above)
+    // ---- z = L^-1 x block by block (:41-43) -------------------------------------------------------------------------------------------
+    T sqA[4] = {T(0), T(0), T(0), T(0)}, sqB[4] = {T(0), T(0), T(0), T(0)};
+#pragma unroll 1
+    for (int J = 0; J < NC; ++J) {
+      const int ncolt = min(8, (D - kPB * J) / 16);
+      if (J > 0) {  // (the residual of block 0 is X_0 itself)
+        acc4 c0 = {T(0), T(0), T(0), T(0)}, c1 = {T(0), T(0), T(0), T(0)};
+        if (wave < ncolt) {
+          const BLR_GLOBAL T* ub = U + (int64_t)(kPB * J + 16 * wave + li) * a.ldu + VEC * g;
+          const T* a0 = tile + li * LD + VEC * g;
+          const T* a1 = a0 + 16 * LD;
+          const int ngrp = J * (NCH / RL);
+          // The factor arrives a GROUP of RL chunks at a time, one group ahead (group 0 was requested before the previous block's
+          // diagonal step): one wait per group, at its start.  Group 0 lets the I + XV loads issued after its own stay in flight;
+          // the later groups wait for everything -- their own loads are the youngest, and what was requested before them (the
+          // inputs' block from HBM) has had a whole group of 64 MFMAs.  Inside a group one pinned stream per chunk: the NEXT
+          // chunk's two fragment reads, then the eight MFMAs of this chunk on operands that arrived during the previous chunk's.
+          vecT x0 = *reinterpret_cast<const vecT*>(a0);
+          vecT x1 = *reinterpret_cast<const vecT*>(a1);
+          MB_T(7);
+          mb_wait<I + XV>();
+          MB_T(1);
+#pragma unroll 1
+          for (int grp = 0; grp < ngrp; ++grp) {
+            const bool more = grp + 1 < ngrp;
+            mb_pin(b);
+            vecT bc[RL];
+#pragma unroll
+            for (int u = 0; u < RL; ++u) bc[u] = b[u];
+            mb_pin(bc);  // (copies made before the next group's loads land in b)
+#if !(defined(BLR_MB_EXP) && (BLR_MB_EXP & 4))
+            if (more) fetch_factor(ub + CH * RL * (grp + 1));
+#endif
+#pragma unroll
+            for (int u = 0; u < RL; ++u) {
+              const int d = CH * (RL * grp + u);
+              const int dn = (more || u + 1 < RL) ? d + CH : d;  // (the last chunk re-reads itself: no branch in the stream)
+              const vecT nx0 = *reinterpret_cast<const vecT*>(a0 + dn);
+              const vecT nx1 = *reinterpret_cast<const vecT*>(a1 + dn);
+              __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+              for (int e = 0; e < VEC; ++e) {
+                c0 = Mfma<T>::mma(x0[e], bc[u][e], c0);
+                c1 = Mfma<T>::mma(x1[e], bc[u][e], c1);
+              }
+              __builtin_amdgcn_sched_barrier(0);
+              x0 = nx0;
+              x1 = nx1;
+            }
+            MB_T(0);
+#if !(defined(BLR_MB_EXP) && (BLR_MB_EXP & 8))
+            if (more) mb_wait<0>();
+#endif
+            MB_T(1);
+          }
+#pragma unroll
+          for (int v = 0; v < 4; ++v) {  // R_J = X_J - sum, in place (these 16 columns belong to this wave alone)
+            T* p = tile + Mfma<T>::crow(lane, v) * LD + kPB * J + 16 * wave + li;
+            p[0] -= c0[v];
+            p[16 * LD] -= c1[v];
+          }
+        }
+        MB_T(2);
+        MB_SYNC();
+        MB_T(3);
+      }
+      // the next block's product starts on these (nothing here depends on the tile)
+      const bool next_prod = J + 1 < NC && wave < min(8, (D - kPB * (J + 1)) / 16);
+      if (next_prod) fetch_factor(U + (int64_t)(kPB * (J + 1) + 16 * wave + li) * a.ldu + VEC * g);
+      // Z_J = R_J L_JJ^-T: job A = rows 0..15 x column tile jA, job B = rows 16..31 x column tile jB (two independent accumulators).
+      // The fragments were requested in the previous phase; younger than them: XV input vectors, the R factor chunks above.
+      MB_T(7);
+      if (next_prod) mb_wait<XV + R>();
+      else mb_wait<XV>();
+      MB_T(4);
+      mb_pin(f);
+      acc4 zA = {T(0), T(0), T(0), T(0)}, zB = {T(0), T(0), T(0), T(0)};
+      {
+        const T* apA = tile + li * LD + kPB * J + VEC * g;
+        const T* apB = tile + (16 + li) * LD + kPB * J + VEC * g;
+        const bool doA = jA < ncolt, doB = jB < ncolt;
+        vecT x = *reinterpret_cast<const vecT*>(apA);
+#pragma unroll
+        for (int u = 0; u < NI; ++u) {
+          // (the next chunk's read goes out before this chunk's MFMAs; the list is A's chunks, then B's)
+          const int un = u + 1 < NI ? u + 1 : u;
+          const vecT nx = *reinterpret_cast<const vecT*>(un < nuA ? apA + CH * un : apB + CH * (un - nuA));
+          if (u < nuA) {
+            if (doA) {
+#pragma unroll
+              for (int e = 0; e < VEC; ++e) zA = Mfma<T>::mma(x[e], f[u][e], zA);
+            }
+          } else if (doB) {
+#pragma unroll
+            for (int e = 0; e < VEC; ++e) zB = Mfma<T>::mma(x[e], f[u][e], zB);
+          }
+          x = nx;
+        }
+      }
+      // (the MFMAs above have read f: pinned behind them through the accumulators)
+      asm volatile("" : "+v"(zA), "+v"(zB));
+#if !(defined(BLR_MB_EXP) && (BLR_MB_EXP & 2))
+      fetch_image(J + 1 < NC ? J + 1 : 0);  // for the next diagonal step: a whole product away
+#endif
+      MB_T(5);
+      MB_SYNC();  // everybody has read R_J
+      MB_T(3);
+#pragma unroll
+      for (int v = 0; v < 4; ++v) {
+        const int r = Mfma<T>::crow(lane, v);
+        if (jA < ncolt) {
+          tile[r * LD + kPB * J + 16 * jA + li] = zA[v];
+          sqA[v] += zA[v] * zA[v];
+        }
+        if (jB < ncolt) {
+          tile[(16 + r) * LD + kPB * J + 16 * jB + li] = zB[v];
+          sqB[v] += zB[v] * zB[v];
+        }
+      }
+      // the inputs' next block goes into its place (after the last block: block 0 of the next tile -- nobody reads Z_0 any more),
+      // and the one after it is requested.  It was requested at the end of the previous phase; younger: R (if any) and I.
+      if (J == NC - 1) {  // ... this tile's mean is complete: the 16 threads of a row
+        if (a.mean) {
+          const double m = row16_allreduce(macc);
+          if (xv0 == 0 && n0 + xrow < N) a.mean[n0 + xrow] = (T)m;
+        }
+        macc = 0.0;
+      }
+      MB_T(7);
+      if (next_prod) mb_wait<R + I>();
+      else mb_wait<I>();
+      MB_T(6);
+      mb_pin(xbuf);
+      store_block(J + 1 < NC ? J + 1 : 0);
+      {
+        const int Jn = J + 2;
+        fetch_block(Jn < NC ? t : t + tstride, Jn < NC ? Jn : Jn - NC);
+      }
+      MB_T(7);
+      if (J + 1 < NC) MB_SYNC();  // Z_J and X_(J+1) visible to the next block's product
+      MB_T(3);
+    }
+    // ---- var_n = |z_n|^2 + s_n: over the 16 columns a lane group holds, then over the waves in wave order ------------------------------
+#pragma unroll
+    for (int v = 0; v < 4; ++v) {
+      const double ra = (double)row16_allreduce(sqA[v]);
+      const double rb = (double)row16_allreduce(sqB[v]);
+      if (li == 0) {
+        red[wave * C::RT + Mfma<T>::crow(lane, v)] = ra;
+        red[wave * C::RT + 16 + Mfma<T>::crow(lane, v)] = rb;
+      }
+    }
+    __syncthreads();
+    if (tid < C::RT && n0 + tid < N) {
+      double sum = 0.0;
+#pragma unroll
+      for (int w = 0; w < C::WAVES; ++w) sum += red[w * C::RT + tid];
+      a.var[n0 + tid] = (T)sum + ((a.noise_kind == NOISE_DIAGONAL) ? s[n0 + tid] : s[0]);
+    }
+    MB_T(7);
+  }
+  MB_TFLUSH();
 }
 
 }  // namespace blr

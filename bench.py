@@ -316,7 +316,7 @@ def secondary_ops(torch, _abi, h, dev):
         # mean: 2DN flops on DN elements (a7, pure bandwidth); var: the D^2 N triangular solve (a8: D^2 flops per input) + 2DN
         flops = B * N * (2 * D if mean_only else D * D + 4 * D)
         nbytes = w * B * (N * D + D + (0 if mean_only else D * D) + N * (1 if mean_only else 2))
-        kern = ("mean_stream_kernel" if mean_only else "trsm_block_kernel + trail_update_kernel") if D > 128 else "marginals_mfma_kernel"
+        kern = ("mean_stream_kernel" if mean_only else "marg_blocksub_kernel") if D > 128 else ("marginals_mfma_kernel" if mean_only else "marginals_gemm_kernel")
         return Op(f"B={B}, D={D}, N={N}, {dt}: {'mean' if mean_only else 'mean + var'} of the marginals, factor prior (PDMat / posterior)",
                   fn, B * N, "marginals/s", flops, nbytes, dt, kern, check, keep=(X, mw, Ucm, s, mean, var, info))
 
