@@ -958,6 +958,75 @@ int prior_factor(blr_handle* h, int64_t B, int64_t D, int prior_kind, const T* L
 }
 
 
+// ---- large-D marginals with a factor or a dense prior: block forward substitution on LDS-resident tiles of 32 inputs ---------------
+// (marg_blocksub_kernel: X is read once, nothing but the outputs is written).  A whole batch per launch (blockIdx.y = regressor;
+// a dense prior's blocked Cholesky takes the batch through chol_large's groups).  Needs the tile in LDS (D <= 1152 in fp32, 576
+// in fp64) and 16-byte loads along d from X and U.  Returns 1 when the call does not qualify (the caller takes the tall-matrix route).
+template <typename T>
+int marginals_large_group(blr_handle* h, int layout, int64_t B, int64_t D, int64_t N, const T* X, int64_t ldx, int64_t strideX,
+                          int noise_kind, const T* s, int64_t strides, int prior_kind, const T* mw, int64_t stridemw, const T* Lw,
+                          int64_t ldl, int64_t strideLw, T* mean, int64_t stridemean, T* var, int64_t stridevar, int32_t* info_dev) {
+  using MB = MargBlockCfg<T>;
+  using MG = MargGemmCfg<T>;
+  constexpr int VEC = Mfma<T>::VEC;
+  const int DP = (int)((D + kPB - 1) / kPB * kPB), NC = DP / kPB;
+  const bool u_given = prior_kind == BLR_PRIOR_UPPER_FACTOR;
+  auto vec_ok = [&](const T* p, int64_t ld, int64_t stride) {
+    return ld % VEC == 0 && ((uintptr_t)p % 16) == 0 && (B == 1 || (stride * (int64_t)sizeof(T)) % 16 == 0);
+  };
+  if (!var || prior_kind == BLR_PRIOR_DIAGONAL || h->opt.no_marg_gemm || layout != BLR_LAYOUT_COLVECS || D % 16 != 0 || N < 1 ||
+      MB::lds_bytes(DP) > MB::kMaxLds || !vec_ok(X, ldx, strideX) || (u_given && !vec_ok(Lw, ldl, strideLw)))
+    return 1;
+  int rc;
+  if ((rc = set_lds_once(h, reinterpret_cast<const void*>(marg_image_kernel<T>), (size_t)TrsmCfg<T>::LDS_BYTES))) return rc;
+  if ((rc = set_lds_once(h, reinterpret_cast<const void*>(marg_blocksub_kernel<T>), (size_t)MB::kMaxLds))) return rc;
+  // regressors per launch: grid.y, the images (36 / 72 KB per diagonal block) within 256 MiB, a dense prior's two D x D copies
+  // within 1 GiB and chol_large's group size
+  const size_t mat = (((size_t)DP * DP * sizeof(T)) + 255) & ~(size_t)255;
+  int64_t chunk = std::min<int64_t>(B, std::min<int64_t>(65535, ((int64_t)256 << 20) / ((int64_t)NC * MG::IMG_ELEMS * (int64_t)sizeof(T))));
+  if (!u_given) chunk = std::min<int64_t>(chunk, std::min<int64_t>(kChainBatchMax, std::max<int64_t>(1, ((int64_t)1 << 30) / (int64_t)(2 * mat))));
+  if ((rc = ensure_aux(h, (size_t)chunk * NC * MG::IMG_ELEMS * sizeof(T)))) return rc;
+  if (!u_given && (rc = ensure_ws(h, (size_t)chunk * 2 * mat + 256))) return rc;
+  T* const img = reinterpret_cast<T*>(h->aux);
+  HIP_TRY(h, hipMemsetAsync(info_dev, 0, (size_t)B * sizeof(int32_t), h->stream));
+  for (int64_t b0 = 0; b0 < B; b0 += chunk) {
+    const int nb = (int)std::min<int64_t>(chunk, B - b0);
+    const T* U = Lw + b0 * strideLw;
+    int64_t ldu = ldl, strideU = strideLw;
+    int32_t* const inf = info_dev + b0;
+    if (u_given) {  // a factor with a non-positive diagonal entry is not a Cholesky factor: LAPACK-style index
+      hipLaunchKernelGGL(prior_diag_kernel<T>, dim3(1, nb), dim3(kThreads), 0, h->stream, U, ldl, (int)PRIOR_UPPER_FACTOR, (int)D,
+                         (double*)nullptr, inf, ScratchInit(), strideLw, (int64_t)sizeof(int32_t));
+    } else {  // dense precision: L = chol(Lw) (reference :41), then U = L' with the contraction index contiguous
+      T* Lf = reinterpret_cast<T*>(h->ws);
+      T* Ut = reinterpret_cast<T*>(h->ws + (size_t)chunk * mat);
+      const int64_t mstride = (int64_t)(mat / sizeof(T));
+      hipLaunchKernelGGL(prior_copy_kernel<T>, dim3(256, nb), dim3(kThreads), 0, h->stream, Lw + b0 * strideLw, ldl, (int)D, DP, Lf, (int64_t)DP,
+                         strideLw, mstride);
+      if ((rc = chol_large<T>(h, Lf, DP, DP, DP, inf, nb, mstride, 1))) return rc;  // (status words: one int32 apart)
+      dim3 tg((DP + 31) / 32, (DP + 31) / 32, nb);
+      hipLaunchKernelGGL(transpose_out_kernel<T>, tg, dim3(kThreads), 0, h->stream, (const T*)Lf, (int64_t)DP, DP, Ut, (int64_t)DP,
+                         (T*)nullptr, (int64_t)0, 0, mstride);
+      U = Ut;
+      ldu = DP;
+      strideU = mstride;
+    }
+    const int Df = u_given ? (int)D : DP;  // order of the factor the kernels see (a dense prior's is padded with a unit diagonal)
+    hipLaunchKernelGGL(marg_image_kernel<T>, dim3((unsigned)(NC * nb), 2), dim3(kThreads), TrsmCfg<T>::LDS_BYTES, h->stream, U, ldu,
+                       (int64_t)kPB * (ldu + 1), (int)kPB, img, (const int32_t*)inf, 0, Df, NC, strideU);
+    MargBlockArgs<T> m{};
+    m.X = X + b0 * strideX; m.ldx = ldx; m.U = U; m.ldu = ldu; m.img = img; m.mw = mw + b0 * stridemw; m.s = s + b0 * strides;
+    m.noise_kind = noise_kind; m.mean = mean ? mean + b0 * stridemean : nullptr; m.var = var + b0 * stridevar; m.info = inf;
+    m.D = Df; m.Dx = (int)D; m.DP = DP; m.N = (int)N;
+    m.strideX = strideX; m.strideU = strideU; m.stridemw = stridemw; m.strides = strides; m.stridemean = stridemean; m.stridevar = stridevar;
+    const int64_t ntiles = (N + MB::RT - 1) / MB::RT;
+    const int64_t gx = std::min<int64_t>(ntiles, std::max<int64_t>(1, (h->cus + nb - 1) / nb));  // one workgroup per CU
+    hipLaunchKernelGGL(marg_blocksub_kernel<T>, dim3((unsigned)gx, (unsigned)nb), dim3(MB::THREADS), (size_t)MB::lds_bytes(DP), h->stream, m);
+  }
+  HIP_TRY(h, hipGetLastError());
+  return 0;
+}
+
 // ---- large-D marginals: mean stream + (var) tall TRSM through the factorisation's panel machinery -------------------
 template <typename T>
 int marginals_large_one(blr_handle* h, int layout, int64_t D, int64_t N, const T* X, int64_t ldx, int noise_kind,
@@ -971,50 +1040,6 @@ int marginals_large_one(blr_handle* h, int layout, int64_t D, int64_t N, const T
   const int64_t ldy = (int64_t)DP + NP;
   int rc;
   HIP_TRY(h, hipMemsetAsync(info_dev, 0, sizeof(int32_t), h->stream));
-  {
-    // Block forward substitution on LDS-resident tiles of 32 inputs (marg_blocksub_kernel): X is read once, nothing but the
-    // outputs is written.  Needs the tile in LDS (D <= 1152 in fp32, 576 in fp64) and 16-byte loads along d from X and U.
-    using MB = MargBlockCfg<T>;
-    using MG = MargGemmCfg<T>;
-    constexpr int VEC = Mfma<T>::VEC;
-    const bool u_given = prior_kind == BLR_PRIOR_UPPER_FACTOR;
-    if (var && prior_kind != BLR_PRIOR_DIAGONAL && !h->opt.no_marg_gemm && layout == BLR_LAYOUT_COLVECS && D % 16 == 0 &&
-        MB::lds_bytes(DP) <= MB::kMaxLds && ldx % VEC == 0 && ((uintptr_t)X % 16) == 0 && N >= 1 &&
-        (!u_given || (ldl % VEC == 0 && ((uintptr_t)Lw % 16) == 0))) {
-      const T* U = Lw;
-      int64_t ldu = ldl;
-      if (u_given) {  // a factor with a non-positive diagonal entry is not a Cholesky factor: LAPACK-style index
-        hipLaunchKernelGGL(prior_diag_kernel<T>, dim3(1), dim3(kThreads), 0, h->stream, Lw, ldl, (int)PRIOR_UPPER_FACTOR, (int)D,
-                           (double*)nullptr, info_dev);
-      } else {  // dense precision: L = chol(Lw) (reference :41), then U = L' with the contraction index contiguous
-        const size_t mat = (((size_t)DP * DP * sizeof(T)) + 255) & ~(size_t)255;
-        if ((rc = ensure_ws(h, 2 * mat + 256))) return rc;
-        T* Lf = reinterpret_cast<T*>(h->ws);
-        T* Ut = reinterpret_cast<T*>(h->ws + mat);
-        hipLaunchKernelGGL(prior_copy_kernel<T>, dim3(1024), dim3(kThreads), 0, h->stream, Lw, ldl, (int)D, DP, Lf, (int64_t)DP);
-        if ((rc = chol_large<T>(h, Lf, DP, DP, DP, info_dev))) return rc;
-        dim3 tg((DP + 31) / 32, (DP + 31) / 32);
-        hipLaunchKernelGGL(transpose_out_kernel<T>, tg, dim3(kThreads), 0, h->stream, (const T*)Lf, (int64_t)DP, DP, Ut, (int64_t)DP,
-                           (T*)nullptr, (int64_t)0, 0);
-        U = Ut;
-        ldu = DP;
-      }
-      if ((rc = ensure_aux(h, (size_t)NC * MG::IMG_ELEMS * sizeof(T)))) return rc;
-      T* const img = reinterpret_cast<T*>(h->aux);
-      if ((rc = set_lds_once(h, reinterpret_cast<const void*>(marg_image_kernel<T>), (size_t)TrsmCfg<T>::LDS_BYTES))) return rc;
-      if ((rc = set_lds_once(h, reinterpret_cast<const void*>(marg_blocksub_kernel<T>), (size_t)MB::kMaxLds))) return rc;
-      hipLaunchKernelGGL(marg_image_kernel<T>, dim3((unsigned)NC, 2), dim3(kThreads), TrsmCfg<T>::LDS_BYTES, h->stream, U, ldu,
-                         (int64_t)kPB * (ldu + 1), (int)kPB, img, (const int32_t*)info_dev, 0, u_given ? (int)D : DP);
-      MargBlockArgs<T> m{};
-      m.X = X; m.ldx = ldx; m.U = U; m.ldu = ldu; m.img = img; m.mw = mw; m.s = s; m.noise_kind = noise_kind;
-      m.mean = mean; m.var = var; m.info = info_dev; m.D = u_given ? (int)D : DP; m.Dx = (int)D; m.DP = DP; m.N = (int)N;
-      const int64_t ntiles = (N + MB::RT - 1) / MB::RT;
-      hipLaunchKernelGGL(marg_blocksub_kernel<T>, dim3((unsigned)std::min<int64_t>(ntiles, h->cus)), dim3(MB::THREADS),
-                         (size_t)MB::lds_bytes(DP), h->stream, m);
-      HIP_TRY(h, hipGetLastError());
-      return 0;
-    }
-  }
   const bool need_tall = var && prior_kind != BLR_PRIOR_DIAGONAL;
   T* Ybar = nullptr;
   if (need_tall) {
@@ -1126,13 +1151,17 @@ int marginals_batched(blr_handle* h, int memspace, int layout, int64_t B, int64_
   } else {
     a.X = X; a.s = s; a.mw = mw; a.mean = mean; a.var = var;
   }
-  if (D > kMaxSmallD) {  // large-D path, one regressor at a time
-    for (int64_t reg = 0; reg < B; ++reg) {
+  if (D > kMaxSmallD) {  // large-D path: the whole batch on LDS-resident tiles if it qualifies, else one regressor at a time
+    rc = marginals_large_group<T>(h, layout, B, D, N, a.X, ldx, strideX, noise_kind, a.s, strides, prior_kind, a.mw, stridemw, Lw_dev, ldl,
+                                  strideLw, a.mean, stridemean, a.var, stridevar, info_out_dev);
+    if (rc < 0 || rc > 1) return rc;
+    for (int64_t reg = 0; rc == 1 && reg < B; ++reg) {
       rc = marginals_large_one<T>(h, layout, D, N, a.X + reg * strideX, ldx, noise_kind, a.s ? a.s + reg * strides : nullptr,
                                   prior_kind, a.mw + reg * stridemw, Lw_dev ? Lw_dev + reg * strideLw : nullptr, ldl,
                                   a.mean ? a.mean + reg * stridemean : nullptr, a.var ? a.var + reg * stridevar : nullptr,
                                   info_out_dev + reg);
       if (rc) return rc;
+      rc = 1;
     }
     if (memspace == BLR_MEM_HOST) {
       if (mean) HIP_TRY(h, hipMemcpyAsync(mean, a.mean, extent(B, stridemean, (size_t)N) * sizeof(T), hipMemcpyDeviceToHost, h->stream));

@@ -35,7 +35,8 @@ struct MargGemmCfg {
 // ---- M = L^-T in B-fragment order, two workgroups per regressor (blockIdx.y: rows 0..63 / 64..127 of M) ----------------------------
 template <typename T>
 __global__ __launch_bounds__(kThreads) void marg_image_kernel(const T* __restrict__ U, int64_t ldu, int64_t strideU, int D, T* __restrict__ img,
-                                                              const int32_t* __restrict__ info, int reg0, int Dtotal = 0) {
+                                                              const int32_t* __restrict__ info, int reg0, int Dtotal = 0, int nblk = 1,
+                                                              int64_t strideB = 0) {
   using Cfg = TrsmCfg<T>;
   using G = MargGemmCfg<T>;
   constexpr int VEC = Mfma<T>::VEC;
@@ -47,13 +48,15 @@ __global__ __launch_bounds__(kThreads) void marg_image_kernel(const T* __restric
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = uni(tid >> 6);
   const int reg = reg0 + blockIdx.x;
-  if (Dtotal) {  // the "regressors" are the diagonal 128-blocks of ONE factor of order Dtotal (marg_blocksub_kernel): one status word
-    if (info && info[0] != 0) return;
-    D = min(kPB, Dtotal - kPB * reg);
-  } else if (info && info[reg] != 0) {
-    return;
+  if (Dtotal) {  // the "regressors" are the nblk diagonal 128-blocks of factors of order Dtotal (marg_blocksub_kernel): one status
+    const int b = reg / nblk, blk = reg % nblk;  // word, one factor (strideB elements apart) per nblk of them
+    if (info && info[b] != 0) return;
+    D = min(kPB, Dtotal - kPB * blk);
+    U += (int64_t)b * strideB + (int64_t)blk * strideU;
+  } else {
+    if (info && info[reg] != 0) return;
+    U += (int64_t)reg * strideU;
   }
-  U += (int64_t)reg * strideU;
   img += (int64_t)reg * G::IMG_ELEMS;
   const int nchunks = kPB / 16;
   const bool uvec = D == kPB && (ldu % VEC) == 0 && ((uintptr_t)U % 16) == 0;
@@ -240,6 +243,8 @@ struct MargBlockArgs {
   const int32_t* info;
   int D, DP, N;  // D: order of the factor (a dense prior's padded Cholesky factor: DP)
   int Dx;        // features of an input (<= D; the tile is zero beyond)
+  // blockIdx.y = regressor of a batch: element strides (img: DP / 128 images apart; info: one word each)
+  int64_t strideX, strideU, stridemw, strides, stridemean, stridevar;
 };
 
 // 16-byte global loads the compiler does not see, and the waits that go with them.  hipcc retires in-order memory counters
@@ -287,13 +292,16 @@ __global__ __launch_bounds__(MargBlockCfg<T>::THREADS) void marg_blocksub_kernel
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = uni(tid >> 6);
   const int g = lane >> 4, li = lane & 15;
-  if (a.info && a.info[0] != 0) return;
+  const int64_t reg = blockIdx.y;
+  if (a.info && a.info[reg] != 0) return;
   const int D = a.D, N = a.N, NC = a.DP / kPB, LD = C::ld(a.DP);
-  const BLR_GLOBAL T* X = as_global(a.X);
-  const BLR_GLOBAL T* U = as_global(a.U);
-  const BLR_GLOBAL T* img = as_global(a.img);
-  const BLR_GLOBAL T* mw = as_global(a.mw);
-  const BLR_GLOBAL T* s = as_global(a.s);
+  const BLR_GLOBAL T* X = as_global(a.X) + reg * a.strideX;
+  const BLR_GLOBAL T* U = as_global(a.U) + reg * a.strideU;
+  const BLR_GLOBAL T* img = as_global(a.img) + reg * NC * G::IMG_ELEMS;
+  const BLR_GLOBAL T* mw = as_global(a.mw) + reg * a.stridemw;
+  const BLR_GLOBAL T* s = as_global(a.s) + reg * a.strides;
+  T* const mean_out = a.mean ? a.mean + reg * a.stridemean : nullptr;
+  T* const var_out = a.var + reg * a.stridevar;
   const int ntiles = (N + C::RT - 1) / C::RT;
   const int jA = wave, jB = 7 - wave;  // diagonal-step jobs: rows 0..15 x column tile jA, rows 16..31 x column tile jB
   // The inputs arrive one 128-column block at a time: thread -> row tid / 16 of the tile, vectors tid % 16 + 16 k of the block (a
@@ -499,7 +507,7 @@ __global__ __launch_bounds__(MargBlockCfg<T>::THREADS) void marg_blocksub_kernel
       if (J == NC - 1) {  // ... this tile's mean is complete: the 16 threads of a row
         if (a.mean) {
           const double m = row16_allreduce(macc);
-          if (xv0 == 0 && n0 + xrow < N) a.mean[n0 + xrow] = (T)m;
+          if (xv0 == 0 && n0 + xrow < N) mean_out[n0 + xrow] = (T)m;
         }
         macc = 0.0;
       }
@@ -532,7 +540,7 @@ __global__ __launch_bounds__(MargBlockCfg<T>::THREADS) void marg_blocksub_kernel
       double sum = 0.0;
 #pragma unroll
       for (int w = 0; w < C::WAVES; ++w) sum += red[w * C::RT + tid];
-      a.var[n0 + tid] = (T)sum + ((a.noise_kind == NOISE_DIAGONAL) ? s[n0 + tid] : s[0]);
+      var_out[n0 + tid] = (T)sum + ((a.noise_kind == NOISE_DIAGONAL) ? s[n0 + tid] : s[0]);
     }
     MB_T(7);
   }

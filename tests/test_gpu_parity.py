@@ -959,6 +959,53 @@ def test_large_d_marginals(B, dtype, D, N):
         B.var(B.BayesianLinearRegressor(mw, -Lw)(np.asfortranarray(X), s))
 
 
+@pytest.mark.parametrize("dtype,D,N,Bn,kind", [(np.float64, 256, 200, 5, "factor"), (np.float32, 400, 333, 3, "dense"), (np.float64, 272, 70, 4, "dense"),
+                                                (np.float32, 1024, 100, 9, "factor")])
+def test_large_d_marginals_batched_share_the_launches(B, dtype, D, N, Bn, kind):
+    # a batch at D > 128 goes through ONE set of launches (blockIdx.y = regressor): every regressor against the oracle, a regressor
+    # whose prior is not positive definite stops alone (LAPACK-style index in ITS info word), the others are untouched by it
+    from blr_amd import _abi
+
+    rng = _rng(9300 + D + Bn)
+    X = rng.standard_normal((Bn, N, D)).astype(dtype)
+    mw = rng.standard_normal((Bn, D)).astype(dtype)
+    Lw = np.empty((Bn, D, D), dtype=dtype)
+    for b in range(Bn):
+        Bm = rng.standard_normal((D, D)) / np.sqrt(D)
+        Lw[b] = (Bm @ Bm.T + np.eye(D)).astype(dtype)
+    bad = 1
+    arg = np.empty((Bn, D, D), dtype=dtype)
+    for b in range(Bn):
+        if kind == "factor":
+            U = O.chol_upper(Lw[b].astype(float)).astype(dtype)
+            if b == bad:
+                U[7, 7] = -U[7, 7]
+            arg[b] = U.T  # (column-major storage of U)
+        else:
+            A = Lw[b].copy()
+            if b == bad:
+                A[7, 7] = -50.0
+            arg[b] = A.T
+    s = np.exp(0.3 * rng.standard_normal((Bn, N))).astype(dtype)
+    mean = np.full((Bn, N), -7.0, dtype=dtype)
+    var = np.full((Bn, N), -7.0, dtype=dtype)
+    info = np.full(Bn, 99, dtype=np.int32)
+    h = _abi.default_handle()
+    pk = _abi.PRIOR_UPPER_FACTOR if kind == "factor" else _abi.PRIOR_DENSE
+    h.marginals_batched(dtype, _abi.MEM_HOST, _abi.LAYOUT_COLVECS, Bn, D, N, X, D, N * D, _abi.NOISE_DIAGONAL, s, N, pk, mw, D, arg, D, D * D, mean, N, var, N,
+                        info)
+    rt = 1e-10 if dtype == np.float64 else 3e-4
+    for b in range(Bn):
+        if b == bad:
+            assert info[b] == 8
+            continue
+        assert info[b] == 0
+        m_o = O.mean(mw[b].astype(float), X[b].T.astype(float))
+        v_o = O.var(mw[b].astype(float), Lw[b].astype(float), X[b].T.astype(float), s[b].astype(float))
+        np.testing.assert_allclose(mean[b], m_o, rtol=rt, atol=rt * 10)
+        np.testing.assert_allclose(var[b], v_o, rtol=rt)
+
+
 @pytest.mark.parametrize("dtype,D,N,S", [(np.float64, 130, 40, 3), (np.float64, 384, 257, 70), (np.float32, 1024, 500, 5)])
 def test_large_d_rand_and_weight_draws(B, dtype, D, N, S):
     # reference :46-53 at D > 128: blocked factorisation of the prior + wavefront back substitution, one grid column per draw

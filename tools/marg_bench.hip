@@ -32,7 +32,7 @@ int main(int argc, char** argv) {
                      (const int32_t*)dinfo, 0, D);
   MargBlockArgs<T> m{};
   m.X = dX; m.ldx = D; m.U = dU; m.ldu = D; m.img = dimg; m.mw = dmw; m.s = ds; m.noise_kind = NOISE_ISOTROPIC; m.mean = dmean; m.var = dvar;
-  m.info = dinfo; m.D = D; m.Dx = D; m.DP = DP; m.N = N;
+  m.info = dinfo; m.D = D; m.Dx = D; m.DP = DP; m.N = N;  // (one regressor: the batch strides stay zero)
   int cus = 256; { hipDeviceProp_t pr; CK(hipGetDeviceProperties(&pr, 0)); cus = pr.multiProcessorCount; }
   const int ntiles = (N + 31) / 32, grid = ntiles < cus ? ntiles : cus;
   hipEvent_t e0, e1; CK(hipEventCreate(&e0)); CK(hipEventCreate(&e1));
