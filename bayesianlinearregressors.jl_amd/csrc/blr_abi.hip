@@ -737,7 +737,7 @@ int posterior_large_group(blr_handle* h, const PosteriorArgs<T>& a, int64_t reg0
   auto gram_tiles = [&](hipStream_t st, int nsp, int nt, T* gp) {
     g.nsplit = nsp; g.ntiles = nt; g.Gpart = gp;
     g.nsplit_diag = nsplit_diag; g.nlong = nlong;
-    g.xcd_swizzle = (nsp > 1 && !no_swizzle && nlong == 0) ? 1 : 0;  // (three kinds of work items: dispatch order IS the plan)
+    g.xcd_swizzle = (nsp > 1 && !no_swizzle) ? (nlong == 0 ? 1 : 2) : 0;  // (three kinds of work items: remapped inside a kind, the dispatch order of the kinds IS the plan)
     const int nwg = nsplit_diag ? (nt - NC) * nsp - nlong + NC * nsplit_diag : nt * nsp;
     hipLaunchKernelGGL(gram_tile_kernel<T>, dim3(nwg, G), dim3(kThreads), LC::LDS_BYTES, st, g);
     if (prior_factor) {

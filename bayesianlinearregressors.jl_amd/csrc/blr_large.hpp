@@ -482,9 +482,24 @@ __global__ __launch_bounds__(kThreads, (sizeof(T) == 4 ? BLR_GRAM_WGS : 2)) void
   // (split, tile) work items, so that the tiles of one N-slice -- which all stream the same columns of X -- share one
   // L2 instead of pulling the slice into all eight (bijective for any grid size).
   int w = blockIdx.x + blockIdx.y * gridDim.x;  // (dispatch order: x fastest)
-  if (a.xcd_swizzle) {
+  if (a.xcd_swizzle == 1) {
     const int nwg = gridDim.x * gridDim.y, xcd = w & 7, qq = nwg >> 3, rr = nwg & 7;
     w = (xcd < rr ? xcd * (qq + 1) : rr * (qq + 1) + (xcd - rr) * qq) + (w >> 3);
+  } else if (a.xcd_swizzle == 2 && gridDim.y == 1) {
+    // A planned launch (three kinds of work items, below): the dispatch order of the KINDS is the plan, so the remapping stays
+    // inside a kind -- each XCD gets a contiguous run of the kind's range-major list (the k-th workgroup of XCD x within the
+    // kind takes the k-th item of x's run).  Bijective for any sizes: XCD y holds ceil((n - f_y) / 8) of a kind's n workgroups,
+    // f_y = its first position there.
+    const int nd = a.nblocks * a.nsplit_diag, nl = a.nlong * (a.nsplit - 1);
+    const int base = w < nd ? 0 : (w < nd + nl ? nd : nd + nl);
+    const int n = w < nd ? nd : (w < nd + nl ? nl : (int)gridDim.x - nd - nl);
+    const int xcd = w & 7, k = (w - base - ((xcd - base) & 7)) >> 3;
+    int start = 0;
+    for (int y = 0; y < xcd; ++y) {
+      const int fy = (y - base) & 7;
+      start += fy < n ? (n - fy + 7) >> 3 : 0;
+    }
+    w = base + start + k;
   }
   if (gridDim.y > 1) {  // regressor of the group, then the work item within it
     const int64_t g = w / (int)gridDim.x;
