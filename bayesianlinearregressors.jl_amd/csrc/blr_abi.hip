@@ -346,7 +346,7 @@ int launch_fused_wave(blr_handle* h, const PosteriorArgs<T>& a) {
 
 // D = 128, fp64, aligned ColVecs, isotropic noise, diagonal prior, whole 32-column k-steps: the Gram matrix on the int8 matrix
 // cores (blr_fused_i8.hpp), followed by the fp64 kernel in retry-only mode for the regressors the fast path handed back
-// (non-zero prior mean, a row bound broken, non-finite input): every regressor leaves with the status and the numbers of an
+// (a row bound broken, non-finite input): every regressor leaves with the status and the numbers of an
 // fp64-accurate update, none is computed twice on the fast path.
 int launch_fused_i8(blr_handle* h, const PosteriorArgs<double>& a) {
   int rc = set_lds_once(h, reinterpret_cast<const void*>(fused_i8_kernel), (size_t)I8Cfg::LDS_BYTES);

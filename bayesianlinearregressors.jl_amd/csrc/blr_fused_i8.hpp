@@ -6,7 +6,7 @@
 // matrix-pipe time on v_mfma_i32_32x32x32_i8 and is then bound by the HBM stream of X (4.2 MB per update).
 //
 // Arithmetic (reference src/bayesian_linear_regression.jl:86, G = X X'):
-//   per row i of X a power of two 2^e_i bounds every |x_in| (e_i = exponent of the row's largest entry in the first 32
+//   per row i of X a power of two 2^e_i bounds every |x_in| (e_i = exponent of the row's largest entry in the first 96
 //   columns + kI8Margin; a later entry that breaks the bound sends the WHOLE regressor back to the fp64 kernel -- status
 //   kI8Retry, consumed by a follow-up launch of fused_small_kernel -- so the fast path never returns a wrong number);
 //   Q_in = round-to-nearest-even(x_in 2^(47 - e_i)) is a 48-bit signed integer, obtained with ONE v_add_f64 (the classic
@@ -36,12 +36,15 @@
 //   * inside a k-step the order is pinned by hand: MFMA, then (in its 32-cycle shadow) the fragment reads two MFMAs ahead
 //     and one of 14 chunks of the slicing; ONE workgroup barrier per k-step;
 //   * after the stream: accumulators -> fp64 -> packed triangle of A in LDS; waves 4-7 exit; waves 0-3 run the phases of
-//     fused_small_kernel (blocked Cholesky, substitutions, evidence) unchanged.
+//     fused_small_kernel (blocked Cholesky, substitutions, evidence) unchanged;
+//   * a prior mean mw != 0 (reference :57, :82: delta = y - X'mw) never touches the stream: G is exact, so
+//     b = X delta / s = X y / s - (A - Lw) mw and delta'delta / s = y'y / s - 2 mw'X y / s + mw'(A - Lw) mw are formed from the
+//     finished A (one 128 x 128 symmetric matrix-vector product in LDS).
 // (Measured alternatives, tools/i8_gram.hip: four waves with the whole register file each -- no register pressure, but one wave
 // per SIMD cannot keep the matrix pipe fed next to the slicing and the DMA issue: 4000 cycles per k-step against 3000; the
 // factorisations as a second launch with two workgroups per CU: 4.9 ms per 4096 updates against 4.7, the stream-only kernel
-// runs at a lower clock; staggered starts of the workgroups, static priority for waves 4-7, cache-warming touches three
-// k-steps ahead: no gain or a loss.  The stream is bound by what one CU pulls from HBM, ~25 GB/s.)
+// runs at the same power-limited clock (second attempt, per-kernel timings: stream 4.33 ms + finish 0.74 ms against 5.22 ms fused); staggered starts of the workgroups, static priority for waves 4-7, cache-warming touches three
+// k-steps ahead: no gain or a loss.  On zero operands the kernel runs 4.04 ms per 4096 updates against 5.28 on N(0,1) inputs: power-bound.)
 #pragma once
 #include "blr_fused_small.hpp"
 
@@ -392,16 +395,21 @@ __device__ __forceinline__ void i8_gram_stream(char* smem, const BLR_GLOBAL doub
 
   const int nissue0 = nk < 3 ? nk : 3;
   for (int t = 0; t < nissue0; ++t) issue(t);
-  wait_keep(nissue0 - 1);
-  __syncthreads();  // block 0 visible
-  // ---- row scales from block 0: e_r = exponent of the row's largest entry + 1 + margin
+  wait_keep(0);
+  __syncthreads();  // the first blocks visible
+  // ---- row scales from the blocks of the prologue (96 columns): e_r = exponent of the row's largest entry there + 1 + margin.
+  // (From block 0 alone -- 32 columns -- a row of N(0,1) entries stays below 1 sigma once in 2e5 rows and then accepts |x| < 4 sigma
+  // only: about one regressor in 7000 handed back, every other launch of 4096 paying a lone fp64 update, +10 %.  Over 96 columns
+  // the same event is 1e-16.)
   {
-    const double* col = reinterpret_cast<const double*>(ring) + (cq * 8) * 128 + r;
     unsigned m = 0;
+    for (int t = 0; t < nissue0; ++t) {
+      const double* col = reinterpret_cast<const double*>(ring + t * C::SLOT_BYTES) + (cq * 8) * 128 + r;
 #pragma unroll
-    for (int j = 0; j < 8; ++j) {
-      const unsigned ax = (unsigned)__double2hiint(col[j * 128]) & 0x7fffffffu;
-      m = ax > m ? ax : m;
+      for (int j = 0; j < 8; ++j) {
+        const unsigned ax = (unsigned)__double2hiint(col[j * 128]) & 0x7fffffffu;
+        m = ax > m ? ax : m;
+      }
     }
     xch[cq * 128 + r] = (int)m;
   }
@@ -491,13 +499,10 @@ __global__ __launch_bounds__(kI8Threads, 2) void fused_i8_kernel(PosteriorArgs<d
   const BLR_GLOBAL T* Lw = as_global(a.Lw + (int64_t)reg * a.strideLw);
   const T s_iso = as_global(a.s + (int64_t)reg * a.strides)[0];
 
-  // the fast path takes a zero prior mean only (mean(fx) = X'mw = 0 exactly, delta = y): anything else -> fp64 kernel
+  // A prior mean costs the stream nothing: with G = X X' exact, b = X (y - X'mw) / s = X y / s - (A - Lw) mw and
+  // delta'delta / s = y'y / s - 2 mw'X y / s + mw'(A - Lw) mw come out of the finished A after the hand-over (below).
   int ok = 1;
-  if (tid < D && mw[tid] != T(0)) ok = 0;
-  if (__syncthreads_or(!ok)) {  // handed back BEFORE the stream: the fp64 kernel reads X once, nobody reads it twice
-    if (tid == 0) a.info[reg] = kI8Retry;
-    return;
-  }
+  const int has_mw = __syncthreads_or(tid < D && mw[tid] != T(0));
   if (tid == 0) flag[0] = 1;
 
   I8Slice st;
@@ -615,6 +620,24 @@ __global__ __launch_bounds__(kI8Threads, 2) void fused_i8_kernel(PosteriorArgs<d
     if (tid == 0) a.info[reg] = kI8Retry;
     return;
   }
+  double quad_mw = quad;
+  if (has_mw) {  // (uniform)  prior mean != 0: fold it into the right-hand side and the quadratic form
+    T* const mwl = reinterpret_cast<T*>(smem + SC::OFF_MW);
+    if (tid < D) mwl[tid] = mw[tid];
+    __syncthreads();
+    double gm = 0.0, mi = 0.0;
+    if (tid < D) {
+      mi = (double)mwl[tid];
+      double am = 0.0;
+#pragma unroll 4
+      for (int j = 0; j < D; ++j) am += (double)((j <= tid) ? P[pidx(tid, j)] : P[pidx(j, tid)]) * (double)mwl[j];
+      gm = am - (double)Lw[tid] * mi;  // ((A - Lw) mw)_i = (G mw)_i / s
+    }
+    const double s1 = block_allreduce(mi * bsum, scr, tid);
+    const double s2 = block_allreduce(mi * gm, scr, tid);
+    quad_mw = quad - 2.0 * s1 + s2;
+    bsum -= gm;
+  }
   if (tid < D) bvec[tid] = (T)bsum;
   // prior (diagonal): SPD check + logdet (reference :78), noise variance (reference :79)
   int info = 0;
@@ -661,7 +684,7 @@ __global__ __launch_bounds__(kI8Threads, 2) void fused_i8_kernel(PosteriorArgs<d
     a.info[reg] = 0;
     if (a.logpdf) {
       const double LOG2PI = 1.8378770664093454835606594728112;
-      a.logpdf[reg] = -0.5 * ((double)N * LOG2PI + logdet_Sy + quad + scr[7] - logdet_Lw - scr[6]);  // :84 + :57
+      a.logpdf[reg] = -0.5 * ((double)N * LOG2PI + logdet_Sy + quad_mw + scr[7] - logdet_Lw - scr[6]);  // :84 + :57
     }
   }
   I8_KSTAMP(7);

@@ -161,7 +161,12 @@ def test_c2_shape_fp64(B):
     mw_o, T_o, L_o, lp_o = O.posterior_logpdf_direct(mw, np.ones(D), X, 0.1, y)
     assert lp == pytest.approx(lp_o, rel=1e-11)
     np.testing.assert_allclose(fp.mw, mw_o, rtol=1e-9, atol=1e-12)
-    np.testing.assert_allclose(fp.Lw.toarray(), L_o, rtol=1e-11)
+    # A = Lw + X X' / s: every entry within 1e-13 of the scale of its row and column (the int8-sliced Gram's error model: 48 bits
+    # per input relative to its ROW's bound -- an entry that nearly cancels is off by that much of sqrt(A_ii A_jj), not of itself),
+    # and within the documented 1e-9 of itself
+    dA = np.sqrt(np.diag(L_o))
+    assert (np.abs(fp.Lw.toarray() - L_o) / np.outer(dA, dA)).max() <= 1e-13
+    np.testing.assert_allclose(fp.Lw.toarray(), L_o, rtol=1e-9)
     assert lp == pytest.approx(O.logpdf_literal(mw, np.ones(D), X, 0.1, y), rel=1e-10)
     # determinism: fixed accumulation order, no float atomics -> bitwise reproducible
     assert B.logpdf(fx, y) == lp
@@ -2127,11 +2132,12 @@ def _i8_case(rng, nb, N, kind):
 
 @pytest.mark.parametrize("kind", ["gauss", "scales", "outlier", "zero_row", "tiny"])
 @pytest.mark.parametrize("N", [512, 4096])
-def test_i8_gram_path_vs_oracle_and_fp64_kernel(B, opt, kind, N):
+@pytest.mark.parametrize("prior_mean", [False, True])
+def test_i8_gram_path_vs_oracle_and_fp64_kernel(B, opt, kind, N, prior_mean):
     # the SAME call with the fast path on (default) and off (NO_I8_GRAM: fused_small_kernel, the fp64 matrix pipe), both against
     # the oracle's direct form at the fp64 tolerances of test_c2_shape_fp64; the two device paths must agree far inside them:
     # the digit splitting keeps 48 bits of every entry relative to its row's bound and every digit-pair product down to
-    # 2^-52 of the result (Gram entries within 3e-14 of sqrt(G_ii G_jj)).  Outliers / non-finite input / a prior mean send a regressor back to the fp64 kernel: then
+    # 2^-52 of the result (Gram entries within 3e-14 of sqrt(G_ii G_jj)).  Outliers / non-finite input send a regressor back to the fp64 kernel: then
     # the bits must be the fp64 kernel's.
     a = B._abi
     h = a.default_handle()
@@ -2140,6 +2146,9 @@ def test_i8_gram_path_vs_oracle_and_fp64_kernel(B, opt, kind, N):
     X, y = _i8_case(rng, nb, N, kind)
     dpr = np.exp(0.3 * rng.standard_normal((nb, D)))
     mw = np.zeros((nb, D))
+    if prior_mean:  # test/test_utils.jl:6: mw = randn(D) (in the units of the rows); on the fast path it enters through the finished A
+        rowscale = np.ldexp(1.0, (np.arange(D) % 7) * 4 - 12) if kind == "scales" else np.ones(D)
+        mw = rng.standard_normal((nb, D)) / rowscale[None, :]
     s = np.array([0.1])
 
     def run():
@@ -2178,8 +2187,9 @@ def test_i8_gram_path_vs_oracle_and_fp64_kernel(B, opt, kind, N):
 
 
 def test_i8_gram_path_hands_back_what_it_cannot_do(B, opt):
-    # prior mean != 0, NaN / Inf in X, a bad noise variance, a non-positive prior entry: status, NaN evidence and untouched
-    # outputs exactly as the fp64 kernel reports them (the fast path either reproduces the status or hands the regressor back)
+    # NaN / Inf in X, a bad noise variance, a non-positive prior entry: status, NaN evidence and untouched outputs exactly as the
+    # fp64 kernel reports them (the fast path either reproduces the status or hands the regressor back); a prior mean stays on
+    # the fast path
     a = B._abi
     h = a.default_handle()
     rng = _rng(4300)
@@ -2207,12 +2217,14 @@ def test_i8_gram_path_hands_back_what_it_cannot_do(B, opt):
     assert fast[3].tolist() == slow[3].tolist()
     assert fast[3][4] == 78 and fast[3][0] == 0 and fast[3][1] == 0
     for b in range(nb):
-        if b in (1, 2, 3, 4, 5):  # handed back or failed before any arithmetic: identical bits / identical NaN pattern
+        if b in (2, 3, 4, 5):  # handed back or failed before any arithmetic: identical bits / identical NaN pattern
             np.testing.assert_array_equal(fast[0][b], slow[0][b])
             np.testing.assert_array_equal(fast[1][b], slow[1][b])
             assert (fast[2][b] == slow[2][b]) or (np.isnan(fast[2][b]) and np.isnan(slow[2][b]))
         else:
             assert fast[2][b] == pytest.approx(slow[2][b], rel=1e-11)
+            np.testing.assert_allclose(fast[0][b], slow[0][b], rtol=1e-9, atol=1e-11)
+            np.testing.assert_allclose(fast[1][b], slow[1][b], rtol=1e-9, atol=1e-11)
     assert np.all(fast[0][4] == 7.0) and np.all(fast[1][4] == 7.0)  # failed regressor: outputs untouched
     bad = run(np.array([-0.5]))  # sigma^2 <= 0: PosDefException(1) at reference :79 for every regressor whose prior is fine
     assert bad[3].tolist() == [1, 1, 1, 1, 78, 1, 1, 1] and np.all(np.isnan(bad[2]))

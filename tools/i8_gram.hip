@@ -28,6 +28,7 @@ int main(int argc, char** argv) {
   for (auto& v : X) v = gauss();
   for (auto& v : y) v = 3.0 * gauss();
   for (int i = 0; i < D; ++i) dpr[i] = 0.5 + rnd();
+  if (getenv("I8_MW")) for (int i = 0; i < D; ++i) mw[i] = gauss();  // a prior mean (folded in after the stream)
   if (mode == 2)
     for (int b = 0; b < BU; ++b)
       for (int n = 0; n < N; ++n)
