@@ -979,7 +979,15 @@ int marginals_large_group(blr_handle* h, int layout, int64_t B, int64_t D, int64
     return 1;
   int rc;
   if ((rc = set_lds_once(h, reinterpret_cast<const void*>(marg_image_kernel<T>), (size_t)TrsmCfg<T>::LDS_BYTES))) return rc;
-  if ((rc = set_lds_once(h, reinterpret_cast<const void*>(marg_blocksub_kernel<T>), (size_t)MB::kMaxLds))) return rc;
+  // Tile height: 32 inputs on eight waves, one workgroup per CU -- or, when such tiles leave CUs idle (short N), 16 inputs on four
+  // waves, two workgroups per CU (twice the factor traffic per input: 1.02 against 0.77 ms at D = 1024, N = 65536, but 0.081
+  // against 0.104 ms at N = 999; fp32 only: the fp64 instance does not fit the registers of two workgroups per CU)
+  using MB16 = MargBlockCfg<T, 16>;
+  const bool small_tiles = sizeof(T) == 4 && ((N + MB::RT - 1) / MB::RT) * B < h->cus;
+  if ((rc = set_lds_once(h, reinterpret_cast<const void*>(marg_blocksub_kernel<T, 32>), (size_t)MB::kMaxLds))) return rc;
+  if constexpr (sizeof(T) == 4) {
+    if (small_tiles && (rc = set_lds_once(h, reinterpret_cast<const void*>(marg_blocksub_kernel<T, 16>), (size_t)MB16::lds_bytes(DP)))) return rc;
+  }
   // regressors per launch: grid.y, the images (36 / 72 KB per diagonal block) within 256 MiB, a dense prior's two D x D copies
   // within 1 GiB and chol_large's group size
   const size_t mat = (((size_t)DP * DP * sizeof(T)) + 255) & ~(size_t)255;
@@ -1019,9 +1027,20 @@ int marginals_large_group(blr_handle* h, int layout, int64_t B, int64_t D, int64
     m.noise_kind = noise_kind; m.mean = mean ? mean + b0 * stridemean : nullptr; m.var = var + b0 * stridevar; m.info = inf;
     m.D = Df; m.Dx = (int)D; m.DP = DP; m.N = (int)N;
     m.strideX = strideX; m.strideU = strideU; m.stridemw = stridemw; m.strides = strides; m.stridemean = stridemean; m.stridevar = stridevar;
-    const int64_t ntiles = (N + MB::RT - 1) / MB::RT;
-    const int64_t gx = std::min<int64_t>(ntiles, std::max<int64_t>(1, (h->cus + nb - 1) / nb));  // one workgroup per CU
-    hipLaunchKernelGGL(marg_blocksub_kernel<T>, dim3((unsigned)gx, (unsigned)nb), dim3(MB::THREADS), (size_t)MB::lds_bytes(DP), h->stream, m);
+    if constexpr (sizeof(T) == 4) {
+      if (small_tiles) {
+        const int64_t ntiles = (N + MB16::RT - 1) / MB16::RT;
+        const int64_t gx = std::min<int64_t>(ntiles, std::max<int64_t>(1, (2 * h->cus + nb - 1) / nb));  // two workgroups per CU
+        hipLaunchKernelGGL((marg_blocksub_kernel<T, 16>), dim3((unsigned)gx, (unsigned)nb), dim3(MB16::THREADS), (size_t)MB16::lds_bytes(DP),
+                           h->stream, m);
+      }
+    }
+    if (!small_tiles) {
+      const int64_t ntiles = (N + MB::RT - 1) / MB::RT;
+      const int64_t gx = std::min<int64_t>(ntiles, std::max<int64_t>(1, (h->cus + nb - 1) / nb));  // one workgroup per CU
+      hipLaunchKernelGGL((marg_blocksub_kernel<T, 32>), dim3((unsigned)gx, (unsigned)nb), dim3(MB::THREADS), (size_t)MB::lds_bytes(DP),
+                         h->stream, m);
+    }
   }
   HIP_TRY(h, hipGetLastError());
   return 0;

@@ -217,9 +217,14 @@ __device__ unsigned long long g_mbstamps[8][8];
 #else
 #define MB_SYNC() __syncthreads()
 #endif
-template <typename T>
+template <typename T, int RT_ = 32>
 struct MargBlockCfg {
-  static constexpr int RT = 32, WAVES = 8, THREADS = 512;
+  // RT = 32: eight waves, one workgroup per CU -- in the product a wave owns one column tile for both 16-row halves (a factor
+  // fragment feeds two MFMAs).  RT = 16: four waves, TWO workgroups per CU -- a wave owns two column tiles of the one row tile
+  // (an input fragment feeds two MFMAs; twice the factor traffic per input), and one workgroup's diagonal step / hand-overs
+  // run under the other's product.
+  static constexpr int RT = RT_, WAVES = RT_ / 4, THREADS = 64 * WAVES, WGS = 32 / RT_;  // (WGS: workgroups per CU)
+  static_assert(RT_ == 32 || RT_ == 16, "tile height");
   static constexpr int VEC = Mfma<T>::VEC;
   static constexpr int CH = 4 * VEC;               // contraction indices per 16-byte load of the four lane groups: 16 (f32) / 8 (f64)
   static constexpr int NCH = kPB / CH;             // such chunks per 128-block
@@ -270,9 +275,10 @@ __device__ __forceinline__ void mb_pin(V (&r)[K]) {  // (after an mb_wait: uses 
   for (int k = 0; k < K; ++k) asm volatile("" : "+v"(r[k]));
 }
 
-template <typename T>
-__global__ __launch_bounds__(MargBlockCfg<T>::THREADS) void marg_blocksub_kernel(MargBlockArgs<T> a) {
-  using C = MargBlockCfg<T>;
+template <typename T, int RT>
+__global__ __launch_bounds__((MargBlockCfg<T, RT>::THREADS), (MargBlockCfg<T, RT>::WGS)) void marg_blocksub_kernel(MargBlockArgs<T> a) {
+  using C = MargBlockCfg<T, RT>;
+  constexpr bool kTwoCols = RT == 16;  // the product's two accumulators: two column tiles of one row tile (else two row tiles of one)
   using G = MargGemmCfg<T>;
   using acc4 = typename Mfma<T>::acc4;
   constexpr int VEC = C::VEC, CH = C::CH, NCH = C::NCH;
@@ -283,7 +289,7 @@ __global__ __launch_bounds__(MargBlockCfg<T>::THREADS) void marg_blocksub_kernel
   // loads per wave and phase, in issue order: R factor chunks for the next product | I image vectors for the next diagonal step |
   // XV input vectors for the block after next  (always that many: out-of-range ones re-read a valid address)
   constexpr int NI = 9 * (16 / CH);              // chunks of the two jobs of a wave together: (jA + 1) + (jB + 1) = 9 column-tile heights
-  constexpr int R = RL, I = NI;
+  constexpr int R = kTwoCols ? 2 * RL : RL, I = NI;
   typedef T vecT __attribute__((ext_vector_type(Mfma<T>::VEC)));
   extern __shared__ __attribute__((aligned(16))) char smem[];
   T* const tile = reinterpret_cast<T*>(smem);
@@ -361,10 +367,21 @@ __global__ __launch_bounds__(MargBlockCfg<T>::THREADS) void marg_blocksub_kernel
 #pragma unroll
     for (int u = 0; u < NI; ++u) mb_load16(f[u], u < nuA ? pa + u * sa : pb + (u - nuA) * sb);
   };
-  vecT b[RL];
-  auto fetch_factor = [&](const BLR_GLOBAL T* p) {
+  vecT b[RL], b2[kTwoCols ? RL : 1];
+  auto fetch_factor = [&](const BLR_GLOBAL T* p, const BLR_GLOBAL T* p2) {
 #pragma unroll
     for (int u = 0; u < RL; ++u) mb_load16(b[u], p + CH * u);
+    if constexpr (kTwoCols) {
+#pragma unroll
+      for (int u = 0; u < RL; ++u) mb_load16(b2[u], p2 + CH * u);
+    }
+  };
+  // rows of U' this wave multiplies with in block J: column tile `wave` (and, two-column form, 7 - wave; one that lies beyond D
+  // re-reads the first: the count of loads stays R)
+  auto factor_rows = [&](int J, int which) {
+    const int nct = min(8, (D - kPB * J) / 16);
+    const int ct = (which == 1 && 7 - wave < nct) ? 7 - wave : wave;
+    return U + (int64_t)(kPB * J + 16 * ct + li) * a.ldu + VEC * g;
   };
   const int tstride = gridDim.x;
   if (a.mean) {
@@ -391,15 +408,17 @@ __global__ __launch_bounds__(MargBlockCfg<T>::THREADS) void marg_blocksub_kernel
       if (J > 0) {  // (the residual of block 0 is X_0 itself)
         acc4 c0 = {T(0), T(0), T(0), T(0)}, c1 = {T(0), T(0), T(0), T(0)};
         if (wave < ncolt) {
-          const BLR_GLOBAL T* ub = U + (int64_t)(kPB * J + 16 * wave + li) * a.ldu + VEC * g;
+          const BLR_GLOBAL T* ub = factor_rows(J, 0);
+          const BLR_GLOBAL T* ub2 = factor_rows(J, 1);
+          const bool two = kTwoCols && 7 - wave < ncolt;  // (the second column tile exists in this block)
           const T* a0 = tile + li * LD + VEC * g;
-          const T* a1 = a0 + 16 * LD;
+          const T* a1 = kTwoCols ? a0 : a0 + 16 * LD;
           const int ngrp = J * (NCH / RL);
           // The factor arrives a GROUP of RL chunks at a time, one group ahead (group 0 was requested before the previous block's
           // diagonal step): one wait per group, at its start.  Group 0 lets the I + XV loads issued after its own stay in flight;
           // the later groups wait for everything -- their own loads are the youngest, and what was requested before them (the
           // inputs' block from HBM) has had a whole group of 64 MFMAs.  Inside a group one pinned stream per chunk: the NEXT
-          // chunk's two fragment reads, then the eight MFMAs of this chunk on operands that arrived during the previous chunk's.
+          // chunk's fragment reads, then the eight MFMAs of this chunk on operands that arrived during the previous chunk's.
           vecT x0 = *reinterpret_cast<const vecT*>(a0);
           vecT x1 = *reinterpret_cast<const vecT*>(a1);
           MB_T(7);
@@ -409,24 +428,31 @@ __global__ __launch_bounds__(MargBlockCfg<T>::THREADS) void marg_blocksub_kernel
           for (int grp = 0; grp < ngrp; ++grp) {
             const bool more = grp + 1 < ngrp;
             mb_pin(b);
-            vecT bc[RL];
+            if constexpr (kTwoCols) mb_pin(b2);
+            vecT bc[RL], bc2[kTwoCols ? RL : 1];
 #pragma unroll
-            for (int u = 0; u < RL; ++u) bc[u] = b[u];
+            for (int u = 0; u < RL; ++u) {
+              bc[u] = b[u];
+              if constexpr (kTwoCols) bc2[u] = b2[u];
+            }
             mb_pin(bc);  // (copies made before the next group's loads land in b)
+            if constexpr (kTwoCols) mb_pin(bc2);
 #if !(defined(BLR_MB_EXP) && (BLR_MB_EXP & 4))
-            if (more) fetch_factor(ub + CH * RL * (grp + 1));
+            if (more) fetch_factor(ub + CH * RL * (grp + 1), ub2 + CH * RL * (grp + 1));
 #endif
 #pragma unroll
             for (int u = 0; u < RL; ++u) {
               const int d = CH * (RL * grp + u);
               const int dn = (more || u + 1 < RL) ? d + CH : d;  // (the last chunk re-reads itself: no branch in the stream)
               const vecT nx0 = *reinterpret_cast<const vecT*>(a0 + dn);
-              const vecT nx1 = *reinterpret_cast<const vecT*>(a1 + dn);
+              vecT nx1 = nx0;
+              if constexpr (!kTwoCols) nx1 = *reinterpret_cast<const vecT*>(a1 + dn);
               __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
               for (int e = 0; e < VEC; ++e) {
                 c0 = Mfma<T>::mma(x0[e], bc[u][e], c0);
-                c1 = Mfma<T>::mma(x1[e], bc[u][e], c1);
+                if constexpr (kTwoCols) c1 = Mfma<T>::mma(x0[e], bc2[u][e], c1);
+                else c1 = Mfma<T>::mma(x1[e], bc[u][e], c1);
               }
               __builtin_amdgcn_sched_barrier(0);
               x0 = nx0;
@@ -439,10 +465,14 @@ __global__ __launch_bounds__(MargBlockCfg<T>::THREADS) void marg_blocksub_kernel
             MB_T(1);
           }
 #pragma unroll
-          for (int v = 0; v < 4; ++v) {  // R_J = X_J - sum, in place (these 16 columns belong to this wave alone)
+          for (int v = 0; v < 4; ++v) {  // R_J = X_J - sum, in place (these columns belong to this wave alone)
             T* p = tile + Mfma<T>::crow(lane, v) * LD + kPB * J + 16 * wave + li;
             p[0] -= c0[v];
-            p[16 * LD] -= c1[v];
+            if constexpr (kTwoCols) {
+              if (two) p[16 * (7 - 2 * wave)] -= c1[v];  // (column tile 7 - wave of the same rows)
+            } else {
+              p[16 * LD] -= c1[v];
+            }
           }
         }
         MB_T(2);
@@ -451,7 +481,7 @@ __global__ __launch_bounds__(MargBlockCfg<T>::THREADS) void marg_blocksub_kernel
       }
       // the next block's product starts on these (nothing here depends on the tile)
       const bool next_prod = J + 1 < NC && wave < min(8, (D - kPB * (J + 1)) / 16);
-      if (next_prod) fetch_factor(U + (int64_t)(kPB * (J + 1) + 16 * wave + li) * a.ldu + VEC * g);
+      if (next_prod) fetch_factor(factor_rows(J + 1, 0), factor_rows(J + 1, 1));
       // Z_J = R_J L_JJ^-T: job A = rows 0..15 x column tile jA, job B = rows 16..31 x column tile jB (two independent accumulators).
       // The fragments were requested in the previous phase; younger than them: XV input vectors, the R factor chunks above.
       MB_T(7);
@@ -462,7 +492,7 @@ __global__ __launch_bounds__(MargBlockCfg<T>::THREADS) void marg_blocksub_kernel
       acc4 zA = {T(0), T(0), T(0), T(0)}, zB = {T(0), T(0), T(0), T(0)};
       {
         const T* apA = tile + li * LD + kPB * J + VEC * g;
-        const T* apB = tile + (16 + li) * LD + kPB * J + VEC * g;
+        const T* apB = tile + ((kTwoCols ? 0 : 16) + li) * LD + kPB * J + VEC * g;
         const bool doA = jA < ncolt, doB = jB < ncolt;
         vecT x = *reinterpret_cast<const vecT*>(apA);
 #pragma unroll
@@ -498,7 +528,7 @@ __global__ __launch_bounds__(MargBlockCfg<T>::THREADS) void marg_blocksub_kernel
           sqA[v] += zA[v] * zA[v];
         }
         if (jB < ncolt) {
-          tile[(16 + r) * LD + kPB * J + 16 * jB + li] = zB[v];
+          tile[((kTwoCols ? 0 : 16) + r) * LD + kPB * J + 16 * jB + li] = zB[v];
           sqB[v] += zB[v] * zB[v];
         }
       }
@@ -531,8 +561,12 @@ __global__ __launch_bounds__(MargBlockCfg<T>::THREADS) void marg_blocksub_kernel
       const double ra = (double)row16_allreduce(sqA[v]);
       const double rb = (double)row16_allreduce(sqB[v]);
       if (li == 0) {
-        red[wave * C::RT + Mfma<T>::crow(lane, v)] = ra;
-        red[wave * C::RT + 16 + Mfma<T>::crow(lane, v)] = rb;
+        if constexpr (kTwoCols) {
+          red[wave * C::RT + Mfma<T>::crow(lane, v)] = ra + rb;
+        } else {
+          red[wave * C::RT + Mfma<T>::crow(lane, v)] = ra;
+          red[wave * C::RT + 16 + Mfma<T>::crow(lane, v)] = rb;
+        }
       }
     }
     __syncthreads();

@@ -938,7 +938,7 @@ def test_padded_leading_dimensions_and_shared_inputs(B):
 
 @pytest.mark.parametrize("dtype,D,N", [(np.float64, 130, 77), (np.float64, 300, 1000), (np.float32, 1024, 3000), (np.float64, 256, 500),
                                        (np.float64, 400, 1000), (np.float64, 576, 95), (np.float32, 144, 100), (np.float32, 1040, 333),
-                                       (np.float32, 1152, 31)])
+                                       (np.float32, 1152, 31), (np.float32, 256, 8200)])
 def test_large_d_marginals(B, dtype, D, N):
     # reference :33, :40-43 at D > 128: GEMV stream for the mean; var by block forward substitution on LDS-resident tiles of inputs
     # (16 | D, tile fits LDS: aligned ColVecs) or by the tall TRSM through the panel machinery of the factorisation (everything else)

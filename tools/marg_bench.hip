@@ -25,21 +25,24 @@ int main(int argc, char** argv) {
   CK(hipMalloc((void**)&dinfo, 4)); CK(hipMemset(dinfo, 0, 4));
   CK(hipMemcpy(dX, X.data(), X.size() * 4, hipMemcpyHostToDevice)); CK(hipMemcpy(dU, U.data(), U.size() * 4, hipMemcpyHostToDevice));
   CK(hipMemcpy(dmw, mw.data(), D * 4, hipMemcpyHostToDevice)); const T s_iso = 0.1f; CK(hipMemcpy(ds, &s_iso, 4, hipMemcpyHostToDevice));
-  using MB = MargBlockCfg<T>;
+#ifndef MB_RT
+#define MB_RT 32
+#endif
+  using MB = MargBlockCfg<T, MB_RT>;
   CK(hipFuncSetAttribute(reinterpret_cast<const void*>(marg_image_kernel<T>), hipFuncAttributeMaxDynamicSharedMemorySize, TrsmCfg<T>::LDS_BYTES));
-  CK(hipFuncSetAttribute(reinterpret_cast<const void*>(marg_blocksub_kernel<T>), hipFuncAttributeMaxDynamicSharedMemorySize, MB::kMaxLds));
+  CK(hipFuncSetAttribute(reinterpret_cast<const void*>(marg_blocksub_kernel<T, MB_RT>), hipFuncAttributeMaxDynamicSharedMemorySize, MB::kMaxLds));
   hipLaunchKernelGGL(marg_image_kernel<T>, dim3(NC, 2), dim3(kThreads), TrsmCfg<T>::LDS_BYTES, 0, (const T*)dU, (int64_t)D, (int64_t)128 * (D + 1), 128, dimg,
-                     (const int32_t*)dinfo, 0, D);
+                     (const int32_t*)dinfo, 0, D, NC, (int64_t)0);
   MargBlockArgs<T> m{};
   m.X = dX; m.ldx = D; m.U = dU; m.ldu = D; m.img = dimg; m.mw = dmw; m.s = ds; m.noise_kind = NOISE_ISOTROPIC; m.mean = dmean; m.var = dvar;
   m.info = dinfo; m.D = D; m.Dx = D; m.DP = DP; m.N = N;  // (one regressor: the batch strides stay zero)
   int cus = 256; { hipDeviceProp_t pr; CK(hipGetDeviceProperties(&pr, 0)); cus = pr.multiProcessorCount; }
-  const int ntiles = (N + 31) / 32, grid = ntiles < cus ? ntiles : cus;
+  const int ntiles = (N + MB_RT - 1) / MB_RT, slots = cus * (32 / MB_RT), grid = ntiles < slots ? ntiles : slots;
   hipEvent_t e0, e1; CK(hipEventCreate(&e0)); CK(hipEventCreate(&e1));
-  for (int w = 0; w < 3; ++w) hipLaunchKernelGGL(marg_blocksub_kernel<T>, dim3(grid), dim3(MB::THREADS), MB::lds_bytes(DP), 0, m);
+  for (int w = 0; w < 3; ++w) hipLaunchKernelGGL((marg_blocksub_kernel<T, MB_RT>), dim3(grid), dim3(MB::THREADS), MB::lds_bytes(DP), 0, m);
   CK(hipDeviceSynchronize()); CK(hipGetLastError());
   CK(hipEventRecord(e0));
-  for (int r = 0; r < reps; ++r) hipLaunchKernelGGL(marg_blocksub_kernel<T>, dim3(grid), dim3(MB::THREADS), MB::lds_bytes(DP), 0, m);
+  for (int r = 0; r < reps; ++r) hipLaunchKernelGGL((marg_blocksub_kernel<T, MB_RT>), dim3(grid), dim3(MB::THREADS), MB::lds_bytes(DP), 0, m);
   CK(hipEventRecord(e1)); CK(hipEventSynchronize(e1));
   float ms; CK(hipEventElapsedTime(&ms, e0, e1)); ms /= reps;
 #ifdef BLR_MB_STAMPS
