@@ -457,6 +457,7 @@ def secondary_ops(torch, _abi, h, dev):
         "marginals_var_c2_f32": lambda: marginals(64, 128, 4096, "f32", False),
         "marginals_mean_c3_f32": lambda: marginals(1, 1024, 65536, "f32", True),
         "marginals_var_c3_f32": lambda: marginals(1, 1024, 65536, "f32", False),
+        "marginals_var_D512_B16_f32": lambda: marginals(16, 512, 16384, "f32", False),  # a batch at D > 128: one set of launches
         "rand_c2_f64_S64": lambda: rand(128, 4096, 64, "f64"),
         "rand_c3_f32_S64": lambda: rand(1024, 65536, 64, "f32"),
         "logpdf_grad_c2_f64": lambda: grad(1024, 128, 4096, "f64"),

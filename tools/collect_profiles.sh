@@ -22,9 +22,14 @@ $B --D 1024 --N 65536 --dtype f32 --noise diagonal --batch 8 --steps 10 --warmup
 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/stats_c3b8 -- $B --D 1024 --N 65536 --dtype f32 --noise diagonal --batch 8 --steps 10 --warmup 2 > /dev/null 2>&1
 # PMC: separate passes (TCC FETCH_SIZE and WRITE_SIZE do not fit one pass), kernel-trace only
 SQ="GRBM_GUI_ACTIVE SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_VALU_MFMA_BUSY_CYCLES SQ_WAIT_INST_LDS SQ_LDS_BANK_CONFLICT"
+# (the default c2 path is the int8-sliced Gram; the fp64 kernel of the same shape under BLR_MI355X_NO_I8_GRAM -- the variable is set
+# for rocprofv3 itself, the program after `--` stays python3)
+for c in FETCH_SIZE WRITE_SIZE; do
+  BLR_MI355X_NO_I8_GRAM=1 rocprofv3 --pmc $c --kernel-trace --output-format csv -d $OUT/pmc_${c}_c2fp64 -- $B --steps 5 --warmup 2 > /dev/null 2>&1
+done
+BLR_MI355X_NO_I8_GRAM=1 rocprofv3 --pmc $SQ --kernel-trace --output-format csv -d $OUT/pmc_sq_c2fp64 -- $B --steps 5 --warmup 2 > /dev/null 2>&1
 rocprofv3 --pmc FETCH_SIZE --kernel-trace --output-format csv -d $OUT/pmc_fetch_c2 -- $B --steps 5 --warmup 2 > /dev/null 2>&1
 rocprofv3 --pmc WRITE_SIZE --kernel-trace --output-format csv -d $OUT/pmc_write_c2 -- $B --steps 5 --warmup 2 > /dev/null 2>&1
-rocprofv3 --pmc $SQ --kernel-trace --output-format csv -d $OUT/pmc_sq_c2 -- $B --steps 5 --warmup 2 > /dev/null 2>&1
 rocprofv3 --pmc $SQ --kernel-trace --output-format csv -d $OUT/pmc_sq_c2f32 -- $B --dtype f32 --steps 5 --warmup 2 > /dev/null 2>&1
 rocprofv3 --pmc $SQ --kernel-trace --output-format csv -d $OUT/pmc_sq_c3 -- $B --config c3 --steps 5 --warmup 2 > /dev/null 2>&1
 rocprofv3 --pmc $SQ --kernel-trace --output-format csv -d $OUT/pmc_sq_c4 -- $B --config c4 --steps 5 --warmup 2 > /dev/null 2>&1
@@ -43,14 +48,15 @@ rocprofv3 --pmc $SQ --kernel-trace --output-format csv -d $OUT/pmc_sq_c3b8 -- $B
 ( cd $R/tools && [ -x ./ring_probe ] || /opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -std=c++17 -DRING_MWZ=true -I$R/bayesianlinearregressors.jl_amd/csrc ring_probe.hip -o ring_probe 2>/dev/null
   { echo "# tools/ring_probe 8192 0 (zero operands)"; ./ring_probe 8192 0; echo "# tools/ring_probe 8192 1 (random operands)"; ./ring_probe 8192 1; } > $OUT/ring_probe.txt 2>&1
   python3 $R/tools/power_probe.py > $OUT/power_probe.txt 2>&1
+  { ./marg_bench 1024 65536 20; [ -x ./marg_bench16 ] && ./marg_bench16 1024 65536 20; ./marg_bench 1024 999 20; [ -x ./marg_bench16 ] && ./marg_bench16 1024 999 20; [ -x ./marg_bench_st ] && ./marg_bench_st 1024 65536 5 | grep wave; } > $OUT/marg_bench.txt 2>&1
   # int8-sliced Gram against the fp64 kernel, same inputs: rates, agreement, the retry path (mode 1), per-phase cycle stamps
-  { for m in 0 2; do ./i8_gram 4096 4096 10 $m; done; ./i8_gram 512 4096 3 1; ./i8_gram 512 1024 3 0; [ -x ./i8_gram_st ] && ./i8_gram_st 4096 4096 4 0 | grep "wave"; } > $OUT/i8_gram.txt 2>&1 )
+  { for m in 0 2; do ./i8_gram 4096 4096 10 $m; done; ./i8_gram 512 4096 3 1; ./i8_gram 512 1024 3 0; ./i8_gram 4096 4096 10 3; I8_MW=1 ./i8_gram 4096 4096 10 0; [ -x ./i8_gram_st ] && ./i8_gram_st 4096 4096 4 0 | grep "wave"; } > $OUT/i8_gram.txt 2>&1 )
 # every secondary entry of the driver line: kernel stats of the hot-path rows, HBM bytes per CALL (all of a call's kernels) by PMC
-for e in marginals_var_c2_f64 marginals_var_c3_f32 rand_c2_f64_S64 rand_c3_f32_S64 logpdf_grad_c2_f64; do
+for e in marginals_var_c2_f64 marginals_var_c3_f32 marginals_var_D512_B16_f32 rand_c2_f64_S64 rand_c3_f32_S64 logpdf_grad_c2_f64 logpdf_multi_c3_f32_S64; do
   rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/stats_$e -- $B --secondary-only $e > /dev/null 2>&1
 done
-for e in c2_f64_mw c2_f64_diag_noise c4_f32 c4_f64_B1024 c3_f32_mw logpdf_only_c3_f32 c3_f32_B8 c5_shape_f32_B8 marginals_mean_c2_f64 marginals_var_c2_f64 \
-         marginals_var_c2_f32 marginals_mean_c3_f32 marginals_var_c3_f32 rand_c2_f64_S64 rand_c3_f32_S64 logpdf_grad_c2_f64 logpdf_multi_c3_f32_S64 \
+for e in c2_f64_mw c2_f64_diag_noise c4_f32 c4_f64_B4096 c4_f64_B2048 c4_f64_B1024 c3_f32_mw logpdf_only_c3_f32 c3_f32_B8 c5_shape_f32_B8 marginals_mean_c2_f64 marginals_var_c2_f64 \
+         marginals_var_c2_f32 marginals_mean_c3_f32 marginals_var_c3_f32 marginals_var_D512_B16_f32 rand_c2_f64_S64 rand_c3_f32_S64 logpdf_grad_c2_f64 logpdf_multi_c3_f32_S64 \
          update_factor_D128_k1_f64 update_factor_D128_k16_f64; do
   rocprofv3 --pmc FETCH_SIZE --kernel-trace --output-format csv -d $OUT/sec_fetch_$e -- $B --secondary-only $e > $OUT/sec_fetch_$e.json 2>/dev/null
   rocprofv3 --pmc WRITE_SIZE --kernel-trace --output-format csv -d $OUT/sec_write_$e -- $B --secondary-only $e > $OUT/sec_write_$e.json 2>/dev/null

@@ -66,9 +66,9 @@ def counters(dirname, kernel_substr):
 summary = {"note": "per-dispatch means for the dominant kernel; rocprofv3 --pmc, one counter group per pass "
                    "(tools/collect_profiles.sh); FETCH_SIZE / WRITE_SIZE in KiB, FETCH_SIZE x2 on gfx950 "
                    "(MI355X_MICROARCH.md, HBM/rocprofv3 section)"}
-fetch = counters("pmc_fetch_c2", "fused_small_kernel")
-write = counters("pmc_write_c2", "fused_small_kernel")
-sq2 = counters("pmc_sq_c2", "fused_small_kernel")
+fetch = counters("pmc_FETCH_SIZE_c2fp64", "fused_small_kernel")  # (the fp64 kernel: runs under BLR_MI355X_NO_I8_GRAM)
+write = counters("pmc_WRITE_SIZE_c2fp64", "fused_small_kernel")
+sq2 = counters("pmc_sq_c2fp64", "fused_small_kernel")
 sq3 = counters("pmc_sq_c3", "gram_tile_kernel")
 if fetch and write:
     rd = fetch["FETCH_SIZE"] * 1024.0 * 2.0
@@ -100,7 +100,7 @@ for key, d, kern, units in (("c2_f32_fused_small_kernel_hbm", "c2f32", "fused_sm
 for src in sorted(glob.glob(os.path.join(os.path.dirname(RAW), "microbench", "*.txt"))):  # tools/run_microbench.sh
     if os.path.getsize(src):
         shutil.copy(src, os.path.join(DST, f"{tag}_microbench_{os.path.basename(src)}"))
-for extra in ("ring_probe.txt", "power_probe.txt", "i8_gram.txt"):
+for extra in ("ring_probe.txt", "power_probe.txt", "i8_gram.txt", "marg_bench.txt"):
     src = os.path.join(RAW, extra)
     if os.path.exists(src) and os.path.getsize(src):
         shutil.copy(src, os.path.join(DST, f"{tag}_microbench_{extra}"))
