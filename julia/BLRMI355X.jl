@@ -652,6 +652,18 @@ mutable struct DeviceArray{T}
         finalizer(a -> ccall((:blr_device_free, LIB), Cint, (Ptr{Cvoid}, Ptr{Cvoid}), handle(), a.ptr), a)
     end
 end
+# Run-time switches of this task's handle (A/B measurements and tests; the defaults are the measured best).  `key` with or
+# without the BLR_MI355X_ prefix (include/blr_mi355x.h lists them); `value === nothing` restores the default.
+function set_option!(key::AbstractString, value::Union{Nothing,AbstractString,Integer}=nothing)
+    h = handle()
+    v = value === nothing ? C_NULL : string(value)
+    rc = ccall((:blr_set_option, LIB), Cint, (Ptr{Cvoid}, Cstring, Cstring), h, key, v)
+    rc == 0 || throw(ArgumentError("blr_set_option: unknown key or malformed value: $key = $value"))
+    return nothing
+end
+# Give the handle's workspace, feature and side buffers back to the allocator (they are re-created by the next call that needs them).
+release_workspace!() = (h = handle(); check(h, ccall((:blr_release_workspace, LIB), Cint, (Ptr{Cvoid},), h)); nothing)
+
 function upload(a::Array{T}) where {T}
     d = DeviceArray{T}(length(a))
     h = handle()

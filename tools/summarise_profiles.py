@@ -24,7 +24,8 @@ for name in ("bench_c2_f64", "bench_c2_f32", "bench_c3_f32", "bench_c5_f32", "be
     src = os.path.join(RAW, name + ".json")
     if os.path.exists(src) and os.path.getsize(src):
         shutil.copy(src, os.path.join(DST, f"{tag}_{name}.json"))
-for cfg in ("c2", "c3", "c5", "c4", "c3b8", "marginals_var_c2_f64", "marginals_var_c3_f32", "rand_c2_f64_S64", "rand_c3_f32_S64", "logpdf_grad_c2_f64"):
+for cfg in ("c2", "c3", "c5", "c4", "c3b8", "marginals_var_c2_f64", "marginals_var_c3_f32", "rand_c2_f64_S64", "rand_c3_f32_S64", "logpdf_grad_c2_f64",
+            "marginals_var_D512_B16_f32", "logpdf_multi_c3_f32_S64"):
     f = one(f"{RAW}/stats_{cfg}/*/*_kernel_stats.csv")
     if f:
         shutil.copy(f, os.path.join(DST, f"{tag}_{cfg}_kernel_stats.csv"))
