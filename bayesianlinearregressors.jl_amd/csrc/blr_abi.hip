@@ -1700,13 +1700,6 @@ int logpdf_multi(blr_handle* h, int memspace, int layout, int64_t D, int64_t N, 
   using LC = LargeCfg<T>;
   Staging guard(h);
   int rc;
-  auto tmp = [&](size_t bytes, void** out) -> int {  // call-scoped device temporaries (freed by the Staging guard)
-    void* p = nullptr;
-    HIP_TRY(h, hipMalloc(&p, std::max<size_t>(bytes, 256)));
-    h->staged.push_back(p);
-    *out = p;
-    return 0;
-  };
   const T *X_d = X, *Y_d = Y, *s_d = s, *mw_d = mw, *Lw_d = Lw;
   double* lp_d = logpdf;
   T* mp_d = mw_post;
@@ -1731,19 +1724,24 @@ int logpdf_multi(blr_handle* h, int memspace, int layout, int64_t D, int64_t N, 
   // split-K over N: fill the 512 workgroup slots
   const int max_split = std::max(1, std::min<int>(64, (int)((N + LC::NSC - 1) / LC::NSC)));
   const int nsplit = std::max(1, std::min(max_split, 512 / std::max(1, ntiles)));
+  // eleven call-scoped temporaries, carved out of the handle's side buffer (it only grows: no hipMalloc / hipFree -- each of which
+  // drains the device -- on a steady-state call; neither the update of step (1) nor the mean stream of step (2) uses that buffer)
   void *vTf, *vlp0, *vmu, *vR, *vq, *vG, *vY, *vsq, *vuu, *vzero, *vinfo2;
   const int64_t ldr = layout == BLR_LAYOUT_COLVECS ? SP : N;
-  if ((rc = tmp((size_t)D * D * sizeof(T), &vTf))) return rc;
-  if ((rc = tmp(sizeof(double), &vlp0))) return rc;
-  if ((rc = tmp((size_t)N * sizeof(T), &vmu))) return rc;
-  if ((rc = tmp((size_t)SP * N * sizeof(T), &vR))) return rc;
-  if ((rc = tmp((size_t)NP64 * SP * sizeof(double), &vq))) return rc;
-  if ((rc = tmp((size_t)nsplit * ntiles * kPB * kPB * sizeof(T), &vG))) return rc;
-  if ((rc = tmp((size_t)ldy * DP * sizeof(T), &vY))) return rc;
-  if ((rc = tmp((size_t)SP * sizeof(double), &vsq))) return rc;
-  if ((rc = tmp((size_t)SP * sizeof(T), &vuu))) return rc;
-  if ((rc = tmp(sizeof(T), &vzero))) return rc;
-  if ((rc = tmp(sizeof(int32_t), &vinfo2))) return rc;
+  {
+    const size_t sizes[11] = {(size_t)D * D * sizeof(T), sizeof(double), (size_t)N * sizeof(T), (size_t)SP * N * sizeof(T),
+                              (size_t)NP64 * SP * sizeof(double), (size_t)nsplit * ntiles * kPB * kPB * sizeof(T),
+                              (size_t)ldy * DP * sizeof(T), (size_t)SP * sizeof(double), (size_t)SP * sizeof(T), sizeof(T), sizeof(int32_t)};
+    void** const outs[11] = {&vTf, &vlp0, &vmu, &vR, &vq, &vG, &vY, &vsq, &vuu, &vzero, &vinfo2};
+    size_t total = 0;
+    for (size_t b : sizes) total += (b + 255) & ~(size_t)255;
+    if ((rc = ensure_aux(h, total))) return rc;
+    size_t off = 0;
+    for (int i = 0; i < 11; ++i) {
+      *outs[i] = h->aux + off;
+      off += (sizes[i] + 255) & ~(size_t)255;
+    }
+  }
   T* Tf = static_cast<T*>(vTf);
   double* lp0 = static_cast<double*>(vlp0);
   T* mu = static_cast<T*>(vmu);
@@ -1825,7 +1823,7 @@ int logpdf_multi(blr_handle* h, int memspace, int layout, int64_t D, int64_t N, 
                        (const int32_t*)info_d, rs);
     if (p + 1 < NC) trailing(p, p + 1, NC - 1 - p);
   }
-  hipLaunchKernelGGL(multi_finish_kernel<T>, dim3((unsigned)((S + kThreads - 1) / kThreads)), dim3(kThreads), 0, h->stream,
+  hipLaunchKernelGGL(multi_finish_kernel<T>, dim3((unsigned)S), dim3(kThreads), 0, h->stream,
                      (const double*)lp0, (const double*)qpart, NP64, SP, (const T*)uu, (int)S, lp_d);
   if (mp_d) {
     for (int p = NC - 1; p >= 0; --p) {
@@ -1841,8 +1839,10 @@ int logpdf_multi(blr_handle* h, int memspace, int layout, int64_t D, int64_t N, 
     HIP_TRY(h, hipMemcpyAsync(logpdf, lp_d, (size_t)S * sizeof(double), hipMemcpyDeviceToHost, h->stream));
     if (mw_post) HIP_TRY(h, hipMemcpyAsync(mw_post, mp_d, mat_extent(D, S, ldmp) * sizeof(T), hipMemcpyDeviceToHost, h->stream));
     HIP_TRY(h, hipMemcpyAsync(info, info_d, sizeof(int32_t), hipMemcpyDeviceToHost, h->stream));
+    HIP_TRY(h, hipStreamSynchronize(h->stream));
+  } else if (!h->async) {
+    HIP_TRY(h, hipStreamSynchronize(h->stream));
   }
-  HIP_TRY(h, hipStreamSynchronize(h->stream));  // the temporaries of this call are freed on return
   return 0;
 }
 

@@ -2643,7 +2643,15 @@ __global__ __launch_bounds__(kThreads) void multi_reduce_kernel(const T* Gpart, 
   for (int e = e_begin + threadIdx.x; e < e_end; e += kThreads) {
     const int rl = e % kPB, cl = e / kPB;
     T sum = T(0);
-    for (int sp = 0; sp < nsplit; ++sp) sum += Gpart[((int64_t)sp * ntiles + t) * (kPB * kPB) + e];
+    int sp = 0;
+    for (; sp + 8 <= nsplit; sp += 8) {  // eight partials in flight, added in split order (one load and a dependent add per split
+      T v[8];                            // was a latency chain of nsplit global loads)
+#pragma unroll
+      for (int u = 0; u < 8; ++u) v[u] = Gpart[((int64_t)(sp + u) * ntiles + t) * (kPB * kPB) + e];
+#pragma unroll
+      for (int u = 0; u < 8; ++u) sum += v[u];
+    }
+    for (; sp < nsplit; ++sp) sum += Gpart[((int64_t)sp * ntiles + t) * (kPB * kPB) + e];
     Ybar[(int64_t)(J * kPB + cl) * ldy + row0 + I * kPB + rl] = sum;
   }
 }
@@ -2652,19 +2660,27 @@ __global__ __launch_bounds__(kThreads) void multi_reduce_kernel(const T* Gpart, 
 template <typename T>
 __global__ __launch_bounds__(kThreads) void multi_finish_kernel(const double* lp0, const double* qpart, int nqparts, int SP,
                                                                 const T* uu, int S, double* logpdf) {
-  __shared__ double base[2];
-  if (threadIdx.x == 0 && blockIdx.x >= 0) {
-    double q0 = 0.0;
-    for (int g = 0; g < nqparts; ++g) q0 += qpart[(int64_t)g * SP];
-    base[0] = q0;
-    base[1] = (double)uu[0];
-  }
-  __syncthreads();
-  const int sidx = blockIdx.x * kThreads + threadIdx.x;
+  // one workgroup per column s: q_s and q_0 are sums of nqparts partials each (a single thread walking them was 1024 dependent
+  // global loads: 0.75 ms of a 3 ms call) -- thread t takes the partials t, t + 256, ..., then a fixed-order tree: deterministic
+  __shared__ double red[2][kThreads];
+  const int sidx = blockIdx.x, tid = threadIdx.x;
   if (sidx >= S) return;
-  double q = 0.0;
-  for (int g = 0; g < nqparts; ++g) q += qpart[(int64_t)g * SP + sidx];
-  logpdf[sidx] = *lp0 + 0.5 * (base[0] - base[1]) - 0.5 * (q - (double)uu[sidx]);
+  double q = 0.0, q0 = 0.0;
+  for (int g = tid; g < nqparts; g += kThreads) {
+    q += qpart[(int64_t)g * SP + sidx];
+    q0 += qpart[(int64_t)g * SP];
+  }
+  red[0][tid] = q;
+  red[1][tid] = q0;
+  __syncthreads();
+  for (int m = kThreads / 2; m >= 1; m >>= 1) {
+    if (tid < m) {
+      red[0][tid] += red[0][tid + m];
+      red[1][tid] += red[1][tid + m];
+    }
+    __syncthreads();
+  }
+  if (tid == 0) logpdf[sidx] = *lp0 + 0.5 * (red[1][0] - (double)uu[0]) - 0.5 * (red[0][0] - (double)uu[sidx]);
 }
 template <typename T>
 __global__ __launch_bounds__(kThreads) void multi_means_kernel(const T* Ybar, int64_t ldy, int row0, const T* mw, int D, int S,

@@ -283,7 +283,7 @@ __global__ __launch_bounds__((MargBlockCfg<T, RT>::THREADS), (MargBlockCfg<T, RT
   using acc4 = typename Mfma<T>::acc4;
   constexpr int VEC = C::VEC, CH = C::CH, NCH = C::NCH;
   constexpr int RL = 8;                          // chunks of the factor per group (one wait per group): 128 (f32) / 64 (f64) rows
-  constexpr int NU = 8 * (16 / CH);              // 16-byte chunks of R_J behind the widest column tile of a diagonal block
+
   constexpr int BV = kPB / VEC;                  // 16-byte vectors per row of a 128-column block: 32 (f32) / 64 (f64)
   constexpr int XV = C::RT * BV / C::THREADS;    // ... per thread: 2 / 4
   // loads per wave and phase, in issue order: R factor chunks for the next product | I image vectors for the next diagonal step |
@@ -298,7 +298,18 @@ __global__ __launch_bounds__((MargBlockCfg<T, RT>::THREADS), (MargBlockCfg<T, RT
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = uni(tid >> 6);
   const int g = lane >> 4, li = lane & 15;
-  const int64_t reg = blockIdx.y;
+  // A batch: workgroups are dealt round-robin over the 8 XCDs in dispatch order (x fastest), so a regressor's workgroups would
+  // land on all eight and every L2 would hold every factor.  Renumbered so that an XCD gets whole regressors (bijective when
+  // the grid is a multiple of 8; otherwise left as dispatched).
+  int bid = blockIdx.x, breg = blockIdx.y;
+  const int nbx = gridDim.x;
+  if (gridDim.y > 1 && ((nbx * gridDim.y) & 7) == 0) {
+    const int w = blockIdx.x + blockIdx.y * nbx, per = (nbx * (int)gridDim.y) >> 3;
+    const int w2 = (w & 7) * per + (w >> 3);
+    breg = w2 / nbx;
+    bid = w2 - breg * nbx;
+  }
+  const int64_t reg = breg;
   if (a.info && a.info[reg] != 0) return;
   const int D = a.D, N = a.N, NC = a.DP / kPB, LD = C::ld(a.DP);
   const BLR_GLOBAL T* X = as_global(a.X) + reg * a.strideX;
@@ -383,21 +394,21 @@ __global__ __launch_bounds__((MargBlockCfg<T, RT>::THREADS), (MargBlockCfg<T, RT
     const int ct = (which == 1 && 7 - wave < nct) ? 7 - wave : wave;
     return U + (int64_t)(kPB * J + 16 * ct + li) * a.ldu + VEC * g;
   };
-  const int tstride = gridDim.x;
+  const int tstride = nbx;
   if (a.mean) {
     for (int e = tid; e < a.Dx; e += C::THREADS) mws[e] = mw[e];  // (visible after the first barrier of the tile loop)
     __syncthreads();
   }
   MB_T0;
   {
-    fetch_block(blockIdx.x, 0);
+    fetch_block(bid, 0);
     mb_wait<0>();
     mb_pin(xbuf);
     store_block(0);
     fetch_image(0);              // (issue order of a phase: image, then inputs)
-    fetch_block(blockIdx.x, 1);  // (D > 128: at least two blocks)
+    fetch_block(bid, 1);  // (D > 128: at least two blocks)
   }
-  for (int t = blockIdx.x; t < ntiles; t += tstride) {
+  for (int t = bid; t < ntiles; t += tstride) {
     const int n0 = t * C::RT;
     __syncthreads();  // block 0 of this tile is in place (stored at the end of the previous tile / above)
     // ---- z = L^-1 x block by block (:41-43) -------------------------------------------------------------------------------------------
