@@ -966,6 +966,39 @@ def test_large_d_marginals(B, dtype, D, N):
         B.var(B.BayesianLinearRegressor(mw, -Lw)(np.asfortranarray(X), s))
 
 
+def test_release_workspace_and_options_round_trip(B, opt):
+    # blr_release_workspace frees the handle's device scratch (D > 128 workspace, marginal images, multi-output temporaries);
+    # the next calls allocate it again and return the same bits.  blr_set_option rejects unknown keys / malformed values.
+    a = B._abi
+    h = a.default_handle()
+    rng = _rng(9400)
+    D, N = 256, 300
+    X = np.asfortranarray(rng.standard_normal((D, N)))
+    y = rng.standard_normal(N)
+    mw = rng.standard_normal(D)
+    Bm = rng.standard_normal((D, D)) / np.sqrt(D)
+    Lw = Bm @ Bm.T + np.eye(D)
+    f = B.BayesianLinearRegressor(mw, Lw)
+
+    def everything():
+        fx = f(X, 0.3)
+        fp = B.posterior(fx, y)
+        m, v = B.mean_and_var(fp(X, 0.3))
+        lps = B.logpdf(fx, np.asfortranarray(np.stack([y, 2 * y], axis=1)))
+        return B.logpdf(fx, y), fp.mw.copy(), m, v, np.asarray(lps)
+
+    first = everything()
+    h.release_workspace()
+    h.release_workspace()  # (nothing left to free: still fine)
+    again = everything()
+    for u, v in zip(first, again):
+        np.testing.assert_array_equal(np.asarray(u), np.asarray(v))
+    for key, value in (("NO_SUCH_SWITCH", "1"), ("WAVE_SPLIT", "3"), ("SWEEP", "sometimes"), ("GRAM_SPLITS", "7")):
+        with pytest.raises(Exception):
+            h.set_option(key, value)
+    opt("WAVE_SPLIT", "2")  # a well-formed one round-trips (restored by the fixture)
+
+
 @pytest.mark.parametrize("dtype,D,N,Bn,kind", [(np.float64, 256, 200, 5, "factor"), (np.float32, 400, 333, 3, "dense"), (np.float64, 272, 70, 4, "dense"),
                                                 (np.float32, 1024, 100, 9, "factor")])
 def test_large_d_marginals_batched_share_the_launches(B, dtype, D, N, Bn, kind):
