@@ -422,21 +422,36 @@ def secondary_ops(torch, _abi, h, dev):
                   "updates/s", flops, nbytes, dt, "rank1_sweep_kernel" if k <= 1 else "fused_small_kernel (factor prior, in place)", check,
                   keep=(Tm, T0, X, y, s, mw, lp, info))
 
-    def post(name, b, d, n, dt, noise, din=None, steps=20, **kw):
+    def post(name, b, d, n, dt, noise, din=None, steps=20, option=None, **kw):
         def build():
             w2 = Workload(torch, a, h, dev, name, b, d, n, dt, noise, 123456 + 7, din, **kw)
+            launch, kern = w2.launch, w2.kernel_name()
+            if option:  # the same workload with a run-time switch of the handle set for the duration of each call (A/B entry)
+
+                def launch():
+                    h.set_option(option, "1")
+                    try:
+                        w2.launch()
+                    finally:
+                        h.set_option(option, None)
+
+                if option == "NO_I8_GRAM":
+                    kern = "fused_small_kernel<double, 8, 4>"
 
             def check():
                 assert int(w2.info.abs().sum().item()) == 0 and bool(torch.isfinite(w2.lp).all().item())
 
             r = w2.roofline(1.0)
-            tag = (", prior mean ~ N(0, I)" if kw.get("mw_random") else "") + (", logpdf only (no mw', no T)" if kw.get("logpdf_only") else "")
+            tag = (", prior mean ~ N(0, I)" if kw.get("mw_random") else "") + (", logpdf only (no mw', no T)" if kw.get("logpdf_only") else "") \
+                + (f", handle option {option}" if option else "")
             return Op(f"B={b}, D={d}, N={n}, {dt}, {noise} noise" + (f", D_in={din} random-Fourier features" if din else "") + tag,
-                      w2.launch, b, "updates/s", r["algorithmic_flops"], r["algorithmic_bytes"], dt, w2.kernel_name(), check, steps=steps, keep=(w2,))
+                      launch, b, "updates/s", r["algorithmic_flops"], r["algorithmic_bytes"], dt, kern, check, steps=steps, keep=(w2,))
         return build
 
     ops = {
         "c2_f32": post("c2_f32", 4096, 128, 4096, "f32", "isotropic"),
+        # the driver line's workload on the fp64 matrix pipe (fused_small_kernel) instead of the int8-sliced Gram: same box, same data
+        "c2_f64_fp64_kernel": post("c2", 4096, 128, 4096, "f64", "isotropic", option="NO_I8_GRAM"),
         "c2_f64_mw": post("c2_f64_mw", 4096, 128, 4096, "f64", "isotropic", mw_random=True),
         "c2_f64_diag_noise": post("c2_f64_diag", 4096, 128, 4096, "f64", "diagonal"),
         "c4_f64": post("c4_f64", 8192, 64, 1024, "f64", "isotropic"),
