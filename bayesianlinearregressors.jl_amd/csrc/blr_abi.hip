@@ -1221,8 +1221,10 @@ int marginals_batched(blr_handle* h, int memspace, int layout, int64_t B, int64_
       // (the kernels index regressor reg0 + blockIdx; the images of a chunk start at its first regressor)
       hipLaunchKernelGGL(marg_image_kernel<T>, dim3((unsigned)nb, 2), dim3(kThreads), TC::LDS_BYTES, h->stream, a.U, a.ldu, a.strideU, (int)D,
                          img - b0 * G::IMG_ELEMS, a.info, (int)b0);
-      // two workgroups per CU; every workgroup copies the 74 KB image once: give it at least four tiles per wave
-      const int64_t per_reg = std::max<int64_t>(1, std::min<int64_t>((ntiles + 15) / 16, (2 * (int64_t)h->cus * 2 + nb - 1) / nb));
+      // two workgroups per CU, ONE round of them (tools/marg128_bench, 64 x 4096 inputs, stream kernel alone: 8 workgroups per
+      // regressor 104.8 us, 16 -- two rounds -- 116.3, 32: 126.9; 256 regressors: 2 per regressor); every workgroup copies the
+      // 74 KB image once: at least four tiles per wave
+      const int64_t per_reg = std::max<int64_t>(1, std::min<int64_t>((ntiles + 15) / 16, (2 * (int64_t)h->cus + nb - 1) / nb));
       a.reg0 = (int)b0;
       hipLaunchKernelGGL(marginals_gemm_kernel<T>, dim3((unsigned)per_reg, (unsigned)nb), dim3(kThreads), G::LDS_BYTES, h->stream, a,
                          (const T*)(img - b0 * G::IMG_ELEMS));

@@ -1123,15 +1123,19 @@ __device__ __forceinline__ void trsm_prepare(const T* __restrict__ P, const T* _
   using Cfg = TrsmCfg<T>;
   constexpr int LI = Cfg::LDI;
   if (tid < 16 * nchunks) {
+    // column j of inv(L_JJ) by forward substitution, COLUMN-oriented: once x_k is known every pending row takes its update at
+    // once (independent multiply-adds) -- the row-oriented form summed k < i terms one after the other for each i: a chain of
+    // 136 dependent operations instead of 32
     const int j = tid & 15, j0 = 16 * (tid >> 4);
-    T x[16];
+    T sacc[16];
 #pragma unroll
-    for (int i = 0; i < 16; ++i) {
-      T sacc = (i == j) ? T(1) : T(0);
+    for (int i = 0; i < 16; ++i) sacc[i] = (i == j) ? T(1) : T(0);
 #pragma unroll
-      for (int k = 0; k < i; ++k) sacc -= P[pidx(j0, j0) + i * j0 + (i * (i + 1)) / 2 + k] * x[k];
-      x[i] = sacc * dinv[j0 + i];
-      Linv[(j0 + i) * LI + j] = x[i];
+    for (int k = 0; k < 16; ++k) {
+      const T xk = sacc[k] * dinv[j0 + k];
+      Linv[(j0 + k) * LI + j] = xk;
+#pragma unroll
+      for (int i = k + 1; i < 16; ++i) sacc[i] -= P[pidx(j0, j0) + i * j0 + (i * (i + 1)) / 2 + k] * xk;
     }
   }
   __syncthreads();

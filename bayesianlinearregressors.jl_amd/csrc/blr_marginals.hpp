@@ -128,13 +128,20 @@ __global__ __launch_bounds__(kThreads, 2) void marginals_gemm_kernel(MarginalArg
   const int g = lane >> 4, li = lane & 15;
   // this lane's slice of a tile: input n0 + li, entries d = 4 VEC m' + VEC g .. + VEC of it, m' = 0 .. NL - 1
   vecT av[NL], an[NL];
-  auto fetch = [&](int tile, vecT (&dst)[NL]) {
+  // the noise variances of the inputs whose var this lane stores travel with the tile's loads (one value per call when the noise
+  // is isotropic): loaded at the store they were a global-memory round trip at the END of every tile, with nothing left to hide it
+  const bool diag_noise = a.noise_kind == NOISE_DIAGONAL;
+  const T s_iso = diag_noise ? T(0) : s[0];
+  T sv[4], sn[4];
+  auto fetch = [&](int tile, vecT (&dst)[NL], T (&sd)[4]) {
     const int n = min(tile * 16 + li, N - 1);  // (inputs past the end re-read the last one; never stored)
     const BLR_GLOBAL vecT* p = reinterpret_cast<const BLR_GLOBAL vecT*>(X + (int64_t)n * a.ldx + VEC * g);
 #pragma unroll
     for (int u = 0; u < NL; ++u) dst[u] = p[4 * u];  // (4 VEC elements = 4 vectors apart)
+#pragma unroll
+    for (int v = 0; v < 4; ++v) sd[v] = (diag_noise && a.var) ? s[min(tile * 16 + Mfma<T>::crow(lane, v), N - 1)] : s_iso;
   };
-  if (t0 < ntiles) fetch(t0, av);
+  if (t0 < ntiles) fetch(t0, av, sv);
   // the image and the prior mean: once per workgroup
   {
     const BLR_GLOBAL vecT* src = reinterpret_cast<const BLR_GLOBAL vecT*>(as_global(img_all + (int64_t)reg * G::IMG_ELEMS));
@@ -145,7 +152,7 @@ __global__ __launch_bounds__(kThreads, 2) void marginals_gemm_kernel(MarginalArg
   __syncthreads();
   for (int tile = t0; tile < ntiles; tile += tstep) {
     const bool more = tile + tstep < ntiles;
-    if (more) fetch(tile + tstep, an);  // in flight during this tile's 144 MFMAs
+    if (more) fetch(tile + tstep, an, sn);  // in flight during this tile's 144 MFMAs
     // mean_n = x_n'mw (:33): this lane's 4 VEC NL / ... entries, then over the four lane groups of an input
     T macc = T(0);
     if (a.mean) {
@@ -177,12 +184,14 @@ __global__ __launch_bounds__(kThreads, 2) void marginals_gemm_kernel(MarginalArg
 #pragma unroll
       for (int v = 0; v < 4; ++v) {
         const int n = n0 + Mfma<T>::crow(lane, v);
-        if (n < N) a.var[(int64_t)reg * a.stridevar + n] = sq[v] + ((a.noise_kind == NOISE_DIAGONAL) ? s[n] : s[0]);
+        if (n < N) a.var[(int64_t)reg * a.stridevar + n] = sq[v] + sv[v];
       }
     }
     if (more) {
 #pragma unroll
       for (int u = 0; u < NL; ++u) av[u] = an[u];
+#pragma unroll
+      for (int v = 0; v < 4; ++v) sv[v] = sn[v];
     }
   }
 }
