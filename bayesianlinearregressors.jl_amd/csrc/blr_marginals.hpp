@@ -59,6 +59,13 @@ __global__ __launch_bounds__(kThreads) void marg_image_kernel(const T* __restric
   }
   img += (int64_t)reg * G::IMG_ELEMS;
   const int nchunks = kPB / 16;
+#ifdef BLR_IMG_STAMPS
+  unsigned long long ist[6]; int isn = 0;
+#define IMG_T() do { ist[isn++] = __builtin_amdgcn_s_memtime(); } while (0)
+#else
+#define IMG_T() do {} while (0)
+#endif
+  IMG_T();
   const bool uvec = D == kPB && (ldu % VEC) == 0 && ((uintptr_t)U % 16) == 0;
   if (uvec) load_upper_block_to_packed(P, U, ldu, tid);
 #pragma unroll 1
@@ -79,9 +86,12 @@ __global__ __launch_bounds__(kThreads) void marg_image_kernel(const T* __restric
     }
   }
   __syncthreads();
+  IMG_T();
   if (tid < kPB) dinv[tid] = T(1) / P[pidx(tid, tid)];
   __syncthreads();
+  IMG_T();
   trsm_prepare<T>(P, dinv, Linv, nchunks, tid);
+  IMG_T();
   {
     const int half = blockIdx.y;
     __syncthreads();
@@ -91,17 +101,26 @@ __global__ __launch_bounds__(kThreads) void marg_image_kernel(const T* __restric
     }
     __syncthreads();
     trsm_sweep<T>(Xs, P, Linv, nchunks, lane, wave);  // rows 64 half .. + 63 of L^-T (ends with a barrier)
-    // image entries whose contraction index d falls into this half
-    for (int e = tid; e < G::IMG_ELEMS; e += kThreads) {
-      const int f = e >> 6, l = e & 63;
-      int J = 0;
-      while (G::frag0(J + 1) <= f) ++J;
-      const int m = f - G::frag0(J);
-      const int d = G::d_of(m, l >> 4);
-      // (diagonal blocks of a large factor: the VEC fragments one 16-byte load of the inputs feeds sit next to each other per lane)
-      const int at = Dtotal ? ((f / VEC) * 64 + l) * VEC + (f % VEC) : e;
-      if ((d >> 6) == half) img[at] = Xs[(d & 63) * Cfg::LDX + 16 * J + (l & 15)];
+    IMG_T();
+    // image entries whose contraction index d falls into this half: fragment m of column block J to wave m % 4 (a flat loop over
+    // the 9216 entries with a search for J per entry was half of this kernel's time)
+    const int g4 = lane >> 4;
+#pragma unroll 1
+    for (int J = 0; J < 8; ++J) {
+      for (int m = wave; m < 4 * (J + 1); m += kWaves) {
+        const int f = G::frag0(J) + m;
+        const int d = G::d_of(m, g4);
+        // (diagonal blocks of a large factor: the VEC fragments one 16-byte load of the inputs feeds sit next to each other per lane)
+        const int at = Dtotal ? ((f / VEC) * 64 + lane) * VEC + (f % VEC) : f * 64 + lane;
+        if ((d >> 6) == half) img[at] = Xs[(d & 63) * Cfg::LDX + 16 * J + (lane & 15)];
+      }
     }
+    IMG_T();
+#ifdef BLR_IMG_STAMPS
+    if (blockIdx.x == 0 && blockIdx.y == 0 && tid == 0)
+      printf("image kernel, cycles: load %llu | 1/diag %llu | 16x16 inverses %llu | identity + sweep %llu | image out %llu\n", ist[1] - ist[0],
+             ist[2] - ist[1], ist[3] - ist[2], ist[4] - ist[3], ist[5] - ist[4]);
+#endif
   }
 }
 
