@@ -162,15 +162,17 @@ __global__ __launch_bounds__(kThreads, 2) void rand_project_mfma_kernel(const T*
   for (int i = 0; i < 2; ++i)
 #pragma unroll
     for (int k = 0; k < 4; ++k) acc[i][k] = acc4{T(0), T(0), T(0), T(0)};
-  vecT pa[Cf::VA], pb[Cf::VB];
-  auto prefetch = [&](int d0) {
+  // TWO chunks in flight per workgroup (register sets 0 / 1): 512 workgroups of 128 inputs are two per CU, and one 24 KB chunk each
+  // kept 48 KB per CU in flight -- 2 TB/s of a stream that has nothing else to wait for
+  vecT pa[2][Cf::VA], pb[2][Cf::VB];
+  auto prefetch = [&](int d0, vecT (&qa)[Cf::VA], vecT (&qb)[Cf::VB]) {
 #pragma unroll
     for (int u = 0; u < Cf::VA; ++u) {
       const int vi = u * kThreads + tid, dv = vi % VPR, nl = vi / VPR;
       const int d = d0 + dv * VEC, n = n0 + nl;
       const bool ok = d < D && n < N;  // D is a multiple of VEC on this path: a vector is inside or outside as a whole
       const vecT v = *reinterpret_cast<const vecT*>(X + (ok ? (int64_t)n * ldx + d : 0));
-      pa[u] = ok ? v : vecT(T(0));
+      qa[u] = ok ? v : vecT(T(0));
     }
 #pragma unroll
     for (int u = 0; u < Cf::VB; ++u) {
@@ -179,11 +181,13 @@ __global__ __launch_bounds__(kThreads, 2) void rand_project_mfma_kernel(const T*
       const int64_t sidx = s0 + sl;
       const bool ok = d < D && sidx < S;
       const vecT v = *reinterpret_cast<const vecT*>(W + (ok ? sidx * ldw + d : 0));
-      pb[u] = ok ? v : vecT(T(0));
+      qb[u] = ok ? v : vecT(T(0));
     }
   };
-  // fragment image [k-step][16-row block][lane = (k & 3) * 16 + row % 16]
-  auto store = [&](T* slot) {
+  // fragment image [k-step][16-row block][lane = (k & 3) * 16 + row % 16], the 64 words of k-step j rotated by 4 j: a thread holds
+  // VEC consecutive k of ONE row, and the eight threads that share a row (one per k-step of the chunk) would all store to the
+  // same bank (k-steps are 512 words apart): 8-way conflicts on every ds_write_b32; rotated, a group of 32 lanes covers 32 banks
+  auto store = [&](T* slot, const vecT (&qa)[Cf::VA], const vecT (&qb)[Cf::VB]) {
     T* const A = slot;
     T* const Bm = slot + Cf::SIDE_A;
 #pragma unroll
@@ -192,7 +196,7 @@ __global__ __launch_bounds__(kThreads, 2) void rand_project_mfma_kernel(const T*
 #pragma unroll
       for (int e = 0; e < VEC; ++e) {
         const int k = dv * VEC + e;
-        A[(((k >> 2) * (Cf::TN / 16) + (nl >> 4)) << 6) + ((k & 3) << 4) + (nl & 15)] = pa[u][e];
+        A[(((k >> 2) * (Cf::TN / 16) + (nl >> 4)) << 6) + ((((k & 3) << 4) + (nl & 15) + 4 * (k >> 2)) & 63)] = qa[u][e];
       }
     }
 #pragma unroll
@@ -201,30 +205,42 @@ __global__ __launch_bounds__(kThreads, 2) void rand_project_mfma_kernel(const T*
 #pragma unroll
       for (int e = 0; e < VEC; ++e) {
         const int k = dv * VEC + e;
-        Bm[(((k >> 2) * (Cf::TS / 16) + (sl >> 4)) << 6) + ((k & 3) << 4) + (sl & 15)] = pb[u][e];
+        Bm[(((k >> 2) * (Cf::TS / 16) + (sl >> 4)) << 6) + ((((k & 3) << 4) + (sl & 15) + 4 * (k >> 2)) & 63)] = qb[u][e];
       }
     }
   };
-  const int nchunks = (D + Cf::KC - 1) / Cf::KC;
-  prefetch(0);
-  store(base);
-  __syncthreads();
-  for (int c = 0; c < nchunks; ++c) {
-    const T* slot = base + (c & 1) * (Cf::SIDE_A + Cf::SIDE_B);
-    if (c + 1 < nchunks) prefetch((c + 1) * Cf::KC);
+  auto multiply = [&](const T* slot) {
 #pragma unroll
     for (int j = 0; j < Cf::KST; ++j) {
       T fa[2], fb[4];
+      const int rl = (lane + 4 * j) & 63;  // (the image of k-step j is rotated by 4 j lanes, above)
 #pragma unroll
-      for (int i = 0; i < 2; ++i) fa[i] = slot[((j * (Cf::TN / 16) + 2 * wave + i) << 6) + lane];
+      for (int i = 0; i < 2; ++i) fa[i] = slot[((j * (Cf::TN / 16) + 2 * wave + i) << 6) + rl];
 #pragma unroll
-      for (int k = 0; k < 4; ++k) fb[k] = slot[Cf::SIDE_A + ((j * (Cf::TS / 16) + k) << 6) + lane];
+      for (int k = 0; k < 4; ++k) fb[k] = slot[Cf::SIDE_A + ((j * (Cf::TS / 16) + k) << 6) + rl];
 #pragma unroll
       for (int i = 0; i < 2; ++i)
 #pragma unroll
         for (int k = 0; k < 4; ++k) acc[i][k] = Mfma<T>::mma(fa[i], fb[k], acc[i][k]);
     }
-    if (c + 1 < nchunks) store(base + ((c + 1) & 1) * (Cf::SIDE_A + Cf::SIDE_B));
+  };
+  const int nchunks = (D + Cf::KC - 1) / Cf::KC;
+  T* const slot0 = base;
+  T* const slot1 = base + (Cf::SIDE_A + Cf::SIDE_B);
+  prefetch(0, pa[0], pb[0]);
+  store(slot0, pa[0], pb[0]);
+  if (nchunks > 1) prefetch(Cf::KC, pa[1], pb[1]);
+  __syncthreads();
+  // chunk c sits in slot c & 1, chunk c + 1 is in flight in register set (c + 1) & 1; set c & 1 is free for chunk c + 2
+  for (int c = 0; c < nchunks; c += 2) {
+    if (c + 2 < nchunks) prefetch((c + 2) * Cf::KC, pa[0], pb[0]);
+    multiply(slot0);
+    if (c + 1 < nchunks) store(slot1, pa[1], pb[1]);
+    __syncthreads();
+    if (c + 1 >= nchunks) break;
+    if (c + 3 < nchunks) prefetch((c + 3) * Cf::KC, pa[1], pb[1]);
+    multiply(slot1);
+    if (c + 2 < nchunks) store(slot0, pa[0], pb[0]);
     __syncthreads();
   }
   // Y[n, s] = acc + sqrt(s_n) z2[n, s]: lane (column = draw, 4 rows = inputs)
