@@ -38,8 +38,8 @@
 //   * after the stream: accumulators -> fp64 -> packed triangle of A in LDS; waves 4-7 exit; waves 0-3 run the phases of
 //     fused_small_kernel (blocked Cholesky, substitutions, evidence) unchanged;
 //   * a prior mean mw != 0 (reference :57, :82: delta = y - X'mw) never touches the stream: G is exact, so
-//     b = X delta / s = X y / s - (A - Lw) mw and delta'delta / s = y'y / s - 2 mw'X y / s + mw'(A - Lw) mw are formed from the
-//     finished A (one 128 x 128 symmetric matrix-vector product in LDS).
+//     b = X delta / s = X y / s - (G / s) mw and delta'delta / s = y'y / s - 2 mw'X y / s + mw'(G / s) mw are formed from the
+//     finished matrix (one 128 x 128 symmetric matrix-vector product in LDS; diag(G) / s is kept next to A = Lw + G / s).
 // (Measured alternatives, tools/i8_gram.hip: four waves with the whole register file each -- no register pressure, but one wave
 // per SIMD cannot keep the matrix pipe fed next to the slicing and the DMA issue: 4000 cycles per k-step against 3000; the
 // factorisations as a second launch with two workgroups per CU: 4.9 ms per 4096 updates against 4.7, the stream-only kernel
@@ -92,8 +92,9 @@ struct I8Cfg {
   static constexpr int OFF_VTAB = OFF_DIG;                      // offset-term tables TA, TB, TC: 3 x 128 doubles
   static constexpr int OFF_SC = OFF_VTAB + 3 * 128 * 8;         // 2^(e_i - 47): 128 doubles
   static constexpr int OFF_BRED = OFF_SC + 128 * 8;             // b partials: 4 x 128 doubles
+  static constexpr int OFF_GD = OFF_BRED + 4 * 128 * 8;         // diag(G) / sigma^2 WITHOUT the prior (prior-mean terms): 128 doubles
   static_assert(SmallCfg<double, 8>::LDS_BYTES <= RING_BYTES, "the phase functions' LDS image must fit in the dead ring");
-  static_assert(OFF_BRED + 4 * 128 * 8 <= OFF_YB, "conversion tables must fit in the digit area");
+  static_assert(OFF_GD + 128 * 8 <= OFF_YB, "conversion tables must fit in the digit area");
   static_assert(LDS_BYTES <= 160 * 1024, "LDS of one CU");
 };
 
@@ -487,6 +488,7 @@ __global__ __launch_bounds__(kI8Threads, 2) void fused_i8_kernel(PosteriorArgs<d
   double* const tabC = tabA + 256;
   double* const sctab = reinterpret_cast<double*>(smem + C::OFF_SC);
   double* const bred = reinterpret_cast<double*>(smem + C::OFF_BRED);
+  double* const gdiag = reinterpret_cast<double*>(smem + C::OFF_GD);
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = uni(tid >> 6);
   const int reg = blockIdx.x;
@@ -499,8 +501,9 @@ __global__ __launch_bounds__(kI8Threads, 2) void fused_i8_kernel(PosteriorArgs<d
   const BLR_GLOBAL T* Lw = as_global(a.Lw + (int64_t)reg * a.strideLw);
   const T s_iso = as_global(a.s + (int64_t)reg * a.strides)[0];
 
-  // A prior mean costs the stream nothing: with G = X X' exact, b = X (y - X'mw) / s = X y / s - (A - Lw) mw and
-  // delta'delta / s = y'y / s - 2 mw'X y / s + mw'(A - Lw) mw come out of the finished A after the hand-over (below).
+  // A prior mean costs the stream nothing: with G = X X' exact, b = X (y - X'mw) / s = X y / s - (G / s) mw and
+  // delta'delta / s = y'y / s - 2 mw'X y / s + mw'(G / s) mw come out of the finished matrix after the hand-over (below; G / s is
+  // A off the diagonal and kept next to it on the diagonal: A_ii - Lw_i would lose the data term under a strong prior).
   int ok = 1;
   const int has_mw = __syncthreads_or(tid < D && mw[tid] != T(0));
   if (tid == 0) flag[0] = 1;
@@ -579,6 +582,10 @@ __global__ __launch_bounds__(kI8Threads, 2) void fused_i8_kernel(PosteriorArgs<d
         if (i >= j) {
           if constexpr (it.phase != 0) P[pidx(i, j)] += g;
           else P[pidx(i, j)] = g + ((i == j) ? Lw[i] : T(0));
+          if (i == j) {  // (the data term alone: A_ii - Lw_i would lose it under a strong prior)
+            if constexpr (it.phase != 0) gdiag[i] += g;
+            else gdiag[i] = g;
+          }
         }
         __builtin_amdgcn_sched_barrier(0);  // one entry at a time
       }
@@ -630,8 +637,11 @@ __global__ __launch_bounds__(kI8Threads, 2) void fused_i8_kernel(PosteriorArgs<d
       mi = (double)mwl[tid];
       double am = 0.0;
 #pragma unroll 4
-      for (int j = 0; j < D; ++j) am += (double)((j <= tid) ? P[pidx(tid, j)] : P[pidx(j, tid)]) * (double)mwl[j];
-      gm = am - (double)Lw[tid] * mi;  // ((A - Lw) mw)_i = (G mw)_i / s
+      for (int j = 0; j < D; ++j) {
+        const double aij = (j < tid) ? P[pidx(tid, j)] : ((j > tid) ? P[pidx(j, tid)] : gdiag[tid]);  // off the diagonal A = G / s
+        am += aij * (double)mwl[j];
+      }
+      gm = am;  // (G mw)_i / s
     }
     const double s1 = block_allreduce(mi * bsum, scr, tid);
     const double s2 = block_allreduce(mi * gm, scr, tid);

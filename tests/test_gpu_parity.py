@@ -2221,6 +2221,41 @@ def test_i8_gram_path_vs_oracle_and_fp64_kernel(B, opt, kind, N, prior_mean):
             np.testing.assert_array_equal(fast[1][b], slow[1][b])
 
 
+def test_i8_gram_prior_mean_under_a_strong_prior(B, opt):
+    # A prior mean enters the int8 route through the finished matrix: b = X y / s - (G / s) mw.  G / s must be the data term itself,
+    # not A - Lw: with prior precisions up to 2^40 times the data term (rows scaled by 2^-20) the difference keeps no digit of G
+    # (found by tools/fuzz_round4.py: evidence off by a factor 150).  Both device routes against the oracle and against each other.
+    a = B._abi
+    h = a.default_handle()
+    rng = _rng(4400)
+    nb, D, N = 4, 128, 1024
+    scale = np.ldexp(1.0, rng.integers(-20, 21, size=D))
+    X = rng.standard_normal((nb, N, D)) * scale[None, None, :]
+    w = rng.standard_normal((nb, D)) / scale[None, :]
+    y = np.einsum("bnd,bd->bn", X, w) + np.sqrt(0.1) * rng.standard_normal((nb, N))
+    mw = rng.standard_normal((nb, D)) / scale[None, :]
+    dpr = np.exp(0.3 * rng.standard_normal((nb, D))) / scale[None, :] ** 2
+    s = np.array([0.1])
+
+    def run():
+        mp = np.zeros((nb, D)); lp = np.zeros(nb); info = np.full(nb, 9, dtype=np.int32)
+        h.posterior_batched(np.float64, a.MEM_HOST, a.LAYOUT_COLVECS, nb, D, N, X, D, N * D, y, N, a.NOISE_ISOTROPIC, s, 0, a.PRIOR_DIAGONAL,
+                            mw, D, dpr, 1, D, mp, D, None, D, D * D, None, D, D * D, lp, info)
+        return mp, lp, info
+
+    fast = run()
+    opt("NO_I8_GRAM", "1")
+    slow = run()
+    assert fast[2].tolist() == [0] * nb and slow[2].tolist() == [0] * nb
+    for b in range(nb):
+        mw_o, _, A_o, lp_o = O.posterior_logpdf_direct(mw[b], dpr[b], X[b].T, 0.1, y[b])
+        dA = np.sqrt(np.diag(A_o))
+        for mp, lp, _ in (fast, slow):
+            assert lp[b] == pytest.approx(lp_o, rel=1e-10)
+            np.testing.assert_allclose(mp[b] * dA, mw_o * dA, rtol=1e-7, atol=1e-8 * np.abs(mw_o * dA).max())
+        assert fast[1][b] == pytest.approx(slow[1][b], rel=1e-10)
+
+
 def test_i8_gram_path_hands_back_what_it_cannot_do(B, opt):
     # NaN / Inf in X, a bad noise variance, a non-positive prior entry: status, NaN evidence and untouched outputs exactly as the
     # fp64 kernel reports them (the fast path either reproduces the status or hands the regressor back); a prior mean stays on

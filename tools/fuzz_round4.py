@@ -1,0 +1,91 @@
+"""Randomised parity sweep of the kernels added in round 4, through the C ABI against the oracle:
+  marg   marginals at D > 128 (block substitution on LDS tiles, both tile heights, batches, factor / dense priors, padded ldx) and D = 128
+  i8     the int8-sliced Gram route at D = 128 (N a multiple of 32 in 512 .. 16384, prior mean on / off, rows of different scale)
+Not part of the test suite (minutes of GPU time): python tools/fuzz_round4.py [marg|i8] [cases] [seed]"""
+import os, sys
+import numpy as np
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import blr_amd as B
+from blr_amd import _abi
+from oracle import blr_oracle as O
+
+
+def marg(rng, case):
+    dtype = np.float32 if rng.random() < 0.5 else np.float64
+    Ds = [128, 144, 160, 256, 272, 400, 512, 576] + ([1024, 1040, 1152] if dtype == np.float32 else [130, 300])
+    D = int(rng.choice(Ds))
+    N = int(rng.choice([1, 2, 15, 16, 17, 31, 32, 33, 63, 64, 65, 100, 255, 256, 257, 1000, 3000, 9000]))
+    Bn = int(rng.choice([1, 1, 2, 3, 5]))
+    if D >= 1024 and N > 1000:
+        Bn = 1
+    kind = rng.choice(["factor", "dense"])
+    diag = rng.random() < 0.5
+    pad = int(rng.choice([0, 0, 4, 8, 16]))
+    want_mean = rng.random() < 0.8
+    ldx = D + pad
+    X = np.zeros((Bn, N, ldx), dtype=dtype)
+    X[:, :, :D] = rng.standard_normal((Bn, N, D))
+    mw = rng.standard_normal((Bn, D)).astype(dtype)
+    Lw = np.empty((Bn, D, D)); arg = np.empty((Bn, D, D), dtype=dtype)
+    for b in range(Bn):
+        Bm = rng.standard_normal((D, D)) / np.sqrt(D)
+        Lw[b] = (Bm @ Bm.T + np.eye(D)).astype(dtype)
+        arg[b] = (O.chol_upper(Lw[b]).astype(dtype) if kind == "factor" else Lw[b].astype(dtype)).T
+    s = np.exp(0.3 * rng.standard_normal((Bn, N))).astype(dtype) if diag else np.full((Bn, 1), 0.4, dtype=dtype)
+    mean = np.full((Bn, N), -7.0, dtype=dtype); var = np.full((Bn, N), -7.0, dtype=dtype); info = np.full(Bn, 9, dtype=np.int32)
+    h = _abi.default_handle()
+    h.marginals_batched(dtype, _abi.MEM_HOST, _abi.LAYOUT_COLVECS, Bn, D, N, X, ldx, N * ldx, _abi.NOISE_DIAGONAL if diag else _abi.NOISE_ISOTROPIC, s,
+                        N if diag else 1, _abi.PRIOR_UPPER_FACTOR if kind == "factor" else _abi.PRIOR_DENSE, mw, D, arg, D, D * D,
+                        mean if want_mean else None, N, var, N, info)
+    rt = 1e-9 if dtype == np.float64 else 5e-4
+    assert np.all(info == 0), (case, info)
+    for b in range(Bn):
+        Xb = X[b, :, :D].T.astype(float)
+        sb = s[b].astype(float) if diag else float(s[b, 0])
+        v_o = O.var(mw[b].astype(float), Lw[b].astype(dtype).astype(float), Xb, sb)
+        np.testing.assert_allclose(var[b], v_o, rtol=rt, err_msg=f"case {case}: var D={D} N={N} B={Bn} {kind} {dtype.__name__}")
+        if want_mean:
+            m_o = O.mean(mw[b].astype(float), Xb)
+            np.testing.assert_allclose(mean[b], m_o, rtol=rt, atol=rt * 30, err_msg=f"case {case}: mean D={D} N={N}")
+    return f"D={D} N={N} B={Bn} {kind} {'diag' if diag else 'iso'} {dtype.__name__} ldx=D+{pad}"
+
+
+def i8(rng, case):
+    D = 128
+    N = 32 * int(rng.integers(16, 513)) if rng.random() < 0.3 else int(rng.choice([512, 544, 1024, 4096, 16384]))
+    nb = int(rng.choice([1, 3, 8]))
+    X = rng.standard_normal((nb, N, D))
+    scale = np.ldexp(1.0, rng.integers(-20, 21, size=D)) if rng.random() < 0.5 else np.ones(D)
+    X *= scale[None, None, :]
+    w = rng.standard_normal((nb, D)) / scale[None, :]
+    y = np.einsum("bnd,bd->bn", X, w) + np.sqrt(0.1) * rng.standard_normal((nb, N))
+    if rng.random() < 0.2:
+        X[0, N // 3, 7] *= 1e4  # breaks its row's bound: that regressor goes back to the fp64 kernel
+    mw = rng.standard_normal((nb, D)) / scale[None, :] if rng.random() < 0.6 else np.zeros((nb, D))
+    dpr = np.exp(0.3 * rng.standard_normal((nb, D))) / scale[None, :] ** 2
+    s = np.array([0.1])
+    mp = np.zeros((nb, D)); Tp = np.zeros((nb, D, D)); Ap = np.zeros((nb, D, D)); lp = np.zeros(nb); info = np.full(nb, 9, dtype=np.int32)
+    h = _abi.default_handle()
+    h.posterior_batched(np.float64, _abi.MEM_HOST, _abi.LAYOUT_COLVECS, nb, D, N, X, D, N * D, y, N, _abi.NOISE_ISOTROPIC, s, 0, _abi.PRIOR_DIAGONAL,
+                        mw, D, dpr, 1, D, mp, D, Tp, D, D * D, Ap, D, D * D, lp, info)
+    assert np.all(info == 0), (case, info)
+    for b in range(nb):
+        mw_o, T_o, A_o, lp_o = O.posterior_logpdf_direct(mw[b], dpr[b], X[b].T, 0.1, y[b])
+        dA = np.sqrt(np.diag(A_o))
+        # (the evidence is a difference of terms of size y'y / s: an injected outlier makes them 1e6 times the evidence itself)
+        assert abs(lp[b] - lp_o) <= 2e-10 * abs(lp_o) + 1e-12 * float(y[b] @ y[b]) / 0.1 * max(1.0, float(np.abs(X[b]).max() / np.abs(X[b]).mean()) ** 2 / 1e4), (case, b, lp[b], lp_o)
+        assert (np.abs(Ap[b] - A_o) / np.outer(dA, dA)).max() <= 1e-12, case
+        np.testing.assert_allclose(mp[b] * dA, mw_o * dA, rtol=1e-7, atol=1e-8 * np.abs(mw_o * dA).max(), err_msg=f"case {case}")
+    return f"N={N} B={nb} mw={'yes' if np.any(mw) else 'no'} scaled={'yes' if np.any(scale != 1) else 'no'}"
+
+
+if __name__ == "__main__":
+    which = sys.argv[1] if len(sys.argv) > 1 else "marg"
+    cases = int(sys.argv[2]) if len(sys.argv) > 2 else 100
+    rng = np.random.default_rng(int(sys.argv[3]) if len(sys.argv) > 3 else 2027)
+    fn = marg if which == "marg" else i8
+    for c in range(cases):
+        d = fn(rng, c)
+        if c % 10 == 0:
+            print(f"case {c}: {d} ok", flush=True)
+    print(f"{cases} {which} cases ok")
