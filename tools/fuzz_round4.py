@@ -1,7 +1,9 @@
 """Randomised parity sweep of the kernels added in round 4, through the C ABI against the oracle:
   marg   marginals at D > 128 (block substitution on LDS tiles, both tile heights, batches, factor / dense priors, padded ldx) and D = 128
   i8     the int8-sliced Gram route at D = 128 (N a multiple of 32 in 512 .. 16384, prior mean on / off, rows of different scale)
-Not part of the test suite (minutes of GPU time): python tools/fuzz_round4.py [marg|i8] [cases] [seed]"""
+  multi  logpdf(fx, Y::Matrix) (temporaries from the side buffer, parallel reductions)
+  rand   rand(rng, fx, S) with given normals (rotated fragment images of the MFMA projection)
+Not part of the test suite (minutes of GPU time): python tools/fuzz_round4.py [marg|i8|multi|rand] [cases] [seed]"""
 import os, sys
 import numpy as np
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
@@ -79,11 +81,61 @@ def i8(rng, case):
     return f"N={N} B={nb} mw={'yes' if np.any(mw) else 'no'} scaled={'yes' if np.any(scale != 1) else 'no'}"
 
 
+def multi(rng, case):
+    dtype = np.float64 if rng.random() < 0.6 else np.float32
+    D = int(rng.choice([3, 16, 64, 100, 128, 130, 256, 300, 512]))
+    N = int(rng.choice([5, 64, 100, 257, 1000, 4096]))
+    S = int(rng.choice([1, 2, 7, 64, 130]))
+    X = np.asfortranarray(rng.standard_normal((D, N)).astype(dtype))
+    Y = np.asfortranarray(rng.standard_normal((N, S)).astype(dtype))
+    mw = rng.standard_normal(D).astype(dtype)
+    diag = rng.random() < 0.5
+    s = np.exp(0.3 * rng.standard_normal(N)).astype(dtype) if diag else dtype(0.5)
+    prior = rng.choice(["dense", "diag"])
+    if prior == "diag":
+        Lw = B.Diagonal(np.exp(0.3 * rng.standard_normal(D)).astype(dtype)); Lw_o = np.diag(np.asarray(Lw.diag, dtype=float))
+    else:
+        Bm = rng.standard_normal((D, D)) / np.sqrt(D); Lw = (Bm @ Bm.T + np.eye(D)).astype(dtype); Lw_o = Lw.astype(float)
+    f = B.BayesianLinearRegressor(mw, Lw)
+    lps = np.asarray(B.logpdf(f(X, s), Y))
+    rt = 1e-9 if dtype == np.float64 else 2e-3
+    for j in range(S):
+        lp_o = O.logpdf_literal(mw.astype(float), Lw_o, X.astype(float), np.asarray(s, dtype=float), Y[:, j].astype(float))
+        assert abs(lps[j] - lp_o) <= rt * abs(lp_o), (case, j, lps[j], lp_o, D, N, S, dtype.__name__)
+    return f"D={D} N={N} S={S} {prior} {'diag' if diag else 'iso'} {dtype.__name__}"
+
+
+def rand(rng, case):
+    dtype = np.float64 if rng.random() < 0.5 else np.float32
+    D = int(rng.choice([4, 32, 64, 128, 130, 256, 384, 1024]))
+    N = int(rng.choice([1, 17, 128, 129, 500, 1000, 5000]))
+    S = int(rng.choice([1, 3, 64, 65, 200]))
+    pad = int(rng.choice([0, 0, 4, 16]))
+    ldx = D + pad
+    Xa = np.zeros((ldx, N), dtype=dtype, order="F"); Xa[:D] = rng.standard_normal((D, N))
+    mw = rng.standard_normal(D).astype(dtype)
+    Bm = rng.standard_normal((D, D)) / np.sqrt(D)
+    Lw = (Bm @ Bm.T + np.eye(D)).astype(dtype)
+    s = np.exp(0.3 * rng.standard_normal(N)).astype(dtype)
+    Z1 = np.asfortranarray(rng.standard_normal((D, S)).astype(dtype)); Z2 = np.asfortranarray(rng.standard_normal((N, S)).astype(dtype))
+    f64 = lambda a: np.asarray(a, dtype=float)
+    Y_o = O.rand(f64(mw), f64(Lw), f64(Xa[:D]), f64(s), f64(Z1), f64(Z2))
+    h = _abi.default_handle()
+    kind = rng.choice(["dense", "factor"])
+    Larg = np.asfortranarray(Lw) if kind == "dense" else np.asfortranarray(O.chol_upper(f64(Lw)).astype(dtype))
+    Y = np.empty((N, S), dtype=dtype, order="F")
+    h.rand(dtype, _abi.MEM_HOST, _abi.LAYOUT_COLVECS, D, N, S, Xa, ldx, _abi.NOISE_DIAGONAL, s, _abi.PRIOR_DENSE if kind == "dense" else _abi.PRIOR_UPPER_FACTOR,
+           mw, Larg, D, Z1, D, Z2, N, Y, N)
+    rt = 1e-9 if dtype == np.float64 else 3e-3
+    np.testing.assert_allclose(Y, Y_o, rtol=rt, atol=rt * 10 * np.abs(Y_o).max(), err_msg=f"case {case}: D={D} N={N} S={S} {kind} {dtype.__name__}")
+    return f"D={D} N={N} S={S} {kind} {dtype.__name__} ldx=D+{pad}"
+
+
 if __name__ == "__main__":
     which = sys.argv[1] if len(sys.argv) > 1 else "marg"
     cases = int(sys.argv[2]) if len(sys.argv) > 2 else 100
     rng = np.random.default_rng(int(sys.argv[3]) if len(sys.argv) > 3 else 2027)
-    fn = marg if which == "marg" else i8
+    fn = {"marg": marg, "i8": i8, "multi": multi, "rand": rand}[which]
     for c in range(cases):
         d = fn(rng, c)
         if c % 10 == 0:
