@@ -375,7 +375,7 @@ int dispatch_fused_small(blr_handle* h, const PosteriorArgs<T>& a) {
   int NB = (a.D + 15) / 16;
   if constexpr (sizeof(T) == 8) {
     if (!h->opt.no_i8_gram && !h->opt.no_ldsdma && a.D == 128 && a.layout == BLR_LAYOUT_COLVECS && a.vec_ok && a.noise_kind == BLR_NOISE_ISOTROPIC &&
-        a.prior_kind == BLR_PRIOR_DIAGONAL && a.N >= kI8MinN && a.N <= kI8MaxN && a.N % I8Cfg::KC == 0 && a.ldx * 8 * I8Cfg::KC < ((int64_t)1 << 31))
+        a.prior_kind == BLR_PRIOR_DIAGONAL && a.N - a.N % I8Cfg::KC >= kI8MinN && a.N - a.N % I8Cfg::KC <= kI8MaxN && a.ldx * 8 * I8Cfg::KC < ((int64_t)1 << 31))
       return launch_fused_i8(h, a);
   }
   if (!h->opt.no_wave_kernel && a.layout == BLR_LAYOUT_COLVECS && a.vec_ok && a.D == 16 * NB &&

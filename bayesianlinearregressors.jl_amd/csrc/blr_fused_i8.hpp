@@ -37,6 +37,8 @@
 //     and one of 14 chunks of the slicing; ONE workgroup barrier per k-step;
 //   * after the stream: accumulators -> fp64 -> packed triangle of A in LDS; waves 4-7 exit; waves 0-3 run the phases of
 //     fused_small_kernel (blocked Cholesky, substitutions, evidence) unchanged;
+//   * N need not be a multiple of 32: whole k-steps go through the stream, the last N % 32 columns are added to the finished matrix,
+//     to b and to y'y in fp64 at the hand-over (a rank-r term, r < 32: ~1 % of an update);
 //   * a prior mean mw != 0 (reference :57, :82: delta = y - X'mw) never touches the stream: G is exact, so
 //     b = X delta / s = X y / s - (G / s) mw and delta'delta / s = y'y / s - 2 mw'X y / s + mw'(G / s) mw are formed from the
 //     finished matrix (one 128 x 128 symmetric matrix-vector product in LDS; diag(G) / s is kept next to A = Lw + G / s).
@@ -93,8 +95,9 @@ struct I8Cfg {
   static constexpr int OFF_SC = OFF_VTAB + 3 * 128 * 8;         // 2^(e_i - 47): 128 doubles
   static constexpr int OFF_BRED = OFF_SC + 128 * 8;             // b partials: 4 x 128 doubles
   static constexpr int OFF_GD = OFF_BRED + 4 * 128 * 8;         // diag(G) / sigma^2 WITHOUT the prior (prior-mean terms): 128 doubles
+  static constexpr int OFF_TAIL = OFF_GD + 128 * 8;             // the last N % 32 columns of X (fp64 rank-r term of the hand-over) + their y: 31 x 128 + 32 doubles
   static_assert(SmallCfg<double, 8>::LDS_BYTES <= RING_BYTES, "the phase functions' LDS image must fit in the dead ring");
-  static_assert(OFF_GD + 128 * 8 <= OFF_YB, "conversion tables must fit in the digit area");
+  static_assert(OFF_TAIL + (31 * 128 + 32) * 8 <= OFF_YB, "conversion tables and the tail columns must fit in the digit area");
   static_assert(LDS_BYTES <= 160 * 1024, "LDS of one CU");
 };
 
@@ -493,6 +496,7 @@ __global__ __launch_bounds__(kI8Threads, 2) void fused_i8_kernel(PosteriorArgs<d
   const int wave = uni(tid >> 6);
   const int reg = blockIdx.x;
   const int N = a.N;
+  const int N32 = N & ~(C::KC - 1);  // whole 32-column k-steps go through the int8 stream; the last N % 32 columns join in fp64 at the hand-over
   constexpr int D = 128;
   const double kNaN = __longlong_as_double(0x7ff8000000000000LL);
   const BLR_GLOBAL T* X = as_global(a.X + (int64_t)reg * a.strideX);
@@ -515,7 +519,7 @@ __global__ __launch_bounds__(kI8Threads, 2) void fused_i8_kernel(PosteriorArgs<d
     constexpr int W = decltype(wtag)::value;
     using PL = I8Plan<W>;
     i32x16 A[PL::NACC];
-    i8_gram_stream<W>(smem, X, y, a.ldx, N, tid, A, st, ok);
+    i8_gram_stream<W>(smem, X, y, a.ldx, N32, tid, A, st, ok);
     I8_KSTAMP(4);
     // ---- hand-over: validity, digit row sums, b partials, row scales (all through the exchange area / the dead digit area)
     if (!ok) flag[0] = 0;  // (benign race: everybody writes the same value)
@@ -541,7 +545,7 @@ __global__ __launch_bounds__(kI8Threads, 2) void fused_i8_kernel(PosteriorArgs<d
         for (int s2 = 0; s2 < 6; ++s2)
           if (s2 <= k - 1 && s2 >= k - 5) acc_s += R[s2];
         const int npairs = k <= 6 ? (k > 1 ? k - 1 : 0) : 11 - k;
-        const double vk = (double)(128LL * acc_s + 8192LL * (long long)N * npairs) * __hiloint2double((1023 + 80 - 8 * k) << 20, 0);
+        const double vk = (double)(128LL * acc_s + 8192LL * (long long)N32 * npairs) * __hiloint2double((1023 + 80 - 8 * k) << 20, 0);
         if (k >= 4) tc += vk;
         else if (k == 3) tb = vk;
         else ta += vk;
@@ -618,9 +622,43 @@ __global__ __launch_bounds__(kI8Threads, 2) void fused_i8_kernel(PosteriorArgs<d
   double bsum = 0.0;
   if (tid < D) bsum = ((bred[tid] + bred[128 + tid]) + (bred[256 + tid] + bred[384 + tid])) * winv;
   const double* qx = reinterpret_cast<const double*>(xch);
-  const double quad = ((qx[0] + qx[1]) + (qx[2] + qx[3])) * winv;
+  double quad = ((qx[0] + qx[1]) + (qx[2] + qx[3])) * winv;
   const int valid = flag[0];
   __syncthreads();  // P complete; the tables in the digit area have been read
+  if (N32 < N && valid) {  // (uniform)  the last r = N % 32 columns: a rank-r term in fp64, all eight waves
+    const int r = N - N32;
+    double* const tb = reinterpret_cast<double*>(smem + C::OFF_TAIL);  // [r][128], then y[r]
+    int bad = 0;
+    for (int e = tid; e < r * D; e += kI8Threads) {
+      const double v = X[(int64_t)(N32 + (e >> 7)) * a.ldx + (e & 127)];
+      tb[e] = v;
+      if (!(fabs(v) < __longlong_as_double(0x7ff0000000000000LL))) bad = 1;  // Inf / NaN: as in the stream, the fp64 kernel reports it
+    }
+    if (tid < r) tb[31 * D + tid] = y[N32 + tid];
+    if (__syncthreads_or(bad)) {
+      if (tid == 0) a.info[reg] = kI8Retry;
+      return;
+    }
+    for (int e = tid; e < SC::PACKED; e += kI8Threads) {
+      int i = (int)((sqrtf(8.0f * (float)e + 1.0f) - 1.0f) * 0.5f);  // packed index -> (i, j), j <= i
+      while ((i + 1) * (i + 2) / 2 <= e) ++i;
+      while (i * (i + 1) / 2 > e) --i;
+      const int j = e - i * (i + 1) / 2;
+      double acc = 0.0;
+      for (int c = 0; c < r; ++c) acc = __builtin_fma(tb[c * D + i], tb[c * D + j], acc);
+      P[e] += acc * winv;
+      if (i == j) gdiag[i] += acc * winv;
+    }
+    double bt = 0.0, qt = 0.0;
+    for (int c = 0; c < r; ++c) {
+      const double yc = tb[31 * D + c];
+      if (tid < D) bt = __builtin_fma(tb[c * D + tid], yc, bt);
+      qt = __builtin_fma(yc, yc, qt);
+    }
+    bsum += bt * winv;
+    quad += qt * winv;
+    __syncthreads();
+  }
   I8_KSTAMP(5);
   if (wave >= 4) return;  // the phases below are four-wave code (their barriers count the surviving waves only)
   if (!valid) {

@@ -107,7 +107,7 @@ int blr_timer_stop(blr_handle* h, float* elapsed_ms); /* records, synchronises, 
  * Numerics: results are bit-reproducible from call to call (fixed accumulation order, no floating-point atomics).  fp64
  * accuracy against the reference's op sequence in LAPACK: evidence 1e-10 relative, mw', T, Lw' 1e-9 (tests/test_gpu_parity.py).
  * One shape takes a different route to the same numbers: D = 128, aligned ColVecs, isotropic noise, diagonal prior,
- * 512 <= N <= 16384, 32 | N forms X X' on the int8 matrix cores from an exact 48-bit splitting of the inputs (per-row
+ * 512 <= N <= 16384 (+ a last partial block of up to 31 columns, added in fp64) forms X X' on the int8 matrix cores from an exact 48-bit splitting of the inputs (per-row
  * power-of-two scales; csrc/blr_fused_i8.hpp) -- entries of Lw' within 1e-13 of sqrt(Lw'_ii Lw'_jj) instead of a few ulp of
  * themselves, everything after the Gram matrix in fp64 as elsewhere; a regressor whose rows outgrow their scale is redone on
  * the fp64 matrix pipe inside the same call.  blr_set_option(h, "NO_I8_GRAM", "1") keeps every regressor on that pipe.

@@ -2166,7 +2166,7 @@ def _i8_case(rng, nb, N, kind):
 
 
 @pytest.mark.parametrize("kind", ["gauss", "scales", "outlier", "zero_row", "tiny"])
-@pytest.mark.parametrize("N", [512, 4096])
+@pytest.mark.parametrize("N", [512, 543, 4096, 4127])  # (543, 4127: a last partial block of 31 columns, added in fp64 at the hand-over)
 @pytest.mark.parametrize("prior_mean", [False, True])
 def test_i8_gram_path_vs_oracle_and_fp64_kernel(B, opt, kind, N, prior_mean):
     # the SAME call with the fast path on (default) and off (NO_I8_GRAM: fused_small_kernel, the fp64 matrix pipe), both against
@@ -2298,6 +2298,37 @@ def test_i8_gram_path_hands_back_what_it_cannot_do(B, opt):
     assert np.all(fast[0][4] == 7.0) and np.all(fast[1][4] == 7.0)  # failed regressor: outputs untouched
     bad = run(np.array([-0.5]))  # sigma^2 <= 0: PosDefException(1) at reference :79 for every regressor whose prior is fine
     assert bad[3].tolist() == [1, 1, 1, 1, 78, 1, 1, 1] and np.all(np.isnan(bad[2]))
+
+
+def test_i8_gram_tail_columns_nonfinite_go_back_to_the_fp64_kernel(B, opt):
+    # N = 1055: 32 whole k-steps through the int8 stream, 31 columns added in fp64 at the hand-over.  A NaN / Inf in THOSE columns
+    # hands the regressor back like one in the stream does: status and bits of the fp64 kernel.
+    a = B._abi
+    h = a.default_handle()
+    rng = _rng(4500)
+    nb, D, N = 4, 128, 1055
+    X, y = _i8_case(rng, nb, N, "gauss")
+    X[1, N - 3, 9] = np.nan
+    X[2, N - 31, 127] = np.inf
+    dpr = np.ones((nb, D)); mw = np.zeros((nb, D)); s = np.array([0.1])
+
+    def run():
+        mp = np.full((nb, D), 7.0); Tp = np.full((nb, D, D), 7.0); lp = np.zeros(nb); info = np.full(nb, 9, dtype=np.int32)
+        h.posterior_batched(np.float64, a.MEM_HOST, a.LAYOUT_COLVECS, nb, D, N, X, D, N * D, y, N, a.NOISE_ISOTROPIC, s, 0, a.PRIOR_DIAGONAL,
+                            mw, D, dpr, 1, D, mp, D, Tp, D, D * D, None, D, D * D, lp, info)
+        return mp, Tp, lp, info
+
+    fast = run()
+    opt("NO_I8_GRAM", "1")
+    slow = run()
+    assert fast[3].tolist() == slow[3].tolist()
+    for b in (1, 2):
+        np.testing.assert_array_equal(fast[0][b], slow[0][b])
+        np.testing.assert_array_equal(fast[1][b], slow[1][b])
+        assert (fast[2][b] == slow[2][b]) or (np.isnan(fast[2][b]) and np.isnan(slow[2][b]))
+    for b in (0, 3):
+        assert fast[3][b] == 0 and fast[2][b] == pytest.approx(slow[2][b], rel=1e-11)
+        np.testing.assert_allclose(fast[0][b], slow[0][b], rtol=1e-9, atol=1e-11)
 
 
 @pytest.mark.parametrize("nb", [8192, 1024])
