@@ -34,7 +34,7 @@ using namespace blr;
 // handle is created (BLR_MI355X_<KEY>), and settable per handle with blr_set_option: no getenv on any launch path.
 struct BlrOptions {
   bool no_ldsdma = false, no_wave_kernel = false, no_gram_ring = false, no_diag_split = false, no_xcd_swizzle = false,
-       no_mfma_project = false, plan_debug = false, no_i8_gram = false, no_marg_gemm = false;
+       no_mfma_project = false, plan_debug = false, no_i8_gram = false, no_marg_gemm = false, no_i8_diag = false;
   int wave_split = 0;     // waves per regressor of the wave kernel: 0 = router, else 1 | 2 | 4
   int chain_batch = 0;    // regressors per shared launch at D > 128: 0 = as many as the workspace holds
   long chain_ws_mb = 0;   // workspace bound of such a group in MiB: 0 = kChainWorkspace
@@ -55,6 +55,7 @@ struct BlrOptions {
     if (!strcmp(key, "PLAN_DEBUG")) return flag(plan_debug);
     if (!strcmp(key, "NO_I8_GRAM")) return flag(no_i8_gram);
     if (!strcmp(key, "NO_MARG_GEMM")) return flag(no_marg_gemm);
+    if (!strcmp(key, "NO_I8_DIAG")) return flag(no_i8_diag);
     if (!strcmp(key, "WAVE_SPLIT")) {
       const int v = on ? atoi(value) : 0;
       wave_split = (v == 1 || v == 2 || v == 4) ? v : 0;
@@ -75,7 +76,7 @@ struct BlrOptions {
   }
   void from_environment() {
     for (const char* k : {"NO_LDSDMA", "NO_WAVE_KERNEL", "NO_GRAM_RING", "NO_DIAG_SPLIT", "NO_XCD_SWIZZLE", "NO_MFMA_PROJECT", "PLAN_DEBUG",
-                          "NO_I8_GRAM", "NO_MARG_GEMM", "WAVE_SPLIT", "CHAIN_BATCH", "CHAIN_WS_MB", "SWEEP", "GRAM_SPLITS"}) {
+                          "NO_I8_GRAM", "NO_MARG_GEMM", "NO_I8_DIAG", "WAVE_SPLIT", "CHAIN_BATCH", "CHAIN_WS_MB", "SWEEP", "GRAM_SPLITS"}) {
       const std::string name = std::string("BLR_MI355X_") + k;
       if (const char* v = getenv(name.c_str())) (void)set(k, *v ? v : "1");  // (an empty variable still switches a flag on)
     }
@@ -349,9 +350,24 @@ int launch_fused_wave(blr_handle* h, const PosteriorArgs<T>& a) {
 // (a row bound broken, non-finite input): every regressor leaves with the status and the numbers of an
 // fp64-accurate update, none is computed twice on the fast path.
 int launch_fused_i8(blr_handle* h, const PosteriorArgs<double>& a) {
-  int rc = set_lds_once(h, reinterpret_cast<const void*>(fused_i8_kernel), (size_t)I8Cfg::LDS_BYTES);
+  const bool diag = a.noise_kind == BLR_NOISE_DIAGONAL;
+  int rc = set_lds_once(h, reinterpret_cast<const void*>(fused_i8_kernel<false>), (size_t)I8Cfg::LDS_BYTES);
   if (rc) return rc;
-  const int grid = (int)std::min<int64_t>(a.B, 1 << 20);
+  if (diag && (rc = set_lds_once(h, reinterpret_cast<const void*>(fused_i8_kernel<true>), (size_t)I8Cfg::LDS_BYTES))) return rc;
+  // diagonal noise: y / sqrt(s), 1 / sqrt(s), sum log s and a validity flag per regressor, once per call, in the handle's side
+  // buffer (16 bytes per observation: slices of at most 1 GiB)
+  const int64_t per_reg = 2 * (int64_t)a.N * (int64_t)sizeof(double);
+  const int grid = (int)std::min<int64_t>(a.B, diag ? std::max<int64_t>(1, ((int64_t)1 << 30) / per_reg) : (1 << 20));
+  double *yt = nullptr, *rw = nullptr, *ld = nullptr, *rmx = nullptr;
+  int32_t* bad = nullptr;
+  if (diag) {
+    const size_t o_rw = (((size_t)grid * a.N * sizeof(double)) + 255) & ~(size_t)255;
+    const size_t o_ld = 2 * o_rw, o_mx = o_ld + (((size_t)grid * sizeof(double) + 255) & ~(size_t)255);
+    const size_t o_bad = o_mx + (((size_t)grid * sizeof(double) + 255) & ~(size_t)255);
+    if ((rc = ensure_aux(h, o_bad + (size_t)grid * sizeof(int32_t)))) return rc;
+    yt = reinterpret_cast<double*>(h->aux); rw = reinterpret_cast<double*>(h->aux + o_rw);
+    ld = reinterpret_cast<double*>(h->aux + o_ld); rmx = reinterpret_cast<double*>(h->aux + o_mx); bad = reinterpret_cast<int32_t*>(h->aux + o_bad);
+  }
   for (int64_t b0 = 0; b0 < a.B; b0 += grid) {  // (one workgroup per regressor: batches beyond 2^20 in slices)
     PosteriorArgs<double> s = a;
     const int nb = (int)std::min<int64_t>(grid, a.B - b0);
@@ -362,7 +378,14 @@ int launch_fused_i8(blr_handle* h, const PosteriorArgs<double>& a) {
     if (s.Lw_post) s.Lw_post += b0 * a.strideLp;
     if (s.logpdf) s.logpdf += b0;
     s.info += b0;
-    hipLaunchKernelGGL(fused_i8_kernel, dim3(nb), dim3(kI8Threads), I8Cfg::LDS_BYTES, h->stream, s);
+    if (diag) {
+      s.i8_yt = yt; s.i8_rw = rw; s.i8_stride = a.N; s.i8_logdet = ld; s.i8_bad = bad; s.i8_rwmax = rmx;
+      hipLaunchKernelGGL(i8_noise_prep_kernel, dim3(nb), dim3(kThreads), 0, h->stream, s.s, a.strides, s.y, a.stridey, (int)a.N, yt, rw, (int64_t)a.N, ld,
+                         bad, rmx);
+      hipLaunchKernelGGL(fused_i8_kernel<true>, dim3(nb), dim3(kI8Threads), I8Cfg::LDS_BYTES, h->stream, s);
+    } else {
+      hipLaunchKernelGGL(fused_i8_kernel<false>, dim3(nb), dim3(kI8Threads), I8Cfg::LDS_BYTES, h->stream, s);
+    }
     HIP_TRY(h, hipGetLastError());
     s.retry_only = 1;
     if ((rc = launch_fused_small<double, 8, 4>(h, s))) return rc;
@@ -374,8 +397,8 @@ template <typename T>
 int dispatch_fused_small(blr_handle* h, const PosteriorArgs<T>& a) {
   int NB = (a.D + 15) / 16;
   if constexpr (sizeof(T) == 8) {
-    if (!h->opt.no_i8_gram && !h->opt.no_ldsdma && a.D == 128 && a.layout == BLR_LAYOUT_COLVECS && a.vec_ok && a.noise_kind == BLR_NOISE_ISOTROPIC &&
-        a.prior_kind == BLR_PRIOR_DIAGONAL && a.N - a.N % I8Cfg::KC >= kI8MinN && a.N - a.N % I8Cfg::KC <= kI8MaxN && a.ldx * 8 * I8Cfg::KC < ((int64_t)1 << 31))
+    if (!h->opt.no_i8_gram && !h->opt.no_ldsdma && a.D == 128 && a.layout == BLR_LAYOUT_COLVECS && a.vec_ok &&
+        (a.noise_kind == BLR_NOISE_ISOTROPIC || (a.noise_kind == BLR_NOISE_DIAGONAL && !h->opt.no_i8_diag)) && a.prior_kind == BLR_PRIOR_DIAGONAL && a.N - a.N % I8Cfg::KC >= kI8MinN && a.N - a.N % I8Cfg::KC <= kI8MaxN && a.ldx * 8 * I8Cfg::KC < ((int64_t)1 << 31))
       return launch_fused_i8(h, a);
   }
   if (!h->opt.no_wave_kernel && a.layout == BLR_LAYOUT_COLVECS && a.vec_ok && a.D == 16 * NB &&

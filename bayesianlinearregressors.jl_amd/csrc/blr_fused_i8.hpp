@@ -86,7 +86,8 @@ struct I8Cfg {
   static constexpr int DIG_BUF = S * 4 * 1024;                  // 24 KiB: [slice][row block of 32][1 KiB fragment]
   static constexpr int OFF_DIG = RING_BYTES;
   static constexpr int OFF_YB = OFF_DIG + 2 * DIG_BUF;          // y ring: NSLOT x 32 doubles
-  static constexpr int OFF_XCH = OFF_YB + NSLOT * KC * 8;       // exchange: 4 x 6 x 128 ints (row sums; row maxima first)
+  static constexpr int OFF_RW = OFF_YB + NSLOT * KC * 8;        // 1 / sqrt(s_n) ring (diagonal noise): NSLOT x 32 doubles
+  static constexpr int OFF_XCH = OFF_RW + NSLOT * KC * 8;       // exchange: 4 x 6 x 128 ints (row sums; row maxima first)
   static constexpr int OFF_FLAG = OFF_XCH + 4 * 6 * 128 * 4;    // 16 ints
   static constexpr int LDS_BYTES = OFF_FLAG + 64;
   // after the stream the ring is dead: P, bvec, ... of SmallCfg<double, 8> live there (phase_chol / phase_backsolve layout);
@@ -184,30 +185,38 @@ struct I8Slice {
 //   x + C: rounded to a multiple of 2^(e_r - 47), its integer Q in the low mantissa bits; bytes 0..3 of Q are bytes 0..3 of the
 //   low word, bytes 4, 5 are bytes 0, 1 of the high word; slice s holds byte 5 - s.  4 x 4 byte transposition of a column quad
 //   with v_perm_b32 (D = perm(S0, S1, sel): selector values 0-3 take bytes of S1, 4-7 bytes of S0).
-template <bool WITH_Q>
+template <bool WITH_Q, bool DIAG = false>
 struct I8SliceSteps {
   double x[2][4], y[2][4];  // two column quads: the second quad's LDS reads are in flight while the first is sliced
+  double w[DIAG ? 2 : 1][4];  // diagonal noise: 1 / sqrt(s_n) of the columns (x enters the Gram matrix as x / sqrt(s_n), y as y / sqrt(s_n))
   unsigned lo[4], hi[4], u[6], p[2][6];
   template <int Q>
-  __device__ __forceinline__ void load(const char* __restrict__ raw, const double* __restrict__ yb, int r, int cq) {
+  __device__ __forceinline__ void load(const char* __restrict__ raw, const double* __restrict__ yb, const double* __restrict__ wb, int r, int cq) {
     const double* col = reinterpret_cast<const double*>(raw) + (cq * 8 + 4 * Q) * 128 + r;
 #pragma unroll
-    for (int j = 0; j < 4; ++j) { x[Q][j] = col[j * 128]; y[Q][j] = yb[cq * 8 + 4 * Q + j]; }  // (y: one address per wave, a broadcast)
+    for (int j = 0; j < 4; ++j) {
+      x[Q][j] = col[j * 128];
+      y[Q][j] = yb[cq * 8 + 4 * Q + j];  // (y: one address per wave, a broadcast)
+      if constexpr (DIAG) w[Q][j] = wb[cq * 8 + 4 * Q + j];
+    }
   }
   // chunk 0: reads of quad 0; chunks 1 + 6 q + c: quad q -- c = 0 reads of quad q + 1, c = 1, 2 magic add / bound check / b and q (two
   // columns each), c = 3, 4 byte transposition, c = 5 digit row sums; chunk 13: digit planes out
   template <int C>
-  __device__ __forceinline__ void step(const char* __restrict__ raw, const double* __restrict__ yb, char* __restrict__ dig, int r, int cq, I8Slice& st) {
+  __device__ __forceinline__ void step(const char* __restrict__ raw, const double* __restrict__ yb, const double* __restrict__ wb, char* __restrict__ dig, int r,
+                                       int cq, I8Slice& st) {
     if constexpr (C == 0) {
-      load<0>(raw, yb, r, cq);
+      load<0>(raw, yb, wb, r, cq);
     } else if constexpr (C < 13) {
       constexpr int q = (C - 1) / 6, c = (C - 1) % 6;  // column quad q of the thread's 8 columns
-      if constexpr (c == 0 && q < 1) load<q + 1>(raw, yb, r, cq);
+      if constexpr (c == 0 && q < 1) load<q + 1>(raw, yb, wb, r, cq);
       if constexpr (c == 1 || c == 2) {
         constexpr int j0 = c == 1 ? 0 : 2;
 #pragma unroll
         for (int j = j0; j < j0 + 2; ++j) {
-          const double xv = x[q][j], yv = y[q][j];
+          double xv = x[q][j];
+          if constexpr (DIAG) xv *= w[q][j];
+          const double yv = y[q][j];
           const double t = xv + st.C;
           lo[j] = (unsigned)__double2loint(t);
           hi[j] = (unsigned)__double2hiint(t);
@@ -281,16 +290,16 @@ __device__ __forceinline__ void glds_s_4x1k(uint64_t saddr_uniform, unsigned vof
 // sched_group_barrier does not move them: the slicing hangs off LDS reads the group solver leaves where they are).  So the
 // k-step is a compile-time list: MFMA i, then (fenced with sched_barrier) the fragment reads MFMA i + 2 is the first to need
 // and the slicing chunks whose turn it is -- reads of the raw columns first, their arithmetic two MFMAs later.
-template <int W, bool SLICE, bool WITH_Q, typename IssueFn>
+template <int W, bool SLICE, bool WITH_Q, bool DIAG, typename IssueFn>
 __device__ __forceinline__ void i8_kstep(const char* __restrict__ dig, const char* __restrict__ raw, const double* __restrict__ yb,
-                                         char* __restrict__ dign, int lane, int r, int cq, i32x16 (&A)[I8Plan<W>::NACC], I8Slice& st,
+                                         const double* __restrict__ wb, char* __restrict__ dign, int lane, int r, int cq, i32x16 (&A)[I8Plan<W>::NACC], I8Slice& st,
                                          IssueFn issue_next) {
   using PL = I8Plan<W>;
   constexpr int NM = PL::NM;
   constexpr int NCH = kI8SliceChunks;
   constexpr int LEAD = 2;   // a fragment is requested this many MFMAs before its first use
   i32x4 F[4][6];            // fragment (row block, slice): only the ones this wave uses ever get registers
-  I8SliceSteps<WITH_Q> sl;
+  I8SliceSteps<WITH_Q, DIAG> sl;
   auto frag_load_one = [&](auto itag, auto qtag) {
     constexpr int i = decltype(itag)::value, q = decltype(qtag)::value, rb = q / 6, sidx = q % 6;
     constexpr int fu = PL::first_use(rb, sidx);
@@ -307,9 +316,9 @@ __device__ __forceinline__ void i8_kstep(const char* __restrict__ dig, const cha
   auto chunk = [&](auto ctag) {
     constexpr int c = decltype(ctag)::value;
 #if defined(BLR_I8_EXP) && BLR_I8_EXP == 3  /* timing experiment: no slicing */
-    if constexpr (false) sl.template step<c>(raw, yb, dign, r, cq, st);
+    if constexpr (false) sl.template step<c>(raw, yb, wb, dign, r, cq, st);
 #else
-    if constexpr (SLICE && c >= 0 && c < NCH) sl.template step<c>(raw, yb, dign, r, cq, st);
+    if constexpr (SLICE && c >= 0 && c < NCH) sl.template step<c>(raw, yb, wb, dign, r, cq, st);
 #endif
   };
   auto unit = [&](auto itag) {
@@ -348,23 +357,26 @@ __device__ __forceinline__ void i8_kstep(const char* __restrict__ dig, const cha
 }
 
 // ---- the stream: on exit the wave's accumulators and the slicing state --------------------------------------------------------------
-template <int W>
+template <int W, bool DIAG>
 __device__ __forceinline__ void i8_gram_stream(char* smem, const BLR_GLOBAL double* X /*uniform*/, const BLR_GLOBAL double* y /*uniform*/,
-                                               int64_t ldx, int N, int tid, i32x16 (&A)[I8Plan<W>::NACC], I8Slice& st, int& ok) {
+                                               const BLR_GLOBAL double* rw /*uniform; DIAG: 1 / sqrt(s_n)*/, double rwmax, int64_t ldx, int N, int tid, i32x16 (&A)[I8Plan<W>::NACC], I8Slice& st, int& ok) {
   using C = I8Cfg;
   const int lane = tid & 63;
   const int r = tid & 127, cq = tid >> 7;
   char* const ring = smem;
   char* const dig0 = smem + C::OFF_DIG;
   double* const yring = reinterpret_cast<double*>(smem + C::OFF_YB);
+  double* const wring = reinterpret_cast<double*>(smem + C::OFF_RW);
   int* const xch = reinterpret_cast<int*>(smem + C::OFF_XCH);
   const int nk = N / C::KC;
-  constexpr int PW = 4 + (W == 0 ? 1 : 0);  // LDS-DMA pieces per wave and k-step: 4 columns (+ the y piece of wave 0)
-  unsigned ring_addr = lds_addr_of(ring), y_addr = lds_addr_of(yring);
-  asm volatile("" : "+v"(ring_addr), "+v"(y_addr));
+  // LDS-DMA pieces per wave and k-step: 4 columns (+ the y piece of wave 0, + the 1 / sqrt(s) piece of wave 1 under diagonal noise)
+  constexpr int PW = 4 + (W == 0 ? 1 : 0) + (DIAG && W == 1 ? 1 : 0);
+  unsigned ring_addr = lds_addr_of(ring), y_addr = lds_addr_of(yring), w_addr = lds_addr_of(wring);
+  asm volatile("" : "+v"(ring_addr), "+v"(y_addr), "+v"(w_addr));
   const uint64_t colbytes = (uint64_t)ldx * 8u;
   uint64_t nextX = (uint64_t)(uintptr_t)X + (uint64_t)(4 * W) * colbytes;  // this wave's four columns of the k-step being issued
   uint64_t nextY = (uint64_t)(uintptr_t)y;
+  uint64_t nextW = (uint64_t)(uintptr_t)rw;
   const unsigned voff = (unsigned)lane * 16u;
   // piece c of k-step t -> ring slot t % 3: c = 0 .. 3 this wave's four columns, c = 4 the y values (wave 0) and the advance to the
   // next k-step (pieces are issued in order: the global addresses just run on)
@@ -378,8 +390,10 @@ __device__ __forceinline__ void i8_gram_stream(char* smem, const BLR_GLOBAL doub
       glds_s<16>(uni((int64_t)(nextX + (uint64_t)c * colbytes)), voff, slot);
     } else {
       if constexpr (W == 0) glds_s<4, 64>(uni((int64_t)nextY), (unsigned)lane * 4u, y_addr + (unsigned)((t % C::NSLOT) * C::KC * 8));
+      if constexpr (DIAG && W == 1) glds_s<4, 64>(uni((int64_t)nextW), (unsigned)lane * 4u, w_addr + (unsigned)((t % C::NSLOT) * C::KC * 8));
       nextX += (uint64_t)C::KC * colbytes;
       nextY += (uint64_t)C::KC * 8u;
+      nextW += (uint64_t)C::KC * 8u;
     }
   };
   auto issue = [&](int t) {
@@ -422,6 +436,13 @@ __device__ __forceinline__ void i8_gram_stream(char* smem, const BLR_GLOBAL doub
     unsigned m = (unsigned)xch[r];
 #pragma unroll
     for (int c = 1; c < 4; ++c) { const unsigned o = (unsigned)xch[c * 128 + r]; m = o > m ? o : m; }
+    if constexpr (DIAG) {
+      // what gets sliced is x / sqrt(s_n): its bound is the row's bound times the LARGEST 1 / sqrt(s_n) of the regressor (known from
+      // the preparation pass).  From the scaled values of the first columns alone, one column of small variance further on
+      // breaks every row's bound: with log-normal variances most regressors went back to the fp64 kernel.
+      const double mv = __hiloint2double((int)m, -1) * rwmax;
+      m = (unsigned)__double2hiint(mv) & 0x7fffffffu;
+    }
     int E1 = (int)(m >> 20);           // biased exponent of the row maximum (0 for a zero / denormal row)
     if (E1 > 1023 + 400) ok = 0;       // Inf / NaN / out of the range the final scaling can represent: fp64 path
     if (E1 < 1023 - 400) E1 = 1023 - 400;
@@ -436,11 +457,11 @@ __device__ __forceinline__ void i8_gram_stream(char* smem, const BLR_GLOBAL doub
   }
   constexpr bool kQ = (W & 1) == 0;  // (rows 64 (W & 1) + lane: row 0 lives in the even waves)
   {  // block 0 -> digit buffer 0 (nothing to overlap with yet)
-    I8SliceSteps<kQ> sl;
+    I8SliceSteps<kQ, DIAG> sl;
     auto rec = [&](auto self, auto ctag) -> void {
       constexpr int c = decltype(ctag)::value;
       if constexpr (c < kI8SliceChunks) {
-        sl.template step<c>(ring, yring, dig0, r, cq, st);
+        sl.template step<c>(ring, yring, wring, dig0, r, cq, st);
         self(self, std::integral_constant<int, c + 1>{});
       }
     };
@@ -456,15 +477,16 @@ __device__ __forceinline__ void i8_gram_stream(char* smem, const BLR_GLOBAL doub
     char* dign = dig0 + ((j + 1) & 1) * C::DIG_BUF;
     const char* raw = ring + ((j + 1) % C::NSLOT) * C::SLOT_BYTES;
     const double* yb = yring + ((j + 1) % C::NSLOT) * C::KC;
+    const double* wb = wring + ((j + 1) % C::NSLOT) * C::KC;
     // k-step j + 3 goes into the slot of block j, which everybody has sliced before the barrier that ended k-step j - 1
-    i8_kstep<W, true, kQ>(dig, raw, yb, dign, lane, r, cq, A, st, [&](auto ctag) { if (j + 3 < nk) issue_piece(j + 3, ctag); });
+    i8_kstep<W, true, kQ, DIAG>(dig, raw, yb, wb, dign, lane, r, cq, A, st, [&](auto ctag) { if (j + 3 < nk) issue_piece(j + 3, ctag); });
     I8_STAMP(0);
     // end of k-step j: raw block j + 2 must have landed (k-step j + 3 may stay in flight), then everybody's is visible
     if (j + 2 < nk) wait_keep(j + 3 < nk ? 1 : 0);
     __syncthreads();
     I8_STAMP(2);
   }
-  i8_kstep<W, false, kQ>(dig0 + ((nk - 1) & 1) * C::DIG_BUF, ring, yring, dig0, lane, r, cq, A, st, [](auto) {});
+  i8_kstep<W, false, kQ, DIAG>(dig0 + ((nk - 1) & 1) * C::DIG_BUF, ring, yring, wring, dig0, lane, r, cq, A, st, [](auto) {});
   I8_STAMP_FLUSH(W);
   if (st.amax >= st.limit) ok = 0;
 #ifdef BLR_I8_EXP
@@ -475,6 +497,7 @@ __device__ __forceinline__ void i8_gram_stream(char* smem, const BLR_GLOBAL doub
 // =========================================================================================================
 // the kernel
 // =========================================================================================================
+template <bool DIAG>
 __global__ __launch_bounds__(kI8Threads, 2) void fused_i8_kernel(PosteriorArgs<double> a) {
   using T = double;
   using C = I8Cfg;
@@ -500,10 +523,18 @@ __global__ __launch_bounds__(kI8Threads, 2) void fused_i8_kernel(PosteriorArgs<d
   constexpr int D = 128;
   const double kNaN = __longlong_as_double(0x7ff8000000000000LL);
   const BLR_GLOBAL T* X = as_global(a.X + (int64_t)reg * a.strideX);
-  const BLR_GLOBAL T* y = as_global(a.y + (int64_t)reg * a.stridey);
+  // diagonal noise: x / sqrt(s_n), y / sqrt(s_n) take the places of x, y (unit noise from there on); i8_noise_prep_kernel has
+  // written y / sqrt(s) and 1 / sqrt(s), summed log s and flagged a variance that is not positive and finite
+  const BLR_GLOBAL T* y = DIAG ? as_global(a.i8_yt + (int64_t)reg * a.i8_stride) : as_global(a.y + (int64_t)reg * a.stridey);
+  const BLR_GLOBAL T* rwp = DIAG ? as_global(a.i8_rw + (int64_t)reg * a.i8_stride) : y;
   const BLR_GLOBAL T* mw = as_global(a.mw + (int64_t)reg * a.stridemw);
   const BLR_GLOBAL T* Lw = as_global(a.Lw + (int64_t)reg * a.strideLw);
-  const T s_iso = as_global(a.s + (int64_t)reg * a.strides)[0];
+  const T s_iso = DIAG ? T(1) : as_global(a.s + (int64_t)reg * a.strides)[0];
+  const double rwmax = DIAG ? a.i8_rwmax[reg] : 1.0;
+  if (DIAG && a.i8_bad[reg] != 0) {  // (uniform)  reference :79: the fp64 kernel reports the index
+    if (tid == 0) a.info[reg] = kI8Retry;
+    return;
+  }
 
   // A prior mean costs the stream nothing: with G = X X' exact, b = X (y - X'mw) / s = X y / s - (G / s) mw and
   // delta'delta / s = y'y / s - 2 mw'X y / s + mw'(G / s) mw come out of the finished matrix after the hand-over (below; G / s is
@@ -519,7 +550,7 @@ __global__ __launch_bounds__(kI8Threads, 2) void fused_i8_kernel(PosteriorArgs<d
     constexpr int W = decltype(wtag)::value;
     using PL = I8Plan<W>;
     i32x16 A[PL::NACC];
-    i8_gram_stream<W>(smem, X, y, a.ldx, N32, tid, A, st, ok);
+    i8_gram_stream<W, DIAG>(smem, X, y, rwp, rwmax, a.ldx, N32, tid, A, st, ok);
     I8_KSTAMP(4);
     // ---- hand-over: validity, digit row sums, b partials, row scales (all through the exchange area / the dead digit area)
     if (!ok) flag[0] = 0;  // (benign race: everybody writes the same value)
@@ -630,7 +661,8 @@ __global__ __launch_bounds__(kI8Threads, 2) void fused_i8_kernel(PosteriorArgs<d
     double* const tb = reinterpret_cast<double*>(smem + C::OFF_TAIL);  // [r][128], then y[r]
     int bad = 0;
     for (int e = tid; e < r * D; e += kI8Threads) {
-      const double v = X[(int64_t)(N32 + (e >> 7)) * a.ldx + (e & 127)];
+      double v = X[(int64_t)(N32 + (e >> 7)) * a.ldx + (e & 127)];
+      if constexpr (DIAG) v *= rwp[N32 + (e >> 7)];
       tb[e] = v;
       if (!(fabs(v) < __longlong_as_double(0x7ff0000000000000LL))) bad = 1;  // Inf / NaN: as in the stream, the fp64 kernel reports it
     }
@@ -710,7 +742,7 @@ __global__ __launch_bounds__(kI8Threads, 2) void fused_i8_kernel(PosteriorArgs<d
     }
     return;
   }
-  const double logdet_Sy = (double)N * log((double)s_iso);
+  const double logdet_Sy = DIAG ? a.i8_logdet[reg] : (double)N * log((double)s_iso);
   __syncthreads();
   if (a.Lw_post) {  // posterior precision Lw' = A, full symmetric (:92)
     T* out = a.Lw_post + (int64_t)reg * a.strideLp;
@@ -736,6 +768,36 @@ __global__ __launch_bounds__(kI8Threads, 2) void fused_i8_kernel(PosteriorArgs<d
     }
   }
   I8_KSTAMP(7);
+}
+
+// ---- diagonal noise: what the int8 route needs from s, once per call --------------------------------------------------------------
+// One workgroup per regressor: yt_n = y_n / sqrt(s_n), rw_n = 1 / sqrt(s_n), logdet = sum_n log s_n (fixed order), bad = some s_n is
+// not positive and finite (reference :79 cholesky(Sigma_y) throws: the fp64 kernel, which the regressor is handed to, reports it).
+__global__ __launch_bounds__(kThreads) void i8_noise_prep_kernel(const double* __restrict__ s, int64_t strides, const double* __restrict__ y,
+                                                                 int64_t stridey, int N, double* __restrict__ yt, double* __restrict__ rw,
+                                                                 int64_t stride, double* __restrict__ logdet, int32_t* __restrict__ bad,
+                                                                 double* __restrict__ rwmax) {
+  __shared__ double scr[8];
+  __shared__ int iscr[8];
+  const int reg = blockIdx.x, tid = threadIdx.x;
+  s += (int64_t)reg * strides; y += (int64_t)reg * stridey; yt += (int64_t)reg * stride; rw += (int64_t)reg * stride;
+  double ld = 0.0, rmax = 0.0;
+  int b = 0;
+  for (int n = tid; n < N; n += kThreads) {
+    const double sn = s[n];
+    const bool okn = sn > 0.0 && sn < __longlong_as_double(0x7ff0000000000000LL);
+    if (!okn) b = 1;
+    const double r = fast_rsqrt(okn ? sn : 1.0);
+    rw[n] = r;
+    rmax = r > rmax ? r : rmax;
+    yt[n] = y[n] * r;
+    ld += log(okn ? sn : 1.0);
+  }
+  ld = block_allreduce(ld, scr, tid);
+  b = -block_min_int(-b, iscr, tid);
+  // (max over the block through the integer minimum: positive doubles order like their bit patterns)
+  const int hi = -block_min_int(-__double2hiint(rmax), iscr, tid);
+  if (tid == 0) { logdet[reg] = ld; bad[reg] = b; rwmax[reg] = __hiloint2double(hi, -1); }
 }
 
 }  // namespace blr

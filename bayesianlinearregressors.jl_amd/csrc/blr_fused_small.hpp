@@ -125,6 +125,10 @@ struct PosteriorArgs {
   int D, N, B;
   int vec_ok;  // ColVecs, 16-byte aligned columns: vector loads allowed
   int retry_only;  // fused_small_kernel: take only the regressors whose info word says kI8Retry (follow-up of fused_i8_kernel)
+  // fused_i8_kernel<true> (diagonal noise), written by i8_noise_prep_kernel: y / sqrt(s) and 1 / sqrt(s), [B][N] at i8_stride each;
+  // sum_n log s_n and a flag (some s_n not positive / not finite: the fp64 kernel reports it) per regressor
+  const T* i8_yt; const T* i8_rw; int64_t i8_stride; const double* i8_logdet; const int32_t* i8_bad;
+  const double* i8_rwmax;  // max_n 1 / sqrt(s_n): the row bounds of the sliced values x / sqrt(s_n) are bounds of x times this
 };
 constexpr int kI8RetryCode = (int)0x80000007u;  // == kI8Retry (blr_fused_i8.hpp)
 

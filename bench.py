@@ -216,8 +216,8 @@ class Workload:
         t = "double" if self.dtype == "f64" else "float"
         if self.D == 64 or (self.D == 32 and self.dtype == "f64"):
             return f"fused_wave_kernel<{t}, {self.D // 16}>"  # one wavefront per regressor (diagonal prior, aligned ColVecs)
-        if self.D == 128 and self.dtype == "f64" and not self.diag and 512 <= self.N - self.N % 32 <= 16384 \
-                and os.environ.get("BLR_MI355X_NO_I8_GRAM") is None:
+        if self.D == 128 and self.dtype == "f64" and 512 <= self.N - self.N % 32 <= 16384 \
+                and os.environ.get("BLR_MI355X_NO_I8_GRAM") is None and not (self.diag and os.environ.get("BLR_MI355X_NO_I8_DIAG") is not None):
             return "fused_i8_kernel"  # Gram on the int8 matrix cores (blr_fused_i8.hpp); its retry pass is an empty launch here
         if self.D <= 128:
             return f"fused_small_kernel<{t}, {(self.D + 15) // 16}, 4>"  # MODE 4: ColVecs through LDS-DMA

@@ -2300,6 +2300,53 @@ def test_i8_gram_path_hands_back_what_it_cannot_do(B, opt):
     assert bad[3].tolist() == [1, 1, 1, 1, 78, 1, 1, 1] and np.all(np.isnan(bad[2]))
 
 
+@pytest.mark.parametrize("N", [512, 1055, 4096])
+@pytest.mark.parametrize("prior_mean", [False, True])
+def test_i8_gram_path_diagonal_noise(B, opt, N, prior_mean):
+    # Diagonal noise on the int8 route: x / sqrt(s_n), y / sqrt(s_n) are what is sliced (i8_noise_prep_kernel supplies 1 / sqrt(s),
+    # y / sqrt(s), sum log s).  Against the oracle, against the fp64 kernel (NO_I8_DIAG), bit-reproducible; a variance that is not
+    # positive sends ITS regressor to the fp64 kernel, which reports the reference's error (:79).
+    a = B._abi
+    h = a.default_handle()
+    rng = _rng(4600 + N + int(prior_mean))
+    nb, D = 5, 128
+    X, y = _i8_case(rng, nb, N, "gauss")
+    s = np.exp(rng.standard_normal((nb, N)))  # variances over two orders of magnitude
+    y = y + np.sqrt(s) * rng.standard_normal((nb, N))
+    dpr = np.exp(0.3 * rng.standard_normal((nb, D)))
+    mw = rng.standard_normal((nb, D)) if prior_mean else np.zeros((nb, D))
+
+    def run(svar):
+        mp = np.full((nb, D), 7.0); Tp = np.zeros((nb, D, D)); Ap = np.zeros((nb, D, D)); lp = np.zeros(nb); info = np.full(nb, 9, dtype=np.int32)
+        h.posterior_batched(np.float64, a.MEM_HOST, a.LAYOUT_COLVECS, nb, D, N, X, D, N * D, y, N, a.NOISE_DIAGONAL, svar, N, a.PRIOR_DIAGONAL,
+                            mw, D, dpr, 1, D, mp, D, Tp, D, D * D, Ap, D, D * D, lp, info)
+        return mp, Tp, Ap, lp, info
+
+    fast = run(s)
+    again = run(s)
+    for u, v in zip(fast, again):
+        np.testing.assert_array_equal(u, v)
+    opt("NO_I8_DIAG", "1")
+    slow = run(s)
+    opt("NO_I8_DIAG", None)
+    assert fast[4].tolist() == [0] * nb and slow[4].tolist() == [0] * nb
+    for b in range(nb):
+        mw_o, T_o, A_o, lp_o = O.posterior_logpdf_direct(mw[b], dpr[b], X[b].T, s[b], y[b])
+        dA = np.sqrt(np.diag(A_o))
+        for mp, Tp, Ap, lp, _ in (fast, slow):
+            assert lp[b] == pytest.approx(lp_o, rel=1e-10)
+            np.testing.assert_allclose(mp[b] * dA, mw_o * dA, rtol=1e-8, atol=1e-9 * np.abs(mw_o * dA).max())
+            assert (np.abs(Ap[b] - A_o) / np.outer(dA, dA)).max() <= 1e-12
+        assert fast[3][b] == pytest.approx(slow[3][b], rel=1e-10)
+    sbad = s.copy()
+    sbad[2, N // 2] = -1.0
+    f2, s2 = run(sbad), None
+    opt("NO_I8_DIAG", "1")
+    s2 = run(sbad)
+    assert f2[4].tolist() == s2[4].tolist() and f2[4][2] != 0 and f2[4][0] == 0
+    assert np.all(f2[0][2] == 7.0)  # failed regressor: outputs untouched
+
+
 def test_i8_gram_tail_columns_nonfinite_go_back_to_the_fp64_kernel(B, opt):
     # N = 1055: 32 whole k-steps through the int8 stream, 31 columns added in fp64 at the hand-over.  A NaN / Inf in THOSE columns
     # hands the regressor back like one in the stream does: status and bits of the fp64 kernel.

@@ -65,13 +65,13 @@ int main(int argc, char** argv) {
   using SC = SmallCfg<T, 8>;
   auto k64 = fused_small_kernel<T, 8, 4>;
   CK(hipFuncSetAttribute(reinterpret_cast<const void*>(k64), hipFuncAttributeMaxDynamicSharedMemorySize, SC::LDS_BYTES));
-  CK(hipFuncSetAttribute(reinterpret_cast<const void*>(fused_i8_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, I8Cfg::LDS_BYTES));
+  CK(hipFuncSetAttribute(reinterpret_cast<const void*>(fused_i8_kernel<false>), hipFuncAttributeMaxDynamicSharedMemorySize, I8Cfg::LDS_BYTES));
   const int stag_first = getenv("I8_STAG_FIRST") ? atoi(getenv("I8_STAG_FIRST")) : (B >= 1024 ? 256 : 0);
   const int stag_ticks = getenv("I8_STAG_TICKS") ? atoi(getenv("I8_STAG_TICKS")) : 25000;  // 250 us
   auto run_i8 = [&](bool lp_only) {
     PosteriorArgs<T> a = args(0);
     if (lp_only) { a.mw_post = nullptr; a.T_post = nullptr; }
-    hipLaunchKernelGGL(fused_i8_kernel, dim3(B), dim3(kI8Threads), I8Cfg::LDS_BYTES, 0, a);
+    hipLaunchKernelGGL(fused_i8_kernel<false>, dim3(B), dim3(kI8Threads), I8Cfg::LDS_BYTES, 0, a);
     a.retry_only = 1;
     hipLaunchKernelGGL(k64, dim3(B), dim3(kThreads), SC::LDS_BYTES, 0, a);
   };
@@ -84,7 +84,7 @@ int main(int argc, char** argv) {
   for (int r = 0; r < reps; ++r) run_i8(false);
   CK(hipEventRecord(e1)); CK(hipEventSynchronize(e1)); CK(hipEventElapsedTime(&ms_i8, e0, e1)); ms_i8 /= reps;
   { PosteriorArgs<T> a = args(0); a.Lw_post = o[0].Lp; a.ldlp = D; a.strideLp = D * D; a.B = BU;
-    hipLaunchKernelGGL(fused_i8_kernel, dim3(BU), dim3(kI8Threads), I8Cfg::LDS_BYTES, 0, a); a.retry_only = 1;
+    hipLaunchKernelGGL(fused_i8_kernel<false>, dim3(BU), dim3(kI8Threads), I8Cfg::LDS_BYTES, 0, a); a.retry_only = 1;
     hipLaunchKernelGGL(k64, dim3(BU), dim3(kThreads), SC::LDS_BYTES, 0, a); }
   run_f64(); CK(hipDeviceSynchronize());
   CK(hipEventRecord(e0));
@@ -97,7 +97,7 @@ int main(int argc, char** argv) {
     unsigned long long z[8][8] = {};
     CK(hipMemcpyToSymbol(HIP_SYMBOL(g_i8stamps), z, sizeof(z)));
     PosteriorArgs<T> a = args(0);
-    hipLaunchKernelGGL(fused_i8_kernel, dim3(B), dim3(kI8Threads), I8Cfg::LDS_BYTES, 0, a);
+    hipLaunchKernelGGL(fused_i8_kernel<false>, dim3(B), dim3(kI8Threads), I8Cfg::LDS_BYTES, 0, a);
     CK(hipDeviceSynchronize());
     CK(hipMemcpyFromSymbol(z, HIP_SYMBOL(g_i8stamps), sizeof(z)));
     const double nk = N / 32;
