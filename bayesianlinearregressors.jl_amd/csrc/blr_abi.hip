@@ -34,7 +34,7 @@ using namespace blr;
 // handle is created (BLR_MI355X_<KEY>), and settable per handle with blr_set_option: no getenv on any launch path.
 struct BlrOptions {
   bool no_ldsdma = false, no_wave_kernel = false, no_gram_ring = false, no_diag_split = false, no_xcd_swizzle = false,
-       no_mfma_project = false, plan_debug = false, no_i8_gram = false, no_marg_gemm = false, no_i8_diag = false;
+       no_mfma_project = false, plan_debug = false, no_i8_gram = false, no_marg_gemm = false, no_i8_diag = false, no_i8_factor = false;
   int wave_split = 0;     // waves per regressor of the wave kernel: 0 = router, else 1 | 2 | 4
   int chain_batch = 0;    // regressors per shared launch at D > 128: 0 = as many as the workspace holds
   long chain_ws_mb = 0;   // workspace bound of such a group in MiB: 0 = kChainWorkspace
@@ -56,6 +56,7 @@ struct BlrOptions {
     if (!strcmp(key, "NO_I8_GRAM")) return flag(no_i8_gram);
     if (!strcmp(key, "NO_MARG_GEMM")) return flag(no_marg_gemm);
     if (!strcmp(key, "NO_I8_DIAG")) return flag(no_i8_diag);
+    if (!strcmp(key, "NO_I8_FACTOR")) return flag(no_i8_factor);
     if (!strcmp(key, "WAVE_SPLIT")) {
       const int v = on ? atoi(value) : 0;
       wave_split = (v == 1 || v == 2 || v == 4) ? v : 0;
@@ -76,7 +77,7 @@ struct BlrOptions {
   }
   void from_environment() {
     for (const char* k : {"NO_LDSDMA", "NO_WAVE_KERNEL", "NO_GRAM_RING", "NO_DIAG_SPLIT", "NO_XCD_SWIZZLE", "NO_MFMA_PROJECT", "PLAN_DEBUG",
-                          "NO_I8_GRAM", "NO_MARG_GEMM", "NO_I8_DIAG", "WAVE_SPLIT", "CHAIN_BATCH", "CHAIN_WS_MB", "SWEEP", "GRAM_SPLITS"}) {
+                          "NO_I8_GRAM", "NO_MARG_GEMM", "NO_I8_DIAG", "NO_I8_FACTOR", "WAVE_SPLIT", "CHAIN_BATCH", "CHAIN_WS_MB", "SWEEP", "GRAM_SPLITS"}) {
       const std::string name = std::string("BLR_MI355X_") + k;
       if (const char* v = getenv(name.c_str())) (void)set(k, *v ? v : "1");  // (an empty variable still switches a flag on)
     }
@@ -398,7 +399,8 @@ int dispatch_fused_small(blr_handle* h, const PosteriorArgs<T>& a) {
   int NB = (a.D + 15) / 16;
   if constexpr (sizeof(T) == 8) {
     if (!h->opt.no_i8_gram && !h->opt.no_ldsdma && a.D == 128 && a.layout == BLR_LAYOUT_COLVECS && a.vec_ok &&
-        (a.noise_kind == BLR_NOISE_ISOTROPIC || (a.noise_kind == BLR_NOISE_DIAGONAL && !h->opt.no_i8_diag)) && a.prior_kind == BLR_PRIOR_DIAGONAL && a.N - a.N % I8Cfg::KC >= kI8MinN && a.N - a.N % I8Cfg::KC <= kI8MaxN && a.ldx * 8 * I8Cfg::KC < ((int64_t)1 << 31))
+        (a.noise_kind == BLR_NOISE_ISOTROPIC || (a.noise_kind == BLR_NOISE_DIAGONAL && !h->opt.no_i8_diag)) &&
+        (a.prior_kind == BLR_PRIOR_DIAGONAL || (a.prior_kind == BLR_PRIOR_UPPER_FACTOR && !h->opt.no_i8_factor)) && a.N - a.N % I8Cfg::KC >= kI8MinN && a.N - a.N % I8Cfg::KC <= kI8MaxN && a.ldx * 8 * I8Cfg::KC < ((int64_t)1 << 31))
       return launch_fused_i8(h, a);
   }
   if (!h->opt.no_wave_kernel && a.layout == BLR_LAYOUT_COLVECS && a.vec_ok && a.D == 16 * NB &&

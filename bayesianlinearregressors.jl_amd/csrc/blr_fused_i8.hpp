@@ -531,6 +531,7 @@ __global__ __launch_bounds__(kI8Threads, 2) void fused_i8_kernel(PosteriorArgs<d
   const BLR_GLOBAL T* Lw = as_global(a.Lw + (int64_t)reg * a.strideLw);
   const T s_iso = DIAG ? T(1) : as_global(a.s + (int64_t)reg * a.strides)[0];
   const double rwmax = DIAG ? a.i8_rwmax[reg] : 1.0;
+  const bool fac = a.prior_kind == PRIOR_UPPER_FACTOR;  // Lw is the upper factor U of the prior precision (PDMat / a carried-forward posterior): U'U joins at the hand-over
   if (DIAG && a.i8_bad[reg] != 0) {  // (uniform)  reference :79: the fp64 kernel reports the index
     if (tid == 0) a.info[reg] = kI8Retry;
     return;
@@ -616,7 +617,7 @@ __global__ __launch_bounds__(kI8Threads, 2) void fused_i8_kernel(PosteriorArgs<d
         const double g = sum * sctab[i] * scj;
         if (i >= j) {
           if constexpr (it.phase != 0) P[pidx(i, j)] += g;
-          else P[pidx(i, j)] = g + ((i == j) ? Lw[i] : T(0));
+          else P[pidx(i, j)] = g + ((i == j && !fac) ? Lw[i] : T(0));
           if (i == j) {  // (the data term alone: A_ii - Lw_i would lose it under a strong prior)
             if constexpr (it.phase != 0) gdiag[i] += g;
             else gdiag[i] = g;
@@ -719,20 +720,88 @@ __global__ __launch_bounds__(kI8Threads, 2) void fused_i8_kernel(PosteriorArgs<d
     bsum -= gm;
   }
   if (tid < D) bvec[tid] = (T)bsum;
-  // prior (diagonal): SPD check + logdet (reference :78), noise variance (reference :79)
+  // prior: SPD check + logdet (reference :78; a factor: its diagonal, logdet = 2 sum log U_kk), noise variance (reference :79)
   int info = 0;
   double logdet_Lw = 0.0;
   {
     double v = 0.0;
     int bad = 0x7fffffff;
     if (tid < D) {
-      const T dv = Lw[tid];
+      const T dv = fac ? Lw[(int64_t)tid * a.ldl + tid] : Lw[tid];
       if (dv > T(0)) v = log((double)dv);
       else bad = tid + 1;
     }
     bad = block_min_int(bad, iscr, tid);
     if (bad != 0x7fffffff) info = bad;
-    logdet_Lw = block_allreduce(v, scr, tid);
+    logdet_Lw = block_allreduce(v, scr, tid) * (fac ? 2.0 : 1.0);
+  }
+  if (fac && info == 0) {  // (uniform)
+    // A = U'U + G / s: the prior's part in fp64, after the prior-mean terms have been taken from the pure data matrix.  4 x 4 blocks
+    // of the lower triangle (528 of them on 256 threads), U staged sixteen rows at a time (zero above its diagonal, so that a
+    // term with k > min(i, j) vanishes), the next chunk's loads in flight while this one is multiplied.  ~7 % of an update.
+    double* const ub = reinterpret_cast<double*>(smem + C::OFF_TAIL);
+    constexpr int LU = 130;  // row stride of the staged chunk (16 x 128, padded)
+    int bi[3], bj[3];
+    double acc[3][16];
+#pragma unroll
+    for (int q = 0; q < 3; ++q) {
+      const int blk = tid + kThreads * q;
+      int i = -1, j = 0;
+      if (blk < 528) {
+        i = (int)((sqrtf(8.0f * (float)blk + 1.0f) - 1.0f) * 0.5f);
+        while ((i + 1) * (i + 2) / 2 <= blk) ++i;
+        while (i * (i + 1) / 2 > blk) --i;
+        j = blk - i * (i + 1) / 2;
+      }
+      bi[q] = i; bj[q] = j;
+#pragma unroll
+      for (int e = 0; e < 16; ++e) acc[q][e] = 0.0;
+    }
+    const int skk = tid & 15, sc0 = tid >> 4;  // staging: rows k0 + skk of columns sc0 + 16 u (16 consecutive doubles of a column per 16 threads)
+    double pre[8];
+    auto fetch = [&](int k0) {
+#pragma unroll
+      for (int u = 0; u < 8; ++u) {
+        const int c = sc0 + 16 * u, k = k0 + skk;
+        pre[u] = (k <= c) ? (double)Lw[(int64_t)c * a.ldl + k] : 0.0;
+      }
+    };
+    fetch(0);
+#pragma unroll 1
+    for (int k0 = 0; k0 < D; k0 += 16) {
+      __syncthreads();  // the previous chunk has been consumed
+#pragma unroll
+      for (int u = 0; u < 8; ++u) ub[skk * LU + sc0 + 16 * u] = pre[u];
+      if (k0 + 16 < D) fetch(k0 + 16);
+      __syncthreads();
+#pragma unroll
+      for (int q = 0; q < 3; ++q) {
+        if (bi[q] < 0 || k0 > 4 * bj[q] + 3) continue;  // (rows k > j of column j are zero)
+        const double* pa = ub + 4 * bi[q];
+        const double* pb = ub + 4 * bj[q];
+#pragma unroll 4
+        for (int kk = 0; kk < 16; ++kk) {
+          double av[4], bv[4];
+#pragma unroll
+          for (int e = 0; e < 4; ++e) { av[e] = pa[kk * LU + e]; bv[e] = pb[kk * LU + e]; }
+#pragma unroll
+          for (int rr = 0; rr < 4; ++rr)
+#pragma unroll
+            for (int cc = 0; cc < 4; ++cc) acc[q][4 * rr + cc] = __builtin_fma(av[rr], bv[cc], acc[q][4 * rr + cc]);
+        }
+      }
+    }
+#pragma unroll
+    for (int q = 0; q < 3; ++q) {
+      if (bi[q] < 0) continue;
+#pragma unroll
+      for (int rr = 0; rr < 4; ++rr)
+#pragma unroll
+        for (int cc = 0; cc < 4; ++cc) {
+          const int i = 4 * bi[q] + rr, j = 4 * bj[q] + cc;
+          if (j <= i) P[pidx(i, j)] += acc[q][4 * rr + cc];
+        }
+    }
   }
   if (info == 0 && !(s_iso > T(0))) info = 1;
   if (info != 0) {

@@ -2347,6 +2347,53 @@ def test_i8_gram_path_diagonal_noise(B, opt, N, prior_mean):
     assert np.all(f2[0][2] == 7.0)  # failed regressor: outputs untouched
 
 
+@pytest.mark.parametrize("N", [512, 1055])
+@pytest.mark.parametrize("prior_mean", [False, True])
+def test_i8_gram_path_factor_prior(B, opt, N, prior_mean):
+    # A prior given by its upper factor U (PDMat / a carried-forward posterior) on the int8 route: U'U joins the finished data matrix
+    # in fp64 at the hand-over, after the prior-mean terms have been taken from the pure data matrix.  Against the oracle and the
+    # fp64 kernel (NO_I8_FACTOR); in place (T_post == Lw, mw_post == mw) as blr_update_factor_* uses it; a factor with a
+    # non-positive diagonal entry reports its index.
+    a = B._abi
+    h = a.default_handle()
+    rng = _rng(4700 + N + int(prior_mean))
+    nb, D = 4, 128
+    X, y = _i8_case(rng, nb, N, "gauss")
+    mw = rng.standard_normal((nb, D)) if prior_mean else np.zeros((nb, D))
+    Lw = np.empty((nb, D, D)); Uc = np.empty((nb, D, D))
+    for b in range(nb):
+        Bm = rng.standard_normal((D, D)) / np.sqrt(D)
+        Lw[b] = Bm @ Bm.T + np.exp(rng.standard_normal()) * np.eye(D)
+        Uc[b] = O.chol_upper(Lw[b]).T  # column-major storage of U
+    s = np.array([0.1])
+
+    def run(U_in, mw_in):
+        mp = np.full((nb, D), 7.0); Tp = np.zeros((nb, D, D)); Ap = np.zeros((nb, D, D)); lp = np.zeros(nb); info = np.full(nb, 9, dtype=np.int32)
+        h.posterior_batched(np.float64, a.MEM_HOST, a.LAYOUT_COLVECS, nb, D, N, X, D, N * D, y, N, a.NOISE_ISOTROPIC, s, 0, a.PRIOR_UPPER_FACTOR,
+                            mw_in, D, U_in, D, D * D, mp, D, Tp, D, D * D, Ap, D, D * D, lp, info)
+        return mp, Tp, Ap, lp, info
+
+    fast = run(Uc, mw)
+    opt("NO_I8_FACTOR", "1")
+    slow = run(Uc, mw)
+    opt("NO_I8_FACTOR", None)
+    assert fast[4].tolist() == [0] * nb and slow[4].tolist() == [0] * nb
+    for b in range(nb):
+        mw_o, T_o, A_o, lp_o = O.posterior_logpdf_direct(mw[b], Lw[b], X[b].T, 0.1, y[b])
+        dA = np.sqrt(np.diag(A_o))
+        for mp, Tp, Ap, lp, _ in (fast, slow):
+            assert lp[b] == pytest.approx(lp_o, rel=1e-10)
+            np.testing.assert_allclose(mp[b] * dA, mw_o * dA, rtol=1e-8, atol=1e-9 * np.abs(mw_o * dA).max())
+            assert (np.abs(Ap[b] - A_o) / np.outer(dA, dA)).max() <= 1e-12
+            Tn = np.triu(Tp[b].T)
+            assert (np.abs(Tn.T @ Tn - A_o) / np.outer(dA, dA)).max() <= 1e-10
+        assert fast[3][b] == pytest.approx(slow[3][b], rel=1e-10)
+    Ubad = Uc.copy()
+    Ubad[1, 40, 40] = -Ubad[1, 40, 40]
+    fb = run(Ubad, mw)
+    assert fb[4].tolist() == [0, 41, 0, 0] and np.all(fb[0][1] == 7.0)
+
+
 def test_i8_gram_tail_columns_nonfinite_go_back_to_the_fp64_kernel(B, opt):
     # N = 1055: 32 whole k-steps through the int8 stream, 31 columns added in fp64 at the hand-over.  A NaN / Inf in THOSE columns
     # hands the regressor back like one in the stream does: status and bits of the fp64 kernel.

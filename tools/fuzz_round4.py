@@ -65,6 +65,16 @@ def i8(rng, case):
         X[0, N // 3, 7] *= 1e4  # breaks its row's bound: that regressor goes back to the fp64 kernel
     mw = rng.standard_normal((nb, D)) / scale[None, :] if rng.random() < 0.6 else np.zeros((nb, D))
     dpr = np.exp(0.3 * rng.standard_normal((nb, D))) / scale[None, :] ** 2
+    factor = rng.random() < 0.35  # a prior given by its upper factor U (U'U joins at the hand-over)
+    Lw_o = [np.diag(dpr[b]) for b in range(nb)]
+    prior_arg, pk, ldl, strideL = dpr, _abi.PRIOR_DIAGONAL, 1, D
+    if factor:
+        Uc = np.empty((nb, D, D))
+        for b in range(nb):
+            Bm = rng.standard_normal((D, D)) / np.sqrt(D) / scale[None, :]
+            Lw_o[b] = Bm.T @ Bm + np.diag(dpr[b])
+            Uc[b] = O.chol_upper(Lw_o[b]).T
+        prior_arg, pk, ldl, strideL = Uc, _abi.PRIOR_UPPER_FACTOR, D, D * D
     diag = rng.random() < 0.4
     s = np.exp(rng.choice([0.3, 1.0, 2.0]) * rng.standard_normal((nb, N))) if diag else np.array([0.1])
     if diag:
@@ -72,16 +82,16 @@ def i8(rng, case):
     mp = np.zeros((nb, D)); Tp = np.zeros((nb, D, D)); Ap = np.zeros((nb, D, D)); lp = np.zeros(nb); info = np.full(nb, 9, dtype=np.int32)
     h = _abi.default_handle()
     h.posterior_batched(np.float64, _abi.MEM_HOST, _abi.LAYOUT_COLVECS, nb, D, N, X, D, N * D, y, N, _abi.NOISE_DIAGONAL if diag else _abi.NOISE_ISOTROPIC,
-                        s, N if diag else 0, _abi.PRIOR_DIAGONAL, mw, D, dpr, 1, D, mp, D, Tp, D, D * D, Ap, D, D * D, lp, info)
+                        s, N if diag else 0, pk, mw, D, prior_arg, ldl, strideL, mp, D, Tp, D, D * D, Ap, D, D * D, lp, info)
     assert np.all(info == 0), (case, info)
     for b in range(nb):
-        mw_o, T_o, A_o, lp_o = O.posterior_logpdf_direct(mw[b], dpr[b], X[b].T, s[b] if diag else 0.1, y[b])
+        mw_o, T_o, A_o, lp_o = O.posterior_logpdf_direct(mw[b], Lw_o[b] if factor else dpr[b], X[b].T, s[b] if diag else 0.1, y[b])
         dA = np.sqrt(np.diag(A_o))
         # (the evidence is a difference of terms of size y'y / s: an injected outlier makes them 1e6 times the evidence itself)
         assert abs(lp[b] - lp_o) <= 2e-10 * abs(lp_o) + 1e-12 * float((y[b] * y[b] / (s[b] if diag else 0.1)).sum()) * max(1.0, float(np.abs(X[b]).max() / np.abs(X[b]).mean()) ** 2 / 1e4), (case, b, lp[b], lp_o)
         assert (np.abs(Ap[b] - A_o) / np.outer(dA, dA)).max() <= (1e-11 if diag else 1e-12), case
         np.testing.assert_allclose(mp[b] * dA, mw_o * dA, rtol=1e-7, atol=1e-8 * np.abs(mw_o * dA).max(), err_msg=f"case {case}")
-    return f"N={N} B={nb} mw={'yes' if np.any(mw) else 'no'} scaled={'yes' if np.any(scale != 1) else 'no'} noise={'diag' if diag else 'iso'}"
+    return f"N={N} B={nb} mw={'yes' if np.any(mw) else 'no'} scaled={'yes' if np.any(scale != 1) else 'no'} noise={'diag' if diag else 'iso'} prior={'factor' if factor else 'diag'}"
 
 
 def multi(rng, case):
