@@ -34,7 +34,7 @@ using namespace blr;
 // handle is created (BLR_MI355X_<KEY>), and settable per handle with blr_set_option: no getenv on any launch path.
 struct BlrOptions {
   bool no_ldsdma = false, no_wave_kernel = false, no_gram_ring = false, no_diag_split = false, no_xcd_swizzle = false,
-       no_mfma_project = false, plan_debug = false, no_i8_gram = false, no_marg_gemm = false, no_i8_diag = false, no_i8_factor = false;
+       no_mfma_project = false, plan_debug = false, no_i8_gram = false, no_marg_gemm = false, no_i8_diag = false, no_i8_factor = false, no_i8_rowvecs = false;
   int wave_split = 0;     // waves per regressor of the wave kernel: 0 = router, else 1 | 2 | 4
   int chain_batch = 0;    // regressors per shared launch at D > 128: 0 = as many as the workspace holds
   long chain_ws_mb = 0;   // workspace bound of such a group in MiB: 0 = kChainWorkspace
@@ -57,6 +57,7 @@ struct BlrOptions {
     if (!strcmp(key, "NO_MARG_GEMM")) return flag(no_marg_gemm);
     if (!strcmp(key, "NO_I8_DIAG")) return flag(no_i8_diag);
     if (!strcmp(key, "NO_I8_FACTOR")) return flag(no_i8_factor);
+    if (!strcmp(key, "NO_I8_ROWVECS")) return flag(no_i8_rowvecs);
     if (!strcmp(key, "WAVE_SPLIT")) {
       const int v = on ? atoi(value) : 0;
       wave_split = (v == 1 || v == 2 || v == 4) ? v : 0;
@@ -351,10 +352,11 @@ int launch_fused_wave(blr_handle* h, const PosteriorArgs<T>& a) {
 // (a row bound broken, non-finite input): every regressor leaves with the status and the numbers of an
 // fp64-accurate update, none is computed twice on the fast path.
 int launch_fused_i8(blr_handle* h, const PosteriorArgs<double>& a) {
-  const bool diag = a.noise_kind == BLR_NOISE_DIAGONAL;
-  int rc = set_lds_once(h, reinterpret_cast<const void*>(fused_i8_kernel<false>), (size_t)I8Cfg::LDS_BYTES);
+  const bool diag = a.noise_kind == BLR_NOISE_DIAGONAL, rowv = a.layout == BLR_LAYOUT_ROWVECS;
+  void (*const kern)(PosteriorArgs<double>) = diag ? (rowv ? fused_i8_kernel<true, true> : fused_i8_kernel<true, false>)
+                                                   : (rowv ? fused_i8_kernel<false, true> : fused_i8_kernel<false, false>);
+  int rc = set_lds_once(h, reinterpret_cast<const void*>(kern), (size_t)I8Cfg::LDS_BYTES);
   if (rc) return rc;
-  if (diag && (rc = set_lds_once(h, reinterpret_cast<const void*>(fused_i8_kernel<true>), (size_t)I8Cfg::LDS_BYTES))) return rc;
   // diagonal noise: y / sqrt(s), 1 / sqrt(s), sum log s and a validity flag per regressor, once per call, in the handle's side
   // buffer (16 bytes per observation: slices of at most 1 GiB)
   const int64_t per_reg = 2 * (int64_t)a.N * (int64_t)sizeof(double);
@@ -383,13 +385,11 @@ int launch_fused_i8(blr_handle* h, const PosteriorArgs<double>& a) {
       s.i8_yt = yt; s.i8_rw = rw; s.i8_stride = a.N; s.i8_logdet = ld; s.i8_bad = bad; s.i8_rwmax = rmx;
       hipLaunchKernelGGL(i8_noise_prep_kernel, dim3(nb), dim3(kThreads), 0, h->stream, s.s, a.strides, s.y, a.stridey, (int)a.N, yt, rw, (int64_t)a.N, ld,
                          bad, rmx);
-      hipLaunchKernelGGL(fused_i8_kernel<true>, dim3(nb), dim3(kI8Threads), I8Cfg::LDS_BYTES, h->stream, s);
-    } else {
-      hipLaunchKernelGGL(fused_i8_kernel<false>, dim3(nb), dim3(kI8Threads), I8Cfg::LDS_BYTES, h->stream, s);
     }
+    hipLaunchKernelGGL(kern, dim3(nb), dim3(kI8Threads), I8Cfg::LDS_BYTES, h->stream, s);
     HIP_TRY(h, hipGetLastError());
     s.retry_only = 1;
-    if ((rc = launch_fused_small<double, 8, 4>(h, s))) return rc;
+    if ((rc = launch_fused_small_mode<double, 8>(h, s))) return rc;
   }
   return 0;
 }
@@ -398,7 +398,11 @@ template <typename T>
 int dispatch_fused_small(blr_handle* h, const PosteriorArgs<T>& a) {
   int NB = (a.D + 15) / 16;
   if constexpr (sizeof(T) == 8) {
-    if (!h->opt.no_i8_gram && !h->opt.no_ldsdma && a.D == 128 && a.layout == BLR_LAYOUT_COLVECS && a.vec_ok &&
+    // (RowVecs: a feature's 32 observations of a k-step are 16 DMA lanes of 16 bytes: rows and regressors 16-byte aligned)
+    const bool i8_layout = a.layout == BLR_LAYOUT_COLVECS
+                               ? a.vec_ok
+                               : (!h->opt.no_i8_rowvecs && ((uintptr_t)a.X & 15) == 0 && (a.ldx & 1) == 0 && (a.B == 1 || (a.strideX & 1) == 0));
+    if (!h->opt.no_i8_gram && !h->opt.no_ldsdma && a.D == 128 && i8_layout &&
         (a.noise_kind == BLR_NOISE_ISOTROPIC || (a.noise_kind == BLR_NOISE_DIAGONAL && !h->opt.no_i8_diag)) &&
         (a.prior_kind == BLR_PRIOR_DIAGONAL || (a.prior_kind == BLR_PRIOR_UPPER_FACTOR && !h->opt.no_i8_factor)) && a.N - a.N % I8Cfg::KC >= kI8MinN && a.N - a.N % I8Cfg::KC <= kI8MaxN && a.ldx * 8 * I8Cfg::KC < ((int64_t)1 << 31))
       return launch_fused_i8(h, a);

@@ -185,17 +185,34 @@ struct I8Slice {
 //   x + C: rounded to a multiple of 2^(e_r - 47), its integer Q in the low mantissa bits; bytes 0..3 of Q are bytes 0..3 of the
 //   low word, bytes 4, 5 are bytes 0, 1 of the high word; slice s holds byte 5 - s.  4 x 4 byte transposition of a column quad
 //   with v_perm_b32 (D = perm(S0, S1, sel): selector values 0-3 take bytes of S1, 4-7 bytes of S0).
-template <bool WITH_Q, bool DIAG = false>
+// ROWV: the inputs are RowVecs (N x D column-major: a feature's values over the observations are contiguous).  A k-step's raw block
+// is then 32 LDS-DMA pieces of FOUR rows d = 4 p .. 4 p + 3 x 32 observations (16 lanes x 16 bytes per row), and within piece p the pair
+// of observations l16 of row q sits at 16-byte position ((l16 + p) mod 16) 4 + q: a wave reads one pair for 64 consecutive rows,
+// and the rotation by p puts the 16 lanes of every ds_read_b128 group on 16 different slots of the 256-byte bank row.
+template <bool WITH_Q, bool DIAG = false, bool ROWV = false>
 struct I8SliceSteps {
   double x[2][4], y[2][4];  // two column quads: the second quad's LDS reads are in flight while the first is sliced
   double w[DIAG ? 2 : 1][4];  // diagonal noise: 1 / sqrt(s_n) of the columns (x enters the Gram matrix as x / sqrt(s_n), y as y / sqrt(s_n))
   unsigned lo[4], hi[4], u[6], p[2][6];
   template <int Q>
   __device__ __forceinline__ void load(const char* __restrict__ raw, const double* __restrict__ yb, const double* __restrict__ wb, int r, int cq) {
-    const double* col = reinterpret_cast<const double*>(raw) + (cq * 8 + 4 * Q) * 128 + r;
+    if constexpr (ROWV) {
+      typedef double d2 __attribute__((ext_vector_type(2)));
+      const int p = r >> 2, q = r & 3;
+#pragma unroll
+      for (int hh = 0; hh < 2; ++hh) {
+        const int l16 = cq * 4 + 2 * Q + hh;
+        const d2 v = *reinterpret_cast<const d2*>(raw + p * 1024 + ((((l16 + p) & 15) << 2) + q) * 16);
+        x[Q][2 * hh] = v[0];
+        x[Q][2 * hh + 1] = v[1];
+      }
+    } else {
+      const double* col = reinterpret_cast<const double*>(raw) + (cq * 8 + 4 * Q) * 128 + r;
+#pragma unroll
+      for (int j = 0; j < 4; ++j) x[Q][j] = col[j * 128];
+    }
 #pragma unroll
     for (int j = 0; j < 4; ++j) {
-      x[Q][j] = col[j * 128];
       y[Q][j] = yb[cq * 8 + 4 * Q + j];  // (y: one address per wave, a broadcast)
       if constexpr (DIAG) w[Q][j] = wb[cq * 8 + 4 * Q + j];
     }
@@ -290,7 +307,7 @@ __device__ __forceinline__ void glds_s_4x1k(uint64_t saddr_uniform, unsigned vof
 // sched_group_barrier does not move them: the slicing hangs off LDS reads the group solver leaves where they are).  So the
 // k-step is a compile-time list: MFMA i, then (fenced with sched_barrier) the fragment reads MFMA i + 2 is the first to need
 // and the slicing chunks whose turn it is -- reads of the raw columns first, their arithmetic two MFMAs later.
-template <int W, bool SLICE, bool WITH_Q, bool DIAG, typename IssueFn>
+template <int W, bool SLICE, bool WITH_Q, bool DIAG, bool ROWV, typename IssueFn>
 __device__ __forceinline__ void i8_kstep(const char* __restrict__ dig, const char* __restrict__ raw, const double* __restrict__ yb,
                                          const double* __restrict__ wb, char* __restrict__ dign, int lane, int r, int cq, i32x16 (&A)[I8Plan<W>::NACC], I8Slice& st,
                                          IssueFn issue_next) {
@@ -299,7 +316,7 @@ __device__ __forceinline__ void i8_kstep(const char* __restrict__ dig, const cha
   constexpr int NCH = kI8SliceChunks;
   constexpr int LEAD = 2;   // a fragment is requested this many MFMAs before its first use
   i32x4 F[4][6];            // fragment (row block, slice): only the ones this wave uses ever get registers
-  I8SliceSteps<WITH_Q, DIAG> sl;
+  I8SliceSteps<WITH_Q, DIAG, ROWV> sl;
   auto frag_load_one = [&](auto itag, auto qtag) {
     constexpr int i = decltype(itag)::value, q = decltype(qtag)::value, rb = q / 6, sidx = q % 6;
     constexpr int fu = PL::first_use(rb, sidx);
@@ -357,7 +374,7 @@ __device__ __forceinline__ void i8_kstep(const char* __restrict__ dig, const cha
 }
 
 // ---- the stream: on exit the wave's accumulators and the slicing state --------------------------------------------------------------
-template <int W, bool DIAG>
+template <int W, bool DIAG, bool ROWV>
 __device__ __forceinline__ void i8_gram_stream(char* smem, const BLR_GLOBAL double* X /*uniform*/, const BLR_GLOBAL double* y /*uniform*/,
                                                const BLR_GLOBAL double* rw /*uniform; DIAG: 1 / sqrt(s_n)*/, double rwmax, int64_t ldx, int N, int tid, i32x16 (&A)[I8Plan<W>::NACC], I8Slice& st, int& ok) {
   using C = I8Cfg;
@@ -374,7 +391,13 @@ __device__ __forceinline__ void i8_gram_stream(char* smem, const BLR_GLOBAL doub
   unsigned ring_addr = lds_addr_of(ring), y_addr = lds_addr_of(yring), w_addr = lds_addr_of(wring);
   asm volatile("" : "+v"(ring_addr), "+v"(y_addr), "+v"(w_addr));
   const uint64_t colbytes = (uint64_t)ldx * 8u;
-  uint64_t nextX = (uint64_t)(uintptr_t)X + (uint64_t)(4 * W) * colbytes;  // this wave's four columns of the k-step being issued
+  // ColVecs: this wave's four columns of the k-step being issued.  RowVecs: the k-step's 32 observations of row 0; piece c of
+  // this wave = rows 4 (4 W + c) .. + 3 (colbytes = the distance between two rows), lane -> (row lane & 3, pair of observations
+  // ((lane >> 2) - piece) mod 16): the rotation of the LDS image (I8SliceSteps)
+  uint64_t nextX = (uint64_t)(uintptr_t)X + (ROWV ? (uint64_t)0 : (uint64_t)(4 * W) * colbytes);
+  unsigned voffR[4];
+#pragma unroll
+  for (int c = 0; c < 4; ++c) voffR[c] = (unsigned)(lane & 3) * (unsigned)colbytes + (unsigned)((((lane >> 2) - (4 * W + c)) & 15) * 16);
   uint64_t nextY = (uint64_t)(uintptr_t)y;
   uint64_t nextW = (uint64_t)(uintptr_t)rw;
   const unsigned voff = (unsigned)lane * 16u;
@@ -387,11 +410,12 @@ __device__ __forceinline__ void i8_gram_stream(char* smem, const BLR_GLOBAL doub
 #endif
     if constexpr (c < 4) {
       const unsigned slot = ring_addr + (unsigned)((t % C::NSLOT) * C::SLOT_BYTES) + (unsigned)((4 * W + c) * 1024);
-      glds_s<16>(uni((int64_t)(nextX + (uint64_t)c * colbytes)), voff, slot);
+      if constexpr (ROWV) glds_s<16>(uni((int64_t)(nextX + (uint64_t)(4 * (4 * W + c)) * colbytes)), voffR[c], slot);
+      else glds_s<16>(uni((int64_t)(nextX + (uint64_t)c * colbytes)), voff, slot);
     } else {
       if constexpr (W == 0) glds_s<4, 64>(uni((int64_t)nextY), (unsigned)lane * 4u, y_addr + (unsigned)((t % C::NSLOT) * C::KC * 8));
       if constexpr (DIAG && W == 1) glds_s<4, 64>(uni((int64_t)nextW), (unsigned)lane * 4u, w_addr + (unsigned)((t % C::NSLOT) * C::KC * 8));
-      nextX += (uint64_t)C::KC * colbytes;
+      nextX += ROWV ? (uint64_t)C::KC * 8u : (uint64_t)C::KC * colbytes;
       nextY += (uint64_t)C::KC * 8u;
       nextW += (uint64_t)C::KC * 8u;
     }
@@ -422,11 +446,23 @@ __device__ __forceinline__ void i8_gram_stream(char* smem, const BLR_GLOBAL doub
   {
     unsigned m = 0;
     for (int t = 0; t < nissue0; ++t) {
-      const double* col = reinterpret_cast<const double*>(ring + t * C::SLOT_BYTES) + (cq * 8) * 128 + r;
+      if constexpr (ROWV) {
+        typedef double d2 __attribute__((ext_vector_type(2)));
+        const int p = r >> 2, q = r & 3;
 #pragma unroll
-      for (int j = 0; j < 8; ++j) {
-        const unsigned ax = (unsigned)__double2hiint(col[j * 128]) & 0x7fffffffu;
-        m = ax > m ? ax : m;
+        for (int hh = 0; hh < 4; ++hh) {
+          const d2 v = *reinterpret_cast<const d2*>(ring + t * C::SLOT_BYTES + p * 1024 + ((((cq * 4 + hh + p) & 15) << 2) + q) * 16);
+          const unsigned a0 = (unsigned)__double2hiint(v[0]) & 0x7fffffffu, a1 = (unsigned)__double2hiint(v[1]) & 0x7fffffffu;
+          m = a0 > m ? a0 : m;
+          m = a1 > m ? a1 : m;
+        }
+      } else {
+        const double* col = reinterpret_cast<const double*>(ring + t * C::SLOT_BYTES) + (cq * 8) * 128 + r;
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+          const unsigned ax = (unsigned)__double2hiint(col[j * 128]) & 0x7fffffffu;
+          m = ax > m ? ax : m;
+        }
       }
     }
     xch[cq * 128 + r] = (int)m;
@@ -457,7 +493,7 @@ __device__ __forceinline__ void i8_gram_stream(char* smem, const BLR_GLOBAL doub
   }
   constexpr bool kQ = (W & 1) == 0;  // (rows 64 (W & 1) + lane: row 0 lives in the even waves)
   {  // block 0 -> digit buffer 0 (nothing to overlap with yet)
-    I8SliceSteps<kQ, DIAG> sl;
+    I8SliceSteps<kQ, DIAG, ROWV> sl;
     auto rec = [&](auto self, auto ctag) -> void {
       constexpr int c = decltype(ctag)::value;
       if constexpr (c < kI8SliceChunks) {
@@ -479,14 +515,14 @@ __device__ __forceinline__ void i8_gram_stream(char* smem, const BLR_GLOBAL doub
     const double* yb = yring + ((j + 1) % C::NSLOT) * C::KC;
     const double* wb = wring + ((j + 1) % C::NSLOT) * C::KC;
     // k-step j + 3 goes into the slot of block j, which everybody has sliced before the barrier that ended k-step j - 1
-    i8_kstep<W, true, kQ, DIAG>(dig, raw, yb, wb, dign, lane, r, cq, A, st, [&](auto ctag) { if (j + 3 < nk) issue_piece(j + 3, ctag); });
+    i8_kstep<W, true, kQ, DIAG, ROWV>(dig, raw, yb, wb, dign, lane, r, cq, A, st, [&](auto ctag) { if (j + 3 < nk) issue_piece(j + 3, ctag); });
     I8_STAMP(0);
     // end of k-step j: raw block j + 2 must have landed (k-step j + 3 may stay in flight), then everybody's is visible
     if (j + 2 < nk) wait_keep(j + 3 < nk ? 1 : 0);
     __syncthreads();
     I8_STAMP(2);
   }
-  i8_kstep<W, false, kQ, DIAG>(dig0 + ((nk - 1) & 1) * C::DIG_BUF, ring, yring, wring, dig0, lane, r, cq, A, st, [](auto) {});
+  i8_kstep<W, false, kQ, DIAG, ROWV>(dig0 + ((nk - 1) & 1) * C::DIG_BUF, ring, yring, wring, dig0, lane, r, cq, A, st, [](auto) {});
   I8_STAMP_FLUSH(W);
   if (st.amax >= st.limit) ok = 0;
 #ifdef BLR_I8_EXP
@@ -497,7 +533,7 @@ __device__ __forceinline__ void i8_gram_stream(char* smem, const BLR_GLOBAL doub
 // =========================================================================================================
 // the kernel
 // =========================================================================================================
-template <bool DIAG>
+template <bool DIAG, bool ROWV = false>
 __global__ __launch_bounds__(kI8Threads, 2) void fused_i8_kernel(PosteriorArgs<double> a) {
   using T = double;
   using C = I8Cfg;
@@ -551,7 +587,7 @@ __global__ __launch_bounds__(kI8Threads, 2) void fused_i8_kernel(PosteriorArgs<d
     constexpr int W = decltype(wtag)::value;
     using PL = I8Plan<W>;
     i32x16 A[PL::NACC];
-    i8_gram_stream<W, DIAG>(smem, X, y, rwp, rwmax, a.ldx, N32, tid, A, st, ok);
+    i8_gram_stream<W, DIAG, ROWV>(smem, X, y, rwp, rwmax, a.ldx, N32, tid, A, st, ok);
     I8_KSTAMP(4);
     // ---- hand-over: validity, digit row sums, b partials, row scales (all through the exchange area / the dead digit area)
     if (!ok) flag[0] = 0;  // (benign race: everybody writes the same value)
@@ -662,7 +698,7 @@ __global__ __launch_bounds__(kI8Threads, 2) void fused_i8_kernel(PosteriorArgs<d
     double* const tb = reinterpret_cast<double*>(smem + C::OFF_TAIL);  // [r][128], then y[r]
     int bad = 0;
     for (int e = tid; e < r * D; e += kI8Threads) {
-      double v = X[(int64_t)(N32 + (e >> 7)) * a.ldx + (e & 127)];
+      double v = ROWV ? X[(int64_t)(e & 127) * a.ldx + N32 + (e >> 7)] : X[(int64_t)(N32 + (e >> 7)) * a.ldx + (e & 127)];
       if constexpr (DIAG) v *= rwp[N32 + (e >> 7)];
       tb[e] = v;
       if (!(fabs(v) < __longlong_as_double(0x7ff0000000000000LL))) bad = 1;  // Inf / NaN: as in the stream, the fp64 kernel reports it

@@ -70,7 +70,7 @@ int blr_reset_stream(blr_handle* h);              /* back to the handle's own (n
 int blr_set_async(blr_handle* h, int async);      /* 1: DEVICE-memspace calls return after enqueue       */
 int blr_synchronize(blr_handle* h);
 /* Run-time switches of the handle (A/B measurements and tests; the defaults are the measured best).  `key` is one of NO_LDSDMA,
- * NO_WAVE_KERNEL, NO_GRAM_RING, NO_DIAG_SPLIT, NO_XCD_SWIZZLE, NO_MFMA_PROJECT, NO_I8_GRAM, NO_I8_DIAG, NO_I8_FACTOR, NO_MARG_GEMM, PLAN_DEBUG (flags: any non-empty value = on),
+ * NO_WAVE_KERNEL, NO_GRAM_RING, NO_DIAG_SPLIT, NO_XCD_SWIZZLE, NO_MFMA_PROJECT, NO_I8_GRAM, NO_I8_DIAG, NO_I8_FACTOR, NO_I8_ROWVECS, NO_MARG_GEMM, PLAN_DEBUG (flags: any non-empty value = on),
  * WAVE_SPLIT = 1|2|4, CHAIN_BATCH = 1..128, CHAIN_WS_MB, SWEEP = always|never|auto, GRAM_SPLITS = "o,d[,nlong]" (README.md);
  * a "BLR_MI355X_" prefix is accepted.  value NULL or "" restores the built-in default.  The environment variables
  * BLR_MI355X_<KEY> are read ONCE, by blr_create -- no entry point reads the environment.  -> 0, or -2 / -3 (unknown key /
@@ -106,7 +106,7 @@ int blr_timer_stop(blr_handle* h, float* elapsed_ms); /* records, synchronises, 
  * Lw + i*strideLw and writes the outputs at their strides; a stride of 0 shares an input.
  * Numerics: results are bit-reproducible from call to call (fixed accumulation order, no floating-point atomics).  fp64
  * accuracy against the reference's op sequence in LAPACK: evidence 1e-10 relative, mw', T, Lw' 1e-9 (tests/test_gpu_parity.py).
- * One shape takes a different route to the same numbers: D = 128, aligned ColVecs, isotropic or diagonal noise, diagonal or upper-factor prior,
+ * One shape takes a different route to the same numbers: D = 128, aligned ColVecs or RowVecs (16-byte aligned rows), isotropic or diagonal noise, diagonal or upper-factor prior,
  * 512 <= N <= 16384 (+ a last partial block of up to 31 columns, added in fp64) forms X X' on the int8 matrix cores from an exact 48-bit splitting of the inputs (per-row
  * power-of-two scales; csrc/blr_fused_i8.hpp) -- entries of Lw' within 1e-13 of sqrt(Lw'_ii Lw'_jj) instead of a few ulp of
  * themselves, everything after the Gram matrix in fp64 as elsewhere; a regressor whose rows outgrow their scale is redone on

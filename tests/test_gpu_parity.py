@@ -2394,6 +2394,75 @@ def test_i8_gram_path_factor_prior(B, opt, N, prior_mean):
     assert fb[4].tolist() == [0, 41, 0, 0] and np.all(fb[0][1] == 7.0)
 
 
+@pytest.mark.parametrize("kind", ["gauss", "scales", "outlier"])
+@pytest.mark.parametrize("N,noise,prior", [(512, "iso", "diag"), (543, "diag", "diag"), (4127, "iso", "factor"), (1055, "diag", "factor")])
+def test_i8_gram_path_rowvecs(B, opt, kind, N, noise, prior):
+    # RowVecs inputs (N x D column-major, lda >= N: src/bayesian_linear_regression.jl's X' handed over as stored) on the int8 route:
+    # the stream gathers four feature rows per LDS-DMA piece instead of four columns, everything after the raw block is the ColVecs
+    # code -- so the RowVecs call must give the BITS of the ColVecs call on the transposed copy (prior mean, ragged N, diagonal noise,
+    # factor prior, a handed-back regressor included), and the oracle's numbers.  Rows that are not 16-byte aligned (odd lda) and
+    # NO_I8_ROWVECS take the fp64 kernel: same numbers at its tolerances.
+    a = B._abi
+    h = a.default_handle()
+    rng = _rng(4800 + N + len(kind))
+    nb, D = 4, 128
+    X, y = _i8_case(rng, nb, N, kind)
+    mw = rng.standard_normal((nb, D)) / (np.ldexp(1.0, (np.arange(D) % 7) * 4 - 12) if kind == "scales" else 1.0)
+    svar = np.exp(0.5 * rng.standard_normal((nb, N))) * 0.1 if noise == "diag" else np.array([0.1])
+    if prior == "factor":
+        Lw = np.empty((nb, D, D)); Lin = np.empty((nb, D, D))
+        for b in range(nb):
+            Bm = rng.standard_normal((D, D)) / np.sqrt(D)
+            Lw[b] = Bm @ Bm.T + np.eye(D)
+            Lin[b] = O.chol_upper(Lw[b]).T
+        pk, ldl, sl = a.PRIOR_UPPER_FACTOR, D, D * D
+    else:
+        Lin = np.exp(0.3 * rng.standard_normal((nb, D)))
+        Lw = Lin
+        pk, ldl, sl = a.PRIOR_DIAGONAL, 1, D
+    nk, ss = (a.NOISE_DIAGONAL, N) if noise == "diag" else (a.NOISE_ISOTROPIC, 0)
+
+    def run(layout, Xin, ldx, strideX):
+        mp = np.full((nb, D), 7.0); Tp = np.zeros((nb, D, D)); Ap = np.zeros((nb, D, D)); lp = np.zeros(nb); info = np.full(nb, 9, dtype=np.int32)
+        h.posterior_batched(np.float64, a.MEM_HOST, layout, nb, D, N, Xin, ldx, strideX, y, N, nk, svar, ss, pk,
+                            mw, D, Lin, ldl, sl, mp, D, Tp, D, D * D, Ap, D, D * D, lp, info)
+        return mp, Tp, Ap, lp, info
+
+    def rowvecs(ld):
+        Xr = np.full((nb, D, ld), 3.0e5)  # (the padding below row N must never be read: it would break every row bound)
+        Xr[:, :, :N] = X.transpose(0, 2, 1)
+        return Xr
+
+    col = run(a.LAYOUT_COLVECS, X, D, N * D)
+    ld = N + 2 + (N & 1)
+    row = run(a.LAYOUT_ROWVECS, rowvecs(ld), ld, D * ld)
+    assert col[4].tolist() == [0] * nb
+    if kind != "outlier":  # (a handed-back regressor is redone by the fp64 kernel of ITS layout: other accumulation order)
+        for u, v in zip(col, row):
+            np.testing.assert_array_equal(u, v)
+    else:
+        for b in range(1, nb, 2):
+            for u, v in zip(col, row):
+                np.testing.assert_array_equal(u[b], v[b])
+    odd = run(a.LAYOUT_ROWVECS, rowvecs(ld + 1), ld + 1, D * (ld + 1))
+    opt("NO_I8_ROWVECS", "1")
+    slow = run(a.LAYOUT_ROWVECS, rowvecs(ld), ld, D * ld)
+    opt("NO_I8_ROWVECS", None)
+    for u, v in zip(odd, slow):
+        np.testing.assert_array_equal(u, v)  # both on the fp64 RowVecs kernel
+    for b in range(nb):
+        sv = svar[b] if noise == "diag" else 0.1
+        mw_o, T_o, A_o, lp_o = O.posterior_logpdf_direct(mw[b], Lw[b], X[b].T, sv, y[b])
+        dA = np.sqrt(np.diag(A_o))
+        for mp, Tp, Ap, lp, info in (row, slow):
+            assert info[b] == 0
+            assert lp[b] == pytest.approx(lp_o, rel=1e-10)
+            np.testing.assert_allclose(mp[b] * dA, mw_o * dA, rtol=1e-8, atol=1e-9 * np.abs(mw_o * dA).max())
+            assert (np.abs(Ap[b] - A_o) / np.outer(dA, dA)).max() <= 1e-12
+            Tn = np.triu(Tp[b].T)
+            assert (np.abs(Tn.T @ Tn - A_o) / np.outer(dA, dA)).max() <= 1e-10
+
+
 def test_i8_gram_tail_columns_nonfinite_go_back_to_the_fp64_kernel(B, opt):
     # N = 1055: 32 whole k-steps through the int8 stream, 31 columns added in fp64 at the hand-over.  A NaN / Inf in THOSE columns
     # hands the regressor back like one in the stream does: status and bits of the fp64 kernel.

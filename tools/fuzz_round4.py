@@ -1,6 +1,6 @@
 """Randomised parity sweep of the kernels added in round 4, through the C ABI against the oracle:
   marg   marginals at D > 128 (block substitution on LDS tiles, both tile heights, batches, factor / dense priors, padded ldx) and D = 128
-  i8     the int8-sliced Gram route at D = 128 (N in 512 .. 16415, prior mean on / off, rows of different scale)
+  i8     the int8-sliced Gram route at D = 128 (N in 512 .. 16415, prior mean on / off, rows of different scale, both layouts)
   multi  logpdf(fx, Y::Matrix) (temporaries from the side buffer, parallel reductions)
   rand   rand(rng, fx, S) with given normals (rotated fragment images of the MFMA projection)
 Not part of the test suite (minutes of GPU time): python tools/fuzz_round4.py [marg|i8|multi|rand] [cases] [seed]"""
@@ -81,7 +81,15 @@ def i8(rng, case):
         y = y + np.sqrt(s) * rng.standard_normal((nb, N))
     mp = np.zeros((nb, D)); Tp = np.zeros((nb, D, D)); Ap = np.zeros((nb, D, D)); lp = np.zeros(nb); info = np.full(nb, 9, dtype=np.int32)
     h = _abi.default_handle()
-    h.posterior_batched(np.float64, _abi.MEM_HOST, _abi.LAYOUT_COLVECS, nb, D, N, X, D, N * D, y, N, _abi.NOISE_DIAGONAL if diag else _abi.NOISE_ISOTROPIC,
+    rowv = rng.random() < 0.4  # RowVecs storage (N x D column-major, padded leading dimension): four feature rows per DMA piece
+    if rowv:
+        ld = N + 2 * int(rng.integers(0, 4)) + (N & 1)
+        Xin = np.full((nb, D, ld), 1.0e30)
+        Xin[:, :, :N] = X.transpose(0, 2, 1)
+        lay, ldx, sx = _abi.LAYOUT_ROWVECS, ld, D * ld
+    else:
+        Xin, lay, ldx, sx = X, _abi.LAYOUT_COLVECS, D, N * D
+    h.posterior_batched(np.float64, _abi.MEM_HOST, lay, nb, D, N, Xin, ldx, sx, y, N, _abi.NOISE_DIAGONAL if diag else _abi.NOISE_ISOTROPIC,
                         s, N if diag else 0, pk, mw, D, prior_arg, ldl, strideL, mp, D, Tp, D, D * D, Ap, D, D * D, lp, info)
     assert np.all(info == 0), (case, info)
     for b in range(nb):
@@ -91,7 +99,7 @@ def i8(rng, case):
         assert abs(lp[b] - lp_o) <= 2e-10 * abs(lp_o) + 1e-12 * float((y[b] * y[b] / (s[b] if diag else 0.1)).sum()) * max(1.0, float(np.abs(X[b]).max() / np.abs(X[b]).mean()) ** 2 / 1e4), (case, b, lp[b], lp_o)
         assert (np.abs(Ap[b] - A_o) / np.outer(dA, dA)).max() <= (1e-11 if diag else 1e-12), case
         np.testing.assert_allclose(mp[b] * dA, mw_o * dA, rtol=1e-7, atol=1e-8 * np.abs(mw_o * dA).max(), err_msg=f"case {case}")
-    return f"N={N} B={nb} mw={'yes' if np.any(mw) else 'no'} scaled={'yes' if np.any(scale != 1) else 'no'} noise={'diag' if diag else 'iso'} prior={'factor' if factor else 'diag'}"
+    return f"N={N} B={nb} mw={'yes' if np.any(mw) else 'no'} scaled={'yes' if np.any(scale != 1) else 'no'} noise={'diag' if diag else 'iso'} prior={'factor' if factor else 'diag'} layout={'RowVecs' if rowv else 'ColVecs'}"
 
 
 def multi(rng, case):
