@@ -139,9 +139,11 @@ def cpu_baseline(D, N, seconds, seed):
 class Workload:
     """One BASELINE shape resident on the device + the call that runs one step of it."""
 
-    def __init__(self, torch, _abi, h, dev, name, B, D, N, dtype, noise, seed, Din=None, mw_random=False, logpdf_only=False, block=None):
+    def __init__(self, torch, _abi, h, dev, name, B, D, N, dtype, noise, seed, Din=None, mw_random=False, logpdf_only=False, block=None, rowvecs=False,
+                 factor_prior=False):
         self.name, self.B, self.D, self.N, self.dtype, self.noise, self.Din = name, B, D, N, dtype, noise, Din
         self.logpdf_only = logpdf_only
+        self.rowvecs, self.factor_prior = rowvecs, factor_prior
         self.mw_random = mw_random
         self.torch, self._abi, self.h = torch, _abi, h
         t_dt = torch.float64 if dtype == "f64" else torch.float32
@@ -191,6 +193,11 @@ class Workload:
         # problems draw mw = randn(D), test/test_utils.jl:6)
         self.mw = torch.randn((B, D), generator=g, dtype=t_dt, device=dev) if mw_random else torch.zeros((B, D), dtype=t_dt, device=dev)
         self.dprior = torch.ones((D,), dtype=t_dt, device=dev)
+        if rowvecs:  # the same design matrices stored N x D column-major (RowVecs: a feature's observations contiguous)
+            self.X = self.X.transpose(1, 2).contiguous()
+        if factor_prior:  # a prior given by its upper factor U (Lw = U'U, a PDMat / a carried-forward posterior), shared by the batch;
+            # [D, D] row-major lower triangle == column-major upper U
+            self.Uprior = torch.tril(torch.randn((D, D), generator=g, dtype=t_dt, device=dev) / float(np.sqrt(D)), -1) + 1.5 * torch.eye(D, dtype=t_dt, device=dev)
         self.mw_post = torch.empty((B, D), dtype=t_dt, device=dev)
         self.T_post = torch.empty((B, D, D), dtype=t_dt, device=dev)
         self.lp = torch.empty((B,), dtype=torch.float64, device=dev)
@@ -201,9 +208,11 @@ class Workload:
     def launch(self):
         a, B, D, N = self._abi, self.B, self.D, self.N
         if self.Din is None:
-            self.h.posterior_batched(self.np_dt, a.MEM_DEVICE, a.LAYOUT_COLVECS, B, D, N, self.X.data_ptr(), D, N * D, self.y.data_ptr(), N,
-                                     self.noise_kind, self.s.data_ptr(), N if self.diag else 0, a.PRIOR_DIAGONAL, self.mw.data_ptr(), D,
-                                     self.dprior.data_ptr(), 1, 0, None if self.logpdf_only else self.mw_post.data_ptr(), D,
+            pk, pr, ldl = (a.PRIOR_UPPER_FACTOR, self.Uprior, D) if self.factor_prior else (a.PRIOR_DIAGONAL, self.dprior, 1)
+            self.h.posterior_batched(self.np_dt, a.MEM_DEVICE, a.LAYOUT_ROWVECS if self.rowvecs else a.LAYOUT_COLVECS, B, D, N, self.X.data_ptr(),
+                                     N if self.rowvecs else D, N * D, self.y.data_ptr(), N,
+                                     self.noise_kind, self.s.data_ptr(), N if self.diag else 0, pk, self.mw.data_ptr(), D,
+                                     pr.data_ptr(), ldl, 0, None if self.logpdf_only else self.mw_post.data_ptr(), D,
                                      None if self.logpdf_only else self.T_post.data_ptr(), D, D * D, None, D,
                                      D * D, self.lp.data_ptr(), self.info.data_ptr())
         else:
@@ -443,6 +452,7 @@ def secondary_ops(torch, _abi, h, dev):
 
             r = w2.roofline(1.0)
             tag = (", prior mean ~ N(0, I)" if kw.get("mw_random") else "") + (", logpdf only (no mw', no T)" if kw.get("logpdf_only") else "") \
+                + (", RowVecs storage" if kw.get("rowvecs") else "") + (", prior by its upper factor" if kw.get("factor_prior") else "") \
                 + (f", handle option {option}" if option else "")
             return Op(f"B={b}, D={d}, N={n}, {dt}, {noise} noise" + (f", D_in={din} random-Fourier features" if din else "") + tag,
                       launch, b, "updates/s", r["algorithmic_flops"], r["algorithmic_bytes"], dt, kern, check, steps=steps, keep=(w2,))
@@ -454,6 +464,8 @@ def secondary_ops(torch, _abi, h, dev):
         "c2_f64_fp64_kernel": post("c2", 4096, 128, 4096, "f64", "isotropic", option="NO_I8_GRAM"),
         "c2_f64_mw": post("c2_f64_mw", 4096, 128, 4096, "f64", "isotropic", mw_random=True),
         "c2_f64_diag_noise": post("c2_f64_diag", 4096, 128, 4096, "f64", "diagonal"),
+        "c2_f64_factor_prior": post("c2_f64_factor", 4096, 128, 4096, "f64", "isotropic", factor_prior=True),
+        "c2_f64_rowvecs": post("c2_f64_rowvecs", 4096, 128, 4096, "f64", "isotropic", rowvecs=True),
         "c4_f64": post("c4_f64", 8192, 64, 1024, "f64", "isotropic"),
         "c4_f32": post("c4_f32", 8192, 64, 1024, "f32", "isotropic"),
         # the per-GPU blocks of config 4 (8192 regressors) on 2 / 4 / 8 GPUs: the expected strong-scaling curve
