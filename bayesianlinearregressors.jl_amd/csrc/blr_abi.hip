@@ -353,8 +353,13 @@ int launch_fused_wave(blr_handle* h, const PosteriorArgs<T>& a) {
 // fp64-accurate update, none is computed twice on the fast path.
 int launch_fused_i8(blr_handle* h, const PosteriorArgs<double>& a) {
   const bool diag = a.noise_kind == BLR_NOISE_DIAGONAL, rowv = a.layout == BLR_LAYOUT_ROWVECS;
+#ifdef BLR_DEV_FAST  /* development builds only: one instantiation of the int8 kernel (the four take 5 of the 6.5 minutes of a build) */
+  void (*const kern)(PosteriorArgs<double>) = fused_i8_kernel<false, false>;
+  if (diag || rowv) return hip_fail(h, hipErrorInvalidValue, "BLR_DEV_FAST build");
+#else
   void (*const kern)(PosteriorArgs<double>) = diag ? (rowv ? fused_i8_kernel<true, true> : fused_i8_kernel<true, false>)
                                                    : (rowv ? fused_i8_kernel<false, true> : fused_i8_kernel<false, false>);
+#endif
   int rc = set_lds_once(h, reinterpret_cast<const void*>(kern), (size_t)I8Cfg::LDS_BYTES);
   if (rc) return rc;
   // diagonal noise: y / sqrt(s), 1 / sqrt(s), sum log s and a validity flag per regressor, once per call, in the handle's side
@@ -1200,8 +1205,17 @@ int marginals_batched(blr_handle* h, int memspace, int layout, int64_t B, int64_
     a.X = X; a.s = s; a.mw = mw; a.mean = mean; a.var = var;
   }
   if (D > kMaxSmallD) {  // large-D path: the whole batch on LDS-resident tiles if it qualifies, else one regressor at a time
-    rc = marginals_large_group<T>(h, layout, B, D, N, a.X, ldx, strideX, noise_kind, a.s, strides, prior_kind, a.mw, stridemw, Lw_dev, ldl,
-                                  strideLw, a.mean, stridemean, a.var, stridevar, info_out_dev);
+    if (h->opt.chain_batch == 1 && B > 1) {  // measurements only (tools/group_scan.py): the same kernels, one regressor per set of launches
+      rc = 0;
+      for (int64_t reg = 0; rc == 0 && reg < B; ++reg)
+        rc = marginals_large_group<T>(h, layout, 1, D, N, a.X + reg * strideX, ldx, strideX, noise_kind, a.s ? a.s + reg * strides : nullptr, strides,
+                                      prior_kind, a.mw + reg * stridemw, stridemw, Lw_dev ? Lw_dev + reg * strideLw : nullptr, ldl, strideLw,
+                                      a.mean ? a.mean + reg * stridemean : nullptr, stridemean, a.var ? a.var + reg * stridevar : nullptr, stridevar,
+                                      info_out_dev + reg);
+    } else {
+      rc = marginals_large_group<T>(h, layout, B, D, N, a.X, ldx, strideX, noise_kind, a.s, strides, prior_kind, a.mw, stridemw, Lw_dev, ldl,
+                                    strideLw, a.mean, stridemean, a.var, stridevar, info_out_dev);
+    }
     if (rc < 0 || rc > 1) return rc;
     for (int64_t reg = 0; rc == 1 && reg < B; ++reg) {
       rc = marginals_large_one<T>(h, layout, D, N, a.X + reg * strideX, ldx, noise_kind, a.s ? a.s + reg * strides : nullptr,
@@ -1439,11 +1453,23 @@ int posterior_from_stats(blr_handle* h, int64_t D64, int64_t N_total, T* stats, 
   return 0;
 }
 
-// ---- gradient for D > 128, one regressor: forward + backward panels over the tall matrix [F; X'; I] ----------------------
+// ---- gradient for D > 128: forward + backward panels over the tall matrix [F; X'; I], G regressors per launch ------------
+// Regressor g of the group: caller's arrays at their element strides, the tall matrix and the per-observation vectors in ITS slice
+// of the workspace (blockIdx.y of every launch; posterior_large_group's scheme).
+struct GradGroupStrides {
+  int64_t X, y, s, mwp, Tf, dX, dy, ds, dmw, Ai;
+};
 template <typename T>
-int logpdf_grad_large_one(blr_handle* h, int layout, int64_t D, int64_t N, const T* X, int64_t ldx, const T* y, int noise_kind,
-                          const T* s, const T* mwp, const T* Tfac, int64_t ldt, T* dX, int64_t lddx, T* dy, T* ds, T* dmw,
-                          T* Ainv, int64_t ldai, int32_t* info_dev) {
+size_t grad_large_ws_bytes(int64_t D, int64_t N, bool with_ainv, bool with_dmw) {
+  const size_t DP = (size_t)((D + kPB - 1) / kPB * kPB), NP = (size_t)((N + kPB - 1) / kPB * kPB), DI = with_ainv ? DP : 0;
+  auto al = [](size_t b) { return (b + 255) & ~(size_t)255; };
+  return al((DP + NP + DI) * DP * sizeof(T)) + al((NP + DI) * sizeof(double)) + 3 * al(NP * sizeof(T)) + al((NP + DI) * sizeof(T)) +
+         al(with_dmw ? (NP / 64) * DP * sizeof(double) : 0);
+}
+template <typename T>
+int logpdf_grad_large_group(blr_handle* h, int G, int layout, int64_t D, int64_t N, const T* X, int64_t ldx, const T* y, int noise_kind,
+                            const T* s, const T* mwp, const T* Tfac, int64_t ldt, T* dX, int64_t lddx, T* dy, T* ds, T* dmw,
+                            T* Ainv, int64_t ldai, int32_t* info_dev, const GradGroupStrides& gs) {
   using TC = TrsmCfg<T>;
   using LC = LargeCfg<T>;
   const int DP = (int)((D + kPB - 1) / kPB * kPB), NC = DP / kPB;
@@ -1460,7 +1486,8 @@ int logpdf_grad_large_one(blr_handle* h, int layout, int64_t D, int64_t N, const
   const size_t o_r = carve((size_t)NP * sizeof(T));
   const size_t o_w = carve((size_t)NP * sizeof(T));
   const size_t o_part = carve(dmw ? (size_t)(NP / 64) * DP * sizeof(double) : 0);
-  int rc = ensure_ws(h, off);
+  const int64_t wsb = (int64_t)off;  // one regressor's slice
+  int rc = ensure_ws(h, off * (size_t)G);
   if (rc) return rc;
   T* Ybar = reinterpret_cast<T*>(h->ws + o_y);
   double* rowsq = reinterpret_cast<double*>(h->ws + o_sq);
@@ -1469,15 +1496,17 @@ int logpdf_grad_large_one(blr_handle* h, int layout, int64_t D, int64_t N, const
   T* rvec = reinterpret_cast<T*>(h->ws + o_r);
   T* wvec = reinterpret_cast<T*>(h->ws + o_w);
   double* part = dmw ? reinterpret_cast<double*>(h->ws + o_part) : nullptr;
+  const unsigned ug = (unsigned)G;
 
   {
-    dim3 grid((DP + 31) / 32, (DP + 31) / 32);
-    hipLaunchKernelGGL(factor_sym_fill_kernel<T>, grid, dim3(kThreads), 0, h->stream, Tfac, ldt, (int)D, DP, Ybar, ldy);
+    dim3 grid((DP + 31) / 32, (DP + 31) / 32, ug);
+    hipLaunchKernelGGL(factor_sym_fill_kernel<T>, grid, dim3(kThreads), 0, h->stream, Tfac, ldt, (int)D, DP, Ybar, ldy, gs.Tf, wsb);
     MeanFillArgs<T> m{};
     m.X = X; m.ldx = ldx; m.layout = layout; m.mw = mwp; m.mean = mu; m.Ybar = Ybar; m.ldy = ldy; m.row0 = DP;
     m.D = (int)D; m.DP = DP; m.N = (int)N;
-    hipLaunchKernelGGL(mean_fill_kernel<T>, dim3((unsigned)(NP / 64)), dim3(kThreads), 0, h->stream, m);
-    if (DI) hipLaunchKernelGGL(identity_rows_kernel<T>, dim3(1024), dim3(kThreads), 0, h->stream, Ybar, ldy, DP + NP, DP);
+    m.grp_X = gs.X; m.grp_mw = gs.mwp; m.grp_ws = wsb;
+    hipLaunchKernelGGL(mean_fill_kernel<T>, dim3((unsigned)(NP / 64), ug), dim3(kThreads), 0, h->stream, m);
+    if (DI) hipLaunchKernelGGL(identity_rows_kernel<T>, dim3(G > 8 ? 128 : 1024, ug), dim3(kThreads), 0, h->stream, Ybar, ldy, DP + NP, DP, wsb);
   }
   if ((rc = set_lds<T>(h, reinterpret_cast<const void*>(trsm_block_kernel<T>), TC::LDS_BYTES))) return rc;
   if ((rc = set_lds<T>(h, reinterpret_cast<const void*>(trsm_back_block_kernel<T>), TC::LDS_BYTES))) return rc;
@@ -1491,20 +1520,25 @@ int logpdf_grad_large_one(blr_handle* h, int layout, int64_t D, int64_t N, const
     g.D = R; g.n_begin = 0; g.n_end = kPB; g.nsplit = 1;
     g.tile_i0 = NC; g.tile_j0 = j0; g.tri = 3; g.ntile_rows = nyb; g.ntiles = nyb * ncolblocks; g.nblocks = NC + nyb;
     g.C = Ybar; g.ldc = ldy; g.mode_out = 1;
-    hipLaunchKernelGGL(gram_tile_kernel<T>, dim3(g.ntiles), dim3(kThreads), LC::LDS_BYTES, h->stream, g);
+    g.grp_X = wsb / (int64_t)sizeof(T); g.grp_s = 0; g.grp_ws = wsb;
+    hipLaunchKernelGGL(gram_tile_kernel<T>, dim3(g.ntiles, ug), dim3(kThreads), LC::LDS_BYTES, h->stream, g);
   };
   for (int p = 0; p < NC; ++p) {  // forward: rows x' -> x'L^-T, with the row sums of squares riding along
     RowSqArgs<T> rs{};
     rs.acc = rowsq; rs.var = var; rs.s = s; rs.noise_kind = noise_kind; rs.N = (int)N; rs.first = p == 0; rs.last = p == NC - 1;
-    hipLaunchKernelGGL(trsm_block_kernel<T>, dim3(nblk), dim3(kThreads), TC::LDS_BYTES, h->stream, Ybar, ldy, p, DP, R,
-                       (const int32_t*)info_dev, rs);
+    rs.grp_ws = wsb; rs.grp_s = gs.s;
+    hipLaunchKernelGGL(trsm_block_kernel<T>, dim3(nblk, ug), dim3(kThreads), TC::LDS_BYTES, h->stream, Ybar, ldy, p, DP, R,
+                       (const int32_t*)info_dev, rs, wsb);
     if (p + 1 < NC) trailing(p, p + 1, NC - 1 - p);
   }
-  hipLaunchKernelGGL(grad_obs_kernel<T>, dim3((unsigned)((N + kThreads - 1) / kThreads)), dim3(kThreads), 0, h->stream, y,
-                     (const T*)mu, (const T*)var, s, noise_kind, (int)N, rvec, wvec, dy, ds);
+  {
+    GradObsGroup og{gs.y, gs.s, gs.dy, gs.ds, wsb};
+    hipLaunchKernelGGL(grad_obs_kernel<T>, dim3((unsigned)((N + kThreads - 1) / kThreads), ug), dim3(kThreads), 0, h->stream, y,
+                       (const T*)mu, (const T*)var, s, noise_kind, (int)N, rvec, wvec, dy, ds, og);
+  }
   for (int p = NC - 1; p >= 0; --p) {  // backward: x'L^-T -> x'L^-T L^-1 = x'A^-1
-    hipLaunchKernelGGL(trsm_back_block_kernel<T>, dim3(nblk), dim3(kThreads), TC::LDS_BYTES, h->stream, Ybar, ldy, p, DP, R,
-                       (const int32_t*)info_dev);
+    hipLaunchKernelGGL(trsm_back_block_kernel<T>, dim3(nblk, ug), dim3(kThreads), TC::LDS_BYTES, h->stream, Ybar, ldy, p, DP, R,
+                       (const int32_t*)info_dev, wsb);
     if (p > 0) trailing(p, 0, p);  // second operand: the UPPER triangle of the factor block (T = L')
   }
   if (dX || dmw) {
@@ -1512,12 +1546,15 @@ int logpdf_grad_large_one(blr_handle* h, int layout, int64_t D, int64_t N, const
     o.Ybar = Ybar; o.ldy = ldy; o.row0 = DP; o.X = X; o.ldx = ldx; o.layout = layout;
     o.rvec = rvec; o.wvec = wvec; o.mwp = mwp; o.dX = dX; o.lddx = lddx; o.dmw_part = part;
     o.D = (int)D; o.DP = DP; o.N = (int)N;
-    hipLaunchKernelGGL(grad_out_large_kernel<T>, dim3((unsigned)(NP / 64)), dim3(kThreads), 0, h->stream, o);
+    o.grp_X = gs.X; o.grp_mwp = gs.mwp; o.grp_dX = gs.dX; o.grp_ws = wsb;
+    hipLaunchKernelGGL(grad_out_large_kernel<T>, dim3((unsigned)(NP / 64), ug), dim3(kThreads), 0, h->stream, o);
     if (dmw)
-      hipLaunchKernelGGL(grad_reduce_large_kernel<T>, dim3((unsigned)((D + kThreads - 1) / kThreads)), dim3(kThreads), 0, h->stream,
-                         (const double*)part, NP / 64, DP, (int)D, dmw);
+      hipLaunchKernelGGL(grad_reduce_large_kernel<T>, dim3((unsigned)((D + kThreads - 1) / kThreads), ug), dim3(kThreads), 0, h->stream,
+                         (const double*)part, NP / 64, DP, (int)D, dmw, wsb, gs.dmw);
   }
-  if (Ainv) hipLaunchKernelGGL(ainv_copy_kernel<T>, dim3(1024), dim3(kThreads), 0, h->stream, (const T*)Ybar, ldy, DP + NP, (int)D, Ainv, ldai);
+  if (Ainv)
+    hipLaunchKernelGGL(ainv_copy_kernel<T>, dim3(G > 8 ? 128 : 1024, ug), dim3(kThreads), 0, h->stream, (const T*)Ybar, ldy, DP + NP, (int)D, Ainv, ldai,
+                       wsb, gs.Ai);
   HIP_TRY(h, hipGetLastError());
   return 0;
 }
@@ -1590,36 +1627,51 @@ int logpdf_grad_batched(blr_handle* h, int memspace, int layout, int64_t B, int6
   } else {
     a.X = X; a.y = y; a.s = s; a.mw = mw; a.Lw = Lw;
   }
-  if (D > kMaxSmallD) {  // large-D path: one regressor at a time; factor and posterior mean in buffers of their own
+  if (D > kMaxSmallD) {
+    // large-D path: the regressors go through the update (posterior_large_group) and through the sweeps over the tall matrix in
+    // groups that share every launch; factors and posterior means of a group in buffers of their own
+    int gmax = kChainBatchMax;
+    if (h->opt.chain_batch > 0) gmax = std::min(kChainBatchMax, h->opt.chain_batch);  // measurements only
+    if ((strideX * (int64_t)sizeof(T)) % 16 != 0) gmax = 1;
+    {
+      size_t ws_cap = kChainWorkspace;
+      if (h->opt.chain_ws_mb > 0) ws_cap = (size_t)h->opt.chain_ws_mb << 20;
+      const size_t one_ws = grad_large_ws_bytes<T>(D, N, Ai_d != nullptr, dmw_d != nullptr) + (size_t)D * D * sizeof(T);
+      gmax = (int)std::max<size_t>(1, std::min<size_t>((size_t)gmax, ws_cap / one_ws));
+      const int64_t ngroups = std::max<int64_t>(1, (B + gmax - 1) / gmax);
+      gmax = (int)((B + ngroups - 1) / ngroups);  // even groups
+    }
     T* Tf = nullptr;
     T* mp = nullptr;
     {
       void* p0 = nullptr;
-      HIP_TRY(h, hipMalloc(&p0, (size_t)D * D * sizeof(T)));
+      HIP_TRY(h, hipMalloc(&p0, (size_t)gmax * D * D * sizeof(T)));
       h->staged.push_back(p0);
       Tf = static_cast<T*>(p0);
       void* p1 = nullptr;
-      HIP_TRY(h, hipMalloc(&p1, (size_t)D * sizeof(T)));
+      HIP_TRY(h, hipMalloc(&p1, (size_t)gmax * D * sizeof(T)));
       h->staged.push_back(p1);
       mp = static_cast<T*>(p1);
     }
     a.vec_ok = 0;
-    for (int64_t reg = 0; reg < B; ++reg) {
+    for (int64_t reg = 0; reg < B;) {
       PosteriorArgs<T> one = a;
-      one.mw_post = mwp_d ? mwp_d + reg * stride_mwpost : mp; one.stride_mwpost = 0;
-      one.T_post = Tf; one.ldt = D; one.strideT = 0;
+      // posterior_large_group indexes the batched arrays by the regressor's number: shift the outputs that are NOT batched here
+      one.stride_mwpost = mwp_d ? stride_mwpost : D;
+      one.mw_post = mwp_d ? mwp_d : mp - reg * one.stride_mwpost;
+      one.ldt = D; one.strideT = D * D; one.T_post = Tf - reg * one.strideT;
       one.Lw_post = nullptr; one.ldlp = D; one.strideLp = 0;
       one.logpdf = lp_d; one.info = info_d;
-      // posterior_large_one indexes the batched arrays by `reg`: shift the outputs that are NOT batched here
-      one.mw_post -= reg * one.stride_mwpost;
-      if ((rc = posterior_large_one<T>(h, one, reg))) return rc;
-      int32_t* inf = info_d + reg;
-      if ((rc = logpdf_grad_large_one<T>(h, layout, D, N, a.X + reg * strideX, ldx, a.y + reg * stridey, noise_kind,
-                                         a.s + reg * strides, one.mw_post, Tf, D, dX_d ? dX_d + reg * stridedX : nullptr, lddx,
-                                         dy_d ? dy_d + reg * stridedy : nullptr, ds_d ? ds_d + reg * strideds : nullptr,
-                                         dmw_d ? dmw_d + reg * stridedmw : nullptr, Ai_d ? Ai_d + reg * strideAi : nullptr,
-                                         ldai, inf)))
+      int done = 1;
+      if ((rc = posterior_large_group<T>(h, one, reg, (int)std::min<int64_t>(gmax, B - reg), &done))) return rc;
+      GradGroupStrides gs{strideX, stridey, strides, one.stride_mwpost, one.strideT, stridedX, stridedy, strideds, stridedmw, strideAi};
+      if ((rc = logpdf_grad_large_group<T>(h, done, layout, D, N, a.X + reg * strideX, ldx, a.y + reg * stridey, noise_kind,
+                                           a.s + reg * strides, one.mw_post + reg * one.stride_mwpost, Tf, D,
+                                           dX_d ? dX_d + reg * stridedX : nullptr, lddx, dy_d ? dy_d + reg * stridedy : nullptr,
+                                           ds_d ? ds_d + reg * strideds : nullptr, dmw_d ? dmw_d + reg * stridedmw : nullptr,
+                                           Ai_d ? Ai_d + reg * strideAi : nullptr, ldai, info_d + reg, gs)))
         return rc;
+      reg += done;
     }
     HIP_TRY(h, hipStreamSynchronize(h->stream));  // Tf / mp are temporaries of this call
     if (memspace == BLR_MEM_HOST) {

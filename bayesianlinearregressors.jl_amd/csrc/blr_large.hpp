@@ -508,6 +508,7 @@ __global__ __launch_bounds__(kThreads, (sizeof(T) == 4 ? BLR_GRAM_WGS : 2)) void
     if (a.s) a.s += g * a.grp_s;
     a.r = ws_shift(a.r, g * a.grp_ws); a.wpre = ws_shift(a.wpre, g * a.grp_ws); a.Gpart = ws_shift(a.Gpart, g * a.grp_ws);
     a.bpart = ws_shift(a.bpart, g * a.grp_ws);
+    a.C = ws_shift(a.C, g * a.grp_ws);  // (mode 1: the tall matrix of a grouped sweep lives in the regressor's workspace)
   }
   int t = w % a.ntiles, sidx = w / a.ntiles;
   int nsplit_here = a.nsplit;
@@ -1275,12 +1276,18 @@ struct RowSqArgs {      // optional fused epilogue of the marginal stream: var_n
   double* acc;          // [N] running row sums of squares (NULL: off); panel 0 writes, later panels add
   T* var; const T* s;   // last panel: var[n] = acc[n] + s_n
   int noise_kind, N, first, last;
+  int64_t grp_ws, grp_s;  // blockIdx.y = regressor of a group: byte stride of acc / var, element stride of s
 };
 
 template <typename T>
 __global__ __launch_bounds__(kThreads) void trsm_block_kernel(T* Abar, int64_t lda, int p, int row_begin, int nrows_total,
-                                                              const int32_t* info, RowSqArgs<T> rs) {
+                                                              const int32_t* info, RowSqArgs<T> rs, int64_t grp_ws = 0) {
   __builtin_amdgcn_s_setprio(3);  // latency-critical chain kernel: issue ahead of co-resident Gram waves
+  if (const int64_t g = blockIdx.y) {  // regressor of a group: the tall matrix by grp_ws bytes, one status word each
+    Abar = ws_shift(Abar, g * grp_ws); info += g;
+    rs.acc = ws_shift(rs.acc, g * rs.grp_ws); rs.var = ws_shift(rs.var, g * rs.grp_ws);
+    if (rs.s) rs.s += g * rs.grp_s;
+  }
   using Cfg = TrsmCfg<T>;
   extern __shared__ __attribute__((aligned(16))) char smem[];
   T* const P = reinterpret_cast<T*>(smem);                    // packed lower triangle of L_pp
@@ -1784,10 +1791,15 @@ struct MeanFillArgs {
   const T* mw; T* mean;          // mean may be NULL
   T* Ybar; int64_t ldy; int row0;  // Ybar may be NULL
   int D, DP, N;
+  int64_t grp_X, grp_mw, grp_ws;  // blockIdx.y = regressor of a group: element strides of X / mw, byte stride of mean / Ybar
 };
 
 template <typename T>
 __global__ __launch_bounds__(kThreads) void mean_fill_kernel(MeanFillArgs<T> a) {
+  if (const int64_t g = blockIdx.y) {
+    a.X += g * a.grp_X; a.mw += g * a.grp_mw;
+    a.mean = ws_shift(a.mean, g * a.grp_ws); a.Ybar = ws_shift(a.Ybar, g * a.grp_ws);
+  }
   constexpr int VEC = Mfma<T>::VEC;
   constexpr int LDT = 68;  // row stride: 16-byte aligned rows, 4-way (not 16-way) conflicts on the transposing writes
   typedef T vecT __attribute__((ext_vector_type(Mfma<T>::VEC)));
@@ -2409,8 +2421,10 @@ __global__ __launch_bounds__(kPB) void grad_reduce_kernel(const double* part, in
 
 // top block: lower triangle L = U', upper triangle U, unit padding
 template <typename T>
-__global__ __launch_bounds__(kThreads) void factor_sym_fill_kernel(const T* U, int64_t ldu, int D, int DP, T* Ybar, int64_t ldy) {
+__global__ __launch_bounds__(kThreads) void factor_sym_fill_kernel(const T* U, int64_t ldu, int D, int DP, T* Ybar, int64_t ldy, int64_t grp_U = 0,
+                                                                   int64_t grp_ws = 0) {
   __shared__ T tile[32][33];
+  if (const int64_t g = blockIdx.z) { U += g * grp_U; Ybar = ws_shift(Ybar, g * grp_ws); }  // regressor of a group
   const int bx = blockIdx.x * 32, by = blockIdx.y * 32;
   const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;
   for (int k = ty; k < 32; k += 8) {
@@ -2431,7 +2445,8 @@ __global__ __launch_bounds__(kThreads) void factor_sym_fill_kernel(const T* U, i
 
 // rows [row0, row0 + DP) of the tall matrix := identity
 template <typename T>
-__global__ __launch_bounds__(kThreads) void identity_rows_kernel(T* Ybar, int64_t ldy, int row0, int DP) {
+__global__ __launch_bounds__(kThreads) void identity_rows_kernel(T* Ybar, int64_t ldy, int row0, int DP, int64_t grp_ws = 0) {
+  Ybar = ws_shift(Ybar, (int64_t)blockIdx.y * grp_ws);
   for (int64_t e = (int64_t)blockIdx.x * kThreads + threadIdx.x; e < (int64_t)DP * DP; e += (int64_t)gridDim.x * kThreads) {
     const int c = (int)(e / DP), r = (int)(e % DP);
     Ybar[(int64_t)c * ldy + row0 + r] = (r == c) ? T(1) : T(0);
@@ -2441,7 +2456,8 @@ __global__ __launch_bounds__(kThreads) void identity_rows_kernel(T* Ybar, int64_
 // X <- X L_pp^-1 for one block of RB rows (the backward panel step)
 template <typename T>
 __global__ __launch_bounds__(kThreads) void trsm_back_block_kernel(T* Abar, int64_t lda, int p, int row_begin, int nrows_total,
-                                                                   const int32_t* info) {
+                                                                   const int32_t* info, int64_t grp_ws = 0) {
+  if (const int64_t g = blockIdx.y) { Abar = ws_shift(Abar, g * grp_ws); info += g; }  // regressor of a group
   using Cfg = TrsmCfg<T>;
   extern __shared__ __attribute__((aligned(16))) char smem[];
   T* const P = reinterpret_cast<T*>(smem);
@@ -2486,11 +2502,20 @@ __global__ __launch_bounds__(kThreads) void trsm_back_block_kernel(T* Abar, int6
 
 // per observation: r_n = y_n - mean_n, w_n = 1/s_n; wr_n = w_n r_n; dy_n = -w_n r_n; ds_n = -(s_n - r_n^2 - v_n)/(2 s_n^2)
 // (var_n = v_n + s_n comes from the forward panels' fused row sums of squares)
+struct GradObsGroup {  // blockIdx.y = regressor of a group: element strides of the caller's arrays, byte stride of mean / var / rvec / wvec
+  int64_t y, s, dy, ds, ws;
+};
 template <typename T>
 __global__ __launch_bounds__(kThreads) void grad_obs_kernel(const T* y, const T* mean, const T* var, const T* s, int noise_kind,
-                                                            int N, T* rvec, T* wvec, T* dy, T* ds) {
+                                                            int N, T* rvec, T* wvec, T* dy, T* ds, GradObsGroup grp = GradObsGroup()) {
   const int n = blockIdx.x * kThreads + threadIdx.x;
   if (n >= N) return;
+  if (const int64_t g = blockIdx.y) {
+    y += g * grp.y; s += g * grp.s;
+    if (dy) dy += g * grp.dy;
+    if (ds) ds += g * grp.ds;
+    mean = ws_shift(mean, g * grp.ws); var = ws_shift(var, g * grp.ws); rvec = ws_shift(rvec, g * grp.ws); wvec = ws_shift(wvec, g * grp.ws);
+  }
   const T sv = (noise_kind == NOISE_DIAGONAL) ? s[n] : s[0];
   const T w = T(1) / sv, rr = y[n] - mean[n];
   rvec[n] = rr;
@@ -2510,11 +2535,18 @@ struct GradOutArgs {
   T* dX; int64_t lddx;
   double* dmw_part;                        // [gridDim.x][DP]
   int D, DP, N;
+  int64_t grp_X, grp_mwp, grp_dX, grp_ws;  // blockIdx.y = regressor of a group: element strides of X / mwp / dX, byte stride of the rest
 };
 template <typename T>
 __global__ __launch_bounds__(kThreads) void grad_out_large_kernel(GradOutArgs<T> a) {
   __shared__ T tile[64][65];
   __shared__ T wr[64], rr[64], ww[64];
+  if (const int64_t g = blockIdx.y) {
+    a.X += g * a.grp_X; a.mwp += g * a.grp_mwp;
+    if (a.dX) a.dX += g * a.grp_dX;
+    a.Ybar = ws_shift(a.Ybar, g * a.grp_ws); a.rvec = ws_shift(a.rvec, g * a.grp_ws); a.wvec = ws_shift(a.wvec, g * a.grp_ws);
+    a.dmw_part = ws_shift(a.dmw_part, g * a.grp_ws);
+  }
   const int tid = threadIdx.x;
   const int n0 = blockIdx.x * 64;
   if (tid < 64) {
@@ -2563,16 +2595,20 @@ __global__ __launch_bounds__(kThreads) void grad_out_large_kernel(GradOutArgs<T>
   }
 }
 template <typename T>
-__global__ __launch_bounds__(kThreads) void grad_reduce_large_kernel(const double* part, int nparts, int DP, int D, T* dmw) {
+__global__ __launch_bounds__(kThreads) void grad_reduce_large_kernel(const double* part, int nparts, int DP, int D, T* dmw, int64_t grp_ws = 0,
+                                                                     int64_t grp_dmw = 0) {
   const int d = blockIdx.x * kThreads + threadIdx.x;
   if (d >= D) return;
+  part = ws_shift(part, (int64_t)blockIdx.y * grp_ws); dmw += (int64_t)blockIdx.y * grp_dmw;  // regressor of a group
   double acc = 0.0;
   for (int g = 0; g < nparts; ++g) acc += part[(int64_t)g * DP + d];
   dmw[d] = (T)acc;
 }
 // A^-1 from the identity rows of the tall matrix
 template <typename T>
-__global__ __launch_bounds__(kThreads) void ainv_copy_kernel(const T* Ybar, int64_t ldy, int row0, int D, T* Ainv, int64_t ldai) {
+__global__ __launch_bounds__(kThreads) void ainv_copy_kernel(const T* Ybar, int64_t ldy, int row0, int D, T* Ainv, int64_t ldai, int64_t grp_ws = 0,
+                                                             int64_t grp_Ai = 0) {
+  Ybar = ws_shift(Ybar, (int64_t)blockIdx.y * grp_ws); Ainv += (int64_t)blockIdx.y * grp_Ai;  // regressor of a group
   for (int64_t e = (int64_t)blockIdx.x * kThreads + threadIdx.x; e < (int64_t)D * D; e += (int64_t)gridDim.x * kThreads) {
     const int c = (int)(e / D), r = (int)(e % D);
     Ainv[(int64_t)c * ldai + r] = Ybar[(int64_t)c * ldy + row0 + r];

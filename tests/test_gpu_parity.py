@@ -1207,6 +1207,58 @@ def test_large_d_logpdf_gradient(B, dtype, D, N):
     assert float(g["noise"]) == pytest.approx(float(np.sum(g_i["s"])), rel=rt * 10)
 
 
+@pytest.mark.parametrize("Bn", [1, 3, 17])
+@pytest.mark.parametrize("dtype,D,N", [(np.float64, 300, 500), (np.float32, 256, 1100)])
+def test_large_d_logpdf_gradient_batched_share_the_launches(B, opt, Bn, dtype, D, N):
+    # D > 128, a batch: the regressors go through the update and through the forward / backward sweeps of the tall matrix together
+    # (blockIdx.y of every launch).  Each against the oracle; the grouped call agrees with one regressor at a time (CHAIN_BATCH=1) to
+    # rounding; a regressor whose prior is not positive definite reports it and leaves the others alone.
+    a = B._abi
+    h = a.default_handle()
+    rng = _rng(9750 + D + Bn)
+    X = rng.standard_normal((Bn, N, D)).astype(dtype)  # [N, D] row-major == D x N column-major
+    y = rng.standard_normal((Bn, N)).astype(dtype)
+    s = np.exp(0.3 * rng.standard_normal((Bn, N))).astype(dtype)
+    mw = (0.3 * rng.standard_normal((Bn, D))).astype(dtype)
+    d = np.exp(0.2 * rng.standard_normal((Bn, D))).astype(dtype)
+    bad = 1 if Bn > 1 else None
+    if bad is not None:
+        d[bad, 5] = -1.0
+
+    def run(with_ainv):
+        lp = np.zeros(Bn); info = np.full(Bn, 9, dtype=np.int32)
+        dX = np.zeros_like(X); dy = np.zeros_like(y); ds = np.zeros_like(s); dmw = np.zeros_like(mw); mwp = np.zeros_like(mw)
+        Ai = np.zeros((Bn, D, D), dtype=dtype) if with_ainv else None
+        h.logpdf_grad_batched(dtype, a.MEM_HOST, a.LAYOUT_COLVECS, Bn, D, N, X, D, N * D, y, N, a.NOISE_DIAGONAL, s, N, a.PRIOR_DIAGONAL,
+                              mw, D, d, 1, D, lp, dX, D, N * D, dy, N, ds, N, dmw, D, mwp, D, Ai, D, D * D, info)
+        return lp, dX, dy, ds, dmw, mwp, Ai, info
+
+    grouped = run(True)
+    opt("CHAIN_BATCH", "1")
+    single = run(True)
+    opt("CHAIN_BATCH", None)
+    no_ainv = run(False)
+    ok = [b for b in range(Bn) if b != bad]
+    # (not bit-equal: the split of the Gram launch over the observations is planned for the group that shares it)
+    eq = 1e-11 if dtype == np.float64 else 1e-3  # (fp32: the sums over the observations are rounded differently, 2e-4 seen)
+    for u, v in zip(grouped[:7], single[:7]):
+        np.testing.assert_allclose(u[ok], v[ok], rtol=eq, atol=eq * np.abs(v[ok]).max())
+    np.testing.assert_array_equal(grouped[7], single[7])
+    for u, v in zip(grouped[:6], no_ainv[:6]):
+        np.testing.assert_array_equal(u[ok], v[ok])  # same group, same plan: the identity rows do not touch the others
+    lp, dX, dy, ds, dmw, mwp, Ai, info = grouped
+    if bad is not None:
+        assert info[bad] == 6 and np.isnan(lp[bad])
+    rt = 1e-8 if dtype == np.float64 else 3e-3
+    f64 = lambda v: np.asarray(v, dtype=float)
+    for b in ok[:4]:
+        assert info[b] == 0
+        lp_o, g_o = O.logpdf_grad(f64(mw[b]), np.diag(f64(d[b])), f64(X[b]).T, f64(s[b]), f64(y[b]))
+        assert lp[b] == pytest.approx(lp_o, rel=1e-10 if dtype == np.float64 else 3e-4)
+        for got, ref in ((dX[b].T, g_o["X"]), (dy[b], g_o["y"]), (ds[b], g_o["s"]), (dmw[b], g_o["mw"]), (Ai[b], g_o["Ainv"]), (mwp[b], g_o["mw_post"])):
+            np.testing.assert_allclose(got, ref, rtol=rt, atol=rt * np.abs(ref).max())
+
+
 @pytest.mark.parametrize("dtype,D,N,S", [(np.float64, 5, 13, 4), (np.float64, 128, 900, 70), (np.float64, 300, 700, 130),
                                          (np.float32, 1024, 3000, 9)])
 def test_shared_x_multi_output_logpdf(B, dtype, D, N, S):
