@@ -353,14 +353,10 @@ int launch_fused_wave(blr_handle* h, const PosteriorArgs<T>& a) {
 // fp64-accurate update, none is computed twice on the fast path.
 int launch_fused_i8(blr_handle* h, const PosteriorArgs<double>& a) {
   const bool diag = a.noise_kind == BLR_NOISE_DIAGONAL, rowv = a.layout == BLR_LAYOUT_ROWVECS;
-#ifdef BLR_DEV_FAST  /* development builds only: one instantiation of the int8 kernel (the four take 5 of the 6.5 minutes of a build) */
-  void (*const kern)(PosteriorArgs<double>) = fused_i8_kernel<false, false>;
-  if (diag || rowv) return hip_fail(h, hipErrorInvalidValue, "BLR_DEV_FAST build");
-#else
-  void (*const kern)(PosteriorArgs<double>) = diag ? (rowv ? fused_i8_kernel<true, true> : fused_i8_kernel<true, false>)
-                                                   : (rowv ? fused_i8_kernel<false, true> : fused_i8_kernel<false, false>);
-#endif
-  int rc = set_lds_once(h, reinterpret_cast<const void*>(kern), (size_t)I8Cfg::LDS_BYTES);
+  // (the kernel's four instantiations: blr_i8_kernels.hip)
+  const void* const kern = diag ? i8_kernel_ptr_diag(rowv) : i8_kernel_ptr_iso(rowv);
+  if (kern == nullptr) return hip_fail(h, hipErrorInvalidValue, "BLR_DEV_FAST build: isotropic ColVecs form of the int8 kernel only");
+  int rc = set_lds_once(h, kern, (size_t)I8Cfg::LDS_BYTES);
   if (rc) return rc;
   // diagonal noise: y / sqrt(s), 1 / sqrt(s), sum log s and a validity flag per regressor, once per call, in the handle's side
   // buffer (16 bytes per observation: slices of at most 1 GiB)
@@ -391,7 +387,8 @@ int launch_fused_i8(blr_handle* h, const PosteriorArgs<double>& a) {
       hipLaunchKernelGGL(i8_noise_prep_kernel, dim3(nb), dim3(kThreads), 0, h->stream, s.s, a.strides, s.y, a.stridey, (int)a.N, yt, rw, (int64_t)a.N, ld,
                          bad, rmx);
     }
-    hipLaunchKernelGGL(kern, dim3(nb), dim3(kI8Threads), I8Cfg::LDS_BYTES, h->stream, s);
+    if (diag) i8_kernel_launch_diag(rowv, (unsigned)nb, h->stream, s);
+    else i8_kernel_launch_iso(rowv, (unsigned)nb, h->stream, s);
     HIP_TRY(h, hipGetLastError());
     s.retry_only = 1;
     if ((rc = launch_fused_small_mode<double, 8>(h, s))) return rc;

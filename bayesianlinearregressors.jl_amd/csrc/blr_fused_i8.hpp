@@ -878,7 +878,7 @@ __global__ __launch_bounds__(kI8Threads, 2) void fused_i8_kernel(PosteriorArgs<d
 // ---- diagonal noise: what the int8 route needs from s, once per call --------------------------------------------------------------
 // One workgroup per regressor: yt_n = y_n / sqrt(s_n), rw_n = 1 / sqrt(s_n), logdet = sum_n log s_n (fixed order), bad = some s_n is
 // not positive and finite (reference :79 cholesky(Sigma_y) throws: the fp64 kernel, which the regressor is handed to, reports it).
-__global__ __launch_bounds__(kThreads) void i8_noise_prep_kernel(const double* __restrict__ s, int64_t strides, const double* __restrict__ y,
+static __global__ __launch_bounds__(kThreads) void i8_noise_prep_kernel(const double* __restrict__ s, int64_t strides, const double* __restrict__ y,
                                                                  int64_t stridey, int N, double* __restrict__ yt, double* __restrict__ rw,
                                                                  int64_t stride, double* __restrict__ logdet, int32_t* __restrict__ bad,
                                                                  double* __restrict__ rwmax) {
@@ -904,5 +904,13 @@ __global__ __launch_bounds__(kThreads) void i8_noise_prep_kernel(const double* _
   const int hi = -block_min_int(-__double2hiint(rmax), iscr, tid);
   if (tid == 0) { logdet[reg] = ld; bad[reg] = b; rwmax[reg] = __hiloint2double(hi, -1); }
 }
+
+// The four instantiations of fused_i8_kernel are most of the library's build time, so they live in translation units of their own
+// (blr_i8_kernels.hip, compiled once per noise kind, next to blr_abi.hip: make -j3).  The host side reaches them through these:
+// the kernel's address (hipFuncSetAttribute) and one launch of `grid` workgroups, RowVecs or ColVecs inputs.
+const void* i8_kernel_ptr_iso(bool rowv);
+const void* i8_kernel_ptr_diag(bool rowv);
+void i8_kernel_launch_iso(bool rowv, unsigned grid, hipStream_t stream, const PosteriorArgs<double>& a);
+void i8_kernel_launch_diag(bool rowv, unsigned grid, hipStream_t stream, const PosteriorArgs<double>& a);
 
 }  // namespace blr

@@ -149,7 +149,8 @@ def test_hot_kernels_keep_two_workgroups_per_cu(tmp_path):
     subprocess.run([objdump, "--offloading", str(so)], check=True, capture_output=True, cwd=tmp_path)
     cos = [p for p in os.listdir(tmp_path) if "gfx950" in p]
     assert cos, "no gfx950 code object in the library"
-    notes = subprocess.run([readelf, "--notes", str(tmp_path / cos[0])], check=True, capture_output=True, text=True).stdout
+    # (one code object per translation unit: the host ABI with most kernels, the int8-sliced kernel once per noise kind)
+    notes = "".join(subprocess.run([readelf, "--notes", str(tmp_path / c)], check=True, capture_output=True, text=True).stdout for c in sorted(cos))
     kernels = {}
     cur = {}
     for line in notes.splitlines():
@@ -166,6 +167,9 @@ def test_hot_kernels_keep_two_workgroups_per_cu(tmp_path):
     assert len(hot) >= 60, f"expected the fused/gram kernels in the code object, found {len(hot)}"
     over = {k: v for k, v in hot.items() if v > 256}
     assert not over, f"kernels above 256 registers (1 workgroup per CU): {over}"
+    i8 = {k: v for k, v in kernels.items() if "fused_i8_kernel" in k}
+    n_i8 = 1 if "asan" in os.path.basename(str(_abi.LIB_PATH)) else 4  # (the sanitizer build carries one form: BLR_DEV_FAST)
+    assert len(i8) == n_i8 and max(i8.values()) <= 256, f"the four forms of the int8-sliced kernel (8 waves of 256 registers): {i8}"
 
 
 def test_julia_shim_ccall_signatures_match_the_header(repo_root):
