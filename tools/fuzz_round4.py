@@ -3,7 +3,9 @@
   i8     the int8-sliced Gram route at D = 128 (N in 512 .. 16415, prior mean on / off, rows of different scale, both layouts)
   multi  logpdf(fx, Y::Matrix) (temporaries from the side buffer, parallel reductions)
   rand   rand(rng, fx, S) with given normals (rotated fragment images of the MFMA projection)
-Not part of the test suite (minutes of GPU time): python tools/fuzz_round4.py [marg|i8|multi|rand] [cases] [seed]"""
+  grad   the evidence gradient at D > 128 with the regressors of a batch sharing every launch (both layouts, padded leading
+         dimensions, all prior kinds, optional outputs left out, a failing regressor inside the group)
+Not part of the test suite (minutes of GPU time): python tools/fuzz_round4.py [marg|i8|multi|rand|grad] [cases] [seed]"""
 import os, sys
 import numpy as np
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
@@ -152,11 +154,94 @@ def rand(rng, case):
     return f"D={D} N={N} S={S} {kind} {dtype.__name__} ldx=D+{pad}"
 
 
+def grad(rng, case):
+    dtype = np.float32 if rng.random() < 0.4 else np.float64
+    D = int(rng.choice([129, 130, 160, 256, 300, 384, 520]))
+    N = int(rng.choice([1, 7, 64, 100, 129, 500, 1100, 2500]))
+    Bn = int(rng.choice([1, 2, 3, 5, 9, 17]))
+    rowv = rng.random() < 0.4
+    diag = rng.random() < 0.6
+    kind = rng.choice(["diag", "dense", "factor"])
+    pad = int(rng.choice([0, 0, 2, 4, 6]))
+    Xc = rng.standard_normal((Bn, D, N))  # D x N
+    if rowv:  # N x D column-major: [D][ldx] in memory
+        ldx = N + pad
+        X = np.zeros((Bn, D, ldx), dtype=dtype); X[:, :, :N] = Xc
+        dX = np.full((Bn, D, ldx), -7.0, dtype=dtype)
+        sx = D * ldx
+    else:     # D x N column-major: [N][ldx] in memory
+        ldx = D + pad
+        X = np.zeros((Bn, N, ldx), dtype=dtype); X[:, :, :D] = Xc.transpose(0, 2, 1)
+        dX = np.full((Bn, N, ldx), -7.0, dtype=dtype)
+        sx = N * ldx
+    Xc = (X[:, :, :N] if rowv else X[:, :, :D].transpose(0, 2, 1)).astype(float)
+    y = rng.standard_normal((Bn, N)).astype(dtype)
+    s = np.exp(0.3 * rng.standard_normal((Bn, N))).astype(dtype) if diag else np.full((Bn, 1), 0.4, dtype=dtype)
+    mw = (0.3 * rng.standard_normal((Bn, D))).astype(dtype)
+    Lw_o = np.empty((Bn, D, D))
+    if kind == "diag":
+        arg = np.exp(0.2 * rng.standard_normal((Bn, D))).astype(dtype)
+        for b in range(Bn):
+            Lw_o[b] = np.diag(arg[b].astype(float))
+        pk, ldl, sl = _abi.PRIOR_DIAGONAL, 1, D
+    else:
+        arg = np.empty((Bn, D, D), dtype=dtype)
+        for b in range(Bn):
+            Bm = rng.standard_normal((D, D)) / np.sqrt(D)
+            L = (Bm @ Bm.T + np.eye(D)).astype(dtype)
+            if kind == "factor":
+                U = O.chol_upper(L.astype(float)).astype(dtype)
+                arg[b] = U.T
+                Lw_o[b] = U.astype(float).T @ U.astype(float)
+            else:
+                arg[b] = L
+                Lw_o[b] = L.astype(float)
+        pk, ldl, sl = (_abi.PRIOR_UPPER_FACTOR if kind == "factor" else _abi.PRIOR_DENSE), D, D * D
+    bad = int(rng.integers(0, Bn)) if (Bn > 1 and rng.random() < 0.3) else None
+    if bad is not None:
+        if kind == "diag":
+            arg[bad, 3] = -1.0
+        else:
+            arg[bad, 3, 3] = -arg[bad, 3, 3] if kind == "factor" else -5.0
+    want_ai = rng.random() < 0.6
+    want_dx = rng.random() < 0.8
+    lp = np.zeros(Bn); info = np.full(Bn, 9, dtype=np.int32)
+    dy = np.zeros_like(y); ds = np.zeros((Bn, N), dtype=dtype); dmw = np.zeros_like(mw); mwp = np.zeros_like(mw)
+    Ai = np.zeros((Bn, D, D), dtype=dtype) if want_ai else None
+    h = _abi.default_handle()
+    h.logpdf_grad_batched(dtype, _abi.MEM_HOST, _abi.LAYOUT_ROWVECS if rowv else _abi.LAYOUT_COLVECS, Bn, D, N, X, ldx, sx, y, N,
+                          _abi.NOISE_DIAGONAL if diag else _abi.NOISE_ISOTROPIC, s, N if diag else 1, pk, mw, D, arg, ldl, sl, lp,
+                          dX if want_dx else None, ldx, sx, dy, N, ds, N, dmw, D, mwp, D, Ai, D, D * D, info)
+    rt = 1e-8 if dtype == np.float64 else 5e-3
+    tag = f"D={D} N={N} B={Bn} {'RowVecs' if rowv else 'ColVecs'} {kind} {'diag' if diag else 'iso'} {dtype.__name__} pad={pad} bad={bad}"
+    for b in range(Bn):
+        if b == bad:
+            assert info[b] != 0, (case, tag, info)
+            continue
+        assert info[b] == 0, (case, tag, info)
+        if b > 3 and b != Bn - 1:
+            continue
+        sb = s[b].astype(float) if diag else float(s[b, 0])
+        lp_o, g_o = O.logpdf_grad(mw[b].astype(float), Lw_o[b], Xc[b], sb, y[b].astype(float))
+        assert abs(lp[b] - lp_o) <= (1e-10 if dtype == np.float64 else 3e-4) * abs(lp_o), (case, tag, lp[b], lp_o)
+        got = [(dy[b], g_o["y"]), (dmw[b], g_o["mw"]), (mwp[b], g_o["mw_post"])]
+        got.append((ds[b], g_o["s"]) if diag else (np.array([ds[b].sum()]), np.array([np.sum(g_o["s"])])))
+        if want_dx:
+            got.append(((dX[b][:, :N] if rowv else dX[b][:, :D].T), g_o["X"]))
+        if want_ai:
+            got.append((Ai[b], g_o["Ainv"]))
+        for u, v in got:
+            np.testing.assert_allclose(u, v, rtol=rt, atol=rt * np.abs(v).max(), err_msg=f"case {case}: {tag}")
+    if want_dx and pad:  # the padding of dX is not written
+        assert np.all((dX[:, :, N:] if rowv else dX[:, :, D:]) == -7.0), (case, tag)
+    return tag
+
+
 if __name__ == "__main__":
     which = sys.argv[1] if len(sys.argv) > 1 else "marg"
     cases = int(sys.argv[2]) if len(sys.argv) > 2 else 100
     rng = np.random.default_rng(int(sys.argv[3]) if len(sys.argv) > 3 else 2027)
-    fn = {"marg": marg, "i8": i8, "multi": multi, "rand": rand}[which]
+    fn = {"marg": marg, "i8": i8, "multi": multi, "rand": rand, "grad": grad}[which]
     for c in range(cases):
         d = fn(rng, c)
         if c % 10 == 0:
