@@ -205,15 +205,17 @@ def grad(rng, case):
             arg[bad, 3, 3] = -arg[bad, 3, 3] if kind == "factor" else -5.0
     want_ai = rng.random() < 0.6
     want_dx = rng.random() < 0.8
+    want_mwp, want_dmw, want_dyds = rng.random() < 0.7, rng.random() < 0.8, rng.random() < 0.8
     lp = np.zeros(Bn); info = np.full(Bn, 9, dtype=np.int32)
     dy = np.zeros_like(y); ds = np.zeros((Bn, N), dtype=dtype); dmw = np.zeros_like(mw); mwp = np.zeros_like(mw)
     Ai = np.zeros((Bn, D, D), dtype=dtype) if want_ai else None
     h = _abi.default_handle()
     h.logpdf_grad_batched(dtype, _abi.MEM_HOST, _abi.LAYOUT_ROWVECS if rowv else _abi.LAYOUT_COLVECS, Bn, D, N, X, ldx, sx, y, N,
                           _abi.NOISE_DIAGONAL if diag else _abi.NOISE_ISOTROPIC, s, N if diag else 1, pk, mw, D, arg, ldl, sl, lp,
-                          dX if want_dx else None, ldx, sx, dy, N, ds, N, dmw, D, mwp, D, Ai, D, D * D, info)
+                          dX if want_dx else None, ldx, sx, dy if want_dyds else None, N, ds if want_dyds else None, N, dmw if want_dmw else None, D,
+                          mwp if want_mwp else None, D, Ai, D, D * D, info)
     rt = 1e-8 if dtype == np.float64 else 5e-3
-    tag = f"D={D} N={N} B={Bn} {'RowVecs' if rowv else 'ColVecs'} {kind} {'diag' if diag else 'iso'} {dtype.__name__} pad={pad} bad={bad}"
+    tag = f"D={D} N={N} B={Bn} {'RowVecs' if rowv else 'ColVecs'} {kind} {'diag' if diag else 'iso'} {dtype.__name__} pad={pad} bad={bad} out={int(want_dx)}{int(want_ai)}{int(want_mwp)}{int(want_dmw)}{int(want_dyds)}"
     for b in range(Bn):
         if b == bad:
             assert info[b] != 0, (case, tag, info)
@@ -224,8 +226,14 @@ def grad(rng, case):
         sb = s[b].astype(float) if diag else float(s[b, 0])
         lp_o, g_o = O.logpdf_grad(mw[b].astype(float), Lw_o[b], Xc[b], sb, y[b].astype(float))
         assert abs(lp[b] - lp_o) <= (1e-10 if dtype == np.float64 else 3e-4) * abs(lp_o), (case, tag, lp[b], lp_o)
-        got = [(dy[b], g_o["y"]), (dmw[b], g_o["mw"]), (mwp[b], g_o["mw_post"])]
-        got.append((ds[b], g_o["s"]) if diag else (np.array([ds[b].sum()]), np.array([np.sum(g_o["s"])])))
+        got = []
+        if want_dyds:
+            got.append((dy[b], g_o["y"]))
+            got.append((ds[b], g_o["s"]) if diag else (np.array([ds[b].sum()]), np.array([np.sum(g_o["s"])])))
+        if want_dmw:
+            got.append((dmw[b], g_o["mw"]))
+        if want_mwp:
+            got.append((mwp[b], g_o["mw_post"]))
         if want_dx:
             got.append(((dX[b][:, :N] if rowv else dX[b][:, :D].T), g_o["X"]))
         if want_ai:
