@@ -34,7 +34,7 @@ using namespace blr;
 // handle is created (BLR_MI355X_<KEY>), and settable per handle with blr_set_option: no getenv on any launch path.
 struct BlrOptions {
   bool no_ldsdma = false, no_wave_kernel = false, no_gram_ring = false, no_diag_split = false, no_xcd_swizzle = false,
-       no_mfma_project = false, plan_debug = false, no_i8_gram = false, no_marg_gemm = false, no_i8_diag = false, no_i8_factor = false, no_i8_rowvecs = false;
+       no_mfma_project = false, plan_debug = false, no_i8_gram = false, no_marg_gemm = false, no_i8_diag = false, no_i8_factor = false, no_i8_rowvecs = false, no_grad_gemm = false;
   int wave_split = 0;     // waves per regressor of the wave kernel: 0 = router, else 1 | 2 | 4
   int chain_batch = 0;    // regressors per shared launch at D > 128: 0 = as many as the workspace holds
   long chain_ws_mb = 0;   // workspace bound of such a group in MiB: 0 = kChainWorkspace
@@ -55,6 +55,7 @@ struct BlrOptions {
     if (!strcmp(key, "PLAN_DEBUG")) return flag(plan_debug);
     if (!strcmp(key, "NO_I8_GRAM")) return flag(no_i8_gram);
     if (!strcmp(key, "NO_MARG_GEMM")) return flag(no_marg_gemm);
+    if (!strcmp(key, "NO_GRAD_GEMM")) return flag(no_grad_gemm);
     if (!strcmp(key, "NO_I8_DIAG")) return flag(no_i8_diag);
     if (!strcmp(key, "NO_I8_FACTOR")) return flag(no_i8_factor);
     if (!strcmp(key, "NO_I8_ROWVECS")) return flag(no_i8_rowvecs);
@@ -78,7 +79,7 @@ struct BlrOptions {
   }
   void from_environment() {
     for (const char* k : {"NO_LDSDMA", "NO_WAVE_KERNEL", "NO_GRAM_RING", "NO_DIAG_SPLIT", "NO_XCD_SWIZZLE", "NO_MFMA_PROJECT", "PLAN_DEBUG",
-                          "NO_I8_GRAM", "NO_MARG_GEMM", "NO_I8_DIAG", "NO_I8_FACTOR", "WAVE_SPLIT", "CHAIN_BATCH", "CHAIN_WS_MB", "SWEEP", "GRAM_SPLITS"}) {
+                          "NO_I8_GRAM", "NO_MARG_GEMM", "NO_GRAD_GEMM", "NO_I8_DIAG", "NO_I8_FACTOR", "NO_I8_ROWVECS", "WAVE_SPLIT", "CHAIN_BATCH", "CHAIN_WS_MB", "SWEEP", "GRAM_SPLITS"}) {
       const std::string name = std::string("BLR_MI355X_") + k;
       if (const char* v = getenv(name.c_str())) (void)set(k, *v ? v : "1");  // (an empty variable still switches a flag on)
     }
@@ -1690,12 +1691,22 @@ int logpdf_grad_batched(blr_handle* h, int memspace, int layout, int64_t B, int6
   // workspace: factor T [B][D x D], posterior mean (if the caller does not want it), dmw partials
   using TC = TrsmCfg<T>;
   const int64_t ntiles = (N + TC::RB - 1) / TC::RB + (Ainv ? (D + TC::RB - 1) / TC::RB : 0);
-  const int64_t per_reg = std::max<int64_t>(1, std::min<int64_t>(ntiles, (512 + B - 1) / B));
+  int64_t per_reg = std::max<int64_t>(1, std::min<int64_t>(ntiles, (512 + B - 1) / B));
+  // D = 128, aligned ColVecs: both sweeps as products with the explicit triangular inverse (grad_gemm_kernel, blr_marginals.hpp):
+  // one workgroup of eight waves per CU, a wave per 16 inputs; A^-1 itself (if wanted) from the sweep kernel's identity tiles
+  using GG = GradGemmCfg<T>;
+  using MG = MargGemmCfg<T>;
+  const bool gemm = !h->opt.no_grad_gemm && D == kPB && layout == BLR_LAYOUT_COLVECS && N >= 64 && B <= 65535 && (ldx % Mfma<T>::VEC) == 0 &&
+                    ((uintptr_t)a.X % 16) == 0 && ((strideX * (int64_t)sizeof(T)) % 16) == 0 &&
+                    (size_t)B * 2 * MG::IMG_ELEMS * sizeof(T) <= ((size_t)1 << 30);
+  const int64_t per_reg_sweep = per_reg;
+  if (gemm) per_reg = std::max<int64_t>(1, std::min<int64_t>(((N + 15) / 16 + 4 * GG::WAVES - 1) / (4 * GG::WAVES), ((int64_t)h->cus + B - 1) / B));
   size_t off = 0;
   auto carve = [&](size_t bytes) { size_t o = off; off = (off + bytes + 255) & ~(size_t)255; return o; };
   const size_t o_T = carve((size_t)B * D * D * sizeof(T));
   const size_t o_mp = carve(mwp_d ? 0 : (size_t)B * D * sizeof(T));
   const size_t o_part = carve(dmw_d ? (size_t)B * per_reg * kPB * sizeof(double) : 0);
+  const size_t o_img = carve(gemm ? (size_t)B * 2 * MG::IMG_ELEMS * sizeof(T) : 0);
   if ((rc = ensure_ws(h, off))) return rc;
   T* Tf = reinterpret_cast<T*>(h->ws + o_T);
   int64_t smp = stride_mwpost;
@@ -1714,7 +1725,28 @@ int logpdf_grad_batched(blr_handle* h, int memspace, int layout, int64_t B, int6
   g.dX = dX_d; g.lddx = lddx; g.stridedX = stridedX; g.dy = dy_d; g.stridedy = stridedy; g.ds = ds_d; g.strideds = strideds;
   g.dmw_part = part; g.Ainv = Ai_d; g.ldai = ldai; g.strideAi = strideAi; g.info = info_d;
   g.layout = layout; g.noise_kind = noise_kind; g.D = (int)D; g.N = (int)N; g.B = (int)B;
-  {
+  if (gemm) {
+    auto kern = logpdf_grad_kernel<T>;
+    const int lds = TC::LDS_BYTES + (kPB + 3 * TC::RB) * (int)sizeof(T);
+    if ((rc = set_lds_once(h, reinterpret_cast<const void*>(marg_image_kernel<T>), (size_t)TC::LDS_BYTES))) return rc;
+    if ((rc = set_lds_once(h, reinterpret_cast<const void*>(grad_gemm_kernel<T>), (size_t)GG::LDS_BYTES))) return rc;
+    T* const img = reinterpret_cast<T*>(h->ws + o_img);
+    T* const img2 = img + B * MG::IMG_ELEMS;
+    hipLaunchKernelGGL(marg_image_kernel<T>, dim3((unsigned)B, 2), dim3(kThreads), TC::LDS_BYTES, h->stream, (const T*)Tf, D, D * D, (int)D, img,
+                       (const int32_t*)info_d, 0, 0, 1, (int64_t)0, img2);
+    g.reg0 = 0;
+    hipLaunchKernelGGL(grad_gemm_kernel<T>, dim3((unsigned)per_reg, (unsigned)B), dim3(GG::THREADS), GG::LDS_BYTES, h->stream, g, (const T*)img,
+                       (const T*)img2);
+    if (Ai_d) {  // A^-1: the identity tiles of the sweep kernel, nothing else (N = 0)
+      if ((rc = set_lds_once(h, reinterpret_cast<const void*>(kern), (size_t)lds))) return rc;
+      GradArgs<T> gi = g;
+      gi.N = 0; gi.dX = nullptr; gi.dy = nullptr; gi.ds = nullptr; gi.dmw_part = nullptr;
+      hipLaunchKernelGGL(kern, dim3((unsigned)std::min<int64_t>(2, per_reg_sweep), (unsigned)B), dim3(kThreads), lds, h->stream, gi);
+    }
+    if (dmw_d)
+      hipLaunchKernelGGL(grad_reduce_kernel<T>, dim3((unsigned)B), dim3(kPB), 0, h->stream, (const double*)part, (int)per_reg,
+                         dmw_d, stridedmw, (int)D);
+  } else {
     auto kern = logpdf_grad_kernel<T>;
     const int lds = TC::LDS_BYTES + (kPB + 3 * TC::RB) * (int)sizeof(T);
     { const int rc_lds = set_lds_once(h, reinterpret_cast<const void*>(kern), (size_t)(lds)); if (rc_lds) return rc_lds; }

@@ -30,13 +30,15 @@ struct MargGemmCfg {
   // contraction index of MFMA m (of a column block), lane group g = lane >> 4:  one 16-byte load covers VEC consecutive d
   __host__ __device__ static constexpr int d_of(int m, int g) { return 4 * VEC * (m / VEC) + VEC * g + (m % VEC); }
   __host__ __device__ static constexpr int frag0(int J) { return 2 * J * (J + 1); }  // first fragment of column block J
+  // second image (gradient): groups of four fragments (Jc, J), J = Jc .. 7, in this order; first group of output block Jc
+  __host__ __device__ static constexpr int frag2_0(int Jc) { return 8 * Jc - Jc * (Jc - 1) / 2; }
 };
 
 // ---- M = L^-T in B-fragment order, two workgroups per regressor (blockIdx.y: rows 0..63 / 64..127 of M) ----------------------------
 template <typename T>
 __global__ __launch_bounds__(kThreads) void marg_image_kernel(const T* __restrict__ U, int64_t ldu, int64_t strideU, int D, T* __restrict__ img,
                                                               const int32_t* __restrict__ info, int reg0, int Dtotal = 0, int nblk = 1,
-                                                              int64_t strideB = 0) {
+                                                              int64_t strideB = 0, T* __restrict__ img2 = nullptr) {
   using Cfg = TrsmCfg<T>;
   using G = MargGemmCfg<T>;
   constexpr int VEC = Mfma<T>::VEC;
@@ -58,6 +60,7 @@ __global__ __launch_bounds__(kThreads) void marg_image_kernel(const T* __restric
     U += (int64_t)reg * strideU;
   }
   img += (int64_t)reg * G::IMG_ELEMS;
+  if (img2) img2 += (int64_t)reg * G::IMG_ELEMS;
   const int nchunks = kPB / 16;
 #ifdef BLR_IMG_STAMPS
   unsigned long long ist[6]; int isn = 0;
@@ -114,6 +117,16 @@ __global__ __launch_bounds__(kThreads) void marg_image_kernel(const T* __restric
         const int at = Dtotal ? ((f / VEC) * 64 + lane) * VEC + (f % VEC) : f * 64 + lane;
         if ((d >> 6) == half) img[at] = Xs[(d & 63) * Cfg::LDX + 16 * J + (lane & 15)];
       }
+    }
+    // the second image (grad_gemm_kernel): B fragments of M' for g = z M' -- fragment (Jc, J, v), J >= Jc, holds M[16 Jc + col][k]
+    // with the contraction index k = 16 J + crow(lane, v): the order in which the accumulators of z' = M'x leave the first product
+    if (img2) {
+#pragma unroll 1
+      for (int Jc = 4 * half; Jc < 4 * half + 4; ++Jc)
+        for (int J = Jc; J < 8; ++J) {
+          const int f2 = (G::frag2_0(Jc) + (J - Jc)) * 4 + wave;  // v = wave
+          img2[f2 * 64 + lane] = Xs[(16 * (Jc & 3) + (lane & 15)) * Cfg::LDX + 16 * J + Mfma<T>::crow(lane, wave)];
+        }
     }
     IMG_T();
 #ifdef BLR_IMG_STAMPS
@@ -211,6 +224,173 @@ __global__ __launch_bounds__(kThreads, 2) void marginals_gemm_kernel(MarginalArg
       for (int u = 0; u < NL; ++u) av[u] = an[u];
 #pragma unroll
       for (int v = 0; v < 4; ++v) sv[v] = sn[v];
+    }
+  }
+}
+
+// ---- the evidence gradient at D = 128 as two products with the same inverse (reference :55-58 through its reverse rule) ------------------
+// logpdf_grad_kernel (blr_large.hpp) sweeps every tile of inputs forward (x'L^-T: the quadratic form) and backward (x'A^-1: dX)
+// through LDS: two dependent chains of eight steps per tile, 0.25 of the matrix peak.  With M = L^-T explicit both are plain
+// products, and the first one's accumulators ARE the second one's A operands if the first is computed transposed:
+//   z' = M'x with the IMAGE as the A operand and the tile's registers as B: lane (n, g) ends up holding z_n[16 J + crow(g, v)] --
+//   four contraction indices per lane group, exactly what an A fragment of  g = z M'  needs once the B fragments of M' are laid out in
+//   that order (marg_image_kernel's second image).  G = X'A^-1 leaves in C layout: sixteen consecutive d per store.
+// One workgroup of eight waves per CU (both images in LDS: 144 KB in fp64), a wave per 16-input tile, the next tile's loads in
+// flight during the second product; dmw partials per lane, reduced once at the end in a fixed order.
+template <typename T>
+struct GradGemmCfg {
+  using G = MargGemmCfg<T>;
+#ifndef BLR_GG_WAVES64
+#define BLR_GG_WAVES64 4
+#endif
+  // fp64: av, z and the dmw partials are 64 registers each -- four waves (512 registers per lane) instead of eight with 100+ spilled
+  static constexpr int WAVES = sizeof(T) == 8 ? BLR_GG_WAVES64 : 8, THREADS = 64 * WAVES;
+  static constexpr int OFF_IMG2 = G::IMG_ELEMS * (int)sizeof(T);
+  static constexpr int OFF_MW = 2 * OFF_IMG2;
+  static constexpr int OFF_RED = OFF_MW + kPB * (int)sizeof(T);          // [WAVES][128] doubles: dmw partials of the waves
+  static constexpr int LDS_BYTES = OFF_RED + WAVES * kPB * 8;
+};
+
+template <typename T>
+__global__ __launch_bounds__(GradGemmCfg<T>::THREADS, 1) void grad_gemm_kernel(GradArgs<T> a, const T* __restrict__ img_all,
+                                                                                const T* __restrict__ img2_all) {
+  using G = MargGemmCfg<T>;
+  using C = GradGemmCfg<T>;
+  using acc4 = typename Mfma<T>::acc4;
+  constexpr int VEC = G::VEC, NL = G::NLOAD;
+  typedef T vecT __attribute__((ext_vector_type(Mfma<T>::VEC)));
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  T* const img = reinterpret_cast<T*>(smem);
+  T* const img2 = reinterpret_cast<T*>(smem + C::OFF_IMG2);
+  T* const mwl = reinterpret_cast<T*>(smem + C::OFF_MW);
+  double* const red = reinterpret_cast<double*>(smem + C::OFF_RED);
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = uni(tid >> 6);
+  const int N = a.N;
+  const int reg = a.reg0 + blockIdx.y;
+  const bool ok = !(a.info && a.info[reg] != 0);
+  T dacc[NL][VEC];  // this lane's share of dmw_d = sum_n x_dn w_n r_n: d = d_of(VEC u + e, g), inputs n = li (mod 16)
+#pragma unroll
+  for (int u = 0; u < NL; ++u)
+#pragma unroll
+    for (int e = 0; e < VEC; ++e) dacc[u][e] = T(0);
+  const int g = lane >> 4, li = lane & 15;
+  if (ok) {
+    const BLR_GLOBAL T* X = as_global(a.X + (int64_t)reg * a.strideX);
+    const BLR_GLOBAL T* s = as_global(a.s + (int64_t)reg * a.strides);
+    const BLR_GLOBAL T* y = as_global(a.y + (int64_t)reg * a.stridey);
+    const BLR_GLOBAL T* mwp = as_global(a.mwp + (int64_t)reg * a.stridemwp);
+    T* const dXr = a.dX ? a.dX + (int64_t)reg * a.stridedX : nullptr;
+    const int ntiles = (N + 15) >> 4;
+    const int t0 = blockIdx.x * C::WAVES + wave, tstep = gridDim.x * C::WAVES;
+    const bool diag_noise = a.noise_kind == NOISE_DIAGONAL;
+    const T s_iso = diag_noise ? T(1) : s[0];
+    vecT av[NL];  // (fp64: 64 registers -- and so are z and the dmw partials: the next tile's loads reuse av once the first product is done)
+    T yv = T(0), svv = s_iso;
+    auto fetch = [&](int tile, vecT (&dst)[NL], T& yd, T& sd) {
+      const int n = min(tile * 16 + li, N - 1);  // (inputs past the end re-read the last one; never stored, weight 0)
+      const BLR_GLOBAL vecT* p = reinterpret_cast<const BLR_GLOBAL vecT*>(X + (int64_t)n * a.ldx + VEC * g);
+#pragma unroll
+      for (int u = 0; u < NL; ++u) dst[u] = p[4 * u];
+      yd = y[n];
+      sd = diag_noise ? s[n] : s_iso;
+    };
+    if (t0 < ntiles) fetch(t0, av, yv, svv);
+    {
+      const BLR_GLOBAL vecT* src = reinterpret_cast<const BLR_GLOBAL vecT*>(as_global(img_all + (int64_t)reg * G::IMG_ELEMS));
+      const BLR_GLOBAL vecT* src2 = reinterpret_cast<const BLR_GLOBAL vecT*>(as_global(img2_all + (int64_t)reg * G::IMG_ELEMS));
+      vecT* dst = reinterpret_cast<vecT*>(img);
+      vecT* dst2 = reinterpret_cast<vecT*>(img2);
+      for (int e = tid; e < G::IMG_ELEMS / VEC; e += C::THREADS) { dst[e] = src[e]; dst2[e] = src2[e]; }
+      if (tid < kPB) mwl[tid] = mwp[tid];
+    }
+    __syncthreads();
+    for (int tile = t0; tile < ntiles; tile += tstep) {
+      const bool more = tile + tstep < ntiles;
+      const int n0 = tile * 16;
+      const bool valid = n0 + li < N;
+      // posterior mean of the input and its residual (lane (li, g): the same value in all four lane groups after the reduction)
+      T macc = T(0);
+#pragma unroll
+      for (int u = 0; u < NL; ++u)
+#pragma unroll
+        for (int e = 0; e < VEC; ++e) macc += av[u][e] * mwl[4 * VEC * u + VEC * g + e];
+      macc += __shfl_xor(macc, 16, 64);
+      macc += __shfl_xor(macc, 32, 64);
+      const T w = valid ? T(1) / svv : T(0);
+      const T rr = valid ? yv - macc : T(0);
+      const T wr = w * rr;
+#pragma unroll
+      for (int u = 0; u < NL; ++u)
+#pragma unroll
+        for (int e = 0; e < VEC; ++e) dacc[u][e] += av[u][e] * wr;
+      // first product, transposed: z[J][v] on lane (li, g) = z_n[16 J + crow(lane, v)], n = n0 + li
+      acc4 z[8];
+      T vq = T(0);
+#pragma unroll
+      for (int J = 0; J < 8; ++J) {
+        acc4 acc = {T(0), T(0), T(0), T(0)};
+        const T* fb = img + G::frag0(J) * 64 + lane;
+#pragma unroll
+        for (int m = 0; m < 4 * (J + 1); ++m) acc = Mfma<T>::mma(fb[m * 64], av[m / VEC][m % VEC], acc);
+        z[J] = acc;
+#pragma unroll
+        for (int v = 0; v < 4; ++v) vq += acc[v] * acc[v];
+        __builtin_amdgcn_sched_barrier(0);  // (without these the scheduler hoists the fragment reads of later blocks: 450 spilled registers)
+      }
+      vq += __shfl_xor(vq, 16, 64);
+      vq += __shfl_xor(vq, 32, 64);  // x_n'A^-1 x_n
+      if (g == 0 && valid) {
+        if (a.dy) a.dy[(int64_t)reg * a.stridedy + n0 + li] = -wr;
+        if (a.ds) a.ds[(int64_t)reg * a.strideds + n0 + li] = -(svv - rr * rr - vq) / (T(2) * svv * svv);
+      }
+      if (more) fetch(tile + tstep, av, yv, svv);  // in flight during the second product (av is dead since the first)
+      // the rows this lane stores: n0 + crow(lane, v)
+      T wrow[4], rrow[4];
+#pragma unroll
+      for (int v = 0; v < 4; ++v) {
+        const int src = Mfma<T>::crow(lane, v);
+        wrow[v] = __shfl(w, src, 64);
+        rrow[v] = __shfl(rr, src, 64);
+      }
+      // second product: G[n][16 Jc + c] = sum_{k >= 16 Jc} z_n[k] M[16 Jc + c][k]
+      __builtin_amdgcn_sched_barrier(0);
+      if (dXr) {
+#pragma unroll
+        for (int Jc = 0; Jc < 8; ++Jc) {
+          acc4 acc = {T(0), T(0), T(0), T(0)};
+          const T* fb2 = img2 + G::frag2_0(Jc) * 4 * 64 + lane;
+#pragma unroll
+          for (int J = Jc; J < 8; ++J)
+#pragma unroll
+            for (int v = 0; v < 4; ++v) acc = Mfma<T>::mma(z[J][v], fb2[((J - Jc) * 4 + v) * 64], acc);
+          const T mwc = mwl[16 * Jc + li];
+#pragma unroll
+          for (int v = 0; v < 4; ++v) {
+            const int n = n0 + Mfma<T>::crow(lane, v);
+            if (n < N) dXr[(int64_t)n * a.lddx + 16 * Jc + li] = wrow[v] * (rrow[v] * mwc - acc[v]);
+          }
+          __builtin_amdgcn_sched_barrier(0);
+        }
+      }
+    }
+  }
+  // dmw partial of this workgroup: lanes of a group hold the same d for 16 different inputs
+  if (a.dmw_part) {
+#pragma unroll
+    for (int u = 0; u < NL; ++u)
+#pragma unroll
+      for (int e = 0; e < VEC; ++e) {
+        double v = (double)dacc[u][e];
+        v += __shfl_xor(v, 1, 64); v += __shfl_xor(v, 2, 64); v += __shfl_xor(v, 4, 64); v += __shfl_xor(v, 8, 64);
+        if (li == 0) red[wave * kPB + 4 * VEC * u + VEC * g + e] = v;
+      }
+    __syncthreads();
+    if (tid < kPB) {
+      double acc = 0.0;
+#pragma unroll
+      for (int w8 = 0; w8 < C::WAVES; ++w8) acc += red[w8 * kPB + tid];
+      a.dmw_part[((int64_t)reg * gridDim.x + blockIdx.x) * kPB + tid] = acc;
     }
   }
 }

@@ -1207,6 +1207,59 @@ def test_large_d_logpdf_gradient(B, dtype, D, N):
     assert float(g["noise"]) == pytest.approx(float(np.sum(g_i["s"])), rel=rt * 10)
 
 
+@pytest.mark.parametrize("dtype,N,noise", [(np.float64, 1000, "diag"), (np.float64, 64, "iso"), (np.float32, 1543, "diag"), (np.float32, 257, "iso")])
+def test_logpdf_gradient_d128_product_form_vs_sweeps_and_oracle(B, opt, dtype, N, noise):
+    # D = 128, aligned ColVecs: both triangular sweeps of the gradient as products with the explicit inverse factor
+    # (grad_gemm_kernel) against the sweep kernel (NO_GRAD_GEMM) and the oracle: a batch with padded leading dimensions of X and dX,
+    # N not a multiple of 16, a regressor whose prior is not positive definite, with and without A^-1 / dX.
+    a = B._abi
+    h = a.default_handle()
+    rng = _rng(9850 + N)
+    Bn, D, ldx = 5, 128, 128 + 4
+    X = np.zeros((Bn, N, ldx), dtype=dtype); X[:, :, :D] = rng.standard_normal((Bn, N, D))
+    y = rng.standard_normal((Bn, N)).astype(dtype)
+    s = np.exp(0.3 * rng.standard_normal((Bn, N))).astype(dtype) if noise == "diag" else np.full((Bn, 1), 0.37, dtype=dtype)
+    mw = (0.3 * rng.standard_normal((Bn, D))).astype(dtype)
+    Lw = np.empty((Bn, D, D), dtype=dtype)
+    for b in range(Bn):
+        Bm = rng.standard_normal((D, D)) / np.sqrt(D)
+        Lw[b] = Bm @ Bm.T + np.eye(D)
+    Lw[3] = -Lw[3]
+
+    def run(want_dx, want_ai):
+        lp = np.zeros(Bn); info = np.full(Bn, 9, dtype=np.int32)
+        dX = np.full_like(X, -7.0) if want_dx else None
+        dy = np.zeros_like(y); ds = np.zeros((Bn, N), dtype=dtype); dmw = np.zeros_like(mw); mwp = np.zeros_like(mw)
+        Ai = np.zeros((Bn, D, D), dtype=dtype) if want_ai else None
+        h.logpdf_grad_batched(dtype, a.MEM_HOST, a.LAYOUT_COLVECS, Bn, D, N, X, ldx, N * ldx, y, N,
+                              a.NOISE_DIAGONAL if noise == "diag" else a.NOISE_ISOTROPIC, s, N if noise == "diag" else 1, a.PRIOR_DENSE,
+                              mw, D, Lw, D, D * D, lp, dX, ldx, N * ldx, dy, N, ds, N, dmw, D, mwp, D, Ai, D, D * D, info)
+        return lp, dX, dy, ds, dmw, mwp, Ai, info
+
+    fast = run(True, True)
+    lean = run(False, False)
+    opt("NO_GRAD_GEMM", "1")
+    slow = run(True, True)
+    opt("NO_GRAD_GEMM", None)
+    ok = [0, 1, 2, 4]
+    assert fast[7].tolist() == slow[7].tolist() and fast[7][3] != 0 and all(fast[7][b] == 0 for b in ok)
+    assert np.all(fast[1][:, :, D:] == -7.0) and np.all(fast[1][3] == -7.0)  # padding and the failed regressor untouched
+    eq = 1e-9 if dtype == np.float64 else 2e-3
+    for u, v in zip(fast[:7], slow[:7]):
+        np.testing.assert_allclose(u[ok], v[ok], rtol=eq, atol=eq * np.abs(v[ok]).max())
+    for i in (0, 2, 3, 4, 5):  # the outputs that do not depend on dX / A^-1 being asked for
+        np.testing.assert_array_equal(fast[i][ok], lean[i][ok])
+    rt = 1e-8 if dtype == np.float64 else 3e-3
+    f64 = lambda v: np.asarray(v, dtype=float)
+    for b in ok:
+        sb = f64(s[b]) if noise == "diag" else float(s[b, 0])
+        lp_o, g_o = O.logpdf_grad(f64(mw[b]), f64(Lw[b]), f64(X[b, :, :D]).T, sb, f64(y[b]))
+        assert fast[0][b] == pytest.approx(lp_o, rel=1e-10 if dtype == np.float64 else 3e-4)
+        for got, ref in ((fast[1][b][:, :D].T, g_o["X"]), (fast[2][b], g_o["y"]), (fast[3][b], g_o["s"]), (fast[4][b], g_o["mw"]),
+                         (fast[5][b], g_o["mw_post"]), (fast[6][b], g_o["Ainv"])):
+            np.testing.assert_allclose(got, ref, rtol=rt, atol=rt * np.abs(ref).max())
+
+
 @pytest.mark.parametrize("Bn", [1, 3, 17])
 @pytest.mark.parametrize("dtype,D,N", [(np.float64, 300, 500), (np.float32, 256, 1100)])
 def test_large_d_logpdf_gradient_batched_share_the_launches(B, opt, Bn, dtype, D, N):

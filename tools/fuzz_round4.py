@@ -3,7 +3,7 @@
   i8     the int8-sliced Gram route at D = 128 (N in 512 .. 16415, prior mean on / off, rows of different scale, both layouts)
   multi  logpdf(fx, Y::Matrix) (temporaries from the side buffer, parallel reductions)
   rand   rand(rng, fx, S) with given normals (rotated fragment images of the MFMA projection)
-  grad   the evidence gradient at D > 128 with the regressors of a batch sharing every launch (both layouts, padded leading
+  grad   the evidence gradient at D = 128 (product form) and D > 128 with the regressors of a batch sharing every launch (both layouts, padded leading
          dimensions, all prior kinds, optional outputs left out, a failing regressor inside the group)
 Not part of the test suite (minutes of GPU time): python tools/fuzz_round4.py [marg|i8|multi|rand|grad] [cases] [seed]"""
 import os, sys
@@ -156,7 +156,7 @@ def rand(rng, case):
 
 def grad(rng, case):
     dtype = np.float32 if rng.random() < 0.4 else np.float64
-    D = int(rng.choice([129, 130, 160, 256, 300, 384, 520]))
+    D = int(rng.choice([128, 128, 129, 130, 160, 256, 300, 384, 520]))  # (128, aligned ColVecs, N >= 64: the product form of the sweeps)
     N = int(rng.choice([1, 7, 64, 100, 129, 500, 1100, 2500]))
     Bn = int(rng.choice([1, 2, 3, 5, 9, 17]))
     rowv = rng.random() < 0.4
