@@ -379,7 +379,7 @@ def secondary_ops(torch, _abi, h, dev):
         flops = B * (D * (D + 1) * N + 2.0 * D * D * N + D**3 + 12.0 * D * N)
         nbytes = w * B * (2 * N * D + 4 * N + D * D + 4 * D)
         return Op(f"B={B}, D={D}, N={N}, {dt}: value + gradient of the log marginal likelihood w.r.t. X, y, s, mw (+ A^-1)", fn, B,
-                  "evaluations/s", flops, nbytes, dt, "logpdf_grad_kernel", check, steps=10, keep=(X, y, s, mw, d, lp, info, dX, dy, ds, dmw, mwp, Ai))
+                  "evaluations/s", flops, nbytes, dt, "grad_gemm_kernel", check, steps=10, keep=(X, y, s, mw, d, lp, info, dX, dy, ds, dmw, mwp, Ai))
 
     def multi(D, N, S, dt):
         t, nd, w = tdt(dt)
