@@ -353,7 +353,7 @@ def secondary_ops(torch, _abi, h, dev):
                   N * S, "outputs/s", 2.0 * D * N * S + D * D * S, w * (D * N + 2 * N * S + 2 * D * S + D * D + D), dt,
                   "rand_project_mfma_kernel", check, keep=(X, Z1, Z2, Y, s, mw, Ucm))
 
-    def grad(B, D, N, dt):
+    def grad(B, D, N, dt, option=None):
         t, nd, w = tdt(dt)
         g = torch.Generator(device=dev).manual_seed(13)
         X = torch.randn((B, N, D), generator=g, dtype=t, device=dev)
@@ -372,14 +372,25 @@ def secondary_ops(torch, _abi, h, dev):
                                   N * D, dy.data_ptr(), N, ds.data_ptr(), N, dmw.data_ptr(), D, mwp.data_ptr(), D, Ai.data_ptr(), D, D * D,
                                   info.data_ptr())
 
+        if option:  # the same call with a run-time switch of the handle set for its duration (A/B entry)
+            fn0 = fn
+
+            def fn():
+                h.set_option(option, "1")
+                try:
+                    fn0()
+                finally:
+                    h.set_option(option, None)
+
         def check():
             assert int(info.abs().sum().item()) == 0 and bool(torch.isfinite(lp).all().item()) and bool(torch.isfinite(dX).all().item())
 
         # value (SYRK half D(D+1)N + 4DN + chol D^3/3) + A^-1 (2D^3/3) + the dX pass (A^-1 X: 2 D^2 N) + O(DN) vector work
         flops = B * (D * (D + 1) * N + 2.0 * D * D * N + D**3 + 12.0 * D * N)
         nbytes = w * B * (2 * N * D + 4 * N + D * D + 4 * D)
-        return Op(f"B={B}, D={D}, N={N}, {dt}: value + gradient of the log marginal likelihood w.r.t. X, y, s, mw (+ A^-1)", fn, B,
-                  "evaluations/s", flops, nbytes, dt, "grad_gemm_kernel", check, steps=10, keep=(X, y, s, mw, d, lp, info, dX, dy, ds, dmw, mwp, Ai))
+        return Op(f"B={B}, D={D}, N={N}, {dt}: value + gradient of the log marginal likelihood w.r.t. X, y, s, mw (+ A^-1)"
+                  + (f", handle option {option}" if option else ""), fn, B,
+                  "evaluations/s", flops, nbytes, dt, "logpdf_grad_kernel" if option == "NO_GRAD_GEMM" else "grad_gemm_kernel", check, steps=10, keep=(X, y, s, mw, d, lp, info, dX, dy, ds, dmw, mwp, Ai))
 
     def multi(D, N, S, dt):
         t, nd, w = tdt(dt)
@@ -488,6 +499,9 @@ def secondary_ops(torch, _abi, h, dev):
         "rand_c2_f64_S64": lambda: rand(128, 4096, 64, "f64"),
         "rand_c3_f32_S64": lambda: rand(1024, 65536, 64, "f32"),
         "logpdf_grad_c2_f64": lambda: grad(1024, 128, 4096, "f64"),
+        # the same call on the sweep kernel (two blocked triangular sweeps per tile through LDS) instead of the product form
+        "logpdf_grad_c2_f64_sweep_kernel": lambda: grad(1024, 128, 4096, "f64", option="NO_GRAD_GEMM"),
+        "logpdf_grad_c2_f32": lambda: grad(1024, 128, 4096, "f32"),
         "logpdf_multi_c3_f32_S64": lambda: multi(1024, 65536, 64, "f32"),
         "update_factor_D128_k1_f64": lambda: update(2048, 128, 1, "f64"),
         "update_factor_D128_k16_f64": lambda: update(2048, 128, 16, "f64"),

@@ -59,7 +59,7 @@ for e in marginals_var_c2_f64 marginals_var_c3_f32 marginals_var_D512_B16_f32 ra
   rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/stats_$e -- $B --secondary-only $e > /dev/null 2>&1
 done
 for e in c2_f64_mw c2_f64_diag_noise c2_f64_factor_prior c2_f64_rowvecs c4_f32 c4_f64_B4096 c4_f64_B2048 c4_f64_B1024 c3_f32_mw logpdf_only_c3_f32 c3_f32_B8 c5_shape_f32_B8 marginals_mean_c2_f64 marginals_var_c2_f64 \
-         marginals_var_c2_f32 marginals_mean_c3_f32 marginals_var_c3_f32 marginals_var_D512_B16_f32 rand_c2_f64_S64 rand_c3_f32_S64 logpdf_grad_c2_f64 logpdf_multi_c3_f32_S64 \
+         marginals_var_c2_f32 marginals_mean_c3_f32 marginals_var_c3_f32 marginals_var_D512_B16_f32 rand_c2_f64_S64 rand_c3_f32_S64 logpdf_grad_c2_f64 logpdf_grad_c2_f64_sweep_kernel logpdf_grad_c2_f32 logpdf_multi_c3_f32_S64 \
          update_factor_D128_k1_f64 update_factor_D128_k16_f64; do
   rocprofv3 --pmc FETCH_SIZE --kernel-trace --output-format csv -d $OUT/sec_fetch_$e -- $B --secondary-only $e > $OUT/sec_fetch_$e.json 2>/dev/null
   rocprofv3 --pmc WRITE_SIZE --kernel-trace --output-format csv -d $OUT/sec_write_$e -- $B --secondary-only $e > $OUT/sec_write_$e.json 2>/dev/null
