@@ -1160,8 +1160,13 @@ BLR_PHASE int phase_chol(char* smem, int D_in, int with_rhs_in) {
   asm volatile("" : "+v"(tid));
   const int lane = tid & 63;
   const int wave = uni(tid >> 6);
-  const int D = uni(D_in);
-  const bool with_rhs = uni(with_rhs_in) != 0;
+  // (opaque to interprocedural constant propagation: with ONE caller that passes D = 128 -- the int8 kernel's translation unit --
+  //  hipcc specialises and unrolls this function into three times the code with 270 scratch accesses)
+  int D = uni(D_in);
+  asm volatile("" : "+s"(D));
+  int with_rhs_i = uni(with_rhs_in);
+  asm volatile("" : "+s"(with_rhs_i));
+  const bool with_rhs = with_rhs_i != 0;
   const int nblk = (D + 15) >> 4;
   const int r = lane & 15, q = lane >> 4;
   const int pr = (r * (r + 1)) >> 1;  // pidx(r, 0)
@@ -1299,7 +1304,8 @@ BLR_PHASE void phase_backsolve(char* smem, int D_in, T* Tout_in, int64_t ldt_in)
   asm volatile("" : "+v"(tid));
   const int lane = tid & 63;
   const int wave = uni(tid >> 6);
-  const int D = uni(D_in);
+  int D = uni(D_in);
+  asm volatile("" : "+s"(D));  // (see phase_chol)
   BLR_GLOBAL T* const Tout = as_global(uni(Tout_in));
   const int64_t ldt = uni(ldt_in);
   if (tid < D) dinv[tid] = T(1) / P[pidx(tid, tid)];
