@@ -1693,13 +1693,12 @@ int logpdf_grad_batched(blr_handle* h, int memspace, int layout, int64_t B, int6
   const int64_t ntiles = (N + TC::RB - 1) / TC::RB + (Ainv ? (D + TC::RB - 1) / TC::RB : 0);
   int64_t per_reg = std::max<int64_t>(1, std::min<int64_t>(ntiles, (512 + B - 1) / B));
   // D = 128, aligned ColVecs: both sweeps as products with the explicit triangular inverse (grad_gemm_kernel, blr_marginals.hpp):
-  // one workgroup of eight waves per CU, a wave per 16 inputs; A^-1 itself (if wanted) from the sweep kernel's identity tiles
+  // one workgroup per CU, a wave per 16 inputs; A^-1 itself (if wanted) = M M' from the same images
   using GG = GradGemmCfg<T>;
   using MG = MargGemmCfg<T>;
   const bool gemm = !h->opt.no_grad_gemm && D == kPB && layout == BLR_LAYOUT_COLVECS && N >= 64 && B <= 65535 && (ldx % Mfma<T>::VEC) == 0 &&
                     ((uintptr_t)a.X % 16) == 0 && ((strideX * (int64_t)sizeof(T)) % 16) == 0 &&
                     (size_t)B * 2 * MG::IMG_ELEMS * sizeof(T) <= ((size_t)1 << 30);
-  const int64_t per_reg_sweep = per_reg;
   if (gemm) per_reg = std::max<int64_t>(1, std::min<int64_t>(((N + 15) / 16 + 4 * GG::WAVES - 1) / (4 * GG::WAVES), ((int64_t)h->cus + B - 1) / B));
   size_t off = 0;
   auto carve = [&](size_t bytes) { size_t o = off; off = (off + bytes + 255) & ~(size_t)255; return o; };
@@ -1726,8 +1725,6 @@ int logpdf_grad_batched(blr_handle* h, int memspace, int layout, int64_t B, int6
   g.dmw_part = part; g.Ainv = Ai_d; g.ldai = ldai; g.strideAi = strideAi; g.info = info_d;
   g.layout = layout; g.noise_kind = noise_kind; g.D = (int)D; g.N = (int)N; g.B = (int)B;
   if (gemm) {
-    auto kern = logpdf_grad_kernel<T>;
-    const int lds = TC::LDS_BYTES + (kPB + 3 * TC::RB) * (int)sizeof(T);
     if ((rc = set_lds_once(h, reinterpret_cast<const void*>(marg_image_kernel<T>), (size_t)TC::LDS_BYTES))) return rc;
     if ((rc = set_lds_once(h, reinterpret_cast<const void*>(grad_gemm_kernel<T>), (size_t)GG::LDS_BYTES))) return rc;
     T* const img = reinterpret_cast<T*>(h->ws + o_img);
@@ -1737,12 +1734,6 @@ int logpdf_grad_batched(blr_handle* h, int memspace, int layout, int64_t B, int6
     g.reg0 = 0;
     hipLaunchKernelGGL(grad_gemm_kernel<T>, dim3((unsigned)per_reg, (unsigned)B), dim3(GG::THREADS), GG::LDS_BYTES, h->stream, g, (const T*)img,
                        (const T*)img2);
-    if (Ai_d) {  // A^-1: the identity tiles of the sweep kernel, nothing else (N = 0)
-      if ((rc = set_lds_once(h, reinterpret_cast<const void*>(kern), (size_t)lds))) return rc;
-      GradArgs<T> gi = g;
-      gi.N = 0; gi.dX = nullptr; gi.dy = nullptr; gi.ds = nullptr; gi.dmw_part = nullptr;
-      hipLaunchKernelGGL(kern, dim3((unsigned)std::min<int64_t>(2, per_reg_sweep), (unsigned)B), dim3(kThreads), lds, h->stream, gi);
-    }
     if (dmw_d)
       hipLaunchKernelGGL(grad_reduce_kernel<T>, dim3((unsigned)B), dim3(kPB), 0, h->stream, (const double*)part, (int)per_reg,
                          dmw_d, stridedmw, (int)D);

@@ -374,6 +374,25 @@ __global__ __launch_bounds__(GradGemmCfg<T>::THREADS, 1) void grad_gemm_kernel(G
         }
       }
     }
+    // A^-1 = M M' (for dL/dLw) from the second image: its fragments (Jn, J, v) are at once the A operand "rows 16 Jn .. of M as
+    // inputs" and the B operand of output block Jc -- 64 blocks of at most 32 MFMAs, dealt over the waves of the regressor's first
+    // workgroup; stored through the symmetry so that sixteen lanes write consecutive addresses
+    if (a.Ainv && blockIdx.x == 0) {
+      T* const Ai = a.Ainv + (int64_t)reg * a.strideAi;
+#pragma unroll 1
+      for (int p = wave; p < 64; p += C::WAVES) {
+        const int Jn = p >> 3, Jc = p & 7;
+        acc4 acc = {T(0), T(0), T(0), T(0)};
+        const T* fa = img2 + (G::frag2_0(Jn) - Jn) * 4 * 64 + lane;
+        const T* fb = img2 + (G::frag2_0(Jc) - Jc) * 4 * 64 + lane;
+#pragma unroll 1
+        for (int J = max(Jn, Jc); J < 8; ++J)
+#pragma unroll
+          for (int v = 0; v < 4; ++v) acc = Mfma<T>::mma(fa[(J * 4 + v) * 64], fb[(J * 4 + v) * 64], acc);
+#pragma unroll
+        for (int v = 0; v < 4; ++v) Ai[(int64_t)(16 * Jn + Mfma<T>::crow(lane, v)) * a.ldai + 16 * Jc + li] = acc[v];
+      }
+    }
   }
   // dmw partial of this workgroup: lanes of a group hold the same d for 16 different inputs
   if (a.dmw_part) {
