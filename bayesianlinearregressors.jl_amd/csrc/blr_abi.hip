@@ -1247,14 +1247,16 @@ int marginals_batched(blr_handle* h, int memspace, int layout, int64_t B, int64_
   else HIP_TRY(h, hipMemsetAsync(info_out_dev, 0, (size_t)B * sizeof(int32_t), h->stream));
   // D = 128 with a factor, aligned ColVecs: the triangular inverse once per regressor, then a dependency-free product
   // (blr_marginals.hpp); regressors in chunks whose images fit 256 MiB
-  if (var && kind == BLR_PRIOR_UPPER_FACTOR && !h->opt.no_marg_gemm && D == kPB && layout == BLR_LAYOUT_COLVECS && N >= 64 &&
-      (ldx % Mfma<T>::VEC) == 0 && ((uintptr_t)a.X % 16) == 0 && ((strideX * (int64_t)sizeof(T)) % 16) == 0) {
+  const bool rowv = layout == BLR_LAYOUT_ROWVECS;  // (RowVecs: scalar loads, no alignment to ask for)
+  if (var && kind == BLR_PRIOR_UPPER_FACTOR && !h->opt.no_marg_gemm && D == kPB && N >= 64 &&
+      (rowv || ((ldx % Mfma<T>::VEC) == 0 && ((uintptr_t)a.X % 16) == 0 && ((strideX * (int64_t)sizeof(T)) % 16) == 0))) {
     using G = MargGemmCfg<T>;
     using TC = TrsmCfg<T>;
     const int64_t chunk = std::min<int64_t>(std::min<int64_t>(B, 65535), ((int64_t)256 << 20) / (G::IMG_ELEMS * (int64_t)sizeof(T)));
     if ((rc = ensure_aux(h, (size_t)chunk * G::IMG_ELEMS * sizeof(T)))) return rc;
     if ((rc = set_lds_once(h, reinterpret_cast<const void*>(marg_image_kernel<T>), (size_t)TC::LDS_BYTES))) return rc;
-    if ((rc = set_lds_once(h, reinterpret_cast<const void*>(marginals_gemm_kernel<T>), (size_t)G::LDS_BYTES))) return rc;
+    void (*const gemm_kern)(MarginalArgs<T>, const T*) = rowv ? marginals_gemm_kernel<T, true> : marginals_gemm_kernel<T, false>;
+    if ((rc = set_lds_once(h, reinterpret_cast<const void*>(gemm_kern), (size_t)G::LDS_BYTES))) return rc;
     T* const img = reinterpret_cast<T*>(h->aux);
     const int64_t ntiles = (N + 15) / 16;
     for (int64_t b0 = 0; b0 < B; b0 += chunk) {
@@ -1267,7 +1269,7 @@ int marginals_batched(blr_handle* h, int memspace, int layout, int64_t B, int64_
       // 74 KB image once: at least four tiles per wave
       const int64_t per_reg = std::max<int64_t>(1, std::min<int64_t>((ntiles + 15) / 16, (2 * (int64_t)h->cus + nb - 1) / nb));
       a.reg0 = (int)b0;
-      hipLaunchKernelGGL(marginals_gemm_kernel<T>, dim3((unsigned)per_reg, (unsigned)nb), dim3(kThreads), G::LDS_BYTES, h->stream, a,
+      hipLaunchKernelGGL(gemm_kern, dim3((unsigned)per_reg, (unsigned)nb), dim3(kThreads), G::LDS_BYTES, h->stream, a,
                          (const T*)(img - b0 * G::IMG_ELEMS));
     }
   } else {
@@ -1696,8 +1698,9 @@ int logpdf_grad_batched(blr_handle* h, int memspace, int layout, int64_t B, int6
   // one workgroup per CU, a wave per 16 inputs; A^-1 itself (if wanted) = M M' from the same images
   using GG = GradGemmCfg<T>;
   using MG = MargGemmCfg<T>;
-  const bool gemm = !h->opt.no_grad_gemm && D == kPB && layout == BLR_LAYOUT_COLVECS && N >= 64 && B <= 65535 && (ldx % Mfma<T>::VEC) == 0 &&
-                    ((uintptr_t)a.X % 16) == 0 && ((strideX * (int64_t)sizeof(T)) % 16) == 0 &&
+  const bool rowv = layout == BLR_LAYOUT_ROWVECS;  // (RowVecs: scalar loads, no alignment to ask for)
+  const bool gemm = !h->opt.no_grad_gemm && D == kPB && N >= 64 && B <= 65535 &&
+                    (rowv || ((ldx % Mfma<T>::VEC) == 0 && ((uintptr_t)a.X % 16) == 0 && ((strideX * (int64_t)sizeof(T)) % 16) == 0)) &&
                     (size_t)B * 2 * MG::IMG_ELEMS * sizeof(T) <= ((size_t)1 << 30);
   if (gemm) per_reg = std::max<int64_t>(1, std::min<int64_t>(((N + 15) / 16 + 4 * GG::WAVES - 1) / (4 * GG::WAVES), ((int64_t)h->cus + B - 1) / B));
   size_t off = 0;
@@ -1726,13 +1729,14 @@ int logpdf_grad_batched(blr_handle* h, int memspace, int layout, int64_t B, int6
   g.layout = layout; g.noise_kind = noise_kind; g.D = (int)D; g.N = (int)N; g.B = (int)B;
   if (gemm) {
     if ((rc = set_lds_once(h, reinterpret_cast<const void*>(marg_image_kernel<T>), (size_t)TC::LDS_BYTES))) return rc;
-    if ((rc = set_lds_once(h, reinterpret_cast<const void*>(grad_gemm_kernel<T>), (size_t)GG::LDS_BYTES))) return rc;
+    void (*const gg_kern)(GradArgs<T>, const T*, const T*) = rowv ? grad_gemm_kernel<T, true> : grad_gemm_kernel<T, false>;
+    if ((rc = set_lds_once(h, reinterpret_cast<const void*>(gg_kern), (size_t)GG::LDS_BYTES))) return rc;
     T* const img = reinterpret_cast<T*>(h->ws + o_img);
     T* const img2 = img + B * MG::IMG_ELEMS;
     hipLaunchKernelGGL(marg_image_kernel<T>, dim3((unsigned)B, 2), dim3(kThreads), TC::LDS_BYTES, h->stream, (const T*)Tf, D, D * D, (int)D, img,
                        (const int32_t*)info_d, 0, 0, 1, (int64_t)0, img2);
     g.reg0 = 0;
-    hipLaunchKernelGGL(grad_gemm_kernel<T>, dim3((unsigned)per_reg, (unsigned)B), dim3(GG::THREADS), GG::LDS_BYTES, h->stream, g, (const T*)img,
+    hipLaunchKernelGGL(gg_kern, dim3((unsigned)per_reg, (unsigned)B), dim3(GG::THREADS), GG::LDS_BYTES, h->stream, g, (const T*)img,
                        (const T*)img2);
     if (dmw_d)
       hipLaunchKernelGGL(grad_reduce_kernel<T>, dim3((unsigned)B), dim3(kPB), 0, h->stream, (const double*)part, (int)per_reg,

@@ -13,7 +13,7 @@
 //                        the A operands of all 144 MFMAs (column block J of M needs rows d < 16 (J + 1) only), the squares of
 //                        the accumulators give var, mean rides on the same registers.
 // The explicit inverse costs forward accuracy cond(L) eps -- the bound of the substitution itself; the 16 x 16 diagonal blocks
-// were inverted explicitly already.  Routed for D = 128, aligned ColVecs; everything else stays on the sweep kernel.
+// were inverted explicitly already.  Routed for D = 128, aligned ColVecs or RowVecs (scalar loads); everything else stays on the sweep kernel.
 #pragma once
 #include "blr_large.hpp"
 
@@ -138,7 +138,9 @@ __global__ __launch_bounds__(kThreads) void marg_image_kernel(const T* __restric
 }
 
 // ---- the stream ------------------------------------------------------------------------------------------------------------------
-template <typename T>
+// ROWV: RowVecs inputs (N x D column-major): the same registers filled by scalar loads -- for a fixed d the sixteen inputs of a tile
+// are consecutive (128 bytes in fp64), so the loads stay whole cache lines; twice (fp64) / four times (fp32) the load instructions.
+template <typename T, bool ROWV = false>
 __global__ __launch_bounds__(kThreads, 2) void marginals_gemm_kernel(MarginalArgs<T> a, const T* __restrict__ img_all) {
   using G = MargGemmCfg<T>;
   using acc4 = typename Mfma<T>::acc4;
@@ -167,9 +169,17 @@ __global__ __launch_bounds__(kThreads, 2) void marginals_gemm_kernel(MarginalArg
   T sv[4], sn[4];
   auto fetch = [&](int tile, vecT (&dst)[NL], T (&sd)[4]) {
     const int n = min(tile * 16 + li, N - 1);  // (inputs past the end re-read the last one; never stored)
-    const BLR_GLOBAL vecT* p = reinterpret_cast<const BLR_GLOBAL vecT*>(X + (int64_t)n * a.ldx + VEC * g);
+    if constexpr (ROWV) {
+      const BLR_GLOBAL T* p = X + n + (int64_t)(VEC * g) * a.ldx;
 #pragma unroll
-    for (int u = 0; u < NL; ++u) dst[u] = p[4 * u];  // (4 VEC elements = 4 vectors apart)
+      for (int u = 0; u < NL; ++u)
+#pragma unroll
+        for (int e = 0; e < VEC; ++e) dst[u][e] = p[(int64_t)(4 * VEC * u + e) * a.ldx];
+    } else {
+      const BLR_GLOBAL vecT* p = reinterpret_cast<const BLR_GLOBAL vecT*>(X + (int64_t)n * a.ldx + VEC * g);
+#pragma unroll
+      for (int u = 0; u < NL; ++u) dst[u] = p[4 * u];  // (4 VEC elements = 4 vectors apart)
+    }
 #pragma unroll
     for (int v = 0; v < 4; ++v) sd[v] = (diag_noise && a.var) ? s[min(tile * 16 + Mfma<T>::crow(lane, v), N - 1)] : s_iso;
   };
@@ -251,7 +261,7 @@ struct GradGemmCfg {
   static constexpr int LDS_BYTES = OFF_RED + WAVES * kPB * 8;
 };
 
-template <typename T>
+template <typename T, bool ROWV = false>
 __global__ __launch_bounds__(GradGemmCfg<T>::THREADS, 1) void grad_gemm_kernel(GradArgs<T> a, const T* __restrict__ img_all,
                                                                                 const T* __restrict__ img2_all) {
   using G = MargGemmCfg<T>;
@@ -289,9 +299,17 @@ __global__ __launch_bounds__(GradGemmCfg<T>::THREADS, 1) void grad_gemm_kernel(G
     T yv = T(0), svv = s_iso;
     auto fetch = [&](int tile, vecT (&dst)[NL], T& yd, T& sd) {
       const int n = min(tile * 16 + li, N - 1);  // (inputs past the end re-read the last one; never stored, weight 0)
-      const BLR_GLOBAL vecT* p = reinterpret_cast<const BLR_GLOBAL vecT*>(X + (int64_t)n * a.ldx + VEC * g);
+      if constexpr (ROWV) {  // RowVecs: scalar loads, sixteen consecutive inputs per d (marginals_gemm_kernel)
+        const BLR_GLOBAL T* p = X + n + (int64_t)(VEC * g) * a.ldx;
 #pragma unroll
-      for (int u = 0; u < NL; ++u) dst[u] = p[4 * u];
+        for (int u = 0; u < NL; ++u)
+#pragma unroll
+          for (int e = 0; e < VEC; ++e) dst[u][e] = p[(int64_t)(4 * VEC * u + e) * a.ldx];
+      } else {
+        const BLR_GLOBAL vecT* p = reinterpret_cast<const BLR_GLOBAL vecT*>(X + (int64_t)n * a.ldx + VEC * g);
+#pragma unroll
+        for (int u = 0; u < NL; ++u) dst[u] = p[4 * u];
+      }
       yd = y[n];
       sd = diag_noise ? s[n] : s_iso;
     };
@@ -368,7 +386,8 @@ __global__ __launch_bounds__(GradGemmCfg<T>::THREADS, 1) void grad_gemm_kernel(G
 #pragma unroll
           for (int v = 0; v < 4; ++v) {
             const int n = n0 + Mfma<T>::crow(lane, v);
-            if (n < N) dXr[(int64_t)n * a.lddx + 16 * Jc + li] = wrow[v] * (rrow[v] * mwc - acc[v]);
+            // (RowVecs: the four stores of a block fill sixteen 128-byte lines between them)
+            if (n < N) dXr[ROWV ? (int64_t)(16 * Jc + li) * a.lddx + n : (int64_t)n * a.lddx + 16 * Jc + li] = wrow[v] * (rrow[v] * mwc - acc[v]);
           }
           __builtin_amdgcn_sched_barrier(0);
         }

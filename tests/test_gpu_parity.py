@@ -1260,6 +1260,69 @@ def test_logpdf_gradient_d128_product_form_vs_sweeps_and_oracle(B, opt, dtype, N
             np.testing.assert_allclose(got, ref, rtol=rt, atol=rt * np.abs(ref).max())
 
 
+@pytest.mark.parametrize("dtype", [np.float64, np.float32])
+def test_d128_product_forms_rowvecs_give_the_bits_of_colvecs(B, dtype):
+    # marginals_gemm_kernel / grad_gemm_kernel with RowVecs inputs (N x D column-major, padded leading dimension): the same
+    # registers filled by scalar loads, the same MFMA sequence -- in fp64 the bits of the ColVecs call on the transposed copy (the
+    # gradient: to rounding, its update runs on the kernel of the layout); N not a multiple of 16.
+    a = B._abi
+    h = a.default_handle()
+    rng = _rng(9870)
+    Bn, D, N = 3, 128, 1000 + 7
+    ldr = N + 3
+    Xc = rng.standard_normal((Bn, N, D)).astype(dtype)            # [N, D] row-major == D x N ColVecs
+    Xr = np.zeros((Bn, D, ldr), dtype=dtype); Xr[:, :, :N] = Xc.transpose(0, 2, 1)  # N x D column-major, lda = N + 3
+    y = rng.standard_normal((Bn, N)).astype(dtype)
+    s = np.exp(0.3 * rng.standard_normal((Bn, N))).astype(dtype)
+    mw = (0.3 * rng.standard_normal((Bn, D))).astype(dtype)
+    U = np.empty((Bn, D, D), dtype=dtype)
+    for b in range(Bn):
+        Bm = rng.standard_normal((D, D)) / np.sqrt(D)
+        U[b] = O.chol_upper(Bm @ Bm.T + np.eye(D)).astype(dtype).T  # column-major upper factor
+
+    def marg(layout, X, ldx, sx):
+        mean = np.zeros((Bn, N), dtype=dtype); var = np.zeros((Bn, N), dtype=dtype); info = np.full(Bn, 9, dtype=np.int32)
+        h.marginals_batched(dtype, a.MEM_HOST, layout, Bn, D, N, X, ldx, sx, a.NOISE_DIAGONAL, s, N, a.PRIOR_UPPER_FACTOR, mw, D, U, D, D * D,
+                            mean, N, var, N, info)
+        assert info.tolist() == [0] * Bn
+        return mean, var
+
+    mc, vc = marg(a.LAYOUT_COLVECS, Xc, D, N * D)
+    mr, vr = marg(a.LAYOUT_ROWVECS, Xr, ldr, D * ldr)
+    if dtype == np.float64:
+        np.testing.assert_array_equal(vc, vr)
+        np.testing.assert_array_equal(mc, mr)
+    else:  # (fp32: hipcc packs pairs of multiplies / adds differently in the two instantiations: an ulp here and there)
+        np.testing.assert_allclose(vr, vc, rtol=1e-6)
+        np.testing.assert_allclose(mr, mc, rtol=1e-5, atol=1e-5)
+    v_o = O.var(mw[0].astype(float), (U[0].T.astype(float).T @ U[0].T.astype(float)), Xc[0].T.astype(float), s[0].astype(float))
+    np.testing.assert_allclose(vr[0], v_o, rtol=1e-9 if dtype == np.float64 else 5e-4)
+
+    def grad(layout, X, ldx, sx):
+        lp = np.zeros(Bn); info = np.full(Bn, 9, dtype=np.int32)
+        dX = np.full_like(X, -7.0); dy = np.zeros_like(y); ds = np.zeros_like(s); dmw = np.zeros_like(mw); mwp = np.zeros_like(mw)
+        Ai = np.zeros((Bn, D, D), dtype=dtype)
+        h.logpdf_grad_batched(dtype, a.MEM_HOST, layout, Bn, D, N, X, ldx, sx, y, N, a.NOISE_DIAGONAL, s, N, a.PRIOR_UPPER_FACTOR,
+                              mw, D, U, D, D * D, lp, dX, ldx, sx, dy, N, ds, N, dmw, D, mwp, D, Ai, D, D * D, info)
+        assert info.tolist() == [0] * Bn
+        return lp, dX, dy, ds, dmw, mwp, Ai
+
+    gc = grad(a.LAYOUT_COLVECS, Xc, D, N * D)
+    gr = grad(a.LAYOUT_ROWVECS, Xr, ldr, D * ldr)
+    # (the update in front runs on the kernel of its layout: the posterior, hence everything after it, agrees to rounding only)
+    eq = 1e-10 if dtype == np.float64 else 2e-3
+    np.testing.assert_allclose(gr[1][:, :, :N].transpose(0, 2, 1), gc[1], rtol=eq, atol=eq * np.abs(gc[1]).max())
+    assert np.all(gr[1][:, :, N:] == -7.0)
+    for i in (0, 2, 3, 4, 5, 6):
+        np.testing.assert_allclose(gr[i], gc[i], rtol=eq, atol=eq * np.abs(gc[i]).max())
+    f64 = lambda v: np.asarray(v, dtype=float)
+    Lw0 = f64(U[0].T).T @ f64(U[0].T)
+    lp_o, g_o = O.logpdf_grad(f64(mw[0]), Lw0, f64(Xc[0]).T, f64(s[0]), f64(y[0]))
+    rt = 1e-8 if dtype == np.float64 else 3e-3
+    np.testing.assert_allclose(gr[1][0][:, :N], g_o["X"], rtol=rt, atol=rt * np.abs(g_o["X"]).max())
+    np.testing.assert_allclose(gr[6][0], g_o["Ainv"], rtol=rt, atol=rt * np.abs(g_o["Ainv"]).max())
+
+
 @pytest.mark.parametrize("Bn", [1, 3, 17])
 @pytest.mark.parametrize("dtype,D,N", [(np.float64, 300, 500), (np.float32, 256, 1100)])
 def test_large_d_logpdf_gradient_batched_share_the_launches(B, opt, Bn, dtype, D, N):

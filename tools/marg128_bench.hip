@@ -28,7 +28,7 @@ int main(int argc, char** argv) {
   CK(hipMemcpy(dmw, mw.data(), D * 8, hipMemcpyHostToDevice)); const T s_iso = 0.1; CK(hipMemcpy(ds, &s_iso, 8, hipMemcpyHostToDevice));
   using G = MargGemmCfg<T>;
   CK(hipFuncSetAttribute(reinterpret_cast<const void*>(marg_image_kernel<T>), hipFuncAttributeMaxDynamicSharedMemorySize, TrsmCfg<T>::LDS_BYTES));
-  CK(hipFuncSetAttribute(reinterpret_cast<const void*>(marginals_gemm_kernel<T>), hipFuncAttributeMaxDynamicSharedMemorySize, G::LDS_BYTES));
+  CK(hipFuncSetAttribute(reinterpret_cast<const void*>(marginals_gemm_kernel<T, false>), hipFuncAttributeMaxDynamicSharedMemorySize, G::LDS_BYTES));
   MarginalArgs<T> a{};
   a.X = dX; a.ldx = D; a.strideX = (int64_t)D * N; a.layout = LAYOUT_COLVECS; a.s = ds; a.strides = 0; a.noise_kind = NOISE_ISOTROPIC;
   a.mw = dmw; a.stridemw = 0; a.U = dU; a.ldu = D; a.strideU = 0; a.prior_kind = PRIOR_UPPER_FACTOR;
@@ -39,7 +39,7 @@ int main(int argc, char** argv) {
     CK(hipEventRecord(e0));
     hipLaunchKernelGGL(marg_image_kernel<T>, dim3(B, 2), dim3(kThreads), TrsmCfg<T>::LDS_BYTES, 0, (const T*)dU, (int64_t)D, (int64_t)0, D, dimg, (const int32_t*)dinfo, 0);
     CK(hipEventRecord(e1));
-    hipLaunchKernelGGL(marginals_gemm_kernel<T>, dim3(per_reg, B), dim3(kThreads), G::LDS_BYTES, 0, a, (const T*)dimg);
+    hipLaunchKernelGGL((marginals_gemm_kernel<T, false>), dim3(per_reg, B), dim3(kThreads), G::LDS_BYTES, 0, a, (const T*)dimg);
     CK(hipEventRecord(e2)); CK(hipEventSynchronize(e2));
     float t1, t2; CK(hipEventElapsedTime(&t1, e0, e1)); CK(hipEventElapsedTime(&t2, e1, e2));
     if (r >= 3) { ms_img += t1 / reps; ms_gemm += t2 / reps; }
