@@ -50,6 +50,7 @@ rocprofv3 --pmc $SQ --kernel-trace --output-format csv -d $OUT/pmc_sq_c3b8 -- $B
   python3 $R/tools/power_probe.py > $OUT/power_probe.txt 2>&1
   python3 $R/tools/group_scan.py > $OUT/group_scan.txt 2>&1
   python3 $R/tools/layout_time.py > $OUT/layout_time.txt 2>&1
+  python3 $R/tools/rowvecs_gap.py > $OUT/rowvecs_gap.txt 2>&1
   { ./marg128_bench 64 4096 8; ./marg128_bench 64 4096 16; ./marg128_bench 256 4096 2; [ -x ./marg128_bench_st ] && ./marg128_bench_st 64 4096 8 1 | grep "image kernel" | head -1; } > $OUT/marg128_bench.txt 2>&1
   { ./marg_bench 1024 65536 20; [ -x ./marg_bench16 ] && ./marg_bench16 1024 65536 20; ./marg_bench 1024 999 20; [ -x ./marg_bench16 ] && ./marg_bench16 1024 999 20; [ -x ./marg_bench_st ] && ./marg_bench_st 1024 65536 5 | grep wave; } > $OUT/marg_bench.txt 2>&1
   # int8-sliced Gram against the fp64 kernel, same inputs: rates, agreement, the retry path (mode 1), per-phase cycle stamps

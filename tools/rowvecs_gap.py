@@ -1,5 +1,6 @@
+"""RowVecs against ColVecs storage on the two product-form kernels at D = 128 (marginals, evidence gradient): python tools/rowvecs_gap.py"""
 import os, sys, time
-sys.path.insert(0, "/root/repo")
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import numpy as np, torch
 import blr_amd
 from blr_amd import _abi as a
