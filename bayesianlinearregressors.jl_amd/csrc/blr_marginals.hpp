@@ -166,8 +166,11 @@ __global__ __launch_bounds__(kThreads, 2) void marginals_gemm_kernel(MarginalArg
   // is isotropic): loaded at the store they were a global-memory round trip at the END of every tile, with nothing left to hide it
   const bool diag_noise = a.noise_kind == NOISE_DIAGONAL;
   const T s_iso = diag_noise ? T(0) : s[0];
-  T sv[4], sn[4];
-  auto fetch = [&](int tile, vecT (&dst)[NL], T (&sd)[4]) {
+  // (the product is computed transposed, z' = M'x with the image as the A operand -- grad_gemm_kernel's trick: lane (li, g) then holds
+  //  entries of ITS input's z, so the row sum needs two shuffles instead of sixteen DPP adds, and noise value and store are one
+  //  coalesced access of the sixteen g = 0 lanes instead of four scattered ones)
+  T sv, sn;
+  auto fetch = [&](int tile, vecT (&dst)[NL], T& sd) {
     const int n = min(tile * 16 + li, N - 1);  // (inputs past the end re-read the last one; never stored)
     if constexpr (ROWV) {
       const BLR_GLOBAL T* p = X + n + (int64_t)(VEC * g) * a.ldx;
@@ -180,8 +183,7 @@ __global__ __launch_bounds__(kThreads, 2) void marginals_gemm_kernel(MarginalArg
 #pragma unroll
       for (int u = 0; u < NL; ++u) dst[u] = p[4 * u];  // (4 VEC elements = 4 vectors apart)
     }
-#pragma unroll
-    for (int v = 0; v < 4; ++v) sd[v] = (diag_noise && a.var) ? s[min(tile * 16 + Mfma<T>::crow(lane, v), N - 1)] : s_iso;
+    sd = (diag_noise && a.var) ? s[n] : s_iso;
   };
   if (t0 < ntiles) fetch(t0, av, sv);
   // the image and the prior mean: once per workgroup
@@ -206,34 +208,29 @@ __global__ __launch_bounds__(kThreads, 2) void marginals_gemm_kernel(MarginalArg
       macc += __shfl_xor(macc, 32, 64);
     }
     // z = x'M column block by column block; var_n = |z_n|^2
-    T sq[4] = {T(0), T(0), T(0), T(0)};
+    T sq = T(0);
     if (a.var) {
 #pragma unroll
       for (int J = 0; J < 8; ++J) {
         acc4 acc = {T(0), T(0), T(0), T(0)};
         const T* fb = img + G::frag0(J) * 64 + lane;
 #pragma unroll
-        for (int m = 0; m < 4 * (J + 1); ++m) acc = Mfma<T>::mma(av[m / VEC][m % VEC], fb[m * 64], acc);
+        for (int m = 0; m < 4 * (J + 1); ++m) acc = Mfma<T>::mma(fb[m * 64], av[m / VEC][m % VEC], acc);
 #pragma unroll
-        for (int v = 0; v < 4; ++v) sq[v] += acc[v] * acc[v];
+        for (int v = 0; v < 4; ++v) sq += acc[v] * acc[v];
       }
-#pragma unroll
-      for (int v = 0; v < 4; ++v) sq[v] = row16_allreduce(sq[v]);  // over the 16 columns of the block a lane group holds
+      sq += __shfl_xor(sq, 16, 64);
+      sq += __shfl_xor(sq, 32, 64);
     }
     const int n0 = tile * 16;
-    if (a.mean && g == 0 && n0 + li < N) a.mean[(int64_t)reg * a.stridemean + n0 + li] = macc;
-    if (a.var && li == 0) {
-#pragma unroll
-      for (int v = 0; v < 4; ++v) {
-        const int n = n0 + Mfma<T>::crow(lane, v);
-        if (n < N) a.var[(int64_t)reg * a.stridevar + n] = sq[v] + sv[v];
-      }
+    if (g == 0 && n0 + li < N) {
+      if (a.mean) a.mean[(int64_t)reg * a.stridemean + n0 + li] = macc;
+      if (a.var) a.var[(int64_t)reg * a.stridevar + n0 + li] = sq + sv;
     }
     if (more) {
 #pragma unroll
       for (int u = 0; u < NL; ++u) av[u] = an[u];
-#pragma unroll
-      for (int v = 0; v < 4; ++v) sv[v] = sn[v];
+      sv = sn;
     }
   }
 }
