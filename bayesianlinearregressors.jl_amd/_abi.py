@@ -52,6 +52,9 @@ _SIGS = {
     "blr_synchronize": ([_H], _int),
     "blr_set_option": ([_H, C.c_char_p, C.c_char_p], _int),
     "blr_release_workspace": ([_H], _int),
+    "blr_last_route": ([_H], C.c_char_p),
+    "blr_get_stat": ([_H, C.c_char_p, C.POINTER(_i64)], _int),
+    "blr_reset_stats": ([_H], _int),
     "blr_device_alloc": ([_H, C.c_size_t, C.POINTER(_vp)], _int),
     "blr_device_free": ([_H, _vp], _int),
     "blr_memcpy_h2d": ([_H, _vp, _vp, C.c_size_t], _int),
@@ -214,6 +217,19 @@ class Handle:
     def set_option(self, key, value=None):
         """Run-time switch of this handle (include/blr_mi355x.h blr_set_option); value None = the built-in default."""
         self.check(self.lib.blr_set_option(self._h, str(key).encode(), None if value is None else str(value).encode()))
+
+    def last_route(self):
+        """Kernel family the most recent posterior / logpdf dispatch launched (include/blr_mi355x.h blr_last_route)."""
+        return self.lib.blr_last_route(self._h).decode()
+
+    def get_stat(self, key):
+        """Counter of this handle: "i8_regressors", "i8_handed_back", "workspace_bytes" (blr_get_stat)."""
+        v = _i64()
+        self.check(self.lib.blr_get_stat(self._h, str(key).encode(), C.byref(v)))
+        return int(v.value)
+
+    def reset_stats(self):
+        self.check(self.lib.blr_reset_stats(self._h))
 
     def timer_start(self):
         self.check(self.lib.blr_timer_start(self._h))

@@ -34,15 +34,22 @@ using namespace blr;
 // handle is created (BLR_MI355X_<KEY>), and settable per handle with blr_set_option: no getenv on any launch path.
 struct BlrOptions {
   bool no_ldsdma = false, no_wave_kernel = false, no_gram_ring = false, no_diag_split = false, no_xcd_swizzle = false,
-       no_mfma_project = false, plan_debug = false, no_i8_gram = false, no_marg_gemm = false, no_i8_diag = false, no_i8_factor = false, no_i8_rowvecs = false, no_grad_gemm = false;
+       no_mfma_project = false, plan_debug = false, no_i8_gram = false, no_marg_gemm = false, no_i8_diag = false, no_i8_factor = false, no_i8_rowvecs = false, no_grad_gemm = false, no_i8_dense = false, no_i8_fallback = false;
   int wave_split = 0;     // waves per regressor of the wave kernel: 0 = router, else 1 | 2 | 4
   int chain_batch = 0;    // regressors per shared launch at D > 128: 0 = as many as the workspace holds
   long chain_ws_mb = 0;   // workspace bound of such a group in MiB: 0 = kChainWorkspace
   int sweep = 0;          // blr_update_factor_* route: 0 = router, 1 = always the Givens sweep, 2 = never
   int gs_fields = 0, gs_so = 0, gs_sd = 0, gs_nl = 0;  // GRAM_SPLITS = "off-diagonal,diagonal[,nlong]" (gs_fields = numbers parsed)
-  // -> 0, or -1 for an unknown key / malformed value.  value NULL or "" = the built-in default
+  // -> 0, -2 for an unknown key, -3 for a malformed value (the codes blr_set_option documents).  value NULL or "" = the built-in default
+  static bool parse_long(const char* v, long& out) {  // the whole string must be a decimal number
+    char* end = nullptr;
+    const long x = strtol(v, &end, 10);
+    if (end == v || *end != '\0') return false;
+    out = x;
+    return true;
+  }
   int set(const char* key, const char* value) {
-    if (!key) return -1;
+    if (!key) return -2;
     if (!strncmp(key, "BLR_MI355X_", 11)) key += 11;
     const bool on = value && *value;
     auto flag = [&](bool& f) { f = on; return 0; };
@@ -59,29 +66,52 @@ struct BlrOptions {
     if (!strcmp(key, "NO_I8_DIAG")) return flag(no_i8_diag);
     if (!strcmp(key, "NO_I8_FACTOR")) return flag(no_i8_factor);
     if (!strcmp(key, "NO_I8_ROWVECS")) return flag(no_i8_rowvecs);
+    if (!strcmp(key, "NO_I8_DENSE")) return flag(no_i8_dense);
+    if (!strcmp(key, "NO_I8_FALLBACK")) return flag(no_i8_fallback);
+    long v = 0;
     if (!strcmp(key, "WAVE_SPLIT")) {
-      const int v = on ? atoi(value) : 0;
-      wave_split = (v == 1 || v == 2 || v == 4) ? v : 0;
-      return (!on || wave_split) ? 0 : -1;
+      if (!on) { wave_split = 0; return 0; }
+      if (!parse_long(value, v) || !(v == 1 || v == 2 || v == 4)) return -3;
+      wave_split = (int)v;
+      return 0;
     }
-    if (!strcmp(key, "CHAIN_BATCH")) { chain_batch = on ? std::max(1, atoi(value)) : 0; return 0; }
-    if (!strcmp(key, "CHAIN_WS_MB")) { chain_ws_mb = on ? std::max(1L, atol(value)) : 0; return 0; }
+    if (!strcmp(key, "CHAIN_BATCH")) {
+      if (!on) { chain_batch = 0; return 0; }
+      if (!parse_long(value, v) || v < 1 || v > 128) return -3;
+      chain_batch = (int)v;
+      return 0;
+    }
+    if (!strcmp(key, "CHAIN_WS_MB")) {
+      if (!on) { chain_ws_mb = 0; return 0; }
+      if (!parse_long(value, v) || v < 1) return -3;
+      chain_ws_mb = v;
+      return 0;
+    }
     if (!strcmp(key, "SWEEP")) {
-      sweep = !on ? 0 : (!strcmp(value, "always") ? 1 : (!strcmp(value, "never") ? 2 : 0));
-      return (!on || sweep || !strcmp(value, "auto")) ? 0 : -1;
+      if (!on || !strcmp(value, "auto")) { sweep = 0; return 0; }
+      if (!strcmp(value, "always")) { sweep = 1; return 0; }
+      if (!strcmp(value, "never")) { sweep = 2; return 0; }
+      return -3;
     }
     if (!strcmp(key, "GRAM_SPLITS")) {
       gs_fields = gs_so = gs_sd = gs_nl = 0;
       if (on) gs_fields = sscanf(value, "%d,%d,%d", &gs_so, &gs_sd, &gs_nl);
-      return (!on || gs_fields >= 2) ? 0 : -1;
+      return (!on || gs_fields >= 2) ? 0 : -3;
     }
-    return -1;
+    return -2;
   }
   void from_environment() {
+    // boolean flags: a variable that is set -- even to the empty string -- switches the flag on
     for (const char* k : {"NO_LDSDMA", "NO_WAVE_KERNEL", "NO_GRAM_RING", "NO_DIAG_SPLIT", "NO_XCD_SWIZZLE", "NO_MFMA_PROJECT", "PLAN_DEBUG",
-                          "NO_I8_GRAM", "NO_MARG_GEMM", "NO_GRAD_GEMM", "NO_I8_DIAG", "NO_I8_FACTOR", "NO_I8_ROWVECS", "WAVE_SPLIT", "CHAIN_BATCH", "CHAIN_WS_MB", "SWEEP", "GRAM_SPLITS"}) {
+                          "NO_I8_GRAM", "NO_MARG_GEMM", "NO_GRAD_GEMM", "NO_I8_DIAG", "NO_I8_FACTOR", "NO_I8_ROWVECS", "NO_I8_DENSE", "NO_I8_FALLBACK"}) {
       const std::string name = std::string("BLR_MI355X_") + k;
-      if (const char* v = getenv(name.c_str())) (void)set(k, *v ? v : "1");  // (an empty variable still switches a flag on)
+      if (const char* v = getenv(name.c_str())) (void)set(k, *v ? v : "1");
+    }
+    // valued options: an empty variable is ignored (the built-in default stays), a malformed one too
+    for (const char* k : {"WAVE_SPLIT", "CHAIN_BATCH", "CHAIN_WS_MB", "SWEEP", "GRAM_SPLITS"}) {
+      const std::string name = std::string("BLR_MI355X_") + k;
+      if (const char* v = getenv(name.c_str()))
+        if (*v) (void)set(k, v);
     }
   }
 };
@@ -100,8 +130,16 @@ struct blr_handle {
   size_t ws_bytes = 0;
   char* feat = nullptr;        // grow-only feature matrix of blr_posterior_rff_*
   size_t feat_bytes = 0;
-  char* aux = nullptr;         // grow-only: triangular-inverse images of the marginal stream (blr_marginals.hpp)
+  char* aux = nullptr;         // grow-only: triangular-inverse images of the marginal stream (blr_marginals.hpp), temporaries of logpdf_multi
   size_t aux_bytes = 0;
+  char* i8side = nullptr;      // grow-only: what the int8 route prepares per call (y / sqrt(s), 1 / sqrt(s), ... -- launch_fused_i8); a buffer of
+  size_t i8side_bytes = 0;     // its own because logpdf_multi carves ITS temporaries from `aux` around a nested update that may take that route
+  // counters behind blr_get_stat: [0] regressors the int8 route handed back to the fp64 kernel (cumulative); [8 + 2 k + {0, 1}]:
+  // hand-backs of slice k of the current call (two banks, alternating), read by the NEXT slice's launch (launch_fused_i8)
+  unsigned long long* stats_dev = nullptr;
+  unsigned long long i8_attempted = 0;   // regressors sent down the int8 route (host count)
+  unsigned i8_slices = 0;                // parity = bank of the per-slice hand-back counter
+  const char* route = "none";            // kernel family the most recent posterior dispatch launched (blr_last_route)
   // wavefront back substitution (D > 128): tagged exchange buffer, start-order ticket counter, launch epoch
   unsigned long long* xchg = nullptr;
   size_t xchg_bytes = 0;
@@ -236,6 +274,25 @@ int ensure_ws(blr_handle* h, size_t bytes) {
   return 0;
 }
 
+int ensure_i8side(blr_handle* h, size_t bytes) {
+  if (bytes <= h->i8side_bytes) return 0;
+  if (h->i8side) {
+    HIP_TRY(h, hipStreamSynchronize(h->stream));
+    HIP_TRY(h, hipFree(h->i8side));
+    h->i8side = nullptr;
+    h->i8side_bytes = 0;
+  }
+  HIP_TRY(h, hipMalloc((void**)&h->i8side, bytes));
+  h->i8side_bytes = bytes;
+  return 0;
+}
+int ensure_stats(blr_handle* h) {
+  if (h->stats_dev) return 0;
+  HIP_TRY(h, hipMalloc((void**)&h->stats_dev, 16 * sizeof(unsigned long long)));
+  HIP_TRY(h, hipMemsetAsync(h->stats_dev, 0, 16 * sizeof(unsigned long long), h->stream));
+  return 0;
+}
+
 int ensure_aux(blr_handle* h, size_t bytes) {
   if (bytes <= h->aux_bytes) return 0;
   if (h->aux) {
@@ -311,6 +368,11 @@ int launch_fused_small(blr_handle* h, const PosteriorArgs<T>& a) {
   int grid = (int)std::min<int64_t>(a.B, 1 << 20);
   hipLaunchKernelGGL(kern, dim3(grid), dim3(kThreads), C::LDS_BYTES, h->stream, a);
   HIP_TRY(h, hipGetLastError());
+  if (!a.retry_only) {
+    static const std::string name = std::string("fused_small_kernel<") + (sizeof(T) == 8 ? "double" : "float") + ", " + std::to_string(NB) + ", " +
+                                    std::to_string(MODE) + ">";
+    h->route = name.c_str();
+  }
   return 0;
 }
 
@@ -335,6 +397,9 @@ int launch_fused_wave_nw(blr_handle* h, const PosteriorArgs<T>& a) {
   }
   hipLaunchKernelGGL((fused_wave_kernel<T, NB, NW>), dim3(grid), dim3(64 * NW), NW * C::LDS_BYTES, h->stream, a);
   HIP_TRY(h, hipGetLastError());
+  static const std::string name = std::string("fused_wave_kernel<") + (sizeof(T) == 8 ? "double" : "float") + ", " + std::to_string(NB) + ", " +
+                                  std::to_string(NW) + ">";
+  h->route = name.c_str();
   return 0;
 }
 // The chip has 2048 wave slots for this kernel.  A batch that cannot fill them with one regressor per wave splits each
@@ -356,11 +421,12 @@ int launch_fused_i8(blr_handle* h, const PosteriorArgs<double>& a) {
   const bool diag = a.noise_kind == BLR_NOISE_DIAGONAL, rowv = a.layout == BLR_LAYOUT_ROWVECS;
   // (the kernel's four instantiations: blr_i8_kernels.hip)
   const void* const kern = diag ? i8_kernel_ptr_diag(rowv) : i8_kernel_ptr_iso(rowv);
-  if (kern == nullptr) return hip_fail(h, hipErrorInvalidValue, "BLR_DEV_FAST build: isotropic ColVecs form of the int8 kernel only");
+  if (kern == nullptr) return hip_fail(h, hipErrorInvalidValue, "this build lacks the requested form of the int8 kernel");
   int rc = set_lds_once(h, kern, (size_t)I8Cfg::LDS_BYTES);
   if (rc) return rc;
-  // diagonal noise: y / sqrt(s), 1 / sqrt(s), sum log s and a validity flag per regressor, once per call, in the handle's side
-  // buffer (16 bytes per observation: slices of at most 1 GiB)
+  if ((rc = ensure_stats(h))) return rc;
+  // diagonal noise: y / sqrt(s), 1 / sqrt(s), sum log s and a validity flag per regressor, once per call, in a side buffer of the
+  // handle (16 bytes per observation: slices of at most 1 GiB)
   const int64_t per_reg = 2 * (int64_t)a.N * (int64_t)sizeof(double);
   const int grid = (int)std::min<int64_t>(a.B, diag ? std::max<int64_t>(1, ((int64_t)1 << 30) / per_reg) : (1 << 20));
   double *yt = nullptr, *rw = nullptr, *ld = nullptr, *rmx = nullptr;
@@ -369,13 +435,22 @@ int launch_fused_i8(blr_handle* h, const PosteriorArgs<double>& a) {
     const size_t o_rw = (((size_t)grid * a.N * sizeof(double)) + 255) & ~(size_t)255;
     const size_t o_ld = 2 * o_rw, o_mx = o_ld + (((size_t)grid * sizeof(double) + 255) & ~(size_t)255);
     const size_t o_bad = o_mx + (((size_t)grid * sizeof(double) + 255) & ~(size_t)255);
-    if ((rc = ensure_aux(h, o_bad + (size_t)grid * sizeof(int32_t)))) return rc;
-    yt = reinterpret_cast<double*>(h->aux); rw = reinterpret_cast<double*>(h->aux + o_rw);
-    ld = reinterpret_cast<double*>(h->aux + o_ld); rmx = reinterpret_cast<double*>(h->aux + o_mx); bad = reinterpret_cast<int32_t*>(h->aux + o_bad);
+    if ((rc = ensure_i8side(h, o_bad + (size_t)grid * sizeof(int32_t)))) return rc;
+    yt = reinterpret_cast<double*>(h->i8side); rw = reinterpret_cast<double*>(h->i8side + o_rw);
+    ld = reinterpret_cast<double*>(h->i8side + o_ld); rmx = reinterpret_cast<double*>(h->i8side + o_mx); bad = reinterpret_cast<int32_t*>(h->i8side + o_bad);
   }
-  for (int64_t b0 = 0; b0 < a.B; b0 += grid) {  // (one workgroup per regressor: batches beyond 2^20 in slices)
+  // Slices: one workgroup per regressor (batches beyond 2^20, or beyond the side buffer, in several launches).  A batch of more than
+  // kI8ProbeMin regressors starts with a PROBE slice of kI8Probe (one round of workgroups on the chip): every later slice reads how
+  // many regressors of the slice before it the fast path had to hand back, and when that was more than a quarter its workgroups
+  // leave their regressors to the fp64 kernel at once instead of streaming them twice (heavy-tailed inputs: blr_get_stat
+  // "i8_handed_back").  The decision depends on the data of the previous slice only: same inputs, same bits.
+  int64_t b0 = 0;
+  int prev_n = 0;
+  while (b0 < a.B) {
     PosteriorArgs<double> s = a;
-    const int nb = (int)std::min<int64_t>(grid, a.B - b0);
+    int64_t want = std::min<int64_t>(grid, a.B - b0);
+    if (b0 == 0 && a.B > kI8ProbeMin && !h->opt.no_i8_fallback) want = std::min<int64_t>(want, kI8Probe);
+    const int nb = (int)want;
     s.B = nb;
     s.X += b0 * a.strideX; s.y += b0 * a.stridey; s.s += b0 * a.strides; s.mw += b0 * a.stridemw; s.Lw += b0 * a.strideLw;
     if (s.mw_post) s.mw_post += b0 * a.stride_mwpost;
@@ -383,6 +458,11 @@ int launch_fused_i8(blr_handle* h, const PosteriorArgs<double>& a) {
     if (s.Lw_post) s.Lw_post += b0 * a.strideLp;
     if (s.logpdf) s.logpdf += b0;
     s.info += b0;
+    s.i8_handed_tot = h->stats_dev;
+    s.i8_handed_slice = h->stats_dev + 8 + (h->i8_slices & 1u);         // zeroed by this slice's int8 launch, counted up by its retry launch
+    s.i8_prev_handed = h->stats_dev + 8 + ((h->i8_slices & 1u) ^ 1u);   // final since the previous slice's retry launch
+    s.i8_prev_n = h->opt.no_i8_fallback ? 0 : prev_n;
+    ++h->i8_slices;
     if (diag) {
       s.i8_yt = yt; s.i8_rw = rw; s.i8_stride = a.N; s.i8_logdet = ld; s.i8_bad = bad; s.i8_rwmax = rmx;
       hipLaunchKernelGGL(i8_noise_prep_kernel, dim3(nb), dim3(kThreads), 0, h->stream, s.s, a.strides, s.y, a.stridey, (int)a.N, yt, rw, (int64_t)a.N, ld,
@@ -393,7 +473,11 @@ int launch_fused_i8(blr_handle* h, const PosteriorArgs<double>& a) {
     HIP_TRY(h, hipGetLastError());
     s.retry_only = 1;
     if ((rc = launch_fused_small_mode<double, 8>(h, s))) return rc;
+    h->i8_attempted += (unsigned long long)nb;
+    prev_n = nb;
+    b0 += nb;
   }
+  h->route = "fused_i8_kernel";
   return 0;
 }
 
@@ -405,7 +489,8 @@ int dispatch_fused_small(blr_handle* h, const PosteriorArgs<T>& a) {
     const bool i8_layout = a.layout == BLR_LAYOUT_COLVECS
                                ? a.vec_ok
                                : (!h->opt.no_i8_rowvecs && ((uintptr_t)a.X & 15) == 0 && (a.ldx & 1) == 0 && (a.B == 1 || (a.strideX & 1) == 0));
-    if (!h->opt.no_i8_gram && !h->opt.no_ldsdma && a.D == 128 && i8_layout &&
+    const bool i8_built = (a.noise_kind == BLR_NOISE_DIAGONAL ? i8_kernel_ptr_diag(a.layout == BLR_LAYOUT_ROWVECS) : i8_kernel_ptr_iso(a.layout == BLR_LAYOUT_ROWVECS)) != nullptr;
+    if (i8_built && !h->opt.no_i8_gram && !h->opt.no_ldsdma && a.D == 128 && i8_layout &&
         (a.noise_kind == BLR_NOISE_ISOTROPIC || (a.noise_kind == BLR_NOISE_DIAGONAL && !h->opt.no_i8_diag)) &&
         (a.prior_kind == BLR_PRIOR_DIAGONAL || (a.prior_kind == BLR_PRIOR_UPPER_FACTOR && !h->opt.no_i8_factor)) && a.N - a.N % I8Cfg::KC >= kI8MinN && a.N - a.N % I8Cfg::KC <= kI8MaxN && a.ldx * 8 * I8Cfg::KC < ((int64_t)1 << 31))
       return launch_fused_i8(h, a);
@@ -559,6 +644,7 @@ inline GramPlan plan_gram_rounds(int n_off, int NC, int s0, int N, int nsc, int 
 // the small kernels around the Gram launch.  G = 1 is the single-regressor path.
 template <typename T>
 int posterior_large_group(blr_handle* h, const PosteriorArgs<T>& a, int64_t reg0, int G, int* G_done = nullptr) {
+  h->route = sizeof(T) == 8 ? "gram_tile_kernel<double>" : "gram_tile_kernel<float>";  // (large-D pipeline: the Gram launch dominates)
   using LC = LargeCfg<T>;
   const int D = a.D, N = a.N;
   const int DP = (D + kPB - 1) / kPB * kPB, NC = DP / kPB;
@@ -2784,6 +2870,8 @@ int blr_destroy(blr_handle* h) {
   if (h->ws) (void)hipFree(h->ws);
   if (h->feat) (void)hipFree(h->feat);
   if (h->aux) (void)hipFree(h->aux);
+  if (h->i8side) (void)hipFree(h->i8side);
+  if (h->stats_dev) (void)hipFree(h->stats_dev);
   if (h->xchg) (void)hipFree(h->xchg);
   if (h->ticket) (void)hipFree(h->ticket);
   if (h->ev0) (void)hipEventDestroy(h->ev0);
@@ -2803,25 +2891,66 @@ int blr_release_workspace(blr_handle* h) {
   if (h->ws) { HIP_TRY(h, hipFree(h->ws)); h->ws = nullptr; h->ws_bytes = 0; }
   if (h->feat) { HIP_TRY(h, hipFree(h->feat)); h->feat = nullptr; h->feat_bytes = 0; }
   if (h->aux) { HIP_TRY(h, hipFree(h->aux)); h->aux = nullptr; h->aux_bytes = 0; }
+  if (h->i8side) { HIP_TRY(h, hipFree(h->i8side)); h->i8side = nullptr; h->i8side_bytes = 0; }
   return 0;
 }
 
 int blr_set_option(blr_handle* h, const char* key, const char* value) {
   if (!h) return -1;
   h->err.clear();
-  if (h->opt.set(key, value) != 0) return bad_arg(h, key ? 3 : 2, "unknown option or malformed value");
+  const int orc = h->opt.set(key, value);
+  if (orc == -2) return bad_arg(h, 2, "unknown option key");
+  if (orc != 0) return bad_arg(h, 3, "malformed option value");
   h->gram_plans.clear();  // (cached launch plans were made under the old switches)
   return 0;
 }
 
+// Work of one handle is ordered by ITS stream: the arrival counters of panel_chain_kernel, the tagged exchange buffer and the
+// grow-only scratch assume that a launch's predecessor on the handle has finished with them.  Switching streams therefore
+// drains the old one first and re-arms both banks of arrival counters (a launch clears the bank of its successor, which on a
+// second stream could already be counting in it).
+static int switch_stream(blr_handle* h, hipStream_t next) {
+  if (next == h->stream) return 0;
+  HIP_TRY(h, hipSetDevice(h->device));
+  HIP_TRY(h, hipStreamSynchronize(h->stream));
+  h->stream = next;
+  if (h->ticket) HIP_TRY(h, hipMemsetAsync(h->ticket + 16, 0, 2 * kPanelArriveWords * sizeof(unsigned), h->stream));
+  h->panel_launches = 0;
+  return 0;
+}
 int blr_set_stream(blr_handle* h, void* hip_stream) {
   if (!h) return -1;
-  h->stream = static_cast<hipStream_t>(hip_stream);
-  return 0;
+  return switch_stream(h, static_cast<hipStream_t>(hip_stream));
 }
 int blr_reset_stream(blr_handle* h) {
   if (!h) return -1;
-  h->stream = h->own_stream;
+  return switch_stream(h, h->own_stream);
+}
+const char* blr_last_route(blr_handle* h) { return h ? h->route : "null handle"; }
+
+int blr_get_stat(blr_handle* h, const char* key, int64_t* value) {
+  if (!h) return -1;
+  h->err.clear();
+  if (!key) return bad_arg(h, 2, "key is NULL");
+  if (!value) return bad_arg(h, 3, "value is NULL");
+  if (!strcmp(key, "i8_regressors")) { *value = (int64_t)h->i8_attempted; return 0; }
+  if (!strcmp(key, "i8_handed_back")) {
+    unsigned long long v = 0;
+    if (h->stats_dev) {
+      HIP_TRY(h, hipSetDevice(h->device));
+      HIP_TRY(h, hipMemcpyAsync(&v, h->stats_dev, sizeof(v), hipMemcpyDeviceToHost, h->stream));
+      HIP_TRY(h, hipStreamSynchronize(h->stream));
+    }
+    *value = (int64_t)v;
+    return 0;
+  }
+  if (!strcmp(key, "workspace_bytes")) { *value = (int64_t)(h->ws_bytes + h->feat_bytes + h->aux_bytes + h->i8side_bytes + h->xchg_bytes); return 0; }
+  return bad_arg(h, 2, "unknown statistic");
+}
+int blr_reset_stats(blr_handle* h) {
+  if (!h) return -1;
+  h->i8_attempted = 0;
+  if (h->stats_dev) HIP_TRY(h, hipMemsetAsync(h->stats_dev, 0, sizeof(unsigned long long), h->stream));
   return 0;
 }
 int blr_set_async(blr_handle* h, int async) {

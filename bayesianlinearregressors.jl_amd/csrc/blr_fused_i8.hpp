@@ -57,6 +57,8 @@ constexpr int kI8Retry = kI8RetryCode;  // info: "this regressor must be redone 
 constexpr int kI8Margin = 3;            // binades of headroom above the first block's row maximum
 constexpr int kI8MaxN = 16384;          // int32 accumulators: 6 N 2^14 < 2^31
 constexpr int kI8MinN = 512;            // below, the fixed costs of the fast path buy nothing
+constexpr int kI8Probe = 256;           // regressors of a large batch's first slice (one round of workgroups): its hand-back count steers the rest
+constexpr int kI8ProbeMin = 1024;       // batches up to this size go in one slice
 
 // BLR_I8_STAMPS: diagnostic builds only (tools/i8_gram.hip): cycle sums of workgroup 0, one row per wave --
 //   [0] the k-steps (MFMAs + slicing)  [2] DMA wait + barrier  [4] whole stream  [5] hand-over + conversion
@@ -568,7 +570,14 @@ __global__ __launch_bounds__(kI8Threads, 2) void fused_i8_kernel(PosteriorArgs<d
   const T s_iso = DIAG ? T(1) : as_global(a.s + (int64_t)reg * a.strides)[0];
   const double rwmax = DIAG ? a.i8_rwmax[reg] : 1.0;
   const bool fac = a.prior_kind == PRIOR_UPPER_FACTOR;  // Lw is the upper factor U of the prior precision (PDMat / a carried-forward posterior): U'U joins at the hand-over
+  if (blockIdx.x == 0 && tid == 0 && a.i8_handed_slice != nullptr) *a.i8_handed_slice = 0ull;  // (this slice's retry launch counts into it)
   if (DIAG && a.i8_bad[reg] != 0) {  // (uniform)  reference :79: the fp64 kernel reports the index
+    if (tid == 0) a.info[reg] = kI8Retry;
+    return;
+  }
+  // the slice before this one handed back more than a quarter of its regressors (heavy-tailed rows: bounds from the first columns do
+  // not hold): streaming these twice costs more than the fp64 kernel alone
+  if (a.i8_prev_n > 0 && __builtin_nontemporal_load(a.i8_prev_handed) * 4ull > (unsigned long long)a.i8_prev_n) {
     if (tid == 0) a.info[reg] = kI8Retry;
     return;
   }
@@ -753,7 +762,17 @@ __global__ __launch_bounds__(kI8Threads, 2) void fused_i8_kernel(PosteriorArgs<d
     const double s1 = block_allreduce(mi * bsum, scr, tid);
     const double s2 = block_allreduce(mi * gm, scr, tid);
     quad_mw = quad - 2.0 * s1 + s2;
+    // Both are differences of y'y / s-sized numbers.  When the prior mean already explains the data (a carried-forward posterior
+    // conditioned on more of the same stream) they cancel: the error of delta'delta / s is eps y'y / s, not eps delta'delta / s
+    // (reference :82 forms delta = y - X'mw first, and so does the fp64 kernel).  Three digits of cancellation are the most this
+    // route keeps for itself -- inside the 1e-10 the header promises for the evidence; beyond, the fp64 kernel redoes the regressor.
+    const double bn_old = block_allreduce(bsum * bsum, scr, tid);
     bsum -= gm;
+    const double bn_new = block_allreduce(bsum * bsum, scr, tid);
+    if (!(quad_mw > 1e-3 * quad) || !(bn_new >= 1e-6 * bn_old)) {  // (uniform)
+      if (tid == 0) a.info[reg] = kI8Retry;
+      return;
+    }
   }
   if (tid < D) bvec[tid] = (T)bsum;
   // prior: SPD check + logdet (reference :78; a factor: its diagonal, logdet = 2 sum log U_kk), noise variance (reference :79)

@@ -129,6 +129,10 @@ struct PosteriorArgs {
   // sum_n log s_n and a flag (some s_n not positive / not finite: the fp64 kernel reports it) per regressor
   const T* i8_yt; const T* i8_rw; int64_t i8_stride; const double* i8_logdet; const int32_t* i8_bad;
   const double* i8_rwmax;  // max_n 1 / sqrt(s_n): the row bounds of the sliced values x / sqrt(s_n) are bounds of x times this
+  // hand-back accounting of the int8 route (launch_fused_i8): the retry launch counts the regressors it redoes into *i8_handed_slice
+  // (zeroed by the slice's int8 launch) and *i8_handed_tot (blr_get_stat); the int8 launch of the NEXT slice reads the previous
+  // slice's count -- *i8_prev_handed of i8_prev_n regressors -- and leaves its regressors to the fp64 kernel when that was > 1/4
+  unsigned long long* i8_handed_tot; unsigned long long* i8_handed_slice; const unsigned long long* i8_prev_handed; int i8_prev_n;
 };
 constexpr int kI8RetryCode = (int)0x80000007u;  // == kI8Retry (blr_fused_i8.hpp)
 
@@ -1415,7 +1419,13 @@ __global__ __launch_bounds__(kThreads, (NB <= 4 ? 4 : (sizeof(T) == 4 ? BLR_F32_
   const double kNaN = __longlong_as_double(0x7ff8000000000000LL);
 
   for (int reg = blockIdx.x; reg < a.B; reg += gridDim.x) {
-    if (a.retry_only && a.info[reg] != kI8RetryCode) continue;  // (uniform; the int8 kernel finished this regressor)
+    if (a.retry_only) {
+      if (a.info[reg] != kI8RetryCode) continue;  // (uniform; the int8 kernel finished this regressor)
+      if (tid == 0 && a.i8_handed_slice != nullptr) {
+        atomicAdd(a.i8_handed_slice, 1ull);
+        atomicAdd(a.i8_handed_tot, 1ull);
+      }
+    }
     const T* mw = a.mw + (int64_t)reg * a.stridemw;
     const T* Lw = a.Lw + (int64_t)reg * a.strideLw;
     __syncthreads();  // previous regressor fully done with LDS

@@ -508,13 +508,8 @@ def logpdf_and_gradient(fx, y):
     if prior_kind == _abi.PRIOR_DIAGONAL:
         gL = -0.5 * (m * m + np.diag(Ai) - 1.0 / np.asarray(Lw, dtype=np.float64))
     else:
-        if prior_kind == _abi.PRIOR_UPPER_FACTOR:
-            U = np.triu(np.asarray(Lw, dtype=np.float64))
-            Lw_dense = U.T @ U
-        else:
-            A0 = np.asarray(Lw, dtype=np.float64)
-            Lw_dense = np.triu(A0) + np.triu(A0, 1).T
-        gL = -0.5 * (np.outer(m, m) + Ai - _prior_inverse_on_device(_handle(), dtype, prior_kind, Lw, D))
+        # (the prior's inverse in float64 whatever the element type of the call: D x D work, and the three terms cancel)
+        gL = -0.5 * (np.outer(m, m) + Ai - _prior_inverse_on_device(_handle(), np.float64, prior_kind, Lw, D))
     # hand dX back in the caller's container orientation
     x = fx.x
     if isinstance(x, RowVecs):

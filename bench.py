@@ -12,8 +12,11 @@ One "posterior update" = one regressor's full (mw', T, logpdf).
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P \
         bench.py --gpus N --steps K --warmup W
 
-Prints ONE JSON line on rank 0 (contract in the task statement) with `roofline`, `cpu_baseline` and -- at one GPU --
-`secondary`: the other BASELINE shapes (c2 in fp32, c4, c3, c5 end to end), each timed the same way in the same process.
+Output on rank 0 (contract in the task statement): the LAST stdout line is ONE compact JSON object (< 3 KB: metric, value, unit,
+n_gpus, steps, warmup, ms_per_step, dtype, config, roofline, cpu_baseline, scaling, vs_baseline).  At one GPU the other BASELINE
+shapes and hot-path rows (c2 in fp32, c4, c3, c5 end to end, marginals, rand, gradient, ...) are timed the same way in the same
+process AFTER the timed region; each prints one short JSON line ({"secondary": name, ms, per_s, bound, frac, traffic_x, kernel})
+BEFORE the headline line, and their full records go to gpurun_out/bench_secondary_latest.json.
 """
 import argparse
 import glob
@@ -129,10 +132,9 @@ def cpu_baseline(D, N, seconds, seed):
         "kind": "port",
         "direct_gram_value": rate(dirr),
         "threaded_blas_value": rate(thr),
-        "sample": f"D={D}, N={N}, fp64, oracle (NumPy/SciPy on OpenBLAS): {sum(d for d, _ in lit)} regressors through the reference's "
-                  f"literal op sequence logpdf+posterior on {len(lit)} processes x 1 BLAS thread (= physical cores of the host, "
-                  f"{os.cpu_count()} hardware threads) for {per:.0f} s each; direct_gram_value: the same layout on the one-pass Gram "
-                  f"form; threaded_blas_value: one process, OpenBLAS on {cores} threads; {wall:.0f} s wall in total",
+        "sample": f"{sum(d for d, _ in lit)} regressors D={D} N={N} fp64, reference op sequence (logpdf+posterior) restated on "
+                  f"NumPy/OpenBLAS: {len(lit)} procs x 1 BLAS thread, {per:.0f} s; direct_gram_value = one-pass Gram form, "
+                  f"threaded_blas_value = 1 proc x {cores} BLAS threads; {wall:.0f} s wall",
     }
 
 
@@ -222,60 +224,103 @@ class Workload:
                                  self.T_post.data_ptr(), D, None, D, self.lp.data_ptr(), self.info.data_ptr())
 
     def kernel_name(self):
-        t = "double" if self.dtype == "f64" else "float"
-        if self.D == 64 or (self.D == 32 and self.dtype == "f64"):
-            return f"fused_wave_kernel<{t}, {self.D // 16}>"  # one wavefront per regressor (diagonal prior, aligned ColVecs)
-        if self.D == 128 and self.dtype == "f64" and 512 <= self.N - self.N % 32 <= 16384 \
-                and os.environ.get("BLR_MI355X_NO_I8_GRAM") is None and not (self.diag and os.environ.get("BLR_MI355X_NO_I8_DIAG") is not None):
-            return "fused_i8_kernel"  # Gram on the int8 matrix cores (blr_fused_i8.hpp); its retry pass is an empty launch here
-        if self.D <= 128:
-            return f"fused_small_kernel<{t}, {(self.D + 15) // 16}, 4>"  # MODE 4: ColVecs through LDS-DMA
-        return f"gram_tile_kernel<{t}>"
+        """The kernel family the dispatcher took for the most recent launch of this workload (blr_last_route): asked, not re-derived."""
+        return self.h.last_route()
 
     def roofline(self, ms):
         fl = algorithmic_flops(self.D, self.N, self.Din) * self.B
         by = algorithmic_bytes(self.D, self.N, self.w_bytes, self.diag, self.Din) * self.B
         if self.logpdf_only:  # no mw', no T written
             by -= self.w_bytes * (self.D + self.D * self.D) * self.B
-        tf = fl / (ms * 1e-3) / 1e12
-        gbs = by / (ms * 1e-3) / 1e9
-        t_hbm = by / (PEAK_HBM_GBS * 1e9)
-        t_mfma = fl / (PEAK_TF[self.dtype] * 1e12)
-        if t_mfma >= t_hbm:
-            r = {"bound": "mfma", "achieved": tf, "peak": PEAK_TF[self.dtype], "unit": "TFLOP/s", "frac": tf / PEAK_TF[self.dtype]}
-        else:
-            r = {"bound": "hbm", "achieved": gbs, "peak": PEAK_HBM_GBS, "unit": "GB/s", "frac": gbs / PEAK_HBM_GBS}
-        if self.kernel_name() == "fused_i8_kernel":
-            # The Gram of this path runs on the INT8 matrix cores: 26 digit-pair products per 32 x 32 tile, 10 lower tiles, 2 x 32 x 32
-            # operations per column and product (blr_fused_i8.hpp) against the dense int8 peak (2 x the bf16 peak per clock:
-            # 5 POP/s, MI355X_MICROARCH.md matrix-core table).  That takes less time than streaming X at 8 TB/s, so the binding
-            # roofline of the update is HBM; the fp64-equivalent rate stays in mfma_TFLOPps for comparison with the fp64 kernel.
-            ops = 26 * 10 * 2048.0 * self.N * self.B
-            t_i8 = ops / 5.0e15
-            i8 = {"int8_ops": ops, "int8_TOPps": ops / (ms * 1e-3) / 1e12, "int8_peak_TOPps": 5000.0, "int8_frac": ops / (ms * 1e-3) / 5.0e15}
-            if t_hbm >= t_i8:
-                r = {"bound": "hbm", "achieved": gbs, "peak": PEAK_HBM_GBS, "unit": "GB/s", "frac": gbs / PEAK_HBM_GBS}
-            else:
-                r = {"bound": "mfma", "achieved": i8["int8_TOPps"], "peak": 5000.0, "unit": "TOP/s (int8)", "frac": i8["int8_frac"]}
-            r.update(i8)
-        r.update({"kernel": self.kernel_name(), "kernel_ms_avg": ms, "units_per_launch": self.B, "algorithmic_bytes": by,
-                  "algorithmic_flops": fl, "hbm_GBps": gbs, "hbm_frac": gbs / PEAK_HBM_GBS, "mfma_TFLOPps": tf,
-                  "mfma_frac": tf / PEAK_TF[self.dtype]})
+        kern = self.kernel_name()
+        r = roofline_of(fl, by, self.dtype, ms, kern, i8_cols=self.N * self.B if kern == "fused_i8_kernel" else None)
+        r.update({"kernel_ms_avg": ms, "units_per_launch": self.B})
         return r
 
 
-def roofline_of(flops, nbytes, dtype, ms, kernel):
-    """bound = whichever of t_HBM (8 TB/s) and t_MFMA (dense matrix peak of the dtype) is longer for the ALGORITHMIC bytes / flops
-    of one call (stated per entry in DESIGN.md 4, "secondary entries"); frac = that time / measured time."""
-    tf = flops / (ms * 1e-3) / 1e12
-    gbs = nbytes / (ms * 1e-3) / 1e9
-    if flops / (PEAK_TF[dtype] * 1e12) >= nbytes / (PEAK_HBM_GBS * 1e9):
-        r = {"bound": "mfma", "achieved": tf, "peak": PEAK_TF[dtype], "unit": "TFLOP/s", "frac": tf / PEAK_TF[dtype]}
+I8_OPS_PER_COLUMN = 26 * 10 * 2048.0  # int8 route: 26 digit-pair products x 10 lower 32 x 32 tiles x 2 x 32 x 32 operations per column
+PEAK_I8_TOPS = 5000.0                 # dense int8 peak (2 x the bf16 peak per clock; MI355X_MICROARCH.md matrix-core table)
+
+
+def i8_ops_per_column():
+    """Digit-pair products per column of the int8 route AS BUILT (csrc/blr_fused_i8.hpp states its plan in kI8MfmaPerKstep)."""
+    try:
+        src = open(os.path.join(ROOT, "bayesianlinearregressors.jl_amd", "csrc", "blr_fused_i8.hpp")).read()
+        m = re.search(r"constexpr int kI8MfmaPerKstep\s*=\s*(\d+)", src)
+        if m:
+            return int(m.group(1)) * 2048.0
+    except Exception:
+        pass
+    return I8_OPS_PER_COLUMN
+
+
+def roofline_of(flops, nbytes, dtype, ms, kernel, i8_cols=None):
+    """bound = whichever of t_HBM (8 TB/s) and t_matrix is longer for the ALGORITHMIC bytes / flops of one call (stated per entry in
+    DESIGN.md 5); frac = that time / measured time.  t_matrix is flops / the dense matrix peak of the dtype -- except on the int8
+    route (i8_cols = columns streamed per call), whose Gram runs on the int8 cores: there it is int8 operations / 5 POP/s, which is
+    shorter than streaming X, so the route is HBM-bound; every entry that takes it gets the same three fractions (hbm_frac,
+    int8_frac, f64_equiv_frac = the fp64-matrix-pipe rate the same work would need) so rounds and routes stay comparable."""
+    sec = ms * 1e-3
+    tf = flops / sec / 1e12
+    gbs = nbytes / sec / 1e9
+    t_hbm = nbytes / (PEAK_HBM_GBS * 1e9)
+    t_mat = flops / (PEAK_TF[dtype] * 1e12)
+    extra = {}
+    if i8_cols is not None:
+        ops = i8_ops_per_column() * i8_cols
+        t_mat = ops / (PEAK_I8_TOPS * 1e12)
+        extra = {"int8_TOPps": ops / sec / 1e12, "int8_frac": ops / sec / (PEAK_I8_TOPS * 1e12), "f64_equiv_frac": tf / PEAK_TF[dtype]}
+    if t_mat >= t_hbm:
+        if i8_cols is not None:
+            r = {"bound": "mfma", "achieved": extra["int8_TOPps"], "peak": PEAK_I8_TOPS, "unit": "TOP/s (int8)", "frac": extra["int8_frac"]}
+        else:
+            r = {"bound": "mfma", "achieved": tf, "peak": PEAK_TF[dtype], "unit": "TFLOP/s", "frac": tf / PEAK_TF[dtype]}
     else:
         r = {"bound": "hbm", "achieved": gbs, "peak": PEAK_HBM_GBS, "unit": "GB/s", "frac": gbs / PEAK_HBM_GBS}
     r.update({"kernel": kernel, "hbm_frac": gbs / PEAK_HBM_GBS, "mfma_frac": tf / PEAK_TF[dtype], "algorithmic_bytes": nbytes,
               "algorithmic_flops": flops})
+    r.update(extra)
     return r
+
+
+def _sig(x, n=4):
+    return float(f"{x:.{n}g}") if isinstance(x, float) else x
+
+
+def secondary_line(name, e):
+    """One short JSON line (<= 256 B) per secondary entry, printed BEFORE the headline: a tail of stdout still reads them."""
+    if "error" in e:
+        return json.dumps({"secondary": name, "error": e["error"][:120]})
+    r = e["roofline"]
+    tx = (r["traffic"] / r["algorithmic_bytes"]) if r.get("traffic") else None
+    d = {"secondary": name, "ms": _sig(e["ms"]), "per_s": _sig(e["per_s"]), "unit": e["unit"], "bound": r["bound"], "frac": _sig(r["frac"], 3),
+         "traffic_x": _sig(tx, 3) if tx else None, "kernel": r["kernel"][:40]}
+    if "int8_frac" in r:
+        d["int8_frac"], d["f64_equiv_frac"] = _sig(r["int8_frac"], 3), _sig(r["f64_equiv_frac"], 3)
+    return json.dumps(d)
+
+
+HEADLINE_KEYS = ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling", "vs_baseline", "dtype",
+                 "data", "config", "roofline", "cpu_baseline", "total_log_evidence", "preheat_s", "sustained", "secondary_file", "n_secondary")
+ROOFLINE_KEYS = ("bound", "achieved", "peak", "unit", "frac", "traffic", "kernel", "kernel_ms_avg", "kernel_ms_min", "kernel_ms_median",
+                 "units_per_launch", "algorithmic_bytes", "algorithmic_flops", "hbm_frac", "mfma_frac", "int8_frac", "f64_equiv_frac",
+                 "traffic_source", "matrix_peak_measured_TFLOPps", "mfma_frac_of_measured_peak")
+
+
+def headline_line(out):
+    """The driver's line: the contract's keys only, floats at 6 significant digits, < 3 KB whatever the run added to `out`."""
+    d = {k: out[k] for k in HEADLINE_KEYS if k in out}
+    if "roofline" in d:
+        d["roofline"] = {k: (_sig(v, 6) if isinstance(v, float) else v) for k, v in out["roofline"].items() if k in ROOFLINE_KEYS}
+    if "cpu_baseline" in d:
+        d["cpu_baseline"] = {k: (_sig(v, 6) if isinstance(v, float) else v) for k, v in out["cpu_baseline"].items()}
+        d["cpu_baseline"]["sample"] = d["cpu_baseline"].get("sample", "")[:400]
+    for k in ("value", "ms_per_step", "total_log_evidence"):
+        if isinstance(d.get(k), float):
+            d[k] = _sig(d[k], 9)
+    line = json.dumps(d)
+    assert len(line) < 3072, f"headline line is {len(line)} bytes"
+    return line
 
 
 class Op:
@@ -445,7 +490,7 @@ def secondary_ops(torch, _abi, h, dev):
     def post(name, b, d, n, dt, noise, din=None, steps=20, option=None, **kw):
         def build():
             w2 = Workload(torch, a, h, dev, name, b, d, n, dt, noise, 123456 + 7, din, **kw)
-            launch, kern = w2.launch, w2.kernel_name()
+            launch, kern = w2.launch, "posterior"
             if option:  # the same workload with a run-time switch of the handle set for the duration of each call (A/B entry)
 
                 def launch():
@@ -455,13 +500,12 @@ def secondary_ops(torch, _abi, h, dev):
                     finally:
                         h.set_option(option, None)
 
-                if option == "NO_I8_GRAM":
-                    kern = "fused_small_kernel<double, 8, 4>"
-
             def check():
                 assert int(w2.info.abs().sum().item()) == 0 and bool(torch.isfinite(w2.lp).all().item())
 
-            r = w2.roofline(1.0)
+            r = {"algorithmic_flops": algorithmic_flops(w2.D, w2.N, w2.Din) * w2.B,
+                 "algorithmic_bytes": (algorithmic_bytes(w2.D, w2.N, w2.w_bytes, w2.diag, w2.Din)
+                                       - (w2.w_bytes * (w2.D + w2.D * w2.D) if w2.logpdf_only else 0)) * w2.B}
             tag = (", prior mean ~ N(0, I)" if kw.get("mw_random") else "") + (", logpdf only (no mw', no T)" if kw.get("logpdf_only") else "") \
                 + (", RowVecs storage" if kw.get("rowvecs") else "") + (", prior by its upper factor" if kw.get("factor_prior") else "") \
                 + (f", handle option {option}" if option else "")
@@ -519,7 +563,14 @@ def run_secondary(torch, _abi, h, dev, stream, only=None):
             torch.cuda.synchronize(dev)
             wall, ms = timed(torch, stream, dev, op.fn, op.steps, 3)
             op.check()
-            r = roofline_of(op.flops, op.nbytes, op.dtype, ms, op.kernel)
+            kern = op.kernel
+            if op.unit == "updates/s" and not op.kernel.startswith("rank1") and "in place" not in op.kernel:
+                kern = h.last_route()  # posterior workloads: the route the dispatcher took on the last call
+            i8_cols = None
+            if kern == "fused_i8_kernel":
+                w2 = op.keep[0]
+                i8_cols = w2.N * w2.B
+            r = roofline_of(op.flops, op.nbytes, op.dtype, ms, kern, i8_cols=i8_cols)
             # HBM bytes of one CALL by PMC (all of the call's kernels; tools/collect_profiles.sh runs `--secondary-only <name>` under
             # rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE); summaries of earlier rounds hold the dominant kernel of four entries per update
             per_call, src = pmc_traffic_per_update(name + "_hbm")
@@ -530,6 +581,7 @@ def run_secondary(torch, _abi, h, dev, stream, only=None):
                 if per_call is not None and name in ("c2_f32", "c4_f64"):
                     per_call *= op.units
             r["traffic"], r["traffic_source"] = per_call, src
+            print(secondary_line(name, {"ms": ms, "unit": op.unit, "per_s": op.units / (ms * 1e-3), "roofline": r}), flush=True)
             sec[name] = {"workload": op.workload, "ms": ms, "unit": op.unit, "per_s": op.units / (ms * 1e-3),
                          "wall_per_s": op.units * op.steps / wall, "calls": op.steps + 3, "roofline": r}
             if op.unit == "updates/s":
@@ -538,6 +590,7 @@ def run_secondary(torch, _abi, h, dev, stream, only=None):
             torch.cuda.empty_cache()
         except Exception as e:  # a secondary entry must never take the headline line down
             sec[name] = {"error": f"{type(e).__name__}: {e}"}
+            print(secondary_line(name, sec[name]), flush=True)
             torch.cuda.empty_cache()
     return sec
 
@@ -567,6 +620,9 @@ def main():
     ap.add_argument("--N", type=int, default=4096)
     ap.add_argument("--dtype", choices=["f64", "f32"], default="f64")
     ap.add_argument("--noise", choices=["isotropic", "diagonal"], default="isotropic")
+    ap.add_argument("--preheat-seconds", type=float, default=None,
+                    help="untimed back-to-back steps BEFORE the W warm-up steps, so that the K timed steps run at the clock the part "
+                         "SUSTAINS under this load rather than at a cold burst clock (default: 2 s on the headline workload, else 0)")
     ap.add_argument("--cpu-seconds", type=float, default=None,
                     help="wall budget of the cpu_baseline leg (0 = skip; default: 24 s at the headline shape, skipped otherwise)")
     ap.add_argument("--secondary", type=int, default=None,
@@ -598,6 +654,8 @@ def main():
         args.cpu_seconds = 24.0 if headline else 0.0
     if args.secondary_only:
         args.cpu_seconds = 0.0
+    if args.preheat_seconds is None:
+        args.preheat_seconds = 2.0 if headline else 0.0
 
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
@@ -642,7 +700,8 @@ def main():
 
     if args.secondary_only:
         only = None if args.secondary_only == "all" else set(args.secondary_only.split(","))
-        print(json.dumps({"secondary": run_secondary(torch, _abi, h, dev, stream, only)}), flush=True)
+        sec = run_secondary(torch, _abi, h, dev, stream, only)
+        print(json.dumps({"secondary": sec}), flush=True)  # (last line: the full records; tools/summarise_profiles.py reads it)
         h.close()
         return
     D, N = args.D, args.N
@@ -699,6 +758,18 @@ def main():
         else:
             h.logpdf_sum(_abi.MEM_DEVICE, B, wl.lp.data_ptr(), lp_sum.data_ptr())
 
+    # pre-heat: untimed steps for --preheat-seconds of device time (DVFS settles; MI355X_MICROARCH.md, clocks), then the contract's W
+    # warm-up steps and EXACTLY K timed steps
+    preheat_steps = 0
+    if args.preheat_seconds > 0:
+        step()
+        torch.cuda.synchronize(dev)
+        t_pre = time.perf_counter()
+        while time.perf_counter() - t_pre < args.preheat_seconds:
+            for _ in range(8):
+                step()
+            torch.cuda.synchronize(dev)
+            preheat_steps += 8
     for _ in range(args.warmup):
         step()
     torch.cuda.synchronize(dev)
@@ -719,7 +790,8 @@ def main():
     if dist is not None:
         dist.all_reduce(t_el, op=dist.ReduceOp.MAX)
     elapsed = float(t_el.item())
-    kern_ms = float(np.mean([a.elapsed_time(b) for a, b in events]))
+    kern_all = [a.elapsed_time(b) for a, b in events]
+    kern_ms = float(np.mean(kern_all))
 
     # sanity: the timed work produced valid results
     assert int(wl.info.abs().sum().item()) == 0, "a regressor failed to factorise"
@@ -735,11 +807,12 @@ def main():
             per_update, src = pmc_traffic_per_update("c2_fused_i8_kernel_hbm" if roof["kernel"] == "fused_i8_kernel" else "c2_fused_small_kernel_hbm")
         peak_meas, peak_src = measured_matrix_peak(args.dtype)
         roof.update({
+            "kernel_ms_min": float(np.min(kern_all)), "kernel_ms_median": float(np.median(kern_all)),
             "traffic": per_update * B if per_update else None,
             "traffic_source": src,
             "matrix_peak_measured_TFLOPps": peak_meas,
             "matrix_peak_measured_source": peak_src,
-            "mfma_frac_of_measured_peak": (roof["mfma_TFLOPps"] / peak_meas) if peak_meas else None,
+            "mfma_frac_of_measured_peak": (roof["mfma_frac"] * PEAK_TF[args.dtype] / peak_meas) if peak_meas else None,
         })
         out = {
             "metric": "posterior-updates/sec + logpdf/sec at (D,N)",
@@ -759,23 +832,33 @@ def main():
                             f"Lw=I, fused posterior+logpdf" + (f", random-Fourier basis D_in={Din} on the device" if Din else ""),
                 "D": D, "N": N, "batch_per_gpu": B, "global_batch": global_batch,
                 "sharding": f"regressors x{world} ({'fixed batch, contiguous blocks' if strong else 'fixed block per GPU'}), no data-path "
-                            f"collective; one all-gather of {Bmax * world} doubles through "
-                            f"{'the library RCCL binding (blr_logpdf_allgather_sum)' if use_lib_comm else ('torch.distributed ' + backend) if dist is not None else 'nothing (one rank)'}",
+                            f"collective; one all-gather of {Bmax * world} doubles via "
+                            f"{'library RCCL (blr_logpdf_allgather_sum)' if use_lib_comm else ('torch.distributed ' + backend) if dist is not None else 'nothing (one rank)'}",
             },
             "roofline": roof,
             "total_log_evidence": total_evidence,
+            "preheat_s": args.preheat_seconds,
         }
         if cpu_leg is not None:
             out["cpu_baseline"] = cpu_leg
 
     # ---- the other BASELINE shapes and the other hot-path rows (mean / var / rand / gradient / ...), same process, same timing
-    # method (one GPU only)
+    # method (one GPU only): one short line each BEFORE the headline, full records in a side file
     if args.secondary and world == 1 and rank == 0:
         del wl, lp_all
         torch.cuda.empty_cache()
-        out["secondary"] = run_secondary(torch, _abi, h, dev, stream)
+        sec = run_secondary(torch, _abi, h, dev, stream)
+        out["n_secondary"] = len(sec)
+        try:
+            side = os.path.join(ROOT, "gpurun_out")
+            os.makedirs(side, exist_ok=True)
+            with open(os.path.join(side, "bench_secondary_latest.json"), "w") as f:
+                json.dump({"headline": out, "secondary": sec}, f, indent=1)
+            out["secondary_file"] = "gpurun_out/bench_secondary_latest.json"
+        except OSError:
+            out["secondary_file"] = None
     if rank == 0:
-        print(json.dumps(out), flush=True)
+        print(headline_line(out), flush=True)  # the LAST line of stdout
     if use_lib_comm:
         h.comm_destroy()
     if dist is not None:

@@ -65,17 +65,32 @@ int blr_device_count(void);                       /* number of visible HIP devic
 int blr_create(int device, blr_handle** out);     /* one handle per Julia task / thread                  */
 int blr_destroy(blr_handle* h);
 const char* blr_last_error(blr_handle* h);        /* valid until the next call on h; never NULL         */
+/* A handle's work is ordered by ONE stream at a time: switching streams drains the old one first.  Not supported: capturing a
+ * handle's launches into a HIP graph and replaying them, and calls on one handle from two streams / threads at once (the large-D
+ * factorisation keeps arrival counters and tagged exchange words per handle) -- use one handle per stream. */
 int blr_set_stream(blr_handle* h, void* hip_stream); /* run on the caller's hipStream_t; NULL = the HIP null stream */
 int blr_reset_stream(blr_handle* h);              /* back to the handle's own (non-blocking) stream      */
 int blr_set_async(blr_handle* h, int async);      /* 1: DEVICE-memspace calls return after enqueue       */
 int blr_synchronize(blr_handle* h);
 /* Run-time switches of the handle (A/B measurements and tests; the defaults are the measured best).  `key` is one of NO_LDSDMA,
- * NO_WAVE_KERNEL, NO_GRAM_RING, NO_DIAG_SPLIT, NO_XCD_SWIZZLE, NO_MFMA_PROJECT, NO_I8_GRAM, NO_I8_DIAG, NO_I8_FACTOR, NO_I8_ROWVECS, NO_MARG_GEMM, NO_GRAD_GEMM, PLAN_DEBUG (flags: any non-empty value = on),
+ * NO_WAVE_KERNEL, NO_GRAM_RING, NO_DIAG_SPLIT, NO_XCD_SWIZZLE, NO_MFMA_PROJECT, NO_I8_GRAM, NO_I8_DIAG, NO_I8_FACTOR, NO_I8_ROWVECS, NO_I8_DENSE, NO_I8_FALLBACK, NO_MARG_GEMM, NO_GRAD_GEMM, PLAN_DEBUG (flags: any non-empty value = on),
  * WAVE_SPLIT = 1|2|4, CHAIN_BATCH = 1..128, CHAIN_WS_MB, SWEEP = always|never|auto, GRAM_SPLITS = "o,d[,nlong]" (README.md);
  * a "BLR_MI355X_" prefix is accepted.  value NULL or "" restores the built-in default.  The environment variables
  * BLR_MI355X_<KEY> are read ONCE, by blr_create -- no entry point reads the environment.  -> 0, or -2 / -3 (unknown key /
  * malformed value). */
 int blr_set_option(blr_handle* h, const char* key, const char* value);
+/* Which kernel family the most recent blr_posterior_* / blr_logpdf_* dispatch of this handle launched -- what a profile of the call
+ * shows: "fused_i8_kernel", "fused_small_kernel<double, 8, 4>", "fused_wave_kernel<double, 4, 1>", "gram_tile_kernel<float>" (the
+ * large-D pipeline), ...; "none" before the first call.  The pointer stays valid for the life of the library.  (bench.py labels its
+ * roofline with it instead of re-deriving the dispatcher's decision.) */
+const char* blr_last_route(blr_handle* h);
+/* Counters of the handle since blr_create / blr_reset_stats.  key: "i8_regressors" = regressors sent down the int8-sliced Gram route
+ * (blr_posterior_batched_f64 above); "i8_handed_back" = those of them that route could not finish (rows outgrowing their scale
+ * beyond what it corrects in place, non-finite inputs) and the fp64 kernel redid inside the same call -- each of these cost two
+ * passes over its data (reading it synchronises the handle's stream); "workspace_bytes" = device scratch the handle holds now.
+ * -> 0, -2 unknown key, -3 NULL value. */
+int blr_get_stat(blr_handle* h, const char* key, int64_t* value);
+int blr_reset_stats(blr_handle* h);
 /* The handle's device scratch (factorisation workspaces of D > 128 calls -- up to 8 GiB for a large batched call, see CHAIN_WS_MB --
  * the feature matrix of blr_posterior_rff_*, the int8 / marginal side buffers) only ever GROWS between calls; this drains the
  * stream and frees all of it.  The next call allocates what it needs again. */

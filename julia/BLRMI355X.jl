@@ -661,6 +661,17 @@ function set_option!(key::AbstractString, value::Union{Nothing,AbstractString,In
     rc == 0 || throw(ArgumentError("blr_set_option: unknown key or malformed value: $key = $value"))
     return nothing
 end
+# Which kernel family this task's most recent posterior / logpdf call ran on ("fused_i8_kernel", "fused_small_kernel<double, 8, 4>", ...).
+last_route() = unsafe_string(ccall((:blr_last_route, LIB), Cstring, (Ptr{Cvoid},), handle()))
+# Counters of this task's handle: "i8_regressors" (sent down the int8-sliced Gram route), "i8_handed_back" (of those, redone by the fp64
+# kernel inside the same call: each cost two passes over its data -- heavy-tailed design matrices), "workspace_bytes".
+function get_stat(key::AbstractString)
+    h = handle()
+    v = Ref{Int64}(0)
+    check(h, ccall((:blr_get_stat, LIB), Cint, (Ptr{Cvoid}, Cstring, Ref{Int64}), h, key, v))
+    return v[]
+end
+reset_stats!() = (h = handle(); check(h, ccall((:blr_reset_stats, LIB), Cint, (Ptr{Cvoid},), h)); nothing)
 # Give the handle's workspace, feature and side buffers back to the allocator (they are re-created by the next call that needs them).
 release_workspace!() = (h = handle(); check(h, ccall((:blr_release_workspace, LIB), Cint, (Ptr{Cvoid},), h)); nothing)
 

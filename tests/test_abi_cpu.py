@@ -250,3 +250,35 @@ def test_comm_entry_points_validate_without_a_gpu():
     assert lib.blr_allreduce_sum(None, 1, None, 4) == -1
     assert lib.blr_comm_unique_id(None) == -1
 
+
+
+def test_bench_headline_line_stays_under_3k(repo_root):
+    # the driver keeps 8 KB of stdout and the round-4 line had grown to 21.6 KB (31 secondary entries), so the head of it
+    # -- value, roofline, cpu_baseline -- was lost.  bench.py now prints the secondaries as one short line each BEFORE a compact
+    # headline object; run the formatter on the recorded round-4 result (the widest one there is) and hold it to the budget.
+    import importlib.util
+    import json
+
+    ROOT = repo_root
+    spec = importlib.util.spec_from_file_location("bench_mod", os.path.join(ROOT, "bench.py"))
+    bench = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(bench)
+    rec = json.load(open(os.path.join(ROOT, "profiles", "r04_bench_c2_f64.json")))
+    rec["roofline"].update({"kernel_ms_min": 5.04, "kernel_ms_median": 5.2, "f64_equiv_frac": 0.68})
+    rec["preheat_s"], rec["n_secondary"], rec["secondary_file"] = 2.0, len(rec["secondary"]), "gpurun_out/bench_secondary_latest.json"
+    line = bench.headline_line(rec)
+    assert len(line) < 3072 and "\n" not in line
+    d = json.loads(line)
+    for k in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "dtype", "config", "roofline", "cpu_baseline", "scaling",
+              "vs_baseline", "higher_is_better", "data"):
+        assert k in d, k
+    assert "secondary" not in d
+    for k in ("bound", "achieved", "peak", "unit", "frac", "traffic", "hbm_frac", "int8_frac", "f64_equiv_frac", "kernel"):
+        assert k in d["roofline"], k
+    for k in ("value", "unit", "cores", "kind", "sample"):
+        assert k in d["cpu_baseline"], k
+    assert abs(d["value"] - rec["value"]) <= 1e-8 * rec["value"]
+    for name, e in rec["secondary"].items():
+        s = bench.secondary_line(name, e)
+        assert len(s) <= 300 and json.loads(s)["secondary"] == name
+    assert len(bench.secondary_line("x", {"error": "E" * 5000})) < 300

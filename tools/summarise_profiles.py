@@ -129,7 +129,7 @@ def call_bytes(dirname, counter):
 for f in sorted(glob.glob(f"{RAW}/sec_fetch_*.json")):
     e = os.path.basename(f)[len("sec_fetch_"):-len(".json")]
     try:
-        calls = json.load(open(f))["secondary"][e]["calls"]
+        calls = json.loads(open(f).read().strip().splitlines()[-1])["secondary"][e]["calls"]  # (last stdout line = the full records)
     except Exception:
         continue
     fe, wr = call_bytes(f"sec_fetch_{e}", "FETCH_SIZE"), call_bytes(f"sec_write_{e}", "WRITE_SIZE")
