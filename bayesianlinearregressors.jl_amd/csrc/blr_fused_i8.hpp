@@ -54,23 +54,42 @@ namespace blr {
 
 constexpr int kI8Threads = 512;
 constexpr int kI8Retry = kI8RetryCode;  // info: "this regressor must be redone by the fp64 kernel" (never returned to callers)
-constexpr int kI8Margin = 3;            // binades of headroom above the first block's row maximum
 constexpr int kI8MaxN = 16384;          // int32 accumulators: 6 N 2^14 < 2^31
 constexpr int kI8MinN = 512;            // below, the fixed costs of the fast path buy nothing
 constexpr int kI8Probe = 256;           // regressors of a large batch's first slice (one round of workgroups): its hand-back count steers the rest
 constexpr int kI8ProbeMin = 1024;       // batches up to this size go in one slice
+constexpr int kI8MaxRepair = 32;        // 32-column blocks with entries beyond their row's capacity that are corrected in fp64 at the hand-over; more: fp64 kernel
+// Digit groups kept (k = s + t < NG) and binades of capacity above the exponent of a row's largest entry in the first 96 columns:
+//   isotropic noise: 6 groups, capacity 2^(E + 2) -- between 2 and 4 times that maximum, the whole two's-complement range of the
+//     48-bit integer in use (the first versions kept a spare bit and three binades: 4 bits fewer per operand, 2^8 in the products --
+//     what the seventh group bought).  N(0,1) rows: capacity 8 sigma for 99 % of the rows; the entries that do outgrow a row's
+//     capacity (0.3 per regressor at N = 4096) wrap around in the integer and are corrected at the hand-over (i8 repair below);
+//   diagonal noise: 7 groups, capacity 2^(E + 3) of x times the regressor's LARGEST 1 / sqrt(s_n) -- that bound is loose by the spread
+//     of the variances, and the seventh group is what keeps the products accurate under it.
+constexpr int kI8GroupsIso = 6, kI8GroupsDiag = 7;
+template <int NG> struct I8Mode {
+  static constexpr bool SYM = NG == 6;          // diagonal tiles: products s < t once (mirrored at the hand-over), s = t in accumulators of their own
+  static constexpr int CAP = NG == 6 ? 2 : 3;   // capacity 2^(E + CAP)
+};
+// int8 MFMAs per 32-column k-step of the two plans (bench.py prices the int8 work of a launch with these)
+constexpr int kI8MfmaPerKstep = 174;      // isotropic: 6 off-diagonal tiles x 21 + 4 diagonal tiles x (9 + 3)
+constexpr int kI8MfmaPerKstepDiag = 260;  // diagonal noise: 10 tiles x 26
 
 // BLR_I8_STAMPS: diagnostic builds only (tools/i8_gram.hip): cycle sums of workgroup 0, one row per wave --
-//   [0] the k-steps (MFMAs + slicing)  [2] DMA wait + barrier  [4] whole stream  [5] hand-over + conversion
+//   (sums over the workgroups with blockIdx % 256 == 0)  [0] the k-steps (MFMAs + slicing)  [2] DMA wait + barrier  [3] repair of marked blocks  [4] whole stream  [5] hand-over + conversion (+ tail columns, prior mean)
 //   [6] factorisation  [7] back substitution + outputs
 #ifdef BLR_I8_STAMPS
 __device__ unsigned long long g_i8stamps[8][8];
+__device__ unsigned long long g_i8clk[4];
 #define I8_STAMP_DECL unsigned long long i8t_prev = __builtin_amdgcn_s_memtime(), i8t_acc[4] = {0, 0, 0, 0}
 #define I8_STAMP(slot) do { const unsigned long long t__ = __builtin_amdgcn_s_memtime(); i8t_acc[slot] += t__ - i8t_prev; i8t_prev = t__; } while (0)
-#define I8_STAMP_FLUSH(W) do { if (blockIdx.x == 0 && (threadIdx.x & 63) == 0) for (int q__ = 0; q__ < 4; ++q__) g_i8stamps[W][q__] += i8t_acc[q__]; } while (0)
-#define I8_KSTAMP(slot) do { const unsigned long long t__ = __builtin_amdgcn_s_memtime(); if (blockIdx.x == 0 && (threadIdx.x & 63) == 0) g_i8stamps[threadIdx.x >> 6][slot] += t__ - i8k_prev; i8k_prev = t__; } while (0)
-#define I8_KSTAMP_DECL unsigned long long i8k_prev = __builtin_amdgcn_s_memtime()
+#define I8_STAMP_FLUSH(W) do { if ((blockIdx.x & 255) == 0 && (threadIdx.x & 63) == 0) for (int q__ = 0; q__ < 3; ++q__) atomicAdd(&g_i8stamps[W][q__], i8t_acc[q__]); } while (0)
+#define I8_KSTAMP(slot) do { const unsigned long long t__ = __builtin_amdgcn_s_memtime(); if ((blockIdx.x & 255) == 0 && (threadIdx.x & 63) == 0) atomicAdd(&g_i8stamps[threadIdx.x >> 6][slot], t__ - i8k_prev); i8k_prev = t__; } while (0)
+#define I8_KSTAMP_DECL unsigned long long i8k_prev = __builtin_amdgcn_s_memtime(); const unsigned long long i8k_c0 = i8k_prev, i8k_r0 = __builtin_amdgcn_s_memrealtime()
+// whole-workgroup shader cycles and 100 MHz ticks, summed over the workgroups with blockIdx % 256 == 0: the clock the part holds under this kernel
+#define I8_CLKSTAMP do { if ((blockIdx.x & 255) == 0 && threadIdx.x == 0) { atomicAdd(&g_i8clk[0], __builtin_amdgcn_s_memtime() - i8k_c0); atomicAdd(&g_i8clk[1], __builtin_amdgcn_s_memrealtime() - i8k_r0); atomicAdd(&g_i8clk[2], 1ull); } } while (0)
 #else
+#define I8_CLKSTAMP do {} while (0)
 #define I8_STAMP_DECL do {} while (0)
 #define I8_STAMP(slot) do {} while (0)
 #define I8_STAMP_FLUSH(W) do {} while (0)
@@ -91,36 +110,62 @@ struct I8Cfg {
   static constexpr int OFF_RW = OFF_YB + NSLOT * KC * 8;        // 1 / sqrt(s_n) ring (diagonal noise): NSLOT x 32 doubles
   static constexpr int OFF_XCH = OFF_RW + NSLOT * KC * 8;       // exchange: 4 x 6 x 128 ints (row sums; row maxima first)
   static constexpr int OFF_FLAG = OFF_XCH + 4 * 6 * 128 * 4;    // 16 ints
-  static constexpr int LDS_BYTES = OFF_FLAG + 64;
+  static constexpr int OFF_OFLAG = OFF_FLAG + 64;               // one byte per 32-column block: some entry outgrew its row's capacity (<= 512 blocks + 32)
+  static constexpr int OFF_OMASK = OFF_OFLAG + 544;             // the same as 8 x 64-bit masks; then the repair's column masks 32 x 4 words, 4 words of scratch
+  static constexpr int LDS_BYTES = OFF_OMASK + 64 + 512 + 32;
   // after the stream the ring is dead: P, bvec, ... of SmallCfg<double, 8> live there (phase_chol / phase_backsolve layout);
   // the conversion tables live in the digit area
   static constexpr int OFF_VTAB = OFF_DIG;                      // offset-term tables TA, TB, TC: 3 x 128 doubles
   static constexpr int OFF_SC = OFF_VTAB + 3 * 128 * 8;         // 2^(e_i - 47): 128 doubles
   static constexpr int OFF_BRED = OFF_SC + 128 * 8;             // b partials: 4 x 128 doubles
   static constexpr int OFF_GD = OFF_BRED + 4 * 128 * 8;         // diag(G) / sigma^2 WITHOUT the prior (prior-mean terms): 128 doubles
-  static constexpr int OFF_TAIL = OFF_GD + 128 * 8;             // the last N % 32 columns of X (fp64 rank-r term of the hand-over) + their y: 31 x 128 + 32 doubles
-  static_assert(SmallCfg<double, 8>::LDS_BYTES <= RING_BYTES, "the phase functions' LDS image must fit in the dead ring");
-  static_assert(OFF_TAIL + (31 * 128 + 32) * 8 <= OFF_YB, "conversion tables and the tail columns must fit in the digit area");
+  static constexpr int OFF_TD = OFF_GD + 128 * 8;               // TD: sum_n a_3(i, n)^2 2^32, the diagonal's share of the dropped digit pair (3, 3) (6-group plan): 128 doubles
+  static constexpr int OFF_TAIL = OFF_TD + 128 * 8;             // the last N % 32 columns of X (fp64 rank-r term of the hand-over) + their y: 31 x 128 + 32 doubles
+  static constexpr int OFF_UW = 80 * 1024;                     // (dead ring, above the phase functions' image) U_s, W_s, s = 1 .. 5: 10 x 128 doubles
+  static_assert(SmallCfg<double, 8>::LDS_BYTES <= OFF_UW && OFF_UW + 10 * 128 * 8 <= RING_BYTES, "the phase functions' LDS image and the mean-product tables must fit in the dead ring");
+  static_assert(OFF_TAIL + (32 * 128 + 32) * 8 <= OFF_YB, "conversion tables and the tail columns / a block under repair must fit in the digit area");
   static_assert(LDS_BYTES <= 160 * 1024, "LDS of one CU");
 };
 
-// ---- which (tile, digit groups) a wave owns ------------------------------------------------------------------------------------
-// item = tile (I, K) of 32 x 32 (I >= K), groups k0..k1 (k = s + t; s, t <= 5).  Work of group k = min(k, 5) - max(0, k - 5) + 1
-// MFMAs per k-step (1 2 3 4 5 6 5: 26 per tile), 16 registers.  70 accumulators, 260 MFMAs per k-step, dealt by a small search
-// (at most 9 accumulators per wave -- the slicing shares the 256 registers -- and SIMD partners w, w + 4 balanced):
-//   MFMAs:  w0 35 + w4 29 | w1 35 + w5 29 | w2 33 + w6 32 | w3 34 + w7 33        accumulators: 9 9 9 9 | 9 9 8 8
-// `phase`: a tile whose groups are split over waves is assembled in up to three rounds, a barrier between them -- the
-// phase-0 item stores (with the prior), the others add.
-struct I8Item { int I, K, k0, k1, phase; };
-template <int W> struct I8Items;
-template <> struct I8Items<0> { static constexpr int N = 2; static constexpr I8Item it[3] = {{0, 0, 0, 6, 0}, {2, 0, 3, 4, 1}, {0, 0, 0, -1, 0}}; };
-template <> struct I8Items<1> { static constexpr int N = 2; static constexpr I8Item it[3] = {{1, 1, 0, 6, 0}, {3, 1, 3, 4, 1}, {0, 0, 0, -1, 0}}; };
-template <> struct I8Items<2> { static constexpr int N = 2; static constexpr I8Item it[3] = {{3, 0, 2, 6, 0}, {1, 0, 0, 3, 0}, {0, 0, 0, -1, 0}}; };
-template <> struct I8Items<3> { static constexpr int N = 3; static constexpr I8Item it[3] = {{3, 2, 2, 6, 0}, {2, 0, 0, 2, 0}, {2, 1, 6, 6, 1}}; };
-template <> struct I8Items<4> { static constexpr int N = 2; static constexpr I8Item it[3] = {{2, 2, 0, 6, 0}, {3, 0, 0, 1, 1}, {0, 0, 0, -1, 0}}; };
-template <> struct I8Items<5> { static constexpr int N = 2; static constexpr I8Item it[3] = {{3, 3, 0, 6, 0}, {3, 2, 0, 1, 1}, {0, 0, 0, -1, 0}}; };
-template <> struct I8Items<6> { static constexpr int N = 2; static constexpr I8Item it[3] = {{2, 1, 0, 5, 0}, {2, 0, 5, 6, 2}, {0, 0, 0, -1, 0}}; };
-template <> struct I8Items<7> { static constexpr int N = 3; static constexpr I8Item it[3] = {{1, 0, 4, 6, 1}, {3, 1, 5, 6, 2}, {3, 1, 0, 2, 0}}; };
+// ---- which (tile, accumulator slots) a wave owns -----------------------------------------------------------------------------------
+// item = tile (I, K) of 32 x 32 (I >= K), slots q0..q1, one accumulator of 16 registers per slot.
+//   ordinary tile: slot q = digit group k = q: the products (s, t), s + t = k, both orders (min(k, 5) - max(0, k - 5) + 1 MFMAs per k-step);
+//   symmetric diagonal tile (I == K, 6-group plan): P(t, s) = P(s, t)', so the group sum is Q_k + Q_k' + R_k with Q_k the pairs s < t and
+//     R_k = P(k/2, k/2): slots 0 .. NG - 2 are Q_1 .. Q_{NG-1} (1 1 2 2 3 MFMAs), slots NG - 1 .. are R_0, R_2, R_4 (1 MFMA each);
+//     the conversion adds Q_k(i, j) to entry (max, min) from BOTH halves of the accumulator (twice on the diagonal), R_k to the lower half.
+// 7-group plan: 70 accumulators, 260 MFMAs per k-step (w0 35 + w4 29 | w1 35 + w5 29 | w2 33 + w6 32 | w3 34 + w7 33).
+// 6-group plan: 68 accumulators (36 + 4 x 8), 174 MFMAs per k-step, dealt by tools/i8_plan_search.py: at most 9 accumulators per
+// wave (the slicing shares the 256 registers), SIMD partners (w, w + 4) carrying 44 44 44 42 between them, 95 fragment reads per k-step.
+// `phase`: a tile whose slots are split over waves is assembled in up to three rounds, a barrier between them -- the
+// phase-0 item stores (with the offset tables and the prior), the others add.
+struct I8Item { int I, K, q0, q1, phase; };
+template <int NG, int W> struct I8Items;
+template <> struct I8Items<7, 0> { static constexpr int N = 2; static constexpr I8Item it[3] = {{0, 0, 0, 6, 0}, {2, 0, 3, 4, 1}, {0, 0, 0, -1, 0}}; };
+template <> struct I8Items<7, 1> { static constexpr int N = 2; static constexpr I8Item it[3] = {{1, 1, 0, 6, 0}, {3, 1, 3, 4, 1}, {0, 0, 0, -1, 0}}; };
+template <> struct I8Items<7, 2> { static constexpr int N = 2; static constexpr I8Item it[3] = {{3, 0, 2, 6, 0}, {1, 0, 0, 3, 0}, {0, 0, 0, -1, 0}}; };
+template <> struct I8Items<7, 3> { static constexpr int N = 3; static constexpr I8Item it[3] = {{3, 2, 2, 6, 0}, {2, 0, 0, 2, 0}, {2, 1, 6, 6, 1}}; };
+template <> struct I8Items<7, 4> { static constexpr int N = 2; static constexpr I8Item it[3] = {{2, 2, 0, 6, 0}, {3, 0, 0, 1, 1}, {0, 0, 0, -1, 0}}; };
+template <> struct I8Items<7, 5> { static constexpr int N = 2; static constexpr I8Item it[3] = {{3, 3, 0, 6, 0}, {3, 2, 0, 1, 1}, {0, 0, 0, -1, 0}}; };
+template <> struct I8Items<7, 6> { static constexpr int N = 2; static constexpr I8Item it[3] = {{2, 1, 0, 5, 0}, {2, 0, 5, 6, 2}, {0, 0, 0, -1, 0}}; };
+template <> struct I8Items<7, 7> { static constexpr int N = 3; static constexpr I8Item it[3] = {{1, 0, 4, 6, 1}, {3, 1, 5, 6, 2}, {3, 1, 0, 2, 0}}; };
+template <> struct I8Items<6, 0> { static constexpr int N = 2; static constexpr I8Item it[3] = {{3, 2, 3, 5, 1}, {3, 3, 0, 4, 0}, {0, 0, 0, -1, 0}}; };
+template <> struct I8Items<6, 1> { static constexpr int N = 3; static constexpr I8Item it[3] = {{3, 0, 0, 5, 0}, {3, 1, 0, 1, 0}, {3, 3, 5, 5, 1}}; };
+template <> struct I8Items<6, 2> { static constexpr int N = 3; static constexpr I8Item it[3] = {{3, 1, 2, 5, 1}, {3, 2, 0, 2, 0}, {3, 3, 6, 7, 2}}; };
+template <> struct I8Items<6, 3> { static constexpr int N = 3; static constexpr I8Item it[3] = {{0, 0, 1, 2, 1}, {2, 0, 0, 3, 0}, {2, 2, 0, 2, 0}}; };
+template <> struct I8Items<6, 4> { static constexpr int N = 3; static constexpr I8Item it[3] = {{0, 0, 0, 0, 0}, {1, 0, 4, 5, 1}, {1, 1, 3, 7, 1}}; };
+template <> struct I8Items<6, 5> { static constexpr int N = 2; static constexpr I8Item it[3] = {{2, 0, 4, 5, 1}, {2, 2, 3, 7, 1}, {0, 0, 0, -1, 0}}; };
+template <> struct I8Items<6, 6> { static constexpr int N = 2; static constexpr I8Item it[3] = {{0, 0, 3, 7, 2}, {1, 0, 0, 3, 0}, {0, 0, 0, -1, 0}}; };
+template <> struct I8Items<6, 7> { static constexpr int N = 2; static constexpr I8Item it[3] = {{1, 1, 0, 2, 0}, {2, 1, 0, 5, 0}, {0, 0, 0, -1, 0}}; };
+
+template <int NG> constexpr bool i8_sym_tile(int I, int K) { return I8Mode<NG>::SYM && I == K; }
+// slot -> kind (0: whole group, entries i >= j; 1: Q, mirrored; 2: R, entries i >= j), digit group k (scale 2^(80 - 8 k)), membership of (s, t)
+template <int NG> constexpr int i8_slot_kind(int I, int K, int q) { return !i8_sym_tile<NG>(I, K) ? 0 : (q < NG - 1 ? 1 : 2); }
+template <int NG> constexpr int i8_slot_k(int I, int K, int q) { return !i8_sym_tile<NG>(I, K) ? q : (q < NG - 1 ? q + 1 : 2 * (q - (NG - 1))); }
+template <int NG> constexpr bool i8_slot_has(int I, int K, int q, int s, int t) {
+  if (!i8_sym_tile<NG>(I, K)) return s + t == q;
+  if (q < NG - 1) return s < t && s + t == q + 1;
+  return s == t && s == q - (NG - 1);
+}
 
 struct I8Mma { int item, s, t; };
 struct I8PlanTable {
@@ -131,31 +176,33 @@ struct I8PlanTable {
   int acc_base[4] = {};
   int nacc = 0;
 };
-template <int W>
+template <int NG, int W>
 struct I8Plan {
-  static constexpr int NI = I8Items<W>::N;
+  using Items = I8Items<NG, W>;
+  static constexpr int NI = Items::N;
   // the k-step's MFMA list, built ONCE at compile time: items in order, inside an item s-major from the highest slice
   // (fragment live ranges stay short)
   static constexpr I8PlanTable build() {
     I8PlanTable p;
     for (int IT = 0; IT < NI; ++IT) {
-      const I8Item it = I8Items<W>::it[IT];
+      const I8Item it = Items::it[IT];
       p.acc_base[IT] = p.nacc;
       for (int s = 5; s >= 0; --s)
         for (int t = 0; t <= 5; ++t)
-          if (s + t >= it.k0 && s + t <= it.k1) {
-            p.mm[p.nm] = I8Mma{IT, s, t};
-            p.acc_index[p.nm] = p.nacc + s + t - it.k0;
-            ++p.nm;
-          }
-      p.nacc += it.k1 - it.k0 + 1;
+          for (int q = it.q0; q <= it.q1; ++q)
+            if (i8_slot_has<NG>(it.I, it.K, q, s, t)) {
+              p.mm[p.nm] = I8Mma{IT, s, t};
+              p.acc_index[p.nm] = p.nacc + q - it.q0;
+              ++p.nm;
+            }
+      p.nacc += it.q1 - it.q0 + 1;
     }
     p.acc_base[NI] = p.nacc;
     for (int rb = 0; rb < 4; ++rb)
       for (int sl = 0; sl < 6; ++sl) {
         p.first_use[rb][sl] = p.nm;
         for (int i = p.nm - 1; i >= 0; --i) {
-          const I8Item it = I8Items<W>::it[p.mm[i].item];
+          const I8Item it = Items::it[p.mm[i].item];
           if ((it.I == rb && p.mm[i].s == sl) || (it.K == rb && p.mm[i].t == sl)) p.first_use[rb][sl] = i;
         }
       }
@@ -165,20 +212,28 @@ struct I8Plan {
   static constexpr int NM = T.nm;
   static constexpr int NACC = T.nacc;
   static constexpr int acc_base(int IT) { return T.acc_base[IT]; }
-  static constexpr int rowblock(int i, int side) { return side == 0 ? I8Items<W>::it[T.mm[i].item].I : I8Items<W>::it[T.mm[i].item].K; }
+  static constexpr int rowblock(int i, int side) { return side == 0 ? Items::it[T.mm[i].item].I : Items::it[T.mm[i].item].K; }
   static constexpr int slice(int i, int side) { return side == 0 ? T.mm[i].s : T.mm[i].t; }
   static constexpr int first_use(int rb, int sl) { return T.first_use[rb][sl]; }
   static constexpr int acc_index(int i) { return T.acc_index[i]; }
 };
+// (the plans as stated above)
+static_assert(I8Plan<6, 0>::NM + I8Plan<6, 1>::NM + I8Plan<6, 2>::NM + I8Plan<6, 3>::NM + I8Plan<6, 4>::NM + I8Plan<6, 5>::NM + I8Plan<6, 6>::NM +
+                  I8Plan<6, 7>::NM == kI8MfmaPerKstep, "6-group plan: every product exactly once");
+static_assert(I8Plan<6, 0>::NACC + I8Plan<6, 1>::NACC + I8Plan<6, 2>::NACC + I8Plan<6, 3>::NACC + I8Plan<6, 4>::NACC + I8Plan<6, 5>::NACC +
+                  I8Plan<6, 6>::NACC + I8Plan<6, 7>::NACC == 68, "6-group plan: 36 + 4 x 8 accumulators");
+static_assert(I8Plan<7, 0>::NM + I8Plan<7, 1>::NM + I8Plan<7, 2>::NM + I8Plan<7, 3>::NM + I8Plan<7, 4>::NM + I8Plan<7, 5>::NM + I8Plan<7, 6>::NM +
+                  I8Plan<7, 7>::NM == kI8MfmaPerKstepDiag, "7-group plan: every product exactly once");
 
 __device__ __forceinline__ i32x4 lds_read_b128(const char* p) { return *reinterpret_cast<const i32x4*>(p); }
 
 // per-thread slicing state: row r = tid & 127, column octet cq = tid >> 7 of every k-step
 struct I8Slice {
   double C;          // magic constant 1.5 2^(e_r + 5)
-  unsigned limit;    // high word of 2^(e_r - 1): every |x| must stay below it
+  unsigned limit;    // high word of the row's capacity 2^e_r, minus one: an |x| at or above it is beyond the 48-bit integer (mark_block)
   unsigned amax;     // running maximum of the high words of |x|
   int rs[6];         // digit row sums of this thread's columns
+  int sq3;           // sum of a_3^2 over this thread's columns (6-group plan: the dropped product (3, 3) is not zero-mean on the diagonal)
   double b;          // sum_n x_rn y_n over this thread's columns
   double q;          // sum_n y_n^2 over this thread's columns (waves that hold row 0 only)
 };
@@ -191,7 +246,7 @@ struct I8Slice {
 // is then 32 LDS-DMA pieces of FOUR rows d = 4 p .. 4 p + 3 x 32 observations (16 lanes x 16 bytes per row), and within piece p the pair
 // of observations l16 of row q sits at 16-byte position ((l16 + p) mod 16) 4 + q: a wave reads one pair for 64 consecutive rows,
 // and the rotation by p puts the 16 lanes of every ds_read_b128 group on 16 different slots of the 256-byte bank row.
-template <bool WITH_Q, bool DIAG = false, bool ROWV = false>
+template <bool WITH_Q, bool DIAG = false, bool ROWV = false, bool WITH_SQ3 = false>
 struct I8SliceSteps {
   double x[2][4], y[2][4];  // two column quads: the second quad's LDS reads are in flight while the first is sliced
   double w[DIAG ? 2 : 1][4];  // diagonal noise: 1 / sqrt(s_n) of the columns (x enters the Gram matrix as x / sqrt(s_n), y as y / sqrt(s_n))
@@ -234,9 +289,9 @@ struct I8SliceSteps {
 #pragma unroll
         for (int j = j0; j < j0 + 2; ++j) {
           double xv = x[q][j];
-          if constexpr (DIAG) xv *= w[q][j];
+          if constexpr (DIAG) xv = __dmul_rn(xv, w[q][j]);  // (never contracted into the magic addition: the repair recomputes these bits)
           const double yv = y[q][j];
-          const double t = xv + st.C;
+          const double t = __dadd_rn(xv, st.C);
           lo[j] = (unsigned)__double2loint(t);
           hi[j] = (unsigned)__double2hiint(t);
           const unsigned ax = (unsigned)__double2hiint(xv) & 0x7fffffffu;
@@ -269,6 +324,10 @@ struct I8SliceSteps {
 #pragma unroll
         for (int s = 0; s < 6; ++s) st.rs[s] = __builtin_amdgcn_sdot4((int)p[q][s], 0x01010101, st.rs[s], false);
         asm volatile("" : "+v"(st.rs[0]), "+v"(st.rs[1]), "+v"(st.rs[2]), "+v"(st.rs[3]), "+v"(st.rs[4]), "+v"(st.rs[5]));
+        if constexpr (WITH_SQ3) {
+          st.sq3 = __builtin_amdgcn_sdot4((int)p[q][3], (int)p[q][3], st.sq3, false);
+          asm volatile("" : "+v"(st.sq3));
+        }
       }
     } else {  // C == 13: digit planes out.  Fragment (s, I = r >> 5): lane (half = cq >> 1, row r & 31) at byte 16 (32 half + (r & 31));
               // this thread's 8 columns are bytes 8 (cq & 1) .. + 8 of the lane's 16
@@ -309,16 +368,16 @@ __device__ __forceinline__ void glds_s_4x1k(uint64_t saddr_uniform, unsigned vof
 // sched_group_barrier does not move them: the slicing hangs off LDS reads the group solver leaves where they are).  So the
 // k-step is a compile-time list: MFMA i, then (fenced with sched_barrier) the fragment reads MFMA i + 2 is the first to need
 // and the slicing chunks whose turn it is -- reads of the raw columns first, their arithmetic two MFMAs later.
-template <int W, bool SLICE, bool WITH_Q, bool DIAG, bool ROWV, typename IssueFn>
+template <int NG, int W, bool SLICE, bool WITH_Q, bool DIAG, bool ROWV, typename IssueFn>
 __device__ __forceinline__ void i8_kstep(const char* __restrict__ dig, const char* __restrict__ raw, const double* __restrict__ yb,
-                                         const double* __restrict__ wb, char* __restrict__ dign, int lane, int r, int cq, i32x16 (&A)[I8Plan<W>::NACC], I8Slice& st,
+                                         const double* __restrict__ wb, char* __restrict__ dign, int lane, int r, int cq, i32x16 (&A)[I8Plan<NG, W>::NACC], I8Slice& st,
                                          IssueFn issue_next) {
-  using PL = I8Plan<W>;
+  using PL = I8Plan<NG, W>;
   constexpr int NM = PL::NM;
   constexpr int NCH = kI8SliceChunks;
   constexpr int LEAD = 2;   // a fragment is requested this many MFMAs before its first use
   i32x4 F[4][6];            // fragment (row block, slice): only the ones this wave uses ever get registers
-  I8SliceSteps<WITH_Q, DIAG, ROWV> sl;
+  I8SliceSteps<WITH_Q, DIAG, ROWV, NG == 6> sl;
   auto frag_load_one = [&](auto itag, auto qtag) {
     constexpr int i = decltype(itag)::value, q = decltype(qtag)::value, rb = q / 6, sidx = q % 6;
     constexpr int fu = PL::first_use(rb, sidx);
@@ -358,7 +417,10 @@ __device__ __forceinline__ void i8_kstep(const char* __restrict__ dig, const cha
     __builtin_amdgcn_sched_barrier(0);
     // the LDS-DMA pieces of the k-step three ahead (their slot was freed by the barrier that opened this k-step) go out one at a
     // time, every sixth MFMA (~60 cycles of issue each: beside the partner wave's MFMAs, not in a bunch behind the barrier)
-    if constexpr (i >= 2 && (i - 2) % 6 == 0 && (i - 2) / 6 < 5) issue_next(std::integral_constant<int, (i - 2) / 6>{});
+    // (every sixth MFMA where the wave has 27 or more of them; waves of the 6-group plan carry 17 to 26: closer together)
+    constexpr int ISTEP = (NM - 2) / 5 >= 6 ? 6 : ((NM - 2) / 5 >= 1 ? (NM - 2) / 5 : 1);
+    static_assert(2 + 4 * ISTEP < NM, "all five LDS-DMA pieces of a k-step must find a slot among the wave's MFMAs");
+    if constexpr (i >= 2 && (i - 2) % ISTEP == 0 && (i - 2) / ISTEP < 5) issue_next(std::integral_constant<int, (i - 2) / ISTEP>{});
     // slicing chunks c with floor(c NM / NCH) == i
     constexpr int c_lo = (i * NCH + NM - 1) / NM, c_hi = ((i + 1) * NCH + NM - 1) / NM;
     if constexpr (c_lo < c_hi) chunk(std::integral_constant<int, c_lo>{});
@@ -376,9 +438,9 @@ __device__ __forceinline__ void i8_kstep(const char* __restrict__ dig, const cha
 }
 
 // ---- the stream: on exit the wave's accumulators and the slicing state --------------------------------------------------------------
-template <int W, bool DIAG, bool ROWV>
+template <int NG, int W, bool DIAG, bool ROWV>
 __device__ __forceinline__ void i8_gram_stream(char* smem, const BLR_GLOBAL double* X /*uniform*/, const BLR_GLOBAL double* y /*uniform*/,
-                                               const BLR_GLOBAL double* rw /*uniform; DIAG: 1 / sqrt(s_n)*/, double rwmax, int64_t ldx, int N, int tid, i32x16 (&A)[I8Plan<W>::NACC], I8Slice& st, int& ok) {
+                                               const BLR_GLOBAL double* rw /*uniform; DIAG: 1 / sqrt(s_n)*/, double rwmax, int64_t ldx, int N, int tid, i32x16 (&A)[I8Plan<NG, W>::NACC], I8Slice& st, int& ok) {
   using C = I8Cfg;
   const int lane = tid & 63;
   const int r = tid & 127, cq = tid >> 7;
@@ -387,7 +449,17 @@ __device__ __forceinline__ void i8_gram_stream(char* smem, const BLR_GLOBAL doub
   double* const yring = reinterpret_cast<double*>(smem + C::OFF_YB);
   double* const wring = reinterpret_cast<double*>(smem + C::OFF_RW);
   int* const xch = reinterpret_cast<int*>(smem + C::OFF_XCH);
+  unsigned char* const oflag = reinterpret_cast<unsigned char*>(smem + C::OFF_OFLAG);
   const int nk = N / C::KC;
+  // an entry of the block just sliced outgrew its row's capacity (or is Inf / NaN): its digits are those of a wrapped value; the block
+  // is marked and put right in fp64 at the hand-over (i8_repair_block).  The running maximum starts afresh for the next block.
+  auto mark_block = [&](int blk) {
+    if (__builtin_amdgcn_ballot_w64(st.amax >= st.limit) != 0ull) {
+      if (lane == 0) oflag[blk] = 1;
+    }
+    st.amax = 0;
+  };
+  if (tid < 136) reinterpret_cast<int*>(oflag)[tid] = 0;
   // LDS-DMA pieces per wave and k-step: 4 columns (+ the y piece of wave 0, + the 1 / sqrt(s) piece of wave 1 under diagonal noise)
   constexpr int PW = 4 + (W == 0 ? 1 : 0) + (DIAG && W == 1 ? 1 : 0);
   unsigned ring_addr = lds_addr_of(ring), y_addr = lds_addr_of(yring), w_addr = lds_addr_of(wring);
@@ -433,7 +505,7 @@ __device__ __forceinline__ void i8_gram_stream(char* smem, const BLR_GLOBAL doub
     else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
   };
 #pragma unroll
-  for (int g = 0; g < I8Plan<W>::NACC; ++g)
+  for (int g = 0; g < I8Plan<NG, W>::NACC; ++g)
 #pragma unroll
     for (int v = 0; v < 16; ++v) A[g][v] = 0;
 
@@ -484,18 +556,21 @@ __device__ __forceinline__ void i8_gram_stream(char* smem, const BLR_GLOBAL doub
     int E1 = (int)(m >> 20);           // biased exponent of the row maximum (0 for a zero / denormal row)
     if (E1 > 1023 + 400) ok = 0;       // Inf / NaN / out of the range the final scaling can represent: fp64 path
     if (E1 < 1023 - 400) E1 = 1023 - 400;
-    const int eb = E1 + 1 + kI8Margin;  // biased e_r: every |x| < 2^(e_r - 1) is accepted
+    // biased e_r = E + CAP: the capacity of the row.  Q = round(x 2^(47 - e_r)) uses the whole signed 48-bit range; an entry within 2^-21
+    // of the capacity could round up to 2^47 and counts as beyond it
+    const int eb = E1 + I8Mode<NG>::CAP;
     st.C = __hiloint2double((int)(((unsigned)(eb + 5) << 20) | 0x00080000u), 0);  // 1.5 2^(e_r + 5)
-    st.limit = (unsigned)(eb - 1) << 20;
+    st.limit = ((unsigned)eb << 20) - 1u;
     st.amax = 0;
     st.b = 0.0;
     st.q = 0.0;
 #pragma unroll
     for (int s = 0; s < 6; ++s) st.rs[s] = 0;
+    st.sq3 = 0;
   }
   constexpr bool kQ = (W & 1) == 0;  // (rows 64 (W & 1) + lane: row 0 lives in the even waves)
   {  // block 0 -> digit buffer 0 (nothing to overlap with yet)
-    I8SliceSteps<kQ, DIAG, ROWV> sl;
+    I8SliceSteps<kQ, DIAG, ROWV, NG == 6> sl;
     auto rec = [&](auto self, auto ctag) -> void {
       constexpr int c = decltype(ctag)::value;
       if constexpr (c < kI8SliceChunks) {
@@ -505,6 +580,7 @@ __device__ __forceinline__ void i8_gram_stream(char* smem, const BLR_GLOBAL doub
     };
     rec(rec, std::integral_constant<int, 0>{});
   }
+  mark_block(0);
   if (nk > 1) wait_keep(nissue0 - 2 > 0 ? nissue0 - 2 : 0);
   __syncthreads();  // digits of block 0 and raw block 1 visible; raw block 0 consumed by everyone
   I8_STAMP_DECL;
@@ -517,25 +593,22 @@ __device__ __forceinline__ void i8_gram_stream(char* smem, const BLR_GLOBAL doub
     const double* yb = yring + ((j + 1) % C::NSLOT) * C::KC;
     const double* wb = wring + ((j + 1) % C::NSLOT) * C::KC;
     // k-step j + 3 goes into the slot of block j, which everybody has sliced before the barrier that ended k-step j - 1
-    i8_kstep<W, true, kQ, DIAG, ROWV>(dig, raw, yb, wb, dign, lane, r, cq, A, st, [&](auto ctag) { if (j + 3 < nk) issue_piece(j + 3, ctag); });
+    i8_kstep<NG, W, true, kQ, DIAG, ROWV>(dig, raw, yb, wb, dign, lane, r, cq, A, st, [&](auto ctag) { if (j + 3 < nk) issue_piece(j + 3, ctag); });
+    mark_block(j + 1);
     I8_STAMP(0);
     // end of k-step j: raw block j + 2 must have landed (k-step j + 3 may stay in flight), then everybody's is visible
     if (j + 2 < nk) wait_keep(j + 3 < nk ? 1 : 0);
     __syncthreads();
     I8_STAMP(2);
   }
-  i8_kstep<W, false, kQ, DIAG, ROWV>(dig0 + ((nk - 1) & 1) * C::DIG_BUF, ring, yring, wring, dig0, lane, r, cq, A, st, [](auto) {});
+  i8_kstep<NG, W, false, kQ, DIAG, ROWV>(dig0 + ((nk - 1) & 1) * C::DIG_BUF, ring, yring, wring, dig0, lane, r, cq, A, st, [](auto) {});
   I8_STAMP_FLUSH(W);
-  if (st.amax >= st.limit) ok = 0;
-#ifdef BLR_I8_EXP
-  ok = 1;
-#endif
 }
 
 // =========================================================================================================
 // the kernel
 // =========================================================================================================
-template <bool DIAG, bool ROWV = false>
+template <bool DIAG, bool ROWV = false, int NG = (DIAG ? kI8GroupsDiag : kI8GroupsIso)>
 __global__ __launch_bounds__(kI8Threads, 2) void fused_i8_kernel(PosteriorArgs<double> a) {
   using T = double;
   using C = I8Cfg;
@@ -553,6 +626,8 @@ __global__ __launch_bounds__(kI8Threads, 2) void fused_i8_kernel(PosteriorArgs<d
   double* const sctab = reinterpret_cast<double*>(smem + C::OFF_SC);
   double* const bred = reinterpret_cast<double*>(smem + C::OFF_BRED);
   double* const gdiag = reinterpret_cast<double*>(smem + C::OFF_GD);
+  double* const tabD = reinterpret_cast<double*>(smem + C::OFF_TD);
+  double* const tabU = reinterpret_cast<double*>(smem + C::OFF_UW);  // [5][128]; tabW = tabU + 640
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = uni(tid >> 6);
   const int reg = blockIdx.x;
@@ -594,14 +669,17 @@ __global__ __launch_bounds__(kI8Threads, 2) void fused_i8_kernel(PosteriorArgs<d
   // one copy of the stream per wave: the tile / group table is static
   auto run = [&](auto wtag) {
     constexpr int W = decltype(wtag)::value;
-    using PL = I8Plan<W>;
+    using PL = I8Plan<NG, W>;
+    using Items = I8Items<NG, W>;
     i32x16 A[PL::NACC];
-    i8_gram_stream<W, DIAG, ROWV>(smem, X, y, rwp, rwmax, a.ldx, N32, tid, A, st, ok);
+    i8_gram_stream<NG, W, DIAG, ROWV>(smem, X, y, rwp, rwmax, a.ldx, N32, tid, A, st, ok);
     I8_KSTAMP(4);
     // ---- hand-over: validity, digit row sums, b partials, row scales (all through the exchange area / the dead digit area)
     if (!ok) flag[0] = 0;  // (benign race: everybody writes the same value)
 #pragma unroll
     for (int s = 0; s < 6; ++s) xch[((tid >> 7) * 6 + s) * 128 + (tid & 127)] = st.rs[s];
+    // (the raw ring has been dead since the barrier that ended the last slicing k-step; P goes there only after the next two barriers)
+    if constexpr (NG == 6) reinterpret_cast<int*>(smem)[(tid >> 7) * 128 + (tid & 127)] = st.sq3;
     __syncthreads();  // ring and digit buffers are dead from here on
     bred[(tid >> 7) * 128 + (tid & 127)] = st.b;
     if (tid < 128) {
@@ -630,6 +708,37 @@ __global__ __launch_bounds__(kI8Threads, 2) void fused_i8_kernel(PosteriorArgs<d
       tabA[tid] = ta;
       tabB[tid] = tb;
       tabC[tid] = tc;
+      // The products that are dropped (s + t >= NG) are sums over the columns of centred digits, sum_n a_s(i, n) a_t(j, n).  With
+      // a = abar + atilde (abar_s(i) = R_s(i) / N the row's mean digit) such a sum is N abar_s(i) abar_t(j) + sum_n atilde atilde:
+      //   * the mean part is systematic whenever low digits are not uniform -- inputs that came from float32, integers, powers of
+      //     two have CONSTANT low digits (a = -128: 16384 per column and pair, 3e-13 of the diagonal scale with 6 groups) -- and costs
+      //     nothing to keep: sum over the dropped pairs of U_s(i) U_t(j) / N with U_s = R_s 2^(40 - 8 s), i.e. sum_{s=1..5} U_s(i) W_s(j),
+      //     W_s(j) = sum_{t >= NG - s} U_t(j) / N: ten numbers per row, five multiply-adds per entry (conversion);
+      //   * the fluctuating part is zero-mean noise (2^-52 of the diagonal scale with 7 groups, 3e-15 with 6) -- except the pair
+      //     (3, 3) of the 6-group plan on the diagonal, a sum of squares (5461 N: 8e-14 of G_ii).  sum_n a_3^2 is exact from one more
+      //     v_dot4 per quad (I8Slice::sq3); TD = (sum a_3^2 - R_3^2 / N) 2^32 joins G_ii.
+      {
+        const double ninv = 1.0 / (double)N32;
+        double U[6];
+#pragma unroll
+        for (int s2 = 1; s2 < 6; ++s2) {
+          U[s2] = (double)R[s2] * __hiloint2double((1023 + 40 - 8 * s2) << 20, 0);
+          tabU[(s2 - 1) * 128 + tid] = U[s2];
+        }
+#pragma unroll
+        for (int s2 = 1; s2 < 6; ++s2) {
+          double w = 0.0;
+#pragma unroll
+          for (int t2 = 5; t2 >= 1; --t2)
+            if (t2 >= NG - s2) w += U[t2];
+          tabU[640 + (s2 - 1) * 128 + tid] = w * ninv;
+        }
+        if constexpr (NG == 6) {
+          const int* sq = reinterpret_cast<const int*>(smem);
+          const long long s33 = ((long long)sq[tid] + sq[128 + tid]) + ((long long)sq[256 + tid] + sq[384 + tid]);
+          tabD[tid] = ((double)s33 - (double)R[3] * (double)R[3] * ninv) * __hiloint2double((1023 + 80 - 48) << 20, 0);
+        }
+      }
       // 2^(e_i - 47) from the magic constant: C = 1.5 2^(e + 5)  ->  exponent field - 52
       const int ef = (int)(((unsigned)__double2hiint(st.C) >> 20) & 0x7ffu);
       sctab[tid] = __hiloint2double((ef - 52) << 20, 0);
@@ -639,28 +748,54 @@ __global__ __launch_bounds__(kI8Threads, 2) void fused_i8_kernel(PosteriorArgs<d
     __syncthreads();
     if ((tid & 127) == 0) reinterpret_cast<double*>(xch)[tid >> 7] = qsum;
     const int valid = flag[0];
-    // ---- accumulators -> fp64 -> packed lower triangle of A = Lw + G / sigma^2 (diagonal prior), first items store, second add
+    // ---- accumulators -> fp64 -> packed lower triangle of A = Lw + G / sigma^2 (diagonal prior), phase-0 items store, the others add
     const T winv = T(1) / s_iso;
     auto convert = [&](auto ittag) {
       constexpr int IT = decltype(ittag)::value;
-      constexpr I8Item it = I8Items<W>::it[IT];
+      constexpr I8Item it = Items::it[IT];
       constexpr int base = PL::acc_base(IT);
-      const int j = 32 * it.K + (lane & 31);
+      constexpr bool symt = i8_sym_tile<NG>(it.I, it.K);
+      const int jl = lane & 31, j = 32 * it.K + jl;
       const double scj = sctab[j] * winv;
       const double tAj = tabA[j], tBj = tabB[j], tCj = tabC[j];
+      double wj[5];
+#pragma unroll
+      for (int s2 = 0; s2 < 5; ++s2) wj[s2] = it.phase == 0 ? tabU[640 + s2 * 128 + j] : 0.0;
+      double gq[symt ? 16 : 1];  // symmetric diagonal tile: the Q part of every entry, added to its mirror image in a second sweep
 #pragma unroll
       for (int v = 0; v < 16; ++v) {
-        const int i = 32 * it.I + 8 * (v >> 2) + 4 * (lane >> 5) + (v & 3);
-        double sum = 0.0;
-        if constexpr (it.k1 == 6) sum = tabC[i] + tCj;  // (one item per tile ends with group 6: it carries the offset terms of groups 4 .. 10)
+        const int il = 8 * (v >> 2) + 4 * (lane >> 5) + (v & 3), i = 32 * it.I + il;
+        double lo = 0.0, qs = 0.0;
+        // the offset terms of ALL digit pairs (tables TA, TB, TC) come in once per entry, with the tile's phase-0 item; smallest first
+        if constexpr (it.phase == 0) {
+          // (the dropped digit pairs' mean parts first: the smallest terms)
+#ifndef BLR_I8_NO_MEANPROD
 #pragma unroll
-        for (int k = it.k1; k >= it.k0; --k) {  // smallest scale first
-          sum = __builtin_fma((double)A[base + k - it.k0][v], __hiloint2double((1023 + 80 - 8 * k) << 20, 0), sum);
-          if (k == 3) sum += tabB[i] + tBj;
-          if (k == 1) sum += tabA[i] + tAj;
+          for (int s2 = 4; s2 >= 0; --s2) lo = __builtin_fma(tabU[s2 * 128 + i], wj[s2], lo);
+#endif
+          lo += tabC[i] + tCj;
         }
-        const double g = sum * sctab[i] * scj;
+        if constexpr (NG == 6 && it.phase == 0 && it.I == it.K) lo += (i == j) ? tabD[i] : 0.0;
+#pragma unroll
+        for (int k = 10; k >= 0; --k) {  // smallest scale first
+#pragma unroll
+          for (int q = it.q0; q <= it.q1; ++q)
+            if (i8_slot_k<NG>(it.I, it.K, q) == k) {
+              const double term = (double)A[base + q - it.q0][v];
+              const double sc2 = __hiloint2double((1023 + 80 - 8 * k) << 20, 0);
+              if (i8_slot_kind<NG>(it.I, it.K, q) == 1) qs = __builtin_fma(term, sc2, qs);
+              else lo = __builtin_fma(term, sc2, lo);
+            }
+          if constexpr (it.phase == 0) {
+            if (k == 3) lo += tabB[i] + tBj;
+            if (k == 1) lo += tabA[i] + tAj;
+          }
+        }
+        const double sc = sctab[i] * scj;
+        if constexpr (symt) gq[v] = qs * sc;
         if (i >= j) {
+          double g = lo * sc;
+          if constexpr (symt) g += (i == j) ? 2.0 * gq[v] : gq[v];
           if constexpr (it.phase != 0) P[pidx(i, j)] += g;
           else P[pidx(i, j)] = g + ((i == j && !fac) ? Lw[i] : T(0));
           if (i == j) {  // (the data term alone: A_ii - Lw_i would lose it under a strong prior)
@@ -670,11 +805,19 @@ __global__ __launch_bounds__(kI8Threads, 2) void fused_i8_kernel(PosteriorArgs<d
         }
         __builtin_amdgcn_sched_barrier(0);  // one entry at a time
       }
+      if constexpr (symt) {  // Q_k(i, j) with i < j belongs to entry (j, i): every lower entry of the tile has been stored / updated above
+#pragma unroll
+        for (int v = 0; v < 16; ++v) {
+          const int il = 8 * (v >> 2) + 4 * (lane >> 5) + (v & 3), i = 32 * it.I + il;
+          if (i < j) P[pidx(j, i)] += gq[v];
+          __builtin_amdgcn_sched_barrier(0);
+        }
+      }
     };
     auto convert_all = [&](auto self, auto ittag, auto phase_tag) -> void {
       constexpr int IT = decltype(ittag)::value;
       if constexpr (IT < PL::NI) {
-        if constexpr (I8Items<W>::it[IT].phase == decltype(phase_tag)::value) convert(ittag);
+        if constexpr (Items::it[IT].phase == decltype(phase_tag)::value) convert(ittag);
         self(self, std::integral_constant<int, IT + 1>{}, phase_tag);
       }
     };
@@ -702,6 +845,115 @@ __global__ __launch_bounds__(kI8Threads, 2) void fused_i8_kernel(PosteriorArgs<d
   double quad = ((qx[0] + qx[1]) + (qx[2] + qx[3])) * winv;
   const int valid = flag[0];
   __syncthreads();  // P complete; the tables in the digit area have been read
+  // ---- repair: blocks in which an entry outgrew its row's capacity.  Its digits were those of c = x - m 2^(e_r + 1) (the integer wraps; beyond
+  // 16 capacities they are whatever the magic addition left in the low mantissa bits -- still a definite number c), so the stream added
+  // c c' for that column where x x' was meant.  Per marked block: read its 32 columns again, recompute c exactly as the slicing did, and add
+  // x x' - c c' = d v' + v d' + d d' (d = x - c, v = the column as the matrix has it) entry by entry in fp64, in a fixed order.  b and y'y
+  // were formed from the fp64 values and need nothing.  Inf / NaN, or more than kI8MaxRepair marked blocks: the fp64 kernel.
+  I8_KSTAMP(5);
+  if (valid) {  // (uniform)
+    const unsigned char* const oflag = reinterpret_cast<const unsigned char*>(smem + C::OFF_OFLAG);
+    unsigned long long* const omask = reinterpret_cast<unsigned long long*>(smem + C::OFF_OMASK);
+    unsigned* const cmask = reinterpret_cast<unsigned*>(smem + C::OFF_OMASK + 64);      // [32 columns][4 words of 32 rows]
+    unsigned* const oscr = reinterpret_cast<unsigned*>(smem + C::OFF_OMASK + 64 + 512);  // [0] columns with an entry to correct; [2..3] d
+    const int nk = N32 / C::KC;
+    const int nmarked = __syncthreads_count(tid < nk && oflag[tid] != 0);
+    // (at most one marked block in 16, and never more than kI8MaxRepair: beyond, the rows' scales do not fit the data -- heavy tails, a
+    //  feature that wakes up late -- and reading the blocks again costs more than the fp64 kernel)
+    if (nmarked > (nk / 16 > kI8MaxRepair ? kI8MaxRepair : (nk / 16 < 2 ? 2 : nk / 16))) {
+      if (tid == 0) a.info[reg] = kI8Retry;
+      return;
+    }
+    if (nmarked > 0) {  // (uniform; rare)
+      if (wave == 0) {
+#pragma unroll
+        for (int q8 = 0; q8 < 8; ++q8) {
+          const int blk = 64 * q8 + lane;
+          const unsigned long long m = __builtin_amdgcn_ballot_w64(blk < nk && oflag[blk] != 0);
+          if (lane == 0) omask[q8] = m;
+        }
+      }
+      __syncthreads();
+      double* const vt = reinterpret_cast<double*>(smem + C::OFF_TAIL);  // the block as the matrix has it: [32 columns][128 rows]
+      const int r = tid & 127, cq = tid >> 7;
+      // this row's magic constant, capacity test and grid, from 2^(e_r - 47) (sctab)
+      const int ef = (int)(((unsigned)__double2hiint(sctab[r]) >> 20) & 0x7ffu);  // biased e_r - 47
+      const double Cr = __hiloint2double((int)(((unsigned)(ef + 47 + 5) << 20) | 0x00080000u), 0);
+      const unsigned limit = ((unsigned)(ef + 47) << 20) - 1u;
+      const double grid = sctab[r];
+      for (int q8 = 0; q8 < 8; ++q8) {
+        unsigned long long bm = omask[q8];
+        bm = ((unsigned long long)(unsigned)__builtin_amdgcn_readfirstlane((int)(bm >> 32)) << 32) | (unsigned)__builtin_amdgcn_readfirstlane((int)bm);
+        while (bm != 0ull) {
+          const int jb = 64 * q8 + __builtin_ctzll(bm);
+          bm &= bm - 1ull;
+          if (tid < 128) cmask[tid] = 0u;
+          if (tid == 0) oscr[0] = 0u;
+          __syncthreads();
+          double dreg[8];
+          int bad = 0;
+#pragma unroll
+          for (int c = 0; c < 8; ++c) {
+            const int n = C::KC * jb + 8 * cq + c;
+            double xv = ROWV ? X[(int64_t)r * a.ldx + n] : X[(int64_t)n * a.ldx + r];
+            if constexpr (DIAG) xv = __dmul_rn(xv, rwp[n]);
+            const unsigned ax = (unsigned)__double2hiint(xv) & 0x7fffffffu;
+            if (ax >= 0x7ff00000u) bad = 1;
+            double cur = xv;
+            dreg[c] = 0.0;
+            if (ax >= limit) {  // the test of the slicing, the arithmetic of the slicing
+              const double t = __dadd_rn(xv, Cr);
+              const long long q48 = ((long long)(short)((unsigned)__double2hiint(t) & 0xffffu) << 32) | (long long)(unsigned)__double2loint(t);
+              cur = (double)q48 * grid;
+              dreg[c] = xv - cur;
+              atomicOr(&cmask[(8 * cq + c) * 4 + (r >> 5)], 1u << (r & 31));
+              atomicOr(&oscr[0], 1u << (8 * cq + c));
+            }
+            vt[(8 * cq + c) * 128 + r] = cur;
+          }
+          if (__syncthreads_or(bad)) {  // Inf / NaN: the fp64 kernel reports what the reference would
+            if (tid == 0) a.info[reg] = kI8Retry;
+            return;
+          }
+          unsigned cols = (unsigned)__builtin_amdgcn_readfirstlane((int)oscr[0]);
+          while (cols != 0u) {
+            const int cl = __builtin_ctz(cols);
+            cols &= cols - 1u;
+            for (int wq = 0; wq < 4; ++wq) {
+              unsigned rm = (unsigned)__builtin_amdgcn_readfirstlane((int)cmask[cl * 4 + wq]);
+              while (rm != 0u) {
+                const int rr = 32 * wq + __builtin_ctz(rm);
+                rm &= rm - 1u;
+                if (tid == rr + 128 * (cl >> 3)) {  // the thread that holds this entry's d publishes it
+                  const int c8 = cl & 7;
+                  double dv = dreg[0];
+#pragma unroll
+                  for (int c = 1; c < 8; ++c) dv = (c8 == c) ? dreg[c] : dv;
+                  reinterpret_cast<double*>(oscr)[1] = dv;
+                }
+                __syncthreads();
+                const double dv = reinterpret_cast<const double*>(oscr)[1];
+                if (tid < 128) {
+                  const double vj = vt[cl * 128 + tid];
+                  if (tid != rr) {
+                    P[tid > rr ? pidx(tid, rr) : pidx(rr, tid)] += winv * dv * vj;
+                  } else {
+                    const double g = winv * (2.0 * dv * vj + dv * dv);
+                    P[pidx(rr, rr)] += g;
+                    gdiag[rr] += g;
+                    vt[cl * 128 + rr] = vj + dv;  // the column now holds the true entry
+                  }
+                }
+                __syncthreads();
+              }
+            }
+          }
+          __syncthreads();
+        }
+      }
+    }
+  }
+  I8_KSTAMP(3);
   if (N32 < N && valid) {  // (uniform)  the last r = N % 32 columns: a rank-r term in fp64, all eight waves
     const int r = N - N32;
     double* const tb = reinterpret_cast<double*>(smem + C::OFF_TAIL);  // [r][128], then y[r]
@@ -892,6 +1144,7 @@ __global__ __launch_bounds__(kI8Threads, 2) void fused_i8_kernel(PosteriorArgs<d
     }
   }
   I8_KSTAMP(7);
+  I8_CLKSTAMP;
 }
 
 // ---- diagonal noise: what the int8 route needs from s, once per call --------------------------------------------------------------

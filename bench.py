@@ -233,20 +233,21 @@ class Workload:
         if self.logpdf_only:  # no mw', no T written
             by -= self.w_bytes * (self.D + self.D * self.D) * self.B
         kern = self.kernel_name()
-        r = roofline_of(fl, by, self.dtype, ms, kern, i8_cols=self.N * self.B if kern == "fused_i8_kernel" else None)
+        r = roofline_of(fl, by, self.dtype, ms, kern, i8_cols=self.N * self.B if kern == "fused_i8_kernel" else None, i8_diag=self.diag)
         r.update({"kernel_ms_avg": ms, "units_per_launch": self.B})
         return r
 
 
-I8_OPS_PER_COLUMN = 26 * 10 * 2048.0  # int8 route: 26 digit-pair products x 10 lower 32 x 32 tiles x 2 x 32 x 32 operations per column
+I8_OPS_PER_COLUMN = 174 * 2048.0  # int8 route: MFMAs (32 x 32 x 32: 2 x 32 x 32 operations per column each) per k-step; fallback if the header cannot be read
 PEAK_I8_TOPS = 5000.0                 # dense int8 peak (2 x the bf16 peak per clock; MI355X_MICROARCH.md matrix-core table)
 
 
-def i8_ops_per_column():
-    """Digit-pair products per column of the int8 route AS BUILT (csrc/blr_fused_i8.hpp states its plan in kI8MfmaPerKstep)."""
+def i8_ops_per_column(diag=False):
+    """int8 operations per column of the int8 route AS BUILT: csrc/blr_fused_i8.hpp states the MFMAs (32 x 32 x 32) per 32-column
+    k-step of its two plans in kI8MfmaPerKstep (isotropic noise) and kI8MfmaPerKstepDiag (diagonal noise)."""
     try:
         src = open(os.path.join(ROOT, "bayesianlinearregressors.jl_amd", "csrc", "blr_fused_i8.hpp")).read()
-        m = re.search(r"constexpr int kI8MfmaPerKstep\s*=\s*(\d+)", src)
+        m = re.search(r"constexpr int kI8MfmaPerKstep%s\s*=\s*(\d+)" % ("Diag" if diag else ""), src)
         if m:
             return int(m.group(1)) * 2048.0
     except Exception:
@@ -254,7 +255,7 @@ def i8_ops_per_column():
     return I8_OPS_PER_COLUMN
 
 
-def roofline_of(flops, nbytes, dtype, ms, kernel, i8_cols=None):
+def roofline_of(flops, nbytes, dtype, ms, kernel, i8_cols=None, i8_diag=False):
     """bound = whichever of t_HBM (8 TB/s) and t_matrix is longer for the ALGORITHMIC bytes / flops of one call (stated per entry in
     DESIGN.md 5); frac = that time / measured time.  t_matrix is flops / the dense matrix peak of the dtype -- except on the int8
     route (i8_cols = columns streamed per call), whose Gram runs on the int8 cores: there it is int8 operations / 5 POP/s, which is
@@ -267,7 +268,7 @@ def roofline_of(flops, nbytes, dtype, ms, kernel, i8_cols=None):
     t_mat = flops / (PEAK_TF[dtype] * 1e12)
     extra = {}
     if i8_cols is not None:
-        ops = i8_ops_per_column() * i8_cols
+        ops = i8_ops_per_column(i8_diag) * i8_cols
         t_mat = ops / (PEAK_I8_TOPS * 1e12)
         extra = {"int8_TOPps": ops / sec / 1e12, "int8_frac": ops / sec / (PEAK_I8_TOPS * 1e12), "f64_equiv_frac": tf / PEAK_TF[dtype]}
     if t_mat >= t_hbm:
@@ -566,11 +567,11 @@ def run_secondary(torch, _abi, h, dev, stream, only=None):
             kern = op.kernel
             if op.unit == "updates/s" and not op.kernel.startswith("rank1") and "in place" not in op.kernel:
                 kern = h.last_route()  # posterior workloads: the route the dispatcher took on the last call
-            i8_cols = None
+            i8_cols, i8_diag = None, False
             if kern == "fused_i8_kernel":
                 w2 = op.keep[0]
-                i8_cols = w2.N * w2.B
-            r = roofline_of(op.flops, op.nbytes, op.dtype, ms, kern, i8_cols=i8_cols)
+                i8_cols, i8_diag = w2.N * w2.B, w2.diag
+            r = roofline_of(op.flops, op.nbytes, op.dtype, ms, kern, i8_cols=i8_cols, i8_diag=i8_diag)
             # HBM bytes of one CALL by PMC (all of the call's kernels; tools/collect_profiles.sh runs `--secondary-only <name>` under
             # rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE); summaries of earlier rounds hold the dominant kernel of four entries per update
             per_call, src = pmc_traffic_per_update(name + "_hbm")

@@ -159,7 +159,12 @@ def test_c2_shape_fp64(B):
     lp = B.logpdf(fx, y)
     fp = B.posterior(fx, y)
     mw_o, T_o, L_o, lp_o = O.posterior_logpdf_direct(mw, np.ones(D), X, 0.1, y)
-    assert lp == pytest.approx(lp_o, rel=1e-11)
+    # The evidence is delta'delta / s - |u|^2 + ...: on this instance (data explained by the weights) two terms of 1e7 leave 1.9e3.
+    # The documented contract is 1e-10 of the evidence (include/blr_mi355x.h; asserted against the literal sequence below); the sharper
+    # check here scales with what cancels: 1e-11 of the evidence + 1e-14 of delta'delta / s.  (Six digit groups on the int8 route put
+    # A within 4e-14 of its diagonal scale, which this instance turns into 1.5e-11 of the evidence; the fp64 kernel sits at 1e-12.)
+    dlt = y - X.T @ mw
+    assert abs(lp - lp_o) <= 1e-11 * abs(lp_o) + 1e-14 * float(dlt @ dlt) / 0.1
     np.testing.assert_allclose(fp.mw, mw_o, rtol=1e-9, atol=1e-12)
     # A = Lw + X X' / s: every entry within 1e-13 of the scale of its row and column (the int8-sliced Gram's error model: 48 bits
     # per input relative to its ROW's bound -- an entry that nearly cancels is off by that much of sqrt(A_ii A_jj), not of itself),
@@ -2328,8 +2333,8 @@ def _i8_case(rng, nb, N, kind):
         X[:, ::3, 9] *= 1e-310
     w = rng.standard_normal((nb, D)) / rowscale[None, :]
     y = np.einsum("bnd,bd->bn", X, w) + np.sqrt(0.1) * rng.standard_normal((nb, N))
-    if kind == "outlier":     # one entry far above its row's bound, in the middle of the stream: the fast path must hand the regressor
-        X[::2, N // 2, 5] = 1.0e3  # back (y is left as it was: an outlier in y would only make the evidence ill-conditioned for everybody)
+    if kind == "outlier":     # one entry far above its row's capacity, in the middle of the stream: wrapped digits, repaired in fp64 at the
+        X[::2, N // 2, 5] = 1.0e3  # hand-over (y is left as it was: an outlier in y would only make the evidence ill-conditioned for everybody)
     return X, y
 
 
@@ -2360,7 +2365,9 @@ def test_i8_gram_path_vs_oracle_and_fp64_kernel(B, opt, kind, N, prior_mean):
                             mw, D, dpr, 1, D, mp, D, Tp, D, D * D, Ap, D, D * D, lp, info)
         return mp, Tp, Ap, lp, info
 
+    h.reset_stats()
     fast = run()
+    handed_back = h.get_stat("i8_handed_back")
     again = run()
     for u, v in zip(fast, again):
         np.testing.assert_array_equal(u, v)  # fixed accumulation order on the fast path too
@@ -2370,20 +2377,29 @@ def test_i8_gram_path_vs_oracle_and_fp64_kernel(B, opt, kind, N, prior_mean):
     for b in range(nb):
         mw_o, T_o, A_o, lp_o = O.posterior_logpdf_direct(mw[b], dpr[b], X[b].T, 0.1, y[b])
         scale = np.abs(A_o).max()
+        # evidence: the documented 1e-10 is the contract (header); the check here is sharper and scales with what cancels in
+        # delta'delta / s - |u|^2 (well-explained data: terms ~1e3 times the evidence) -- 1e-11 of the evidence + 1e-14 of delta'delta / s
+        dlt = y[b] - X[b] @ mw[b]
+        lp_tol = 1e-11 * abs(lp_o) + 1e-14 * float(dlt @ dlt) / 0.1
         for mp, Tp, Ap, lp, _ in (fast, slow):
-            assert lp[b] == pytest.approx(lp_o, rel=1e-11)
+            assert abs(lp[b] - lp_o) <= lp_tol
             np.testing.assert_allclose(mp[b] * np.sqrt(np.diag(A_o)), mw_o * np.sqrt(np.diag(A_o)), rtol=1e-8, atol=1e-9 * np.abs(mw_o * np.sqrt(np.diag(A_o))).max())
             # entries of A against the scale of their row and column (rows of very different magnitude: "scales")
             dA = np.sqrt(np.diag(A_o))
             assert (np.abs(Ap[b] - A_o) / np.outer(dA, dA)).max() <= 1e-12
             Tn = np.triu(Tp[b].T)
             assert (np.abs(Tn.T @ Tn - A_o) / np.outer(dA, dA)).max() <= 1e-10
-        # (the evidence is a difference of two terms ~1e3 times its size on well-explained data -- y'Sy against |u|^2: one ulp of
-        # those is 1e-12 of the evidence, on either path)
-        assert fast[3][b] == pytest.approx(slow[3][b], rel=1e-11)
+        assert abs(fast[3][b] - slow[3][b]) <= lp_tol
         dsc = np.sqrt(np.diag(O.posterior_logpdf_direct(mw[b], dpr[b], X[b].T, 0.1, y[b])[2]))
         assert np.abs((fast[0][b] - slow[0][b]) * dsc).max() <= 1e-10 * np.abs(slow[0][b] * dsc).max()
-        if kind == "outlier" and b % 2 == 0:  # handed back: the fp64 kernel's bits
+    # An entry beyond its row's capacity wraps around in the 48-bit integer and is put right in fp64 at the hand-over ("outlier": a
+    # 1e3 among N(0,1) entries, 100 capacities out -- checked against the oracle above like everything else); only a row that wakes up
+    # after the columns its scale came from ("zero_row", every other regressor) marks more blocks than are repaired and goes back.
+    if kind in ("gauss", "scales", "outlier", "tiny"):
+        assert handed_back == 0
+    if kind == "zero_row":  # (N / 64 marked blocks against at most one in 16 repaired: handed back)
+        assert handed_back == nb // 2
+        for b in range(1, nb, 2):  # the fp64 kernel's bits
             assert fast[3][b] == slow[3][b]
             np.testing.assert_array_equal(fast[0][b], slow[0][b])
             np.testing.assert_array_equal(fast[1][b], slow[1][b])

@@ -2,7 +2,7 @@
 // noise, diagonal prior; timed with HIP events; every output compared with fused_small_kernel<double, 8, 4> on the same inputs
 // (and the first regressors' evidence with a plain host evaluation).  Not part of the product.
 //   hipcc --offload-arch=gfx950 -O3 -std=c++17 -I../bayesianlinearregressors.jl_amd/csrc i8_gram.hip -o i8_gram
-//   ./i8_gram [B] [N] [reps] [mode]     mode 0: N(0,1) inputs   1: one outlier per regressor (retry path)   2: rows of very different scale   3: X = 0
+//   ./i8_gram [B] [N] [reps] [mode]     mode 0: N(0,1) inputs   1: one far outlier in every other regressor (repair path)   2: rows of very different scale   3: X = 0   4: ~10 entries per regressor 6 x larger (wrapped values, repair path)   5: NaN in every other regressor (hand-back path)
 #include <hip/hip_runtime.h>
 #include <algorithm>
 #include <cmath>
@@ -35,7 +35,11 @@ int main(int argc, char** argv) {
         for (int i = 0; i < D; ++i) X[((size_t)b * N + n) * D + i] *= std::ldexp(1.0, (i % 7) * 9 - 27);  // rows from 2^-27 to 2^27
   if (mode == 3) std::fill(X.begin(), X.end(), 0.0);  // zero operands: what the clock does without data toggling
   if (mode == 1)
-    for (int b = 0; b < BU; b += 2) X[((size_t)b * N + N / 2) * D + 5] = 1.0e6;  // breaks the row bound of every other regressor
+    for (int b = 0; b < BU; b += 2) X[((size_t)b * N + N / 2) * D + 5] = 1.0e6;  // far beyond the capacity of its row in every other regressor
+  if (mode == 4)
+    for (auto& v : X) if (rnd() < 2.0e-5) v *= 6.0;
+  if (mode == 5)
+    for (int b = 0; b < BU; b += 2) X[((size_t)b * N + N / 2) * D + 5] = std::nan("");
   const T s_iso = 0.1;
   T *dX, *dy, *ds, *dmw, *dpri; CK(hipMalloc((void**)&dX, (size_t)B * N * D * 8)); CK(hipMalloc((void**)&dy, (size_t)B * N * 8));
   CK(hipMalloc((void**)&ds, 8)); CK(hipMalloc((void**)&dmw, D * 8)); CK(hipMalloc((void**)&dpri, D * 8));
@@ -63,15 +67,21 @@ int main(int argc, char** argv) {
     return a;
   };
   using SC = SmallCfg<T, 8>;
+#ifndef I8_NG
+#define I8_NG 6
+#endif
+  auto ki8 = fused_i8_kernel<false, false, I8_NG>;
   auto k64 = fused_small_kernel<T, 8, 4>;
   CK(hipFuncSetAttribute(reinterpret_cast<const void*>(k64), hipFuncAttributeMaxDynamicSharedMemorySize, SC::LDS_BYTES));
-  CK(hipFuncSetAttribute(reinterpret_cast<const void*>(fused_i8_kernel<false>), hipFuncAttributeMaxDynamicSharedMemorySize, I8Cfg::LDS_BYTES));
+  CK(hipFuncSetAttribute(reinterpret_cast<const void*>(ki8), hipFuncAttributeMaxDynamicSharedMemorySize, I8Cfg::LDS_BYTES));
   const int stag_first = getenv("I8_STAG_FIRST") ? atoi(getenv("I8_STAG_FIRST")) : (B >= 1024 ? 256 : 0);
   const int stag_ticks = getenv("I8_STAG_TICKS") ? atoi(getenv("I8_STAG_TICKS")) : 25000;  // 250 us
+  unsigned long long* dcnt; CK(hipMalloc((void**)&dcnt, 64)); CK(hipMemset(dcnt, 0, 64));
   auto run_i8 = [&](bool lp_only) {
     PosteriorArgs<T> a = args(0);
+    a.i8_handed_tot = dcnt; a.i8_handed_slice = dcnt + 1;
     if (lp_only) { a.mw_post = nullptr; a.T_post = nullptr; }
-    hipLaunchKernelGGL(fused_i8_kernel<false>, dim3(B), dim3(kI8Threads), I8Cfg::LDS_BYTES, 0, a);
+    hipLaunchKernelGGL(ki8, dim3(B), dim3(kI8Threads), I8Cfg::LDS_BYTES, 0, a);
     a.retry_only = 1;
     hipLaunchKernelGGL(k64, dim3(B), dim3(kThreads), SC::LDS_BYTES, 0, a);
   };
@@ -84,7 +94,7 @@ int main(int argc, char** argv) {
   for (int r = 0; r < reps; ++r) run_i8(false);
   CK(hipEventRecord(e1)); CK(hipEventSynchronize(e1)); CK(hipEventElapsedTime(&ms_i8, e0, e1)); ms_i8 /= reps;
   { PosteriorArgs<T> a = args(0); a.Lw_post = o[0].Lp; a.ldlp = D; a.strideLp = D * D; a.B = BU;
-    hipLaunchKernelGGL(fused_i8_kernel<false>, dim3(BU), dim3(kI8Threads), I8Cfg::LDS_BYTES, 0, a); a.retry_only = 1;
+    hipLaunchKernelGGL(ki8, dim3(BU), dim3(kI8Threads), I8Cfg::LDS_BYTES, 0, a); a.retry_only = 1;
     hipLaunchKernelGGL(k64, dim3(BU), dim3(kThreads), SC::LDS_BYTES, 0, a); }
   run_f64(); CK(hipDeviceSynchronize());
   CK(hipEventRecord(e0));
@@ -97,13 +107,13 @@ int main(int argc, char** argv) {
     unsigned long long z[8][8] = {};
     CK(hipMemcpyToSymbol(HIP_SYMBOL(g_i8stamps), z, sizeof(z)));
     PosteriorArgs<T> a = args(0);
-    hipLaunchKernelGGL(fused_i8_kernel<false>, dim3(B), dim3(kI8Threads), I8Cfg::LDS_BYTES, 0, a);
+    hipLaunchKernelGGL(ki8, dim3(B), dim3(kI8Threads), I8Cfg::LDS_BYTES, 0, a);
     CK(hipDeviceSynchronize());
     CK(hipMemcpyFromSymbol(z, HIP_SYMBOL(g_i8stamps), sizeof(z)));
-    const double nk = N / 32;
+    const double nwg = (B + 255) / 256, nk = N / 32 * nwg;  // (sums over the workgroups with blockIdx % 256 == 0)
     for (int w = 0; w < 8; ++w)
-      printf("  wave %d of WG 0, cycles per k-step: MFMA %6.0f | slicing %6.0f | DMA wait + barrier %6.0f | DMA issue %5.0f || stream %8llu | hand-over + conversion %7llu | chol %7llu | backsolve + out %7llu\n",
-             w, z[w][0] / nk, z[w][1] / nk, z[w][2] / nk, z[w][3] / nk, z[w][4], z[w][5], z[w][6], z[w][7]);
+      printf("  wave %d, mean over %d workgroups, cycles per k-step: MFMAs + slicing %6.0f | DMA wait + barrier %6.0f || per regressor: stream %8.0f | hand-over + conversion %7.0f | repair %6.0f | chol %7.0f | backsolve + out %7.0f\n",
+             w, (int)nwg, z[w][0] / nk, z[w][2] / nk, z[w][4] / nwg, z[w][5] / nwg, z[w][3] / nwg, z[w][6] / nwg, z[w][7] / nwg);
   }
 #endif
   // compare
@@ -131,9 +141,11 @@ int main(int argc, char** argv) {
       e_A = std::max(e_A, std::fabs(A0[(size_t)b * D * D + i] - A1[(size_t)b * D * D + i]) / am);
     }
   }
+  unsigned long long hcnt[2]; CK(hipMemcpy(hcnt, dcnt, 16, hipMemcpyDeviceToHost));
+  printf("  handed back to the fp64 kernel: %llu regressors over %d launches of %d\n", hcnt[0], reps + 2, B);
   printf("D=128 N=%d B=%d mode %d: int8 path %.3f ms/launch = %.3f M updates/s (%.2f TB/s of X) | fp64 kernel %.3f ms = %.3f M updates/s\n", N, B, mode,
          ms_i8, B / ms_i8 / 1e3, (double)B * N * D * 8 / ms_i8 / 1e9, ms_f64, B / ms_f64 / 1e3);
   printf("  int8 vs fp64 kernel: logpdf max rel diff %.2e (%d of %d bit-equal) | A = Lw' max |diff| / max|A| %.2e | mw' %.2e | T %.2e | status/replica mismatches %d\n",
          e_lp, exact_lp, B, e_A, e_m, e_T, bad);
-  return bad != 0 || !(e_lp < 1e-11) || !(e_m < 1e-9) || !(e_T < 1e-9);
+  return (mode != 5 && bad != 0) || !(e_lp < 1e-11) || !(e_m < 1e-9) || !(e_T < 1e-9);
 }
