@@ -76,15 +76,15 @@ constexpr int kI8MfmaPerKstep = 174;      // isotropic: 6 off-diagonal tiles x 2
 constexpr int kI8MfmaPerKstepDiag = 260;  // diagonal noise: 10 tiles x 26
 
 // BLR_I8_STAMPS: diagnostic builds only (tools/i8_gram.hip): cycle sums of workgroup 0, one row per wave --
-//   (sums over the workgroups with blockIdx % 256 == 0)  [0] the k-steps (MFMAs + slicing)  [2] DMA wait + barrier  [3] repair of marked blocks  [4] whole stream  [5] hand-over + conversion (+ tail columns, prior mean)
+//   (sums over the workgroups with blockIdx % 257 == 0)  [0] the k-steps (MFMAs + slicing)  [2] DMA wait + barrier  [3] repair of marked blocks  [4] whole stream  [5] hand-over + conversion (+ tail columns, prior mean)
 //   [6] factorisation  [7] back substitution + outputs
 #ifdef BLR_I8_STAMPS
-__device__ unsigned long long g_i8stamps[8][8];
+__device__ unsigned long long g_i8stamps[8][16];
 __device__ unsigned long long g_i8clk[4];
 #define I8_STAMP_DECL unsigned long long i8t_prev = __builtin_amdgcn_s_memtime(), i8t_acc[4] = {0, 0, 0, 0}
 #define I8_STAMP(slot) do { const unsigned long long t__ = __builtin_amdgcn_s_memtime(); i8t_acc[slot] += t__ - i8t_prev; i8t_prev = t__; } while (0)
-#define I8_STAMP_FLUSH(W) do { if ((blockIdx.x & 255) == 0 && (threadIdx.x & 63) == 0) for (int q__ = 0; q__ < 3; ++q__) atomicAdd(&g_i8stamps[W][q__], i8t_acc[q__]); } while (0)
-#define I8_KSTAMP(slot) do { const unsigned long long t__ = __builtin_amdgcn_s_memtime(); if ((blockIdx.x & 255) == 0 && (threadIdx.x & 63) == 0) atomicAdd(&g_i8stamps[threadIdx.x >> 6][slot], t__ - i8k_prev); i8k_prev = t__; } while (0)
+#define I8_STAMP_FLUSH(W) do { if ((blockIdx.x % 257) == 0 && (threadIdx.x & 63) == 0) for (int q__ = 0; q__ < 3; ++q__) atomicAdd(&g_i8stamps[W][q__], i8t_acc[q__]); } while (0)
+#define I8_KSTAMP(slot) do { const unsigned long long t__ = __builtin_amdgcn_s_memtime(); if ((blockIdx.x % 257) == 0 && (threadIdx.x & 63) == 0) atomicAdd(&g_i8stamps[threadIdx.x >> 6][slot], t__ - i8k_prev); i8k_prev = t__; } while (0)
 #define I8_KSTAMP_DECL unsigned long long i8k_prev = __builtin_amdgcn_s_memtime(); const unsigned long long i8k_c0 = i8k_prev, i8k_r0 = __builtin_amdgcn_s_memrealtime()
 // whole-workgroup shader cycles and 100 MHz ticks, summed over the workgroups with blockIdx % 256 == 0: the clock the part holds under this kernel
 #define I8_CLKSTAMP do { if ((blockIdx.x & 255) == 0 && threadIdx.x == 0) { atomicAdd(&g_i8clk[0], __builtin_amdgcn_s_memtime() - i8k_c0); atomicAdd(&g_i8clk[1], __builtin_amdgcn_s_memrealtime() - i8k_r0); atomicAdd(&g_i8clk[2], 1ull); } } while (0)
@@ -121,8 +121,10 @@ struct I8Cfg {
   static constexpr int OFF_GD = OFF_BRED + 4 * 128 * 8;         // diag(G) / sigma^2 WITHOUT the prior (prior-mean terms): 128 doubles
   static constexpr int OFF_TD = OFF_GD + 128 * 8;               // TD: sum_n a_3(i, n)^2 2^32, the diagonal's share of the dropped digit pair (3, 3) (6-group plan): 128 doubles
   static constexpr int OFF_TAIL = OFF_TD + 128 * 8;             // the last N % 32 columns of X (fp64 rank-r term of the hand-over) + their y: 31 x 128 + 32 doubles
-  static constexpr int OFF_UW = 80 * 1024;                     // (dead ring, above the phase functions' image) U_s, W_s, s = 1 .. 5: 10 x 128 doubles
-  static_assert(SmallCfg<double, 8>::LDS_BYTES <= OFF_UW && OFF_UW + 10 * 128 * 8 <= RING_BYTES, "the phase functions' LDS image and the mean-product tables must fit in the dead ring");
+  // (dead ring, above the phase functions' image) what the conversion adds to the products of an entry (i, j), packed per row as the
+  // LEFT index i: {T, 2^(e_i - 47), U_1 .. U_5, TD} and as the RIGHT index j: {T, 2^(e_j - 47), W_1 .. W_5, Lw_j (diagonal prior)} -- 2 x 128 x 8 doubles
+  static constexpr int OFF_UW = 80 * 1024;
+  static_assert(SmallCfg<double, 8>::LDS_BYTES <= OFF_UW && OFF_UW + 2 * 128 * 8 * 8 <= RING_BYTES, "the phase functions' LDS image and the conversion records must fit in the dead ring");
   static_assert(OFF_TAIL + (32 * 128 + 32) * 8 <= OFF_YB, "conversion tables and the tail columns / a block under repair must fit in the digit area");
   static_assert(LDS_BYTES <= 160 * 1024, "LDS of one CU");
 };
@@ -136,26 +138,28 @@ struct I8Cfg {
 // 7-group plan: 70 accumulators, 260 MFMAs per k-step (w0 35 + w4 29 | w1 35 + w5 29 | w2 33 + w6 32 | w3 34 + w7 33).
 // 6-group plan: 68 accumulators (36 + 4 x 8), 174 MFMAs per k-step, dealt by tools/i8_plan_search.py: at most 9 accumulators per
 // wave (the slicing shares the 256 registers), SIMD partners (w, w + 4) carrying 44 44 44 42 between them, 95 fragment reads per k-step.
-// `phase`: a tile whose slots are split over waves is assembled in up to three rounds, a barrier between them -- the
-// phase-0 item stores (with the offset tables and the prior), the others add.
-struct I8Item { int I, K, q0, q1, phase; };
+// `phase`: a tile whose slots are split over waves is assembled in up to three rounds, a barrier between them -- its `first`
+// item stores, the others add; the offset tables, the mean parts of the dropped pairs and the prior join in a pass of their own.
+struct I8Item { int I, K, q0, q1, phase, first; };  // first: this item STORES its tile's entries (the tile's other items, in later phases, add)
 template <int NG, int W> struct I8Items;
-template <> struct I8Items<7, 0> { static constexpr int N = 2; static constexpr I8Item it[3] = {{0, 0, 0, 6, 0}, {2, 0, 3, 4, 1}, {0, 0, 0, -1, 0}}; };
-template <> struct I8Items<7, 1> { static constexpr int N = 2; static constexpr I8Item it[3] = {{1, 1, 0, 6, 0}, {3, 1, 3, 4, 1}, {0, 0, 0, -1, 0}}; };
-template <> struct I8Items<7, 2> { static constexpr int N = 2; static constexpr I8Item it[3] = {{3, 0, 2, 6, 0}, {1, 0, 0, 3, 0}, {0, 0, 0, -1, 0}}; };
-template <> struct I8Items<7, 3> { static constexpr int N = 3; static constexpr I8Item it[3] = {{3, 2, 2, 6, 0}, {2, 0, 0, 2, 0}, {2, 1, 6, 6, 1}}; };
-template <> struct I8Items<7, 4> { static constexpr int N = 2; static constexpr I8Item it[3] = {{2, 2, 0, 6, 0}, {3, 0, 0, 1, 1}, {0, 0, 0, -1, 0}}; };
-template <> struct I8Items<7, 5> { static constexpr int N = 2; static constexpr I8Item it[3] = {{3, 3, 0, 6, 0}, {3, 2, 0, 1, 1}, {0, 0, 0, -1, 0}}; };
-template <> struct I8Items<7, 6> { static constexpr int N = 2; static constexpr I8Item it[3] = {{2, 1, 0, 5, 0}, {2, 0, 5, 6, 2}, {0, 0, 0, -1, 0}}; };
-template <> struct I8Items<7, 7> { static constexpr int N = 3; static constexpr I8Item it[3] = {{1, 0, 4, 6, 1}, {3, 1, 5, 6, 2}, {3, 1, 0, 2, 0}}; };
-template <> struct I8Items<6, 0> { static constexpr int N = 2; static constexpr I8Item it[3] = {{3, 2, 3, 5, 1}, {3, 3, 0, 4, 0}, {0, 0, 0, -1, 0}}; };
-template <> struct I8Items<6, 1> { static constexpr int N = 3; static constexpr I8Item it[3] = {{3, 0, 0, 5, 0}, {3, 1, 0, 1, 0}, {3, 3, 5, 5, 1}}; };
-template <> struct I8Items<6, 2> { static constexpr int N = 3; static constexpr I8Item it[3] = {{3, 1, 2, 5, 1}, {3, 2, 0, 2, 0}, {3, 3, 6, 7, 2}}; };
-template <> struct I8Items<6, 3> { static constexpr int N = 3; static constexpr I8Item it[3] = {{0, 0, 1, 2, 1}, {2, 0, 0, 3, 0}, {2, 2, 0, 2, 0}}; };
-template <> struct I8Items<6, 4> { static constexpr int N = 3; static constexpr I8Item it[3] = {{0, 0, 0, 0, 0}, {1, 0, 4, 5, 1}, {1, 1, 3, 7, 1}}; };
-template <> struct I8Items<6, 5> { static constexpr int N = 2; static constexpr I8Item it[3] = {{2, 0, 4, 5, 1}, {2, 2, 3, 7, 1}, {0, 0, 0, -1, 0}}; };
-template <> struct I8Items<6, 6> { static constexpr int N = 2; static constexpr I8Item it[3] = {{0, 0, 3, 7, 2}, {1, 0, 0, 3, 0}, {0, 0, 0, -1, 0}}; };
-template <> struct I8Items<6, 7> { static constexpr int N = 2; static constexpr I8Item it[3] = {{1, 1, 0, 2, 0}, {2, 1, 0, 5, 0}, {0, 0, 0, -1, 0}}; };
+template <> struct I8Items<7, 0> { static constexpr int N = 2; static constexpr I8Item it[3] = {{0, 0, 0, 6, 0, 1}, {2, 0, 3, 4, 1, 0}, {0, 0, 0, -1, 0, 0}}; };
+template <> struct I8Items<7, 1> { static constexpr int N = 2; static constexpr I8Item it[3] = {{1, 1, 0, 6, 0, 1}, {3, 1, 3, 4, 1, 0}, {0, 0, 0, -1, 0, 0}}; };
+template <> struct I8Items<7, 2> { static constexpr int N = 2; static constexpr I8Item it[3] = {{3, 0, 2, 6, 0, 1}, {1, 0, 0, 3, 0, 1}, {0, 0, 0, -1, 0, 0}}; };
+template <> struct I8Items<7, 3> { static constexpr int N = 3; static constexpr I8Item it[3] = {{3, 2, 2, 6, 0, 1}, {2, 0, 0, 2, 0, 1}, {2, 1, 6, 6, 1, 0}}; };
+template <> struct I8Items<7, 4> { static constexpr int N = 2; static constexpr I8Item it[3] = {{2, 2, 0, 6, 0, 1}, {3, 0, 0, 1, 1, 0}, {0, 0, 0, -1, 0, 0}}; };
+template <> struct I8Items<7, 5> { static constexpr int N = 2; static constexpr I8Item it[3] = {{3, 3, 0, 6, 0, 1}, {3, 2, 0, 1, 1, 0}, {0, 0, 0, -1, 0, 0}}; };
+template <> struct I8Items<7, 6> { static constexpr int N = 2; static constexpr I8Item it[3] = {{2, 1, 0, 5, 0, 1}, {2, 0, 5, 6, 2, 0}, {0, 0, 0, -1, 0, 0}}; };
+template <> struct I8Items<7, 7> { static constexpr int N = 3; static constexpr I8Item it[3] = {{1, 0, 4, 6, 1, 0}, {3, 1, 5, 6, 2, 0}, {3, 1, 0, 2, 0, 1}}; };
+// 6-group plan: the phases are a 3-colouring of the (tile, wave) incidence -- no wave converts two items in one phase, no tile is touched
+// by two waves in one phase -- and a tile's earliest item stores
+template <> struct I8Items<6, 0> { static constexpr int N = 2; static constexpr I8Item it[3] = {{3, 2, 3, 5, 1, 0}, {3, 3, 0, 4, 0, 1}, {0, 0, 0, -1, 0, 0}}; };
+template <> struct I8Items<6, 1> { static constexpr int N = 3; static constexpr I8Item it[3] = {{3, 0, 0, 5, 2, 1}, {3, 1, 0, 1, 0, 1}, {3, 3, 5, 5, 1, 0}}; };
+template <> struct I8Items<6, 2> { static constexpr int N = 3; static constexpr I8Item it[3] = {{3, 1, 2, 5, 1, 0}, {3, 2, 0, 2, 0, 1}, {3, 3, 6, 7, 2, 0}}; };
+template <> struct I8Items<6, 3> { static constexpr int N = 3; static constexpr I8Item it[3] = {{0, 0, 1, 2, 0, 1}, {2, 0, 0, 3, 1, 0}, {2, 2, 0, 2, 2, 0}}; };
+template <> struct I8Items<6, 4> { static constexpr int N = 3; static constexpr I8Item it[3] = {{0, 0, 0, 0, 1, 0}, {1, 0, 4, 5, 0, 1}, {1, 1, 3, 7, 2, 0}}; };
+template <> struct I8Items<6, 5> { static constexpr int N = 2; static constexpr I8Item it[3] = {{2, 0, 4, 5, 0, 1}, {2, 2, 3, 7, 1, 1}, {0, 0, 0, -1, 0, 0}}; };
+template <> struct I8Items<6, 6> { static constexpr int N = 2; static constexpr I8Item it[3] = {{0, 0, 3, 7, 2, 0}, {1, 0, 0, 3, 1, 0}, {0, 0, 0, -1, 0, 0}}; };
+template <> struct I8Items<6, 7> { static constexpr int N = 2; static constexpr I8Item it[3] = {{1, 1, 0, 2, 0, 1}, {2, 1, 0, 5, 1, 1}, {0, 0, 0, -1, 0, 0}}; };
 
 template <int NG> constexpr bool i8_sym_tile(int I, int K) { return I8Mode<NG>::SYM && I == K; }
 // slot -> kind (0: whole group, entries i >= j; 1: Q, mirrored; 2: R, entries i >= j), digit group k (scale 2^(80 - 8 k)), membership of (s, t)
@@ -375,7 +379,10 @@ __device__ __forceinline__ void i8_kstep(const char* __restrict__ dig, const cha
   using PL = I8Plan<NG, W>;
   constexpr int NM = PL::NM;
   constexpr int NCH = kI8SliceChunks;
-  constexpr int LEAD = 2;   // a fragment is requested this many MFMAs before its first use
+#ifndef BLR_I8_LEAD
+#define BLR_I8_LEAD 2
+#endif
+  constexpr int LEAD = BLR_I8_LEAD;   // a fragment is requested this many MFMAs before its first use
   i32x4 F[4][6];            // fragment (row block, slice): only the ones this wave uses ever get registers
   I8SliceSteps<WITH_Q, DIAG, ROWV, NG == 6> sl;
   auto frag_load_one = [&](auto itag, auto qtag) {
@@ -404,6 +411,8 @@ __device__ __forceinline__ void i8_kstep(const char* __restrict__ dig, const cha
     if constexpr (i == 0) {  // at the head: everything the first LEAD MFMAs need
       frag_loads(std::integral_constant<int, 0>{});
       frag_loads(std::integral_constant<int, 1>{});
+      if constexpr (LEAD >= 3) frag_loads(std::integral_constant<int, 2>{});
+      if constexpr (LEAD >= 4) frag_loads(std::integral_constant<int, 3>{});
     }
     if constexpr (i + LEAD < NM) frag_loads(std::integral_constant<int, i + LEAD>{});
     __builtin_amdgcn_sched_barrier(0);
@@ -620,14 +629,11 @@ __global__ __launch_bounds__(kI8Threads, 2) void fused_i8_kernel(PosteriorArgs<d
   int* const iscr = reinterpret_cast<int*>(smem + SC::OFF_SCR + 64);
   int* const xch = reinterpret_cast<int*>(smem + C::OFF_XCH);
   int* const flag = reinterpret_cast<int*>(smem + C::OFF_FLAG);
-  double* const tabA = reinterpret_cast<double*>(smem + C::OFF_VTAB);
-  double* const tabB = tabA + 128;
-  double* const tabC = tabA + 256;
   double* const sctab = reinterpret_cast<double*>(smem + C::OFF_SC);
   double* const bred = reinterpret_cast<double*>(smem + C::OFF_BRED);
   double* const gdiag = reinterpret_cast<double*>(smem + C::OFF_GD);
-  double* const tabD = reinterpret_cast<double*>(smem + C::OFF_TD);
-  double* const tabU = reinterpret_cast<double*>(smem + C::OFF_UW);  // [5][128]; tabW = tabU + 640
+  double* const rowpk = reinterpret_cast<double*>(smem + C::OFF_UW);  // [128][8] (left index), then colpk [128][8] (right index)
+  double* const colpk = rowpk + 128 * 8;
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = uni(tid >> 6);
   const int reg = blockIdx.x;
@@ -689,10 +695,10 @@ __global__ __launch_bounds__(kI8Threads, 2) void fused_i8_kernel(PosteriorArgs<d
       // Offset terms of digit group k (header comment), per row:  V_k(i) = 128 sum_s R_s(i) over the s that pair with an OFFSET
       // digit t = k - s in 1 .. 5 (s = max(0, k - 5) .. min(5, k - 1)), for ALL groups k = 1 .. 10 -- also those whose products are
       // dropped -- plus half of the constant c_k = 16384 N #{(s, t): s, t >= 1, s + t = k} (the other half comes in with the
-      // column index).  Exact integers.  Folded over k with the group scales 2^(80 - 8k) into three tables so that the
-      // conversion adds 2 x 3 numbers per entry:  TA = groups 1, 2 (exact: 35 significant bits)   TB = group 3
-      // TC = groups 4 .. 10 (rounded at 2^-53 of ITS size, 2^-65 of the result)
-      double ta = 0.0, tb = 0.0, tc = 0.0;
+      // column index).  Exact integers, folded over k with the group scales 2^(80 - 8k), smallest first, into ONE number per row
+      // (rounded at 2^-53 of the largest term, group 1 or 2: 2^-55 of the diagonal scale.  The seven-group version kept three
+      // tables to assemble every entry to the last bit; with the digit products cut at 2^-45 that buys nothing).
+      double tsum = 0.0;
 #pragma unroll
       for (int k = 10; k >= 1; --k) {
         long long acc_s = 0;
@@ -700,14 +706,8 @@ __global__ __launch_bounds__(kI8Threads, 2) void fused_i8_kernel(PosteriorArgs<d
         for (int s2 = 0; s2 < 6; ++s2)
           if (s2 <= k - 1 && s2 >= k - 5) acc_s += R[s2];
         const int npairs = k <= 6 ? (k > 1 ? k - 1 : 0) : 11 - k;
-        const double vk = (double)(128LL * acc_s + 8192LL * (long long)N32 * npairs) * __hiloint2double((1023 + 80 - 8 * k) << 20, 0);
-        if (k >= 4) tc += vk;
-        else if (k == 3) tb = vk;
-        else ta += vk;
+        tsum += (double)(128LL * acc_s + 8192LL * (long long)N32 * npairs) * __hiloint2double((1023 + 80 - 8 * k) << 20, 0);
       }
-      tabA[tid] = ta;
-      tabB[tid] = tb;
-      tabC[tid] = tc;
       // The products that are dropped (s + t >= NG) are sums over the columns of centred digits, sum_n a_s(i, n) a_t(j, n).  With
       // a = abar + atilde (abar_s(i) = R_s(i) / N the row's mean digit) such a sum is N abar_s(i) abar_t(j) + sum_n atilde atilde:
       //   * the mean part is systematic whenever low digits are not uniform -- inputs that came from float32, integers, powers of
@@ -717,13 +717,21 @@ __global__ __launch_bounds__(kI8Threads, 2) void fused_i8_kernel(PosteriorArgs<d
       //   * the fluctuating part is zero-mean noise (2^-52 of the diagonal scale with 7 groups, 3e-15 with 6) -- except the pair
       //     (3, 3) of the 6-group plan on the diagonal, a sum of squares (5461 N: 8e-14 of G_ii).  sum_n a_3^2 is exact from one more
       //     v_dot4 per quad (I8Slice::sq3); TD = (sum a_3^2 - R_3^2 / N) 2^32 joins G_ii.
+      // 2^(e_i - 47) from the magic constant: C = 1.5 2^(e + 5)  ->  exponent field - 52
+      const int ef = (int)(((unsigned)__double2hiint(st.C) >> 20) & 0x7ffu);
+      const double sci = __hiloint2double((ef - 52) << 20, 0);
+      sctab[tid] = sci;
       {
         const double ninv = 1.0 / (double)N32;
         double U[6];
+        double* const rp = rowpk + tid * 8;
+        double* const cp = colpk + tid * 8;
+        rp[0] = tsum; cp[0] = tsum;
+        rp[1] = sci; cp[1] = sci;
 #pragma unroll
         for (int s2 = 1; s2 < 6; ++s2) {
           U[s2] = (double)R[s2] * __hiloint2double((1023 + 40 - 8 * s2) << 20, 0);
-          tabU[(s2 - 1) * 128 + tid] = U[s2];
+          rp[1 + s2] = U[s2];
         }
 #pragma unroll
         for (int s2 = 1; s2 < 6; ++s2) {
@@ -731,23 +739,24 @@ __global__ __launch_bounds__(kI8Threads, 2) void fused_i8_kernel(PosteriorArgs<d
 #pragma unroll
           for (int t2 = 5; t2 >= 1; --t2)
             if (t2 >= NG - s2) w += U[t2];
-          tabU[640 + (s2 - 1) * 128 + tid] = w * ninv;
+          cp[1 + s2] = w * ninv;
         }
+        double td = 0.0;
         if constexpr (NG == 6) {
           const int* sq = reinterpret_cast<const int*>(smem);
           const long long s33 = ((long long)sq[tid] + sq[128 + tid]) + ((long long)sq[256 + tid] + sq[384 + tid]);
-          tabD[tid] = ((double)s33 - (double)R[3] * (double)R[3] * ninv) * __hiloint2double((1023 + 80 - 48) << 20, 0);
+          td = ((double)s33 - (double)R[3] * (double)R[3] * ninv) * __hiloint2double((1023 + 80 - 48) << 20, 0);
         }
+        rp[7] = td;
+        cp[7] = fac ? 0.0 : (double)Lw[tid];  // (a diagonal prior joins the diagonal at the conversion; a factor prior after the prior-mean terms)
       }
-      // 2^(e_i - 47) from the magic constant: C = 1.5 2^(e + 5)  ->  exponent field - 52
-      const int ef = (int)(((unsigned)__double2hiint(st.C) >> 20) & 0x7ffu);
-      sctab[tid] = __hiloint2double((ef - 52) << 20, 0);
     }
     double qsum = 0.0;
     if ((tid & 127) == 0) qsum = st.q;  // the four threads of row 0 hold the four column octets' shares
     __syncthreads();
     if ((tid & 127) == 0) reinterpret_cast<double*>(xch)[tid >> 7] = qsum;
     const int valid = flag[0];
+    I8_KSTAMP(8);
     // ---- accumulators -> fp64 -> packed lower triangle of A = Lw + G / sigma^2 (diagonal prior), phase-0 items store, the others add
     const T winv = T(1) / s_iso;
     auto convert = [&](auto ittag) {
@@ -757,25 +766,11 @@ __global__ __launch_bounds__(kI8Threads, 2) void fused_i8_kernel(PosteriorArgs<d
       constexpr bool symt = i8_sym_tile<NG>(it.I, it.K);
       const int jl = lane & 31, j = 32 * it.K + jl;
       const double scj = sctab[j] * winv;
-      const double tAj = tabA[j], tBj = tabB[j], tCj = tabC[j];
-      double wj[5];
-#pragma unroll
-      for (int s2 = 0; s2 < 5; ++s2) wj[s2] = it.phase == 0 ? tabU[640 + s2 * 128 + j] : 0.0;
       double gq[symt ? 16 : 1];  // symmetric diagonal tile: the Q part of every entry, added to its mirror image in a second sweep
 #pragma unroll
       for (int v = 0; v < 16; ++v) {
         const int il = 8 * (v >> 2) + 4 * (lane >> 5) + (v & 3), i = 32 * it.I + il;
         double lo = 0.0, qs = 0.0;
-        // the offset terms of ALL digit pairs (tables TA, TB, TC) come in once per entry, with the tile's phase-0 item; smallest first
-        if constexpr (it.phase == 0) {
-          // (the dropped digit pairs' mean parts first: the smallest terms)
-#ifndef BLR_I8_NO_MEANPROD
-#pragma unroll
-          for (int s2 = 4; s2 >= 0; --s2) lo = __builtin_fma(tabU[s2 * 128 + i], wj[s2], lo);
-#endif
-          lo += tabC[i] + tCj;
-        }
-        if constexpr (NG == 6 && it.phase == 0 && it.I == it.K) lo += (i == j) ? tabD[i] : 0.0;
 #pragma unroll
         for (int k = 10; k >= 0; --k) {  // smallest scale first
 #pragma unroll
@@ -786,30 +781,32 @@ __global__ __launch_bounds__(kI8Threads, 2) void fused_i8_kernel(PosteriorArgs<d
               if (i8_slot_kind<NG>(it.I, it.K, q) == 1) qs = __builtin_fma(term, sc2, qs);
               else lo = __builtin_fma(term, sc2, lo);
             }
-          if constexpr (it.phase == 0) {
-            if (k == 3) lo += tabB[i] + tBj;
-            if (k == 1) lo += tabA[i] + tAj;
-          }
         }
         const double sc = sctab[i] * scj;
         if constexpr (symt) gq[v] = qs * sc;
-        if (i >= j) {
+        if (it.I != it.K || i >= j) {  // (off-diagonal tiles lie below the diagonal as a whole)
           double g = lo * sc;
           if constexpr (symt) g += (i == j) ? 2.0 * gq[v] : gq[v];
-          if constexpr (it.phase != 0) P[pidx(i, j)] += g;
-          else P[pidx(i, j)] = g + ((i == j && !fac) ? Lw[i] : T(0));
-          if (i == j) {  // (the data term alone: A_ii - Lw_i would lose it under a strong prior)
-            if constexpr (it.phase != 0) gdiag[i] += g;
-            else gdiag[i] = g;
-          }
+          if constexpr (it.first) P[pidx(i, j)] = g;
+          else P[pidx(i, j)] += g;
         }
-        __builtin_amdgcn_sched_barrier(0);  // one entry at a time
+        if ((v & 3) == 3) __builtin_amdgcn_sched_barrier(0);  // four entries at a time (their LDS round trips overlap; more would spill)
       }
       if constexpr (symt) {  // Q_k(i, j) with i < j belongs to entry (j, i): every lower entry of the tile has been stored / updated above
+        __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
-        for (int v = 0; v < 16; ++v) {
-          const int il = 8 * (v >> 2) + 4 * (lane >> 5) + (v & 3), i = 32 * it.I + il;
-          if (i < j) P[pidx(j, i)] += gq[v];
+        for (int v0 = 0; v0 < 16; v0 += 8) {  // eight independent read-modify-writes in flight
+          double cur[8];
+#pragma unroll
+          for (int v = v0; v < v0 + 8; ++v) {
+            const int i = 32 * it.I + 8 * (v >> 2) + 4 * (lane >> 5) + (v & 3);
+            cur[v - v0] = (i < j) ? P[pidx(j, i)] : 0.0;
+          }
+#pragma unroll
+          for (int v = v0; v < v0 + 8; ++v) {
+            const int i = 32 * it.I + 8 * (v >> 2) + 4 * (lane >> 5) + (v & 3);
+            if (i < j) P[pidx(j, i)] = cur[v - v0] + gq[v];
+          }
           __builtin_amdgcn_sched_barrier(0);
         }
       }
@@ -822,10 +819,57 @@ __global__ __launch_bounds__(kI8Threads, 2) void fused_i8_kernel(PosteriorArgs<d
       }
     };
     if (valid) convert_all(convert_all, std::integral_constant<int, 0>{}, std::integral_constant<int, 0>{});
+    I8_KSTAMP(9);
     __syncthreads();
     if (valid) convert_all(convert_all, std::integral_constant<int, 0>{}, std::integral_constant<int, 1>{});
+    I8_KSTAMP(10);
     __syncthreads();
     if (valid) convert_all(convert_all, std::integral_constant<int, 0>{}, std::integral_constant<int, 2>{});
+    I8_KSTAMP(11);
+    __syncthreads();
+    // ---- what does not come out of the accumulators: per entry (i, j) the offset terms T_i + T_j of ALL digit pairs, the mean parts
+    // sum_s U_s(i) W_s(j) of the dropped ones, TD_i on the diagonal -- scaled like the products -- and the diagonal prior.  Row i of the
+    // packed triangle per thread (its record in registers), 32 columns each; diag(G) / s goes to `gdiag` before the prior joins.
+    if (valid) {
+      typedef double d2 __attribute__((ext_vector_type(2)));
+      const int i = tid & 127, j0 = 32 * (tid >> 7);
+      const d2* const rp = reinterpret_cast<const d2*>(rowpk + i * 8);
+      const d2 r01 = rp[0], r23 = rp[1], r45 = rp[2], r67 = rp[3];
+      const double sci = r01[1] * winv;
+      T* const prow = P + ((i * (i + 1)) >> 1);
+      // (four columns per step: their record reads and read-modify-writes overlap)
+#pragma unroll 1
+      for (int jb = j0; jb < j0 + 32 && jb <= i; jb += 4) {
+        d2 c01[4], c23[4], c45[4], c67[4];
+        double cur[4];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+          const d2* const cj = reinterpret_cast<const d2*>(colpk + (jb + u) * 8);
+          c01[u] = cj[0]; c23[u] = cj[1]; c45[u] = cj[2]; c67[u] = cj[3];
+          cur[u] = (jb + u <= i) ? prow[jb + u] : 0.0;
+        }
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+          const int j = jb + u;
+          double tb = r67[0] * c67[u][0];
+          tb = __builtin_fma(r45[1], c45[u][1], tb);
+          tb = __builtin_fma(r45[0], c45[u][0], tb);
+          tb = __builtin_fma(r23[1], c23[u][1], tb);
+          tb = __builtin_fma(r23[0], c23[u][0], tb);
+#ifdef BLR_I8_NO_MEANPROD
+          tb = 0.0;
+#endif
+          if (i == j) tb += r67[1];
+          tb += r01[0] + c01[u][0];
+          double e = __builtin_fma(tb, sci * c01[u][1], cur[u]);
+          if (i == j) {
+            gdiag[i] = e;      // (the data term alone: A_ii - Lw_i would lose it under a strong prior)
+            e += c67[u][1];    // the diagonal prior (0 for a factor prior: U'U joins after the prior-mean terms)
+          }
+          if (j <= i) prow[j] = e;
+        }
+      }
+    }
   };
   switch (wave) {
     case 0: run(std::integral_constant<int, 0>{}); break;

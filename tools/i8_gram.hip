@@ -91,7 +91,8 @@ int main(int argc, char** argv) {
   for (int w = 0; w < 2; ++w) run_i8(false);
   CK(hipDeviceSynchronize()); CK(hipGetLastError());
   CK(hipEventRecord(e0));
-  for (int r = 0; r < reps; ++r) run_i8(false);
+  const bool lponly = getenv("I8_LPONLY") != nullptr;  // timing experiment: no mw', no T written
+  for (int r = 0; r < reps; ++r) run_i8(lponly);
   CK(hipEventRecord(e1)); CK(hipEventSynchronize(e1)); CK(hipEventElapsedTime(&ms_i8, e0, e1)); ms_i8 /= reps;
   { PosteriorArgs<T> a = args(0); a.Lw_post = o[0].Lp; a.ldlp = D; a.strideLp = D * D; a.B = BU;
     hipLaunchKernelGGL(ki8, dim3(BU), dim3(kI8Threads), I8Cfg::LDS_BYTES, 0, a); a.retry_only = 1;
@@ -104,16 +105,19 @@ int main(int argc, char** argv) {
   CK(hipDeviceSynchronize());
 #ifdef BLR_I8_STAMPS
   {
-    unsigned long long z[8][8] = {};
+    unsigned long long z[8][16] = {};
     CK(hipMemcpyToSymbol(HIP_SYMBOL(g_i8stamps), z, sizeof(z)));
     PosteriorArgs<T> a = args(0);
     hipLaunchKernelGGL(ki8, dim3(B), dim3(kI8Threads), I8Cfg::LDS_BYTES, 0, a);
     CK(hipDeviceSynchronize());
     CK(hipMemcpyFromSymbol(z, HIP_SYMBOL(g_i8stamps), sizeof(z)));
-    const double nwg = (B + 255) / 256, nk = N / 32 * nwg;  // (sums over the workgroups with blockIdx % 256 == 0)
+    const double nwg = (B + 256) / 257, nk = N / 32 * nwg;  // (sums over the workgroups with blockIdx % 257 == 0: different replicas of the inputs)
     for (int w = 0; w < 8; ++w)
       printf("  wave %d, mean over %d workgroups, cycles per k-step: MFMAs + slicing %6.0f | DMA wait + barrier %6.0f || per regressor: stream %8.0f | hand-over + conversion %7.0f | repair %6.0f | chol %7.0f | backsolve + out %7.0f\n",
              w, (int)nwg, z[w][0] / nk, z[w][2] / nk, z[w][4] / nwg, z[w][5] / nwg, z[w][3] / nwg, z[w][6] / nwg, z[w][7] / nwg);
+    for (int w = 0; w < 8; ++w)
+      printf("    wave %d hand-over in detail: sums + tables + barriers %6.0f | conversion phase 0 %6.0f | (barrier +) phase 1 %6.0f | (barrier +) phase 2 %6.0f | rest (barrier, tail columns) %6.0f\n",
+             w, z[w][8] / nwg, z[w][9] / nwg, z[w][10] / nwg, z[w][11] / nwg, z[w][5] / nwg);
   }
 #endif
   // compare
