@@ -79,7 +79,6 @@ constexpr int kI8MfmaPerKstepDiag = 260;  // diagonal noise: 10 tiles x 26
 //   (sums over the workgroups with blockIdx % 257 == 0)  [0] the k-steps (MFMAs + slicing)  [2] DMA wait + barrier  [3] repair of marked blocks  [4] whole stream  [5] hand-over + conversion (+ tail columns, prior mean)
 //   [6] factorisation  [7] back substitution + outputs
 #ifdef BLR_I8_STAMPS
-__device__ unsigned long long g_i8stamps[8][16];
 __device__ unsigned long long g_i8clk[4];
 #define I8_STAMP_DECL unsigned long long i8t_prev = __builtin_amdgcn_s_memtime(), i8t_acc[4] = {0, 0, 0, 0}
 #define I8_STAMP(slot) do { const unsigned long long t__ = __builtin_amdgcn_s_memtime(); i8t_acc[slot] += t__ - i8t_prev; i8t_prev = t__; } while (0)
@@ -498,9 +497,12 @@ __device__ __forceinline__ void i8_gram_stream(char* smem, const BLR_GLOBAL doub
     } else {
       if constexpr (W == 0) glds_s<4, 64>(uni((int64_t)nextY), (unsigned)lane * 4u, y_addr + (unsigned)((t % C::NSLOT) * C::KC * 8));
       if constexpr (DIAG && W == 1) glds_s<4, 64>(uni((int64_t)nextW), (unsigned)lane * 4u, w_addr + (unsigned)((t % C::NSLOT) * C::KC * 8));
-      nextX += ROWV ? (uint64_t)C::KC * 8u : (uint64_t)C::KC * colbytes;
-      nextY += (uint64_t)C::KC * 8u;
-      nextW += (uint64_t)C::KC * 8u;
+      // (pieces are issued for three k-steps beyond the last one too -- a branch per piece in the k-step split its schedule: 4.73 -> 4.62 ms
+      // per 4096 updates without them; they load the last block again, from L2: the addresses stop advancing there)
+      const uint64_t adv = (t + 1 < nk) ? ~(uint64_t)0 : (uint64_t)0;
+      nextX += (ROWV ? (uint64_t)C::KC * 8u : (uint64_t)C::KC * colbytes) & adv;
+      nextY += ((uint64_t)C::KC * 8u) & adv;
+      nextW += ((uint64_t)C::KC * 8u) & adv;
     }
   };
   auto issue = [&](int t) {
@@ -602,16 +604,112 @@ __device__ __forceinline__ void i8_gram_stream(char* smem, const BLR_GLOBAL doub
     const double* yb = yring + ((j + 1) % C::NSLOT) * C::KC;
     const double* wb = wring + ((j + 1) % C::NSLOT) * C::KC;
     // k-step j + 3 goes into the slot of block j, which everybody has sliced before the barrier that ended k-step j - 1
-    i8_kstep<NG, W, true, kQ, DIAG, ROWV>(dig, raw, yb, wb, dign, lane, r, cq, A, st, [&](auto ctag) { if (j + 3 < nk) issue_piece(j + 3, ctag); });
+    i8_kstep<NG, W, true, kQ, DIAG, ROWV>(dig, raw, yb, wb, dign, lane, r, cq, A, st, [&](auto ctag) { issue_piece(j + 3, ctag); });
     mark_block(j + 1);
     I8_STAMP(0);
     // end of k-step j: raw block j + 2 must have landed (k-step j + 3 may stay in flight), then everybody's is visible
-    if (j + 2 < nk) wait_keep(j + 3 < nk ? 1 : 0);
+    wait_keep(1);
     __syncthreads();
     I8_STAMP(2);
   }
   i8_kstep<NG, W, false, kQ, DIAG, ROWV>(dig0 + ((nk - 1) & 1) * C::DIG_BUF, ring, yring, wring, dig0, lane, r, cq, A, st, [](auto) {});
+  wait_keep(0);  // (the pieces issued beyond the last k-step land in a ring that is about to be reused)
   I8_STAMP_FLUSH(W);
+}
+
+// ---- back substitution m = L^-T u for D = 128, blocked by 16 ------------------------------------------------------------------------------
+// phase_backsolve (blr_fused_small.hpp) walks the 128 pivots one after the other on one wave: 312 cycles per pivot, 40 k cycles per
+// regressor with the matrix pipe and seven waves idle.  Here the chain is 8 block steps: the inverses W_J = L_JJ^-1 of the eight 16 x 16
+// diagonal blocks first (all at once: one column per lane, 128 lanes), then for J = 7 .. 0
+//     m_J = W_J' r_J      (16 x 16 product: lane = column, r_J by v_readlane)
+//     r_K -= L_JK' m_J    for the rows K < J (lane = column of L, m_J by v_readlane)
+// on wave 0, while waves 1 - 3 write T = L'.  Same interface as phase_backsolve: on entry P = L (packed), bvec = u; on exit bvec = m,
+// scr[6] = |u|^2, scr[7] = logdet A.  Four-wave code (the waves that survive the hand-over).
+__device__ __attribute__((noinline)) void i8_backsolve_blocked(char* smem, double* Tout_in, int64_t ldt_in) {
+  using SC = SmallCfg<double, 8>;
+  constexpr int D = 128;
+  double* const P = reinterpret_cast<double*>(smem);
+  double* const bvec = reinterpret_cast<double*>(smem + SC::OFF_B);
+  double* const dinv = reinterpret_cast<double*>(smem + SC::OFF_DINV);
+  double* const scr = reinterpret_cast<double*>(smem + SC::OFF_SCR);
+  double* const Wst = reinterpret_cast<double*>(smem + I8Cfg::OFF_UW);  // [8 blocks][16 rows i][16 columns c] (the conversion records are dead)
+  int tid = threadIdx.x;
+  asm volatile("" : "+v"(tid));
+  const int lane = tid & 63;
+  const int wave = uni(tid >> 6);
+  BLR_GLOBAL double* const Tout = as_global(uni(Tout_in));
+  const int64_t ldt = uni(ldt_in);
+  BLR_BS_STAMP_DECL;
+  if (tid < D) dinv[tid] = 1.0 / P[pidx(tid, tid)];
+  __syncthreads();
+  if (tid < D) {  // W = L_JJ^-1, column c per lane: forward substitution on e_c, sixteen steps in lockstep
+    const int blk = tid >> 4, c = tid & 15;
+    double w[16];
+#pragma unroll
+    for (int i = 0; i < 16; ++i) {
+      const double* row = P + pidx(16 * blk + i, 16 * blk);
+      double sum = (i == c) ? 1.0 : 0.0;
+#pragma unroll
+      for (int k = 0; k < i; ++k) sum = __builtin_fma(-row[k], w[k], sum);
+      w[i] = sum * dinv[16 * blk + i];
+      Wst[(blk * 16 + i) * 16 + c] = w[i];
+    }
+  }
+  __syncthreads();
+  BLR_BS_STAMP(12);
+  if (wave != 0) {
+    // T = L' (upper, column-major; strictly-lower part zero) goes out while wave 0 runs the substitution (:67, chol(...).U)
+    if (Tout != nullptr) {
+      for (int c = wave - 1; c < D; c += kWaves - 1) {
+        const double* row = P + pidx(c, 0);
+        BLR_GLOBAL double* out = Tout + (int64_t)c * ldt;
+        const int r0 = lane, r1 = lane + 64;
+        out[r0] = (r0 <= c) ? row[r0] : 0.0;
+        out[r1] = (r1 <= c) ? row[r1] : 0.0;
+      }
+    }
+  } else {
+    double b0 = bvec[lane], b1 = bvec[lane + 64];
+    double uu = wave_allreduce(b0 * b0 + b1 * b1);
+    const int c = lane & 15, grp = lane >> 4;
+#pragma unroll 1
+    for (int J = 7; J >= 0; --J) {
+      const bool hi = J >= 4;   // (uniform) block J lives in b1 (rows 64 ..) or in b0
+      const int jb = J & 3;     // its 16-lane group there
+      const double rs = hi ? b1 : b0;
+      // (1) m_J = W_J' r_J: column c of W_J (zero above the diagonal: a term with i < c vanishes)
+      const double* wc = Wst + J * 256 + c;
+      double acc = 0.0;
+#pragma unroll
+      for (int i = 0; i < 16; ++i) acc = __builtin_fma(wc[i * 16], readlane(rs, 16 * jb + i), acc);
+      if (grp == jb) { if (hi) b1 = acc; else b0 = acc; }
+      if (J == 0) break;
+      // (2) the rows above: r_c -= sum_i L(16 J + i, c) m_i for c < 16 J
+      const double ms = hi ? b1 : b0;
+      const double* rowJ = P + pidx(16 * J, 0);
+      const bool act0 = lane < 16 * J, act1 = lane + 64 < 16 * J;
+      double d0 = 0.0, d1 = 0.0;
+      int ro = 0;  // offset of row 16 J + i within the packed triangle, relative to row 16 J
+#pragma unroll
+      for (int i = 0; i < 16; ++i) {
+        const double mi = readlane(ms, 16 * jb + i);
+        d0 = __builtin_fma(rowJ[ro + lane], mi, d0);
+        if (hi) d1 = __builtin_fma(rowJ[ro + lane + 64], mi, d1);  // (uniform; J <= 4: nothing of b1 lies above block J)
+        ro += 16 * J + i + 1;
+      }
+      if (act0) b0 -= d0;
+      if (act1) b1 -= d1;
+    }
+    bvec[lane] = b0;
+    bvec[lane + 64] = b1;
+    BLR_BS_STAMP(13);
+    double ld = log(P[pidx(lane, lane)]) + log(P[pidx(lane + 64, lane + 64)]);
+    ld = 2.0 * wave_allreduce(ld);  // logdet A
+    if (lane == 0) { scr[6] = uu; scr[7] = ld; }
+  }
+  BLR_BS_STAMP(14);
+  __syncthreads();
+  BLR_BS_STAMP(15);
 }
 
 // =========================================================================================================
@@ -1178,7 +1276,7 @@ __global__ __launch_bounds__(kI8Threads, 2) void fused_i8_kernel(PosteriorArgs<d
     }
     return;
   }
-  phase_backsolve<T, 8>(smem, D, a.T_post ? a.T_post + (int64_t)reg * a.strideT : (T*)nullptr, a.ldt);
+  i8_backsolve_blocked(smem, a.T_post ? a.T_post + (int64_t)reg * a.strideT : (T*)nullptr, a.ldt);
   if (a.mw_post && tid < D) a.mw_post[(int64_t)reg * a.stride_mwpost + tid] = mw[tid] + bvec[tid];  // :68
   if (tid == 0) {
     a.info[reg] = 0;

@@ -1297,6 +1297,14 @@ BLR_PHASE int phase_chol(char* smem, int D_in, int with_rhs_in) {
 // phase 3 (noinline, wave 0 does the serial part): m = L^-T u by column-oriented back substitution.
 // Returns through LDS: bvec <- m (rows < D), scr[6] = |u|^2, scr[7] = logdet A.
 // =========================================================================================================
+#ifdef BLR_I8_STAMPS
+__device__ unsigned long long g_i8stamps[8][16];  // (tools/i8_gram.hip; slots 12 - 15: inside phase_backsolve)
+#define BLR_BS_STAMP(slot) do { const unsigned long long t__ = __builtin_amdgcn_s_memtime(); if ((blockIdx.x % 257) == 0 && (threadIdx.x & 63) == 0) atomicAdd(&g_i8stamps[threadIdx.x >> 6][slot], t__ - bs_prev); bs_prev = t__; } while (0)
+#define BLR_BS_STAMP_DECL unsigned long long bs_prev = __builtin_amdgcn_s_memtime()
+#else
+#define BLR_BS_STAMP(slot) do {} while (0)
+#define BLR_BS_STAMP_DECL do {} while (0)
+#endif
 template <typename T, int NB, int TAG = 0>
 BLR_PHASE void phase_backsolve(char* smem, int D_in, T* Tout_in, int64_t ldt_in) {
   using C = SmallCfg<T, NB>;
@@ -1312,8 +1320,10 @@ BLR_PHASE void phase_backsolve(char* smem, int D_in, T* Tout_in, int64_t ldt_in)
   asm volatile("" : "+s"(D));  // (see phase_chol)
   BLR_GLOBAL T* const Tout = as_global(uni(Tout_in));
   const int64_t ldt = uni(ldt_in);
+  BLR_BS_STAMP_DECL;
   if (tid < D) dinv[tid] = T(1) / P[pidx(tid, tid)];
   __syncthreads();
+  BLR_BS_STAMP(12);
   if (wave != 0) {
     // T = L' (upper, column-major; strictly-lower part zero) goes out while wave 0 runs the serial substitution: the
     // three waves would otherwise sit at the closing barrier (:67, chol(...).U)
@@ -1363,13 +1373,16 @@ BLR_PHASE void phase_backsolve(char* smem, int D_in, T* Tout_in, int64_t ldt_in)
     }
     if (i0 < D) bvec[i0] = b0;
     if (i1 < D) bvec[i1] = b1;
+    BLR_BS_STAMP(13);
     double ld = 0.0;
     if (i0 < D) ld += log((double)P[pidx(i0, i0)]);
     if (i1 < D) ld += log((double)P[pidx(i1, i1)]);
     ld = 2.0 * wave_allreduce(ld);  // logdet A
     if (lane == 0) { scr[6] = uu; scr[7] = ld; }
   }
+  BLR_BS_STAMP(14);
   __syncthreads();
+  BLR_BS_STAMP(15);
 }
 
 // ---- scalar right-looking Cholesky on the packed triangle (standalone chol_small_kernel only) --------------

@@ -115,6 +115,9 @@ int main(int argc, char** argv) {
     for (int w = 0; w < 8; ++w)
       printf("  wave %d, mean over %d workgroups, cycles per k-step: MFMAs + slicing %6.0f | DMA wait + barrier %6.0f || per regressor: stream %8.0f | hand-over + conversion %7.0f | repair %6.0f | chol %7.0f | backsolve + out %7.0f\n",
              w, (int)nwg, z[w][0] / nk, z[w][2] / nk, z[w][4] / nwg, z[w][5] / nwg, z[w][3] / nwg, z[w][6] / nwg, z[w][7] / nwg);
+    for (int w = 0; w < 4; ++w)
+      printf("    wave %d back substitution in detail: reciprocal pivots + barrier %6.0f | substitution (wave 0) / T written (waves 1-3) %6.0f | logdet %6.0f | closing barrier %6.0f\n",
+             w, z[w][12] / nwg, z[w][13] / nwg, z[w][14] / nwg, z[w][15] / nwg);
     for (int w = 0; w < 8; ++w)
       printf("    wave %d hand-over in detail: sums + tables + barriers %6.0f | conversion phase 0 %6.0f | (barrier +) phase 1 %6.0f | (barrier +) phase 2 %6.0f | rest (barrier, tail columns) %6.0f\n",
              w, z[w][8] / nwg, z[w][9] / nwg, z[w][10] / nwg, z[w][11] / nwg, z[w][5] / nwg);
