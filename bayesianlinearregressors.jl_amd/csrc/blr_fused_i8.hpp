@@ -617,6 +617,136 @@ __device__ __forceinline__ void i8_gram_stream(char* smem, const BLR_GLOBAL doub
   I8_STAMP_FLUSH(W);
 }
 
+// ---- hand-over, the parts that do not depend on the wave's accumulators: ONE copy of each (noinline) -- inlined into the eight
+// per-wave instances of the stream they added 30 KB to a kernel whose straight-line hand-over code already overflows the
+// instruction cache once per regressor
+template <int NG>
+__device__ __attribute__((noinline)) void i8_build_tables(char* smem, int N32_in, double Cmagic, int fac_in, const BLR_GLOBAL double* Lw) {
+  using C = I8Cfg;
+  const int* const xch = reinterpret_cast<const int*>(smem + C::OFF_XCH);
+  double* const sctab = reinterpret_cast<double*>(smem + C::OFF_SC);
+  double* const rowpk = reinterpret_cast<double*>(smem + C::OFF_UW);
+  double* const colpk = rowpk + 128 * 8;
+  int tid = threadIdx.x;
+  asm volatile("" : "+v"(tid));
+  const int N32 = uni(N32_in);
+  const bool fac = uni(fac_in) != 0;
+  if (tid < 128) {
+      int R[6];
+#pragma unroll
+      for (int s = 0; s < 6; ++s) R[s] = (xch[s * 128 + tid] + xch[(6 + s) * 128 + tid]) + (xch[(12 + s) * 128 + tid] + xch[(18 + s) * 128 + tid]);
+      // Offset terms of digit group k (header comment), per row:  V_k(i) = 128 sum_s R_s(i) over the s that pair with an OFFSET
+      // digit t = k - s in 1 .. 5 (s = max(0, k - 5) .. min(5, k - 1)), for ALL groups k = 1 .. 10 -- also those whose products are
+      // dropped -- plus half of the constant c_k = 16384 N #{(s, t): s, t >= 1, s + t = k} (the other half comes in with the
+      // column index).  Exact integers, folded over k with the group scales 2^(80 - 8k), smallest first, into ONE number per row
+      // (rounded at 2^-53 of the largest term, group 1 or 2: 2^-55 of the diagonal scale.  The seven-group version kept three
+      // tables to assemble every entry to the last bit; with the digit products cut at 2^-45 that buys nothing).
+      double tsum = 0.0;
+#pragma unroll
+      for (int k = 10; k >= 1; --k) {
+        long long acc_s = 0;
+#pragma unroll
+        for (int s2 = 0; s2 < 6; ++s2)
+          if (s2 <= k - 1 && s2 >= k - 5) acc_s += R[s2];
+        const int npairs = k <= 6 ? (k > 1 ? k - 1 : 0) : 11 - k;
+        tsum += (double)(128LL * acc_s + 8192LL * (long long)N32 * npairs) * __hiloint2double((1023 + 80 - 8 * k) << 20, 0);
+      }
+      // The products that are dropped (s + t >= NG) are sums over the columns of centred digits, sum_n a_s(i, n) a_t(j, n).  With
+      // a = abar + atilde (abar_s(i) = R_s(i) / N the row's mean digit) such a sum is N abar_s(i) abar_t(j) + sum_n atilde atilde:
+      //   * the mean part is systematic whenever low digits are not uniform -- inputs that came from float32, integers, powers of
+      //     two have CONSTANT low digits (a = -128: 16384 per column and pair, 3e-13 of the diagonal scale with 6 groups) -- and costs
+      //     nothing to keep: sum over the dropped pairs of U_s(i) U_t(j) / N with U_s = R_s 2^(40 - 8 s), i.e. sum_{s=1..5} U_s(i) W_s(j),
+      //     W_s(j) = sum_{t >= NG - s} U_t(j) / N: ten numbers per row, five multiply-adds per entry (conversion);
+      //   * the fluctuating part is zero-mean noise (2^-52 of the diagonal scale with 7 groups, 3e-15 with 6) -- except the pair
+      //     (3, 3) of the 6-group plan on the diagonal, a sum of squares (5461 N: 8e-14 of G_ii).  sum_n a_3^2 is exact from one more
+      //     v_dot4 per quad (I8Slice::sq3); TD = (sum a_3^2 - R_3^2 / N) 2^32 joins G_ii.
+      // 2^(e_i - 47) from the magic constant: C = 1.5 2^(e + 5)  ->  exponent field - 52
+      const int ef = (int)(((unsigned)__double2hiint(Cmagic) >> 20) & 0x7ffu);
+      const double sci = __hiloint2double((ef - 52) << 20, 0);
+      sctab[tid] = sci;
+      {
+        const double ninv = 1.0 / (double)N32;
+        double U[6];
+        double* const rp = rowpk + tid * 8;
+        double* const cp = colpk + tid * 8;
+        rp[0] = tsum; cp[0] = tsum;
+        rp[1] = sci; cp[1] = sci;
+#pragma unroll
+        for (int s2 = 1; s2 < 6; ++s2) {
+          U[s2] = (double)R[s2] * __hiloint2double((1023 + 40 - 8 * s2) << 20, 0);
+          rp[1 + s2] = U[s2];
+        }
+#pragma unroll
+        for (int s2 = 1; s2 < 6; ++s2) {
+          double w = 0.0;
+#pragma unroll
+          for (int t2 = 5; t2 >= 1; --t2)
+            if (t2 >= NG - s2) w += U[t2];
+          cp[1 + s2] = w * ninv;
+        }
+        double td = 0.0;
+        if constexpr (NG == 6) {
+          const int* sq = reinterpret_cast<const int*>(smem);
+          const long long s33 = ((long long)sq[tid] + sq[128 + tid]) + ((long long)sq[256 + tid] + sq[384 + tid]);
+          td = ((double)s33 - (double)R[3] * (double)R[3] * ninv) * __hiloint2double((1023 + 80 - 48) << 20, 0);
+        }
+        rp[7] = td;
+        cp[7] = fac ? 0.0 : (double)Lw[tid];  // (a diagonal prior joins the diagonal at the conversion; a factor prior after the prior-mean terms)
+      }
+    }
+}
+
+__device__ __attribute__((noinline)) void i8_table_pass(char* smem, double winv) {
+  using C = I8Cfg;
+  double* const P = reinterpret_cast<double*>(smem);
+  double* const gdiag = reinterpret_cast<double*>(smem + C::OFF_GD);
+  const double* const rowpk = reinterpret_cast<const double*>(smem + C::OFF_UW);
+  const double* const colpk = rowpk + 128 * 8;
+  int tid = threadIdx.x;
+  asm volatile("" : "+v"(tid));
+    // ---- what does not come out of the accumulators: per entry (i, j) the offset terms T_i + T_j of ALL digit pairs, the mean parts
+    // sum_s U_s(i) W_s(j) of the dropped ones, TD_i on the diagonal -- scaled like the products -- and the diagonal prior.  Column j of the
+    // packed triangle per thread (its record in registers; consecutive lanes = consecutive words of a row: no bank conflicts), 32 rows
+    // each, four at a time; diag(G) / s goes to `gdiag` before the prior joins.
+    {
+      typedef double d2 __attribute__((ext_vector_type(2)));
+      const int j = tid & 127, i0 = 32 * (tid >> 7);
+      const d2* const cp = reinterpret_cast<const d2*>(colpk + j * 8);
+      const d2 c01 = cp[0], c23 = cp[1], c45 = cp[2], c67 = cp[3];
+      const double scj = c01[1] * winv;
+#pragma unroll 1
+      for (int ib = i0; ib < i0 + 32; ib += 4) {
+        if (ib + 3 < j) continue;
+        d2 r01[4], r23[4], r45[4], r67[4];
+        double cur[4];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+          const d2* const rp = reinterpret_cast<const d2*>(rowpk + (ib + u) * 8);
+          r01[u] = rp[0]; r23[u] = rp[1]; r45[u] = rp[2]; r67[u] = rp[3];
+          cur[u] = (ib + u >= j) ? P[pidx(ib + u, j)] : 0.0;
+        }
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+          const int i = ib + u;
+          double tb = __builtin_fma(r45[u][1], c45[1], r67[u][0] * c67[0]);
+          const double tb2 = __builtin_fma(r23[u][1], c23[1], r45[u][0] * c45[0]);
+          tb += __builtin_fma(r23[u][0], c23[0], tb2);
+#ifdef BLR_I8_NO_MEANPROD
+          tb = 0.0;
+#endif
+          if (i == j) tb += r67[u][1];
+          tb += r01[u][0] + c01[0];
+          double e = __builtin_fma(tb, r01[u][1] * scj, cur[u]);
+          if (i == j) {
+            gdiag[i] = e;   // (the data term alone: A_ii - Lw_i would lose it under a strong prior)
+            e += c67[1];    // the diagonal prior (0 for a factor prior: U'U joins after the prior-mean terms)
+          }
+          if (i >= j) P[pidx(i, j)] = e;
+        }
+      }
+    }
+}
+
 // ---- back substitution m = L^-T u for D = 128, blocked by 16 ------------------------------------------------------------------------------
 // phase_backsolve (blr_fused_small.hpp) walks the 128 pivots one after the other on one wave: 312 cycles per pivot, 40 k cycles per
 // regressor with the matrix pipe and seven waves idle.  Here the chain is 8 block steps: the inverses W_J = L_JJ^-1 of the eight 16 x 16
@@ -648,10 +778,10 @@ __device__ __attribute__((noinline)) void i8_backsolve_blocked(char* smem, doubl
 #pragma unroll
     for (int i = 0; i < 16; ++i) {
       const double* row = P + pidx(16 * blk + i, 16 * blk);
-      double sum = (i == c) ? 1.0 : 0.0;
+      double s2[2] = {(i == c) ? 1.0 : 0.0, 0.0};
 #pragma unroll
-      for (int k = 0; k < i; ++k) sum = __builtin_fma(-row[k], w[k], sum);
-      w[i] = sum * dinv[16 * blk + i];
+      for (int k = 0; k < i; ++k) s2[k & 1] = __builtin_fma(-row[k], w[k], s2[k & 1]);
+      w[i] = (s2[0] + s2[1]) * dinv[16 * blk + i];
       Wst[(blk * 16 + i) * 16 + c] = w[i];
     }
   }
@@ -679,26 +809,27 @@ __device__ __attribute__((noinline)) void i8_backsolve_blocked(char* smem, doubl
       const double rs = hi ? b1 : b0;
       // (1) m_J = W_J' r_J: column c of W_J (zero above the diagonal: a term with i < c vanishes)
       const double* wc = Wst + J * 256 + c;
-      double acc = 0.0;
+      double a4[4] = {0.0, 0.0, 0.0, 0.0};  // (four independent chains: a dependent fp64 FMA waits ~4 issue slots for its predecessor)
 #pragma unroll
-      for (int i = 0; i < 16; ++i) acc = __builtin_fma(wc[i * 16], readlane(rs, 16 * jb + i), acc);
+      for (int i = 0; i < 16; ++i) a4[i & 3] = __builtin_fma(wc[i * 16], readlane(rs, 16 * jb + i), a4[i & 3]);
+      const double acc = (a4[0] + a4[1]) + (a4[2] + a4[3]);
       if (grp == jb) { if (hi) b1 = acc; else b0 = acc; }
       if (J == 0) break;
       // (2) the rows above: r_c -= sum_i L(16 J + i, c) m_i for c < 16 J
       const double ms = hi ? b1 : b0;
       const double* rowJ = P + pidx(16 * J, 0);
       const bool act0 = lane < 16 * J, act1 = lane + 64 < 16 * J;
-      double d0 = 0.0, d1 = 0.0;
+      double d0[2] = {0.0, 0.0}, d1[2] = {0.0, 0.0};
       int ro = 0;  // offset of row 16 J + i within the packed triangle, relative to row 16 J
 #pragma unroll
       for (int i = 0; i < 16; ++i) {
         const double mi = readlane(ms, 16 * jb + i);
-        d0 = __builtin_fma(rowJ[ro + lane], mi, d0);
-        if (hi) d1 = __builtin_fma(rowJ[ro + lane + 64], mi, d1);  // (uniform; J <= 4: nothing of b1 lies above block J)
+        d0[i & 1] = __builtin_fma(rowJ[ro + lane], mi, d0[i & 1]);
+        if (hi) d1[i & 1] = __builtin_fma(rowJ[ro + lane + 64], mi, d1[i & 1]);  // (uniform; J <= 4: nothing of b1 lies above block J)
         ro += 16 * J + i + 1;
       }
-      if (act0) b0 -= d0;
-      if (act1) b1 -= d1;
+      if (act0) b0 -= d0[0] + d0[1];
+      if (act1) b1 -= d1[0] + d1[1];
     }
     bvec[lane] = b0;
     bvec[lane + 64] = b1;
@@ -786,69 +917,7 @@ __global__ __launch_bounds__(kI8Threads, 2) void fused_i8_kernel(PosteriorArgs<d
     if constexpr (NG == 6) reinterpret_cast<int*>(smem)[(tid >> 7) * 128 + (tid & 127)] = st.sq3;
     __syncthreads();  // ring and digit buffers are dead from here on
     bred[(tid >> 7) * 128 + (tid & 127)] = st.b;
-    if (tid < 128) {
-      int R[6];
-#pragma unroll
-      for (int s = 0; s < 6; ++s) R[s] = (xch[s * 128 + tid] + xch[(6 + s) * 128 + tid]) + (xch[(12 + s) * 128 + tid] + xch[(18 + s) * 128 + tid]);
-      // Offset terms of digit group k (header comment), per row:  V_k(i) = 128 sum_s R_s(i) over the s that pair with an OFFSET
-      // digit t = k - s in 1 .. 5 (s = max(0, k - 5) .. min(5, k - 1)), for ALL groups k = 1 .. 10 -- also those whose products are
-      // dropped -- plus half of the constant c_k = 16384 N #{(s, t): s, t >= 1, s + t = k} (the other half comes in with the
-      // column index).  Exact integers, folded over k with the group scales 2^(80 - 8k), smallest first, into ONE number per row
-      // (rounded at 2^-53 of the largest term, group 1 or 2: 2^-55 of the diagonal scale.  The seven-group version kept three
-      // tables to assemble every entry to the last bit; with the digit products cut at 2^-45 that buys nothing).
-      double tsum = 0.0;
-#pragma unroll
-      for (int k = 10; k >= 1; --k) {
-        long long acc_s = 0;
-#pragma unroll
-        for (int s2 = 0; s2 < 6; ++s2)
-          if (s2 <= k - 1 && s2 >= k - 5) acc_s += R[s2];
-        const int npairs = k <= 6 ? (k > 1 ? k - 1 : 0) : 11 - k;
-        tsum += (double)(128LL * acc_s + 8192LL * (long long)N32 * npairs) * __hiloint2double((1023 + 80 - 8 * k) << 20, 0);
-      }
-      // The products that are dropped (s + t >= NG) are sums over the columns of centred digits, sum_n a_s(i, n) a_t(j, n).  With
-      // a = abar + atilde (abar_s(i) = R_s(i) / N the row's mean digit) such a sum is N abar_s(i) abar_t(j) + sum_n atilde atilde:
-      //   * the mean part is systematic whenever low digits are not uniform -- inputs that came from float32, integers, powers of
-      //     two have CONSTANT low digits (a = -128: 16384 per column and pair, 3e-13 of the diagonal scale with 6 groups) -- and costs
-      //     nothing to keep: sum over the dropped pairs of U_s(i) U_t(j) / N with U_s = R_s 2^(40 - 8 s), i.e. sum_{s=1..5} U_s(i) W_s(j),
-      //     W_s(j) = sum_{t >= NG - s} U_t(j) / N: ten numbers per row, five multiply-adds per entry (conversion);
-      //   * the fluctuating part is zero-mean noise (2^-52 of the diagonal scale with 7 groups, 3e-15 with 6) -- except the pair
-      //     (3, 3) of the 6-group plan on the diagonal, a sum of squares (5461 N: 8e-14 of G_ii).  sum_n a_3^2 is exact from one more
-      //     v_dot4 per quad (I8Slice::sq3); TD = (sum a_3^2 - R_3^2 / N) 2^32 joins G_ii.
-      // 2^(e_i - 47) from the magic constant: C = 1.5 2^(e + 5)  ->  exponent field - 52
-      const int ef = (int)(((unsigned)__double2hiint(st.C) >> 20) & 0x7ffu);
-      const double sci = __hiloint2double((ef - 52) << 20, 0);
-      sctab[tid] = sci;
-      {
-        const double ninv = 1.0 / (double)N32;
-        double U[6];
-        double* const rp = rowpk + tid * 8;
-        double* const cp = colpk + tid * 8;
-        rp[0] = tsum; cp[0] = tsum;
-        rp[1] = sci; cp[1] = sci;
-#pragma unroll
-        for (int s2 = 1; s2 < 6; ++s2) {
-          U[s2] = (double)R[s2] * __hiloint2double((1023 + 40 - 8 * s2) << 20, 0);
-          rp[1 + s2] = U[s2];
-        }
-#pragma unroll
-        for (int s2 = 1; s2 < 6; ++s2) {
-          double w = 0.0;
-#pragma unroll
-          for (int t2 = 5; t2 >= 1; --t2)
-            if (t2 >= NG - s2) w += U[t2];
-          cp[1 + s2] = w * ninv;
-        }
-        double td = 0.0;
-        if constexpr (NG == 6) {
-          const int* sq = reinterpret_cast<const int*>(smem);
-          const long long s33 = ((long long)sq[tid] + sq[128 + tid]) + ((long long)sq[256 + tid] + sq[384 + tid]);
-          td = ((double)s33 - (double)R[3] * (double)R[3] * ninv) * __hiloint2double((1023 + 80 - 48) << 20, 0);
-        }
-        rp[7] = td;
-        cp[7] = fac ? 0.0 : (double)Lw[tid];  // (a diagonal prior joins the diagonal at the conversion; a factor prior after the prior-mean terms)
-      }
-    }
+    i8_build_tables<NG>(smem, N32, st.C, fac ? 1 : 0, Lw);
     double qsum = 0.0;
     if ((tid & 127) == 0) qsum = st.q;  // the four threads of row 0 hold the four column octets' shares
     __syncthreads();
@@ -868,7 +937,9 @@ __global__ __launch_bounds__(kI8Threads, 2) void fused_i8_kernel(PosteriorArgs<d
 #pragma unroll
       for (int v = 0; v < 16; ++v) {
         const int il = 8 * (v >> 2) + 4 * (lane >> 5) + (v & 3), i = 32 * it.I + il;
-        double lo = 0.0, qs = 0.0;
+        // sum over the slots of (exact integer) x 2^(80 - 8 k): two interleaved partial sums per kind -- a dependent fp64 operation waits
+        // ~40 cycles for its predecessor, and a chain over nine slots was most of the conversion's time
+        double lo2[2] = {0.0, 0.0}, qs2[2] = {0.0, 0.0};
 #pragma unroll
         for (int k = 10; k >= 0; --k) {  // smallest scale first
 #pragma unroll
@@ -876,10 +947,11 @@ __global__ __launch_bounds__(kI8Threads, 2) void fused_i8_kernel(PosteriorArgs<d
             if (i8_slot_k<NG>(it.I, it.K, q) == k) {
               const double term = (double)A[base + q - it.q0][v];
               const double sc2 = __hiloint2double((1023 + 80 - 8 * k) << 20, 0);
-              if (i8_slot_kind<NG>(it.I, it.K, q) == 1) qs = __builtin_fma(term, sc2, qs);
-              else lo = __builtin_fma(term, sc2, lo);
+              if (i8_slot_kind<NG>(it.I, it.K, q) == 1) qs2[q & 1] = __builtin_fma(term, sc2, qs2[q & 1]);
+              else lo2[q & 1] = __builtin_fma(term, sc2, lo2[q & 1]);
             }
         }
+        const double lo = lo2[0] + lo2[1], qs = qs2[0] + qs2[1];
         const double sc = sctab[i] * scj;
         if constexpr (symt) gq[v] = qs * sc;
         if (it.I != it.K || i >= j) {  // (off-diagonal tiles lie below the diagonal as a whole)
@@ -925,49 +997,7 @@ __global__ __launch_bounds__(kI8Threads, 2) void fused_i8_kernel(PosteriorArgs<d
     if (valid) convert_all(convert_all, std::integral_constant<int, 0>{}, std::integral_constant<int, 2>{});
     I8_KSTAMP(11);
     __syncthreads();
-    // ---- what does not come out of the accumulators: per entry (i, j) the offset terms T_i + T_j of ALL digit pairs, the mean parts
-    // sum_s U_s(i) W_s(j) of the dropped ones, TD_i on the diagonal -- scaled like the products -- and the diagonal prior.  Row i of the
-    // packed triangle per thread (its record in registers), 32 columns each; diag(G) / s goes to `gdiag` before the prior joins.
-    if (valid) {
-      typedef double d2 __attribute__((ext_vector_type(2)));
-      const int i = tid & 127, j0 = 32 * (tid >> 7);
-      const d2* const rp = reinterpret_cast<const d2*>(rowpk + i * 8);
-      const d2 r01 = rp[0], r23 = rp[1], r45 = rp[2], r67 = rp[3];
-      const double sci = r01[1] * winv;
-      T* const prow = P + ((i * (i + 1)) >> 1);
-      // (four columns per step: their record reads and read-modify-writes overlap)
-#pragma unroll 1
-      for (int jb = j0; jb < j0 + 32 && jb <= i; jb += 4) {
-        d2 c01[4], c23[4], c45[4], c67[4];
-        double cur[4];
-#pragma unroll
-        for (int u = 0; u < 4; ++u) {
-          const d2* const cj = reinterpret_cast<const d2*>(colpk + (jb + u) * 8);
-          c01[u] = cj[0]; c23[u] = cj[1]; c45[u] = cj[2]; c67[u] = cj[3];
-          cur[u] = (jb + u <= i) ? prow[jb + u] : 0.0;
-        }
-#pragma unroll
-        for (int u = 0; u < 4; ++u) {
-          const int j = jb + u;
-          double tb = r67[0] * c67[u][0];
-          tb = __builtin_fma(r45[1], c45[u][1], tb);
-          tb = __builtin_fma(r45[0], c45[u][0], tb);
-          tb = __builtin_fma(r23[1], c23[u][1], tb);
-          tb = __builtin_fma(r23[0], c23[u][0], tb);
-#ifdef BLR_I8_NO_MEANPROD
-          tb = 0.0;
-#endif
-          if (i == j) tb += r67[1];
-          tb += r01[0] + c01[u][0];
-          double e = __builtin_fma(tb, sci * c01[u][1], cur[u]);
-          if (i == j) {
-            gdiag[i] = e;      // (the data term alone: A_ii - Lw_i would lose it under a strong prior)
-            e += c67[u][1];    // the diagonal prior (0 for a factor prior: U'U joins after the prior-mean terms)
-          }
-          if (j <= i) prow[j] = e;
-        }
-      }
-    }
+    if (valid) i8_table_pass(smem, winv);
   };
   switch (wave) {
     case 0: run(std::integral_constant<int, 0>{}); break;
