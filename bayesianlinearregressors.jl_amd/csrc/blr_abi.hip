@@ -417,6 +417,7 @@ int launch_fused_wave(blr_handle* h, const PosteriorArgs<T>& a) {
 // cores (blr_fused_i8.hpp), followed by the fp64 kernel in retry-only mode for the regressors the fast path handed back
 // (a row bound broken, non-finite input): every regressor leaves with the status and the numbers of an
 // fp64-accurate update, none is computed twice on the fast path.
+constexpr size_t kSmall8Lds = SmallCfg<double, 8>::LDS_BYTES;
 int launch_fused_i8(blr_handle* h, const PosteriorArgs<double>& a) {
   const bool diag = a.noise_kind == BLR_NOISE_DIAGONAL, rowv = a.layout == BLR_LAYOUT_ROWVECS;
   // (the kernel's four instantiations: blr_i8_kernels.hip)
@@ -431,11 +432,26 @@ int launch_fused_i8(blr_handle* h, const PosteriorArgs<double>& a) {
   const int grid = (int)std::min<int64_t>(a.B, diag ? std::max<int64_t>(1, ((int64_t)1 << 30) / per_reg) : (1 << 20));
   double *yt = nullptr, *rw = nullptr, *ld = nullptr, *rmx = nullptr;
   int32_t* bad = nullptr;
+  // dense prior: logdet Lw and the status of its Cholesky per prior, from i8_prior_logdet_kernel (ONE prior when the batch shares it)
+  const bool dense = a.prior_kind == BLR_PRIOR_DENSE;
+  const bool shared_prior = a.strideLw == 0 || a.B == 1;
+  double* pld = nullptr;
+  int32_t* pinfo = nullptr;
+  size_t o_prior = 0;
+  if (diag) {
+    const size_t o_rw = (((size_t)grid * a.N * sizeof(double)) + 255) & ~(size_t)255;
+    o_prior = 2 * o_rw + 2 * (((size_t)grid * sizeof(double) + 255) & ~(size_t)255) + (((size_t)grid * sizeof(int32_t) + 255) & ~(size_t)255);
+  }
+  if (dense) {
+    const size_t np = shared_prior ? 1 : (size_t)grid;
+    if ((rc = ensure_i8side(h, o_prior + ((np * sizeof(double) + 255) & ~(size_t)255) + np * sizeof(int32_t)))) return rc;
+    if ((rc = set_lds_once(h, reinterpret_cast<const void*>(i8_prior_logdet_kernel), kSmall8Lds))) return rc;
+  }
   if (diag) {
     const size_t o_rw = (((size_t)grid * a.N * sizeof(double)) + 255) & ~(size_t)255;
     const size_t o_ld = 2 * o_rw, o_mx = o_ld + (((size_t)grid * sizeof(double) + 255) & ~(size_t)255);
     const size_t o_bad = o_mx + (((size_t)grid * sizeof(double) + 255) & ~(size_t)255);
-    if ((rc = ensure_i8side(h, o_bad + (size_t)grid * sizeof(int32_t)))) return rc;
+    if (!dense && (rc = ensure_i8side(h, o_bad + (size_t)grid * sizeof(int32_t)))) return rc;
     yt = reinterpret_cast<double*>(h->i8side); rw = reinterpret_cast<double*>(h->i8side + o_rw);
     ld = reinterpret_cast<double*>(h->i8side + o_ld); rmx = reinterpret_cast<double*>(h->i8side + o_mx); bad = reinterpret_cast<int32_t*>(h->i8side + o_bad);
   }
@@ -444,6 +460,15 @@ int launch_fused_i8(blr_handle* h, const PosteriorArgs<double>& a) {
   // many regressors of the slice before it the fast path had to hand back, and when that was more than a quarter its workgroups
   // leave their regressors to the fp64 kernel at once instead of streaming them twice (heavy-tailed inputs: blr_get_stat
   // "i8_handed_back").  The decision depends on the data of the previous slice only: same inputs, same bits.
+  if (dense) {
+    const size_t np = shared_prior ? 1 : (size_t)grid;
+    pld = reinterpret_cast<double*>(h->i8side + o_prior);
+    pinfo = reinterpret_cast<int32_t*>(h->i8side + o_prior + ((np * sizeof(double) + 255) & ~(size_t)255));
+    if (shared_prior) {
+      hipLaunchKernelGGL(i8_prior_logdet_kernel, dim3(1), dim3(kThreads), kSmall8Lds, h->stream, a.Lw, a.ldl, (int64_t)0, 1, pld, pinfo);
+      HIP_TRY(h, hipGetLastError());
+    }
+  }
   int64_t b0 = 0;
   int prev_n = 0;
   while (b0 < a.B) {
@@ -467,6 +492,14 @@ int launch_fused_i8(blr_handle* h, const PosteriorArgs<double>& a) {
       s.i8_yt = yt; s.i8_rw = rw; s.i8_stride = a.N; s.i8_logdet = ld; s.i8_bad = bad; s.i8_rwmax = rmx;
       hipLaunchKernelGGL(i8_noise_prep_kernel, dim3(nb), dim3(kThreads), 0, h->stream, s.s, a.strides, s.y, a.stridey, (int)a.N, yt, rw, (int64_t)a.N, ld,
                          bad, rmx);
+    }
+    if (dense) {
+      if (!shared_prior) {
+        hipLaunchKernelGGL(i8_prior_logdet_kernel, dim3(std::min(nb, 2 * h->cus)), dim3(kThreads), kSmall8Lds, h->stream, s.Lw, a.ldl,
+                           a.strideLw, nb, pld, pinfo);
+        HIP_TRY(h, hipGetLastError());
+      }
+      s.i8_prior_logdet = pld; s.i8_prior_info = pinfo; s.i8_prior_stride = shared_prior ? 0 : 1;
     }
     if (diag) i8_kernel_launch_diag(rowv, (unsigned)nb, h->stream, s);
     else i8_kernel_launch_iso(rowv, (unsigned)nb, h->stream, s);
@@ -492,7 +525,8 @@ int dispatch_fused_small(blr_handle* h, const PosteriorArgs<T>& a) {
     const bool i8_built = (a.noise_kind == BLR_NOISE_DIAGONAL ? i8_kernel_ptr_diag(a.layout == BLR_LAYOUT_ROWVECS) : i8_kernel_ptr_iso(a.layout == BLR_LAYOUT_ROWVECS)) != nullptr;
     if (i8_built && !h->opt.no_i8_gram && !h->opt.no_ldsdma && a.D == 128 && i8_layout &&
         (a.noise_kind == BLR_NOISE_ISOTROPIC || (a.noise_kind == BLR_NOISE_DIAGONAL && !h->opt.no_i8_diag)) &&
-        (a.prior_kind == BLR_PRIOR_DIAGONAL || (a.prior_kind == BLR_PRIOR_UPPER_FACTOR && !h->opt.no_i8_factor)) && a.N - a.N % I8Cfg::KC >= kI8MinN && a.N - a.N % I8Cfg::KC <= kI8MaxN && a.ldx * 8 * I8Cfg::KC < ((int64_t)1 << 31))
+        (a.prior_kind == BLR_PRIOR_DIAGONAL || (a.prior_kind == BLR_PRIOR_UPPER_FACTOR && !h->opt.no_i8_factor) ||
+         (a.prior_kind == BLR_PRIOR_DENSE && !h->opt.no_i8_dense)) && a.N - a.N % I8Cfg::KC >= kI8MinN && a.N - a.N % I8Cfg::KC <= kI8MaxN && a.ldx * 8 * I8Cfg::KC < ((int64_t)1 << 31))
       return launch_fused_i8(h, a);
   }
   if (!h->opt.no_wave_kernel && a.layout == BLR_LAYOUT_COLVECS && a.vec_ok && a.D == 16 * NB &&

@@ -861,8 +861,6 @@ __global__ __launch_bounds__(kI8Threads, 2) void fused_i8_kernel(PosteriorArgs<d
   double* const sctab = reinterpret_cast<double*>(smem + C::OFF_SC);
   double* const bred = reinterpret_cast<double*>(smem + C::OFF_BRED);
   double* const gdiag = reinterpret_cast<double*>(smem + C::OFF_GD);
-  double* const rowpk = reinterpret_cast<double*>(smem + C::OFF_UW);  // [128][8] (left index), then colpk [128][8] (right index)
-  double* const colpk = rowpk + 128 * 8;
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = uni(tid >> 6);
   const int reg = blockIdx.x;
@@ -880,6 +878,10 @@ __global__ __launch_bounds__(kI8Threads, 2) void fused_i8_kernel(PosteriorArgs<d
   const T s_iso = DIAG ? T(1) : as_global(a.s + (int64_t)reg * a.strides)[0];
   const double rwmax = DIAG ? a.i8_rwmax[reg] : 1.0;
   const bool fac = a.prior_kind == PRIOR_UPPER_FACTOR;  // Lw is the upper factor U of the prior precision (PDMat / a carried-forward posterior): U'U joins at the hand-over
+  // Lw is a dense symmetric precision (upper triangle read; the reference's own toy priors, test/test_utils.jl:6-8): it joins the finished
+  // matrix at the hand-over like a factor does; its Cholesky -- only logdet Lw and the positive-definiteness check of reference :78 come
+  // from it -- has been done by i8_prior_logdet_kernel before this launch (once for a prior shared by the batch)
+  const bool dns = a.prior_kind == PRIOR_DENSE;
   if (blockIdx.x == 0 && tid == 0 && a.i8_handed_slice != nullptr) *a.i8_handed_slice = 0ull;  // (this slice's retry launch counts into it)
   if (DIAG && a.i8_bad[reg] != 0) {  // (uniform)  reference :79: the fp64 kernel reports the index
     if (tid == 0) a.info[reg] = kI8Retry;
@@ -917,7 +919,7 @@ __global__ __launch_bounds__(kI8Threads, 2) void fused_i8_kernel(PosteriorArgs<d
     if constexpr (NG == 6) reinterpret_cast<int*>(smem)[(tid >> 7) * 128 + (tid & 127)] = st.sq3;
     __syncthreads();  // ring and digit buffers are dead from here on
     bred[(tid >> 7) * 128 + (tid & 127)] = st.b;
-    i8_build_tables<NG>(smem, N32, st.C, fac ? 1 : 0, Lw);
+    i8_build_tables<NG>(smem, N32, st.C, (fac || dns) ? 1 : 0, Lw);
     double qsum = 0.0;
     if ((tid & 127) == 0) qsum = st.q;  // the four threads of row 0 hold the four column octets' shares
     __syncthreads();
@@ -1202,7 +1204,32 @@ __global__ __launch_bounds__(kI8Threads, 2) void fused_i8_kernel(PosteriorArgs<d
   // prior: SPD check + logdet (reference :78; a factor: its diagonal, logdet = 2 sum log U_kk), noise variance (reference :79)
   int info = 0;
   double logdet_Lw = 0.0;
-  {
+  if (dns) {  // (uniform)
+    info = a.i8_prior_info[(int64_t)reg * a.i8_prior_stride];
+    logdet_Lw = a.i8_prior_logdet[(int64_t)reg * a.i8_prior_stride];
+    if (info == 0) {
+      // A += Lw, after the prior-mean terms have been taken from the pure data matrix: rows over the four waves, a row's entries
+      // j <= i over the lanes (element (j, i) of the caller's upper triangle: consecutive lanes, consecutive words), four rows in flight
+      const int w4 = tid >> 6, l = tid & 63;
+#pragma unroll 1
+      for (int i0 = 4 * w4; i0 < D; i0 += 16) {
+        double v0[4], v1[4];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+          const int i = i0 + u;
+          v0[u] = (l <= i) ? (double)Lw[(int64_t)i * a.ldl + l] : 0.0;
+          v1[u] = (l + 64 <= i) ? (double)Lw[(int64_t)i * a.ldl + l + 64] : 0.0;
+        }
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+          const int i = i0 + u;
+          if (l <= i) P[pidx(i, l)] += v0[u];
+          if (l + 64 <= i) P[pidx(i, l + 64)] += v1[u];
+        }
+      }
+      __syncthreads();
+    }
+  } else {
     double v = 0.0;
     int bad = 0x7fffffff;
     if (tid < D) {
@@ -1317,6 +1344,30 @@ __global__ __launch_bounds__(kI8Threads, 2) void fused_i8_kernel(PosteriorArgs<d
   }
   I8_KSTAMP(7);
   I8_CLKSTAMP;
+}
+
+// ---- dense prior: what the int8 route needs from Lw, once per call ------------------------------------------------------------------
+// One 256-thread workgroup per prior (one prior in all when the batch shares it): the blocked Cholesky of fused_small_kernel's prior
+// phase on the packed triangle -> logdet Lw (fixed order) and the LAPACK-style index of a failing leading minor (reference :78).
+static __global__ __launch_bounds__(kThreads, 2) void i8_prior_logdet_kernel(const double* __restrict__ Lw, int64_t ldl, int64_t strideLw, int nprior,
+                                                                          double* __restrict__ logdet, int32_t* __restrict__ info_out) {
+  using SC = SmallCfg<double, 8>;
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  double* const P = reinterpret_cast<double*>(smem);
+  double* const scr = reinterpret_cast<double*>(smem + SC::OFF_SCR);
+  const int tid = threadIdx.x;
+  constexpr int D = 128;
+  for (int p = blockIdx.x; p < nprior; p += gridDim.x) {
+    const double* A = Lw + (int64_t)p * strideLw;
+    __syncthreads();
+    for (int i = tid >> 6; i < D; i += kWaves)
+      for (int k = tid & 63; k <= i; k += kWave) P[pidx(i, k)] = A[(int64_t)i * ldl + k];  // upper entry (k, i) -> lower (i, k)
+    __syncthreads();
+    const int info = phase_chol<double, 8>(smem, D, 0);
+    const double v = (info == 0 && tid < D) ? log(P[pidx(tid, tid)]) : 0.0;
+    const double ld = 2.0 * block_allreduce(v, scr, tid);
+    if (tid == 0) { logdet[p] = ld; info_out[p] = info; }
+  }
 }
 
 // ---- diagonal noise: what the int8 route needs from s, once per call --------------------------------------------------------------

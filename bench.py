@@ -142,10 +142,10 @@ class Workload:
     """One BASELINE shape resident on the device + the call that runs one step of it."""
 
     def __init__(self, torch, _abi, h, dev, name, B, D, N, dtype, noise, seed, Din=None, mw_random=False, logpdf_only=False, block=None, rowvecs=False,
-                 factor_prior=False):
+                 factor_prior=False, dense_prior=False):
         self.name, self.B, self.D, self.N, self.dtype, self.noise, self.Din = name, B, D, N, dtype, noise, Din
         self.logpdf_only = logpdf_only
-        self.rowvecs, self.factor_prior = rowvecs, factor_prior
+        self.rowvecs, self.factor_prior, self.dense_prior = rowvecs, factor_prior, dense_prior
         self.mw_random = mw_random
         self.torch, self._abi, self.h = torch, _abi, h
         t_dt = torch.float64 if dtype == "f64" else torch.float32
@@ -200,6 +200,10 @@ class Workload:
         if factor_prior:  # a prior given by its upper factor U (Lw = U'U, a PDMat / a carried-forward posterior), shared by the batch;
             # [D, D] row-major lower triangle == column-major upper U
             self.Uprior = torch.tril(torch.randn((D, D), generator=g, dtype=t_dt, device=dev) / float(np.sqrt(D)), -1) + 1.5 * torch.eye(D, dtype=t_dt, device=dev)
+        if dense_prior:  # one dense symmetric precision PER regressor, Lw = B B' / D + I (the reference's toy priors, test/test_utils.jl:6-8)
+            Bm = torch.randn((B, D, D), generator=g, dtype=t_dt, device=dev) / float(np.sqrt(D))
+            self.Lprior = torch.bmm(Bm, Bm.transpose(1, 2)) + torch.eye(D, dtype=t_dt, device=dev)
+            del Bm
         self.mw_post = torch.empty((B, D), dtype=t_dt, device=dev)
         self.T_post = torch.empty((B, D, D), dtype=t_dt, device=dev)
         self.lp = torch.empty((B,), dtype=torch.float64, device=dev)
@@ -211,10 +215,13 @@ class Workload:
         a, B, D, N = self._abi, self.B, self.D, self.N
         if self.Din is None:
             pk, pr, ldl = (a.PRIOR_UPPER_FACTOR, self.Uprior, D) if self.factor_prior else (a.PRIOR_DIAGONAL, self.dprior, 1)
+            sLw = 0
+            if self.dense_prior:
+                pk, pr, ldl, sLw = a.PRIOR_DENSE, self.Lprior, D, D * D
             self.h.posterior_batched(self.np_dt, a.MEM_DEVICE, a.LAYOUT_ROWVECS if self.rowvecs else a.LAYOUT_COLVECS, B, D, N, self.X.data_ptr(),
                                      N if self.rowvecs else D, N * D, self.y.data_ptr(), N,
                                      self.noise_kind, self.s.data_ptr(), N if self.diag else 0, pk, self.mw.data_ptr(), D,
-                                     pr.data_ptr(), ldl, 0, None if self.logpdf_only else self.mw_post.data_ptr(), D,
+                                     pr.data_ptr(), ldl, sLw, None if self.logpdf_only else self.mw_post.data_ptr(), D,
                                      None if self.logpdf_only else self.T_post.data_ptr(), D, D * D, None, D,
                                      D * D, self.lp.data_ptr(), self.info.data_ptr())
         else:
@@ -229,7 +236,7 @@ class Workload:
 
     def roofline(self, ms):
         fl = algorithmic_flops(self.D, self.N, self.Din) * self.B
-        by = algorithmic_bytes(self.D, self.N, self.w_bytes, self.diag, self.Din) * self.B
+        by = algorithmic_bytes(self.D, self.N, self.w_bytes, self.diag, self.Din, dense_prior=self.dense_prior) * self.B
         if self.logpdf_only:  # no mw', no T written
             by -= self.w_bytes * (self.D + self.D * self.D) * self.B
         kern = self.kernel_name()
@@ -505,10 +512,11 @@ def secondary_ops(torch, _abi, h, dev):
                 assert int(w2.info.abs().sum().item()) == 0 and bool(torch.isfinite(w2.lp).all().item())
 
             r = {"algorithmic_flops": algorithmic_flops(w2.D, w2.N, w2.Din) * w2.B,
-                 "algorithmic_bytes": (algorithmic_bytes(w2.D, w2.N, w2.w_bytes, w2.diag, w2.Din)
+                 "algorithmic_bytes": (algorithmic_bytes(w2.D, w2.N, w2.w_bytes, w2.diag, w2.Din, dense_prior=w2.dense_prior)
                                        - (w2.w_bytes * (w2.D + w2.D * w2.D) if w2.logpdf_only else 0)) * w2.B}
             tag = (", prior mean ~ N(0, I)" if kw.get("mw_random") else "") + (", logpdf only (no mw', no T)" if kw.get("logpdf_only") else "") \
                 + (", RowVecs storage" if kw.get("rowvecs") else "") + (", prior by its upper factor" if kw.get("factor_prior") else "") \
+                + (", dense prior precision per regressor" if kw.get("dense_prior") else "") \
                 + (f", handle option {option}" if option else "")
             return Op(f"B={b}, D={d}, N={n}, {dt}, {noise} noise" + (f", D_in={din} random-Fourier features" if din else "") + tag,
                       launch, b, "updates/s", r["algorithmic_flops"], r["algorithmic_bytes"], dt, kern, check, steps=steps, keep=(w2,))
@@ -522,6 +530,7 @@ def secondary_ops(torch, _abi, h, dev):
         "c2_f64_diag_noise": post("c2_f64_diag", 4096, 128, 4096, "f64", "diagonal"),
         "c2_f64_factor_prior": post("c2_f64_factor", 4096, 128, 4096, "f64", "isotropic", factor_prior=True),
         "c2_f64_rowvecs": post("c2_f64_rowvecs", 4096, 128, 4096, "f64", "isotropic", rowvecs=True),
+        "c2_f64_dense_prior": post("c2_f64_dense", 4096, 128, 4096, "f64", "isotropic", dense_prior=True),
         "c4_f64": post("c4_f64", 8192, 64, 1024, "f64", "isotropic"),
         "c4_f32": post("c4_f32", 8192, 64, 1024, "f32", "isotropic"),
         # the per-GPU blocks of config 4 (8192 regressors) on 2 / 4 / 8 GPUs: the expected strong-scaling curve
@@ -731,23 +740,48 @@ def main():
     # (BLR_BENCH_FORCE_COMM=1: run that code path with a one-rank communicator on a one-GPU box)
     use_lib_comm = (dist is not None and backend == "nccl" and args.comm == "rccl") or (
         world == 1 and os.environ.get("BLR_BENCH_FORCE_COMM") == "1")
+    # The exchange runs OFF the critical path: a second handle carries the communicator on a side stream, step k's all-gather + sum
+    # overlap step k + 1's launch (two alternating evidence buffers; events order the two streams).  Per step the job still produces
+    # the total log evidence of that step's batch -- one step later.  (the exchange is latency-bound, 8 KB per rank; on
+    # the launch stream it cost 30-50 us of a 150 us step at 8 GPUs.)
+    hc, side = None, None
     if use_lib_comm:
         box = [_abi.Handle.comm_unique_id() if rank == 0 else None]
         if dist is not None:
             dist.broadcast_object_list(box, src=0)
-        h.comm_init(world, rank, box[0])
+        hc = _abi.Handle(local_rank)
+        side = torch.cuda.Stream(dev)
+        hc.set_stream(side.cuda_stream)
+        hc.set_async(True)
+        hc.comm_init(world, rank, box[0])
+        lp_bufs = [lp_loc, torch.zeros_like(lp_loc)]
+        lp_alls = [lp_all, torch.empty_like(lp_all)]
+        lp_sums = [lp_sum, torch.zeros_like(lp_sum)]
+        ev_done = [torch.cuda.Event(), torch.cuda.Event()]
+        ev_free = [torch.cuda.Event(), torch.cuda.Event()]
+        for e in ev_free:
+            e.record(side)
+    nstep = [0]
 
     def step(ev=None):
         if ev is not None:
             ev[0].record(stream)
+        if use_lib_comm:
+            k = nstep[0] & 1
+            nstep[0] += 1
+            stream.wait_event(ev_free[k])      # the exchange two steps back has read this buffer
+            wl.lp = lp_bufs[k][:B]
         wl.launch()
         if ev is not None:
             ev[1].record(stream)
         # the path's only exchange: all-gather of the per-regressor log evidences (8 B each), then the SAME
         # fixed-order device sum on every rank -> identical bits for every rank count that divides the batch (SURVEY.md 8e;
         # uneven blocks are zero-padded, which regroups the sum: equal to rounding only)
-        if use_lib_comm:  # ncclAllGather on the handle's stream + the fixed-order sum, one library call
-            h.logpdf_allgather_sum(Bmax, lp_loc.data_ptr(), lp_all.data_ptr(), lp_sum.data_ptr())
+        if use_lib_comm:  # ncclAllGather on the side stream + the fixed-order sum, one library call
+            ev_done[k].record(stream)
+            side.wait_event(ev_done[k])
+            hc.logpdf_allgather_sum(Bmax, lp_bufs[k].data_ptr(), lp_alls[k].data_ptr(), lp_sums[k].data_ptr())
+            ev_free[k].record(side)
         elif dist is not None:
             if backend == "nccl":
                 dist.all_gather_into_tensor(lp_all, lp_loc)
@@ -796,6 +830,8 @@ def main():
 
     # sanity: the timed work produced valid results
     assert int(wl.info.abs().sum().item()) == 0, "a regressor failed to factorise"
+    if use_lib_comm:
+        lp_sum = lp_sums[(nstep[0] - 1) & 1]  # the last step's exchange
     total_evidence = float(lp_sum.item())
     assert np.isfinite(total_evidence)
 
@@ -834,7 +870,7 @@ def main():
                 "D": D, "N": N, "batch_per_gpu": B, "global_batch": global_batch,
                 "sharding": f"regressors x{world} ({'fixed batch, contiguous blocks' if strong else 'fixed block per GPU'}), no data-path "
                             f"collective; one all-gather of {Bmax * world} doubles via "
-                            f"{'library RCCL (blr_logpdf_allgather_sum)' if use_lib_comm else ('torch.distributed ' + backend) if dist is not None else 'nothing (one rank)'}",
+                            f"{'library RCCL (blr_logpdf_allgather_sum) on a side stream, overlapping the next step' if use_lib_comm else ('torch.distributed ' + backend) if dist is not None else 'nothing (one rank)'}",
             },
             "roofline": roof,
             "total_log_evidence": total_evidence,
@@ -858,14 +894,23 @@ def main():
             out["secondary_file"] = "gpurun_out/bench_secondary_latest.json"
         except OSError:
             out["secondary_file"] = None
-    if rank == 0:
-        print(headline_line(out), flush=True)  # the LAST line of stdout
     if use_lib_comm:
-        h.comm_destroy()
+        hc.comm_destroy()
+        hc.close()
     if dist is not None:
         dist.barrier()
         dist.destroy_process_group()
     h.close()
+    if rank == 0:
+        # RCCL prints its version banner through C stdio, which is flushed at exit -- AFTER anything Python has printed: drain it
+        # first, so that the headline really is the LAST line of stdout
+        try:
+            import ctypes
+
+            ctypes.CDLL(None).fflush(None)
+        except Exception:
+            pass
+        print(headline_line(out), flush=True)
 
 
 if __name__ == "__main__":

@@ -2578,6 +2578,66 @@ def test_i8_gram_path_factor_prior(B, opt, N, prior_mean):
     assert fb[4].tolist() == [0, 41, 0, 0] and np.all(fb[0][1] == 7.0)
 
 
+@pytest.mark.parametrize("N,noise", [(512, "iso"), (1055, "diag"), (4096, "iso")])
+@pytest.mark.parametrize("shared", [False, True])
+@pytest.mark.parametrize("prior_mean", [False, True])
+def test_i8_gram_path_dense_prior(B, opt, N, noise, shared, prior_mean):
+    # A dense prior precision -- what the reference's own toy problems use (test/test_utils.jl:6-8: Lw = B B' + I; `_cholesky(blr.Lw)` at
+    # src/bayesian_linear_regression.jl:78) -- on the int8 route: logdet Lw and the positive-definiteness check come from one blocked
+    # Cholesky per prior before the launch (ONE for a prior the batch shares: strideLw = 0), Lw itself joins the finished matrix at the
+    # hand-over after the prior-mean terms.  Only the UPPER triangle of the caller's matrix is read (the lower one holds NaN here).
+    # Against the oracle and the fp64 kernel (NO_I8_DENSE); a prior that is not positive definite reports ITS leading minor.
+    a = B._abi
+    h = a.default_handle()
+    rng = _rng(5000 + N + 2 * int(shared) + int(prior_mean))
+    nb, D = 4, 128
+    X, y = _i8_case(rng, nb, N, "gauss")
+    mw = rng.standard_normal((nb, D)) if prior_mean else np.zeros((nb, D))
+    npri = 1 if shared else nb
+    Lw = np.empty((npri, D, D)); Lin = np.empty((npri, D, D))
+    for b in range(npri):
+        Bm = rng.standard_normal((D, D)) / np.sqrt(D)
+        Lw[b] = Bm @ Bm.T + np.exp(rng.standard_normal()) * np.eye(D)
+        Lin[b] = np.triu(Lw[b]).T + np.tril(np.full((D, D), np.nan), -1).T  # column-major: upper triangle valid, lower one NaN
+    svar = np.exp(0.5 * rng.standard_normal((nb, N))) * 0.1 if noise == "diag" else np.array([0.1])
+    nk, sstr = (a.NOISE_DIAGONAL, N) if noise == "diag" else (a.NOISE_ISOTROPIC, 0)
+
+    def run(L_in):
+        mp = np.full((nb, D), 7.0); Tp = np.zeros((nb, D, D)); Ap = np.zeros((nb, D, D)); lp = np.zeros(nb); info = np.full(nb, 9, dtype=np.int32)
+        h.posterior_batched(np.float64, a.MEM_HOST, a.LAYOUT_COLVECS, nb, D, N, X, D, N * D, y, N, nk, svar, sstr, a.PRIOR_DENSE,
+                            mw, D, L_in, D, 0 if shared else D * D, mp, D, Tp, D, D * D, Ap, D, D * D, lp, info)
+        return mp, Tp, Ap, lp, info
+
+    fast = run(Lin)
+    assert h.last_route() == "fused_i8_kernel"
+    again = run(Lin)
+    for u, v in zip(fast, again):
+        np.testing.assert_array_equal(u, v)
+    opt("NO_I8_DENSE", "1")
+    slow = run(Lin)
+    assert h.last_route().startswith("fused_small_kernel<double, 8,")
+    opt("NO_I8_DENSE", None)
+    assert fast[4].tolist() == [0] * nb and slow[4].tolist() == [0] * nb
+    for b in range(nb):
+        sb = svar[b] if noise == "diag" else 0.1
+        mw_o, T_o, A_o, lp_o = O.posterior_logpdf_direct(mw[b], Lw[0 if shared else b], X[b].T, sb, y[b])
+        dA = np.sqrt(np.diag(A_o))
+        for mp, Tp, Ap, lp, _ in (fast, slow):
+            assert lp[b] == pytest.approx(lp_o, rel=1e-10)
+            np.testing.assert_allclose(mp[b] * dA, mw_o * dA, rtol=1e-8, atol=1e-9 * np.abs(mw_o * dA).max())
+            assert (np.abs(Ap[b] - A_o) / np.outer(dA, dA)).max() <= 1e-12
+            Tn = np.triu(Tp[b].T)
+            assert (np.abs(Tn.T @ Tn - A_o) / np.outer(dA, dA)).max() <= 1e-10
+        assert fast[3][b] == pytest.approx(slow[3][b], rel=1e-10)
+    Lbad = Lin.copy()
+    Lbad[npri - 1, 40, 40] = -50.0  # the leading 41 x 41 minor is the first that is not positive definite
+    fb = run(Lbad)
+    sbad = run(Lbad) if False else None
+    expect = [41] * nb if shared else [0] * (nb - 1) + [41]
+    assert fb[4].tolist() == expect
+    assert np.all(fb[0][nb - 1] == 7.0) and np.isnan(fb[3][nb - 1])
+
+
 @pytest.mark.parametrize("kind", ["gauss", "scales", "outlier"])
 @pytest.mark.parametrize("N,noise,prior", [(512, "iso", "diag"), (543, "diag", "diag"), (4127, "iso", "factor"), (1055, "diag", "factor")])
 def test_i8_gram_path_rowvecs(B, opt, kind, N, noise, prior):
