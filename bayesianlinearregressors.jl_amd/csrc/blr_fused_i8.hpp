@@ -1,52 +1,65 @@
-// Fused per-regressor inference kernel for the headline shape (D = 128, fp64, aligned ColVecs, isotropic noise, diagonal
-// prior) with the Gram matrix on the INT8 matrix cores: an Ozaki-style exact splitting of the fp64 inputs.
+// Fused per-regressor inference kernel for the headline shape (D = 128, fp64, 512 <= N <= 16384 + a partial block) with the Gram matrix
+// on the INT8 matrix cores: an Ozaki-style exact splitting of the fp64 inputs.
 //
-// Why: the f64 matrix pipe (v_mfma_f64_16x16x4, 78.6 TF spec) bounds fused_small_kernel at ~0.75 M updates/s at the clock
-// the part holds under that load (profiles/r04_microbench_ring_probe_sustained.txt); the same Gram costs a third of the
-// matrix-pipe time on v_mfma_i32_32x32x32_i8 and is then bound by the HBM stream of X (4.2 MB per update).
+// Why: the f64 matrix pipe (v_mfma_f64_16x16x4, 78.6 TF spec) bounds fused_small_kernel at ~0.75 M updates/s at the clock the part
+// holds under that load (profiles/r04_microbench_ring_probe_sustained.txt); the same Gram costs a fifth of the matrix-pipe time on
+// v_mfma_i32_32x32x32_i8 and the update is then bound by the HBM stream of X (4.2 MB per update) and by the slicing.
 //
 // Arithmetic (reference src/bayesian_linear_regression.jl:86, G = X X'):
-//   per row i of X a power of two 2^e_i bounds every |x_in| (e_i = exponent of the row's largest entry in the first 96
-//   columns + kI8Margin; a later entry that breaks the bound sends the WHOLE regressor back to the fp64 kernel -- status
-//   kI8Retry, consumed by a follow-up launch of fused_small_kernel -- so the fast path never returns a wrong number);
-//   Q_in = round-to-nearest-even(x_in 2^(47 - e_i)) is a 48-bit signed integer, obtained with ONE v_add_f64 (the classic
-//   magic-constant trick: the integer sits in the low mantissa bits of x + 1.5 2^(e_i + 5));
-//   its six two's-complement bytes are the digits: Q = sum_s d_s 2^(8 (5 - s)), d_0 signed, d_1..d_5 unsigned; the unsigned
-//   ones are stored as a_s = d_s - 128 (one XOR) so that every operand of the signed int8 MFMA fits;
-//   sum_n Q_in Q_jn = sum_{s,t} 2^(8 (10 - s - t)) sum_n (a_is + o_s)(a_jt + o_t),  o_0 = 0, o_s = 128:
-//       the products sum_n a_is a_jt come out of the matrix cores EXACTLY (int32, |.| < 2^29 for N <= 16384), grouped by
-//       k = s + t, one accumulator per group, for the 26 digit pairs with k <= 6;
-//       the offset terms are rank-one -- 128 (sum_s R_s(i) + sum_t R_t(j)) over the partners of group k, + 16384 N per pair of
-//       offset digits, with the digit row sums R_s(i) = sum_n a_is from one v_dot4 per packed dword -- and are kept for ALL
-//       36 pairs (the unsigned digits have mean 127.5: the dropped pairs' offset parts are systematic, their centred
-//       products are zero-mean);
-//   G_ij = 2^(e_i + e_j - 94) sum_k 2^(80 - 8k) [P_k(i,j) + V_k(i) + V_k(j)], evaluated once per regressor in fp64.
-// Error: rounding |x_in - 2^(e_i - 47) Q_in| <= 2^(e_i - 48), unbiased (6e-15 of the diagonal scale on N(0,1) inputs);
-// dropped: centred products of the groups k >= 7, 2^-52 of the diagonal scale.  (With k <= 5 only -- 21 pairs, the first
-// version -- the dropped group 6 is 2^-43: 1.5e-13 of the diagonal scale, which costs the evidence three digits whenever
-// the data are well explained, y'Sy and |u|^2 cancelling; measured, tools/i8_gram.hip.)
+//   * per row i of X a power of two 2^e_i, its CAPACITY: e_i = exponent of the row's largest entry in the first 96 columns + 2 (isotropic
+//     noise; + 3 on x times the regressor's largest 1 / sqrt(s_n) under diagonal noise).  Q_in = round-to-nearest-even(x_in 2^(47 - e_i))
+//     is a 48-bit signed integer using the WHOLE two's-complement range, obtained with ONE v_add_f64 (the magic-constant trick: the
+//     integer sits in the low mantissa bits of x + 1.5 2^(e_i + 5));
+//   * its six two's-complement bytes are the digits: Q = sum_s d_s 2^(8 (5 - s)), d_0 signed, d_1..d_5 unsigned, stored as
+//     a_s = d_s - 128 (one XOR) so that every operand of the signed int8 MFMA fits;
+//     sum_n Q_in Q_jn = sum_{s,t} 2^(8 (10 - s - t)) sum_n (a_is + o_s)(a_jt + o_t),  o_0 = 0, o_s = 128:
+//       - the products sum_n a_is a_jt come out of the matrix cores EXACTLY (int32, |.| < 2^31 for N <= 16384), one accumulator per
+//         digit group k = s + t, for the pairs with k < NG: NG = 6 (21 pairs) under isotropic noise, 7 (26 pairs) under diagonal noise;
+//       - on the DIAGONAL tiles of the 6-group plan P(t, s) = P(s, t)': the pairs s < t once, mirrored at the hand-over, the pairs
+//         s = t in accumulators of their own: 12 MFMAs instead of 21 (174 per 32-column k-step for the 10 tiles instead of 260);
+//       - the offset terms are rank-one -- 128 (sum_s R_s(i) + sum_t R_t(j)) over the partners of group k, + 16384 N per pair of
+//         offset digits, with the digit row sums R_s(i) = sum_n a_is from one v_dot4 per packed dword -- and are kept for ALL 36 pairs;
+//       - of the DROPPED pairs (k >= NG) the mean part N abar_s(i) abar_t(j) = R_s(i) R_t(j) / N is kept too (five multiply-adds per
+//         entry): inputs that came from float32, integers or powers of two have constant low digits, and their dropped products are
+//         systematic, not noise (3e-13 of the diagonal scale with 6 groups); on the diagonal the pair (3, 3) is a sum of squares and comes
+//         exactly from one more v_dot4; what is left of the dropped pairs is zero-mean: 3e-15 of the diagonal scale at N = 4096 (1 sigma);
+//   * G_ij = 2^(e_i + e_j - 94) [sum_k 2^(80 - 8k) P_k(i,j) + offsets + mean parts], evaluated once per regressor in fp64.
+//   * an entry beyond its row's capacity WRAPS in the 48-bit integer: the stream has then added c c' for that column, c = x - m 2^(e_i + 1).
+//     The 32-column block is marked (one compare per k-step), read again at the hand-over and x x' - c c' is added in fp64, entry by
+//     entry, in a fixed order (i8 repair).  N(0,1) rows: 0.3 marked blocks per regressor at N = 4096.  More than one marked block in 16
+//     (heavy tails, a feature that wakes up late), Inf / NaN: the regressor goes to the fp64 kernel -- status kI8Retry, consumed by a
+//     follow-up launch of fused_small_kernel -- so the fast path never returns a wrong number; blr_get_stat counts these.
+// Error (measured against the fp64 kernel, tools/i8_gram.hip): A within 3e-14 of its diagonal scale (max over 32 x 128 x 128 entries), the
+// evidence within 1e-15 .. 1e-14 on generic data and 1.5e-11 where delta'delta / s and |u|^2 cancel a thousandfold (seven groups: 8e-15
+// of the diagonal scale; they cost 260 MFMAs per k-step, and 0.78 against 0.91 M updates/s).
 //
-// Structure: ONE 512-thread workgroup per regressor and CU (8 waves, two per SIMD, <= 256 registers each): the 10 lower 32 x 32
-// tiles x 7 digit groups are 70 accumulators of 16 registers, at most 9 per wave.
-//   * X streams HBM -> LDS by LDS-DMA, one 1 KiB piece per column, through a ring of three 32-column slots (two in flight);
+// Structure: ONE 512-thread workgroup per regressor and CU (8 waves, two per SIMD, <= 256 registers each): the 68 accumulators of 16
+// registers of the 6-group plan (36 + 4 x 8), at most 9 per wave.
+//   * X streams HBM -> LDS by LDS-DMA, one 1 KiB piece per column, through a ring of three 32-column slots (two in flight); the pieces are
+//     issued unconditionally (three k-steps beyond the end they load the last block again): a branch per piece split the k-step's schedule;
 //   * every thread owns one row and 8 columns of a 32-column k-step: magic add, byte transposition with v_perm_b32, digit
 //     planes to LDS in MFMA fragment order (double-buffered), b += x y in fp64 on the way;
-//   * (tile, group range) items are dealt to the 8 waves so that the two waves of a SIMD (w, w + 4) carry 64 - 67 MFMAs per k-step
-//     between them (table in I8Items);
-//   * inside a k-step the order is pinned by hand: MFMA, then (in its 32-cycle shadow) the fragment reads two MFMAs ahead
-//     and one of 14 chunks of the slicing; ONE workgroup barrier per k-step;
-//   * after the stream: accumulators -> fp64 -> packed triangle of A in LDS; waves 4-7 exit; waves 0-3 run the phases of
-//     fused_small_kernel (blocked Cholesky, substitutions, evidence) unchanged;
+//   * (tile, slot range) items are dealt to the 8 waves so that the two waves of a SIMD (w, w + 4) carry 42 - 44 MFMAs per k-step
+//     between them (tables I8Items, from tools/i8_plan_search.py);
+//   * inside a k-step the order is pinned by hand: MFMA, then the fragment reads two MFMAs ahead and one of 14 chunks of the slicing;
+//     ONE workgroup barrier per k-step.  With 174 MFMAs the k-step is bound by the slicing path (2.9 k cycles with or without the
+//     MFMAs; 2.4 k without the slicing), no longer by the matrix pipe or by power (in-kernel clock 2.0 GHz on N(0,1) data, 2.4 on zeros);
+//   * hand-over: accumulators -> fp64 -> packed triangle of A in LDS by products only, in three phases that are a 3-colouring of the
+//     (tile, wave) incidence; offsets, mean parts, prior in a pass of their own (shared noinline code: the hand-over's straight-line code
+//     overflows the instruction cache once per regressor); repair of marked blocks; waves 4-7 exit; waves 0-3 run the blocked Cholesky
+//     of fused_small_kernel (phase_chol) and a back substitution blocked by 16 (i8_backsolve_blocked);
 //   * N need not be a multiple of 32: whole k-steps go through the stream, the last N % 32 columns are added to the finished matrix,
 //     to b and to y'y in fp64 at the hand-over (a rank-r term, r < 32: ~1 % of an update);
 //   * a prior mean mw != 0 (reference :57, :82: delta = y - X'mw) never touches the stream: G is exact, so
 //     b = X delta / s = X y / s - (G / s) mw and delta'delta / s = y'y / s - 2 mw'X y / s + mw'(G / s) mw are formed from the
-//     finished matrix (one 128 x 128 symmetric matrix-vector product in LDS; diag(G) / s is kept next to A = Lw + G / s).
-// (Measured alternatives, tools/i8_gram.hip: four waves with the whole register file each -- no register pressure, but one wave
-// per SIMD cannot keep the matrix pipe fed next to the slicing and the DMA issue: 4000 cycles per k-step against 3000; the
-// factorisations as a second launch with two workgroups per CU: 4.9 ms per 4096 updates against 4.7, the stream-only kernel
-// runs at the same power-limited clock (second attempt, per-kernel timings: stream 4.33 ms + finish 0.74 ms against 5.22 ms fused); staggered starts of the workgroups, static priority for waves 4-7, cache-warming touches three
-// k-steps ahead: no gain or a loss.  On zero operands the kernel runs 4.04 ms per 4096 updates against 5.28 on N(0,1) inputs: power-bound.)
+//     finished matrix (one 128 x 128 symmetric matrix-vector product in LDS; diag(G) / s is kept next to A = Lw + G / s); when these
+//     differences cancel more than three digits (a prior mean that already explains the data) the fp64 kernel redoes the regressor;
+//   * priors: diagonal (joins in the table pass), upper factor U (U'U added in fp64 after the prior-mean terms), dense (Lw added there
+//     too; logdet Lw and the check of reference :78 from i8_prior_logdet_kernel, one blocked Cholesky per prior before the launch).
+// (Measured alternatives, tools/i8_gram.hip: four waves with the whole register file each -- one wave per SIMD cannot keep the matrix
+// pipe fed next to the slicing and the DMA issue: 4000 cycles per k-step against 3000; the factorisations as a second launch with two
+// workgroups per CU: no gain; staggered starts, static priority for waves 4-7 (BLR_I8_SETPRIO), cache-warming touches, fragment reads
+// three or four MFMAs ahead (BLR_I8_LEAD): no gain or a loss.)
 #pragma once
 #include "blr_fused_small.hpp"
 
@@ -334,7 +347,15 @@ struct I8SliceSteps {
       }
     } else {  // C == 13: digit planes out.  Fragment (s, I = r >> 5): lane (half = cq >> 1, row r & 31) at byte 16 (32 half + (r & 31));
               // this thread's 8 columns are bytes 8 (cq & 1) .. + 8 of the lane's 16
+#ifdef BLR_I8_DIG_PLANES  /* measured, not shipped: the fragment as TWO planes of 8 bytes per lane, 512 bytes apart -- a wave's 32 rows write
+                             consecutive words, where the 16-byte slots of a single plane put lanes l and l + 16 on the same banks (2-way
+                             conflicts: the kernel's 1.0e8 SQ_LDS_BANK_CONFLICT cycles per launch, 190 LDS cycles of a 2900-cycle k-step).
+                             Conflict-free on both sides with one ds_read2_b64 per fragment -- and 1 % SLOWER (4.62 against 4.56 ms per
+                             4096 updates, same box, twice): the LDS pipe is not what the k-step waits for. */
+      char* dst = dig + (r >> 5) * 1024 + (cq & 1) * 512 + (((cq >> 1) * 32 + (r & 31)) * 8);
+#else
       char* dst = dig + (r >> 5) * 1024 + (((cq >> 1) * 32 + (r & 31)) * 16) + (cq & 1) * 8;
+#endif
 #pragma unroll
       for (int s = 0; s < 6; ++s) {
         uint2 v;
@@ -387,7 +408,15 @@ __device__ __forceinline__ void i8_kstep(const char* __restrict__ dig, const cha
   auto frag_load_one = [&](auto itag, auto qtag) {
     constexpr int i = decltype(itag)::value, q = decltype(qtag)::value, rb = q / 6, sidx = q % 6;
     constexpr int fu = PL::first_use(rb, sidx);
+#ifdef BLR_I8_DIG_PLANES
+    if constexpr (fu == i) {  // (one ds_read2_b64: the lane's 8 + 8 contraction bytes from the two planes)
+      const uint2* pl = reinterpret_cast<const uint2*>(dig + (sidx * 4 + rb) * 1024 + lane * 8);
+      const uint2 lo8 = pl[0], hi8 = pl[64];
+      F[rb][sidx] = i32x4{(int)lo8.x, (int)lo8.y, (int)hi8.x, (int)hi8.y};
+    }
+#else
     if constexpr (fu == i) F[rb][sidx] = lds_read_b128(dig + (sidx * 4 + rb) * 1024 + lane * 16);
+#endif
   };
   auto frag_loads_rec = [&](auto self, auto itag, auto qtag) -> void {  // the reads whose first use is MFMA i
     constexpr int q = decltype(qtag)::value;
@@ -595,6 +624,11 @@ __device__ __forceinline__ void i8_gram_stream(char* smem, const BLR_GLOBAL doub
   if (nk > 1) wait_keep(nissue0 - 2 > 0 ? nissue0 - 2 : 0);
   __syncthreads();  // digits of block 0 and raw block 1 visible; raw block 0 consumed by everyone
   I8_STAMP_DECL;
+#ifdef BLR_I8_SETPRIO
+  // the second-dispatched half of the workgroup (waves 4 - 7) loses the issue arbitration on its SIMD to its older partner in every
+  // k-step (MI355X_MICROARCH.md, two waves per SIMD): one static priority for the whole stream
+  if constexpr (W >= 4) __builtin_amdgcn_s_setprio(BLR_I8_SETPRIO);
+#endif
   // (the last k-step has nothing to slice: peeled, so that the loop body is ONE basic block and the accumulators stay in place)
 #pragma unroll 1
   for (int j = 0; j + 1 < nk; ++j) {
@@ -614,6 +648,9 @@ __device__ __forceinline__ void i8_gram_stream(char* smem, const BLR_GLOBAL doub
   }
   i8_kstep<NG, W, false, kQ, DIAG, ROWV>(dig0 + ((nk - 1) & 1) * C::DIG_BUF, ring, yring, wring, dig0, lane, r, cq, A, st, [](auto) {});
   wait_keep(0);  // (the pieces issued beyond the last k-step land in a ring that is about to be reused)
+#ifdef BLR_I8_SETPRIO
+  if constexpr (W >= 4) __builtin_amdgcn_s_setprio(0);
+#endif
   I8_STAMP_FLUSH(W);
 }
 

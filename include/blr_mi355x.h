@@ -121,11 +121,23 @@ int blr_timer_stop(blr_handle* h, float* elapsed_ms); /* records, synchronises, 
  * Lw + i*strideLw and writes the outputs at their strides; a stride of 0 shares an input.
  * Numerics: results are bit-reproducible from call to call (fixed accumulation order, no floating-point atomics).  fp64
  * accuracy against the reference's op sequence in LAPACK: evidence 1e-10 relative, mw', T, Lw' 1e-9 (tests/test_gpu_parity.py).
- * One shape takes a different route to the same numbers: D = 128, aligned ColVecs or RowVecs (16-byte aligned rows), isotropic or diagonal noise, diagonal or upper-factor prior,
- * 512 <= N <= 16384 (+ a last partial block of up to 31 columns, added in fp64) forms X X' on the int8 matrix cores from an exact 48-bit splitting of the inputs (per-row
- * power-of-two scales; csrc/blr_fused_i8.hpp) -- entries of Lw' within 1e-13 of sqrt(Lw'_ii Lw'_jj) instead of a few ulp of
- * themselves, everything after the Gram matrix in fp64 as elsewhere; a regressor whose rows outgrow their scale is redone on
- * the fp64 matrix pipe inside the same call.  blr_set_option(h, "NO_I8_GRAM", "1") keeps every regressor on that pipe.
+ * One shape takes a different route to the same numbers: D = 128 in fp64 -- aligned ColVecs or RowVecs (16-byte aligned rows), isotropic or
+ * diagonal noise, any prior kind, 512 <= N <= 16384 (+ a last partial block of up to 31 columns, added in fp64) -- forms X X' on the int8
+ * matrix cores from an exact 48-bit splitting of the inputs against per-row power-of-two scales (csrc/blr_fused_i8.hpp); everything after
+ * the Gram matrix is fp64 as elsewhere.  Its error model, stated BEFORE the tests that hold it to it (tests/test_gpu_parity.py test_i8_*,
+ * test_c2_shape_fp64):
+ *   - entries of Lw' within 1e-13 of sqrt(Lw'_ii Lw'_jj) (measured: 3e-14) instead of a few ulp of themselves -- an entry that nearly
+ *     cancels is off by that much of its row's and column's scale, not of itself;
+ *   - the evidence within the 1e-10 above; where delta'Sigma^-1 delta and |T^-T b|^2 cancel (data explained by the weights) the error is
+ *     1e-14 of delta'Sigma^-1 delta: |d logpdf| <= 1e-11 |logpdf| + 1e-14 delta'Sigma^-1 delta is what the tests assert;
+ *   - inputs whose low mantissa bits are not random (float32 values, integers, powers of two) are covered: the systematic part of the
+ *     truncated digit products is kept exactly;
+ *   - an entry that outgrows its row's scale (taken from the first 96 columns, 2 - 4 x their largest entry) is corrected in fp64 inside the
+ *     kernel; a regressor with more than one such 32-column block in 16 (heavy-tailed features), Inf / NaN, or a prior mean that explains
+ *     the data to three digits is REDONE on the fp64 matrix pipe inside the same call -- it then costs two passes; blr_get_stat(h,
+ *     "i8_handed_back", ..) counts them, and a batch of more than 1024 regressors whose first 256 were handed back by more than a quarter
+ *     sends the rest to the fp64 kernel directly.
+ * blr_set_option(h, "NO_I8_GRAM", "1") keeps every regressor on the fp64 matrix pipe.
  */
 int blr_posterior_batched_f64(blr_handle* h, int memspace, int layout, int64_t B, int64_t D, int64_t N,
                               const double* X, int64_t ldx, int64_t strideX,

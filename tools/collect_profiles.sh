@@ -7,8 +7,11 @@ R=${GRAFT_REPO_ROOT:-$(pwd)}
 OUT=$R/gpurun_out/profiles_raw
 rm -rf "$OUT"; mkdir -p "$OUT"
 cd /tmp && export TMPDIR=/tmp
-B="python3 $R/bench.py --cpu-seconds 0 --secondary 0"
-python3 $R/bench.py --cpu-seconds 12 > $OUT/bench_c2_f64.json 2> $OUT/bench_c2_f64.err
+B="python3 $R/bench.py --cpu-seconds 0 --secondary 0 --preheat-seconds 0"
+# the driver's command: one short line per secondary entry, then the headline as the LAST line; full secondary records in a side file
+python3 $R/bench.py --gpus 1 --steps 20 --warmup 5 > $OUT/bench_c2_f64.out 2> $OUT/bench_c2_f64.err
+tail -1 $OUT/bench_c2_f64.out > $OUT/bench_c2_f64.json
+cp $R/gpurun_out/bench_secondary_latest.json $OUT/bench_c2_f64_secondary.json 2>/dev/null
 $B --dtype f32 > $OUT/bench_c2_f32.json 2>/dev/null
 $B --config c3 --steps 20 --warmup 3 > $OUT/bench_c3_f32.json 2>/dev/null
 $B --config c5 --steps 20 --warmup 3 > $OUT/bench_c5_f32.json 2>/dev/null
@@ -54,20 +57,23 @@ rocprofv3 --pmc $SQ --kernel-trace --output-format csv -d $OUT/pmc_sq_c3b8 -- $B
   { ./marg128_bench 64 4096 8; ./marg128_bench 64 4096 16; ./marg128_bench 256 4096 2; [ -x ./marg128_bench_st ] && ./marg128_bench_st 64 4096 8 1 | grep "image kernel" | head -1; } > $OUT/marg128_bench.txt 2>&1
   { ./marg_bench 1024 65536 20; [ -x ./marg_bench16 ] && ./marg_bench16 1024 65536 20; ./marg_bench 1024 999 20; [ -x ./marg_bench16 ] && ./marg_bench16 1024 999 20; [ -x ./marg_bench_st ] && ./marg_bench_st 1024 65536 5 | grep wave; } > $OUT/marg_bench.txt 2>&1
   # int8-sliced Gram against the fp64 kernel, same inputs: rates, agreement, the retry path (mode 1), per-phase cycle stamps
-  { for m in 0 2; do ./i8_gram 4096 4096 10 $m; done; ./i8_gram 512 4096 3 1; ./i8_gram 512 1024 3 0; ./i8_gram 4096 4096 10 3; I8_MW=1 ./i8_gram 4096 4096 10 0; [ -x ./i8_gram_st ] && ./i8_gram_st 4096 4096 4 0 | grep "wave"; } > $OUT/i8_gram.txt 2>&1 )
+  { for m in 0 2 4 1; do ./i8_gram 4096 4096 10 $m; done; ./i8_gram 512 4096 3 5; ./i8_gram 512 1024 3 0; ./i8_gram 256 16384 3 0; ./i8_gram 4096 4096 10 3; I8_MW=1 ./i8_gram 4096 4096 10 0;
+    [ -x ./i8_gram_st ] && ./i8_gram_st 4096 4096 4 0 | grep "wave"; } > $OUT/i8_gram.txt 2>&1
+  # sustained (>= 2.5 s of back-to-back launches) in-kernel clock of the int8 kernel, N(0,1) operands against zeros
+  [ -x ./i8_gram_st ] && { I8_SUSTAINED=2.5 ./i8_gram_st 4096 4096 4 0 | grep "sustained"; I8_SUSTAINED=2.5 ./i8_gram_st 4096 4096 4 3 | grep "sustained"; } > $OUT/i8_sustained.txt 2>&1 )
 # every secondary entry of the driver line: kernel stats of the hot-path rows, HBM bytes per CALL (all of a call's kernels) by PMC
 for e in marginals_var_c2_f64 marginals_var_c3_f32 marginals_var_D512_B16_f32 rand_c2_f64_S64 rand_c3_f32_S64 logpdf_grad_c2_f64 logpdf_multi_c3_f32_S64; do
   rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/stats_$e -- $B --secondary-only $e > /dev/null 2>&1
 done
-for e in c2_f64_mw c2_f64_diag_noise c2_f64_factor_prior c2_f64_rowvecs c4_f32 c4_f64_B4096 c4_f64_B2048 c4_f64_B1024 c3_f32_mw logpdf_only_c3_f32 c3_f32_B8 c5_shape_f32_B8 marginals_mean_c2_f64 marginals_var_c2_f64 \
+for e in c2_f64_mw c2_f64_diag_noise c2_f64_factor_prior c2_f64_rowvecs c2_f64_dense_prior c4_f32 c4_f64_B4096 c4_f64_B2048 c4_f64_B1024 c3_f32_mw logpdf_only_c3_f32 c3_f32_B8 c5_shape_f32_B8 marginals_mean_c2_f64 marginals_var_c2_f64 \
          marginals_var_c2_f32 marginals_mean_c3_f32 marginals_var_c3_f32 marginals_var_D512_B16_f32 rand_c2_f64_S64 rand_c3_f32_S64 logpdf_grad_c2_f64 logpdf_grad_c2_f64_sweep_kernel logpdf_grad_c2_f32 logpdf_multi_c3_f32_S64 \
          update_factor_D128_k1_f64 update_factor_D128_k16_f64; do
   rocprofv3 --pmc FETCH_SIZE --kernel-trace --output-format csv -d $OUT/sec_fetch_$e -- $B --secondary-only $e > $OUT/sec_fetch_$e.json 2>/dev/null
   rocprofv3 --pmc WRITE_SIZE --kernel-trace --output-format csv -d $OUT/sec_write_$e -- $B --secondary-only $e > $OUT/sec_write_$e.json 2>/dev/null
 done
 # the headline kernels of this round: int8-sliced Gram (default) and the fp64 kernel (BLR_MI355X_NO_I8_GRAM=1)
-BLR_MI355X_NO_I8_GRAM=1 python3 $R/bench.py --cpu-seconds 0 --secondary 0 > $OUT/bench_c2_f64_fp64kernel.json 2>/dev/null
+BLR_MI355X_NO_I8_GRAM=1 python3 $R/bench.py --cpu-seconds 0 --secondary 0 2>/dev/null | tail -1 > $OUT/bench_c2_f64_fp64kernel.json
 rocprofv3 --pmc $SQ --kernel-trace --output-format csv -d $OUT/pmc_sq_c2_i8 -- $B --steps 5 --warmup 2 > /dev/null 2>&1
 find $OUT -name "*agent_info*" -delete
 ls -R $OUT | head -80
-cat $OUT/bench_c2_f64.json | cut -c1-400
+tail -1 $OUT/bench_c2_f64.out | cut -c1-600

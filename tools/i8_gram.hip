@@ -111,6 +111,21 @@ int main(int argc, char** argv) {
     hipLaunchKernelGGL(ki8, dim3(B), dim3(kI8Threads), I8Cfg::LDS_BYTES, 0, a);
     CK(hipDeviceSynchronize());
     CK(hipMemcpyFromSymbol(z, HIP_SYMBOL(g_i8stamps), sizeof(z)));
+    if (getenv("I8_SUSTAINED")) {  // >= 2 s of back-to-back launches, then the in-kernel clocks of 20 more (cycles / 100 MHz ticks per workgroup)
+      const double secs = atof(getenv("I8_SUSTAINED"));
+      hipEvent_t s0, s1; CK(hipEventCreate(&s0)); CK(hipEventCreate(&s1));
+      float el = 0; CK(hipEventRecord(s0));
+      int nl = 0;
+      while (el < secs * 1e3) { for (int q = 0; q < 16; ++q) hipLaunchKernelGGL(ki8, dim3(B), dim3(kI8Threads), I8Cfg::LDS_BYTES, 0, a); nl += 16;
+        CK(hipEventRecord(s1)); CK(hipEventSynchronize(s1)); CK(hipEventElapsedTime(&el, s0, s1)); }
+      unsigned long long zc[4] = {}; CK(hipMemcpyToSymbol(HIP_SYMBOL(g_i8clk), zc, sizeof(zc)));
+      CK(hipEventRecord(s0));
+      for (int q = 0; q < 20; ++q) hipLaunchKernelGGL(ki8, dim3(B), dim3(kI8Threads), I8Cfg::LDS_BYTES, 0, a);
+      CK(hipEventRecord(s1)); CK(hipEventSynchronize(s1)); CK(hipEventElapsedTime(&el, s0, s1));
+      CK(hipMemcpyFromSymbol(zc, HIP_SYMBOL(g_i8clk), sizeof(zc)));
+      printf("  sustained (mode %d, %d launches = %.1f s of pre-heat): %.3f ms per launch of %d = %.3f M updates/s; in-kernel clock %.3f GHz (%.0f k cycles, %.1f us per regressor, %llu workgroups sampled)\n",
+             mode, nl, secs, el / 20, B, B / (el / 20) / 1e3, (double)zc[0] / (double)zc[1] * 0.1, (double)zc[0] / zc[2] / 1e3, (double)zc[1] / zc[2] / 100.0, zc[2]);
+    }
     const double nwg = (B + 256) / 257, nk = N / 32 * nwg;  // (sums over the workgroups with blockIdx % 257 == 0: different replicas of the inputs)
     for (int w = 0; w < 8; ++w)
       printf("  wave %d, mean over %d workgroups, cycles per k-step: MFMAs + slicing %6.0f | DMA wait + barrier %6.0f || per regressor: stream %8.0f | hand-over + conversion %7.0f | repair %6.0f | chol %7.0f | backsolve + out %7.0f\n",

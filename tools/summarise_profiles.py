@@ -9,7 +9,7 @@ import os
 import shutil
 import sys
 
-tag = sys.argv[1] if len(sys.argv) > 1 else "r04"
+tag = sys.argv[1] if len(sys.argv) > 1 else "r05"
 RAW = "gpurun_out/profiles_raw"
 DST = "profiles"
 os.makedirs(DST, exist_ok=True)
@@ -20,7 +20,7 @@ def one(pattern):
     return max(g, key=os.path.getmtime) if g else None
 
 
-for name in ("bench_c2_f64", "bench_c2_f32", "bench_c3_f32", "bench_c5_f32", "bench_c4_f64", "bench_c3_f32_B8", "bench_c2_f64_fp64kernel"):
+for name in ("bench_c2_f64", "bench_c2_f64_secondary", "bench_c2_f32", "bench_c3_f32", "bench_c5_f32", "bench_c4_f64", "bench_c3_f32_B8", "bench_c2_f64_fp64kernel"):
     src = os.path.join(RAW, name + ".json")
     if os.path.exists(src) and os.path.getsize(src):
         shutil.copy(src, os.path.join(DST, f"{tag}_{name}.json"))
@@ -29,6 +29,30 @@ for cfg in ("c2", "c3", "c5", "c4", "c3b8", "marginals_var_c2_f64", "marginals_v
     f = one(f"{RAW}/stats_{cfg}/*/*_kernel_stats.csv")
     if f:
         shutil.copy(f, os.path.join(DST, f"{tag}_{cfg}_kernel_stats.csv"))
+
+
+def durations(dirname, kernel_substr):
+    """min / median / mean duration (us) of a kernel's dispatches in a `rocprofv3 --kernel-trace --stats` run (one
+    outlier launch moves the mean by 3 %)"""
+    f = one(f"{RAW}/{dirname}/*/*_kernel_trace.csv")
+    if not f:
+        return None
+    by_grid = collections.defaultdict(list)
+    for r in csv.DictReader(open(f)):
+        if kernel_substr in r["Kernel_Name"]:
+            by_grid[int(r["Grid_Size_X"]) * int(r["Grid_Size_Y"]) * int(r["Grid_Size_Z"])].append((int(r["End_Timestamp"]) - int(r["Start_Timestamp"])) / 1e3)
+    if not by_grid:
+        return None
+    out = {"kernel": kernel_substr, "launch_shapes": {}}
+    step_med = step_mean = 0.0
+    for g, d in sorted(by_grid.items()):
+        d.sort()
+        out["launch_shapes"][str(g)] = {"calls": len(d), "min_us": d[0], "median_us": d[len(d) // 2], "mean_us": sum(d) / len(d), "max_us": d[-1]}
+        step_med += d[len(d) // 2]
+        step_mean += sum(d) / len(d)
+    # (the int8 route launches the kernel twice per call above 1024 regressors: a probe slice of 256, then the rest)
+    out["per_step_median_us"], out["per_step_mean_us"] = step_med, step_mean
+    return out
 
 
 def counters(dirname, kernel_substr):
@@ -63,6 +87,16 @@ def counters(dirname, kernel_substr):
         out[k] = sum(c[k] for c in sel.values()) / len(sel)
     return out
 
+
+kd = {}
+for cfg, kern in (("c2", "fused_i8_kernel"), ("c3", "gram_tile_kernel"), ("c5", "gram_tile_kernel"), ("c4", "fused_wave_kernel"), ("c3b8", "gram_tile_kernel"),
+                  ("marginals_var_c2_f64", "marginals_gemm_kernel"), ("marginals_var_c3_f32", "marg_blocksub_kernel"),
+                  ("logpdf_grad_c2_f64", "grad_gemm_kernel")):
+    r = durations(f"stats_{cfg}", kern)
+    if r:
+        kd[cfg] = r
+if kd:
+    json.dump(kd, open(os.path.join(DST, f"{tag}_kernel_durations.json"), "w"), indent=1)
 
 summary = {"note": "per-dispatch means for the dominant kernel; rocprofv3 --pmc, one counter group per pass "
                    "(tools/collect_profiles.sh); FETCH_SIZE / WRITE_SIZE in KiB, FETCH_SIZE x2 on gfx950 "
@@ -101,7 +135,7 @@ for key, d, kern, units in (("c2_f32_fused_small_kernel_hbm", "c2f32", "fused_sm
 for src in sorted(glob.glob(os.path.join(os.path.dirname(RAW), "microbench", "*.txt"))):  # tools/run_microbench.sh
     if os.path.getsize(src):
         shutil.copy(src, os.path.join(DST, f"{tag}_microbench_{os.path.basename(src)}"))
-for extra in ("ring_probe.txt", "power_probe.txt", "i8_gram.txt", "marg_bench.txt", "marg128_bench.txt", "group_scan.txt", "layout_time.txt", "rowvecs_gap.txt"):
+for extra in ("ring_probe.txt", "power_probe.txt", "i8_gram.txt", "i8_sustained.txt", "marg_bench.txt", "marg128_bench.txt", "group_scan.txt", "layout_time.txt", "rowvecs_gap.txt"):
     src = os.path.join(RAW, extra)
     if os.path.exists(src) and os.path.getsize(src):
         shutil.copy(src, os.path.join(DST, f"{tag}_microbench_{extra}"))
@@ -151,8 +185,10 @@ for key, d in (("c2_fused_i8_kernel_hbm", "c2"),):
         rd = fe["FETCH_SIZE"] * 1024.0 * 2.0
         wr = wr_["WRITE_SIZE"] * 1024.0
         summary[key] = {"FETCH_SIZE_KiB": fe["FETCH_SIZE"], "WRITE_SIZE_KiB": wr_["WRITE_SIZE"], "hbm_read_bytes_per_launch": rd,
-                        "hbm_write_bytes_per_launch": wr, "hbm_bytes_per_launch": rd + wr, "units_per_launch": 4096,
-                        "kernel": "fused_i8_kernel", "avg_duration_ns": fe["avg_duration_ns"]}
+                        "hbm_write_bytes_per_launch": wr, "hbm_bytes_per_launch": rd + wr, "units_per_launch": fe["grid"] // 512,
+                        "kernel": "fused_i8_kernel", "avg_duration_ns": fe["avg_duration_ns"],
+                        "note": "the dominant launch of a call: above 1024 regressors the int8 route runs a probe slice of 256 workgroups "
+                                "first; this is the launch of the remaining ones (one 512-thread workgroup per regressor)"}
 if "c2_fused_small_kernel_hbm" in summary:  # the A/B secondary entry of the driver-line workload on the fp64 kernel
     summary["c2_f64_fp64_kernel_hbm"] = dict(summary["c2_fused_small_kernel_hbm"], units_per_launch=1,
                                              note="= c2_fused_small_kernel_hbm (one launch per call)")
