@@ -170,6 +170,18 @@ def test_hot_kernels_keep_two_workgroups_per_cu(tmp_path):
     i8 = {k: v for k, v in kernels.items() if "fused_i8_kernel" in k}
     n_i8 = 1 if "asan" in os.path.basename(str(_abi.LIB_PATH)) else 4  # (the sanitizer build carries one form: BLR_DEV_FAST)
     assert len(i8) == n_i8 and max(i8.values()) <= 256, f"the four forms of the int8-sliced kernel (8 waves of 256 registers): {i8}"
+    # vector-register spills of the headline kernel: none in the isotropic forms (the diagonal-noise RowVecs form keeps one)
+    spills, name = {}, None
+    for line in notes.splitlines():
+        m = re.match(r"\s+(?:- )?\.(name|vgpr_spill_count):\s+(\S+)", line)
+        if m and m.group(1) == "name":
+            name = m.group(2)
+        elif m and name is not None:
+            spills[name] = int(m.group(2))
+    i8_spills = {k: v for k, v in spills.items() if "fused_i8_kernel" in k}
+    assert len(i8_spills) == n_i8
+    assert all(v == 0 for k, v in i8_spills.items() if "ILb0E" in k), f"isotropic int8 kernels must not spill vector registers: {i8_spills}"
+    assert max(i8_spills.values()) <= 2, i8_spills
 
 
 def test_julia_shim_ccall_signatures_match_the_header(repo_root):
