@@ -59,6 +59,12 @@ def i8(rng, case):
     N = int(rng.integers(512, 16416)) if rng.random() < 0.4 else int(rng.choice([512, 543, 544, 1000, 1024, 4096, 4097, 16384, 16415]))
     nb = int(rng.choice([1, 3, 8]))
     X = rng.standard_normal((nb, N, D))
+    u = rng.random()
+    if u < 0.2:    # values that came from float32: the three low digits of the 48-bit integers are constant
+        X = X.astype(np.float32).astype(np.float64)
+    elif u < 0.3:  # fixed-point values / a constant feature with a repeating binary expansion
+        X = np.round(X * 8.0) / 8.0
+        X[:, :, 11] = 0.1
     scale = np.ldexp(1.0, rng.integers(-20, 21, size=D)) if rng.random() < 0.5 else np.ones(D)
     X *= scale[None, None, :]
     w = rng.standard_normal((nb, D)) / scale[None, :]
@@ -67,7 +73,9 @@ def i8(rng, case):
         X[0, N // 3, 7] *= 1e4  # breaks its row's bound: that regressor goes back to the fp64 kernel
     mw = rng.standard_normal((nb, D)) / scale[None, :] if rng.random() < 0.6 else np.zeros((nb, D))
     dpr = np.exp(0.3 * rng.standard_normal((nb, D))) / scale[None, :] ** 2
-    factor = rng.random() < 0.35  # a prior given by its upper factor U (U'U joins at the hand-over)
+    pr = rng.random()
+    factor = pr < 0.35  # a prior given by its upper factor U (U'U joins at the hand-over)
+    dense = 0.35 <= pr < 0.6  # a dense precision (upper triangle read; its Cholesky before the launch)
     Lw_o = [np.diag(dpr[b]) for b in range(nb)]
     prior_arg, pk, ldl, strideL = dpr, _abi.PRIOR_DIAGONAL, 1, D
     if factor:
@@ -77,6 +85,13 @@ def i8(rng, case):
             Lw_o[b] = Bm.T @ Bm + np.diag(dpr[b])
             Uc[b] = O.chol_upper(Lw_o[b]).T
         prior_arg, pk, ldl, strideL = Uc, _abi.PRIOR_UPPER_FACTOR, D, D * D
+    if dense:
+        Lc = np.empty((nb, D, D))
+        for b in range(nb):
+            Bm = rng.standard_normal((D, D)) / np.sqrt(D) / scale[None, :]
+            Lw_o[b] = Bm.T @ Bm + np.diag(dpr[b])
+            Lc[b] = np.triu(Lw_o[b]).T  # column-major upper triangle; the lower one stays zero (never read)
+        prior_arg, pk, ldl, strideL = Lc, _abi.PRIOR_DENSE, D, D * D
     diag = rng.random() < 0.4
     s = np.exp(rng.choice([0.3, 1.0, 2.0]) * rng.standard_normal((nb, N))) if diag else np.array([0.1])
     if diag:
@@ -95,13 +110,13 @@ def i8(rng, case):
                         s, N if diag else 0, pk, mw, D, prior_arg, ldl, strideL, mp, D, Tp, D, D * D, Ap, D, D * D, lp, info)
     assert np.all(info == 0), (case, info)
     for b in range(nb):
-        mw_o, T_o, A_o, lp_o = O.posterior_logpdf_direct(mw[b], Lw_o[b] if factor else dpr[b], X[b].T, s[b] if diag else 0.1, y[b])
+        mw_o, T_o, A_o, lp_o = O.posterior_logpdf_direct(mw[b], Lw_o[b] if (factor or dense) else dpr[b], X[b].T, s[b] if diag else 0.1, y[b])
         dA = np.sqrt(np.diag(A_o))
         # (the evidence is a difference of terms of size y'y / s: an injected outlier makes them 1e6 times the evidence itself)
         assert abs(lp[b] - lp_o) <= 2e-10 * abs(lp_o) + 1e-12 * float((y[b] * y[b] / (s[b] if diag else 0.1)).sum()) * max(1.0, float(np.abs(X[b]).max() / np.abs(X[b]).mean()) ** 2 / 1e4), (case, b, lp[b], lp_o)
-        assert (np.abs(Ap[b] - A_o) / np.outer(dA, dA)).max() <= (1e-11 if diag else 1e-12), case
+        assert (np.abs(Ap[b] - A_o) / np.outer(dA, dA)).max() <= (1e-11 if diag else 1e-13), case
         np.testing.assert_allclose(mp[b] * dA, mw_o * dA, rtol=1e-7, atol=1e-8 * np.abs(mw_o * dA).max(), err_msg=f"case {case}")
-    return f"N={N} B={nb} mw={'yes' if np.any(mw) else 'no'} scaled={'yes' if np.any(scale != 1) else 'no'} noise={'diag' if diag else 'iso'} prior={'factor' if factor else 'diag'} layout={'RowVecs' if rowv else 'ColVecs'}"
+    return f"N={N} B={nb} mw={'yes' if np.any(mw) else 'no'} scaled={'yes' if np.any(scale != 1) else 'no'} noise={'diag' if diag else 'iso'} prior={'factor' if factor else ('dense' if dense else 'diag')} layout={'RowVecs' if rowv else 'ColVecs'}"
 
 
 def multi(rng, case):
