@@ -37,6 +37,7 @@ struct BlrOptions {
        no_mfma_project = false, plan_debug = false, no_i8_gram = false, no_marg_gemm = false, no_i8_diag = false, no_i8_factor = false, no_i8_rowvecs = false, no_grad_gemm = false, no_i8_dense = false, no_i8_fallback = false;
   int wave_split = 0;     // waves per regressor of the wave kernel: 0 = router, else 1 | 2 | 4
   int chain_batch = 0;    // regressors per shared launch at D > 128: 0 = as many as the workspace holds
+  int i8_probe_min = 0;   // int8 route: batches beyond this many regressors start with a probe slice; 0 = kI8ProbeMin
   long chain_ws_mb = 0;   // workspace bound of such a group in MiB: 0 = kChainWorkspace
   int sweep = 0;          // blr_update_factor_* route: 0 = router, 1 = always the Givens sweep, 2 = never
   int gs_fields = 0, gs_so = 0, gs_sd = 0, gs_nl = 0;  // GRAM_SPLITS = "off-diagonal,diagonal[,nlong]" (gs_fields = numbers parsed)
@@ -81,6 +82,12 @@ struct BlrOptions {
       chain_batch = (int)v;
       return 0;
     }
+    if (!strcmp(key, "I8_PROBE_MIN")) {
+      if (!on) { i8_probe_min = 0; return 0; }
+      if (!parse_long(value, v) || v < 256 || v > (1 << 20)) return -3;
+      i8_probe_min = (int)v;
+      return 0;
+    }
     if (!strcmp(key, "CHAIN_WS_MB")) {
       if (!on) { chain_ws_mb = 0; return 0; }
       if (!parse_long(value, v) || v < 1) return -3;
@@ -108,7 +115,7 @@ struct BlrOptions {
       if (const char* v = getenv(name.c_str())) (void)set(k, *v ? v : "1");
     }
     // valued options: an empty variable is ignored (the built-in default stays), a malformed one too
-    for (const char* k : {"WAVE_SPLIT", "CHAIN_BATCH", "CHAIN_WS_MB", "SWEEP", "GRAM_SPLITS"}) {
+    for (const char* k : {"WAVE_SPLIT", "CHAIN_BATCH", "CHAIN_WS_MB", "SWEEP", "GRAM_SPLITS", "I8_PROBE_MIN"}) {
       const std::string name = std::string("BLR_MI355X_") + k;
       if (const char* v = getenv(name.c_str()))
         if (*v) (void)set(k, v);
@@ -456,7 +463,7 @@ int launch_fused_i8(blr_handle* h, const PosteriorArgs<double>& a) {
     ld = reinterpret_cast<double*>(h->i8side + o_ld); rmx = reinterpret_cast<double*>(h->i8side + o_mx); bad = reinterpret_cast<int32_t*>(h->i8side + o_bad);
   }
   // Slices: one workgroup per regressor (batches beyond 2^20, or beyond the side buffer, in several launches).  A batch of more than
-  // kI8ProbeMin regressors starts with a PROBE slice of kI8Probe (one round of workgroups on the chip): every later slice reads how
+  // kI8ProbeMin = 4096 regressors (option I8_PROBE_MIN) starts with a PROBE slice of kI8Probe (one round of workgroups on the chip): every later slice reads how
   // many regressors of the slice before it the fast path had to hand back, and when that was more than a quarter its workgroups
   // leave their regressors to the fp64 kernel at once instead of streaming them twice (heavy-tailed inputs: blr_get_stat
   // "i8_handed_back").  The decision depends on the data of the previous slice only: same inputs, same bits.
@@ -474,7 +481,7 @@ int launch_fused_i8(blr_handle* h, const PosteriorArgs<double>& a) {
   while (b0 < a.B) {
     PosteriorArgs<double> s = a;
     int64_t want = std::min<int64_t>(grid, a.B - b0);
-    if (b0 == 0 && a.B > kI8ProbeMin && !h->opt.no_i8_fallback) want = std::min<int64_t>(want, kI8Probe);
+    if (b0 == 0 && a.B > (h->opt.i8_probe_min > 0 ? h->opt.i8_probe_min : kI8ProbeMin) && !h->opt.no_i8_fallback) want = std::min<int64_t>(want, kI8Probe);
     const int nb = (int)want;
     s.B = nb;
     s.X += b0 * a.strideX; s.y += b0 * a.stridey; s.s += b0 * a.strides; s.mw += b0 * a.stridemw; s.Lw += b0 * a.strideLw;

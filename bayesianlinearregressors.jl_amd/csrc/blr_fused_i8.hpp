@@ -70,7 +70,7 @@ constexpr int kI8Retry = kI8RetryCode;  // info: "this regressor must be redone 
 constexpr int kI8MaxN = 16384;          // int32 accumulators: 6 N 2^14 < 2^31
 constexpr int kI8MinN = 512;            // below, the fixed costs of the fast path buy nothing
 constexpr int kI8Probe = 256;           // regressors of a large batch's first slice (one round of workgroups): its hand-back count steers the rest
-constexpr int kI8ProbeMin = 1024;       // batches up to this size go in one slice
+constexpr int kI8ProbeMin = 4096;       // batches up to this size go in one slice (handle option I8_PROBE_MIN lowers it: tests)
 constexpr int kI8MaxRepair = 32;        // 32-column blocks with entries beyond their row's capacity that are corrected in fp64 at the hand-over; more: fp64 kernel
 // Digit groups kept (k = s + t < NG) and binades of capacity above the exponent of a row's largest entry in the first 96 columns:
 //   isotropic noise: 6 groups, capacity 2^(E + 2) -- between 2 and 4 times that maximum, the whole two's-complement range of the

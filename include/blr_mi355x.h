@@ -74,7 +74,7 @@ int blr_set_async(blr_handle* h, int async);      /* 1: DEVICE-memspace calls re
 int blr_synchronize(blr_handle* h);
 /* Run-time switches of the handle (A/B measurements and tests; the defaults are the measured best).  `key` is one of NO_LDSDMA,
  * NO_WAVE_KERNEL, NO_GRAM_RING, NO_DIAG_SPLIT, NO_XCD_SWIZZLE, NO_MFMA_PROJECT, NO_I8_GRAM, NO_I8_DIAG, NO_I8_FACTOR, NO_I8_ROWVECS, NO_I8_DENSE, NO_I8_FALLBACK, NO_MARG_GEMM, NO_GRAD_GEMM, PLAN_DEBUG (flags: any non-empty value = on),
- * WAVE_SPLIT = 1|2|4, CHAIN_BATCH = 1..128, CHAIN_WS_MB, SWEEP = always|never|auto, GRAM_SPLITS = "o,d[,nlong]" (README.md);
+ * WAVE_SPLIT = 1|2|4, CHAIN_BATCH = 1..128, CHAIN_WS_MB, I8_PROBE_MIN = 256..2^20, SWEEP = always|never|auto, GRAM_SPLITS = "o,d[,nlong]" (README.md);
  * a "BLR_MI355X_" prefix is accepted.  value NULL or "" restores the built-in default.  The environment variables
  * BLR_MI355X_<KEY> are read ONCE, by blr_create -- no entry point reads the environment.  -> 0, or -2 / -3 (unknown key /
  * malformed value). */
@@ -135,7 +135,7 @@ int blr_timer_stop(blr_handle* h, float* elapsed_ms); /* records, synchronises, 
  *   - an entry that outgrows its row's scale (taken from the first 96 columns, 2 - 4 x their largest entry) is corrected in fp64 inside the
  *     kernel; a regressor with more than one such 32-column block in 16 (heavy-tailed features), Inf / NaN, or a prior mean that explains
  *     the data to three digits is REDONE on the fp64 matrix pipe inside the same call -- it then costs two passes; blr_get_stat(h,
- *     "i8_handed_back", ..) counts them, and a batch of more than 1024 regressors whose first 256 were handed back by more than a quarter
+ *     "i8_handed_back", ..) counts them, and a batch of more than 4096 regressors (option I8_PROBE_MIN) whose first 256 were handed back by more than a quarter
  *     sends the rest to the fp64 kernel directly.
  * blr_set_option(h, "NO_I8_GRAM", "1") keeps every regressor on the fp64 matrix pipe.
  */

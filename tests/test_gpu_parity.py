@@ -2794,7 +2794,7 @@ def test_i8_gram_path_at_its_largest_N(B, opt, N, kind):
 def test_i8_gram_path_heavy_tails_are_counted_and_fall_back(B, opt, tails):
     # VERDICT r4 weak #2c: the row bounds of the int8 route come from the first 96 columns; heavy-tailed features outgrow them, the
     # regressor is handed back and pays BOTH kernels.  blr_get_stat("i8_handed_back") makes that visible, and a batch beyond
-    # kI8ProbeMin = 1024 regressors starts with a probe slice of 256: when more than a quarter of it was handed back, the rest of the
+    # kI8ProbeMin = 4096 regressors (here: option I8_PROBE_MIN = 1024) starts with a probe slice of 256: when more than a quarter of it was handed back, the rest of the
     # call goes to the fp64 kernel directly (NO_I8_FALLBACK switches that off).  Results are checked on both routes either way.
     a = B._abi
     h = a.default_handle()
@@ -2816,6 +2816,7 @@ def test_i8_gram_path_heavy_tails_are_counted_and_fall_back(B, opt, tails):
                             mw, 0, dpr, 1, 0, mp, D, None, D, D * D, None, D, D * D, lp, info)
         return mp, lp, info
 
+    opt("I8_PROBE_MIN", "1024")  # (the library probes batches beyond 4096 regressors: 2 GB of host inputs at this N; lowered for the test)
     h.reset_stats()
     fast = run()
     sent, back = h.get_stat("i8_regressors"), h.get_stat("i8_handed_back")
