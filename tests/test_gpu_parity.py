@@ -2883,6 +2883,49 @@ def test_i8_gram_prior_mean_that_explains_the_data(B, opt):
         np.testing.assert_array_equal(fast[0][b], slow[0][b])
 
 
+def test_switching_streams_between_large_d_calls(B):
+    # the arrival counters of panel_chain_kernel alternate between two banks per handle and a launch clears its successor's
+    # bank -- two streams on one handle could have a launch clear a bank its successor is already counting in.  blr_set_stream now drains
+    # the old stream and re-arms both banks: D > 128 updates (an odd number of panel launches each: D = 384 has three) issued alternately on
+    # the handle's own stream, a torch side stream and the null stream must return the bits of the same call on one stream.
+    import torch
+
+    a = B._abi
+    h = a.default_handle()
+    dev = torch.device("cuda:0")
+    rng = _rng(5100)
+    nb, D, N = 3, 384, 500
+    X = rng.standard_normal((nb, N, D)); y = rng.standard_normal((nb, N)); mw = rng.standard_normal((nb, D))
+    dpr = np.exp(0.3 * rng.standard_normal((nb, D))); s = np.array([0.3])
+
+    def run():
+        mp = np.zeros((nb, D)); Tp = np.zeros((nb, D, D)); lp = np.zeros(nb); info = np.full(nb, 9, dtype=np.int32)
+        h.posterior_batched(np.float64, a.MEM_HOST, a.LAYOUT_COLVECS, nb, D, N, X, D, N * D, y, N, a.NOISE_ISOTROPIC, s, 0, a.PRIOR_DIAGONAL,
+                            mw, D, dpr, 1, D, mp, D, Tp, D, D * D, None, D, D * D, lp, info)
+        assert info.tolist() == [0] * nb
+        return mp, Tp, lp
+
+    ref = run()
+    side = torch.cuda.Stream(dev)
+    try:
+        for k in range(7):
+            if k % 3 == 0:
+                h.set_stream(side.cuda_stream)
+            elif k % 3 == 1:
+                h.set_stream(0)
+            else:
+                h.reset_stream()
+            got = run()
+            for u, v in zip(ref, got):
+                np.testing.assert_array_equal(u, v)
+    finally:
+        h.reset_stream()
+    for b in range(nb):
+        mw_o, _, _, lp_o = O.posterior_logpdf_direct(mw[b], dpr[b], X[b].T, 0.3, y[b])
+        assert ref[2][b] == pytest.approx(lp_o, rel=1e-10)
+        np.testing.assert_allclose(ref[0][b], mw_o, rtol=1e-8, atol=1e-10)
+
+
 def test_last_route_and_option_codes(B, opt):
     # blr_last_route names the kernel family the dispatcher took (bench.py labels its roofline with it); blr_set_option tells an
     # unknown key (-2) from a malformed value (-3), and rejects numbers that are not numbers.
