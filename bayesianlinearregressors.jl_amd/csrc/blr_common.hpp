@@ -206,6 +206,11 @@ __host__ __device__ __forceinline__ int pidx(int i, int k) { return i * (i + 1) 
 // Reciprocal / reciprocal square root for the serial pivot chain of the blocked Cholesky: hardware seed plus
 // Newton steps (f32: 1, f64: 2) instead of the ~15-20-instruction IEEE division / square-root expansions.
 // Result within 1-2 ulp for normal positive inputs, which is all the pivot of an SPD matrix can be.
+// a * b + c in ONE rounding, spelled out: where the bits matter (the elimination of phase_chol) the contraction is not left to the optimiser
+// -- the SLP vectoriser otherwise turns some of the products into v_pk_mul_f32 + v_sub_f32
+__device__ __forceinline__ float fused_madd(float a, float b, float c) { return __builtin_fmaf(a, b, c); }
+__device__ __forceinline__ double fused_madd(double a, double b, double c) { return __builtin_fma(a, b, c); }
+
 __device__ __forceinline__ float fast_rcp(float x) {
   float r = __builtin_amdgcn_rcpf(x);
   return __builtin_fmaf(__builtin_fmaf(-x, r, 1.0f), r, r);

@@ -138,6 +138,7 @@ struct I8Cfg {
   static constexpr int OFF_UW = 80 * 1024;
   static_assert(SmallCfg<double, 8>::LDS_BYTES <= OFF_UW && OFF_UW + 2 * 128 * 8 * 8 <= RING_BYTES, "the phase functions' LDS image and the conversion records must fit in the dead ring");
   static_assert(OFF_TAIL + (32 * 128 + 32) * 8 <= OFF_YB, "conversion tables and the tail columns / a block under repair must fit in the digit area");
+  static_assert(OFF_TAIL + 4 * 32 * 33 * 8 <= OFF_YB, "the four mirror tiles of the conversion (one per diagonal block) use the same area, before the repair");
   static_assert(LDS_BYTES <= 160 * 1024, "LDS of one CU");
 };
 
@@ -741,47 +742,60 @@ __device__ __attribute__((noinline)) void i8_table_pass(char* smem, double winv)
   const double* const colpk = rowpk + 128 * 8;
   int tid = threadIdx.x;
   asm volatile("" : "+v"(tid));
-    // ---- what does not come out of the accumulators: per entry (i, j) the offset terms T_i + T_j of ALL digit pairs, the mean parts
-    // sum_s U_s(i) W_s(j) of the dropped ones, TD_i on the diagonal -- scaled like the products -- and the diagonal prior.  Column j of the
-    // packed triangle per thread (its record in registers; consecutive lanes = consecutive words of a row: no bank conflicts), 32 rows
-    // each, four at a time; diag(G) / s goes to `gdiag` before the prior joins.
-    {
-      typedef double d2 __attribute__((ext_vector_type(2)));
-      const int j = tid & 127, i0 = 32 * (tid >> 7);
-      const d2* const cp = reinterpret_cast<const d2*>(colpk + j * 8);
-      const d2 c01 = cp[0], c23 = cp[1], c45 = cp[2], c67 = cp[3];
-      const double scj = c01[1] * winv;
+  const int lane = tid & 63, wave = uni(tid >> 6);
+  // ---- what does not come out of the int8 accumulators: per entry (i, j) the offset terms T_i + T_j of ALL digit pairs and the mean parts
+  // sum_s U_s(i) W_s(j) of the dropped ones, scaled like the products.  That is a rank-7 product [T_i, 1, U_1..U_5] [1, T_j, W_1..W_5]':
+  // two v_mfma_f64_16x16x4 per 16 x 16 tile of the packed triangle (36 tiles over the eight waves), added to P in the accumulator layout
+  // (consecutive lanes = consecutive words of a row).  (As a loop over the entries -- five multiply-adds, four 16-byte record reads and
+  // a read-modify-write each -- this pass took 12 k cycles per regressor.)
+  const int r16 = lane & 15, q4 = lane >> 4;
+  // (Branch-free on purpose: written with conditional reads this loop took 2.4 k cycles per tile -- some forty taken branches and six
+  // dependent LDS round trips.  The reads are unconditional with a clamped index, the triangle mask steers the address to a dump word.)
+  double* const dump = reinterpret_cast<double*>(smem + C::OFF_TAIL) + tid;  // (the mirror tiles of the conversion are dead)
+  const int ia = (q4 == 1) ? 0 : q4, ib = (q4 < 3) ? 4 + q4 : 4;   // row record: T_i, (1), U_1, U_2 | U_3, U_4, U_5, (0)
+  const int ja = (q4 < 2) ? 0 : q4;                                // column record: (1), T_j, W_1, W_2 | W_3, W_4, W_5, (0)
 #pragma unroll 1
-      for (int ib = i0; ib < i0 + 32; ib += 4) {
-        if (ib + 3 < j) continue;
-        d2 r01[4], r23[4], r45[4], r67[4];
-        double cur[4];
+  for (int t = wave; t < 36; t += 8) {
+    int I = 0;
 #pragma unroll
-        for (int u = 0; u < 4; ++u) {
-          const d2* const rp = reinterpret_cast<const d2*>(rowpk + (ib + u) * 8);
-          r01[u] = rp[0]; r23[u] = rp[1]; r45[u] = rp[2]; r67[u] = rp[3];
-          cur[u] = (ib + u >= j) ? P[pidx(ib + u, j)] : 0.0;
-        }
-#pragma unroll
-        for (int u = 0; u < 4; ++u) {
-          const int i = ib + u;
-          double tb = __builtin_fma(r45[u][1], c45[1], r67[u][0] * c67[0]);
-          const double tb2 = __builtin_fma(r23[u][1], c23[1], r45[u][0] * c45[0]);
-          tb += __builtin_fma(r23[u][0], c23[0], tb2);
+    for (int i = 1; i < 8; ++i) I += (t >= i * (i + 1) / 2) ? 1 : 0;
+    const int K = t - I * (I + 1) / 2;
+    const double* const ri = rowpk + (16 * I + r16) * 8;
+    const double* const cj = colpk + (16 * K + r16) * 8;
+    const double sci = ri[1], scj = cj[1] * winv;
+    const double ra = ri[ia], rb = ri[ib], ca = cj[ja], cb = cj[ib];
+    double a0 = (q4 == 1) ? 1.0 : ra;
+    double a1 = (q4 < 3) ? rb : 0.0;
+    const double b0 = (q4 == 0) ? 1.0 : ca;
+    const double b1 = (q4 < 3) ? cb : 0.0;
 #ifdef BLR_I8_NO_MEANPROD
-          tb = 0.0;
+    if (q4 >= 2) a0 = 0.0;
+    a1 = 0.0;
 #endif
-          if (i == j) tb += r67[u][1];
-          tb += r01[u][0] + c01[0];
-          double e = __builtin_fma(tb, r01[u][1] * scj, cur[u]);
-          if (i == j) {
-            gdiag[i] = e;   // (the data term alone: A_ii - Lw_i would lose it under a strong prior)
-            e += c67[1];    // the diagonal prior (0 for a factor prior: U'U joins after the prior-mean terms)
-          }
-          if (i >= j) P[pidx(i, j)] = e;
-        }
-      }
+    const int col = 16 * K + r16;
+    double* addr[4];
+    double cur[4];
+#pragma unroll
+    for (int v = 0; v < 4; ++v) {
+      const int row = 16 * I + q4 + 4 * v;
+      addr[v] = (row >= col) ? P + pidx(row, col) : dump;
+      cur[v] = *addr[v];
     }
+    typename Mfma<double>::acc4 acc = {0.0, 0.0, 0.0, 0.0};
+    acc = Mfma<double>::mma(a0 * sci, b0 * scj, acc);
+    acc = Mfma<double>::mma(a1 * sci, b1 * scj, acc);
+#pragma unroll
+    for (int v = 0; v < 4; ++v) *addr[v] = cur[v] + acc[v];
+  }
+  __syncthreads();
+  // the diagonal: TD_i (the dropped pair (3, 3), a sum of squares), diag(G) / s to `gdiag` before the diagonal prior joins (0 for a factor or a
+  // dense prior: those are added after the prior-mean terms)
+  if (tid < 128) {
+    const double* const ri = rowpk + tid * 8;
+    const double e = __builtin_fma(ri[7], ri[1] * ri[1] * winv, P[pidx(tid, tid)]);
+    gdiag[tid] = e;  // (the data term alone: A_ii - Lw_i would lose it under a strong prior)
+    P[pidx(tid, tid)] = e + colpk[tid * 8 + 7];
+  }
 }
 
 // ---- back substitution m = L^-T u for D = 128, blocked by 16 ------------------------------------------------------------------------------
@@ -970,53 +984,80 @@ __global__ __launch_bounds__(kI8Threads, 2) void fused_i8_kernel(PosteriorArgs<d
       constexpr I8Item it = Items::it[IT];
       constexpr int base = PL::acc_base(IT);
       constexpr bool symt = i8_sym_tile<NG>(it.I, it.K);
+      // (a symmetric diagonal tile's item has Q slots -- pairs s < t, whose transposes belong to the same entries -- unless it holds R slots only)
+      constexpr bool hasq = symt && i8_slot_kind<NG>(it.I, it.K, it.q0) == 1;
       const int jl = lane & 31, j = 32 * it.K + jl;
       const double scj = sctab[j] * winv;
-      double gq[symt ? 16 : 1];  // symmetric diagonal tile: the Q part of every entry, added to its mirror image in a second sweep
+      // Mirror through a scratch tile of the wave's own (32 x 32 doubles, row stride 33: written with consecutive lanes = consecutive
+      // words, read transposed without bank conflicts; one tile per diagonal block, and the phases never give two waves the same block):
+      // entry (i, j) of the result takes Q(i, j) + Q(j, i) -- on the diagonal that is 2 Q(i, i) by itself.  (First version: lanes with
+      // i < j added their Q to P[(j, i)] in a second sweep -- triangular-number strides, 4-way bank conflicts, two dependent LDS round
+      // trips per entry: 7 k cycles per item against 2.7 k for an off-diagonal one.)
+      double* const mir = reinterpret_cast<double*>(smem + C::OFF_TAIL) + it.I * (32 * 33);
+      double glo[hasq ? 16 : 1];
+      if constexpr (hasq) {
 #pragma unroll
-      for (int v = 0; v < 16; ++v) {
-        const int il = 8 * (v >> 2) + 4 * (lane >> 5) + (v & 3), i = 32 * it.I + il;
-        // sum over the slots of (exact integer) x 2^(80 - 8 k): two interleaved partial sums per kind -- a dependent fp64 operation waits
-        // ~40 cycles for its predecessor, and a chain over nine slots was most of the conversion's time
-        double lo2[2] = {0.0, 0.0}, qs2[2] = {0.0, 0.0};
+        for (int v = 0; v < 16; ++v) {
+          const int il = 8 * (v >> 2) + 4 * (lane >> 5) + (v & 3), i = 32 * it.I + il;
+          double lo2[2] = {0.0, 0.0}, qs2[2] = {0.0, 0.0};
 #pragma unroll
-        for (int k = 10; k >= 0; --k) {  // smallest scale first
+          for (int k = 10; k >= 0; --k) {
 #pragma unroll
-          for (int q = it.q0; q <= it.q1; ++q)
-            if (i8_slot_k<NG>(it.I, it.K, q) == k) {
-              const double term = (double)A[base + q - it.q0][v];
-              const double sc2 = __hiloint2double((1023 + 80 - 8 * k) << 20, 0);
-              if (i8_slot_kind<NG>(it.I, it.K, q) == 1) qs2[q & 1] = __builtin_fma(term, sc2, qs2[q & 1]);
-              else lo2[q & 1] = __builtin_fma(term, sc2, lo2[q & 1]);
-            }
+            for (int q = it.q0; q <= it.q1; ++q)
+              if (i8_slot_k<NG>(it.I, it.K, q) == k) {
+                const double term = (double)A[base + q - it.q0][v];
+                const double sc2 = __hiloint2double((1023 + 80 - 8 * k) << 20, 0);
+                if (i8_slot_kind<NG>(it.I, it.K, q) == 1) qs2[q & 1] = __builtin_fma(term, sc2, qs2[q & 1]);
+                else lo2[q & 1] = __builtin_fma(term, sc2, lo2[q & 1]);
+              }
+          }
+          const double sc = sctab[i] * scj;
+          const double gqv = (qs2[0] + qs2[1]) * sc;
+          glo[v] = (lo2[0] + lo2[1]) * sc + gqv;
+          mir[il * 33 + jl] = gqv;
+          if ((v & 3) == 3) __builtin_amdgcn_sched_barrier(0);
         }
-        const double lo = lo2[0] + lo2[1], qs = qs2[0] + qs2[1];
-        const double sc = sctab[i] * scj;
-        if constexpr (symt) gq[v] = qs * sc;
-        if (it.I != it.K || i >= j) {  // (off-diagonal tiles lie below the diagonal as a whole)
-          double g = lo * sc;
-          if constexpr (symt) g += (i == j) ? 2.0 * gq[v] : gq[v];
-          if constexpr (it.first) P[pidx(i, j)] = g;
-          else P[pidx(i, j)] += g;
-        }
-        if ((v & 3) == 3) __builtin_amdgcn_sched_barrier(0);  // four entries at a time (their LDS round trips overlap; more would spill)
-      }
-      if constexpr (symt) {  // Q_k(i, j) with i < j belongs to entry (j, i): every lower entry of the tile has been stored / updated above
         __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
-        for (int v0 = 0; v0 < 16; v0 += 8) {  // eight independent read-modify-writes in flight
-          double cur[8];
+        for (int v0 = 0; v0 < 16; v0 += 8) {
+          double tr[8], cur[8];
 #pragma unroll
           for (int v = v0; v < v0 + 8; ++v) {
-            const int i = 32 * it.I + 8 * (v >> 2) + 4 * (lane >> 5) + (v & 3);
-            cur[v - v0] = (i < j) ? P[pidx(j, i)] : 0.0;
+            const int il = 8 * (v >> 2) + 4 * (lane >> 5) + (v & 3), i = 32 * it.I + il;
+            tr[v - v0] = mir[jl * 33 + il];
+            cur[v - v0] = (!it.first && i >= j) ? P[pidx(i, j)] : 0.0;
           }
 #pragma unroll
           for (int v = v0; v < v0 + 8; ++v) {
             const int i = 32 * it.I + 8 * (v >> 2) + 4 * (lane >> 5) + (v & 3);
-            if (i < j) P[pidx(j, i)] = cur[v - v0] + gq[v];
+            if (i >= j) P[pidx(i, j)] = cur[v - v0] + glo[v] + tr[v - v0];
           }
           __builtin_amdgcn_sched_barrier(0);
+        }
+      } else {
+#pragma unroll
+        for (int v = 0; v < 16; ++v) {
+          const int il = 8 * (v >> 2) + 4 * (lane >> 5) + (v & 3), i = 32 * it.I + il;
+          // sum over the slots of (exact integer) x 2^(80 - 8 k): two interleaved partial sums -- a dependent fp64 operation waits for its
+          // predecessor
+          double lo2[2] = {0.0, 0.0};
+#pragma unroll
+          for (int k = 10; k >= 0; --k) {  // smallest scale first
+#pragma unroll
+            for (int q = it.q0; q <= it.q1; ++q)
+              if (i8_slot_k<NG>(it.I, it.K, q) == k) {
+                const double term = (double)A[base + q - it.q0][v];
+                const double sc2 = __hiloint2double((1023 + 80 - 8 * k) << 20, 0);
+                lo2[q & 1] = __builtin_fma(term, sc2, lo2[q & 1]);
+              }
+          }
+          const double sc = sctab[i] * scj;
+          if (it.I != it.K || i >= j) {  // (off-diagonal tiles lie below the diagonal as a whole)
+            const double g = (lo2[0] + lo2[1]) * sc;
+            if constexpr (it.first) P[pidx(i, j)] = g;
+            else P[pidx(i, j)] += g;
+          }
+          if ((v & 3) == 3) __builtin_amdgcn_sched_barrier(0);  // four entries at a time (their LDS round trips overlap; more would spill)
         }
       }
     };
@@ -1036,7 +1077,9 @@ __global__ __launch_bounds__(kI8Threads, 2) void fused_i8_kernel(PosteriorArgs<d
     if (valid) convert_all(convert_all, std::integral_constant<int, 0>{}, std::integral_constant<int, 2>{});
     I8_KSTAMP(11);
     __syncthreads();
+    I8_KSTAMP(16);
     if (valid) i8_table_pass(smem, winv);
+    I8_KSTAMP(17);
   };
   switch (wave) {
     case 0: run(std::integral_constant<int, 0>{}); break;

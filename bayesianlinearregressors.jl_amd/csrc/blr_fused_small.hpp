@@ -1226,6 +1226,38 @@ BLR_PHASE int phase_chol(char* smem, int D_in, int with_rhs_in) {
     // t = a_ic / d2, update a_ik -= t * a_kc, b_i -= t * b_c), so the serial chain per column is
     // readlane -> reciprocal -> multiply -> fma; the square root is taken off the critical path afterwards.
     T own_rsq = T(1);
+    if (ncols == 16) {  // (scalar) a full panel -- every panel when 16 | D
+      // One basic block, software-pipelined by hand: the serial chain of a column is  multiplier -> update of column c + 1 -> its pivot by
+      // readlane -> reciprocal (five dependent operations), and the other 14 - c updates of column c are independent of it -- so the next
+      // pivot's reciprocal is started right after the first update and the rest of the updates fill its latency.  The square roots leave the
+      // loop altogether: the pivots stay unscaled in lane c's arow[c], ONE reciprocal square root over the 16 lanes afterwards, and the
+      // columns are scaled by readlane.  Operation for operation the same arithmetic as the generic loop below (bit-identical L, u);
+      // as 16 per-column blocks with the rsqrt chain inside each, the elimination was 410 cycles per column.
+      T d2 = readlane(arow[0], 0);
+      T rc = fast_rcp(d2);
+#pragma unroll
+      for (int c = 0; c < 16; ++c) {
+        if (!(d2 > T(0))) {  // wave-uniform (SGPR) and identical in all four waves
+          if (info == 0) info = 16 * J + c + 1;
+        }
+        const T t = arow[c] * rc;
+        if (c + 1 < 16) {
+          arow[c + 1] = fused_madd(-t, readlane(arow[c], c + 1), arow[c + 1]);
+          d2 = readlane(arow[c + 1], c + 1);
+          rc = fast_rcp(d2);
+        }
+        const T bc = readlane(bl, c);
+        if (lane > c) bl = fused_madd(-t, bc, bl);
+#pragma unroll
+        for (int k = c + 2; k < 16; ++k) arow[k] = fused_madd(-t, readlane(arow[c], k), arow[k]);  // unscaled A[16J + k][16J + c]
+      }
+      T piv = T(1);
+#pragma unroll
+      for (int c = 0; c < 16; ++c) piv = (lane == c) ? arow[c] : piv;
+      own_rsq = fast_rsqrt(piv);
+#pragma unroll
+      for (int c = 0; c < 16; ++c) arow[c] *= readlane(own_rsq, c);  // L[i][c] = a_ic / sqrt(d2); lane c: d2 / sqrt(d2)
+    } else {
 #pragma unroll
     for (int c = 0; c < 16; ++c) {
       if (c < ncols) {
@@ -1235,16 +1267,17 @@ BLR_PHASE int phase_chol(char* smem, int D_in, int with_rhs_in) {
         }
         const T t = arow[c] * fast_rcp(d2);
         const T bc = readlane(bl, c);
-        if (lane > c) bl -= t * bc;
+        if (lane > c) bl = fused_madd(-t, bc, bl);
 #pragma unroll
         for (int k = c + 1; k < 16; ++k) {
           const T akc = readlane(arow[c], k);  // unscaled A[16J + k][16J + c]
-          arow[k] -= t * akc;
+          arow[k] = fused_madd(-t, akc, arow[k]);
         }
         const T rsq = fast_rsqrt(d2);
         if (lane == c) own_rsq = rsq;
         arow[c] = (lane == c) ? d2 * rsq : arow[c] * rsq;  // L[i][c] = a_ic / sqrt(d2); diagonal = sqrt(d2)
       }
+    }
     }
     if (is_diag) bl *= own_rsq;  // u_c = b_c / L_cc for the diagonal-block rows
     BLR_STAMP(3);
@@ -1300,7 +1333,7 @@ BLR_PHASE int phase_chol(char* smem, int D_in, int with_rhs_in) {
 // Returns through LDS: bvec <- m (rows < D), scr[6] = |u|^2, scr[7] = logdet A.
 // =========================================================================================================
 #ifdef BLR_I8_STAMPS
-__device__ unsigned long long g_i8stamps[8][16];  // (tools/i8_gram.hip; slots 12 - 15: inside phase_backsolve)
+__device__ unsigned long long g_i8stamps[8][20];  // (tools/i8_gram.hip; slots 12 - 15: inside phase_backsolve)
 #define BLR_BS_STAMP(slot) do { const unsigned long long t__ = __builtin_amdgcn_s_memtime(); if ((blockIdx.x % 257) == 0 && (threadIdx.x & 63) == 0) atomicAdd(&g_i8stamps[threadIdx.x >> 6][slot], t__ - bs_prev); bs_prev = t__; } while (0)
 #define BLR_BS_STAMP_DECL unsigned long long bs_prev = __builtin_amdgcn_s_memtime()
 #else

@@ -4,7 +4,9 @@
 #include <cstdio>
 #include <vector>
 #include <cmath>
+#include <cstdlib>
 #include "blr_fused_small.hpp"
+#include "blr_chol_dpp.hpp"
 #ifndef BLR_STAMPS
 namespace blr { __device__ unsigned long long g_stamps[8]; }
 #endif
@@ -28,6 +30,77 @@ __global__ __launch_bounds__(256, 2) void k(const T* A, T* out, int* info, int r
   }
   if (tid == 0) info[blockIdx.x] = rc;
   for (int idx = tid; idx < 128 * 128; idx += 256) { int c = idx >> 7, r = idx & 127; if (r >= c) out[c * 128 + r] = P[pidx(r, c)]; }
+}
+
+constexpr int kOffW = (SmallCfg<double, 8>::LDS_BYTES + 15) & ~15, kOffU = kOffW + 16384, kLds2 = kOffU + 1024;
+__global__ __launch_bounds__(256, 2) void k2(const double* A, double* out, double* uout, int* info, int reps, int which) {
+  using C = SmallCfg<double, 8>;
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  double* P = reinterpret_cast<double*>(smem);
+  double* bvec = reinterpret_cast<double*>(smem + C::OFF_B);
+  const int tid = threadIdx.x;
+  int rc = 0;
+  for (int rep = 0; rep < reps; ++rep) {
+    __syncthreads();
+    for (int idx = tid; idx < 128 * 128; idx += 256) { int c = idx >> 7, r = idx & 127; if (r >= c) P[pidx(r, c)] = A[c * 128 + r]; }
+    if (tid < 128) bvec[tid] = 1.0 + 0.01 * tid;
+    __syncthreads();
+    rc = which ? chol128_dpp<kOffW, kOffU>(smem) : phase_chol<double, 8>(smem, 128, 1);
+  }
+  if (tid == 0) info[blockIdx.x] = rc;
+  for (int idx = tid; idx < 128 * 128; idx += 256) { int c = idx >> 7, r = idx & 127; if (r >= c) out[c * 128 + r] = P[pidx(r, c)]; }
+  if (tid < 128) uout[tid] = bvec[tid];
+  if (which) for (int idx = tid; idx < 2048; idx += 256) uout[128 + idx] = reinterpret_cast<double*>(smem + kOffW)[idx];
+}
+
+int run2() {
+  std::vector<double> A(128 * 128);
+  for (int c = 0; c < 128; ++c) for (int r = 0; r < 128; ++r) A[c * 128 + r] = ((r == c ? 200.0 : 0.0) + std::cos(0.37 * (r + 1) * (c + 1)));
+  for (int c = 0; c < 128; ++c) for (int r = 0; r < c; ++r) A[c * 128 + r] = A[r * 128 + c];
+  double *dA, *dO, *dU; int* dI;
+  CK(hipMalloc((void**)&dA, A.size() * 8)); CK(hipMalloc((void**)&dO, A.size() * 8)); CK(hipMalloc((void**)&dU, (128 + 2048) * 8)); CK(hipMalloc((void**)&dI, 4096));
+  CK(hipMemcpy(dA, A.data(), A.size() * 8, hipMemcpyHostToDevice));
+  CK(hipFuncSetAttribute(reinterpret_cast<const void*>(k2), hipFuncAttributeMaxDynamicSharedMemorySize, kLds2));
+  hipEvent_t e0, e1; CK(hipEventCreate(&e0)); CK(hipEventCreate(&e1));
+  const int reps = 50;
+  unsigned long long zero[8] = {0};
+  std::vector<double> L[2], U[2];
+  for (int which = 0; which < 2; ++which) {
+    for (int grid : {1, 256}) {
+      float ms;
+      k2<<<grid, 256, kLds2>>>(dA, dO, dU, dI, 2, which);
+      CK(hipMemcpyToSymbol(HIP_SYMBOL(g_stamps), zero, sizeof(zero)));
+      CK(hipEventRecord(e0));
+      k2<<<grid, 256, kLds2>>>(dA, dO, dU, dI, reps, which);
+      CK(hipEventRecord(e1)); CK(hipEventSynchronize(e1)); CK(hipEventElapsedTime(&ms, e0, e1));
+      unsigned long long st[8];
+      CK(hipMemcpyFromSymbol(st, HIP_SYMBOL(g_stamps), sizeof(st)));
+      int info; CK(hipMemcpy(&info, dI, 4, hipMemcpyDeviceToHost));
+      printf("%s grid=%d: %.2f us per factorisation (info=%d)", which ? "chol128_dpp" : "phase_chol ", grid, ms * 1e3 / reps, info);
+      if (grid == 1) {
+        if (which) printf("  cycles/fact: load-tiles %llu | barrier %llu | diag tile factor + inverse %llu | u_J, stores, solves %llu | barrier %llu | r update + trailing %llu",
+               st[0] / reps, st[1] / reps, st[2] / reps, st[3] / reps, st[4] / reps, st[5] / reps);
+        else printf("  cycles/fact: load-tiles %llu | barrier %llu | (a) store panel %llu | (b) eliminate %llu | writeback+barrier %llu | (c) trailing %llu",
+               st[0] / reps, st[1] / reps, st[2] / reps, st[3] / reps, st[4] / reps, st[5] / reps);
+      }
+      printf("\n");
+    }
+    L[which].resize(128 * 128); U[which].resize(128 + 2048);
+    CK(hipMemcpy(L[which].data(), dO, 128 * 128 * 8, hipMemcpyDeviceToHost));
+    CK(hipMemcpy(U[which].data(), dU, (128 + 2048) * 8, hipMemcpyDeviceToHost));
+  }
+  double dl = 0, du = 0, ml = 0, mu = 0;
+  for (int c = 0; c < 128; ++c) for (int r = c; r < 128; ++r) { dl = fmax(dl, fabs(L[0][c * 128 + r] - L[1][c * 128 + r])); ml = fmax(ml, fabs(L[0][c * 128 + r])); }
+  for (int i = 0; i < 128; ++i) { du = fmax(du, fabs(U[0][i] - U[1][i])); mu = fmax(mu, fabs(U[0][i])); }
+  // W_J L_JJ = I ?
+  double dw = 0;
+  for (int J = 0; J < 8; ++J) for (int i = 0; i < 16; ++i) for (int c = 0; c < 16; ++c) {
+    double s = 0;
+    for (int k = 0; k < 16; ++k) { const int rr = 16 * J + k, cc = 16 * J + c; s += U[1][128 + (16 * J + i) * 16 + k] * (rr >= cc ? L[1][cc * 128 + rr] : 0.0); }
+    dw = fmax(dw, fabs(s - (i == c ? 1.0 : 0.0)));
+  }
+  printf("chol128_dpp vs phase_chol: max |dL| %.3e (max |L| %.3e) | max |du| %.3e (max |u| %.3e) | max |W_J L_JJ - I| %.3e\n", dl, ml, du, mu, dw);
+  return 0;
 }
 
 template <typename T>
@@ -54,7 +127,12 @@ int run(const char* name) {
     unsigned long long st[8];
     CK(hipMemcpyFromSymbol(st, HIP_SYMBOL(g_stamps), sizeof(st)));
     int info; CK(hipMemcpy(&info, dI, 4, hipMemcpyDeviceToHost));
-    printf("%s grid=%d: %.2f us per factorisation (info=%d)", name, grid, ms * 1e3 / reps, info);
+    std::vector<T> O(128 * 128);
+    CK(hipMemcpy(O.data(), dO, O.size() * sizeof(T), hipMemcpyDeviceToHost));
+    unsigned long long hsh = 1469598103934665603ull;  // FNV-1a over the lower triangle: a bit-for-bit fingerprint of L
+    for (int c = 0; c < 128; ++c) for (int r = c; r < 128; ++r) { const unsigned char* b = reinterpret_cast<const unsigned char*>(&O[c * 128 + r]); for (size_t q = 0; q < sizeof(T); ++q) { hsh ^= b[q]; hsh *= 1099511628211ull; } }
+    if (const char* dp = getenv("CHOL_DUMP")) { if (grid == 1) { char fn[256]; snprintf(fn, sizeof fn, "%s_%s.bin", dp, name); FILE* f = fopen(fn, "wb"); fwrite(O.data(), sizeof(T), O.size(), f); fclose(f); } }
+    printf("%s grid=%d: %.2f us per factorisation (info=%d, L fingerprint %016llx)", name, grid, ms * 1e3 / reps, info, hsh);
     if (grid == 1) {
       printf("  cycles/fact: load-tiles %llu | barrier %llu | (a) store panel %llu | (b) eliminate %llu | writeback+barrier %llu | (c) trailing %llu",
              st[0] / reps, st[1] / reps, st[2] / reps, st[3] / reps, st[4] / reps, st[5] / reps);
@@ -63,4 +141,4 @@ int run(const char* name) {
   }
   return 0;
 }
-int main() { run<float>("f32"); run<double>("f64"); return 0; }
+int main(int argc, char** argv) { if (argc > 1) return run2(); run<float>("f32"); run<double>("f64"); return 0; }

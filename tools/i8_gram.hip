@@ -105,7 +105,7 @@ int main(int argc, char** argv) {
   CK(hipDeviceSynchronize());
 #ifdef BLR_I8_STAMPS
   {
-    unsigned long long z[8][16] = {};
+    unsigned long long z[8][20] = {};
     CK(hipMemcpyToSymbol(HIP_SYMBOL(g_i8stamps), z, sizeof(z)));
     PosteriorArgs<T> a = args(0);
     hipLaunchKernelGGL(ki8, dim3(B), dim3(kI8Threads), I8Cfg::LDS_BYTES, 0, a);
@@ -134,8 +134,8 @@ int main(int argc, char** argv) {
       printf("    wave %d back substitution in detail: reciprocal pivots + barrier %6.0f | substitution (wave 0) / T written (waves 1-3) %6.0f | logdet %6.0f | closing barrier %6.0f\n",
              w, z[w][12] / nwg, z[w][13] / nwg, z[w][14] / nwg, z[w][15] / nwg);
     for (int w = 0; w < 8; ++w)
-      printf("    wave %d hand-over in detail: sums + tables + barriers %6.0f | conversion phase 0 %6.0f | (barrier +) phase 1 %6.0f | (barrier +) phase 2 %6.0f | rest (barrier, tail columns) %6.0f\n",
-             w, z[w][8] / nwg, z[w][9] / nwg, z[w][10] / nwg, z[w][11] / nwg, z[w][5] / nwg);
+      printf("    wave %d hand-over in detail: sums + tables + barriers %6.0f | conversion phase 0 %6.0f | (barrier +) phase 1 %6.0f | (barrier +) phase 2 %6.0f | barrier %6.0f | table pass %6.0f | rest (b, y'y, barrier) %6.0f\n",
+             w, z[w][8] / nwg, z[w][9] / nwg, z[w][10] / nwg, z[w][11] / nwg, z[w][16] / nwg, z[w][17] / nwg, z[w][5] / nwg);
   }
 #endif
   // compare
