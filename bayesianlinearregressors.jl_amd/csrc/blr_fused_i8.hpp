@@ -659,7 +659,7 @@ __device__ __forceinline__ void i8_gram_stream(char* smem, const BLR_GLOBAL doub
 // per-wave instances of the stream they added 30 KB to a kernel whose straight-line hand-over code already overflows the
 // instruction cache once per regressor
 template <int NG>
-__device__ __attribute__((noinline)) void i8_build_tables(char* smem, int N32_in, double Cmagic, int fac_in, const BLR_GLOBAL double* Lw) {
+static __device__ __attribute__((noinline, not_tail_called)) void i8_build_tables(char* smem, int N32_in, double Cmagic, int fac_in, const BLR_GLOBAL double* Lw) {
   using C = I8Cfg;
   const int* const xch = reinterpret_cast<const int*>(smem + C::OFF_XCH);
   double* const sctab = reinterpret_cast<double*>(smem + C::OFF_SC);
@@ -734,7 +734,7 @@ __device__ __attribute__((noinline)) void i8_build_tables(char* smem, int N32_in
     }
 }
 
-__device__ __attribute__((noinline)) void i8_table_pass(char* smem, double winv) {
+static __device__ __attribute__((noinline, not_tail_called)) void i8_table_pass(char* smem, double winv) {
   using C = I8Cfg;
   double* const P = reinterpret_cast<double*>(smem);
   double* const gdiag = reinterpret_cast<double*>(smem + C::OFF_GD);
@@ -806,7 +806,7 @@ __device__ __attribute__((noinline)) void i8_table_pass(char* smem, double winv)
 //     r_K -= L_JK' m_J    for the rows K < J (lane = column of L, m_J by v_readlane)
 // on wave 0, while waves 1 - 3 write T = L'.  Same interface as phase_backsolve: on entry P = L (packed), bvec = u; on exit bvec = m,
 // scr[6] = |u|^2, scr[7] = logdet A.  Four-wave code (the waves that survive the hand-over).
-__device__ __attribute__((noinline)) void i8_backsolve_blocked(char* smem, double* Tout_in, int64_t ldt_in) {
+static __device__ __attribute__((noinline, not_tail_called)) void i8_backsolve_blocked(char* smem, double* Tout_in, int64_t ldt_in) {
   using SC = SmallCfg<double, 8>;
   constexpr int D = 128;
   double* const P = reinterpret_cast<double*>(smem);

@@ -43,7 +43,13 @@
 #if BLR_PHASE_INLINE
 #define BLR_PHASE __device__ __forceinline__
 #else
-#define BLR_PHASE __device__ __attribute__((noinline))
+// `static` + `not_tail_called`: with internal linkage and no call site marked `tail`, LLVM's interprocedural register allocation
+// (on by default for AMDGPU) applies its no-callee-saved-registers optimisation -- TargetFrameLowering::isSafeForNoCSROpt wants a local,
+// non-recursive function none of whose calls is a tail call, and the optimiser marks every call of a function that takes no stack
+// pointer `tail`.  Without the two attributes a phase that uses all 256 registers saves the ABI's ~125 callee-saved ones at its entry
+// and restores them at its exit for a caller that keeps nothing in them: 612 B per lane of scratch in fused_small_kernel<double, 8, 4>
+// (500 of them phase_gram's), ~0.9 MB of scratch traffic per regressor next to 4.2 MB of X.  With them: 252 B, of which the phases 60.
+#define BLR_PHASE static __device__ __attribute__((noinline, not_tail_called))
 #endif
 
 namespace blr {

@@ -170,18 +170,23 @@ def test_hot_kernels_keep_two_workgroups_per_cu(tmp_path):
     i8 = {k: v for k, v in kernels.items() if "fused_i8_kernel" in k}
     n_i8 = 1 if "asan" in os.path.basename(str(_abi.LIB_PATH)) else 4  # (the sanitizer build carries one form: BLR_DEV_FAST)
     assert len(i8) == n_i8 and max(i8.values()) <= 256, f"the four forms of the int8-sliced kernel (8 waves of 256 registers): {i8}"
-    # vector-register spills of the headline kernel: none in the isotropic forms (the diagonal-noise RowVecs form keeps one)
-    spills, name = {}, None
+    # Scratch of the hot kernels.  The phase functions have internal linkage and no tail-called call site, so LLVM's
+    # interprocedural register allocation drops their callee-saved-register saves (blr_fused_small.hpp, BLR_PHASE); what is left is
+    # the few values a kernel keeps across its calls, which the code object now books as the KERNEL's spills.  The honest measure is
+    # the scratch per lane: 612 B (fp64 fallback kernel) and 320 B (int8 kernel) before.
+    scratch, spills, name = {}, {}, None
     for line in notes.splitlines():
-        m = re.match(r"\s+(?:- )?\.(name|vgpr_spill_count):\s+(\S+)", line)
+        m = re.match(r"\s+(?:- )?\.(name|private_segment_fixed_size|vgpr_spill_count):\s+(\S+)", line)
         if m and m.group(1) == "name":
             name = m.group(2)
         elif m and name is not None:
-            spills[name] = int(m.group(2))
-    i8_spills = {k: v for k, v in spills.items() if "fused_i8_kernel" in k}
-    assert len(i8_spills) == n_i8
-    assert all(v == 0 for k, v in i8_spills.items() if "ILb0E" in k), f"isotropic int8 kernels must not spill vector registers: {i8_spills}"
-    assert max(i8_spills.values()) <= 2, i8_spills
+            (scratch if m.group(1) == "private_segment_fixed_size" else spills)[name] = int(m.group(2))
+    i8_scratch = {k: v for k, v in scratch.items() if "fused_i8_kernel" in k}
+    assert len(i8_scratch) == n_i8
+    assert max(i8_scratch.values()) <= 64, f"int8 kernels: bytes of scratch per lane {i8_scratch}"
+    assert max(v for k, v in spills.items() if "fused_i8_kernel" in k) <= 8
+    fb = {k: v for k, v in scratch.items() if "fused_small_kernelIdLi8ELi4" in k}
+    assert len(fb) == 1 and max(fb.values()) <= 256, f"fp64 fallback kernel: bytes of scratch per lane {fb}"
 
 
 def test_julia_shim_ccall_signatures_match_the_header(repo_root):

@@ -271,4 +271,173 @@ __device__ __attribute__((noinline)) int chol128_dpp(char* smem) {
   return info;
 }
 
+// ---- the same factorisation with the serial part on ONE wave ---------------------------------------------------------------------------------
+// chol128_dpp lets every wave factor the diagonal tile: 2.8 k cycles per tile that no wave spends on anything else (the tile is bound by
+// the ISSUE of its ~350 fp64 instructions on one wave, not by their latency), then solves and updates -- 60 k cycles per factorisation,
+// no better than phase_chol.  Here wave 0 is the CHAIN wave, it owns block row J + 1 at step J and never waits for the bulk of a trailing
+// update; the trailing matrix stays in LDS (any wave takes any tile).  Per block column J, two barriers:
+//   B2  chain wave: solve tile (J+1, J), r_{J+1} -= L u_J, update tile (J+1, J+1)   |  waves 1 - 3: solve the tiles (I, J), I > J + 1,
+//                                                                                   |  and take r_I -= L_IJ u_J along
+//   B3  chain wave: factor + invert tile (J+1, J+1); L, W, u to LDS                 |  waves 1 - 3: trailing update J of every other tile
+template <int OFF_W, int OFF_U>
+__device__ __attribute__((noinline)) int chol128_cw(char* smem) {
+  using T = double;
+  using C = SmallCfg<double, 8>;
+  using acc4 = typename Mfma<T>::acc4;
+  T* const P = reinterpret_cast<T*>(smem);
+  T* const bvec = reinterpret_cast<T*>(smem + C::OFF_B);
+  T* const Wst = reinterpret_cast<T*>(smem + OFF_W);
+  T* const ust = reinterpret_cast<T*>(smem + OFF_U);
+  int* const iscr = reinterpret_cast<int*>(smem + C::OFF_SCR + 64);
+  int tid = threadIdx.x;
+  asm volatile("" : "+v"(tid));
+  const int lane = tid & 63;
+  const int wave = uni(tid >> 6);
+  const int r = lane & 15, q = lane >> 4;
+  const int pr = (r * (r + 1)) >> 1;  // pidx(r, 0)
+  T* const dummy = reinterpret_cast<T*>(smem + C::OFF_DINV) + r;
+  int cr[4], pcr[4];  // C-layout rows of this lane inside a tile, and pidx(cr, 0)
+#pragma unroll
+  for (int v = 0; v < 4; ++v) {
+    cr[v] = Mfma<T>::crow(lane, v);
+    pcr[v] = (cr[v] * (cr[v] + 1)) >> 1;
+  }
+  // P_IK -= L_IJ L_KJ' for TWO tiles of the trailing matrix at a time, in place (diagonal tiles: the lower half).  `two` false: the
+  // second tile is absent (its reads repeat the first tile's, its writes go to the dump word).
+  auto update_tiles = [&](int I0, int K0, int I1, int K1, bool two, int J) {
+    const int bI0 = 128 * I0 * I0 + 8 * I0, bK0 = 128 * K0 * K0 + 8 * K0;  // pidx(16 I, 0)
+    const int bI1 = 128 * I1 * I1 + 8 * I1, bK1 = 128 * K1 * K1 + 8 * K1;
+    const int fo = pr + 16 * J + q;
+    const T* pI0 = P + (bI0 + 16 * I0 * r + fo);  // pidx(16 I + r, 16 J + q)
+    const T* pK0 = P + (bK0 + 16 * K0 * r + fo);
+    const T* pI1 = P + (bI1 + 16 * I1 * r + fo);
+    const T* pK1 = P + (bK1 + 16 * K1 * r + fo);
+    T fa0[4], fb0[4], fa1[4], fb1[4];
+#pragma unroll
+    for (int ks = 0; ks < 4; ++ks) { fa0[ks] = pI0[4 * ks]; fb0[ks] = pK0[4 * ks]; fa1[ks] = pI1[4 * ks]; fb1[ks] = pK1[4 * ks]; }
+    T *pc0[4], *pc1[4];
+    acc4 acc0, acc1;
+#pragma unroll
+    for (int v = 0; v < 4; ++v) {
+      pc0[v] = (I0 != K0 || r <= cr[v]) ? P + (bI0 + 16 * I0 * cr[v] + pcr[v] + 16 * K0 + r) : dummy;
+      pc1[v] = (two && (I1 != K1 || r <= cr[v])) ? P + (bI1 + 16 * I1 * cr[v] + pcr[v] + 16 * K1 + r) : dummy;
+      acc0[v] = *pc0[v];
+      acc1[v] = *pc1[v];
+    }
+#pragma unroll
+    for (int ks = 0; ks < 4; ++ks) {
+      acc0 = Mfma<T>::mma(-fa0[ks], fb0[ks], acc0);
+      acc1 = Mfma<T>::mma(-fa1[ks], fb1[ks], acc1);
+    }
+#pragma unroll
+    for (int v = 0; v < 4; ++v) { *pc0[v] = acc0[v]; *pc1[v] = acc1[v]; }
+  };
+  // L_IJ = A_IJ L_JJ^-T (B fragment = W_J) for one tile, then r_I -= L_IJ u_J from the solved tile's own fragments
+  auto solve_row = [&](int I, int J, const T (&w)[4], const T (&uq)[4]) {
+    const int tb = (128 * I * I + 8 * I) + 16 * J;   // pidx(16 I, 16 J)
+    const T* pa = P + (tb + 16 * I * r + pr + q);    // pidx(16 I + r, 16 J + q)
+    T fa[4];
+#pragma unroll
+    for (int ks = 0; ks < 4; ++ks) fa[ks] = pa[4 * ks];
+    acc4 x = {T(0), T(0), T(0), T(0)};
+#pragma unroll
+    for (int ks = 0; ks < 4; ++ks) x = Mfma<T>::mma(fa[ks], w[ks], x);
+#pragma unroll
+    for (int v = 0; v < 4; ++v) P[tb + 16 * I * cr[v] + pcr[v] + r] = x[v];  // L(16 I + cr, 16 J + r)
+    T sacc = T(0);
+#pragma unroll
+    for (int j = 0; j < 4; ++j) sacc = __builtin_fma(pa[4 * j], uq[j], sacc);  // (the wave's own stores: in order)
+    sacc += xor_lanes(sacc, 16);
+    sacc += xor_lanes(sacc, 32);
+    if (q == 0) bvec[16 * I + r] -= sacc;
+  };
+  // the chain wave's tile: factor + invert (J, J); L_JJ, W_J, u_J = W_J r_J and the verdict on the pivots to LDS
+  auto factor_tile = [&](int J) {
+    T* const rowp = P + ((128 * J * J + 8 * J) + 16 * J * r + pr + 16 * J);  // pidx(16 J + r, 16 J)
+    T a[16], y[4], rsr, rj[4];
+#pragma unroll
+    for (int c = 0; c < 16; ++c) a[c] = rowp[c];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) rj[j] = bvec[16 * J + 4 * j + q];
+    tile_factor_invert_f64h(a, y, rsr, lane);
+    const uint64_t badm = __ballot(!(rsr > T(0) && rsr < __builtin_inf()));  // a non-positive pivot: +inf or NaN from there on
+    if (lane == 0) iscr[7] = (badm != 0) ? 16 * J + __builtin_ctzll(badm) + 1 : 0;
+    T w[4], up = T(0);  // w = (L_JJ^-1)(r, 4 j + q)
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      w[j] = y[j] * rsr;
+      up = __builtin_fma(w[j], rj[j], up);
+    }
+    up += xor_lanes(up, 16);
+    up += xor_lanes(up, 32);
+#pragma unroll
+    for (int j = 0; j < 4; ++j) Wst[(16 * J + r) * 16 + 4 * j + q] = w[j];
+    if (q == 0) {
+      ust[16 * J + r] = up;
+#pragma unroll
+      for (int c = 0; c < 16; ++c) {
+        T* dst = (c <= r) ? rowp + c : dummy;
+        *dst = a[c];
+      }
+    }
+  };
+
+  int info = 0;
+  BLR_STAMP_INIT;
+  __syncthreads();
+  BLR_STAMP(0);
+  if (wave == 0) factor_tile(0);
+  BLR_STAMP(1);
+#pragma unroll 1
+  for (int J = 0; J < 8; ++J) {
+    __syncthreads();  // B2: L_JJ, W_J, u_J and the verdict on the pivots are in LDS; trailing update J - 1 is complete
+    BLR_STAMP(2);
+    info = iscr[7];
+    if (info != 0 || J == 7) break;  // (uniform)
+    {
+      T w[4], uq[4];
+#pragma unroll
+      for (int j = 0; j < 4; ++j) { w[j] = Wst[(16 * J + r) * 16 + 4 * j + q]; uq[j] = ust[16 * J + 4 * j + q]; }
+      if (wave == 0) {
+        solve_row(J + 1, J, w, uq);
+        update_tiles(J + 1, J + 1, J + 1, J + 1, false, J);
+      } else {
+#pragma unroll 1
+        for (int I = J + 1 + wave; I < 8; I += 3) solve_row(I, J, w, uq);
+      }
+    }
+    BLR_STAMP(3);
+    __syncthreads();  // B3: block column J of L is in P, tile (J + 1, J + 1) is final
+    BLR_STAMP(4);
+    if (wave == 0) {
+      factor_tile(J + 1);
+    } else {
+      // trailing update J of the tiles (I, K), J + 1 <= K <= I <= 7, without (J + 1, J + 1): dealt over the three update waves in pairs
+      const int n1 = 7 - J;  // tiles per edge
+      const int nt = n1 * (n1 + 1) / 2;
+      auto tile_of = [&](int t, int& I, int& K) {
+        int i = 0;
+#pragma unroll
+        for (int k = 1; k < 7; ++k) i += (t >= k * (k + 1) / 2) ? 1 : 0;
+        I = J + 1 + i;
+        K = J + 1 + t - i * (i + 1) / 2;
+      };
+#pragma unroll 1
+      for (int t = wave; t < nt; t += 6) {  // (t = 0 is the chain wave's tile)
+        int I0, K0, I1, K1;
+        const bool two = t + 3 < nt;
+        tile_of(t, I0, K0);
+        tile_of(two ? t + 3 : t, I1, K1);
+        update_tiles(I0, K0, I1, K1, two, J);
+      }
+    }
+    BLR_STAMP(5);
+  }
+  __syncthreads();
+  if (info == 0 && tid < 128) bvec[tid] = ust[tid];
+  __syncthreads();
+  BLR_STAMP_FLUSH;
+  return info;
+}
+
 }  // namespace blr

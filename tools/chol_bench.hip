@@ -6,7 +6,7 @@
 #include <cmath>
 #include <cstdlib>
 #include "blr_fused_small.hpp"
-#include "blr_chol_dpp.hpp"
+#include "blr_chol_dpp_experiment.hpp"
 #ifndef BLR_STAMPS
 namespace blr { __device__ unsigned long long g_stamps[8]; }
 #endif
@@ -45,7 +45,7 @@ __global__ __launch_bounds__(256, 2) void k2(const double* A, double* out, doubl
     for (int idx = tid; idx < 128 * 128; idx += 256) { int c = idx >> 7, r = idx & 127; if (r >= c) P[pidx(r, c)] = A[c * 128 + r]; }
     if (tid < 128) bvec[tid] = 1.0 + 0.01 * tid;
     __syncthreads();
-    rc = which ? chol128_dpp<kOffW, kOffU>(smem) : phase_chol<double, 8>(smem, 128, 1);
+    rc = which == 2 ? chol128_cw<kOffW, kOffU>(smem) : (which ? chol128_dpp<kOffW, kOffU>(smem) : phase_chol<double, 8>(smem, 128, 1));
   }
   if (tid == 0) info[blockIdx.x] = rc;
   for (int idx = tid; idx < 128 * 128; idx += 256) { int c = idx >> 7, r = idx & 127; if (r >= c) out[c * 128 + r] = P[pidx(r, c)]; }
@@ -64,8 +64,8 @@ int run2() {
   hipEvent_t e0, e1; CK(hipEventCreate(&e0)); CK(hipEventCreate(&e1));
   const int reps = 50;
   unsigned long long zero[8] = {0};
-  std::vector<double> L[2], U[2];
-  for (int which = 0; which < 2; ++which) {
+  std::vector<double> L[3], U[3];
+  for (int which = 0; which < 3; ++which) {
     for (int grid : {1, 256}) {
       float ms;
       k2<<<grid, 256, kLds2>>>(dA, dO, dU, dI, 2, which);
@@ -76,9 +76,11 @@ int run2() {
       unsigned long long st[8];
       CK(hipMemcpyFromSymbol(st, HIP_SYMBOL(g_stamps), sizeof(st)));
       int info; CK(hipMemcpy(&info, dI, 4, hipMemcpyDeviceToHost));
-      printf("%s grid=%d: %.2f us per factorisation (info=%d)", which ? "chol128_dpp" : "phase_chol ", grid, ms * 1e3 / reps, info);
+      printf("%s grid=%d: %.2f us per factorisation (info=%d)", which == 2 ? "chol128_cw " : (which ? "chol128_dpp" : "phase_chol "), grid, ms * 1e3 / reps, info);
       if (grid == 1) {
-        if (which) printf("  cycles/fact: load-tiles %llu | barrier %llu | diag tile factor + inverse %llu | u_J, stores, solves %llu | barrier %llu | r update + trailing %llu",
+        if (which == 2) printf("  chain wave, cycles/fact: first tile %llu | wait B2 %llu | solve row J+1 + update its diagonal tile %llu | wait B3 %llu | factor + invert + stores %llu",
+               st[1] / reps, st[2] / reps, st[3] / reps, st[4] / reps, st[5] / reps);
+        else if (which) printf("  cycles/fact: load-tiles %llu | barrier %llu | diag tile factor + inverse %llu | u_J, stores, solves %llu | barrier %llu | r update + trailing %llu",
                st[0] / reps, st[1] / reps, st[2] / reps, st[3] / reps, st[4] / reps, st[5] / reps);
         else printf("  cycles/fact: load-tiles %llu | barrier %llu | (a) store panel %llu | (b) eliminate %llu | writeback+barrier %llu | (c) trailing %llu",
                st[0] / reps, st[1] / reps, st[2] / reps, st[3] / reps, st[4] / reps, st[5] / reps);
@@ -89,17 +91,18 @@ int run2() {
     CK(hipMemcpy(L[which].data(), dO, 128 * 128 * 8, hipMemcpyDeviceToHost));
     CK(hipMemcpy(U[which].data(), dU, (128 + 2048) * 8, hipMemcpyDeviceToHost));
   }
+  for (int w = 1; w < 3; ++w) {
   double dl = 0, du = 0, ml = 0, mu = 0;
-  for (int c = 0; c < 128; ++c) for (int r = c; r < 128; ++r) { dl = fmax(dl, fabs(L[0][c * 128 + r] - L[1][c * 128 + r])); ml = fmax(ml, fabs(L[0][c * 128 + r])); }
-  for (int i = 0; i < 128; ++i) { du = fmax(du, fabs(U[0][i] - U[1][i])); mu = fmax(mu, fabs(U[0][i])); }
-  // W_J L_JJ = I ?
-  double dw = 0;
+  for (int c = 0; c < 128; ++c) for (int r = c; r < 128; ++r) { dl = fmax(dl, fabs(L[0][c * 128 + r] - L[w][c * 128 + r])); ml = fmax(ml, fabs(L[0][c * 128 + r])); }
+  for (int i = 0; i < 128; ++i) { du = fmax(du, fabs(U[0][i] - U[w][i])); mu = fmax(mu, fabs(U[0][i])); }
+  double dw = 0;  // W_J L_JJ = I ?
   for (int J = 0; J < 8; ++J) for (int i = 0; i < 16; ++i) for (int c = 0; c < 16; ++c) {
     double s = 0;
-    for (int k = 0; k < 16; ++k) { const int rr = 16 * J + k, cc = 16 * J + c; s += U[1][128 + (16 * J + i) * 16 + k] * (rr >= cc ? L[1][cc * 128 + rr] : 0.0); }
+    for (int k = 0; k < 16; ++k) { const int rr = 16 * J + k, cc = 16 * J + c; s += U[w][128 + (16 * J + i) * 16 + k] * (rr >= cc ? L[w][cc * 128 + rr] : 0.0); }
     dw = fmax(dw, fabs(s - (i == c ? 1.0 : 0.0)));
   }
-  printf("chol128_dpp vs phase_chol: max |dL| %.3e (max |L| %.3e) | max |du| %.3e (max |u| %.3e) | max |W_J L_JJ - I| %.3e\n", dl, ml, du, mu, dw);
+  printf("%s vs phase_chol: max |dL| %.3e (max |L| %.3e) | max |du| %.3e (max |u| %.3e) | max |W_J L_JJ - I| %.3e\n", w == 2 ? "chol128_cw " : "chol128_dpp", dl, ml, du, mu, dw);
+  }
   return 0;
 }
 
