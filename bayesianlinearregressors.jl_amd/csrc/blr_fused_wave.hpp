@@ -487,9 +487,60 @@ BLR_PHASE int wave_chol(char* smem) {
   return info;
 }
 
-template <typename T, int NB, int NW = 1>
-__global__ __launch_bounds__(64 * NW, 2) void fused_wave_kernel(PosteriorArgs<T> a) {
+// ---- phase 3: m = L^-T u (column-oriented, 8 pivots per block of prefetched rows), |u|^2, logdet A.  In: P = L, bvec = u.
+//      Out: bvec = m, scr[2] = |u|^2, scr[3] = logdet A.  A function of its own so that its 2 x DP lane masks (lane < k, lane == k for
+//      every pivot of the unrolled loop) are made where they are used: inlined in the kernel, hipcc hoisted them out of the loop over
+//      the regressors and parked 256 scalar registers in VGPR lanes -- the kernel's "348 SGPR spills".
+template <typename T, int NB>
+BLR_PHASE void wave_backsolve(char* smem) {
   using C = WaveCfg<T, NB>;
+  T* const P = reinterpret_cast<T*>(smem);
+  T* const bvec = reinterpret_cast<T*>(smem + C::OFF_B);
+  double* const scr = reinterpret_cast<double*>(smem + C::OFF_SCR);
+  int lane = threadIdx.x & 63;
+  asm volatile("" : "+v"(lane));
+  constexpr int D = C::DP;
+  const bool in = lane < D;
+  T b0 = in ? bvec[lane] : T(0);
+  const T lii = in ? P[pidx(lane, lane)] : T(1);
+  const T r0 = fast_rcp(lii);
+  const double uu = wave_allreduce((double)b0 * (double)b0);
+  const double logdetA = 2.0 * wave_allreduce(in ? log((double)lii) : 0.0);
+  for (int kb = D - 1; kb >= 0; kb -= 8) {
+    T row[8];
+#pragma unroll
+    for (int u = 0; u < 8; ++u) {
+      const int k = kb - u;
+      row[u] = (k >= 0 && lane < k) ? P[pidx(k, 0) + lane] : T(0);
+    }
+#pragma unroll
+    for (int u = 0; u < 8; ++u) {
+      const int k = kb - u;
+      if (k >= 0) {
+        const T mk = readlane(b0, k) * readlane(r0, k);
+        if (lane == k) b0 = mk;
+        b0 -= row[u] * mk;
+      }
+    }
+  }
+  if (in) bvec[lane] = b0;
+  if (lane == 0) { scr[2] = uu; scr[3] = logdetA; }
+  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+  __builtin_amdgcn_wave_barrier();
+}
+
+template <typename T, int NB, int NW = 1>
+__global__ __launch_bounds__(64 * NW, 2) void fused_wave_kernel(PosteriorArgs<T> a_kernarg) {
+  using C = WaveCfg<T, NB>;
+  // The arguments are READ AGAIN from the kernarg segment after every phase call instead of being kept: the phases clobber every
+  // scalar register (no callee-saved registers, BLR_PHASE), and hipcc kept some forty 64-bit fields and what it derived from them
+  // alive across the calls in VGPR lanes -- 348 v_writelane + as many v_readlane among the kernel's 3400 instructions, every regressor.
+  // A scalar load from the kernarg segment hits the constant cache.
+  typedef const __attribute__((address_space(4))) PosteriorArgs<T>* ArgPtr;
+  const ArgPtr ap0 = (ArgPtr)__builtin_amdgcn_kernarg_segment_ptr();
+  ArgPtr ap = ap0;
+#define a (*ap)
+#define BLR_FORGET_ARGS() do { unsigned z__ = 0; asm volatile("" : "+s"(z__)); ap = reinterpret_cast<ArgPtr>(reinterpret_cast<const __attribute__((address_space(4))) char*>(ap0) + z__); } while (0)
   extern __shared__ __attribute__((aligned(16))) char smem_all[];
   // NW > 1: every wave works in its own slice; waves 1 .. NW-1 only take part in the prior check (redundantly: every early
   // exit below must be taken by ALL waves, the Gram phase contains workgroup barriers) and in the Gram phase
@@ -501,7 +552,6 @@ __global__ __launch_bounds__(64 * NW, 2) void fused_wave_kernel(PosteriorArgs<T>
   int* const iscr = reinterpret_cast<int*>(smem + C::OFF_SCR + 32);
   const int lane = threadIdx.x & 63;
   constexpr int D = C::DP;
-  const int N = a.N;
   const double kNaN = __longlong_as_double(0x7ff8000000000000LL);
 
   for (int64_t reg = blockIdx.x; reg < a.B; reg += gridDim.x) {
@@ -520,6 +570,7 @@ __global__ __launch_bounds__(64 * NW, 2) void fused_wave_kernel(PosteriorArgs<T>
       __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
       __builtin_amdgcn_wave_barrier();
       info = wave_chol<T, NB>(smem);
+      BLR_FORGET_ARGS();
       logdet_Lw = 2.0 * wave_allreduce((info == 0 && lane < D) ? log((double)P[pidx(lane, lane)]) : 0.0);
       __builtin_amdgcn_wave_barrier();
     } else {
@@ -537,12 +588,14 @@ __global__ __launch_bounds__(64 * NW, 2) void fused_wave_kernel(PosteriorArgs<T>
     }
     if (a.noise_kind == NOISE_DIAGONAL)
       wave_gram<T, NB, true, NW>(smem_all, as_global(a.X + reg * a.strideX), a.ldx, as_global(a.y + reg * a.stridey),
-                                 as_global(a.s + reg * a.strides), mw, dpr, N, a.prior_kind, Lw, a.ldl);
+                                 as_global(a.s + reg * a.strides), mw, dpr, a.N, a.prior_kind, Lw, a.ldl);
     else
       wave_gram<T, NB, false, NW>(smem_all, as_global(a.X + reg * a.strideX), a.ldx, as_global(a.y + reg * a.stridey),
-                                  as_global(a.s + reg * a.strides), mw, dpr, N, a.prior_kind, Lw, a.ldl);
+                                  as_global(a.s + reg * a.strides), mw, dpr, a.N, a.prior_kind, Lw, a.ldl);
+    BLR_FORGET_ARGS();
     if (wv != 0) continue;  // the factorisation is wave 0's
     const double quad = scr[0], logdet_Sy = scr[1];
+    const int N = a.N;
     if (iscr[0] != 0x7fffffff) {  // Sigma_y is not positive definite: PosDefException(index), as :79 would throw
       if (lane == 0) { a.info[reg] = iscr[0]; if (a.logpdf) a.logpdf[reg] = kNaN; }
       __builtin_amdgcn_wave_barrier();
@@ -558,6 +611,7 @@ __global__ __launch_bounds__(64 * NW, 2) void fused_wave_kernel(PosteriorArgs<T>
         if (lane < D) out[(int64_t)c * a.ldlp + lane] = (lane >= c) ? P[pidx(lane, c)] : P[pidx(c, lane)];
     }
     info = wave_chol<T, NB>(smem);
+    BLR_FORGET_ARGS();
     if (info != 0) {
       if (lane == 0) { a.info[reg] = info; if (a.logpdf) a.logpdf[reg] = kNaN; }
       __builtin_amdgcn_wave_barrier();
@@ -569,43 +623,25 @@ __global__ __launch_bounds__(64 * NW, 2) void fused_wave_kernel(PosteriorArgs<T>
         if (lane < D) out[(int64_t)c * a.ldt + lane] = (lane <= c) ? P[pidx(c, lane)] : T(0);
     }
 
-    // ---- m = L^-T u (column-oriented, 8 pivots per block of prefetched rows), |u|^2, logdet A
+    // ---- m = L^-T u, |u|^2, logdet A: a phase of its own (see wave_backsolve)
+    wave_backsolve<T, NB>(smem);
+    BLR_FORGET_ARGS();
     {
       const bool in = lane < D;
-      T b0 = in ? bvec[lane] : T(0);
-      const T lii = in ? P[pidx(lane, lane)] : T(1);
-      const T r0 = fast_rcp(lii);
-      const double uu = wave_allreduce((double)b0 * (double)b0);
-      const double logdetA = 2.0 * wave_allreduce(in ? log((double)lii) : 0.0);
-      for (int kb = D - 1; kb >= 0; kb -= 8) {
-        T row[8];
-#pragma unroll
-        for (int u = 0; u < 8; ++u) {
-          const int k = kb - u;
-          row[u] = (k >= 0 && lane < k) ? P[pidx(k, 0) + lane] : T(0);
-        }
-#pragma unroll
-        for (int u = 0; u < 8; ++u) {
-          const int k = kb - u;
-          if (k >= 0) {
-            const T mk = readlane(b0, k) * readlane(r0, k);
-            if (lane == k) b0 = mk;
-            b0 -= row[u] * mk;
-          }
-        }
-      }
-      if (a.mw_post && in) a.mw_post[reg * a.stride_mwpost + lane] = mw[lane] + b0;  // :68
+      if (a.mw_post && in) a.mw_post[reg * a.stride_mwpost + lane] = as_global(a.mw + reg * a.stridemw)[lane] + bvec[lane];  // :68
       if (lane == 0) {
         a.info[reg] = 0;
         if (a.logpdf) {
           const double LOG2PI = 1.8378770664093454835606594728112;
-          a.logpdf[reg] = -0.5 * ((double)N * LOG2PI + logdet_Sy + quad + logdetA - logdet_Lw - uu);  // :84 + :57
+          a.logpdf[reg] = -0.5 * ((double)N * LOG2PI + logdet_Sy + quad + scr[3] - logdet_Lw - scr[2]);  // :84 + :57
         }
       }
     }
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
     __builtin_amdgcn_wave_barrier();  // P / ring reuse by the next regressor
   }
+#undef a
+#undef BLR_FORGET_ARGS
 }
 
 }  // namespace blr
