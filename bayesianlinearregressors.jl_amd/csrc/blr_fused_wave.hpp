@@ -242,6 +242,10 @@ BLR_PHASE void wave_gram(char* smem0, const BLR_GLOBAL T* X, int64_t ldx, const 
     if constexpr (DIAG) weights(sbuf + sl * C::NSC, (t0 + t) * C::NSC);
 #if BLR_EXP == 5  // streaming only: what the memory system delivers to this access pattern
     qacc += (double)ring[sl * C::SLOT + lane];
+#elif BLR_EXP == 6 || BLR_EXP == 7  // streaming + an idle pause as long as a stage's MFMAs (6: one wave's 1280 cycles, 7: two waves' 2560 -- the pipe is shared)
+    qacc += (double)ring[sl * C::SLOT + lane];
+#pragma unroll 1
+    for (int z = 0; z < (BLR_EXP == 6 ? 20 : 40); ++z) __builtin_amdgcn_s_sleep(1);
 #else
     compute(ring + sl * C::SLOT, ybuf + sl * C::NSC, true);
 #endif
@@ -529,6 +533,9 @@ BLR_PHASE void wave_backsolve(char* smem) {
   __builtin_amdgcn_wave_barrier();
 }
 
+#ifdef BLR_WAVE_CLK
+__device__ unsigned long long g_waveclk[2];
+#endif
 template <typename T, int NB, int NW = 1>
 __global__ __launch_bounds__(64 * NW, 2) void fused_wave_kernel(PosteriorArgs<T> a_kernarg) {
   using C = WaveCfg<T, NB>;
@@ -554,6 +561,9 @@ __global__ __launch_bounds__(64 * NW, 2) void fused_wave_kernel(PosteriorArgs<T>
   constexpr int D = C::DP;
   const double kNaN = __longlong_as_double(0x7ff8000000000000LL);
 
+#ifdef BLR_WAVE_CLK  /* tools/fused_bench.hip: the clock the part holds under this kernel (shader cycles against the 100 MHz counter) */
+  const unsigned long long wck0 = __builtin_amdgcn_s_memtime(), wrt0 = __builtin_amdgcn_s_memrealtime();
+#endif
   for (int64_t reg = blockIdx.x; reg < a.B; reg += gridDim.x) {
     const BLR_GLOBAL T* mw = as_global(a.mw + reg * a.stridemw);
     const BLR_GLOBAL T* Lw = as_global(a.Lw + reg * a.strideLw);
@@ -601,7 +611,7 @@ __global__ __launch_bounds__(64 * NW, 2) void fused_wave_kernel(PosteriorArgs<T>
       __builtin_amdgcn_wave_barrier();
       continue;
     }
-#if BLR_EXP >= 1 && BLR_EXP <= 5
+#if BLR_EXP >= 1 && BLR_EXP <= 7
     if (lane == 0) { a.info[reg] = 0; if (a.logpdf) a.logpdf[reg] = quad + (double)P[lane]; }
     continue;
 #endif
@@ -640,6 +650,12 @@ __global__ __launch_bounds__(64 * NW, 2) void fused_wave_kernel(PosteriorArgs<T>
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
     __builtin_amdgcn_wave_barrier();  // P / ring reuse by the next regressor
   }
+#ifdef BLR_WAVE_CLK
+  if ((blockIdx.x & 63) == 0 && threadIdx.x == 0) {
+    atomicAdd(&g_waveclk[0], __builtin_amdgcn_s_memtime() - wck0);
+    atomicAdd(&g_waveclk[1], __builtin_amdgcn_s_memrealtime() - wrt0);
+  }
+#endif
 #undef a
 #undef BLR_FORGET_ARGS
 }

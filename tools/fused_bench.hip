@@ -176,6 +176,13 @@ int main(int argc, char** argv) {
   }
   for (int r = 0; r < B; ++r) { if (info[r] != 0) ++bad; if (!shareX && lp[r] != lp[r % BU]) ++bad; }
   const double flops = (double)D * (D + 1) * N + 4.0 * D * N + (double)D * D * D / 3 + 3.0 * D * D + 5.0 * N;
+#ifdef BLR_WAVE_CLK
+  {
+    unsigned long long wc[2];
+    CK(hipMemcpyFromSymbol(wc, HIP_SYMBOL(blr::g_waveclk), sizeof(wc)));
+    if (wc[1]) printf("  in-kernel clock: %.3f GHz (shader cycles / 100 MHz ticks, summed over every 64th workgroup and all launches)\n", (double)wc[0] / (double)wc[1] * 0.1);
+  }
+#endif
   printf("%s D=%d N=%d B=%d %s: %.3f ms/launch  %.3f M updates/s  %.1f TFLOP/s (algorithmic)  logpdf rel err vs host %.2e  bad=%d  [EXP=%d]\n",
          sizeof(T) == 8 ? "f64" : "f32", D, N, B, diag ? (shareX ? "diag sharedX" : "diag") : (shareX ? "iso sharedX" : "iso"), ms, B / ms / 1e3, flops * B / ms / 1e9, worst, bad, BLR_EXP);
   return bad != 0 || !(worst < (sizeof(T) == 8 ? 1e-10 : 1e-3) || zero_ops);
