@@ -1459,7 +1459,7 @@ __device__ __forceinline__ int chol_packed(T* __restrict__ P, T* __restrict__ di
 // (<= 128 registers, ~35 KB of LDS each) keep 4 x 16 KB of LDS-DMA in flight per CU; D > 64 is MFMA-bound and
 // needs the registers for accumulators: two workgroups per CU.
 template <typename T, int NB, int MODE /* data loader: 0 ColVecs generic, 1 RowVecs, 3 ColVecs vector regs, 4 ColVecs LDS-DMA */>
-__global__ __launch_bounds__(kThreads, (NB <= 4 ? 4 : (sizeof(T) == 4 ? BLR_F32_WAVES_PER_SIMD : 2))) void fused_small_kernel(PosteriorArgs<T> a) {
+__global__ __launch_bounds__(kThreads, (NB <= 4 ? 4 : (sizeof(T) == 4 ? BLR_F32_WAVES_PER_SIMD : 2))) void fused_small_kernel(PosteriorArgs<T> a_kernarg) {
   using C = SmallCfg<T, NB>;
   extern __shared__ __attribute__((aligned(16))) char smem[];
   T* const P = reinterpret_cast<T*>(smem);
@@ -1467,12 +1467,20 @@ __global__ __launch_bounds__(kThreads, (NB <= 4 ? 4 : (sizeof(T) == 4 ? BLR_F32_
   double* const scr = reinterpret_cast<double*>(smem + C::OFF_SCR);
   int* const iscr = reinterpret_cast<int*>(smem + C::OFF_SCR + 64);
   RegCtx<T>* ctx = reinterpret_cast<RegCtx<T>*>(smem + C::OFF_CTX);
+  // The arguments are READ AGAIN from the kernarg segment after every phase call instead of being kept across it: the phases clobber
+  // every register (BLR_PHASE: no callee-saved registers), so whatever the kernel keeps alive over a call it has to put in scratch itself
+  // -- the fields of `a` and what was derived from them were most of that.  A scalar load from the kernarg segment hits the constant cache.
+  typedef const __attribute__((address_space(4))) PosteriorArgs<T>* ArgPtr;
+  const ArgPtr ap0 = (ArgPtr)__builtin_amdgcn_kernarg_segment_ptr();
+  ArgPtr ap = ap0;
+#define a (*ap)
+#define BLR_FORGET_ARGS() do { unsigned z__ = 0; asm volatile("" : "+s"(z__)); ap = reinterpret_cast<ArgPtr>(reinterpret_cast<const __attribute__((address_space(4))) char*>(ap0) + z__); } while (0)
 
   const int tid = threadIdx.x;
-  const int D = a.D, N = a.N;
   const double kNaN = __longlong_as_double(0x7ff8000000000000LL);
 
   for (int reg = blockIdx.x; reg < a.B; reg += gridDim.x) {
+    int D = a.D;
     if (a.retry_only) {
       if (a.info[reg] != kI8RetryCode) continue;  // (uniform; the int8 kernel finished this regressor)
       if (tid == 0 && a.i8_handed_slice != nullptr) {
@@ -1480,19 +1488,18 @@ __global__ __launch_bounds__(kThreads, (NB <= 4 ? 4 : (sizeof(T) == 4 ? BLR_F32_
         atomicAdd(a.i8_handed_tot, 1ull);
       }
     }
-    const T* mw = a.mw + (int64_t)reg * a.stridemw;
     const T* Lw = a.Lw + (int64_t)reg * a.strideLw;
     __syncthreads();  // previous regressor fully done with LDS
     if (tid == 0) {
       ctx->X = a.X + (int64_t)reg * a.strideX;
       ctx->y = a.y + (int64_t)reg * a.stridey;
       ctx->s = a.s + (int64_t)reg * a.strides;
-      ctx->mw = mw;
+      ctx->mw = a.mw + (int64_t)reg * a.stridemw;
       ctx->Lw = Lw;
       ctx->ldx = a.ldx;
       ctx->ldl = a.ldl;
       ctx->D = D;
-      ctx->N = N;
+      ctx->N = a.N;
       ctx->noise_kind = a.noise_kind;
       ctx->prior_kind = a.prior_kind;
     }
@@ -1508,6 +1515,8 @@ __global__ __launch_bounds__(kThreads, (NB <= 4 ? 4 : (sizeof(T) == 4 ? BLR_F32_
       for (int idx = D * (D + 1) / 2 + tid; idx < C::PACKED; idx += kThreads) P[idx] = T(0);  // padded rows
       __syncthreads();
       info = phase_chol<T, NB>(smem, D, 0);  // :78
+      BLR_FORGET_ARGS();
+      D = a.D;
       double v = (info == 0 && tid < D) ? log((double)P[pidx(tid, tid)]) : 0.0;
       logdet_Lw = 2.0 * block_allreduce(v, scr, tid);
     } else {
@@ -1536,6 +1545,8 @@ __global__ __launch_bounds__(kThreads, (NB <= 4 ? 4 : (sizeof(T) == 4 ? BLR_F32_
     __syncthreads();
     BLR_PSTAMP(0);
     phase_gram<T, NB, MODE>(smem);
+    BLR_FORGET_ARGS();
+    D = a.D;
     BLR_PSTAMP(1);
 #if BLR_EXP >= 1 && BLR_EXP <= 4
     if (tid == 0) {
@@ -1562,6 +1573,8 @@ __global__ __launch_bounds__(kThreads, (NB <= 4 ? 4 : (sizeof(T) == 4 ? BLR_F32_
     // ---- phase 2: blocked Cholesky + fused forward substitution ------------------------------------------
     BLR_PSTAMP(2);
     info = phase_chol<T, NB>(smem, D, 1);  // :86; T = L' is chol(Lw + G).U (:67)
+    BLR_FORGET_ARGS();
+    D = a.D;
     BLR_PSTAMP(3);
     if (info != 0) {
       if (tid == 0) {
@@ -1573,13 +1586,15 @@ __global__ __launch_bounds__(kThreads, (NB <= 4 ? 4 : (sizeof(T) == 4 ? BLR_F32_
     // ---- phase 3: back substitution (wave 0) with T = L' written by the other three waves, evidence ------
     BLR_PSTAMP(4);
     phase_backsolve<T, NB>(smem, D, a.T_post ? a.T_post + (int64_t)reg * a.strideT : (T*)nullptr, a.ldt);
+    BLR_FORGET_ARGS();
+    D = a.D;
     BLR_PSTAMP(5);
-    if (a.mw_post && tid < D) a.mw_post[(int64_t)reg * a.stride_mwpost + tid] = mw[tid] + bvec[tid];  // :68
+    if (a.mw_post && tid < D) a.mw_post[(int64_t)reg * a.stride_mwpost + tid] = (a.mw + (int64_t)reg * a.stridemw)[tid] + bvec[tid];  // :68
     if (tid == 0) {
       a.info[reg] = 0;
       if (a.logpdf) {
         const double LOG2PI = 1.8378770664093454835606594728112;
-        a.logpdf[reg] = -0.5 * ((double)N * LOG2PI + logdet_Sy + quad + scr[7] - logdet_Lw - scr[6]);  // :84 + :57
+        a.logpdf[reg] = -0.5 * ((double)a.N * LOG2PI + logdet_Sy + quad + scr[7] - logdet_Lw - scr[6]);  // :84 + :57
       }
     }
     BLR_PSTAMP(6);
@@ -1591,6 +1606,8 @@ __global__ __launch_bounds__(kThreads, (NB <= 4 ? 4 : (sizeof(T) == 4 ? BLR_F32_
 #endif
 #endif
   }
+#undef a
+#undef BLR_FORGET_ARGS
 }
 
 }  // namespace blr
