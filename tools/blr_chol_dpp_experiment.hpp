@@ -1,3 +1,6 @@
+// EXPERIMENT (round 5) -- not part of the library; built only by tools/chol_bench.hip.  Measured 37 - 39 us against phase_chol's 40 us per
+// 128 x 128 fp64 factorisation (profiles/r05_microbench_chol_bench.txt) and left here with its measurements (LOG.md, late round 5).
+//
 // Blocked Cholesky of the packed 128 x 128 lower triangle in LDS, fp64, for the int8 route's kernel (reference:
 // `cholesky(Symmetric(...))`, bayesian_linear_regression.jl:86, and the forward substitution of :57 / :68 riding along).
 //

@@ -1,5 +1,7 @@
 // Diagnostic: where do the cycles of phase_chol (128 x 128 blocked Cholesky in LDS/registers) go?
-//   hipcc --offload-arch=gfx950 -O3 -std=c++17 -DBLR_STAMPS -I../bayesianlinearregressors.jl_amd/csrc chol_bench.hip -o chol_bench
+//   hipcc --offload-arch=gfx950 -O3 -std=c++17 -DBLR_STAMPS -I. -I../bayesianlinearregressors.jl_amd/csrc chol_bench.hip -o chol_bench
+//   ./chol_bench      phase_chol, f32 and f64: time, per-section cycles of wave 0, FNV fingerprint of L (bit-identity across versions)
+//   ./chol_bench 2    fp64: phase_chol against the two experiments of blr_chol_dpp_experiment.hpp (time, sections, max |dL|, |du|, |W L - I|)
 #include <hip/hip_runtime.h>
 #include <cstdio>
 #include <vector>
