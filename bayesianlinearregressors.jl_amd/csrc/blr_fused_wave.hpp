@@ -418,70 +418,90 @@ BLR_PHASE int wave_chol(char* smem) {
         acc[t][v] = P[pidx(max(row, col), min(row, col))];
       }
     }
+  // (round 5: the panel step as in phase_chol -- rows loaded unmasked (entries right of the diagonal of a diagonal-block row are dead
+  // values), predicated stores through an address select to a dump word instead of an exec-mask branch each, the elimination as one
+  // basic block with the next pivot's reciprocal started early and the 16 reciprocal square roots taken once after the loop, fragment
+  // addresses without per-element triangle arithmetic)
+  const int pr = (r16 * (r16 + 1)) >> 1;  // pidx(r16, 0)
+  T* const dummy = reinterpret_cast<T*>(smem + C::OFF_Y) + r16;  // (the y ring is dead here)
+  int cr[4], pcr[4];
+#pragma unroll
+  for (int v = 0; v < 4; ++v) {
+    cr[v] = Mfma<T>::crow(lane, v);
+    pcr[v] = (cr[v] * (cr[v] + 1)) >> 1;
+  }
   int info = 0;
 #pragma unroll 1
   for (int J = 0; J < NB; ++J) {
     const bool is_diag = lane < 16;
     const int ri = is_diag ? 16 * J + lane : 16 * (J + 1) + (lane - 16);
     const bool active = ri < D;
+    const int ria = active ? ri : 0;
+    T* const rowp = P + (((ria * (ria + 1)) >> 1) + 16 * J);
     T arow[16];
-    T bl = T(0);
+#pragma unroll
+    for (int c = 0; c < 16; ++c) arow[c] = rowp[c];
+    T bl = bvec[ria];
+    T own_rsq;
     {
-      const T* src = P + pidx(active ? ri : 0, 16 * J);
+      T d2 = readlane(arow[0], 0);
+      T rc = fast_rcp(d2);
 #pragma unroll
       for (int c = 0; c < 16; ++c) {
-        const bool ok = active && (!is_diag || c <= lane);
-        arow[c] = ok ? src[c] : T(0);
-      }
-      if (active) bl = bvec[ri];
-    }
-    T own_rsq = T(1);
+        if (!(d2 > T(0)) && info == 0) info = 16 * J + c + 1;  // wave-uniform
+        const T tm = arow[c] * rc;
+        if (c + 1 < 16) {
+          arow[c + 1] = fused_madd(-tm, readlane(arow[c], c + 1), arow[c + 1]);
+          d2 = readlane(arow[c + 1], c + 1);
+          rc = fast_rcp(d2);
+        }
+        const T bc = readlane(bl, c);
+        if (lane > c) bl = fused_madd(-tm, bc, bl);
 #pragma unroll
-    for (int c = 0; c < 16; ++c) {
-      const T d2 = readlane(arow[c], c);
-      if (!(d2 > T(0)) && info == 0) info = 16 * J + c + 1;  // wave-uniform
-      const T tm = arow[c] * fast_rcp(d2);
-      const T bc = readlane(bl, c);
-      if (lane > c) bl -= tm * bc;
-#pragma unroll
-      for (int k = c + 1; k < 16; ++k) {
-        const T akc = readlane(arow[c], k);
-        arow[k] -= tm * akc;
+        for (int k = c + 2; k < 16; ++k) arow[k] = fused_madd(-tm, readlane(arow[c], k), arow[k]);
       }
-      const T rsq = fast_rsqrt(d2);
-      if (lane == c) own_rsq = rsq;
-      arow[c] = (lane == c) ? d2 * rsq : arow[c] * rsq;
+      T piv = T(1);
+#pragma unroll
+      for (int c = 0; c < 16; ++c) piv = (lane == c) ? arow[c] : piv;
+      own_rsq = fast_rsqrt(piv);
+#pragma unroll
+      for (int c = 0; c < 16; ++c) arow[c] *= readlane(own_rsq, c);  // L[i][c] = a_ic / sqrt(d2); lane c: d2 / sqrt(d2)
     }
     if (is_diag) bl *= own_rsq;
     if (info != 0) break;
-    if (active) {
-      T* dst = P + pidx(ri, 16 * J);
+    {
+      const int lim = active ? (is_diag ? lane : 15) : -1;  // columns 0 .. lim of this lane's row are stored
 #pragma unroll
-      for (int c = 0; c < 16; ++c)
-        if (!is_diag || c <= lane) dst[c] = arow[c];
-      bvec[ri] = bl;
+      for (int c = 0; c < 16; ++c) {
+        T* dst = (c <= lim) ? rowp + c : dummy;
+        *dst = arow[c];
+      }
+      T* bd = active ? bvec + ri : dummy;
+      *bd = bl;
     }
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
     __builtin_amdgcn_wave_barrier();
     // trailing update from the finished panel; block column J + 1 goes straight back to P
+    const int pc = pr + 16 * J + q4;
 #pragma unroll
     for (int I = 1; I < NB; ++I)
 #pragma unroll
       for (int K = 1; K <= I; ++K) {
         if (K <= J) continue;  // wave-uniform
         const int t = I * (I + 1) / 2 + K;
+        const T* pI = P + ((128 * I * I + 8 * I) + (16 * I) * r16 + pc);  // pidx(16 I + r16, 16 J + q4)
+        const T* pK = P + ((128 * K * K + 8 * K) + (16 * K) * r16 + pc);
+        T fa[4], fb[4];
 #pragma unroll
-        for (int ks = 0; ks < 4; ++ks) {
-          const T fI = P[pidx(16 * I + r16, 16 * J + 4 * ks + q4)];
-          const T fK = P[pidx(16 * K + r16, 16 * J + 4 * ks + q4)];
-          acc[t] = Mfma<T>::mma(-fI, fK, acc[t]);
-        }
+        for (int ks = 0; ks < 4; ++ks) { fa[ks] = pI[4 * ks]; fb[ks] = pK[4 * ks]; }
+#pragma unroll
+        for (int ks = 0; ks < 4; ++ks) acc[t] = Mfma<T>::mma(-fa[ks], fb[ks], acc[t]);
         if (K == J + 1) {
-          const int col = 16 * K + r16;
+          const int sb = (128 * I * I + 8 * I) + 16 * K + r16;
 #pragma unroll
           for (int v = 0; v < 4; ++v) {
-            const int row = 16 * I + Mfma<T>::crow(lane, v);
-            if (col <= row) P[pidx(row, col)] = acc[t][v];
+            T* dst = (I != K || r16 <= cr[v]) ? P + (sb + (16 * I) * cr[v] + pcr[v]) : dummy;
+            *dst = acc[t][v];
           }
         }
       }
