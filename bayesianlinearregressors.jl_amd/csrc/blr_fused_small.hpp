@@ -150,6 +150,7 @@ struct RegCtx {
   const T* X; const T* y; const T* s; const T* mw; const T* Lw;
   int64_t ldx, ldl;
   int D, N, noise_kind, prior_kind;
+  double logdet_Lw;  // (kept here between the glue phases of fused_small_kernel)
 };
 
 template <typename T, int NB>
@@ -1455,159 +1456,180 @@ __device__ __forceinline__ int chol_packed(T* __restrict__ P, T* __restrict__ di
 }
 
 // ---- the kernel -----------------------------------------------------------------------------------
+// Everything between the phases is a phase too ("glue"): the phases keep no callee-saved registers (BLR_PHASE), so whatever the KERNEL
+// holds across a call goes to scratch -- with the glue inline that was 220 B per lane of loop invariants and live values (612 B while the
+// phases still saved the ABI's callee-saved registers).  The kernel keeps the regressor index and the kernarg pointer, in scalar
+// registers; the arguments are read from the kernarg segment where they are used (constant cache), `logdet Lw` waits in the LDS context.
+template <typename T>
+using KernArgPtr = const __attribute__((address_space(4))) PosteriorArgs<T>*;
+
+// prior (reference :78) + per-regressor context.  Returns 0: go on, 1: this regressor is finished (skipped, or failed and reported)
+template <typename T, int NB>
+BLR_PHASE int glue_prior(char* smem, KernArgPtr<T> ap, int reg) {
+  using C = SmallCfg<T, NB>;
+#define a (*ap)
+  T* const P = reinterpret_cast<T*>(smem);
+  double* const scr = reinterpret_cast<double*>(smem + C::OFF_SCR);
+  int* const iscr = reinterpret_cast<int*>(smem + C::OFF_SCR + 64);
+  RegCtx<T>* ctx = reinterpret_cast<RegCtx<T>*>(smem + C::OFF_CTX);
+  const int tid = threadIdx.x;
+  const int D = a.D;
+  const double kNaN = __longlong_as_double(0x7ff8000000000000LL);
+  if (a.retry_only) {
+    if (a.info[reg] != kI8RetryCode) return 1;  // (uniform; the int8 kernel finished this regressor)
+    if (tid == 0 && a.i8_handed_slice != nullptr) {
+      atomicAdd(a.i8_handed_slice, 1ull);
+      atomicAdd(a.i8_handed_tot, 1ull);
+    }
+  }
+  const T* Lw = a.Lw + (int64_t)reg * a.strideLw;
+  __syncthreads();  // previous regressor fully done with LDS
+  if (tid == 0) {
+    ctx->X = a.X + (int64_t)reg * a.strideX;
+    ctx->y = a.y + (int64_t)reg * a.stridey;
+    ctx->s = a.s + (int64_t)reg * a.strides;
+    ctx->mw = a.mw + (int64_t)reg * a.stridemw;
+    ctx->Lw = Lw;
+    ctx->ldx = a.ldx;
+    ctx->ldl = a.ldl;
+    ctx->D = D;
+    ctx->N = a.N;
+    ctx->noise_kind = a.noise_kind;
+    ctx->prior_kind = a.prior_kind;
+  }
+  int info = 0;
+  double logdet_Lw = 0.0;
+  if (a.prior_kind == PRIOR_DENSE) {
+    // upper triangle (k <= i) of column i; columns over waves, rows over lanes: no per-element integer division
+    for (int i = tid >> 6; i < D; i += kWaves)
+      for (int k = tid & 63; k <= i; k += kWave) P[pidx(i, k)] = Lw[(int64_t)i * a.ldl + k];
+    for (int idx = D * (D + 1) / 2 + tid; idx < C::PACKED; idx += kThreads) P[idx] = T(0);  // padded rows
+    __syncthreads();
+    info = phase_chol<T, NB>(smem, D, 0);  // :78
+    double v = (info == 0 && tid < D) ? log((double)P[pidx(tid, tid)]) : 0.0;
+    logdet_Lw = 2.0 * block_allreduce(v, scr, tid);
+  } else {
+    // diagonal entries of d (DIAGONAL) or of the factor U (UPPER_FACTOR) must be positive
+    double v = 0.0;
+    int bad = 0x7fffffff;
+    if (tid < D) {
+      T dv = (a.prior_kind == PRIOR_DIAGONAL) ? Lw[tid] : Lw[(int64_t)tid * a.ldl + tid];
+      if (dv > T(0)) v = log((double)dv);
+      else bad = tid + 1;
+    }
+    bad = block_min_int(bad, iscr, tid);
+    if (bad != 0x7fffffff) info = bad;
+    v = block_allreduce(v, scr, tid);
+    logdet_Lw = (a.prior_kind == PRIOR_DIAGONAL) ? v : 2.0 * v;
+  }
+  if (info != 0) {  // block-uniform
+    if (tid == 0) {
+      a.info[reg] = info;
+      if (a.logpdf) a.logpdf[reg] = kNaN;
+    }
+    return 1;
+  }
+  if (tid == 0) ctx->logdet_Lw = logdet_Lw;
+  __syncthreads();
+  return 0;
+#undef a
+}
+
+// after the Gram phase: the noise check of reference :79 and the posterior precision (:92).  Returns 1 when the regressor is finished.
+template <typename T, int NB>
+BLR_PHASE int glue_after_gram(char* smem, KernArgPtr<T> ap, int reg) {
+  using C = SmallCfg<T, NB>;
+#define a (*ap)
+  T* const P = reinterpret_cast<T*>(smem);
+  int* const iscr = reinterpret_cast<int*>(smem + C::OFF_SCR + 64);
+  const int tid = threadIdx.x;
+  const int D = a.D;
+  if (iscr[6] != 0x7fffffff) {  // Sigma_y is not positive definite (block-uniform): PosDefException(index), as :79 would throw
+    if (tid == 0) {
+      a.info[reg] = iscr[6];
+      if (a.logpdf) a.logpdf[reg] = __longlong_as_double(0x7ff8000000000000LL);
+    }
+    return 1;
+  }
+  if (a.Lw_post) {  // posterior precision Lw' = A, full symmetric (:92)
+    T* out = a.Lw_post + (int64_t)reg * a.strideLp;
+    for (int c = tid >> 6; c < D; c += kWaves)
+      for (int r = tid & 63; r < D; r += kWave) out[(int64_t)c * a.ldlp + r] = (r >= c) ? P[pidx(r, c)] : P[pidx(c, r)];
+  }
+  return 0;
+#undef a
+}
+
+// the regressor's status, and what goes out when it succeeded: mw' = mw + m (:68), the evidence (:84 + :57)
+template <typename T, int NB>
+BLR_PHASE void glue_finish(char* smem, KernArgPtr<T> ap, int reg, int info) {
+  using C = SmallCfg<T, NB>;
+#define a (*ap)
+  T* const bvec = reinterpret_cast<T*>(smem + C::OFF_B);
+  double* const scr = reinterpret_cast<double*>(smem + C::OFF_SCR);
+  RegCtx<T>* ctx = reinterpret_cast<RegCtx<T>*>(smem + C::OFF_CTX);
+  const int tid = threadIdx.x;
+  if (info != 0) {
+    if (tid == 0) {
+      a.info[reg] = info;
+      if (a.logpdf) a.logpdf[reg] = __longlong_as_double(0x7ff8000000000000LL);
+    }
+    return;
+  }
+  if (a.mw_post && tid < a.D) a.mw_post[(int64_t)reg * a.stride_mwpost + tid] = (a.mw + (int64_t)reg * a.stridemw)[tid] + bvec[tid];  // :68
+  if (tid == 0) {
+    a.info[reg] = 0;
+    if (a.logpdf) {
+      const double LOG2PI = 1.8378770664093454835606594728112;
+      a.logpdf[reg] = -0.5 * ((double)a.N * LOG2PI + scr[5] + scr[4] + scr[7] - ctx->logdet_Lw - scr[6]);  // :84 + :57
+    }
+  }
+#undef a
+}
+
 // Occupancy target: D <= 64 (NB <= 4) is HBM/latency-bound -- four workgroups per CU
 // (<= 128 registers, ~35 KB of LDS each) keep 4 x 16 KB of LDS-DMA in flight per CU; D > 64 is MFMA-bound and
 // needs the registers for accumulators: two workgroups per CU.
 template <typename T, int NB, int MODE /* data loader: 0 ColVecs generic, 1 RowVecs, 3 ColVecs vector regs, 4 ColVecs LDS-DMA */>
 __global__ __launch_bounds__(kThreads, (NB <= 4 ? 4 : (sizeof(T) == 4 ? BLR_F32_WAVES_PER_SIMD : 2))) void fused_small_kernel(PosteriorArgs<T> a_kernarg) {
-  using C = SmallCfg<T, NB>;
   extern __shared__ __attribute__((aligned(16))) char smem[];
-  T* const P = reinterpret_cast<T*>(smem);
-  T* const bvec = reinterpret_cast<T*>(smem + C::OFF_B);
-  double* const scr = reinterpret_cast<double*>(smem + C::OFF_SCR);
-  int* const iscr = reinterpret_cast<int*>(smem + C::OFF_SCR + 64);
-  RegCtx<T>* ctx = reinterpret_cast<RegCtx<T>*>(smem + C::OFF_CTX);
-  // The arguments are READ AGAIN from the kernarg segment after every phase call instead of being kept across it: the phases clobber
-  // every register (BLR_PHASE: no callee-saved registers), so whatever the kernel keeps alive over a call it has to put in scratch itself
-  // -- the fields of `a` and what was derived from them were most of that.  A scalar load from the kernarg segment hits the constant cache.
-  typedef const __attribute__((address_space(4))) PosteriorArgs<T>* ArgPtr;
-  const ArgPtr ap0 = (ArgPtr)__builtin_amdgcn_kernarg_segment_ptr();
-  ArgPtr ap = ap0;
+  const KernArgPtr<T> ap = (KernArgPtr<T>)__builtin_amdgcn_kernarg_segment_ptr();
 #define a (*ap)
-#define BLR_FORGET_ARGS() do { unsigned z__ = 0; asm volatile("" : "+s"(z__)); ap = reinterpret_cast<ArgPtr>(reinterpret_cast<const __attribute__((address_space(4))) char*>(ap0) + z__); } while (0)
-
-  const int tid = threadIdx.x;
-  const double kNaN = __longlong_as_double(0x7ff8000000000000LL);
-
   for (int reg = blockIdx.x; reg < a.B; reg += gridDim.x) {
-    int D = a.D;
-    if (a.retry_only) {
-      if (a.info[reg] != kI8RetryCode) continue;  // (uniform; the int8 kernel finished this regressor)
-      if (tid == 0 && a.i8_handed_slice != nullptr) {
-        atomicAdd(a.i8_handed_slice, 1ull);
-        atomicAdd(a.i8_handed_tot, 1ull);
-      }
-    }
-    const T* Lw = a.Lw + (int64_t)reg * a.strideLw;
-    __syncthreads();  // previous regressor fully done with LDS
-    if (tid == 0) {
-      ctx->X = a.X + (int64_t)reg * a.strideX;
-      ctx->y = a.y + (int64_t)reg * a.stridey;
-      ctx->s = a.s + (int64_t)reg * a.strides;
-      ctx->mw = a.mw + (int64_t)reg * a.stridemw;
-      ctx->Lw = Lw;
-      ctx->ldx = a.ldx;
-      ctx->ldl = a.ldl;
-      ctx->D = D;
-      ctx->N = a.N;
-      ctx->noise_kind = a.noise_kind;
-      ctx->prior_kind = a.prior_kind;
-    }
-    int info = 0;
-    double logdet_Lw = 0.0;
-    BLR_PSTAMP_INIT;
-
     // ---- phase 0: prior -----------------------------------------------------------------------
-    if (a.prior_kind == PRIOR_DENSE) {
-      // upper triangle (k <= i) of column i; columns over waves, rows over lanes: no per-element integer division
-      for (int i = tid >> 6; i < D; i += kWaves)
-        for (int k = tid & 63; k <= i; k += kWave) P[pidx(i, k)] = Lw[(int64_t)i * a.ldl + k];
-      for (int idx = D * (D + 1) / 2 + tid; idx < C::PACKED; idx += kThreads) P[idx] = T(0);  // padded rows
-      __syncthreads();
-      info = phase_chol<T, NB>(smem, D, 0);  // :78
-      BLR_FORGET_ARGS();
-      D = a.D;
-      double v = (info == 0 && tid < D) ? log((double)P[pidx(tid, tid)]) : 0.0;
-      logdet_Lw = 2.0 * block_allreduce(v, scr, tid);
-    } else {
-      // diagonal entries of d (DIAGONAL) or of the factor U (UPPER_FACTOR) must be positive
-      double v = 0.0;
-      int bad = 0x7fffffff;
-      if (tid < D) {
-        T dv = (a.prior_kind == PRIOR_DIAGONAL) ? Lw[tid] : Lw[(int64_t)tid * a.ldl + tid];
-        if (dv > T(0)) v = log((double)dv);
-        else bad = tid + 1;
-      }
-      bad = block_min_int(bad, iscr, tid);
-      if (bad != 0x7fffffff) info = bad;
-      v = block_allreduce(v, scr, tid);
-      logdet_Lw = (a.prior_kind == PRIOR_DIAGONAL) ? v : 2.0 * v;
-    }
-    if (info != 0) {  // block-uniform
-      if (tid == 0) {
-        a.info[reg] = info;
-        if (a.logpdf) a.logpdf[reg] = kNaN;
-      }
-      continue;
-    }
-
+    if (glue_prior<T, NB>(smem, ap, reg) != 0) continue;
+    BLR_PSTAMP_INIT;
     // ---- phase 1: streaming Gram -> P, bvec, scr[4..5] ------------------------------------------------
-    __syncthreads();
     BLR_PSTAMP(0);
     phase_gram<T, NB, MODE>(smem);
-    BLR_FORGET_ARGS();
-    D = a.D;
     BLR_PSTAMP(1);
 #if BLR_EXP >= 1 && BLR_EXP <= 4
-    if (tid == 0) {
+    if (threadIdx.x == 0) {
       a.info[reg] = 0;
-      if (a.logpdf) a.logpdf[reg] = scr[4] + (double)P[tid];
+      if (a.logpdf) a.logpdf[reg] = reinterpret_cast<double*>(smem + SmallCfg<T, NB>::OFF_SCR)[4] + (double)reinterpret_cast<T*>(smem)[0];
     }
     continue;
 #endif
-    const double quad = scr[4], logdet_Sy = scr[5];
-    if (iscr[6] != 0x7fffffff) {  // Sigma_y is not positive definite (block-uniform): PosDefException(index), as :79 would throw
-      if (tid == 0) {
-        a.info[reg] = iscr[6];
-        if (a.logpdf) a.logpdf[reg] = kNaN;
-      }
-      continue;
-    }
-
-    if (a.Lw_post) {  // posterior precision Lw' = A, full symmetric (:92)
-      T* out = a.Lw_post + (int64_t)reg * a.strideLp;
-      for (int c = tid >> 6; c < D; c += kWaves)
-        for (int r = tid & 63; r < D; r += kWave) out[(int64_t)c * a.ldlp + r] = (r >= c) ? P[pidx(r, c)] : P[pidx(c, r)];
-    }
-
+    if (glue_after_gram<T, NB>(smem, ap, reg) != 0) continue;
     // ---- phase 2: blocked Cholesky + fused forward substitution ------------------------------------------
     BLR_PSTAMP(2);
-    info = phase_chol<T, NB>(smem, D, 1);  // :86; T = L' is chol(Lw + G).U (:67)
-    BLR_FORGET_ARGS();
-    D = a.D;
+    const int info = phase_chol<T, NB>(smem, a.D, 1);  // :86; T = L' is chol(Lw + G).U (:67)
     BLR_PSTAMP(3);
-    if (info != 0) {
-      if (tid == 0) {
-        a.info[reg] = info;
-        if (a.logpdf) a.logpdf[reg] = kNaN;
-      }
-      continue;
-    }
     // ---- phase 3: back substitution (wave 0) with T = L' written by the other three waves, evidence ------
     BLR_PSTAMP(4);
-    phase_backsolve<T, NB>(smem, D, a.T_post ? a.T_post + (int64_t)reg * a.strideT : (T*)nullptr, a.ldt);
-    BLR_FORGET_ARGS();
-    D = a.D;
+    if (info == 0) phase_backsolve<T, NB>(smem, a.D, a.T_post ? a.T_post + (int64_t)reg * a.strideT : (T*)nullptr, a.ldt);
     BLR_PSTAMP(5);
-    if (a.mw_post && tid < D) a.mw_post[(int64_t)reg * a.stride_mwpost + tid] = (a.mw + (int64_t)reg * a.stridemw)[tid] + bvec[tid];  // :68
-    if (tid == 0) {
-      a.info[reg] = 0;
-      if (a.logpdf) {
-        const double LOG2PI = 1.8378770664093454835606594728112;
-        a.logpdf[reg] = -0.5 * ((double)a.N * LOG2PI + logdet_Sy + quad + scr[7] - logdet_Lw - scr[6]);  // :84 + :57
-      }
-    }
+    glue_finish<T, NB>(smem, ap, reg, info);
     BLR_PSTAMP(6);
 #ifdef BLR_GRAM_STAMPS
 #ifdef BLR_PSTAMP_ALL
-    if (tid == 0) atomicAdd(&g_pstamps[15], 1ull);
+    if (threadIdx.x == 0) atomicAdd(&g_pstamps[15], 1ull);
 #else
-    if (blockIdx.x == 0 && tid == 0) g_pstamps[15] += 1;
+    if (blockIdx.x == 0 && threadIdx.x == 0) g_pstamps[15] += 1;
 #endif
 #endif
   }
 #undef a
-#undef BLR_FORGET_ARGS
 }
 
 }  // namespace blr

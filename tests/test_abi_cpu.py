@@ -173,7 +173,8 @@ def test_hot_kernels_keep_two_workgroups_per_cu(tmp_path):
     # Scratch of the hot kernels.  The phase functions have internal linkage and no tail-called call site, so LLVM's
     # interprocedural register allocation drops their callee-saved-register saves (blr_fused_small.hpp, BLR_PHASE); what is left is
     # the few values a kernel keeps across its calls, which the code object now books as the KERNEL's spills.  The honest measure is
-    # the scratch per lane: 612 B (fp64 fallback kernel) and 320 B (int8 kernel) before.
+    # the scratch per lane: 612 B (fp64 fallback kernel) and 320 B (int8 kernel) before; the fallback kernel's own glue code
+    # between the phases is a set of phases too, so the kernel keeps two scalar values across its calls (76 B, 2 vector spills).
     scratch, spills, name = {}, {}, None
     for line in notes.splitlines():
         m = re.match(r"\s+(?:- )?\.(name|private_segment_fixed_size|vgpr_spill_count):\s+(\S+)", line)
@@ -186,7 +187,8 @@ def test_hot_kernels_keep_two_workgroups_per_cu(tmp_path):
     assert max(i8_scratch.values()) <= 64, f"int8 kernels: bytes of scratch per lane {i8_scratch}"
     assert max(v for k, v in spills.items() if "fused_i8_kernel" in k) <= 8
     fb = {k: v for k, v in scratch.items() if "fused_small_kernelIdLi8ELi4" in k}
-    assert len(fb) == 1 and max(fb.values()) <= 256, f"fp64 fallback kernel: bytes of scratch per lane {fb}"
+    assert len(fb) == 1 and max(fb.values()) <= 128, f"fp64 fallback kernel: bytes of scratch per lane {fb}"
+    assert max(v for k, v in spills.items() if "fused_small_kernelIdLi8ELi4" in k) <= 4
     # config 4's one-wave kernel (VERDICT r4 #4a): its back substitution is a phase of its own, so the 128 lane masks of the unrolled
     # pivots are no longer hoisted out of the loop over the regressors and parked in VGPR lanes (348 scalar spills before)
     sg, name = {}, None
