@@ -1,5 +1,10 @@
-// EXPERIMENT (round 5) -- not part of the library; built only by tools/chol_bench.hip.  Measured 37 - 39 us against phase_chol's 40 us per
-// 128 x 128 fp64 factorisation (profiles/r05_microbench_chol_bench.txt) and left here with its measurements (LOG.md, late round 5).
+// EXPERIMENT (round 5) -- not part of the library; built only by tools/chol_bench.hip (profiles/r05_microbench_chol_bench.txt; LOG.md,
+// late round 5).  Per 128 x 128 fp64 factorisation: phase_chol 40.3 us; chol128_dpp 38.7; chol128_cw with 4 waves 37.0, with 8 waves
+// (one chain wave, six update waves, its SIMD partner idle) 32.1 us -- most of that a higher clock in the microbenchmark: in cycles
+// 63 k against 68 k.  chol128_cw<.., 8> was also built INTO fused_i8_kernel (waves 4 - 7 kept alive through the four-wave prior code by
+// counting barriers, the block inverses handed to the back substitution): -4.3 k cycles of factorisation and -5.5 k of substitution
+// per regressor, and 4.403 -> 4.398 ms per 4096 updates sustained (in-kernel clock 1.812 -> 1.802 GHz): the kernel runs at the power
+// limit and gave the cycles back as clock.  Not shipped.
 //
 // Blocked Cholesky of the packed 128 x 128 lower triangle in LDS, fp64, for the int8 route's kernel (reference:
 // `cholesky(Symmetric(...))`, bayesian_linear_regression.jl:86, and the forward substitution of :57 / :68 riding along).
@@ -282,8 +287,11 @@ __device__ __attribute__((noinline)) int chol128_dpp(char* smem) {
 //   B2  chain wave: solve tile (J+1, J), r_{J+1} -= L u_J, update tile (J+1, J+1)   |  waves 1 - 3: solve the tiles (I, J), I > J + 1,
 //                                                                                   |  and take r_I -= L_IJ u_J along
 //   B3  chain wave: factor + invert tile (J+1, J+1); L, W, u to LDS                 |  waves 1 - 3: trailing update J of every other tile
-template <int OFF_W, int OFF_U>
+template <int OFF_W, int OFF_U, int NW = 4>
 __device__ __attribute__((noinline)) int chol128_cw(char* smem) {
+  // update waves: with 8 waves, wave 4 -- the chain wave's partner on SIMD 0 -- only keeps the barriers company (as an update wave it
+  // took issue slots from the chain: 33.1 us against 3x.x with the SIMD left to the chain wave)
+  constexpr int NU = NW == 8 ? 6 : NW - 1;
   using T = double;
   using C = SmallCfg<double, 8>;
   using acc4 = typename Mfma<T>::acc4;
@@ -296,6 +304,8 @@ __device__ __attribute__((noinline)) int chol128_cw(char* smem) {
   asm volatile("" : "+v"(tid));
   const int lane = tid & 63;
   const int wave = uni(tid >> 6);
+  const int uw = (NW == 8) ? (wave < 4 ? wave - 1 : wave - 2) : wave - 1;  // update-wave index; wave 4 of 8: 2 -> see NU (it gets none)
+  const bool idle = (NW == 8) && wave == 4;
   const int r = lane & 15, q = lane >> 4;
   const int pr = (r * (r + 1)) >> 1;  // pidx(r, 0)
   T* const dummy = reinterpret_cast<T*>(smem + C::OFF_DINV) + r;
@@ -334,6 +344,26 @@ __device__ __attribute__((noinline)) int chol128_cw(char* smem) {
     }
 #pragma unroll
     for (int v = 0; v < 4; ++v) { *pc0[v] = acc0[v]; *pc1[v] = acc1[v]; }
+  };
+  auto update_one = [&](int I, int K, int J) {
+    const int bI = 128 * I * I + 8 * I, bK = 128 * K * K + 8 * K;
+    const int fo = pr + 16 * J + q;
+    const T* pI = P + (bI + 16 * I * r + fo);
+    const T* pK = P + (bK + 16 * K * r + fo);
+    T fa[4], fb[4];
+#pragma unroll
+    for (int ks = 0; ks < 4; ++ks) { fa[ks] = pI[4 * ks]; fb[ks] = pK[4 * ks]; }
+    T* pc[4];
+    acc4 acc;
+#pragma unroll
+    for (int v = 0; v < 4; ++v) {
+      pc[v] = (I != K || r <= cr[v]) ? P + (bI + 16 * I * cr[v] + pcr[v] + 16 * K + r) : dummy;
+      acc[v] = *pc[v];
+    }
+#pragma unroll
+    for (int ks = 0; ks < 4; ++ks) acc = Mfma<T>::mma(-fa[ks], fb[ks], acc);
+#pragma unroll
+    for (int v = 0; v < 4; ++v) *pc[v] = acc[v];
   };
   // L_IJ = A_IJ L_JJ^-T (B fragment = W_J) for one tile, then r_I -= L_IJ u_J from the solved tile's own fragments
   auto solve_row = [&](int I, int J, const T (&w)[4], const T (&uq)[4]) {
@@ -403,10 +433,10 @@ __device__ __attribute__((noinline)) int chol128_cw(char* smem) {
       for (int j = 0; j < 4; ++j) { w[j] = Wst[(16 * J + r) * 16 + 4 * j + q]; uq[j] = ust[16 * J + 4 * j + q]; }
       if (wave == 0) {
         solve_row(J + 1, J, w, uq);
-        update_tiles(J + 1, J + 1, J + 1, J + 1, false, J);
-      } else {
+        update_one(J + 1, J + 1, J);
+      } else if (!idle) {
 #pragma unroll 1
-        for (int I = J + 1 + wave; I < 8; I += 3) solve_row(I, J, w, uq);
+        for (int I = J + 2 + uw; I < 8; I += NU) solve_row(I, J, w, uq);
       }
     }
     BLR_STAMP(3);
@@ -414,7 +444,7 @@ __device__ __attribute__((noinline)) int chol128_cw(char* smem) {
     BLR_STAMP(4);
     if (wave == 0) {
       factor_tile(J + 1);
-    } else {
+    } else if (!idle) {
       // trailing update J of the tiles (I, K), J + 1 <= K <= I <= 7, without (J + 1, J + 1): dealt over the three update waves in pairs
       const int n1 = 7 - J;  // tiles per edge
       const int nt = n1 * (n1 + 1) / 2;
@@ -426,11 +456,11 @@ __device__ __attribute__((noinline)) int chol128_cw(char* smem) {
         K = J + 1 + t - i * (i + 1) / 2;
       };
 #pragma unroll 1
-      for (int t = wave; t < nt; t += 6) {  // (t = 0 is the chain wave's tile)
+      for (int t = 1 + uw; t < nt; t += 2 * NU) {  // (t = 0 is the chain wave's tile)
         int I0, K0, I1, K1;
-        const bool two = t + 3 < nt;
+        const bool two = t + NU < nt;
         tile_of(t, I0, K0);
-        tile_of(two ? t + 3 : t, I1, K1);
+        tile_of(two ? t + NU : t, I1, K1);
         update_tiles(I0, K0, I1, K1, two, J);
       }
     }

@@ -55,6 +55,26 @@ __global__ __launch_bounds__(256, 2) void k2(const double* A, double* out, doubl
   if (which) for (int idx = tid; idx < 2048; idx += 256) uout[128 + idx] = reinterpret_cast<double*>(smem + kOffW)[idx];
 }
 
+__global__ __launch_bounds__(512, 1) void k3(const double* A, double* out, double* uout, int* info, int reps) {
+  using C = SmallCfg<double, 8>;
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  double* P = reinterpret_cast<double*>(smem);
+  double* bvec = reinterpret_cast<double*>(smem + C::OFF_B);
+  const int tid = threadIdx.x;
+  int rc = 0;
+  for (int rep = 0; rep < reps; ++rep) {
+    __syncthreads();
+    for (int idx = tid; idx < 128 * 128; idx += 512) { int c = idx >> 7, r = idx & 127; if (r >= c) P[pidx(r, c)] = A[c * 128 + r]; }
+    if (tid < 128) bvec[tid] = 1.0 + 0.01 * tid;
+    __syncthreads();
+    rc = chol128_cw<kOffW, kOffU, 8>(smem);
+  }
+  if (tid == 0) info[blockIdx.x] = rc;
+  for (int idx = tid; idx < 128 * 128; idx += 512) { int c = idx >> 7, r = idx & 127; if (r >= c) out[c * 128 + r] = P[pidx(r, c)]; }
+  if (tid < 128) uout[tid] = bvec[tid];
+  for (int idx = tid; idx < 2048; idx += 512) uout[128 + idx] = reinterpret_cast<double*>(smem + kOffW)[idx];
+}
+
 int run2() {
   std::vector<double> A(128 * 128);
   for (int c = 0; c < 128; ++c) for (int r = 0; r < 128; ++r) A[c * 128 + r] = ((r == c ? 200.0 : 0.0) + std::cos(0.37 * (r + 1) * (c + 1)));
@@ -66,21 +86,22 @@ int run2() {
   hipEvent_t e0, e1; CK(hipEventCreate(&e0)); CK(hipEventCreate(&e1));
   const int reps = 50;
   unsigned long long zero[8] = {0};
-  std::vector<double> L[3], U[3];
-  for (int which = 0; which < 3; ++which) {
+  CK(hipFuncSetAttribute(reinterpret_cast<const void*>(k3), hipFuncAttributeMaxDynamicSharedMemorySize, kLds2));
+  std::vector<double> L[4], U[4];
+  for (int which = 0; which < 4; ++which) {
     for (int grid : {1, 256}) {
       float ms;
-      k2<<<grid, 256, kLds2>>>(dA, dO, dU, dI, 2, which);
+      if (which == 3) k3<<<grid, 512, kLds2>>>(dA, dO, dU, dI, 2); else k2<<<grid, 256, kLds2>>>(dA, dO, dU, dI, 2, which);
       CK(hipMemcpyToSymbol(HIP_SYMBOL(g_stamps), zero, sizeof(zero)));
       CK(hipEventRecord(e0));
-      k2<<<grid, 256, kLds2>>>(dA, dO, dU, dI, reps, which);
+      if (which == 3) k3<<<grid, 512, kLds2>>>(dA, dO, dU, dI, reps); else k2<<<grid, 256, kLds2>>>(dA, dO, dU, dI, reps, which);
       CK(hipEventRecord(e1)); CK(hipEventSynchronize(e1)); CK(hipEventElapsedTime(&ms, e0, e1));
       unsigned long long st[8];
       CK(hipMemcpyFromSymbol(st, HIP_SYMBOL(g_stamps), sizeof(st)));
       int info; CK(hipMemcpy(&info, dI, 4, hipMemcpyDeviceToHost));
-      printf("%s grid=%d: %.2f us per factorisation (info=%d)", which == 2 ? "chol128_cw " : (which ? "chol128_dpp" : "phase_chol "), grid, ms * 1e3 / reps, info);
+      printf("%s grid=%d: %.2f us per factorisation (info=%d)", which == 3 ? "chol128_cw8" : (which == 2 ? "chol128_cw " : (which ? "chol128_dpp" : "phase_chol ")), grid, ms * 1e3 / reps, info);
       if (grid == 1) {
-        if (which == 2) printf("  chain wave, cycles/fact: first tile %llu | wait B2 %llu | solve row J+1 + update its diagonal tile %llu | wait B3 %llu | factor + invert + stores %llu",
+        if (which >= 2) printf("  chain wave, cycles/fact: first tile %llu | wait B2 %llu | solve row J+1 + update its diagonal tile %llu | wait B3 %llu | factor + invert + stores %llu",
                st[1] / reps, st[2] / reps, st[3] / reps, st[4] / reps, st[5] / reps);
         else if (which) printf("  cycles/fact: load-tiles %llu | barrier %llu | diag tile factor + inverse %llu | u_J, stores, solves %llu | barrier %llu | r update + trailing %llu",
                st[0] / reps, st[1] / reps, st[2] / reps, st[3] / reps, st[4] / reps, st[5] / reps);
@@ -93,7 +114,7 @@ int run2() {
     CK(hipMemcpy(L[which].data(), dO, 128 * 128 * 8, hipMemcpyDeviceToHost));
     CK(hipMemcpy(U[which].data(), dU, (128 + 2048) * 8, hipMemcpyDeviceToHost));
   }
-  for (int w = 1; w < 3; ++w) {
+  for (int w = 1; w < 4; ++w) {
   double dl = 0, du = 0, ml = 0, mu = 0;
   for (int c = 0; c < 128; ++c) for (int r = c; r < 128; ++r) { dl = fmax(dl, fabs(L[0][c * 128 + r] - L[w][c * 128 + r])); ml = fmax(ml, fabs(L[0][c * 128 + r])); }
   for (int i = 0; i < 128; ++i) { du = fmax(du, fabs(U[0][i] - U[w][i])); mu = fmax(mu, fabs(U[0][i])); }
@@ -103,7 +124,7 @@ int run2() {
     for (int k = 0; k < 16; ++k) { const int rr = 16 * J + k, cc = 16 * J + c; s += U[w][128 + (16 * J + i) * 16 + k] * (rr >= cc ? L[w][cc * 128 + rr] : 0.0); }
     dw = fmax(dw, fabs(s - (i == c ? 1.0 : 0.0)));
   }
-  printf("%s vs phase_chol: max |dL| %.3e (max |L| %.3e) | max |du| %.3e (max |u| %.3e) | max |W_J L_JJ - I| %.3e\n", w == 2 ? "chol128_cw " : "chol128_dpp", dl, ml, du, mu, dw);
+  printf("%s vs phase_chol: max |dL| %.3e (max |L| %.3e) | max |du| %.3e (max |u| %.3e) | max |W_J L_JJ - I| %.3e\n", w == 3 ? "chol128_cw8" : (w == 2 ? "chol128_cw " : "chol128_dpp"), dl, ml, du, mu, dw);
   }
   return 0;
 }
