@@ -1467,7 +1467,7 @@ using KernArgPtr = const __attribute__((address_space(4))) PosteriorArgs<T>*;
 template <typename T, int NB>
 BLR_PHASE int glue_prior(char* smem, KernArgPtr<T> ap, int reg) {
   using C = SmallCfg<T, NB>;
-#define a (*ap)
+  const __attribute__((address_space(4))) PosteriorArgs<T>& a = *ap;  // (the kernarg segment: scalar loads where a field is used)
   T* const P = reinterpret_cast<T*>(smem);
   double* const scr = reinterpret_cast<double*>(smem + C::OFF_SCR);
   int* const iscr = reinterpret_cast<int*>(smem + C::OFF_SCR + 64);
@@ -1532,14 +1532,13 @@ BLR_PHASE int glue_prior(char* smem, KernArgPtr<T> ap, int reg) {
   if (tid == 0) ctx->logdet_Lw = logdet_Lw;
   __syncthreads();
   return 0;
-#undef a
 }
 
 // after the Gram phase: the noise check of reference :79 and the posterior precision (:92).  Returns 1 when the regressor is finished.
 template <typename T, int NB>
 BLR_PHASE int glue_after_gram(char* smem, KernArgPtr<T> ap, int reg) {
   using C = SmallCfg<T, NB>;
-#define a (*ap)
+  const __attribute__((address_space(4))) PosteriorArgs<T>& a = *ap;
   T* const P = reinterpret_cast<T*>(smem);
   int* const iscr = reinterpret_cast<int*>(smem + C::OFF_SCR + 64);
   const int tid = threadIdx.x;
@@ -1557,14 +1556,13 @@ BLR_PHASE int glue_after_gram(char* smem, KernArgPtr<T> ap, int reg) {
       for (int r = tid & 63; r < D; r += kWave) out[(int64_t)c * a.ldlp + r] = (r >= c) ? P[pidx(r, c)] : P[pidx(c, r)];
   }
   return 0;
-#undef a
 }
 
 // the regressor's status, and what goes out when it succeeded: mw' = mw + m (:68), the evidence (:84 + :57)
 template <typename T, int NB>
 BLR_PHASE void glue_finish(char* smem, KernArgPtr<T> ap, int reg, int info) {
   using C = SmallCfg<T, NB>;
-#define a (*ap)
+  const __attribute__((address_space(4))) PosteriorArgs<T>& a = *ap;
   T* const bvec = reinterpret_cast<T*>(smem + C::OFF_B);
   double* const scr = reinterpret_cast<double*>(smem + C::OFF_SCR);
   RegCtx<T>* ctx = reinterpret_cast<RegCtx<T>*>(smem + C::OFF_CTX);
@@ -1584,7 +1582,6 @@ BLR_PHASE void glue_finish(char* smem, KernArgPtr<T> ap, int reg, int info) {
       a.logpdf[reg] = -0.5 * ((double)a.N * LOG2PI + scr[5] + scr[4] + scr[7] - ctx->logdet_Lw - scr[6]);  // :84 + :57
     }
   }
-#undef a
 }
 
 // Occupancy target: D <= 64 (NB <= 4) is HBM/latency-bound -- four workgroups per CU
@@ -1594,7 +1591,7 @@ template <typename T, int NB, int MODE /* data loader: 0 ColVecs generic, 1 RowV
 __global__ __launch_bounds__(kThreads, (NB <= 4 ? 4 : (sizeof(T) == 4 ? BLR_F32_WAVES_PER_SIMD : 2))) void fused_small_kernel(PosteriorArgs<T> a_kernarg) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
   const KernArgPtr<T> ap = (KernArgPtr<T>)__builtin_amdgcn_kernarg_segment_ptr();
-#define a (*ap)
+  const __attribute__((address_space(4))) PosteriorArgs<T>& a = *ap;
   for (int reg = blockIdx.x; reg < a.B; reg += gridDim.x) {
     // ---- phase 0: prior -----------------------------------------------------------------------
     if (glue_prior<T, NB>(smem, ap, reg) != 0) continue;
@@ -1629,7 +1626,6 @@ __global__ __launch_bounds__(kThreads, (NB <= 4 ? 4 : (sizeof(T) == 4 ? BLR_F32_
 #endif
 #endif
   }
-#undef a
 }
 
 }  // namespace blr
