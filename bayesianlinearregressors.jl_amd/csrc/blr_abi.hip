@@ -34,7 +34,7 @@ using namespace blr;
 // handle is created (BLR_MI355X_<KEY>), and settable per handle with blr_set_option: no getenv on any launch path.
 struct BlrOptions {
   bool no_ldsdma = false, no_wave_kernel = false, no_gram_ring = false, no_diag_split = false, no_xcd_swizzle = false,
-       no_mfma_project = false, plan_debug = false, no_i8_gram = false, no_marg_gemm = false, no_i8_diag = false, no_i8_factor = false, no_i8_rowvecs = false, no_grad_gemm = false, no_i8_dense = false, no_i8_fallback = false;
+       no_mfma_project = false, plan_debug = false, no_i8_gram = false, no_marg_gemm = false, no_i8_diag = false, no_i8_factor = false, no_i8_rowvecs = false, no_grad_gemm = false, no_i8_dense = false, no_i8_fallback = false, no_bf16x3 = false;
   int wave_split = 0;     // waves per regressor of the wave kernel: 0 = router, else 1 | 2 | 4
   int chain_batch = 0;    // regressors per shared launch at D > 128: 0 = as many as the workspace holds
   int i8_probe_min = 0;   // int8 route: batches beyond this many regressors start with a probe slice; 0 = kI8ProbeMin
@@ -68,6 +68,7 @@ struct BlrOptions {
     if (!strcmp(key, "NO_I8_FACTOR")) return flag(no_i8_factor);
     if (!strcmp(key, "NO_I8_ROWVECS")) return flag(no_i8_rowvecs);
     if (!strcmp(key, "NO_I8_DENSE")) return flag(no_i8_dense);
+    if (!strcmp(key, "NO_BF16X3")) return flag(no_bf16x3);
     if (!strcmp(key, "NO_I8_FALLBACK")) return flag(no_i8_fallback);
     long v = 0;
     if (!strcmp(key, "WAVE_SPLIT")) {
@@ -110,7 +111,7 @@ struct BlrOptions {
   void from_environment() {
     // boolean flags: a variable that is set -- even to the empty string -- switches the flag on
     for (const char* k : {"NO_LDSDMA", "NO_WAVE_KERNEL", "NO_GRAM_RING", "NO_DIAG_SPLIT", "NO_XCD_SWIZZLE", "NO_MFMA_PROJECT", "PLAN_DEBUG",
-                          "NO_I8_GRAM", "NO_MARG_GEMM", "NO_GRAD_GEMM", "NO_I8_DIAG", "NO_I8_FACTOR", "NO_I8_ROWVECS", "NO_I8_DENSE", "NO_I8_FALLBACK"}) {
+                          "NO_I8_GRAM", "NO_MARG_GEMM", "NO_GRAD_GEMM", "NO_I8_DIAG", "NO_I8_FACTOR", "NO_I8_ROWVECS", "NO_I8_DENSE", "NO_I8_FALLBACK", "NO_BF16X3"}) {
       const std::string name = std::string("BLR_MI355X_") + k;
       if (const char* v = getenv(name.c_str())) (void)set(k, *v ? v : "1");
     }
@@ -879,10 +880,14 @@ int posterior_large_group(blr_handle* h, const PosteriorArgs<T>& a, int64_t reg0
 
   // ---- Gram (reference :86) : split-K partial tiles, then the prior factor as pseudo-observations
   if ((rc = set_lds<T>(h, reinterpret_cast<const void*>(gram_tile_kernel<T>), LC::LDS_BYTES))) return rc;
+  if constexpr (sizeof(T) == 4) {
+    if ((rc = set_lds<T>(h, reinterpret_cast<const void*>(gram_tile_kernel<T, true>), LC::LDS_BYTES))) return rc;
+  }
   GramTileArgs<T> g{};
   g.X = X; g.ldx = a.ldx; g.layout = a.layout;
   const bool no_ring = h->opt.no_gram_ring;  // A/B experiments only
   g.use_dma = (a.layout == LAYOUT_COLVECS && ((uintptr_t)X % 16 == 0) && ((a.ldx * (int64_t)sizeof(T)) % 16 == 0)) ? (no_ring ? 2 : 1) : 0;
+  g.bf3 = (sizeof(T) == 4 && !h->opt.no_bf16x3) ? 1 : 0;  // (f32 only: the ring loop is)
   g.s = s; g.noise_kind = a.noise_kind; g.r = rvec; g.wpre = wvec;
   g.D = D; g.n_begin = 0; g.n_end = N; g.nblocks = NC; g.bpart = bpart; g.mode_out = 0;
   g.grp_X = a.strideX; g.grp_s = a.strides; g.grp_ws = wsb;
@@ -898,7 +903,12 @@ int posterior_large_group(blr_handle* h, const PosteriorArgs<T>& a, int64_t reg0
     g.nsplit_diag = nsplit_diag; g.nlong = nlong;
     g.xcd_swizzle = (nsp > 1 && !no_swizzle) ? (nlong == 0 ? 1 : 2) : 0;  // (three kinds of work items: remapped inside a kind, the dispatch order of the kinds IS the plan)
     const int nwg = nsplit_diag ? (nt - NC) * nsp - nlong + NC * nsplit_diag : nt * nsp;
-    hipLaunchKernelGGL(gram_tile_kernel<T>, dim3(nwg, G), dim3(kThreads), LC::LDS_BYTES, st, g);
+    if constexpr (sizeof(T) == 4) {
+      if (g.bf3) hipLaunchKernelGGL((gram_tile_kernel<T, true>), dim3(nwg, G), dim3(kThreads), LC::LDS_BYTES, st, g);
+      else hipLaunchKernelGGL(gram_tile_kernel<T>, dim3(nwg, G), dim3(kThreads), LC::LDS_BYTES, st, g);
+    } else {
+      hipLaunchKernelGGL(gram_tile_kernel<T>, dim3(nwg, G), dim3(kThreads), LC::LDS_BYTES, st, g);
+    }
     if (prior_factor) {
       GramTileArgs<T> u = g;
       u.xcd_swizzle = 0;

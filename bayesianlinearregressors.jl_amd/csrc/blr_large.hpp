@@ -275,12 +275,58 @@ __device__ __forceinline__ void gram_kstep_ring(typename Mfma<T>::acc4 (&acc)[4]
 #undef BLR_M
 }
 
+// ---- the same product on the bf16 matrix cores: an fp32 number is EXACTLY three bf16 numbers ------------------------------------------------
+// (24 mantissa bits = 3 x 8: bf16(x), bf16 of the remainder, the rest); of the nine products the six with hh, hm, mh, mm, hl, lh
+// keep fp32-level accuracy under fp32 accumulation (tools/bf3_unit.hip: 2.6e-7 of sum |a b| against 2.1e-7 for an fp32 fma chain), and
+// v_mfma_f32_32x32x16_bf16 runs at 2.2 PFLOP/s against 0.155 for v_mfma_f32_16x16x4_f32 (profiles/r05_microbench_bf16_probe.txt):
+// 24 instructions per wave and half-stage instead of 64.  The operands come from the SAME fragment registers: after
+// v_permlane16_swap_b32 of the fragments of row blocks I0 and I0 + 1, lane (r16, q) holds row block I0 + (q & 1) with column
+// 4 ks + 2 (q >> 1) in the first register and 4 ks + 2 (q >> 1) + 1 in the second -- a consistent 32-row operand whose eight k slots are
+// the four k-steps of a half x {first, second}.  Both sides are built the same way, so slot j pairs the same column on both.
+typedef float gram_f16v __attribute__((ext_vector_type(16)));
+typedef __bf16 gram_bf8 __attribute__((ext_vector_type(8)));
+typedef unsigned gram_u4 __attribute__((ext_vector_type(4)));
+struct Bf3Planes { gram_u4 h, m, l; };  // eight bf16 k slots per lane and plane
+typedef __bf16 gram_bf2 __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ unsigned bf3_pk(float lo, float hi) {  // v_cvt_pk_bf16_f32: round to nearest even, `lo` to bits 15:0
+  const gram_bf2 v = {(__bf16)lo, (__bf16)hi};
+  return __builtin_bit_cast(unsigned, v);
+}
+// Rounded to NEAREST at every level (a split by masking truncates: same-sign residuals, and the three dropped products add up coherently
+// over the observations -- 6e-8 of a diagonal entry per 16 columns in tools/bf3_unit.hip, 2.4e-6 of A at config 5 against 3.7e-7 for fp32
+// LAPACK; rounded, the residuals are signed and zero-mean: 1.4e-7 of sum |a b| against 2.1e-7 for an fp32 fma chain)
+__device__ __forceinline__ Bf3Planes bf3_split_pack(const float (&f0)[4], const float (&f1)[4]) {  // fragments of row blocks I0, I0 + 1, four k-steps
+  Bf3Planes p;
+#pragma unroll
+  for (int ks = 0; ks < 4; ++ks) {
+    const auto sw = __builtin_amdgcn_permlane16_swap(__float_as_uint(f0[ks]), __float_as_uint(f1[ks]), false, false);
+    const float x = __uint_as_float(sw[0]), y = __uint_as_float(sw[1]);  // slots 2 ks, 2 ks + 1
+    const unsigned h = bf3_pk(x, y);
+    const float xr = x - __uint_as_float(h << 16), yr = y - __uint_as_float(h & 0xffff0000u);
+    const unsigned m = bf3_pk(xr, yr);
+    const float xl = xr - __uint_as_float(m << 16), yl = yr - __uint_as_float(m & 0xffff0000u);
+    p.h[ks] = h;
+    p.m[ks] = m;
+    p.l[ks] = bf3_pk(xl, yl);
+  }
+  return p;
+}
+__device__ __forceinline__ gram_f16v bf3_mma(const Bf3Planes& a, const Bf3Planes& b, gram_f16v c) {  // smallest terms first
+  c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(gram_bf8, a.l), __builtin_bit_cast(gram_bf8, b.h), c, 0, 0, 0);
+  c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(gram_bf8, a.h), __builtin_bit_cast(gram_bf8, b.l), c, 0, 0, 0);
+  c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(gram_bf8, a.m), __builtin_bit_cast(gram_bf8, b.m), c, 0, 0, 0);
+  c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(gram_bf8, a.m), __builtin_bit_cast(gram_bf8, b.h), c, 0, 0, 0);
+  c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(gram_bf8, a.h), __builtin_bit_cast(gram_bf8, b.m), c, 0, 0, 0);
+  c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(gram_bf8, a.h), __builtin_bit_cast(gram_bf8, b.h), c, 0, 0, 0);
+  return c;
+}
+
 // columns [c0, c0 + 16 nh) of the operand rows rowA.. (A side) and rowB.. (B side); baseA / baseB point at (row, column 0).
 // DIAGT: diagonal macro tile -- one side only (B = A) and only the 36 tiles of 16 x 16 on or below the diagonal: waves 0 and 3
 // take the 10 of their diagonal quadrant (acc[i][k], k <= i), waves 2 and 1 share the quadrant below the diagonal (its tile rows
 // 0-1 / 2-3, acc[0..1][k]); wave 1 -- which used to sit out -- also accumulates b_I = X_I r (r != NULL).  10 MFMAs per k-step
 // on the critical waves instead of 16: the host gives diagonal tiles longer column ranges (fewer splits) to match.
-template <typename T, bool SCALE, bool DIAGT, bool PRE = false /* s holds the weights 1 / s_n themselves */>
+template <typename T, bool SCALE, bool DIAGT, bool PRE = false /* s holds the weights 1 / s_n themselves */, bool BF3 = false /* off-diagonal tiles on the bf16 matrix cores */>
 __device__ __forceinline__ void gram_ring_loop(T* __restrict__ ring, T* __restrict__ wring, T* __restrict__ rring,
                                                const BLR_GLOBAL T* baseA, int64_t ldA, const BLR_GLOBAL T* baseB, int64_t ldB,
                                                const BLR_GLOBAL T* s /* + c0; SCALE */, const BLR_GLOBAL T* r /* + c0 or NULL; DIAGT */,
@@ -423,7 +469,185 @@ __device__ __forceinline__ void gram_ring_loop(T* __restrict__ ring, T* __restri
       }
     }
   };
-  if constexpr (!DIAGT) {
+  // the whole quadrant on the bf16 matrix cores (see bf3_split_pack): per half the 32 fragments of its four k-steps are read, scaled,
+  // split and packed, then 2 x 2 tiles of 32 x 32 take six products each; the finished quadrant goes back to the 16 x 16 accumulator
+  // layout of the kernel's epilogues through the (then free) ring, 16 KiB per wave
+  auto run_bf3 = [&]() {
+    gram_f16v accb[2][2];
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+      for (int k = 0; k < 2; ++k)
+#pragma unroll
+        for (int v = 0; v < 16; ++v) accb[i][k][v] = 0.f;
+    T wcur[4] = {T(1), T(1), T(1), T(1)}, wnxt[4] = {T(1), T(1), T(1), T(1)};
+    const int rowA0 = 4 * wr, colB0 = 4 * wc;
+    if constexpr (SCALE) {
+#pragma unroll
+      for (int j = 0; j < 4; ++j) wcur[j] = PRE ? wring[4 * j + (lane >> 4)] : fast_rcp(wring[4 * j + (lane >> 4)]);
+    }
+#pragma unroll 1
+    for (int h = 0; h < nh; ++h) {
+      const T* slot = ring + (h & 3) * HALF;
+      const T* kA = slot + rowA0 * 64 + lane;
+      const T* kB = slot + SIDE + colB0 * 64 + lane;
+      const T* wv_n = wring + ((h + 1) & 3) * HC + (lane >> 4);
+      const bool more = h + 3 < nh;  // slot (h + 3) % 4 was freed by the barrier that ended half h-1
+      float fa[4][4], fb[4][4];  // [row block][k-step]
+#pragma unroll
+      for (int j = 0; j < 4; ++j)
+#pragma unroll
+        for (int i = 0; i < 4; ++i) { fa[i][j] = kA[j * 512 + i * 64]; fb[i][j] = kB[j * 512 + i * 64]; }
+      if (more) { issue_first(); issue_second(); }
+      if constexpr (SCALE) {
+#pragma unroll
+        for (int j = 0; j < 4; ++j) wnxt[j] = PRE ? wv_n[4 * j] : fast_rcp(wv_n[4 * j]);  // half h+1: visible since the last barrier
+#pragma unroll
+        for (int j = 0; j < 4; ++j)
+#pragma unroll
+          for (int i = 0; i < 4; ++i) fa[i][j] *= wcur[j];  // Sigma_y^-1 on the A side only
+      }
+      const Bf3Planes a0 = bf3_split_pack(fa[0], fa[1]), a1 = bf3_split_pack(fa[2], fa[3]);
+      const Bf3Planes b0 = bf3_split_pack(fb[0], fb[1]), b1 = bf3_split_pack(fb[2], fb[3]);
+      accb[0][0] = bf3_mma(a0, b0, accb[0][0]);
+      accb[0][1] = bf3_mma(a0, b1, accb[0][1]);
+      accb[1][0] = bf3_mma(a1, b0, accb[1][0]);
+      accb[1][1] = bf3_mma(a1, b1, accb[1][1]);
+#pragma unroll
+      for (int j = 0; j < 4; ++j) wcur[j] = wnxt[j];
+      if (h + 1 < nh) {
+        if (h + 2 < nh) retire(more);
+        __syncthreads();
+      }
+    }
+    __syncthreads();  // everybody is done with the ring
+    float* const Q = ring + wave * 4096;  // this wave's 64 x 64 quadrant, row-major
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+      for (int k = 0; k < 2; ++k)
+#pragma unroll
+        for (int v = 0; v < 16; ++v) Q[(32 * i + 8 * (v >> 2) + 4 * (lane >> 5) + (v & 3)) * 64 + 32 * k + (lane & 31)] = accb[i][k][v];
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    __builtin_amdgcn_wave_barrier();
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+      for (int k = 0; k < 4; ++k)
+#pragma unroll
+        for (int v = 0; v < 4; ++v) acc[i][k][v] += Q[(16 * i + Mfma<T>::crow(lane, v)) * 64 + 16 * k + (lane & 15)];
+  };
+  // diagonal macro tile on the bf16 matrix cores: the lower triangle as 10 tiles of 32 x 32 (pi, pk), pk <= pi, dealt 3 + 2 + 3 + 2 --
+  // wave 0: (0,0) (1,0) (1,1); wave 1: (3,0) (3,1) and the b partials (it issues their LDS-DMA piece); wave 2: (2,0) (2,1) (2,2);
+  // wave 3: (3,2) (3,3) -- 18 matrix instructions per half on the critical waves against 24 of an off-diagonal tile: the ratio the
+  // host's split plan assumes (kDiagCost).  The A role of a row pair carries Sigma_y^-1, the B role does not: up to four splits per wave.
+  // The finished triangle goes through the ring (128 x 128 floats) into the accumulator dealing the epilogue expects.
+  auto run_bf3_diag = [&](auto wtag) {
+    constexpr int W = decltype(wtag)::value;
+    constexpr int NTL = (W == 0 || W == 2) ? 3 : 2;
+    constexpr int PI[3] = {W == 0 ? 0 : (W == 2 ? 2 : 3), W == 0 ? 1 : (W == 2 ? 2 : 3), W == 0 ? 1 : 2};
+    constexpr int PK[3] = {W == 0 ? 0 : (W == 3 ? 2 : 0), W == 0 ? 0 : (W == 3 ? 3 : 1), W == 0 ? 1 : 2};
+    constexpr unsigned AMASK = W == 0 ? 0x3u : (W == 2 ? 0x4u : 0x8u);                       // row pairs in the A role (scaled)
+    constexpr unsigned BMASK = W == 0 ? 0x3u : (W == 1 ? 0x3u : (W == 2 ? 0x7u : 0xcu));     // row pairs in the B role
+    gram_f16v accb[3];
+#pragma unroll
+    for (int i = 0; i < 3; ++i)
+#pragma unroll
+      for (int v = 0; v < 16; ++v) accb[i][v] = 0.f;
+    T wcur[4] = {T(1), T(1), T(1), T(1)}, wnxt[4] = {T(1), T(1), T(1), T(1)};
+    if constexpr (SCALE) {
+#pragma unroll
+      for (int j = 0; j < 4; ++j) wcur[j] = PRE ? wring[4 * j + (lane >> 4)] : fast_rcp(wring[4 * j + (lane >> 4)]);
+    }
+    const bool do_b = W == 1 && r != nullptr;
+#pragma unroll 1
+    for (int h = 0; h < nh; ++h) {
+      const T* slot = ring + (h & 3) * HALF;
+      const T* kA = slot + lane;  // fragment (k-step j, row block i) at kA[j * 512 + i * 64]
+      const T* wv_n = wring + ((h + 1) & 3) * HC + (lane >> 4);
+      const T* rb = rring + (h & 3) * HC + (lane >> 4);
+      const bool more = h + 3 < nh;
+      Bf3Planes PS[4], PU[4];
+      auto do_pair = [&](auto ptag) {
+        constexpr int p = decltype(ptag)::value;
+        if constexpr (((AMASK | BMASK) >> p) & 1u) {
+          float f0[4], f1[4];
+#pragma unroll
+          for (int j = 0; j < 4; ++j) { f0[j] = kA[j * 512 + (2 * p) * 64]; f1[j] = kA[j * 512 + (2 * p + 1) * 64]; }
+          if constexpr ((BMASK >> p) & 1u) PU[p] = bf3_split_pack(f0, f1);
+          if constexpr ((AMASK >> p) & 1u) {
+            if constexpr (SCALE) {
+#pragma unroll
+              for (int j = 0; j < 4; ++j) { f0[j] *= wcur[j]; f1[j] *= wcur[j]; }
+              PS[p] = bf3_split_pack(f0, f1);
+            } else if constexpr ((BMASK >> p) & 1u) {
+              PS[p] = PU[p];
+            } else {
+              PS[p] = bf3_split_pack(f0, f1);
+            }
+          }
+        }
+      };
+      do_pair(std::integral_constant<int, 0>{}); do_pair(std::integral_constant<int, 1>{});
+      do_pair(std::integral_constant<int, 2>{}); do_pair(std::integral_constant<int, 3>{});
+      if constexpr (W == 1) {
+        if (do_b) {
+#pragma unroll
+          for (int j = 0; j < 4; ++j) {
+            const double brn = (double)rb[4 * j];
+#pragma unroll
+            for (int i = 0; i < 8; ++i) bacc[i] += (double)kA[j * 512 + i * 64] * brn;
+          }
+        }
+      }
+      if (more) { issue_first(); issue_second(); }
+      if constexpr (SCALE) {
+#pragma unroll
+        for (int j = 0; j < 4; ++j) wnxt[j] = PRE ? wv_n[4 * j] : fast_rcp(wv_n[4 * j]);
+      }
+      accb[0] = bf3_mma(PS[PI[0]], PU[PK[0]], accb[0]);
+      accb[1] = bf3_mma(PS[PI[1]], PU[PK[1]], accb[1]);
+      if constexpr (NTL == 3) accb[2] = bf3_mma(PS[PI[2]], PU[PK[2]], accb[2]);
+#pragma unroll
+      for (int j = 0; j < 4; ++j) wcur[j] = wnxt[j];
+      if (h + 1 < nh) {
+        if (h + 2 < nh) retire(more);
+        __syncthreads();
+      }
+    }
+    __syncthreads();  // everybody is done with the ring
+    auto put_tile = [&](auto ttag) {
+      constexpr int tl = decltype(ttag)::value;
+      if constexpr (tl < NTL) {
+#pragma unroll
+        for (int v = 0; v < 16; ++v)
+          ring[(32 * PI[tl] + 8 * (v >> 2) + 4 * (lane >> 5) + (v & 3)) * 128 + 32 * PK[tl] + (lane & 31)] = accb[tl][v];
+      }
+    };
+    put_tile(std::integral_constant<int, 0>{}); put_tile(std::integral_constant<int, 1>{}); put_tile(std::integral_constant<int, 2>{});
+    __syncthreads();
+    // the dealing of the f32 roles (gram_tile_kernel's epilogue): waves 0, 3: k <= i of their diagonal quadrant; waves 2, 1: tile rows 4-5 / 6-7
+    constexpr bool half_role = W == 1 || W == 2;
+    constexpr int tr0 = half_role ? 4 + 2 * (W == 1 ? 1 : 0) : 4 * (W >> 1), tc0 = half_role ? 0 : 4 * (W & 1);
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+      for (int k = 0; k < 4; ++k) {
+        if (half_role ? i >= 2 : k > i) continue;
+#pragma unroll
+        for (int v = 0; v < 4; ++v) acc[i][k][v] += ring[(16 * (tr0 + i) + Mfma<T>::crow(lane, v)) * 128 + 16 * (tc0 + k) + (lane & 15)];
+      }
+  };
+  if constexpr (DIAGT && BF3) {
+    switch (wave) {  // (uniform)
+      case 0: run_bf3_diag(std::integral_constant<int, 0>{}); break;
+      case 1: run_bf3_diag(std::integral_constant<int, 1>{}); break;
+      case 2: run_bf3_diag(std::integral_constant<int, 2>{}); break;
+      default: run_bf3_diag(std::integral_constant<int, 3>{}); break;
+    }
+  } else if constexpr (!DIAGT && BF3) {
+    run_bf3();
+  } else if constexpr (!DIAGT) {
     run(std::integral_constant<int, 0>{});
   } else {
     if (wave == 0 || wave == 3) run(std::integral_constant<int, 1>{});
@@ -436,6 +660,7 @@ struct GramTileArgs {
   const T* X; int64_t ldx;   // operand matrix; element (d, n) at X[d + n*ldx] (ColVecs) or X[n + d*ldx] (RowVecs)
   int layout;                // LAYOUT_COLVECS / LAYOUT_ROWVECS / 2 = upper factor as pseudo-columns (mask n <= d)
   int use_dma;               // ColVecs, 16-byte aligned: LDS-DMA staging (1: + the ring loop for full off-diagonal f32 tiles, 2: stage loop only)
+  int bf3;                   // f32 ring loop: full off-diagonal macro tiles as bf16 x 3 products on the bf16 matrix cores (see bf3_split_pack)
   const T* s; int noise_kind;  // weights w_n = 1/s_n; s == NULL: w = 1
   const T* r;                // delta_n / s_n for the b partials (NULL: skip)
   const T* wpre;             // diagonal noise: 1 / s_n precomputed (colstats_kernel), used by the ring loop instead of s; may be NULL
@@ -464,7 +689,9 @@ struct GramTileArgs {
   int64_t grp_X, grp_s, grp_ws;
 };
 
-template <typename T>
+// BF3K: the instantiation whose full f32 ring tiles run on the bf16 matrix cores (the posterior's Gram launch); a kernel of its own so
+// that the plain f32 one keeps its register allocation (sharing one kernel cost the f32 path 15 %)
+template <typename T, bool BF3K = false>
 __global__ __launch_bounds__(kThreads, (sizeof(T) == 4 ? BLR_GRAM_WGS : 2)) void gram_tile_kernel(GramTileArgs<T> a) {
   using L = LargeCfg<T>;
   using acc4 = typename Mfma<T>::acc4;
@@ -674,7 +901,21 @@ __global__ __launch_bounds__(kThreads, (sizeof(T) == 4 ? BLR_GRAM_WGS : 2)) void
       const BLR_GLOBAL T* rp = want_b ? as_global(a.r + c0) : (const BLR_GLOBAL T*)nullptr;
       const int nh = ncol >> 4;
 #define BLR_RING(SC, DG, PR) gram_ring_loop<T, SC, DG, PR>(slot0, wbuf, rbuf, bA, a.ldx, bB, ldB, sp, rp, c0, nh, voffA, voffB, lane, wave, acc, bacc)
+      if constexpr (BF3K) {
       if (diag_tile) {
+#define BLR_RING3D(SC, PR) gram_ring_loop<T, SC, true, PR, true>(slot0, wbuf, rbuf, bA, a.ldx, bB, ldB, sp, rp, c0, nh, voffA, voffB, lane, wave, acc, bacc)
+        if (pre) BLR_RING3D(true, true);
+        else if (scale) BLR_RING3D(true, false);
+        else BLR_RING3D(false, false);
+#undef BLR_RING3D
+      } else {
+#define BLR_RING3(SC, PR) gram_ring_loop<T, SC, false, PR, true>(slot0, wbuf, rbuf, bA, a.ldx, bB, ldB, sp, rp, c0, nh, voffA, voffB, lane, wave, acc, bacc)
+        if (pre) BLR_RING3(true, true);
+        else if (scale) BLR_RING3(true, false);
+        else BLR_RING3(false, false);
+#undef BLR_RING3
+      }
+      } else if (diag_tile) {
         if (pre) BLR_RING(true, true, true);
         else if (scale) BLR_RING(true, true, false);
         else BLR_RING(false, true, false);
