@@ -720,7 +720,10 @@ int posterior_large_group(blr_handle* h, const PosteriorArgs<T>& a, int64_t reg0
     // workgroup slots that frees go to the off-diagonal tiles.  Chosen so that the longest workgroup is shortest
     // (c3: 36 x 14 -> 28 x 15 + 8 x 11, i.e. 16 N / 14 -> 16 N / 15 per workgroup on 508 of 512 slots: 0.963 -> 0.935 ms;
     // tools/scan_splits.sh).  Multi-round launches (c5: 136 tiles x 15) keep one factor: there the dispatcher balances.
-    constexpr double kDiagCost = 11.5;
+    // (on the bf16 matrix cores -- gram_tile_kernel<float, true> -- a diagonal tile is 18 matrix instructions and up to four operand
+    // builds per half against 24 and four: the builds dominate and the tiles cost nearly the same per column; tools/scan_splits.sh at
+    // c3: 15 | 11 0.80 ms, 14 | 14 0.75, 14 | 12 and 13 | 13 0.765)
+    const double kDiagCost = (sizeof(T) == 4 && !h->opt.no_bf16x3) ? 15.5 : 11.5;
     nsplit_diag = 0;  // 0: one factor for all tiles
     nlong = 0;        // strictly lower tiles with one column range less (multi-round launches)
     {
