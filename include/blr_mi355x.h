@@ -73,7 +73,7 @@ int blr_reset_stream(blr_handle* h);              /* back to the handle's own (n
 int blr_set_async(blr_handle* h, int async);      /* 1: DEVICE-memspace calls return after enqueue       */
 int blr_synchronize(blr_handle* h);
 /* Run-time switches of the handle (A/B measurements and tests; the defaults are the measured best).  `key` is one of NO_LDSDMA,
- * NO_WAVE_KERNEL, NO_GRAM_RING, NO_DIAG_SPLIT, NO_XCD_SWIZZLE, NO_MFMA_PROJECT, NO_I8_GRAM, NO_I8_DIAG, NO_I8_FACTOR, NO_I8_ROWVECS, NO_I8_DENSE, NO_I8_FALLBACK, NO_MARG_GEMM, NO_GRAD_GEMM, PLAN_DEBUG (flags: any non-empty value = on),
+ * NO_WAVE_KERNEL, NO_GRAM_RING, NO_DIAG_SPLIT, NO_XCD_SWIZZLE, NO_MFMA_PROJECT, NO_I8_GRAM, NO_I8_DIAG, NO_I8_FACTOR, NO_I8_ROWVECS, NO_I8_DENSE, NO_I8_FALLBACK, NO_BF16X3, NO_MARG_GEMM, NO_GRAD_GEMM, PLAN_DEBUG (flags: any non-empty value = on),
  * WAVE_SPLIT = 1|2|4, CHAIN_BATCH = 1..128, CHAIN_WS_MB, I8_PROBE_MIN = 256..2^20, SWEEP = always|never|auto, GRAM_SPLITS = "o,d[,nlong]" (README.md);
  * a "BLR_MI355X_" prefix is accepted.  value NULL or "" restores the built-in default.  The environment variables
  * BLR_MI355X_<KEY> are read ONCE, by blr_create -- no entry point reads the environment.  -> 0, or -2 / -3 (unknown key /
@@ -138,6 +138,11 @@ int blr_timer_stop(blr_handle* h, float* elapsed_ms); /* records, synchronises, 
  *     "i8_handed_back", ..) counts them, and a batch of more than 4096 regressors (option I8_PROBE_MIN) whose first 256 were handed back by more than a quarter
  *     sends the rest to the fp64 kernel directly.
  * blr_set_option(h, "NO_I8_GRAM", "1") keeps every regressor on the fp64 matrix pipe.
+ * fp32, D > 128, aligned ColVecs: the Gram matrix is formed on the bf16 matrix cores from an EXACT three-way split of every fp32 operand
+ * (x = h + m + l, each rounded to nearest), keeping the six products hh, hm, mh, mm, hl, lh under fp32 accumulation: the dropped ones are
+ * 2^-24 of |a||b| each and zero-mean, the result is as accurate as an fp32 fma chain (tools/bf3_unit.hip; tests hold A to 4 x the error
+ * of fp32 LAPACK on the same inputs, test_c3_full_size / test_c5_full_size).  blr_set_option(h, "NO_BF16X3", "1") uses the fp32 matrix
+ * instruction instead.
  */
 int blr_posterior_batched_f64(blr_handle* h, int memspace, int layout, int64_t B, int64_t D, int64_t N,
                               const double* X, int64_t ldx, int64_t strideX,
