@@ -507,13 +507,10 @@ __device__ __forceinline__ void gram_ring_loop(T* __restrict__ ring, T* __restri
 #pragma unroll
           for (int i = 0; i < 4; ++i) fa[i][j] *= wcur[j];  // Sigma_y^-1 on the A side only
       }
-      // (source order = issue order, more or less: a pair's six matrix instructions run while the next operand is being built)
-      const Bf3Planes a0 = bf3_split_pack(fa[0], fa[1]);
-      const Bf3Planes b0 = bf3_split_pack(fb[0], fb[1]);
+      const Bf3Planes a0 = bf3_split_pack(fa[0], fa[1]), a1 = bf3_split_pack(fa[2], fa[3]);
+      const Bf3Planes b0 = bf3_split_pack(fb[0], fb[1]), b1 = bf3_split_pack(fb[2], fb[3]);
       accb[0][0] = bf3_mma(a0, b0, accb[0][0]);
-      const Bf3Planes b1 = bf3_split_pack(fb[2], fb[3]);
       accb[0][1] = bf3_mma(a0, b1, accb[0][1]);
-      const Bf3Planes a1 = bf3_split_pack(fa[2], fa[3]);
       accb[1][0] = bf3_mma(a1, b0, accb[1][0]);
       accb[1][1] = bf3_mma(a1, b1, accb[1][1]);
 #pragma unroll
