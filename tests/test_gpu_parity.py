@@ -2961,6 +2961,47 @@ def test_last_route_and_option_codes(B, opt):
     assert h.get_stat("workspace_bytes") >= 0
 
 
+@pytest.mark.parametrize("noise", ["iso", "diag"])
+def test_large_d_fp32_gram_on_bf16_matrix_cores_vs_f32_route(B, opt, noise):
+    # D > 128 in fp32, aligned ColVecs, whole 128-row blocks and column ranges in multiples of 16: the Gram launch forms every macro tile
+    # from an exact three-way bf16 split of the fp32 operands, six products, fp32 accumulation (blr_large.hpp, bf3_split_pack).  Against
+    # the fp64 oracle it must be as good as the fp32 matrix instruction it replaces (option NO_BF16X3): within 4 x its error + 1e-7 on
+    # the precision matrix, and both inside the fp32 tolerances of the other large-D tests.  Positive features on purpose: a split that
+    # truncates instead of rounding is biased exactly there (same-sign residuals add up over the observations).
+    a = B._abi
+    h = a.default_handle()
+    rng = _rng(5150)
+    D, N = 384, 4096
+    X = np.asfortranarray((0.5 + np.abs(rng.standard_normal((D, N)))).astype(np.float32))
+    s = (np.exp(0.3 * rng.standard_normal(N)) if noise == "diag" else np.full(N, 0.7)).astype(np.float32)
+    w0 = rng.standard_normal(D) / np.sqrt(D)
+    y = (X.astype(float).T @ w0 + np.sqrt(s.astype(float)) * rng.standard_normal(N)).astype(np.float32)
+    mw = (0.1 * rng.standard_normal(D)).astype(np.float32)
+    dvec = np.exp(0.2 * rng.standard_normal(D)).astype(np.float32)
+    mw_o, T_o, A_o, lp_o = O.posterior_logpdf_direct(mw.astype(float), dvec.astype(float), X.astype(float), s.astype(float), y.astype(float))
+
+    def run():
+        mwp = np.zeros(D, dtype=np.float32); Tp = np.zeros((D, D), dtype=np.float32, order="F"); Ap = np.zeros((D, D), dtype=np.float32, order="F")
+        lp = np.zeros(1); info = np.zeros(1, dtype=np.int32)
+        if noise == "diag":
+            nk, sv, ss = a.NOISE_DIAGONAL, s, N
+        else:
+            nk, sv, ss = a.NOISE_ISOTROPIC, s[:1].copy(), 0
+        h.posterior_batched(np.float32, a.MEM_HOST, a.LAYOUT_COLVECS, 1, D, N, X, D, N * D, y, N, nk, sv, ss,
+                            a.PRIOR_DIAGONAL, mw, 0, dvec, 1, 0, mwp, D, Tp, D, D * D, Ap, D, D * D, lp, info)
+        assert info[0] == 0
+        return _rel_errs(mwp, Ap, lp[0], mw_o, A_o, lp_o)
+
+    e_bf3 = run()
+    assert h.last_route() == "gram_tile_kernel<float>"
+    opt("NO_BF16X3", "1")
+    e_f32 = run()
+    print(f"large-D fp32 Gram ({noise}): rel err (mw', A, logpdf)  bf16 x 3 {e_bf3}  f32 matrix instruction {e_f32}")
+    assert e_bf3[1] <= 4 * e_f32[1] + 1e-7, (e_bf3, e_f32)
+    assert e_bf3[0] <= 4 * e_f32[0] + 1e-6 and e_bf3[2] <= 4 * e_f32[2] + 1e-7, (e_bf3, e_f32)
+    assert e_bf3[1] <= 2e-5 and e_bf3[2] <= 2e-4
+
+
 @pytest.mark.parametrize("nb", [8192, 1024])
 def test_c4_at_its_stated_batch_vs_literal_oracle(B, nb):
     # BASELINE config 4 exactly as stated -- 8192 x (D = 64, N = 1024), fp64, isotropic noise, Lw = I -- and the 1024-regressor
