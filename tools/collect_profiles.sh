@@ -63,6 +63,10 @@ rocprofv3 --pmc $SQ --kernel-trace --output-format csv -d $OUT/pmc_sq_c3b8 -- $B
   for e in 0 1 4 5; do [ -x ./fused_bench_w$e ] || /opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -std=c++17 -DFB_WAVE -DFB_D=64 -DBLR_WAVE_CLK -DBLR_EXP=$e -I$R/bayesianlinearregressors.jl_amd/csrc fused_bench.hip -o fused_bench_w$e 2>/dev/null; done
   { echo "# tools/fused_bench, -DFB_WAVE -DFB_D=64 -DBLR_WAVE_CLK: EXP=0 the kernel, 1 Gram phase only, 4 no LDS-DMA (MFMAs on stale data), 5 LDS-DMA only"; for e in 0 1 4 5; do ./fused_bench_w$e 8192 1024 0 30 | tail -2; done; } > $OUT/c4_clocks.txt 2>&1
   { echo "# tools/chol_bench: phase_chol, cycles per section (wave 0), f32 and f64; tools/chol_bench 2: the experiments of blr_chol_dpp_experiment.hpp"; ./chol_bench; ./chol_bench 2; } > $OUT/chol_bench.txt 2>&1
+  # bf16 matrix instructions next to the f32 one, and the unit check of the bf16 x 3 product the fp32 large-D Gram uses
+  [ -x ./bf16_probe ] || /opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -std=c++17 bf16_probe.hip -o bf16_probe 2>/dev/null
+  [ -x ./bf3_unit ] || /opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -std=c++17 bf3_unit.hip -o bf3_unit 2>/dev/null
+  { echo "# tools/bf16_probe: matrix instructions of gfx950, 8 accumulators per wave (the 16 x 16 forms are latency-bound at that depth)"; ./bf16_probe; echo "# tools/bf3_unit"; ./bf3_unit; } > $OUT/bf16_probe.txt 2>&1
   # sustained (>= 2.5 s of back-to-back launches) in-kernel clock of the int8 kernel, N(0,1) operands against zeros
   [ -x ./i8_gram_st ] && { I8_SUSTAINED=2.5 ./i8_gram_st 4096 4096 4 0 | grep "sustained"; I8_SUSTAINED=2.5 ./i8_gram_st 4096 4096 4 3 | grep "sustained"; } > $OUT/i8_sustained.txt 2>&1 )
 # every secondary entry of the driver line: kernel stats of the hot-path rows, HBM bytes per CALL (all of a call's kernels) by PMC

@@ -135,7 +135,7 @@ for key, d, kern, units in (("c2_f32_fused_small_kernel_hbm", "c2f32", "fused_sm
 for src in sorted(glob.glob(os.path.join(os.path.dirname(RAW), "microbench", "*.txt"))):  # tools/run_microbench.sh
     if os.path.getsize(src):
         shutil.copy(src, os.path.join(DST, f"{tag}_microbench_{os.path.basename(src)}"))
-for extra in ("ring_probe.txt", "power_probe.txt", "i8_gram.txt", "i8_sustained.txt", "c4_clocks.txt", "chol_bench.txt", "marg_bench.txt", "marg128_bench.txt", "group_scan.txt", "layout_time.txt", "rowvecs_gap.txt"):
+for extra in ("ring_probe.txt", "power_probe.txt", "i8_gram.txt", "i8_sustained.txt", "c4_clocks.txt", "chol_bench.txt", "bf16_probe.txt", "marg_bench.txt", "marg128_bench.txt", "group_scan.txt", "layout_time.txt", "rowvecs_gap.txt"):
     src = os.path.join(RAW, extra)
     if os.path.exists(src) and os.path.getsize(src):
         shutil.copy(src, os.path.join(DST, f"{tag}_microbench_{extra}"))
