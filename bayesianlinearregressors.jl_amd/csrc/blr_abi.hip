@@ -686,7 +686,7 @@ inline GramPlan plan_gram_rounds(int n_off, int NC, int s0, int N, int nsc, int 
 // the small kernels around the Gram launch.  G = 1 is the single-regressor path.
 template <typename T>
 int posterior_large_group(blr_handle* h, const PosteriorArgs<T>& a, int64_t reg0, int G, int* G_done = nullptr) {
-  h->route = sizeof(T) == 8 ? "gram_tile_kernel<double>" : "gram_tile_kernel<float>";  // (large-D pipeline: the Gram launch dominates)
+  h->route = sizeof(T) == 8 ? "gram_tile_kernel<double>" : (h->opt.no_bf16x3 ? "gram_tile_kernel<float>" : "gram_tile_kernel<float, true>");  // (large-D pipeline: the Gram launch dominates; <float, true>: full tiles on the bf16 matrix cores)
   using LC = LargeCfg<T>;
   const int D = a.D, N = a.N;
   const int DP = (D + kPB - 1) / kPB * kPB, NC = DP / kPB;

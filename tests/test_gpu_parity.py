@@ -2945,7 +2945,7 @@ def test_last_route_and_option_codes(B, opt):
     assert post(128, 100, 2) == "fused_small_kernel<double, 8, 4>"
     assert post(64, 100, 2) == "fused_wave_kernel<double, 4, 4>"
     assert post(48, 100, 2, np.float32).startswith("fused_small_kernel<float, 3,")
-    assert post(256, 300, 2, np.float32) == "gram_tile_kernel<float>"
+    assert post(256, 300, 2, np.float32) == "gram_tile_kernel<float, true>"
     opt("NO_I8_GRAM", "1")
     assert post(128, 512, 2) == "fused_small_kernel<double, 8, 4>"
     for key, value, code in (("NO_SUCH_SWITCH", "1", -2), ("WAVE_SPLIT", "3", -3), ("CHAIN_BATCH", "abc", -3), ("CHAIN_BATCH", "12x", -3),
@@ -2993,9 +2993,10 @@ def test_large_d_fp32_gram_on_bf16_matrix_cores_vs_f32_route(B, opt, noise):
         return _rel_errs(mwp, Ap, lp[0], mw_o, A_o, lp_o)
 
     e_bf3 = run()
-    assert h.last_route() == "gram_tile_kernel<float>"
+    assert h.last_route() == "gram_tile_kernel<float, true>"
     opt("NO_BF16X3", "1")
     e_f32 = run()
+    assert h.last_route() == "gram_tile_kernel<float>"
     print(f"large-D fp32 Gram ({noise}): rel err (mw', A, logpdf)  bf16 x 3 {e_bf3}  f32 matrix instruction {e_f32}")
     assert e_bf3[1] <= 4 * e_f32[1] + 1e-7, (e_bf3, e_f32)
     assert e_bf3[0] <= 4 * e_f32[0] + 1e-6 and e_bf3[2] <= 4 * e_f32[2] + 1e-7, (e_bf3, e_f32)
