@@ -11,6 +11,8 @@ One "posterior update" = one regressor's full (mw', T, logpdf).
     python bench.py --gpus 1 --steps 20 --warmup 3
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P \
         bench.py --gpus N --steps K --warmup W
+    python bench.py --gpus N ...          (no launcher: bench.py starts that launcher itself as a child process and relays rank 0's
+                                           line; a launcher that cannot start, or WORLD_SIZE != --gpus, is a non-zero exit)
 
 Output on rank 0 (contract in the task statement): the LAST stdout line is ONE compact JSON object (< 3 KB: metric, value, unit,
 n_gpus, steps, warmup, ms_per_step, dtype, config, roofline, cpu_baseline, scaling, vs_baseline).  At one GPU the other BASELINE
@@ -620,6 +622,46 @@ def timed(torch, stream, dev, fn, steps, warmup):
     return time.perf_counter() - t0, float(np.mean([a.elapsed_time(b) for a, b in ev]))
 
 
+def spawn_ranks(n):
+    """`python bench.py --gpus N` without a launcher: start the N ranks the way the driver would (torch.distributed.run, one process
+    per GPU, rendezvous on 127.0.0.1) as a CHILD process -- this process has not initialised the GPU and never does -- relay its
+    output line by line (rank 0's headline stays the last stdout line) and return its exit code; a launcher that cannot start
+    is a non-zero exit, not a one-rank run.  BLR_BENCH_LAUNCHER overrides the launcher module (tests force a spawn failure with it)."""
+    import socket
+    import subprocess
+
+    with socket.socket() as sk:
+        sk.bind(("127.0.0.1", 0))
+        port = sk.getsockname()[1]
+    launcher = os.environ.get("BLR_BENCH_LAUNCHER", "torch.distributed.run")
+    cmd = [sys.executable, "-m", launcher, "--nnodes=1", f"--nproc-per-node={n}", "--master-addr", "127.0.0.1",
+           "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    print(f"bench.py: --gpus {n} without a launcher: spawning {' '.join(cmd[1:8])} ...", file=sys.stderr, flush=True)
+    try:
+        proc = subprocess.Popen(cmd, env=env, stdout=subprocess.PIPE, text=True, bufsize=1)
+    except OSError as e:
+        print(f"bench.py: could not start the launcher: {e}", file=sys.stderr, flush=True)
+        return 1
+    last = None
+    for line in proc.stdout:
+        sys.stdout.write(line)
+        sys.stdout.flush()
+        if line.strip():
+            last = line
+    rc = proc.wait()
+    if rc == 0:
+        try:
+            ok = json.loads(last).get("n_gpus") == n
+        except Exception:
+            ok = False
+        if not ok:
+            print(f"bench.py: the spawned job did not end with a headline for n_gpus = {n}", file=sys.stderr, flush=True)
+            return 1
+    return rc
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -670,8 +712,13 @@ def main():
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
-    if world != args.gpus and world > 1:
-        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}")
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ and not args.secondary_only:
+        # run bare (no launcher): become the launcher -- N fresh rank processes, BEFORE anything here touches the GPU -- and relay
+        # rank 0's output and the job's exit code.  Never a silent one-rank run labelled n_gpus = 1.
+        raise SystemExit(spawn_ranks(args.gpus))
+    if world != args.gpus:
+        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}: launch one rank per GPU "
+                         f"(python -m torch.distributed.run --nproc-per-node {args.gpus} bench.py --gpus {args.gpus} ...)")
     if args.secondary is None:
         args.secondary = 1 if (headline and world == 1) else 0
     cpu_leg = None
@@ -795,12 +842,23 @@ def main():
 
     # pre-heat: untimed steps for --preheat-seconds of device time (DVFS settles; MI355X_MICROARCH.md, clocks), then the contract's W
     # warm-up steps and EXACTLY K timed steps
+    # (every step issues the exchange, a collective: all ranks must run the SAME number of pre-heat steps -- a loop that ends on
+    # each rank's own clock lets two ranks straddle the boundary and hang.  One timed batch of 8, its time MAXed over the ranks,
+    # gives the count every rank then runs.)
     preheat_steps = 0
     if args.preheat_seconds > 0:
         step()
         torch.cuda.synchronize(dev)
         t_pre = time.perf_counter()
-        while time.perf_counter() - t_pre < args.preheat_seconds:
+        for _ in range(8):
+            step()
+        torch.cuda.synchronize(dev)
+        t_batch = torch.tensor([time.perf_counter() - t_pre], dtype=torch.float64, device=dev if backend == "nccl" else "cpu")
+        if dist is not None:
+            dist.all_reduce(t_batch, op=dist.ReduceOp.MAX)
+        n_batches = max(0, min(100000, int(np.ceil(args.preheat_seconds / max(float(t_batch.item()), 1e-6))) - 1))
+        preheat_steps = 8
+        for _ in range(n_batches):
             for _ in range(8):
                 step()
             torch.cuda.synchronize(dev)

@@ -51,7 +51,11 @@ def pytest_collection_finish(session):
         "two": [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
                 "--master-port", str(_free_port())] + common + ["--gpus", "2"],
         "one": [sys.executable] + common + ["--gpus", "1"],
+        # run BARE, the way the driver calls `python bench.py --gpus 1`: bench.py itself must spawn the two ranks
+        "bare2": [sys.executable] + common + ["--gpus", "2"],
     }
+    env.pop("WORLD_SIZE", None)
+    env.pop("RANK", None)
     for key, cmd in runs.items():
         out = open(os.path.join(tmp, key + ".out"), "w")
         err = open(os.path.join(tmp, key + ".err"), "w")

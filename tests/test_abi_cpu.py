@@ -312,3 +312,25 @@ def test_bench_headline_line_stays_under_3k(repo_root):
         s = bench.secondary_line(name, e)
         assert len(s) <= 300 and json.loads(s)["secondary"] == name
     assert len(bench.secondary_line("x", {"error": "E" * 5000})) < 300
+
+
+def test_bench_bare_multi_gpu_invocation_never_runs_one_rank(repo_root):
+    # `python bench.py --gpus N` without a launcher must either run N ranks or fail -- never one rank labelled
+    # n_gpus = 1.  The spawn happens before anything touches the GPU, so its failure modes are checkable here:
+    #  (a) the launcher cannot start -> non-zero exit, no JSON headline;
+    #  (b) a launcher-provided WORLD_SIZE that disagrees with --gpus -> non-zero exit (also for WORLD_SIZE = 1).
+    import subprocess
+    import sys
+
+    bench = os.path.join(repo_root, "bench.py")
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK")}
+    r = subprocess.run([sys.executable, bench, "--gpus", "2", "--cpu-seconds", "0"], env=dict(env, BLR_BENCH_LAUNCHER="blr_no_such_launcher_module"),
+                       capture_output=True, text=True, timeout=300)
+    assert r.returncode != 0
+    assert not any(ln.startswith("{") and '"n_gpus"' in ln for ln in r.stdout.splitlines())
+    r = subprocess.run([sys.executable, bench, "--gpus", "2", "--cpu-seconds", "0"], env=dict(env, WORLD_SIZE="1", RANK="0"),
+                       capture_output=True, text=True, timeout=300)
+    assert r.returncode != 0 and "WORLD_SIZE=1" in (r.stderr + r.stdout)
+    r = subprocess.run([sys.executable, bench, "--gpus", "1", "--cpu-seconds", "0"], env=dict(env, WORLD_SIZE="2", RANK="0"),
+                       capture_output=True, text=True, timeout=300)
+    assert r.returncode != 0 and "WORLD_SIZE=2" in (r.stderr + r.stdout)

@@ -3199,3 +3199,14 @@ def test_bench_two_ranks_strong_scaling_line(bench_two_rank_runs):
     assert np.isfinite(two["total_log_evidence"])
     assert two["total_log_evidence"] == one["total_log_evidence"]  # bit for bit
     assert two["roofline"]["frac"] > 0 and two["roofline"]["kernel"].startswith("fused_wave_kernel")
+
+
+@pytest.mark.gpu
+def test_bench_two_ranks_bare_invocation_spawns_its_ranks(bench_two_rank_runs):
+    # `python bench.py --config c4 --gpus 2` WITHOUT a launcher used to run one rank and print n_gpus = 1.
+    # It now starts the two ranks itself (before touching the GPU) and relays rank 0's line: same line as the launcher-started run.
+    bare, two = bench_two_rank_runs["bare2"], bench_two_rank_runs["two"]
+    assert bare["n_gpus"] == 2 and bare["scaling"] == "strong"
+    assert bare["config"]["batch_per_gpu"] == 4096 and bare["config"]["global_batch"] == 8192
+    assert bare["total_log_evidence"] == two["total_log_evidence"]  # bit for bit
+
