@@ -686,7 +686,12 @@ inline GramPlan plan_gram_rounds(int n_off, int NC, int s0, int N, int nsc, int 
 // the small kernels around the Gram launch.  G = 1 is the single-regressor path.
 template <typename T>
 int posterior_large_group(blr_handle* h, const PosteriorArgs<T>& a, int64_t reg0, int G, int* G_done = nullptr) {
-  h->route = sizeof(T) == 8 ? "gram_tile_kernel<double>" : (h->opt.no_bf16x3 ? "gram_tile_kernel<float>" : "gram_tile_kernel<float, true>");  // (large-D pipeline: the Gram launch dominates; <float, true>: full tiles on the bf16 matrix cores)
+  // fp32 Gram on the bf16 matrix cores: only where the ring loop runs (aligned ColVecs -- use_dma == 1).  RowVecs / unaligned fp32 calls
+  // take the plain-f32 instantiation, its split plan and its label (they used to launch the BF3K instantiation's f32 loops,
+  // 15 % slower, with a plan costed for bf16 diagonal tiles and a route that named a kernel form that never ran).
+  const bool bf3 = sizeof(T) == 4 && !h->opt.no_bf16x3 && !h->opt.no_gram_ring && a.layout == LAYOUT_COLVECS &&
+                   ((uintptr_t)(a.X + reg0 * a.strideX) % 16 == 0) && ((a.ldx * (int64_t)sizeof(T)) % 16 == 0);
+  h->route = sizeof(T) == 8 ? "gram_tile_kernel<double>" : (bf3 ? "gram_tile_kernel<float, true>" : "gram_tile_kernel<float>");  // (large-D pipeline: the Gram launch dominates; <float, true>: full tiles on the bf16 matrix cores)
   using LC = LargeCfg<T>;
   const int D = a.D, N = a.N;
   const int DP = (D + kPB - 1) / kPB * kPB, NC = DP / kPB;
@@ -723,7 +728,7 @@ int posterior_large_group(blr_handle* h, const PosteriorArgs<T>& a, int64_t reg0
     // (on the bf16 matrix cores -- gram_tile_kernel<float, true> -- a diagonal tile is 18 matrix instructions and up to four operand
     // builds per half against 24 and four: the builds dominate and the tiles cost nearly the same per column; tools/scan_splits.sh at
     // c3: 15 | 11 0.80 ms, 14 | 14 0.75, 14 | 12 and 13 | 13 0.765)
-    const double kDiagCost = (sizeof(T) == 4 && !h->opt.no_bf16x3) ? 15.5 : 11.5;
+    const double kDiagCost = bf3 ? 15.5 : 11.5;
     nsplit_diag = 0;  // 0: one factor for all tiles
     nlong = 0;        // strictly lower tiles with one column range less (multi-round launches)
     {
@@ -890,7 +895,7 @@ int posterior_large_group(blr_handle* h, const PosteriorArgs<T>& a, int64_t reg0
   g.X = X; g.ldx = a.ldx; g.layout = a.layout;
   const bool no_ring = h->opt.no_gram_ring;  // A/B experiments only
   g.use_dma = (a.layout == LAYOUT_COLVECS && ((uintptr_t)X % 16 == 0) && ((a.ldx * (int64_t)sizeof(T)) % 16 == 0)) ? (no_ring ? 2 : 1) : 0;
-  g.bf3 = (sizeof(T) == 4 && !h->opt.no_bf16x3) ? 1 : 0;  // (f32 only: the ring loop is)
+  g.bf3 = bf3 ? 1 : 0;  // (f32 + the LDS-DMA ring only: the bf16 x 3 code lives in the ring loop)
   g.s = s; g.noise_kind = a.noise_kind; g.r = rvec; g.wpre = wvec;
   g.D = D; g.n_begin = 0; g.n_end = N; g.nblocks = NC; g.bpart = bpart; g.mode_out = 0;
   g.grp_X = a.strideX; g.grp_s = a.strides; g.grp_ws = wsb;
@@ -2965,8 +2970,14 @@ int blr_set_option(blr_handle* h, const char* key, const char* value) {
 // second stream could already be counting in it).
 static int switch_stream(blr_handle* h, hipStream_t next) {
   if (next == h->stream) return 0;
+  h->err.clear();
   HIP_TRY(h, hipSetDevice(h->device));
-  HIP_TRY(h, hipStreamSynchronize(h->stream));
+  // The old stream must still be alive here (header).  If the caller has destroyed it all the same, the drain fails -- and must not
+  // leave the handle bound to a dead stream for good: clear the error, drain the device instead, and switch anyway.
+  if (hipStreamSynchronize(h->stream) != hipSuccess) {
+    (void)hipGetLastError();
+    HIP_TRY(h, hipDeviceSynchronize());
+  }
   h->stream = next;
   if (h->ticket) HIP_TRY(h, hipMemsetAsync(h->ticket + 16, 0, 2 * kPanelArriveWords * sizeof(unsigned), h->stream));
   h->panel_launches = 0;
@@ -3003,8 +3014,12 @@ int blr_get_stat(blr_handle* h, const char* key, int64_t* value) {
 }
 int blr_reset_stats(blr_handle* h) {
   if (!h) return -1;
+  h->err.clear();
+  if (h->stats_dev) {  // (device counter first: a failure must not leave the two counters apart)
+    HIP_TRY(h, hipSetDevice(h->device));
+    HIP_TRY(h, hipMemsetAsync(h->stats_dev, 0, sizeof(unsigned long long), h->stream));
+  }
   h->i8_attempted = 0;
-  if (h->stats_dev) HIP_TRY(h, hipMemsetAsync(h->stats_dev, 0, sizeof(unsigned long long), h->stream));
   return 0;
 }
 int blr_set_async(blr_handle* h, int async) {

@@ -84,7 +84,10 @@ __device__ __forceinline__ void glds16(const BLR_GLOBAL void* src, const void* d
 // The same piece with a SCALAR base: global address = saddr (SGPR pair) + voff (per-lane byte offset, 32 bits).  For a full
 // tile the per-lane part of a stage piece's address never changes, so a whole stage costs scalar adds and ONE vector
 // register instead of a 64-bit address computation per piece and lane.  SIZE = 16 (dwordx4) or 4 (dword) bytes per lane.
-template <int SIZE, int LANES = 64>
+// NT: the piece is marked non-temporal -- for inputs that are read ONCE by one workgroup (the per-regressor kernels' X stream).  Measured on
+// fused_i8_kernel: 4.19 against 4.23 ms per 4096 updates on one box and a 20 MHz higher sustained clock (less energy in the cache fills);
+// never for tiles that other workgroups read again from the L2 (gram_tile_kernel).
+template <int SIZE, int LANES = 64, bool NT = false>
 __device__ __forceinline__ void glds_s(uint64_t saddr_uniform, unsigned voff, unsigned lds_addr_uniform) {
   static_assert((SIZE == 16 && LANES == 64) || SIZE == 4, "LDS-DMA piece width");
   static_assert(LANES == 64 || LANES == 32 || LANES == 16 || LANES == 8, "active lanes of the piece");
@@ -93,7 +96,18 @@ __device__ __forceinline__ void glds_s(uint64_t saddr_uniform, unsigned voff, un
   // s_mov -- a build failure, never a silent one; the 64-bit base must really be scalar for the same reason).
   // A 32-lane piece narrows EXEC inside the asm.
   unsigned keep, m0v;
-  if constexpr (SIZE == 16) {
+  if constexpr (SIZE == 16 && NT) {
+    asm volatile(
+        "s_mov_b32 %0, m0\n\t"
+        "v_readfirstlane_b32 %1, %2\n\t"
+        "s_mov_b32 m0, %1\n\t"
+        "s_nop 0\n\t"
+        "global_load_lds_dwordx4 %3, %4 nt\n\t"
+        "s_mov_b32 m0, %0"
+        : "=&s"(keep), "=&s"(m0v)
+        : "v"(lds_addr_uniform), "v"(voff), "s"(saddr_uniform)
+        : "memory");
+  } else if constexpr (SIZE == 16) {
     asm volatile(
         "s_mov_b32 %0, m0\n\t"
         "v_readfirstlane_b32 %1, %2\n\t"

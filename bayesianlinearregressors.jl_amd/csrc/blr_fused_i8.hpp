@@ -120,23 +120,21 @@ struct I8Cfg {
   static constexpr int OFF_DIG = RING_BYTES;
   static constexpr int OFF_YB = OFF_DIG + 2 * DIG_BUF;          // y ring: NSLOT x 32 doubles
   static constexpr int OFF_RW = OFF_YB + NSLOT * KC * 8;        // 1 / sqrt(s_n) ring (diagonal noise): NSLOT x 32 doubles
-  static constexpr int OFF_XCH = OFF_RW + NSLOT * KC * 8;       // exchange: 4 x 6 x 128 ints (row sums; row maxima first)
-  static constexpr int OFF_FLAG = OFF_XCH + 4 * 6 * 128 * 4;    // 16 ints
+  static constexpr int OFF_XCH = OFF_RW + NSLOT * KC * 8;       // exchange: 4 x 128 ints (row maxima; sums of squares of digit 3; y'y shares)
+  static constexpr int OFF_FLAG = OFF_XCH + 4 * 128 * 4;        // 16 ints
   static constexpr int OFF_OFLAG = OFF_FLAG + 64;               // one byte per 32-column block: some entry outgrew its row's capacity (<= 512 blocks + 32)
   static constexpr int OFF_OMASK = OFF_OFLAG + 544;             // the same as 8 x 64-bit masks; then the repair's column masks 32 x 4 words, 4 words of scratch
   static constexpr int LDS_BYTES = OFF_OMASK + 64 + 512 + 32;
   // after the stream the ring is dead: P, bvec, ... of SmallCfg<double, 8> live there (phase_chol / phase_backsolve layout);
   // the conversion tables live in the digit area
-  static constexpr int OFF_VTAB = OFF_DIG;                      // offset-term tables TA, TB, TC: 3 x 128 doubles
-  static constexpr int OFF_SC = OFF_VTAB + 3 * 128 * 8;         // 2^(e_i - 47): 128 doubles
+  static constexpr int OFF_SC = OFF_DIG;                        // 2^(e_i - 47): 128 doubles
   static constexpr int OFF_BRED = OFF_SC + 128 * 8;             // b partials: 4 x 128 doubles
   static constexpr int OFF_GD = OFF_BRED + 4 * 128 * 8;         // diag(G) / sigma^2 WITHOUT the prior (prior-mean terms): 128 doubles
   static constexpr int OFF_TD = OFF_GD + 128 * 8;               // TD: sum_n a_3(i, n)^2 2^32, the diagonal's share of the dropped digit pair (3, 3) (6-group plan): 128 doubles
   static constexpr int OFF_TAIL = OFF_TD + 128 * 8;             // the last N % 32 columns of X (fp64 rank-r term of the hand-over) + their y: 31 x 128 + 32 doubles
-  // (dead ring, above the phase functions' image) what the conversion adds to the products of an entry (i, j), packed per row as the
-  // LEFT index i: {T, 2^(e_i - 47), U_1 .. U_5, TD} and as the RIGHT index j: {T, 2^(e_j - 47), W_1 .. W_5, Lw_j (diagonal prior)} -- 2 x 128 x 8 doubles
+  // (dead ring, above the phase functions' image) the inverses of the eight diagonal blocks of L for the blocked back substitution: 8 x 16 x 16 doubles
   static constexpr int OFF_UW = 80 * 1024;
-  static_assert(SmallCfg<double, 8>::LDS_BYTES <= OFF_UW && OFF_UW + 2 * 128 * 8 * 8 <= RING_BYTES, "the phase functions' LDS image and the conversion records must fit in the dead ring");
+  static_assert(SmallCfg<double, 8>::LDS_BYTES <= OFF_UW && OFF_UW + 8 * 256 * 8 <= RING_BYTES, "the phase functions' LDS image and the block inverses must fit in the dead ring");
   static_assert(OFF_TAIL + (32 * 128 + 32) * 8 <= OFF_YB, "conversion tables and the tail columns / a block under repair must fit in the digit area");
   static_assert(OFF_TAIL + 4 * 32 * 33 * 8 <= OFF_YB, "the four mirror tiles of the conversion (one per diagonal block) use the same area, before the repair");
   static_assert(LDS_BYTES <= 160 * 1024, "LDS of one CU");
@@ -244,12 +242,31 @@ static_assert(I8Plan<7, 0>::NM + I8Plan<7, 1>::NM + I8Plan<7, 2>::NM + I8Plan<7,
 
 __device__ __forceinline__ i32x4 lds_read_b128(const char* p) { return *reinterpret_cast<const i32x4*>(p); }
 
+// Balanced digits.  The six bytes of Q' = Q + 0x8080808080 (top one signed, lower five minus 128 -- one XOR) are digits b_s in
+// [-128, 127] with Q = sum_s b_s 2^(8 (5 - s)) and NO offsets: Q' - 0x8080808080 = d'_5 2^40 + sum_{k<5} (d'_k - 128) 2^(8k).  Q' comes out
+// of the SAME single addition that rounds x to the row's grid: the offset is an (even) integer of that grid and rides in the low mantissa
+// bits of the magic constant, so Q is still round-to-nearest-even(x 2^(47 - e_r)).  (Until round 5 the digits were the bytes of Q itself
+// minus 128: every product then carried rank-one offset terms -- digit row sums from six v_dot4 per column quad and a table pass at the
+// hand-over -- and low digits that are constant (float32 / integer / power-of-two inputs) were -128, so the DROPPED products were systematic
+// and their mean parts had to be kept too.  Balanced, a constant-zero low digit is 0 and its products vanish; what is dropped is zero-mean
+// for anything but inputs whose low digits are a fixed non-zero pattern, e.g. every entry of a row = integer + 1/3: 1e-13 of the diagonal
+// scale there, tools/i8_digits_emul.py.)
+constexpr long long kI8Balance = 0x8080808080LL;
+__device__ __forceinline__ double i8_magic(int eb /*biased exponent of the row's capacity*/) {
+  return __hiloint2double((int)(((unsigned)(eb + 5) << 20) | 0x00080080u), (int)0x80808080u);  // mantissa 2^51 + 0x8080808080 at exponent e_r + 5
+}
+// x + C fits the signed 48-bit integer  <=>  the mantissa of the sum lies in [2^51 - 2^47, 2^51 + 2^47) at exponent e_r + 5  <=>  its HIGH
+// WORD, as an unsigned integer, lies in [hlo, hlo + 0xffff] (a too-large |x| changes the exponent field or the top mantissa bits, a
+// negative sum sets the sign bit, Inf / NaN have the largest exponent field: all outside).  So the capacity test of the stream is the
+// running minimum and maximum of the high words the slicing holds anyway: one v_min3_u32 + one v_max3_u32 per PAIR of entries.
+__device__ __forceinline__ unsigned i8_hlo(int eb) { return ((unsigned)(eb + 5) << 20) | 0x00078000u; }
+__device__ __forceinline__ bool i8_fits(unsigned hi_of_sum, unsigned hlo) { return hi_of_sum - hlo <= 0xffffu; }
+
 // per-thread slicing state: row r = tid & 127, column octet cq = tid >> 7 of every k-step
 struct I8Slice {
-  double C;          // magic constant 1.5 2^(e_r + 5)
-  unsigned limit;    // high word of the row's capacity 2^e_r, minus one: an |x| at or above it is beyond the 48-bit integer (mark_block)
-  unsigned amax;     // running maximum of the high words of |x|
-  int rs[6];         // digit row sums of this thread's columns
+  double C;          // magic constant 1.5 2^(e_r + 5) + 0x8080808080 2^(e_r - 47): the integer in the low mantissa bits is Q + 0x8080808080
+  unsigned hlo;      // the high words of x + C that stand for a 48-bit integer: [hlo, hlo + 0xffff] (i8_hlo)
+  unsigned hmin, hmax;  // running minimum / maximum of the high words of x + C over the block being sliced (mark_block)
   int sq3;           // sum of a_3^2 over this thread's columns (6-group plan: the dropped product (3, 3) is not zero-mean on the diagonal)
   double b;          // sum_n x_rn y_n over this thread's columns
   double q;          // sum_n y_n^2 over this thread's columns (waves that hold row 0 only)
@@ -311,14 +328,16 @@ struct I8SliceSteps {
           const double t = __dadd_rn(xv, st.C);
           lo[j] = (unsigned)__double2loint(t);
           hi[j] = (unsigned)__double2hiint(t);
-          const unsigned ax = (unsigned)__double2hiint(xv) & 0x7fffffffu;
-          st.amax = ax > st.amax ? ax : st.amax;
           st.b = __builtin_fma(xv, yv, st.b);
           if constexpr (WITH_Q) st.q = __builtin_fma(yv, yv, st.q);
         }
+        // capacity test: the range of the sums' high words (v_min3_u32, v_max3_u32)
+        st.hmin = min(st.hmin, min(hi[j0], hi[j0 + 1]));
+        st.hmax = max(st.hmax, max(hi[j0], hi[j0 + 1]));
+        asm volatile("" : "+v"(st.hmin), "+v"(st.hmax));
         // (pinned: nothing reads these sums before the end of the stream, and hipcc would sink their updates out of the
         // MFMA shadows to behind the k-step's barrier)
-        asm volatile("" : "+v"(st.amax), "+v"(st.b));
+        asm volatile("" : "+v"(st.b));
         if constexpr (WITH_Q) asm volatile("" : "+v"(st.q));
       }
       if constexpr (c == 3) {  // byte transposition, first stage
@@ -329,7 +348,7 @@ struct I8SliceSteps {
         u[4] = __builtin_amdgcn_perm(hi[1], hi[0], 0x05010400u);  // b4(0) b4(1) b5(0) b5(1)
         u[5] = __builtin_amdgcn_perm(hi[3], hi[2], 0x05010400u);
       }
-      if constexpr (c == 4) {  // second stage; the unsigned digits are stored minus 128 (one XOR), the top digit is signed as it is
+      if constexpr (c == 4) {  // second stage; bytes of Q + 0x8080808080 minus 128 (one XOR) are the balanced digits, the top one is signed as it is
         p[q][5] = __builtin_amdgcn_perm(u[2], u[0], 0x05040100u) ^ 0x80808080u;
         p[q][4] = __builtin_amdgcn_perm(u[2], u[0], 0x07060302u) ^ 0x80808080u;
         p[q][3] = __builtin_amdgcn_perm(u[3], u[1], 0x05040100u) ^ 0x80808080u;
@@ -337,10 +356,7 @@ struct I8SliceSteps {
         p[q][1] = __builtin_amdgcn_perm(u[5], u[4], 0x05040100u) ^ 0x80808080u;
         p[q][0] = __builtin_amdgcn_perm(u[5], u[4], 0x07060302u);
       }
-      if constexpr (c == 5) {  // digit row sums
-#pragma unroll
-        for (int s = 0; s < 6; ++s) st.rs[s] = __builtin_amdgcn_sdot4((int)p[q][s], 0x01010101, st.rs[s], false);
-        asm volatile("" : "+v"(st.rs[0]), "+v"(st.rs[1]), "+v"(st.rs[2]), "+v"(st.rs[3]), "+v"(st.rs[4]), "+v"(st.rs[5]));
+      if constexpr (c == 5) {  // sum of squares of digit 3 (the diagonal's share of the dropped pair (3, 3))
         if constexpr (WITH_SQ3) {
           st.sq3 = __builtin_amdgcn_sdot4((int)p[q][3], (int)p[q][3], st.sq3, false);
           asm volatile("" : "+v"(st.sq3));
@@ -368,24 +384,27 @@ struct I8SliceSteps {
 };
 constexpr int kI8SliceChunks = 14;
 
-// four consecutive 1 KiB LDS-DMA pieces whose global sources are consecutive too (ldx = 128: the columns of X are contiguous):
-// ONE M0 set-up, the instruction offset moves the global and the LDS address together
-__device__ __forceinline__ void glds_s_4x1k(uint64_t saddr_uniform, unsigned voff, unsigned lds_addr_uniform) {
-  unsigned keep, m0v;
-  asm volatile(
-      "s_mov_b32 %0, m0\n\t"
-      "v_readfirstlane_b32 %1, %2\n\t"
-      "s_mov_b32 m0, %1\n\t"
-      "s_nop 0\n\t"
-      "global_load_lds_dwordx4 %3, %4\n\t"
-      "global_load_lds_dwordx4 %3, %4 offset:1024\n\t"
-      "global_load_lds_dwordx4 %3, %4 offset:2048\n\t"
-      "global_load_lds_dwordx4 %3, %4 offset:3072\n\t"
-      "s_mov_b32 m0, %0"
-      : "=&s"(keep), "=&s"(m0v)
-      : "v"(lds_addr_uniform), "v"(voff), "s"(saddr_uniform)
-      : "memory");
-}
+// ---- who issues the LDS-DMA pieces of a k-step (32 columns of 1 KiB + the y values [+ 1 / sqrt(s) under diagonal noise]) ----------------
+// BLR_I8_DMA_WAVES = 8 (rounds 4, 5): every wave its four columns.  = 4: waves 0 - 3 eight columns each, waves 4 - 7 none.  The two
+// waves of a SIMD are arbitrated by age: the older one (waves 0 - 3) finishes its k-step ~ 600 cycles before its partner and waits at
+// the barrier, so the ~ 60 issue cycles of a piece are free there and on the critical path on waves 4 - 7.  Waves that issue no piece
+// have an empty vector-memory queue of their own and can run ahead of the stream with "touch" loads (BLR_I8_TOUCH = distance in
+// k-steps beyond the LDS-DMA; one dword per 128-byte line, result discarded): the line travels HBM -> L2 then, and the LDS-DMA piece
+// that follows finds it in the L2 -- an in-order queue would make the pieces wait for the touches issued before them (round 4 measured
+// touches from the SAME waves: slower).
+#ifndef BLR_I8_DMA_WAVES
+#define BLR_I8_DMA_WAVES 4
+#endif
+#ifndef BLR_I8_TOUCH
+#define BLR_I8_TOUCH 0
+#endif
+template <int W> struct I8Dma {
+  static constexpr int COLS = BLR_I8_DMA_WAVES == 8 ? 4 : (W < 4 ? 8 : 0);  // column pieces of this wave per k-step
+  static constexpr int SLOTS = COLS + 1;                                   // + the y piece(s) / the advance / the touch
+};
+// (Measured and not shipped: four pieces per M0 set-up -- consecutive KiB of the LDS through the instruction offset, 20 instead of 56
+// instructions per k-step on a wave with eight pieces -- is SLOWER, 4.27 - 4.30 against 4.20 - 4.22 ms per 4096 updates on one box: the
+// pieces then leave in bursts of four, and what the stream needs is an even trickle.)
 
 // ---- one k-step, order pinned by hand ---------------------------------------------------------------------------------------------
 // A 32 x 32 x 32 int8 MFMA holds the matrix pipe for 32 cycles; about five single-issue instructions fit in its shadow.  Left
@@ -456,9 +475,10 @@ __device__ __forceinline__ void i8_kstep(const char* __restrict__ dig, const cha
     // the LDS-DMA pieces of the k-step three ahead (their slot was freed by the barrier that opened this k-step) go out one at a
     // time, every sixth MFMA (~60 cycles of issue each: beside the partner wave's MFMAs, not in a bunch behind the barrier)
     // (every sixth MFMA where the wave has 27 or more of them; waves of the 6-group plan carry 17 to 26: closer together)
-    constexpr int ISTEP = (NM - 2) / 5 >= 6 ? 6 : ((NM - 2) / 5 >= 1 ? (NM - 2) / 5 : 1);
-    static_assert(2 + 4 * ISTEP < NM, "all five LDS-DMA pieces of a k-step must find a slot among the wave's MFMAs");
-    if constexpr (i >= 2 && (i - 2) % ISTEP == 0 && (i - 2) / ISTEP < 5) issue_next(std::integral_constant<int, (i - 2) / ISTEP>{});
+    constexpr int NSLOTS = I8Dma<W>::SLOTS;  // issue slots of this wave per k-step (its LDS-DMA pieces, then the advance to the next k-step)
+    constexpr int ISTEP = (NM - 2) / NSLOTS >= 6 ? 6 : ((NM - 2) / NSLOTS >= 1 ? (NM - 2) / NSLOTS : 1);
+    static_assert(2 + (NSLOTS - 1) * ISTEP < NM, "all LDS-DMA pieces of a k-step must find a slot among the wave's MFMAs");
+    if constexpr (i >= 2 && (i - 2) % ISTEP == 0 && (i - 2) / ISTEP < NSLOTS) issue_next(std::integral_constant<int, (i - 2) / ISTEP>{});
     // slicing chunks c with floor(c NM / NCH) == i
     constexpr int c_lo = (i * NCH + NM - 1) / NM, c_hi = ((i + 1) * NCH + NM - 1) / NM;
     if constexpr (c_lo < c_hi) chunk(std::integral_constant<int, c_lo>{});
@@ -492,39 +512,55 @@ __device__ __forceinline__ void i8_gram_stream(char* smem, const BLR_GLOBAL doub
   // an entry of the block just sliced outgrew its row's capacity (or is Inf / NaN): its digits are those of a wrapped value; the block
   // is marked and put right in fp64 at the hand-over (i8_repair_block).  The running maximum starts afresh for the next block.
   auto mark_block = [&](int blk) {
-    if (__builtin_amdgcn_ballot_w64(st.amax >= st.limit) != 0ull) {
+    if (__builtin_amdgcn_ballot_w64(!i8_fits(st.hmin, st.hlo) || !i8_fits(st.hmax, st.hlo)) != 0ull) {
       if (lane == 0) oflag[blk] = 1;
     }
-    st.amax = 0;
+    st.hmin = 0xffffffffu;
+    st.hmax = 0u;
   };
   if (tid < 136) reinterpret_cast<int*>(oflag)[tid] = 0;
-  // LDS-DMA pieces per wave and k-step: 4 columns (+ the y piece of wave 0, + the 1 / sqrt(s) piece of wave 1 under diagonal noise)
-  constexpr int PW = 4 + (W == 0 ? 1 : 0) + (DIAG && W == 1 ? 1 : 0);
+  // LDS-DMA pieces per wave and k-step (I8Dma): its columns (+ the y piece of wave 0, + the 1 / sqrt(s) piece of wave 1 under diagonal noise)
+  constexpr int NCOL = I8Dma<W>::COLS;
+  constexpr int PW = NCOL + (W == 0 ? 1 : 0) + (DIAG && W == 1 ? 1 : 0);
+  constexpr bool kTouch = BLR_I8_TOUCH > 0 && NCOL == 0;  // this wave issues no piece: it runs ahead of the stream with touch loads
   unsigned ring_addr = lds_addr_of(ring), y_addr = lds_addr_of(yring), w_addr = lds_addr_of(wring);
   asm volatile("" : "+v"(ring_addr), "+v"(y_addr), "+v"(w_addr));
   const uint64_t colbytes = (uint64_t)ldx * 8u;
-  // ColVecs: this wave's four columns of the k-step being issued.  RowVecs: the k-step's 32 observations of row 0; piece c of
-  // this wave = rows 4 (4 W + c) .. + 3 (colbytes = the distance between two rows), lane -> (row lane & 3, pair of observations
+  // ColVecs: this wave's columns of the k-step being issued.  RowVecs: the k-step's 32 observations of row 0; piece c of
+  // this wave = rows 4 (NCOL W + c) .. + 3 (colbytes = the distance between two rows), lane -> (row lane & 3, pair of observations
   // ((lane >> 2) - piece) mod 16): the rotation of the LDS image (I8SliceSteps)
-  uint64_t nextX = (uint64_t)(uintptr_t)X + (ROWV ? (uint64_t)0 : (uint64_t)(4 * W) * colbytes);
-  unsigned voffR[4];
+  uint64_t nextX = (uint64_t)(uintptr_t)X + (ROWV ? (uint64_t)0 : (uint64_t)(NCOL * W) * colbytes);
+  unsigned voffR[NCOL > 0 ? NCOL : 1];
 #pragma unroll
-  for (int c = 0; c < 4; ++c) voffR[c] = (unsigned)(lane & 3) * (unsigned)colbytes + (unsigned)((((lane >> 2) - (4 * W + c)) & 15) * 16);
+  for (int c = 0; c < NCOL; ++c) voffR[c] = (unsigned)(lane & 3) * (unsigned)colbytes + (unsigned)((((lane >> 2) - (NCOL * W + c)) & 15) * 16);
   uint64_t nextY = (uint64_t)(uintptr_t)y;
   uint64_t nextW = (uint64_t)(uintptr_t)rw;
   const unsigned voff = (unsigned)lane * 16u;
-  // piece c of k-step t -> ring slot t % 3: c = 0 .. 3 this wave's four columns, c = 4 the y values (wave 0) and the advance to the
+  // touch loads (waves without pieces): one dword per 128-byte line of block t + BLR_I8_TOUCH, a quarter of the block per wave --
+  // ColVecs: columns 8 (W - 4) .. + 7, eight lines each; RowVecs: rows 32 (W - 4) .. + 31, two lines each
+  uint64_t touchX = (uint64_t)(uintptr_t)X;
+  unsigned voffT = 0, tdummy = 0;
+  if constexpr (kTouch) {
+    voffT = ROWV ? (unsigned)(32 * (W - 4) + (lane >> 1)) * (unsigned)colbytes + (unsigned)(lane & 1) * 128u
+                 : (unsigned)(8 * (W - 4) + (lane >> 3)) * (unsigned)colbytes + (unsigned)(lane & 7) * 128u;
+    const int t0 = (BLR_I8_TOUCH < nk) ? BLR_I8_TOUCH : nk - 1;  // the block touched when k-step 0 is issued (the prologue issues k-steps 0 .. 2)
+    touchX += (uint64_t)t0 * (ROWV ? (uint64_t)C::KC * 8u : (uint64_t)C::KC * colbytes);
+  }
+  auto touch = [&](uint64_t base) {
+    asm volatile("global_load_dword %0, %1, %2" : "+v"(tdummy) : "v"(voffT), "s"(uni((int64_t)base)) : "memory");
+  };
+  // piece c of k-step t -> ring slot t % 3: c = 0 .. NCOL - 1 this wave's columns, c = NCOL the y values (wave 0) and the advance to the
   // next k-step (pieces are issued in order: the global addresses just run on)
   auto issue_piece = [&](int t, auto ctag) {
     constexpr int c = decltype(ctag)::value;
 #if defined(BLR_I8_EXP) && BLR_I8_EXP == 1  /* timing experiment: no DMA after the first three k-steps (the ring keeps them) */
     if (t >= 3) return;
 #endif
-    if constexpr (c < 4) {
-      const unsigned slot = ring_addr + (unsigned)((t % C::NSLOT) * C::SLOT_BYTES) + (unsigned)((4 * W + c) * 1024);
-      if constexpr (ROWV) glds_s<16>(uni((int64_t)(nextX + (uint64_t)(4 * (4 * W + c)) * colbytes)), voffR[c], slot);
-      else glds_s<16>(uni((int64_t)(nextX + (uint64_t)c * colbytes)), voff, slot);
-    } else {
+    if constexpr (c < NCOL) {
+      const unsigned slot = ring_addr + (unsigned)((t % C::NSLOT) * C::SLOT_BYTES) + (unsigned)((NCOL * W + c) * 1024);
+      if constexpr (ROWV) glds_s<16, 64, true>(uni((int64_t)(nextX + (uint64_t)(4 * (NCOL * W + c)) * colbytes)), voffR[c], slot);
+      else glds_s<16, 64, true>(uni((int64_t)(nextX + (uint64_t)c * colbytes)), voff, slot);
+    } else if constexpr (c == NCOL) {
       if constexpr (W == 0) glds_s<4, 64>(uni((int64_t)nextY), (unsigned)lane * 4u, y_addr + (unsigned)((t % C::NSLOT) * C::KC * 8));
       if constexpr (DIAG && W == 1) glds_s<4, 64>(uni((int64_t)nextW), (unsigned)lane * 4u, w_addr + (unsigned)((t % C::NSLOT) * C::KC * 8));
       // (pieces are issued for three k-steps beyond the last one too -- a branch per piece in the k-step split its schedule: 4.73 -> 4.62 ms
@@ -533,17 +569,29 @@ __device__ __forceinline__ void i8_gram_stream(char* smem, const BLR_GLOBAL doub
       nextX += (ROWV ? (uint64_t)C::KC * 8u : (uint64_t)C::KC * colbytes) & adv;
       nextY += ((uint64_t)C::KC * 8u) & adv;
       nextW += ((uint64_t)C::KC * 8u) & adv;
+      if constexpr (kTouch) {
+        touch(touchX);
+        const uint64_t advT = (t + BLR_I8_TOUCH + 1 < nk) ? ~(uint64_t)0 : (uint64_t)0;
+        touchX += (ROWV ? (uint64_t)C::KC * 8u : (uint64_t)C::KC * colbytes) & advT;
+      }
     }
   };
-  auto issue = [&](int t) {
-    issue_piece(t, std::integral_constant<int, 0>{}); issue_piece(t, std::integral_constant<int, 1>{});
-    issue_piece(t, std::integral_constant<int, 2>{}); issue_piece(t, std::integral_constant<int, 3>{});
-    issue_piece(t, std::integral_constant<int, 4>{});
+  auto issue_rec = [&](auto self, int t, auto ctag) -> void {
+    constexpr int c = decltype(ctag)::value;
+    if constexpr (c <= NCOL) {
+      issue_piece(t, ctag);
+      self(self, t, std::integral_constant<int, c + 1>{});
+    }
   };
+  auto issue = [&](int t) { issue_rec(issue_rec, t, std::integral_constant<int, 0>{}); };
   auto wait_keep = [&](int groups) {  // all but the youngest `groups` issued k-steps of THIS wave have landed
-    if (groups >= 2) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(2 * PW) : "memory");
-    else if (groups == 1) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(PW) : "memory");
-    else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    if constexpr (PW == 0) {  // (no pieces of its own; its touch loads are never waited for inside the stream)
+      if (groups == 0) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    } else {
+      if (groups >= 2) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(2 * PW) : "memory");
+      else if (groups == 1) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(PW) : "memory");
+      else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    }
   };
 #pragma unroll
   for (int g = 0; g < I8Plan<NG, W>::NACC; ++g)
@@ -597,16 +645,15 @@ __device__ __forceinline__ void i8_gram_stream(char* smem, const BLR_GLOBAL doub
     int E1 = (int)(m >> 20);           // biased exponent of the row maximum (0 for a zero / denormal row)
     if (E1 > 1023 + 400) ok = 0;       // Inf / NaN / out of the range the final scaling can represent: fp64 path
     if (E1 < 1023 - 400) E1 = 1023 - 400;
-    // biased e_r = E + CAP: the capacity of the row.  Q = round(x 2^(47 - e_r)) uses the whole signed 48-bit range; an entry within 2^-21
-    // of the capacity could round up to 2^47 and counts as beyond it
+    // biased e_r = E + CAP: the capacity of the row.  Q = round(x 2^(47 - e_r)); what the mantissa holds is Q + 0x8080808080 (the
+    // balancing offset rides in the magic constant), which must stay a signed 48-bit integer (i8_hlo / i8_fits: tested on the sum itself)
     const int eb = E1 + I8Mode<NG>::CAP;
-    st.C = __hiloint2double((int)(((unsigned)(eb + 5) << 20) | 0x00080000u), 0);  // 1.5 2^(e_r + 5)
-    st.limit = ((unsigned)eb << 20) - 1u;
-    st.amax = 0;
+    st.C = i8_magic(eb);
+    st.hlo = i8_hlo(eb);
+    st.hmin = 0xffffffffu;
+    st.hmax = 0u;
     st.b = 0.0;
     st.q = 0.0;
-#pragma unroll
-    for (int s = 0; s < 6; ++s) st.rs[s] = 0;
     st.sq3 = 0;
   }
   constexpr bool kQ = (W & 1) == 0;  // (rows 64 (W & 1) + lane: row 0 lives in the even waves)
@@ -649,153 +696,11 @@ __device__ __forceinline__ void i8_gram_stream(char* smem, const BLR_GLOBAL doub
   }
   i8_kstep<NG, W, false, kQ, DIAG, ROWV>(dig0 + ((nk - 1) & 1) * C::DIG_BUF, ring, yring, wring, dig0, lane, r, cq, A, st, [](auto) {});
   wait_keep(0);  // (the pieces issued beyond the last k-step land in a ring that is about to be reused)
+  if constexpr (kTouch) asm volatile("" ::"v"(tdummy));  // (the touch loads' destination register stays reserved until they have all returned)
 #ifdef BLR_I8_SETPRIO
   if constexpr (W >= 4) __builtin_amdgcn_s_setprio(0);
 #endif
   I8_STAMP_FLUSH(W);
-}
-
-// ---- hand-over, the parts that do not depend on the wave's accumulators: ONE copy of each (noinline) -- inlined into the eight
-// per-wave instances of the stream they added 30 KB to a kernel whose straight-line hand-over code already overflows the
-// instruction cache once per regressor
-template <int NG>
-static __device__ __attribute__((noinline, not_tail_called)) void i8_build_tables(char* smem, int N32_in, double Cmagic, int fac_in, const BLR_GLOBAL double* Lw) {
-  using C = I8Cfg;
-  const int* const xch = reinterpret_cast<const int*>(smem + C::OFF_XCH);
-  double* const sctab = reinterpret_cast<double*>(smem + C::OFF_SC);
-  double* const rowpk = reinterpret_cast<double*>(smem + C::OFF_UW);
-  double* const colpk = rowpk + 128 * 8;
-  int tid = threadIdx.x;
-  asm volatile("" : "+v"(tid));
-  const int N32 = uni(N32_in);
-  const bool fac = uni(fac_in) != 0;
-  if (tid < 128) {
-      int R[6];
-#pragma unroll
-      for (int s = 0; s < 6; ++s) R[s] = (xch[s * 128 + tid] + xch[(6 + s) * 128 + tid]) + (xch[(12 + s) * 128 + tid] + xch[(18 + s) * 128 + tid]);
-      // Offset terms of digit group k (header comment), per row:  V_k(i) = 128 sum_s R_s(i) over the s that pair with an OFFSET
-      // digit t = k - s in 1 .. 5 (s = max(0, k - 5) .. min(5, k - 1)), for ALL groups k = 1 .. 10 -- also those whose products are
-      // dropped -- plus half of the constant c_k = 16384 N #{(s, t): s, t >= 1, s + t = k} (the other half comes in with the
-      // column index).  Exact integers, folded over k with the group scales 2^(80 - 8k), smallest first, into ONE number per row
-      // (rounded at 2^-53 of the largest term, group 1 or 2: 2^-55 of the diagonal scale.  The seven-group version kept three
-      // tables to assemble every entry to the last bit; with the digit products cut at 2^-45 that buys nothing).
-      double tsum = 0.0;
-#pragma unroll
-      for (int k = 10; k >= 1; --k) {
-        long long acc_s = 0;
-#pragma unroll
-        for (int s2 = 0; s2 < 6; ++s2)
-          if (s2 <= k - 1 && s2 >= k - 5) acc_s += R[s2];
-        const int npairs = k <= 6 ? (k > 1 ? k - 1 : 0) : 11 - k;
-        tsum += (double)(128LL * acc_s + 8192LL * (long long)N32 * npairs) * __hiloint2double((1023 + 80 - 8 * k) << 20, 0);
-      }
-      // The products that are dropped (s + t >= NG) are sums over the columns of centred digits, sum_n a_s(i, n) a_t(j, n).  With
-      // a = abar + atilde (abar_s(i) = R_s(i) / N the row's mean digit) such a sum is N abar_s(i) abar_t(j) + sum_n atilde atilde:
-      //   * the mean part is systematic whenever low digits are not uniform -- inputs that came from float32, integers, powers of
-      //     two have CONSTANT low digits (a = -128: 16384 per column and pair, 3e-13 of the diagonal scale with 6 groups) -- and costs
-      //     nothing to keep: sum over the dropped pairs of U_s(i) U_t(j) / N with U_s = R_s 2^(40 - 8 s), i.e. sum_{s=1..5} U_s(i) W_s(j),
-      //     W_s(j) = sum_{t >= NG - s} U_t(j) / N: ten numbers per row, five multiply-adds per entry (conversion);
-      //   * the fluctuating part is zero-mean noise (2^-52 of the diagonal scale with 7 groups, 3e-15 with 6) -- except the pair
-      //     (3, 3) of the 6-group plan on the diagonal, a sum of squares (5461 N: 8e-14 of G_ii).  sum_n a_3^2 is exact from one more
-      //     v_dot4 per quad (I8Slice::sq3); TD = (sum a_3^2 - R_3^2 / N) 2^32 joins G_ii.
-      // 2^(e_i - 47) from the magic constant: C = 1.5 2^(e + 5)  ->  exponent field - 52
-      const int ef = (int)(((unsigned)__double2hiint(Cmagic) >> 20) & 0x7ffu);
-      const double sci = __hiloint2double((ef - 52) << 20, 0);
-      sctab[tid] = sci;
-      {
-        const double ninv = 1.0 / (double)N32;
-        double U[6];
-        double* const rp = rowpk + tid * 8;
-        double* const cp = colpk + tid * 8;
-        rp[0] = tsum; cp[0] = tsum;
-        rp[1] = sci; cp[1] = sci;
-#pragma unroll
-        for (int s2 = 1; s2 < 6; ++s2) {
-          U[s2] = (double)R[s2] * __hiloint2double((1023 + 40 - 8 * s2) << 20, 0);
-          rp[1 + s2] = U[s2];
-        }
-#pragma unroll
-        for (int s2 = 1; s2 < 6; ++s2) {
-          double w = 0.0;
-#pragma unroll
-          for (int t2 = 5; t2 >= 1; --t2)
-            if (t2 >= NG - s2) w += U[t2];
-          cp[1 + s2] = w * ninv;
-        }
-        double td = 0.0;
-        if constexpr (NG == 6) {
-          const int* sq = reinterpret_cast<const int*>(smem);
-          const long long s33 = ((long long)sq[tid] + sq[128 + tid]) + ((long long)sq[256 + tid] + sq[384 + tid]);
-          td = ((double)s33 - (double)R[3] * (double)R[3] * ninv) * __hiloint2double((1023 + 80 - 48) << 20, 0);
-        }
-        rp[7] = td;
-        cp[7] = fac ? 0.0 : (double)Lw[tid];  // (a diagonal prior joins the diagonal at the conversion; a factor prior after the prior-mean terms)
-      }
-    }
-}
-
-static __device__ __attribute__((noinline, not_tail_called)) void i8_table_pass(char* smem, double winv) {
-  using C = I8Cfg;
-  double* const P = reinterpret_cast<double*>(smem);
-  double* const gdiag = reinterpret_cast<double*>(smem + C::OFF_GD);
-  const double* const rowpk = reinterpret_cast<const double*>(smem + C::OFF_UW);
-  const double* const colpk = rowpk + 128 * 8;
-  int tid = threadIdx.x;
-  asm volatile("" : "+v"(tid));
-  const int lane = tid & 63, wave = uni(tid >> 6);
-  // ---- what does not come out of the int8 accumulators: per entry (i, j) the offset terms T_i + T_j of ALL digit pairs and the mean parts
-  // sum_s U_s(i) W_s(j) of the dropped ones, scaled like the products.  That is a rank-7 product [T_i, 1, U_1..U_5] [1, T_j, W_1..W_5]':
-  // two v_mfma_f64_16x16x4 per 16 x 16 tile of the packed triangle (36 tiles over the eight waves), added to P in the accumulator layout
-  // (consecutive lanes = consecutive words of a row).  (As a loop over the entries -- five multiply-adds, four 16-byte record reads and
-  // a read-modify-write each -- this pass took 12 k cycles per regressor.)
-  const int r16 = lane & 15, q4 = lane >> 4;
-  // (Branch-free on purpose: written with conditional reads this loop took 2.4 k cycles per tile -- some forty taken branches and six
-  // dependent LDS round trips.  The reads are unconditional with a clamped index, the triangle mask steers the address to a dump word.)
-  double* const dump = reinterpret_cast<double*>(smem + C::OFF_TAIL) + tid;  // (the mirror tiles of the conversion are dead)
-  const int ia = (q4 == 1) ? 0 : q4, ib = (q4 < 3) ? 4 + q4 : 4;   // row record: T_i, (1), U_1, U_2 | U_3, U_4, U_5, (0)
-  const int ja = (q4 < 2) ? 0 : q4;                                // column record: (1), T_j, W_1, W_2 | W_3, W_4, W_5, (0)
-#pragma unroll 1
-  for (int t = wave; t < 36; t += 8) {
-    int I = 0;
-#pragma unroll
-    for (int i = 1; i < 8; ++i) I += (t >= i * (i + 1) / 2) ? 1 : 0;
-    const int K = t - I * (I + 1) / 2;
-    const double* const ri = rowpk + (16 * I + r16) * 8;
-    const double* const cj = colpk + (16 * K + r16) * 8;
-    const double sci = ri[1], scj = cj[1] * winv;
-    const double ra = ri[ia], rb = ri[ib], ca = cj[ja], cb = cj[ib];
-    double a0 = (q4 == 1) ? 1.0 : ra;
-    double a1 = (q4 < 3) ? rb : 0.0;
-    const double b0 = (q4 == 0) ? 1.0 : ca;
-    const double b1 = (q4 < 3) ? cb : 0.0;
-#ifdef BLR_I8_NO_MEANPROD
-    if (q4 >= 2) a0 = 0.0;
-    a1 = 0.0;
-#endif
-    const int col = 16 * K + r16;
-    double* addr[4];
-    double cur[4];
-#pragma unroll
-    for (int v = 0; v < 4; ++v) {
-      const int row = 16 * I + q4 + 4 * v;
-      addr[v] = (row >= col) ? P + pidx(row, col) : dump;
-      cur[v] = *addr[v];
-    }
-    typename Mfma<double>::acc4 acc = {0.0, 0.0, 0.0, 0.0};
-    acc = Mfma<double>::mma(a0 * sci, b0 * scj, acc);
-    acc = Mfma<double>::mma(a1 * sci, b1 * scj, acc);
-#pragma unroll
-    for (int v = 0; v < 4; ++v) *addr[v] = cur[v] + acc[v];
-  }
-  __syncthreads();
-  // the diagonal: TD_i (the dropped pair (3, 3), a sum of squares), diag(G) / s to `gdiag` before the diagonal prior joins (0 for a factor or a
-  // dense prior: those are added after the prior-mean terms)
-  if (tid < 128) {
-    const double* const ri = rowpk + tid * 8;
-    const double e = __builtin_fma(ri[7], ri[1] * ri[1] * winv, P[pidx(tid, tid)]);
-    gdiag[tid] = e;  // (the data term alone: A_ii - Lw_i would lose it under a strong prior)
-    P[pidx(tid, tid)] = e + colpk[tid * 8 + 7];
-  }
 }
 
 // ---- back substitution m = L^-T u for D = 128, blocked by 16 ------------------------------------------------------------------------------
@@ -813,7 +718,7 @@ static __device__ __attribute__((noinline, not_tail_called)) void i8_backsolve_b
   double* const bvec = reinterpret_cast<double*>(smem + SC::OFF_B);
   double* const dinv = reinterpret_cast<double*>(smem + SC::OFF_DINV);
   double* const scr = reinterpret_cast<double*>(smem + SC::OFF_SCR);
-  double* const Wst = reinterpret_cast<double*>(smem + I8Cfg::OFF_UW);  // [8 blocks][16 rows i][16 columns c] (the conversion records are dead)
+  double* const Wst = reinterpret_cast<double*>(smem + I8Cfg::OFF_UW);  // [8 blocks][16 rows i][16 columns c]
   int tid = threadIdx.x;
   asm volatile("" : "+v"(tid));
   const int lane = tid & 63;
@@ -912,6 +817,7 @@ __global__ __launch_bounds__(kI8Threads, 2) void fused_i8_kernel(PosteriorArgs<d
   double* const sctab = reinterpret_cast<double*>(smem + C::OFF_SC);
   double* const bred = reinterpret_cast<double*>(smem + C::OFF_BRED);
   double* const gdiag = reinterpret_cast<double*>(smem + C::OFF_GD);
+  double* const tdtab = reinterpret_cast<double*>(smem + C::OFF_TD);
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = uni(tid >> 6);
   const int reg = blockIdx.x;
@@ -948,6 +854,13 @@ __global__ __launch_bounds__(kI8Threads, 2) void fused_i8_kernel(PosteriorArgs<d
   // A prior mean costs the stream nothing: with G = X X' exact, b = X (y - X'mw) / s = X y / s - (G / s) mw and
   // delta'delta / s = y'y / s - 2 mw'X y / s + mw'(G / s) mw come out of the finished matrix after the hand-over (below; G / s is
   // A off the diagonal and kept next to it on the diagonal: A_ii - Lw_i would lose the data term under a strong prior).
+#ifdef BLR_I8_STAGGER  /* diagnostic builds: the first round's workgroups start BLR_I8_STAGGER x (blockIdx & 7) us apart, so that the CUs' stream and tail phases interleave */
+  if (blockIdx.x < 256) {
+    const unsigned long long t0 = __builtin_amdgcn_s_memrealtime();
+    const unsigned long long dt = (unsigned long long)(BLR_I8_STAGGER) * 100ull * (unsigned long long)(blockIdx.x & 7);
+    while (__builtin_amdgcn_s_memrealtime() - t0 < dt) __builtin_amdgcn_s_sleep(32);
+  }
+#endif
   int ok = 1;
   const int has_mw = __syncthreads_or(tid < D && mw[tid] != T(0));
   if (tid == 0) flag[0] = 1;
@@ -963,14 +876,24 @@ __global__ __launch_bounds__(kI8Threads, 2) void fused_i8_kernel(PosteriorArgs<d
     i8_gram_stream<NG, W, DIAG, ROWV>(smem, X, y, rwp, rwmax, a.ldx, N32, tid, A, st, ok);
     I8_KSTAMP(4);
     // ---- hand-over: validity, digit row sums, b partials, row scales (all through the exchange area / the dead digit area)
-    if (!ok) flag[0] = 0;  // (benign race: everybody writes the same value)
-#pragma unroll
-    for (int s = 0; s < 6; ++s) xch[((tid >> 7) * 6 + s) * 128 + (tid & 127)] = st.rs[s];
-    // (the raw ring has been dead since the barrier that ended the last slicing k-step; P goes there only after the next two barriers)
-    if constexpr (NG == 6) reinterpret_cast<int*>(smem)[(tid >> 7) * 128 + (tid & 127)] = st.sq3;
+    // (Inf / NaN in X fail the capacity test and are seen by the repair; in y they show up in b = sum x y)
+    if (!ok || !(__builtin_fabs(st.b) < __longlong_as_double(0x7ff0000000000000LL))) flag[0] = 0;  // (benign race: everybody writes the same value)
+    xch[(tid >> 7) * 128 + (tid & 127)] = st.sq3;
+    // a diagonal prior joins the diagonal after the conversion (a factor or a dense prior after the prior-mean terms): in flight meanwhile
+    double lwd = 0.0;
+    if (tid < D && !(fac || dns)) lwd = (double)Lw[tid];
     __syncthreads();  // ring and digit buffers are dead from here on
     bred[(tid >> 7) * 128 + (tid & 127)] = st.b;
-    i8_build_tables<NG>(smem, N32, st.C, (fac || dns) ? 1 : 0, Lw);
+    if (tid < D) {
+      // 2^(e_i - 47) from the magic constant: C = 1.5 2^(e + 5) (+ the balancing offset)  ->  exponent field - 52
+      const int ef = (int)(((unsigned)__double2hiint(st.C) >> 20) & 0x7ffu);
+      sctab[tid] = __hiloint2double((ef - 52) << 20, 0);
+      // The products that are dropped (s + t >= NG) are sums over the columns of balanced digits: zero-mean (header) -- except the pair
+      // (3, 3) of the 6-group plan on the diagonal, a sum of squares (5461 N for uniform digits: 8e-14 of G_ii).  sum_n b_3^2 is exact
+      // from one more v_dot4 per quad (I8Slice::sq3): TD = sum b_3^2 2^32 joins G_ii.
+      const long long s33 = ((long long)xch[tid] + xch[128 + tid]) + ((long long)xch[256 + tid] + xch[384 + tid]);
+      tdtab[tid] = NG == 6 ? (double)s33 * __hiloint2double((1023 + 80 - 48) << 20, 0) : 0.0;
+    }
     double qsum = 0.0;
     if ((tid & 127) == 0) qsum = st.q;  // the four threads of row 0 hold the four column octets' shares
     __syncthreads();
@@ -1078,7 +1001,14 @@ __global__ __launch_bounds__(kI8Threads, 2) void fused_i8_kernel(PosteriorArgs<d
     I8_KSTAMP(11);
     __syncthreads();
     I8_KSTAMP(16);
-    if (valid) i8_table_pass(smem, winv);
+    // the diagonal: TD_i (the dropped pair (3, 3), a sum of squares); diag(G) / s to `gdiag` BEFORE the diagonal prior joins (the data term
+    // alone: A_ii - Lw_i would lose it under a strong prior)
+    if (valid && tid < D) {
+      const double sci = sctab[tid];
+      const double e = __builtin_fma(tdtab[tid], sci * sci * winv, P[pidx(tid, tid)]);
+      gdiag[tid] = e;
+      P[pidx(tid, tid)] = e + lwd;
+    }
     I8_KSTAMP(17);
   };
   switch (wave) {
@@ -1132,8 +1062,8 @@ __global__ __launch_bounds__(kI8Threads, 2) void fused_i8_kernel(PosteriorArgs<d
       const int r = tid & 127, cq = tid >> 7;
       // this row's magic constant, capacity test and grid, from 2^(e_r - 47) (sctab)
       const int ef = (int)(((unsigned)__double2hiint(sctab[r]) >> 20) & 0x7ffu);  // biased e_r - 47
-      const double Cr = __hiloint2double((int)(((unsigned)(ef + 47 + 5) << 20) | 0x00080000u), 0);
-      const unsigned limit = ((unsigned)(ef + 47) << 20) - 1u;
+      const double Cr = i8_magic(ef + 47);
+      const unsigned hlo = i8_hlo(ef + 47);
       const double grid = sctab[r];
       for (int q8 = 0; q8 < 8; ++q8) {
         unsigned long long bm = omask[q8];
@@ -1155,10 +1085,10 @@ __global__ __launch_bounds__(kI8Threads, 2) void fused_i8_kernel(PosteriorArgs<d
             if (ax >= 0x7ff00000u) bad = 1;
             double cur = xv;
             dreg[c] = 0.0;
-            if (ax >= limit) {  // the test of the slicing, the arithmetic of the slicing
-              const double t = __dadd_rn(xv, Cr);
+            const double t = __dadd_rn(xv, Cr);
+            if (!i8_fits((unsigned)__double2hiint(t), hlo)) {  // the test of the slicing, the arithmetic of the slicing
               const long long q48 = ((long long)(short)((unsigned)__double2hiint(t) & 0xffffu) << 32) | (long long)(unsigned)__double2loint(t);
-              cur = (double)q48 * grid;
+              cur = (double)(q48 - kI8Balance) * grid;  // (the digits of the wrapped Q' stand for Q' - 0x8080808080)
               dreg[c] = xv - cur;
               atomicOr(&cmask[(8 * cq + c) * 4 + (r >> 5)], 1u << (r & 31));
               atomicOr(&oscr[0], 1u << (8 * cq + c));

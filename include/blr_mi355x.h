@@ -67,7 +67,9 @@ int blr_destroy(blr_handle* h);
 const char* blr_last_error(blr_handle* h);        /* valid until the next call on h; never NULL         */
 /* A handle's work is ordered by ONE stream at a time: switching streams drains the old one first.  Not supported: capturing a
  * handle's launches into a HIP graph and replaying them, and calls on one handle from two streams / threads at once (the large-D
- * factorisation keeps arrival counters and tagged exchange words per handle) -- use one handle per stream. */
+ * factorisation keeps arrival counters and tagged exchange words per handle) -- use one handle per stream.  The stream being
+ * left must still be alive when blr_set_stream / blr_reset_stream is called (it is drained); if it has been destroyed already the
+ * whole device is drained instead and the switch still happens. */
 int blr_set_stream(blr_handle* h, void* hip_stream); /* run on the caller's hipStream_t; NULL = the HIP null stream */
 int blr_reset_stream(blr_handle* h);              /* back to the handle's own (non-blocking) stream      */
 int blr_set_async(blr_handle* h, int async);      /* 1: DEVICE-memspace calls return after enqueue       */
