@@ -38,6 +38,7 @@ struct BlrOptions {
   int wave_split = 0;     // waves per regressor of the wave kernel: 0 = router, else 1 | 2 | 4
   int chain_batch = 0;    // regressors per shared launch at D > 128: 0 = as many as the workspace holds
   int i8_probe_min = 0;   // int8 route: batches beyond this many regressors start with a probe slice; 0 = kI8ProbeMin
+  int i8_groups = 0;      // int8 route: digit groups kept, 0 / 6 = the six-group plan, 7 = the seven-group plan (3x closer to the fp64 kernel, 0.8x the rate)
   long chain_ws_mb = 0;   // workspace bound of such a group in MiB: 0 = kChainWorkspace
   int sweep = 0;          // blr_update_factor_* route: 0 = router, 1 = always the Givens sweep, 2 = never
   int gs_fields = 0, gs_so = 0, gs_sd = 0, gs_nl = 0;  // GRAM_SPLITS = "off-diagonal,diagonal[,nlong]" (gs_fields = numbers parsed)
@@ -89,6 +90,12 @@ struct BlrOptions {
       i8_probe_min = (int)v;
       return 0;
     }
+    if (!strcmp(key, "I8_GROUPS")) {
+      if (!on) { i8_groups = 0; return 0; }
+      if (!parse_long(value, v) || !(v == 6 || v == 7)) return -3;
+      i8_groups = (int)v;
+      return 0;
+    }
     if (!strcmp(key, "CHAIN_WS_MB")) {
       if (!on) { chain_ws_mb = 0; return 0; }
       if (!parse_long(value, v) || v < 1) return -3;
@@ -116,7 +123,7 @@ struct BlrOptions {
       if (const char* v = getenv(name.c_str())) (void)set(k, *v ? v : "1");
     }
     // valued options: an empty variable is ignored (the built-in default stays), a malformed one too
-    for (const char* k : {"WAVE_SPLIT", "CHAIN_BATCH", "CHAIN_WS_MB", "SWEEP", "GRAM_SPLITS", "I8_PROBE_MIN"}) {
+    for (const char* k : {"WAVE_SPLIT", "CHAIN_BATCH", "CHAIN_WS_MB", "SWEEP", "GRAM_SPLITS", "I8_PROBE_MIN", "I8_GROUPS"}) {
       const std::string name = std::string("BLR_MI355X_") + k;
       if (const char* v = getenv(name.c_str()))
         if (*v) (void)set(k, v);
@@ -148,6 +155,8 @@ struct blr_handle {
   unsigned long long i8_attempted = 0;   // regressors sent down the int8 route (host count)
   unsigned i8_slices = 0;                // parity = bank of the per-slice hand-back counter
   const char* route = "none";            // kernel family the most recent posterior dispatch launched (blr_last_route)
+  int64_t route_i8_B = 0;                // > 0: that dispatch took the int8 route with this many regressors (blr_last_route looks at its hand-backs)
+  std::string route_buf;
   // wavefront back substitution (D > 128): tagged exchange buffer, start-order ticket counter, launch epoch
   unsigned long long* xchg = nullptr;
   size_t xchg_bytes = 0;
@@ -380,6 +389,7 @@ int launch_fused_small(blr_handle* h, const PosteriorArgs<T>& a) {
     static const std::string name = std::string("fused_small_kernel<") + (sizeof(T) == 8 ? "double" : "float") + ", " + std::to_string(NB) + ", " +
                                     std::to_string(MODE) + ">";
     h->route = name.c_str();
+    h->route_i8_B = 0;
   }
   return 0;
 }
@@ -408,6 +418,7 @@ int launch_fused_wave_nw(blr_handle* h, const PosteriorArgs<T>& a) {
   static const std::string name = std::string("fused_wave_kernel<") + (sizeof(T) == 8 ? "double" : "float") + ", " + std::to_string(NB) + ", " +
                                   std::to_string(NW) + ">";
   h->route = name.c_str();
+  h->route_i8_B = 0;
   return 0;
 }
 // The chip has 2048 wave slots for this kernel.  A batch that cannot fill them with one regressor per wave splits each
@@ -429,7 +440,8 @@ constexpr size_t kSmall8Lds = SmallCfg<double, 8>::LDS_BYTES;
 int launch_fused_i8(blr_handle* h, const PosteriorArgs<double>& a) {
   const bool diag = a.noise_kind == BLR_NOISE_DIAGONAL, rowv = a.layout == BLR_LAYOUT_ROWVECS;
   // (the kernel's four instantiations: blr_i8_kernels.hip)
-  const void* const kern = diag ? i8_kernel_ptr_diag(rowv) : i8_kernel_ptr_iso(rowv);
+  const bool g7 = h->opt.i8_groups == 7 && i8_kernel_ptr_g7(diag, rowv) != nullptr;
+  const void* const kern = g7 ? i8_kernel_ptr_g7(diag, rowv) : (diag ? i8_kernel_ptr_diag(rowv) : i8_kernel_ptr_iso(rowv));
   if (kern == nullptr) return hip_fail(h, hipErrorInvalidValue, "this build lacks the requested form of the int8 kernel");
   int rc = set_lds_once(h, kern, (size_t)I8Cfg::LDS_BYTES);
   if (rc) return rc;
@@ -492,6 +504,7 @@ int launch_fused_i8(blr_handle* h, const PosteriorArgs<double>& a) {
     if (s.logpdf) s.logpdf += b0;
     s.info += b0;
     s.i8_handed_tot = h->stats_dev;
+    s.i8_call_base = b0 == 0 ? h->stats_dev + 2 : nullptr;
     s.i8_handed_slice = h->stats_dev + 8 + (h->i8_slices & 1u);         // zeroed by this slice's int8 launch, counted up by its retry launch
     s.i8_prev_handed = h->stats_dev + 8 + ((h->i8_slices & 1u) ^ 1u);   // final since the previous slice's retry launch
     s.i8_prev_n = h->opt.no_i8_fallback ? 0 : prev_n;
@@ -509,7 +522,8 @@ int launch_fused_i8(blr_handle* h, const PosteriorArgs<double>& a) {
       }
       s.i8_prior_logdet = pld; s.i8_prior_info = pinfo; s.i8_prior_stride = shared_prior ? 0 : 1;
     }
-    if (diag) i8_kernel_launch_diag(rowv, (unsigned)nb, h->stream, s);
+    if (g7) i8_kernel_launch_g7(diag, rowv, (unsigned)nb, h->stream, s);
+    else if (diag) i8_kernel_launch_diag(rowv, (unsigned)nb, h->stream, s);
     else i8_kernel_launch_iso(rowv, (unsigned)nb, h->stream, s);
     HIP_TRY(h, hipGetLastError());
     s.retry_only = 1;
@@ -518,7 +532,8 @@ int launch_fused_i8(blr_handle* h, const PosteriorArgs<double>& a) {
     prev_n = nb;
     b0 += nb;
   }
-  h->route = "fused_i8_kernel";
+  h->route = g7 ? "fused_i8_kernel (7 digit groups)" : "fused_i8_kernel";
+  h->route_i8_B = a.B;
   return 0;
 }
 
@@ -691,6 +706,7 @@ int posterior_large_group(blr_handle* h, const PosteriorArgs<T>& a, int64_t reg0
   // 15 % slower, with a plan costed for bf16 diagonal tiles and a route that named a kernel form that never ran).
   const bool bf3 = sizeof(T) == 4 && !h->opt.no_bf16x3 && !h->opt.no_gram_ring && a.layout == LAYOUT_COLVECS &&
                    ((uintptr_t)(a.X + reg0 * a.strideX) % 16 == 0) && ((a.ldx * (int64_t)sizeof(T)) % 16 == 0);
+  h->route_i8_B = 0;
   h->route = sizeof(T) == 8 ? "gram_tile_kernel<double>" : (bf3 ? "gram_tile_kernel<float, true>" : "gram_tile_kernel<float>");  // (large-D pipeline: the Gram launch dominates; <float, true>: full tiles on the bf16 matrix cores)
   using LC = LargeCfg<T>;
   const int D = a.D, N = a.N;
@@ -2991,7 +3007,26 @@ int blr_reset_stream(blr_handle* h) {
   if (!h) return -1;
   return switch_stream(h, h->own_stream);
 }
-const char* blr_last_route(blr_handle* h) { return h ? h->route : "null handle"; }
+const char* blr_last_route(blr_handle* h) {
+  if (!h) return "null handle";
+  // The int8 route decides ON THE DEVICE what it keeps: a probe slice that hands back more than a quarter of its regressors (heavy
+  // tails) sends the rest of the batch to the fp64 kernel, and then that kernel is what a profile of the call shows.  Look at the
+  // call's hand-back count (this drains the handle's stream) and name the kernel that did most of the work.
+  if (h->route_i8_B > 0 && h->stats_dev != nullptr) {
+    unsigned long long v[3] = {0, 0, 0};
+    if (hipSetDevice(h->device) == hipSuccess &&
+        hipMemcpyAsync(v, h->stats_dev, sizeof(v), hipMemcpyDeviceToHost, h->stream) == hipSuccess && hipStreamSynchronize(h->stream) == hipSuccess) {
+      const unsigned long long handed = v[0] - v[2];
+      if (2 * handed > (unsigned long long)h->route_i8_B) {
+        h->route_buf = "fused_small_kernel<double, 8, 4> (int8 route handed back " + std::to_string(handed) + " of " + std::to_string(h->route_i8_B) + ")";
+        return h->route_buf.c_str();
+      }
+    } else {
+      (void)hipGetLastError();
+    }
+  }
+  return h->route;
+}
 
 int blr_get_stat(blr_handle* h, const char* key, int64_t* value) {
   if (!h) return -1;
@@ -3017,7 +3052,7 @@ int blr_reset_stats(blr_handle* h) {
   h->err.clear();
   if (h->stats_dev) {  // (device counter first: a failure must not leave the two counters apart)
     HIP_TRY(h, hipSetDevice(h->device));
-    HIP_TRY(h, hipMemsetAsync(h->stats_dev, 0, sizeof(unsigned long long), h->stream));
+    HIP_TRY(h, hipMemsetAsync(h->stats_dev, 0, 3 * sizeof(unsigned long long), h->stream));  // (total, spare, the last call's base)
   }
   h->i8_attempted = 0;
   return 0;

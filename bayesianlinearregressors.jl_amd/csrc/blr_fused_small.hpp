@@ -139,6 +139,7 @@ struct PosteriorArgs {
   // (zeroed by the slice's int8 launch) and *i8_handed_tot (blr_get_stat); the int8 launch of the NEXT slice reads the previous
   // slice's count -- *i8_prev_handed of i8_prev_n regressors -- and leaves its regressors to the fp64 kernel when that was > 1/4
   unsigned long long* i8_handed_tot; unsigned long long* i8_handed_slice; const unsigned long long* i8_prev_handed; int i8_prev_n;
+  unsigned long long* i8_call_base;  // first slice of a call only: receives *i8_handed_tot as it stands when the call starts (blr_last_route: hand-backs of THIS call)
   // dense prior on the int8 route: logdet Lw and the status of its Cholesky per prior (i8_prior_logdet_kernel); stride 0 = one shared prior
   const double* i8_prior_logdet; const int32_t* i8_prior_info; int64_t i8_prior_stride;
 };

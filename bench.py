@@ -144,7 +144,7 @@ class Workload:
     """One BASELINE shape resident on the device + the call that runs one step of it."""
 
     def __init__(self, torch, _abi, h, dev, name, B, D, N, dtype, noise, seed, Din=None, mw_random=False, logpdf_only=False, block=None, rowvecs=False,
-                 factor_prior=False, dense_prior=False):
+                 factor_prior=False, dense_prior=False, features="gauss"):
         self.name, self.B, self.D, self.N, self.dtype, self.noise, self.Din = name, B, D, N, dtype, noise, Din
         self.logpdf_only = logpdf_only
         self.rowvecs, self.factor_prior, self.dense_prior = rowvecs, factor_prior, dense_prior
@@ -158,6 +158,13 @@ class Workload:
         def gen(nb, g):
             if Din is None:
                 X = torch.randn((nb, N, D), generator=g, dtype=t_dt, device=dev)  # [N, D] row-major == D x N column-major
+                if features == "student_t3":  # heavy-tailed features (Student-t, 3 degrees of freedom): rows outgrow bounds taken from their first columns
+                    for c0 in range(0, nb, 256):
+                        chi = torch.zeros_like(X[c0:c0 + 256])
+                        for _ in range(3):
+                            chi += torch.randn(chi.shape, generator=g, dtype=t_dt, device=dev) ** 2
+                        X[c0:c0 + 256] /= torch.sqrt(chi / 3.0)
+                        del chi
                 wstar = torch.randn((nb, D), generator=g, dtype=t_dt, device=dev)
                 mean = torch.einsum("bnd,bd->bn", X, wstar) if nb * N * D < (1 << 32) else torch.stack([X[b] @ wstar[b] for b in range(nb)])
             else:  # c5: raw inputs D_in x N, random-Fourier basis on the device
@@ -304,7 +311,7 @@ def secondary_line(name, e):
     r = e["roofline"]
     tx = (r["traffic"] / r["algorithmic_bytes"]) if r.get("traffic") else None
     d = {"secondary": name, "ms": _sig(e["ms"]), "per_s": _sig(e["per_s"]), "unit": e["unit"], "bound": r["bound"], "frac": _sig(r["frac"], 3),
-         "traffic_x": _sig(tx, 3) if tx else None, "kernel": r["kernel"][:40]}
+         "traffic_x": _sig(tx, 3) if tx else None, "kernel": r["kernel"][:72]}
     if "int8_frac" in r:
         d["int8_frac"], d["f64_equiv_frac"] = _sig(r["int8_frac"], 3), _sig(r["f64_equiv_frac"], 3)
     return json.dumps(d)
@@ -519,6 +526,7 @@ def secondary_ops(torch, _abi, h, dev):
             tag = (", prior mean ~ N(0, I)" if kw.get("mw_random") else "") + (", logpdf only (no mw', no T)" if kw.get("logpdf_only") else "") \
                 + (", RowVecs storage" if kw.get("rowvecs") else "") + (", prior by its upper factor" if kw.get("factor_prior") else "") \
                 + (", dense prior precision per regressor" if kw.get("dense_prior") else "") \
+                + (", Student-t(3) features" if kw.get("features") == "student_t3" else "") \
                 + (f", handle option {option}" if option else "")
             return Op(f"B={b}, D={d}, N={n}, {dt}, {noise} noise" + (f", D_in={din} random-Fourier features" if din else "") + tag,
                       launch, b, "updates/s", r["algorithmic_flops"], r["algorithmic_bytes"], dt, kern, check, steps=steps, keep=(w2,))
@@ -533,6 +541,9 @@ def secondary_ops(torch, _abi, h, dev):
         "c2_f64_factor_prior": post("c2_f64_factor", 4096, 128, 4096, "f64", "isotropic", factor_prior=True),
         "c2_f64_rowvecs": post("c2_f64_rowvecs", 4096, 128, 4096, "f64", "isotropic", rowvecs=True),
         "c2_f64_dense_prior": post("c2_f64_dense", 4096, 128, 4096, "f64", "isotropic", dense_prior=True),
+        # what the DEFAULT route costs on heavy-tailed features (Student-t(3): the int8 route's row bounds do not hold; 8192 regressors: the
+        # probe slice of 256 hands back more than a quarter and the rest of the batch goes to the fp64 kernel directly)
+        "c2_f64_heavy_tail": post("c2_f64_heavy_tail", 8192, 128, 4096, "f64", "isotropic", steps=6, features="student_t3"),
         "c4_f64": post("c4_f64", 8192, 64, 1024, "f64", "isotropic"),
         "c4_f32": post("c4_f32", 8192, 64, 1024, "f32", "isotropic"),
         # the per-GPU blocks of config 4 (8192 regressors) on 2 / 4 / 8 GPUs: the expected strong-scaling curve

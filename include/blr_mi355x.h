@@ -76,15 +76,18 @@ int blr_set_async(blr_handle* h, int async);      /* 1: DEVICE-memspace calls re
 int blr_synchronize(blr_handle* h);
 /* Run-time switches of the handle (A/B measurements and tests; the defaults are the measured best).  `key` is one of NO_LDSDMA,
  * NO_WAVE_KERNEL, NO_GRAM_RING, NO_DIAG_SPLIT, NO_XCD_SWIZZLE, NO_MFMA_PROJECT, NO_I8_GRAM, NO_I8_DIAG, NO_I8_FACTOR, NO_I8_ROWVECS, NO_I8_DENSE, NO_I8_FALLBACK, NO_BF16X3, NO_MARG_GEMM, NO_GRAD_GEMM, PLAN_DEBUG (flags: any non-empty value = on),
- * WAVE_SPLIT = 1|2|4, CHAIN_BATCH = 1..128, CHAIN_WS_MB, I8_PROBE_MIN = 256..2^20, SWEEP = always|never|auto, GRAM_SPLITS = "o,d[,nlong]" (README.md);
+ * WAVE_SPLIT = 1|2|4, CHAIN_BATCH = 1..128, CHAIN_WS_MB, I8_PROBE_MIN = 256..2^20, I8_GROUPS = 6|7, SWEEP = always|never|auto, GRAM_SPLITS = "o,d[,nlong]" (README.md);
  * a "BLR_MI355X_" prefix is accepted.  value NULL or "" restores the built-in default.  The environment variables
  * BLR_MI355X_<KEY> are read ONCE, by blr_create -- no entry point reads the environment.  -> 0, or -2 / -3 (unknown key /
  * malformed value). */
 int blr_set_option(blr_handle* h, const char* key, const char* value);
 /* Which kernel family the most recent blr_posterior_* / blr_logpdf_* dispatch of this handle launched -- what a profile of the call
  * shows: "fused_i8_kernel", "fused_small_kernel<double, 8, 4>", "fused_wave_kernel<double, 4, 1>", "gram_tile_kernel<float>" (the
- * large-D pipeline), ...; "none" before the first call.  The pointer stays valid for the life of the library.  (bench.py labels its
- * roofline with it instead of re-deriving the dispatcher's decision.) */
+ * large-D pipeline), ...; "none" before the first call.  The pointer stays valid until the next call on the handle.  (bench.py labels
+ * its roofline with it instead of re-deriving the dispatcher's decision.)  The int8 route decides on the device what it keeps: when
+ * it handed more than half of the call's regressors back to the fp64 kernel (heavy-tailed inputs: the probe slice sends the rest of
+ * the batch there) the answer is "fused_small_kernel<double, 8, 4> (int8 route handed back K of B)" -- after an int8-route call this
+ * function therefore drains the handle's stream. */
 const char* blr_last_route(blr_handle* h);
 /* Counters of the handle since blr_create / blr_reset_stats.  key: "i8_regressors" = regressors sent down the int8-sliced Gram route
  * (blr_posterior_batched_f64 above); "i8_handed_back" = those of them that route could not finish (rows outgrowing their scale
@@ -132,8 +135,10 @@ int blr_timer_stop(blr_handle* h, float* elapsed_ms); /* records, synchronises, 
  *     cancels is off by that much of its row's and column's scale, not of itself;
  *   - the evidence within the 1e-10 above; where delta'Sigma^-1 delta and |T^-T b|^2 cancel (data explained by the weights) the error is
  *     1e-14 of delta'Sigma^-1 delta: |d logpdf| <= 1e-11 |logpdf| + 1e-14 delta'Sigma^-1 delta is what the tests assert;
- *   - inputs whose low mantissa bits are not random (float32 values, integers, powers of two) are covered: the systematic part of the
- *     truncated digit products is kept exactly;
+ *   - inputs whose low mantissa bits are zero (float32 values, integers, powers of two) are covered: the digits are BALANCED (bytes of
+ *     the integer + 0x8080808080, minus 128), so a zero low digit is 0 and its truncated products vanish; what is truncated is zero-mean
+ *     unless the low digits of a row are a constant non-zero pattern (every entry = integer + 1/3): 1e-13 there (tools/i8_digits_emul.py);
+ *   - option I8_GROUPS = 7 keeps a seventh digit group: entries within 1e-14 (measured) instead of 3e-14 of their scale at 0.8 x the rate;
  *   - an entry that outgrows its row's scale (taken from the first 96 columns, 2 - 4 x their largest entry) is corrected in fp64 inside the
  *     kernel; a regressor with more than one such 32-column block in 16 (heavy-tailed features), Inf / NaN, or a prior mean that explains
  *     the data to three digits is REDONE on the fp64 matrix pipe inside the same call -- it then costs two passes; blr_get_stat(h,
