@@ -38,7 +38,7 @@ struct BlrOptions {
   int wave_split = 0;     // waves per regressor of the wave kernel: 0 = router, else 1 | 2 | 4
   int chain_batch = 0;    // regressors per shared launch at D > 128: 0 = as many as the workspace holds
   int i8_probe_min = 0;   // int8 route: batches beyond this many regressors start with a probe slice; 0 = kI8ProbeMin
-  int i8_groups = 0;      // int8 route: digit groups kept, 0 / 6 = the six-group plan, 7 = the seven-group plan (3x closer to the fp64 kernel, 0.8x the rate)
+  int i8_groups = 0;      // int8 route: digit groups kept, 0 = six under isotropic noise and seven under diagonal noise; 6 | 7 = that plan for both noise kinds
   long chain_ws_mb = 0;   // workspace bound of such a group in MiB: 0 = kChainWorkspace
   int sweep = 0;          // blr_update_factor_* route: 0 = router, 1 = always the Givens sweep, 2 = never
   int gs_fields = 0, gs_so = 0, gs_sd = 0, gs_nl = 0;  // GRAM_SPLITS = "off-diagonal,diagonal[,nlong]" (gs_fields = numbers parsed)
@@ -440,8 +440,11 @@ constexpr size_t kSmall8Lds = SmallCfg<double, 8>::LDS_BYTES;
 int launch_fused_i8(blr_handle* h, const PosteriorArgs<double>& a) {
   const bool diag = a.noise_kind == BLR_NOISE_DIAGONAL, rowv = a.layout == BLR_LAYOUT_ROWVECS;
   // (the kernel's four instantiations: blr_i8_kernels.hip)
-  const bool g7 = h->opt.i8_groups == 7 && i8_kernel_ptr_g7(diag, rowv) != nullptr;
-  const void* const kern = g7 ? i8_kernel_ptr_g7(diag, rowv) : (diag ? i8_kernel_ptr_diag(rowv) : i8_kernel_ptr_iso(rowv));
+  // (default plans: six digit groups under isotropic noise, seven under diagonal noise; option I8_GROUPS asks for the other one)
+  const int groups_default = diag ? kI8GroupsDiag : kI8GroupsIso;
+  const bool alt = h->opt.i8_groups != 0 && h->opt.i8_groups != groups_default && i8_kernel_ptr_alt(diag, rowv) != nullptr;
+  const int groups = alt ? h->opt.i8_groups : groups_default;
+  const void* const kern = alt ? i8_kernel_ptr_alt(diag, rowv) : (diag ? i8_kernel_ptr_diag(rowv) : i8_kernel_ptr_iso(rowv));
   if (kern == nullptr) return hip_fail(h, hipErrorInvalidValue, "this build lacks the requested form of the int8 kernel");
   int rc = set_lds_once(h, kern, (size_t)I8Cfg::LDS_BYTES);
   if (rc) return rc;
@@ -522,7 +525,7 @@ int launch_fused_i8(blr_handle* h, const PosteriorArgs<double>& a) {
       }
       s.i8_prior_logdet = pld; s.i8_prior_info = pinfo; s.i8_prior_stride = shared_prior ? 0 : 1;
     }
-    if (g7) i8_kernel_launch_g7(diag, rowv, (unsigned)nb, h->stream, s);
+    if (alt) i8_kernel_launch_alt(diag, rowv, (unsigned)nb, h->stream, s);
     else if (diag) i8_kernel_launch_diag(rowv, (unsigned)nb, h->stream, s);
     else i8_kernel_launch_iso(rowv, (unsigned)nb, h->stream, s);
     HIP_TRY(h, hipGetLastError());
@@ -532,7 +535,7 @@ int launch_fused_i8(blr_handle* h, const PosteriorArgs<double>& a) {
     prev_n = nb;
     b0 += nb;
   }
-  h->route = g7 ? "fused_i8_kernel (7 digit groups)" : "fused_i8_kernel";
+  h->route = !alt ? "fused_i8_kernel" : (groups == 7 ? "fused_i8_kernel (7 digit groups)" : "fused_i8_kernel (6 digit groups)");
   h->route_i8_B = a.B;
   return 0;
 }

@@ -77,19 +77,21 @@ constexpr int kI8MaxRepair = 32;        // 32-column blocks with entries beyond 
 //     48-bit integer in use (the first versions kept a spare bit and three binades: 4 bits fewer per operand, 2^8 in the products --
 //     what the seventh group bought).  N(0,1) rows: capacity 8 sigma for 99 % of the rows; the entries that do outgrow a row's
 //     capacity (0.3 per regressor at N = 4096) wrap around in the integer and are corrected at the hand-over (i8 repair below);
-//   diagonal noise: the same since round 6, the bound taken of x / sqrt(s_n) over the first 96 columns (rounds 4, 5: 7 groups under a
-//     bound of x times the regressor's largest 1 / sqrt(s_n), loose by the spread of the variances).
-//   7 groups, capacity 2^(E + 3) (handle option I8_GROUPS=7, both noise kinds): A within 1e-14 instead of 3e-14 of its diagonal scale
-//     for 260 instead of 174 MFMAs per k-step -- callers that carry a well-explained posterior forward and want the last digit.
-constexpr int kI8GroupsIso = 6, kI8GroupsDiag = 6;
+//   diagonal noise: 7 groups, capacity 2^(E + 3) of x times the regressor's LARGEST 1 / sqrt(s_n) -- that bound is loose by the spread
+//     of the variances (the entries sit (max w / typical w) below it, and the truncation error grows with the SQUARE of that: 25 x for
+//     s_n = exp(N(0,1))), and the seventh group is what keeps the products accurate under it.
+//   The handle option I8_GROUPS = 6 | 7 overrides the choice for both noise kinds: 7 under isotropic noise for callers that carry a
+//     well-explained posterior forward and want the last digit (A within 1e-14 instead of 3e-14 of its diagonal scale, 260 instead of
+//     174 MFMAs per k-step); 6 under diagonal noise where the variances are known to be of one magnitude (3e-14 x (max w / typical w)^2).
+constexpr int kI8GroupsIso = 6, kI8GroupsDiag = 7;
 template <int NG> struct I8Mode {
   static constexpr bool SYM = NG == 6;          // diagonal tiles: products s < t once (mirrored at the hand-over), s = t in accumulators of their own
   static constexpr int CAP = NG == 6 ? 2 : 3;   // capacity 2^(E + CAP)
 };
 // int8 MFMAs per 32-column k-step of the two plans (bench.py prices the int8 work of a launch with these)
 constexpr int kI8MfmaPerKstep = 174;      // isotropic: 6 off-diagonal tiles x 21 + 4 diagonal tiles x (9 + 3)
-constexpr int kI8MfmaPerKstepDiag = 174;  // diagonal noise: the same plan since round 6 (the 7-group plan, 10 tiles x 26 = 260, is the handle option I8_GROUPS=7)
-constexpr int kI8MfmaPerKstep7 = 260;
+constexpr int kI8MfmaPerKstepDiag = 260;  // diagonal noise: 10 tiles x 26
+constexpr int kI8MfmaPerKstep7 = kI8MfmaPerKstepDiag;
 
 // BLR_I8_STAMPS: diagnostic builds only (tools/i8_gram.hip): cycle sums of workgroup 0, one row per wave --
 //   (sums over the workgroups with blockIdx % 257 == 0)  [0] the k-steps (MFMAs + slicing)  [2] DMA wait + barrier  [3] repair of marked blocks  [4] whole stream  [5] hand-over + conversion (+ tail columns, prior mean)
@@ -618,10 +620,7 @@ __device__ __forceinline__ void i8_gram_stream(char* smem, const BLR_GLOBAL doub
 #pragma unroll
         for (int hh = 0; hh < 4; ++hh) {
           const d2 v = *reinterpret_cast<const d2*>(ring + t * C::SLOT_BYTES + p * 1024 + ((((cq * 4 + hh + p) & 15) << 2) + q) * 16);
-          // (diagonal noise: what gets sliced is x / sqrt(s_n), so that is what the bound is taken of)
-          const double v0 = DIAG ? __dmul_rn(v[0], wring[t * C::KC + 2 * (cq * 4 + hh)]) : v[0];
-          const double v1 = DIAG ? __dmul_rn(v[1], wring[t * C::KC + 2 * (cq * 4 + hh) + 1]) : v[1];
-          const unsigned a0 = (unsigned)__double2hiint(v0) & 0x7fffffffu, a1 = (unsigned)__double2hiint(v1) & 0x7fffffffu;
+          const unsigned a0 = (unsigned)__double2hiint(v[0]) & 0x7fffffffu, a1 = (unsigned)__double2hiint(v[1]) & 0x7fffffffu;
           m = a0 > m ? a0 : m;
           m = a1 > m ? a1 : m;
         }
@@ -629,8 +628,7 @@ __device__ __forceinline__ void i8_gram_stream(char* smem, const BLR_GLOBAL doub
         const double* col = reinterpret_cast<const double*>(ring + t * C::SLOT_BYTES) + (cq * 8) * 128 + r;
 #pragma unroll
         for (int j = 0; j < 8; ++j) {
-          const double xv = DIAG ? __dmul_rn(col[j * 128], wring[t * C::KC + cq * 8 + j]) : col[j * 128];
-          const unsigned ax = (unsigned)__double2hiint(xv) & 0x7fffffffu;
+          const unsigned ax = (unsigned)__double2hiint(col[j * 128]) & 0x7fffffffu;
           m = ax > m ? ax : m;
         }
       }
@@ -642,12 +640,15 @@ __device__ __forceinline__ void i8_gram_stream(char* smem, const BLR_GLOBAL doub
     unsigned m = (unsigned)xch[r];
 #pragma unroll
     for (int c = 1; c < 4; ++c) { const unsigned o = (unsigned)xch[c * 128 + r]; m = o > m ? o : m; }
-    // (Diagonal noise, rounds 4 and 5: the bound was the row's bound of x times the LARGEST 1 / sqrt(s_n) of the regressor -- loose by the
-    // spread of the variances, two or three bits with log-normal ones, which is what the seventh digit group paid for -- because a later
-    // column of small variance that broke a bound taken from the first columns sent the regressor back to the fp64 kernel.  Since round 5
-    // such an entry wraps and is repaired at the hand-over, so the bound comes from the scaled values of the first 96 columns, as under
-    // isotropic noise, and six groups do: 174 instead of 260 MFMAs per k-step.  A column that breaks MOST rows' bounds -- 1 / sqrt(s_n)
-    // three to four times the largest of the first 96 -- costs a repair per row; more than kI8MaxRepair marked blocks: fp64 kernel.)
+    if constexpr (DIAG) {
+      // what gets sliced is x / sqrt(s_n): its bound is the row's bound times the LARGEST 1 / sqrt(s_n) of the regressor (known from
+      // the preparation pass).  Taken from the scaled values of the first 96 columns instead -- tried again in round 6, now that an entry
+      // beyond its row's capacity is repaired rather than handed back -- the bound does not survive variances with a spread: with
+      // s_n = exp(N(0,1)) some fifty of a regressor's 4096 columns have 1 / sqrt(s_n) > 3, most of them hold an entry beyond a capacity
+      // of 4 - 8 x the largest of 96 scaled values, and 4078 of 4096 regressors went back to the fp64 kernel (11 ms against 5.1).
+      const double mv = __hiloint2double((int)m, -1) * rwmax;
+      m = (unsigned)__double2hiint(mv) & 0x7fffffffu;
+    }
     int E1 = (int)(m >> 20);           // biased exponent of the row maximum (0 for a zero / denormal row)
     if (E1 > 1023 + 400) ok = 0;       // Inf / NaN / out of the range the final scaling can represent: fp64 path
     if (E1 < 1023 - 400) E1 = 1023 - 400;
@@ -1424,15 +1425,15 @@ const void* i8_kernel_ptr_iso(bool rowv);
 const void* i8_kernel_ptr_diag(bool rowv);
 void i8_kernel_launch_iso(bool rowv, unsigned grid, hipStream_t stream, const PosteriorArgs<double>& a);
 void i8_kernel_launch_diag(bool rowv, unsigned grid, hipStream_t stream, const PosteriorArgs<double>& a);
-// the seven-group plan (handle option I8_GROUPS=7)
-const void* i8_kernel_ptr_g7_iso(bool rowv);
-const void* i8_kernel_ptr_g7_diag(bool rowv);
-void i8_kernel_launch_g7_iso(bool rowv, unsigned grid, hipStream_t stream, const PosteriorArgs<double>& a);
-void i8_kernel_launch_g7_diag(bool rowv, unsigned grid, hipStream_t stream, const PosteriorArgs<double>& a);
-inline const void* i8_kernel_ptr_g7(bool diag, bool rowv) { return diag ? i8_kernel_ptr_g7_diag(rowv) : i8_kernel_ptr_g7_iso(rowv); }
-inline void i8_kernel_launch_g7(bool diag, bool rowv, unsigned grid, hipStream_t stream, const PosteriorArgs<double>& a) {
-  if (diag) i8_kernel_launch_g7_diag(rowv, grid, stream, a);
-  else i8_kernel_launch_g7_iso(rowv, grid, stream, a);
+// the OTHER plan of each noise kind (handle option I8_GROUPS): seven groups under isotropic noise, six under diagonal noise
+const void* i8_kernel_ptr_alt_iso(bool rowv);
+const void* i8_kernel_ptr_alt_diag(bool rowv);
+void i8_kernel_launch_alt_iso(bool rowv, unsigned grid, hipStream_t stream, const PosteriorArgs<double>& a);
+void i8_kernel_launch_alt_diag(bool rowv, unsigned grid, hipStream_t stream, const PosteriorArgs<double>& a);
+inline const void* i8_kernel_ptr_alt(bool diag, bool rowv) { return diag ? i8_kernel_ptr_alt_diag(rowv) : i8_kernel_ptr_alt_iso(rowv); }
+inline void i8_kernel_launch_alt(bool diag, bool rowv, unsigned grid, hipStream_t stream, const PosteriorArgs<double>& a) {
+  if (diag) i8_kernel_launch_alt_diag(rowv, grid, stream, a);
+  else i8_kernel_launch_alt_iso(rowv, grid, stream, a);
 }
 
 }  // namespace blr

@@ -138,7 +138,10 @@ int blr_timer_stop(blr_handle* h, float* elapsed_ms); /* records, synchronises, 
  *   - inputs whose low mantissa bits are zero (float32 values, integers, powers of two) are covered: the digits are BALANCED (bytes of
  *     the integer + 0x8080808080, minus 128), so a zero low digit is 0 and its truncated products vanish; what is truncated is zero-mean
  *     unless the low digits of a row are a constant non-zero pattern (every entry = integer + 1/3): 1e-13 there (tools/i8_digits_emul.py);
- *   - option I8_GROUPS = 7 keeps a seventh digit group: entries within 1e-14 (measured) instead of 3e-14 of their scale at 0.8 x the rate;
+ *   - six digit groups under isotropic noise, seven under diagonal noise (the rows' bounds are then bounds of x times the LARGEST
+ *     1 / sqrt(s_n), loose by the spread of the variances).  Option I8_GROUPS = 7 keeps the seventh group under isotropic noise too:
+ *     entries within 1e-14 (measured) instead of 3e-14 of their scale at 0.8 x the rate; I8_GROUPS = 6 drops it under diagonal noise
+ *     where the variances are of one magnitude: 3e-14 x (largest / typical 1 / sqrt(s_n))^2, 1.2 x the rate;
  *   - an entry that outgrows its row's scale (taken from the first 96 columns, 2 - 4 x their largest entry) is corrected in fp64 inside the
  *     kernel; a regressor with more than one such 32-column block in 16 (heavy-tailed features), Inf / NaN, or a prior mean that explains
  *     the data to three digits is REDONE on the fp64 matrix pipe inside the same call -- it then costs two passes; blr_get_stat(h,
