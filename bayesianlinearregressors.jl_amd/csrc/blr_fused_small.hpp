@@ -142,6 +142,9 @@ struct PosteriorArgs {
   unsigned long long* i8_call_base;  // first slice of a call only: receives *i8_handed_tot as it stands when the call starts (blr_last_route: hand-backs of THIS call)
   // dense prior on the int8 route: logdet Lw and the status of its Cholesky per prior (i8_prior_logdet_kernel); stride 0 = one shared prior
   const double* i8_prior_logdet; const int32_t* i8_prior_info; int64_t i8_prior_stride;
+  // D > 128, fp32: the design matrix is a random-Fourier basis phi_f(x_n) = rff_scale cos(Omega_f' x_n + phase_f) that is never
+  // materialised (blr_posterior_rff_f32; rff_Omega != NULL: X is not read) -- planes_kernel evaluates it once per element
+  const T* rff_Xin; int64_t rff_ldxin; const T* rff_Omega; int64_t rff_ldo; const T* rff_phase; T rff_scale; int rff_Din;
 };
 constexpr int kI8RetryCode = (int)0x80000007u;  // == kI8Retry (blr_fused_i8.hpp)
 

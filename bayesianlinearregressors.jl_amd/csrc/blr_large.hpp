@@ -66,6 +66,10 @@ struct ColstatsArgs {
   int layout, noise_kind, D, N;
   // blockIdx.y = regressor of a group: element strides of the caller's arrays, byte stride of r / qpart / lpart / noise_info
   int64_t grp_X, grp_y, grp_s, grp_mw, grp_ws;
+  int w_sqrt;         // w receives sqrt(1 / s_n): the planes path scales BOTH operands of the Gram product (blr_planes.hpp)
+  // X == NULL: the design matrix is a random-Fourier basis that is never materialised (blr_posterior_rff_f32 at D > 128):
+  // phi_f(x_n) = rff_scale cos(Omega_f' x_n + phase_f) is evaluated here when the prior mean is not zero
+  const T* rff_Xin; int64_t rff_ldxin; const T* rff_Omega; int64_t rff_ldo; const T* rff_phase; T rff_scale; int rff_Din;
 };
 
 template <typename T>
@@ -76,7 +80,8 @@ __global__ __launch_bounds__(kThreads) void colstats_kernel(ColstatsArgs<T> a) {
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int D = a.D, N = a.N;
   if (const int64_t g = blockIdx.y) {
-    a.X += g * a.grp_X; a.y += g * a.grp_y; a.s += g * a.grp_s; a.mw += g * a.grp_mw;
+    if (a.X) a.X += g * a.grp_X;
+    a.y += g * a.grp_y; a.s += g * a.grp_s; a.mw += g * a.grp_mw;
     a.r = ws_shift(a.r, g * a.grp_ws); a.w = ws_shift(a.w, g * a.grp_ws); a.qpart = ws_shift(a.qpart, g * a.grp_ws); a.lpart = ws_shift(a.lpart, g * a.grp_ws);
     a.noise_info = ws_shift(a.noise_info, g * a.grp_ws);
   }
@@ -93,7 +98,7 @@ __global__ __launch_bounds__(kThreads) void colstats_kernel(ColstatsArgs<T> a) {
   unsigned bad = 0xFFFFFFFFu;  // reference :79: _cholesky(Sigma_y) throws at the first variance that is not positive
   typedef T vecT __attribute__((ext_vector_type(Mfma<T>::VEC)));
   constexpr int VEC = Mfma<T>::VEC;
-  const bool vec_ok = a.layout == LAYOUT_COLVECS && (D % VEC) == 0 && (a.ldx % VEC) == 0 && ((uintptr_t)a.X % 16) == 0;
+  const bool vec_ok = a.X != nullptr && a.layout == LAYOUT_COLVECS && (D % VEC) == 0 && (a.ldx % VEC) == 0 && ((uintptr_t)a.X % 16) == 0;
   if (!mw_nonzero) {
     // zero prior mean (the reference's usual prior, and SURVEY 8(d)'s): X'mw = 0 exactly, so delta = y and this pass does not
     // have to read X at all (42 us of HBM streaming at D = 1024, N = 65536)
@@ -103,9 +108,35 @@ __global__ __launch_bounds__(kThreads) void colstats_kernel(ColstatsArgs<T> a) {
       const T delta = a.y[n];
       const T rn = delta / sv;
       a.r[n] = rn;
-      if (a.w) a.w[n] = T(1) / sv;
+      if (a.w) a.w[n] = a.w_sqrt ? (T)sqrt((double)(T(1) / sv)) : T(1) / sv;
       q += (double)delta * (double)rn;
       if (diag) l += log((double)sv);
+    }
+  } else if (a.X == nullptr) {
+    // random-Fourier basis, prior mean != 0: X'mw needs the features; one column per wave, lanes stride over the features (each lane
+    // evaluates its own: Din multiply-adds and one cosine), fixed-order butterfly
+    if constexpr (sizeof(T) == 4) {
+      for (int n = blockIdx.x * kWaves + wave; n < N; n += gridDim.x * kWaves) {
+        const T* xin = a.rff_Xin + (int64_t)n * a.rff_ldxin;
+        double mu = 0.0;
+        for (int f = lane; f < D; f += 64) {
+          const T* om = a.rff_Omega + (int64_t)f * a.rff_ldo;
+          float acc = a.rff_phase[f];
+          for (int k = 0; k < a.rff_Din; ++k) acc = __builtin_fmaf(om[k], xin[k], acc);
+          mu += (double)(a.rff_scale * rff_cos(acc)) * (double)mwl[f];
+        }
+        mu = wave_allreduce(mu);
+        const T sv = diag ? a.s[n] : s_iso;
+        if (!(sv > T(0))) bad = min(bad, (unsigned)(n + 1));
+        const T delta = a.y[n] - (T)mu;
+        const T rn = delta / sv;
+        if (lane == 0) {
+          a.r[n] = rn;
+          if (a.w) a.w[n] = a.w_sqrt ? (T)sqrt((double)(T(1) / sv)) : T(1) / sv;
+          q += (double)delta * (double)rn;
+          if (diag) l += log((double)sv);
+        }
+      }
     }
   } else if (vec_ok) {
     // two columns per wave per step, 16-byte loads, up to 8 loads in flight per lane before the first use
@@ -149,7 +180,7 @@ __global__ __launch_bounds__(kThreads) void colstats_kernel(ColstatsArgs<T> a) {
         const T delta = a.y[nn] - (T)mu;
         const T rn = delta / sv;
         a.r[nn] = rn;
-        if (a.w) a.w[nn] = T(1) / sv;
+        if (a.w) a.w[nn] = a.w_sqrt ? (T)sqrt((double)(T(1) / sv)) : T(1) / sv;
         q += (double)delta * (double)rn;
         if (diag) l += log((double)sv);
       }
@@ -167,7 +198,7 @@ __global__ __launch_bounds__(kThreads) void colstats_kernel(ColstatsArgs<T> a) {
       const T rn = delta / sv;
       if (lane == 0) {
         a.r[n] = rn;
-        if (a.w) a.w[n] = T(1) / sv;
+        if (a.w) a.w[n] = a.w_sqrt ? (T)sqrt((double)(T(1) / sv)) : T(1) / sv;
         q += (double)delta * (double)rn;
         if (diag) l += log((double)sv);
       }
@@ -182,7 +213,7 @@ __global__ __launch_bounds__(kThreads) void colstats_kernel(ColstatsArgs<T> a) {
       const T delta = a.y[n] - (T)mu;
       const T rn = delta / sv;
       a.r[n] = rn;
-      if (a.w) a.w[n] = T(1) / sv;
+      if (a.w) a.w[n] = a.w_sqrt ? (T)sqrt((double)(T(1) / sv)) : T(1) / sv;
       q += (double)delta * (double)rn;
       if (diag) l += log((double)sv);
     }
@@ -1049,6 +1080,7 @@ struct ReduceArgs {
   int pseudo_split;          // 1: the last of the nsplit_total partials is the prior factor's (present for every tile)
   int nlong;                 // strictly lower tiles o < nlong hold one data partial less (see GramTileArgs)
   int ntiles, nblocks;       // lower-triangular macro tiles, row blocks
+  int nsplit_b;              // 0, or the number of b partials when they do not come from the Gram launch (planes_kernel's column chunks)
   const T* Lw; int64_t ldl; int prior_kind;
   int D, DP;
   T* Abar; int64_t lda;      // (DP + 128) x DP
@@ -1094,7 +1126,13 @@ __global__ __launch_bounds__(kThreads) void gram_reduce_kernel(ReduceArgs<T> a) 
 #pragma unroll
         for (int u = 0; u < 8; ++u) sum += v[u];  // fixed order
       }
-      for (; sp < ndata; ++sp) sum += *reinterpret_cast<const vecT*>(src + sp * sstride);
+      if (sp < ndata) {  // the remaining (< 8) partials: requested together as well
+        vecT v[8];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) v[u] = (sp + u < ndata) ? *reinterpret_cast<const vecT*>(src + (sp + u) * sstride) : vecT(T(0));
+#pragma unroll
+        for (int u = 0; u < 8; ++u) sum += v[u];  // fixed order (zeros beyond ndata change nothing)
+      }
       if (short_stack && a.pseudo_split) sum += *reinterpret_cast<const vecT*>(src + (a.nsplit_total - 1) * sstride);
 #pragma unroll
       for (int q = 0; q < VEC; ++q) {
@@ -1122,7 +1160,18 @@ __global__ __launch_bounds__(kThreads) void gram_reduce_kernel(ReduceArgs<T> a) 
       T v = T(0);
       if (rl == 0 && col < a.D) {
         double sum = 0.0;
-        for (int sp = 0; sp < a.nsplit_total; ++sp) sum += a.bpart[((int64_t)sp * a.nblocks + I) * kPB + cl];
+        const int nb = a.nsplit_b > 0 ? a.nsplit_b : a.nsplit_total;
+        const double* src = a.bpart + (int64_t)I * kPB + cl;
+        const int64_t sst = (int64_t)a.nblocks * kPB;
+        int sp = 0;
+        for (; sp + 16 <= nb; sp += 16) {  // sixteen partials requested before the first is used (a load per partial and a dependent add: 0.5 us each)
+          double v[16];
+#pragma unroll
+          for (int u = 0; u < 16; ++u) v[u] = src[(sp + u) * sst];
+#pragma unroll
+          for (int u = 0; u < 16; ++u) sum += v[u];  // fixed order
+        }
+        for (; sp < nb; ++sp) sum += src[sp * sst];
         v = (T)sum;
       }
       a.Abar[(int64_t)col * a.lda + a.DP + rl] = v;
