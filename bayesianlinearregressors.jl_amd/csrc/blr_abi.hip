@@ -35,7 +35,7 @@ using namespace blr;
 // handle is created (BLR_MI355X_<KEY>), and settable per handle with blr_set_option: no getenv on any launch path.
 struct BlrOptions {
   bool no_ldsdma = false, no_wave_kernel = false, no_gram_ring = false, no_diag_split = false, no_xcd_swizzle = false,
-       no_mfma_project = false, plan_debug = false, no_i8_gram = false, no_marg_gemm = false, no_i8_diag = false, no_i8_factor = false, no_i8_rowvecs = false, no_grad_gemm = false, no_i8_dense = false, no_i8_fallback = false, no_bf16x3 = false, no_planes = false;
+       no_mfma_project = false, plan_debug = false, no_i8_gram = false, no_marg_gemm = false, no_i8_diag = false, no_i8_factor = false, no_i8_rowvecs = false, no_grad_gemm = false, no_i8_dense = false, no_i8_fallback = false, no_bf16x3 = false, no_planes = false, no_fp16_planes = false;
   int wave_split = 0;     // waves per regressor of the wave kernel: 0 = router, else 1 | 2 | 4
   int chain_batch = 0;    // regressors per shared launch at D > 128: 0 = as many as the workspace holds
   int i8_probe_min = 0;   // int8 route: batches beyond this many regressors start with a probe slice; 0 = kI8ProbeMin
@@ -72,6 +72,7 @@ struct BlrOptions {
     if (!strcmp(key, "NO_I8_DENSE")) return flag(no_i8_dense);
     if (!strcmp(key, "NO_BF16X3")) return flag(no_bf16x3);
     if (!strcmp(key, "NO_PLANES")) return flag(no_planes);
+    if (!strcmp(key, "NO_FP16_PLANES")) return flag(no_fp16_planes);
     if (!strcmp(key, "NO_I8_FALLBACK")) return flag(no_i8_fallback);
     long v = 0;
     if (!strcmp(key, "WAVE_SPLIT")) {
@@ -719,7 +720,9 @@ int posterior_large_group(blr_handle* h, const PosteriorArgs<T>& a, int64_t reg0
   const bool planes = sizeof(T) == 4 && !h->opt.no_bf16x3 && !h->opt.no_planes && a.layout == LAYOUT_COLVECS && a.N > 0;
   if (rff && !planes) return hip_fail(h, hipErrorInvalidValue, "a basis that is not materialised needs the planes path");
   h->route_i8_B = 0;
-  h->route = sizeof(T) == 8 ? "gram_tile_kernel<double>" : (planes ? "gram_planes_kernel" : (bf3 ? "gram_tile_kernel<float, true>" : "gram_tile_kernel<float>"));  // (large-D pipeline: the Gram launch dominates; <float, true>: full tiles on the bf16 matrix cores)
+  const int NP = h->opt.no_fp16_planes ? 3 : 2;  // planes per operand: two fp16 (three products) or three bf16 (six)
+  h->route = sizeof(T) == 8 ? "gram_tile_kernel<double>"
+                            : (planes ? (NP == 2 ? "gram_planes_kernel<2>" : "gram_planes_kernel<3>") : (bf3 ? "gram_tile_kernel<float, true>" : "gram_tile_kernel<float>"));  // (large-D pipeline: the Gram launch dominates; <float, true>: full tiles on the bf16 matrix cores)
   using LC = LargeCfg<T>;
   const int D = a.D, N = a.N;
   const int DP = (D + kPB - 1) / kPB * kPB, NC = DP / kPB;
@@ -805,7 +808,8 @@ int posterior_large_group(blr_handle* h, const PosteriorArgs<T>& a, int64_t reg0
     }
   };
   // the planes path: one 512-thread workgroup per CU, k-blocks of 16 columns, diagonal macro tiles as long as the others
-  const int NKB = (N + 15) / 16;
+  const int kbs = NP == 2 ? PlanesCfg<2>::KBS : PlanesCfg<3>::KBS;
+  const int NKB = ((N + 15) / 16 + kbs - 1) / kbs * kbs;  // k-blocks of 16 columns, padded to whole stages of the Gram launch (zero columns)
   auto plan_splits_planes = [&](int G) {
     nsplit_diag = 0; nlong = 0; nsplit = 1;
     double best = 1e300;
@@ -830,8 +834,8 @@ int posterior_large_group(blr_handle* h, const PosteriorArgs<T>& a, int64_t reg0
     auto per_for = [&](int nsp) {  // the carve below, as a function of the split factor
       const size_t nst = (size_t)(nsp + pf);
       return al((size_t)lda * DP * sizeof(T)) + al(a.prior_kind == PRIOR_DENSE ? (size_t)DP * DP * sizeof(T) : 0) +
-             al(planes ? (size_t)NKB * NC * 12 * 1024 : 0) +
-             al(nst * ntiles * kPB * kPB * sizeof(T)) + al(std::max<size_t>(nst, (size_t)nbchunks) * NC * kPB * sizeof(double)) + al((size_t)std::max(N, 1) * sizeof(T)) +
+             al(planes ? (size_t)NKB * NC * 4 * NP * 1024 : 0) +
+             al(nst * ntiles * kPB * kPB * sizeof(T)) + al(std::max<size_t>(nst, (size_t)nbchunks) * NC * kPB * sizeof(double) + (size_t)DP * sizeof(unsigned)) + al((size_t)std::max(N, 1) * sizeof(T)) +
              al(a.noise_kind == NOISE_DIAGONAL ? (size_t)std::max(N, 1) * sizeof(T) : 0) + 2 * al((size_t)1024 * sizeof(double)) +
              al((size_t)DP * DP * sizeof(T)) + al(64);
     };
@@ -851,9 +855,11 @@ int posterior_large_group(blr_handle* h, const PosteriorArgs<T>& a, int64_t reg0
   auto carve = [&](size_t bytes) { size_t o = off; off = (off + bytes + 255) & ~(size_t)255; return o; };
   const size_t o_abar = carve((size_t)lda * DP * sizeof(T));
   const size_t o_w = carve(a.prior_kind == PRIOR_DENSE ? (size_t)DP * DP * sizeof(T) : 0);
-  const size_t o_xp = carve(planes ? (size_t)NKB * NC * 12 * 1024 : 0);
+  const size_t o_xp = carve(planes ? (size_t)NKB * NC * 4 * NP * 1024 : 0);
   const size_t o_gp = carve((size_t)gp_tiles * kPB * kPB * sizeof(T));
-  const size_t o_bp = carve((size_t)std::max(nsplit_total, nbchunks) * NC * kPB * sizeof(double));
+  // b partials, then (planes path) the rows' largest entries: both zeroed by the prior launch's scratch initialisation
+  const int bslots = std::max(nsplit_total, nbchunks);
+  const size_t o_bp = carve((size_t)bslots * NC * kPB * sizeof(double) + (size_t)DP * sizeof(unsigned));
   const size_t o_r = carve((size_t)std::max(N, 1) * sizeof(T));
   const size_t o_wv = carve(a.noise_kind == NOISE_DIAGONAL ? (size_t)std::max(N, 1) * sizeof(T) : 0);  // 1 / s_n for the Gram launch
   const size_t o_q = carve((size_t)gridc * sizeof(double));
@@ -906,7 +912,7 @@ int posterior_large_group(blr_handle* h, const PosteriorArgs<T>& a, int64_t reg0
     init.words16 = reinterpret_cast<unsigned*>(ws + o_sc);
     init.ones = info_noise;
     init.zeros = bpart;
-    init.nzeros = (long long)nsplit_total * NC * kPB;
+    init.nzeros = (long long)bslots * NC * kPB + DP / 2;  // (+ the row maxima behind the b partials: DP words)
     init.info_copy = dense ? nullptr : info_chol;
     const int gridp = (int)std::min<long long>(64, 1 + init.nzeros / (8 * kThreads));
     // (dense: the kernel's own look at Lw's diagonal is not the answer -- status and logdet go to spare scratch words)
@@ -990,23 +996,34 @@ int posterior_large_group(blr_handle* h, const PosteriorArgs<T>& a, int64_t reg0
   bool planes_done = false;
   if constexpr (sizeof(T) == 4) {
     if (planes) {
-      if ((rc = set_lds_once(h, reinterpret_cast<const void*>(gram_planes_kernel), (size_t)kPlanesLds))) return rc;
+      if ((rc = set_lds_once(h, reinterpret_cast<const void*>(gram_planes_kernel<2>), (size_t)PlanesCfg<2>::LDS))) return rc;
+      if ((rc = set_lds_once(h, reinterpret_cast<const void*>(gram_planes_kernel<3>), (size_t)PlanesCfg<3>::LDS))) return rc;
       unsigned short* Xp = reinterpret_cast<unsigned short*>(ws + o_xp);
+      unsigned* rowmax = reinterpret_cast<unsigned*>(bpart + (int64_t)bslots * NC * kPB);
       PlanesArgs pa{};
       pa.X = rff ? nullptr : X; pa.ldx = a.ldx;
       pa.Xin = a.rff_Xin; pa.ldxin = a.rff_ldxin; pa.Omega = a.rff_Omega; pa.ldo = a.rff_ldo; pa.phase = a.rff_phase; pa.scale = a.rff_scale; pa.Din = a.rff_Din;
-      pa.wsq = wvec; pa.r = rvec; pa.Xp = Xp; pa.bpart = bpart;
+      pa.wsq = wvec; pa.r = rvec; pa.Xp = Xp; pa.bpart = bpart; pa.rowmax = rowmax;
       pa.D = D; pa.N = N; pa.NC = NC; pa.NKB = NKB; pa.nchunks = nbchunks;
       pa.grp_X = a.strideX; pa.grp_ws = wsb;
       const size_t plds = (size_t)(2 * 16 * kPlanesChunkKb + (rff ? a.rff_Din * 16 : 0)) * sizeof(float);
-      if (rff) hipLaunchKernelGGL(planes_kernel<true>, dim3(nbchunks, NC, G), dim3(kThreads), plds, h->stream, pa);
-      else hipLaunchKernelGGL(planes_kernel<false>, dim3(nbchunks, NC, G), dim3(kThreads), plds, h->stream, pa);
+      if (NP == 2) {  // the rows' power-of-two scales need the rows' largest entries first: one more pass over X (a basis: its bound)
+        if (rff) hipLaunchKernelGGL(rowmax_kernel<true>, dim3(nbchunks, 1, G), dim3(kThreads), 0, h->stream, pa);
+        else hipLaunchKernelGGL(rowmax_kernel<false>, dim3(nbchunks, NC, G), dim3(kThreads), 0, h->stream, pa);
+        if (rff) hipLaunchKernelGGL((planes_kernel<2, true>), dim3(nbchunks, NC, G), dim3(kThreads), plds, h->stream, pa);
+        else hipLaunchKernelGGL((planes_kernel<2, false>), dim3(nbchunks, NC, G), dim3(kThreads), plds, h->stream, pa);
+      } else {
+        if (rff) hipLaunchKernelGGL((planes_kernel<3, true>), dim3(nbchunks, NC, G), dim3(kThreads), plds, h->stream, pa);
+        else hipLaunchKernelGGL((planes_kernel<3, false>), dim3(nbchunks, NC, G), dim3(kThreads), plds, h->stream, pa);
+      }
       GramPlanesArgs ga{};
       ga.Xp = Xp; ga.NC = NC; ga.NKB = NKB; ga.Gpart = Gpart; ga.ntiles = ntiles; ga.nsplit = nsplit;
       ga.s_iso = a.noise_kind == NOISE_DIAGONAL ? nullptr : s;
+      ga.rowmax = rowmax;
       ga.xcd_swizzle = (nsplit > 1 && !no_swizzle) ? 1 : 0;
       ga.grp_ws = wsb; ga.grp_s = a.strides;
-      hipLaunchKernelGGL(gram_planes_kernel, dim3(ntiles * nsplit, G), dim3(kPlanesThreads), (size_t)kPlanesLds, h->stream, ga);
+      if (NP == 2) hipLaunchKernelGGL(gram_planes_kernel<2>, dim3(ntiles * nsplit, G), dim3(kPlanesThreads), (size_t)PlanesCfg<2>::LDS, h->stream, ga);
+      else hipLaunchKernelGGL(gram_planes_kernel<3>, dim3(ntiles * nsplit, G), dim3(kPlanesThreads), (size_t)PlanesCfg<3>::LDS, h->stream, ga);
       if (prior_factor) {  // the prior factor as pseudo-observations: one more partial per tile, from the f32 kernel
         GramTileArgs<T> u = g;
         u.nsplit = 1; u.ntiles = ntiles; u.nsplit_diag = 0; u.nlong = 0;
@@ -1015,7 +1032,7 @@ int posterior_large_group(blr_handle* h, const PosteriorArgs<T>& a, int64_t reg0
         u.grp_X = a.strideLw; u.grp_s = 0;
         u.n_begin = 0; u.n_end = D;
         u.Gpart = Gpart + (int64_t)nsplit * ntiles * kPB * kPB;
-        u.bpart = bpart + (int64_t)std::max(nsplit_total, nbchunks) * NC * kPB;  // (never written: r == NULL)
+        u.bpart = bpart;  // (never written: r == NULL)
         hipLaunchKernelGGL(gram_tile_kernel<T>, dim3(ntiles, G), dim3(kThreads), LC::LDS_BYTES, h->stream, u);
       }
       r.nsplit_b = nbchunks;

@@ -1,35 +1,70 @@
-// fp32 Gram matrices at D > 128 (configs 3 and 5) from PRE-SPLIT operands: the bf16 x 3 representation of the design matrix is made
-// ONCE per element, in the fragment order of the bf16 matrix instruction, and the Gram launch is nothing but LDS-DMA, fragment reads
-// and v_mfma_f32_32x32x16_bf16.
+// fp32 Gram matrices at D > 128 (configs 3 and 5) from PRE-SPLIT operands: the low-precision planes of the design matrix are made ONCE
+// per element, in the fragment order of the matrix instruction, and the Gram launch is nothing but LDS-DMA, fragment reads and
+// v_mfma_f32_32x32x16_{f16, bf16}.
 //
 // Why (round 5, gram_tile_kernel<float, true>): an fp32 number is exactly three bf16 numbers, and the six products hh, hm, mh, mm, hl,
 // lh under fp32 accumulation are as accurate as an fp32 fma chain (tools/bf3_unit.hip) at 14 x the rate of v_mfma_f32_16x16x4_f32 --
 // but that kernel split its operands inside the matrix loop, once per macro tile that touches an element (8 x at config 3, 16 x at
-// config 5): ~ 290 vector instructions per 16 columns and wave next to 24 matrix instructions, matrix pipe 37 % busy.  Here:
+// config 5): ~ 290 vector instructions per 16 columns and wave next to 24 matrix instructions, matrix pipe 37 % busy.  With the split
+// moved out of the loop (NP = 3 below) the matrix pipe IS the time -- and, on random operands, at the clock the part then holds it is no
+// faster than before (config 3: 374 + 118 us for the Gram launch + the planes pass against 522; same-box end to end 0.79 / 0.80 ms).
+// What buys time is fewer products.  NP = 2, the default:
+//   * every row r gets a power-of-two scale 2^e_r that puts its largest entry (of z = x sqrt(w), over ALL columns: rowmax_kernel, one
+//     more pass over X; a random-Fourier basis is bounded by its own scale factor) into [2^12, 2^13);  z' = z 2^-e_r = h + l + rho with
+//     h = fp16(z'), l = fp16(z' - h), both rounded to nearest: 22 significant bits for every entry within 2^-14 of its row's largest,
+//     an absolute 2^-36 of the row's largest below that (fp16 subnormals) -- against fp32's 24 bits the inputs are perturbed by at most
+//     2^-23 of themselves, signed and zero-mean: over N observations that is 2^-23 sqrt(3 / N) of a diagonal entry, 1e-9 at config 3,
+//     where fp32 LAPACK's own accumulation error is 3e-7;
+//   * three products h h, h l, l h (l l is 2^-22 of the result and dropped) under fp32 accumulation, the product of the leading planes
+//     in an accumulator of its own (every matrix instruction rounds its accumulator once: the small sum's roundings are 2^-11 of the
+//     large one's);  G_ij = 2^(e_i + e_j) sum_n z'_in z'_jn, the scales applied to the finished tile (exact).
+//   Half the matrix instructions and two thirds of the bytes of NP = 3.  Tests hold both to 4 x the error of fp32 LAPACK on the same
+//   inputs (test_c3_full_size, test_c5_full_size, test_large_d_fp32_gram_on_bf16_matrix_cores_vs_f32_route).
+//
+// Kernels:
+//   * rowmax_kernel (NP = 2): max_n |x_rn| sqrt(w_n) per row, atomicMax on the bit patterns (order-independent).
 //   * planes_kernel (one pass over X, or over the raw inputs of a random-Fourier basis -- reference src/basis_function_regression.jl:41
 //     materialises phi(x); here phi is evaluated once per element and leaves as planes, the fp32 feature matrix never exists):
-//       z_dn = x_dn sqrt(w_n)   (w_n = 1 / s_n under diagonal noise, 1 otherwise: G = sum_n w_n x_n x_n' = Z Z', both operands the same)
-//       h = bf16(z), m = bf16(z - h), l = bf16(z - h - m), each rounded to nearest
-//     stored as Xp[k-block of 16 columns][row block of 128][32-row sub-block j][plane p][lane][8 bf16]: one KiB per (j, p) is ONE matrix
-//     operand (lane = row r of the sub-block + 32 x (columns 8 .. 15)), twelve consecutive KiB are one side of a macro tile's half.
+//     z = x sqrt(w)   (w_n = 1 / s_n under diagonal noise, 1 otherwise: G = sum_n w_n x_n x_n' = Z Z', both operands the same)
+//     stored as Xp[k-block of 16 columns][row block of 128][32-row sub-block j][plane p][lane][8 x 16 bit]: one KiB per (j, p) is ONE
+//     matrix operand (lane = row r of the sub-block + 32 x (columns 8 .. 15)), 4 NP consecutive KiB are one side of a macro tile's half.
 //     The same pass accumulates b = X r (r = delta / s, reference :57) in fp64 per row and column chunk: the Gram launch carries no
 //     right-hand side.
-//   * gram_planes_kernel: one 512-thread workgroup per CU and (macro tile, column range); a ring of SIX halves of 24 KiB (A side + B side,
-//     12 pieces of 1 KiB each, issued five halves ahead: the operands of the next ~ 4 k cycles are in flight); wave (i, c) owns the two
-//     32 x 32 tiles (i, 2c), (i, 2c + 1) of the 128 x 128 macro tile: per half 9 fragment reads of 16 bytes per lane and 12 matrix
-//     instructions (six products per tile, smallest terms first).  A diagonal macro tile computes its tiles with column block <= row
-//     block (10 of 16) from the A side alone.  Split-K partial tiles in the layout of gram_tile_kernel: gram_reduce_kernel is unchanged.
+//   * gram_planes_kernel: one 512-thread workgroup per CU and (macro tile, column range); a ring of halves of 8 NP KiB (A side + B
+//     side), issued SLOTS - 1 halves ahead; wave (i, c) owns the two 32 x 32 tiles (i, 2c), (i, 2c + 1) of the 128 x 128 macro tile:
+//     per half 3 NP fragment reads of 16 bytes per lane and 12 (NP = 3) or 6 (NP = 2) matrix instructions.  A diagonal macro tile
+//     computes its tiles with column block <= row block (10 of 16) from the A side alone.  Split-K partial tiles in the layout of
+//     gram_tile_kernel: gram_reduce_kernel is unchanged.
 #pragma once
 #include "blr_large.hpp"
 
 namespace blr {
 
 constexpr int kPlanesThreads = 512;
-constexpr int kPlanesHalf = 24 * 1024;   // bytes of one half in the ring: A side 12 KiB + B side 12 KiB
-constexpr int kPlanesSlots = 6;
-constexpr int kPlanesAhead = kPlanesSlots - 1;  // halves in flight beyond the one being computed
-constexpr int kPlanesLds = kPlanesSlots * kPlanesHalf;
-static_assert(kPlanesLds <= 160 * 1024, "LDS of one CU");
+template <int NP> struct PlanesCfg {
+  static constexpr int SIDE = 4 * NP * 1024;       // bytes of one side of a k-block: four 32-row sub-blocks x NP planes x 1 KiB
+  static constexpr int HALF = 2 * SIDE;            // A side + B side of one k-block (16 columns)
+  static constexpr int KBS = NP == 3 ? 1 : 2;      // k-blocks per stage = per workgroup barrier: 12 matrix instructions per wave either way
+                                                   // (NP = 2 with one k-block per barrier: 327 us for config 3's Gram launch, the barrier and
+                                                   // the fragment reads of 8 waves in step weigh as much as its 6 instructions)
+  static constexpr int STAGE = KBS * HALF;         // 24 KiB / 32 KiB
+  static constexpr int SLOTS = NP == 3 ? 6 : 4;    // stages in the ring
+  static constexpr int AHEAD = SLOTS - 1;          // stages in flight beyond the one being computed
+  static constexpr int LDS = SLOTS * STAGE;        // 144 KiB / 128 KiB
+  static constexpr int PW = NP * KBS;              // LDS-DMA pieces per loader wave and stage (waves 0 - 3: A side, 4 - 7: B side)
+  static_assert(LDS <= 160 * 1024, "LDS of one CU");
+};
+
+typedef _Float16 gram_h8 __attribute__((ext_vector_type(8)));
+typedef _Float16 gram_h2 __attribute__((ext_vector_type(2)));
+
+// row scales of the fp16 planes from the row's largest |z| (bit pattern; 0 for an all-zero row): z 2^-e in [2^12, 2^13)
+__device__ __forceinline__ void planes_row_scale(unsigned maxbits, float& down /* 2^-e */, float& up /* 2^e */) {
+  int E = (int)((maxbits >> 23) & 0xffu);  // biased exponent of the largest entry
+  E = E < 13 ? 13 : (E > 254 ? 254 : E);   // (zero / denormal rows: any scale does; Inf / NaN rows stay Inf / NaN)
+  down = __uint_as_float((unsigned)(266 - E) << 23);
+  up = __uint_as_float((unsigned)(E - 12) << 23);
+}
 
 // ---- the producer --------------------------------------------------------------------------------------------------------------------
 struct PlanesArgs {
@@ -40,8 +75,9 @@ struct PlanesArgs {
   const float* r;       // [N] delta_n / s_n for b = X r, or NULL
   unsigned short* Xp;   // planes (layout above)
   double* bpart;        // [nchunks][NC][128] partial sums of b (fixed order: one chunk, one writer)
+  unsigned* rowmax;     // NP = 2: [DP] bit patterns of the rows' largest |z| (rowmax_kernel; a basis: |scale| max_n sqrt(w_n))
   int D, N, NC, NKB, nchunks;
-  int64_t grp_X, grp_ws;  // blockIdx.z = regressor of a group: element stride of X, byte stride of wsq / r / Xp / bpart
+  int64_t grp_X, grp_ws;  // blockIdx.z = regressor of a group: element stride of X, byte stride of wsq / r / Xp / bpart / rowmax
 };
 
 __device__ __forceinline__ float rff_feature(const PlanesArgs& a, const float* __restrict__ om /* Omega_f */, float ph, const float* __restrict__ xs /* LDS: [Din][16] */,
@@ -53,7 +89,47 @@ __device__ __forceinline__ float rff_feature(const PlanesArgs& a, const float* _
 
 constexpr int kPlanesChunkKb = 64;  // k-blocks per column chunk at most (the chunk's r and sqrt(w) live in LDS: 2 x 4 KiB)
 
+// max_n |x_rn| sqrt(w_n) per row r (rowmax zeroed by the launch before: prior_diag_kernel's scratch initialisation).  One thread per row
+// of the row block and column parity; positive floats order like their bit patterns, the maximum does not depend on the order.
 template <bool RFF>
+__global__ __launch_bounds__(kThreads) void rowmax_kernel(PlanesArgs a) {
+  const int tid = threadIdx.x;
+  if (const int64_t g = blockIdx.z) {
+    if (!RFF) a.X += g * a.grp_X;
+    a.wsq = ws_shift(a.wsq, g * a.grp_ws); a.rowmax = ws_shift(a.rowmax, g * a.grp_ws);
+  }
+  const int per = (a.NKB + a.nchunks - 1) / a.nchunks;
+  const int n0 = 16 * blockIdx.x * per, n1 = min(a.N, 16 * min(a.NKB, (int)(blockIdx.x + 1) * per));
+  if constexpr (RFF) {  // |phi| <= |scale|: the bound is |scale| times the largest weight, the same for every row
+    if (blockIdx.y != 0) return;
+    __shared__ float red[kWaves];
+    float m = 0.f;
+    for (int n = n0 + tid; n < n1; n += kThreads) m = fmaxf(m, a.wsq ? a.wsq[n] : 1.f);
+    for (int off = 32; off >= 1; off >>= 1) m = fmaxf(m, __shfl_xor(m, off));
+    if ((tid & 63) == 0) red[tid >> 6] = m;
+    __syncthreads();
+    m = fabsf(a.scale) * fmaxf(fmaxf(red[0], red[1]), fmaxf(red[2], red[3]));
+    for (int d = tid; d < a.NC * kPB; d += kThreads) atomicMax(&a.rowmax[d], __float_as_uint(m));
+  } else {
+    const int row = blockIdx.y * kPB + (tid & 127);
+    if (row >= a.D) return;
+    float m = 0.f;
+    for (int n = n0 + (tid >> 7); n < n1; n += 32) {  // sixteen columns in flight per thread (four: 194 us for config 3's 268 MB)
+      float v[16];
+#pragma unroll
+      for (int u = 0; u < 16; ++u) v[u] = (n + 2 * u < n1) ? a.X[(int64_t)(n + 2 * u) * a.ldx + row] : 0.f;
+      if (a.wsq) {
+#pragma unroll
+        for (int u = 0; u < 16; ++u) v[u] *= (n + 2 * u < n1) ? a.wsq[n + 2 * u] : 0.f;
+      }
+#pragma unroll
+      for (int u = 0; u < 16; ++u) m = fmaxf(m, fabsf(v[u]));
+    }
+    atomicMax(&a.rowmax[row], __float_as_uint(m));  // (a NaN entry: fmaxf drops it; the planes keep it, the factorisation reports it)
+  }
+}
+
+template <int NP, bool RFF>
 __global__ __launch_bounds__(kThreads) void planes_kernel(PlanesArgs a) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
   float* const rs = reinterpret_cast<float*>(smem);            // the chunk's r_n          [16 per]
@@ -64,7 +140,7 @@ __global__ __launch_bounds__(kThreads) void planes_kernel(PlanesArgs a) {
   if (const int64_t g = blockIdx.z) {
     if (!RFF) a.X += g * a.grp_X;
     a.wsq = ws_shift(a.wsq, g * a.grp_ws); a.r = ws_shift(a.r, g * a.grp_ws); a.Xp = ws_shift(a.Xp, g * a.grp_ws);
-    a.bpart = ws_shift(a.bpart, g * a.grp_ws);
+    a.bpart = ws_shift(a.bpart, g * a.grp_ws); a.rowmax = ws_shift(a.rowmax, g * a.grp_ws);
   }
   const int per = (a.NKB + a.nchunks - 1) / a.nchunks;  // (<= kPlanesChunkKb: the host sizes nchunks)
   const int kb0 = blockIdx.x * per, kb1 = min(a.NKB, kb0 + per);
@@ -78,6 +154,9 @@ __global__ __launch_bounds__(kThreads) void planes_kernel(PlanesArgs a) {
     rs[c] = (a.r && n < a.N) ? a.r[n] : 0.f;
     wsm[c] = n < a.N ? (a.wsq ? a.wsq[n] : 1.f) : 0.f;
   }
+  float down = 1.f, up = 1.f;
+  if constexpr (NP == 2) planes_row_scale(a.rowmax[row], down, up);
+  (void)up;
   __syncthreads();
   double bacc = 0.0;
   const float* om = nullptr;
@@ -97,6 +176,7 @@ __global__ __launch_bounds__(kThreads) void planes_kernel(PlanesArgs a) {
   };
   fetch(kb0, xa);
   fetch(kb0 + 1, xb);
+  constexpr int FR = 4 * NP;  // KiB per row block and k-block
   for (int kb = kb0; kb < kb1; ++kb) {
     float x[8];
     if constexpr (RFF) {
@@ -122,18 +202,31 @@ __global__ __launch_bounds__(kThreads) void planes_kernel(PlanesArgs a) {
       bacc += (double)x[e] * (double)rk[e];  // (exact products, fp64 sum: as the Gram kernels' b partials)
       z[e] = x[e] * wk[e];
     }
-    gram_u4 H, M, L;
+    gram_u4* dst = reinterpret_cast<gram_u4*>(reinterpret_cast<char*>(a.Xp) + (((int64_t)kb * a.NC + I) * FR + NP * j) * 1024) + lane;
+    if constexpr (NP == 3) {
+      gram_u4 H, M, L;
 #pragma unroll
-    for (int q = 0; q < 4; ++q) {  // (bf3_split_pack's arithmetic, without the lane exchange: the layout is made here)
-      const float u = z[2 * q], v = z[2 * q + 1];
-      const unsigned hh = bf3_pk(u, v);
-      const float ur = u - __uint_as_float(hh << 16), vr = v - __uint_as_float(hh & 0xffff0000u);
-      const unsigned mm = bf3_pk(ur, vr);
-      const float ul = ur - __uint_as_float(mm << 16), vl = vr - __uint_as_float(mm & 0xffff0000u);
-      H[q] = hh; M[q] = mm; L[q] = bf3_pk(ul, vl);
+      for (int q = 0; q < 4; ++q) {  // (bf3_split_pack's arithmetic, without the lane exchange: the layout is made here)
+        const float u = z[2 * q], v = z[2 * q + 1];
+        const unsigned hh = bf3_pk(u, v);
+        const float ur = u - __uint_as_float(hh << 16), vr = v - __uint_as_float(hh & 0xffff0000u);
+        const unsigned mm = bf3_pk(ur, vr);
+        const float ul = ur - __uint_as_float(mm << 16), vl = vr - __uint_as_float(mm & 0xffff0000u);
+        H[q] = hh; M[q] = mm; L[q] = bf3_pk(ul, vl);
+      }
+      dst[0] = H; dst[64] = M; dst[128] = L;  // three KiB, each written by one wave instruction
+    } else {
+      gram_u4 H, L;
+#pragma unroll
+      for (int q = 0; q < 4; ++q) {
+        const float u = z[2 * q] * down, v = z[2 * q + 1] * down;   // (exact: a power of two)
+        const _Float16 hu = (_Float16)u, hv = (_Float16)v;          // round to nearest even
+        const _Float16 lu = (_Float16)(u - (float)hu), lv = (_Float16)(v - (float)hv);
+        const gram_h2 hp = {hu, hv}, lp = {lu, lv};
+        H[q] = __builtin_bit_cast(unsigned, hp); L[q] = __builtin_bit_cast(unsigned, lp);
+      }
+      dst[0] = H; dst[64] = L;
     }
-    gram_u4* dst = reinterpret_cast<gram_u4*>(reinterpret_cast<char*>(a.Xp) + (((int64_t)kb * a.NC + I) * 12 + 3 * j) * 1024) + lane;
-    dst[0] = H; dst[64] = M; dst[128] = L;  // three KiB, each written by one wave instruction
   }
   if (a.bpart) {
     bacc += __shfl_xor(bacc, 32);  // the two column halves of a row
@@ -148,11 +241,14 @@ struct GramPlanesArgs {
   float* Gpart;            // [nsplit][ntiles][128 * 128] column-major tiles (row = A-side row): gram_tile_kernel's layout
   int ntiles, nsplit;
   const float* s_iso;      // isotropic noise: the variance (device scalar; 1 / s is applied to the finished tile), else NULL
+  const unsigned* rowmax;  // NP = 2: the rows' largest |z| (bit patterns): the tile leaves scaled by 2^(e_i + e_j)
   int xcd_swizzle;
-  int64_t grp_ws, grp_s;   // blockIdx.y = regressor of a group: byte stride of Xp / Gpart, element stride of s_iso
+  int64_t grp_ws, grp_s;   // blockIdx.y = regressor of a group: byte stride of Xp / Gpart / rowmax, element stride of s_iso
 };
 
+template <int NP>
 __global__ __launch_bounds__(kPlanesThreads, 2) void gram_planes_kernel(GramPlanesArgs a) {
+  using C = PlanesCfg<NP>;
   extern __shared__ __attribute__((aligned(16))) char smem[];
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = uni(tid >> 6);
@@ -164,7 +260,7 @@ __global__ __launch_bounds__(kPlanesThreads, 2) void gram_planes_kernel(GramPlan
     w = (xcd < rr ? xcd * (qq + 1) : rr * (qq + 1) + (xcd - rr) * qq) + (w >> 3);
   }
   if (const int64_t g = blockIdx.y) {
-    a.Xp = ws_shift(a.Xp, g * a.grp_ws); a.Gpart = ws_shift(a.Gpart, g * a.grp_ws);
+    a.Xp = ws_shift(a.Xp, g * a.grp_ws); a.Gpart = ws_shift(a.Gpart, g * a.grp_ws); a.rowmax = ws_shift(a.rowmax, g * a.grp_ws);
     if (a.s_iso) a.s_iso += g * a.grp_s;
   }
   const float post_scale = a.s_iso ? 1.0f / a.s_iso[0] : 1.0f;
@@ -173,105 +269,140 @@ __global__ __launch_bounds__(kPlanesThreads, 2) void gram_planes_kernel(GramPlan
   while ((I + 1) * (I + 2) / 2 <= t) ++I;
   const int J = t - I * (I + 1) / 2;
   const bool diag = I == J;
-  const int per = (a.NKB + a.nsplit - 1) / a.nsplit;
-  const int kb0 = sidx * per, kb1 = min(a.NKB, kb0 + per);
-  const int nh = kb1 > kb0 ? kb1 - kb0 : 0;
+  // column range of this split in stages of KBS k-blocks (the host pads the planes to whole stages: zero columns beyond N)
+  const int nst_all = a.NKB / C::KBS;
+  const int per = (nst_all + a.nsplit - 1) / a.nsplit;
+  const int st0 = sidx * per, st1 = min(nst_all, st0 + per);
+  const int nh = st1 > st0 ? st1 - st0 : 0;   // stages of this work item
+  const int kb0 = st0 * C::KBS;
 
-  // Two accumulators per tile: the product of the leading planes (h h, magnitude 1) in one, the five small products (2^-8 .. 2^-16 of
-  // it) in the other.  Every matrix instruction rounds its accumulator once; with all six in one register the sum picked up six
-  // roundings of ITS magnitude per 16 columns -- 1.4e-6 of max |A| over the 74 halves of a column range at config 3's shape reduced to
-  // N = 8192, 4.04 x the error of fp32 LAPACK -- now one (the small sum's roundings are 2^-7 of that).
+  // Two accumulators per tile: the product of the leading planes (magnitude 1) in one, the small products (2^-8 .. 2^-16 of it with bf16
+  // planes, 2^-11 with fp16 planes) in the other.  Every matrix instruction rounds its accumulator once; with all of them in one register
+  // the sum picked up six roundings of ITS magnitude per 16 columns -- 1.4e-6 of max |A| over the 74 halves of a column range at config
+  // 3's shape reduced to N = 8192, 4.04 x the error of fp32 LAPACK -- now one.
   gram_f16v acc[2], accs[2];
 #pragma unroll
   for (int k = 0; k < 2; ++k)
 #pragma unroll
     for (int v = 0; v < 16; ++v) { acc[k][v] = 0.f; accs[k][v] = 0.f; }
-  // one product of the six, into the accumulator of its class
-#define BLR_PM(ACC, XP, YP) ACC = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(gram_bf8, XP), __builtin_bit_cast(gram_bf8, YP), ACC, 0, 0, 0)
+  // one product, into the accumulator of its class
+#define BLR_PM3(ACC, XP, YP) ACC = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(gram_bf8, XP), __builtin_bit_cast(gram_bf8, YP), ACC, 0, 0, 0)
+#define BLR_PM2(ACC, XP, YP) ACC = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(gram_h8, XP), __builtin_bit_cast(gram_h8, YP), ACC, 0, 0, 0)
   // which of the wave's two tiles exist: a diagonal macro tile keeps column block <= row block
   const bool t0 = !diag || 2 * tc <= ti, t1 = !diag || 2 * tc + 1 <= ti;
 
-  // LDS-DMA: waves 0 - 3 bring the A side (pieces 3 w .. 3 w + 2 of its 12), waves 4 - 7 the B side (none for a diagonal macro tile);
-  // three pieces per wave and half, always issued (beyond the last half the last one is fetched again into a slot nobody reads: no
-  // branch in the loop, one constant in the wait)
+  // LDS-DMA: waves 0 - 3 bring the A side (pieces NP w .. NP w + NP - 1 of its 4 NP), waves 4 - 7 the B side (none for a diagonal macro
+  // tile); always issued (beyond the last half the last one is fetched again into a slot nobody reads: no branch in the loop, one
+  // constant in the wait)
   const bool loader = wave < 4 || !diag;
-  const int side = wave >> 2, p0 = 3 * (wave & 3);
+  const int side = wave >> 2, p0 = NP * (wave & 3);
   unsigned ring_addr = lds_addr_of(smem);
   asm volatile("" : "+v"(ring_addr));
-  const uint64_t kbstep = (uint64_t)a.NC * 12u * 1024u;
-  uint64_t next = (uint64_t)(uintptr_t)a.Xp + ((uint64_t)kb0 * a.NC + (uint64_t)(side ? J : I)) * 12u * 1024u + (uint64_t)p0 * 1024u;
+  const uint64_t kbstep = (uint64_t)a.NC * (uint64_t)C::SIDE;
+  uint64_t next = (uint64_t)(uintptr_t)a.Xp + ((uint64_t)kb0 * a.NC + (uint64_t)(side ? J : I)) * (uint64_t)C::SIDE + (uint64_t)p0 * 1024u;
   const unsigned voff = (unsigned)lane * 16u;
-  int hi = 0;  // half the next issue belongs to
-  // piece c (0 .. 2) of the half being issued; piece 2 moves on to the next half
-  auto issue_piece = [&](auto ctag) {
-    constexpr int c = decltype(ctag)::value;
+  int hi = 0;  // stage the next issue belongs to
+  auto issue = [&]() {
 #if defined(BLR_PLANES_EXP) && BLR_PLANES_EXP == 2  /* timing experiment: no LDS-DMA beyond the prologue */
-    if (loader && hi < kPlanesAhead) {
+    if (loader && hi < C::AHEAD) {
 #else
     if (loader) {
 #endif
-      const unsigned slot = ring_addr + (unsigned)((hi % kPlanesSlots) * kPlanesHalf + side * (kPlanesHalf / 2) + p0 * 1024);
-      glds_s<16>(uni((int64_t)(next + (uint64_t)c * 1024u)), voff, slot + (unsigned)c * 1024u);
+      const unsigned slot = ring_addr + (unsigned)((hi % C::SLOTS) * C::STAGE + side * C::SIDE + p0 * 1024);
+#pragma unroll
+      for (int u = 0; u < C::KBS; ++u)
+#pragma unroll
+        for (int c = 0; c < NP; ++c)
+          glds_s<16>(uni((int64_t)(next + (uint64_t)u * kbstep + (uint64_t)c * 1024u)), voff, slot + (unsigned)(u * C::HALF + c * 1024));
     }
-    if constexpr (c == 2) {
-      if (hi + 1 < nh) next += kbstep;
-      ++hi;
-    }
+    if (hi + 1 < nh) next += (uint64_t)C::KBS * kbstep;
+    ++hi;
   };
-  auto issue = [&]() {
-    issue_piece(std::integral_constant<int, 0>{}); issue_piece(std::integral_constant<int, 1>{}); issue_piece(std::integral_constant<int, 2>{});
-  };
-  // the wave's nine operand fragments of a half: one row sub-block of the A side, two of the B side (the A side again on a diagonal tile)
-  struct Frags { gram_u4 v[9]; };  // A.h A.m A.l | B0.h B0.m B0.l | B1.h B1.m B1.l
-  const int offa = (ti * 3) * 1024 + lane * 16, offb = (diag ? 0 : kPlanesHalf / 2) + (2 * tc * 3) * 1024 + lane * 16;
-  auto read_frag = [&](const char* slot, Frags& f, auto itag) {
-    constexpr int i = decltype(itag)::value;
-    f.v[i] = *reinterpret_cast<const gram_u4*>(slot + (i < 3 ? offa + i * 1024 : offb + (i - 3) * 1024));
-  };
-  // One half: nine fragment reads, the three LDS-DMA pieces of half h + 5, twelve matrix instructions -- the two tiles' chains interleaved
-  // (a dependent instruction waits for its predecessor), smallest terms first within an accumulator.
-  // (Measured and not shipped, gram launch of config 3 on one box: the fragments of half h + 1 read into a second register set under
-  // this half's instructions 410 us against 374; the same with reads and pieces pinned one behind each matrix instruction 432.  The
-  // loop is not short of overlap: without its matrix instructions it takes 171 us, without its LDS-DMA 361 -- the matrix pipe on
-  // random bf16 operands at the clock the part then holds (MI355X_MICROARCH.md, DVFS give-back (5): 1.5 - 1.7 GHz) IS the time, and
-  // a denser instruction stream lowers that clock further.)
+  // the wave's 3 NP operand fragments of a half: one row sub-block of the A side, two of the B side (the A side again on a diagonal tile)
+  const int offa = (ti * NP) * 1024 + lane * 16, offb = (diag ? 0 : C::SIDE) + (2 * tc * NP) * 1024 + lane * 16;
+  // One half: the fragment reads, the LDS-DMA pieces of half h + AHEAD, the matrix instructions -- the two tiles' chains interleaved (a
+  // dependent instruction waits for its predecessor), smallest terms first within an accumulator.
+  // (Measured and not shipped, NP = 3, gram launch of config 3 on one box: the fragments of half h + 1 read into a second register set
+  // under this half's instructions 410 us against 374; the same with reads and pieces pinned one behind each matrix instruction 432.
+  // The loop is not short of overlap: without its matrix instructions it takes 171 us, without its LDS-DMA 361 -- the matrix pipe on
+  // random operands at the clock the part then holds (MI355X_MICROARCH.md, DVFS give-back (5): 1.5 - 1.7 GHz) IS the time, and a
+  // denser instruction stream lowers that clock further.)
   auto half = [&](const char* slot) {
-    Frags f;
-    read_frag(slot, f, std::integral_constant<int, 0>{}); read_frag(slot, f, std::integral_constant<int, 1>{}); read_frag(slot, f, std::integral_constant<int, 2>{});
-    read_frag(slot, f, std::integral_constant<int, 3>{}); read_frag(slot, f, std::integral_constant<int, 4>{}); read_frag(slot, f, std::integral_constant<int, 5>{});
-    read_frag(slot, f, std::integral_constant<int, 6>{}); read_frag(slot, f, std::integral_constant<int, 7>{}); read_frag(slot, f, std::integral_constant<int, 8>{});
-    issue();  // half h + 5 into the slot of half h - 1 (everybody left it at the barrier that ended half h - 1)
+    gram_u4 A[NP], B0[NP], B1[NP];
+    gram_u4 A2[NP], B02[NP], B12[NP];  // NP = 2: the stage's second k-block
+#pragma unroll
+    for (int p = 0; p < NP; ++p) A[p] = *reinterpret_cast<const gram_u4*>(slot + offa + p * 1024);
+#pragma unroll
+    for (int p = 0; p < NP; ++p) B0[p] = *reinterpret_cast<const gram_u4*>(slot + offb + p * 1024);
+#pragma unroll
+    for (int p = 0; p < NP; ++p) B1[p] = *reinterpret_cast<const gram_u4*>(slot + offb + (NP + p) * 1024);
+    if constexpr (C::KBS == 2) {
+#pragma unroll
+      for (int p = 0; p < NP; ++p) A2[p] = *reinterpret_cast<const gram_u4*>(slot + C::HALF + offa + p * 1024);
+#pragma unroll
+      for (int p = 0; p < NP; ++p) B02[p] = *reinterpret_cast<const gram_u4*>(slot + C::HALF + offb + p * 1024);
+#pragma unroll
+      for (int p = 0; p < NP; ++p) B12[p] = *reinterpret_cast<const gram_u4*>(slot + C::HALF + offb + (NP + p) * 1024);
+    }
+    issue();  // stage h + AHEAD into the slot of stage h - 1 (everybody left it at the barrier that ended stage h - 1)
 #if defined(BLR_PLANES_EXP) && BLR_PLANES_EXP == 1  /* timing experiment: no matrix instructions */
-    acc[0][0] += __uint_as_float(f.v[0][0] ^ f.v[3][0] ^ f.v[8][3]);
+    acc[0][0] += __uint_as_float(A[0][0] ^ B0[0][0] ^ B1[NP - 1][3]);
+    if constexpr (C::KBS == 2) acc[0][1] += __uint_as_float(A2[0][0] ^ B02[0][0] ^ B12[NP - 1][3]);
     return;
 #endif
-    const gram_u4 &Ah = f.v[0], &Am = f.v[1], &Al = f.v[2], &B0h = f.v[3], &B0m = f.v[4], &B0l = f.v[5], &B1h = f.v[6], &B1m = f.v[7], &B1l = f.v[8];
-    if (t0 && t1) {
-      BLR_PM(accs[0], Al, B0h); BLR_PM(accs[1], Al, B1h);
-      BLR_PM(acc[0], Ah, B0h);  BLR_PM(acc[1], Ah, B1h);
-      BLR_PM(accs[0], Ah, B0l); BLR_PM(accs[1], Ah, B1l);
-      BLR_PM(accs[0], Am, B0m); BLR_PM(accs[1], Am, B1m);
-      BLR_PM(accs[0], Am, B0h); BLR_PM(accs[1], Am, B1h);
-      BLR_PM(accs[0], Ah, B0m); BLR_PM(accs[1], Ah, B1m);
-    } else if (t0) {
-      BLR_PM(accs[0], Al, B0h); BLR_PM(acc[0], Ah, B0h); BLR_PM(accs[0], Ah, B0l);
-      BLR_PM(accs[0], Am, B0m); BLR_PM(accs[0], Am, B0h); BLR_PM(accs[0], Ah, B0m);
+    if constexpr (NP == 3) {  // planes h, m, l
+      if (t0 && t1) {
+        BLR_PM3(accs[0], A[2], B0[0]); BLR_PM3(accs[1], A[2], B1[0]);
+        BLR_PM3(acc[0], A[0], B0[0]);  BLR_PM3(acc[1], A[0], B1[0]);
+        BLR_PM3(accs[0], A[0], B0[2]); BLR_PM3(accs[1], A[0], B1[2]);
+        BLR_PM3(accs[0], A[1], B0[1]); BLR_PM3(accs[1], A[1], B1[1]);
+        BLR_PM3(accs[0], A[1], B0[0]); BLR_PM3(accs[1], A[1], B1[0]);
+        BLR_PM3(accs[0], A[0], B0[1]); BLR_PM3(accs[1], A[0], B1[1]);
+      } else if (t0) {
+        BLR_PM3(accs[0], A[2], B0[0]); BLR_PM3(acc[0], A[0], B0[0]); BLR_PM3(accs[0], A[0], B0[2]);
+        BLR_PM3(accs[0], A[1], B0[1]); BLR_PM3(accs[0], A[1], B0[0]); BLR_PM3(accs[0], A[0], B0[1]);
+      }
+    } else {  // planes h, l
+      if (t0 && t1) {
+        BLR_PM2(accs[0], A[1], B0[0]); BLR_PM2(accs[1], A[1], B1[0]);
+        BLR_PM2(acc[0], A[0], B0[0]);  BLR_PM2(acc[1], A[0], B1[0]);
+        BLR_PM2(accs[0], A[0], B0[1]); BLR_PM2(accs[1], A[0], B1[1]);
+        BLR_PM2(accs[0], A2[1], B02[0]); BLR_PM2(accs[1], A2[1], B12[0]);
+        BLR_PM2(acc[0], A2[0], B02[0]);  BLR_PM2(acc[1], A2[0], B12[0]);
+        BLR_PM2(accs[0], A2[0], B02[1]); BLR_PM2(accs[1], A2[0], B12[1]);
+      } else if (t0) {
+        BLR_PM2(accs[0], A[1], B0[0]); BLR_PM2(acc[0], A[0], B0[0]); BLR_PM2(accs[0], A[0], B0[1]);
+        BLR_PM2(accs[0], A2[1], B02[0]); BLR_PM2(acc[0], A2[0], B02[0]); BLR_PM2(accs[0], A2[0], B02[1]);
+      }
     }
   };
   if (nh > 0) {
-    for (int q = 0; q < kPlanesAhead; ++q) issue();
-    asm volatile("s_waitcnt vmcnt(%0)" ::"n"(3 * (kPlanesAhead - 1)) : "memory");  // half 0 has landed
+    for (int q = 0; q < C::AHEAD; ++q) issue();
+    asm volatile("s_waitcnt vmcnt(%0)" ::"n"(C::PW * (C::AHEAD - 1)) : "memory");  // half 0 has landed
     __syncthreads();
 #pragma unroll 1
     for (int h = 0; h < nh; ++h) {
-      half(smem + (h % kPlanesSlots) * kPlanesHalf);
-      // end of half h: half h + 1 must have landed (the four younger ones may stay in flight), then everybody's pieces are visible
-      asm volatile("s_waitcnt vmcnt(%0)" ::"n"(3 * (kPlanesAhead - 1)) : "memory");
+      half(smem + (h % C::SLOTS) * C::STAGE);
+      // end of half h: half h + 1 must have landed (the younger ones may stay in flight), then everybody's pieces are visible
+      asm volatile("s_waitcnt vmcnt(%0)" ::"n"(C::PW * (C::AHEAD - 1)) : "memory");
       __syncthreads();
     }
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // (the pieces issued beyond the last half)
   }
-#undef BLR_PM
+#undef BLR_PM3
+#undef BLR_PM2
+  // row scales of the macro tile's rows and columns (NP = 2), through the ring (everybody left it at the last barrier)
+  float* const sI = reinterpret_cast<float*>(smem);
+  float* const sJ = sI + kPB;
+  if constexpr (NP == 2) {
+    __syncthreads();
+    if (tid < 2 * kPB) {
+      float down, up;
+      planes_row_scale(a.rowmax[(tid < kPB ? I : J) * kPB + (tid & (kPB - 1))], down, up);
+      sI[tid] = up;
+    }
+    __syncthreads();
+  }
   // ---- epilogue: the wave's tiles into the split's partial tile, column-major (row = A-side row): a lane holds 4 consecutive rows
   float* out = a.Gpart + ((int64_t)sidx * a.ntiles + t) * (kPB * kPB);
   typedef float f4 __attribute__((ext_vector_type(4)));
@@ -279,11 +410,17 @@ __global__ __launch_bounds__(kPlanesThreads, 2) void gram_planes_kernel(GramPlan
   for (int k = 0; k < 2; ++k) {
     if (!(k == 0 ? t0 : t1)) continue;  // (wave-uniform; the reduction never reads the strictly upper tiles of a diagonal macro tile)
     const int col = 32 * (2 * tc + k) + (lane & 31);
+    const float cs = NP == 2 ? post_scale * sJ[col] : post_scale;
 #pragma unroll
     for (int q = 0; q < 4; ++q) {
+      const int row0 = 32 * ti + 8 * q + 4 * (lane >> 5);
       f4 v = {acc[k][4 * q] + accs[k][4 * q], acc[k][4 * q + 1] + accs[k][4 * q + 1], acc[k][4 * q + 2] + accs[k][4 * q + 2], acc[k][4 * q + 3] + accs[k][4 * q + 3]};
-      v *= post_scale;
-      *reinterpret_cast<f4*>(out + (int64_t)col * kPB + 32 * ti + 8 * q + 4 * (lane >> 5)) = v;
+      if constexpr (NP == 2) {
+        const f4 rsc = *reinterpret_cast<const f4*>(sI + row0);
+        v *= rsc;
+      }
+      v *= cs;
+      *reinterpret_cast<f4*>(out + (int64_t)col * kPB + row0) = v;
     }
   }
 }
