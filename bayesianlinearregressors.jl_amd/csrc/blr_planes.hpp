@@ -327,67 +327,103 @@ __global__ __launch_bounds__(kPlanesThreads, 2) void gram_planes_kernel(GramPlan
   // The loop is not short of overlap: without its matrix instructions it takes 171 us, without its LDS-DMA 361 -- the matrix pipe on
   // random operands at the clock the part then holds (MI355X_MICROARCH.md, DVFS give-back (5): 1.5 - 1.7 GHz) IS the time, and a
   // denser instruction stream lowers that clock further.)
-  auto half = [&](const char* slot) {
-    gram_u4 A[NP], B0[NP], B1[NP];
-    gram_u4 A2[NP], B02[NP], B12[NP];  // NP = 2: the stage's second k-block
+  constexpr int NF = 3 * NP * C::KBS;  // fragments of a stage: per k-block A, B0, B1 with NP planes each
+  struct Frags { gram_u4 v[NF]; };
+  auto read_stage = [&](const char* slot, Frags& f) {
 #pragma unroll
-    for (int p = 0; p < NP; ++p) A[p] = *reinterpret_cast<const gram_u4*>(slot + offa + p * 1024);
+    for (int u = 0; u < C::KBS; ++u) {
 #pragma unroll
-    for (int p = 0; p < NP; ++p) B0[p] = *reinterpret_cast<const gram_u4*>(slot + offb + p * 1024);
+      for (int p = 0; p < NP; ++p) f.v[u * 3 * NP + p] = *reinterpret_cast<const gram_u4*>(slot + u * C::HALF + offa + p * 1024);
 #pragma unroll
-    for (int p = 0; p < NP; ++p) B1[p] = *reinterpret_cast<const gram_u4*>(slot + offb + (NP + p) * 1024);
-    if constexpr (C::KBS == 2) {
+      for (int p = 0; p < NP; ++p) f.v[u * 3 * NP + NP + p] = *reinterpret_cast<const gram_u4*>(slot + u * C::HALF + offb + p * 1024);
 #pragma unroll
-      for (int p = 0; p < NP; ++p) A2[p] = *reinterpret_cast<const gram_u4*>(slot + C::HALF + offa + p * 1024);
-#pragma unroll
-      for (int p = 0; p < NP; ++p) B02[p] = *reinterpret_cast<const gram_u4*>(slot + C::HALF + offb + p * 1024);
-#pragma unroll
-      for (int p = 0; p < NP; ++p) B12[p] = *reinterpret_cast<const gram_u4*>(slot + C::HALF + offb + (NP + p) * 1024);
+      for (int p = 0; p < NP; ++p) f.v[u * 3 * NP + 2 * NP + p] = *reinterpret_cast<const gram_u4*>(slot + u * C::HALF + offb + (NP + p) * 1024);
     }
-    issue();  // stage h + AHEAD into the slot of stage h - 1 (everybody left it at the barrier that ended stage h - 1)
+  };
+  auto compute = [&](const Frags& f) {
 #if defined(BLR_PLANES_EXP) && BLR_PLANES_EXP == 1  /* timing experiment: no matrix instructions */
-    acc[0][0] += __uint_as_float(A[0][0] ^ B0[0][0] ^ B1[NP - 1][3]);
-    if constexpr (C::KBS == 2) acc[0][1] += __uint_as_float(A2[0][0] ^ B02[0][0] ^ B12[NP - 1][3]);
+    acc[0][0] += __uint_as_float(f.v[0][0] ^ f.v[NP][0] ^ f.v[NF - 1][3]);
     return;
 #endif
-    if constexpr (NP == 3) {  // planes h, m, l
-      if (t0 && t1) {
-        BLR_PM3(accs[0], A[2], B0[0]); BLR_PM3(accs[1], A[2], B1[0]);
-        BLR_PM3(acc[0], A[0], B0[0]);  BLR_PM3(acc[1], A[0], B1[0]);
-        BLR_PM3(accs[0], A[0], B0[2]); BLR_PM3(accs[1], A[0], B1[2]);
-        BLR_PM3(accs[0], A[1], B0[1]); BLR_PM3(accs[1], A[1], B1[1]);
-        BLR_PM3(accs[0], A[1], B0[0]); BLR_PM3(accs[1], A[1], B1[0]);
-        BLR_PM3(accs[0], A[0], B0[1]); BLR_PM3(accs[1], A[0], B1[1]);
-      } else if (t0) {
-        BLR_PM3(accs[0], A[2], B0[0]); BLR_PM3(acc[0], A[0], B0[0]); BLR_PM3(accs[0], A[0], B0[2]);
-        BLR_PM3(accs[0], A[1], B0[1]); BLR_PM3(accs[0], A[1], B0[0]); BLR_PM3(accs[0], A[0], B0[1]);
+    auto kblock = [&](auto utag) {
+      constexpr int u = decltype(utag)::value;
+      if constexpr (u < C::KBS) {
+#define A(p) f.v[u * 3 * NP + (p)]
+#define B0(p) f.v[u * 3 * NP + NP + (p)]
+#define B1(p) f.v[u * 3 * NP + 2 * NP + (p)]
+      if constexpr (NP == 3) {  // planes h, m, l
+        if (t0 && t1) {
+          BLR_PM3(accs[0], A(2), B0(0)); BLR_PM3(accs[1], A(2), B1(0));
+          BLR_PM3(acc[0], A(0), B0(0));  BLR_PM3(acc[1], A(0), B1(0));
+          BLR_PM3(accs[0], A(0), B0(2)); BLR_PM3(accs[1], A(0), B1(2));
+          BLR_PM3(accs[0], A(1), B0(1)); BLR_PM3(accs[1], A(1), B1(1));
+          BLR_PM3(accs[0], A(1), B0(0)); BLR_PM3(accs[1], A(1), B1(0));
+          BLR_PM3(accs[0], A(0), B0(1)); BLR_PM3(accs[1], A(0), B1(1));
+        } else if (t0) {
+          BLR_PM3(accs[0], A(2), B0(0)); BLR_PM3(acc[0], A(0), B0(0)); BLR_PM3(accs[0], A(0), B0(2));
+          BLR_PM3(accs[0], A(1), B0(1)); BLR_PM3(accs[0], A(1), B0(0)); BLR_PM3(accs[0], A(0), B0(1));
+        }
+      } else {  // planes h, l
+        if (t0 && t1) {
+          BLR_PM2(accs[0], A(1), B0(0)); BLR_PM2(accs[1], A(1), B1(0));
+          BLR_PM2(acc[0], A(0), B0(0));  BLR_PM2(acc[1], A(0), B1(0));
+          BLR_PM2(accs[0], A(0), B0(1)); BLR_PM2(accs[1], A(0), B1(1));
+        } else if (t0) {
+          BLR_PM2(accs[0], A(1), B0(0)); BLR_PM2(acc[0], A(0), B0(0)); BLR_PM2(accs[0], A(0), B0(1));
+        }
       }
-    } else {  // planes h, l
-      if (t0 && t1) {
-        BLR_PM2(accs[0], A[1], B0[0]); BLR_PM2(accs[1], A[1], B1[0]);
-        BLR_PM2(acc[0], A[0], B0[0]);  BLR_PM2(acc[1], A[0], B1[0]);
-        BLR_PM2(accs[0], A[0], B0[1]); BLR_PM2(accs[1], A[0], B1[1]);
-        BLR_PM2(accs[0], A2[1], B02[0]); BLR_PM2(accs[1], A2[1], B12[0]);
-        BLR_PM2(acc[0], A2[0], B02[0]);  BLR_PM2(acc[1], A2[0], B12[0]);
-        BLR_PM2(accs[0], A2[0], B02[1]); BLR_PM2(accs[1], A2[0], B12[1]);
-      } else if (t0) {
-        BLR_PM2(accs[0], A[1], B0[0]); BLR_PM2(acc[0], A[0], B0[0]); BLR_PM2(accs[0], A[0], B0[1]);
-        BLR_PM2(accs[0], A2[1], B02[0]); BLR_PM2(acc[0], A2[0], B02[0]); BLR_PM2(accs[0], A2[0], B02[1]);
+#undef A
+#undef B0
+#undef B1
       }
-    }
+    };
+    kblock(std::integral_constant<int, 0>{});
+    kblock(std::integral_constant<int, 1>{});
+  };
+  const auto end_of_stage = [&]() {
+    // stage h + 1 must have landed (the younger ones may stay in flight), then everybody's pieces are visible
+    asm volatile("s_waitcnt vmcnt(%0)" ::"n"(C::PW * (C::AHEAD - 1)) : "memory");
+    __syncthreads();
   };
   if (nh > 0) {
     for (int q = 0; q < C::AHEAD; ++q) issue();
-    asm volatile("s_waitcnt vmcnt(%0)" ::"n"(C::PW * (C::AHEAD - 1)) : "memory");  // half 0 has landed
+    asm volatile("s_waitcnt vmcnt(%0)" ::"n"(C::PW * (C::AHEAD - 1)) : "memory");  // stage 0 has landed
     __syncthreads();
+    // The two waves of a SIMD (w, w + 4) work half a stage apart.  Waves 0 - 3: read stage h, compute it.  Waves 4 - 7: compute stage
+    // h - 1 from the registers they filled in the interval before, THEN read stage h -- their matrix instructions run under their
+    // partners' fragment reads and LDS-DMA issue and the other way round (in step, every wave of the CU read, then every wave computed:
+    // the Gram launch of config 3 took what its matrix instructions and its data movement take one after the other, 262 us of 180 + 115).
+    // Stage h + AHEAD goes into the slot of stage h - 1, which everybody had read by the barrier that ended interval h - 1.
+    if (wave < 4) {
 #pragma unroll 1
-    for (int h = 0; h < nh; ++h) {
-      half(smem + (h % C::SLOTS) * C::STAGE);
-      // end of half h: half h + 1 must have landed (the younger ones may stay in flight), then everybody's pieces are visible
-      asm volatile("s_waitcnt vmcnt(%0)" ::"n"(C::PW * (C::AHEAD - 1)) : "memory");
-      __syncthreads();
+      for (int h = 0; h < nh; ++h) {
+        Frags f;
+        read_stage(smem + (h % C::SLOTS) * C::STAGE, f);
+        issue();
+        compute(f);
+        end_of_stage();
+      }
+    } else {
+      // (their fragment reads are not consumed before the barrier: drained explicitly, so that no read of a slot is still in the LDS
+      // queue when, an interval later, a partner's LDS-DMA piece is issued into it)
+      const auto end_of_stage_lag = [&]() {
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        end_of_stage();
+      };
+      Frags f;
+      read_stage(smem, f);
+      issue();
+      end_of_stage_lag();
+#pragma unroll 1
+      for (int h = 1; h < nh; ++h) {
+        compute(f);  // stage h - 1
+        read_stage(smem + (h % C::SLOTS) * C::STAGE, f);  // (into the registers the instructions above have read)
+        issue();
+        end_of_stage_lag();
+      }
+      compute(f);  // stage nh - 1
     }
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // (the pieces issued beyond the last half)
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // (the pieces issued beyond the last stage)
   }
 #undef BLR_PM3
 #undef BLR_PM2
