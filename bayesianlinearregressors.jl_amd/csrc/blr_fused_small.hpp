@@ -20,6 +20,9 @@
 // address/mask/tile-coordinate values across the phases and the hot MFMA loop spills (measured: 1.5 KB
 // of scratch per lane and 46 % MFMA utilisation).
 #pragma once
+#ifndef BLR_SMALL_NT
+#define BLR_SMALL_NT true  /* the X stream of the per-regressor kernels is read once: non-temporal LDS-DMA pieces (blr_common.hpp, glds_s) */
+#endif
 #include <utility>
 
 #include "blr_common.hpp"
@@ -754,7 +757,7 @@ __device__ __forceinline__ void gram_iso_ring(T* __restrict__ ring, T* __restric
     const unsigned slot = ring_addr + (unsigned)(slot_of(h) * HALF * (int)sizeof(T));
 #pragma unroll
     for (int p = 0; p < PW; ++p)
-      glds_s<16>(uni((int64_t)(nextX + offp[p])), voff, slot + (unsigned)((p * kWaves + WS) * 1024));
+      glds_s<16, 64, BLR_SMALL_NT>(uni((int64_t)(nextX + offp[p])), voff, slot + (unsigned)((p * kWaves + WS) * 1024));
     if constexpr (WS == 0)
       glds_s<4, YL>(uni((int64_t)nextY), (unsigned)(lane * 4), ybuf_addr + (unsigned)(slot_of(h) * HC * (int)sizeof(T)));
 #endif

@@ -17,6 +17,9 @@
 //     keeps the matrix pipe busy.
 // Anything outside the fast path (RowVecs, unaligned columns, D not 32 / 64) stays on blr_fused_small.hpp.
 #pragma once
+#ifndef BLR_WAVE_NT
+#define BLR_WAVE_NT true  /* the X stream of the per-regressor kernels is read once: non-temporal LDS-DMA pieces (blr_common.hpp, glds_s) */
+#endif
 #include "blr_fused_small.hpp"
 
 namespace blr {
@@ -136,7 +139,7 @@ BLR_PHASE void wave_gram(char* smem0, const BLR_GLOBAL T* X, int64_t ldx, const 
     const int sl = td & (C::DEPTH - 1);
     const unsigned slot_addr = ring_addr + (unsigned)(sl * C::SLOT * (int)sizeof(T));
 #pragma unroll
-    for (int g = 0; g < C::NG; ++g) glds_s<16>(uni((int64_t)(nextX + offg[g])), voff, slot_addr + (unsigned)(g * 1024));
+    for (int g = 0; g < C::NG; ++g) glds_s<16, 64, BLR_WAVE_NT>(uni((int64_t)(nextX + offg[g])), voff, slot_addr + (unsigned)(g * 1024));
     glds_s<4, C::YL>(uni((int64_t)nextY), (unsigned)(lane * 4), ybuf_addr + (unsigned)(sl * C::NSC * (int)sizeof(T)));
     if constexpr (DIAG) glds_s<4, C::YL>(uni((int64_t)nextS), (unsigned)(lane * 4), sbuf_addr + (unsigned)(sl * C::NSC * (int)sizeof(T)));
     nextX += stepX;

@@ -39,6 +39,7 @@ import numpy as np  # noqa: E402
 # fp32 matrix 157.3 TF
 PEAK_HBM_GBS = 8000.0
 PEAK_TF = {"f64": 78.6, "f32": 157.3}
+PEAK_F16_TF = 2500.0  # dense fp16 / bf16 matrix peak (same guide; never the 2:1-sparsity figure)
 
 
 def measured_matrix_peak(dtype):
@@ -287,8 +288,16 @@ def roofline_of(flops, nbytes, dtype, ms, kernel, i8_cols=None, i8_diag=False):
         ops = i8_ops_per_column(i8_diag) * i8_cols
         t_mat = ops / (PEAK_I8_TOPS * 1e12)
         extra = {"int8_TOPps": ops / sec / 1e12, "int8_frac": ops / sec / (PEAK_I8_TOPS * 1e12), "f64_equiv_frac": tf / PEAK_TF[dtype]}
+    planes = {"gram_planes_kernel<2>": 3.0, "gram_planes_kernel<3>": 6.0}.get(kernel)
+    if planes is not None and dtype == "f32":
+        # the fp32 Gram from pre-split 16-bit planes (csrc/blr_planes.hpp): `planes` products of the half-precision matrix instruction
+        # (2.5 PFLOP/s dense) per fp32 product -- priced against the pipe it runs on; f32_equiv_frac keeps the round-5 convention
+        t_mat = planes * flops / (PEAK_F16_TF * 1e12)
+        extra = {"f16_TFLOPps": planes * tf, "f16_frac": planes * tf / PEAK_F16_TF, "f32_equiv_frac": tf / PEAK_TF[dtype]}
     if t_mat >= t_hbm:
-        if i8_cols is not None:
+        if planes is not None and dtype == "f32":
+            r = {"bound": "mfma", "achieved": extra["f16_TFLOPps"], "peak": PEAK_F16_TF, "unit": "TFLOP/s (fp16 / bf16 products)", "frac": extra["f16_frac"]}
+        elif i8_cols is not None:
             r = {"bound": "mfma", "achieved": extra["int8_TOPps"], "peak": PEAK_I8_TOPS, "unit": "TOP/s (int8)", "frac": extra["int8_frac"]}
         else:
             r = {"bound": "mfma", "achieved": tf, "peak": PEAK_TF[dtype], "unit": "TFLOP/s", "frac": tf / PEAK_TF[dtype]}
@@ -314,6 +323,8 @@ def secondary_line(name, e):
          "traffic_x": _sig(tx, 3) if tx else None, "kernel": r["kernel"][:72]}
     if "int8_frac" in r:
         d["int8_frac"], d["f64_equiv_frac"] = _sig(r["int8_frac"], 3), _sig(r["f64_equiv_frac"], 3)
+    if "f32_equiv_frac" in r:
+        d["f32_equiv_frac"] = _sig(r["f32_equiv_frac"], 3)
     return json.dumps(d)
 
 
