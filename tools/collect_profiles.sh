@@ -57,6 +57,7 @@ rocprofv3 --pmc $SQ --kernel-trace --output-format csv -d $OUT/pmc_sq_c3b8 -- $B
   { ./marg128_bench 64 4096 8; ./marg128_bench 64 4096 16; ./marg128_bench 256 4096 2; [ -x ./marg128_bench_st ] && ./marg128_bench_st 64 4096 8 1 | grep "image kernel" | head -1; } > $OUT/marg128_bench.txt 2>&1
   { ./marg_bench 1024 65536 20; [ -x ./marg_bench16 ] && ./marg_bench16 1024 65536 20; ./marg_bench 1024 999 20; [ -x ./marg_bench16 ] && ./marg_bench16 1024 999 20; [ -x ./marg_bench_st ] && ./marg_bench_st 1024 65536 5 | grep wave; } > $OUT/marg_bench.txt 2>&1
   # int8-sliced Gram against the fp64 kernel, same inputs: rates, agreement, the retry path (mode 1), per-phase cycle stamps
+  [ -x ./i8_gram ] || /opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -std=c++17 -Wno-unused-function -I$R/bayesianlinearregressors.jl_amd/csrc i8_gram.hip -o i8_gram 2>/dev/null
   { for m in 0 2 4 1; do ./i8_gram 4096 4096 10 $m; done; ./i8_gram 512 4096 3 5; ./i8_gram 512 1024 3 0; ./i8_gram 256 16384 3 0; ./i8_gram 4096 4096 10 3; I8_MW=1 ./i8_gram 4096 4096 10 0;
     [ -x ./i8_gram_st ] && ./i8_gram_st 4096 4096 4 0 | grep "wave"; } > $OUT/i8_gram.txt 2>&1
   # config 4's one-wave kernel: whole / Gram phase only / MFMAs without the stream / stream without the MFMAs, with the clock each holds
@@ -73,7 +74,7 @@ rocprofv3 --pmc $SQ --kernel-trace --output-format csv -d $OUT/pmc_sq_c3b8 -- $B
 for e in marginals_var_c2_f64 marginals_var_c3_f32 marginals_var_D512_B16_f32 rand_c2_f64_S64 rand_c3_f32_S64 logpdf_grad_c2_f64 logpdf_multi_c3_f32_S64; do
   rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/stats_$e -- $B --secondary-only $e > /dev/null 2>&1
 done
-for e in c2_f64_mw c2_f64_diag_noise c2_f64_factor_prior c2_f64_rowvecs c2_f64_dense_prior c4_f32 c4_f64_B4096 c4_f64_B2048 c4_f64_B1024 c3_f32_mw logpdf_only_c3_f32 c3_f32_B8 c5_shape_f32_B8 marginals_mean_c2_f64 marginals_var_c2_f64 \
+for e in c3_f32 c5_f32_end_to_end c2_f64_heavy_tail c2_f64_mw c2_f64_diag_noise c2_f64_factor_prior c2_f64_rowvecs c2_f64_dense_prior c4_f32 c4_f64_B4096 c4_f64_B2048 c4_f64_B1024 c3_f32_mw logpdf_only_c3_f32 c3_f32_B8 c5_shape_f32_B8 marginals_mean_c2_f64 marginals_var_c2_f64 \
          marginals_var_c2_f32 marginals_mean_c3_f32 marginals_var_c3_f32 marginals_var_D512_B16_f32 rand_c2_f64_S64 rand_c3_f32_S64 logpdf_grad_c2_f64 logpdf_grad_c2_f64_sweep_kernel logpdf_grad_c2_f32 logpdf_multi_c3_f32_S64 \
          update_factor_D128_k1_f64 update_factor_D128_k16_f64; do
   rocprofv3 --pmc FETCH_SIZE --kernel-trace --output-format csv -d $OUT/sec_fetch_$e -- $B --secondary-only $e > $OUT/sec_fetch_$e.json 2>/dev/null

@@ -9,7 +9,7 @@ import os
 import shutil
 import sys
 
-tag = sys.argv[1] if len(sys.argv) > 1 else "r05"
+tag = sys.argv[1] if len(sys.argv) > 1 else "r06"
 RAW = "gpurun_out/profiles_raw"
 DST = "profiles"
 os.makedirs(DST, exist_ok=True)
@@ -89,7 +89,7 @@ def counters(dirname, kernel_substr):
 
 
 kd = {}
-for cfg, kern in (("c2", "fused_i8_kernel"), ("c3", "gram_tile_kernel"), ("c5", "gram_tile_kernel"), ("c4", "fused_wave_kernel"), ("c3b8", "gram_tile_kernel"),
+for cfg, kern in (("c2", "fused_i8_kernel"), ("c3", "gram_planes_kernel"), ("c5", "gram_planes_kernel"), ("c4", "fused_wave_kernel"), ("c3b8", "gram_planes_kernel"),
                   ("marginals_var_c2_f64", "marginals_gemm_kernel"), ("marginals_var_c3_f32", "marg_blocksub_kernel"),
                   ("logpdf_grad_c2_f64", "grad_gemm_kernel")):
     r = durations(f"stats_{cfg}", kern)
@@ -104,7 +104,7 @@ summary = {"note": "per-dispatch means for the dominant kernel; rocprofv3 --pmc,
 fetch = counters("pmc_FETCH_SIZE_c2fp64", "fused_small_kernel")  # (the fp64 kernel: runs under BLR_MI355X_NO_I8_GRAM)
 write = counters("pmc_WRITE_SIZE_c2fp64", "fused_small_kernel")
 sq2 = counters("pmc_sq_c2fp64", "fused_small_kernel")
-sq3 = counters("pmc_sq_c3", "gram_tile_kernel")
+sq3 = counters("pmc_sq_c3", "gram_planes_kernel")
 if fetch and write:
     rd = fetch["FETCH_SIZE"] * 1024.0 * 2.0
     wr = write["WRITE_SIZE"] * 1024.0
@@ -121,10 +121,10 @@ if f4 and w4:
                                             "hbm_read_bytes_per_launch": rd, "hbm_write_bytes_per_launch": wr,
                                             "hbm_bytes_per_launch": rd + wr, "units_per_launch": 8192}
 sq4 = counters("pmc_sq_c4", "fused_wave_kernel")
-sq5 = counters("pmc_sq_c5", "gram_tile_kernel")
-sq3b8 = counters("pmc_sq_c3b8", "gram_tile_kernel")  # 8 regressors of c3's shape in one launch
-for key, d, kern, units in (("c2_f32_fused_small_kernel_hbm", "c2f32", "fused_small_kernel", 4096), ("c3_gram_tile_kernel_hbm", "c3", "gram_tile_kernel", 1),
-                            ("c5_gram_tile_kernel_hbm", "c5", "gram_tile_kernel", 1)):
+sq5 = counters("pmc_sq_c5", "gram_planes_kernel")
+sq3b8 = counters("pmc_sq_c3b8", "gram_planes_kernel")  # 8 regressors of c3's shape in one launch
+for key, d, kern, units in (("c2_f32_fused_small_kernel_hbm", "c2f32", "fused_small_kernel", 4096), ("c3_gram_planes_kernel_hbm", "c3", "gram_planes_kernel", 1),
+                            ("c5_gram_planes_kernel_hbm", "c5", "gram_planes_kernel", 1)):
     fe, wr_ = counters(f"pmc_fetch_{d}", kern), counters(f"pmc_write_{d}", kern)
     if fe and wr_:
         rd = fe["FETCH_SIZE"] * 1024.0 * 2.0
@@ -139,8 +139,8 @@ for extra in ("ring_probe.txt", "power_probe.txt", "i8_gram.txt", "i8_sustained.
     src = os.path.join(RAW, extra)
     if os.path.exists(src) and os.path.getsize(src):
         shutil.copy(src, os.path.join(DST, f"{tag}_microbench_{extra}"))
-for key, c in (("c2_fused_small_kernel_sq", sq2), ("c2_f32_fused_small_kernel_sq", sq2f), ("c3_gram_tile_kernel_sq", sq3),
-               ("c4_fused_wave_kernel_sq", sq4), ("c5_gram_tile_kernel_sq", sq5), ("c3_B8_gram_tile_kernel_sq", sq3b8)):
+for key, c in (("c2_fused_small_kernel_sq", sq2), ("c2_f32_fused_small_kernel_sq", sq2f), ("c3_gram_planes_kernel_sq", sq3),
+               ("c4_fused_wave_kernel_sq", sq4), ("c5_gram_planes_kernel_sq", sq5), ("c3_B8_gram_planes_kernel_sq", sq3b8)):
     if c:
         ns = c["avg_duration_ns"]
         c["effective_clock_GHz"] = c["GRBM_GUI_ACTIVE"] / 8.0 / ns
@@ -192,5 +192,15 @@ for key, d in (("c2_fused_i8_kernel_hbm", "c2"),):
 if "c2_fused_small_kernel_hbm" in summary:  # the A/B secondary entry of the driver-line workload on the fp64 kernel
     summary["c2_f64_fp64_kernel_hbm"] = dict(summary["c2_fused_small_kernel_hbm"], units_per_launch=1,
                                              note="= c2_fused_small_kernel_hbm (one launch per call)")
+# what this collection measured: the kernel sources as they stood (bench.py marks a `traffic` figure stale when they have changed since)
+import hashlib
+import subprocess
+src_dir = os.path.join("bayesianlinearregressors.jl_amd", "csrc")
+summary["_kernel_source_sha16"] = {f: hashlib.sha256(open(os.path.join(src_dir, f), "rb").read()).hexdigest()[:16]
+                                   for f in sorted(os.listdir(src_dir)) if f.endswith((".hpp", ".hip"))}
+try:
+    summary["_collected_at_commit"] = subprocess.run(["git", "rev-parse", "--short=12", "HEAD"], capture_output=True, text=True).stdout.strip()
+except Exception:
+    pass
 json.dump(summary, open(os.path.join(DST, f"{tag}_pmc_summary.json"), "w"), indent=1)
 print(json.dumps(summary, indent=1)[:3000])
