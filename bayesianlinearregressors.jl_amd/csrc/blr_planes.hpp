@@ -48,7 +48,7 @@ template <int NP> struct PlanesCfg {
                                                    // (NP = 2 with one k-block per barrier: 327 us for config 3's Gram launch, the barrier and
                                                    // the fragment reads of 8 waves in step weigh as much as its 6 instructions)
   static constexpr int STAGE = KBS * HALF;         // 24 KiB / 32 KiB
-  static constexpr int SLOTS = NP == 3 ? 6 : 4;    // stages in the ring
+  static constexpr int SLOTS = NP == 3 ? 6 : 4;    // stages in the ring (five -- all of the LDS -- measured the same)
   static constexpr int AHEAD = SLOTS - 1;          // stages in flight beyond the one being computed
   static constexpr int LDS = SLOTS * STAGE;        // 144 KiB / 128 KiB
   static constexpr int PW = NP * KBS;              // LDS-DMA pieces per loader wave and stage (waves 0 - 3: A side, 4 - 7: B side)
@@ -416,7 +416,11 @@ __global__ __launch_bounds__(kPlanesThreads, 2) void gram_planes_kernel(GramPlan
       end_of_stage_lag();
 #pragma unroll 1
       for (int h = 1; h < nh; ++h) {
+        // (priority over the partner for the matrix instructions: they run first and back to back, the partner's -- whose fragments
+        // are still on their way from the LDS -- behind them; interleaved, this wave's reads below started late and ended the interval)
+        __builtin_amdgcn_s_setprio(2);
         compute(f);  // stage h - 1
+        __builtin_amdgcn_s_setprio(0);
         read_stage(smem + (h % C::SLOTS) * C::STAGE, f);  // (into the registers the instructions above have read)
         issue();
         end_of_stage_lag();
