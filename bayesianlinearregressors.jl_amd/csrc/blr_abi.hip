@@ -35,7 +35,7 @@ using namespace blr;
 // handle is created (BLR_MI355X_<KEY>), and settable per handle with blr_set_option: no getenv on any launch path.
 struct BlrOptions {
   bool no_ldsdma = false, no_wave_kernel = false, no_gram_ring = false, no_diag_split = false, no_xcd_swizzle = false,
-       no_mfma_project = false, plan_debug = false, no_i8_gram = false, no_marg_gemm = false, no_i8_diag = false, no_i8_factor = false, no_i8_rowvecs = false, no_grad_gemm = false, no_i8_dense = false, no_i8_fallback = false, no_bf16x3 = false, no_planes = false, no_fp16_planes = false;
+       no_mfma_project = false, plan_debug = false, no_i8_gram = false, no_marg_gemm = false, no_i8_diag = false, no_i8_factor = false, no_i8_rowvecs = false, no_grad_gemm = false, no_i8_dense = false, no_i8_fallback = false, no_bf16x3 = false, no_planes = false, no_fp16_planes = false, planes8 = false;
   int wave_split = 0;     // waves per regressor of the wave kernel: 0 = router, else 1 | 2 | 4
   int chain_batch = 0;    // regressors per shared launch at D > 128: 0 = as many as the workspace holds
   int i8_probe_min = 0;   // int8 route: batches beyond this many regressors start with a probe slice; 0 = kI8ProbeMin
@@ -73,6 +73,7 @@ struct BlrOptions {
     if (!strcmp(key, "NO_BF16X3")) return flag(no_bf16x3);
     if (!strcmp(key, "NO_PLANES")) return flag(no_planes);
     if (!strcmp(key, "NO_FP16_PLANES")) return flag(no_fp16_planes);
+    if (!strcmp(key, "PLANES8")) return flag(planes8);
     if (!strcmp(key, "NO_I8_FALLBACK")) return flag(no_i8_fallback);
     long v = 0;
     if (!strcmp(key, "WAVE_SPLIT")) {
@@ -722,7 +723,8 @@ int posterior_large_group(blr_handle* h, const PosteriorArgs<T>& a, int64_t reg0
   h->route_i8_B = 0;
   const int NP = h->opt.no_fp16_planes ? 3 : 2;  // planes per operand: two fp16 (three products) or three bf16 (six)
   h->route = sizeof(T) == 8 ? "gram_tile_kernel<double>"
-                            : (planes ? (NP == 2 ? "gram_planes_kernel<2>" : "gram_planes_kernel<3>") : (bf3 ? "gram_tile_kernel<float, true>" : "gram_tile_kernel<float>"));  // (large-D pipeline: the Gram launch dominates; <float, true>: full tiles on the bf16 matrix cores)
+                            : (planes ? (NP == 2 ? (h->opt.planes8 ? "gram_planes_kernel<2>" : "gram_planes4_kernel") : "gram_planes_kernel<3>")
+                                      : (bf3 ? "gram_tile_kernel<float, true>" : "gram_tile_kernel<float>"));  // (large-D pipeline: the Gram launch dominates; <float, true>: full tiles on the bf16 matrix cores)
   using LC = LargeCfg<T>;
   const int D = a.D, N = a.N;
   const int DP = (D + kPB - 1) / kPB * kPB, NC = DP / kPB;
@@ -808,12 +810,13 @@ int posterior_large_group(blr_handle* h, const PosteriorArgs<T>& a, int64_t reg0
     }
   };
   // the planes path: one 512-thread workgroup per CU, k-blocks of 16 columns, diagonal macro tiles as long as the others
+  const bool planes4 = NP == 2 && !h->opt.planes8;  // 64 x 64 per wave, two 256-thread workgroups per CU (gram_planes4_kernel)
   const int kbs = NP == 2 ? PlanesCfg<2>::KBS : PlanesCfg<3>::KBS;
   const int NKB = ((N + 15) / 16 + kbs - 1) / kbs * kbs;  // k-blocks of 16 columns, padded to whole stages of the Gram launch (zero columns)
   auto plan_splits_planes = [&](int G) {
     nsplit_diag = 0; nlong = 0; nsplit = 1;
     double best = 1e300;
-    const int slots = h->cus;
+    const int slots = h->cus * (planes4 ? 2 : 1);
     for (int sp = 1; sp <= std::min(64, std::max(1, NKB)); ++sp) {
       const int rounds = (ntiles * sp * G + slots - 1) / slots;
       const double cost = (double)rounds * (16.0 * ((NKB + sp - 1) / sp) + 192.0);  // (192: a workgroup's pipeline fill and its 64 KB partial tile, in columns)
@@ -1022,7 +1025,10 @@ int posterior_large_group(blr_handle* h, const PosteriorArgs<T>& a, int64_t reg0
       ga.rowmax = rowmax;
       ga.xcd_swizzle = (nsplit > 1 && !no_swizzle) ? 1 : 0;
       ga.grp_ws = wsb; ga.grp_s = a.strides;
-      if (NP == 2) hipLaunchKernelGGL(gram_planes_kernel<2>, dim3(ntiles * nsplit, G), dim3(kPlanesThreads), (size_t)PlanesCfg<2>::LDS, h->stream, ga);
+      if (planes4) {
+        if ((rc = set_lds_once(h, reinterpret_cast<const void*>(gram_planes4_kernel), (size_t)Planes4Cfg::LDS))) return rc;
+        hipLaunchKernelGGL(gram_planes4_kernel, dim3(ntiles * nsplit, G), dim3(kThreads), (size_t)Planes4Cfg::LDS, h->stream, ga);
+      } else if (NP == 2) hipLaunchKernelGGL(gram_planes_kernel<2>, dim3(ntiles * nsplit, G), dim3(kPlanesThreads), (size_t)PlanesCfg<2>::LDS, h->stream, ga);
       else hipLaunchKernelGGL(gram_planes_kernel<3>, dim3(ntiles * nsplit, G), dim3(kPlanesThreads), (size_t)PlanesCfg<3>::LDS, h->stream, ga);
       if (prior_factor) {  // the prior factor as pseudo-observations: one more partial per tile, from the f32 kernel
         GramTileArgs<T> u = g;

@@ -465,4 +465,138 @@ __global__ __launch_bounds__(kPlanesThreads, 2) void gram_planes_kernel(GramPlan
   }
 }
 
+// ---- the consumer, 64 x 64 per wave (NP = 2) ------------------------------------------------------------------------------------------
+// Four waves per workgroup, each owning a 64 x 64 quadrant of the macro tile (four 32 x 32 tiles, eight accumulators of 16 registers),
+// two workgroups per CU (ring of four halves of 16 KiB each): per half and wave 8 fragment reads for 12 matrix instructions where
+// gram_planes_kernel reads 12 for 12, and the two workgroups of a CU drift apart by themselves -- one's reads and barrier under the
+// other's matrix instructions.  Same planes, same partial tiles.
+struct Planes4Cfg {
+  static constexpr int SIDE = 8 * 1024, HALF = 2 * SIDE, SLOTS = 4, AHEAD = SLOTS - 1, LDS = SLOTS * HALF;
+};
+__global__ __launch_bounds__(kThreads, 2) void gram_planes4_kernel(GramPlanesArgs a) {
+  using C = Planes4Cfg;
+  constexpr int NP = 2;
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = uni(tid >> 6);
+  const int wr = wave >> 1, wc = wave & 1;
+  int w = blockIdx.x;
+  if (a.xcd_swizzle) {
+    const int nwg = gridDim.x, xcd = w & 7, qq = nwg >> 3, rr = nwg & 7;
+    w = (xcd < rr ? xcd * (qq + 1) : rr * (qq + 1) + (xcd - rr) * qq) + (w >> 3);
+  }
+  if (const int64_t g = blockIdx.y) {
+    a.Xp = ws_shift(a.Xp, g * a.grp_ws); a.Gpart = ws_shift(a.Gpart, g * a.grp_ws); a.rowmax = ws_shift(a.rowmax, g * a.grp_ws);
+    if (a.s_iso) a.s_iso += g * a.grp_s;
+  }
+  const float post_scale = a.s_iso ? 1.0f / a.s_iso[0] : 1.0f;
+  const int t = w % a.ntiles, sidx = w / a.ntiles;
+  int I = 0;
+  while ((I + 1) * (I + 2) / 2 <= t) ++I;
+  const int J = t - I * (I + 1) / 2;
+  const bool diag = I == J;
+  const int per = (a.NKB + a.nsplit - 1) / a.nsplit;
+  const int kb0 = sidx * per, kb1 = min(a.NKB, kb0 + per);
+  const int nh = kb1 > kb0 ? kb1 - kb0 : 0;
+  gram_f16v acc[2][2], accs[2][2];  // [row sub-block a][column sub-block b]: leading product | the two small ones
+#pragma unroll
+  for (int x = 0; x < 2; ++x)
+#pragma unroll
+    for (int y = 0; y < 2; ++y)
+#pragma unroll
+      for (int v = 0; v < 16; ++v) { acc[x][y][v] = 0.f; accs[x][y][v] = 0.f; }
+  // tile (a, b) of the quadrant exists unless the macro tile is diagonal and the tile lies above its diagonal
+  const bool ex00 = !diag || 2 * wc <= 2 * wr, ex01 = !diag || 2 * wc + 1 <= 2 * wr, ex10 = !diag || 2 * wc <= 2 * wr + 1, ex11 = !diag || 2 * wc + 1 <= 2 * wr + 1;
+  unsigned ring_addr = lds_addr_of(smem);
+  asm volatile("" : "+v"(ring_addr));
+  const uint64_t kbstep = (uint64_t)a.NC * (uint64_t)C::SIDE;
+  const uint64_t baseA = (uint64_t)(uintptr_t)a.Xp + ((uint64_t)kb0 * a.NC + (uint64_t)I) * (uint64_t)C::SIDE + (uint64_t)(2 * wave) * 1024u;
+  const uint64_t baseB = (uint64_t)(uintptr_t)a.Xp + ((uint64_t)kb0 * a.NC + (uint64_t)J) * (uint64_t)C::SIDE + (uint64_t)(2 * wave) * 1024u;
+  uint64_t adv = 0;
+  const unsigned voff = (unsigned)lane * 16u;
+  int hi = 0;
+  auto run = [&](auto dtag) {
+    constexpr bool DG = decltype(dtag)::value;
+    constexpr int PW = DG ? 2 : 4;  // LDS-DMA pieces per wave and half: its two KiB of the A side (+ of the B side)
+    auto issue = [&]() {
+      const unsigned slot = ring_addr + (unsigned)((hi % C::SLOTS) * C::HALF + 2 * wave * 1024);
+      glds_s<16>(uni((int64_t)(baseA + adv)), voff, slot);
+      glds_s<16>(uni((int64_t)(baseA + adv + 1024u)), voff, slot + 1024u);
+      if constexpr (!DG) {
+        glds_s<16>(uni((int64_t)(baseB + adv)), voff, slot + (unsigned)C::SIDE);
+        glds_s<16>(uni((int64_t)(baseB + adv + 1024u)), voff, slot + (unsigned)C::SIDE + 1024u);
+      }
+      if (hi + 1 < nh) adv += kbstep;
+      ++hi;
+    };
+    const int offa = (2 * wr * NP) * 1024 + lane * 16, offb = (DG ? 0 : C::SIDE) + (2 * wc * NP) * 1024 + lane * 16;
+    for (int q = 0; q < C::AHEAD; ++q) issue();
+    asm volatile("s_waitcnt vmcnt(%0)" ::"n"(PW * (C::AHEAD - 1)) : "memory");
+    __syncthreads();
+#define BLR_PM2(ACC, XP, YP) ACC = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(gram_h8, XP), __builtin_bit_cast(gram_h8, YP), ACC, 0, 0, 0)
+#pragma unroll 1
+    for (int h = 0; h < nh; ++h) {
+      const char* slot = smem + (h % C::SLOTS) * C::HALF;
+      gram_u4 A0h = *reinterpret_cast<const gram_u4*>(slot + offa), A0l = *reinterpret_cast<const gram_u4*>(slot + offa + 1024);
+      gram_u4 A1h = *reinterpret_cast<const gram_u4*>(slot + offa + 2048), A1l = *reinterpret_cast<const gram_u4*>(slot + offa + 3072);
+      gram_u4 B0h = *reinterpret_cast<const gram_u4*>(slot + offb), B0l = *reinterpret_cast<const gram_u4*>(slot + offb + 1024);
+      gram_u4 B1h = *reinterpret_cast<const gram_u4*>(slot + offb + 2048), B1l = *reinterpret_cast<const gram_u4*>(slot + offb + 3072);
+      issue();
+      // four independent chains interleaved; within a tile the small products, then the leading one
+      if (ex10) {  // (wave-uniform; the full quadrant in every off-diagonal macro tile)
+        if (ex00) BLR_PM2(accs[0][0], A0l, B0h);
+        BLR_PM2(accs[1][0], A1l, B0h);
+        if (ex01) BLR_PM2(accs[0][1], A0l, B1h);
+        if (ex11) BLR_PM2(accs[1][1], A1l, B1h);
+        if (ex00) BLR_PM2(accs[0][0], A0h, B0l);
+        BLR_PM2(accs[1][0], A1h, B0l);
+        if (ex01) BLR_PM2(accs[0][1], A0h, B1l);
+        if (ex11) BLR_PM2(accs[1][1], A1h, B1l);
+        if (ex00) BLR_PM2(acc[0][0], A0h, B0h);
+        BLR_PM2(acc[1][0], A1h, B0h);
+        if (ex01) BLR_PM2(acc[0][1], A0h, B1h);
+        if (ex11) BLR_PM2(acc[1][1], A1h, B1h);
+      }
+      asm volatile("s_waitcnt vmcnt(%0)" ::"n"(PW * (C::AHEAD - 1)) : "memory");
+      __syncthreads();
+    }
+#undef BLR_PM2
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  };
+  if (nh > 0) {
+    if (diag) run(std::true_type{});
+    else run(std::false_type{});
+  }
+  float* const sI = reinterpret_cast<float*>(smem);
+  float* const sJ = sI + kPB;
+  __syncthreads();
+  {
+    float down, up;
+    planes_row_scale(a.rowmax[(tid < kPB ? I : J) * kPB + (tid & (kPB - 1))], down, up);
+    sI[tid] = up;  // (256 threads: rows of I, then rows of J)
+  }
+  __syncthreads();
+  float* out = a.Gpart + ((int64_t)sidx * a.ntiles + t) * (kPB * kPB);
+  typedef float f4 __attribute__((ext_vector_type(4)));
+#pragma unroll
+  for (int x = 0; x < 2; ++x)
+#pragma unroll
+    for (int y = 0; y < 2; ++y) {
+      const bool ex = x == 0 ? (y == 0 ? ex00 : ex01) : (y == 0 ? ex10 : ex11);
+      if (!ex) continue;
+      const int col = 32 * (2 * wc + y) + (lane & 31);
+      const float cs = post_scale * sJ[col];
+#pragma unroll
+      for (int q = 0; q < 4; ++q) {
+        const int row0 = 32 * (2 * wr + x) + 8 * q + 4 * (lane >> 5);
+        f4 v = {acc[x][y][4 * q] + accs[x][y][4 * q], acc[x][y][4 * q + 1] + accs[x][y][4 * q + 1], acc[x][y][4 * q + 2] + accs[x][y][4 * q + 2],
+                acc[x][y][4 * q + 3] + accs[x][y][4 * q + 3]};
+        v *= *reinterpret_cast<const f4*>(sI + row0);
+        v *= cs;
+        *reinterpret_cast<f4*>(out + (int64_t)col * kPB + row0) = v;
+      }
+    }
+}
+
+
 }  // namespace blr

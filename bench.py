@@ -303,7 +303,7 @@ def roofline_of(flops, nbytes, dtype, ms, kernel, i8_cols=None, i8_diag=False):
         ops = i8_ops_per_column(i8_diag) * i8_cols
         t_mat = ops / (PEAK_I8_TOPS * 1e12)
         extra = {"int8_TOPps": ops / sec / 1e12, "int8_frac": ops / sec / (PEAK_I8_TOPS * 1e12), "f64_equiv_frac": tf / PEAK_TF[dtype]}
-    planes = {"gram_planes_kernel<2>": 3.0, "gram_planes_kernel<3>": 6.0}.get(kernel)
+    planes = {"gram_planes4_kernel": 3.0, "gram_planes_kernel<2>": 3.0, "gram_planes_kernel<3>": 6.0}.get(kernel)
     if planes is not None and dtype == "f32":
         # the fp32 Gram from pre-split 16-bit planes (csrc/blr_planes.hpp): `planes` products of the half-precision matrix instruction
         # (2.5 PFLOP/s dense) per fp32 product -- priced against the pipe it runs on; f32_equiv_frac keeps the round-5 convention

@@ -2945,8 +2945,10 @@ def test_last_route_and_option_codes(B, opt):
     assert post(128, 100, 2) == "fused_small_kernel<double, 8, 4>"
     assert post(64, 100, 2) == "fused_wave_kernel<double, 4, 4>"
     assert post(48, 100, 2, np.float32).startswith("fused_small_kernel<float, 3,")
-    assert post(256, 300, 2, np.float32) == "gram_planes_kernel<2>"
+    assert post(256, 300, 2, np.float32) == "gram_planes4_kernel"
     assert post(256, 300, 2) == "gram_tile_kernel<double>"
+    opt("PLANES8", "1")
+    assert post(256, 300, 2, np.float32) == "gram_planes_kernel<2>"
     opt("NO_FP16_PLANES", "1")
     assert post(256, 300, 2, np.float32) == "gram_planes_kernel<3>"
     opt("NO_PLANES", "1")
@@ -3000,7 +3002,10 @@ def test_large_d_fp32_gram_on_bf16_matrix_cores_vs_f32_route(B, opt, noise):
     # (round 6: the default route splits the operands ONCE, in a pass of its own -- blr_planes.hpp, "gram_planes_kernel"; option NO_PLANES
     # keeps round 5's kernel, which splits them inside the matrix loop; both are held to the f32 matrix instruction)
     e_pl = run()
-    assert h.last_route() == "gram_planes_kernel<2>"   # two fp16 planes per operand under per-row power-of-two scales, three products
+    assert h.last_route() == "gram_planes4_kernel"   # two fp16 planes per operand under per-row power-of-two scales, three products, 64 x 64 per wave
+    opt("PLANES8", "1")
+    e_pl8 = run()
+    assert h.last_route() == "gram_planes_kernel<2>"   # the same planes, eight waves of 32 x 64
     opt("NO_FP16_PLANES", "1")
     e_pl3 = run()
     assert h.last_route() == "gram_planes_kernel<3>"   # three bf16 planes, six products
@@ -3010,8 +3015,8 @@ def test_large_d_fp32_gram_on_bf16_matrix_cores_vs_f32_route(B, opt, noise):
     opt("NO_BF16X3", "1")
     e_f32 = run()
     assert h.last_route() == "gram_tile_kernel<float>"
-    print(f"large-D fp32 Gram ({noise}): rel err (mw', A, logpdf)  fp16 x 2 planes {e_pl}  bf16 x 3 planes {e_pl3}  bf16 x 3 in the loop {e_bf3}  f32 matrix instruction {e_f32}")
-    for e in (e_pl, e_pl3, e_bf3):
+    print(f"large-D fp32 Gram ({noise}): rel err (mw', A, logpdf)  fp16 x 2 planes {e_pl} (eight-wave kernel {e_pl8})  bf16 x 3 planes {e_pl3}  bf16 x 3 in the loop {e_bf3}  f32 matrix instruction {e_f32}")
+    for e in (e_pl, e_pl8, e_pl3, e_bf3):
         assert e[1] <= 4 * e_f32[1] + 1e-7, (e, e_f32)
         assert e[0] <= 4 * e_f32[0] + 1e-6 and e[2] <= 4 * e_f32[2] + 1e-7, (e, e_f32)
         assert e[1] <= 2e-5 and e[2] <= 2e-4
