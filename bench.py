@@ -829,15 +829,51 @@ def main():
     # the total log evidence of that step's batch -- one step later.  (the exchange is latency-bound, 8 KB per rank; on
     # the launch stream it cost 30-50 us of a 150 us step at 8 GPUs.)
     hc, side = None, None
+    comm_note = None
     if use_lib_comm:
-        box = [_abi.Handle.comm_unique_id() if rank == 0 else None]
+        # The library's binding has only ever met a one-rank communicator on the build boxes.  A failure to set it up -- on ANY
+        # rank -- must not cost the job its line: every rank learns of it (MIN over the ranks of a success flag, on the torch
+        # process group that is already up) and all of them take the torch.distributed exchange instead, said in `config.sharding`.
+        # BLR_BENCH_FAIL_LIB_COMM=1 forces that path (tests).
+        ok, why = 1, ""
+        try:
+            if os.environ.get("BLR_BENCH_FAIL_LIB_COMM") == "1":
+                raise RuntimeError("BLR_BENCH_FAIL_LIB_COMM=1")
+            box = [_abi.Handle.comm_unique_id() if rank == 0 else None]
+        except Exception as e:  # noqa: BLE001
+            ok, why, box = 0, f"{type(e).__name__}: {e}", [None]
         if dist is not None:
             dist.broadcast_object_list(box, src=0)
-        hc = _abi.Handle(local_rank)
-        side = torch.cuda.Stream(dev)
-        hc.set_stream(side.cuda_stream)
-        hc.set_async(True)
-        hc.comm_init(world, rank, box[0])
+        if ok and box[0] is not None:
+            try:
+                hc = _abi.Handle(local_rank)
+                side = torch.cuda.Stream(dev)
+                hc.set_stream(side.cuda_stream)
+                hc.set_async(True)
+                hc.comm_init(world, rank, box[0])
+            except Exception as e:  # noqa: BLE001
+                ok, why = 0, f"{type(e).__name__}: {e}"
+        else:
+            ok = 0
+        if dist is not None:
+            flag = torch.tensor([ok], dtype=torch.int32, device=dev if backend == "nccl" else "cpu")
+            dist.all_reduce(flag, op=dist.ReduceOp.MIN)
+            ok_all = int(flag.item())
+        else:
+            ok_all = ok
+        if not ok_all:
+            if hc is not None:
+                try:
+                    if ok:
+                        hc.comm_destroy()
+                    hc.close()
+                except Exception:  # noqa: BLE001
+                    pass
+            hc, side, use_lib_comm = None, None, False
+            comm_note = "library RCCL binding failed" + (f" here ({why})" if why else " on another rank") + \
+                        ": exchange through torch.distributed instead"
+            print(f"bench.py[rank {rank}]: {comm_note}", file=sys.stderr, flush=True)
+    if use_lib_comm:
         lp_bufs = [lp_loc, torch.zeros_like(lp_loc)]
         lp_alls = [lp_all, torch.empty_like(lp_all)]
         lp_sums = [lp_sum, torch.zeros_like(lp_sum)]
@@ -965,7 +1001,8 @@ def main():
                 "D": D, "N": N, "batch_per_gpu": B, "global_batch": global_batch,
                 "sharding": f"regressors x{world} ({'fixed batch, contiguous blocks' if strong else 'fixed block per GPU'}), no data-path "
                             f"collective; one all-gather of {Bmax * world} doubles via "
-                            f"{'library RCCL (blr_logpdf_allgather_sum) on a side stream, overlapping the next step' if use_lib_comm else ('torch.distributed ' + backend) if dist is not None else 'nothing (one rank)'}",
+                            f"{'library RCCL (blr_logpdf_allgather_sum) on a side stream, overlapping the next step' if use_lib_comm else ('torch.distributed ' + backend) if dist is not None else 'nothing (one rank)'}"
+                            + (f" [{comm_note}]" if comm_note else ""),
             },
             "roofline": roof,
             "total_log_evidence": total_evidence,

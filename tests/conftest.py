@@ -35,7 +35,7 @@ def _free_port():
 
 
 def pytest_collection_finish(session):
-    if not any(item.name.startswith("test_bench_two_ranks") for item in session.items):
+    if not any("bench_two_rank_runs" in getattr(item, "fixturenames", ()) for item in session.items):
         return
     try:
         import torch
@@ -54,12 +54,17 @@ def pytest_collection_finish(session):
         # run BARE, the way the driver calls `python bench.py --gpus 1`: bench.py itself must spawn the two ranks
         "bare2": [sys.executable] + common + ["--gpus", "2"],
     }
+    # one rank with the exchange on the LIBRARY's RCCL binding (a one-rank communicator on a side stream), and the same with
+    # the binding's set-up forced to fail: the job must still end with its line, on the torch.distributed / local-sum path
+    runs["comm1"] = [sys.executable] + common + ["--gpus", "1"]
+    runs["commfail"] = [sys.executable] + common + ["--gpus", "1"]
+    extra = {"comm1": {"BLR_BENCH_FORCE_COMM": "1"}, "commfail": {"BLR_BENCH_FORCE_COMM": "1", "BLR_BENCH_FAIL_LIB_COMM": "1"}}
     env.pop("WORLD_SIZE", None)
     env.pop("RANK", None)
     for key, cmd in runs.items():
         out = open(os.path.join(tmp, key + ".out"), "w")
         err = open(os.path.join(tmp, key + ".err"), "w")
-        _BENCH_RUNS[key] = (subprocess.Popen(cmd, cwd=ROOT, env=env, stdout=out, stderr=err), out.name, err.name)
+        _BENCH_RUNS[key] = (subprocess.Popen(cmd, cwd=ROOT, env=dict(env, **extra.get(key, {})), stdout=out, stderr=err), out.name, err.name)
 
 
 @pytest.fixture(scope="session")
@@ -75,6 +80,7 @@ def bench_two_rank_runs():
         lines = [ln for ln in text.splitlines() if ln.startswith("{")]
         assert len(lines) == 1, f"bench ({key}) must print ONE JSON line, got {len(lines)}"
         res[key] = json.loads(lines[0])
+        res[key]["_stderr"] = open(err).read()[-4000:]
     return res
 
 

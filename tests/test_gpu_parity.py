@@ -3231,6 +3231,19 @@ def test_bench_two_ranks_bare_invocation_spawns_its_ranks(bench_two_rank_runs):
 
 
 
+@pytest.mark.gpu
+def test_bench_library_comm_and_its_fallback(bench_two_rank_runs):
+    # The evidence exchange on the library's own RCCL binding (one-rank communicator, side stream, two alternating buffers) gives
+    # the bits of the plain local sum; a binding that cannot be set up does not cost the job its line -- every rank is told (MIN of
+    # a success flag) and the exchange goes through torch.distributed / the local sum, which the line's `config.sharding` says.
+    one, comm, fail = bench_two_rank_runs["one"], bench_two_rank_runs["comm1"], bench_two_rank_runs["commfail"]
+    assert "library RCCL" in comm["config"]["sharding"] and "failed" not in comm["config"]["sharding"]
+    assert comm["total_log_evidence"] == one["total_log_evidence"]
+    assert "library RCCL binding failed" in fail["config"]["sharding"]
+    assert "library RCCL binding failed" in fail["_stderr"]
+    assert fail["n_gpus"] == 1 and fail["total_log_evidence"] == one["total_log_evidence"]
+
+
 # ---- round 6: a yardstick for the fp64-emulating route -----------------------------------------------------
 def _extended_truth(mw, dpr, X, s, y):
     """(A, mw', logpdf) of reference :55-69 / :72-89 in the direct form, evaluated in np.longdouble (x86: 64-bit mantissa, 1e-19) --
