@@ -223,7 +223,7 @@ class Handle:
         return self.lib.blr_last_route(self._h).decode()
 
     def get_stat(self, key):
-        """Counter of this handle: "i8_regressors", "i8_handed_back", "workspace_bytes" (blr_get_stat)."""
+        """Counter of this handle: "i8_regressors", "i8_handed_back", "planes_redone", "workspace_bytes" (blr_get_stat)."""
         v = _i64()
         self.check(self.lib.blr_get_stat(self._h, str(key).encode(), C.byref(v)))
         return int(v.value)

@@ -35,7 +35,7 @@ using namespace blr;
 // handle is created (BLR_MI355X_<KEY>), and settable per handle with blr_set_option: no getenv on any launch path.
 struct BlrOptions {
   bool no_ldsdma = false, no_wave_kernel = false, no_gram_ring = false, no_diag_split = false, no_xcd_swizzle = false,
-       no_mfma_project = false, plan_debug = false, no_i8_gram = false, no_marg_gemm = false, no_i8_diag = false, no_i8_factor = false, no_i8_rowvecs = false, no_grad_gemm = false, no_i8_dense = false, no_i8_fallback = false, no_bf16x3 = false, no_planes = false, no_fp16_planes = false, planes8 = false;
+       no_mfma_project = false, plan_debug = false, no_i8_gram = false, no_marg_gemm = false, no_i8_diag = false, no_i8_factor = false, no_i8_rowvecs = false, no_grad_gemm = false, no_i8_dense = false, no_i8_fallback = false, no_bf16x3 = false, no_planes = false, no_fp16_planes = false, planes8 = false, no_spec_rowmax = false;
   int wave_split = 0;     // waves per regressor of the wave kernel: 0 = router, else 1 | 2 | 4
   int chain_batch = 0;    // regressors per shared launch at D > 128: 0 = as many as the workspace holds
   int i8_probe_min = 0;   // int8 route: batches beyond this many regressors start with a probe slice; 0 = kI8ProbeMin
@@ -72,6 +72,7 @@ struct BlrOptions {
     if (!strcmp(key, "NO_I8_DENSE")) return flag(no_i8_dense);
     if (!strcmp(key, "NO_BF16X3")) return flag(no_bf16x3);
     if (!strcmp(key, "NO_PLANES")) return flag(no_planes);
+    if (!strcmp(key, "NO_SPEC_ROWMAX")) return flag(no_spec_rowmax);  // exact row maxima (one more pass over X) instead of the sampled ones
     if (!strcmp(key, "NO_FP16_PLANES")) return flag(no_fp16_planes);
     if (!strcmp(key, "PLANES8")) return flag(planes8);
     if (!strcmp(key, "NO_I8_FALLBACK")) return flag(no_i8_fallback);
@@ -122,7 +123,8 @@ struct BlrOptions {
   void from_environment() {
     // boolean flags: a variable that is set -- even to the empty string -- switches the flag on
     for (const char* k : {"NO_LDSDMA", "NO_WAVE_KERNEL", "NO_GRAM_RING", "NO_DIAG_SPLIT", "NO_XCD_SWIZZLE", "NO_MFMA_PROJECT", "PLAN_DEBUG",
-                          "NO_I8_GRAM", "NO_MARG_GEMM", "NO_GRAD_GEMM", "NO_I8_DIAG", "NO_I8_FACTOR", "NO_I8_ROWVECS", "NO_I8_DENSE", "NO_I8_FALLBACK", "NO_BF16X3"}) {
+                          "NO_I8_GRAM", "NO_MARG_GEMM", "NO_GRAD_GEMM", "NO_I8_DIAG", "NO_I8_FACTOR", "NO_I8_ROWVECS", "NO_I8_DENSE", "NO_I8_FALLBACK", "NO_BF16X3",
+                          "NO_PLANES", "NO_FP16_PLANES", "PLANES8", "NO_SPEC_ROWMAX"}) {
       const std::string name = std::string("BLR_MI355X_") + k;
       if (const char* v = getenv(name.c_str())) (void)set(k, *v ? v : "1");
     }
@@ -838,7 +840,7 @@ int posterior_large_group(blr_handle* h, const PosteriorArgs<T>& a, int64_t reg0
       const size_t nst = (size_t)(nsp + pf);
       return al((size_t)lda * DP * sizeof(T)) + al(a.prior_kind == PRIOR_DENSE ? (size_t)DP * DP * sizeof(T) : 0) +
              al(planes ? (size_t)NKB * NC * 4 * NP * 1024 : 0) +
-             al(nst * ntiles * kPB * kPB * sizeof(T)) + al(std::max<size_t>(nst, (size_t)nbchunks) * NC * kPB * sizeof(double) + (size_t)DP * sizeof(unsigned)) + al((size_t)std::max(N, 1) * sizeof(T)) +
+             al(nst * ntiles * kPB * kPB * sizeof(T)) + al(std::max<size_t>(nst, (size_t)nbchunks) * NC * kPB * sizeof(double) + (size_t)DP * sizeof(unsigned) + 8) + al((size_t)std::max(N, 1) * sizeof(T)) +
              al(a.noise_kind == NOISE_DIAGONAL ? (size_t)std::max(N, 1) * sizeof(T) : 0) + 2 * al((size_t)1024 * sizeof(double)) +
              al((size_t)DP * DP * sizeof(T)) + al(64);
     };
@@ -862,7 +864,7 @@ int posterior_large_group(blr_handle* h, const PosteriorArgs<T>& a, int64_t reg0
   const size_t o_gp = carve((size_t)gp_tiles * kPB * kPB * sizeof(T));
   // b partials, then (planes path) the rows' largest entries: both zeroed by the prior launch's scratch initialisation
   const int bslots = std::max(nsplit_total, nbchunks);
-  const size_t o_bp = carve((size_t)bslots * NC * kPB * sizeof(double) + (size_t)DP * sizeof(unsigned));
+  const size_t o_bp = carve((size_t)bslots * NC * kPB * sizeof(double) + (size_t)DP * sizeof(unsigned) + 8);  // (+ the planes pass's redo flag)
   const size_t o_r = carve((size_t)std::max(N, 1) * sizeof(T));
   const size_t o_wv = carve(a.noise_kind == NOISE_DIAGONAL ? (size_t)std::max(N, 1) * sizeof(T) : 0);  // 1 / s_n for the Gram launch
   const size_t o_q = carve((size_t)gridc * sizeof(double));
@@ -915,7 +917,7 @@ int posterior_large_group(blr_handle* h, const PosteriorArgs<T>& a, int64_t reg0
     init.words16 = reinterpret_cast<unsigned*>(ws + o_sc);
     init.ones = info_noise;
     init.zeros = bpart;
-    init.nzeros = (long long)bslots * NC * kPB + DP / 2;  // (+ the row maxima behind the b partials: DP words)
+    init.nzeros = (long long)bslots * NC * kPB + DP / 2 + 1;  // (+ the row maxima behind the b partials: DP words, + the redo flag)
     init.info_copy = dense ? nullptr : info_chol;
     const int gridp = (int)std::min<long long>(64, 1 + init.nzeros / (8 * kThreads));
     // (dense: the kernel's own look at Lw's diagonal is not the answer -- status and logdet go to spare scratch words)
@@ -1010,11 +1012,27 @@ int posterior_large_group(blr_handle* h, const PosteriorArgs<T>& a, int64_t reg0
       pa.D = D; pa.N = N; pa.NC = NC; pa.NKB = NKB; pa.nchunks = nbchunks;
       pa.grp_X = a.strideX; pa.grp_ws = wsb;
       const size_t plds = (size_t)(2 * 16 * kPlanesChunkKb + (rff ? a.rff_Din * 16 : 0)) * sizeof(float);
-      if (NP == 2) {  // the rows' power-of-two scales need the rows' largest entries first: one more pass over X (a basis: its bound)
-        if (rff) hipLaunchKernelGGL(rowmax_kernel<true>, dim3(nbchunks, 1, G), dim3(kThreads), 0, h->stream, pa);
-        else hipLaunchKernelGGL(rowmax_kernel<false>, dim3(nbchunks, NC, G), dim3(kThreads), 0, h->stream, pa);
-        if (rff) hipLaunchKernelGGL((planes_kernel<2, true>), dim3(nbchunks, NC, G), dim3(kThreads), plds, h->stream, pa);
-        else hipLaunchKernelGGL((planes_kernel<2, false>), dim3(nbchunks, NC, G), dim3(kThreads), plds, h->stream, pa);
+      if (NP == 2) {  // the rows' power-of-two scales need (a bound of) the rows' largest entries first
+        if (rff) {  // a basis: its bound
+          hipLaunchKernelGGL(rowmax_kernel<true>, dim3(nbchunks, 1, G), dim3(kThreads), 0, h->stream, pa);
+          hipLaunchKernelGGL((planes_kernel<2, true>), dim3(nbchunks, NC, G), dim3(kThreads), plds, h->stream, pa);
+        } else if (h->opt.no_spec_rowmax) {  // the exact maxima: one more pass over X
+          hipLaunchKernelGGL(rowmax_kernel<false>, dim3(nbchunks, NC, G), dim3(kThreads), 0, h->stream, pa);
+          hipLaunchKernelGGL((planes_kernel<2, false>), dim3(nbchunks, NC, G), dim3(kThreads), plds, h->stream, pa);
+        } else {
+          // sampled maxima with head-room, the planes pass checks that every entry fits; the exact pass + the planes again only if one
+          // did not (two launches that return at once otherwise: ~ 5 us against the 58 us of the exact pass at config 3)
+          if ((rc = ensure_stats(h))) return rc;
+          pa.redo = rowmax + DP;
+          pa.redo_total = h->stats_dev + 1;
+          pa.sample_kb = 2;
+          hipLaunchKernelGGL(rowmax_kernel<false>, dim3(nbchunks, NC, G), dim3(kThreads), 0, h->stream, pa);
+          hipLaunchKernelGGL((planes_kernel<2, false>), dim3(nbchunks, NC, G), dim3(kThreads), plds, h->stream, pa);
+          pa.sample_kb = 0;
+          pa.redo_pass = 1;
+          hipLaunchKernelGGL(rowmax_kernel<false>, dim3(nbchunks, NC, G), dim3(kThreads), 0, h->stream, pa);
+          hipLaunchKernelGGL((planes_kernel<2, false>), dim3(nbchunks, NC, G), dim3(kThreads), plds, h->stream, pa);
+        }
       } else {
         if (rff) hipLaunchKernelGGL((planes_kernel<3, true>), dim3(nbchunks, NC, G), dim3(kThreads), plds, h->stream, pa);
         else hipLaunchKernelGGL((planes_kernel<3, false>), dim3(nbchunks, NC, G), dim3(kThreads), plds, h->stream, pa);
@@ -3198,6 +3216,16 @@ int blr_get_stat(blr_handle* h, const char* key, int64_t* value) {
     *value = (int64_t)v;
     return 0;
   }
+  if (!strcmp(key, "planes_redone")) {  // large-D fp32 updates whose sampled row scales did not hold: exact row maxima + planes made again
+    unsigned long long v = 0;
+    if (h->stats_dev) {
+      HIP_TRY(h, hipSetDevice(h->device));
+      HIP_TRY(h, hipMemcpyAsync(&v, h->stats_dev + 1, sizeof(v), hipMemcpyDeviceToHost, h->stream));
+      HIP_TRY(h, hipStreamSynchronize(h->stream));
+    }
+    *value = (int64_t)v;
+    return 0;
+  }
   if (!strcmp(key, "workspace_bytes")) { *value = (int64_t)(h->ws_bytes + h->feat_bytes + h->aux_bytes + h->i8side_bytes + h->xchg_bytes); return 0; }
   return bad_arg(h, 2, "unknown statistic");
 }
@@ -3206,7 +3234,7 @@ int blr_reset_stats(blr_handle* h) {
   h->err.clear();
   if (h->stats_dev) {  // (device counter first: a failure must not leave the two counters apart)
     HIP_TRY(h, hipSetDevice(h->device));
-    HIP_TRY(h, hipMemsetAsync(h->stats_dev, 0, 3 * sizeof(unsigned long long), h->stream));  // (total, spare, the last call's base)
+    HIP_TRY(h, hipMemsetAsync(h->stats_dev, 0, 3 * sizeof(unsigned long long), h->stream));  // (total, planes made twice, the last call's base)
   }
   h->i8_attempted = 0;
   return 0;

@@ -78,6 +78,16 @@ struct PlanesArgs {
   unsigned* rowmax;     // NP = 2: [DP] bit patterns of the rows' largest |z| (rowmax_kernel; a basis: |scale| max_n sqrt(w_n))
   int D, N, NC, NKB, nchunks;
   int64_t grp_X, grp_ws;  // blockIdx.z = regressor of a group: element stride of X, byte stride of wsq / r / Xp / bpart / rowmax
+  // Speculative row scales (NP = 2, source 0).  The exact row maxima cost a pass over X of their own (58 us of config 3's 0.58 ms).
+  // Instead: rowmax_kernel looks at the first `sample_kb` k-blocks of every column chunk only and stores TWICE what it finds (head-room:
+  // the scale then puts the sample's largest entry into [2^11, 2^12), an entry of up to 16 x the sample's largest still is a finite fp16
+  // number); planes_kernel raises `redo` when an entry does not fit all the same; the SECOND pair of launches (redo_pass = 1: the exact
+  // row maxima over all columns, then the planes again) returns at once unless it is raised.  Gaussian rows: the largest of 65536 entries
+  // is 1.3 x the largest of 2048; Student-t(3): 3 x.  Either way the result is a deterministic function of the inputs.
+  int sample_kb;     // rowmax_kernel: k-blocks per chunk it reads (0: all of them)
+  int redo_pass;     // 1: this launch runs only if *redo != 0
+  unsigned* redo;    // [1] raised by planes_kernel (zeroed with rowmax by the launch before); NULL: exact row maxima, no check
+  unsigned long long* redo_total;  // cumulative count of regressors whose planes were made twice (blr_get_stat "planes_redone"), or NULL
 };
 
 __device__ __forceinline__ float rff_feature(const PlanesArgs& a, const float* __restrict__ om /* Omega_f */, float ph, const float* __restrict__ xs /* LDS: [Din][16] */,
@@ -97,9 +107,12 @@ __global__ __launch_bounds__(kThreads) void rowmax_kernel(PlanesArgs a) {
   if (const int64_t g = blockIdx.z) {
     if (!RFF) a.X += g * a.grp_X;
     a.wsq = ws_shift(a.wsq, g * a.grp_ws); a.rowmax = ws_shift(a.rowmax, g * a.grp_ws);
+    if (a.redo) a.redo = ws_shift(a.redo, g * a.grp_ws);
   }
+  if (a.redo_pass && *a.redo == 0u) return;  // (uniform over the regressor's workgroups)
   const int per = (a.NKB + a.nchunks - 1) / a.nchunks;
-  const int n0 = 16 * blockIdx.x * per, n1 = min(a.N, 16 * min(a.NKB, (int)(blockIdx.x + 1) * per));
+  const int n0 = 16 * blockIdx.x * per;
+  const int n1 = min(a.N, 16 * min(a.NKB, (int)blockIdx.x * per + (a.sample_kb > 0 ? min(per, a.sample_kb) : per)));
   if constexpr (RFF) {  // |phi| <= |scale|: the bound is |scale| times the largest weight, the same for every row
     if (blockIdx.y != 0) return;
     __shared__ float red[kWaves];
@@ -125,6 +138,7 @@ __global__ __launch_bounds__(kThreads) void rowmax_kernel(PlanesArgs a) {
 #pragma unroll
       for (int u = 0; u < 16; ++u) m = fmaxf(m, fabsf(v[u]));
     }
+    if (a.sample_kb > 0) m *= 2.f;  // head-room of a sampled maximum (an Inf stays an Inf: the planes pass then asks for the exact pass)
     atomicMax(&a.rowmax[row], __float_as_uint(m));  // (a NaN entry: fmaxf drops it; the planes keep it, the factorisation reports it)
   }
 }
@@ -141,7 +155,11 @@ __global__ __launch_bounds__(kThreads) void planes_kernel(PlanesArgs a) {
     if (!RFF) a.X += g * a.grp_X;
     a.wsq = ws_shift(a.wsq, g * a.grp_ws); a.r = ws_shift(a.r, g * a.grp_ws); a.Xp = ws_shift(a.Xp, g * a.grp_ws);
     a.bpart = ws_shift(a.bpart, g * a.grp_ws); a.rowmax = ws_shift(a.rowmax, g * a.grp_ws);
+    if (a.redo) a.redo = ws_shift(a.redo, g * a.grp_ws);
   }
+  if (a.redo_pass && *a.redo == 0u) return;  // (uniform over the regressor's workgroups; nobody of this launch writes the flag)
+  const bool check = NP == 2 && !RFF && a.redo != nullptr && !a.redo_pass;
+  bool over = false;
   const int per = (a.NKB + a.nchunks - 1) / a.nchunks;  // (<= kPlanesChunkKb: the host sizes nchunks)
   const int kb0 = blockIdx.x * per, kb1 = min(a.NKB, kb0 + per);
   const int r32 = lane & 31, kh = lane >> 5;
@@ -220,6 +238,7 @@ __global__ __launch_bounds__(kThreads) void planes_kernel(PlanesArgs a) {
 #pragma unroll
       for (int q = 0; q < 4; ++q) {
         const float u = z[2 * q] * down, v = z[2 * q + 1] * down;   // (exact: a power of two)
+        over = over || fmaxf(fabsf(u), fabsf(v)) > 65504.f;         // beyond the largest finite fp16 number (speculative scale only)
         const _Float16 hu = (_Float16)u, hv = (_Float16)v;          // round to nearest even
         const _Float16 lu = (_Float16)(u - (float)hu), lv = (_Float16)(v - (float)hv);
         const gram_h2 hp = {hu, hv}, lp = {lu, lv};
@@ -227,6 +246,9 @@ __global__ __launch_bounds__(kThreads) void planes_kernel(PlanesArgs a) {
       }
       dst[0] = H; dst[64] = L;
     }
+  }
+  if (check && __any(over) && lane == 0) {
+    if (atomicOr(a.redo, 1u) == 0u && a.redo_total) atomicAdd(a.redo_total, 1ull);  // (the one thread that raises it counts the regressor)
   }
   if (a.bpart) {
     bacc += __shfl_xor(bacc, 32);  // the two column halves of a row

@@ -75,7 +75,7 @@ int blr_reset_stream(blr_handle* h);              /* back to the handle's own (n
 int blr_set_async(blr_handle* h, int async);      /* 1: DEVICE-memspace calls return after enqueue       */
 int blr_synchronize(blr_handle* h);
 /* Run-time switches of the handle (A/B measurements and tests; the defaults are the measured best).  `key` is one of NO_LDSDMA,
- * NO_WAVE_KERNEL, NO_GRAM_RING, NO_DIAG_SPLIT, NO_XCD_SWIZZLE, NO_MFMA_PROJECT, NO_I8_GRAM, NO_I8_DIAG, NO_I8_FACTOR, NO_I8_ROWVECS, NO_I8_DENSE, NO_I8_FALLBACK, NO_BF16X3, NO_PLANES, NO_FP16_PLANES, PLANES8, NO_MARG_GEMM, NO_GRAD_GEMM, PLAN_DEBUG (flags: any non-empty value = on),
+ * NO_WAVE_KERNEL, NO_GRAM_RING, NO_DIAG_SPLIT, NO_XCD_SWIZZLE, NO_MFMA_PROJECT, NO_I8_GRAM, NO_I8_DIAG, NO_I8_FACTOR, NO_I8_ROWVECS, NO_I8_DENSE, NO_I8_FALLBACK, NO_BF16X3, NO_PLANES, NO_FP16_PLANES, PLANES8, NO_SPEC_ROWMAX, NO_MARG_GEMM, NO_GRAD_GEMM, PLAN_DEBUG (flags: any non-empty value = on),
  * WAVE_SPLIT = 1|2|4, CHAIN_BATCH = 1..128, CHAIN_WS_MB, I8_PROBE_MIN = 256..2^20, I8_GROUPS = 6|7, SWEEP = always|never|auto, GRAM_SPLITS = "o,d[,nlong]" (README.md);
  * a "BLR_MI355X_" prefix is accepted.  value NULL or "" restores the built-in default.  The environment variables
  * BLR_MI355X_<KEY> are read ONCE, by blr_create -- no entry point reads the environment.  -> 0, or -2 / -3 (unknown key /
@@ -92,7 +92,11 @@ const char* blr_last_route(blr_handle* h);
 /* Counters of the handle since blr_create / blr_reset_stats.  key: "i8_regressors" = regressors sent down the int8-sliced Gram route
  * (blr_posterior_batched_f64 above); "i8_handed_back" = those of them that route could not finish (rows outgrowing their scale
  * beyond what it corrects in place, non-finite inputs) and the fp64 kernel redid inside the same call -- each of these cost two
- * passes over its data (reading it synchronises the handle's stream); "workspace_bytes" = device scratch the handle holds now.
+ * passes over its data (reading it synchronises the handle's stream); "planes_redone" = fp32 updates at D > 128 (ColVecs) whose
+ * SAMPLED row scales did not hold -- the operand planes of the Gram product are scaled per row by a power of two taken from the first 32
+ * columns of every column chunk (doubled: an entry up to 16 x the sample's largest still fits); an entry beyond that sends the call
+ * through the exact row maxima and the planes pass a second time (one more read of X; option NO_SPEC_ROWMAX = 1 always takes the exact
+ * maxima: one more read of X on every call); "workspace_bytes" = device scratch the handle holds now.
  * -> 0, -2 unknown key, -3 NULL value. */
 int blr_get_stat(blr_handle* h, const char* key, int64_t* value);
 int blr_reset_stats(blr_handle* h);

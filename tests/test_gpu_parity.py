@@ -3022,6 +3022,71 @@ def test_large_d_fp32_gram_on_bf16_matrix_cores_vs_f32_route(B, opt, noise):
         assert e[1] <= 2e-5 and e[2] <= 2e-4
 
 
+def test_large_d_fp32_sampled_row_scales_and_their_exact_second_pass(B, opt):
+    # Round 6: the row scales of the fp16 planes come from a SAMPLE of each row (the first 32 columns of every column chunk, doubled for
+    # head-room) instead of a pass over X of its own; the planes pass checks that every entry still is a finite fp16 number and, when one
+    # is not, the exact row maxima + the planes are made again (blr_planes.hpp; blr_get_stat "planes_redone").  (a) ordinary data: no
+    # second pass, as good as the exact scales (option NO_SPEC_ROWMAX); (b) one entry 4000 x its row's other entries, in a column the
+    # sample does not see: the second pass runs -- once, for that regressor -- and the result is as good as with exact scales; (c) an Inf
+    # in the same place: info != 0 / NaN evidence either way, as before.
+    a = B._abi
+    h = a.default_handle()
+    rng = _rng(6161)
+    D, N = 256, 32768   # 2 row blocks, 256 column chunks of 128 columns: the sample is columns 0 .. 31 of each
+    X0 = np.asfortranarray(rng.standard_normal((D, N)).astype(np.float32))
+    s = np.full(1, 0.5, dtype=np.float32)
+    w0 = rng.standard_normal(D) / np.sqrt(D)
+    mw = np.zeros(D, dtype=np.float32)
+    dvec = np.ones(D, dtype=np.float32)
+
+    def run(X, y):
+        mwp = np.zeros(D, dtype=np.float32); Tp = np.zeros((D, D), dtype=np.float32, order="F"); Ap = np.zeros((D, D), dtype=np.float32, order="F")
+        lp = np.zeros(1); info = np.zeros(1, dtype=np.int32)
+        h.posterior_batched(np.float32, a.MEM_HOST, a.LAYOUT_COLVECS, 1, D, N, X, D, N * D, y, N, a.NOISE_ISOTROPIC, s, 0,
+                            a.PRIOR_DIAGONAL, mw, 0, dvec, 1, 0, mwp, D, Tp, D, D * D, Ap, D, D * D, lp, info)
+        return mwp, Ap, lp[0], info[0]
+
+    def case(X):
+        y = (X.astype(float).T @ w0 + np.sqrt(0.5) * rng.standard_normal(N)).astype(np.float32)
+        mw_o, T_o, A_o, lp_o = O.posterior_logpdf_direct(mw.astype(float), dvec.astype(float), X.astype(float), 0.5, y.astype(float))
+        h.reset_stats()
+        m1, A1, l1, i1 = run(X, y)
+        assert h.last_route() == "gram_planes4_kernel" and i1 == 0
+        redone = h.get_stat("planes_redone")
+        m1b, A1b, l1b, _ = run(X, y)
+        assert np.array_equal(A1, A1b) and np.array_equal(m1, m1b) and l1 == l1b   # same inputs, same bits
+        opt("NO_SPEC_ROWMAX", "1")
+        m2, A2, l2, i2 = run(X, y)
+        opt("NO_SPEC_ROWMAX", None)
+        assert i2 == 0
+        return redone, _rel_errs(m1, A1, l1, mw_o, A_o, lp_o), _rel_errs(m2, A2, l2, mw_o, A_o, lp_o)
+
+    redone, e_s, e_x = case(X0)
+    print(f"sampled row scales, gaussian rows: second pass ran {redone} x; rel err (mw', A, logpdf) sampled {e_s}  exact {e_x}")
+    assert redone == 0
+    assert e_s[1] <= 2 * e_x[1] + 5e-8 and e_s[0] <= 2 * e_x[0] + 1e-6 and e_s[2] <= 2 * e_x[2] + 1e-7, (e_s, e_x)
+    Xm = X0.copy(order="F")
+    Xm[200, 100] = 25.0     # 6 x the row's other entries, unseen by the sample: inside the head-room, a scale two binades off the exact one
+    redone, e_s, e_x = case(Xm)
+    print(f"sampled row scales, one entry 6 x its row: second pass ran {redone} x; rel err sampled {e_s}  exact {e_x}")
+    assert redone == 0
+    assert e_s[1] <= 2 * e_x[1] + 5e-8 and e_s[0] <= 2 * e_x[0] + 1e-6 and e_s[2] <= 2 * e_x[2] + 1e-7, (e_s, e_x)
+    X1 = X0.copy(order="F")
+    X1[200, 100] = 4000.0   # row 200 (second row block), column 100: chunk 0, beyond its first 32 columns
+    redone, e_s, e_x = case(X1)
+    print(f"sampled row scales, one entry 4000 x its row: second pass ran {redone} x; rel err sampled {e_s}  exact {e_x}")
+    assert redone == 1
+    assert e_s[1] <= 2 * e_x[1] + 5e-8 and e_s[0] <= 2 * e_x[0] + 1e-6 and e_s[2] <= 2 * e_x[2] + 1e-7, (e_s, e_x)
+    X2 = X0.copy(order="F")
+    X2[200, 100] = np.inf
+    y = (X0.astype(float).T @ w0).astype(np.float32)
+    for o in (None, "1"):
+        opt("NO_SPEC_ROWMAX", o)
+        _, _, lp, info = run(X2, y)
+        assert info != 0 or not np.isfinite(lp)
+    opt("NO_SPEC_ROWMAX", None)
+
+
 @pytest.mark.parametrize("nb", [8192, 1024])
 def test_c4_at_its_stated_batch_vs_literal_oracle(B, nb):
     # BASELINE config 4 exactly as stated -- 8192 x (D = 64, N = 1024), fp64, isotropic noise, Lw = I -- and the 1024-regressor
