@@ -35,7 +35,7 @@ using namespace blr;
 // handle is created (BLR_MI355X_<KEY>), and settable per handle with blr_set_option: no getenv on any launch path.
 struct BlrOptions {
   bool no_ldsdma = false, no_wave_kernel = false, no_gram_ring = false, no_diag_split = false, no_xcd_swizzle = false,
-       no_mfma_project = false, plan_debug = false, no_i8_gram = false, no_marg_gemm = false, no_i8_diag = false, no_i8_factor = false, no_i8_rowvecs = false, no_grad_gemm = false, no_i8_dense = false, no_i8_fallback = false, no_bf16x3 = false, no_planes = false, no_fp16_planes = false, planes8 = false, no_spec_rowmax = false;
+       no_mfma_project = false, plan_debug = false, no_i8_gram = false, no_marg_gemm = false, no_i8_diag = false, no_i8_factor = false, no_i8_rowvecs = false, no_grad_gemm = false, no_i8_dense = false, no_i8_fallback = false, no_bf16x3 = false, no_planes = false, no_fp16_planes = false, planes8 = false, no_spec_rowmax = false, no_multi_planes = false;
   int wave_split = 0;     // waves per regressor of the wave kernel: 0 = router, else 1 | 2 | 4
   int chain_batch = 0;    // regressors per shared launch at D > 128: 0 = as many as the workspace holds
   int i8_probe_min = 0;   // int8 route: batches beyond this many regressors start with a probe slice; 0 = kI8ProbeMin
@@ -72,6 +72,7 @@ struct BlrOptions {
     if (!strcmp(key, "NO_I8_DENSE")) return flag(no_i8_dense);
     if (!strcmp(key, "NO_BF16X3")) return flag(no_bf16x3);
     if (!strcmp(key, "NO_PLANES")) return flag(no_planes);
+    if (!strcmp(key, "NO_MULTI_PLANES")) return flag(no_multi_planes);  // logpdf_multi at D > 128, fp32: the separate residual product + panel sweep
     if (!strcmp(key, "NO_SPEC_ROWMAX")) return flag(no_spec_rowmax);  // exact row maxima (one more pass over X) instead of the sampled ones
     if (!strcmp(key, "NO_FP16_PLANES")) return flag(no_fp16_planes);
     if (!strcmp(key, "PLANES8")) return flag(planes8);
@@ -124,7 +125,7 @@ struct BlrOptions {
     // boolean flags: a variable that is set -- even to the empty string -- switches the flag on
     for (const char* k : {"NO_LDSDMA", "NO_WAVE_KERNEL", "NO_GRAM_RING", "NO_DIAG_SPLIT", "NO_XCD_SWIZZLE", "NO_MFMA_PROJECT", "PLAN_DEBUG",
                           "NO_I8_GRAM", "NO_MARG_GEMM", "NO_GRAD_GEMM", "NO_I8_DIAG", "NO_I8_FACTOR", "NO_I8_ROWVECS", "NO_I8_DENSE", "NO_I8_FALLBACK", "NO_BF16X3",
-                          "NO_PLANES", "NO_FP16_PLANES", "PLANES8", "NO_SPEC_ROWMAX"}) {
+                          "NO_PLANES", "NO_FP16_PLANES", "PLANES8", "NO_SPEC_ROWMAX", "NO_MULTI_PLANES"}) {
       const std::string name = std::string("BLR_MI355X_") + k;
       if (const char* v = getenv(name.c_str())) (void)set(k, *v ? v : "1");
     }
@@ -163,6 +164,10 @@ struct blr_handle {
   const char* route = "none";            // kernel family the most recent posterior dispatch launched (blr_last_route)
   struct RffSrc { const void *Xin, *Omega, *phase; int64_t ldxin, ldo; double scale; int Din; };
   const RffSrc* rff_src = nullptr;       // set by posterior_rff around its posterior_batched call: the basis is evaluated inside the planes pass
+  // set by logpdf_multi around its update of column 0 (fp32, ColVecs, D > 128, S <= 128): the other columns of Y ride through the SAME
+  // planes pass, Gram launch and factorisation as one more row block (blr_planes.hpp); the group function leaves what the finish needs
+  struct MultiSrc { const void* Y; int64_t ldY; int S; void* Abar; int64_t lda; void* Tfull; int DP; double* qsp; int nq; bool done; };
+  MultiSrc* multi_src = nullptr;
   int64_t route_i8_B = 0;                // > 0: that dispatch took the int8 route with this many regressors (blr_last_route looks at its hand-backs)
   std::string route_buf;
   // wavefront back substitution (D > 128): tagged exchange buffer, start-order ticket counter, launch epoch
@@ -732,6 +737,12 @@ int posterior_large_group(blr_handle* h, const PosteriorArgs<T>& a, int64_t reg0
   const int DP = (D + kPB - 1) / kPB * kPB, NC = DP / kPB;
   const int64_t lda = DP + kPB;
   const int ntiles = NC * (NC + 1) / 2;
+  // multi-output evidence: one more row block of operand planes (the residuals of Y's columns), its macro tiles in the Gram launch
+  blr_handle::MultiSrc* const ms = h->multi_src;
+  if (ms && !(planes && !rff && !h->opt.no_fp16_planes && G == 1 && a.prior_kind != PRIOR_UPPER_FACTOR && ms->S >= 1 && ms->S <= kPB))
+    return hip_fail(h, hipErrorInvalidValue, "multi-output rows need the fp16 planes path (internal)");
+  const int NCA = NC + (ms ? 1 : 0), DPA = NCA * kPB;
+  const int ntiles_g = NCA * (NCA + 1) / 2;
   const int nstage_cols = LC::NSC;
   // The split plan depends on how many regressors share the launch -- and the workspace one regressor needs depends on the
   // plan.  Plan for the requested group first, clamp the group to the workspace bound, then plan AGAIN for the group that will
@@ -820,7 +831,7 @@ int posterior_large_group(blr_handle* h, const PosteriorArgs<T>& a, int64_t reg0
     double best = 1e300;
     const int slots = h->cus * (planes4 ? 2 : 1);
     for (int sp = 1; sp <= std::min(64, std::max(1, NKB)); ++sp) {
-      const int rounds = (ntiles * sp * G + slots - 1) / slots;
+      const int rounds = (ntiles_g * sp * G + slots - 1) / slots;
       const double cost = (double)rounds * (16.0 * ((NKB + sp - 1) / sp) + 192.0);  // (192: a workgroup's pipeline fill and its 64 KB partial tile, in columns)
       if (cost < best) { best = cost; nsplit = sp; }
     }
@@ -839,8 +850,9 @@ int posterior_large_group(blr_handle* h, const PosteriorArgs<T>& a, int64_t reg0
     auto per_for = [&](int nsp) {  // the carve below, as a function of the split factor
       const size_t nst = (size_t)(nsp + pf);
       return al((size_t)lda * DP * sizeof(T)) + al(a.prior_kind == PRIOR_DENSE ? (size_t)DP * DP * sizeof(T) : 0) +
-             al(planes ? (size_t)NKB * NC * 4 * NP * 1024 : 0) +
-             al(nst * ntiles * kPB * kPB * sizeof(T)) + al(std::max<size_t>(nst, (size_t)nbchunks) * NC * kPB * sizeof(double) + (size_t)DP * sizeof(unsigned) + 8) + al((size_t)std::max(N, 1) * sizeof(T)) +
+             al(planes ? (size_t)NKB * NCA * 4 * NP * 1024 : 0) +
+             al(nst * ntiles_g * kPB * kPB * sizeof(T)) + al(std::max<size_t>(nst, (size_t)nbchunks) * NCA * kPB * sizeof(double) + (size_t)DPA * sizeof(unsigned) + 8) + al((size_t)std::max(N, 1) * sizeof(T)) +
+             (ms ? al((size_t)std::max(N, 1) * sizeof(T)) + al((size_t)nbchunks * kPB * sizeof(double)) : 0) +
              al(a.noise_kind == NOISE_DIAGONAL ? (size_t)std::max(N, 1) * sizeof(T) : 0) + 2 * al((size_t)1024 * sizeof(double)) +
              al((size_t)DP * DP * sizeof(T)) + al(64);
     };
@@ -853,18 +865,20 @@ int posterior_large_group(blr_handle* h, const PosteriorArgs<T>& a, int64_t reg0
   const int nsplit_total = nsplit + pf;  // (nsplit_diag <= nsplit: the partial workspace is laid out for the larger factor)
   const int gridc = 1024;
 
-  const int64_t gp_tiles = (int64_t)nsplit_total * ntiles;
+  const int64_t gp_tiles = (int64_t)nsplit_total * ntiles_g;
 
   // workspace carve
   size_t off = 0;
   auto carve = [&](size_t bytes) { size_t o = off; off = (off + bytes + 255) & ~(size_t)255; return o; };
   const size_t o_abar = carve((size_t)lda * DP * sizeof(T));
   const size_t o_w = carve(a.prior_kind == PRIOR_DENSE ? (size_t)DP * DP * sizeof(T) : 0);
-  const size_t o_xp = carve(planes ? (size_t)NKB * NC * 4 * NP * 1024 : 0);
+  const size_t o_xp = carve(planes ? (size_t)NKB * NCA * 4 * NP * 1024 : 0);
   const size_t o_gp = carve((size_t)gp_tiles * kPB * kPB * sizeof(T));
   // b partials, then (planes path) the rows' largest entries: both zeroed by the prior launch's scratch initialisation
   const int bslots = std::max(nsplit_total, nbchunks);
-  const size_t o_bp = carve((size_t)bslots * NC * kPB * sizeof(double) + (size_t)DP * sizeof(unsigned) + 8);  // (+ the planes pass's redo flag)
+  const size_t o_bp = carve((size_t)bslots * NCA * kPB * sizeof(double) + (size_t)DPA * sizeof(unsigned) + 8);  // (+ the planes pass's redo flag)
+  const size_t o_mu = carve(ms ? (size_t)std::max(N, 1) * sizeof(T) : 0);           // multi-output: x_n'mw
+  const size_t o_qs = carve(ms ? (size_t)nbchunks * kPB * sizeof(double) : 0);      // multi-output: partial sums of q_s per column chunk
   const size_t o_r = carve((size_t)std::max(N, 1) * sizeof(T));
   const size_t o_wv = carve(a.noise_kind == NOISE_DIAGONAL ? (size_t)std::max(N, 1) * sizeof(T) : 0);  // 1 / s_n for the Gram launch
   const size_t o_q = carve((size_t)gridc * sizeof(double));
@@ -917,7 +931,7 @@ int posterior_large_group(blr_handle* h, const PosteriorArgs<T>& a, int64_t reg0
     init.words16 = reinterpret_cast<unsigned*>(ws + o_sc);
     init.ones = info_noise;
     init.zeros = bpart;
-    init.nzeros = (long long)bslots * NC * kPB + DP / 2 + 1;  // (+ the row maxima behind the b partials: DP words, + the redo flag)
+    init.nzeros = (long long)bslots * NCA * kPB + DPA / 2 + 1;  // (+ the row maxima behind the b partials: DP words, + the redo flag)
     init.info_copy = dense ? nullptr : info_chol;
     const int gridp = (int)std::min<long long>(64, 1 + init.nzeros / (8 * kThreads));
     // (dense: the kernel's own look at Lw's diagonal is not the answer -- status and logdet go to spare scratch words)
@@ -940,6 +954,7 @@ int posterior_large_group(blr_handle* h, const PosteriorArgs<T>& a, int64_t reg0
     c.layout = a.layout; c.noise_kind = a.noise_kind; c.D = D; c.N = N;
     c.grp_X = a.strideX; c.grp_y = a.stridey; c.grp_s = a.strides; c.grp_mw = a.stridemw; c.grp_ws = wsb;
     c.w_sqrt = planes ? 1 : 0;
+    c.mu = ms ? reinterpret_cast<T*>(ws + o_mu) : nullptr;
     if (rff) {
       c.X = nullptr;
       c.rff_Xin = a.rff_Xin; c.rff_ldxin = a.rff_ldxin; c.rff_Omega = a.rff_Omega; c.rff_ldo = a.rff_ldo; c.rff_phase = a.rff_phase;
@@ -1004,50 +1019,56 @@ int posterior_large_group(blr_handle* h, const PosteriorArgs<T>& a, int64_t reg0
       if ((rc = set_lds_once(h, reinterpret_cast<const void*>(gram_planes_kernel<2>), (size_t)PlanesCfg<2>::LDS))) return rc;
       if ((rc = set_lds_once(h, reinterpret_cast<const void*>(gram_planes_kernel<3>), (size_t)PlanesCfg<3>::LDS))) return rc;
       unsigned short* Xp = reinterpret_cast<unsigned short*>(ws + o_xp);
-      unsigned* rowmax = reinterpret_cast<unsigned*>(bpart + (int64_t)bslots * NC * kPB);
+      unsigned* rowmax = reinterpret_cast<unsigned*>(bpart + (int64_t)bslots * NCA * kPB);
       PlanesArgs pa{};
       pa.X = rff ? nullptr : X; pa.ldx = a.ldx;
       pa.Xin = a.rff_Xin; pa.ldxin = a.rff_ldxin; pa.Omega = a.rff_Omega; pa.ldo = a.rff_ldo; pa.phase = a.rff_phase; pa.scale = a.rff_scale; pa.Din = a.rff_Din;
       pa.wsq = wvec; pa.r = rvec; pa.Xp = Xp; pa.bpart = bpart; pa.rowmax = rowmax;
-      pa.D = D; pa.N = N; pa.NC = NC; pa.NKB = NKB; pa.nchunks = nbchunks;
+      pa.D = D; pa.N = N; pa.NC = NCA; pa.NKB = NKB; pa.nchunks = nbchunks;
       pa.grp_X = a.strideX; pa.grp_ws = wsb;
-      const size_t plds = (size_t)(2 * 16 * kPlanesChunkKb + (rff ? a.rff_Din * 16 : 0)) * sizeof(float);
+      if constexpr (sizeof(T) == 4) {
+        if (ms) {
+          pa.Y = static_cast<const float*>(ms->Y); pa.ldY = ms->ldY; pa.S = ms->S;
+          pa.mu = reinterpret_cast<const float*>(ws + o_mu); pa.qsp = reinterpret_cast<double*>(ws + o_qs);
+        }
+      }
+      const size_t plds = (size_t)(3 * 16 * kPlanesChunkKb + (rff ? a.rff_Din * 16 : 0)) * sizeof(float);
       if (NP == 2) {  // the rows' power-of-two scales need (a bound of) the rows' largest entries first
         if (rff) {  // a basis: its bound
           hipLaunchKernelGGL(rowmax_kernel<true>, dim3(nbchunks, 1, G), dim3(kThreads), 0, h->stream, pa);
           hipLaunchKernelGGL((planes_kernel<2, true>), dim3(nbchunks, NC, G), dim3(kThreads), plds, h->stream, pa);
         } else if (h->opt.no_spec_rowmax) {  // the exact maxima: one more pass over X
-          hipLaunchKernelGGL(rowmax_kernel<false>, dim3(nbchunks, NC, G), dim3(kThreads), 0, h->stream, pa);
-          hipLaunchKernelGGL((planes_kernel<2, false>), dim3(nbchunks, NC, G), dim3(kThreads), plds, h->stream, pa);
+          hipLaunchKernelGGL(rowmax_kernel<false>, dim3(nbchunks, NCA, G), dim3(kThreads), 0, h->stream, pa);
+          hipLaunchKernelGGL((planes_kernel<2, false>), dim3(nbchunks, NCA, G), dim3(kThreads), plds, h->stream, pa);
         } else {
           // sampled maxima with head-room, the planes pass checks that every entry fits; the exact pass + the planes again only if one
           // did not (two launches that return at once otherwise: ~ 5 us against the 58 us of the exact pass at config 3)
           if ((rc = ensure_stats(h))) return rc;
-          pa.redo = rowmax + DP;
+          pa.redo = rowmax + DPA;
           pa.redo_total = h->stats_dev + 1;
           pa.sample_kb = 2;
-          hipLaunchKernelGGL(rowmax_kernel<false>, dim3(nbchunks, NC, G), dim3(kThreads), 0, h->stream, pa);
-          hipLaunchKernelGGL((planes_kernel<2, false>), dim3(nbchunks, NC, G), dim3(kThreads), plds, h->stream, pa);
+          hipLaunchKernelGGL(rowmax_kernel<false>, dim3(nbchunks, NCA, G), dim3(kThreads), 0, h->stream, pa);
+          hipLaunchKernelGGL((planes_kernel<2, false>), dim3(nbchunks, NCA, G), dim3(kThreads), plds, h->stream, pa);
           pa.sample_kb = 0;
           pa.redo_pass = 1;
-          hipLaunchKernelGGL(rowmax_kernel<false>, dim3(nbchunks, NC, G), dim3(kThreads), 0, h->stream, pa);
-          hipLaunchKernelGGL((planes_kernel<2, false>), dim3(nbchunks, NC, G), dim3(kThreads), plds, h->stream, pa);
+          hipLaunchKernelGGL(rowmax_kernel<false>, dim3(nbchunks, NCA, G), dim3(kThreads), 0, h->stream, pa);
+          hipLaunchKernelGGL((planes_kernel<2, false>), dim3(nbchunks, NCA, G), dim3(kThreads), plds, h->stream, pa);
         }
       } else {
         if (rff) hipLaunchKernelGGL((planes_kernel<3, true>), dim3(nbchunks, NC, G), dim3(kThreads), plds, h->stream, pa);
         else hipLaunchKernelGGL((planes_kernel<3, false>), dim3(nbchunks, NC, G), dim3(kThreads), plds, h->stream, pa);
       }
       GramPlanesArgs ga{};
-      ga.Xp = Xp; ga.NC = NC; ga.NKB = NKB; ga.Gpart = Gpart; ga.ntiles = ntiles; ga.nsplit = nsplit;
+      ga.Xp = Xp; ga.NC = NCA; ga.NKB = NKB; ga.Gpart = Gpart; ga.ntiles = ntiles_g; ga.nsplit = nsplit;
       ga.s_iso = a.noise_kind == NOISE_DIAGONAL ? nullptr : s;
       ga.rowmax = rowmax;
       ga.xcd_swizzle = (nsplit > 1 && !no_swizzle) ? 1 : 0;
       ga.grp_ws = wsb; ga.grp_s = a.strides;
       if (planes4) {
         if ((rc = set_lds_once(h, reinterpret_cast<const void*>(gram_planes4_kernel), (size_t)Planes4Cfg::LDS))) return rc;
-        hipLaunchKernelGGL(gram_planes4_kernel, dim3(ntiles * nsplit, G), dim3(kThreads), (size_t)Planes4Cfg::LDS, h->stream, ga);
-      } else if (NP == 2) hipLaunchKernelGGL(gram_planes_kernel<2>, dim3(ntiles * nsplit, G), dim3(kPlanesThreads), (size_t)PlanesCfg<2>::LDS, h->stream, ga);
-      else hipLaunchKernelGGL(gram_planes_kernel<3>, dim3(ntiles * nsplit, G), dim3(kPlanesThreads), (size_t)PlanesCfg<3>::LDS, h->stream, ga);
+        hipLaunchKernelGGL(gram_planes4_kernel, dim3(ntiles_g * nsplit, G), dim3(kThreads), (size_t)Planes4Cfg::LDS, h->stream, ga);
+      } else if (NP == 2) hipLaunchKernelGGL(gram_planes_kernel<2>, dim3(ntiles_g * nsplit, G), dim3(kPlanesThreads), (size_t)PlanesCfg<2>::LDS, h->stream, ga);
+      else hipLaunchKernelGGL(gram_planes_kernel<3>, dim3(ntiles_g * nsplit, G), dim3(kPlanesThreads), (size_t)PlanesCfg<3>::LDS, h->stream, ga);
       if (prior_factor) {  // the prior factor as pseudo-observations: one more partial per tile, from the f32 kernel
         GramTileArgs<T> u = g;
         u.nsplit = 1; u.ntiles = ntiles; u.nsplit_diag = 0; u.nlong = 0;
@@ -1060,7 +1081,9 @@ int posterior_large_group(blr_handle* h, const PosteriorArgs<T>& a, int64_t reg0
         hipLaunchKernelGGL(gram_tile_kernel<T>, dim3(ntiles, G), dim3(kThreads), LC::LDS_BYTES, h->stream, u);
       }
       r.nsplit_b = nbchunks;
-      gram_reduce(h->stream, nsplit, ntiles, Gpart, NC);
+      r.nblocks = NCA;                 // (stride of the planes pass's b partials)
+      r.multi_block = ms ? NC : 0;
+      gram_reduce(h->stream, nsplit, ntiles_g, Gpart, NC);
       planes_done = true;
     }
   }
@@ -1071,7 +1094,13 @@ int posterior_large_group(blr_handle* h, const PosteriorArgs<T>& a, int64_t reg0
   // ---- blocked Cholesky of Abar (rows DP.. = rhs) -> L, u  (reference :86, :57)
   // (only the first 64 of the 128 padding rows ride along: row DP is b', the others are zero and nobody reads them back --
   // half the right-hand-side sub-tiles of every trailing update, and c5's first trailing updates fit one round)
-  if ((rc = chol_large<T>(h, Abar, lda, DP, DP + TrailCfg<T>::SB, info_chol, G, wse, (int)(per / sizeof(int32_t))))) return rc;
+  // (multi-output: rows DP + s are b_s' for the columns s < S of Y; more than 64 of them take all 128 rows along)
+  if ((rc = chol_large<T>(h, Abar, lda, DP, DP + ((ms && ms->S > TrailCfg<T>::SB) ? kPB : TrailCfg<T>::SB), info_chol, G, wse,
+                          (int)(per / sizeof(int32_t))))) return rc;
+  if (ms) {
+    ms->Abar = Abar; ms->lda = lda; ms->Tfull = ws + o_m; ms->DP = DP;
+    ms->qsp = reinterpret_cast<double*>(ws + o_qs); ms->nq = nbchunks; ms->done = true;
+  }
 
   // ---- T = L' (for the caller and for the AXPY-form back substitution), then m, posterior mean, evidence: one launch each
   // over the group (blockIdx.z / WaveSolveArgs::group)
@@ -2105,6 +2134,57 @@ int logpdf_multi(blr_handle* h, int memspace, int layout, int64_t D, int64_t N, 
     if ((rc = stage_out_alloc(h, info, (size_t)1, &info_d))) return rc;
   }
   const int DP = (int)((D + kPB - 1) / kPB * kPB), NC = DP / kPB;
+  // fp32, ColVecs, D > 128, up to 128 columns: the residuals of ALL columns ride through the update of column 0 as one more row block of
+  // operand planes -- their b_s = X Sigma^-1 (y_s - mu) come out of the same Gram launch (NC + 1 more macro tiles), their u_s = L^-1 b_s
+  // out of the same blocked factorisation (rows it carries along anyway), their q_s out of the planes pass.  No residual matrix, no
+  // second product over X, no panel sweep of its own (round 6; until then: steps (2) - (5) below, 0.5 ms of a 1.09 ms call at config 3's
+  // shape with 64 columns, 9.7 x the algorithmic bytes).
+  if constexpr (sizeof(T) == 4) {
+    if (D > kMaxSmallD && layout == BLR_LAYOUT_COLVECS && S <= kPB && prior_kind != BLR_PRIOR_UPPER_FACTOR && !h->opt.no_planes &&
+        !h->opt.no_bf16x3 && !h->opt.no_fp16_planes && !h->opt.no_multi_planes) {
+      void *vTf, *vlp0;
+      {
+        const size_t sz_tf = mp_d ? (((size_t)D * D * sizeof(T) + 255) & ~(size_t)255) : 0;
+        if ((rc = ensure_aux(h, sz_tf + 256))) return rc;
+        vTf = h->aux; vlp0 = h->aux + sz_tf;
+      }
+      T* Tf = static_cast<T*>(vTf);
+      double* lp0 = static_cast<double*>(vlp0);
+      blr_handle::MultiSrc ms{};
+      ms.Y = Y_d; ms.ldY = ldY; ms.S = (int)S;
+      PosteriorArgs<T> a{};
+      a.X = X_d; a.ldx = ldx; a.strideX = 0; a.y = Y_d; a.stridey = 0; a.s = s_d; a.strides = 0; a.mw = mw_d; a.stridemw = 0;
+      a.Lw = Lw_d; a.ldl = ldl; a.strideLw = 0;
+      a.mw_post = nullptr; a.stride_mwpost = D; a.T_post = mp_d ? Tf : nullptr; a.ldt = D; a.strideT = D * D;  // (the means need T = L')
+      a.Lw_post = nullptr; a.ldlp = D; a.strideLp = 0; a.logpdf = lp0; a.info = info_d;
+      a.layout = layout; a.noise_kind = noise_kind; a.prior_kind = prior_kind; a.D = (int)D; a.N = (int)N; a.B = 1;
+      a.vec_ok = (D % Mfma<T>::VEC == 0 && aligned16(X_d, ldx, 0)) ? 1 : 0;
+      h->multi_src = &ms;
+      rc = dispatch_posterior<T>(h, a);
+      h->multi_src = nullptr;
+      if (rc) return rc;
+      if (!ms.done) return hip_fail(h, hipErrorInvalidValue, "multi-output rows were not taken along (internal)");
+      hipLaunchKernelGGL(multi_rows_finish_kernel<T>, dim3((unsigned)S), dim3(kThreads), 0, h->stream, (const double*)lp0, (const double*)ms.qsp,
+                         ms.nq, noise_kind == BLR_NOISE_ISOTROPIC ? s_d : (const T*)nullptr, (const T*)ms.Abar, ms.lda, ms.DP, (int)D, (int)S, lp_d);
+      if (mp_d) {  // m_s = L^-T u_s, one wavefront of workgroups per column (as the weight draws of blr_sample_weights_*)
+        WaveSolveArgs<T> b{};
+        b.Tf = static_cast<const T*>(ms.Tfull); b.ldtf = ms.DP; b.D = (int)D; b.DP = ms.DP;
+        b.rhs = static_cast<const T*>(ms.Abar) + ms.DP; b.ldrhs = 1; b.rhs_inc = ms.lda;
+        b.add = mw_d; b.out = mp_d; b.ldout = ldmp;
+        if ((rc = launch_wave_solve<T>(h, b, NC, S))) return rc;
+      }
+      HIP_TRY(h, hipGetLastError());
+      if (memspace == BLR_MEM_HOST) {
+        HIP_TRY(h, hipMemcpyAsync(logpdf, lp_d, (size_t)S * sizeof(double), hipMemcpyDeviceToHost, h->stream));
+        if (mw_post) HIP_TRY(h, hipMemcpyAsync(mw_post, mp_d, mat_extent(D, S, ldmp) * sizeof(T), hipMemcpyDeviceToHost, h->stream));
+        HIP_TRY(h, hipMemcpyAsync(info, info_d, sizeof(int32_t), hipMemcpyDeviceToHost, h->stream));
+        HIP_TRY(h, hipStreamSynchronize(h->stream));
+      } else if (!h->async) {
+        HIP_TRY(h, hipStreamSynchronize(h->stream));
+      }
+      return 0;
+    }
+  }
   const int SP = (int)((S + kPB - 1) / kPB * kPB);
   const int NP64 = (int)((N + 63) / 64);
   const int64_t ldy = (int64_t)DP + SP;

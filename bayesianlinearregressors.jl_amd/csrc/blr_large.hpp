@@ -58,6 +58,7 @@ struct ColstatsArgs {
   const T* X; int64_t ldx;
   const T* y; const T* s; const T* mw;
   T* r;               // [N]  delta_n / s_n
+  T* mu;              // [N]  x_n'mw, or NULL (multi-output evidence: the residuals of the other columns of Y need it)
   T* w;               // [N]  1 / s_n for the Gram launch (diagonal noise; may be NULL): an exact division here instead of a
                       //      reciprocal approximation per wave and half-stage inside the matrix loop
   double* qpart;      // [gridDim.x]
@@ -82,7 +83,7 @@ __global__ __launch_bounds__(kThreads) void colstats_kernel(ColstatsArgs<T> a) {
   if (const int64_t g = blockIdx.y) {
     if (a.X) a.X += g * a.grp_X;
     a.y += g * a.grp_y; a.s += g * a.grp_s; a.mw += g * a.grp_mw;
-    a.r = ws_shift(a.r, g * a.grp_ws); a.w = ws_shift(a.w, g * a.grp_ws); a.qpart = ws_shift(a.qpart, g * a.grp_ws); a.lpart = ws_shift(a.lpart, g * a.grp_ws);
+    a.r = ws_shift(a.r, g * a.grp_ws); a.mu = ws_shift(a.mu, g * a.grp_ws); a.w = ws_shift(a.w, g * a.grp_ws); a.qpart = ws_shift(a.qpart, g * a.grp_ws); a.lpart = ws_shift(a.lpart, g * a.grp_ws);
     a.noise_info = ws_shift(a.noise_info, g * a.grp_ws);
   }
   int mw_nonzero = 0;
@@ -108,6 +109,7 @@ __global__ __launch_bounds__(kThreads) void colstats_kernel(ColstatsArgs<T> a) {
       const T delta = a.y[n];
       const T rn = delta / sv;
       a.r[n] = rn;
+      if (a.mu) a.mu[n] = T(0);
       if (a.w) a.w[n] = a.w_sqrt ? (T)sqrt((double)(T(1) / sv)) : T(1) / sv;
       q += (double)delta * (double)rn;
       if (diag) l += log((double)sv);
@@ -132,6 +134,7 @@ __global__ __launch_bounds__(kThreads) void colstats_kernel(ColstatsArgs<T> a) {
         const T rn = delta / sv;
         if (lane == 0) {
           a.r[n] = rn;
+          if (a.mu) a.mu[n] = (T)mu;
           if (a.w) a.w[n] = a.w_sqrt ? (T)sqrt((double)(T(1) / sv)) : T(1) / sv;
           q += (double)delta * (double)rn;
           if (diag) l += log((double)sv);
@@ -180,6 +183,7 @@ __global__ __launch_bounds__(kThreads) void colstats_kernel(ColstatsArgs<T> a) {
         const T delta = a.y[nn] - (T)mu;
         const T rn = delta / sv;
         a.r[nn] = rn;
+        if (a.mu) a.mu[nn] = (T)mu;
         if (a.w) a.w[nn] = a.w_sqrt ? (T)sqrt((double)(T(1) / sv)) : T(1) / sv;
         q += (double)delta * (double)rn;
         if (diag) l += log((double)sv);
@@ -198,6 +202,7 @@ __global__ __launch_bounds__(kThreads) void colstats_kernel(ColstatsArgs<T> a) {
       const T rn = delta / sv;
       if (lane == 0) {
         a.r[n] = rn;
+        if (a.mu) a.mu[n] = (T)mu;
         if (a.w) a.w[n] = a.w_sqrt ? (T)sqrt((double)(T(1) / sv)) : T(1) / sv;
         q += (double)delta * (double)rn;
         if (diag) l += log((double)sv);
@@ -213,6 +218,7 @@ __global__ __launch_bounds__(kThreads) void colstats_kernel(ColstatsArgs<T> a) {
       const T delta = a.y[n] - (T)mu;
       const T rn = delta / sv;
       a.r[n] = rn;
+      if (a.mu) a.mu[n] = (T)mu;
       if (a.w) a.w[n] = a.w_sqrt ? (T)sqrt((double)(T(1) / sv)) : T(1) / sv;
       q += (double)delta * (double)rn;
       if (diag) l += log((double)sv);
@@ -1081,6 +1087,9 @@ struct ReduceArgs {
   int nlong;                 // strictly lower tiles o < nlong hold one data partial less (see GramTileArgs)
   int ntiles, nblocks;       // lower-triangular macro tiles, row blocks
   int nsplit_b;              // 0, or the number of b partials when they do not come from the Gram launch (planes_kernel's column chunks)
+  int multi_block;           // 0, or the index (= D's row blocks) of the ONE extra row block of a multi-output call: its macro tiles
+                             // (multi_block, J) hold b_s' for the output columns s -- rows DP + s of Abar, no prior; row DP itself (column
+                             // 0) keeps the fp64 partial sums of the planes pass; nblocks counts the extra block
   const T* Lw; int64_t ldl; int prior_kind;
   int D, DP;
   T* Abar; int64_t lda;      // (DP + 128) x DP
@@ -1103,6 +1112,8 @@ __global__ __launch_bounds__(kThreads) void gram_reduce_kernel(ReduceArgs<T> a) 
     int ii = 0;
     while ((ii + 1) * (ii + 2) / 2 <= t) ++ii;
     const int I = ii, J = t - ii * (ii + 1) / 2;
+    const bool mrows = a.multi_block > 0 && I == a.multi_block;
+    if (mrows && J == I) return;  // (residuals x residuals: nobody's)
     // one 16-byte vector of 4 (f32) / 2 (f64) consecutive rows per thread and pass; the partials of 8 splits are requested
     // before the first is used (one load per split and a dependent add behind it made this kernel a ~50 us latency chain)
     constexpr int VEC = Mfma<T>::VEC;
@@ -1139,6 +1150,10 @@ __global__ __launch_bounds__(kThreads) void gram_reduce_kernel(ReduceArgs<T> a) 
         const int row = row0 + q;
         if (col > row) continue;
         T val = sum[q];
+        if (mrows) {  // b_s[col], s = rl + q >= 1
+          if (rl + q >= 1) a.Abar[(int64_t)col * a.lda + row] = col < a.D ? val : T(0);
+          continue;
+        }
         if (row < a.D) {
           if (a.prior_kind == PRIOR_DENSE) val += a.Lw[(int64_t)row * a.ldl + col];  // upper entry (col, row)
           else if (a.prior_kind == PRIOR_DIAGONAL && row == col) val += a.Lw[row];
@@ -1174,6 +1189,7 @@ __global__ __launch_bounds__(kThreads) void gram_reduce_kernel(ReduceArgs<T> a) 
         for (; sp < nb; ++sp) sum += src[sp * sst];
         v = (T)sum;
       }
+      if (a.multi_block > 0 && rl != 0) continue;  // (those rows are the other output columns': written above)
       a.Abar[(int64_t)col * a.lda + a.DP + rl] = v;
     }
   }
@@ -3011,6 +3027,38 @@ __global__ __launch_bounds__(kThreads) void multi_finish_kernel(const double* lp
     __syncthreads();
   }
   if (tid == 0) logpdf[sidx] = *lp0 + 0.5 * (red[1][0] - (double)uu[0]) - 0.5 * (red[0][0] - (double)uu[sidx]);
+}
+// The same from the rows the blocked factorisation carried along (multi-output call on the planes route): u_s' = row DP + s of the
+// factored Abar, q_s from the planes pass's partial sums (isotropic noise: still without the 1 / s).  One workgroup per column.
+template <typename T>
+__global__ __launch_bounds__(kThreads) void multi_rows_finish_kernel(const double* lp0, const double* qsp, int nq, const T* s_iso, const T* Abar,
+                                                                     int64_t lda, int DP, int D, int S, double* logpdf) {
+  __shared__ double red[4][kThreads];
+  const int sidx = blockIdx.x, tid = threadIdx.x;
+  if (sidx >= S) return;
+  double q = 0.0, q0 = 0.0, uu = 0.0, uu0 = 0.0;
+  for (int g = tid; g < nq; g += kThreads) {
+    q += qsp[(int64_t)g * kPB + sidx];
+    q0 += qsp[(int64_t)g * kPB];
+  }
+  for (int d = tid; d < D; d += kThreads) {
+    const double u = (double)Abar[(int64_t)d * lda + DP + sidx], u0 = (double)Abar[(int64_t)d * lda + DP];
+    uu += u * u;
+    uu0 += u0 * u0;
+  }
+  red[0][tid] = q; red[1][tid] = q0; red[2][tid] = uu; red[3][tid] = uu0;
+  __syncthreads();
+  for (int m = kThreads / 2; m >= 1; m >>= 1) {
+    if (tid < m) {
+#pragma unroll
+      for (int k = 0; k < 4; ++k) red[k][tid] += red[k][tid + m];
+    }
+    __syncthreads();
+  }
+  if (tid == 0) {
+    const double sc = s_iso ? 1.0 / (double)s_iso[0] : 1.0;
+    logpdf[sidx] = sidx == 0 ? *lp0 : *lp0 + 0.5 * (sc * red[1][0] - red[3][0]) - 0.5 * (sc * red[0][0] - red[2][0]);
+  }
 }
 template <typename T>
 __global__ __launch_bounds__(kThreads) void multi_means_kernel(const T* Ybar, int64_t ldy, int row0, const T* mw, int D, int S,

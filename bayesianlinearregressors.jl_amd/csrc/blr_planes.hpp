@@ -88,6 +88,13 @@ struct PlanesArgs {
   int redo_pass;     // 1: this launch runs only if *redo != 0
   unsigned* redo;    // [1] raised by planes_kernel (zeroed with rowmax by the launch before); NULL: exact row maxima, no check
   unsigned long long* redo_total;  // cumulative count of regressors whose planes were made twice (blr_get_stat "planes_redone"), or NULL
+  // Shared-X multi-output evidence (blr_logpdf_multi_f32 at D > 128; reference: logpdf(fx, Y::Matrix)): Y != NULL makes the LAST row
+  // block (NC - 1) hold the S <= 128 residual rows rho_s = (Y[:, s] - mu) sqrt(w) instead of rows of X.  The Gram launch then leaves
+  // b_s = X Sigma^-1 (y_s - mu) in the macro tiles (NC - 1, J) -- the rows the blocked factorisation carries along as right-hand
+  // sides -- and this pass the partial sums of q_s = (y_s - mu)' Sigma^-1 (y_s - mu) in fp64 (isotropic noise: without the 1 / s).
+  const float* Y; int64_t ldY; int S;
+  const float* mu;      // [N] x_n'mw (colstats_kernel), or NULL for a zero prior mean
+  double* qsp;          // [nchunks][128]
 };
 
 __device__ __forceinline__ float rff_feature(const PlanesArgs& a, const float* __restrict__ om /* Omega_f */, float ph, const float* __restrict__ xs /* LDS: [Din][16] */,
@@ -125,12 +132,19 @@ __global__ __launch_bounds__(kThreads) void rowmax_kernel(PlanesArgs a) {
     for (int d = tid; d < a.NC * kPB; d += kThreads) atomicMax(&a.rowmax[d], __float_as_uint(m));
   } else {
     const int row = blockIdx.y * kPB + (tid & 127);
-    if (row >= a.D) return;
+    const bool yblk = a.Y != nullptr && (int)blockIdx.y == a.NC - 1;  // the residual rows of a multi-output call
+    if (yblk ? (tid & 127) >= a.S : row >= a.D) return;
+    const float* const yrow = yblk ? a.Y + (int64_t)(tid & 127) * a.ldY : nullptr;
     float m = 0.f;
     for (int n = n0 + (tid >> 7); n < n1; n += 32) {  // sixteen columns in flight per thread (four: 194 us for config 3's 268 MB)
       float v[16];
+      if (yblk) {
 #pragma unroll
-      for (int u = 0; u < 16; ++u) v[u] = (n + 2 * u < n1) ? a.X[(int64_t)(n + 2 * u) * a.ldx + row] : 0.f;
+        for (int u = 0; u < 16; ++u) v[u] = (n + 2 * u < n1) ? yrow[n + 2 * u] - (a.mu ? a.mu[n + 2 * u] : 0.f) : 0.f;
+      } else {
+#pragma unroll
+        for (int u = 0; u < 16; ++u) v[u] = (n + 2 * u < n1) ? a.X[(int64_t)(n + 2 * u) * a.ldx + row] : 0.f;
+      }
       if (a.wsq) {
 #pragma unroll
         for (int u = 0; u < 16; ++u) v[u] *= (n + 2 * u < n1) ? a.wsq[n + 2 * u] : 0.f;
@@ -148,7 +162,8 @@ __global__ __launch_bounds__(kThreads) void planes_kernel(PlanesArgs a) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
   float* const rs = reinterpret_cast<float*>(smem);            // the chunk's r_n          [16 per]
   float* const wsm = rs + 16 * kPlanesChunkKb;                 // the chunk's sqrt(w_n)    [16 per] (1 without weights, 0 beyond N)
-  float* const xs = wsm + 16 * kPlanesChunkKb;                 // RFF: the k-block's raw inputs [Din][16]
+  float* const mus = wsm + 16 * kPlanesChunkKb;                // the chunk's mu_n (residual rows of a multi-output call)
+  float* const xs = mus + 16 * kPlanesChunkKb;                 // RFF: the k-block's raw inputs [Din][16]
   const int tid = threadIdx.x, lane = tid & 63, j = tid >> 6;  // wave j: rows 32 j .. 32 j + 31 of row block I
   const int I = blockIdx.y;
   if (const int64_t g = blockIdx.z) {
@@ -164,13 +179,16 @@ __global__ __launch_bounds__(kThreads) void planes_kernel(PlanesArgs a) {
   const int kb0 = blockIdx.x * per, kb1 = min(a.NKB, kb0 + per);
   const int r32 = lane & 31, kh = lane >> 5;
   const int row = I * kPB + 32 * j + r32;
-  const bool row_ok = row < a.D;
+  const bool yblk = !RFF && a.Y != nullptr && I == a.NC - 1;   // the residual rows of a multi-output call (uniform over the workgroup)
+  const bool row_ok = yblk ? 32 * j + r32 < a.S : row < a.D;
+  const float* const yrow = yblk ? a.Y + (int64_t)(32 * j + r32) * a.ldY : nullptr;
   // the chunk's per-column scalars once, through LDS (as loads inside the loop they were a dependent L2 round trip per k-block: 234 us
   // for config 3's 671 MB)
   for (int c = tid; c < 16 * (kb1 - kb0); c += kThreads) {
     const int n = 16 * kb0 + c;
     rs[c] = (a.r && n < a.N) ? a.r[n] : 0.f;
     wsm[c] = n < a.N ? (a.wsq ? a.wsq[n] : 1.f) : 0.f;
+    if (yblk) mus[c] = (a.mu && n < a.N) ? a.mu[n] : 0.f;
   }
   float down = 1.f, up = 1.f;
   if constexpr (NP == 2) planes_row_scale(a.rowmax[row], down, up);
@@ -185,10 +203,18 @@ __global__ __launch_bounds__(kThreads) void planes_kernel(PlanesArgs a) {
   float xa[8], xb[8];  // raw entries of this lane's row in columns 16 kb + 8 kh .. + 7, two k-blocks ahead
   auto fetch = [&](int kb, float (&dst)[8]) {
     if constexpr (!RFF) {
+      if (yblk) {  // eight consecutive observations of output column 32 j + r32: contiguous in Y
 #pragma unroll
-      for (int e = 0; e < 8; ++e) {
-        const int n = 16 * kb + 8 * kh + e;
-        dst[e] = (row_ok && kb < kb1 && n < a.N) ? a.X[(int64_t)n * a.ldx + row] : 0.f;
+        for (int e = 0; e < 8; ++e) {
+          const int n = 16 * kb + 8 * kh + e;
+          dst[e] = (row_ok && kb < kb1 && n < a.N) ? yrow[n] - mus[16 * (kb - kb0) + 8 * kh + e] : 0.f;
+        }
+      } else {
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {
+          const int n = 16 * kb + 8 * kh + e;
+          dst[e] = (row_ok && kb < kb1 && n < a.N) ? a.X[(int64_t)n * a.ldx + row] : 0.f;
+        }
       }
     }
   };
@@ -217,8 +243,9 @@ __global__ __launch_bounds__(kThreads) void planes_kernel(PlanesArgs a) {
     const float* wk = wsm + 16 * (kb - kb0) + 8 * kh;
 #pragma unroll
     for (int e = 0; e < 8; ++e) {
-      bacc += (double)x[e] * (double)rk[e];  // (exact products, fp64 sum: as the Gram kernels' b partials)
       z[e] = x[e] * wk[e];
+      // b = X r (exact products, fp64 sum: as the Gram kernels' b partials); a residual row: its share of q_s = sum_n w_n d_n^2
+      bacc += yblk ? (double)z[e] * (double)z[e] : (double)x[e] * (double)rk[e];
     }
     gram_u4* dst = reinterpret_cast<gram_u4*>(reinterpret_cast<char*>(a.Xp) + (((int64_t)kb * a.NC + I) * FR + NP * j) * 1024) + lane;
     if constexpr (NP == 3) {
@@ -250,7 +277,10 @@ __global__ __launch_bounds__(kThreads) void planes_kernel(PlanesArgs a) {
   if (check && __any(over) && lane == 0) {
     if (atomicOr(a.redo, 1u) == 0u && a.redo_total) atomicAdd(a.redo_total, 1ull);  // (the one thread that raises it counts the regressor)
   }
-  if (a.bpart) {
+  if (yblk) {
+    bacc += __shfl_xor(bacc, 32);
+    if (kh == 0 && a.qsp) a.qsp[(int64_t)blockIdx.x * kPB + 32 * j + r32] = bacc;
+  } else if (a.bpart) {
     bacc += __shfl_xor(bacc, 32);  // the two column halves of a row
     if (kh == 0) a.bpart[((int64_t)blockIdx.x * a.NC + I) * kPB + 32 * j + r32] = bacc;
   }

@@ -75,7 +75,7 @@ int blr_reset_stream(blr_handle* h);              /* back to the handle's own (n
 int blr_set_async(blr_handle* h, int async);      /* 1: DEVICE-memspace calls return after enqueue       */
 int blr_synchronize(blr_handle* h);
 /* Run-time switches of the handle (A/B measurements and tests; the defaults are the measured best).  `key` is one of NO_LDSDMA,
- * NO_WAVE_KERNEL, NO_GRAM_RING, NO_DIAG_SPLIT, NO_XCD_SWIZZLE, NO_MFMA_PROJECT, NO_I8_GRAM, NO_I8_DIAG, NO_I8_FACTOR, NO_I8_ROWVECS, NO_I8_DENSE, NO_I8_FALLBACK, NO_BF16X3, NO_PLANES, NO_FP16_PLANES, PLANES8, NO_SPEC_ROWMAX, NO_MARG_GEMM, NO_GRAD_GEMM, PLAN_DEBUG (flags: any non-empty value = on),
+ * NO_WAVE_KERNEL, NO_GRAM_RING, NO_DIAG_SPLIT, NO_XCD_SWIZZLE, NO_MFMA_PROJECT, NO_I8_GRAM, NO_I8_DIAG, NO_I8_FACTOR, NO_I8_ROWVECS, NO_I8_DENSE, NO_I8_FALLBACK, NO_BF16X3, NO_PLANES, NO_FP16_PLANES, PLANES8, NO_SPEC_ROWMAX, NO_MULTI_PLANES, NO_MARG_GEMM, NO_GRAD_GEMM, PLAN_DEBUG (flags: any non-empty value = on),
  * WAVE_SPLIT = 1|2|4, CHAIN_BATCH = 1..128, CHAIN_WS_MB, I8_PROBE_MIN = 256..2^20, I8_GROUPS = 6|7, SWEEP = always|never|auto, GRAM_SPLITS = "o,d[,nlong]" (README.md);
  * a "BLR_MI355X_" prefix is accepted.  value NULL or "" restores the built-in default.  The environment variables
  * BLR_MI355X_<KEY> are read ONCE, by blr_create -- no entry point reads the environment.  -> 0, or -2 / -3 (unknown key /

@@ -1411,6 +1411,43 @@ def test_shared_x_multi_output_logpdf(B, dtype, D, N, S):
         B.logpdf_columns(B.BayesianLinearRegressor(mw, -Lw)(np.asfortranarray(X), s), Y)
 
 
+@pytest.mark.parametrize("S,zero_mean,noise", [(64, True, "diag"), (100, False, "iso"), (3, False, "diag")])
+def test_shared_x_multi_output_rides_the_update_of_column_0(B, opt, S, zero_mean, noise):
+    # Round 6: at D > 128 in fp32 (ColVecs, up to 128 columns) the residuals of ALL columns of Y are one more row block of the operand
+    # planes of column 0's update: b_s out of the same Gram launch, u_s = L^-1 b_s out of the rows the blocked factorisation carries
+    # along (64, or all 128 when S > 64), q_s out of the planes pass -- no residual matrix, no second product over X, no panel sweep
+    # (blr_planes.hpp).  Held to the route it replaces (option NO_MULTI_PLANES: residual product on the f32 matrix instruction + tall
+    # panels) against the fp64 oracle, per column: evidence and posterior mean within 4 x its error + a floor; N not a multiple of 16.
+    rng = _rng(4400 + S)
+    D, N = 384, 5000 + 7
+    X = np.asfortranarray(rng.standard_normal((D, N)).astype(np.float32))
+    mw = np.zeros(D, dtype=np.float32) if zero_mean else (0.3 * rng.standard_normal(D)).astype(np.float32)
+    dvec = np.exp(0.2 * rng.standard_normal(D)).astype(np.float32)
+    s = np.exp(0.3 * rng.standard_normal(N)).astype(np.float32) if noise == "diag" else np.float32(0.6)
+    W = rng.standard_normal((D, S)) / np.sqrt(D)
+    Y = (X.astype(float).T @ W + np.sqrt(np.asarray(s, float)).reshape(-1, 1) * rng.standard_normal((N, S))).astype(np.float32)
+    f64 = lambda a: np.asarray(a, dtype=float)
+    cols = sorted(set([0, 1, S // 2, S - 1]))
+    ref = {j: O.posterior_logpdf_direct(f64(mw), f64(dvec), f64(X), f64(s), f64(Y[:, j])) for j in cols}
+    lp_all = np.array([O.posterior_logpdf_direct(f64(mw), f64(dvec), f64(X), f64(s), f64(Y[:, j]))[3] for j in range(S)])
+    fx = B.BayesianLinearRegressor(mw, B.Diagonal(dvec))(X, s if noise == "iso" else B.Diagonal(s))
+
+    def errs():
+        lp, M = B.logpdf_columns(fx, Y, return_means=True)
+        e_lp = float(np.max(np.abs(lp - lp_all) / np.abs(lp_all)))
+        e_m = max(float(np.linalg.norm(M[:, j] - ref[j][0]) / np.linalg.norm(ref[j][0])) for j in cols)
+        lp2 = B.logpdf_columns(fx, Y)   # without the means: the factor is never transposed
+        assert np.array_equal(lp, lp2) or float(np.max(np.abs(lp - lp2) / np.abs(lp))) < 1e-6
+        return e_lp, e_m
+
+    e_new = errs()
+    opt("NO_MULTI_PLANES", "1")
+    e_old = errs()
+    print(f"multi-output evidence, S = {S}: max rel err (logpdf, posterior mean)  riding along {e_new}   residual product + panels {e_old}")
+    assert e_new[0] <= 4 * e_old[0] + 2e-7 and e_new[1] <= 4 * e_old[1] + 2e-6, (e_new, e_old)
+    assert e_new[0] <= 3e-5 and e_new[1] <= 3e-4
+
+
 @pytest.mark.parametrize("dtype,D,N,noise,prior", [(np.float64, 5, 40, "diag", "dense"), (np.float64, 130, 500, "iso", "diag"),
                                                    (np.float64, 300, 900, "diag", "dense"), (np.float32, 1024, 4000, "diag", "diag")])
 def test_n_sharded_single_regressor(B, dtype, D, N, noise, prior):
