@@ -1032,7 +1032,9 @@ int posterior_large_group(blr_handle* h, const PosteriorArgs<T>& a, int64_t reg0
           pa.mu = reinterpret_cast<const float*>(ws + o_mu); pa.qsp = reinterpret_cast<double*>(ws + o_qs);
         }
       }
-      const size_t plds = (size_t)(3 * 16 * kPlanesChunkKb + (rff ? a.rff_Din * 16 : 0)) * sizeof(float);
+      // a basis of up to 8 input dimensions: the raw inputs of a workgroup's whole column chunk are staged once (blr_planes.hpp, xs_chunk)
+      pa.xs_chunk = (rff && a.rff_Din <= 8) ? 1 : 0;
+      const size_t plds = (size_t)(3 * 16 * kPlanesChunkKb + (rff ? (pa.xs_chunk ? 8 * 16 * kPlanesChunkKb : a.rff_Din * 16) : 0)) * sizeof(float);
       if (NP == 2) {  // the rows' power-of-two scales need (a bound of) the rows' largest entries first
         if (rff) {  // a basis: its bound
           hipLaunchKernelGGL(rowmax_kernel<true>, dim3(nbchunks, 1, G), dim3(kThreads), 0, h->stream, pa);

@@ -92,6 +92,10 @@ struct PlanesArgs {
   // block (NC - 1) hold the S <= 128 residual rows rho_s = (Y[:, s] - mu) sqrt(w) instead of rows of X.  The Gram launch then leaves
   // b_s = X Sigma^-1 (y_s - mu) in the macro tiles (NC - 1, J) -- the rows the blocked factorisation carries along as right-hand
   // sides -- and this pass the partial sums of q_s = (y_s - mu)' Sigma^-1 (y_s - mu) in fp64 (isotropic noise: without the 1 / s).
+  int xs_chunk;         // source 1: 1 = the raw inputs of the workgroup's WHOLE column chunk are staged once ([k-block][8][16] floats, input
+                        // dimensions padded to 8 with zeros: Din <= 8), the lane's row of Omega lives in registers -- per k-block the loop
+                        // used to pay two workgroup barriers, a dependent global round trip and 64 cached loads of Omega per lane (config
+                        // 5: 77 us for a pass whose arithmetic and stores take 35)
   const float* Y; int64_t ldY; int S;
   const float* mu;      // [N] x_n'mw (colstats_kernel), or NULL for a zero prior mean
   double* qsp;          // [nchunks][128]
@@ -174,7 +178,7 @@ __global__ __launch_bounds__(kThreads) void planes_kernel(PlanesArgs a) {
   }
   if (a.redo_pass && *a.redo == 0u) return;  // (uniform over the regressor's workgroups; nobody of this launch writes the flag)
   const bool check = NP == 2 && !RFF && a.redo != nullptr && !a.redo_pass;
-  bool over = false;
+  float umax = 0.f;  // largest scaled entry this lane has split (NP = 2)
   const int per = (a.NKB + a.nchunks - 1) / a.nchunks;  // (<= kPlanesChunkKb: the host sizes nchunks)
   const int kb0 = blockIdx.x * per, kb1 = min(a.NKB, kb0 + per);
   const int r32 = lane & 31, kh = lane >> 5;
@@ -189,6 +193,18 @@ __global__ __launch_bounds__(kThreads) void planes_kernel(PlanesArgs a) {
     rs[c] = (a.r && n < a.N) ? a.r[n] : 0.f;
     wsm[c] = n < a.N ? (a.wsq ? a.wsq[n] : 1.f) : 0.f;
     if (yblk) mus[c] = (a.mu && n < a.N) ? a.mu[n] : 0.f;
+  }
+  float omr[8];  // RFF, xs_chunk: this lane's row of Omega, zero beyond Din
+  if constexpr (RFF) {
+    if (a.xs_chunk) {
+      for (int idx = tid; idx < 8 * 16 * (kb1 - kb0); idx += kThreads) {
+        const int k = idx & 7, c = idx >> 3;   // consecutive threads: consecutive input dimensions of one column (contiguous in memory)
+        const int n = 16 * kb0 + c;
+        xs[(c >> 4) * 128 + k * 16 + (c & 15)] = (k < a.Din && n < a.N) ? a.Xin[(int64_t)n * a.ldxin + k] : 0.f;
+      }
+#pragma unroll
+      for (int k = 0; k < 8; ++k) omr[k] = (row < a.D && k < a.Din) ? a.Omega[(int64_t)row * a.ldo + k] : 0.f;
+    }
   }
   float down = 1.f, up = 1.f;
   if constexpr (NP == 2) planes_row_scale(a.rowmax[row], down, up);
@@ -224,6 +240,16 @@ __global__ __launch_bounds__(kThreads) void planes_kernel(PlanesArgs a) {
   for (int kb = kb0; kb < kb1; ++kb) {
     float x[8];
     if constexpr (RFF) {
+      if (a.xs_chunk) {  // (uniform over the launch)
+        const float* const xk = xs + (kb - kb0) * 128;
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {
+          float acc = ph;
+#pragma unroll
+          for (int k = 0; k < 8; ++k) acc = __builtin_fmaf(omr[k], xk[k * 16 + 8 * kh + e], acc);  // (same order as rff_feature; a zero term adds nothing)
+          x[e] = (row_ok && 16 * kb + 8 * kh + e < a.N) ? a.scale * rff_cos(acc) : 0.f;
+        }
+      } else {
       __syncthreads();
       for (int idx = tid; idx < a.Din * 16; idx += kThreads) {
         const int k = idx % a.Din, c = idx / a.Din;  // consecutive threads: consecutive input dimensions of one column (contiguous in memory)
@@ -233,6 +259,7 @@ __global__ __launch_bounds__(kThreads) void planes_kernel(PlanesArgs a) {
       __syncthreads();
 #pragma unroll
       for (int e = 0; e < 8; ++e) x[e] = (row_ok && 16 * kb + 8 * kh + e < a.N) ? rff_feature(a, om, ph, xs, 8 * kh + e) : 0.f;
+      }
     } else {
 #pragma unroll
       for (int e = 0; e < 8; ++e) { x[e] = xa[e]; xa[e] = xb[e]; }
@@ -242,10 +269,13 @@ __global__ __launch_bounds__(kThreads) void planes_kernel(PlanesArgs a) {
     const float* rk = rs + 16 * (kb - kb0) + 8 * kh;
     const float* wk = wsm + 16 * (kb - kb0) + 8 * kh;
 #pragma unroll
-    for (int e = 0; e < 8; ++e) {
-      z[e] = x[e] * wk[e];
-      // b = X r (exact products, fp64 sum: as the Gram kernels' b partials); a residual row: its share of q_s = sum_n w_n d_n^2
-      bacc += yblk ? (double)z[e] * (double)z[e] : (double)x[e] * (double)rk[e];
+    for (int e = 0; e < 8; ++e) z[e] = x[e] * wk[e];
+    if (yblk) {  // (uniform) a residual row: its share of q_s = sum_n w_n d_n^2
+#pragma unroll
+      for (int e = 0; e < 8; ++e) bacc += (double)z[e] * (double)z[e];
+    } else {     // b = X r (exact products, fp64 sum: as the Gram kernels' b partials)
+#pragma unroll
+      for (int e = 0; e < 8; ++e) bacc += (double)x[e] * (double)rk[e];
     }
     gram_u4* dst = reinterpret_cast<gram_u4*>(reinterpret_cast<char*>(a.Xp) + (((int64_t)kb * a.NC + I) * FR + NP * j) * 1024) + lane;
     if constexpr (NP == 3) {
@@ -265,7 +295,7 @@ __global__ __launch_bounds__(kThreads) void planes_kernel(PlanesArgs a) {
 #pragma unroll
       for (int q = 0; q < 4; ++q) {
         const float u = z[2 * q] * down, v = z[2 * q + 1] * down;   // (exact: a power of two)
-        over = over || fmaxf(fabsf(u), fabsf(v)) > 65504.f;         // beyond the largest finite fp16 number (speculative scale only)
+        umax = fmaxf(umax, fmaxf(fabsf(u), fabsf(v)));              // (one v_max3_f32; a NaN is passed by, as in rowmax_kernel)
         const _Float16 hu = (_Float16)u, hv = (_Float16)v;          // round to nearest even
         const _Float16 lu = (_Float16)(u - (float)hu), lv = (_Float16)(v - (float)hv);
         const gram_h2 hp = {hu, hv}, lp = {lu, lv};
@@ -274,7 +304,8 @@ __global__ __launch_bounds__(kThreads) void planes_kernel(PlanesArgs a) {
       dst[0] = H; dst[64] = L;
     }
   }
-  if (check && __any(over) && lane == 0) {
+  // beyond the largest finite fp16 number: the sampled scale did not hold for this row
+  if (check && __any(umax > 65504.f) && lane == 0) {
     if (atomicOr(a.redo, 1u) == 0u && a.redo_total) atomicAdd(a.redo_total, 1ull);  // (the one thread that raises it counts the regressor)
   }
   if (yblk) {

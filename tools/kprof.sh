@@ -12,6 +12,6 @@ import csv,sys
 rows=list(csv.DictReader(open(sys.argv[1])))
 rows.sort(key=lambda r:-float(r["TotalDurationNs"]))
 for r in rows[:14]:
-    print("%-90s calls %5s avg %10.1f us  total %6.2f %%" % (r["Name"][:90], r["Calls"], float(r["AverageNs"])/1e3, float(r["Percentage"])))
+    print("%-90s calls %5s avg %8.1f min %8.1f max %8.1f us  total %6.2f %%" % (r["Name"][:90], r["Calls"], float(r["AverageNs"])/1e3, float(r["MinNs"])/1e3, float(r["MaxNs"])/1e3, float(r["Percentage"])))
 PY
 cat $R/gpurun_out/kprof_$e.txt
