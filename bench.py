@@ -613,8 +613,8 @@ def run_secondary(torch, _abi, h, dev, stream, only=None):
             wall, ms = timed(torch, stream, dev, op.fn, op.steps, 3)
             op.check()
             kern = op.kernel
-            if op.unit == "updates/s" and not op.kernel.startswith("rank1") and "in place" not in op.kernel:
-                kern = h.last_route()  # posterior workloads: the route the dispatcher took on the last call
+            if op.unit in ("updates/s", "evidences/s") and not op.kernel.startswith("rank1") and "in place" not in op.kernel:
+                kern = h.last_route()  # posterior workloads (the multi-output evidence rides one): the route the dispatcher took on the last call
             i8_cols, i8_diag = None, False
             if kern == "fused_i8_kernel":
                 w2 = op.keep[0]
