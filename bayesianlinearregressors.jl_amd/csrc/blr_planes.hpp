@@ -625,6 +625,7 @@ __global__ __launch_bounds__(kThreads, 2) void gram_planes4_kernel(GramPlanesArg
       gram_u4 B0h = *reinterpret_cast<const gram_u4*>(slot + offb), B0l = *reinterpret_cast<const gram_u4*>(slot + offb + 1024);
       gram_u4 B1h = *reinterpret_cast<const gram_u4*>(slot + offb + 2048), B1l = *reinterpret_cast<const gram_u4*>(slot + offb + 3072);
       issue();
+      __builtin_amdgcn_s_setprio(2);  // over the other workgroup's wave on this SIMD while the matrix instructions issue (same-box A/B: c3 -0.7 %, 8 x c3 -1.5 %)
       // four independent chains interleaved; within a tile the small products, then the leading one
       if (ex10) {  // (wave-uniform; the full quadrant in every off-diagonal macro tile)
         if (ex00) BLR_PM2(accs[0][0], A0l, B0h);
@@ -640,6 +641,7 @@ __global__ __launch_bounds__(kThreads, 2) void gram_planes4_kernel(GramPlanesArg
         if (ex01) BLR_PM2(acc[0][1], A0h, B1h);
         if (ex11) BLR_PM2(acc[1][1], A1h, B1h);
       }
+      __builtin_amdgcn_s_setprio(0);
       asm volatile("s_waitcnt vmcnt(%0)" ::"n"(PW * (C::AHEAD - 1)) : "memory");
       __syncthreads();
     }
