@@ -89,7 +89,7 @@ def counters(dirname, kernel_substr):
 
 
 kd = {}
-for cfg, kern in (("c2", "fused_i8_kernel"), ("c3", "gram_planes_kernel"), ("c5", "gram_planes_kernel"), ("c4", "fused_wave_kernel"), ("c3b8", "gram_planes_kernel"),
+for cfg, kern in (("c2", "fused_i8_kernel"), ("c3", "gram_planes"), ("c5", "gram_planes"), ("c4", "fused_wave_kernel"), ("c3b8", "gram_planes"),
                   ("marginals_var_c2_f64", "marginals_gemm_kernel"), ("marginals_var_c3_f32", "marg_blocksub_kernel"),
                   ("logpdf_grad_c2_f64", "grad_gemm_kernel")):
     r = durations(f"stats_{cfg}", kern)
@@ -104,7 +104,7 @@ summary = {"note": "per-dispatch means for the dominant kernel; rocprofv3 --pmc,
 fetch = counters("pmc_FETCH_SIZE_c2fp64", "fused_small_kernel")  # (the fp64 kernel: runs under BLR_MI355X_NO_I8_GRAM)
 write = counters("pmc_WRITE_SIZE_c2fp64", "fused_small_kernel")
 sq2 = counters("pmc_sq_c2fp64", "fused_small_kernel")
-sq3 = counters("pmc_sq_c3", "gram_planes_kernel")
+sq3 = counters("pmc_sq_c3", "gram_planes")
 if fetch and write:
     rd = fetch["FETCH_SIZE"] * 1024.0 * 2.0
     wr = write["WRITE_SIZE"] * 1024.0
@@ -121,10 +121,10 @@ if f4 and w4:
                                             "hbm_read_bytes_per_launch": rd, "hbm_write_bytes_per_launch": wr,
                                             "hbm_bytes_per_launch": rd + wr, "units_per_launch": 8192}
 sq4 = counters("pmc_sq_c4", "fused_wave_kernel")
-sq5 = counters("pmc_sq_c5", "gram_planes_kernel")
-sq3b8 = counters("pmc_sq_c3b8", "gram_planes_kernel")  # 8 regressors of c3's shape in one launch
-for key, d, kern, units in (("c2_f32_fused_small_kernel_hbm", "c2f32", "fused_small_kernel", 4096), ("c3_gram_planes_kernel_hbm", "c3", "gram_planes_kernel", 1),
-                            ("c5_gram_planes_kernel_hbm", "c5", "gram_planes_kernel", 1)):
+sq5 = counters("pmc_sq_c5", "gram_planes")
+sq3b8 = counters("pmc_sq_c3b8", "gram_planes")  # 8 regressors of c3's shape in one launch
+for key, d, kern, units in (("c2_f32_fused_small_kernel_hbm", "c2f32", "fused_small_kernel", 4096), ("c3_gram_planes_kernel_hbm", "c3", "gram_planes", 1),
+                            ("c5_gram_planes_kernel_hbm", "c5", "gram_planes", 1)):
     fe, wr_ = counters(f"pmc_fetch_{d}", kern), counters(f"pmc_write_{d}", kern)
     if fe and wr_:
         rd = fe["FETCH_SIZE"] * 1024.0 * 2.0
