@@ -9,8 +9,10 @@
 // moved out of the loop (NP = 3 below) the matrix pipe IS the time -- and, on random operands, at the clock the part then holds it is no
 // faster than before (config 3: 374 + 118 us for the Gram launch + the planes pass against 522; same-box end to end 0.79 / 0.80 ms).
 // What buys time is fewer products.  NP = 2, the default:
-//   * every row r gets a power-of-two scale 2^e_r that puts its largest entry (of z = x sqrt(w), over ALL columns: rowmax_kernel, one
-//     more pass over X; a random-Fourier basis is bounded by its own scale factor) into [2^12, 2^13);  z' = z 2^-e_r = h + l + rho with
+//   * every row r gets a power-of-two scale 2^e_r that puts (a bound of) its largest entry of z = x sqrt(w) into [2^12, 2^13) -- the
+//     bound is twice the largest entry of a SAMPLE of the row (rowmax_kernel: the first 32 columns of every column chunk; the planes
+//     pass checks that every entry fits and asks for the exact maxima + a second planes pass when one does not: PlanesArgs::redo; a
+//     random-Fourier basis is bounded by its own scale factor);  z' = z 2^-e_r = h + l + rho with
 //     h = fp16(z'), l = fp16(z' - h), both rounded to nearest: 22 significant bits for every entry within 2^-14 of its row's largest,
 //     an absolute 2^-36 of the row's largest below that (fp16 subnormals) -- against fp32's 24 bits the inputs are perturbed by at most
 //     2^-23 of themselves, signed and zero-mean: over N observations that is 2^-23 sqrt(3 / N) of a diagonal entry, 1e-9 at config 3,
@@ -22,7 +24,8 @@
 //   inputs (test_c3_full_size, test_c5_full_size, test_large_d_fp32_gram_on_bf16_matrix_cores_vs_f32_route).
 //
 // Kernels:
-//   * rowmax_kernel (NP = 2): max_n |x_rn| sqrt(w_n) per row, atomicMax on the bit patterns (order-independent).
+//   * rowmax_kernel (NP = 2): max_n |x_rn| sqrt(w_n) per row -- over a sample of the columns, doubled, or over all of them --,
+//     atomicMax on the bit patterns (order-independent).
 //   * planes_kernel (one pass over X, or over the raw inputs of a random-Fourier basis -- reference src/basis_function_regression.jl:41
 //     materialises phi(x); here phi is evaluated once per element and leaves as planes, the fp32 feature matrix never exists):
 //     z = x sqrt(w)   (w_n = 1 / s_n under diagonal noise, 1 otherwise: G = sum_n w_n x_n x_n' = Z Z', both operands the same)
@@ -30,6 +33,7 @@
 //     matrix operand (lane = row r of the sub-block + 32 x (columns 8 .. 15)), 4 NP consecutive KiB are one side of a macro tile's half.
 //     The same pass accumulates b = X r (r = delta / s, reference :57) in fp64 per row and column chunk: the Gram launch carries no
 //     right-hand side.
+//   * gram_planes4_kernel (the default, end of this file): two 256-thread workgroups per CU, 64 x 64 per wave.
 //   * gram_planes_kernel: one 512-thread workgroup per CU and (macro tile, column range); a ring of halves of 8 NP KiB (A side + B
 //     side), issued SLOTS - 1 halves ahead; wave (i, c) owns the two 32 x 32 tiles (i, 2c), (i, 2c + 1) of the 128 x 128 macro tile:
 //     per half 3 NP fragment reads of 16 bytes per lane and 12 (NP = 3) or 6 (NP = 2) matrix instructions.  A diagonal macro tile
