@@ -664,7 +664,8 @@ end
 # Which kernel family this task's most recent posterior / logpdf call ran on ("fused_i8_kernel", "fused_small_kernel<double, 8, 4>", ...).
 last_route() = unsafe_string(ccall((:blr_last_route, LIB), Cstring, (Ptr{Cvoid},), handle()))
 # Counters of this task's handle: "i8_regressors" (sent down the int8-sliced Gram route), "i8_handed_back" (of those, redone by the fp64
-# kernel inside the same call: each cost two passes over its data -- heavy-tailed design matrices), "workspace_bytes".
+# kernel inside the same call: each cost two passes over its data -- heavy-tailed design matrices), "planes_redone" (fp32 updates at
+# D > 128 whose sampled row scales did not hold: exact row maxima + the operand planes a second time), "workspace_bytes".
 function get_stat(key::AbstractString)
     h = handle()
     v = Ref{Int64}(0)
