@@ -396,6 +396,7 @@ int launch_fused_small(blr_handle* h, const PosteriorArgs<T>& a) {
   // "already set" flag left the second device at the 64 KB default)
   { const int rc_lds = set_lds_once(h, reinterpret_cast<const void*>(kern), (size_t)(C::LDS_BYTES)); if (rc_lds) return rc_lds; }
   int grid = (int)std::min<int64_t>(a.B, 1 << 20);
+  if (a.retry_only) grid = std::min(grid, 2 * h->cus);  // (one round of workgroups, each walking its share: see the kernel's head)
   hipLaunchKernelGGL(kern, dim3(grid), dim3(kThreads), C::LDS_BYTES, h->stream, a);
   HIP_TRY(h, hipGetLastError());
   if (!a.retry_only) {

@@ -1599,6 +1599,14 @@ __global__ __launch_bounds__(kThreads, (NB <= 4 ? 4 : (sizeof(T) == 4 ? BLR_F32_
   extern __shared__ __attribute__((aligned(16))) char smem[];
   const KernArgPtr<T> ap = (KernArgPtr<T>)__builtin_amdgcn_kernarg_segment_ptr();
   const __attribute__((address_space(4))) PosteriorArgs<T>& a = *ap;
+  if (a.retry_only) {
+    // follow-up of fused_i8_kernel: nearly always there is nothing to redo.  The workgroup looks at the status words of ALL its
+    // regressors at once (one memory round trip) and leaves; one dependent load per regressor inside the loop below, on a grid of
+    // one workgroup per regressor with 70 KB of LDS each, made this launch 12 us of a 4.1 ms step.
+    int any = 0;
+    for (int reg = blockIdx.x + threadIdx.x * gridDim.x; reg < a.B; reg += kThreads * gridDim.x) any |= (a.info[reg] == kI8RetryCode) ? 1 : 0;
+    if (!__syncthreads_or(any)) return;
+  }
   for (int reg = blockIdx.x; reg < a.B; reg += gridDim.x) {
     // ---- phase 0: prior -----------------------------------------------------------------------
     if (glue_prior<T, NB>(smem, ap, reg) != 0) continue;
